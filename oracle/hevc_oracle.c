@@ -1,0 +1,655 @@
+/*
+ * hevc_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU restatement; never linked into the product).
+ *
+ * Plain-C restatement of the algorithms behind openHEVC's HEVCDSPContext / HEVCPredContext tables
+ * (libavcodec/hevcdsp_template.c, libavcodec/hevcpred_template.c), written from their integer
+ * semantics with one generic, run-time bit-depth code path (the reference instantiates a template
+ * per BIT_DEPTH).  Each function cites the reference lines it restates.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks every function here bit-for-bit
+ * against the reference's own compiled C (oracle/_ref/libhevcref.so, built by oracle/Makefile from
+ * /root/reference) on seeded random and corner-case inputs, and tests/golden/ holds fixtures
+ * generated from that reference build (tests/golden/make_golden.py) so the pin also holds where
+ * /root/reference is absent.  The reference ships no golden vectors of its own.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define OHX(name) ohor_##name
+#include "oracle_api.h"
+
+int ohor_available(void) { return 1; }
+
+/* ------------------------------------------------------------------ helpers */
+static inline int clip3(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+static inline int clip_i16(int v) { return clip3(v, -32768, 32767); }              /* libavutil/common.h:139 */
+static inline int clip_px(int v, int bd) { return clip3(v, 0, (1 << bd) - 1); }    /* bit_depth_template.c:67,86 */
+static inline int psz(int bd) { return bd > 8 ? 2 : 1; }
+
+static inline int ldpx(const uint8_t *p, int bd)
+{
+    return bd > 8 ? *(const uint16_t *)p : *p;
+}
+static inline void stpx(uint8_t *p, int bd, int v)
+{
+    if (bd > 8) *(uint16_t *)p = (uint16_t)v; else *p = (uint8_t)v;
+}
+/* pixel (x,y) relative to p, stride in bytes */
+#define PX(p, stride, x, y) ((p) + (ptrdiff_t)(y) * (stride) + (ptrdiff_t)(x) * ps)
+
+/* ------------------------------------------------------------------ transform matrix
+ * The HEVC core transform is an integer approximation of 64*sqrt(2)*cos(k*pi/64); all 32x32 entries are
+ * +-(one of 32 magnitudes) selected by the angle index (2c+1)*r mod 128.  This generates the same table the
+ * reference spells out literally (libavcodec/hevcdsp.c:879-944). */
+static const int8_t kCosMag[33] = {
+    64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+    61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0
+};
+static int dct_coef(int r, int c)    /* row r (frequency), column c (sample), 32-point */
+{
+    int m = (r * (2 * c + 1)) & 127;
+    if (m <= 32) return  kCosMag[m];
+    if (m <= 64) return -kCosMag[64 - m];
+    if (m <= 96) return -kCosMag[m - 64];
+    return kCosMag[128 - m];
+}
+
+/* Which input index j does an N-point partial butterfly with bound `end` actually read?
+ * TR_32/TR_16/TR_8/TR_4 (hevcdsp_template.c:210-262): the odd half of the outermost stage reads odd j < end;
+ * TR_32 forwards end/2 to its inner TR_16; every deeper stage is called with its full length. */
+static int tr_reads(int n, int j, int end)
+{
+    if (n == 4) return 1;
+    if (j & 1) return j < end;
+    if (n == 32 && (j & 3) == 2) return (j >> 1) < end / 2;
+    return 1;
+}
+
+static void inv_dct_1d(int n, const int *src, int *dst, int end)
+{
+    int step = 32 / n;
+    for (int k = 0; k < n; k++) {
+        int acc = 0;
+        for (int j = 0; j < n; j++)
+            if (tr_reads(n, j, end))
+                acc += dct_coef(j * step, k) * src[j];
+        dst[k] = acc;
+    }
+}
+
+/* idct_NxN: hevcdsp_template.c:264-301 */
+static void idct_full(int bd, int log2, int16_t *c, int col_limit)
+{
+    int n = 1 << log2, in[32], out[32];
+    int limit  = col_limit < n ? col_limit : n;
+    int limit2 = col_limit + 4 < n ? col_limit + 4 : n;
+    int shift = 7, add = 1 << (shift - 1);
+    for (int i = 0; i < n; i++) {                   /* pass 1: columns, in place */
+        for (int j = 0; j < n; j++) in[j] = c[j * n + i];
+        inv_dct_1d(n, in, out, limit2);
+        for (int j = 0; j < n; j++) c[j * n + i] = (int16_t)clip_i16((out[j] + add) >> shift);
+        if (limit2 < n && i % 4 == 0 && i != 0)
+            limit2 -= 4;
+    }
+    shift = 20 - bd; add = 1 << (shift - 1);
+    for (int i = 0; i < n; i++) {                   /* pass 2: rows */
+        for (int j = 0; j < n; j++) in[j] = c[i * n + j];
+        inv_dct_1d(n, in, out, limit);
+        for (int j = 0; j < n; j++) c[i * n + j] = (int16_t)clip_i16((out[j] + add) >> shift);
+    }
+}
+
+/* idct_NxN_dc: hevcdsp_template.c:303-316 */
+static void idct_dc(int bd, int log2, int16_t *c)
+{
+    int n2 = 1 << (2 * log2), shift = 14 - bd, add = 1 << (shift - 1);
+    int v = (((c[0] + 1) >> 1) + add) >> shift;
+    for (int i = 0; i < n2; i++) c[i] = (int16_t)v;
+}
+
+/* transform_4x4_luma (inverse DST-VII): hevcdsp_template.c:170-203 */
+static void dst4_1d(const int *s, int *d)
+{
+    /* rows of the 4x4 DST matrix {29,55,74,84},{74,74,0,-74},{84,-29,-74,55},{55,-84,74,-29} applied transposed */
+    d[0] = 29 * s[0] + 74 * s[1] + 84 * s[2] + 55 * s[3];
+    d[1] = 55 * s[0] + 74 * s[1] - 29 * s[2] - 84 * s[3];
+    d[2] = 74 * s[0]             - 74 * s[2] + 74 * s[3];
+    d[3] = 84 * s[0] - 74 * s[1] + 55 * s[2] - 29 * s[3];
+}
+static void idct_dst4(int bd, int16_t *c)
+{
+    int in[4], out[4], shift = 7, add = 64;
+    for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) in[j] = c[j * 4 + i];
+        dst4_1d(in, out);
+        for (int j = 0; j < 4; j++) c[j * 4 + i] = (int16_t)clip_i16((out[j] + add) >> shift);
+    }
+    shift = 20 - bd; add = 1 << (shift - 1);
+    for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) in[j] = c[i * 4 + j];
+        dst4_1d(in, out);
+        for (int j = 0; j < 4; j++) c[i * 4 + j] = (int16_t)clip_i16((out[j] + add) >> shift);
+    }
+}
+
+/* transform_skip: hevcdsp_template.c:139-163 (note: results wrap to int16 like the in-place reference) */
+static void tr_skip(int bd, int log2, int16_t *c)
+{
+    int n2 = 1 << (2 * log2), shift = 15 - bd - log2;
+    if (shift > 0) {
+        int off = 1 << (shift - 1);
+        for (int i = 0; i < n2; i++) c[i] = (int16_t)((c[i] + off) >> shift);
+    } else {
+        for (int i = 0; i < n2; i++) c[i] = (int16_t)(c[i] << -shift);
+    }
+}
+
+/* transform_rdpcm: hevcdsp_template.c:114-136 (mode 0: running sum along rows, 1: along columns) */
+static void tr_rdpcm(int log2, int16_t *c, int mode)
+{
+    int n = 1 << log2;
+    if (mode) {
+        for (int y = 1; y < n; y++)
+            for (int x = 0; x < n; x++) c[y * n + x] = (int16_t)(c[y * n + x] + c[(y - 1) * n + x]);
+    } else {
+        for (int y = 0; y < n; y++)
+            for (int x = 1; x < n; x++) c[y * n + x] = (int16_t)(c[y * n + x] + c[y * n + x - 1]);
+    }
+}
+
+void ohor_tu_residual(int bd, int kind, int log2, int16_t *coeffs, int col_limit)
+{
+    switch (kind) {
+    case OH_TU_IDCT: idct_full(bd, log2, coeffs, col_limit); break;
+    case OH_TU_DC:   idct_dc(bd, log2, coeffs); break;
+    case OH_TU_DST4: idct_dst4(bd, coeffs); break;
+    case OH_TU_SKIP: tr_skip(bd, log2, coeffs); break;
+    case OH_TU_SKIP_RDPCM_H: tr_skip(bd, log2, coeffs); tr_rdpcm(log2, coeffs, 0); break;
+    case OH_TU_SKIP_RDPCM_V: tr_skip(bd, log2, coeffs); tr_rdpcm(log2, coeffs, 1); break;
+    case OH_TU_BYPASS: break;
+    case OH_TU_BYPASS_RDPCM_H: tr_rdpcm(log2, coeffs, 0); break;
+    case OH_TU_BYPASS_RDPCM_V: tr_rdpcm(log2, coeffs, 1); break;
+    }
+}
+
+/* transform_add: hevcdsp_template.c:45-111 */
+void ohor_transform_add(int bd, int log2, uint8_t *dst, ptrdiff_t stride, int16_t *res)
+{
+    int n = 1 << log2, ps = psz(bd);
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            uint8_t *p = PX(dst, stride, x, y);
+            stpx(p, bd, clip_px(ldpx(p, bd) + res[y * n + x], bd));
+        }
+}
+
+void ohor_tu_batch(int bd, int kind, int log2, int n, const int16_t *coeffs, uint8_t *plane,
+                   ptrdiff_t stride, const int32_t *xy, int col_limit)
+{
+    int nn = 1 << (2 * log2), ps = psz(bd);
+    int16_t tmp[32 * 32];
+    for (int i = 0; i < n; i++) {
+        memcpy(tmp, coeffs + (size_t)i * nn, nn * sizeof(int16_t));
+        ohor_tu_residual(bd, kind, log2, tmp, col_limit);
+        ohor_transform_add(bd, log2, PX(plane, stride, xy[2 * i], xy[2 * i + 1]), stride, tmp);
+    }
+}
+
+struct tu_mt_arg { int bd, kind, log2, n, col_limit; const int16_t *coeffs; uint8_t *plane; ptrdiff_t stride; const int32_t *xy; };
+static void *tu_mt_worker(void *p)
+{
+    struct tu_mt_arg *a = p;
+    ohor_tu_batch(a->bd, a->kind, a->log2, a->n, a->coeffs, a->plane, a->stride, a->xy, a->col_limit);
+    return NULL;
+}
+void ohor_tu_batch_mt(int bd, int kind, int log2, int n, const int16_t *coeffs, uint8_t *plane,
+                      ptrdiff_t stride, const int32_t *xy, int col_limit, int threads)
+{
+    pthread_t th[64];
+    struct tu_mt_arg a[64];
+    int nn = 1 << (2 * log2);
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    for (int t = 0; t < threads; t++) {
+        int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);
+        a[t] = (struct tu_mt_arg){ bd, kind, log2, hi - lo, col_limit, coeffs + (size_t)lo * nn, plane, stride, xy + 2 * lo };
+        pthread_create(&th[t], NULL, tu_mt_worker, &a[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+}
+
+/* ------------------------------------------------------------------ motion compensation
+ * Interpolation taps: the HEVC luma quarter-sample (8-tap) and chroma eighth-sample (4-tap) filters,
+ * reference tables ff_hevc_qpel_filters / ff_hevc_epel_filters (libavcodec/hevcdsp.c:1028-1042). */
+static const int8_t kLumaTaps[3][8] = {
+    { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 },
+    { 0, 1, -5, 17, 58, -10, 4, -1 },
+};
+static const int8_t kChromaTaps[7][4] = {
+    { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 },
+    { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 },
+};
+
+/* 14-bit intermediate sample of put_hevc_{qpel,epel}_{pixels,h,v,hv}
+ * (hevcdsp_template.c:610-624,731-794,1185-1247): src points at the block's (0,0) integer sample. */
+static int mc_sample14(int bd, int luma, const uint8_t *src, ptrdiff_t stride, int x, int y, int mx, int my)
+{
+    int ps = psz(bd), taps = luma ? 8 : 4, before = luma ? 3 : 1;
+    const int8_t *fh = mx ? (luma ? kLumaTaps[mx - 1] : kChromaTaps[mx - 1]) : NULL;
+    const int8_t *fv = my ? (luma ? kLumaTaps[my - 1] : kChromaTaps[my - 1]) : NULL;
+    if (!fh && !fv)
+        return ldpx(PX(src, stride, x, y), bd) << (14 - bd);
+    if (fh && !fv) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fh[k] * ldpx(PX(src, stride, x + k - before, y), bd);
+        return s >> (bd - 8);
+    }
+    if (!fh && fv) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fv[k] * ldpx(PX(src, stride, x, y + k - before), bd);
+        return s >> (bd - 8);
+    }
+    int acc = 0;
+    for (int r = 0; r < taps; r++) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fh[k] * ldpx(PX(src, stride, x + k - before, y + r - before), bd);
+        acc += fv[r] * (int16_t)(s >> (bd - 8));          /* the h-pass lands in an int16 tmp[] (:763-776) */
+    }
+    return acc >> 6;
+}
+
+void ohor_mc(int bd, int luma, int variant, uint8_t *dst, ptrdiff_t dststride,
+             uint8_t *src, ptrdiff_t srcstride, int16_t *src2, ptrdiff_t src2stride,
+             int height, int mx, int my, int width,
+             int denom, int wx0, int wx1, int ox0, int ox1)
+{
+    int ps = psz(bd);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int v = mc_sample14(bd, luma, src, srcstride, x, y, mx, my);
+            if (variant == OH_MC_PUT) {
+                ((int16_t *)dst)[y * dststride + x] = (int16_t)v;
+                continue;
+            }
+            int out;
+            switch (variant) {
+            case OH_MC_UNI: {           /* :626-640,796-820,...: ((v + off) >> shift); full-pel == copy */
+                int shift = 14 - bd, off = bd < 14 ? 1 << (shift - 1) : 0;
+                out = clip_px((v + off) >> shift, bd);
+                break;
+            }
+            case OH_MC_BI: {            /* :642-666,822-848,... */
+                int shift = 15 - bd, off = bd < 14 ? 1 << (shift - 1) : 0;
+                out = clip_px((v + src2[y * src2stride + x] + off) >> shift, bd);
+                break;
+            }
+            case OH_MC_UNI_W: {         /* :668-690,985-1010,... */
+                int shift = denom + 14 - bd, off = bd < 14 ? 1 << (shift - 1) : 0;
+                out = clip_px(((v * wx0 + off) >> shift) + ox0 * (1 << (bd - 8)), bd);
+                break;
+            }
+            default: {                  /* OH_MC_BI_W :692-716,1012-1038,... */
+                int log2wd = denom + 14 - bd;
+                int o0 = ox0 * (1 << (bd - 8)), o1 = ox1 * (1 << (bd - 8));
+                out = clip_px((v * wx1 + src2[y * src2stride + x] * wx0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1), bd);
+                break;
+            }
+            }
+            stpx(PX(dst, dststride, x, y), bd, out);
+        }
+}
+
+/* ------------------------------------------------------------------ deblocking
+ * hevc_loop_filter_luma: hevcdsp_template.c:1629-1723.  `xs` steps ACROSS the edge, `ys` ALONG it (bytes). */
+static void deblock_luma(int bd, uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, int beta,
+                         const int *tc_in, const uint8_t *no_p_in, const uint8_t *no_q_in)
+{
+#define S(i, line) ldpx(pix + (i) * xs + (line) * ys, bd)          /* i = -4..3 : p3..p0,q0..q3 */
+#define W(i, line, v) stpx(pix + (i) * xs + (line) * ys, bd, (v))
+    beta <<= bd - 8;
+    for (int seg = 0; seg < 2; seg++, pix += 4 * ys) {
+        int dp0 = abs(S(-3, 0) - 2 * S(-2, 0) + S(-1, 0)), dq0 = abs(S(2, 0) - 2 * S(1, 0) + S(0, 0));
+        int dp3 = abs(S(-3, 3) - 2 * S(-2, 3) + S(-1, 3)), dq3 = abs(S(2, 3) - 2 * S(1, 3) + S(0, 3));
+        int d0 = dp0 + dq0, d3 = dp3 + dq3;
+        int tc = tc_in[seg] << (bd - 8), no_p = no_p_in[seg], no_q = no_q_in[seg];
+        if (d0 + d3 >= beta)
+            continue;
+        int tc25 = (tc * 5 + 1) >> 1;
+        int strong = abs(S(-4, 0) - S(-1, 0)) + abs(S(3, 0) - S(0, 0)) < (beta >> 3) && abs(S(-1, 0) - S(0, 0)) < tc25 &&
+                     abs(S(-4, 3) - S(-1, 3)) + abs(S(3, 3) - S(0, 3)) < (beta >> 3) && abs(S(-1, 3) - S(0, 3)) < tc25 &&
+                     (d0 << 1) < (beta >> 2) && (d3 << 1) < (beta >> 2);
+        if (strong) {
+            int tc2 = tc << 1;
+            for (int l = 0; l < 4; l++) {
+                int p3 = S(-4, l), p2 = S(-3, l), p1 = S(-2, l), p0 = S(-1, l);
+                int q0 = S(0, l), q1 = S(1, l), q2 = S(2, l), q3 = S(3, l);
+                if (!no_p) {
+                    W(-1, l, p0 + clip3(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -tc2, tc2));
+                    W(-2, l, p1 + clip3(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -tc2, tc2));
+                    W(-3, l, p2 + clip3(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -tc2, tc2));
+                }
+                if (!no_q) {
+                    W(0, l, q0 + clip3(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -tc2, tc2));
+                    W(1, l, q1 + clip3(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -tc2, tc2));
+                    W(2, l, q2 + clip3(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -tc2, tc2));
+                }
+            }
+        } else {
+            int side = (beta + (beta >> 1)) >> 3, tc_2 = tc >> 1;
+            int nd_p = dp0 + dp3 < side ? 2 : 1, nd_q = dq0 + dq3 < side ? 2 : 1;
+            for (int l = 0; l < 4; l++) {
+                int p2 = S(-3, l), p1 = S(-2, l), p0 = S(-1, l), q0 = S(0, l), q1 = S(1, l), q2 = S(2, l);
+                int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+                if (abs(delta) >= 10 * tc)
+                    continue;
+                delta = clip3(delta, -tc, tc);
+                if (!no_p) W(-1, l, clip_px(p0 + delta, bd));
+                if (!no_q) W(0, l, clip_px(q0 - delta, bd));
+                if (!no_p && nd_p > 1)
+                    W(-2, l, clip_px(p1 + clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2), bd));
+                if (!no_q && nd_q > 1)
+                    W(1, l, clip_px(q1 + clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2), bd));
+            }
+        }
+    }
+}
+
+/* hevc_loop_filter_chroma: hevcdsp_template.c:1725-1757 */
+static void deblock_chroma(int bd, uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys,
+                           const int *tc_in, const uint8_t *no_p_in, const uint8_t *no_q_in)
+{
+    for (int seg = 0; seg < 2; seg++, pix += 4 * ys) {
+        int tc = tc_in[seg] << (bd - 8);
+        if (tc <= 0)
+            continue;
+        for (int l = 0; l < 4; l++) {
+            int p1 = S(-2, l), p0 = S(-1, l), q0 = S(0, l), q1 = S(1, l);
+            int delta = clip3((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
+            if (!no_p_in[seg]) W(-1, l, clip_px(p0 + delta, bd));
+            if (!no_q_in[seg]) W(0, l, clip_px(q0 - delta, bd));
+        }
+    }
+#undef S
+#undef W
+}
+
+/* wrappers hevc_{h,v}_loop_filter_*: hevcdsp_template.c:1759-1787.  "v" = vertical edge: across = 1 pixel */
+void ohor_deblock_luma(int bd, int vertical_edge, uint8_t *pix, ptrdiff_t stride, int beta,
+                       int *tc, uint8_t *no_p, uint8_t *no_q)
+{
+    if (vertical_edge) deblock_luma(bd, pix, psz(bd), stride, beta, tc, no_p, no_q);
+    else               deblock_luma(bd, pix, stride, psz(bd), beta, tc, no_p, no_q);
+}
+void ohor_deblock_chroma(int bd, int vertical_edge, uint8_t *pix, ptrdiff_t stride,
+                         int *tc, uint8_t *no_p, uint8_t *no_q)
+{
+    if (vertical_edge) deblock_chroma(bd, pix, psz(bd), stride, tc, no_p, no_q);
+    else               deblock_chroma(bd, pix, stride, psz(bd), tc, no_p, no_q);
+}
+
+/* ------------------------------------------------------------------ SAO
+ * sao_band_filter_0: hevcdsp_template.c:340-365 */
+void ohor_sao_band(int bd, uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src,
+                   const int16_t *offset_val, int band_position, int width, int height)
+{
+    int table[32] = { 0 }, ps = psz(bd), shift = bd - 5;
+    for (int k = 0; k < 4; k++)
+        table[(k + band_position) & 31] = offset_val[k + 1];
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int v = ldpx(PX(src, stride_src, x, y), bd);
+            stpx(PX(dst, stride_dst, x, y), bd, clip_px(v + table[v >> shift], bd));
+        }
+}
+
+/* sao_edge_filter_{0,1}: hevcdsp_template.c:372-567 */
+void ohor_sao_edge(int bd, int restore, uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst,
+                   ptrdiff_t stride_src, const int16_t *offset_val, int eo_class, int *borders,
+                   int width, int height, uint8_t *vert_edge, uint8_t *horiz_edge, uint8_t *diag_edge)
+{
+    static const int8_t nb[4][2][2] = {        /* neighbour (dx,dy) pairs per eo_class (:378-383) */
+        { { -1, 0 }, { 1, 0 } }, { { 0, -1 }, { 0, 1 } }, { { -1, -1 }, { 1, 1 } }, { { 1, -1 }, { -1, 1 } },
+    };
+    static const uint8_t edge_idx[5] = { 1, 2, 0, 3, 4 };
+    int ps = psz(bd);
+#define COPYPX(x, y, off) stpx(PX(dst, stride_dst, x, y), bd, clip_px(ldpx(PX(src, stride_src, x, y), bd) + (off), bd))
+#define RESTOREPX(x, y)   stpx(PX(dst, stride_dst, x, y), bd, ldpx(PX(src, stride_src, x, y), bd))
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int c = ldpx(PX(src, stride_src, x, y), bd);
+            int a = ldpx(PX(src, stride_src, x + nb[eo_class][0][0], y + nb[eo_class][0][1]), bd);
+            int b = ldpx(PX(src, stride_src, x + nb[eo_class][1][0], y + nb[eo_class][1][1]), bd);
+            int s0 = (c > a) - (c < a), s1 = (c > b) - (c < b);
+            stpx(PX(dst, stride_dst, x, y), bd, clip_px(c + offset_val[edge_idx[2 + s0 + s1]], bd));
+        }
+    /* picture-border rows/columns get offset_val[0] (:419-455); the reference's second column loop really
+     * runs over `height` (it is a column), kept as is */
+    int init_x = 0, init_y = 0, w = width, h = height;
+    if (eo_class != 1) {
+        if (borders[0]) { for (int y = 0; y < h; y++) COPYPX(0, y, offset_val[0]); init_x = 1; }
+        if (borders[2]) { for (int y = 0; y < h; y++) COPYPX(w - 1, y, offset_val[0]); w--; }
+    }
+    if (eo_class != 0) {
+        if (borders[1]) { for (int x = init_x; x < w; x++) COPYPX(x, 0, offset_val[0]); }
+        if (borders[3]) { for (int x = init_x; x < w; x++) COPYPX(x, h - 1, offset_val[0]); h--; }
+    }
+    if (!restore)
+        return;
+    /* variant 1 (:533-566): undo the filter across slice/tile edges that may not be crossed */
+    int sul = !diag_edge[0] && eo_class == 2 && !borders[0] && !borders[1];
+    int sur = !diag_edge[1] && eo_class == 3 && !borders[1] && !borders[2];
+    int slr = !diag_edge[2] && eo_class == 2 && !borders[2] && !borders[3];
+    int sll = !diag_edge[3] && eo_class == 3 && !borders[0] && !borders[3];
+    if (vert_edge[0] && eo_class != 1)
+        for (int y = init_y + sul; y < h - sll; y++) RESTOREPX(0, y);
+    if (vert_edge[1] && eo_class != 1)
+        for (int y = init_y + sur; y < h - slr; y++) RESTOREPX(w - 1, y);
+    if (horiz_edge[0] && eo_class != 0)
+        for (int x = init_x + sul; x < w - sur; x++) RESTOREPX(x, 0);
+    if (horiz_edge[1] && eo_class != 0)
+        for (int x = init_x + sll; x < w - slr; x++) RESTOREPX(x, h - 1);
+    if (diag_edge[0] && eo_class == 2) RESTOREPX(0, 0);
+    if (diag_edge[1] && eo_class == 3) RESTOREPX(w - 1, 0);
+    if (diag_edge[2] && eo_class == 2) RESTOREPX(w - 1, h - 1);
+    if (diag_edge[3] && eo_class == 3) RESTOREPX(0, h - 1);
+#undef COPYPX
+#undef RESTOREPX
+}
+
+/* ------------------------------------------------------------------ intra predictors
+ * All three take integer neighbour arrays t[-1..2N-1], l[-1..2N-1] and write an N x N block. */
+static void predict_planar(int bd, int log2, uint8_t *dst, ptrdiff_t stride, const int *t, const int *l)
+{   /* hevcpred_template.c:359-372 */
+    int n = 1 << log2, ps = psz(bd);
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+            stpx(PX(dst, stride, x, y), bd,
+                 ((n - 1 - x) * l[y] + (x + 1) * t[n] + (n - 1 - y) * t[x] + (y + 1) * l[n] + n) >> (log2 + 1));
+}
+
+static void predict_dc(int bd, int log2, uint8_t *dst, ptrdiff_t stride, const int *t, const int *l, int c_idx)
+{   /* hevcpred_template.c:388-417 */
+    int n = 1 << log2, ps = psz(bd), dc = n;
+    for (int i = 0; i < n; i++) dc += l[i] + t[i];
+    dc >>= log2 + 1;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) stpx(PX(dst, stride, x, y), bd, dc);
+    if (c_idx == 0 && n < 32) {
+        stpx(PX(dst, stride, 0, 0), bd, (l[0] + 2 * dc + t[0] + 2) >> 2);
+        for (int x = 1; x < n; x++) stpx(PX(dst, stride, x, 0), bd, (t[x] + 3 * dc + 2) >> 2);
+        for (int y = 1; y < n; y++) stpx(PX(dst, stride, 0, y), bd, (l[y] + 3 * dc + 2) >> 2);
+    }
+}
+
+static void predict_angular(int bd, int log2, uint8_t *dst, ptrdiff_t stride, const int *t, const int *l,
+                            int c_idx, int mode)
+{   /* hevcpred_template.c:419-510 */
+    static const int8_t angle_tab[33] = {
+        32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+        -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+    static const int16_t inv_angle_tab[15] = {
+        -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+    int n = 1 << log2, ps = psz(bd), angle = angle_tab[mode - 2], last = (n * angle) >> 5;
+    int vertical = mode >= 18;
+    const int *main_ = vertical ? t : l, *side = vertical ? l : t;
+    int refbuf[3 * 32 + 4], *ref = refbuf + 32;     /* ref[k] == main_[k-1] for k >= 0 */
+    /* the reference copies main_[-1..n-1] rounded up to a multiple of four samples when it projects (:444-449);
+     * without projection it reads main_ directly, up to index 2n-1 */
+    for (int k = 0; k <= 2 * n; k++) ref[k] = main_[k - 1];
+    if (angle < 0 && last < -1)
+        for (int k = last; k <= -1; k++)
+            ref[k] = side[-1 + ((k * inv_angle_tab[mode - 11] + 128) >> 8)];
+    for (int a = 0; a < n; a++) {                   /* a runs along the prediction direction's minor axis */
+        int idx = ((a + 1) * angle) >> 5, fact = ((a + 1) * angle) & 31;
+        for (int b = 0; b < n; b++) {
+            int v = fact ? ((32 - fact) * ref[b + idx + 1] + fact * ref[b + idx + 2] + 16) >> 5 : ref[b + idx + 1];
+            if (vertical) stpx(PX(dst, stride, b, a), bd, v);
+            else          stpx(PX(dst, stride, a, b), bd, v);
+        }
+    }
+    if (c_idx == 0 && n < 32) {                     /* edge smoothing of the pure vertical / horizontal modes */
+        if (mode == 26)
+            for (int y = 0; y < n; y++) stpx(PX(dst, stride, 0, y), bd, clip_px(t[0] + ((l[y] - l[-1]) >> 1), bd));
+        if (mode == 10)
+            for (int x = 0; x < n; x++) stpx(PX(dst, stride, x, 0), bd, clip_px(l[0] + ((t[x] - t[-1]) >> 1), bd));
+    }
+}
+
+static void load_nb(int bd, int n2, const uint8_t *p, int *out)   /* p -> element 0; copies [-1 .. n2-1] */
+{
+    int ps = psz(bd);
+    for (int i = -1; i < n2; i++) out[i] = ldpx(p + (ptrdiff_t)i * ps, bd);
+}
+
+void ohor_pred_planar(int bd, int log2, uint8_t *src, const uint8_t *top, const uint8_t *left, ptrdiff_t stride)
+{
+    int tb[66], lb[66];
+    load_nb(bd, 2 << log2, top, tb + 1); load_nb(bd, 2 << log2, left, lb + 1);
+    predict_planar(bd, log2, src, stride, tb + 1, lb + 1);
+}
+void ohor_pred_dc(int bd, int log2, uint8_t *src, const uint8_t *top, const uint8_t *left, ptrdiff_t stride, int c_idx)
+{
+    int tb[66], lb[66];
+    load_nb(bd, 2 << log2, top, tb + 1); load_nb(bd, 2 << log2, left, lb + 1);
+    predict_dc(bd, log2, src, stride, tb + 1, lb + 1, c_idx);
+}
+void ohor_pred_angular(int bd, int log2, uint8_t *src, const uint8_t *top, const uint8_t *left,
+                       ptrdiff_t stride, int c_idx, int mode)
+{
+    int tb[66], lb[66];
+    load_nb(bd, 2 << log2, top, tb + 1); load_nb(bd, 2 << log2, left, lb + 1);
+    predict_angular(bd, log2, src, stride, tb + 1, lb + 1, c_idx, mode);
+}
+
+/* ------------------------------------------------------------------ intra_pred(): neighbour preparation
+ * hevcpred_template.c:30-357.  z-scan order inside a CTB, -1 outside (hevc_ps.c:2551-2567). */
+static int zscan_addr(int x, int y, int bits)
+{
+    if (x < 0 || y < 0) return -1;
+    int v = 0;
+    for (int i = 0; i < bits; i++)
+        v |= ((x >> i) & 1) << (2 * i) | ((y >> i) & 1) << (2 * i + 1);
+    return v;
+}
+
+void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, int c_idx, int mode,
+                     int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right)
+{
+    int ps = psz(bd), cfi = pic->chroma_format_idc;
+    int hs = c_idx ? (cfi == 1 || cfi == 2) : 0, vs = c_idx ? (cfi == 1) : 0;
+    int n = 1 << log2;
+    int nlh = n << hs, nlv = n << vs;                         /* block size in luma samples */
+    int tb_bits = pic->log2_ctb_size - pic->log2_min_tb_size, tb_mask = (1 << tb_bits) - 1;
+    int x_tb = (x0 >> pic->log2_min_tb_size) & tb_mask, y_tb = (y0 >> pic->log2_min_tb_size) & tb_mask;
+    int cur = zscan_addr(x_tb, y_tb, tb_bits);
+    ptrdiff_t stride = pic->linesize[c_idx];
+    uint8_t *blk = pic->data[c_idx] + (ptrdiff_t)(y0 >> vs) * stride + (ptrdiff_t)(x0 >> hs) * ps;
+    int lbuf[2 * 32 + 8], tbuf[2 * 32 + 8], flbuf[2 * 32 + 8], ftbuf[2 * 32 + 8];
+    int *l = lbuf + 4, *t = tbuf + 4, *fl = flbuf + 4, *ft = ftbuf + 4;
+#define REC(x, y) ldpx(PX(blk, stride, x, y), bd)
+
+    /* z-scan qualification of the two "ahead" candidates (:105-109) */
+    cand_bottom_left = cand_bottom_left &&
+        cur > zscan_addr(x_tb - 1, (y_tb + (nlv >> pic->log2_min_tb_size)) & tb_mask, tb_bits);
+    cand_up_right = cand_up_right &&
+        cur > zscan_addr((x_tb + (nlh >> pic->log2_min_tb_size)) & tb_mask, y_tb - 1, tb_bits);
+
+    int y_end = y0 + 2 * nlv < pic->height ? y0 + 2 * nlv : pic->height;
+    int x_end = x0 + 2 * nlh < pic->width  ? x0 + 2 * nlh : pic->width;
+    int bl_size = (y_end - (y0 + nlv)) >> vs, tr_size = (x_end - (x0 + nlh)) >> hs;   /* :111-114 */
+
+    if (pic->constrained_intra_pred) {
+        /* constrained-intra substitution (:116-163,185-249) is restated in round 2; refuse loudly */
+        abort();
+    }
+    if (cand_up_left) { l[-1] = REC(-1, -1); t[-1] = l[-1]; }
+    if (cand_up) for (int i = 0; i < n; i++) t[i] = REC(i, -1);
+    if (cand_up_right) {
+        for (int i = n; i < n + tr_size; i++) t[i] = REC(i, -1);
+        for (int i = n + tr_size; i < 2 * n; i++) t[i] = REC(n + tr_size - 1, -1);
+    }
+    if (cand_left) for (int i = 0; i < n; i++) l[i] = REC(-1, i);
+    if (cand_bottom_left) {
+        for (int i = n; i < n + bl_size; i++) l[i] = REC(-1, i);
+        for (int i = n + bl_size; i < 2 * n; i++) l[i] = REC(-1, n + bl_size - 1);
+    }
+    /* substitution of unavailable samples (:251-286) */
+    if (!cand_bottom_left) {
+        if (cand_left) {
+            for (int i = n; i < 2 * n; i++) l[i] = l[n - 1];
+        } else if (cand_up_left) {
+            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
+            cand_left = 1;
+        } else if (cand_up) {
+            l[-1] = t[0];
+            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
+            cand_up_left = cand_left = 1;
+        } else if (cand_up_right) {
+            for (int i = 0; i < n; i++) t[i] = t[n];
+            l[-1] = t[n];
+            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
+            cand_up = cand_up_left = cand_left = 1;
+        } else {
+            l[-1] = 1 << (bd - 1);
+            for (int i = 0; i < 2 * n; i++) t[i] = l[i] = l[-1];
+        }
+    }
+    if (!cand_left) for (int i = 0; i < n; i++) l[i] = l[n];
+    if (!cand_up_left) l[-1] = l[0];
+    if (!cand_up) for (int i = 0; i < n; i++) t[i] = l[-1];
+    if (!cand_up_right) for (int i = n; i < 2 * n; i++) t[i] = t[n - 1];
+    t[-1] = l[-1];
+
+    /* reference-sample smoothing (:289-327) */
+    if (!pic->intra_smoothing_disabled && (c_idx == 0 || cfi == 3) && mode != 1 && n != 4) {
+        static const int thresh[3] = { 7, 1, 0 };
+        int dv = abs(mode - 26), dh = abs(mode - 10), dist = dv < dh ? dv : dh;
+        if (dist > thresh[log2 - 3]) {
+            int lim = 1 << (bd - 5);
+            if (pic->strong_intra_smoothing && c_idx == 0 && log2 == 5 &&
+                abs(t[-1] + t[63] - 2 * t[31]) < lim && abs(l[-1] + l[63] - 2 * l[31]) < lim) {
+                ft[-1] = t[-1]; ft[63] = t[63]; fl[-1] = l[-1]; fl[63] = l[63];
+                for (int i = 0; i < 63; i++) {
+                    ft[i] = ((63 - i) * t[-1] + (i + 1) * t[63] + 32) >> 6;
+                    fl[i] = ((63 - i) * l[-1] + (i + 1) * l[63] + 32) >> 6;
+                }
+            } else {
+                fl[2 * n - 1] = l[2 * n - 1]; ft[2 * n - 1] = t[2 * n - 1];
+                for (int i = 2 * n - 2; i >= 0; i--) {
+                    fl[i] = (l[i + 1] + 2 * l[i] + l[i - 1] + 2) >> 2;
+                    ft[i] = (t[i + 1] + 2 * t[i] + t[i - 1] + 2) >> 2;
+                }
+                ft[-1] = fl[-1] = (l[0] + 2 * l[-1] + t[0] + 2) >> 2;
+            }
+            l = fl; t = ft;
+        }
+    }
+    if (mode == 0)      predict_planar(bd, log2, blk, stride, t, l);
+    else if (mode == 1) predict_dc(bd, log2, blk, stride, t, l, c_idx);
+    else                predict_angular(bd, log2, blk, stride, t, l, c_idx, mode);
+#undef REC
+}

@@ -1,0 +1,187 @@
+"""ctypes access to the CPU oracles -- TEST INFRASTRUCTURE ONLY.
+
+Two libraries expose the same C API (oracle/oracle_api.h):
+
+* ``ref``    -> oracle/_ref/libhevcref.so : the reference's own hevcdsp.c/hevcpred.c compiled unmodified
+* ``oracle`` -> oracle/liboracle.so       : our plain-C restatement (oracle/hevc_oracle.c)
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+TU_IDCT, TU_DC, TU_DST4, TU_SKIP, TU_SKIP_RDPCM_H, TU_SKIP_RDPCM_V, TU_BYPASS, TU_BYPASS_RDPCM_H, TU_BYPASS_RDPCM_V = range(9)
+MC_PUT, MC_UNI, MC_UNI_W, MC_BI, MC_BI_W = range(5)
+
+
+class IntraPic(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("linesize", C.c_int32 * 3), ("width", C.c_int32), ("height", C.c_int32),
+                ("chroma_format_idc", C.c_int32), ("log2_ctb_size", C.c_int32), ("log2_min_tb_size", C.c_int32),
+                ("log2_min_pu_size", C.c_int32), ("strong_intra_smoothing", C.c_int32),
+                ("intra_smoothing_disabled", C.c_int32), ("constrained_intra_pred", C.c_int32),
+                ("is_intra", C.c_void_p)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def build(target="all"):
+    """(Re)build the oracle libraries; the reference part is skipped when /root/reference is absent."""
+    subprocess.run(["make", "-s", "-C", HERE, target], check=True)
+
+
+class OracleLib:
+    """One implementation of oracle_api.h (prefix ``ohref_`` or ``ohor_``)."""
+
+    def __init__(self, path, prefix):
+        self.path, self.prefix = path, prefix
+        self.lib = C.CDLL(path)
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    # ---- transforms
+    def tu_residual(self, bd, kind, log2, coeffs, col_limit=None):
+        """Returns the residual (int16, N x N) of a dense coefficient block."""
+        n = 1 << log2
+        c = np.ascontiguousarray(coeffs, dtype=np.int16).reshape(n * n).copy()
+        buf = _aligned_copy(c)
+        self._f("tu_residual")(C.c_int(bd), C.c_int(kind), C.c_int(log2), _p(buf), C.c_int(n if col_limit is None else col_limit))
+        return buf.reshape(n, n).copy()
+
+    def tu_batch(self, bd, kind, log2, coeffs, plane, xy, col_limit=None, threads=0):
+        """In-place on `plane` (2-D uint8/uint16 array): adds the residual of every block at its (x,y)."""
+        n = 1 << log2
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        nblk = xy.shape[0]
+        assert coeffs.size == nblk * n * n and plane.flags.c_contiguous
+        args = [C.c_int(bd), C.c_int(kind), C.c_int(log2), C.c_int(nblk), _p(coeffs), _p(plane),
+                C.c_ssize_t(plane.strides[0]), _p(xy), C.c_int(n if col_limit is None else col_limit)]
+        if threads:
+            self._f("tu_batch_mt")(*args, C.c_int(threads))
+        else:
+            self._f("tu_batch")(*args)
+        return plane
+
+    # ---- motion compensation.  `ref` is a 2-D pixel array, (sx, sy) the integer sample the block starts at.
+    def mc(self, bd, luma, variant, ref, sx, sy, w, h, mx, my, src2=None, denom=0, wx0=0, wx1=0, ox0=0, ox1=0):
+        ps = ref.itemsize
+        src_addr = ref.ctypes.data + sy * ref.strides[0] + sx * ps
+        if variant == MC_PUT:
+            out = np.zeros((h, 64), dtype=np.int16)
+            dst, dstride = out, 64
+        else:
+            out = np.zeros((h, w), dtype=ref.dtype)
+            dst, dstride = out, out.strides[0]
+        s2 = np.ascontiguousarray(src2, dtype=np.int16) if src2 is not None else np.zeros((1, 64), np.int16)
+        self._f("mc")(C.c_int(bd), C.c_int(luma), C.c_int(variant), _p(dst), C.c_ssize_t(dstride),
+                      C.c_void_p(src_addr), C.c_ssize_t(ref.strides[0]), _p(s2), C.c_ssize_t(s2.shape[1]),
+                      C.c_int(h), C.c_int(mx), C.c_int(my), C.c_int(w),
+                      C.c_int(denom), C.c_int(wx0), C.c_int(wx1), C.c_int(ox0), C.c_int(ox1))
+        return out[:, :w].copy() if variant == MC_PUT else out
+
+    # ---- deblocking: `plane` modified in place; (x, y) is the q0 sample of the first line of the 8-line edge
+    def deblock_luma(self, bd, vertical_edge, plane, x, y, beta, tc, no_p, no_q):
+        tc_a = (C.c_int * 2)(*tc); p_a = (C.c_uint8 * 2)(*no_p); q_a = (C.c_uint8 * 2)(*no_q)
+        addr = plane.ctypes.data + y * plane.strides[0] + x * plane.itemsize
+        self._f("deblock_luma")(C.c_int(bd), C.c_int(vertical_edge), C.c_void_p(addr), C.c_ssize_t(plane.strides[0]),
+                                C.c_int(beta), tc_a, p_a, q_a)
+
+    def deblock_chroma(self, bd, vertical_edge, plane, x, y, tc, no_p, no_q):
+        tc_a = (C.c_int * 2)(*tc); p_a = (C.c_uint8 * 2)(*no_p); q_a = (C.c_uint8 * 2)(*no_q)
+        addr = plane.ctypes.data + y * plane.strides[0] + x * plane.itemsize
+        self._f("deblock_chroma")(C.c_int(bd), C.c_int(vertical_edge), C.c_void_p(addr), C.c_ssize_t(plane.strides[0]),
+                                  tc_a, p_a, q_a)
+
+    # ---- SAO on a w x h block at (x,y): reads `src` (needs a 1-px ring for edge), writes `dst`
+    def sao_band(self, bd, dst, src, x, y, w, h, offset_val, band_position):
+        ov = np.ascontiguousarray(offset_val, dtype=np.int16)
+        self._f("sao_band")(C.c_int(bd), C.c_void_p(dst.ctypes.data + y * dst.strides[0] + x * dst.itemsize),
+                            C.c_void_p(src.ctypes.data + y * src.strides[0] + x * src.itemsize),
+                            C.c_ssize_t(dst.strides[0]), C.c_ssize_t(src.strides[0]), _p(ov), C.c_int(band_position),
+                            C.c_int(w), C.c_int(h))
+
+    def sao_edge(self, bd, restore, dst, src, x, y, w, h, offset_val, eo_class, borders,
+                 vert_edge=(0, 0), horiz_edge=(0, 0), diag_edge=(0, 0, 0, 0)):
+        ov = np.ascontiguousarray(offset_val, dtype=np.int16)
+        b = (C.c_int * 4)(*borders); ve = (C.c_uint8 * 2)(*vert_edge); he = (C.c_uint8 * 2)(*horiz_edge)
+        de = (C.c_uint8 * 4)(*diag_edge)
+        self._f("sao_edge")(C.c_int(bd), C.c_int(restore),
+                            C.c_void_p(dst.ctypes.data + y * dst.strides[0] + x * dst.itemsize),
+                            C.c_void_p(src.ctypes.data + y * src.strides[0] + x * src.itemsize),
+                            C.c_ssize_t(dst.strides[0]), C.c_ssize_t(src.strides[0]), _p(ov), C.c_int(eo_class), b,
+                            C.c_int(w), C.c_int(h), ve, he, de)
+
+    # ---- pure predictors: top/left are 1-D pixel arrays holding [-1 .. 2N-1] (so element 0 is at index 1)
+    def pred(self, bd, log2, mode, top, left, c_idx=0):
+        n = 1 << log2
+        dt = np.uint16 if bd > 8 else np.uint8
+        out = np.zeros((n, n), dtype=dt)
+        t = np.ascontiguousarray(top, dtype=dt); l = np.ascontiguousarray(left, dtype=dt)
+        tp = C.c_void_p(t.ctypes.data + t.itemsize); lp = C.c_void_p(l.ctypes.data + l.itemsize)
+        if mode == 0:
+            self._f("pred_planar")(C.c_int(bd), C.c_int(log2), _p(out), tp, lp, C.c_ssize_t(out.strides[0]))
+        elif mode == 1:
+            self._f("pred_dc")(C.c_int(bd), C.c_int(log2), _p(out), tp, lp, C.c_ssize_t(out.strides[0]), C.c_int(c_idx))
+        else:
+            self._f("pred_angular")(C.c_int(bd), C.c_int(log2), _p(out), tp, lp, C.c_ssize_t(out.strides[0]),
+                                    C.c_int(c_idx), C.c_int(mode))
+        return out
+
+    # ---- full intra_pred() on a picture (list of 3 plane arrays, modified in place)
+    def intra_pred(self, bd, planes, width, height, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1,
+                   log2_ctb_size=6, log2_min_tb_size=2, log2_min_pu_size=2, strong=1, smoothing_disabled=0,
+                   constrained=0, is_intra=None):
+        pic = IntraPic()
+        for i in range(3):
+            pic.data[i] = planes[i].ctypes.data
+            pic.linesize[i] = planes[i].strides[0]
+        pic.width, pic.height, pic.chroma_format_idc = width, height, chroma_format_idc
+        pic.log2_ctb_size, pic.log2_min_tb_size, pic.log2_min_pu_size = log2_ctb_size, log2_min_tb_size, log2_min_pu_size
+        pic.strong_intra_smoothing, pic.intra_smoothing_disabled, pic.constrained_intra_pred = strong, smoothing_disabled, constrained
+        keep = None
+        if is_intra is not None:
+            keep = np.ascontiguousarray(is_intra, dtype=np.uint8)
+            pic.is_intra = keep.ctypes.data
+        bl, lf, ul, up, ur = cands
+        self._f("intra_pred")(C.c_int(bd), C.byref(pic), C.c_int(x0), C.c_int(y0), C.c_int(log2), C.c_int(c_idx),
+                              C.c_int(mode), C.c_int(bl), C.c_int(lf), C.c_int(ul), C.c_int(up), C.c_int(ur))
+
+
+def _aligned_copy(a, align=64):
+    raw = np.empty(a.nbytes + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    out = raw[off:off + a.nbytes].view(a.dtype)
+    out[:] = a
+    return out
+
+
+_cache = {}
+
+
+def load(which):
+    """which: 'oracle' (restatement, always buildable), 'ref' (reference build) or 'sse'. Returns None if absent."""
+    if which in _cache:
+        return _cache[which]
+    if which == "oracle":
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(path)
+        lib = OracleLib(path, "ohor_")
+    elif which == "ref":
+        path = os.path.join(HERE, "_ref", "libhevcref.so")
+        lib = OracleLib(path, "ohref_") if os.path.exists(path) else None
+    elif which == "sse":
+        path = os.path.join(HERE, "_ref", "libhevcref_sse.so")
+        lib = C.CDLL(path) if os.path.exists(path) else None
+    else:
+        raise ValueError(which)
+    _cache[which] = lib
+    return lib

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    return pyoracle.load("oracle")
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle import pyoracle
+    lib = pyoracle.load("ref")
+    if lib is None:
+        pytest.skip("oracle/_ref/libhevcref.so not built (needs /root/reference)")
+    return lib

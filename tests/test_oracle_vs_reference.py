@@ -1,0 +1,207 @@
+"""Pin the CPU restatement (oracle/hevc_oracle.c) against the reference's own compiled C
+(oracle/_ref/libhevcref.so = /root/reference/libavcodec/hevcdsp.c + hevcpred.c, unmodified).
+
+The reference ships no tests or golden vectors, so this differential test plus the
+fixtures in tests/golden/ (generated from the same reference build) are what pins the oracle.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+BDS = [8, 10, 12]
+
+
+def pixdt(bd):
+    return np.uint16 if bd > 8 else np.uint8
+
+
+def rand_plane(rng, bd, h, w):
+    return rng.integers(0, 1 << bd, size=(h, w)).astype(pixdt(bd))
+
+
+# ------------------------------------------------------------------ transforms
+@pytest.mark.parametrize("bd", BDS)
+@pytest.mark.parametrize("log2", [2, 3, 4, 5])
+def test_idct_dense(oracle, ref, bd, log2):
+    rng = np.random.default_rng(100 + bd * 10 + log2)
+    n = 1 << log2
+    for amp in (1 << 15, 1024, 64):
+        for _ in range(6):
+            c = rng.integers(-amp, amp, size=(n, n)).astype(np.int16)
+            assert np.array_equal(oracle.tu_residual(bd, po.TU_IDCT, log2, c), ref.tu_residual(bd, po.TU_IDCT, log2, c))
+    # extreme values exercise both clip_int16 stages
+    for v in (-32768, 32767):
+        c = np.full((n, n), v, np.int16)
+        assert np.array_equal(oracle.tu_residual(bd, po.TU_IDCT, log2, c), ref.tu_residual(bd, po.TU_IDCT, log2, c))
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("log2", [2, 3, 4, 5])
+def test_idct_col_limit_semantics(oracle, ref, bd, log2):
+    """The partial butterflies skip inputs beyond col_limit (hevcdsp_template.c:264-301); the restatement
+    must agree even on (contract-violating) dense input, and a full transform must agree on legal input."""
+    rng = np.random.default_rng(7 + log2)
+    n = 1 << log2
+    for col_limit in sorted({4, 8, 12, 24, n} & set(range(4, n + 1)) | {n}):
+        c = rng.integers(-2000, 2000, size=(n, n)).astype(np.int16)
+        a = oracle.tu_residual(bd, po.TU_IDCT, log2, c, col_limit)
+        b = ref.tu_residual(bd, po.TU_IDCT, log2, c, col_limit)
+        assert np.array_equal(a, b), (col_limit,)
+        # legal input: nonzeros only where x + y <= col_limit - 4 (hevc_cabac.c:1923-1934)
+        yy, xx = np.mgrid[0:n, 0:n]
+        legal = np.where(xx + yy <= col_limit - 4, c, 0).astype(np.int16)
+        full = oracle.tu_residual(bd, po.TU_IDCT, log2, legal, n)
+        assert np.array_equal(full, ref.tu_residual(bd, po.TU_IDCT, log2, legal, col_limit))
+
+
+@pytest.mark.parametrize("bd", BDS)
+def test_other_residual_kinds(oracle, ref, bd):
+    rng = np.random.default_rng(5 + bd)
+    for log2 in (2, 3, 4, 5):
+        n = 1 << log2
+        kinds = [po.TU_DC, po.TU_SKIP, po.TU_SKIP_RDPCM_H, po.TU_SKIP_RDPCM_V, po.TU_BYPASS,
+                 po.TU_BYPASS_RDPCM_H, po.TU_BYPASS_RDPCM_V] + ([po.TU_DST4] if log2 == 2 else [])
+        for kind in kinds:
+            for amp in (1 << 15, 300):
+                c = rng.integers(-amp, amp, size=(n, n)).astype(np.int16)
+                assert np.array_equal(oracle.tu_residual(bd, kind, log2, c), ref.tu_residual(bd, kind, log2, c)), (kind, log2)
+
+
+@pytest.mark.parametrize("bd", BDS)
+@pytest.mark.parametrize("log2", [2, 3, 4, 5])
+def test_tu_batch_add(oracle, ref, bd, log2):
+    rng = np.random.default_rng(11 + bd + log2)
+    n = 1 << log2
+    nblk = 24
+    plane = rand_plane(rng, bd, 4 * n, 6 * n + 8)
+    xy = np.array([[(i % 6) * n + 4, (i // 6) * n] for i in range(nblk)], np.int32)
+    c = rng.integers(-1024, 1024, size=(nblk, n, n)).astype(np.int16)
+    a = oracle.tu_batch(bd, po.TU_IDCT, log2, c, plane.copy(), xy)
+    b = ref.tu_batch(bd, po.TU_IDCT, log2, c, plane.copy(), xy)
+    assert np.array_equal(a, b)
+    assert np.array_equal(oracle.tu_batch(bd, po.TU_IDCT, log2, c, plane.copy(), xy, threads=3), b)
+    assert np.array_equal(ref.tu_batch(bd, po.TU_IDCT, log2, c, plane.copy(), xy, threads=3), b)
+
+
+# ------------------------------------------------------------------ motion compensation
+WIDTHS_LUMA = [4, 8, 12, 16, 24, 32, 48, 64]
+WIDTHS_CHROMA = [2, 4, 6, 8, 12, 16, 24, 32]
+
+
+@pytest.mark.parametrize("bd", BDS)
+@pytest.mark.parametrize("luma", [1, 0])
+def test_mc_all_variants(oracle, ref, bd, luma):
+    rng = np.random.default_rng(21 + bd + luma)
+    refp = rand_plane(rng, bd, 96, 112)
+    fr = 4 if luma else 8
+    for w in (WIDTHS_LUMA if luma else WIDTHS_CHROMA):
+        for (mx, my) in [(0, 0), (1, 0), (0, 2), (3, 1), (fr - 1, fr - 1)]:
+            h = int(rng.choice([4, 8, 16, 24])) if w > 2 else 4
+            sx, sy = int(rng.integers(4, 20)), int(rng.integers(4, 20))
+            src2 = rng.integers(-8000, 16000, size=(h, 64)).astype(np.int16)
+            kw = dict(denom=int(rng.integers(0, 8)), wx0=int(rng.integers(-128, 128)), wx1=int(rng.integers(-128, 128)),
+                      ox0=int(rng.integers(-128, 128)), ox1=int(rng.integers(-128, 128)))
+            for variant in (po.MC_PUT, po.MC_UNI, po.MC_UNI_W, po.MC_BI, po.MC_BI_W):
+                a = oracle.mc(bd, luma, variant, refp, sx, sy, w, h, mx, my, src2=src2, **kw)
+                b = ref.mc(bd, luma, variant, refp, sx, sy, w, h, mx, my, src2=src2, **kw)
+                assert np.array_equal(a, b), (w, h, mx, my, variant, kw)
+
+
+# ------------------------------------------------------------------ deblocking
+@pytest.mark.parametrize("bd", BDS)
+def test_deblock(oracle, ref, bd):
+    rng = np.random.default_rng(31 + bd)
+    for it in range(300):
+        # smooth-ish content so that all three decisions (off / normal / strong) occur
+        base = rng.integers(0, 1 << bd)
+        amp = int(rng.choice([1, 2, 4, 16, 64])) << (bd - 8)
+        plane = np.clip(base + rng.integers(-amp, amp + 1, size=(24, 24)), 0, (1 << bd) - 1).astype(pixdt(bd))
+        if it % 3 == 0:
+            plane[:, 12:] = np.clip(plane[:, 12:].astype(int) + (int(rng.integers(-12, 13)) << (bd - 8)), 0, (1 << bd) - 1)
+            plane[12:, :] = np.clip(plane[12:, :].astype(int) + (int(rng.integers(-12, 13)) << (bd - 8)), 0, (1 << bd) - 1)
+        beta = int(rng.integers(0, 65)); tc = [int(rng.integers(0, 25)), int(rng.integers(0, 25))]
+        no_p = [int(rng.random() < 0.15), int(rng.random() < 0.15)]; no_q = [int(rng.random() < 0.15), int(rng.random() < 0.15)]
+        for vert in (0, 1):
+            x, y = (12, 8) if vert else (8, 12)
+            a, b = plane.copy(), plane.copy()
+            oracle.deblock_luma(bd, vert, a, x, y, beta, tc, no_p, no_q)
+            ref.deblock_luma(bd, vert, b, x, y, beta, tc, no_p, no_q)
+            assert np.array_equal(a, b), (it, vert, beta, tc)
+            a, b = plane.copy(), plane.copy()
+            oracle.deblock_chroma(bd, vert, a, x, y, tc, no_p, no_q)
+            ref.deblock_chroma(bd, vert, b, x, y, tc, no_p, no_q)
+            assert np.array_equal(a, b), (it, vert, tc)
+
+
+# ------------------------------------------------------------------ SAO
+@pytest.mark.parametrize("bd", BDS)
+def test_sao(oracle, ref, bd):
+    rng = np.random.default_rng(41 + bd)
+    for it in range(120):
+        w, h = int(rng.choice([8, 16, 24, 32, 64])), int(rng.choice([8, 16, 32, 64]))
+        src = rand_plane(rng, bd, h + 2, w + 2)
+        if it % 2:
+            src = (src >> (bd - 3)).astype(src.dtype) + (1 << (bd - 1))     # flat content: many equal neighbours
+        ov = np.concatenate([[0], rng.integers(-31, 32, size=4) << (bd - 8 if bd <= 10 else 2)]).astype(np.int16)
+        a = np.zeros_like(src); b = np.zeros_like(src)
+        bp = int(rng.integers(0, 32))
+        oracle.sao_band(bd, a, src, 1, 1, w, h, ov, bp); ref.sao_band(bd, b, src, 1, 1, w, h, ov, bp)
+        assert np.array_equal(a, b)
+        for eo in range(4):
+            borders = [int(rng.random() < 0.3) for _ in range(4)]
+            ve = [int(rng.random() < 0.3) for _ in range(2)]; he = [int(rng.random() < 0.3) for _ in range(2)]
+            de = [int(rng.random() < 0.3) for _ in range(4)]
+            for restore in (0, 1):
+                a = np.zeros_like(src); b = np.zeros_like(src)
+                oracle.sao_edge(bd, restore, a, src, 1, 1, w, h, ov, eo, borders, ve, he, de)
+                ref.sao_edge(bd, restore, b, src, 1, 1, w, h, ov, eo, borders, ve, he, de)
+                assert np.array_equal(a, b), (it, eo, restore, borders, ve, he, de)
+
+
+# ------------------------------------------------------------------ intra
+@pytest.mark.parametrize("bd", BDS)
+@pytest.mark.parametrize("log2", [2, 3, 4, 5])
+def test_pred_modes(oracle, ref, bd, log2):
+    rng = np.random.default_rng(51 + bd + log2)
+    n = 1 << log2
+    for mode in range(35):
+        for c_idx in (0, 1):
+            top = rng.integers(0, 1 << bd, size=2 * n + 1 + 8)
+            left = rng.integers(0, 1 << bd, size=2 * n + 1 + 8)
+            a = oracle.pred(bd, log2, mode, top, left, c_idx); b = ref.pred(bd, log2, mode, top, left, c_idx)
+            assert np.array_equal(a, b), (mode, c_idx)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_pred_full(oracle, ref, bd):
+    rng = np.random.default_rng(61 + bd)
+    W, H = 136, 72                      # not CTB aligned: exercises picture-edge clipping of the 2N neighbours
+    for it in range(400):
+        log2 = int(rng.integers(2, 6)); n = 1 << log2
+        c_idx = int(rng.integers(0, 3))
+        cfi = int(rng.choice([1, 1, 1, 3]))
+        sh = 1 if (c_idx and cfi == 1) else 0
+        nl = n << sh
+        x0 = int(rng.integers(0, (W - nl) // nl + 1)) * nl; y0 = int(rng.integers(0, (H - nl) // nl + 1)) * nl
+        if it % 5 == 0:
+            x0, y0 = (W - nl) // nl * nl, (H - nl) // nl * nl
+        mode = int(rng.integers(0, 35))
+        cands = [int(rng.random() < 0.7) for _ in range(5)]
+        if x0 == 0: cands[0] = cands[1] = cands[2] = 0
+        if y0 == 0: cands[2] = cands[3] = cands[4] = 0
+        if x0 + nl >= W: cands[4] = 0
+        if y0 + nl >= H: cands[0] = 0
+        if it % 7 == 0:                  # smooth neighbourhood: triggers the strong 32x32 filter
+            planes = [np.full((H + 8, W + 8), int(rng.integers(0, 1 << bd)), pixdt(bd)) + (np.arange(W + 8) // 16).astype(pixdt(bd)) for _ in range(3)]
+            planes = [np.ascontiguousarray(p) for p in planes]
+        else:
+            planes = [rand_plane(rng, bd, H + 8, W + 8) for _ in range(3)]
+        strong = int(rng.random() < 0.7); dis = int(rng.random() < 0.1)
+        pa = [p.copy() for p in planes]; pb = [p.copy() for p in planes]
+        kw = dict(chroma_format_idc=cfi, strong=strong, smoothing_disabled=dis,
+                  log2_ctb_size=int(rng.choice([4, 5, 6])), log2_min_tb_size=2)
+        oracle.intra_pred(bd, pa, W, H, x0, y0, log2, c_idx, mode, cands, **kw)
+        ref.intra_pred(bd, pb, W, H, x0, y0, log2, c_idx, mode, cands, **kw)
+        for i in range(3):
+            assert np.array_equal(pa[i], pb[i]), (it, log2, c_idx, mode, cands, x0, y0, kw)
