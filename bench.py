@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X pixel-reconstruction backend (BASELINE.json config 2).
+
+Workload ("step" = one pass of the hot path over one batch, inputs already resident in HBM):
+  synthetic batched 32x32 int16 inverse-DCT + add (idct[3] + transform_add[3], hevcdsp_template.c:45-111,
+  264-301), 2^20 blocks per GPU, coefficients uniform in [-1024, 1023], prediction pixels uniform,
+  seed 1234, destination = one tiled picture plane 16384 samples wide (real row strides), 8-bit.
+
+Prints ONE JSON line (rank 0).  `value` = whole-job Mpixel/s over all GPUs; `roofline` = algorithmic HBM bytes
+per launch (4 B/pixel at 8-bit: 2 coeff + 1 pred read + 1 write; 6 B at >8-bit) / mean kernel time measured
+with HIP events on the launch stream; `cpu_baseline` = the reference's own C tables (oracle/_ref) timed on
+this host's cores on a bounded sample of the same workload (N=1, rank 0 only).
+Multi-GPU: one process per GPU (torch.distributed / RCCL only for the barrier + max-over-ranks timing);
+blocks are independent units, each rank owns its own batch: no data-path collective, "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log2", type=int, default=5, help="block size log2 (5 = 32x32, the graded kernel; 4 = 16x16)")
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default 2^20 for 32x32, 2^22 for 16x16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sparse", action="store_true", help="decoder-like coefficients: non-zeros only in the top-left 8x8")
+    return ap.parse_args()
+
+
+def cpu_baseline(log2, bd, target_seconds=12.0):
+    """Reference C tables (oracle/_ref/libhevcref.so, kind 'reference'; falls back to our C port, kind 'port')
+    on all host cores, on a bounded sample of the same workload."""
+    from oracle import pyoracle as po
+    lib, kind = po.load("ref"), "reference"
+    if lib is None:
+        lib, kind = po.load("oracle"), "port"
+    sse = po.load("sse")
+    cores = min(os.cpu_count() or 1, 64)
+    n = 1 << log2
+    rng = np.random.default_rng(1234)
+    dt = np.uint16 if bd > 8 else np.uint8
+    per_row = 4096 // n
+
+    def make(nblk):
+        plane = rng.integers(0, 1 << bd, size=((nblk + per_row - 1) // per_row * n, 4096)).astype(dt)
+        coeffs = rng.integers(-1024, 1024, size=(nblk, n, n)).astype(np.int16)
+        idx = np.arange(nblk)
+        xy = np.stack([(idx % per_row) * n, (idx // per_row) * n], 1).astype(np.int32)
+        return plane, coeffs, xy
+
+    def run(nblk):
+        plane, coeffs, xy = make(nblk)
+        t0 = time.perf_counter()
+        lib.tu_batch(bd, po.TU_IDCT, log2, coeffs, plane, xy, threads=cores)
+        return time.perf_counter() - t0, (plane, coeffs, xy)
+
+    probe = 1 << 12
+    t, _ = run(probe)
+    nblk = int(min(1 << 20, max(probe, probe * target_seconds / max(t, 1e-6))))
+    t, data = run(nblk)
+    out = {"value": round(nblk * n * n / t / 1e6, 2), "unit": "Mpixel/s", "cores": cores, "kind": kind,
+           "sample": f"{nblk} blocks {n}x{n} {bd}-bit, reference C tables (idct+transform_add), {cores} threads, {t:.1f} s"}
+    if sse is not None and bd in (8, 10):
+        import ctypes as C
+        plane, coeffs, xy = data
+        t0 = time.perf_counter()
+        rc = sse.ohsse_idct_add_batch_mt(C.c_int(bd), C.c_int(log2), C.c_int(nblk), coeffs.ctypes.data_as(C.c_void_p),
+                                         plane.ctypes.data_as(C.c_void_p), C.c_ssize_t(plane.strides[0]),
+                                         xy.ctypes.data_as(C.c_void_p), C.c_int(cores))
+        ts = time.perf_counter() - t0
+        if rc == 0:
+            out["simd_value"] = round(nblk * n * n / ts / 1e6, 2)
+            out["simd_note"] = "reference x86 SSE4 intrinsics path (x86/hevc_idct_sse.c), same sample and threads"
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    from openhevc_amd import lib as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    L.check(L.load_library().ohevc_set_device(local_rank))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    log2, bd = args.log2, args.bit_depth
+    n = 1 << log2
+    nblk = args.blocks or (1 << 20 if log2 == 5 else 1 << 22 if log2 == 4 else 1 << 22)
+    per_row = 16384 // n
+    assert nblk % per_row == 0
+    H, W = nblk // per_row * n, 16384
+    assert H <= 65536
+
+    # ---- synthetic inputs, generated on the device (seed 1234 + rank), resident in HBM before timing
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    if bd == 8:
+        plane = torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
+    else:
+        plane = torch.randint(0, 1 << bd, (H, W), dtype=torch.int16, device="cuda", generator=g)
+    coeffs = torch.randint(-1024, 1024, (nblk, n, n), dtype=torch.int16, device="cuda", generator=g)
+    if args.sparse:
+        coeffs[:, 8:, :] = 0
+        coeffs[:, :, 8:] = 0
+    idx = np.arange(nblk)
+    jobs = np.zeros(nblk, L.TU_JOB)
+    jobs["x"], jobs["y"], jobs["coeff_off"] = (idx % per_row) * n, (idx // per_row) * n, idx.astype(np.uint32) * n * n
+    d_jobs = torch.from_numpy(jobs.view(np.uint8)).cuda()
+    planes = L.planes_of([plane, None, None])
+    stream = torch.cuda.current_stream()
+
+    def step():
+        L.dev_tu_batch(planes, bd, log2, L.TU_IDCT, d_jobs.data_ptr(), nblk, coeffs.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:                       # events are recorded on the same (current) stream as the launches
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    bytes_per_px = 2 + 2 * (2 if bd > 8 else 1)
+    alg_bytes = nblk * n * n * bytes_per_px
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+    if os.path.exists(tpath) and log2 == 5 and bd == 8 and not args.sparse:
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "decoded Mpixels/s (fps x W x H) + per-kernel GB/s vs HBM roofline",
+            "value": round(world * nblk * n * n * args.steps / elapsed / 1e6, 1),
+            "unit": "Mpixel/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16 coefficients, u%d pixels, int32 accumulate" % (16 if bd > 8 else 8),
+            "data": "synthetic",
+            "config": {"workload": f"synthetic batched {n}x{n} int16 IDCT+add (BASELINE config 2), {nblk} blocks/GPU, {bd}-bit, "
+                                   f"16384-wide tiled plane, coeffs U[-1024,1023]{' top-left 8x8 only' if args.sparse else ''}, seed 1234",
+                       "blocks_per_gpu": nblk, "block": n, "bit_depth": bd, "parallelism": f"blocks sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": L.load_library().ohevc_tu_kernel_name(bd, log2, L.TU_IDCT).decode(),
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(log2, bd)
+            except Exception as e:      # the baseline is reporting only; never let it kill the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

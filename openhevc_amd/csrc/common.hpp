@@ -1,0 +1,91 @@
+// common.hpp -- shared host/device helpers for libohevc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "ohevc_hip.h"
+
+namespace ohevc {
+
+// ---- error plumbing: every HIP failure is recorded (thread-local) and surfaces as OHEVC_ERR_HIP
+void set_error(const char *fmt, ...);
+
+#define OHEVC_HIP_TRY(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            ::ohevc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),   \
+                               __FILE__, __LINE__);                                      \
+            return OHEVC_ERR_HIP;                                                        \
+        }                                                                                \
+    } while (0)
+
+#define OHEVC_REQUIRE(cond, msg)                                                         \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            ::ohevc::set_error("bad argument: %s (%s)", msg, #cond);                     \
+            return OHEVC_ERR_ARG;                                                        \
+        }                                                                                \
+    } while (0)
+
+// Kernel-side view of the up-to-3 planes of one picture (passed by value as a kernel argument).
+struct PlaneSet {
+    unsigned char *data[3];
+    int            stride[3];   // bytes
+    int            width[3];
+    int            height[3];
+};
+
+inline int make_plane_set(const ohevc_plane planes[3], PlaneSet &ps)
+{
+    for (int i = 0; i < 3; i++) {
+        ps.data[i]   = static_cast<unsigned char *>(planes[i].data);
+        ps.stride[i] = planes[i].stride;
+        ps.width[i]  = planes[i].width;
+        ps.height[i] = planes[i].height;
+        if (planes[i].data) {
+            OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(planes[i].data) & 15) == 0, "plane data must be 16-byte aligned");
+            OHEVC_REQUIRE((planes[i].stride & 15) == 0 && planes[i].stride > 0, "plane stride must be a positive multiple of 16 bytes");
+        }
+    }
+    return OHEVC_OK;
+}
+
+// ---- device helpers
+typedef short          s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int   u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int   u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename To, typename From>
+__device__ __forceinline__ To bitcast(From v) { return __builtin_bit_cast(To, v); }
+
+// acc + a.lo*b.lo + a.hi*b.hi on int16 halves: v_dot2c_i32_i16 (2 MACs per VALU op; exact, no saturation)
+__device__ __forceinline__ int dot2_i16(unsigned a, unsigned b, int acc)
+{
+    return __builtin_amdgcn_sdot2(bitcast<s16x2>(a), bitcast<s16x2>(b), acc, false);
+}
+
+// {clip_int16(lo), clip_int16(hi)} packed: v_cvt_pk_i16_i32
+__device__ __forceinline__ unsigned sat_pack_i16(int lo, int hi)
+{
+    return bitcast<unsigned>(__builtin_amdgcn_cvt_pk_i16(lo, hi));
+}
+
+// per-half clamp(a + b, 0, maxv) with a, b packed int16 pairs (saturating add: v_pk_add_i16 clamp)
+__device__ __forceinline__ unsigned add_clamp_px2(unsigned a, unsigned b, unsigned maxv2)
+{
+    s16x2 s = __builtin_elementwise_add_sat(bitcast<s16x2>(a), bitcast<s16x2>(b));
+    s16x2 z = { 0, 0 };
+    s = __builtin_elementwise_max(s, z);
+    s = __builtin_elementwise_min(s, bitcast<s16x2>(maxv2));
+    return bitcast<unsigned>(s);
+}
+
+__host__ __device__ constexpr unsigned pack16(int lo, int hi)
+{
+    return (static_cast<unsigned>(lo) & 0xffffu) | ((static_cast<unsigned>(hi) & 0xffffu) << 16);
+}
+
+}  // namespace ohevc

@@ -1,0 +1,417 @@
+// tu_kernels.hip -- residual (TU) family for gfx950: inverse transform + add into the picture plane.
+//
+// Replaces, in batched form, the reference's per-block sequence (hevc_cabac.c:1868-1949)
+//     idct[log2-2] / idct_dc / idct_4x4_luma / transform_skip [+ transform_rdpcm]   (hevcdsp_template.c:114-326)
+//     transform_add[log2-2](dst, coeffs, stride)                                      (hevcdsp_template.c:45-111)
+//
+// Main kernel (8x8 .. 32x32 inverse DCT + add), one 64-lane wavefront per 64/N blocks:
+//   * lane = (block g, index i).  Pass 1: lane owns COLUMN i; pass 2: lane owns ROW i; the epilogue adds
+//     row i of the residual to row i of the prediction and writes it back with 8/16-byte accesses.
+//   * coefficients go HBM -> LDS with 16-byte loads, are re-read as int16 pairs, and every multiply-add runs
+//     on v_dot2c_i32_i16 (2 int16 MACs per VALU op, exact 32-bit accumulate): the partial butterfly's odd
+//     half of each level is a dot product over same-parity inputs, so inputs are kept as packed pairs
+//     (j, j') of the same butterfly level ("pair order", see ord_lo/ord_hi).
+//   * the column->row transpose goes through wave-private LDS: pass 1 scatters int16 results to
+//     [row][slot(i)], pass 2 gathers its row with ds_read_b128 already in pair order.
+//   * both clip_int16 stages are v_cvt_pk_i16_i32 (saturating pack); rounding constants ride in the DC lane of
+//     the butterfly; the final clip_pixel is a saturating packed add + packed max/min.
+// No floating point, no MFMA (int16 x int8 butterflies; the kernel is HBM-bound).
+#include "common.hpp"
+
+namespace ohevc {
+
+// ------------------------------------------------------------------ the HEVC core transform matrix
+// 64*sqrt(2)*cos(m*pi/64) rounded as in the standard; entry (r, c) of the 32-point matrix is
+// +-mag[(2c+1)*r mod 128 folded into one quadrant]  (same numbers as libavcodec/hevcdsp.c:879-944).
+__host__ __device__ constexpr int cos_mag(int m)
+{
+    constexpr int t[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                            61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+    return t[m];
+}
+__host__ __device__ constexpr int dct32(int r, int c)
+{
+    int m = (r * (2 * c + 1)) & 127;
+    return m <= 32 ? cos_mag(m) : m <= 64 ? -cos_mag(64 - m) : m <= 96 ? -cos_mag(m - 64) : cos_mag(128 - m);
+}
+
+// "pair order" of an N-point input vector: N/2 dwords; dword m holds inputs (ord_lo, ord_hi).
+//   first N/4 dwords: the odd inputs (1,3),(5,7),...   (odd half of the outermost butterfly level)
+//   then the same rule applied to the even inputs (halved), down to the 4-point base {(1,3),(0,2)}.
+__host__ __device__ constexpr int ord_lo(int n, int m)
+{
+    return n == 4 ? (m == 0 ? 1 : 0) : m < n / 4 ? 4 * m + 1 : 2 * ord_lo(n / 2, m - n / 4);
+}
+__host__ __device__ constexpr int ord_hi(int n, int m)
+{
+    return n == 4 ? (m == 0 ? 3 : 2) : m < n / 4 ? 4 * m + 3 : 2 * ord_hi(n / 2, m - n / 4);
+}
+// inverse map: int16 slot (2*dword + half) of input index i
+__host__ __device__ constexpr int slot_of(int n, int i)
+{
+    if ((i & (n / 2 - 1)) == 0) return n - 2 + (i ? 1 : 0);
+    int t = 0;
+    while (!((i >> t) & 1)) t++;
+    return n - (n >> t) + (i >> (t + 1));
+}
+template <int N> constexpr bool pair_order_ok()
+{
+    for (int m = 0; m < N / 2; m++)
+        if (slot_of(N, ord_lo(N, m)) != 2 * m || slot_of(N, ord_hi(N, m)) != 2 * m + 1) return false;
+    return true;
+}
+static_assert(pair_order_ok<4>() && pair_order_ok<8>() && pair_order_ok<16>() && pair_order_ok<32>(), "pair order");
+
+// compile-time tables (indexing them with an unrolled loop counter folds to an immediate)
+template <int N> struct PairTab {
+    int lo[N / 2], hi[N / 2];
+    constexpr PairTab() : lo{}, hi{}
+    {
+        for (int m = 0; m < N / 2; m++) { lo[m] = ord_lo(N, m); hi[m] = ord_hi(N, m); }
+    }
+};
+
+__device__ __forceinline__ int slot_of_rt(int n, int i)
+{
+    if ((i & (n / 2 - 1)) == 0) return n - 2 + (i ? 1 : 0);
+    int t = __builtin_ctz(i);
+    return n - (n >> t) + (i >> (t + 1));
+}
+
+// M-point inverse transform of inputs in pair order -> out[0..M-1] (natural order), exact int32.
+// out[k] = sum_j T_M[j][k] * x[j] + init, with T_M[j][k] = dct32(j * 32/M, k); evaluated as the even/odd
+// partial butterfly of hevcdsp_template.c:210-262 (any evaluation order is bit-identical: no overflow).
+template <int M> struct Idct1D {
+    static __device__ __forceinline__ void run(const unsigned *p, int *out, int init)
+    {
+        int e[M / 2];
+        Idct1D<M / 2>::run(p + M / 4, e, init);
+#pragma unroll
+        for (int i = 0; i < M / 2; i++) {
+            int o = 0;
+#pragma unroll
+            for (int m = 0; m < M / 4; m++)
+                o = dot2_i16(p[m], pack16(dct32((4 * m + 1) * (32 / M), i), dct32((4 * m + 3) * (32 / M), i)), o);
+            out[i]         = e[i] + o;
+            out[M - 1 - i] = e[i] - o;
+        }
+    }
+};
+template <> struct Idct1D<2> {     // inputs (x0, x_{M/2}) of the enclosing 4-point level: the "+-64" lane
+    static __device__ __forceinline__ void run(const unsigned *p, int *out, int init)
+    {
+        out[0] = dot2_i16(p[0], pack16(64, 64), init);
+        out[1] = dot2_i16(p[0], pack16(64, -64), init);
+    }
+};
+
+template <int LOG2N> struct TuLayout {
+    static constexpr int N   = 1 << LOG2N;
+    static constexpr int BPW = 64 / N;                                  // blocks per wavefront
+    // wave-private LDS tile per block: N rows of N int16, row stride padded so that the 16 rows a
+    // ds_read_b128 lane group touches fall into 16 different 16-byte bank slots; block bases skewed so
+    // that blocks sharing a 32-lane half do not collide on the int16 column accesses.
+    static constexpr int RS  = LOG2N == 5 ? 80 : LOG2N == 4 ? 48 : 16;  // bytes
+    static constexpr int BLK = LOG2N == 5 ? 32 * 80 : LOG2N == 4 ? 16 * 48 + 32 : 8 * 16 + 16;
+    static constexpr int WAVE_BYTES = BPW * BLK;
+};
+
+// lane-varying plane select without taking the address of the by-value kernel argument (keeps it out of scratch)
+#define PLANE_PTR(ps, idx)    ((idx) == 0 ? (ps).data[0] : (idx) == 1 ? (ps).data[1] : (ps).data[2])
+#define PLANE_STRIDE(ps, idx) ((idx) == 0 ? (ps).stride[0] : (idx) == 1 ? (ps).stride[1] : (ps).stride[2])
+
+// res[0..N-1] (already >> shift, any int32) + prediction row -> clipped pixels, in place in HBM.
+// clip_pixel(pred + clip_int16(r)) is what transform_add computes; sat_pack_i16 is the clip_int16.
+template <int N, typename Pixel>
+__device__ __forceinline__ void add_row_store(unsigned char *row, const int *res, int bit_depth, bool valid)
+{
+    constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
+    constexpr int VEC   = ROWDW >= 4 ? 4 : ROWDW;                        // dwords per access (4, 2 or 1)
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+    unsigned px[ROWDW];
+    if (valid) {
+#pragma unroll
+        for (int v = 0; v < ROWDW / VEC; v++) {
+            if constexpr (VEC == 4) {
+                u32x4 t = *reinterpret_cast<const u32x4 *>(row + 16 * v);
+                px[4 * v] = t.x; px[4 * v + 1] = t.y; px[4 * v + 2] = t.z; px[4 * v + 3] = t.w;
+            } else if constexpr (VEC == 2) {
+                u32x2 t = *reinterpret_cast<const u32x2 *>(row + 8 * v);
+                px[2 * v] = t.x; px[2 * v + 1] = t.y;
+            } else {
+                px[v] = *reinterpret_cast<const unsigned *>(row + 4 * v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < ROWDW; d++) px[d] = 0;
+    }
+#pragma unroll
+    for (int d = 0; d < ROWDW; d++) {
+        if constexpr (sizeof(Pixel) == 1) {
+            unsigned u01 = __builtin_amdgcn_perm(0u, px[d], 0x0c010c00u);
+            unsigned u23 = __builtin_amdgcn_perm(0u, px[d], 0x0c030c02u);
+            unsigned s01 = add_clamp_px2(sat_pack_i16(res[4 * d], res[4 * d + 1]), u01, max2);
+            unsigned s23 = add_clamp_px2(sat_pack_i16(res[4 * d + 2], res[4 * d + 3]), u23, max2);
+            px[d] = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+        } else {
+            px[d] = add_clamp_px2(sat_pack_i16(res[2 * d], res[2 * d + 1]), px[d], max2);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int v = 0; v < ROWDW / VEC; v++) {
+            if constexpr (VEC == 4) {
+                u32x4 t = { px[4 * v], px[4 * v + 1], px[4 * v + 2], px[4 * v + 3] };
+                *reinterpret_cast<u32x4 *>(row + 16 * v) = t;
+            } else if constexpr (VEC == 2) {
+                u32x2 t = { px[2 * v], px[2 * v + 1] };
+                *reinterpret_cast<u32x2 *>(row + 8 * v) = t;
+            } else {
+                *reinterpret_cast<unsigned *>(row + 4 * v) = px[v];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 8x8 / 16x16 / 32x32 IDCT + add
+template <int LOG2N, typename Pixel>
+__global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
+                                                          int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    using L = TuLayout<LOG2N>;
+    constexpr int N = L::N, RS = L::RS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * L::WAVE_BYTES];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / N, i = lane % N;
+    const int job0 = (blockIdx.x * 4 + wave) * L::BPW;
+    if (job0 >= njobs) return;                              // wave-uniform; no workgroup barrier is used below
+    const bool valid = job0 + g < njobs;
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[valid ? job0 + g : njobs - 1];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
+    const unsigned coeff_off = jraw.z;
+    unsigned char *blk = lds + wave * L::WAVE_BYTES + g * L::BLK;
+
+    // ---- A. coefficients HBM -> LDS (row-major, padded rows), 16 bytes per lane per access
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + coeff_off);
+#pragma unroll
+    for (int q = 0; q < N / 8; q++) {
+        const int c = q * N + i;                            // 16-byte chunk index inside the block
+        const u32x4 v = src[c];
+        *reinterpret_cast<u32x4 *>(blk + (c / (N / 8)) * RS + (c % (N / 8)) * 16) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- B. pass 1: column i, inputs gathered as same-level pairs
+    unsigned p[N / 2];
+    {
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(blk) + i;
+        constexpr PairTab<N> pt{};
+#pragma unroll
+        for (int m = 0; m < N / 2; m++)
+            p[m] = (unsigned)col[pt.lo[m] * (RS / 2)] | ((unsigned)col[pt.hi[m] * (RS / 2)] << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int t[N];
+    Idct1D<N>::run(p, t, 64);                               // + (1 << 6), then >> 7, clip_int16
+    {
+        unsigned short *dst = reinterpret_cast<unsigned short *>(blk) + slot_of_rt(N, i);
+#pragma unroll
+        for (int r = 0; r < N; r += 2) {
+            const unsigned pk = sat_pack_i16(t[r] >> 7, t[r + 1] >> 7);
+            dst[r * (RS / 2)]       = (unsigned short)(pk & 0xffffu);
+            dst[(r + 1) * (RS / 2)] = (unsigned short)(pk >> 16);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- C. pass 2: row i, already in pair order in LDS
+    {
+        const u32x4 *rowp = reinterpret_cast<const u32x4 *>(blk + i * RS);
+#pragma unroll
+        for (int q = 0; q < N / 8; q++) {
+            const u32x4 v = rowp[q];
+            p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+        }
+    }
+    const int shift2 = 20 - bit_depth;
+    Idct1D<N>::run(p, t, 1 << (shift2 - 1));
+#pragma unroll
+    for (int k = 0; k < N; k++) t[k] >>= shift2;
+
+    // ---- D. residual row + prediction row -> plane
+    unsigned char *row = PLANE_PTR(planes, jplane) + (size_t)(jy + i) * PLANE_STRIDE(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    add_row_store<N, Pixel>(row, t, bit_depth, valid);
+}
+
+// ------------------------------------------------------------------ 4x4 IDCT / DST: one lane per block
+template <typename Pixel, bool DST>
+__global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                                     const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    const int job = blockIdx.x * 256 + threadIdx.x;
+    if (job >= njobs) return;
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + jraw.z);
+    const u32x4 a = src[0], b = src[1];
+    const unsigned raw[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+    int c[4][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        c[k / 2][(k % 2) * 2]     = (int)(short)(raw[k] & 0xffffu);
+        c[k / 2][(k % 2) * 2 + 1] = (int)raw[k] >> 16;
+    }
+    auto tr = [](int x0, int x1, int x2, int x3, int add, int &y0, int &y1, int &y2, int &y3) {
+        if constexpr (DST) {        // inverse DST-VII, hevcdsp_template.c:170-203
+            y0 = 29 * x0 + 74 * x1 + 84 * x2 + 55 * x3 + add;
+            y1 = 55 * x0 + 74 * x1 - 29 * x2 - 84 * x3 + add;
+            y2 = 74 * (x0 - x2 + x3) + add;
+            y3 = 84 * x0 - 74 * x1 + 55 * x2 - 29 * x3 + add;
+        } else {                    // TR_4, hevcdsp_template.c:210-222
+            const int e0 = 64 * (x0 + x2) + add, e1 = 64 * (x0 - x2) + add;
+            const int o0 = 83 * x1 + 36 * x3, o1 = 36 * x1 - 83 * x3;
+            y0 = e0 + o0; y1 = e1 + o1; y2 = e1 - o1; y3 = e0 - o0;
+        }
+    };
+    auto clip16 = [](int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {   // columns
+        int y0, y1, y2, y3;
+        tr(c[0][i], c[1][i], c[2][i], c[3][i], 64, y0, y1, y2, y3);
+        c[0][i] = clip16(y0 >> 7); c[1][i] = clip16(y1 >> 7); c[2][i] = clip16(y2 >> 7); c[3][i] = clip16(y3 >> 7);
+    }
+    const int shift2 = 20 - bit_depth;
+    unsigned char *base = PLANE_PTR(planes, jplane) + (size_t)jy * PLANE_STRIDE(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    const int stride = PLANE_STRIDE(planes, jplane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {   // rows
+        int res[4];
+        tr(c[r][0], c[r][1], c[r][2], c[r][3], 1 << (shift2 - 1), res[0], res[1], res[2], res[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) res[k] >>= shift2;
+        add_row_store<4, Pixel>(base + (size_t)r * stride, res, bit_depth, true);
+    }
+}
+
+// ------------------------------------------------------------------ DC-only / transform-skip / bypass (+rdpcm): one lane per row
+// idct_dc :303-316, transform_skip :139-163, transform_rdpcm :114-136 (int16 wrap-around of the in-place reference
+// is reproduced by truncating to int16 after the modular prefix sum).
+template <int LOG2N, typename Pixel>
+__global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                                      const int16_t *__restrict__ coeffs, int bit_depth, int kind)
+{
+    constexpr int N = 1 << LOG2N;
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int job = tid >> LOG2N, r = tid & (N - 1);
+    if (job >= njobs) return;
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
+    int res[N];
+    if (kind == OHEVC_TU_DC) {
+        const int dc = (int)jraw.y >> 16, shift = 14 - bit_depth, add = 1 << (shift - 1);
+        const int v = (((dc + 1) >> 1) + add) >> shift;
+#pragma unroll
+        for (int x = 0; x < N; x++) res[x] = v;
+    } else {
+        const int16_t *blk = coeffs + jraw.z;
+        const bool skip = kind == OHEVC_TU_SKIP || kind == OHEVC_TU_SKIP_RDPCM_H || kind == OHEVC_TU_SKIP_RDPCM_V;
+        const bool vert = kind == OHEVC_TU_SKIP_RDPCM_V || kind == OHEVC_TU_BYPASS_RDPCM_V;
+        const bool horz = kind == OHEVC_TU_SKIP_RDPCM_H || kind == OHEVC_TU_BYPASS_RDPCM_H;
+        const int shift = 15 - bit_depth - LOG2N;
+#pragma unroll
+        for (int x = 0; x < N; x++) res[x] = 0;
+        const int first = vert ? 0 : r;                    // vertical rdpcm: sum rows 0..r
+        for (int yy = first; yy <= r; yy++) {
+            const u32x2 *rowp = reinterpret_cast<const u32x2 *>(blk + yy * N);
+#pragma unroll
+            for (int q = 0; q < N / 4; q++) {
+                const u32x2 v = rowp[q];
+                int e[4] = { (int)(short)(v.x & 0xffffu), (int)v.x >> 16, (int)(short)(v.y & 0xffffu), (int)v.y >> 16 };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int s = e[k];
+                    if (skip) {
+                        if (shift > 0) s = (s + (1 << (shift - 1))) >> shift;
+                        else           s = (int)(short)(s << -shift);
+                    }
+                    res[4 * q + k] += s;
+                }
+            }
+        }
+        if (horz) {
+#pragma unroll
+            for (int x = 1; x < N; x++) res[x] += res[x - 1];
+        }
+#pragma unroll
+        for (int x = 0; x < N; x++) res[x] = (int)(short)res[x];
+    }
+    unsigned char *row = PLANE_PTR(planes, jplane) + (size_t)(jy + r) * PLANE_STRIDE(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    add_row_store<N, Pixel>(row, res, bit_depth, true);
+}
+
+// ------------------------------------------------------------------ launcher
+template <typename Pixel>
+static int launch_tu(const PlaneSet &ps, int bit_depth, int log2, int kind, const ohevc_tu_job *jobs, int njobs,
+                     const int16_t *coeffs, hipStream_t st)
+{
+    if (kind == OHEVC_TU_IDCT && log2 >= 3) {
+        const int bpw = 64 >> log2, per_wg = 4 * bpw, grid = (njobs + per_wg - 1) / per_wg;
+        switch (log2) {
+        case 3: hipLaunchKernelGGL((tu_idct_add_kernel<3, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 4: hipLaunchKernelGGL((tu_idct_add_kernel<4, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 5: hipLaunchKernelGGL((tu_idct_add_kernel<5, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        }
+    } else if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) {
+        const int grid = (njobs + 255) / 256;
+        if (kind == OHEVC_TU_DST4)
+            hipLaunchKernelGGL((tu_4x4_kernel<Pixel, true>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        else
+            hipLaunchKernelGGL((tu_4x4_kernel<Pixel, false>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+    } else {
+        const long long threads = (long long)njobs << log2;
+        const int grid = (int)((threads + 255) / 256);
+        switch (log2) {
+        case 2: hipLaunchKernelGGL((tu_rows_kernel<2, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth, kind); break;
+        case 3: hipLaunchKernelGGL((tu_rows_kernel<3, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth, kind); break;
+        case 4: hipLaunchKernelGGL((tu_rows_kernel<4, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth, kind); break;
+        case 5: hipLaunchKernelGGL((tu_rows_kernel<5, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth, kind); break;
+        }
+    }
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
+}  // namespace ohevc
+
+extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, int log2_size, int kind,
+                                  const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(planes != nullptr, "planes");
+    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(log2_size >= 2 && log2_size <= 5, "log2_size must be 2..5");
+    OHEVC_REQUIRE(kind >= 0 && kind < OHEVC_TU_NKINDS, "unknown residual kind");
+    OHEVC_REQUIRE(kind != OHEVC_TU_DST4 || log2_size == 2, "DST is 4x4 only");
+    OHEVC_REQUIRE(njobs >= 0, "njobs");
+    if (njobs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr, "jobs");
+    OHEVC_REQUIRE(kind == OHEVC_TU_DC || coeffs != nullptr, "coeffs");
+    OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
+    OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "coeffs must be 16-byte aligned");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps);
+    if (rc != OHEVC_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return bit_depth == 8 ? launch_tu<uint8_t>(ps, bit_depth, log2_size, kind, jobs, njobs, coeffs, st)
+                          : launch_tu<uint16_t>(ps, bit_depth, log2_size, kind, jobs, njobs, coeffs, st);
+}
+
+extern "C" const char *ohevc_tu_kernel_name(int bit_depth, int log2_size, int kind)
+{
+    if (kind == OHEVC_TU_IDCT && log2_size >= 3) return "tu_idct_add_kernel";
+    if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) return "tu_4x4_kernel";
+    (void)bit_depth;
+    return "tu_rows_kernel";
+}

@@ -1,0 +1,57 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads without a GPU and exports every symbol
+include/*.h declares; job records have the documented layout.  No compute calls here."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+
+from openhevc_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(ohevc_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = L.load_library()
+    decl = declared_functions()
+    assert decl, "no declarations found"
+    for name in sorted(decl):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported by libohevc_hip.so"
+    assert set(L.EXPORTED_SYMBOLS) <= decl
+
+
+def test_job_record_layouts():
+    assert L.TU_JOB.itemsize == 16
+    assert [L.TU_JOB.fields[k][1] for k in ("x", "y", "plane", "dc", "coeff_off")] == [0, 2, 4, 6, 8]
+    assert C.sizeof(L.Plane) == 24
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = L.load_library()
+    planes = (L.Plane * 3)()
+    # bad bit depth / size / kind are rejected before any HIP call
+    assert lib.ohevc_dev_tu_batch(planes, 7, 5, 0, None, 1, None, None) == L.ERR_ARG
+    assert lib.ohevc_dev_tu_batch(planes, 8, 6, 0, None, 1, None, None) == L.ERR_ARG
+    assert lib.ohevc_dev_tu_batch(planes, 8, 5, 99, None, 1, None, None) == L.ERR_ARG
+    assert lib.ohevc_dev_tu_batch(planes, 8, 3, L.TU_DST4, None, 1, None, None) == L.ERR_ARG
+    assert b"bad argument" in lib.ohevc_last_error()
+    # an empty batch is a no-op
+    assert lib.ohevc_dev_tu_batch(planes, 8, 5, 0, None, 0, None, None) == L.OK
+    assert lib.ohevc_version().startswith(b"ohevc_hip")
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must never route through oracle/ (or any CPU fallback)."""
+    for path in glob.glob(os.path.join(ROOT, "openhevc_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+            text = open(path, errors="ignore").read()
+            assert "pyoracle" not in text and "liboracle" not in text and "hevcref" not in text, path

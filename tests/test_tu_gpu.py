@@ -1,0 +1,128 @@
+"""-m gpu parity tests of the residual (TU) family: HIP path through the C ABI vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+KINDS_ANY = [po.TU_DC, po.TU_SKIP, po.TU_SKIP_RDPCM_H, po.TU_SKIP_RDPCM_V, po.TU_BYPASS, po.TU_BYPASS_RDPCM_H, po.TU_BYPASS_RDPCM_V]
+
+
+def grid_xy(nblk, n, per_row, x0=0, y0=0):
+    return np.array([[x0 + (i % per_row) * n, y0 + (i // per_row) * n] for i in range(nblk)], np.int32)
+
+
+def check_batch(oracle, bd, log2, kind, nblk, amp, seed, per_row=7):
+    import gpu_util as G
+    rng = np.random.default_rng(seed)
+    n = 1 << log2
+    rows = (nblk + per_row - 1) // per_row
+    W = ((per_row * n + 16 + 15) // 16) * 16
+    plane = rng.integers(0, 1 << bd, size=(max(rows, 1) * n + 4, W)).astype(G.pixdt(bd))
+    xy = grid_xy(nblk, n, per_row, x0=0, y0=0)
+    coeffs = rng.integers(-amp, amp, size=(nblk, n, n)).astype(np.int16)
+    dcs = coeffs[:, 0, 0].copy() if kind == po.TU_DC else None
+    jobs = G.make_tu_jobs(xy, n, dcs=dcs)
+    want = oracle.tu_batch(bd, kind, log2, coeffs, plane.copy(), xy) if nblk else plane.copy()
+    got = G.run_tu(bd, log2, kind, [plane], jobs, coeffs)[0]
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"bd={bd} log2={log2} kind={kind} nblk={nblk}: {len(bad)} mismatching samples, first at {bad[:4].tolist()}"
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("log2", [2, 3, 4, 5])
+def test_idct_add_bit_exact(oracle, bd, log2):
+    for nblk, amp in [(1, 1024), (3, 1 << 15), (64, 1024), (257, 4096), (1000, 200)]:
+        check_batch(oracle, bd, log2, po.TU_IDCT, nblk, amp, seed=bd * 100 + log2 * 10 + nblk)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_idct_extreme_coefficients(oracle, bd):
+    """All-max / all-min / alternating coefficients drive both clip_int16 stages and the pixel clip."""
+    import gpu_util as G
+    for log2 in (2, 3, 4, 5):
+        n = 1 << log2
+        pats = [np.full((n, n), 32767), np.full((n, n), -32768), np.where(np.indices((n, n)).sum(0) % 2, 32767, -32768),
+                np.zeros((n, n))]
+        pats[3][0, 0] = 32767
+        coeffs = np.stack(pats).astype(np.int16)
+        plane = np.random.default_rng(3).integers(0, 1 << bd, size=(n, 4 * n)).astype(G.pixdt(bd))
+        xy = grid_xy(4, n, 4)
+        want = oracle.tu_batch(bd, po.TU_IDCT, log2, coeffs, plane.copy(), xy)
+        got = G.run_tu(bd, log2, po.TU_IDCT, [plane], G.make_tu_jobs(xy, n), coeffs)[0]
+        assert np.array_equal(got, want), (bd, log2)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_dst_and_other_kinds(oracle, bd):
+    check_batch(oracle, bd, 2, po.TU_DST4, 333, 1 << 15, seed=bd)
+    check_batch(oracle, bd, 2, po.TU_DST4, 5, 500, seed=bd + 1)
+    for log2 in (2, 3, 4, 5):
+        for kind in KINDS_ANY:
+            check_batch(oracle, bd, log2, kind, 37, 1 << 15, seed=bd * 7 + log2 + kind)
+            check_batch(oracle, bd, log2, kind, 130, 300, seed=bd * 7 + log2 + kind + 1)
+
+
+def test_empty_batch_and_three_planes(oracle):
+    import gpu_util as G
+    check_batch(oracle, 8, 5, po.TU_IDCT, 0, 100, seed=1)
+    rng = np.random.default_rng(9)
+    n, bd = 16, 10
+    planes = [rng.integers(0, 1 << bd, size=(4 * n, 8 * n)).astype(np.uint16) for _ in range(3)]
+    xy = grid_xy(30, n, 8)
+    pl = rng.integers(0, 3, size=30).astype(np.uint8)
+    coeffs = rng.integers(-2048, 2048, size=(30, n, n)).astype(np.int16)
+    want = [p.copy() for p in planes]
+    for i in range(30):
+        oracle.tu_batch(bd, po.TU_IDCT, 4, coeffs[i:i + 1], want[pl[i]], xy[i:i + 1])
+    got = G.run_tu(bd, 4, po.TU_IDCT, planes, G.make_tu_jobs(xy, n, planes=pl), coeffs)
+    for i in range(3):
+        assert np.array_equal(got[i], want[i]), i
+
+
+def test_sparse_coefficients_match_limited_reference_transform(oracle):
+    """Decoder-legal input (zeros beyond col_limit): the GPU's full transform equals the reference's limited one."""
+    import gpu_util as G
+    rng = np.random.default_rng(77)
+    for log2 in (3, 4, 5):
+        n = 1 << log2
+        for col_limit in (4, 8, 12, 24):
+            if col_limit > n:
+                continue
+            yy, xx = np.mgrid[0:n, 0:n]
+            coeffs = np.where(xx + yy <= col_limit - 4, rng.integers(-3000, 3000, size=(20, n, n)), 0).astype(np.int16)
+            plane = rng.integers(0, 256, size=(4 * n, 5 * n + (16 - (5 * n) % 16) % 16)).astype(np.uint8)
+            xy = grid_xy(20, n, 5)
+            want = oracle.tu_batch(8, po.TU_IDCT, log2, coeffs, plane.copy(), xy, col_limit=col_limit)
+            got = G.run_tu(8, log2, po.TU_IDCT, [plane], G.make_tu_jobs(xy, n), coeffs)[0]
+            assert np.array_equal(got, want), (log2, col_limit)
+
+
+def test_full_size_batch_sampled_against_oracle(oracle):
+    """BASELINE config 2 scale (2^20 blocks of 32x32 on a 16384-wide tiled plane): blocks are independent, so a
+    random sample of blocks is compared with the oracle and a zero-coefficient region must stay untouched."""
+    import torch
+    import gpu_util as G
+    from openhevc_amd import lib as L
+    n, nblk, per_row = 32, 1 << 20, 512
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    plane = torch.randint(0, 256, (nblk // per_row * n, per_row * n), dtype=torch.uint8, device="cuda", generator=g)
+    coeffs = torch.randint(-1024, 1024, (nblk, n, n), dtype=torch.int16, device="cuda", generator=g)
+    coeffs[1000:2000] = 0
+    before = plane.clone()
+    idx = np.arange(nblk)
+    jobs = np.zeros(nblk, L.TU_JOB)
+    jobs["x"], jobs["y"], jobs["coeff_off"] = (idx % per_row) * n, (idx // per_row) * n, idx.astype(np.uint32) * n * n
+    d_jobs = G.to_dev(jobs)
+    L.dev_tu_batch(L.planes_of([plane, None, None]), 8, 5, L.TU_IDCT, d_jobs.data_ptr(), nblk, coeffs.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    sample = np.concatenate([np.random.default_rng(5).choice(nblk, 2048, replace=False), [0, nblk - 1, 1500]])
+    for b in sample:
+        x, y = int(jobs["x"][b]), int(jobs["y"][b])
+        ref_blk = before[y:y + n, x:x + n].cpu().numpy()
+        oracle.tu_batch(8, po.TU_IDCT, 5, coeffs[b].cpu().numpy(), ref_blk, np.array([[0, 0]], np.int32))
+        assert np.array_equal(plane[y:y + n, x:x + n].cpu().numpy(), ref_blk), b
+    ys = slice((1000 // per_row + 1) * n, (2000 // per_row) * n)
+    assert torch.equal(plane[ys], before[ys])
