@@ -1,0 +1,15 @@
+/* ohevc_debug.h -- tuning/A-B switches of libohevc_hip.so.  NOT part of the drop-in boundary: nothing a host
+ * integration needs lives here; bench/profiling scripts use it to compare kernel variants inside one process. */
+#ifndef OHEVC_DEBUG_H
+#define OHEVC_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Selects the variant of the 8x8..32x32 IDCT+add kernel used by ohevc_dev_tu_batch (results are identical):
+ * bit 0: prefetch the prediction row before the transform; bit 1: read coefficients straight from HBM as int16
+ * columns instead of staging 16-byte chunks through LDS.  Returns the previous value; 0 is the shipped default. */
+int ohevc_debug_set_tu_variant(int variant);
+#ifdef __cplusplus
+}
+#endif
+#endif

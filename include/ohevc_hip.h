@@ -74,6 +74,122 @@ typedef struct ohevc_tu_job {           /* 16 bytes */
 int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, int log2_size, int kind,
                        const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, void *stream);
 
+/* ---- 2.2 motion compensation: replaces, per prediction block, the wrappers luma_mc_uni/bi, chroma_mc_uni/bi
+ * (hevc.c:1641-1949) together with the table slots they call:
+ *   put_hevc_{qpel,epel}[idx][!!my][!!mx]            (first half of bi-pred, 14-bit intermediate)   hevcdsp.h:68,81
+ *   put_hevc_{qpel,epel}_{uni,uni_w,bi,bi_w}[..]      hevcdsp.h:70-95
+ * and vdsp.emulated_edge_mc (videodsp_template.c:26-100): reference coordinates are clamped to the picture
+ * inside the kernel instead of copying a padded window.  Bi-prediction reads both references in one job, so the
+ * int16 tmp[64*64] round trip of hevc.c:1761-1764 never touches memory. */
+enum { OHEVC_MC_BI = 1, OHEVC_MC_WEIGHTED = 2 };
+
+typedef struct ohevc_mc_job {           /* 32 bytes */
+    uint16_t x, y;                      /* destination block position in its plane (samples) */
+    uint8_t  w, h;                      /* block size in samples: w in {2,4,6,8,12,16,24,32,48,64}, h <= 64 */
+    uint8_t  plane;                     /* 0: luma, 8-tap quarter-sample; 1,2: chroma, 4-tap eighth-sample */
+    uint8_t  flags;                     /* OHEVC_MC_BI | OHEVC_MC_WEIGHTED */
+    int16_t  sx0, sy0;                  /* integer sample position of the block in reference 0: x_off + (mv.x >> 2)
+                                           (chroma: >> (2 + hshift)); may lie outside the picture */
+    int16_t  sx1, sy1;                  /* same for reference 1 (bi only) */
+    uint8_t  mx0, my0, mx1, my1;        /* fractional phase: luma 0..3, chroma 0..7 (the reference's _mx/_my) */
+    int8_t   ref0, ref1;                /* slot of the reference picture in the `refs` table */
+    uint8_t  denom;                     /* luma/chroma_log2_weight_denom */
+    uint8_t  reserved;
+    int16_t  wx0, wx1;                  /* weights: uni uses (wx0, ox0); bi: wx0/ox0 weight reference 0 (list 0,
+                                           the int16 "src2" of the reference), wx1/ox1 reference 1 */
+    int16_t  ox0, ox1;
+} ohevc_mc_job;
+
+/* dst: the 3 planes of the picture being reconstructed.  refs: DEVICE array of n_ref_slots * 3 ohevc_plane
+ * (slot-major: refs[3 * slot + plane]); width/height there are the picture size used for clamping. */
+int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                       const ohevc_mc_job *jobs, int njobs, void *stream);
+
+/* ---- 2.3 deblocking: replaces hevc_{h,v}_loop_filter_{luma,chroma}[_c] (hevcdsp.h:97-104;
+ * hevcdsp_template.c:1629-1787).  One job = one table call = one 8-sample edge (two 4-line segments).
+ * The caller orders passes like deblocking_filter_CTB (hevc_filter.c:345-581): all vertical edges of a
+ * picture (one launch), then all horizontal edges (another launch). */
+enum { OHEVC_DBK_VERTICAL_EDGE = 1, OHEVC_DBK_NO_P0 = 2, OHEVC_DBK_NO_P1 = 4, OHEVC_DBK_NO_Q0 = 8, OHEVC_DBK_NO_Q1 = 16 };
+
+typedef struct ohevc_dbk_job {          /* 16 bytes */
+    uint16_t x, y;                      /* q0 sample of the first line of the edge */
+    uint8_t  plane;                     /* 0: luma filter; 1,2: chroma filter */
+    uint8_t  flags;                     /* OHEVC_DBK_* */
+    uint8_t  beta;                      /* luma only (pre bit-depth scaling) */
+    uint8_t  reserved0;
+    int16_t  tc[2];                     /* per 4-line segment (pre bit-depth scaling) */
+    uint32_t reserved1;
+} ohevc_dbk_job;
+
+int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_job *jobs, int njobs,
+                            void *stream);
+
+/* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
+ * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy
+ * (the reference's sao_frame), one job per CTB and colour plane. */
+enum { OHEVC_SAO_BAND = 1, OHEVC_SAO_EDGE = 2 };
+
+typedef struct ohevc_sao_job {          /* 32 bytes */
+    uint16_t x, y, w, h;                /* block inside the plane */
+    uint8_t  plane;
+    uint8_t  type;                      /* OHEVC_SAO_BAND / OHEVC_SAO_EDGE */
+    uint8_t  klass;                     /* band: band_position (0..31); edge: eo_class (0..3) */
+    uint8_t  borders;                   /* bit i = borders[i] (left, top, right, bottom picture border) */
+    uint8_t  restore;                   /* 0: sao_edge_filter[0]; 1: sao_edge_filter[1] (uses the edge flags below) */
+    uint8_t  edges;                     /* bit0-1 vert_edge[0..1], bit2-3 horiz_edge[0..1], bit4-7 diag_edge[0..3] */
+    int16_t  offset_val[5];             /* SAOParams.offset_val[c_idx][0..4] (hevc.h:519), already << log2_sao_offset_scale */
+    uint8_t  reserved[8];
+} ohevc_sao_job;
+
+int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
+                        const ohevc_sao_job *jobs, int njobs, void *stream);
+
+/* ---- 2.5 intra prediction: replaces intra_pred[log2-2] (hevcpred.h:32; hevcpred_template.c:30-357) and the
+ * predictors it dispatches to, pred_planar / pred_dc / pred_angular (hevcpred.h:34-40).  Everything the
+ * reference derives from HEVCContext is resolved by the host into the job: availability AFTER the z-scan
+ * qualification (hevcpred_template.c:105-109), the picture-clipped neighbour run lengths (:111-114) and the
+ * smoothing switches (:289-296).  Jobs of one launch must be independent (no job reads samples another writes);
+ * the ctx layer orders dependent TUs into successive launches. */
+enum {
+    OHEVC_INTRA_BOTTOM_LEFT = 1, OHEVC_INTRA_LEFT = 2, OHEVC_INTRA_UP_LEFT = 4, OHEVC_INTRA_UP = 8, OHEVC_INTRA_UP_RIGHT = 16,
+    OHEVC_INTRA_NO_SMOOTHING = 32,      /* intra_smoothing_disabled_flag, or chroma outside 4:4:4 */
+    OHEVC_INTRA_STRONG = 64,            /* sps_strong_intra_smoothing_enable_flag && luma */
+    OHEVC_INTRA_LUMA_EDGE = 128         /* c_idx == 0: DC / mode 10 / mode 26 boundary smoothing applies */
+};
+
+typedef struct ohevc_intra_job {        /* 16 bytes */
+    uint16_t x, y;                      /* block position in its plane (samples) */
+    uint8_t  plane;
+    uint8_t  log2_size;                 /* 2..5 */
+    uint8_t  mode;                      /* 0 planar, 1 DC, 2..34 angular */
+    uint8_t  flags;                     /* OHEVC_INTRA_* */
+    uint8_t  bottom_left_size;          /* valid samples below the block in the left column (0..N) */
+    uint8_t  top_right_size;            /* valid samples right of the block in the top row (0..N) */
+    uint8_t  reserved[6];
+} ohevc_intra_job;
+
+int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
+                          void *stream);
+
+/* Host helper (no GPU work): turn one intra_pred[log2-2](s, x0, y0, c_idx) call of the reference into a job.
+ * Inputs are exactly what the reference's front-end holds at the call site (hevc.c:1214-1215): the block position
+ * in LUMA samples, HEVClc->na.cand_* (ff_hevc_set_neighbour_available, hevc_mvs.c:41-58), the prediction mode
+ * (lc->tu.intra_pred_mode[_c]) and the SPS/PPS geometry.  Performs the z-scan qualification of
+ * hevcpred_template.c:105-109 (CTB-local MinTbAddrZs, hevc_ps.c:2551-2567) and the picture clipping of :111-114.
+ * Returns OHEVC_ERR_ARG for constrained_intra_pred streams (not supported yet). */
+typedef struct ohevc_intra_geom {
+    int32_t width, height;              /* luma samples */
+    int32_t chroma_format_idc;          /* 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */
+    int32_t log2_ctb_size, log2_min_tb_size;
+    int32_t strong_intra_smoothing;     /* sps_strong_intra_smoothing_enable_flag */
+    int32_t intra_smoothing_disabled;   /* spsRext.intra_smoothing_disabled_flag */
+    int32_t constrained_intra_pred;     /* pps->constrained_intra_pred_flag */
+} ohevc_intra_geom;
+
+int ohevc_intra_make_job(const ohevc_intra_geom *geom, int x0, int y0, int log2_size, int c_idx, int mode,
+                         int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right,
+                         ohevc_intra_job *out);
+
 /* ------------------------------------------------------------------ 3. library management */
 const char *ohevc_last_error(void);                 /* text of the last HIP failure on this thread */
 int  ohevc_device_count(void);

@@ -51,6 +51,12 @@ inline int make_plane_set(const ohevc_plane planes[3], PlaneSet &ps)
     return OHEVC_OK;
 }
 
+// lane-varying plane select without taking the address of the by-value kernel argument (keeps it out of scratch)
+#define PLANE_PTR3(ps, idx)    ((idx) == 0 ? (ps).data[0] : (idx) == 1 ? (ps).data[1] : (ps).data[2])
+#define PLANE_STRIDE3(ps, idx) ((idx) == 0 ? (ps).stride[0] : (idx) == 1 ? (ps).stride[1] : (ps).stride[2])
+#define PLANE_WIDTH3(ps, idx)  ((idx) == 0 ? (ps).width[0] : (idx) == 1 ? (ps).width[1] : (ps).width[2])
+#define PLANE_HEIGHT3(ps, idx) ((idx) == 0 ? (ps).height[0] : (idx) == 1 ? (ps).height[1] : (ps).height[2])
+
 // ---- device helpers
 typedef short          s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int   u32x2 __attribute__((ext_vector_type(2)));

@@ -1,0 +1,179 @@
+// filter_kernels.hip -- in-loop filters: deblocking (luma/chroma, both edge directions) and SAO (band/edge).
+//
+// Deblocking replaces hevc_{h,v}_loop_filter_{luma,chroma}[_c] (hevcdsp_template.c:1629-1787): one job = one
+// table call = an 8-sample edge = two 4-line segments; one lane per line, the per-segment decisions (which need
+// lines 0 and 3) are exchanged with quad shuffles.  All edges of one direction are independent (an edge reads
+// 4 and writes at most 3 samples on each side; edges are 8 apart), so a whole picture's vertical edges are one
+// launch and its horizontal edges the next -- the order deblocking_filter_CTB enforces (hevc_filter.c:385-580).
+//
+// SAO replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp_template.c:340-567): reads the deblocked copy
+// (the reference's sao_frame, hevc_filter.c:269-315), writes the picture; one workgroup per CTB plane block.
+#include "common.hpp"
+
+namespace ohevc {
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int iclip(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohevc_dbk_job *__restrict__ jobs, int njobs, int bit_depth)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int job = tid >> 3, line = tid & 7, seg = line >> 2;
+    if (job >= njobs) return;                        // whole 8-lane groups leave together
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff, flags = (jraw.y >> 8) & 0xff;
+    const int beta_in = (jraw.y >> 16) & 0xff;
+    const int tc_in = seg ? (int)jraw.z >> 16 : (int)(short)(jraw.z & 0xffff);
+    const bool vertical = flags & OHEVC_DBK_VERTICAL_EDGE;
+    const bool no_p = flags & (seg ? OHEVC_DBK_NO_P1 : OHEVC_DBK_NO_P0);
+    const bool no_q = flags & (seg ? OHEVC_DBK_NO_Q1 : OHEVC_DBK_NO_Q0);
+    const int stride = PLANE_STRIDE3(planes, jplane);
+    const int xs = vertical ? (int)sizeof(Pixel) : stride;      // step across the edge
+    const int ys = vertical ? stride : (int)sizeof(Pixel);      // step along the edge
+    unsigned char *pix = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
+    const int maxv = (1 << bit_depth) - 1;
+#define LD(i) ((int)*reinterpret_cast<const Pixel *>(pix + (ptrdiff_t)(i) * xs))
+#define ST(i, v) (*reinterpret_cast<Pixel *>(pix + (ptrdiff_t)(i) * xs) = (Pixel)(v))
+    const int tc = tc_in << (bit_depth - 8);
+    if (jplane != 0) {                                // hevc_loop_filter_chroma, :1725-1757
+        if (tc <= 0) return;
+        const int p1 = LD(-2), p0 = LD(-1), q0 = LD(0), q1 = LD(1);
+        const int delta = iclip((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
+        if (!no_p) ST(-1, iclip(p0 + delta, 0, maxv));
+        if (!no_q) ST(0, iclip(q0 - delta, 0, maxv));
+        return;
+    }
+    // hevc_loop_filter_luma, :1629-1723
+    const int beta = beta_in << (bit_depth - 8);
+    const int p3 = LD(-4), p2 = LD(-3), p1 = LD(-2), p0 = LD(-1), q0 = LD(0), q1 = LD(1), q2 = LD(2), q3 = LD(3);
+    const int dp = iabs(p2 - 2 * p1 + p0), dq = iabs(q2 - 2 * q1 + q0);
+    const int flat = iabs(p3 - p0) + iabs(q3 - q0), step = iabs(p0 - q0);
+    const int l0 = (threadIdx.x & 63) & ~3, l3 = l0 | 3;        // lanes holding lines 0 and 3 of this segment
+    const int dp0 = __shfl(dp, l0), dp3 = __shfl(dp, l3), dq0 = __shfl(dq, l0), dq3 = __shfl(dq, l3);
+    const int flat0 = __shfl(flat, l0), flat3 = __shfl(flat, l3), step0 = __shfl(step, l0), step3 = __shfl(step, l3);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    const int tc25 = (tc * 5 + 1) >> 1;
+    const bool strong = flat0 < (beta >> 3) && step0 < tc25 && flat3 < (beta >> 3) && step3 < tc25 &&
+                        (d0 << 1) < (beta >> 2) && (d3 << 1) < (beta >> 2);
+    if (strong) {
+        const int tc2 = tc << 1;
+        if (!no_p) {
+            ST(-1, p0 + iclip(((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0, -tc2, tc2));
+            ST(-2, p1 + iclip(((p2 + p1 + p0 + q0 + 2) >> 2) - p1, -tc2, tc2));
+            ST(-3, p2 + iclip(((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2, -tc2, tc2));
+        }
+        if (!no_q) {
+            ST(0, q0 + iclip(((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0, -tc2, tc2));
+            ST(1, q1 + iclip(((p0 + q0 + q1 + q2 + 2) >> 2) - q1, -tc2, tc2));
+            ST(2, q2 + iclip(((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2, -tc2, tc2));
+        }
+    } else {
+        const int side = (beta + (beta >> 1)) >> 3, tc_2 = tc >> 1;
+        const bool two_p = dp0 + dp3 < side, two_q = dq0 + dq3 < side;
+        int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+        if (iabs(delta) >= 10 * tc) return;
+        delta = iclip(delta, -tc, tc);
+        if (!no_p) ST(-1, iclip(p0 + delta, 0, maxv));
+        if (!no_q) ST(0, iclip(q0 - delta, 0, maxv));
+        if (!no_p && two_p) ST(-2, iclip(p1 + iclip((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2), 0, maxv));
+        if (!no_q && two_q) ST(1, iclip(q1 + iclip((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2), 0, maxv));
+    }
+#undef LD
+#undef ST
+}
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth)
+{
+    const ohevc_sao_job jb = jobs[blockIdx.x];
+    const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
+    const int ov0 = jb.offset_val[0], ov1 = jb.offset_val[1], ov2 = jb.offset_val[2], ov3 = jb.offset_val[3], ov4 = jb.offset_val[4];
+    const int sstride = PLANE_STRIDE3(src, jb.plane), dstride = PLANE_STRIDE3(dst, jb.plane);
+    const unsigned char *sbase = PLANE_PTR3(src, jb.plane) + (size_t)jb.y * sstride + (size_t)jb.x * sizeof(Pixel);
+    unsigned char *dbase = PLANE_PTR3(dst, jb.plane) + (size_t)jb.y * dstride + (size_t)jb.x * sizeof(Pixel);
+#define SRC(x, y) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(y) * sstride + (ptrdiff_t)(x) * (int)sizeof(Pixel)))
+    if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
+        const int shift = bit_depth - 5;
+        for (int idx = threadIdx.x; idx < w * h; idx += 256) {
+            const int y = idx / w, x = idx - y * w;
+            const int c = SRC(x, y), k = ((c >> shift) - jb.klass) & 31;
+            const int off = k == 0 ? ov1 : k == 1 ? ov2 : k == 2 ? ov3 : k == 3 ? ov4 : 0;
+            *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)iclip(c + off, 0, maxv);
+        }
+        return;
+    }
+    // sao_edge_filter_{0,1}, :372-567
+    const int dxa = eo == 1 ? 0 : eo == 3 ? 1 : -1, dya = eo == 0 ? 0 : -1;       // first neighbour; second is its mirror
+    const bool b0 = jb.borders & 1, b1 = jb.borders & 2, b2 = jb.borders & 4, b3 = jb.borders & 8;
+    const int init_x = (eo != 1 && b0) ? 1 : 0;
+    const int w2 = w - ((eo != 1 && b2) ? 1 : 0), h2 = h - ((eo != 0 && b3) ? 1 : 0);
+    const bool ve0 = jb.edges & 1, ve1 = jb.edges & 2, he0 = jb.edges & 4, he1 = jb.edges & 8;
+    const bool de0 = jb.edges & 16, de1 = jb.edges & 32, de2 = jb.edges & 64, de3 = jb.edges & 128;
+    const int sul = !de0 && eo == 2 && !b0 && !b1, sur = !de1 && eo == 3 && !b1 && !b2;
+    const int slr = !de2 && eo == 2 && !b2 && !b3, sll = !de3 && eo == 3 && !b0 && !b3;
+    for (int idx = threadIdx.x; idx < w * h; idx += 256) {
+        const int y = idx / w, x = idx - y * w;
+        const int c = SRC(x, y), a = SRC(x + dxa, y + dya), b = SRC(x - dxa, y - dya);
+        const int s = (c > a) - (c < a) + (c > b) - (c < b);                      // -2..2
+        int off = s == -2 ? ov1 : s == -1 ? ov2 : s == 0 ? ov0 : s == 1 ? ov3 : ov4;  // offset_val[edge_idx[2 + s]], edge_idx = {1,2,0,3,4}
+        const bool on_border = (eo != 1 && ((b0 && x == 0) || (b2 && x == w - 1))) ||
+                               (eo != 0 && x >= init_x && x < w2 && ((b1 && y == 0) || (b3 && y == h - 1)));
+        if (on_border) off = ov0;
+        int v = iclip(c + off, 0, maxv);
+        if (jb.restore) {
+            const bool r = (ve0 && eo != 1 && x == 0 && y >= sul && y < h2 - sll) ||
+                           (ve1 && eo != 1 && x == w2 - 1 && y >= sur && y < h2 - slr) ||
+                           (he0 && eo != 0 && y == 0 && x >= init_x + sul && x < w2 - sur) ||
+                           (he1 && eo != 0 && y == h2 - 1 && x >= init_x + sll && x < w2 - slr) ||
+                           (de0 && eo == 2 && x == 0 && y == 0) || (de1 && eo == 3 && x == w2 - 1 && y == 0) ||
+                           (de2 && eo == 2 && x == w2 - 1 && y == h2 - 1) || (de3 && eo == 3 && x == 0 && y == h2 - 1);
+            if (r) v = c;
+        }
+        *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)v;
+    }
+#undef SRC
+}
+
+}  // namespace ohevc
+
+extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_job *jobs, int njobs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(planes != nullptr, "planes");
+    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(njobs >= 0, "njobs");
+    if (njobs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps);
+    if (rc != OHEVC_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = (int)(((long long)njobs * 8 + 255) / 256);
+    if (bit_depth == 8) hipLaunchKernelGGL((deblock_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, bit_depth);
+    else                hipLaunchKernelGGL((deblock_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, bit_depth);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
+                                   const ohevc_sao_job *jobs, int njobs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(dst != nullptr && src != nullptr, "planes");
+    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(njobs >= 0, "njobs");
+    if (njobs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
+    PlaneSet pd, psrc;
+    int rc = make_plane_set(dst, pd);
+    if (rc != OHEVC_OK) return rc;
+    rc = make_plane_set(src, psrc);
+    if (rc != OHEVC_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, jobs, njobs, bit_depth);
+    else                hipLaunchKernelGGL((sao_kernel<uint16_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, jobs, njobs, bit_depth);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}

@@ -116,19 +116,11 @@ template <int LOG2N> struct TuLayout {
     static constexpr int WAVE_BYTES = BPW * BLK;
 };
 
-// lane-varying plane select without taking the address of the by-value kernel argument (keeps it out of scratch)
-#define PLANE_PTR(ps, idx)    ((idx) == 0 ? (ps).data[0] : (idx) == 1 ? (ps).data[1] : (ps).data[2])
-#define PLANE_STRIDE(ps, idx) ((idx) == 0 ? (ps).stride[0] : (idx) == 1 ? (ps).stride[1] : (ps).stride[2])
-
-// res[0..N-1] (already >> shift, any int32) + prediction row -> clipped pixels, in place in HBM.
-// clip_pixel(pred + clip_int16(r)) is what transform_add computes; sat_pack_i16 is the clip_int16.
 template <int N, typename Pixel>
-__device__ __forceinline__ void add_row_store(unsigned char *row, const int *res, int bit_depth, bool valid)
+__device__ __forceinline__ void load_row(const unsigned char *row, unsigned *px, bool valid)
 {
     constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
     constexpr int VEC   = ROWDW >= 4 ? 4 : ROWDW;                        // dwords per access (4, 2 or 1)
-    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
-    unsigned px[ROWDW];
     if (valid) {
 #pragma unroll
         for (int v = 0; v < ROWDW / VEC; v++) {
@@ -146,6 +138,14 @@ __device__ __forceinline__ void add_row_store(unsigned char *row, const int *res
 #pragma unroll
         for (int d = 0; d < ROWDW; d++) px[d] = 0;
     }
+}
+
+template <int N, typename Pixel>
+__device__ __forceinline__ void finish_row(unsigned char *row, unsigned *px, const int *res, int bit_depth, bool valid)
+{
+    constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
+    constexpr int VEC   = ROWDW >= 4 ? 4 : ROWDW;
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
 #pragma unroll
     for (int d = 0; d < ROWDW; d++) {
         if constexpr (sizeof(Pixel) == 1) {
@@ -174,8 +174,20 @@ __device__ __forceinline__ void add_row_store(unsigned char *row, const int *res
     }
 }
 
+// res[0..N-1] (already >> shift, any int32) + prediction row -> clipped pixels, in place in HBM.
+// clip_pixel(pred + clip_int16(r)) is what transform_add computes; sat_pack_i16 is the clip_int16.
+template <int N, typename Pixel>
+__device__ __forceinline__ void add_row_store(unsigned char *row, const int *res, int bit_depth, bool valid)
+{
+    unsigned px[N * (int)sizeof(Pixel) / 4];
+    load_row<N, Pixel>(row, px, valid);
+    finish_row<N, Pixel>(row, px, res, bit_depth, valid);
+}
+
 // ------------------------------------------------------------------ 8x8 / 16x16 / 32x32 IDCT + add
-template <int LOG2N, typename Pixel>
+// VARIANT bits (A/B switches, see ohevc_debug.h): 1 = fetch the prediction row before the transform instead of
+// after it; 2 = read coefficients straight from HBM as int16 columns (no LDS staging pass).
+template <int LOG2N, typename Pixel, int VARIANT>
 __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
                                                           int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
 {
@@ -193,21 +205,30 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
     const unsigned coeff_off = jraw.z;
     unsigned char *blk = lds + wave * L::WAVE_BYTES + g * L::BLK;
 
-    // ---- A. coefficients HBM -> LDS (row-major, padded rows), 16 bytes per lane per access
-    const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + coeff_off);
-#pragma unroll
-    for (int q = 0; q < N / 8; q++) {
-        const int c = q * N + i;                            // 16-byte chunk index inside the block
-        const u32x4 v = src[c];
-        *reinterpret_cast<u32x4 *>(blk + (c / (N / 8)) * RS + (c % (N / 8)) * 16) = v;
-    }
-    __builtin_amdgcn_wave_barrier();
+    unsigned char *row = PLANE_PTR3(planes, jplane) + (size_t)(jy + i) * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    unsigned px[N * (int)sizeof(Pixel) / 4];
+    if constexpr (VARIANT & 1) load_row<N, Pixel>(row, px, valid);
 
-    // ---- B. pass 1: column i, inputs gathered as same-level pairs
     unsigned p[N / 2];
-    {
+    constexpr PairTab<N> pt{};
+    if constexpr (VARIANT & 2) {
+        // ---- A'. coefficients straight from HBM: lane i reads column i, one int16 per row
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(coeffs + coeff_off) + i;
+#pragma unroll
+        for (int m = 0; m < N / 2; m++)
+            p[m] = (unsigned)col[pt.lo[m] * N] | ((unsigned)col[pt.hi[m] * N] << 16);
+    } else {
+        // ---- A. coefficients HBM -> LDS (row-major, padded rows), 16 bytes per lane per access
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + coeff_off);
+#pragma unroll
+        for (int q = 0; q < N / 8; q++) {
+            const int c = q * N + i;                        // 16-byte chunk index inside the block
+            const u32x4 v = src[c];
+            *reinterpret_cast<u32x4 *>(blk + (c / (N / 8)) * RS + (c % (N / 8)) * 16) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- B. pass 1: column i, inputs gathered as same-level pairs
         const unsigned short *col = reinterpret_cast<const unsigned short *>(blk) + i;
-        constexpr PairTab<N> pt{};
 #pragma unroll
         for (int m = 0; m < N / 2; m++)
             p[m] = (unsigned)col[pt.lo[m] * (RS / 2)] | ((unsigned)col[pt.hi[m] * (RS / 2)] << 16);
@@ -241,8 +262,8 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
     for (int k = 0; k < N; k++) t[k] >>= shift2;
 
     // ---- D. residual row + prediction row -> plane
-    unsigned char *row = PLANE_PTR(planes, jplane) + (size_t)(jy + i) * PLANE_STRIDE(planes, jplane) + (size_t)jx * sizeof(Pixel);
-    add_row_store<N, Pixel>(row, t, bit_depth, valid);
+    if constexpr (!(VARIANT & 1)) load_row<N, Pixel>(row, px, valid);
+    finish_row<N, Pixel>(row, px, t, bit_depth, valid);
 }
 
 // ------------------------------------------------------------------ 4x4 IDCT / DST: one lane per block
@@ -283,8 +304,8 @@ __global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohev
         c[0][i] = clip16(y0 >> 7); c[1][i] = clip16(y1 >> 7); c[2][i] = clip16(y2 >> 7); c[3][i] = clip16(y3 >> 7);
     }
     const int shift2 = 20 - bit_depth;
-    unsigned char *base = PLANE_PTR(planes, jplane) + (size_t)jy * PLANE_STRIDE(planes, jplane) + (size_t)jx * sizeof(Pixel);
-    const int stride = PLANE_STRIDE(planes, jplane);
+    unsigned char *base = PLANE_PTR3(planes, jplane) + (size_t)jy * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    const int stride = PLANE_STRIDE3(planes, jplane);
 #pragma unroll
     for (int r = 0; r < 4; r++) {   // rows
         int res[4];
@@ -347,11 +368,24 @@ __global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohe
 #pragma unroll
         for (int x = 0; x < N; x++) res[x] = (int)(short)res[x];
     }
-    unsigned char *row = PLANE_PTR(planes, jplane) + (size_t)(jy + r) * PLANE_STRIDE(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    unsigned char *row = PLANE_PTR3(planes, jplane) + (size_t)(jy + r) * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
     add_row_store<N, Pixel>(row, res, bit_depth, true);
 }
 
 // ------------------------------------------------------------------ launcher
+int g_tu_variant = 0;     // set through ohevc_debug_set_tu_variant(); 0 = shipped configuration
+
+template <int LOG2N, typename Pixel>
+static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
+{
+    switch (g_tu_variant & 3) {
+    case 0: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+    case 1: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+    case 2: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 2>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+    case 3: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 3>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+    }
+}
+
 template <typename Pixel>
 static int launch_tu(const PlaneSet &ps, int bit_depth, int log2, int kind, const ohevc_tu_job *jobs, int njobs,
                      const int16_t *coeffs, hipStream_t st)
@@ -359,9 +393,9 @@ static int launch_tu(const PlaneSet &ps, int bit_depth, int log2, int kind, cons
     if (kind == OHEVC_TU_IDCT && log2 >= 3) {
         const int bpw = 64 >> log2, per_wg = 4 * bpw, grid = (njobs + per_wg - 1) / per_wg;
         switch (log2) {
-        case 3: hipLaunchKernelGGL((tu_idct_add_kernel<3, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
-        case 4: hipLaunchKernelGGL((tu_idct_add_kernel<4, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
-        case 5: hipLaunchKernelGGL((tu_idct_add_kernel<5, Pixel>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 3: launch_idct<3, Pixel>(grid, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 4: launch_idct<4, Pixel>(grid, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 5: launch_idct<5, Pixel>(grid, st, ps, jobs, njobs, coeffs, bit_depth); break;
         }
     } else if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) {
         const int grid = (njobs + 255) / 256;
@@ -406,6 +440,13 @@ extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     return bit_depth == 8 ? launch_tu<uint8_t>(ps, bit_depth, log2_size, kind, jobs, njobs, coeffs, st)
                           : launch_tu<uint16_t>(ps, bit_depth, log2_size, kind, jobs, njobs, coeffs, st);
+}
+
+extern "C" int ohevc_debug_set_tu_variant(int variant)
+{
+    int old = ohevc::g_tu_variant;
+    ohevc::g_tu_variant = variant;
+    return old;
 }
 
 extern "C" const char *ohevc_tu_kernel_name(int bit_depth, int log2_size, int kind)

@@ -39,6 +39,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own ROCm runtime (libamdhip64.so.7, same SONAME as /opt/rocm's).  Whichever copy is loaded
+    # first serves the whole process, and torch only works on its own copy -- so in a Python process torch must be
+    # imported BEFORE this library is dlopen'ed.  (A plain C host links /opt/rocm's runtime and never sees torch.)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise OhevcError(f"{LIB_PATH} is missing: run `make -C openhevc_amd/csrc` (or __graft_entry__.build()) first")
     lib = C.CDLL(LIB_PATH)
@@ -80,3 +84,83 @@ def planes_of(tensors):
 def dev_tu_batch(planes, bit_depth, log2_size, kind, jobs_ptr, njobs, coeffs_ptr, stream=0):
     check(load_library().ohevc_dev_tu_batch(planes, bit_depth, log2_size, kind, C.c_void_p(jobs_ptr), njobs,
                                             C.c_void_p(coeffs_ptr), C.c_void_p(stream)))
+
+
+# ---------------------------------------------------------------- MC / deblock / SAO / intra job records
+MC_BI, MC_WEIGHTED = 1, 2
+MC_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("plane", "u1"), ("flags", "u1"),
+                   ("sx0", "<i2"), ("sy0", "<i2"), ("sx1", "<i2"), ("sy1", "<i2"),
+                   ("mx0", "u1"), ("my0", "u1"), ("mx1", "u1"), ("my1", "u1"),
+                   ("ref0", "i1"), ("ref1", "i1"), ("denom", "u1"), ("reserved", "u1"),
+                   ("wx0", "<i2"), ("wx1", "<i2"), ("ox0", "<i2"), ("ox1", "<i2")])
+assert MC_JOB.itemsize == 32
+
+DBK_VERTICAL_EDGE, DBK_NO_P0, DBK_NO_P1, DBK_NO_Q0, DBK_NO_Q1 = 1, 2, 4, 8, 16
+DBK_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("flags", "u1"), ("beta", "u1"), ("reserved0", "u1"),
+                    ("tc", "<i2", (2,)), ("reserved1", "<u4")])
+assert DBK_JOB.itemsize == 16
+
+SAO_BAND, SAO_EDGE = 1, 2
+SAO_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "<u2"), ("h", "<u2"), ("plane", "u1"), ("type", "u1"),
+                    ("klass", "u1"), ("borders", "u1"), ("restore", "u1"), ("edges", "u1"),
+                    ("offset_val", "<i2", (5,)), ("reserved", "u1", (8,))])
+assert SAO_JOB.itemsize == 32
+
+INTRA_BOTTOM_LEFT, INTRA_LEFT, INTRA_UP_LEFT, INTRA_UP, INTRA_UP_RIGHT = 1, 2, 4, 8, 16
+INTRA_NO_SMOOTHING, INTRA_STRONG, INTRA_LUMA_EDGE = 32, 64, 128
+INTRA_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("log2_size", "u1"), ("mode", "u1"), ("flags", "u1"),
+                      ("bottom_left_size", "u1"), ("top_right_size", "u1"), ("reserved", "u1", (6,))])
+assert INTRA_JOB.itemsize == 16
+
+EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_intra_batch"]
+
+
+def planes_table(list_of_plane_triples):
+    """numpy bytes of a slot-major ohevc_plane[n*3] table (for the MC reference-picture table)."""
+    n = len(list_of_plane_triples)
+    arr = (Plane * (3 * n))()
+    for s, triple in enumerate(list_of_plane_triples):
+        for i, t in enumerate(triple):
+            if t is None:
+                continue
+            arr[3 * s + i].data = t.data_ptr()
+            arr[3 * s + i].stride = t.stride(0) * t.element_size()
+            arr[3 * s + i].width, arr[3 * s + i].height = t.shape[1], t.shape[0]
+    return np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+
+
+def dev_mc_batch(dst_planes, refs_ptr, n_slots, bit_depth, jobs_ptr, njobs, stream=0):
+    lib = load_library()
+    check(lib.ohevc_dev_mc_batch(dst_planes, C.c_void_p(refs_ptr), C.c_int(n_slots), C.c_int(bit_depth),
+                                 C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
+
+
+def dev_deblock_batch(planes, bit_depth, jobs_ptr, njobs, stream=0):
+    check(load_library().ohevc_dev_deblock_batch(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
+
+
+def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):
+    check(load_library().ohevc_dev_sao_batch(dst_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
+
+
+def dev_intra_batch(planes, bit_depth, jobs_ptr, njobs, stream=0):
+    check(load_library().ohevc_dev_intra_batch(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
+
+
+class IntraGeom(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("chroma_format_idc", C.c_int32), ("log2_ctb_size", C.c_int32),
+                ("log2_min_tb_size", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("intra_smoothing_disabled", C.c_int32),
+                ("constrained_intra_pred", C.c_int32)]
+
+
+EXPORTED_SYMBOLS += ["ohevc_intra_make_job"]
+
+
+def intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cands):
+    """cands = (bottom_left, left, up_left, up, up_right) as in HEVClc->na.  Returns a 1-element INTRA_JOB array."""
+    out = np.zeros(1, INTRA_JOB)
+    bl, lf, ul, up, ur = cands
+    check(load_library().ohevc_intra_make_job(C.byref(geom), C.c_int(x0), C.c_int(y0), C.c_int(log2_size), C.c_int(c_idx),
+                                              C.c_int(mode), C.c_int(bl), C.c_int(lf), C.c_int(ul), C.c_int(up), C.c_int(ur),
+                                              out.ctypes.data_as(C.c_void_p)))
+    return out

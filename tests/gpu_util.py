@@ -48,3 +48,12 @@ def make_tu_jobs(xy, n, planes=None, dcs=None):
         if dcs is not None:
             jobs["dc"] = dcs
     return jobs
+
+
+def planes3(d_planes):
+    d = list(d_planes) + [None] * (3 - len(d_planes))
+    return L.planes_of(d)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,71 @@
+"""-m gpu parity tests of intra prediction (host job resolution + HIP kernel) vs the CPU oracle's intra_pred()."""
+import numpy as np
+import pytest
+import torch
+
+from openhevc_amd import lib as L
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_intra_pred_random_calls(oracle, bd):
+    rng = np.random.default_rng(900 + bd)
+    W, H = 136, 72                                      # not CTB aligned -> picture-edge clipping of the 2N neighbours
+    for it in range(250):
+        log2 = int(rng.integers(2, 6)); n = 1 << log2
+        c_idx = int(rng.integers(0, 3)); cfi = int(rng.choice([1, 1, 1, 3]))
+        sh = 1 if (c_idx and cfi == 1) else 0
+        nl = n << sh
+        x0 = int(rng.integers(0, (W - nl) // nl + 1)) * nl; y0 = int(rng.integers(0, (H - nl) // nl + 1)) * nl
+        if it % 5 == 0:
+            x0, y0 = (W - nl) // nl * nl, (H - nl) // nl * nl
+        mode = int(rng.integers(0, 35)) if it % 3 else int(rng.choice([0, 1, 10, 26, 2, 18, 34]))
+        cands = [int(rng.random() < 0.7) for _ in range(5)]
+        if x0 == 0: cands[0] = cands[1] = cands[2] = 0
+        if y0 == 0: cands[2] = cands[3] = cands[4] = 0
+        if x0 + nl >= W: cands[4] = 0
+        if y0 + nl >= H: cands[0] = 0
+        if it % 7 == 0:                                 # smooth content: exercises the strong 32x32 filter
+            planes = [np.ascontiguousarray(np.full((H + 8, W + 8), int(rng.integers(0, 1 << bd)), G.pixdt(bd)) + (np.arange(W + 8) // 16).astype(G.pixdt(bd))) for _ in range(3)]
+        else:
+            planes = [rng.integers(0, 1 << bd, size=(H + 8, W + 8)).astype(G.pixdt(bd)) for _ in range(3)]
+        strong = int(rng.random() < 0.7); dis = int(rng.random() < 0.1); ctb = int(rng.choice([4, 5, 6]))
+        want = [p.copy() for p in planes]
+        oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=cfi, strong=strong,
+                          smoothing_disabled=dis, log2_ctb_size=ctb, log2_min_tb_size=2)
+        geom = L.IntraGeom(W, H, cfi, ctb, 2, strong, dis, 0)
+        job = L.intra_make_job(geom, x0, y0, log2, c_idx, mode, cands)
+        d = [G.to_dev(p) for p in planes]
+        d_jobs = G.to_dev(job)
+        L.dev_intra_batch(G.planes3(d), bd, d_jobs.data_ptr(), 1, G.stream())
+        torch.cuda.synchronize()
+        for pl in range(3):
+            got = G.to_host(d[pl], planes[pl].dtype)
+            assert np.array_equal(got, want[pl]), (it, log2, c_idx, mode, cands, x0, y0, cfi, strong, dis, ctb, pl)
+
+
+def test_intra_batch_of_independent_blocks(oracle):
+    """Many non-adjacent blocks in one launch (one wavefront each)."""
+    bd, W, H = 8, 640, 320
+    rng = np.random.default_rng(4)
+    plane = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    planes = [plane, plane[: H // 2, : W // 2].copy(), plane[: H // 2, : W // 2].copy()]
+    want = [p.copy() for p in planes]
+    geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+    jobs = []
+    for cy in range(0, H - 127, 128):
+        for cx in range(0, W - 127, 128):
+            log2 = int(rng.integers(2, 6)); mode = int(rng.integers(0, 35))
+            x0, y0 = cx + 64, cy + 64
+            cands = [int(rng.random() < 0.8) for _ in range(5)]
+            oracle.intra_pred(bd, want, W, H, x0, y0, log2, 0, mode, cands, chroma_format_idc=1, strong=1, smoothing_disabled=0,
+                              log2_ctb_size=6, log2_min_tb_size=2)
+            jobs.append(L.intra_make_job(geom, x0, y0, log2, 0, mode, cands)[0])
+    batch = np.array(jobs, dtype=L.INTRA_JOB)
+    d = [G.to_dev(p) for p in planes]
+    d_jobs = G.to_dev(batch)
+    L.dev_intra_batch(G.planes3(d), bd, d_jobs.data_ptr(), len(batch), G.stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(G.to_host(d[0], np.uint8), want[0])

@@ -1,41 +1,36 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into HBM bytes per launch of the dominant kernel.
+"""HBM bytes per launch of the dominant kernel from two rocprofv3 PMC passes (rocpd sqlite output).
 
-Units and gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are
-reported in KiB-like units of 1024 B... (hbm_bytes = counter * 1024) and on gfx950 FETCH_SIZE reads exactly 1/2 of the
-bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE is uncalibrated and taken as is.
-Writes <out>/pmc_traffic.json; copy it to profiles/pmc_traffic.json for bench.py to report as roofline.traffic.
+    pmc_traffic.py <fetch_results.db> <write_results.db> [kernel substring] > profiles/pmc_traffic.json
+
+Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
+(their expressions end in /1024); on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane)
+coalesced streaming read, so the read side is doubled.  WRITE_SIZE was calibrated in the same run on a kernel with
+a known byte count (torch's 1 GiB random fill reads 1048750 KiB) and is used as is.
 """
-import csv
-import glob
 import json
-import os
+import sqlite3
 import sys
 
 
-def per_dispatch(dirpath, counter, kernel_substr):
-    vals = []
-    for f in glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True):
-        for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") == counter and kernel_substr in row.get("Kernel_Name", ""):
-                vals.append(float(row["Counter_Value"]))
-    return vals
+def mean_counter(db, counter, substr):
+    con = sqlite3.connect(db)
+    r = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
+                    (counter, f"%{substr}%")).fetchone()
+    return r
 
 
 def main():
-    out = sys.argv[1]
-    kern = sys.argv[2] if len(sys.argv) > 2 else "tu_idct_add_kernel"
-    fetch = per_dispatch(os.path.join(out, "prof_pmc_fetch"), "FETCH_SIZE", kern)
-    write = per_dispatch(os.path.join(out, "prof_pmc_write"), "WRITE_SIZE", kern)
-    res = {"kernel": kern, "fetch_size_raw_mean": sum(fetch) / len(fetch) if fetch else None,
-           "write_size_raw_mean": sum(write) / len(write) if write else None, "dispatches": [len(fetch), len(write)]}
-    if fetch and write:
-        rd = res["fetch_size_raw_mean"] * 1024 * 2      # gfx950: FETCH_SIZE = 1/2 of wide coalesced read bytes
-        wr = res["write_size_raw_mean"] * 1024
+    fetch_db, write_db = sys.argv[1], sys.argv[2]
+    kern = sys.argv[3] if len(sys.argv) > 3 else "tu_idct_add_kernel<5, unsigned char>"
+    f, nf = mean_counter(fetch_db, "FETCH_SIZE", kern)
+    w, nw = mean_counter(write_db, "WRITE_SIZE", kern)
+    res = {"kernel": kern, "fetch_size_kib_mean": f, "write_size_kib_mean": w, "dispatches": [nf, nw]}
+    if f and w:
+        rd, wr = f * 1024 * 2, w * 1024
         res.update({"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-                    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; WRITE_SIZE uncalibrated"})
-    json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(res))
+                    "note": "read side = FETCH_SIZE*1024*2 (gfx950 half-count correction), write side = WRITE_SIZE*1024"})
+    print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
