@@ -38,7 +38,9 @@ enum {
     OHEVC_ERR_STATE   = -4    /* call sequence error (ctx layer)                   */
 };
 
-/* One picture plane in HBM.  data must be 16-byte aligned, stride a multiple of 16 bytes. */
+/* One picture plane in HBM.  For ohevc_dev_tu_batch data must be 16-byte aligned and stride a multiple of 16 bytes
+ * (what the reference's STRIDE_ALIGN frame buffers give, libavcodec/utils.c:432); the other kernels only need
+ * natural pixel alignment. */
 typedef struct ohevc_plane {
     void    *data;
     int32_t  stride;          /* bytes */

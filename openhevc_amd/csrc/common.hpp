@@ -36,7 +36,9 @@ struct PlaneSet {
     int            height[3];
 };
 
-inline int make_plane_set(const ohevc_plane planes[3], PlaneSet &ps)
+// align: required alignment (bytes) of plane base and stride; the TU kernels use 16-byte row accesses (16),
+// the per-sample kernels only need natural pixel alignment (pixel size).
+inline int make_plane_set(const ohevc_plane planes[3], PlaneSet &ps, int align = 16)
 {
     for (int i = 0; i < 3; i++) {
         ps.data[i]   = static_cast<unsigned char *>(planes[i].data);
@@ -44,8 +46,8 @@ inline int make_plane_set(const ohevc_plane planes[3], PlaneSet &ps)
         ps.width[i]  = planes[i].width;
         ps.height[i] = planes[i].height;
         if (planes[i].data) {
-            OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(planes[i].data) & 15) == 0, "plane data must be 16-byte aligned");
-            OHEVC_REQUIRE((planes[i].stride & 15) == 0 && planes[i].stride > 0, "plane stride must be a positive multiple of 16 bytes");
+            OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(planes[i].data) & (align - 1)) == 0, "plane data is not sufficiently aligned");
+            OHEVC_REQUIRE((planes[i].stride & (align - 1)) == 0 && planes[i].stride > 0, "plane stride must be a positive multiple of the required alignment");
         }
     }
     return OHEVC_OK;

@@ -147,7 +147,7 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
     PlaneSet ps;
-    int rc = make_plane_set(planes, ps);
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = (int)(((long long)njobs * 8 + 255) / 256);
@@ -167,9 +167,9 @@ extern "C" int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane s
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
     PlaneSet pd, psrc;
-    int rc = make_plane_set(dst, pd);
+    int rc = make_plane_set(dst, pd, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
-    rc = make_plane_set(src, psrc);
+    rc = make_plane_set(src, psrc, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, jobs, njobs, bit_depth);

@@ -196,7 +196,7 @@ extern "C" int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth,
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
     PlaneSet ps;
-    int rc = make_plane_set(planes, ps);
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bit_depth == 8) hipLaunchKernelGGL((intra_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, njobs, bit_depth);

@@ -151,7 +151,7 @@ extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *r
     OHEVC_REQUIRE(refs != nullptr && n_ref_slots > 0, "refs");
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
     PlaneSet ps;
-    int rc = make_plane_set(dst, ps);
+    int rc = make_plane_set(dst, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bit_depth == 8)

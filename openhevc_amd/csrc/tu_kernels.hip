@@ -266,6 +266,109 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
     finish_row<N, Pixel>(row, px, t, bit_depth, valid);
 }
 
+// ------------------------------------------------------------------ persistent, software-pipelined form
+// Same arithmetic as tu_idct_add_kernel.  Each wavefront walks the job list with a grid-sized stride and keeps
+// the NEXT iteration's coefficients (16 bytes x N/8 per lane) and the job record after that in flight in
+// registers while it transforms the current blocks, so every resident wave always has an HBM request pending
+// (memory-level parallelism no longer depends on how many co-resident waves happen to be in their load phase).
+template <int LOG2N, typename Pixel, int VARIANT>
+__global__ __launch_bounds__(256, (VARIANT & 8) ? 5 : 1) void tu_idct_add_pipe_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
+                                                               int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    using L = TuLayout<LOG2N>;
+    constexpr int N = L::N, RS = L::RS, NQ = N / 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * L::WAVE_BYTES];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / N, i = lane % N;
+    const int step = gridDim.x * 4 * L::BPW;
+    int job0 = (blockIdx.x * 4 + wave) * L::BPW;
+    if (job0 >= njobs) return;
+    unsigned char *blk = lds + wave * L::WAVE_BYTES + g * L::BLK;
+    const u32x4 *jobv = reinterpret_cast<const u32x4 *>(jobs);
+    constexpr PairTab<N> pt{};
+    const int shift2 = 20 - bit_depth;
+
+    u32x4 jraw = jobv[job0 + g < njobs ? job0 + g : njobs - 1];
+    u32x4 cur[NQ];
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + jraw.z);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) cur[q] = src[q * N + i];
+    }
+    int job0n = job0 + step;
+    u32x4 jraw_n = jraw;
+    if (job0n < njobs) jraw_n = jobv[job0n + g < njobs ? job0n + g : njobs - 1];
+
+    for (;;) {
+        const bool has_next = job0n < njobs;                   // wave-uniform
+        u32x4 nxt[NQ];
+        u32x4 jraw_nn = jraw_n;
+        if (has_next) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + jraw_n.z);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) nxt[q] = src[q * N + i];
+            const int job0nn = job0n + step;
+            if (job0nn < njobs) jraw_nn = jobv[job0nn + g < njobs ? job0nn + g : njobs - 1];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) nxt[q] = cur[q];
+        }
+        const bool valid = job0 + g < njobs;
+        const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
+        unsigned char *row = PLANE_PTR3(planes, jplane) + (size_t)(jy + i) * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
+        unsigned px[N * (int)sizeof(Pixel) / 4];
+        if constexpr (VARIANT & 1) load_row<N, Pixel>(row, px, valid);
+
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int c = q * N + i;
+            *reinterpret_cast<u32x4 *>(blk + (c / NQ) * RS + (c % NQ) * 16) = cur[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned p[N / 2];
+        {
+            const unsigned short *col = reinterpret_cast<const unsigned short *>(blk) + i;
+#pragma unroll
+            for (int m = 0; m < N / 2; m++)
+                p[m] = (unsigned)col[pt.lo[m] * (RS / 2)] | ((unsigned)col[pt.hi[m] * (RS / 2)] << 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        int t[N];
+        Idct1D<N>::run(p, t, 64);
+        {
+            unsigned short *dst = reinterpret_cast<unsigned short *>(blk) + slot_of_rt(N, i);
+#pragma unroll
+            for (int r = 0; r < N; r += 2) {
+                const unsigned pk = sat_pack_i16(t[r] >> 7, t[r + 1] >> 7);
+                dst[r * (RS / 2)]       = (unsigned short)(pk & 0xffffu);
+                dst[(r + 1) * (RS / 2)] = (unsigned short)(pk >> 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const u32x4 *rowp = reinterpret_cast<const u32x4 *>(blk + i * RS);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const u32x4 v = rowp[q];
+                p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        Idct1D<N>::run(p, t, 1 << (shift2 - 1));
+#pragma unroll
+        for (int k = 0; k < N; k++) t[k] >>= shift2;
+        if constexpr (!(VARIANT & 1)) load_row<N, Pixel>(row, px, valid);
+        finish_row<N, Pixel>(row, px, t, bit_depth, valid);
+
+        if (!has_next) break;
+        job0 = job0n; job0n += step;
+        jraw = jraw_n; jraw_n = jraw_nn;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) cur[q] = nxt[q];
+    }
+}
+
 // ------------------------------------------------------------------ 4x4 IDCT / DST: one lane per block
 template <typename Pixel, bool DST>
 __global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
@@ -374,10 +477,21 @@ __global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohe
 
 // ------------------------------------------------------------------ launcher
 int g_tu_variant = 0;     // set through ohevc_debug_set_tu_variant(); 0 = shipped configuration
+int g_tu_pipe_wgs = 2048; // workgroups of the persistent form (ohevc_debug_set_tu_pipe_workgroups)
 
 template <int LOG2N, typename Pixel>
 static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
 {
+    if (g_tu_variant & 4) {
+        const int pgrid = grid < g_tu_pipe_wgs ? grid : g_tu_pipe_wgs;
+        switch (g_tu_variant & 9) {
+        case 0: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 0>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 1: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 1>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 8: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 8>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        case 9: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 9>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+        }
+        return;
+    }
     switch (g_tu_variant & 3) {
     case 0: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
     case 1: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
@@ -446,6 +560,13 @@ extern "C" int ohevc_debug_set_tu_variant(int variant)
 {
     int old = ohevc::g_tu_variant;
     ohevc::g_tu_variant = variant;
+    return old;
+}
+
+extern "C" int ohevc_debug_set_tu_pipe_workgroups(int n)
+{
+    int old = ohevc::g_tu_pipe_wgs;
+    if (n > 0) ohevc::g_tu_pipe_wgs = n;
     return old;
 }
 

@@ -29,7 +29,13 @@ def setup(log2, bd, nblk):
 
 def main():
     lib = L.load_library()
-    variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3".split(","))]
+    variants = sys.argv[1].split(",") if len(sys.argv) > 1 else "0,4,5,12,4@1024,4@4096,12@1280".split(",")
+
+    def select(v):                       # "variant" or "variant@pipe_workgroups"
+        var, _, wgs = v.partition("@")
+        lib.ohevc_debug_set_tu_pipe_workgroups(int(wgs) if wgs else 2048)
+        lib.ohevc_debug_set_tu_variant(int(var))
+
     rounds = 12
     results = {}
     for (log2, bd, nblk) in [(5, 8, 1 << 20), (5, 10, 1 << 20), (4, 8, 1 << 22), (3, 8, 1 << 24)]:
@@ -38,7 +44,7 @@ def main():
         st = torch.cuda.current_stream()
         outs = {}
         for v in variants:
-            lib.ohevc_debug_set_tu_variant(v)
+            select(v)
             p = plane0.clone()
             L.dev_tu_batch(L.planes_of([p, None, None]), bd, log2, L.TU_IDCT, d_jobs.data_ptr(), nblk, coeffs.data_ptr(), st.cuda_stream)
             torch.cuda.synchronize()
@@ -50,7 +56,7 @@ def main():
         times = {v: [] for v in variants}
         for r in range(rounds + 2):
             for v in variants:
-                lib.ohevc_debug_set_tu_variant(v)
+                select(v)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(st)
                 L.dev_tu_batch(planes, bd, log2, L.TU_IDCT, d_jobs.data_ptr(), nblk, coeffs.data_ptr(), st.cuda_stream)
@@ -68,7 +74,7 @@ def main():
         print(f"{n}x{n} {bd}-bit identical={same} " + " ".join(f"v{v}:{row[f'v{v}']['GBps_median']}GB/s" for v in variants), flush=True)
         del plane0, coeffs, d_jobs, work
         torch.cuda.empty_cache()
-    lib.ohevc_debug_set_tu_variant(0)
+    select("0")
     print(json.dumps(results))
 
 

@@ -22,7 +22,7 @@ def mean_counter(db, counter, substr):
 
 def main():
     fetch_db, write_db = sys.argv[1], sys.argv[2]
-    kern = sys.argv[3] if len(sys.argv) > 3 else "tu_idct_add_kernel<5, unsigned char>"
+    kern = sys.argv[3] if len(sys.argv) > 3 else "tu_idct_add_kernel<5, unsigned char"
     f, nf = mean_counter(fetch_db, "FETCH_SIZE", kern)
     w, nw = mean_counter(write_db, "WRITE_SIZE", kern)
     res = {"kernel": kern, "fetch_size_kib_mean": f, "write_size_kib_mean": w, "dispatches": [nf, nw]}
