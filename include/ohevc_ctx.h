@@ -1,0 +1,72 @@
+/*
+ * ohevc_ctx.h -- host-side layer of libohevc_hip.so: device-resident picture store (the DPB's pixel planes), a job
+ * recorder and the phase-ordered executor that turns one frame's recorded jobs into kernel launches.
+ *
+ * This is the "extra API" a drop-in needs that the reference does not have: the reference's table
+ * slots compute immediately on host memory; here the front-end records, and flushes at the points where the
+ * reference's own schedule allows it:
+ *     hevc_frame_start (hevc.c:3197)                      -> ohevc_frame_begin
+ *     table calls in hls_coding_unit / hls_transform_unit -> ohevc_rec_* (coefficients are COPIED at call time: the
+ *                                                            reference reuses lc->tu.coeffs for the next TU, hevc.h:1063)
+ *     end of a CTU row / before ff_hevc_hls_filters       -> ohevc_frame_reconstruct (optional, for overlap)
+ *     frame end, before output / MD5 (hevc.c:4146-4181)   -> ohevc_frame_end, ohevc_pic_download
+ *
+ * Ordering rules preserved: inter prediction first (reads other pictures only), then the inter
+ * residuals, then intra blocks in dependency levels (each level: prediction, then its residuals) so that every intra
+ * block sees reconstructed, un-deblocked neighbours; then all vertical edges, all horizontal edges, then SAO from a
+ * deblocked copy (the reference's sao_frame).
+ *
+ * One ohevc_ctx serves one decoding thread (like one HEVCContext); it is not internally synchronised.
+ */
+#ifndef OHEVC_CTX_H
+#define OHEVC_CTX_H
+
+#include "ohevc_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ohevc_ctx ohevc_ctx;
+
+int  ohevc_ctx_create(ohevc_ctx **out, int device);
+void ohevc_ctx_destroy(ohevc_ctx *ctx);
+/* the HIP stream all of this context's copies and launches are issued on (hipStream_t as void*) */
+void *ohevc_ctx_stream(ohevc_ctx *ctx);
+int  ohevc_ctx_sync(ohevc_ctx *ctx);
+
+/* ---- picture store: pixel planes of DPB entries, resident in HBM for the life of the HEVCFrame (hevc_refs.c:75-147) */
+int  ohevc_pic_alloc(ohevc_ctx *ctx, int width, int height, int chroma_format_idc, int bit_depth);   /* slot >= 0 or error */
+int  ohevc_pic_release(ohevc_ctx *ctx, int slot);
+int  ohevc_pic_upload(ohevc_ctx *ctx, int slot, int plane, const void *host, ptrdiff_t host_stride);
+int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff_t host_stride);
+int  ohevc_pic_planes(ohevc_ctx *ctx, int slot, ohevc_plane out[3]);     /* device views (e.g. for an RCCL broadcast) */
+
+/* ---- per-frame recording */
+int  ohevc_frame_begin(ohevc_ctx *ctx, int slot);
+/* transform_add[..] preceded by its inverse transform (kind = OHEVC_TU_*).  `intra` != 0 when the block was just
+ * predicted by ohevc_rec_intra at the same position (it then runs right after that prediction's level). */
+int  ohevc_rec_tu(ohevc_ctx *ctx, int plane, int x, int y, int log2_size, int kind, const int16_t *coeffs, int intra);
+int  ohevc_rec_mc(ohevc_ctx *ctx, const ohevc_mc_job *job);              /* ref0/ref1 are picture-store slots */
+int  ohevc_rec_intra(ohevc_ctx *ctx, const ohevc_intra_job *job);
+int  ohevc_rec_deblock(ohevc_ctx *ctx, const ohevc_dbk_job *job);
+int  ohevc_rec_sao(ohevc_ctx *ctx, const ohevc_sao_job *job);
+
+/* upload + launch prediction/residual work recorded so far (may be called several times per frame) */
+int  ohevc_frame_reconstruct(ohevc_ctx *ctx);
+/* reconstruct + in-loop filters (vertical edges, horizontal edges, SAO); the picture is final when this returns OK
+ * and the stream has drained (ohevc_ctx_sync / ohevc_pic_download) */
+int  ohevc_frame_end(ohevc_ctx *ctx);
+
+/* statistics of the last ohevc_frame_end, for benches: launches issued, intra dependency levels, bytes uploaded */
+typedef struct ohevc_frame_stats {
+    int32_t launches, intra_levels;
+    int64_t upload_bytes;
+    int32_t n_tu, n_mc, n_intra, n_dbk, n_sao;
+} ohevc_frame_stats;
+int  ohevc_frame_get_stats(ohevc_ctx *ctx, ohevc_frame_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHEVC_CTX_H */

@@ -1,0 +1,466 @@
+// ctx.hip -- host side of libohevc_hip.so: picture store, job recorder, phase-ordered executor (include/ohevc_ctx.h).
+// Host code only; the kernels it launches live in the *_kernels.hip files and are reached through the same
+// ohevc_dev_* entry points an external caller would use.
+#include <algorithm>
+#include <map>
+#include <string.h>
+#include <vector>
+#include "common.hpp"
+#include "ohevc_ctx.h"
+
+namespace {
+
+struct Picture {
+    bool used = false;
+    int w = 0, h = 0, cfi = 1, bd = 8;
+    ohevc_plane planes[3] = {};
+};
+
+struct DevBuf {                       // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return OHEVC_OK;
+        if (p) OHEVC_HIP_TRY(hipFree(p));
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)1 << 20);
+        want = (want + (want >> 1) + 255) & ~(size_t)255;
+        OHEVC_HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return OHEVC_OK;
+    }
+};
+
+struct PinnedBuf {                    // grow-only pinned host staging buffer
+    unsigned char *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return OHEVC_OK;
+        if (p) OHEVC_HIP_TRY(hipHostFree(p));
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)1 << 20);
+        want = (want + (want >> 1) + 255) & ~(size_t)255;
+        OHEVC_HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+        cap = want;
+        return OHEVC_OK;
+    }
+};
+
+inline uint32_t tu_key(int level, int log2, int kind) { return ((uint32_t)level << 8) | ((uint32_t)log2 << 4) | (uint32_t)kind; }
+
+}  // namespace
+
+struct ohevc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t staged = nullptr;      // recorded after the last H2D copy out of `stage`
+    bool staged_pending = false;
+    std::vector<Picture> pics;
+    bool table_dirty = true;
+    int cur = -1;
+    Picture twin;                     // deblocked copy for SAO (the reference's sao_frame, hevc.c:369-385)
+
+    std::vector<ohevc_mc_job> mc;
+    std::map<uint32_t, std::vector<ohevc_tu_job>> tu;     // (level, log2, kind) -> jobs
+    std::map<int, std::vector<ohevc_intra_job>> intra;    // level -> jobs
+    std::vector<int16_t> coeffs;
+    std::vector<ohevc_dbk_job> dbk_v, dbk_h;
+    std::vector<ohevc_sao_job> sao;
+    std::vector<uint16_t> level_map[3];
+    int lm_w[3] = {}, lm_h[3] = {};
+
+    DevBuf d_jobs, d_coeffs, d_table;
+    PinnedBuf stage;
+    ohevc_frame_stats stats = {}, last_stats = {};
+};
+
+using namespace ohevc;
+
+static int free_picture(Picture &p)
+{
+    for (auto &pl : p.planes) {
+        if (pl.data) OHEVC_HIP_TRY(hipFree(pl.data));
+        pl = ohevc_plane{};
+    }
+    p.used = false;
+    return OHEVC_OK;
+}
+
+static int alloc_picture(Picture &p, int width, int height, int cfi, int bd)
+{
+    const int ps = bd > 8 ? 2 : 1;
+    p.w = width; p.h = height; p.cfi = cfi; p.bd = bd;
+    for (int i = 0; i < 3; i++) {
+        const int hs = i ? (cfi == 1 || cfi == 2) : 0, vs = i ? (cfi == 1) : 0;
+        const int w = width >> hs, h = height >> vs;
+        const int stride = (w * ps + 255) & ~255;          // 256-byte pitch: whole 128-byte lines per row segment
+        void *d = nullptr;
+        OHEVC_HIP_TRY(hipMalloc(&d, (size_t)stride * h));
+        p.planes[i] = ohevc_plane{ d, stride, w, h };
+    }
+    p.used = true;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
+{
+    OHEVC_REQUIRE(out != nullptr, "out");
+    int rc = ohevc_set_device(device);
+    if (rc != OHEVC_OK) return rc;
+    ohevc_ctx *c = new ohevc_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) != hipSuccess) {
+        set_error("stream/event creation failed");
+        delete c;
+        return OHEVC_ERR_HIP;
+    }
+    *out = c;
+    return OHEVC_OK;
+}
+
+extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &p : c->pics) if (p.used) free_picture(p);
+    if (c->twin.used) free_picture(c->twin);
+    if (c->d_jobs.p) hipFree(c->d_jobs.p);
+    if (c->d_coeffs.p) hipFree(c->d_coeffs.p);
+    if (c->d_table.p) hipFree(c->d_table.p);
+    if (c->stage.p) hipHostFree(c->stage.p);
+    if (c->staged) hipEventDestroy(c->staged);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
+{
+    OHEVC_REQUIRE(c != nullptr, "ctx");
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->staged_pending = false;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int bd)
+{
+    OHEVC_REQUIRE(c != nullptr, "ctx");
+    OHEVC_REQUIRE(width > 0 && height > 0 && width <= 65535 && height <= 65535, "picture size");
+    OHEVC_REQUIRE(cfi >= 1 && cfi <= 3, "chroma_format_idc must be 1..3");
+    OHEVC_REQUIRE(bd >= 8 && bd <= 12, "bit_depth must be 8..12");
+    OHEVC_HIP_TRY(hipSetDevice(c->device));
+    int slot = -1;
+    for (size_t i = 0; i < c->pics.size(); i++) if (!c->pics[i].used) { slot = (int)i; break; }
+    if (slot < 0) { c->pics.emplace_back(); slot = (int)c->pics.size() - 1; }
+    OHEVC_REQUIRE(slot < 127, "too many pictures");
+    int rc = alloc_picture(c->pics[slot], width, height, cfi, bd);
+    if (rc != OHEVC_OK) return rc;
+    c->table_dirty = true;
+    return slot;
+}
+
+static Picture *get_pic(ohevc_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= (int)c->pics.size() || !c->pics[slot].used) return nullptr;
+    return &c->pics[slot];
+}
+
+extern "C" int ohevc_pic_release(ohevc_ctx *c, int slot)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr, "bad picture slot");
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->cur == slot) c->cur = -1;
+    c->table_dirty = true;
+    return free_picture(*p);
+}
+
+extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *host, ptrdiff_t host_stride)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
+    const ohevc_plane &pl = p->planes[plane];
+    OHEVC_HIP_TRY(hipMemcpy2DAsync(pl.data, pl.stride, host, host_stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
+                                   hipMemcpyHostToDevice, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));      // pageable source: do not return before it has been read
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host, ptrdiff_t host_stride)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
+    const ohevc_plane &pl = p->planes[plane];
+    OHEVC_HIP_TRY(hipMemcpy2DAsync(host, host_stride, pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
+                                   hipMemcpyDeviceToHost, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_pic_planes(ohevc_ctx *c, int slot, ohevc_plane out[3])
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && out != nullptr, "bad argument");
+    for (int i = 0; i < 3; i++) out[i] = p->planes[i];
+    return OHEVC_OK;
+}
+
+static void clear_recorded(ohevc_ctx *c)
+{
+    c->mc.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear();
+    for (int i = 0; i < 3; i++) std::fill(c->level_map[i].begin(), c->level_map[i].end(), 0);
+}
+
+extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr, "bad picture slot");
+    c->cur = slot;
+    for (int i = 0; i < 3; i++) {
+        c->lm_w[i] = (p->planes[i].width + 3) >> 2;
+        c->lm_h[i] = (p->planes[i].height + 3) >> 2;
+        c->level_map[i].assign((size_t)c->lm_w[i] * c->lm_h[i], 0);
+    }
+    clear_recorded(c);
+    c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear();
+    c->stats = ohevc_frame_stats{};
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    OHEVC_REQUIRE(plane >= 0 && plane < 3 && log2 >= 2 && log2 <= 5 && kind >= 0 && kind < OHEVC_TU_NKINDS, "bad TU");
+    OHEVC_REQUIRE(kind != OHEVC_TU_DST4 || log2 == 2, "DST is 4x4 only");
+    const int n = 1 << log2;
+    OHEVC_REQUIRE(x >= 0 && y >= 0 && x + n <= p->planes[plane].width && y + n <= p->planes[plane].height && coeffs != nullptr, "TU outside plane");
+    ohevc_tu_job j = {};
+    j.x = (uint16_t)x; j.y = (uint16_t)y; j.plane = (uint8_t)plane;
+    if (kind == OHEVC_TU_DC) {
+        j.dc = coeffs[0];
+    } else {
+        j.coeff_off = (uint32_t)c->coeffs.size();
+        c->coeffs.insert(c->coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
+    }
+    const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
+    c->tu[tu_key(level, log2, kind)].push_back(j);
+    c->stats.n_tu++;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
+    OHEVC_REQUIRE(job->plane < 3 && job->w >= 2 && job->w <= 64 && job->h >= 2 && job->h <= 64, "bad MC block");
+    OHEVC_REQUIRE(get_pic(c, job->ref0) != nullptr && (!(job->flags & OHEVC_MC_BI) || get_pic(c, job->ref1) != nullptr), "bad reference slot");
+    c->mc.push_back(*job);
+    c->stats.n_mc++;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_rec_intra(ohevc_ctx *c, const ohevc_intra_job *job)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
+    OHEVC_REQUIRE(job->plane < 3 && job->log2_size >= 2 && job->log2_size <= 5 && job->mode <= 34, "bad intra job");
+    const int pl = job->plane, n = 1 << job->log2_size, W = c->lm_w[pl], H = c->lm_h[pl];
+    OHEVC_REQUIRE(job->x + n <= p->planes[pl].width && job->y + n <= p->planes[pl].height, "intra block outside plane");
+    // dependency level = 1 + the highest level among the 4x4 cells this block may read (row above incl. corner and
+    // above-right, column to the left incl. below-left): hevcpred_template.c:164-183
+    auto &lm = c->level_map[pl];
+    int level = 0;
+    const int cx0 = (job->x >> 2) - 1, cx1 = std::min(W - 1, (job->x + 2 * n - 1) >> 2);
+    const int cy0 = (job->y >> 2) - 1, cy1 = std::min(H - 1, (job->y + 2 * n - 1) >> 2);
+    if (cy0 >= 0)
+        for (int cx = std::max(cx0, 0); cx <= cx1; cx++) level = std::max(level, (int)lm[(size_t)cy0 * W + cx]);
+    if (cx0 >= 0)
+        for (int cy = std::max(cy0, 0); cy <= cy1; cy++) level = std::max(level, (int)lm[(size_t)cy * W + cx0]);
+    level += 1;
+    OHEVC_REQUIRE(level < 65535, "intra dependency chain too long");
+    for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
+        for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) lm[(size_t)cy * W + cx] = (uint16_t)level;
+    c->intra[level].push_back(*job);
+    c->stats.n_intra++;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_rec_deblock(ohevc_ctx *c, const ohevc_dbk_job *job)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
+    ((job->flags & OHEVC_DBK_VERTICAL_EDGE) ? c->dbk_v : c->dbk_h).push_back(*job);
+    c->stats.n_dbk++;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
+    c->sao.push_back(*job);
+    c->stats.n_sao++;
+    return OHEVC_OK;
+}
+
+// copy `bytes` of host data into the staging buffer at a 256-byte aligned offset; returns that offset
+static size_t stage_put(std::vector<std::pair<const void *, size_t>> &parts, size_t &total, const void *src, size_t bytes)
+{
+    size_t off = total;
+    parts.emplace_back(src, bytes);
+    total += (bytes + 255) & ~(size_t)255;
+    return off;
+}
+
+static int wait_staging_free(ohevc_ctx *c)
+{
+    if (c->staged_pending) {
+        OHEVC_HIP_TRY(hipEventSynchronize(c->staged));
+        c->staged_pending = false;
+    }
+    return OHEVC_OK;
+}
+
+static int upload_table(ohevc_ctx *c)
+{
+    if (!c->table_dirty) return OHEVC_OK;
+    std::vector<ohevc_plane> t(c->pics.size() * 3);
+    for (size_t s = 0; s < c->pics.size(); s++)
+        for (int i = 0; i < 3; i++) t[3 * s + i] = c->pics[s].used ? c->pics[s].planes[i] : ohevc_plane{};
+    int rc = c->d_table.reserve(t.size() * sizeof(ohevc_plane));
+    if (rc != OHEVC_OK) return rc;
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_table.p, t.data(), t.size() * sizeof(ohevc_plane), hipMemcpyHostToDevice, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    c->table_dirty = false;
+    return OHEVC_OK;
+}
+
+// upload a set of job arrays in one H2D copy; fills offs[i] with the device offset of parts[i]
+static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>> &parts, size_t total)
+{
+    if (total == 0) return OHEVC_OK;
+    int rc = wait_staging_free(c);
+    if (rc != OHEVC_OK) return rc;
+    if ((rc = c->stage.reserve(total)) != OHEVC_OK) return rc;
+    if (total > c->d_jobs.cap) {
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));     // in-flight kernels may still read the old buffer
+        if ((rc = c->d_jobs.reserve(total)) != OHEVC_OK) return rc;
+    }
+    size_t off = 0;
+    for (auto &pr : parts) {
+        memcpy(c->stage.p + off, pr.first, pr.second);
+        off += (pr.second + 255) & ~(size_t)255;
+    }
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs.p, c->stage.p, total, hipMemcpyHostToDevice, c->stream));
+    OHEVC_HIP_TRY(hipEventRecord(c->staged, c->stream));
+    c->staged_pending = true;
+    c->stats.upload_bytes += (int64_t)total;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    OHEVC_HIP_TRY(hipSetDevice(c->device));
+    if (c->mc.empty() && c->tu.empty() && c->intra.empty()) return OHEVC_OK;
+    int rc = upload_table(c);
+    if (rc != OHEVC_OK) return rc;
+
+    // ---- stage every job array + the coefficient arena, one H2D copy
+    std::vector<std::pair<const void *, size_t>> parts;
+    size_t total = 0;
+    const size_t off_mc = c->mc.empty() ? 0 : stage_put(parts, total, c->mc.data(), c->mc.size() * sizeof(ohevc_mc_job));
+    std::map<uint32_t, size_t> off_tu;
+    for (auto &kv : c->tu) off_tu[kv.first] = stage_put(parts, total, kv.second.data(), kv.second.size() * sizeof(ohevc_tu_job));
+    std::map<int, size_t> off_intra;
+    for (auto &kv : c->intra) off_intra[kv.first] = stage_put(parts, total, kv.second.data(), kv.second.size() * sizeof(ohevc_intra_job));
+    const size_t off_coeffs = c->coeffs.empty() ? 0 : stage_put(parts, total, c->coeffs.data(), c->coeffs.size() * sizeof(int16_t));
+    if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
+    unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
+    const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
+
+    // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
+    if (!c->mc.empty()) {
+        rc = ohevc_dev_mc_batch(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), (int)c->pics.size(), p->bd,
+                                reinterpret_cast<const ohevc_mc_job *>(base + off_mc), (int)c->mc.size(), c->stream);
+        if (rc != OHEVC_OK) return rc;
+        c->stats.launches++;
+    }
+    // ---- phase 2..: level 0 = residuals of inter blocks; level L >= 1 = intra prediction of level L, then its residuals
+    int max_level = c->intra.empty() ? 0 : c->intra.rbegin()->first;
+    if (!c->tu.empty()) max_level = std::max(max_level, (int)(c->tu.rbegin()->first >> 8));
+    auto tu_it = c->tu.begin();
+    for (int level = 0; level <= max_level; level++) {
+        auto it = c->intra.find(level);
+        if (it != c->intra.end()) {
+            rc = ohevc_dev_intra_batch(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + off_intra[level]),
+                                       (int)it->second.size(), c->stream);
+            if (rc != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
+        for (; tu_it != c->tu.end() && (int)(tu_it->first >> 8) == level; ++tu_it) {
+            const int log2 = (tu_it->first >> 4) & 15, kind = tu_it->first & 15;
+            rc = ohevc_dev_tu_batch(p->planes, p->bd, log2, kind, reinterpret_cast<const ohevc_tu_job *>(base + off_tu[tu_it->first]),
+                                    (int)tu_it->second.size(), d_coeffs, c->stream);
+            if (rc != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
+    }
+    c->stats.intra_levels = std::max(c->stats.intra_levels, max_level);
+    clear_recorded(c);
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_frame_end(ohevc_ctx *c)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    int rc = ohevc_frame_reconstruct(c);
+    if (rc != OHEVC_OK) return rc;
+    if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty()) {
+        std::vector<std::pair<const void *, size_t>> parts;
+        size_t total = 0;
+        const size_t off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
+        const size_t off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
+        const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
+        if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
+        unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
+        // all vertical edges, then all horizontal edges: deblocking_filter_CTB, hevc_filter.c:385-580
+        if (!c->dbk_v.empty()) {
+            if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_v), (int)c->dbk_v.size(), c->stream)) != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
+        if (!c->dbk_h.empty()) {
+            if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_h), (int)c->dbk_h.size(), c->stream)) != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
+        if (!c->sao.empty()) {
+            // SAO reads a deblocked copy and writes the picture: sao_filter_CTB, hevc_filter.c:269-315
+            if (!c->twin.used || c->twin.w != p->w || c->twin.h != p->h || c->twin.cfi != p->cfi || c->twin.bd != p->bd) {
+                OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->twin.used && (rc = free_picture(c->twin)) != OHEVC_OK) return rc;
+                if ((rc = alloc_picture(c->twin, p->w, p->h, p->cfi, p->bd)) != OHEVC_OK) return rc;
+            }
+            for (int i = 0; i < 3; i++)
+                OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
+                                             hipMemcpyDeviceToDevice, c->stream));
+            if ((rc = ohevc_dev_sao_batch(p->planes, c->twin.planes, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), c->stream)) != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
+        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear();
+    }
+    c->last_stats = c->stats;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_frame_get_stats(ohevc_ctx *c, ohevc_frame_stats *out)
+{
+    OHEVC_REQUIRE(c != nullptr && out != nullptr, "bad argument");
+    *out = c->last_stats;
+    return OHEVC_OK;
+}

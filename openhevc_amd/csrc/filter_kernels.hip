@@ -93,7 +93,12 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, co
     const int sstride = PLANE_STRIDE3(src, jb.plane), dstride = PLANE_STRIDE3(dst, jb.plane);
     const unsigned char *sbase = PLANE_PTR3(src, jb.plane) + (size_t)jb.y * sstride + (size_t)jb.x * sizeof(Pixel);
     unsigned char *dbase = PLANE_PTR3(dst, jb.plane) + (size_t)jb.y * dstride + (size_t)jb.x * sizeof(Pixel);
-#define SRC(x, y) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(y) * sstride + (ptrdiff_t)(x) * (int)sizeof(Pixel)))
+    // neighbours outside the plane are never allowed to matter (picture-border samples get offset_val[0], :419-455; the
+    // reference reads its frame padding there): clamp the coordinate instead of reading out of bounds
+    const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; };
+#define SRC(x, y) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(clampi(jb.y + (y), ph - 1) - jb.y) * sstride + \
+                                                          (ptrdiff_t)(clampi(jb.x + (x), pw - 1) - jb.x) * (int)sizeof(Pixel)))
     if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
         const int shift = bit_depth - 5;
         for (int idx = threadIdx.x; idx < w * h; idx += 256) {

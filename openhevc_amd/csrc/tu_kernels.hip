@@ -262,8 +262,62 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
     for (int k = 0; k < N; k++) t[k] >>= shift2;
 
     // ---- D. residual row + prediction row -> plane
-    if constexpr (!(VARIANT & 1)) load_row<N, Pixel>(row, px, valid);
-    finish_row<N, Pixel>(row, px, t, bit_depth, valid);
+    if constexpr ((VARIANT & 16) && LOG2N >= 4) {
+        // Coalesced epilogue: the wave's 64/N blocks form one 64-sample-wide strip.  Residual rows go to LDS as int16
+        // (natural order), then lane L takes 16 bytes of pixels of row L / CPR: one wave instruction covers RPI whole
+        // rows of the strip, i.e. full 64-byte (8-bit) / 128-byte (16-bit) segments per row instead of 16-byte pieces.
+        constexpr int ORS = 144;                               // 128 bytes of int16 per strip row + 16 pad
+        constexpr int PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 64 / CH_PX, RPI = 64 / CPR, ITER = N / RPI;
+        static_assert(N * ORS <= L::WAVE_BYTES, "output strip must fit the wave tile");
+        unsigned char *wbase = lds + wave * L::WAVE_BYTES;
+        __builtin_amdgcn_wave_barrier();
+        {
+            u32x4 *d = reinterpret_cast<u32x4 *>(wbase + i * ORS + g * (N * 2));
+#pragma unroll
+            for (int q = 0; q < N / 8; q++) {
+                u32x4 v = { sat_pack_i16(t[8 * q], t[8 * q + 1]), sat_pack_i16(t[8 * q + 2], t[8 * q + 3]),
+                            sat_pack_i16(t[8 * q + 4], t[8 * q + 5]), sat_pack_i16(t[8 * q + 6], t[8 * q + 7]) };
+                d[q] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int c = lane % CPR, r0 = lane / CPR;
+        const int gsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+        const unsigned oxy = __shfl(jraw.x, gsel * N), opl = __shfl(jraw.y, gsel * N) & 0xff;
+        const bool ovalid = job0 + gsel < njobs;
+        const int ostride = PLANE_STRIDE3(planes, opl);
+        unsigned char *obase = PLANE_PTR3(planes, opl) + (size_t)(oxy >> 16) * ostride + (size_t)((oxy & 0xffff) + pxoff) * PXB;
+        const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            const int rr = r0 + k * RPI;
+            u32x4 pr = { 0, 0, 0, 0 };
+            if (ovalid) pr = *reinterpret_cast<const u32x4 *>(obase + (size_t)rr * ostride);
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(wbase + rr * ORS + c * CH_PX * 2);
+            u32x4 o;
+            if constexpr (PXB == 1) {
+                const u32x4 ra = rp[0], rb = rp[1];
+                const unsigned res[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+                const unsigned pd[4] = { pr.x, pr.y, pr.z, pr.w };
+                unsigned od[4];
+#pragma unroll
+                for (int d4 = 0; d4 < 4; d4++) {
+                    const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
+                    const unsigned s01 = add_clamp_px2(res[2 * d4], u01, max2), s23 = add_clamp_px2(res[2 * d4 + 1], u23, max2);
+                    od[d4] = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+                }
+                o = u32x4{ od[0], od[1], od[2], od[3] };
+            } else {
+                const u32x4 ra = rp[0];
+                o = u32x4{ add_clamp_px2(ra.x, pr.x, max2), add_clamp_px2(ra.y, pr.y, max2),
+                           add_clamp_px2(ra.z, pr.z, max2), add_clamp_px2(ra.w, pr.w, max2) };
+            }
+            if (ovalid) *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
+        }
+    } else {
+        if constexpr (!(VARIANT & 1)) load_row<N, Pixel>(row, px, valid);
+        finish_row<N, Pixel>(row, px, t, bit_depth, valid);
+    }
 }
 
 // ------------------------------------------------------------------ persistent, software-pipelined form
@@ -490,6 +544,10 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
         case 8: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 8>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         case 9: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 9>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         }
+        return;
+    }
+    if (g_tu_variant & 16) {
+        hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         return;
     }
     switch (g_tu_variant & 3) {

@@ -164,3 +164,99 @@ def intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cands):
                                               C.c_int(mode), C.c_int(bl), C.c_int(lf), C.c_int(ul), C.c_int(up), C.c_int(ur),
                                               out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+# ---------------------------------------------------------------- ctx layer (include/ohevc_ctx.h)
+class FrameStats(C.Structure):
+    _fields_ = [("launches", C.c_int32), ("intra_levels", C.c_int32), ("upload_bytes", C.c_int64),
+                ("n_tu", C.c_int32), ("n_mc", C.c_int32), ("n_intra", C.c_int32), ("n_dbk", C.c_int32), ("n_sao", C.c_int32)]
+
+
+EXPORTED_SYMBOLS += ["ohevc_ctx_create", "ohevc_ctx_destroy", "ohevc_ctx_stream", "ohevc_ctx_sync", "ohevc_pic_alloc",
+                     "ohevc_pic_release", "ohevc_pic_upload", "ohevc_pic_download", "ohevc_pic_planes", "ohevc_frame_begin",
+                     "ohevc_rec_tu", "ohevc_rec_mc", "ohevc_rec_intra", "ohevc_rec_deblock", "ohevc_rec_sao",
+                     "ohevc_frame_reconstruct", "ohevc_frame_end", "ohevc_frame_get_stats"]
+
+
+class Ctx:
+    """Thin wrapper over ohevc_ctx_* (one decoding thread's device context)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.lib.ohevc_ctx_stream.restype = C.c_void_p
+        self.h = C.c_void_p()
+        check(self.lib.ohevc_ctx_create(C.byref(self.h), C.c_int(device)))
+
+    def close(self):
+        if self.h:
+            self.lib.ohevc_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.ohevc_ctx_sync(self.h))
+
+    def pic_alloc(self, width, height, chroma_format_idc, bit_depth):
+        slot = self.lib.ohevc_pic_alloc(self.h, width, height, chroma_format_idc, bit_depth)
+        if slot < 0:
+            check(slot)
+        return slot
+
+    def pic_release(self, slot):
+        check(self.lib.ohevc_pic_release(self.h, slot))
+
+    def pic_upload(self, slot, planes):
+        for i, p in enumerate(planes):
+            p = np.ascontiguousarray(p)
+            check(self.lib.ohevc_pic_upload(self.h, slot, i, p.ctypes.data_as(C.c_void_p), C.c_ssize_t(p.strides[0])))
+
+    def pic_download(self, slot, shapes, dtype):
+        out = []
+        for i, shp in enumerate(shapes):
+            a = np.zeros(shp, dtype)
+            check(self.lib.ohevc_pic_download(self.h, slot, i, a.ctypes.data_as(C.c_void_p), C.c_ssize_t(a.strides[0])))
+            out.append(a)
+        return out
+
+    def pic_planes(self, slot):
+        arr = (Plane * 3)()
+        check(self.lib.ohevc_pic_planes(self.h, slot, arr))
+        return arr
+
+    def frame_begin(self, slot):
+        check(self.lib.ohevc_frame_begin(self.h, slot))
+
+    def rec_tu(self, plane, x, y, log2, kind, coeffs, intra):
+        c = np.ascontiguousarray(coeffs, dtype=np.int16)
+        check(self.lib.ohevc_rec_tu(self.h, plane, x, y, log2, kind, c.ctypes.data_as(C.c_void_p), int(intra)))
+
+    def _rec(self, fn, job):
+        check(fn(self.h, job.ctypes.data_as(C.c_void_p)))
+
+    def rec_mc(self, job):
+        self._rec(self.lib.ohevc_rec_mc, job)
+
+    def rec_intra(self, job):
+        self._rec(self.lib.ohevc_rec_intra, job)
+
+    def rec_deblock(self, job):
+        self._rec(self.lib.ohevc_rec_deblock, job)
+
+    def rec_sao(self, job):
+        self._rec(self.lib.ohevc_rec_sao, job)
+
+    def frame_reconstruct(self):
+        check(self.lib.ohevc_frame_reconstruct(self.h))
+
+    def frame_end(self):
+        check(self.lib.ohevc_frame_end(self.h))
+
+    def stats(self):
+        st = FrameStats()
+        check(self.lib.ohevc_frame_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in FrameStats._fields_}

@@ -1,0 +1,111 @@
+"""Execute a tools/synth_stream.py op list two ways: on the CPU oracle strictly in decode order, and through the GPU
+ctx layer (which reorders into phases).  Shared by the ctx parity test and the frame-pipeline bench."""
+import numpy as np
+
+from openhevc_amd import lib as L
+
+
+def chroma_dims(W, H):
+    return [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+
+
+def mc_params(op, c_idx):
+    """(x, y, w, h, [(sx, sy, mx, my) per ref]) in plane samples -- luma_mc_*/chroma_mc_* (hevc.c:1641-1949), 4:2:0."""
+    sh = 1 if c_idx else 0
+    x, y, w, h = op["x0"] >> sh, op["y0"] >> sh, op["w"] >> sh, op["h"] >> sh
+    refs = []
+    for (mvx, mvy) in op["mv"]:
+        refs.append((x + (mvx >> (2 + sh)), y + (mvy >> (2 + sh)), mvx & (7 if sh else 3), mvy & (7 if sh else 3)))
+    return x, y, w, h, refs
+
+
+def window(ref_plane, sx, sy, w, h, taps):
+    before, after = (3, 4) if taps == 8 else (1, 2)
+    rows = np.clip(np.arange(sy - before, sy + h + after), 0, ref_plane.shape[0] - 1)
+    cols = np.clip(np.arange(sx - before, sx + w + after), 0, ref_plane.shape[1] - 1)
+    return np.ascontiguousarray(ref_plane[rows][:, cols]), before
+
+
+def run_oracle(oracle, po, bd, W, H, cur, refs, ops, fops):
+    """cur: list of 3 planes (modified in place and returned), refs: list of [3 planes]."""
+    for op in ops:
+        if op["t"] == "mc":
+            for c_idx in range(3):
+                x, y, w, h, rp = mc_params(op, c_idx)
+                luma = c_idx == 0
+                kw = dict(denom=op["denom"], wx0=op["wx"][0], wx1=op["wx"][1], ox0=op["ox"][0], ox1=op["ox"][1])
+                win0, b = window(refs[op["ref"][0]][c_idx], rp[0][0], rp[0][1], w, h, 8 if luma else 4)
+                if not op["bi"]:
+                    blk = oracle.mc(bd, luma, po.MC_UNI_W if op["weighted"] else po.MC_UNI, win0, b, b, w, h, rp[0][2], rp[0][3], **kw)
+                else:
+                    tmp = oracle.mc(bd, luma, po.MC_PUT, win0, b, b, w, h, rp[0][2], rp[0][3])
+                    src2 = np.zeros((h, 64), np.int16); src2[:, :w] = tmp
+                    win1, b = window(refs[op["ref"][1]][c_idx], rp[1][0], rp[1][1], w, h, 8 if luma else 4)
+                    blk = oracle.mc(bd, luma, po.MC_BI_W if op["weighted"] else po.MC_BI, win1, b, b, w, h, rp[1][2], rp[1][3], src2=src2, **kw)
+                cur[c_idx][y:y + h, x:x + w] = blk
+        elif op["t"] == "tu":
+            sh = 1 if op["c_idx"] else 0
+            xy = np.array([[op["x0"] >> sh, op["y0"] >> sh]], np.int32)
+            oracle.tu_batch(bd, op["kind"], op["log2"], op["coeffs"][None], cur[op["c_idx"]], xy)
+        elif op["t"] == "intra":
+            oracle.intra_pred(bd, cur, W, H, op["x0"], op["y0"], op["log2"], op["c_idx"], op["mode"], op["cands"],
+                              chroma_format_idc=1, strong=1, smoothing_disabled=0, log2_ctb_size=6, log2_min_tb_size=2)
+    for vertical in (1, 0):
+        for op in fops:
+            if op["t"] == "dbk" and op["vertical"] == vertical:
+                if op["c_idx"] == 0:
+                    oracle.deblock_luma(bd, vertical, cur[0], op["x"], op["y"], op["beta"], op["tc"], op["no_p"], op["no_q"])
+                else:
+                    oracle.deblock_chroma(bd, vertical, cur[op["c_idx"]], op["x"], op["y"], op["tc"], op["no_p"], op["no_q"])
+    if any(op["t"] == "sao" for op in fops):
+        src = [np.ascontiguousarray(np.pad(p, 1, mode="edge")) for p in cur]     # deblocked copy (+ ring standing in for frame padding)
+        for op in fops:
+            if op["t"] != "sao":
+                continue
+            c = op["c_idx"]
+            dst = np.ascontiguousarray(np.pad(cur[c], 1, mode="edge"))
+            if op["band"]:
+                oracle.sao_band(bd, dst, src[c], op["x"] + 1, op["y"] + 1, op["w"], op["h"], op["offset_val"], op["klass"])
+            else:
+                oracle.sao_edge(bd, 0, dst, src[c], op["x"] + 1, op["y"] + 1, op["w"], op["h"], op["offset_val"], op["klass"], op["borders"])
+            cur[c][op["y"]:op["y"] + op["h"], op["x"]:op["x"] + op["w"]] = dst[op["y"] + 1:op["y"] + 1 + op["h"], op["x"] + 1:op["x"] + 1 + op["w"]]
+    return cur
+
+
+def record_gpu(ctx, W, H, ref_slots, ops, fops):
+    """Record the op list into an ohevc ctx (frame_begin must have been called)."""
+    geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+    for op in ops:
+        if op["t"] == "mc":
+            for c_idx in range(3):
+                x, y, w, h, rp = mc_params(op, c_idx)
+                j = np.zeros(1, L.MC_JOB)
+                j["x"], j["y"], j["w"], j["h"], j["plane"] = x, y, w, h, c_idx
+                j["flags"] = (L.MC_BI if op["bi"] else 0) | (L.MC_WEIGHTED if op["weighted"] else 0)
+                for s in (0, 1):
+                    j[f"sx{s}"], j[f"sy{s}"], j[f"mx{s}"], j[f"my{s}"] = np.clip(rp[s][0], -32768, 32767), np.clip(rp[s][1], -32768, 32767), rp[s][2], rp[s][3]
+                    j[f"ref{s}"] = ref_slots[op["ref"][s]]
+                    j[f"wx{s}"], j[f"ox{s}"] = op["wx"][s], op["ox"][s]
+                j["denom"] = op["denom"]
+                ctx.rec_mc(j)
+        elif op["t"] == "tu":
+            sh = 1 if op["c_idx"] else 0
+            ctx.rec_tu(op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], op["kind"], op["coeffs"], op["intra"])
+        elif op["t"] == "intra":
+            ctx.rec_intra(L.intra_make_job(geom, op["x0"], op["y0"], op["log2"], op["c_idx"], op["mode"], op["cands"]))
+    for op in fops:
+        if op["t"] == "dbk":
+            j = np.zeros(1, L.DBK_JOB)
+            j["x"], j["y"], j["plane"], j["beta"], j["tc"] = op["x"], op["y"], op["c_idx"], op["beta"], op["tc"]
+            j["flags"] = (L.DBK_VERTICAL_EDGE if op["vertical"] else 0) | (L.DBK_NO_P0 * op["no_p"][0]) | (L.DBK_NO_P1 * op["no_p"][1]) | \
+                         (L.DBK_NO_Q0 * op["no_q"][0]) | (L.DBK_NO_Q1 * op["no_q"][1])
+            ctx.rec_deblock(j)
+        else:
+            j = np.zeros(1, L.SAO_JOB)
+            j["x"], j["y"], j["w"], j["h"], j["plane"] = op["x"], op["y"], op["w"], op["h"], op["c_idx"]
+            j["type"] = L.SAO_BAND if op["band"] else L.SAO_EDGE
+            j["klass"] = op["klass"]
+            b = op["borders"]
+            j["borders"] = b[0] | (b[1] << 1) | (b[2] << 2) | (b[3] << 3)
+            j["offset_val"] = op["offset_val"]
+            ctx.rec_sao(j)

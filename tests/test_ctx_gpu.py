@@ -1,0 +1,75 @@
+"""-m gpu: a whole synthetic picture through the ctx layer (recorder + phase-ordered executor) vs the CPU oracle run
+strictly in decode order.  Validates ordering rules (MC -> inter residual -> intra levels -> V edges -> H edges -> SAO)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from openhevc_amd import lib as L
+import gpu_util as G
+import stream_exec as X
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import synth_stream as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bd,W,H,intra_frac", [(8, 416, 240, 0.15), (10, 192, 136, 0.5), (8, 128, 128, 1.0)])
+def test_synthetic_picture_matches_decode_order_oracle(oracle, bd, W, H, intra_frac):
+    rng = np.random.default_rng(bd * 1000 + W)
+    dt = G.pixdt(bd)
+    dims = X.chroma_dims(W, H)
+    refs = [[rng.integers(0, 1 << bd, size=d).astype(dt) for d in dims] for _ in range(2)]
+    cur0 = [rng.integers(0, 1 << bd, size=d).astype(dt) for d in dims]
+    ops, fops = S.gen_frame_ops(rng, W, H, bd, n_refs=2, intra_frac=intra_frac)
+    want = X.run_oracle(oracle, po, bd, W, H, [p.copy() for p in cur0], refs, ops, fops)
+
+    ctx = L.Ctx(0)
+    ref_slots = []
+    for r in refs:
+        s = ctx.pic_alloc(W, H, 1, bd); ctx.pic_upload(s, r); ref_slots.append(s)
+    cur = ctx.pic_alloc(W, H, 1, bd)
+    ctx.pic_upload(cur, cur0)
+    ctx.frame_begin(cur)
+    X.record_gpu(ctx, W, H, ref_slots, ops, fops)
+    ctx.frame_end()
+    got = ctx.pic_download(cur, dims, dt)
+    st = ctx.stats()
+    ctx.close()
+    assert st["n_mc"] + st["n_intra"] > 0 and st["launches"] > 0
+    for c in range(3):
+        bad = np.argwhere(got[c] != want[c])
+        assert bad.size == 0, f"plane {c}: {len(bad)} mismatches, first {bad[:4].tolist()}; stats {st}"
+
+
+def test_reconstruct_in_several_flushes(oracle):
+    """Calling ohevc_frame_reconstruct after every CTU row (the reference's natural flush point) gives the same picture."""
+    bd, W, H = 8, 256, 192
+    rng = np.random.default_rng(99)
+    dims = X.chroma_dims(W, H)
+    refs = [[rng.integers(0, 256, size=d).astype(np.uint8) for d in dims] for _ in range(2)]
+    cur0 = [rng.integers(0, 256, size=d).astype(np.uint8) for d in dims]
+    ops, fops = S.gen_frame_ops(rng, W, H, bd, intra_frac=0.4)
+    want = X.run_oracle(oracle, po, bd, W, H, [p.copy() for p in cur0], refs, ops, [])
+    ctx = L.Ctx(0)
+    slots = []
+    for r in refs:
+        s = ctx.pic_alloc(W, H, 1, bd); ctx.pic_upload(s, r); slots.append(s)
+    cur = ctx.pic_alloc(W, H, 1, bd); ctx.pic_upload(cur, cur0)
+    ctx.frame_begin(cur)
+    row = 0
+    chunk = []
+    for op in ops:
+        r = op["y0"] // 64
+        if r != row:
+            X.record_gpu(ctx, W, H, slots, chunk, []); ctx.frame_reconstruct(); chunk = []; row = r
+        chunk.append(op)
+    X.record_gpu(ctx, W, H, slots, chunk, [])
+    ctx.frame_end()
+    got = ctx.pic_download(cur, dims, np.uint8)
+    ctx.close()
+    for c in range(3):
+        assert np.array_equal(got[c], want[c]), c
