@@ -8,7 +8,10 @@ extern "C" {
 /* Selects the variant of the 8x8..32x32 IDCT+add kernel used by ohevc_dev_tu_batch (results are identical):
  * bit 0: prefetch the prediction row before the transform; bit 1: read coefficients straight from HBM as int16
  * columns instead of staging 16-byte chunks through LDS; bit 2: persistent waves that prefetch the next blocks'
- * coefficients into registers while transforming the current ones.  Returns the previous value; 0 is the shipped default. */
+ * coefficients into registers while transforming the current ones; bit 3: cap that kernel at 5 waves/SIMD; bit 4:
+ * LDS-transposed epilogue (full 64/128-byte row segments per wave instruction).  Bits 5/6 select ABLATION kernels that
+ * keep the memory traffic but drop the transform (bit 5: also drop the LDS passes) -- their output is NOT correct;
+ * they exist only to locate the bottleneck.  Returns the previous value; 0 is the shipped default. */
 int ohevc_debug_set_tu_variant(int variant);
 /* bit 2 of the variant selects the persistent, software-pipelined kernel; this sets its grid size (workgroups). */
 int ohevc_debug_set_tu_pipe_workgroups(int n);

@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, co
     // reference reads its frame padding there): clamp the coordinate instead of reading out of bounds
     const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
     auto clampi = [](int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; };
-#define SRC(x, y) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(clampi(jb.y + (y), ph - 1) - jb.y) * sstride + \
-                                                          (ptrdiff_t)(clampi(jb.x + (x), pw - 1) - jb.x) * (int)sizeof(Pixel)))
+    const int bx = jb.x, by = jb.y;
+#define SRC(px_, py_) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(clampi(by + (py_), ph - 1) - by) * sstride + \
+                                                              (ptrdiff_t)(clampi(bx + (px_), pw - 1) - bx) * (int)sizeof(Pixel)))
     if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
         const int shift = bit_depth - 5;
         for (int idx = threadIdx.x; idx < w * h; idx += 256) {

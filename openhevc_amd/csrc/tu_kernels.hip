@@ -320,6 +320,70 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
     }
 }
 
+// ------------------------------------------------------------------ ablations (NOT bit-exact; bottleneck analysis only)
+// MODE 0: same loads/stores as tu_idct_add_kernel but no LDS and no transform: lane i adds row i of the raw
+//         coefficients to prediction row i  -> the memory-pattern ceiling of the lane-per-row layout.
+// MODE 1: as MODE 0 but with the LDS staging/transposes kept (transform arithmetic removed).
+template <int LOG2N, typename Pixel, int MODE>
+__global__ __launch_bounds__(256) void tu_ablation_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
+                                                          int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    using L = TuLayout<LOG2N>;
+    constexpr int N = L::N, RS = L::RS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * L::WAVE_BYTES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / N, i = lane % N;
+    const int job0 = (blockIdx.x * 4 + wave) * L::BPW;
+    if (job0 >= njobs) return;
+    const bool valid = job0 + g < njobs;
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[valid ? job0 + g : njobs - 1];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
+    unsigned char *row = PLANE_PTR3(planes, jplane) + (size_t)(jy + i) * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
+    int t[N];
+    if constexpr (MODE == 0) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + jraw.z + i * N);
+#pragma unroll
+        for (int q = 0; q < N / 8; q++) {
+            const u32x4 v = src[q];
+            const unsigned d[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) { t[8 * q + 2 * k] = (int)(short)(d[k] & 0xffffu) >> 4; t[8 * q + 2 * k + 1] = (int)d[k] >> 20; }
+        }
+    } else {
+        unsigned char *blk = lds + wave * L::WAVE_BYTES + g * L::BLK;
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + jraw.z);
+#pragma unroll
+        for (int q = 0; q < N / 8; q++) {
+            const int c = q * N + i;
+            *reinterpret_cast<u32x4 *>(blk + (c / (N / 8)) * RS + (c % (N / 8)) * 16) = src[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned p[N / 2];
+        constexpr PairTab<N> pt{};
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(blk) + i;
+#pragma unroll
+        for (int m = 0; m < N / 2; m++)
+            p[m] = (unsigned)col[pt.lo[m] * (RS / 2)] | ((unsigned)col[pt.hi[m] * (RS / 2)] << 16);
+        __builtin_amdgcn_wave_barrier();
+        unsigned short *dst = reinterpret_cast<unsigned short *>(blk) + slot_of_rt(N, i);
+#pragma unroll
+        for (int r = 0; r < N; r += 2) {
+            dst[r * (RS / 2)]       = (unsigned short)(p[r / 2] & 0xffffu);
+            dst[(r + 1) * (RS / 2)] = (unsigned short)(p[r / 2] >> 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const u32x4 *rowp = reinterpret_cast<const u32x4 *>(blk + i * RS);
+#pragma unroll
+        for (int q = 0; q < N / 8; q++) {
+            const u32x4 v = rowp[q];
+            const unsigned d[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) { t[8 * q + 2 * k] = (int)(short)(d[k] & 0xffffu) >> 4; t[8 * q + 2 * k + 1] = (int)d[k] >> 20; }
+        }
+    }
+    add_row_store<N, Pixel>(row, t, bit_depth, valid);
+}
+
 // ------------------------------------------------------------------ persistent, software-pipelined form
 // Same arithmetic as tu_idct_add_kernel.  Each wavefront walks the job list with a grid-sized stride and keeps
 // the NEXT iteration's coefficients (16 bytes x N/8 per lane) and the job record after that in flight in
@@ -544,6 +608,11 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
         case 8: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 8>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         case 9: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 9>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         }
+        return;
+    }
+    if (g_tu_variant & 96) {          // ablations: 32 = no LDS / no transform, 64 = LDS traffic kept, no transform
+        if (g_tu_variant & 32) hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        else                   hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         return;
     }
     if (g_tu_variant & 16) {
