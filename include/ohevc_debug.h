@@ -11,7 +11,7 @@ extern "C" {
  * coefficients into registers while transforming the current ones; bit 3: cap that kernel at 5 waves/SIMD; bit 4:
  * LDS-transposed epilogue (full 64/128-byte row segments per wave instruction).  Bits 5/6 select ABLATION kernels that
  * keep the memory traffic but drop the transform (bit 5: also drop the LDS passes) -- their output is NOT correct;
- * they exist only to locate the bottleneck.  Returns the previous value; 0 is the shipped default. */
+ * they exist only to locate the bottleneck.  Returns the previous value; -1 restores the shipped default (coalesced epilogue for 16x16/32x32, prefetch for 8x8). */
 int ohevc_debug_set_tu_variant(int variant);
 /* bit 2 of the variant selects the persistent, software-pipelined kernel; this sets its grid size (workgroups). */
 int ohevc_debug_set_tu_pipe_workgroups(int n);

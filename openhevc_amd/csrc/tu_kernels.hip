@@ -594,15 +594,18 @@ __global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohe
 }
 
 // ------------------------------------------------------------------ launcher
-int g_tu_variant = 0;     // set through ohevc_debug_set_tu_variant(); 0 = shipped configuration
+int g_tu_variant = -1;    // set through ohevc_debug_set_tu_variant(); -1 = shipped configuration (see launch_idct)
 int g_tu_pipe_wgs = 2048; // workgroups of the persistent form (ohevc_debug_set_tu_pipe_workgroups)
 
 template <int LOG2N, typename Pixel>
 static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
 {
-    if (g_tu_variant & 4) {
+    // shipped configuration (A/B on MI355X, profiles/r01_ab_tu_variants.txt): LDS-transposed, fully coalesced
+    // epilogue for 16x16 / 32x32; early prediction prefetch for 8x8
+    const int variant = g_tu_variant >= 0 ? g_tu_variant : (LOG2N >= 4 ? 16 : 1);
+    if (variant & 4) {
         const int pgrid = grid < g_tu_pipe_wgs ? grid : g_tu_pipe_wgs;
-        switch (g_tu_variant & 9) {
+        switch (variant & 9) {
         case 0: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 0>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         case 1: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 1>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         case 8: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 8>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
@@ -610,16 +613,16 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
         }
         return;
     }
-    if (g_tu_variant & 96) {          // ablations: 32 = no LDS / no transform, 64 = LDS traffic kept, no transform
-        if (g_tu_variant & 32) hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+    if (variant & 96) {          // ablations: 32 = no LDS / no transform, 64 = LDS traffic kept, no transform
+        if (variant & 32) hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         else                   hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         return;
     }
-    if (g_tu_variant & 16) {
+    if (variant & 16) {
         hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         return;
     }
-    switch (g_tu_variant & 3) {
+    switch (variant & 3) {
     case 0: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
     case 1: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
     case 2: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 2>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;

@@ -74,7 +74,7 @@ def main():
         print(f"{n}x{n} {bd}-bit identical={same} " + " ".join(f"v{v}:{row[f'v{v}']['GBps_median']}GB/s" for v in variants), flush=True)
         del plane0, coeffs, d_jobs, work
         torch.cuda.empty_cache()
-    select("0")
+    select("-1")
     print(json.dumps(results))
 
 

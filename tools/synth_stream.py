@@ -139,7 +139,8 @@ def gen_frame_ops(rng, W, H, bd, n_refs=2, intra_frac=0.15, bi_frac=0.6, coded_f
                 cand_up_left = ctb_up_left if (not x0b and not y0b) else (cand_left and cand_up)
                 sap = (ctb_up_right and not y0b) if (x0b + n_l) == ctb else cand_up
                 cand_up_right = bool(sap and (x0 + n_l) < W)
-                cand_bottom_left = False if (y0 + n_l) >= H else cand_left
+                # lc->end_of_tiles_y = FFMIN(y_ctb + ctb_size, height): the bottom of the CURRENT CTB (hevc.c:2619)
+                cand_bottom_left = False if (y0 + n_l) >= min(cty + ctb, H) else cand_left
                 ops.append(dict(t="intra", x0=x0, y0=y0, log2=log2, c_idx=c_idx, mode=mode,
                                 cands=[int(cand_bottom_left), int(cand_left), int(cand_up_left), int(cand_up), int(cand_up_right)]))
 
