@@ -52,6 +52,16 @@ int  ohevc_rec_intra(ohevc_ctx *ctx, const ohevc_intra_job *job);
 int  ohevc_rec_deblock(ohevc_ctx *ctx, const ohevc_dbk_job *job);
 int  ohevc_rec_sao(ohevc_ctx *ctx, const ohevc_sao_job *job);
 
+/* Bulk forms (one call per CTU row / frame instead of one per block).  Records of different kinds may be handed over
+ * in any order EXCEPT that a block's intra job must be recorded before its residual (the residual inherits the
+ * prediction's dependency level).  ohevc_rec_tu_bulk: desc = n x {plane, x, y, log2_size, kind, intra} (int32 each),
+ * coeffs = the n dense blocks back to back (N*N int16 each, also for OHEVC_TU_DC, which reads only [0]). */
+int  ohevc_rec_mc_bulk(ohevc_ctx *ctx, const ohevc_mc_job *jobs, int n);
+int  ohevc_rec_intra_bulk(ohevc_ctx *ctx, const ohevc_intra_job *jobs, int n);
+int  ohevc_rec_tu_bulk(ohevc_ctx *ctx, int n, const int32_t *desc, const int16_t *coeffs);
+int  ohevc_rec_deblock_bulk(ohevc_ctx *ctx, const ohevc_dbk_job *jobs, int n);
+int  ohevc_rec_sao_bulk(ohevc_ctx *ctx, const ohevc_sao_job *jobs, int n);
+
 /* upload + launch prediction/residual work recorded so far (may be called several times per frame) */
 int  ohevc_frame_reconstruct(ohevc_ctx *ctx);
 /* reconstruct + in-loop filters (vertical edges, horizontal edges, SAO); the picture is final when this returns OK

@@ -307,6 +307,39 @@ extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_rec_mc_bulk(ohevc_ctx *c, const ohevc_mc_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++) { int rc = ohevc_rec_mc(c, jobs + i); if (rc != OHEVC_OK) return rc; }
+    return OHEVC_OK;
+}
+extern "C" int ohevc_rec_intra_bulk(ohevc_ctx *c, const ohevc_intra_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++) { int rc = ohevc_rec_intra(c, jobs + i); if (rc != OHEVC_OK) return rc; }
+    return OHEVC_OK;
+}
+extern "C" int ohevc_rec_tu_bulk(ohevc_ctx *c, int n, const int32_t *desc, const int16_t *coeffs)
+{
+    OHEVC_REQUIRE(n == 0 || (desc != nullptr && coeffs != nullptr), "null argument");
+    for (int i = 0; i < n; i++) {
+        const int32_t *d = desc + 6 * i;
+        OHEVC_REQUIRE(d[3] >= 2 && d[3] <= 5, "bad TU size");
+        int rc = ohevc_rec_tu(c, d[0], d[1], d[2], d[3], d[4], coeffs, d[5]);
+        if (rc != OHEVC_OK) return rc;
+        coeffs += 1 << (2 * d[3]);
+    }
+    return OHEVC_OK;
+}
+extern "C" int ohevc_rec_deblock_bulk(ohevc_ctx *c, const ohevc_dbk_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++) { int rc = ohevc_rec_deblock(c, jobs + i); if (rc != OHEVC_OK) return rc; }
+    return OHEVC_OK;
+}
+extern "C" int ohevc_rec_sao_bulk(ohevc_ctx *c, const ohevc_sao_job *jobs, int n)
+{
+    for (int i = 0; i < n; i++) { int rc = ohevc_rec_sao(c, jobs + i); if (rc != OHEVC_OK) return rc; }
+    return OHEVC_OK;
+}
+
 // copy `bytes` of host data into the staging buffer at a 256-byte aligned offset; returns that offset
 static size_t stage_put(std::vector<std::pair<const void *, size_t>> &parts, size_t &total, const void *src, size_t bytes)
 {

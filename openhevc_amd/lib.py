@@ -175,7 +175,8 @@ class FrameStats(C.Structure):
 EXPORTED_SYMBOLS += ["ohevc_ctx_create", "ohevc_ctx_destroy", "ohevc_ctx_stream", "ohevc_ctx_sync", "ohevc_pic_alloc",
                      "ohevc_pic_release", "ohevc_pic_upload", "ohevc_pic_download", "ohevc_pic_planes", "ohevc_frame_begin",
                      "ohevc_rec_tu", "ohevc_rec_mc", "ohevc_rec_intra", "ohevc_rec_deblock", "ohevc_rec_sao",
-                     "ohevc_frame_reconstruct", "ohevc_frame_end", "ohevc_frame_get_stats"]
+                     "ohevc_frame_reconstruct", "ohevc_frame_end", "ohevc_frame_get_stats", "ohevc_rec_mc_bulk",
+                     "ohevc_rec_intra_bulk", "ohevc_rec_tu_bulk", "ohevc_rec_deblock_bulk", "ohevc_rec_sao_bulk"]
 
 
 class Ctx:
@@ -249,6 +250,21 @@ class Ctx:
 
     def rec_sao(self, job):
         self._rec(self.lib.ohevc_rec_sao, job)
+
+    def rec_bulk(self, mc=None, intra=None, tu_desc=None, tu_coeffs=None, dbk=None, sao=None):
+        """Bulk recording from numpy arrays (job dtypes above; tu_desc int32 [n,6], tu_coeffs int16 concatenated)."""
+        def ptr(a):
+            return a.ctypes.data_as(C.c_void_p)
+        if mc is not None and len(mc):
+            check(self.lib.ohevc_rec_mc_bulk(self.h, ptr(mc), len(mc)))
+        if intra is not None and len(intra):
+            check(self.lib.ohevc_rec_intra_bulk(self.h, ptr(intra), len(intra)))
+        if tu_desc is not None and len(tu_desc):
+            check(self.lib.ohevc_rec_tu_bulk(self.h, len(tu_desc), ptr(tu_desc), ptr(tu_coeffs)))
+        if dbk is not None and len(dbk):
+            check(self.lib.ohevc_rec_deblock_bulk(self.h, ptr(dbk), len(dbk)))
+        if sao is not None and len(sao):
+            check(self.lib.ohevc_rec_sao_bulk(self.h, ptr(sao), len(sao)))
 
     def frame_reconstruct(self):
         check(self.lib.ohevc_frame_reconstruct(self.h))

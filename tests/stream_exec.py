@@ -109,3 +109,49 @@ def record_gpu(ctx, W, H, ref_slots, ops, fops):
             j["borders"] = b[0] | (b[1] << 1) | (b[2] << 2) | (b[3] << 3)
             j["offset_val"] = op["offset_val"]
             ctx.rec_sao(j)
+
+
+def ops_to_arrays(W, H, ref_slots, ops, fops):
+    """Convert an op list into the numpy job arrays ohevc_rec_*_bulk take (intra jobs go through ohevc_intra_make_job)."""
+    geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+    mc, intra, desc, coeffs, dbk, sao = [], [], [], [], [], []
+    for op in ops:
+        if op["t"] == "mc":
+            for c_idx in range(3):
+                x, y, w, h, rp = mc_params(op, c_idx)
+                j = np.zeros(1, L.MC_JOB)[0]
+                j["x"], j["y"], j["w"], j["h"], j["plane"] = x, y, w, h, c_idx
+                j["flags"] = (L.MC_BI if op["bi"] else 0) | (L.MC_WEIGHTED if op["weighted"] else 0)
+                for s in (0, 1):
+                    j[f"sx{s}"], j[f"sy{s}"] = np.clip(rp[s][0], -32768, 32767), np.clip(rp[s][1], -32768, 32767)
+                    j[f"mx{s}"], j[f"my{s}"] = rp[s][2], rp[s][3]
+                    j[f"ref{s}"] = ref_slots[op["ref"][s]]
+                    j[f"wx{s}"], j[f"ox{s}"] = op["wx"][s], op["ox"][s]
+                j["denom"] = op["denom"]
+                mc.append(j)
+        elif op["t"] == "tu":
+            sh = 1 if op["c_idx"] else 0
+            desc.append([op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], op["kind"], op["intra"]])
+            coeffs.append(np.ascontiguousarray(op["coeffs"], dtype=np.int16).reshape(-1))
+        else:
+            intra.append(L.intra_make_job(geom, op["x0"], op["y0"], op["log2"], op["c_idx"], op["mode"], op["cands"])[0])
+    for op in fops:
+        if op["t"] == "dbk":
+            j = np.zeros(1, L.DBK_JOB)[0]
+            j["x"], j["y"], j["plane"], j["beta"], j["tc"] = op["x"], op["y"], op["c_idx"], op["beta"], op["tc"]
+            j["flags"] = (L.DBK_VERTICAL_EDGE if op["vertical"] else 0) | (L.DBK_NO_P0 * op["no_p"][0]) | (L.DBK_NO_P1 * op["no_p"][1]) | \
+                         (L.DBK_NO_Q0 * op["no_q"][0]) | (L.DBK_NO_Q1 * op["no_q"][1])
+            dbk.append(j)
+        else:
+            j = np.zeros(1, L.SAO_JOB)[0]
+            j["x"], j["y"], j["w"], j["h"], j["plane"] = op["x"], op["y"], op["w"], op["h"], op["c_idx"]
+            j["type"] = L.SAO_BAND if op["band"] else L.SAO_EDGE
+            j["klass"] = op["klass"]
+            b = op["borders"]
+            j["borders"] = b[0] | (b[1] << 1) | (b[2] << 2) | (b[3] << 3)
+            j["offset_val"] = op["offset_val"]
+            sao.append(j)
+    return dict(mc=np.array(mc, dtype=L.MC_JOB), intra=np.array(intra, dtype=L.INTRA_JOB),
+                tu_desc=np.array(desc, dtype=np.int32).reshape(-1, 6),
+                tu_coeffs=np.concatenate(coeffs) if coeffs else np.zeros(0, np.int16),
+                dbk=np.array(dbk, dtype=L.DBK_JOB), sao=np.array(sao, dtype=L.SAO_JOB))
