@@ -1,0 +1,96 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU layer: unit sharding, wave planning, frame-parallel execution with
+reference-picture broadcast.  'Reconstruction' is a deterministic stand-in (each picture = f(idx, its references)), so any
+missing/late/mis-routed broadcast changes the result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from openhevc_amd import dist as D
+
+
+def fake_reconstruct(idx, refs, out):
+    acc = torch.full_like(out[0], idx * 7 + 1)
+    for r, planes in sorted(refs.items()):
+        acc = acc * 31 + planes[0] * (r + 3)
+    for k, t in enumerate(out):
+        t.copy_((acc[: t.shape[0], : t.shape[1]] + k) % 65521)
+
+
+def sequential(pictures, alloc):
+    dpb = {}
+    for p in pictures:
+        planes = alloc(p.idx)
+        fake_reconstruct(p.idx, {r: dpb[r] for r in p.refs}, planes)
+        dpb[p.idx] = planes
+    return dpb
+
+
+def alloc(idx):
+    return [torch.zeros(12, 16, dtype=torch.int64), torch.zeros(6, 8, dtype=torch.int64), torch.zeros(6, 8, dtype=torch.int64)]
+
+
+def worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init_from_env("gloo")
+    pics = D.hierarchical_gop(3, 8)
+    runner = D.FrameParallelRunner(alloc=alloc, reconstruct=fake_reconstruct)
+    mine = runner.run(pics)
+    want = sequential(pics, alloc)
+    ok = all(torch.equal(t, w) for idx, planes in mine.items() for t, w in zip(planes, want[idx]))
+    ok_dpb = all(torch.equal(t, w) for idx, planes in runner.dpb.items() for t, w in zip(planes, want[idx]))
+    # kernel-level sharding: disjoint cover + max-over-ranks timing reduction as in bench.py
+    lo, hi = D.shard_range(1000003, rank, world)
+    t = torch.tensor([float(hi - lo)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    tmax = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    q.put((rank, ok, ok_dpb, sorted(mine), int(t.item()), float(tmax.item()), runner.broadcast_bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_plan_and_gop_structure():
+    pics = D.hierarchical_gop(2, 8)
+    assert len(pics) == 17 and pics[0].refs == ()
+    waves = D.plan_waves(pics)
+    seen = set()
+    for w in waves:                                   # every picture's references are in earlier waves
+        for idx in w:
+            assert all(r in seen for r in pics[idx].refs)
+        seen.update(w)
+    assert seen == set(range(17))
+    assert sum(1 for p in pics if not p.is_reference) == 8       # the odd-POC leaves
+    assert D.shard_range(10, 0, 3) == (0, 3) and D.shard_range(10, 2, 3) == (6, 10)
+    cover = [D.shard_range(1 << 20, r, 8) for r in range(8)]
+    assert cover[0][0] == 0 and cover[-1][1] == 1 << 20 and all(cover[i][1] == cover[i + 1][0] for i in range(7))
+
+
+@pytest.mark.timeout(120)
+def test_frame_parallel_two_ranks_gloo():
+    world, port = 2, free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    res.sort()
+    owned = []
+    for rank, ok, ok_dpb, mine, total, tmax, bbytes in res:
+        assert ok and ok_dpb, f"rank {rank}: wrong picture contents"
+        assert total == 1000003 and tmax == 2.0
+        assert bbytes > 0
+        owned += mine
+    assert sorted(owned) == list(range(25))           # every picture reconstructed exactly once across ranks
