@@ -41,6 +41,7 @@ int  ohevc_pic_release(ohevc_ctx *ctx, int slot);
 int  ohevc_pic_upload(ohevc_ctx *ctx, int slot, int plane, const void *host, ptrdiff_t host_stride);
 int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff_t host_stride);
 int  ohevc_pic_planes(ohevc_ctx *ctx, int slot, ohevc_plane out[3]);     /* device views (e.g. for an RCCL broadcast) */
+int  ohevc_pic_info(ohevc_ctx *ctx, int slot, int *width, int *height, int *chroma_format_idc, int *bit_depth);
 
 /* ---- per-frame recording */
 int  ohevc_frame_begin(ohevc_ctx *ctx, int slot);

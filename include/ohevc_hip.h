@@ -57,7 +57,9 @@ enum {
     OHEVC_TU_IDCT = 0, OHEVC_TU_DC = 1, OHEVC_TU_DST4 = 2, OHEVC_TU_SKIP = 3,
     OHEVC_TU_SKIP_RDPCM_H = 4, OHEVC_TU_SKIP_RDPCM_V = 5,
     OHEVC_TU_BYPASS = 6, OHEVC_TU_BYPASS_RDPCM_H = 7, OHEVC_TU_BYPASS_RDPCM_V = 8,
-    OHEVC_TU_NKINDS = 9
+    OHEVC_TU_PCM = 9,     /* put_pcm (hevcdsp_template.c:30-43): the arena block holds the N*N samples the host read from
+                             the bitstream, already << (bit_depth - pcm_bit_depth); they REPLACE the block */
+    OHEVC_TU_NKINDS = 10
 };
 
 typedef struct ohevc_tu_job {           /* 16 bytes */

@@ -1,0 +1,123 @@
+/*
+ * ohevc_tables.h -- the drop-in: fillers for the reference's own function-pointer tables.
+ *
+ * The reference selects its kernels by filling HEVCDSPContext / HEVCPredContext / VideoDSPContext once per SPS
+ * (set_sps, hevc.c:421-423) and lets arch back-ends override slots at the end of the init functions
+ * (`if (ARCH_X86) ff_hevcdsp_init_x86(hevcdsp, bit_depth);` hevcdsp.c:1326-1327, hevcpred.c:84).  The functions below
+ * are a third back-end for exactly that hook: after them, every table call RECORDS a job into the calling thread's
+ * ohevc_ctx (include/ohevc_ctx.h) instead of computing on host memory.  INTEGRATION.md shows the three-line patch.
+ *
+ * The structs here mirror the reference's layouts slot for slot (same order, same signatures); they are ABI
+ * declarations, not code.  Only the slots on the hot path are overridden; SHVC up-sampling slots are left as filled
+ * by the reference.
+ *
+ * Pointer arguments are HOST addresses inside the reference's frame buffers; they are translated to (picture slot,
+ * plane, x, y) through the registry fed by ohevc_tables_begin_frame / ohevc_tables_register_picture.
+ */
+#ifndef OHEVC_TABLES_H
+#define OHEVC_TABLES_H
+
+#include "ohevc_ctx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct GetBitContext;
+struct AVFrame;
+struct UpsamplInf;
+struct HEVCWindow;
+
+/* SAOParams, libavcodec/hevc.h:514-523 */
+typedef struct ohevc_SAOParams {
+    uint8_t offset_abs[3][4];
+    uint8_t offset_sign[3][4];
+    uint8_t band_position[3];
+    int16_t offset_val[3][5];
+    uint8_t eo_class[3];
+    uint8_t type_idx[3];
+} ohevc_SAOParams;
+
+/* HEVCDSPContext, libavcodec/hevcdsp.h:44-124 (COM16_C806_EMT == 0, hevc.h:41) */
+typedef struct ohevc_HEVCDSPContext {
+    void (*put_pcm)(uint8_t *dst, ptrdiff_t stride, int width, int height, struct GetBitContext *gb, int pcm_bit_depth);
+    void (*transform_add[4])(uint8_t *dst, int16_t *coeffs, ptrdiff_t stride);
+    void (*transform_skip)(int16_t *coeffs, int16_t log2_size);
+    void (*transform_rdpcm)(int16_t *coeffs, int16_t log2_size, int mode);
+    void (*idct_4x4_luma)(int16_t *coeffs);
+    void (*idct[4])(int16_t *coeffs, int col_limit);
+    void (*idct_dc[4])(int16_t *coeffs);
+    void (*sao_band_filter)(uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, ohevc_SAOParams *sao,
+                            int *borders, int width, int height, int c_idx);
+    void (*sao_edge_filter[2])(uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src, ohevc_SAOParams *sao,
+                               int *borders, int width, int height, int c_idx, uint8_t *vert_edge, uint8_t *horiz_edge,
+                               uint8_t *diag_edge);
+    void (*put_hevc_qpel[10][2][2])(int16_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                    int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_uni[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                        int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_uni_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                          int height, int denom, int wx, int ox, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_bi[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                       int16_t *src2, ptrdiff_t src2stride, int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_qpel_bi_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                         int16_t *src2, ptrdiff_t src2stride, int height, int denom, int wx0, int wx1,
+                                         int ox0, int ox1, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel[10][2][2])(int16_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                    int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_uni[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                        int height, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_uni_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                          int height, int denom, int wx, int ox, intptr_t mx, intptr_t my, int width);
+    void (*put_hevc_epel_bi[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                       int16_t *src2, ptrdiff_t src2stride, int height, intptr_t mx, intptr_t my, int width);
+    /* call order (denom, wx0, wx1, ox0, ox1) as at hevc.c:1940-1948; the reference header permutes the NAMES only */
+    void (*put_hevc_epel_bi_w[10][2][2])(uint8_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride,
+                                         int16_t *src2, ptrdiff_t src2stride, int height, int denom, int wx0, int wx1,
+                                         int ox0, int ox1, intptr_t mx, intptr_t my, int width);
+    void (*hevc_h_loop_filter_luma)(uint8_t *pix, ptrdiff_t stride, int beta, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_v_loop_filter_luma)(uint8_t *pix, ptrdiff_t stride, int beta, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_h_loop_filter_chroma)(uint8_t *pix, ptrdiff_t stride, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_v_loop_filter_chroma)(uint8_t *pix, ptrdiff_t stride, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_h_loop_filter_luma_c)(uint8_t *pix, ptrdiff_t stride, int beta, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_v_loop_filter_luma_c)(uint8_t *pix, ptrdiff_t stride, int beta, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_h_loop_filter_chroma_c)(uint8_t *pix, ptrdiff_t stride, int *tc, uint8_t *no_p, uint8_t *no_q);
+    void (*hevc_v_loop_filter_chroma_c)(uint8_t *pix, ptrdiff_t stride, int *tc, uint8_t *no_p, uint8_t *no_q);
+    /* SHVC inter-layer slots (hevcdsp.h:106-123): 1 + 4 x 3 pointers, never touched by this back-end */
+    void *shvc_upsample_slots[13];
+} ohevc_HEVCDSPContext;
+
+/* VideoDSPContext, libavcodec/videodsp.h:44-91 */
+typedef struct ohevc_VideoDSPContext {
+    void (*emulated_edge_mc)(uint8_t *dst, const uint8_t *src, ptrdiff_t dst_linesize, ptrdiff_t src_linesize,
+                             int block_w, int block_h, int src_x, int src_y, int w, int h);
+    void *emulated_edge_up_h, *emulated_edge_up_v;
+    void (*prefetch)(uint8_t *buf, ptrdiff_t stride, int h);
+} ohevc_VideoDSPContext;
+
+/* ---- the hooks: call right after the reference's own init (same place as ff_hevcdsp_init_x86 / ff_videodsp_init_x86) */
+void ohevc_hevcdsp_init_hip(ohevc_HEVCDSPContext *c, int bit_depth);
+void ohevc_videodsp_init_hip(ohevc_VideoDSPContext *c, int bit_depth);
+
+/* ---- per-thread binding and the pointer registry */
+int  ohevc_tables_bind(ohevc_ctx *ctx);                    /* this thread's table calls record into ctx (NULL unbinds) */
+/* host planes of a picture living in picture-store slot `slot` (a DPB entry): used to resolve MC source pointers */
+int  ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *const data[3], const int linesize[3]);
+int  ohevc_tables_unregister_picture(ohevc_ctx *ctx, int slot);
+/* hevc_frame_start: picture `slot` (already registered) becomes the reconstruction target */
+int  ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot);
+/* frame end: run everything; with download != 0 the final planes are copied back into the registered host buffers
+ * (needed wherever the CPU still reads pixels: output, MD5 check hevc.c:4146-4181) */
+int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
+/* sticky status of the recording since begin_frame: table slots return void, so failures surface here */
+int  ohevc_tables_status(ohevc_ctx *ctx);
+
+/* intra_pred[log2-2] cannot be mirrored as a bare table slot (it takes HEVCContext*, hevcpred.h:32): the reference-side
+ * stub in INTEGRATION.md extracts the fields below from HEVCContext and calls this. */
+int  ohevc_tables_intra_pred(const ohevc_intra_geom *geom, int x0, int y0, int log2_size, int c_idx, int mode,
+                             int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OHEVC_TABLES_H */

@@ -210,6 +210,17 @@ extern "C" int ohevc_pic_planes(ohevc_ctx *c, int slot, ohevc_plane out[3])
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_pic_info(ohevc_ctx *c, int slot, int *width, int *height, int *cfi, int *bd)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr, "bad picture slot");
+    if (width) *width = p->w;
+    if (height) *height = p->h;
+    if (cfi) *cfi = p->cfi;
+    if (bd) *bd = p->bd;
+    return OHEVC_OK;
+}
+
 static void clear_recorded(ohevc_ctx *c)
 {
     c->mc.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear();

@@ -1,0 +1,414 @@
+// tables.hip -- the drop-in back-end: recording implementations of the reference's table slots (include/ohevc_tables.h).
+//
+// Every function here has the exact signature of a HEVCDSPContext / VideoDSPContext slot.  Instead of touching host
+// pixels it translates its pointer arguments back to (picture slot, plane, x, y) through the registry and appends a job
+// to the calling thread's ohevc_ctx.  Host code only.
+//
+// Call-sequence knowledge used (all from the reference's call sites):
+//   * residuals: idct*/transform_skip/transform_rdpcm run IN PLACE on lc->tu.coeffs and are followed by
+//     transform_add on the same pointer (hevc_cabac.c:1868-1949) -> the in-place calls only note the pending kind, the
+//     raw coefficients are copied when transform_add arrives (they are reused by the next TU, hevc.h:1063);
+//   * bi-prediction: put_hevc_{qpel,epel}(tmp, MAX_PB_SIZE, ref0...) is followed by put_hevc_*_bi[_w](dst, .., ref1.., tmp, ..)
+//     with the same tmp (hevc.c:1761-1773,1933-1948) -> the first call only notes reference 0;
+//   * edge emulation: vdsp.emulated_edge_mc(buf, src - offset, ..., src_x, src_y, w, h) precedes the MC call that reads
+//     `buf + buf_offset` (hevc.c:1660-1675) -> it notes (picture, src_x, src_y) for that buffer and copies nothing; the
+//     MC kernel clamps coordinates instead.
+#include <map>
+#include <mutex>
+#include <string.h>
+#include <vector>
+#include "common.hpp"
+#include "ohevc_tables.h"
+
+namespace {
+
+struct HostPic {
+    int slot = -1, bd = 8, ps = 1;
+    uint8_t *data[3] = {};
+    int linesize[3] = {};
+    int w[3] = {}, h[3] = {};
+};
+
+struct TablesState {
+    std::vector<HostPic> pics;
+    int cur = -1;                     // index into pics
+    int status = OHEVC_OK;
+    ohevc_HEVCDSPContext saved = {};  // the reference's own C slots (put_pcm is still executed on the host into scratch)
+};
+
+std::mutex g_lock;
+std::map<ohevc_ctx *, TablesState *> g_states;
+void (*g_ref_put_pcm[15])(uint8_t *, ptrdiff_t, int, int, struct GetBitContext *, int) = {};
+
+struct Pending {
+    const int16_t *coeffs = nullptr;  // residual kind noted by the in-place transform call
+    int kind = -1;
+    const int16_t *bi_tmp = nullptr;  // first half of a bi-prediction
+    int bi_slot = -1, bi_plane = 0, bi_sx = 0, bi_sy = 0, bi_mx = 0, bi_my = 0;
+    struct Emu { const uint8_t *buf = nullptr; ptrdiff_t linesize = 0; int slot = -1, plane = 0, x = 0, y = 0; } emu[4];
+    int emu_next = 0;
+};
+
+thread_local ohevc_ctx *tl_ctx = nullptr;
+thread_local TablesState *tl_state = nullptr;
+thread_local Pending tl_pend;
+
+void fail(int rc)
+{
+    if (tl_state && tl_state->status == OHEVC_OK) tl_state->status = rc;
+}
+
+struct Loc { int pic = -1, plane = 0, x = 0, y = 0; };
+
+// which registered picture/plane contains host address p?
+bool locate(const uint8_t *p, Loc &out, int only_pic = -1)
+{
+    if (!tl_state) return false;
+    for (size_t i = 0; i < tl_state->pics.size(); i++) {
+        if (only_pic >= 0 && (int)i != only_pic) continue;
+        const HostPic &hp = tl_state->pics[i];
+        if (hp.slot < 0) continue;
+        for (int c = 0; c < 3; c++) {
+            if (!hp.data[c]) continue;
+            const ptrdiff_t off = p - hp.data[c];
+            if (off < 0 || off >= (ptrdiff_t)hp.linesize[c] * hp.h[c]) continue;
+            const int y = (int)(off / hp.linesize[c]), xb = (int)(off % hp.linesize[c]);
+            if (xb >= hp.w[c] * hp.ps) continue;
+            out.pic = (int)i; out.plane = c; out.x = xb / hp.ps; out.y = y;
+            return true;
+        }
+    }
+    return false;
+}
+
+bool locate_cur(const uint8_t *p, Loc &out) { return tl_state && tl_state->cur >= 0 && locate(p, out, tl_state->cur); }
+
+// ------------------------------------------------------------------ residuals
+void note_kind(const int16_t *coeffs, int kind) { tl_pend.coeffs = coeffs; tl_pend.kind = kind; }
+
+template <int LOG2> void t_idct(int16_t *coeffs, int) { note_kind(coeffs, OHEVC_TU_IDCT); }
+template <int LOG2> void t_idct_dc(int16_t *coeffs) { note_kind(coeffs, OHEVC_TU_DC); }
+void t_idct_4x4_luma(int16_t *coeffs) { note_kind(coeffs, OHEVC_TU_DST4); }
+void t_transform_skip(int16_t *coeffs, int16_t) { note_kind(coeffs, OHEVC_TU_SKIP); }
+void t_transform_rdpcm(int16_t *coeffs, int16_t, int mode)
+{
+    const bool after_skip = tl_pend.coeffs == coeffs && tl_pend.kind == OHEVC_TU_SKIP;
+    note_kind(coeffs, after_skip ? (mode ? OHEVC_TU_SKIP_RDPCM_V : OHEVC_TU_SKIP_RDPCM_H)
+                                 : (mode ? OHEVC_TU_BYPASS_RDPCM_V : OHEVC_TU_BYPASS_RDPCM_H));
+}
+
+template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_t)
+{
+    Loc l;
+    if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
+    // no pending in-place transform on this pointer: the caller handed over a finished residual (transquant bypass)
+    const int kind = (tl_pend.coeffs == coeffs && tl_pend.kind >= 0) ? tl_pend.kind : OHEVC_TU_BYPASS;
+    tl_pend.coeffs = nullptr; tl_pend.kind = -1;
+    int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);
+    if (rc != OHEVC_OK) fail(rc);
+}
+
+void t_put_pcm(uint8_t *dst, ptrdiff_t, int width, int height, struct GetBitContext *gb, int pcm_bit_depth)
+{
+    Loc l;
+    if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
+    const HostPic &hp = tl_state->pics[tl_state->cur];
+    if (!g_ref_put_pcm[hp.bd] || width != height || width < 4 || width > 32) { fail(OHEVC_ERR_STATE); return; }
+    // the bit reader is the reference's: let its own put_pcm unpack into scratch, then ship the samples as a block
+    uint16_t scratch16[32 * 32];
+    uint8_t *scratch = reinterpret_cast<uint8_t *>(scratch16);
+    g_ref_put_pcm[hp.bd](scratch, (ptrdiff_t)width * hp.ps, width, height, gb, pcm_bit_depth);
+    int16_t samples[32 * 32];
+    for (int i = 0; i < width * height; i++) samples[i] = hp.ps == 2 ? (int16_t)scratch16[i] : (int16_t)scratch[i];
+    int log2 = 2;
+    while ((1 << log2) < width) log2++;
+    int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, log2, OHEVC_TU_PCM, samples, 1);
+    if (rc != OHEVC_OK) fail(rc);
+}
+
+// ------------------------------------------------------------------ motion compensation
+void t_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize, ptrdiff_t src_linesize,
+                        int, int, int src_x, int src_y, int, int)
+{
+    if (!tl_state) return;
+    // src == plane_base + src_y * linesize + src_x * ps  (possibly outside the plane): recover the plane by its base
+    int k = -1;
+    for (int i = 0; i < 4; i++) if (tl_pend.emu[i].buf == buf) k = i;      // a buffer holds one window at a time
+    if (k < 0) { k = tl_pend.emu_next; tl_pend.emu_next = (tl_pend.emu_next + 1) & 3; }
+    Pending::Emu &e = tl_pend.emu[k];
+    e.buf = nullptr;
+    for (size_t i = 0; i < tl_state->pics.size(); i++) {
+        const HostPic &hp = tl_state->pics[i];
+        if (hp.slot < 0) continue;
+        for (int c = 0; c < 3; c++) {
+            if (hp.data[c] && hp.linesize[c] == src_linesize &&
+                src - (ptrdiff_t)src_y * src_linesize - (ptrdiff_t)src_x * hp.ps == hp.data[c]) {
+                e.buf = buf; e.linesize = buf_linesize; e.slot = hp.slot; e.plane = c; e.x = src_x; e.y = src_y;
+                return;
+            }
+        }
+    }
+    fail(OHEVC_ERR_STATE);
+}
+
+// resolve an MC source pointer: either inside a registered picture or inside a noted edge-emulation buffer
+bool resolve_src(const uint8_t *src, int ps, int &slot, int &plane, int &sx, int &sy)
+{
+    for (const Pending::Emu &e : tl_pend.emu) {
+        if (!e.buf) continue;
+        const ptrdiff_t d = src - e.buf;
+        if (d >= 0 && d < e.linesize * 80) {
+            slot = e.slot; plane = e.plane; sy = e.y + (int)(d / e.linesize); sx = e.x + (int)(d % e.linesize) / ps;
+            return true;
+        }
+    }
+    Loc l;
+    if (!locate(src, l)) return false;
+    slot = tl_state->pics[l.pic].slot; plane = l.plane; sx = l.x; sy = l.y;
+    return true;
+}
+
+void mc_first_half(int16_t *tmp, uint8_t *src, int mx, int my)
+{
+    if (!tl_ctx || !tl_state || tl_state->cur < 0) { fail(OHEVC_ERR_STATE); return; }
+    const int ps = tl_state->pics[tl_state->cur].ps;
+    Pending &p = tl_pend;
+    if (!resolve_src(src, ps, p.bi_slot, p.bi_plane, p.bi_sx, p.bi_sy)) { p.bi_tmp = nullptr; fail(OHEVC_ERR_STATE); return; }
+    p.bi_tmp = tmp; p.bi_mx = mx; p.bi_my = my;
+}
+
+void mc_record(uint8_t *dst, uint8_t *src, const int16_t *src2, int height, int width, int mx, int my,
+               bool weighted, int denom, int wx0, int wx1, int ox0, int ox1)
+{
+    Loc l;
+    if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
+    const int ps = tl_state->pics[tl_state->cur].ps;
+    ohevc_mc_job j = {};
+    j.x = (uint16_t)l.x; j.y = (uint16_t)l.y; j.w = (uint8_t)width; j.h = (uint8_t)height; j.plane = (uint8_t)l.plane;
+    int slot, plane, sx, sy;
+    if (!resolve_src(src, ps, slot, plane, sx, sy)) { fail(OHEVC_ERR_STATE); return; }
+    if (src2) {                         // bi: reference 0 is the noted first half, reference 1 is this call's src
+        if (tl_pend.bi_tmp != src2) { fail(OHEVC_ERR_STATE); return; }
+        j.flags |= OHEVC_MC_BI;
+        j.ref0 = (int8_t)tl_pend.bi_slot; j.sx0 = (int16_t)tl_pend.bi_sx; j.sy0 = (int16_t)tl_pend.bi_sy;
+        j.mx0 = (uint8_t)tl_pend.bi_mx; j.my0 = (uint8_t)tl_pend.bi_my;
+        j.ref1 = (int8_t)slot; j.sx1 = (int16_t)sx; j.sy1 = (int16_t)sy; j.mx1 = (uint8_t)mx; j.my1 = (uint8_t)my;
+        tl_pend.bi_tmp = nullptr;
+    } else {
+        j.ref0 = (int8_t)slot; j.sx0 = (int16_t)sx; j.sy0 = (int16_t)sy; j.mx0 = (uint8_t)mx; j.my0 = (uint8_t)my;
+    }
+    if (weighted) {
+        j.flags |= OHEVC_MC_WEIGHTED;
+        j.denom = (uint8_t)denom; j.wx0 = (int16_t)wx0; j.wx1 = (int16_t)wx1; j.ox0 = (int16_t)ox0; j.ox1 = (int16_t)ox1;
+    }
+    int rc = ohevc_rec_mc(tl_ctx, &j);
+    if (rc != OHEVC_OK) fail(rc);
+}
+
+void t_put(int16_t *dst, ptrdiff_t, uint8_t *src, ptrdiff_t, int, intptr_t mx, intptr_t my, int)
+{
+    mc_first_half(dst, src, (int)mx, (int)my);
+}
+void t_uni(uint8_t *dst, ptrdiff_t, uint8_t *src, ptrdiff_t, int height, intptr_t mx, intptr_t my, int width)
+{
+    mc_record(dst, src, nullptr, height, width, (int)mx, (int)my, false, 0, 0, 0, 0, 0);
+}
+void t_uni_w(uint8_t *dst, ptrdiff_t, uint8_t *src, ptrdiff_t, int height, int denom, int wx, int ox, intptr_t mx, intptr_t my, int width)
+{
+    mc_record(dst, src, nullptr, height, width, (int)mx, (int)my, true, denom, wx, 0, ox, 0);
+}
+void t_bi(uint8_t *dst, ptrdiff_t, uint8_t *src, ptrdiff_t, int16_t *src2, ptrdiff_t, int height, intptr_t mx, intptr_t my, int width)
+{
+    mc_record(dst, src, src2, height, width, (int)mx, (int)my, false, 0, 0, 0, 0, 0);
+}
+void t_bi_w(uint8_t *dst, ptrdiff_t, uint8_t *src, ptrdiff_t, int16_t *src2, ptrdiff_t, int height, int denom, int wx0, int wx1,
+            int ox0, int ox1, intptr_t mx, intptr_t my, int width)
+{
+    mc_record(dst, src, src2, height, width, (int)mx, (int)my, true, denom, wx0, wx1, ox0, ox1);
+}
+
+// ------------------------------------------------------------------ in-loop filters
+void dbk_record(uint8_t *pix, bool vertical, int beta, const int *tc, const uint8_t *no_p, const uint8_t *no_q)
+{
+    Loc l;
+    if (!tl_ctx || !locate_cur(pix, l)) { fail(OHEVC_ERR_STATE); return; }
+    ohevc_dbk_job j = {};
+    j.x = (uint16_t)l.x; j.y = (uint16_t)l.y; j.plane = (uint8_t)l.plane; j.beta = (uint8_t)beta;
+    j.tc[0] = (int16_t)tc[0]; j.tc[1] = (int16_t)tc[1];
+    j.flags = (uint8_t)((vertical ? OHEVC_DBK_VERTICAL_EDGE : 0) | (no_p[0] ? OHEVC_DBK_NO_P0 : 0) | (no_p[1] ? OHEVC_DBK_NO_P1 : 0) |
+                        (no_q[0] ? OHEVC_DBK_NO_Q0 : 0) | (no_q[1] ? OHEVC_DBK_NO_Q1 : 0));
+    int rc = ohevc_rec_deblock(tl_ctx, &j);
+    if (rc != OHEVC_OK) fail(rc);
+}
+void t_h_luma(uint8_t *pix, ptrdiff_t, int beta, int *tc, uint8_t *no_p, uint8_t *no_q) { dbk_record(pix, false, beta, tc, no_p, no_q); }
+void t_v_luma(uint8_t *pix, ptrdiff_t, int beta, int *tc, uint8_t *no_p, uint8_t *no_q) { dbk_record(pix, true, beta, tc, no_p, no_q); }
+void t_h_chroma(uint8_t *pix, ptrdiff_t, int *tc, uint8_t *no_p, uint8_t *no_q) { dbk_record(pix, false, 0, tc, no_p, no_q); }
+void t_v_chroma(uint8_t *pix, ptrdiff_t, int *tc, uint8_t *no_p, uint8_t *no_q) { dbk_record(pix, true, 0, tc, no_p, no_q); }
+
+void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int height, int c_idx, int type, int restore,
+                const uint8_t *ve, const uint8_t *he, const uint8_t *de)
+{
+    Loc l;
+    if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
+    ohevc_sao_job j = {};
+    j.x = (uint16_t)l.x; j.y = (uint16_t)l.y; j.w = (uint16_t)width; j.h = (uint16_t)height; j.plane = (uint8_t)l.plane;
+    j.type = (uint8_t)type;
+    j.klass = type == OHEVC_SAO_BAND ? sao->band_position[c_idx] : sao->eo_class[c_idx];
+    j.borders = (uint8_t)((borders[0] ? 1 : 0) | (borders[1] ? 2 : 0) | (borders[2] ? 4 : 0) | (borders[3] ? 8 : 0));
+    j.restore = (uint8_t)restore;
+    if (restore)
+        j.edges = (uint8_t)((ve[0] ? 1 : 0) | (ve[1] ? 2 : 0) | (he[0] ? 4 : 0) | (he[1] ? 8 : 0) |
+                            (de[0] ? 16 : 0) | (de[1] ? 32 : 0) | (de[2] ? 64 : 0) | (de[3] ? 128 : 0));
+    for (int k = 0; k < 5; k++) j.offset_val[k] = sao->offset_val[c_idx][k];
+    int rc = ohevc_rec_sao(tl_ctx, &j);
+    if (rc != OHEVC_OK) fail(rc);
+}
+// sao_filter_CTB passes (frame, sao_frame copy) as (dst, src): hevc_filter.c:270-274,308-315
+void t_sao_band(uint8_t *dst, uint8_t *, ptrdiff_t, ptrdiff_t, ohevc_SAOParams *sao, int *borders, int width, int height, int c_idx)
+{
+    sao_record(dst, sao, borders, width, height, c_idx, OHEVC_SAO_BAND, 0, nullptr, nullptr, nullptr);
+}
+void t_sao_edge0(uint8_t *dst, uint8_t *, ptrdiff_t, ptrdiff_t, ohevc_SAOParams *sao, int *borders, int width, int height, int c_idx,
+                 uint8_t *, uint8_t *, uint8_t *)
+{
+    sao_record(dst, sao, borders, width, height, c_idx, OHEVC_SAO_EDGE, 0, nullptr, nullptr, nullptr);
+}
+void t_sao_edge1(uint8_t *dst, uint8_t *, ptrdiff_t, ptrdiff_t, ohevc_SAOParams *sao, int *borders, int width, int height, int c_idx,
+                 uint8_t *ve, uint8_t *he, uint8_t *de)
+{
+    sao_record(dst, sao, borders, width, height, c_idx, OHEVC_SAO_EDGE, 1, ve, he, de);
+}
+
+TablesState *state_of(ohevc_ctx *ctx, bool create)
+{
+    std::lock_guard<std::mutex> g(g_lock);
+    auto it = g_states.find(ctx);
+    if (it != g_states.end()) return it->second;
+    if (!create) return nullptr;
+    TablesState *s = new TablesState();
+    g_states[ctx] = s;
+    return s;
+}
+
+}  // namespace
+
+extern "C" void ohevc_hevcdsp_init_hip(ohevc_HEVCDSPContext *c, int bit_depth)
+{
+    if (!c) return;
+    if (bit_depth >= 8 && bit_depth < 15 && c->put_pcm && c->put_pcm != t_put_pcm) g_ref_put_pcm[bit_depth] = c->put_pcm;
+    c->put_pcm = t_put_pcm;
+    c->transform_add[0] = t_transform_add<2>; c->transform_add[1] = t_transform_add<3>;
+    c->transform_add[2] = t_transform_add<4>; c->transform_add[3] = t_transform_add<5>;
+    c->transform_skip = t_transform_skip;
+    c->transform_rdpcm = t_transform_rdpcm;
+    c->idct_4x4_luma = t_idct_4x4_luma;
+    c->idct[0] = t_idct<2>; c->idct[1] = t_idct<3>; c->idct[2] = t_idct<4>; c->idct[3] = t_idct<5>;
+    c->idct_dc[0] = t_idct_dc<2>; c->idct_dc[1] = t_idct_dc<3>; c->idct_dc[2] = t_idct_dc<4>; c->idct_dc[3] = t_idct_dc<5>;
+    c->sao_band_filter = t_sao_band;
+    c->sao_edge_filter[0] = t_sao_edge0;
+    c->sao_edge_filter[1] = t_sao_edge1;
+    for (int i = 0; i < 10; i++)
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                c->put_hevc_qpel[i][a][b] = t_put;        c->put_hevc_epel[i][a][b] = t_put;
+                c->put_hevc_qpel_uni[i][a][b] = t_uni;    c->put_hevc_epel_uni[i][a][b] = t_uni;
+                c->put_hevc_qpel_uni_w[i][a][b] = t_uni_w; c->put_hevc_epel_uni_w[i][a][b] = t_uni_w;
+                c->put_hevc_qpel_bi[i][a][b] = t_bi;      c->put_hevc_epel_bi[i][a][b] = t_bi;
+                c->put_hevc_qpel_bi_w[i][a][b] = t_bi_w;  c->put_hevc_epel_bi_w[i][a][b] = t_bi_w;
+            }
+    c->hevc_h_loop_filter_luma = c->hevc_h_loop_filter_luma_c = t_h_luma;
+    c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = t_v_luma;
+    c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = t_h_chroma;
+    c->hevc_v_loop_filter_chroma = c->hevc_v_loop_filter_chroma_c = t_v_chroma;
+}
+
+extern "C" void ohevc_videodsp_init_hip(ohevc_VideoDSPContext *c, int)
+{
+    if (c) c->emulated_edge_mc = t_emulated_edge_mc;
+}
+
+extern "C" int ohevc_tables_bind(ohevc_ctx *ctx)
+{
+    tl_ctx = ctx;
+    tl_state = ctx ? state_of(ctx, true) : nullptr;
+    tl_pend = Pending();
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *const data[3], const int linesize[3])
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(ctx != nullptr && data != nullptr && linesize != nullptr, "null argument");
+    int w, h, cfi, bd;
+    int rc = ohevc_pic_info(ctx, slot, &w, &h, &cfi, &bd);
+    if (rc != OHEVC_OK) return rc;
+    TablesState *s = state_of(ctx, true);
+    HostPic hp;
+    hp.slot = slot; hp.bd = bd; hp.ps = bd > 8 ? 2 : 1;
+    for (int c = 0; c < 3; c++) {
+        const int hs = c ? (cfi == 1 || cfi == 2) : 0, vs = c ? (cfi == 1) : 0;
+        hp.data[c] = data[c]; hp.linesize[c] = linesize[c]; hp.w[c] = w >> hs; hp.h[c] = h >> vs;
+    }
+    for (auto &p : s->pics) if (p.slot == slot) { p = hp; return OHEVC_OK; }
+    for (auto &p : s->pics) if (p.slot < 0) { p = hp; return OHEVC_OK; }
+    s->pics.push_back(hp);
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_unregister_picture(ohevc_ctx *ctx, int slot)
+{
+    TablesState *s = state_of(ctx, false);
+    if (!s) return OHEVC_OK;
+    for (size_t i = 0; i < s->pics.size(); i++)
+        if (s->pics[i].slot == slot) {
+            s->pics[i].slot = -1;
+            if (s->cur == (int)i) s->cur = -1;
+        }
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
+{
+    using namespace ohevc;
+    TablesState *s = state_of(ctx, false);
+    OHEVC_REQUIRE(s != nullptr, "no picture registered");
+    s->cur = -1;
+    for (size_t i = 0; i < s->pics.size(); i++) if (s->pics[i].slot == slot) s->cur = (int)i;
+    OHEVC_REQUIRE(s->cur >= 0, "picture not registered");
+    s->status = OHEVC_OK;
+    tl_pend = Pending();
+    return ohevc_frame_begin(ctx, slot);
+}
+
+extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
+{
+    using namespace ohevc;
+    TablesState *s = state_of(ctx, false);
+    OHEVC_REQUIRE(s != nullptr && s->cur >= 0, "no frame begun");
+    if (s->status != OHEVC_OK) { set_error("a table call failed while recording (unknown pointer or call order)"); return s->status; }
+    int rc = ohevc_frame_end(ctx);
+    if (rc != OHEVC_OK) return rc;
+    if (download) {
+        const HostPic &hp = s->pics[s->cur];
+        for (int c = 0; c < 3; c++)
+            if ((rc = ohevc_pic_download(ctx, hp.slot, c, hp.data[c], hp.linesize[c])) != OHEVC_OK) return rc;
+    }
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_status(ohevc_ctx *ctx)
+{
+    TablesState *s = state_of(ctx, false);
+    return s ? s->status : OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_intra_pred(const ohevc_intra_geom *geom, int x0, int y0, int log2_size, int c_idx, int mode,
+                                       int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right)
+{
+    if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
+    ohevc_intra_job j;
+    int rc = ohevc_intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, &j);
+    if (rc == OHEVC_OK) rc = ohevc_rec_intra(tl_ctx, &j);
+    if (rc != OHEVC_OK) fail(rc);
+    return rc;
+}

@@ -590,7 +590,13 @@ __global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohe
         for (int x = 0; x < N; x++) res[x] = (int)(short)res[x];
     }
     unsigned char *row = PLANE_PTR3(planes, jplane) + (size_t)(jy + r) * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
-    add_row_store<N, Pixel>(row, res, bit_depth, true);
+    if (kind == OHEVC_TU_PCM) {                      // put_pcm: the samples replace the block (clip(0 + sample) == sample)
+        unsigned px[N * (int)sizeof(Pixel) / 4];
+        load_row<N, Pixel>(row, px, false);
+        finish_row<N, Pixel>(row, px, res, bit_depth, true);
+    } else {
+        add_row_store<N, Pixel>(row, res, bit_depth, true);
+    }
 }
 
 // ------------------------------------------------------------------ launcher

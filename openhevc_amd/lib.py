@@ -153,7 +153,9 @@ class IntraGeom(C.Structure):
                 ("constrained_intra_pred", C.c_int32)]
 
 
-EXPORTED_SYMBOLS += ["ohevc_intra_make_job"]
+EXPORTED_SYMBOLS += ["ohevc_intra_make_job", "ohevc_hevcdsp_init_hip", "ohevc_videodsp_init_hip", "ohevc_tables_bind",
+                     "ohevc_tables_register_picture", "ohevc_tables_unregister_picture", "ohevc_tables_begin_frame",
+                     "ohevc_tables_end_frame", "ohevc_tables_status", "ohevc_tables_intra_pred", "ohevc_pic_info"]
 
 
 def intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cands):

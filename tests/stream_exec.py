@@ -155,3 +155,75 @@ def ops_to_arrays(W, H, ref_slots, ops, fops):
                 tu_desc=np.array(desc, dtype=np.int32).reshape(-1, 6),
                 tu_coeffs=np.concatenate(coeffs) if coeffs else np.zeros(0, np.int16),
                 dbk=np.array(dbk, dtype=L.DBK_JOB), sao=np.array(sao, dtype=L.SAO_JOB))
+
+
+# ---------------------------------------------------------------- table-driver encoding (oracle/table_driver.c)
+OP_WORDS = 24
+
+
+def encode_driver_ops(ops, fops, pcm_ops=()):
+    """Flatten an op list into the int32[n,24] + coefficient + pcm-bit arrays ohref_drive_tables takes."""
+    rows, coeffs, bits = [], [], bytearray()
+    coff = 0
+    for op in ops:
+        if op["t"] == "mc":
+            for c_idx in range(3):
+                x, y, w, h, rp = mc_params(op, c_idx)
+                r = [0, c_idx, x, y, w, h, (1 if op["bi"] else 0) | (2 if op["weighted"] else 0), op["ref"][0], op["ref"][1],
+                     rp[0][0], rp[0][1], rp[0][2], rp[0][3], rp[1][0], rp[1][1], rp[1][2], rp[1][3],
+                     op["denom"], op["wx"][0], op["wx"][1], op["ox"][0], op["ox"][1]]
+                rows.append(r + [0] * (OP_WORDS - len(r)))
+        elif op["t"] == "tu":
+            sh = 1 if op["c_idx"] else 0
+            r = [1, op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], op["kind"], coff]
+            c = np.ascontiguousarray(op["coeffs"], dtype=np.int16).reshape(-1)
+            coeffs.append(c); coff += c.size
+            rows.append(r + [0] * (OP_WORDS - len(r)))
+        else:
+            r = [2, op["c_idx"], op["x0"], op["y0"], op["log2"], op["mode"]] + list(op["cands"])
+            rows.append(r + [0] * (OP_WORDS - len(r)))
+    for op in pcm_ops:      # dict(c_idx, x, y, log2, pcm_bd, samples[N,N])
+        n = 1 << op["log2"]
+        acc, nb = 0, 0
+        start = len(bits)
+        for v in np.asarray(op["samples"]).reshape(-1):
+            acc = (acc << op["pcm_bd"]) | int(v); nb += op["pcm_bd"]
+            while nb >= 8:
+                bits.append((acc >> (nb - 8)) & 255); nb -= 8
+        if nb:
+            bits.append((acc << (8 - nb)) & 255)
+        bits.extend(b"\0" * 8)                       # get_bits reads ahead
+        r = [5, op["c_idx"], op["x"], op["y"], op["log2"], op["pcm_bd"], start, len(bits) - start]
+        rows.append(r + [0] * (OP_WORDS - len(r)))
+    for op in fops:
+        if op["t"] == "dbk":
+            r = [3, op["c_idx"], op["x"], op["y"], op["vertical"], op["beta"], op["tc"][0], op["tc"][1],
+                 op["no_p"][0], op["no_p"][1], op["no_q"][0], op["no_q"][1]]
+        else:
+            r = [4, op["c_idx"], op["x"], op["y"], op["w"], op["h"], int(op["band"]), op["klass"]] + list(op["borders"]) + list(op["offset_val"])
+        rows.append(r + [0] * (OP_WORDS - len(r)))
+    return (np.array(rows, dtype=np.int32).reshape(-1, OP_WORDS),
+            np.concatenate(coeffs) if coeffs else np.zeros(8, np.int16), np.frombuffer(bytes(bits) + b"\0" * 16, dtype=np.uint8).copy())
+
+
+def drive_tables(reflib, bd, W, H, cur, refs, enc, hevcdsp_hook=None, videodsp_hook=None, intra_hook=None, geom=None):
+    """Run oracle/table_driver.c on host planes (numpy, modified in place).  reflib = ctypes CDLL of libhevcref.so."""
+    import ctypes as C
+
+    class DrvPic(C.Structure):
+        _fields_ = [("data", C.c_void_p * 3), ("linesize", C.c_int32 * 3)]
+
+    def pic(planes):
+        p = DrvPic()
+        for i, a in enumerate(planes):
+            p.data[i] = a.ctypes.data; p.linesize[i] = a.strides[0]
+        return p
+    cp = pic(cur)
+    rarr = (DrvPic * len(refs))(*[pic(r) for r in refs])
+    ops, coeffs, bits = enc
+    f = reflib.ohref_drive_tables
+    f.restype = C.c_int
+    rc = f(C.c_int(bd), C.c_int(W), C.c_int(H), C.byref(cp), rarr, C.c_int(len(refs)),
+           ops.ctypes.data_as(C.c_void_p), C.c_int(len(ops)), coeffs.ctypes.data_as(C.c_void_p), bits.ctypes.data_as(C.c_void_p),
+           C.c_void_p(hevcdsp_hook), C.c_void_p(videodsp_hook), C.c_void_p(intra_hook), C.c_void_p(geom))
+    return rc

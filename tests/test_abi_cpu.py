@@ -29,6 +29,50 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert set(L.EXPORTED_SYMBOLS) <= decl
 
 
+def test_table_mirror_layout_matches_reference_headers():
+    """sizeof/offsets of the ABI mirrors (include/ohevc_tables.h) against the reference's real structs, compiled here
+    when /root/reference is available."""
+    import shutil, subprocess, tempfile
+    if not os.path.exists("/root/reference/libavcodec/hevcdsp.h") or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "c", "config.h")):
+        import pytest
+        pytest.skip("reference headers not available")
+    src = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "libavcodec/get_bits.h"
+#include "libavcodec/hevc.h"
+#include "libavcodec/hevcdsp.h"
+#include "libavcodec/videodsp.h"
+#include "ohevc_tables.h"
+#define CHK(a, b) if ((a) != (b)) { printf("MISMATCH %s %zu %zu\n", #a, (size_t)(a), (size_t)(b)); bad = 1; }
+int main(void) { int bad = 0;
+  CHK(sizeof(HEVCDSPContext), sizeof(ohevc_HEVCDSPContext))
+  CHK(offsetof(HEVCDSPContext, transform_add), offsetof(ohevc_HEVCDSPContext, transform_add))
+  CHK(offsetof(HEVCDSPContext, idct), offsetof(ohevc_HEVCDSPContext, idct))
+  CHK(offsetof(HEVCDSPContext, sao_edge_filter), offsetof(ohevc_HEVCDSPContext, sao_edge_filter))
+  CHK(offsetof(HEVCDSPContext, put_hevc_qpel_bi_w), offsetof(ohevc_HEVCDSPContext, put_hevc_qpel_bi_w))
+  CHK(offsetof(HEVCDSPContext, put_hevc_epel_bi_w), offsetof(ohevc_HEVCDSPContext, put_hevc_epel_bi_w))
+  CHK(offsetof(HEVCDSPContext, hevc_h_loop_filter_luma), offsetof(ohevc_HEVCDSPContext, hevc_h_loop_filter_luma))
+  CHK(offsetof(HEVCDSPContext, hevc_v_loop_filter_chroma_c), offsetof(ohevc_HEVCDSPContext, hevc_v_loop_filter_chroma_c))
+  CHK(offsetof(HEVCDSPContext, upsample_base_layer_frame), offsetof(ohevc_HEVCDSPContext, shvc_upsample_slots))
+  CHK(sizeof(VideoDSPContext), sizeof(ohevc_VideoDSPContext))
+  CHK(offsetof(VideoDSPContext, prefetch), offsetof(ohevc_VideoDSPContext, prefetch))
+  CHK(sizeof(SAOParams), sizeof(ohevc_SAOParams))
+  CHK(offsetof(SAOParams, offset_val), offsetof(ohevc_SAOParams, offset_val))
+  CHK(offsetof(SAOParams, eo_class), offsetof(ohevc_SAOParams, eo_class))
+  return bad; }
+"""
+    d = tempfile.mkdtemp()
+    try:
+        open(os.path.join(d, "chk.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=gnu99", "-w", "-I" + os.path.join(ROOT, "oracle", "_ref", "c"), "-I/root/reference",
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(d, "chk.c"), "-o", os.path.join(d, "chk")], check=True)
+        r = subprocess.run([os.path.join(d, "chk")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+    finally:
+        shutil.rmtree(d)
+
+
 def test_job_record_layouts():
     assert L.TU_JOB.itemsize == 16
     assert [L.TU_JOB.fields[k][1] for k in ("x", "y", "plane", "dc", "coeff_off")] == [0, 2, 4, 6, 8]
