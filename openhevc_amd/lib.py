@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libohevc_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_NODEV, ERR_STATE = 0, -1, -2, -3, -4
-TU_IDCT, TU_DC, TU_DST4, TU_SKIP, TU_SKIP_RDPCM_H, TU_SKIP_RDPCM_V, TU_BYPASS, TU_BYPASS_RDPCM_H, TU_BYPASS_RDPCM_V = range(9)
+TU_IDCT, TU_DC, TU_DST4, TU_SKIP, TU_SKIP_RDPCM_H, TU_SKIP_RDPCM_V, TU_BYPASS, TU_BYPASS_RDPCM_H, TU_BYPASS_RDPCM_V, TU_PCM = range(10)
 
 
 class OhevcError(RuntimeError):

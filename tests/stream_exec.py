@@ -50,6 +50,11 @@ def run_oracle(oracle, po, bd, W, H, cur, refs, ops, fops):
         elif op["t"] == "intra":
             oracle.intra_pred(bd, cur, W, H, op["x0"], op["y0"], op["log2"], op["c_idx"], op["mode"], op["cands"],
                               chroma_format_idc=1, strong=1, smoothing_disabled=0, log2_ctb_size=6, log2_min_tb_size=2)
+        elif op["t"] == "pcm":          # put_pcm: dst = sample << (BIT_DEPTH - pcm_bit_depth), hevcdsp_template.c:30-43
+            sh = 1 if op["c_idx"] else 0
+            n = 1 << op["log2"]
+            x, y = op["x0"] >> sh, op["y0"] >> sh
+            cur[op["c_idx"]][y:y + n, x:x + n] = (op["samples"] << (bd - op["pcm_bd"])).astype(cur[op["c_idx"]].dtype)
     for vertical in (1, 0):
         for op in fops:
             if op["t"] == "dbk" and op["vertical"] == vertical:
@@ -70,6 +75,11 @@ def run_oracle(oracle, po, bd, W, H, cur, refs, ops, fops):
                 oracle.sao_edge(bd, 0, dst, src[c], op["x"] + 1, op["y"] + 1, op["w"], op["h"], op["offset_val"], op["klass"], op["borders"])
             cur[c][op["y"]:op["y"] + op["h"], op["x"]:op["x"] + op["w"]] = dst[op["y"] + 1:op["y"] + 1 + op["h"], op["x"] + 1:op["x"] + 1 + op["w"]]
     return cur
+
+
+def pcm_samples(op, bd=None):
+    """Samples as the host would hand them over: already << (bit_depth - pcm_bit_depth)."""
+    return (op["samples"] << (op["bd"] - op["pcm_bd"])).astype(np.int16)
 
 
 def record_gpu(ctx, W, H, ref_slots, ops, fops):
@@ -93,6 +103,9 @@ def record_gpu(ctx, W, H, ref_slots, ops, fops):
             ctx.rec_tu(op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], op["kind"], op["coeffs"], op["intra"])
         elif op["t"] == "intra":
             ctx.rec_intra(L.intra_make_job(geom, op["x0"], op["y0"], op["log2"], op["c_idx"], op["mode"], op["cands"]))
+        elif op["t"] == "pcm":
+            sh = 1 if op["c_idx"] else 0
+            ctx.rec_tu(op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], L.TU_PCM, pcm_samples(op), 1)
     for op in fops:
         if op["t"] == "dbk":
             j = np.zeros(1, L.DBK_JOB)
@@ -133,6 +146,10 @@ def ops_to_arrays(W, H, ref_slots, ops, fops):
             sh = 1 if op["c_idx"] else 0
             desc.append([op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], op["kind"], op["intra"]])
             coeffs.append(np.ascontiguousarray(op["coeffs"], dtype=np.int16).reshape(-1))
+        elif op["t"] == "pcm":
+            sh = 1 if op["c_idx"] else 0
+            desc.append([op["c_idx"], op["x0"] >> sh, op["y0"] >> sh, op["log2"], L.TU_PCM, 1])
+            coeffs.append(pcm_samples(op).reshape(-1))
         else:
             intra.append(L.intra_make_job(geom, op["x0"], op["y0"], op["log2"], op["c_idx"], op["mode"], op["cands"])[0])
     for op in fops:
@@ -165,6 +182,21 @@ def encode_driver_ops(ops, fops, pcm_ops=()):
     """Flatten an op list into the int32[n,24] + coefficient + pcm-bit arrays ohref_drive_tables takes."""
     rows, coeffs, bits = [], [], bytearray()
     coff = 0
+
+    def pack_pcm(op):
+        acc, nb = 0, 0
+        start = len(bits)
+        for v in np.asarray(op["samples"]).reshape(-1):
+            acc = (acc << op["pcm_bd"]) | int(v); nb += op["pcm_bd"]
+            while nb >= 8:
+                bits.append((acc >> (nb - 8)) & 255); nb -= 8
+                acc &= (1 << nb) - 1
+        if nb:
+            bits.append((acc << (8 - nb)) & 255)
+        bits.extend(b"\0" * 8)                      # get_bits reads ahead
+        r = [5, op["c_idx"], op["x"], op["y"], op["log2"], op["pcm_bd"], start, len(bits) - start]
+        rows.append(r + [0] * (OP_WORDS - len(r)))
+
     for op in ops:
         if op["t"] == "mc":
             for c_idx in range(3):
@@ -179,10 +211,15 @@ def encode_driver_ops(ops, fops, pcm_ops=()):
             c = np.ascontiguousarray(op["coeffs"], dtype=np.int16).reshape(-1)
             coeffs.append(c); coff += c.size
             rows.append(r + [0] * (OP_WORDS - len(r)))
-        else:
+        elif op["t"] == "intra":
             r = [2, op["c_idx"], op["x0"], op["y0"], op["log2"], op["mode"]] + list(op["cands"])
             rows.append(r + [0] * (OP_WORDS - len(r)))
+        else:                   # pcm: pack the samples MSB-first, pcm_bd bits each, like the bitstream carries them
+            sh = 1 if op["c_idx"] else 0
+            pack_pcm(dict(c_idx=op["c_idx"], x=op["x0"] >> sh, y=op["y0"] >> sh, log2=op["log2"], pcm_bd=op["pcm_bd"], samples=op["samples"]))
     for op in pcm_ops:      # dict(c_idx, x, y, log2, pcm_bd, samples[N,N])
+        pack_pcm(op)
+    for op in ():
         n = 1 << op["log2"]
         acc, nb = 0, 0
         start = len(bits)

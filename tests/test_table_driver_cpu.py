@@ -14,15 +14,6 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import synth_stream as S  # noqa: E402
 
 
-def pcm_ops_for(rng, bd):
-    out = []
-    for (c_idx, x, y, log2) in [(0, 8, 8, 3), (1, 4, 4, 2), (2, 4, 4, 2), (0, 64, 32, 4)]:
-        pcm_bd = int(rng.integers(4, bd + 1))
-        n = 1 << log2
-        out.append(dict(c_idx=c_idx, x=x, y=y, log2=log2, pcm_bd=pcm_bd, samples=rng.integers(0, 1 << pcm_bd, size=(n, n))))
-    return out
-
-
 @pytest.mark.parametrize("bd,W,H", [(8, 256, 136), (10, 192, 128)])
 def test_driver_on_reference_tables_equals_oracle_stream(oracle, ref, bd, W, H):
     rng = np.random.default_rng(31 + bd)
@@ -30,16 +21,11 @@ def test_driver_on_reference_tables_equals_oracle_stream(oracle, ref, bd, W, H):
     dims = X.chroma_dims(W, H)
     refs = [[rng.integers(0, 1 << bd, size=d).astype(dt) for d in dims] for _ in range(2)]
     cur0 = [rng.integers(0, 1 << bd, size=d).astype(dt) for d in dims]
-    ops, fops = S.gen_frame_ops(rng, W, H, bd, intra_frac=0.3)
-    pcm = pcm_ops_for(rng, bd)
-    # oracle, decode order; PCM blocks replace their area before the in-loop filters
-    want = X.run_oracle(oracle, po, bd, W, H, [p.copy() for p in cur0], refs, ops, [])
-    for p in pcm:
-        n = 1 << p["log2"]
-        want[p["c_idx"]][p["y"]:p["y"] + n, p["x"]:p["x"] + n] = (p["samples"] << (bd - p["pcm_bd"])).astype(dt)
-    want = X.run_oracle(oracle, po, bd, W, H, want, refs, [], fops)
+    ops, fops = S.gen_frame_ops(rng, W, H, bd, intra_frac=0.3, pcm_frac=0.05)
+    assert any(o["t"] == "pcm" for o in ops)
+    want = X.run_oracle(oracle, po, bd, W, H, [p.copy() for p in cur0], refs, ops, fops)
     got = [p.copy() for p in cur0]
-    rc = X.drive_tables(ref.lib, bd, W, H, got, refs, X.encode_driver_ops(ops, fops, pcm))
+    rc = X.drive_tables(ref.lib, bd, W, H, got, refs, X.encode_driver_ops(ops, fops))
     assert rc == 0
     for c in range(3):
         bad = np.argwhere(got[c] != want[c])

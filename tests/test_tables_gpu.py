@@ -12,7 +12,6 @@ import pytest
 from oracle import pyoracle as po
 from openhevc_amd import lib as L
 import stream_exec as X
-from test_table_driver_cpu import pcm_ops_for
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 import synth_stream as S  # noqa: E402
@@ -27,8 +26,9 @@ def test_reference_front_end_on_hooked_tables(ref, bd, W, H, intra_frac):
     dims = X.chroma_dims(W, H)
     refs = [[np.ascontiguousarray(rng.integers(0, 1 << bd, size=d).astype(dt)) for d in dims] for _ in range(2)]
     cur0 = [rng.integers(0, 1 << bd, size=d).astype(dt) for d in dims]
-    ops, fops = S.gen_frame_ops(rng, W, H, bd, intra_frac=intra_frac)
-    enc = X.encode_driver_ops(ops, fops, pcm_ops_for(rng, bd))
+    ops, fops = S.gen_frame_ops(rng, W, H, bd, intra_frac=intra_frac, pcm_frac=0.04)
+    assert any(o["t"] == "pcm" for o in ops)
+    enc = X.encode_driver_ops(ops, fops)
 
     # (a) reference tables, host compute
     want = [p.copy() for p in cur0]

@@ -17,7 +17,8 @@ import numpy as np
 TU_IDCT, TU_DC, TU_DST4, TU_SKIP, TU_BYPASS = 0, 1, 2, 3, 6
 
 
-def gen_frame_ops(rng, W, H, bd, n_refs=2, intra_frac=0.15, bi_frac=0.6, coded_frac=0.4, weighted_frac=0.1, log2_ctb=6):
+def gen_frame_ops(rng, W, H, bd, n_refs=2, intra_frac=0.15, bi_frac=0.6, coded_frac=0.4, weighted_frac=0.1, log2_ctb=6,
+                  pcm_frac=0.01):
     """Returns (ops, filter_ops).  Coordinates of 'tu'/'intra' ops are LUMA positions + c_idx like the reference's calls."""
     ops = []
     ctb = 1 << log2_ctb
@@ -55,10 +56,21 @@ def gen_frame_ops(rng, W, H, bd, n_refs=2, intra_frac=0.15, bi_frac=0.6, coded_f
                     return
                 if x0 + size > W or y0 + size > H:
                     return
-                if rng.random() < intra_frac:
+                if log2 <= 5 and rng.random() < pcm_frac:
+                    pcm_cu(x0, y0, log2)
+                elif rng.random() < intra_frac:
                     intra_cu(x0, y0, log2)
                 else:
                     inter_cu(x0, y0, log2)
+
+            def pcm_cu(x0, y0, log2):
+                # hls_pcm_sample (hevc.c:1587-1621): raw samples for the three planes, pcm bit depth <= bit depth
+                for c_idx in range(3):
+                    l2 = log2 - (1 if c_idx else 0)
+                    pcm_bd = int(rng.integers(4, bd + 1))
+                    n = 1 << l2
+                    ops.append(dict(t="pcm", c_idx=c_idx, x0=x0, y0=y0, log2=l2, pcm_bd=pcm_bd, bd=bd,
+                                    samples=rng.integers(0, 1 << pcm_bd, size=(n, n))))
 
             def inter_cu(x0, y0, log2):
                 size = 1 << log2
