@@ -81,23 +81,28 @@ __device__ __forceinline__ int slot_of_rt(int n, int i)
 // M-point inverse transform of inputs in pair order -> out[0..M-1] (natural order), exact int32.
 // out[k] = sum_j T_M[j][k] * x[j] + init, with T_M[j][k] = dct32(j * 32/M, k); evaluated as the even/odd
 // partial butterfly of hevcdsp_template.c:210-262 (any evaluation order is bit-identical: no overflow).
-template <int M> struct Idct1D {
+template <int M, bool ASM = false> struct Idct1D {
     static __device__ __forceinline__ void run(const unsigned *p, int *out, int init)
     {
         int e[M / 2];
-        Idct1D<M / 2>::run(p + M / 4, e, init);
+        Idct1D<M / 2, ASM>::run(p + M / 4, e, init);
 #pragma unroll
         for (int i = 0; i < M / 2; i++) {
-            int o = 0;
+            int o;
+            if constexpr (ASM) {
+                o = dot2_i16_first(p[0], pack16(dct32(1 * (32 / M), i), dct32(3 * (32 / M), i)));
+            } else {
+                o = dot2_i16(p[0], pack16(dct32(1 * (32 / M), i), dct32(3 * (32 / M), i)), 0);
+            }
 #pragma unroll
-            for (int m = 0; m < M / 4; m++)
+            for (int m = 1; m < M / 4; m++)
                 o = dot2_i16(p[m], pack16(dct32((4 * m + 1) * (32 / M), i), dct32((4 * m + 3) * (32 / M), i)), o);
             out[i]         = e[i] + o;
             out[M - 1 - i] = e[i] - o;
         }
     }
 };
-template <> struct Idct1D<2> {     // inputs (x0, x_{M/2}) of the enclosing 4-point level: the "+-64" lane
+template <bool ASM> struct Idct1D<2, ASM> {     // inputs (x0, x_{M/2}) of the enclosing 4-point level: the "+-64" lane
     static __device__ __forceinline__ void run(const unsigned *p, int *out, int init)
     {
         out[0] = dot2_i16(p[0], pack16(64, 64), init);
@@ -235,7 +240,8 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
     }
     __builtin_amdgcn_wave_barrier();
     int t[N];
-    Idct1D<N>::run(p, t, 64);                               // + (1 << 6), then >> 7, clip_int16
+    constexpr bool ASM = (VARIANT & 128) != 0;
+    Idct1D<N, ASM>::run(p, t, 64);                          // + (1 << 6), then >> 7, clip_int16
     {
         unsigned short *dst = reinterpret_cast<unsigned short *>(blk) + slot_of_rt(N, i);
 #pragma unroll
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
         }
     }
     const int shift2 = 20 - bit_depth;
-    Idct1D<N>::run(p, t, 1 << (shift2 - 1));
+    Idct1D<N, ASM>::run(p, t, 1 << (shift2 - 1));
 #pragma unroll
     for (int k = 0; k < N; k++) t[k] >>= shift2;
 
@@ -303,8 +309,14 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
 #pragma unroll
                 for (int d4 = 0; d4 < 4; d4++) {
                     const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
-                    const unsigned s01 = add_clamp_px2(res[2 * d4], u01, max2), s23 = add_clamp_px2(res[2 * d4 + 1], u23, max2);
-                    od[d4] = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+                    if constexpr (ASM) {      // 8-bit content only (max2 == 255): saturating add, then clamp+pack in one op
+                        const unsigned a01 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4]), bitcast<s16x2>(u01)));
+                        const unsigned a23 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4 + 1]), bitcast<s16x2>(u23)));
+                        od[d4] = sat_pack_u8_i16(a01) | (sat_pack_u8_i16(a23) << 16);
+                    } else {
+                        const unsigned s01 = add_clamp_px2(res[2 * d4], u01, max2), s23 = add_clamp_px2(res[2 * d4 + 1], u23, max2);
+                        od[d4] = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+                    }
                 }
                 o = u32x4{ od[0], od[1], od[2], od[3] };
             } else {
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(256, (VARIANT & 8) ? 5 : 1) void tu_idct_add_pipe_k
         }
         __builtin_amdgcn_wave_barrier();
         int t[N];
-        Idct1D<N>::run(p, t, 64);
+        Idct1D<N, false>::run(p, t, 64);
         {
             unsigned short *dst = reinterpret_cast<unsigned short *>(blk) + slot_of_rt(N, i);
 #pragma unroll
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(256, (VARIANT & 8) ? 5 : 1) void tu_idct_add_pipe_k
             }
         }
         __builtin_amdgcn_wave_barrier();
-        Idct1D<N>::run(p, t, 1 << (shift2 - 1));
+        Idct1D<N, false>::run(p, t, 1 << (shift2 - 1));
 #pragma unroll
         for (int k = 0; k < N; k++) t[k] >>= shift2;
         if constexpr (!(VARIANT & 1)) load_row<N, Pixel>(row, px, valid);
@@ -625,7 +637,8 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
         return;
     }
     if (variant & 16) {
-        hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        if (variant & 128) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16 + 128>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        else               hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         return;
     }
     switch (variant & 3) {
