@@ -618,9 +618,9 @@ int g_tu_pipe_wgs = 2048; // workgroups of the persistent form (ohevc_debug_set_
 template <int LOG2N, typename Pixel>
 static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
 {
-    // shipped configuration (A/B on MI355X, profiles/r01_ab_tu_variants.txt): LDS-transposed, fully coalesced
-    // epilogue for 16x16 / 32x32; early prediction prefetch for 8x8
-    const int variant = g_tu_variant >= 0 ? g_tu_variant : (LOG2N >= 4 ? 16 : 1);
+    // shipped configuration (A/B on MI355X, profiles/r01*_ab_tu_variants.txt): LDS-transposed, fully coalesced epilogue
+    // + non-accumulating chain starts / v_sat_pk_u8_i16 for 16x16 and 32x32; early prediction prefetch for 8x8
+    const int variant = g_tu_variant >= 0 ? g_tu_variant : (LOG2N >= 4 ? 16 + 128 : 1);
     if (variant & 4) {
         const int pgrid = grid < g_tu_pipe_wgs ? grid : g_tu_pipe_wgs;
         switch (variant & 9) {
