@@ -138,6 +138,172 @@ __global__ __launch_bounds__(64) void mc_kernel(PlaneSet dst, const ohevc_plane 
         }
 }
 
+// ------------------------------------------------------------------ v2: packed-pair dot-product form
+// Same semantics as mc_kernel; per 16x16 tile and reference:
+//   1. stage the (tw+7) x (th+7) window into LDS as int16, row-major, window column 0 at LDS column 0.  Interior windows
+//      use aligned dword loads (4 / 2 samples per lane-load); windows touching the picture edge take the clamped
+//      per-sample path.
+//   2. horizontal pass: lane = (window row, group of 4 outputs): 12 consecutive int16 = 6 dwords -> 4 outputs, each
+//      4 x v_dot2_i32_i16 against packed tap pairs (odd outputs use v_alignbit'ed pairs).  Results go to LDS
+//      column-major [x][row].
+//   3. vertical pass: the SAME primitive along the other axis: lane = (column, group of 4 rows).
+//   Zero phases use the identity filter {0,0,0,64,0,0,0,0}: 64*p == p << 6, (64*t) >> 6 == t  -> all four (mx,my)
+//   cases of the reference in one exact path; chroma's 4-tap filters are the 8-tap form with four zero taps.
+__device__ const signed char kLumaTaps8[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+__device__ const signed char kChromaTaps8[8][8] = {
+    { 0, 64, 0, 0, 0, 0, 0, 0 }, { -2, 58, 10, -2, 0, 0, 0, 0 }, { -4, 54, 16, -2, 0, 0, 0, 0 }, { -6, 46, 28, -4, 0, 0, 0, 0 },
+    { -4, 36, 36, -4, 0, 0, 0, 0 }, { -4, 28, 46, -6, 0, 0, 0, 0 }, { -2, 16, 54, -4, 0, 0, 0, 0 }, { -2, 10, 58, -2, 0, 0, 0, 0 } };
+
+constexpr int MC2_PITCH = 24;                 // int16 elements per LDS line (23 used + 1 pad; 48 bytes keeps dwordx2 alignment)
+struct Mc2Shared {
+    short win[MC_WIN][MC2_PITCH];             // [window row][window col]
+    short tmp[MC_TILE][MC2_PITCH];            // [output col][window row]  (column-major for the vertical pass)
+};
+
+__device__ __forceinline__ unsigned tap_pair(const signed char *f, int k)
+{
+    return pack16((int)f[k], (int)f[k + 1]);
+}
+
+// out[i] = init + sum_{k<8} f[k] * v[i + k], i = 0..3, v = the 12 int16 held in d[0..5]
+__device__ __forceinline__ void filt4(const unsigned *d, unsigned f01, unsigned f23, unsigned f45, unsigned f67, int init, int *out)
+{
+    const unsigned m0 = __builtin_amdgcn_alignbit(d[1], d[0], 16), m1 = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+    const unsigned m2 = __builtin_amdgcn_alignbit(d[3], d[2], 16), m3 = __builtin_amdgcn_alignbit(d[4], d[3], 16);
+    const unsigned m4 = __builtin_amdgcn_alignbit(d[5], d[4], 16);
+    out[0] = dot2_i16(d[3], f67, dot2_i16(d[2], f45, dot2_i16(d[1], f23, dot2_i16(d[0], f01, init))));
+    out[1] = dot2_i16(m3, f67, dot2_i16(m2, f45, dot2_i16(m1, f23, dot2_i16(m0, f01, init))));
+    out[2] = dot2_i16(d[4], f67, dot2_i16(d[3], f45, dot2_i16(d[2], f23, dot2_i16(d[1], f01, init))));
+    out[3] = dot2_i16(m4, f67, dot2_i16(m3, f45, dot2_i16(m2, f23, dot2_i16(m1, f01, init))));
+}
+
+template <typename Pixel>
+__device__ __forceinline__ void mc2_tile_ref(Mc2Shared &sh, const ohevc_plane &ref, int sx, int sy, const signed char *fh,
+                                             const signed char *fv, int before, int taps, int tw, int th, int bit_depth,
+                                             int lane, int *v)
+{
+    const int ww = tw + taps - 1, wh = th + taps - 1;
+    const unsigned char *base = static_cast<const unsigned char *>(ref.data);
+    const int wx0 = sx - before, wy0 = sy - before;               // picture position of window (0,0)
+    constexpr int PPD = 4 / (int)sizeof(Pixel);                    // samples per dword
+    const int xa = wx0 & ~(PPD - 1);                               // aligned start of the row span
+    const int ndw = (wx0 + ww - xa + PPD - 1) / PPD;               // dwords per window row (<= 7 / 12)
+    const bool interior = wx0 >= 0 && wy0 >= 0 && wy0 + wh <= ref.height && xa + ndw * PPD <= ref.width &&
+                          ((ref.stride | (int)(reinterpret_cast<uintptr_t>(base))) & 3) == 0;
+    if (interior) {
+        constexpr int DPR = sizeof(Pixel) == 1 ? 8 : 16;           // dword slots per row (power of two >= ndw)
+        for (int idx = lane; idx < wh * DPR; idx += 64) {
+            const int r = idx / DPR, dw = idx % DPR;
+            if (dw >= ndw) continue;
+            const unsigned raw = *reinterpret_cast<const unsigned *>(base + (size_t)(wy0 + r) * ref.stride + (size_t)(xa + dw * PPD) * sizeof(Pixel));
+            const int c0 = xa + dw * PPD - wx0;                    // window column of the first sample in this dword
+#pragma unroll
+            for (int j = 0; j < PPD; j++) {
+                const int c = c0 + j;
+                const int pv = sizeof(Pixel) == 1 ? (int)((raw >> (8 * j)) & 0xff) : (int)((raw >> (16 * j)) & 0xffff);
+                if (c >= 0 && c < MC2_PITCH) sh.win[r][c] = (short)pv;
+            }
+        }
+    } else {
+        const int xmax = ref.width - 1, ymax = ref.height - 1;
+        for (int idx = lane; idx < ww * wh; idx += 64) {
+            const int wy = idx / ww, wx = idx - wy * ww;
+            int x = wx0 + wx, y = wy0 + wy;
+            x = x < 0 ? 0 : x > xmax ? xmax : x;
+            y = y < 0 ? 0 : y > ymax ? ymax : y;
+            sh.win[wy][wx] = (short)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass: lane = (window row r, output group q of 4 columns)
+    {
+        const unsigned f01 = tap_pair(fh, 0), f23 = tap_pair(fh, 2), f45 = tap_pair(fh, 4), f67 = tap_pair(fh, 6);
+        const int hshift = bit_depth - 8;
+        for (int idx = lane; idx < wh * 4; idx += 64) {
+            const int r = idx >> 2, q = idx & 3;
+            if (q * 4 >= tw) continue;
+            const u32x2 *p = reinterpret_cast<const u32x2 *>(&sh.win[r][q * 4]);
+            const u32x2 a = p[0], b = p[1], c = p[2];
+            const unsigned d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+            int o[4];
+            filt4(d, f01, f23, f45, f67, 0, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) sh.tmp[q * 4 + j][r] = (short)(o[j] >> hshift);
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass: lane = (output column x, group g of 4 rows)
+    {
+        const unsigned f01 = tap_pair(fv, 0), f23 = tap_pair(fv, 2), f45 = tap_pair(fv, 4), f67 = tap_pair(fv, 6);
+        const int x = lane & 15, g = lane >> 4;
+        int o[4] = { 0, 0, 0, 0 };
+        if (x < tw && g * 4 < th) {
+            const u32x2 *p = reinterpret_cast<const u32x2 *>(&sh.tmp[x][g * 4]);
+            const u32x2 a = p[0], b = p[1], c = p[2];
+            const unsigned d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+            filt4(d, f01, f23, f45, f67, 0, o);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = o[j] >> 6;
+    }
+    __syncthreads();
+}
+
+template <typename Pixel>
+__global__ __launch_bounds__(64) void mc2_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs,
+                                                 const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth)
+{
+    __shared__ __attribute__((aligned(16))) Mc2Shared sh;
+    const int lane = threadIdx.x;
+    const ohevc_mc_job jb = jobs[blockIdx.x];
+    const bool luma = jb.plane == 0, bi = jb.flags & OHEVC_MC_BI, weighted = jb.flags & OHEVC_MC_WEIGHTED;
+    const ohevc_plane ref0 = refs[3 * jb.ref0 + jb.plane];
+    const ohevc_plane ref1 = refs[3 * (bi ? jb.ref1 : jb.ref0) + jb.plane];
+    unsigned char *dbase = PLANE_PTR3(dst, jb.plane);
+    const int dstride = PLANE_STRIDE3(dst, jb.plane);
+    const int maxv = (1 << bit_depth) - 1;
+    const int before = luma ? 3 : 1, taps = luma ? 8 : 4;
+    const signed char *fh0 = luma ? kLumaTaps8[jb.mx0] : kChromaTaps8[jb.mx0], *fv0 = luma ? kLumaTaps8[jb.my0] : kChromaTaps8[jb.my0];
+    const signed char *fh1 = luma ? kLumaTaps8[jb.mx1] : kChromaTaps8[jb.mx1], *fv1 = luma ? kLumaTaps8[jb.my1] : kChromaTaps8[jb.my1];
+    const int x = lane & 15, g = lane >> 4;
+
+    for (int ty = 0; ty < jb.h; ty += MC_TILE)
+        for (int tx = 0; tx < jb.w; tx += MC_TILE) {
+            const int tw = jb.w - tx < MC_TILE ? jb.w - tx : MC_TILE;
+            const int th = jb.h - ty < MC_TILE ? jb.h - ty : MC_TILE;
+            int v0[4], v1[4] = { 0, 0, 0, 0 };
+            mc2_tile_ref<Pixel>(sh, ref0, jb.sx0 + tx, jb.sy0 + ty, fh0, fv0, before, taps, tw, th, bit_depth, lane, v0);
+            if (bi)
+                mc2_tile_ref<Pixel>(sh, ref1, jb.sx1 + tx, jb.sy1 + ty, fh1, fv1, before, taps, tw, th, bit_depth, lane, v1);
+            if (x >= tw) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int y = g * 4 + j;
+                if (y >= th) continue;
+                int out;
+                if (!bi && !weighted) {
+                    const int shift = 14 - bit_depth;
+                    out = (v0[j] + (1 << (shift - 1))) >> shift;
+                } else if (bi && !weighted) {
+                    const int shift = 15 - bit_depth;
+                    out = (v1[j] + v0[j] + (1 << (shift - 1))) >> shift;
+                } else if (!bi) {
+                    const int shift = jb.denom + 14 - bit_depth;
+                    out = ((v0[j] * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                } else {
+                    const int log2wd = jb.denom + 14 - bit_depth;
+                    const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
+                    out = (v1[j] * jb.wx1 + v0[j] * jb.wx0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
+                }
+                out = out < 0 ? 0 : out > maxv ? maxv : out;
+                *reinterpret_cast<Pixel *>(dbase + (size_t)(jb.y + ty + y) * dstride + (size_t)(jb.x + tx + x) * sizeof(Pixel)) = (Pixel)out;
+            }
+        }
+}
+
+int g_mc_variant = 2;     // 1 = first (scalar) kernel, 2 = packed-pair kernel
+
 }  // namespace ohevc
 
 extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
@@ -154,10 +320,20 @@ extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *r
     int rc = make_plane_set(dst, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bit_depth == 8)
-        hipLaunchKernelGGL((mc_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
-    else
-        hipLaunchKernelGGL((mc_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+    if (g_mc_variant == 1) {
+        if (bit_depth == 8) hipLaunchKernelGGL((mc_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+        else                hipLaunchKernelGGL((mc_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+    } else {
+        if (bit_depth == 8) hipLaunchKernelGGL((mc2_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+        else                hipLaunchKernelGGL((mc2_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+    }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_debug_set_mc_variant(int variant)
+{
+    int old = ohevc::g_mc_variant;
+    if (variant == 1 || variant == 2) ohevc::g_mc_variant = variant;
+    return old;
 }

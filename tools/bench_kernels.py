@@ -88,8 +88,6 @@ def main():
         d_jobs = dev(j)
         ms = timeit(lambda pic: L.dev_deblock_batch(L.planes_of(pic), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g))
         report(f"deblock luma vertical edges, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
-        j["flags"] = 0
-        j["x"], j["y"] = np.meshgrid(np.arange(0, W, 8), np.arange(8, H, 8))[0].ravel()[:n], np.meshgrid(np.arange(0, W, 8), np.arange(8, H, 8))[1].ravel()[:n]
         n2 = np.meshgrid(np.arange(0, W, 8), np.arange(8, H, 8))[0].size
         j2 = np.zeros(n2, L.DBK_JOB)
         xs, ys = np.meshgrid(np.arange(0, W, 8), np.arange(8, H, 8))
