@@ -78,6 +78,15 @@ typedef struct ohevc_tu_job {           /* 16 bytes */
 int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, int log2_size, int kind,
                        const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, void *stream);
 
+/* Same work as several ohevc_dev_tu_batch calls in ONE launch: `segs` (HOST array, <= 40 entries) cuts the job array
+ * into runs of equal (log2_size, kind).  Blocks of different segments must not overlap either. */
+typedef struct ohevc_tu_segment {
+    int32_t log2_size, kind;
+    int32_t first_job, njobs;           /* run inside `jobs` */
+} ohevc_tu_segment;
+int ohevc_dev_tu_multi(const ohevc_plane planes[3], int bit_depth, const ohevc_tu_segment *segs, int nsegs,
+                       const ohevc_tu_job *jobs, const int16_t *coeffs, void *stream);
+
 /* ---- 2.2 motion compensation: replaces, per prediction block, the wrappers luma_mc_uni/bi, chroma_mc_uni/bi
  * (hevc.c:1641-1949) together with the table slots they call:
  *   put_hevc_{qpel,epel}[idx][!!my][!!mx]            (first half of bi-pred, 14-bit intermediate)   hevcdsp.h:68,81

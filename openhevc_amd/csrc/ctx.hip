@@ -447,10 +447,25 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }
+        // every (size, kind) bin of this level in ONE launch (bins are staged back to back, 256-byte = 16-job aligned)
+        std::vector<ohevc_tu_segment> segs;
+        size_t level_base = 0;
         for (; tu_it != c->tu.end() && (int)(tu_it->first >> 8) == level; ++tu_it) {
-            const int log2 = (tu_it->first >> 4) & 15, kind = tu_it->first & 15;
-            rc = ohevc_dev_tu_batch(p->planes, p->bd, log2, kind, reinterpret_cast<const ohevc_tu_job *>(base + off_tu[tu_it->first]),
-                                    (int)tu_it->second.size(), d_coeffs, c->stream);
+            if (segs.empty()) level_base = off_tu[tu_it->first];
+            ohevc_tu_segment sg;
+            sg.log2_size = (tu_it->first >> 4) & 15; sg.kind = tu_it->first & 15;
+            sg.first_job = (int32_t)((off_tu[tu_it->first] - level_base) / sizeof(ohevc_tu_job));
+            sg.njobs = (int32_t)tu_it->second.size();
+            segs.push_back(sg);
+            if (segs.size() == 40) {          // table full: flush (cannot happen with 4 sizes x 10 kinds, kept for safety)
+                rc = ohevc_dev_tu_multi(p->planes, p->bd, segs.data(), (int)segs.size(), reinterpret_cast<const ohevc_tu_job *>(base + level_base), d_coeffs, c->stream);
+                if (rc != OHEVC_OK) return rc;
+                c->stats.launches++;
+                segs.clear();
+            }
+        }
+        if (!segs.empty()) {
+            rc = ohevc_dev_tu_multi(p->planes, p->bd, segs.data(), (int)segs.size(), reinterpret_cast<const ohevc_tu_job *>(base + level_base), d_coeffs, c->stream);
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }

@@ -193,16 +193,15 @@ __device__ __forceinline__ void add_row_store(unsigned char *row, const int *res
 // VARIANT bits (A/B switches, see ohevc_debug.h): 1 = fetch the prediction row before the transform instead of
 // after it; 2 = read coefficients straight from HBM as int16 columns (no LDS staging pass).
 template <int LOG2N, typename Pixel, int VARIANT>
-__global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
-                                                          int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
+__device__ __forceinline__ void tu_idct_add_body(unsigned char *lds, int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
+                                                 int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
 {
     using L = TuLayout<LOG2N>;
     constexpr int N = L::N, RS = L::RS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * L::WAVE_BYTES];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane / N, i = lane % N;
-    const int job0 = (blockIdx.x * 4 + wave) * L::BPW;
+    const int job0 = (wg * 4 + wave) * L::BPW;
     if (job0 >= njobs) return;                              // wave-uniform; no workgroup barrier is used below
     const bool valid = job0 + g < njobs;
     const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[valid ? job0 + g : njobs - 1];
@@ -330,6 +329,14 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
         if constexpr (!(VARIANT & 1)) load_row<N, Pixel>(row, px, valid);
         finish_row<N, Pixel>(row, px, t, bit_depth, valid);
     }
+}
+
+template <int LOG2N, typename Pixel, int VARIANT>
+__global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs,
+                                                          int njobs, const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<LOG2N>::WAVE_BYTES];
+    tu_idct_add_body<LOG2N, Pixel, VARIANT>(lds, blockIdx.x, planes, jobs, njobs, coeffs, bit_depth);
 }
 
 // ------------------------------------------------------------------ ablations (NOT bit-exact; bottleneck analysis only)
@@ -501,10 +508,10 @@ __global__ __launch_bounds__(256, (VARIANT & 8) ? 5 : 1) void tu_idct_add_pipe_k
 
 // ------------------------------------------------------------------ 4x4 IDCT / DST: one lane per block
 template <typename Pixel, bool DST>
-__global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
-                                                     const int16_t *__restrict__ coeffs, int bit_depth)
+__device__ __forceinline__ void tu_4x4_body(int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                            const int16_t *__restrict__ coeffs, int bit_depth)
 {
-    const int job = blockIdx.x * 256 + threadIdx.x;
+    const int job = wg * 256 + threadIdx.x;
     if (job >= njobs) return;
     const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
     const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
@@ -549,15 +556,22 @@ __global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohev
     }
 }
 
+template <typename Pixel, bool DST>
+__global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                                     const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    tu_4x4_body<Pixel, DST>(blockIdx.x, planes, jobs, njobs, coeffs, bit_depth);
+}
+
 // ------------------------------------------------------------------ DC-only / transform-skip / bypass (+rdpcm): one lane per row
 // idct_dc :303-316, transform_skip :139-163, transform_rdpcm :114-136 (int16 wrap-around of the in-place reference
 // is reproduced by truncating to int16 after the modular prefix sum).
 template <int LOG2N, typename Pixel>
-__global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
-                                                      const int16_t *__restrict__ coeffs, int bit_depth, int kind)
+__device__ __forceinline__ void tu_rows_body(int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                             const int16_t *__restrict__ coeffs, int bit_depth, int kind)
 {
     constexpr int N = 1 << LOG2N;
-    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int tid = wg * 256 + threadIdx.x;
     const int job = tid >> LOG2N, r = tid & (N - 1);
     if (job >= njobs) return;
     const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
@@ -609,6 +623,46 @@ __global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohe
     } else {
         add_row_store<N, Pixel>(row, res, bit_depth, true);
     }
+}
+
+template <int LOG2N, typename Pixel>
+__global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                                      const int16_t *__restrict__ coeffs, int bit_depth, int kind)
+{
+    tu_rows_body<LOG2N, Pixel>(blockIdx.x, planes, jobs, njobs, coeffs, bit_depth, kind);
+}
+
+// ------------------------------------------------------------------ one launch for a mix of sizes and kinds
+// A frame's residuals come in up to 4 sizes x 10 kinds.  Launching each (size, kind) bin separately costs a kernel
+// boundary per bin (x every intra dependency level); instead the host passes a small segment table and every workgroup
+// looks up which bin it serves.  All lanes of a workgroup run the same body, so nothing diverges.
+constexpr int TU_MAX_SEGMENTS = 40;
+struct TuSegTable {
+    int nsegs;
+    int first_wg[TU_MAX_SEGMENTS + 1];       // prefix sum of workgroups per segment
+    int first_job[TU_MAX_SEGMENTS];
+    int njobs[TU_MAX_SEGMENTS];
+    unsigned char log2[TU_MAX_SEGMENTS], kind[TU_MAX_SEGMENTS];
+};
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void tu_multi_kernel(PlaneSet planes, TuSegTable tab, const ohevc_tu_job *__restrict__ jobs,
+                                                       const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<5>::WAVE_BYTES];
+    int s = 0;
+    while (s + 1 < tab.nsegs && (int)blockIdx.x >= tab.first_wg[s + 1]) s++;      // wave-uniform scan, <= 40 entries
+    const int wg = blockIdx.x - tab.first_wg[s], log2 = tab.log2[s], kind = tab.kind[s], n = tab.njobs[s];
+    const ohevc_tu_job *j = jobs + tab.first_job[s];
+    if (kind == OHEVC_TU_IDCT && log2 == 5)      tu_idct_add_body<5, Pixel, 16 + 128>(lds, wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_IDCT && log2 == 4) tu_idct_add_body<4, Pixel, 16 + 128>(lds, wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_IDCT && log2 == 3) tu_idct_add_body<3, Pixel, 1>(lds, wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_IDCT)              tu_4x4_body<Pixel, false>(wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_DST4)              tu_4x4_body<Pixel, true>(wg, planes, j, n, coeffs, bit_depth);
+    else if (log2 == 2)                          tu_rows_body<2, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    else if (log2 == 3)                          tu_rows_body<3, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    else if (log2 == 4)                          tu_rows_body<4, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    else                                         tu_rows_body<5, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
 }
 
 // ------------------------------------------------------------------ launcher
@@ -703,6 +757,47 @@ extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     return bit_depth == 8 ? launch_tu<uint8_t>(ps, bit_depth, log2_size, kind, jobs, njobs, coeffs, st)
                           : launch_tu<uint16_t>(ps, bit_depth, log2_size, kind, jobs, njobs, coeffs, st);
+}
+
+// workgroups a segment of n jobs needs (must match the per-kind launch geometry in launch_tu)
+static int tu_workgroups(int log2, int kind, int n)
+{
+    if (kind == OHEVC_TU_IDCT && log2 >= 3) { const int per_wg = 4 * (64 >> log2); return (n + per_wg - 1) / per_wg; }
+    if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) return (n + 255) / 256;
+    return (int)((((long long)n << log2) + 255) / 256);
+}
+
+extern "C" int ohevc_dev_tu_multi(const ohevc_plane planes[3], int bit_depth, const ohevc_tu_segment *segs, int nsegs,
+                                  const ohevc_tu_job *jobs, const int16_t *coeffs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(planes != nullptr && (nsegs == 0 || segs != nullptr), "null argument");
+    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(nsegs >= 0 && nsegs <= TU_MAX_SEGMENTS, "too many segments (max 40)");
+    OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "jobs/coeffs must be 16-byte aligned");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps);
+    if (rc != OHEVC_OK) return rc;
+    TuSegTable tab = {};
+    int wgs = 0;
+    for (int i = 0; i < nsegs; i++) {
+        const ohevc_tu_segment &sg = segs[i];
+        OHEVC_REQUIRE(sg.log2_size >= 2 && sg.log2_size <= 5 && sg.kind < OHEVC_TU_NKINDS && sg.njobs >= 0, "bad segment");
+        OHEVC_REQUIRE(sg.kind != OHEVC_TU_DST4 || sg.log2_size == 2, "DST is 4x4 only");
+        if (sg.njobs == 0) continue;
+        const int k = tab.nsegs++;
+        tab.first_wg[k] = wgs; tab.first_job[k] = sg.first_job; tab.njobs[k] = sg.njobs;
+        tab.log2[k] = (unsigned char)sg.log2_size; tab.kind[k] = (unsigned char)sg.kind;
+        wgs += tu_workgroups(sg.log2_size, sg.kind, sg.njobs);
+    }
+    tab.first_wg[tab.nsegs] = wgs;
+    if (wgs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr, "jobs");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bit_depth == 8) hipLaunchKernelGGL((tu_multi_kernel<uint8_t>), dim3(wgs), dim3(256), 0, st, ps, tab, jobs, coeffs, bit_depth);
+    else                hipLaunchKernelGGL((tu_multi_kernel<uint16_t>), dim3(wgs), dim3(256), 0, st, ps, tab, jobs, coeffs, bit_depth);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
 }
 
 extern "C" int ohevc_debug_set_tu_variant(int variant)

@@ -59,7 +59,7 @@ def load_library():
 
 
 # every symbol include/ohevc_hip.h declares (checked by the CPU-side ABI test)
-EXPORTED_SYMBOLS = ["ohevc_dev_tu_batch", "ohevc_last_error", "ohevc_device_count", "ohevc_set_device",
+EXPORTED_SYMBOLS = ["ohevc_dev_tu_batch", "ohevc_dev_tu_multi", "ohevc_last_error", "ohevc_device_count", "ohevc_set_device",
                     "ohevc_tu_kernel_name", "ohevc_version"]
 
 

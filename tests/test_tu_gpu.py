@@ -126,3 +126,47 @@ def test_full_size_batch_sampled_against_oracle(oracle):
         assert np.array_equal(plane[y:y + n, x:x + n].cpu().numpy(), ref_blk), b
     ys = slice((1000 // per_row + 1) * n, (2000 // per_row) * n)
     assert torch.equal(plane[ys], before[ys])
+
+
+def test_multi_segment_launch_equals_per_bin_launches(oracle):
+    """ohevc_dev_tu_multi: a mix of sizes and kinds in one launch == the oracle applied bin by bin."""
+    import ctypes as C
+    import torch
+    import gpu_util as G
+    from openhevc_amd import lib as L
+    rng = np.random.default_rng(2024)
+    bd = 10
+    plane = rng.integers(0, 1 << bd, size=(256, 512)).astype(np.uint16)
+    want = plane.copy()
+    bins = [(5, po.TU_IDCT, 7), (4, po.TU_IDCT, 9), (3, po.TU_IDCT, 33), (2, po.TU_IDCT, 50), (2, po.TU_DST4, 21),
+            (4, po.TU_DC, 5), (3, po.TU_SKIP, 11), (2, po.TU_BYPASS_RDPCM_V, 3), (5, po.TU_BYPASS, 2)]
+    # non-overlapping placement: one 32-row band per bin
+    jobs_all, coeffs_all, segs = [], [], []
+    coff = 0
+    for band, (log2, kind, n) in enumerate(bins[:8]):
+        pass
+    y0 = 0
+    for (log2, kind, n) in bins:
+        nn = 1 << log2
+        per_row = 512 // nn
+        xy = np.array([[(i % per_row) * nn, y0 + (i // per_row) * nn] for i in range(n)], np.int32)
+        c = rng.integers(-1500, 1500, size=(n, nn, nn)).astype(np.int16)
+        oracle.tu_batch(bd, kind, log2, c, want, xy)
+        j = np.zeros(n + (-n) % 16, L.TU_JOB)                      # pad every bin to a 16-job (256-byte) boundary like the ctx layer does
+        j["x"][:n], j["y"][:n] = xy[:, 0], xy[:, 1]
+        j["coeff_off"][:n] = coff + np.arange(n, dtype=np.uint32) * nn * nn
+        j["dc"][:n] = c[:, 0, 0]
+        segs.append((log2, kind, sum(len(a) for a in jobs_all), n))
+        jobs_all.append(j); coeffs_all.append(c.reshape(-1)); coff += c.size
+        y0 += ((n + per_row - 1) // per_row) * nn
+    assert y0 <= 256
+    jobs = np.concatenate(jobs_all); coeffs = np.concatenate(coeffs_all)
+
+    class Seg(C.Structure):
+        _fields_ = [("log2_size", C.c_int32), ("kind", C.c_int32), ("first_job", C.c_int32), ("njobs", C.c_int32)]
+    sarr = (Seg * len(segs))(*[Seg(*s) for s in segs])
+    d_plane, d_jobs, d_coeffs = G.to_dev(plane), G.to_dev(jobs), G.to_dev(coeffs)
+    L.check(L.load_library().ohevc_dev_tu_multi(L.planes_of([d_plane, None, None]), bd, sarr, len(segs), C.c_void_p(d_jobs.data_ptr()),
+                                                C.c_void_p(d_coeffs.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(G.to_host(d_plane, np.uint16), want)
