@@ -15,7 +15,8 @@ extern "C" {
 int ohevc_debug_set_tu_variant(int variant);
 /* bit 2 of the variant selects the persistent, software-pipelined kernel; this sets its grid size (workgroups). */
 int ohevc_debug_set_tu_pipe_workgroups(int n);
-/* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel (shipped) */
+/* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = 2 + both reference
+ * windows staged before the first barrier (shipped) */
 int ohevc_debug_set_mc_variant(int variant);
 #ifdef __cplusplus
 }

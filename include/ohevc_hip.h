@@ -117,6 +117,10 @@ typedef struct ohevc_mc_job {           /* 32 bytes */
  * (slot-major: refs[3 * slot + plane]); width/height there are the picture size used for clamping. */
 int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
                        const ohevc_mc_job *jobs, int njobs, void *stream);
+/* Same contract for batches in which EVERY job has w <= 8 and h <= 8 (most chroma blocks of 4:2:0 content): four jobs share
+ * one wavefront.  Jobs that violate the size limit produce undefined pixels inside their own block. */
+int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                             const ohevc_mc_job *jobs, int njobs, void *stream);
 
 /* ---- 2.3 deblocking: replaces hevc_{h,v}_loop_filter_{luma,chroma}[_c] (hevcdsp.h:97-104;
  * hevcdsp_template.c:1629-1787).  One job = one table call = one 8-sample edge (two 4-line segments).

@@ -62,7 +62,7 @@ struct ohevc_ctx {
     int cur = -1;
     Picture twin;                     // deblocked copy for SAO (the reference's sao_frame, hevc.c:369-385)
 
-    std::vector<ohevc_mc_job> mc;
+    std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
     std::map<uint32_t, std::vector<ohevc_tu_job>> tu;     // (level, log2, kind) -> jobs
     std::map<int, std::vector<ohevc_intra_job>> intra;    // level -> jobs
     std::vector<int16_t> coeffs;
@@ -223,7 +223,7 @@ extern "C" int ohevc_pic_info(ohevc_ctx *c, int slot, int *width, int *height, i
 
 static void clear_recorded(ohevc_ctx *c)
 {
-    c->mc.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear();
+    c->mc.clear(); c->mc_small.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear();
     for (int i = 0; i < 3; i++) std::fill(c->level_map[i].begin(), c->level_map[i].end(), 0);
 }
 
@@ -271,7 +271,18 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
     OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
     OHEVC_REQUIRE(job->plane < 3 && job->w >= 2 && job->w <= 64 && job->h >= 2 && job->h <= 64, "bad MC block");
     OHEVC_REQUIRE(get_pic(c, job->ref0) != nullptr && (!(job->flags & OHEVC_MC_BI) || get_pic(c, job->ref1) != nullptr), "bad reference slot");
-    c->mc.push_back(*job);
+    // Prediction blocks are cut into tiles of at most 16x16 samples (every tile is an independent job: same references,
+    // positions shifted by the tile offset), so a 64x64 PU spreads over 16 wavefronts; tiles of at most 8x8 go to the
+    // packed small-block kernel (four per wavefront).
+    for (int ty = 0; ty < job->h; ty += 16)
+        for (int tx = 0; tx < job->w; tx += 16) {
+            ohevc_mc_job t = *job;
+            t.x = (uint16_t)(job->x + tx); t.y = (uint16_t)(job->y + ty);
+            t.w = (uint8_t)std::min(16, job->w - tx); t.h = (uint8_t)std::min(16, job->h - ty);
+            t.sx0 = (int16_t)(job->sx0 + tx); t.sy0 = (int16_t)(job->sy0 + ty);
+            t.sx1 = (int16_t)(job->sx1 + tx); t.sy1 = (int16_t)(job->sy1 + ty);
+            ((t.w <= 8 && t.h <= 8) ? c->mc_small : c->mc).push_back(t);
+        }
     c->stats.n_mc++;
     return OHEVC_OK;
 }
@@ -411,7 +422,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     OHEVC_HIP_TRY(hipSetDevice(c->device));
-    if (c->mc.empty() && c->tu.empty() && c->intra.empty()) return OHEVC_OK;
+    if (c->mc.empty() && c->mc_small.empty() && c->tu.empty() && c->intra.empty()) return OHEVC_OK;
     int rc = upload_table(c);
     if (rc != OHEVC_OK) return rc;
 
@@ -419,6 +430,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     std::vector<std::pair<const void *, size_t>> parts;
     size_t total = 0;
     const size_t off_mc = c->mc.empty() ? 0 : stage_put(parts, total, c->mc.data(), c->mc.size() * sizeof(ohevc_mc_job));
+    const size_t off_mcs = c->mc_small.empty() ? 0 : stage_put(parts, total, c->mc_small.data(), c->mc_small.size() * sizeof(ohevc_mc_job));
     std::map<uint32_t, size_t> off_tu;
     for (auto &kv : c->tu) off_tu[kv.first] = stage_put(parts, total, kv.second.data(), kv.second.size() * sizeof(ohevc_tu_job));
     std::map<int, size_t> off_intra;
@@ -432,6 +444,12 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if (!c->mc.empty()) {
         rc = ohevc_dev_mc_batch(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), (int)c->pics.size(), p->bd,
                                 reinterpret_cast<const ohevc_mc_job *>(base + off_mc), (int)c->mc.size(), c->stream);
+        if (rc != OHEVC_OK) return rc;
+        c->stats.launches++;
+    }
+    if (!c->mc_small.empty()) {
+        rc = ohevc_dev_mc_batch_small(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), (int)c->pics.size(), p->bd,
+                                      reinterpret_cast<const ohevc_mc_job *>(base + off_mcs), (int)c->mc_small.size(), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
     }

@@ -302,12 +302,170 @@ __global__ __launch_bounds__(64) void mc2_kernel(PlaneSet dst, const ohevc_plane
         }
 }
 
-int g_mc_variant = 2;     // 1 = first (scalar) kernel, 2 = packed-pair kernel
+// ------------------------------------------------------------------ v3: v2's arithmetic, more parallelism
+// SLOTS = 1: one job per wavefront in 16x16 tiles.  SLOTS = 4: four jobs of at most 8x8 samples per wavefront (16 lanes
+// each) -- chroma blocks of 4:2:0 content and small PUs are mostly that size, and a 64-lane wave is 3/4 idle on them.
+// In both forms the windows of BOTH references are requested before the first barrier, so a bi-predicted block exposes
+// one global-memory latency instead of two.
+template <int SLOTS> struct Mc3Cfg {
+    static constexpr int SL = 64 / SLOTS;            // lanes per job slot
+    static constexpr int T = SLOTS == 1 ? 16 : 8;    // tile edge
+    static constexpr int WIN = T + 7;                // window rows
+    static constexpr int PITCH = T + 8;              // int16 per LDS line (window cols + pad; dwordx2 aligned)
+    static constexpr int GROUPS = T / 4;             // 4-output groups per line
+};
+template <int SLOTS> struct Mc3Shared {
+    short win[SLOTS][2][Mc3Cfg<SLOTS>::WIN][Mc3Cfg<SLOTS>::PITCH];
+    short tmp[SLOTS][Mc3Cfg<SLOTS>::T][Mc3Cfg<SLOTS>::PITCH];
+};
+
+template <typename Pixel, int SLOTS>
+__device__ __forceinline__ void mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], const ohevc_plane &ref, int wx0, int wy0, int ww, int wh,
+                                          int sub, bool active)
+{
+    using C = Mc3Cfg<SLOTS>;
+    const unsigned char *base = static_cast<const unsigned char *>(ref.data);
+    constexpr int PPD = 4 / (int)sizeof(Pixel);
+    constexpr int DPR = (sizeof(Pixel) == 1 || SLOTS == 4) ? 8 : 16;      // dword slots per window row (>= max ndw)
+    const int xa = wx0 & ~(PPD - 1);
+    const int ndw = (wx0 + ww - xa + PPD - 1) / PPD;
+    const bool interior = wx0 >= 0 && wy0 >= 0 && wy0 + wh <= ref.height && xa + ndw * PPD <= ref.width &&
+                          ((ref.stride | (int)(reinterpret_cast<uintptr_t>(base))) & 3) == 0;
+    if (!active) return;
+    if (interior) {
+#pragma unroll 1
+        for (int idx = sub; idx < wh * DPR; idx += C::SL) {
+            const int r = idx / DPR, dw = idx % DPR;
+            if (dw >= ndw) continue;
+            const unsigned raw = *reinterpret_cast<const unsigned *>(base + (size_t)(wy0 + r) * ref.stride + (size_t)(xa + dw * PPD) * sizeof(Pixel));
+            const int c0 = xa + dw * PPD - wx0;
+#pragma unroll
+            for (int j = 0; j < PPD; j++) {
+                const int c = c0 + j;
+                const int pv = sizeof(Pixel) == 1 ? (int)((raw >> (8 * j)) & 0xff) : (int)((raw >> (16 * j)) & 0xffff);
+                if (c >= 0 && c < C::PITCH) win[r][c] = (short)pv;
+            }
+        }
+    } else {
+        const int xmax = ref.width - 1, ymax = ref.height - 1;
+#pragma unroll 1
+        for (int idx = sub; idx < ww * wh; idx += C::SL) {
+            const int wy = idx / ww, wx = idx - wy * ww;
+            int x = wx0 + wx, y = wy0 + wy;
+            x = x < 0 ? 0 : x > xmax ? xmax : x;
+            y = y < 0 ? 0 : y > ymax ? ymax : y;
+            win[wy][wx] = (short)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
+        }
+    }
+}
+
+// horizontal + vertical pass of one staged window -> v[0..3] (4 rows of this lane's column), 14-bit intermediate
+template <int SLOTS>
+__device__ __forceinline__ void mc3_filter(short (*win)[Mc3Cfg<SLOTS>::PITCH], short (*tmp)[Mc3Cfg<SLOTS>::PITCH], const signed char *fh,
+                                           const signed char *fv, int tw, int th, int wh, int bit_depth, int sub, bool active, int *v)
+{
+    using C = Mc3Cfg<SLOTS>;
+    {
+        const unsigned f01 = tap_pair(fh, 0), f23 = tap_pair(fh, 2), f45 = tap_pair(fh, 4), f67 = tap_pair(fh, 6);
+        const int hshift = bit_depth - 8;
+#pragma unroll 1
+        for (int it = 0; it < (C::WIN * C::GROUPS + C::SL - 1) / C::SL; it++) {
+            const int idx = sub + it * C::SL, r = idx / C::GROUPS, q = idx % C::GROUPS;
+            if (active && r < wh && q * 4 < tw) {
+                const u32x2 *p = reinterpret_cast<const u32x2 *>(&win[r][q * 4]);
+                const u32x2 a = p[0], b = p[1], c = p[2];
+                const unsigned d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+                int o[4];
+                filt4(d, f01, f23, f45, f67, 0, o);
+#pragma unroll
+                for (int j = 0; j < 4; j++) tmp[q * 4 + j][r] = (short)(o[j] >> hshift);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned f01 = tap_pair(fv, 0), f23 = tap_pair(fv, 2), f45 = tap_pair(fv, 4), f67 = tap_pair(fv, 6);
+        const int x = sub % C::T, g = sub / C::T;
+        int o[4] = { 0, 0, 0, 0 };
+        if (active && x < tw && g * 4 < th) {
+            const u32x2 *p = reinterpret_cast<const u32x2 *>(&tmp[x][g * 4]);
+            const u32x2 a = p[0], b = p[1], c = p[2];
+            const unsigned d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
+            filt4(d, f01, f23, f45, f67, 0, o);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = o[j] >> 6;
+    }
+    __syncthreads();
+}
+
+template <typename Pixel, int SLOTS>
+__global__ __launch_bounds__(64) void mc3_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs,
+                                                 const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth)
+{
+    using C = Mc3Cfg<SLOTS>;
+    __shared__ __attribute__((aligned(16))) Mc3Shared<SLOTS> sh;
+    const int lane = threadIdx.x;
+    const int slot = SLOTS == 1 ? 0 : lane / C::SL, sub = SLOTS == 1 ? lane : lane % C::SL;   // SLOTS == 1: provably wave-uniform job
+    const int jidx = blockIdx.x * SLOTS + slot;
+    const bool have = jidx < njobs;
+    const ohevc_mc_job jb = jobs[have ? jidx : njobs - 1];
+    const bool luma = jb.plane == 0, bi = jb.flags & OHEVC_MC_BI, weighted = jb.flags & OHEVC_MC_WEIGHTED;
+    const ohevc_plane ref0 = refs[3 * jb.ref0 + jb.plane];
+    const ohevc_plane ref1 = refs[3 * (bi ? jb.ref1 : jb.ref0) + jb.plane];
+    unsigned char *dbase = PLANE_PTR3(dst, jb.plane);
+    const int dstride = PLANE_STRIDE3(dst, jb.plane);
+    const int maxv = (1 << bit_depth) - 1;
+    const int before = luma ? 3 : 1, taps = luma ? 8 : 4;
+    const signed char *fh0 = luma ? kLumaTaps8[jb.mx0] : kChromaTaps8[jb.mx0], *fv0 = luma ? kLumaTaps8[jb.my0] : kChromaTaps8[jb.my0];
+    const signed char *fh1 = luma ? kLumaTaps8[jb.mx1] : kChromaTaps8[jb.mx1], *fv1 = luma ? kLumaTaps8[jb.my1] : kChromaTaps8[jb.my1];
+    const int x = sub % C::T, g = sub / C::T;
+    // all slots iterate the same (maximal) number of tiles so that the barriers stay uniform; SLOTS == 4 jobs fit one tile
+    const int ntx = SLOTS == 1 ? (jb.w + C::T - 1) / C::T : 1, nty = SLOTS == 1 ? (jb.h + C::T - 1) / C::T : 1;
+    for (int tyi = 0; tyi < nty; tyi++)
+        for (int txi = 0; txi < ntx; txi++) {
+            const int tx = txi * C::T, ty = tyi * C::T;
+            const int tw = jb.w - tx < C::T ? jb.w - tx : C::T, th = jb.h - ty < C::T ? jb.h - ty : C::T;
+            const int ww = tw + taps - 1, wh = th + taps - 1;
+            const bool active = have && tw > 0 && th > 0;
+            mc3_stage<Pixel, SLOTS>(sh.win[slot][0], ref0, jb.sx0 + tx - before, jb.sy0 + ty - before, ww, wh, sub, active);
+            mc3_stage<Pixel, SLOTS>(sh.win[slot][1], ref1, jb.sx1 + tx - before, jb.sy1 + ty - before, ww, wh, sub, active && bi);
+            __syncthreads();
+            int v0[4], v1[4] = { 0, 0, 0, 0 };
+            mc3_filter<SLOTS>(sh.win[slot][0], sh.tmp[slot], fh0, fv0, tw, th, wh, bit_depth, sub, active, v0);
+            mc3_filter<SLOTS>(sh.win[slot][1], sh.tmp[slot], fh1, fv1, tw, th, wh, bit_depth, sub, active && bi, v1);
+            if (!active || x >= tw) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int y = g * 4 + j;
+                if (y >= th) continue;
+                int out;
+                if (!bi && !weighted) {
+                    const int shift = 14 - bit_depth;
+                    out = (v0[j] + (1 << (shift - 1))) >> shift;
+                } else if (bi && !weighted) {
+                    const int shift = 15 - bit_depth;
+                    out = (v1[j] + v0[j] + (1 << (shift - 1))) >> shift;
+                } else if (!bi) {
+                    const int shift = jb.denom + 14 - bit_depth;
+                    out = ((v0[j] * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                } else {
+                    const int log2wd = jb.denom + 14 - bit_depth;
+                    const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
+                    out = (v1[j] * jb.wx1 + v0[j] * jb.wx0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
+                }
+                out = out < 0 ? 0 : out > maxv ? maxv : out;
+                *reinterpret_cast<Pixel *>(dbase + (size_t)(jb.y + ty + y) * dstride + (size_t)(jb.x + tx + x) * sizeof(Pixel)) = (Pixel)out;
+            }
+        }
+}
+
+int g_mc_variant = 3;     // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = v2 + dual staging / job slots (shipped)
 
 }  // namespace ohevc
 
-extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
-                                  const ohevc_mc_job *jobs, int njobs, void *stream)
+static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                     const ohevc_mc_job *jobs, int njobs, void *stream, bool small)
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr, "dst");
@@ -320,20 +478,39 @@ extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *r
     int rc = make_plane_set(dst, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g_mc_variant == 1) {
+    if (small) {
+        const int grid = (njobs + 3) / 4;
+        if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+        else                hipLaunchKernelGGL((mc3_kernel<uint16_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+    } else if (g_mc_variant == 1) {
         if (bit_depth == 8) hipLaunchKernelGGL((mc_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
         else                hipLaunchKernelGGL((mc_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
-    } else {
+    } else if (g_mc_variant == 2) {
         if (bit_depth == 8) hipLaunchKernelGGL((mc2_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
         else                hipLaunchKernelGGL((mc2_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+    } else {
+        if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+        else                hipLaunchKernelGGL((mc3_kernel<uint16_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
     }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                                  const ohevc_mc_job *jobs, int njobs, void *stream)
+{
+    return mc_launch(dst, refs, n_ref_slots, bit_depth, jobs, njobs, stream, false);
+}
+
+extern "C" int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                                        const ohevc_mc_job *jobs, int njobs, void *stream)
+{
+    return mc_launch(dst, refs, n_ref_slots, bit_depth, jobs, njobs, stream, true);
+}
+
 extern "C" int ohevc_debug_set_mc_variant(int variant)
 {
     int old = ohevc::g_mc_variant;
-    if (variant == 1 || variant == 2) ohevc::g_mc_variant = variant;
+    if (variant >= 1 && variant <= 3) ohevc::g_mc_variant = variant;
     return old;
 }

@@ -112,7 +112,7 @@ INTRA_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("log2_size",
                       ("bottom_left_size", "u1"), ("top_right_size", "u1"), ("reserved", "u1", (6,))])
 assert INTRA_JOB.itemsize == 16
 
-EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_intra_batch"]
+EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_mc_batch_small", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_intra_batch"]
 
 
 def planes_table(list_of_plane_triples):
@@ -133,6 +133,12 @@ def dev_mc_batch(dst_planes, refs_ptr, n_slots, bit_depth, jobs_ptr, njobs, stre
     lib = load_library()
     check(lib.ohevc_dev_mc_batch(dst_planes, C.c_void_p(refs_ptr), C.c_int(n_slots), C.c_int(bit_depth),
                                  C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
+
+
+def dev_mc_batch_small(dst_planes, refs_ptr, n_slots, bit_depth, jobs_ptr, njobs, stream=0):
+    lib = load_library()
+    check(lib.ohevc_dev_mc_batch_small(dst_planes, C.c_void_p(refs_ptr), C.c_int(n_slots), C.c_int(bit_depth),
+                                       C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
 def dev_deblock_batch(planes, bit_depth, jobs_ptr, njobs, stream=0):

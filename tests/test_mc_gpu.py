@@ -80,3 +80,52 @@ def test_mc_all_variants_and_edges(oracle, bd):
             got = G.to_host(d_dst[pl], dst[pl].dtype)
             bad = np.argwhere(got != want[pl])
             assert bad.size == 0, f"bd={bd} rep={rep} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_mc_small_blocks_four_per_wave(oracle, bd):
+    """ohevc_dev_mc_batch_small: jobs of at most 8x8 samples, four per wavefront, incl. counts that are not multiples of 4."""
+    rng = np.random.default_rng(600 + bd)
+    W, H = 208, 144
+    dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+    refs = [[rng.integers(0, 1 << bd, size=d).astype(G.pixdt(bd)) for d in dims] for _ in range(2)]
+    refs_padded = [[np.pad(p, PAD, mode="edge") for p in slot] for slot in refs]
+    dst = [rng.integers(0, 1 << bd, size=d).astype(G.pixdt(bd)) for d in dims]
+    for njobs in (1, 3, 4, 157):
+        jobs = []
+        used = set()
+        while len(jobs) < njobs:
+            pl = int(rng.integers(0, 3)); luma = pl == 0
+            cx, cy = int(rng.integers(0, dims[pl][1] // 8)), int(rng.integers(0, dims[pl][0] // 8))
+            if (pl, cx, cy) in used:
+                continue
+            used.add((pl, cx, cy))
+            j = np.zeros(1, L.MC_JOB)[0]
+            j["x"], j["y"], j["plane"] = cx * 8, cy * 8, pl
+            j["w"] = int(rng.choice([4, 8] if luma else [2, 4, 6, 8])); j["h"] = int(rng.choice([4, 8] if luma else [2, 4, 6, 8]))
+            j["flags"] = int(rng.integers(0, 4))
+            for s_ in ("0", "1"):
+                far = rng.random() < 0.3
+                j["sx" + s_] = int(rng.integers(-40, dims[pl][1] + 6)) if far else int(rng.integers(0, dims[pl][1] - 8))
+                j["sy" + s_] = int(rng.integers(-40, dims[pl][0] + 6)) if far else int(rng.integers(0, dims[pl][0] - 8))
+                fr = 4 if luma else 8
+                j["mx" + s_], j["my" + s_] = int(rng.integers(0, fr)), int(rng.integers(0, fr))
+                j["ref" + s_] = int(rng.integers(0, 2))
+                j["wx" + s_], j["ox" + s_] = int(rng.integers(-128, 256)), int(rng.integers(-128, 128))
+            j["denom"] = int(rng.integers(0, 8))
+            jobs.append(j)
+        batch = np.array(jobs, dtype=L.MC_JOB)
+        want = [p.copy() for p in dst]
+        for j in batch:
+            pl = int(j["plane"])
+            want[pl][j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]] = expected_block(oracle, bd, pl == 0, j, refs_padded)
+        d_dst = [G.to_dev(p) for p in dst]
+        d_refs = [[G.to_dev(p) for p in slot] for slot in refs]
+        d_table = torch.from_numpy(L.planes_table(d_refs)).cuda()
+        d_jobs = G.to_dev(batch)
+        L.dev_mc_batch_small(G.planes3(d_dst), d_table.data_ptr(), 2, bd, d_jobs.data_ptr(), len(batch), G.stream())
+        torch.cuda.synchronize()
+        for pl in range(3):
+            got = G.to_host(d_dst[pl], dst[pl].dtype)
+            bad = np.argwhere(got != want[pl])
+            assert bad.size == 0, f"bd={bd} njobs={njobs} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
