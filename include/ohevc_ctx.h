@@ -37,6 +37,8 @@ int  ohevc_ctx_sync(ohevc_ctx *ctx);
 
 /* ---- picture store: pixel planes of DPB entries, resident in HBM for the life of the HEVCFrame (hevc_refs.c:75-147) */
 int  ohevc_pic_alloc(ohevc_ctx *ctx, int width, int height, int chroma_format_idc, int bit_depth);   /* slot >= 0 or error */
+/* register planes allocated by someone else (e.g. tensors an RCCL broadcast writes into) as a picture; never freed by ctx */
+int  ohevc_pic_adopt(ohevc_ctx *ctx, const ohevc_plane planes[3], int width, int height, int chroma_format_idc, int bit_depth);
 int  ohevc_pic_release(ohevc_ctx *ctx, int slot);
 int  ohevc_pic_upload(ohevc_ctx *ctx, int slot, int plane, const void *host, ptrdiff_t host_stride);
 int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff_t host_stride);

@@ -11,7 +11,7 @@
 namespace {
 
 struct Picture {
-    bool used = false;
+    bool used = false, owned = true;
     int w = 0, h = 0, cfi = 1, bd = 8;
     ohevc_plane planes[3] = {};
 };
@@ -81,10 +81,10 @@ using namespace ohevc;
 static int free_picture(Picture &p)
 {
     for (auto &pl : p.planes) {
-        if (pl.data) OHEVC_HIP_TRY(hipFree(pl.data));
+        if (pl.data && p.owned) OHEVC_HIP_TRY(hipFree(pl.data));
         pl = ohevc_plane{};
     }
-    p.used = false;
+    p.used = false; p.owned = true;
     return OHEVC_OK;
 }
 
@@ -160,6 +160,25 @@ extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int
     OHEVC_REQUIRE(slot < 127, "too many pictures");
     int rc = alloc_picture(c->pics[slot], width, height, cfi, bd);
     if (rc != OHEVC_OK) return rc;
+    c->table_dirty = true;
+    return slot;
+}
+
+extern "C" int ohevc_pic_adopt(ohevc_ctx *c, const ohevc_plane planes[3], int width, int height, int cfi, int bd)
+{
+    OHEVC_REQUIRE(c != nullptr && planes != nullptr, "null argument");
+    OHEVC_REQUIRE(width > 0 && height > 0 && cfi >= 1 && cfi <= 3 && bd >= 8 && bd <= 12, "bad picture description");
+    int slot = -1;
+    for (size_t i = 0; i < c->pics.size(); i++) if (!c->pics[i].used) { slot = (int)i; break; }
+    if (slot < 0) { c->pics.emplace_back(); slot = (int)c->pics.size() - 1; }
+    OHEVC_REQUIRE(slot < 127, "too many pictures");
+    Picture &p = c->pics[slot];
+    p.w = width; p.h = height; p.cfi = cfi; p.bd = bd; p.owned = false; p.used = true;
+    for (int i = 0; i < 3; i++) {
+        OHEVC_REQUIRE(planes[i].data != nullptr && (planes[i].stride & 15) == 0 && (reinterpret_cast<uintptr_t>(planes[i].data) & 15) == 0,
+                      "adopted planes must be 16-byte aligned with a 16-byte multiple stride");
+        p.planes[i] = planes[i];
+    }
     c->table_dirty = true;
     return slot;
 }

@@ -181,7 +181,7 @@ class FrameStats(C.Structure):
 
 
 EXPORTED_SYMBOLS += ["ohevc_ctx_create", "ohevc_ctx_destroy", "ohevc_ctx_stream", "ohevc_ctx_sync", "ohevc_pic_alloc",
-                     "ohevc_pic_release", "ohevc_pic_upload", "ohevc_pic_download", "ohevc_pic_planes", "ohevc_frame_begin",
+                     "ohevc_pic_release", "ohevc_pic_adopt", "ohevc_pic_upload", "ohevc_pic_download", "ohevc_pic_planes", "ohevc_frame_begin",
                      "ohevc_rec_tu", "ohevc_rec_mc", "ohevc_rec_intra", "ohevc_rec_deblock", "ohevc_rec_sao",
                      "ohevc_frame_reconstruct", "ohevc_frame_end", "ohevc_frame_get_stats", "ohevc_rec_mc_bulk",
                      "ohevc_rec_intra_bulk", "ohevc_rec_tu_bulk", "ohevc_rec_deblock_bulk", "ohevc_rec_sao_bulk"]
@@ -212,6 +212,12 @@ class Ctx:
 
     def pic_alloc(self, width, height, chroma_format_idc, bit_depth):
         slot = self.lib.ohevc_pic_alloc(self.h, width, height, chroma_format_idc, bit_depth)
+        if slot < 0:
+            check(slot)
+        return slot
+
+    def pic_adopt(self, tensors, width, height, chroma_format_idc, bit_depth):
+        slot = self.lib.ohevc_pic_adopt(self.h, planes_of(tensors), width, height, chroma_format_idc, bit_depth)
         if slot < 0:
             check(slot)
         return slot

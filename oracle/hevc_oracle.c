@@ -8,9 +8,11 @@
  *
  * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks every function here bit-for-bit
  * against the reference's own compiled C (oracle/_ref/libhevcref.so, built by oracle/Makefile from
- * /root/reference) on seeded random and corner-case inputs, and tests/golden/ holds fixtures
- * generated from that reference build (tests/golden/make_golden.py) so the pin also holds where
- * /root/reference is absent.  The reference ships no golden vectors of its own.
+ * /root/reference) on seeded random and corner-case inputs; tests/test_table_driver_cpu.py pins it at
+ * whole-picture level against the reference's tables driven by a miniature front-end; and tests/golden/
+ * holds 1652 output digests frozen from that reference build (tests/golden/make_golden.py, replayed by
+ * tests/test_oracle_golden.py) so the pin also holds where /root/reference is absent.  The reference
+ * ships no golden vectors of its own.  Not restated yet: constrained-intra-pred substitution.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
