@@ -54,7 +54,8 @@ def main():
         slots[idx] = ctx.pic_adopt(planes, W, H, 1, bd)
         return planes
 
-    arrays_cache = {}
+    base_arrays = X.ops_to_arrays(W, H, [0, 1], ops, fops)      # built once; reference slots patched per picture
+    base_ref0, base_ref1 = base_arrays["mc"]["ref0"].copy(), base_arrays["mc"]["ref1"].copy()
 
     def reconstruct(idx, refs, out):
         ref_idx = sorted(refs)
@@ -64,12 +65,13 @@ def main():
                 t.copy_(torch.randint(0, 1 << bd, t.shape, dtype=dt, device="cuda", generator=g))
             torch.cuda.synchronize()
             return
-        rs = [slots[ref_idx[0]], slots[ref_idx[-1]]]
-        key = tuple(rs)
-        if key not in arrays_cache:
-            arrays_cache[key] = X.ops_to_arrays(W, H, rs, ops, fops)
+        rs = np.array([slots[ref_idx[0]], slots[ref_idx[-1]]], dtype=np.int8)
+        arrays = dict(base_arrays)
+        mc = base_arrays["mc"].copy()
+        mc["ref0"], mc["ref1"] = rs[base_ref0], rs[base_ref1]
+        arrays["mc"] = mc
         ctx.frame_begin(slots[idx])
-        ctx.rec_bulk(**arrays_cache[key])
+        ctx.rec_bulk(**arrays)
         ctx.frame_end()
         ctx.sync()
 
