@@ -52,6 +52,8 @@ int  ohevc_frame_begin(ohevc_ctx *ctx, int slot);
 int  ohevc_rec_tu(ohevc_ctx *ctx, int plane, int x, int y, int log2_size, int kind, const int16_t *coeffs, int intra);
 int  ohevc_rec_mc(ohevc_ctx *ctx, const ohevc_mc_job *job);              /* ref0/ref1 are picture-store slots */
 int  ohevc_rec_intra(ohevc_ctx *ctx, const ohevc_intra_job *job);
+/* job marked OHEVC_INTRA2_CIP: `cip` is copied and job->cip_index is assigned by the recorder */
+int  ohevc_rec_intra_cip(ohevc_ctx *ctx, const ohevc_intra_job *job, const ohevc_intra_cip *cip);
 int  ohevc_rec_deblock(ohevc_ctx *ctx, const ohevc_dbk_job *job);
 int  ohevc_rec_sao(ohevc_ctx *ctx, const ohevc_sao_job *job);
 

@@ -182,18 +182,35 @@ typedef struct ohevc_intra_job {        /* 16 bytes */
     uint8_t  flags;                     /* OHEVC_INTRA_* */
     uint8_t  bottom_left_size;          /* valid samples below the block in the left column (0..N) */
     uint8_t  top_right_size;            /* valid samples right of the block in the top row (0..N) */
-    uint8_t  reserved[6];
+    uint8_t  flags2;                    /* OHEVC_INTRA2_* */
+    uint8_t  reserved;
+    uint32_t cip_index;                 /* OHEVC_INTRA2_CIP: index of this job's ohevc_intra_cip record */
 } ohevc_intra_job;
+
+/* constrained_intra_pred_flag streams (hevcpred_template.c:116-163,185-249): the five availability flags in the job
+ * are the RE-DERIVED ones (neighbours coded as inter do not count), and this side record carries what the substitution
+ * walk needs: per-sample "is the neighbour intra-coded" bits and the two scan limits. */
+enum { OHEVC_INTRA2_CIP = 1 };
+typedef struct ohevc_intra_cip {        /* 32 bytes */
+    uint8_t top_bits[9];                /* bit k+1: IS_INTRA(k, -1) for k = -1 .. 63 */
+    uint8_t left_bits[9];               /* bit k+1: IS_INTRA(-1, k) for k = -1 .. 63 */
+    uint8_t size_max_x, size_max_y;     /* hevcpred_template.c:187-198 */
+    uint8_t x0_nonzero, y0_nonzero;
+    uint8_t reserved[10];
+} ohevc_intra_cip;
 
 int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
                           void *stream);
+/* same, with the side records of the OHEVC_INTRA2_CIP jobs (device pointer, 16-byte aligned) */
+int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
+                              const ohevc_intra_cip *cip, void *stream);
 
 /* Host helper (no GPU work): turn one intra_pred[log2-2](s, x0, y0, c_idx) call of the reference into a job.
  * Inputs are exactly what the reference's front-end holds at the call site (hevc.c:1214-1215): the block position
  * in LUMA samples, HEVClc->na.cand_* (ff_hevc_set_neighbour_available, hevc_mvs.c:41-58), the prediction mode
  * (lc->tu.intra_pred_mode[_c]) and the SPS/PPS geometry.  Performs the z-scan qualification of
  * hevcpred_template.c:105-109 (CTB-local MinTbAddrZs, hevc_ps.c:2551-2567) and the picture clipping of :111-114.
- * Returns OHEVC_ERR_ARG for constrained_intra_pred streams (not supported yet). */
+ * For constrained_intra_pred streams use ohevc_intra_make_job_cip (this function returns OHEVC_ERR_ARG for them). */
 typedef struct ohevc_intra_geom {
     int32_t width, height;              /* luma samples */
     int32_t chroma_format_idc;          /* 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */
@@ -206,6 +223,14 @@ typedef struct ohevc_intra_geom {
 int ohevc_intra_make_job(const ohevc_intra_geom *geom, int x0, int y0, int log2_size, int c_idx, int mode,
                          int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right,
                          ohevc_intra_job *out);
+/* As above for any stream.  With geom->constrained_intra_pred set, `pred_flag` points at the prediction-mode byte of the
+ * first minimum-PU entry of the picture's motion-field map (the reference's s->ref->tab_mvf[0].pred_flag, hevc.h:1032-1041),
+ * `pred_flag_stride` is the distance in bytes between entries (sizeof(MvField)) and an entry is intra when the byte equals
+ * `intra_value` (PF_INTRA = 0).  Fills *cip and marks the job OHEVC_INTRA2_CIP; the caller stores cip and sets cip_index. */
+int ohevc_intra_make_job_cip(const ohevc_intra_geom *geom, int log2_min_pu_size, const uint8_t *pred_flag,
+                             ptrdiff_t pred_flag_stride, int intra_value, int x0, int y0, int log2_size, int c_idx, int mode,
+                             int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right,
+                             ohevc_intra_job *out, ohevc_intra_cip *cip);
 
 /* ------------------------------------------------------------------ 3. library management */
 const char *ohevc_last_error(void);                 /* text of the last HIP failure on this thread */

@@ -116,6 +116,11 @@ int  ohevc_tables_status(ohevc_ctx *ctx);
  * stub in INTEGRATION.md extracts the fields below from HEVCContext and calls this. */
 int  ohevc_tables_intra_pred(const ohevc_intra_geom *geom, int x0, int y0, int log2_size, int c_idx, int mode,
                              int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right);
+/* same for constrained_intra_pred streams: pass &s->ref->tab_mvf[0].pred_flag, sizeof(MvField), PF_INTRA and
+ * s->sps->log2_min_pu_size (see ohevc_intra_make_job_cip) */
+int  ohevc_tables_intra_pred_cip(const ohevc_intra_geom *geom, int log2_min_pu_size, const uint8_t *pred_flag,
+                                 ptrdiff_t pred_flag_stride, int intra_value, int x0, int y0, int log2_size, int c_idx, int mode,
+                                 int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,7 @@ struct ohevc_ctx {
     std::map<uint32_t, std::vector<ohevc_tu_job>> tu;     // (level, log2, kind) -> jobs
     std::map<int, std::vector<ohevc_intra_job>> intra;    // level -> jobs
     std::vector<int16_t> coeffs;
+    std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
     std::vector<ohevc_sao_job> sao;
     std::vector<uint16_t> level_map[3];
@@ -242,7 +243,7 @@ extern "C" int ohevc_pic_info(ohevc_ctx *c, int slot, int *width, int *height, i
 
 static void clear_recorded(ohevc_ctx *c)
 {
-    c->mc.clear(); c->mc_small.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear();
+    c->mc.clear(); c->mc_small.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear(); c->cips.clear();
     for (int i = 0; i < 3; i++) std::fill(c->level_map[i].begin(), c->level_map[i].end(), 0);
 }
 
@@ -306,7 +307,27 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
     return OHEVC_OK;
 }
 
+static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job);
+
+extern "C" int ohevc_rec_intra_cip(ohevc_ctx *c, const ohevc_intra_job *job, const ohevc_intra_cip *cip)
+{
+    OHEVC_REQUIRE(c != nullptr && job != nullptr, "null argument");
+    ohevc_intra_job j = *job;
+    if (j.flags2 & OHEVC_INTRA2_CIP) {
+        OHEVC_REQUIRE(cip != nullptr, "CIP job without side record");
+        j.cip_index = (uint32_t)c->cips.size();
+        c->cips.push_back(*cip);
+    }
+    return rec_intra_impl(c, &j);
+}
+
 extern "C" int ohevc_rec_intra(ohevc_ctx *c, const ohevc_intra_job *job)
+{
+    OHEVC_REQUIRE(job == nullptr || !(job->flags2 & OHEVC_INTRA2_CIP), "constrained-intra jobs go through ohevc_rec_intra_cip");
+    return rec_intra_impl(c, job);
+}
+
+static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
@@ -455,6 +476,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     std::map<int, size_t> off_intra;
     for (auto &kv : c->intra) off_intra[kv.first] = stage_put(parts, total, kv.second.data(), kv.second.size() * sizeof(ohevc_intra_job));
     const size_t off_coeffs = c->coeffs.empty() ? 0 : stage_put(parts, total, c->coeffs.data(), c->coeffs.size() * sizeof(int16_t));
+    const size_t off_cips = c->cips.empty() ? 0 : stage_put(parts, total, c->cips.data(), c->cips.size() * sizeof(ohevc_intra_cip));
     if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
     unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
     const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
@@ -479,8 +501,9 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     for (int level = 0; level <= max_level; level++) {
         auto it = c->intra.find(level);
         if (it != c->intra.end()) {
-            rc = ohevc_dev_intra_batch(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + off_intra[level]),
-                                       (int)it->second.size(), c->stream);
+            rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + off_intra[level]),
+                                           (int)it->second.size(),
+                                           c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), c->stream);
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }

@@ -8,8 +8,8 @@
 //   * the [1 2 1] / strong bilinear smoothing (:289-327) is one parallel pass;
 //   * prediction: each lane produces N*N/64 samples, stored row-contiguously.
 // Everything the reference derives from HEVCContext (z-scan availability, picture clipping, smoothing enables)
-// arrives resolved in the job record (include/ohevc_hip.h).  constrained_intra_pred substitution is not
-// implemented yet (jobs from such streams must stay on the CPU path).
+// arrives resolved in the job record (include/ohevc_hip.h); constrained_intra_pred streams add a side record with
+// per-sample "neighbour is intra" bits and the substitution walk of :185-249 runs on one lane.
 #include "common.hpp"
 
 namespace ohevc {
@@ -27,7 +27,8 @@ struct IntraShared {
 };
 
 template <typename Pixel>
-__global__ __launch_bounds__(64) void intra_kernel(PlaneSet planes, const ohevc_intra_job *__restrict__ jobs, int njobs, int bit_depth)
+__global__ __launch_bounds__(64) void intra_kernel(PlaneSet planes, const ohevc_intra_job *__restrict__ jobs, int njobs, int bit_depth,
+                                                   const ohevc_intra_cip *__restrict__ cips)
 {
     __shared__ IntraShared sh;
     const int lane = threadIdx.x;
@@ -41,6 +42,13 @@ __global__ __launch_bounds__(64) void intra_kernel(PlaneSet planes, const ohevc_
     int *t = sh.top + 1, *l = sh.left + 1;
 #define REC(x, y) ((int)*reinterpret_cast<const Pixel *>(blk + (ptrdiff_t)(y) * stride + (ptrdiff_t)(x) * (int)sizeof(Pixel)))
 
+    const bool cip = (jb.flags2 & OHEVC_INTRA2_CIP) && cips != nullptr;
+    if (cip) {            // memset(left/top, 128, ...) of BYTES, top[-1] = 128  (:160-162)
+        const int fill = sizeof(Pixel) == 2 ? 0x8080 : 128;
+        t[lane] = fill; l[lane] = fill;
+        if (lane == 63) { t[-1] = 128; l[-1] = 128; }
+        __syncthreads();
+    }
     // ---- gather what is available (:164-183); samples beyond the picture replicate the last valid one
     if (lane < n2) {
         const int k = lane;
@@ -51,6 +59,78 @@ __global__ __launch_bounds__(64) void intra_kernel(PlaneSet planes, const ohevc_
     }
     if (lane == 63 && c_ul) { l[-1] = REC(-1, -1); t[-1] = l[-1]; }
     __syncthreads();
+
+    // ---- constrained intra prediction (:185-249): samples of inter-coded neighbours are overwritten from the nearest
+    //      intra-coded ones.  The walk is order-dependent, so one lane runs it over the LDS arrays (rare streams only).
+    if (cip && (c_bl || c_l || c_ul || c_u || c_ur)) {
+        if (lane == 0) {
+            const ohevc_intra_cip cr = cips[jb.cip_index];
+            // 65 bits each: bit 0 = the corner (k = -1), bits 1..64 = k = 0..63; held as corner + 64-bit mask (no indexing)
+            unsigned long long tmask = 0, lmask = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                tmask |= (unsigned long long)(((unsigned)cr.top_bits[b] | ((unsigned)cr.top_bits[b + 1] << 8)) >> 1 & 0xff) << (8 * b);
+                lmask |= (unsigned long long)(((unsigned)cr.left_bits[b] | ((unsigned)cr.left_bits[b + 1] << 8)) >> 1 & 0xff) << (8 * b);
+            }
+            const int tcorner = cr.top_bits[0] & 1, lcorner = cr.left_bits[0] & 1;
+            auto TB = [&](int k) { return k < 0 ? tcorner : (int)((tmask >> k) & 1); };           // IS_INTRA(k, -1)
+            auto LB = [&](int k) { return k < 0 ? lcorner : (int)((lmask >> k) & 1); };           // IS_INTRA(-1, k)
+            const int smx = cr.size_max_x, smy = cr.size_max_y;
+            int j = n + (c_bl ? bl_size : 0) - 1;
+            if (c_bl || c_l || c_ul) {
+                while (j > -1 && !LB(j)) j--;
+                if (!LB(j)) {
+                    j = 0;
+                    while (j < smx && !TB(j)) j++;
+                    for (int i = j; i > -1; i--) if (!TB(i - 1)) t[i - 1] = t[i];
+                    l[-1] = t[-1];
+                }
+            } else {
+                j = 0;
+                while (j < smx && !TB(j)) j++;
+                if (j > 0) {
+                    if (cr.x0_nonzero) {
+                        for (int i = j; i > -1; i--) if (!TB(i - 1)) t[i - 1] = t[i];
+                    } else {
+                        for (int i = j; i > 0; i--) if (!TB(i - 1)) t[i - 1] = t[i];
+                        t[-1] = t[0];
+                    }
+                }
+                l[-1] = t[-1];
+            }
+            l[-1] = t[-1];
+            if (c_bl || c_l) {
+                int a = l[-1];
+                for (int i = 0; i < smy; i += 4) {
+                    if (!LB(i)) { l[i] = l[i + 1] = l[i + 2] = l[i + 3] = a; } else a = l[i + 3];
+                }
+            }
+            if (!c_l) for (int i = 0; i < n; i++) l[i] = l[-1];
+            if (!c_bl) for (int i = n; i < n2; i++) l[i] = l[n - 1];
+            if (cr.x0_nonzero && cr.y0_nonzero) {
+                int a = l[smy - 1];
+                for (int i = smy - 1; i > -1; i -= 4) {
+                    if (!LB(i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
+                }
+                if (!LB(-1)) l[-1] = l[0];
+            } else if (!cr.x0_nonzero) {
+                for (int i = 0; i < smy; i++) l[i] = 0;
+            } else {
+                int a = l[smy - 1];
+                for (int i = smy - 1; i > -1; i -= 4) {
+                    if (!LB(i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
+                }
+            }
+            t[-1] = l[-1];
+            if (cr.y0_nonzero) {
+                int a = l[-1];
+                for (int i = 0; i < smx; i += 4) {
+                    if (!TB(i)) { t[i] = t[i + 1] = t[i + 2] = t[i + 3] = a; } else a = t[i + 3];
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- substitution of unavailable samples (:251-286); every branch is wave-uniform
     if (!c_bl) {
@@ -187,7 +267,8 @@ __global__ __launch_bounds__(64) void intra_kernel(PlaneSet planes, const ohevc_
 
 }  // namespace ohevc
 
-extern "C" int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs, void *stream)
+extern "C" int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
+                                         const ohevc_intra_cip *cip, void *stream)
 {
     using namespace ohevc;
     OHEVC_REQUIRE(planes != nullptr, "planes");
@@ -195,12 +276,18 @@ extern "C" int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth,
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
+    OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(cip) & 15) == 0, "cip records must be 16-byte aligned");
     PlaneSet ps;
     int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bit_depth == 8) hipLaunchKernelGGL((intra_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, njobs, bit_depth);
-    else                hipLaunchKernelGGL((intra_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, njobs, bit_depth);
+    if (bit_depth == 8) hipLaunchKernelGGL((intra_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, njobs, bit_depth, cip);
+    else                hipLaunchKernelGGL((intra_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, njobs, bit_depth, cip);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs, void *stream)
+{
+    return ohevc_dev_intra_batch_cip(planes, bit_depth, jobs, njobs, nullptr, stream);
 }

@@ -412,3 +412,17 @@ extern "C" int ohevc_tables_intra_pred(const ohevc_intra_geom *geom, int x0, int
     if (rc != OHEVC_OK) fail(rc);
     return rc;
 }
+
+extern "C" int ohevc_tables_intra_pred_cip(const ohevc_intra_geom *geom, int log2_min_pu_size, const uint8_t *pred_flag,
+                                           ptrdiff_t pred_flag_stride, int intra_value, int x0, int y0, int log2_size, int c_idx, int mode,
+                                           int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right)
+{
+    if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
+    ohevc_intra_job j;
+    ohevc_intra_cip cip;
+    int rc = ohevc_intra_make_job_cip(geom, log2_min_pu_size, pred_flag, pred_flag_stride, intra_value, x0, y0, log2_size, c_idx, mode,
+                                      cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, &j, &cip);
+    if (rc == OHEVC_OK) rc = ohevc_rec_intra_cip(tl_ctx, &j, &cip);
+    if (rc != OHEVC_OK) fail(rc);
+    return rc;
+}

@@ -109,10 +109,15 @@ assert SAO_JOB.itemsize == 32
 INTRA_BOTTOM_LEFT, INTRA_LEFT, INTRA_UP_LEFT, INTRA_UP, INTRA_UP_RIGHT = 1, 2, 4, 8, 16
 INTRA_NO_SMOOTHING, INTRA_STRONG, INTRA_LUMA_EDGE = 32, 64, 128
 INTRA_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("log2_size", "u1"), ("mode", "u1"), ("flags", "u1"),
-                      ("bottom_left_size", "u1"), ("top_right_size", "u1"), ("reserved", "u1", (6,))])
+                      ("bottom_left_size", "u1"), ("top_right_size", "u1"), ("flags2", "u1"), ("reserved", "u1"), ("cip_index", "<u4")])
 assert INTRA_JOB.itemsize == 16
+INTRA2_CIP = 1
+INTRA_CIP = np.dtype([("top_bits", "u1", (9,)), ("left_bits", "u1", (9,)), ("size_max_x", "u1"), ("size_max_y", "u1"),
+                      ("x0_nonzero", "u1"), ("y0_nonzero", "u1"), ("reserved", "u1", (10,))])
+assert INTRA_CIP.itemsize == 32
 
-EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_mc_batch_small", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_intra_batch"]
+EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_mc_batch_small", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_intra_batch", "ohevc_dev_intra_batch_cip",
+                     "ohevc_intra_make_job_cip", "ohevc_rec_intra_cip", "ohevc_tables_intra_pred_cip"]
 
 
 def planes_table(list_of_plane_triples):
@@ -149,6 +154,10 @@ def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_sao_batch(dst_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
+def dev_intra_batch_cip(planes, bit_depth, jobs_ptr, njobs, cip_ptr, stream=0):
+    check(load_library().ohevc_dev_intra_batch_cip(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(cip_ptr), C.c_void_p(stream)))
+
+
 def dev_intra_batch(planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_intra_batch(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
@@ -162,6 +171,18 @@ class IntraGeom(C.Structure):
 EXPORTED_SYMBOLS += ["ohevc_intra_make_job", "ohevc_hevcdsp_init_hip", "ohevc_videodsp_init_hip", "ohevc_tables_bind",
                      "ohevc_tables_register_picture", "ohevc_tables_unregister_picture", "ohevc_tables_begin_frame",
                      "ohevc_tables_end_frame", "ohevc_tables_status", "ohevc_tables_intra_pred", "ohevc_pic_info"]
+
+
+def intra_make_job_cip(geom, log2_min_pu_size, is_intra_map, x0, y0, log2_size, c_idx, mode, cands):
+    """is_intra_map: uint8 [pu_h, pu_w], 1 = intra.  Returns (job[1], cip[1])."""
+    out = np.zeros(1, INTRA_JOB); cip = np.zeros(1, INTRA_CIP)
+    m = np.ascontiguousarray(is_intra_map, dtype=np.uint8)
+    bl, lf, ul, up, ur = cands
+    check(load_library().ohevc_intra_make_job_cip(C.byref(geom), C.c_int(log2_min_pu_size), m.ctypes.data_as(C.c_void_p), C.c_ssize_t(1),
+                                                  C.c_int(1), C.c_int(x0), C.c_int(y0), C.c_int(log2_size), C.c_int(c_idx), C.c_int(mode),
+                                                  C.c_int(bl), C.c_int(lf), C.c_int(ul), C.c_int(up), C.c_int(ur),
+                                                  out.ctypes.data_as(C.c_void_p), cip.ctypes.data_as(C.c_void_p)))
+    return out, cip
 
 
 def intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cands):

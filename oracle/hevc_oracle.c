@@ -12,7 +12,7 @@
  * whole-picture level against the reference's tables driven by a miniature front-end; and tests/golden/
  * holds 1652 output digests frozen from that reference build (tests/golden/make_golden.py, replayed by
  * tests/test_oracle_golden.py) so the pin also holds where /root/reference is absent.  The reference
- * ships no golden vectors of its own.  Not restated yet: constrained-intra-pred substitution.
+ * ships no golden vectors of its own.  
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
@@ -584,9 +584,47 @@ void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, 
     int x_end = x0 + 2 * nlh < pic->width  ? x0 + 2 * nlh : pic->width;
     int bl_size = (y_end - (y0 + nlv)) >> vs, tr_size = (x_end - (x0 + nlh)) >> hs;   /* :111-114 */
 
-    if (pic->constrained_intra_pred) {
-        /* constrained-intra substitution (:116-163,185-249) is restated in round 2; refuse loudly */
-        abort();
+    /* ---- constrained intra prediction, part 1 (:116-163): neighbours coded as inter count as unavailable.
+     * IS(px, py): is the minimum PU at LUMA position (px, py) intra?  (MVF_PU / IS_INTRA, :33-40).  Positions outside
+     * the picture read undefined memory in the reference; here they count as "not intra". */
+    const int cip = pic->constrained_intra_pred;
+    const int lpu = pic->log2_min_pu_size;
+    const int pu_w = (pic->width + (1 << lpu) - 1) >> lpu, pu_h = (pic->height + (1 << lpu) - 1) >> lpu;
+#define ISPU(xp, yp) ((xp) >= 0 && (yp) >= 0 && (xp) < pu_w && (yp) < pu_h && pic->is_intra[(xp) + (yp) * pu_w])
+#define ISI(x, y) ISPU((x0 + (int)((unsigned)(x) << hs)) >> lpu, (y0 + (int)((unsigned)(y) << vs)) >> lpu)
+    if (cip) {
+        int spu_v = nlv >> lpu, spu_h = nlh >> lpu;
+        const int edge_x = !(x0 & ((1 << lpu) - 1)), edge_y = !(y0 & ((1 << lpu) - 1));
+        if (!spu_h) spu_h++;                                  /* (only the horizontal count is bumped, :122-123) */
+        if (cand_bottom_left == 1 && edge_x) {
+            const int xl = (x0 - 1) >> lpu, yb = (y0 + nlv) >> lpu;
+            const int max = spu_v < pu_h - yb ? spu_v : pu_h - yb;
+            cand_bottom_left = 0;
+            for (int i = 0; i < max; i += 2) cand_bottom_left |= ISPU(xl, yb + i);
+        }
+        if (cand_left == 1 && edge_x) {
+            const int xl = (x0 - 1) >> lpu, yl = y0 >> lpu;
+            const int max = spu_v < pu_h - yl ? spu_v : pu_h - yl;
+            cand_left = 0;
+            for (int i = 0; i < max; i += 2) cand_left |= ISPU(xl, yl + i);
+        }
+        if (cand_up_left == 1) cand_up_left = ISPU((x0 - 1) >> lpu, (y0 - 1) >> lpu);
+        if (cand_up == 1 && edge_y) {
+            const int xt = x0 >> lpu, yt = (y0 - 1) >> lpu;
+            const int max = spu_h < pu_w - xt ? spu_h : pu_w - xt;
+            cand_up = 0;
+            for (int i = 0; i < max; i += 2) cand_up |= ISPU(xt + i, yt);
+        }
+        if (cand_up_right == 1 && edge_y) {
+            const int yt = (y0 - 1) >> lpu, xr = (x0 + nlh) >> lpu;
+            const int max = spu_h < pu_w - xr ? spu_h : pu_w - xr;
+            cand_up_right = 0;
+            for (int i = 0; i < max; i += 2) cand_up_right |= ISPU(xr + i, yt);
+        }
+        /* memset(left/top, 128, 2*MAX_TB_SIZE*sizeof(pixel)); top[-1] = 128  (:160-162): BYTES of value 128 */
+        const int fill = bd > 8 ? 0x8080 : 128;
+        for (int i = 0; i < 64; i++) l[i] = t[i] = fill;
+        t[-1] = 128; l[-1] = 128;                               /* left[-1] is uninitialised in the reference here */
     }
     if (cand_up_left) { l[-1] = REC(-1, -1); t[-1] = l[-1]; }
     if (cand_up) for (int i = 0; i < n; i++) t[i] = REC(i, -1);
@@ -599,6 +637,68 @@ void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, 
         for (int i = n; i < n + bl_size; i++) l[i] = REC(-1, i);
         for (int i = n + bl_size; i < 2 * n; i++) l[i] = REC(-1, n + bl_size - 1);
     }
+    /* ---- constrained intra prediction, part 2 (:185-249): samples of inter-coded neighbours are overwritten from the
+     * nearest intra-coded ones, in groups of four, in this exact order */
+    if (cip && (cand_bottom_left || cand_left || cand_up_left || cand_up || cand_up_right)) {
+        int smx = x0 + ((2 * n) << hs) < pic->width ? 2 * n : (pic->width - x0) >> hs;
+        int smy = y0 + ((2 * n) << vs) < pic->height ? 2 * n : (pic->height - y0) >> vs;
+        int j = n + (cand_bottom_left ? bl_size : 0) - 1;
+        if (!cand_up_right) smx = x0 + (n << hs) < pic->width ? n : (pic->width - x0) >> hs;
+        if (!cand_bottom_left) smy = y0 + (n << vs) < pic->height ? n : (pic->height - y0) >> vs;
+        if (cand_bottom_left || cand_left || cand_up_left) {
+            while (j > -1 && !ISI(-1, j)) j--;
+            if (!ISI(-1, j)) {
+                j = 0;
+                while (j < smx && !ISI(j, -1)) j++;
+                for (int i = j; i > j - (j + 1); i--) if (!ISI(i - 1, -1)) t[i - 1] = t[i];      /* EXTEND_LEFT_CIP */
+                l[-1] = t[-1];
+            }
+        } else {
+            j = 0;
+            while (j < smx && !ISI(j, -1)) j++;
+            if (j > 0) {
+                if (x0 > 0) {
+                    for (int i = j; i > j - (j + 1); i--) if (!ISI(i - 1, -1)) t[i - 1] = t[i];
+                } else {
+                    for (int i = j; i > j - j; i--) if (!ISI(i - 1, -1)) t[i - 1] = t[i];
+                    t[-1] = t[0];
+                }
+            }
+            l[-1] = t[-1];
+        }
+        l[-1] = t[-1];
+        if (cand_bottom_left || cand_left) {                     /* EXTEND_DOWN_CIP(left, 0, size_max_y) */
+            int a = l[-1];
+            for (int i = 0; i < smy; i += 4) {
+                if (!ISI(-1, i)) { l[i] = l[i + 1] = l[i + 2] = l[i + 3] = a; } else a = l[i + 3];
+            }
+        }
+        if (!cand_left) for (int i = 0; i < n; i++) l[i] = l[-1];
+        if (!cand_bottom_left) for (int i = n; i < 2 * n; i++) l[i] = l[n - 1];
+        if (x0 != 0 && y0 != 0) {
+            int a = l[smy - 1];
+            for (int i = smy - 1; i > smy - 1 - smy; i -= 4) {   /* EXTEND_UP_CIP(left, size_max_y - 1, size_max_y) */
+                if (!ISI(-1, i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
+            }
+            if (!ISI(-1, -1)) l[-1] = l[0];
+        } else if (x0 == 0) {
+            for (int i = 0; i < smy; i++) l[i] = 0;              /* EXTEND(left, 0, size_max_y) */
+        } else {
+            int a = l[smy - 1];
+            for (int i = smy - 1; i > smy - 1 - smy; i -= 4) {
+                if (!ISI(-1, i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
+            }
+        }
+        t[-1] = l[-1];
+        if (y0 != 0) {                                           /* EXTEND_RIGHT_CIP(top, 0, size_max_x) */
+            int a = l[-1];
+            for (int i = 0; i < smx; i += 4) {
+                if (!ISI(i, -1)) { t[i] = t[i + 1] = t[i + 2] = t[i + 3] = a; } else a = t[i + 3];
+            }
+        }
+    }
+#undef ISI
+#undef ISPU
     /* substitution of unavailable samples (:251-286) */
     if (!cand_bottom_left) {
         if (cand_left) {

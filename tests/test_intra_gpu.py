@@ -69,3 +69,43 @@ def test_intra_batch_of_independent_blocks(oracle):
     L.dev_intra_batch(G.planes3(d), bd, d_jobs.data_ptr(), len(batch), G.stream())
     torch.cuda.synchronize()
     assert np.array_equal(G.to_host(d[0], np.uint8), want[0])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_pred_constrained(oracle, bd):
+    """constrained_intra_pred_flag streams: host re-derivation of availability + the kernel's substitution walk."""
+    rng = np.random.default_rng(950 + bd)
+    W, H = 136, 72
+    for it in range(250):
+        log2 = int(rng.integers(2, 6)); n = 1 << log2
+        c_idx = int(rng.integers(0, 3))
+        sh = 1 if c_idx else 0
+        nl = n << sh
+        ny = (H - nl) // nl + 1
+        x0 = int(rng.integers(0, (W - nl) // nl + 1)) * nl; y0 = int(rng.integers(min(1 if it % 4 else 0, ny - 1), ny)) * nl
+        if y0 == 0 and x0 > 0:
+            x0 = 0
+        mode = int(rng.integers(0, 35))
+        cands = [int(rng.random() < 0.8) for _ in range(5)]
+        if x0 == 0: cands[0] = cands[1] = cands[2] = 0
+        if y0 == 0: cands[2] = cands[3] = cands[4] = 0
+        if x0 + nl >= W: cands[4] = 0
+        if y0 + nl >= H: cands[0] = 0
+        lpu = int(rng.choice([2, 3]))
+        pw, ph = (W + (1 << lpu) - 1) >> lpu, (H + (1 << lpu) - 1) >> lpu
+        is_intra = (rng.random((ph, pw)) < float(rng.choice([0.0, 0.2, 0.5, 0.8, 1.0]))).astype(np.uint8)
+        is_intra[y0 >> lpu:((y0 + nl - 1) >> lpu) + 1, x0 >> lpu:((x0 + nl - 1) >> lpu) + 1] = 1
+        planes = [rng.integers(0, 1 << bd, size=(H + 8, W + 8)).astype(G.pixdt(bd)) for _ in range(3)]
+        strong = int(rng.random() < 0.7)
+        want = [p.copy() for p in planes]
+        oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1, strong=strong, smoothing_disabled=0,
+                          log2_ctb_size=6, log2_min_tb_size=2, log2_min_pu_size=lpu, constrained=1, is_intra=is_intra)
+        geom = L.IntraGeom(W, H, 1, 6, 2, strong, 0, 1)
+        job, cip = L.intra_make_job_cip(geom, lpu, is_intra, x0, y0, log2, c_idx, mode, cands)
+        assert job["flags2"][0] & L.INTRA2_CIP
+        d = [G.to_dev(p) for p in planes]
+        d_jobs = G.to_dev(job); d_cip = G.to_dev(cip)
+        L.dev_intra_batch_cip(G.planes3(d), bd, d_jobs.data_ptr(), 1, d_cip.data_ptr(), G.stream())
+        torch.cuda.synchronize()
+        for pl in range(3):
+            assert np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]), (it, log2, c_idx, mode, cands, x0, y0, lpu, pl)

@@ -205,3 +205,41 @@ def test_intra_pred_full(oracle, ref, bd):
         ref.intra_pred(bd, pb, W, H, x0, y0, log2, c_idx, mode, cands, **kw)
         for i in range(3):
             assert np.array_equal(pa[i], pb[i]), (it, log2, c_idx, mode, cands, x0, y0, kw)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_pred_constrained(oracle, ref, bd):
+    """constrained_intra_pred_flag = 1: availability re-derivation + substitution walk (hevcpred_template.c:116-163,185-249).
+    Positions are kept off the top picture row when the block has left neighbours: there the reference itself reads
+    tab_mvf out of bounds (IS_INTRA(-1,-1) with y0 == 0), so its result is undefined."""
+    rng = np.random.default_rng(71 + bd)
+    W, H = 136, 72
+    for it in range(600):
+        log2 = int(rng.integers(2, 6)); n = 1 << log2
+        c_idx = int(rng.integers(0, 3)); cfi = 1
+        sh = 1 if c_idx else 0
+        nl = n << sh
+        ny = (H - nl) // nl + 1
+        x0 = int(rng.integers(0, (W - nl) // nl + 1)) * nl; y0 = int(rng.integers(min(1 if it % 4 else 0, ny - 1), ny)) * nl
+        if y0 == 0 and x0 > 0:
+            x0 = 0
+        mode = int(rng.integers(0, 35))
+        cands = [int(rng.random() < 0.8) for _ in range(5)]
+        if x0 == 0: cands[0] = cands[1] = cands[2] = 0
+        if y0 == 0: cands[2] = cands[3] = cands[4] = 0
+        if x0 + nl >= W: cands[4] = 0
+        if y0 + nl >= H: cands[0] = 0
+        lpu = int(rng.choice([2, 3]))
+        pw, ph = (W + (1 << lpu) - 1) >> lpu, (H + (1 << lpu) - 1) >> lpu
+        p_intra = float(rng.choice([0.0, 0.2, 0.5, 0.8, 1.0]))
+        is_intra = (rng.random((ph, pw)) < p_intra).astype(np.uint8)
+        # the block being predicted is intra itself
+        is_intra[y0 >> lpu:((y0 + nl - 1) >> lpu) + 1, x0 >> lpu:((x0 + nl - 1) >> lpu) + 1] = 1
+        planes = [rand_plane(rng, bd, H + 8, W + 8) for _ in range(3)]
+        pa = [p.copy() for p in planes]; pb = [p.copy() for p in planes]
+        kw = dict(chroma_format_idc=cfi, strong=int(rng.random() < 0.7), smoothing_disabled=0, log2_ctb_size=6, log2_min_tb_size=2,
+                  log2_min_pu_size=lpu, constrained=1, is_intra=is_intra)
+        oracle.intra_pred(bd, pa, W, H, x0, y0, log2, c_idx, mode, cands, **kw)
+        ref.intra_pred(bd, pb, W, H, x0, y0, log2, c_idx, mode, cands, **kw)
+        for i in range(3):
+            assert np.array_equal(pa[i], pb[i]), (it, log2, c_idx, mode, cands, x0, y0, lpu, p_intra)
