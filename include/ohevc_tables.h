@@ -111,6 +111,8 @@ int  ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot);
 int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
 /* sticky status of the recording since begin_frame: table slots return void, so failures surface here */
 int  ohevc_tables_status(ohevc_ctx *ctx);
+/* drop everything registered for ctx (done automatically by ohevc_ctx_destroy) */
+void ohevc_tables_forget(ohevc_ctx *ctx);
 
 /* intra_pred[log2-2] cannot be mirrored as a bare table slot (it takes HEVCContext*, hevcpred.h:32): the reference-side
  * stub in INTEGRATION.md extracts the fields below from HEVCContext and calls this. */

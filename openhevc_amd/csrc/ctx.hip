@@ -122,9 +122,12 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
     return OHEVC_OK;
 }
 
+extern "C" void ohevc_tables_forget(ohevc_ctx *ctx);      // tables.hip: drop the pointer registry of this ctx
+
 extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
 {
     if (!c) return;
+    ohevc_tables_forget(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pics) if (p.used) free_picture(p);

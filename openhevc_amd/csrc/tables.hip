@@ -396,6 +396,18 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     return OHEVC_OK;
 }
 
+// called by ohevc_ctx_destroy: a later ctx may be allocated at the same address and must not inherit this registry
+extern "C" void ohevc_tables_forget(ohevc_ctx *ctx)
+{
+    std::lock_guard<std::mutex> g(g_lock);
+    auto it = g_states.find(ctx);
+    if (it != g_states.end()) {
+        if (tl_state == it->second) { tl_state = nullptr; tl_ctx = nullptr; }
+        delete it->second;
+        g_states.erase(it);
+    }
+}
+
 extern "C" int ohevc_tables_status(ohevc_ctx *ctx)
 {
     TablesState *s = state_of(ctx, false);

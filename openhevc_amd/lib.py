@@ -170,7 +170,7 @@ class IntraGeom(C.Structure):
 
 EXPORTED_SYMBOLS += ["ohevc_intra_make_job", "ohevc_hevcdsp_init_hip", "ohevc_videodsp_init_hip", "ohevc_tables_bind",
                      "ohevc_tables_register_picture", "ohevc_tables_unregister_picture", "ohevc_tables_begin_frame",
-                     "ohevc_tables_end_frame", "ohevc_tables_status", "ohevc_tables_intra_pred", "ohevc_pic_info"]
+                     "ohevc_tables_end_frame", "ohevc_tables_status", "ohevc_tables_forget", "ohevc_tables_intra_pred", "ohevc_pic_info"]
 
 
 def intra_make_job_cip(geom, log2_min_pu_size, is_intra_map, x0, y0, log2_size, c_idx, mode, cands):
