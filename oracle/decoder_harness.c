@@ -1,0 +1,161 @@
+/*
+ * oracle/decoder_harness.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A minimal caller of the reference's own decoder API (libavcodec as vendored in /root/reference: avcodec_open2 /
+ * avcodec_decode_video2, the same calls gpac/modules/openhevc_dec/openHevcWrapper.c:46-134 makes), compiled against
+ * the reference headers and linked with the reference's objects built in place (oracle/Makefile, target `fulldec`).
+ * One access unit (Annex-B bytes) per call, single decoding thread.
+ *
+ * Three libraries share this file:
+ *   _ref/libopenhevc_c.so    the untouched pure-C reference decoder (the bitstream-level oracle)
+ *   _ref/libopenhevc_gen.so  + synth_gen.c: the stream synthesiser (reference parser driven by a random bin source)
+ *   _ref/libopenhevc_hip.so  + hip_hooks.c: the reference front-end with its tables filled by libohevc_hip.so
+ *                            (INTEGRATION.md applied by link-time interposition, no reference source is modified)
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "libavcodec/avcodec.h"
+#include "libavutil/opt.h"
+#include "libavutil/pixdesc.h"
+#include "libavutil/mem.h"
+
+#ifdef OHDEC_HIP
+int  ohdec_backend_open(void);
+int  ohdec_backend_frame_done(void);
+void ohdec_backend_close(void);
+#else
+static int  ohdec_backend_open(void) { return 0; }
+static int  ohdec_backend_frame_done(void) { return 0; }
+static void ohdec_backend_close(void) {}
+#endif
+
+typedef struct ohdec {
+    AVCodecContext *avctx;
+    AVFrame        *frame;
+    uint8_t        *pkt_buf;
+    int             pkt_cap;
+    int             have_frame;
+} ohdec;
+
+/* thread_type: 1 frame threads, 2 slice/WPP threads, 3 both (the -f option of the reference's CLI, main_hm/getopt.c) */
+ohdec *ohdec_open(int threads, int thread_type)
+{
+    static int registered;
+    ohdec *d = calloc(1, sizeof(*d));
+    AVCodec *codec;
+    if (!d)
+        return NULL;
+    if (!registered) {
+        avcodec_register_all();
+        registered = 1;
+    }
+    av_log_set_level(AV_LOG_ERROR);
+    codec = avcodec_find_decoder(AV_CODEC_ID_HEVC);
+    if (!codec)
+        goto fail;
+    d->avctx = avcodec_alloc_context3(codec);
+    d->frame = av_frame_alloc();
+    if (!d->avctx || !d->frame)
+        goto fail;
+    d->avctx->flags |= CODEC_FLAG_UNALIGNED;
+    av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type == 3 ? "frameslice" : "frame", 0);
+    av_opt_set_int(d->avctx, "threads", threads > 0 ? threads : 1, 0);
+    if (ohdec_backend_open() < 0)
+        goto fail;
+    if (avcodec_open2(d->avctx, codec, NULL) < 0)
+        goto fail;
+    return d;
+fail:
+    if (d->frame)
+        av_frame_free(&d->frame);
+    if (d->avctx)
+        av_free(d->avctx);
+    free(d);
+    return NULL;
+}
+
+/* returns 1 when a picture came out (fetch it with ohdec_frame_*), 0 when none, <0 on a decoder / back-end error */
+int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
+{
+    AVPacket pkt;
+    int got = 0, ret;
+
+    if (len + FF_INPUT_BUFFER_PADDING_SIZE > d->pkt_cap) {
+        free(d->pkt_buf);
+        d->pkt_cap = len + FF_INPUT_BUFFER_PADDING_SIZE + 4096;
+        d->pkt_buf = malloc(d->pkt_cap);
+        if (!d->pkt_buf)
+            return -1;
+    }
+    if (len)
+        memcpy(d->pkt_buf, au, len);
+    memset(d->pkt_buf + len, 0, FF_INPUT_BUFFER_PADDING_SIZE);
+
+    av_init_packet(&pkt);
+    pkt.data = len ? d->pkt_buf : NULL;
+    pkt.size = len;
+    pkt.pts  = pts;
+    av_frame_unref(d->frame);
+    ret = avcodec_decode_video2(d->avctx, d->frame, &got, &pkt);
+    if (ret < 0)
+        return -2;
+    /* "frame complete, before output" (INTEGRATION.md section 3): a no-op for the CPU builds */
+    if (ohdec_backend_frame_done() < 0)
+        return -3;
+    d->have_frame = got;
+    return got ? 1 : 0;
+}
+
+/* drain the reorder buffer: call until it returns 0 */
+int ohdec_flush(ohdec *d)
+{
+    return ohdec_decode(d, NULL, 0, 0);
+}
+
+int ohdec_frame_info(ohdec *d, int *w, int *h, int *bit_depth, int *chroma_w_shift, int *chroma_h_shift)
+{
+    const AVPixFmtDescriptor *desc;
+    if (!d->have_frame)
+        return -1;
+    desc = av_pix_fmt_desc_get(d->frame->format);
+    *w = d->frame->width;
+    *h = d->frame->height;
+    *bit_depth = desc->comp[0].depth_minus1 + 1;
+    *chroma_w_shift = desc->log2_chroma_w;
+    *chroma_h_shift = desc->log2_chroma_h;
+    return 0;
+}
+
+/* tightly packed copy of plane c (bytes per sample = 1 or 2) */
+int ohdec_frame_copy(ohdec *d, int c, uint8_t *dst)
+{
+    const AVPixFmtDescriptor *desc;
+    int w, h, bps, y;
+    if (!d->have_frame)
+        return -1;
+    desc = av_pix_fmt_desc_get(d->frame->format);
+    bps = desc->comp[0].depth_minus1 >= 8 ? 2 : 1;
+    w = d->frame->width;
+    h = d->frame->height;
+    if (c) {
+        w = -((-w) >> desc->log2_chroma_w);
+        h = -((-h) >> desc->log2_chroma_h);
+    }
+    for (y = 0; y < h; y++)
+        memcpy(dst + (size_t)y * w * bps, d->frame->data[c] + (size_t)y * d->frame->linesize[c], (size_t)w * bps);
+    return 0;
+}
+
+void ohdec_close(ohdec *d)
+{
+    if (!d)
+        return;
+    avcodec_close(d->avctx);
+    av_free(d->avctx);
+    av_frame_free(&d->frame);
+    ohdec_backend_close();
+    free(d->pkt_buf);
+    free(d);
+}
