@@ -154,13 +154,19 @@ void t_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize
 // resolve an MC source pointer: either inside a registered picture or inside a noted edge-emulation buffer
 bool resolve_src(const uint8_t *src, int ps, int &slot, int &plane, int &sx, int &sy)
 {
+    // the reference's two buffers are adjacent members of HEVCLocalContext, (MAX_PB_SIZE + 7) rows each (hevc.h:1162-1163):
+    // take the noted window whose base is the closest one below src
+    const Pending::Emu *best = nullptr;
     for (const Pending::Emu &e : tl_pend.emu) {
         if (!e.buf) continue;
         const ptrdiff_t d = src - e.buf;
-        if (d >= 0 && d < e.linesize * 80) {
-            slot = e.slot; plane = e.plane; sy = e.y + (int)(d / e.linesize); sx = e.x + (int)(d % e.linesize) / ps;
-            return true;
-        }
+        if (d >= 0 && d < e.linesize * (64 + 7) && (!best || e.buf > best->buf)) best = &e;
+    }
+    if (best) {
+        const ptrdiff_t d = src - best->buf;
+        slot = best->slot; plane = best->plane;
+        sy = best->y + (int)(d / best->linesize); sx = best->x + (int)(d % best->linesize) / ps;
+        return true;
     }
     Loc l;
     if (!locate(src, l)) return false;

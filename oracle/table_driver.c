@@ -43,7 +43,9 @@ int ohref_drive_tables(int bd, int W, int H, drv_pic *cur, drv_pic *refs, int nr
     const int ps = bd > 8 ? 2 : 1, pixel_shift = bd > 8;
     DECLARE_ALIGNED(32, int16_t, tucoeffs)[32 * 32];
     DECLARE_ALIGNED(16, int16_t, tmp)[MAX_PB_SIZE * MAX_PB_SIZE];
-    uint8_t *emu1 = aligned_alloc(32, (MAX_PB_SIZE + 8) * EDGE_EMU_BUFFER_STRIDE * 2), *emu2 = aligned_alloc(32, (MAX_PB_SIZE + 8) * EDGE_EMU_BUFFER_STRIDE * 2);
+    /* adjacent, exactly as the two members of HEVCLocalContext (hevc.h:1162-1163) */
+    uint8_t *emu1 = aligned_alloc(32, 2 * (MAX_PB_SIZE + 7) * EDGE_EMU_BUFFER_STRIDE * 2 + 64);
+    uint8_t *emu2 = emu1 + (MAX_PB_SIZE + 7) * EDGE_EMU_BUFFER_STRIDE * 2;
     drv_pic twin;                              /* the reference's sao_frame: a second full-size frame (hevc.c:369-385) */
     int sao_copied = 0, rc = 0;
 
@@ -178,6 +180,6 @@ int ohref_drive_tables(int bd, int W, int H, drv_pic *cur, drv_pic *refs, int nr
         }
     }
     for (int c = 0; c < 3; c++) free(twin.data[c] - twin.linesize[c] - 32);
-    free(emu1); free(emu2);
+    free(emu1);
     return rc;
 }

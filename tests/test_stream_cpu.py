@@ -1,0 +1,120 @@
+"""Stream synthesiser + bitstream-level oracle, CPU only.
+
+The synthesiser (oracle/pystream.py + oracle/synth_gen.c) is pinned by the UNTOUCHED reference decoder: every stream
+it makes must decode, on oracle/_ref/libopenhevc_c.so, to exactly the pictures the generator reconstructed.  The
+committed fixtures (tests/golden/streams.npz, made by tests/golden/make_streams.py) carry the MD5 of those pictures.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pystream as ps
+from stream_cases import CASES
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "streams.npz")
+
+needs_c = pytest.mark.skipif(not ps.have("c"), reason="oracle/_ref/libopenhevc_c.so not built (needs /root/reference)")
+needs_gen = pytest.mark.skipif(not (ps.have("c") and ps.have("gen")), reason="oracle/_ref decoder libraries not built")
+
+
+def load_golden(name):
+    z = np.load(GOLDEN)
+    data = z[name + ".data"].tobytes()
+    aus, o = [], 0
+    for n in z[name + ".sizes"]:
+        aus.append(data[o:o + int(n)])
+        o += int(n)
+    return aus, [str(m) for m in z[name + ".md5"]]
+
+
+def frames_md5(frames):
+    return [hashlib.md5(pl.tobytes()).hexdigest() for f in frames for pl in f]
+
+
+@needs_gen
+def test_cabac_tables_match_reference():
+    """rangeTabLps / transIdxLps as restated in synth_gen.c vs the reference's packed ff_h264_cabac_tables
+    (cabac.h:39-43, used as lps_range[2*(range&0xC0)+state] and mlps_state[128+state] / [127-state], cabac.c:113-121)."""
+    G = ps._load("gen")
+    with ps.Decoder("c"):
+        tab = (C.c_uint8 * (512 + 4 * 2 * 64 + 4 * 64 + 63)).in_dll(ps._load("c"), "ff_h264_cabac_tables")
+        tab = np.frombuffer(tab, dtype=np.uint8).copy()
+    lps = np.ctypeslib.as_array(G.ohsyn_table_range_lps(), shape=(64, 4))
+    trans = np.ctypeslib.as_array(G.ohsyn_table_trans_lps(), shape=(64,))
+    for p in range(64):
+        for mps in range(2):
+            s = 2 * p + mps
+            for q in range(4):
+                assert tab[512 + q * 128 + s] == lps[p, q], (p, q)
+            if p < 63:      # state 63 is only reached by the terminate path
+                nxt_mps = tab[1024 + 128 + s]
+                assert nxt_mps == 2 * min(p + 1, 62) + mps, p
+                nxt_lps = tab[1024 + 127 - s]
+                want_mps = (1 - mps) if p == 0 else mps
+                assert nxt_lps == 2 * trans[p] + want_mps, p
+
+
+@needs_c
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_stream_decodes_to_recorded_md5(name):
+    aus, md5 = load_golden(name)
+    out = ps.decode_stream("c", aus)
+    assert len(out) == CASES[name]["nframes"]
+    assert frames_md5(out) == md5
+
+
+@needs_gen
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_generator_is_deterministic_and_pinned(name):
+    """Regenerating a case gives the committed bytes, and the generator's own reconstruction is what the clean decoder
+    outputs (checked through the MD5s)."""
+    aus, md5 = load_golden(name)
+    new_aus, gen_frames = ps.generate(ps.StreamParams(**CASES[name]))
+    assert [bytes(a) for a in new_aus] == aus
+    assert frames_md5(gen_frames) == md5
+
+
+@needs_gen
+@pytest.mark.parametrize("threads,thread_type,kw", [
+    (4, 2, dict(gop="lowdelay_b", nframes=5, seed=201, wpp=1, width=416, height=240)),
+    (4, 2, dict(gop="lowdelay_b", nframes=5, seed=202, tiles=(3, 2), width=416, height=240)),
+    (3, 1, dict(gop="random_access", nframes=17, seed=203, width=416, height=240)),
+    (4, 2, dict(gop="lowdelay_b", nframes=5, seed=204, slices_per_picture=3, wpp=1, dependent_slices=1, width=416,
+                height=240)),
+])
+def test_entry_points_hold_under_threaded_decoding(threads, thread_type, kw):
+    """The WPP / tile entry points written into the slice headers are only read by the reference's threaded paths
+    (hls_slice_data, hevc.c:3017-3100): decode with slice threads and frame threads and compare with one thread."""
+    aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+    one = ps.decode_stream("c", aus)
+    many = ps.decode_stream("c", aus, threads, thread_type)
+    assert len(one) == len(many) == kw["nframes"]
+    assert frames_md5(one) == frames_md5(many) == frames_md5(gen_frames)
+
+
+def test_bit_writer_and_escaping():
+    b = ps.Bits()
+    b.ue(0); b.ue(1); b.ue(7); b.se(-2); b.se(3); b.u(3, 5)
+    bits = "".join(map(str, b.b))
+    assert bits == "1" + "010" + "0001000" + "00101" + "00110" + "101"
+    assert ps.escape(bytes([0, 0, 1, 0, 0, 0, 0, 3, 5, 0, 0])) == bytes([0, 0, 3, 1, 0, 0, 3, 0, 0, 3, 3, 5, 0, 0])
+
+
+def test_gop_plans_keep_every_reference_alive():
+    for gop, n in (("lowdelay_p", 7), ("lowdelay_b", 7), ("random_access", 20), ("intra", 3)):
+        pics = ps.plan_gop(ps.StreamParams(gop=gop, nframes=n))
+        assert sorted(p.poc for p in pics) == list(range(n))
+        decoded, dpb = set(), set()
+        for p in pics:
+            rps = {q for q, _ in p.rps_neg + p.rps_pos}
+            assert rps <= dpb, (gop, p.poc)                 # only pictures still in the DPB may be named
+            used = {q for q, u in p.rps_neg + p.rps_pos if u}
+            if p.slice_type != ps.SLICE_I:
+                assert used, (gop, p.poc)
+            assert all(q < p.poc for q, _ in p.rps_neg) and all(q > p.poc for q, _ in p.rps_pos)
+            dpb = rps | {p.poc}
+            decoded.add(p.poc)
+            assert len(dpb) <= 6

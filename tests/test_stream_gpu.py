@@ -1,0 +1,52 @@
+"""The drop-in, end to end: the reference's real decoder (all 125 sources compiled in place) with its DSP / prediction
+/ videodsp tables filled by libohevc_hip.so (oracle/hip_hooks.c = INTEGRATION.md applied at link time) must output the
+same pictures as the untouched reference decoder, on synthetic Annex-B streams."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pystream as ps
+from stream_cases import CASES
+from test_stream_cpu import frames_md5, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ref, hip):
+    assert len(ref) == len(hip)
+    for i, (fa, fb) in enumerate(zip(ref, hip)):
+        for c in range(3):
+            if not np.array_equal(fa[c], fb[c]):
+                d = np.argwhere(fa[c] != fb[c])
+                y, x = d[0]
+                raise AssertionError(f"picture {i} plane {c}: {len(d)} samples differ, first at (x={x}, y={y}) "
+                                     f"ref={fa[c][y, x]} hip={fb[c][y, x]}")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_stream_hip_backend(name):
+    assert ps.have("hip"), "oracle/_ref/libopenhevc_hip.so missing: run __graft_entry__.build() where /root/reference exists"
+    aus, md5 = load_golden(name)
+    hip = ps.decode_stream("hip", aus)
+    assert frames_md5(hip) == md5            # pinned by the committed digests of the untouched decoder ...
+    if ps.have("c"):
+        _compare(ps.decode_stream("c", aus), hip)   # ... and sample-exact against it when it is present
+
+
+@pytest.mark.parametrize("kw", [
+    dict(gop="random_access", nframes=9, seed=301, width=832, height=480, log2_ctb=6),
+    dict(gop="random_access", nframes=9, seed=302, width=832, height=480, log2_ctb=6, bit_depth=10, weighted_bipred=1,
+         cu_qp_delta_depth=1, pcm=8),
+    dict(gop="lowdelay_b", nframes=6, seed=303, width=640, height=360, log2_ctb=5, wpp=1, slices_per_picture=3,
+         constrained_intra=1),
+    dict(gop="lowdelay_b", nframes=4, seed=304, width=1280, height=720, log2_ctb=6, tiles=(4, 2)),
+])
+def test_fresh_larger_streams_hip_backend(kw):
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+    ref = ps.decode_stream("c", aus)
+    assert frames_md5(ref) == frames_md5(gen_frames)
+    _compare(ref, ps.decode_stream("hip", aus))

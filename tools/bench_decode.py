@@ -1,0 +1,75 @@
+"""Whole-decoder comparison on synthetic Annex-B streams (BASELINE.json configs 1/3/4 geometry, synthetic syntax):
+the reference decoder with its own C tables vs the same front-end with the tables filled by libohevc_hip.so.
+
+    python tools/bench_decode.py [--size 1920x1080] [--frames 17] [--bit-depth 8] [--dense]
+
+Prints one JSON line per configuration.  Mpixel/s = luma samples of decoded pictures per second, wall clock, including
+entropy decoding on the host (which the GPU back-end does not touch) and the copy-back of every picture.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np                      # noqa: E402
+from oracle import pystream as ps       # noqa: E402
+
+
+def timed_decode(kind, aus, threads=1, thread_type=1, repeat=2):
+    best = None
+    frames = None
+    for _ in range(repeat):
+        with ps.Decoder(kind, threads, thread_type) as d:
+            t = time.perf_counter()
+            n = 0
+            for i, au in enumerate(aus):
+                r = d.L.ohdec_decode(d.h, au, len(au), i + 1)
+                if r < 0:
+                    raise RuntimeError(f"decode error {r}")
+                n += r
+            while True:
+                r = d.L.ohdec_flush(d.h)
+                if r <= 0:
+                    break
+                n += r
+            dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+        frames = n
+    return best, frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--frames", type=int, default=17)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--gop", default="random_access")
+    ap.add_argument("--cpu-threads", type=int, default=8)
+    a = ap.parse_args()
+    w, h = map(int, a.size.split("x"))
+    h8 = (h + 7) // 8 * 8
+    kw = dict(gop=a.gop, nframes=a.frames, seed=7, width=w, height=h8, log2_ctb=6, bit_depth=a.bit_depth)
+    if a.dense:
+        kw.update(init_qp=38, probs=dict(rqt_root_cbf=0.8, cbf_luma=0.8, sig_coeff=0.6, last_x=0.75, last_y=0.75, skip=0.15))
+    t = time.perf_counter()
+    aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+    tgen = time.perf_counter() - t
+    ref = ps.decode_stream("c", aus)
+    hip = ps.decode_stream("hip", aus)
+    exact = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
+    res = dict(workload=f"synthetic {a.gop} stream {w}x{h8} {a.bit_depth}-bit, {a.frames} pictures, "
+                        f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}",
+               bit_exact=bool(exact), generate_s=round(tgen, 2))
+    mp = w * h8 * a.frames / 1e6
+    for name, kind, th, tt in (("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
+                               ("hip_backend", "hip", 1, 1)):
+        dt, n = timed_decode(kind, aus, th, tt)
+        res[name] = dict(seconds=round(dt, 4), fps=round(a.frames / dt, 2), mpixel_per_s=round(mp / dt, 1), pictures=n)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,12 @@ def first_diff(a, b):
     d = np.argwhere(a != b)
     return None if d.size == 0 else (tuple(int(v) for v in d[0]), int(a[tuple(d[0])]), int(b[tuple(d[0])]), len(d))
 
+if len(sys.argv) > 1:
+    import json
+    CASES = [json.loads(a) for a in sys.argv[1:]]
+    for c in CASES:
+        if "tiles" in c:
+            c["tiles"] = tuple(c["tiles"])
 bad = 0
 for kw in CASES:
     p = ps.StreamParams(**kw)
@@ -41,10 +47,7 @@ for kw in CASES:
             fd = first_diff(fa[c], fb[c])
             if fd:
                 ok = False
-                msg += f" [frame {i} plane {c}: first (y,x)={fd[0]} ref={fd[1]} hip={fd[2]} ndiff={fd[3]}]"
-                break
-        if msg:
-            break
+                msg += f"\n    [frame {i} plane {c}: first (y,x)={fd[0]} ref={fd[1]} hip={fd[2]} ndiff={fd[3]}]"
     print("OK " if ok else "MISMATCH", kw, f"frames {len(ref)}/{len(hip)} {dt:.2f}s", msg)
     bad += not ok
 print("bad", bad)
