@@ -155,11 +155,22 @@ typedef struct ohevc_sao_job {          /* 32 bytes */
     uint8_t  restore;                   /* 0: sao_edge_filter[0]; 1: sao_edge_filter[1] (uses the edge flags below) */
     uint8_t  edges;                     /* bit0-1 vert_edge[0..1], bit2-3 horiz_edge[0..1], bit4-7 diag_edge[0..3] */
     int16_t  offset_val[5];             /* SAOParams.offset_val[c_idx][0..4] (hevc.h:519), already << log2_sao_offset_scale */
-    uint8_t  reserved[8];
+    uint8_t  quirks;                    /* OHEVC_SAO_LAGGED_CORNER or 0 */
+    uint8_t  reserved[7];
 } ohevc_sao_job;
+
+/* The reference front-end filters with a one-CTB lag (ff_hevc_hls_filter, hevc_filter.c:1027-1051) and postpones the
+ * horizontal chroma edges of the last 8*h luma columns of a CTB to the next call (hevc_filter.c:541-547).  With 16x16
+ * CTBs in 4:2:0 that is the whole CTB, so the copy sao_filter_CTB takes of the sample diagonally below-right of a CTB
+ * (:316-321) has only been vertically deblocked.  A job carrying this flag reads that one sample from `lagged` (the
+ * picture as it was between the vertical and the horizontal deblocking pass) and therefore reproduces the reference
+ * decoder bit for bit; without it SAO reads the fully deblocked picture everywhere, as H.265 8.7.3 says. */
+enum { OHEVC_SAO_LAGGED_CORNER = 1 };
 
 int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
                         const ohevc_sao_job *jobs, int njobs, void *stream);
+int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3], int bit_depth,
+                               const ohevc_sao_job *jobs, int njobs, void *stream);
 
 /* ---- 2.5 intra prediction: replaces intra_pred[log2-2] (hevcpred.h:32; hevcpred_template.c:30-357) and the
  * predictors it dispatches to, pred_planar / pred_dc / pred_angular (hevcpred.h:34-40).  Everything the

@@ -61,6 +61,8 @@ struct ohevc_ctx {
     bool table_dirty = true;
     int cur = -1;
     Picture twin;                     // deblocked copy for SAO (the reference's sao_frame, hevc.c:369-385)
+    Picture lag;                      // picture between the two deblocking passes (only for OHEVC_SAO_LAGGED_CORNER jobs)
+    bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAGGED_CORNER
 
     std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
     std::map<uint32_t, std::vector<ohevc_tu_job>> tu;     // (level, log2, kind) -> jobs
@@ -132,6 +134,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &p : c->pics) if (p.used) free_picture(p);
     if (c->twin.used) free_picture(c->twin);
+    if (c->lag.used) free_picture(c->lag);
     if (c->d_jobs.p) hipFree(c->d_jobs.p);
     if (c->d_coeffs.p) hipFree(c->d_coeffs.p);
     if (c->d_table.p) hipFree(c->d_table.p);
@@ -368,6 +371,7 @@ extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
     c->sao.push_back(*job);
+    if (job->quirks & OHEVC_SAO_LAGGED_CORNER) c->sao_lagged = true;
     c->stats.n_sao++;
     return OHEVC_OK;
 }
@@ -557,24 +561,35 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
             if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_v), (int)c->dbk_v.size(), c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
+        const bool lagged = c->sao_lagged && !c->sao.empty() && !c->dbk_h.empty();
+        auto ensure_like = [&](Picture &q) -> int {
+            if (q.used && q.w == p->w && q.h == p->h && q.cfi == p->cfi && q.bd == p->bd) return OHEVC_OK;
+            OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+            int r;
+            if (q.used && (r = free_picture(q)) != OHEVC_OK) return r;
+            return alloc_picture(q, p->w, p->h, p->cfi, p->bd);
+        };
+        if (lagged) {          // the state the reference's early copy saw (ohevc_hip.h, OHEVC_SAO_LAGGED_CORNER): chroma only
+            if ((rc = ensure_like(c->lag)) != OHEVC_OK) return rc;
+            for (int i = 1; i < 3; i++)
+                OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
+                                             hipMemcpyDeviceToDevice, c->stream));
+        }
         if (!c->dbk_h.empty()) {
             if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_h), (int)c->dbk_h.size(), c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
         if (!c->sao.empty()) {
             // SAO reads a deblocked copy and writes the picture: sao_filter_CTB, hevc_filter.c:269-315
-            if (!c->twin.used || c->twin.w != p->w || c->twin.h != p->h || c->twin.cfi != p->cfi || c->twin.bd != p->bd) {
-                OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-                if (c->twin.used && (rc = free_picture(c->twin)) != OHEVC_OK) return rc;
-                if ((rc = alloc_picture(c->twin, p->w, p->h, p->cfi, p->bd)) != OHEVC_OK) return rc;
-            }
+            if ((rc = ensure_like(c->twin)) != OHEVC_OK) return rc;
             for (int i = 0; i < 3; i++)
                 OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
                                              hipMemcpyDeviceToDevice, c->stream));
-            if ((rc = ohevc_dev_sao_batch(p->planes, c->twin.planes, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), c->stream)) != OHEVC_OK) return rc;
+            ohevc_plane lagp[3] = {c->twin.planes[0], lagged ? c->lag.planes[1] : c->twin.planes[1], lagged ? c->lag.planes[2] : c->twin.planes[2]};
+            if ((rc = ohevc_dev_sao_batch_lagged(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
-        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear();
+        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
     }
     c->last_stats = c->stats;
     return OHEVC_OK;

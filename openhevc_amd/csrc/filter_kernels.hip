@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
 }
 
 template <typename Pixel>
-__global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth)
+__global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth)
 {
     const ohevc_sao_job jb = jobs[blockIdx.x];
     const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
@@ -119,9 +119,14 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, co
     const bool de0 = jb.edges & 16, de1 = jb.edges & 32, de2 = jb.edges & 64, de3 = jb.edges & 128;
     const int sul = !de0 && eo == 2 && !b0 && !b1, sur = !de1 && eo == 3 && !b1 && !b2;
     const int slr = !de2 && eo == 2 && !b2 && !b3, sll = !de3 && eo == 3 && !b0 && !b3;
+    const bool lagged_corner = (jb.quirks & OHEVC_SAO_LAGGED_CORNER) && eo == 2 && bx + w < pw && by + h < ph;
     for (int idx = threadIdx.x; idx < w * h; idx += 256) {
         const int y = idx / w, x = idx - y * w;
-        const int c = SRC(x, y), a = SRC(x + dxa, y + dya), b = SRC(x - dxa, y - dya);
+        const int c = SRC(x, y), a = SRC(x + dxa, y + dya);
+        int b = SRC(x - dxa, y - dya);
+        if (lagged_corner && x == w - 1 && y == h - 1)      // the one sample the reference copies too early (ohevc_hip.h)
+            b = (int)*reinterpret_cast<const Pixel *>(PLANE_PTR3(lag, jb.plane) + (size_t)(by + h) * PLANE_STRIDE3(lag, jb.plane) +
+                                                      (size_t)(bx + w) * sizeof(Pixel));
         const int s = (c > a) - (c < a) + (c > b) - (c < b);                      // -2..2
         int off = s == -2 ? ov1 : s == -1 ? ov2 : s == 0 ? ov0 : s == 1 ? ov3 : ov4;  // offset_val[edge_idx[2 + s]], edge_idx = {1,2,0,3,4}
         const bool on_border = (eo != 1 && ((b0 && x == 0) || (b2 && x == w - 1))) ||
@@ -163,23 +168,32 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
-                                   const ohevc_sao_job *jobs, int njobs, void *stream)
+extern "C" int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
+                                          int bit_depth, const ohevc_sao_job *jobs, int njobs, void *stream)
 {
     using namespace ohevc;
-    OHEVC_REQUIRE(dst != nullptr && src != nullptr, "planes");
+    OHEVC_REQUIRE(dst != nullptr && src != nullptr && lagged != nullptr, "planes");
     OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
-    PlaneSet pd, psrc;
+    PlaneSet pd, psrc, plag;
     int rc = make_plane_set(dst, pd, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     rc = make_plane_set(src, psrc, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
+    rc = make_plane_set(lagged, plag, bit_depth > 8 ? 2 : 1);
+    if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, jobs, njobs, bit_depth);
-    else                hipLaunchKernelGGL((sao_kernel<uint16_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, jobs, njobs, bit_depth);
+    if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth);
+    else                hipLaunchKernelGGL((sao_kernel<uint16_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
+                                   const ohevc_sao_job *jobs, int njobs, void *stream)
+{
+    // without a lagged picture the flag has nothing to read from: jobs carrying it read the deblocked copy
+    return ohevc_dev_sao_batch_lagged(dst, src, src, bit_depth, jobs, njobs, stream);
 }

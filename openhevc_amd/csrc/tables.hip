@@ -33,6 +33,7 @@ struct TablesState {
     std::vector<HostPic> pics;
     int cur = -1;                     // index into pics
     int status = OHEVC_OK;
+    int lag_log2_ctb = 0;             // ohevc_tables_emulate_filter_lag
     ohevc_HEVCDSPContext saved = {};  // the reference's own C slots (put_pcm is still executed on the host into scratch)
 };
 
@@ -262,6 +263,12 @@ void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int
     j.klass = type == OHEVC_SAO_BAND ? sao->band_position[c_idx] : sao->eo_class[c_idx];
     j.borders = (uint8_t)((borders[0] ? 1 : 0) | (borders[1] ? 2 : 0) | (borders[2] ? 4 : 0) | (borders[3] ? 8 : 0));
     j.restore = (uint8_t)restore;
+    // the reference front-end's early copy of the below-right chroma sample with 16x16 CTBs (ohevc_hip.h): only when the
+    // integration asked for it, only for full 8x8 chroma CTBs whose right neighbour is not the last CTB column
+    if (tl_state->lag_log2_ctb == 4 && c_idx > 0 && width == 8 && height == 8 && !borders[2] && !borders[3]) {
+        const HostPic &hp = tl_state->pics[tl_state->cur];
+        if (hp.w[c_idx] * 2 == hp.w[0] && hp.h[c_idx] * 2 == hp.h[0] && l.x + 16 < hp.w[c_idx]) j.quirks |= OHEVC_SAO_LAGGED_CORNER;
+    }
     if (restore)
         j.edges = (uint8_t)((ve[0] ? 1 : 0) | (ve[1] ? 2 : 0) | (he[0] ? 4 : 0) | (he[1] ? 8 : 0) |
                             (de[0] ? 16 : 0) | (de[1] ? 32 : 0) | (de[2] ? 64 : 0) | (de[3] ? 128 : 0));
@@ -297,6 +304,14 @@ TablesState *state_of(ohevc_ctx *ctx, bool create)
 }
 
 }  // namespace
+
+extern "C" int ohevc_tables_emulate_filter_lag(ohevc_ctx *ctx, int log2_ctb_size)
+{
+    TablesState *st = state_of(ctx, true);
+    if (!st) return OHEVC_ERR_ARG;
+    st->lag_log2_ctb = log2_ctb_size;
+    return OHEVC_OK;
+}
 
 extern "C" void ohevc_hevcdsp_init_hip(ohevc_HEVCDSPContext *c, int bit_depth)
 {

@@ -103,7 +103,7 @@ assert DBK_JOB.itemsize == 16
 SAO_BAND, SAO_EDGE = 1, 2
 SAO_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "<u2"), ("h", "<u2"), ("plane", "u1"), ("type", "u1"),
                     ("klass", "u1"), ("borders", "u1"), ("restore", "u1"), ("edges", "u1"),
-                    ("offset_val", "<i2", (5,)), ("reserved", "u1", (8,))])
+                    ("offset_val", "<i2", (5,)), ("quirks", "u1"), ("reserved", "u1", (7,))])
 assert SAO_JOB.itemsize == 32
 
 INTRA_BOTTOM_LEFT, INTRA_LEFT, INTRA_UP_LEFT, INTRA_UP, INTRA_UP_RIGHT = 1, 2, 4, 8, 16
@@ -116,7 +116,7 @@ INTRA_CIP = np.dtype([("top_bits", "u1", (9,)), ("left_bits", "u1", (9,)), ("siz
                       ("x0_nonzero", "u1"), ("y0_nonzero", "u1"), ("reserved", "u1", (10,))])
 assert INTRA_CIP.itemsize == 32
 
-EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_mc_batch_small", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_intra_batch", "ohevc_dev_intra_batch_cip",
+EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch", "ohevc_dev_mc_batch_small", "ohevc_dev_deblock_batch", "ohevc_dev_sao_batch", "ohevc_dev_sao_batch_lagged", "ohevc_dev_intra_batch", "ohevc_dev_intra_batch_cip",
                      "ohevc_intra_make_job_cip", "ohevc_rec_intra_cip", "ohevc_tables_intra_pred_cip"]
 
 
@@ -170,7 +170,7 @@ class IntraGeom(C.Structure):
 
 EXPORTED_SYMBOLS += ["ohevc_intra_make_job", "ohevc_hevcdsp_init_hip", "ohevc_videodsp_init_hip", "ohevc_tables_bind",
                      "ohevc_tables_register_picture", "ohevc_tables_unregister_picture", "ohevc_tables_begin_frame",
-                     "ohevc_tables_end_frame", "ohevc_tables_status", "ohevc_tables_forget", "ohevc_tables_intra_pred", "ohevc_pic_info"]
+                     "ohevc_tables_end_frame", "ohevc_tables_status", "ohevc_tables_forget", "ohevc_tables_emulate_filter_lag", "ohevc_tables_intra_pred", "ohevc_pic_info"]
 
 
 def intra_make_job_cip(geom, log2_min_pu_size, is_intra_map, x0, y0, log2_size, c_idx, mode, cands):

@@ -118,6 +118,7 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         g_nbufs++;
     }
     slot = g_bufs[i].slot;
+    ohevc_tables_emulate_filter_lag(g_ctx, s->sps->log2_ctb_size);  /* stay bit-identical with hevc_filter.c's CTB lag */
     if (ohevc_tables_register_picture(g_ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
         ohevc_tables_begin_frame(g_ctx, slot) != OHEVC_OK) {
         fprintf(stderr, "ohhip: begin_frame failed: %s\n", ohevc_last_error());
