@@ -155,17 +155,22 @@ typedef struct ohevc_sao_job {          /* 32 bytes */
     uint8_t  restore;                   /* 0: sao_edge_filter[0]; 1: sao_edge_filter[1] (uses the edge flags below) */
     uint8_t  edges;                     /* bit0-1 vert_edge[0..1], bit2-3 horiz_edge[0..1], bit4-7 diag_edge[0..3] */
     int16_t  offset_val[5];             /* SAOParams.offset_val[c_idx][0..4] (hevc.h:519), already << log2_sao_offset_scale */
-    uint8_t  quirks;                    /* OHEVC_SAO_LAGGED_CORNER or 0 */
+    uint8_t  quirks;                    /* OHEVC_SAO_LAG_* or 0 */
     uint8_t  reserved[7];
 } ohevc_sao_job;
 
 /* The reference front-end filters with a one-CTB lag (ff_hevc_hls_filter, hevc_filter.c:1027-1051) and postpones the
  * horizontal chroma edges of the last 8*h luma columns of a CTB to the next call (hevc_filter.c:541-547).  With 16x16
- * CTBs in 4:2:0 that is the whole CTB, so the copy sao_filter_CTB takes of the sample diagonally below-right of a CTB
- * (:316-321) has only been vertically deblocked.  A job carrying this flag reads that one sample from `lagged` (the
- * picture as it was between the vertical and the horizontal deblocking pass) and therefore reproduces the reference
- * decoder bit for bit; without it SAO reads the fully deblocked picture everywhere, as H.265 8.7.3 says. */
-enum { OHEVC_SAO_LAGGED_CORNER = 1 };
+ * CTBs in 4:2:0 that is the whole CTB, so some of the neighbour samples sao_filter_CTB copies (:289-325) from the first
+ * chroma column of the CTB to the right have only been vertically deblocked at that moment:
+ *   LAG_BELOW  the samples right of the CTB's last row and diagonally below-right (p0/q0 of the next column's edge
+ *              below) -- every CTB row but the last;
+ *   LAG_ABOVE  the samples diagonally above-right and right of the CTB's first row (p0/q0 of the edge above) -- the
+ *              last two CTB rows, whose filter calls the reference interleaves (ff_hevc_hls_filters, :1053-1063).
+ * A job carrying a flag reads those samples from `lagged` (the picture as it was between the vertical and the
+ * horizontal deblocking pass) and therefore reproduces the reference decoder bit for bit; without flags SAO reads the
+ * fully deblocked picture everywhere, as H.265 8.7.3 says. */
+enum { OHEVC_SAO_LAG_BELOW = 1, OHEVC_SAO_LAG_ABOVE = 2 };
 
 int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
                         const ohevc_sao_job *jobs, int njobs, void *stream);

@@ -111,11 +111,13 @@ int  ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot);
 int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
 /* sticky status of the recording since begin_frame: table slots return void, so failures surface here */
 int  ohevc_tables_status(ohevc_ctx *ctx);
-/* Reproduce the reference front-end's filter lag (ff_hevc_hls_filter, hevc_filter.c:1027-1051): with log2_ctb_size == 4
- * in 4:2:0 its SAO reads one chroma sample per CTB before that sample's horizontal edge was deblocked (see
- * OHEVC_SAO_LAGGED_CORNER in ohevc_hip.h).  Call with the SPS value from the frame-start hook to stay bit-identical with
- * the reference decoder; leave it at 0 (default) to follow H.265 8.7.3. */
-int  ohevc_tables_emulate_filter_lag(ohevc_ctx *ctx, int log2_ctb_size);
+/* Reproduce the reference front-end's filter lag (ff_hevc_hls_filter / ff_hevc_hls_filters, hevc_filter.c:1027-1063):
+ * with 16x16 CTBs in 4:2:0 its SAO copies a few chroma samples of the next CTB column before the horizontal edge through
+ * them has been deblocked (OHEVC_SAO_LAG_* in ohevc_hip.h).  When enabled, the recording slots keep the order of the
+ * SAO and horizontal-edge calls and flag exactly the SAO jobs whose neighbour edge was filtered later, which keeps the
+ * output bit-identical with the reference decoder; disabled (default) every SAO job reads the fully deblocked picture
+ * (H.265 8.7.3).  Call once after ohevc_tables_bind. */
+int  ohevc_tables_emulate_filter_lag(ohevc_ctx *ctx, int enable);
 /* drop everything registered for ctx (done automatically by ohevc_ctx_destroy) */
 void ohevc_tables_forget(ohevc_ctx *ctx);
 

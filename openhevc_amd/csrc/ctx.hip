@@ -61,8 +61,8 @@ struct ohevc_ctx {
     bool table_dirty = true;
     int cur = -1;
     Picture twin;                     // deblocked copy for SAO (the reference's sao_frame, hevc.c:369-385)
-    Picture lag;                      // picture between the two deblocking passes (only for OHEVC_SAO_LAGGED_CORNER jobs)
-    bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAGGED_CORNER
+    Picture lag;                      // picture between the two deblocking passes (only for OHEVC_SAO_LAG_* jobs)
+    bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
 
     std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
     std::map<uint32_t, std::vector<ohevc_tu_job>> tu;     // (level, log2, kind) -> jobs
@@ -371,7 +371,7 @@ extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
     c->sao.push_back(*job);
-    if (job->quirks & OHEVC_SAO_LAGGED_CORNER) c->sao_lagged = true;
+    if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE)) c->sao_lagged = true;
     c->stats.n_sao++;
     return OHEVC_OK;
 }
@@ -569,7 +569,7 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
             if (q.used && (r = free_picture(q)) != OHEVC_OK) return r;
             return alloc_picture(q, p->w, p->h, p->cfi, p->bd);
         };
-        if (lagged) {          // the state the reference's early copy saw (ohevc_hip.h, OHEVC_SAO_LAGGED_CORNER): chroma only
+        if (lagged) {          // the state the reference's early copy saw (ohevc_hip.h, OHEVC_SAO_LAG_*): chroma only
             if ((rc = ensure_like(c->lag)) != OHEVC_OK) return rc;
             for (int i = 1; i < 3; i++)
                 OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,

@@ -119,14 +119,21 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
     const bool de0 = jb.edges & 16, de1 = jb.edges & 32, de2 = jb.edges & 64, de3 = jb.edges & 128;
     const int sul = !de0 && eo == 2 && !b0 && !b1, sur = !de1 && eo == 3 && !b1 && !b2;
     const int slr = !de2 && eo == 2 && !b2 && !b3, sll = !de3 && eo == 3 && !b0 && !b3;
-    const bool lagged_corner = (jb.quirks & OHEVC_SAO_LAGGED_CORNER) && eo == 2 && bx + w < pw && by + h < ph;
+    const bool lag_below = (jb.quirks & OHEVC_SAO_LAG_BELOW) != 0, lag_above = (jb.quirks & OHEVC_SAO_LAG_ABOVE) != 0;
+    const bool lag_any = (lag_below || lag_above) && eo != 1 && bx + w < pw;
     for (int idx = threadIdx.x; idx < w * h; idx += 256) {
         const int y = idx / w, x = idx - y * w;
-        const int c = SRC(x, y), a = SRC(x + dxa, y + dya);
-        int b = SRC(x - dxa, y - dya);
-        if (lagged_corner && x == w - 1 && y == h - 1)      // the one sample the reference copies too early (ohevc_hip.h)
-            b = (int)*reinterpret_cast<const Pixel *>(PLANE_PTR3(lag, jb.plane) + (size_t)(by + h) * PLANE_STRIDE3(lag, jb.plane) +
-                                                      (size_t)(bx + w) * sizeof(Pixel));
+        const int c = SRC(x, y);
+        int a = SRC(x + dxa, y + dya), b = SRC(x - dxa, y - dya);
+        if (lag_any && x == w - 1) {                        // samples the reference copies too early (ohevc_hip.h)
+            const unsigned char *lbase = PLANE_PTR3(lag, jb.plane) + (size_t)(bx + w) * sizeof(Pixel);
+            const int lstride = PLANE_STRIDE3(lag, jb.plane);
+            auto stale = [&](int ny) {
+                return by + ny >= 0 && by + ny < ph && ((lag_below && (ny == h - 1 || ny == h)) || (lag_above && (ny == -1 || ny == 0)));
+            };
+            if (dxa == 1 && stale(y + dya)) a = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y + dya) * lstride);
+            if (dxa == -1 && stale(y - dya)) b = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y - dya) * lstride);
+        }
         const int s = (c > a) - (c < a) + (c > b) - (c < b);                      // -2..2
         int off = s == -2 ? ov1 : s == -1 ? ov2 : s == 0 ? ov0 : s == 1 ? ov3 : ov4;  // offset_val[edge_idx[2 + s]], edge_idx = {1,2,0,3,4}
         const bool on_border = (eo != 1 && ((b0 && x == 0) || (b2 && x == w - 1))) ||

@@ -13,8 +13,13 @@
 //   * edge emulation: vdsp.emulated_edge_mc(buf, src - offset, ..., src_x, src_y, w, h) precedes the MC call that reads
 //     `buf + buf_offset` (hevc.c:1660-1675) -> it notes (picture, src_x, src_y) for that buffer and copies nothing; the
 //     MC kernel clamps coordinates instead.
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 #include <string.h>
 #include <vector>
 #include "common.hpp"
@@ -33,7 +38,11 @@ struct TablesState {
     std::vector<HostPic> pics;
     int cur = -1;                     // index into pics
     int status = OHEVC_OK;
-    int lag_log2_ctb = 0;             // ohevc_tables_emulate_filter_lag
+    // ohevc_tables_emulate_filter_lag: call-order bookkeeping of the current frame
+    int lag_on = 0;
+    uint32_t seq = 0;
+    std::unordered_map<uint32_t, uint32_t> h_edge_seq;                    // (plane, x, y) of a chroma horizontal edge -> call number
+    std::vector<std::pair<ohevc_sao_job, uint32_t>> held_sao;           // chroma SAO jobs held back until the frame ends
     ohevc_HEVCDSPContext saved = {};  // the reference's own C slots (put_pcm is still executed on the host into scratch)
 };
 
@@ -244,6 +253,8 @@ void dbk_record(uint8_t *pix, bool vertical, int beta, const int *tc, const uint
     j.tc[0] = (int16_t)tc[0]; j.tc[1] = (int16_t)tc[1];
     j.flags = (uint8_t)((vertical ? OHEVC_DBK_VERTICAL_EDGE : 0) | (no_p[0] ? OHEVC_DBK_NO_P0 : 0) | (no_p[1] ? OHEVC_DBK_NO_P1 : 0) |
                         (no_q[0] ? OHEVC_DBK_NO_Q0 : 0) | (no_q[1] ? OHEVC_DBK_NO_Q1 : 0));
+    if (tl_state->lag_on && !vertical && l.plane > 0)
+        tl_state->h_edge_seq[((uint32_t)l.plane << 30) | ((uint32_t)l.y << 15) | (uint32_t)l.x] = ++tl_state->seq;
     int rc = ohevc_rec_deblock(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
 }
@@ -263,16 +274,19 @@ void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int
     j.klass = type == OHEVC_SAO_BAND ? sao->band_position[c_idx] : sao->eo_class[c_idx];
     j.borders = (uint8_t)((borders[0] ? 1 : 0) | (borders[1] ? 2 : 0) | (borders[2] ? 4 : 0) | (borders[3] ? 8 : 0));
     j.restore = (uint8_t)restore;
-    // the reference front-end's early copy of the below-right chroma sample with 16x16 CTBs (ohevc_hip.h): only when the
-    // integration asked for it, only for full 8x8 chroma CTBs whose right neighbour is not the last CTB column
-    if (tl_state->lag_log2_ctb == 4 && c_idx > 0 && width == 8 && height == 8 && !borders[2] && !borders[3]) {
-        const HostPic &hp = tl_state->pics[tl_state->cur];
-        if (hp.w[c_idx] * 2 == hp.w[0] && hp.h[c_idx] * 2 == hp.h[0] && l.x + 16 < hp.w[c_idx]) j.quirks |= OHEVC_SAO_LAGGED_CORNER;
-    }
     if (restore)
         j.edges = (uint8_t)((ve[0] ? 1 : 0) | (ve[1] ? 2 : 0) | (he[0] ? 4 : 0) | (he[1] ? 8 : 0) |
                             (de[0] ? 16 : 0) | (de[1] ? 32 : 0) | (de[2] ? 64 : 0) | (de[3] ? 128 : 0));
     for (int k = 0; k < 5; k++) j.offset_val[k] = sao->offset_val[c_idx][k];
+    static const bool trace = getenv("OHEVC_TRACE_SAO") != nullptr;
+    if (trace)
+        fprintf(stderr, "sao plane %d x %d y %d w %d h %d type %d klass %d borders %d restore %d edges %d quirks %d off %d %d %d %d %d\n", j.plane, j.x, j.y,
+                j.w, j.h, j.type, j.klass, j.borders, j.restore, j.edges, j.quirks, j.offset_val[0], j.offset_val[1], j.offset_val[2],
+                j.offset_val[3], j.offset_val[4]);
+    if (tl_state->lag_on && c_idx > 0) {        // flags depend on calls still to come: decided in ohevc_tables_end_frame
+        tl_state->held_sao.emplace_back(j, ++tl_state->seq);
+        return;
+    }
     int rc = ohevc_rec_sao(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
 }
@@ -305,11 +319,11 @@ TablesState *state_of(ohevc_ctx *ctx, bool create)
 
 }  // namespace
 
-extern "C" int ohevc_tables_emulate_filter_lag(ohevc_ctx *ctx, int log2_ctb_size)
+extern "C" int ohevc_tables_emulate_filter_lag(ohevc_ctx *ctx, int enable)
 {
     TablesState *st = state_of(ctx, true);
     if (!st) return OHEVC_ERR_ARG;
-    st->lag_log2_ctb = log2_ctb_size;
+    st->lag_on = enable != 0;
     return OHEVC_OK;
 }
 
@@ -397,6 +411,9 @@ extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
     for (size_t i = 0; i < s->pics.size(); i++) if (s->pics[i].slot == slot) s->cur = (int)i;
     OHEVC_REQUIRE(s->cur >= 0, "picture not registered");
     s->status = OHEVC_OK;
+    s->seq = 0;
+    s->h_edge_seq.clear();
+    s->held_sao.clear();
     tl_pend = Pending();
     return ohevc_frame_begin(ctx, slot);
 }
@@ -407,7 +424,24 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     TablesState *s = state_of(ctx, false);
     OHEVC_REQUIRE(s != nullptr && s->cur >= 0, "no frame begun");
     if (s->status != OHEVC_OK) { set_error("a table call failed while recording (unknown pointer or call order)"); return s->status; }
-    int rc = ohevc_frame_end(ctx);
+    int rc;
+    // a held SAO job saw, in the reference, the samples right of its block BEFORE a horizontal edge through them was
+    // filtered iff that edge's table call came after the SAO call (ohevc_hip.h, OHEVC_SAO_LAG_*)
+    const HostPic &cur = s->pics[s->cur];
+    for (auto &held : s->held_sao) {
+        ohevc_sao_job &j = held.first;
+        const int xr = j.x + j.w;
+        if (xr < cur.w[j.plane]) {
+            auto later = [&](int y) {
+                auto it = s->h_edge_seq.find(((uint32_t)j.plane << 30) | ((uint32_t)y << 15) | (uint32_t)xr);
+                return it != s->h_edge_seq.end() && it->second > held.second;
+            };
+            j.quirks = (uint8_t)((later(j.y + j.h) ? OHEVC_SAO_LAG_BELOW : 0) | (later(j.y) ? OHEVC_SAO_LAG_ABOVE : 0));
+        }
+        if ((rc = ohevc_rec_sao(ctx, &j)) != OHEVC_OK) return rc;
+    }
+    s->held_sao.clear();
+    rc = ohevc_frame_end(ctx);
     if (rc != OHEVC_OK) return rc;
     if (download) {
         const HostPic &hp = s->pics[s->cur];

@@ -118,7 +118,6 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         g_nbufs++;
     }
     slot = g_bufs[i].slot;
-    ohevc_tables_emulate_filter_lag(g_ctx, s->sps->log2_ctb_size);  /* stay bit-identical with hevc_filter.c's CTB lag */
     if (ohevc_tables_register_picture(g_ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
         ohevc_tables_begin_frame(g_ctx, slot) != OHEVC_OK) {
         fprintf(stderr, "ohhip: begin_frame failed: %s\n", ohevc_last_error());
@@ -140,7 +139,10 @@ int ohdec_backend_open(void)
     }
     g_nbufs = 0;
     g_error = 0;
-    return ohevc_tables_bind(g_ctx) == OHEVC_OK ? 0 : -1;
+    if (ohevc_tables_bind(g_ctx) != OHEVC_OK)
+        return -1;
+    /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
+    return ohevc_tables_emulate_filter_lag(g_ctx, 1) == OHEVC_OK ? 0 : -1;
 }
 
 /* INTEGRATION.md section 3, last row: run the recorded jobs, copy the picture back for output */

@@ -48,6 +48,10 @@ for kw in CASES:
             if fd:
                 ok = False
                 msg += f"\n    [frame {i} plane {c}: first (y,x)={fd[0]} ref={fd[1]} hip={fd[2]} ndiff={fd[3]}]"
+                if os.environ.get("DIAG_VERBOSE"):
+                    for (y, x) in np.argwhere(fa[c] != fb[c])[:4]:
+                        y0, x0 = max(0, y - 2), max(0, x - 2)
+                        msg += f"\n      at (y={y},x={x}) ref:\n{fa[c][y0:y+3, x0:x+3]}\n      hip:\n{fb[c][y0:y+3, x0:x+3]}"
     print("OK " if ok else "MISMATCH", kw, f"frames {len(ref)}/{len(hip)} {dt:.2f}s", msg)
     bad += not ok
 print("bad", bad)

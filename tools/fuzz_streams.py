@@ -1,0 +1,78 @@
+"""GPU fuzzing of the drop-in: random stream parameters -> synthesiser -> reference decoder (C tables) vs the same
+decoder with HIP tables.  Prints every failing parameter set as JSON (replay with tools/diag_stream.py)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np                      # noqa: E402
+from oracle import pystream as ps       # noqa: E402
+
+
+def random_params(rng):
+    log2_ctb = int(rng.choice([4, 5, 6]))
+    kw = dict(
+        width=int(rng.integers(8, 60)) * 8, height=int(rng.integers(8, 40)) * 8, bit_depth=int(rng.choice([8, 8, 10])),
+        log2_ctb=log2_ctb, log2_max_tb=min(5, log2_ctb), gop=str(rng.choice(["intra", "lowdelay_p", "lowdelay_b", "random_access"])),
+        nframes=int(rng.integers(2, 7)), seed=int(rng.integers(1, 1 << 30)),
+        amp=int(rng.integers(0, 2)), sao=int(rng.integers(0, 4) != 0), strong_intra_smoothing=int(rng.integers(0, 2)),
+        tmvp=int(rng.integers(0, 2)), sign_hiding=int(rng.integers(0, 2)), init_qp=int(rng.integers(12, 48)),
+        constrained_intra=int(rng.integers(0, 4) == 0), transform_skip=int(rng.integers(0, 2)),
+        cu_qp_delta_depth=int(rng.integers(-1, 3)), weighted_pred=int(rng.integers(0, 3) == 0),
+        weighted_bipred=int(rng.integers(0, 3) == 0), deblock_control=int(rng.integers(0, 2)),
+        loop_filter_across_slices=int(rng.integers(0, 2)), loop_filter_across_tiles=int(rng.integers(0, 2)),
+        log2_parallel_merge_level=int(rng.integers(2, log2_ctb + 1)), max_merge_cand=int(rng.integers(1, 6)),
+        rext=int(rng.integers(0, 5) == 0), tu_depth_inter=int(rng.integers(0, 3)), tu_depth_intra=int(rng.integers(0, 3)),
+    )
+    if rng.integers(0, 4) == 0:
+        kw["pcm"] = int(rng.integers(5, kw["bit_depth"] + 1))
+        kw["pcm_log2_max"] = min(5, log2_ctb)
+    mode = int(rng.integers(0, 5))
+    ctb_w = -(-kw["width"] >> log2_ctb)
+    ctb_h = -(-kw["height"] >> log2_ctb)
+    if mode == 1 and ctb_h > 1:
+        kw["wpp"] = 1
+    elif mode == 2 and ctb_w >= 2 and ctb_h >= 2:
+        kw["tiles"] = (int(rng.integers(1, min(4, ctb_w) + 1)), int(rng.integers(1, min(3, ctb_h) + 1)))
+        if kw["tiles"] == (1, 1):
+            kw.pop("tiles")
+    if "tiles" not in kw and rng.integers(0, 2) and ctb_w * ctb_h > 3:
+        kw["slices_per_picture"] = int(rng.integers(2, 5))
+        kw["dependent_slices"] = int(rng.integers(0, 2))
+    if rng.integers(0, 3) == 0:
+        kw["probs"] = dict(rqt_root_cbf=0.85, cbf_luma=0.85, cbf_chroma=0.7, sig_coeff=0.6, skip=0.15, split_cu=float(rng.uniform(0.3, 0.8)),
+                           split_transform=float(rng.uniform(0.2, 0.8)), pred_mode=float(rng.uniform(0.1, 0.7)))
+    return kw
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t0 = time.time()
+    n = bad = gen_fail = 0
+    while time.time() - t0 < budget:
+        kw = random_params(rng)
+        try:
+            aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+            ref = ps.decode_stream("c", aus)
+        except Exception as e:      # an illegal random combination: not a back-end problem
+            gen_fail += 1
+            continue
+        n += 1
+        try:
+            hip = ps.decode_stream("hip", aus)
+            ok = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
+            same_gen = all(np.array_equal(x, y) for fa, fb in zip(ref, gen_frames) for x, y in zip(fa, fb))
+        except Exception as e:
+            ok, same_gen = False, True
+            print("EXC", e)
+        if not ok or not same_gen:
+            bad += 1
+            print("FAIL" if not ok else "GEN-MISMATCH", json.dumps(kw))
+    print(json.dumps(dict(streams=n, failed=bad, rejected_by_generator=gen_fail, seconds=round(time.time() - t0, 1))))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
