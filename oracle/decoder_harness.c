@@ -60,6 +60,7 @@ ohdec *ohdec_open(int threads, int thread_type)
     if (!d->avctx || !d->frame)
         goto fail;
     d->avctx->flags |= CODEC_FLAG_UNALIGNED;
+    d->avctx->err_recognition |= AV_EF_EXPLODE;     /* a syntax error fails the call instead of being concealed (hevc.c:3480) */
     av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type == 3 ? "frameslice" : "frame", 0);
     av_opt_set_int(d->avctx, "threads", threads > 0 ? threads : 1, 0);
     if (ohdec_backend_open() < 0)

@@ -669,7 +669,7 @@ def generate(p: StreamParams, check: bool = True):
                 ptr = C.POINTER(C.c_uint8)()
                 n = L.ohsyn_slice_payload(k, C.byref(ptr))
                 if n < 0:
-                    raise RuntimeError("payload not byte aligned")
+                    raise RuntimeError("slice segment incomplete: the reference parser rejected the random syntax")
                 payload = bytes(np.ctypeslib.as_array(ptr, shape=(n,))) if n else b""
                 if nep:
                     sp = C.POINTER(C.c_uint32)()

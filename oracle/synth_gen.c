@@ -176,6 +176,7 @@ static struct {
     int      nslices;                   /* slice segments started in this access unit */
     int      planned[OHSYN_MAX_SLICES]; /* CTUs in slice segment k */
     int      ctus_done;
+    int      ended[OHSYN_MAX_SLICES];   /* end_of_slice_segment_flag = 1 was produced for segment k */
     int      flushed;                   /* the encoder was flushed and nothing has been coded since */
     int      nsub[OHSYN_MAX_SLICES];
     uint32_t sub_start[OHSYN_MAX_SLICES][OHSYN_MAX_SUBSTR]; /* byte offset where substream j of slice k starts */
@@ -235,6 +236,7 @@ void ohsyn_begin_au(const int *ctus_per_slice, int n)
             memset(G.sink[i].buf, 0, G.sink[i].cap);
         G.nsub[i] = 0;
         G.planned[i] = i < n ? ctus_per_slice[i] : 0;
+        G.ended[i] = 0;
     }
     G.nslices = 0;
     G.error = 0;
@@ -243,8 +245,8 @@ void ohsyn_begin_au(const int *ctus_per_slice, int n)
 int ohsyn_num_slices(void) { return G.error ? -1 : G.nslices; }
 int ohsyn_slice_payload(int k, const uint8_t **p)
 {
-    if (k < 0 || k >= G.nslices || (G.sink[k].bits & 7))
-        return -1;
+    if (k < 0 || k >= G.nslices || (G.sink[k].bits & 7) || !G.ended[k])
+        return -1;      /* the parser gave up inside this segment: the random syntax was not decodable */
     *p = G.sink[k].buf;
     return (int)(G.sink[k].bits >> 3);
 }
@@ -349,6 +351,8 @@ int ohsyn_end_of_slice_flag(HEVCContext *s)
     G.ctus_done++;
     last = k < 0 || G.ctus_done >= G.planned[k];
     if (last) {
+        if (k >= 0)
+            G.ended[k] = 1;
         terminate_and_align();      /* the flush's final 1 bit is rbsp_stop_one_bit, then rbsp_alignment_zero_bits */
     } else {
         enc_terminate(&G.enc, cur_sink(), 0);
