@@ -13,6 +13,7 @@
  */
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 
 #include "libavcodec/hevc.h"
 
@@ -21,6 +22,8 @@
 static ohevc_ctx *g_ctx;
 static int        g_frame_open;
 static int        g_error;
+static double     g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
+static long long  g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
 
 /* host buffer -> picture-store slot.  Keyed by the luma plane address: libavcodec's buffer pool hands a buffer out
  * again only once no frame references it, so a known address means "the picture that lived there is dead". */
@@ -152,7 +155,19 @@ int ohdec_backend_frame_done(void)
     if (!g_frame_open)
         return g_error ? -1 : 0;
     g_frame_open = 0;
-    st = ohevc_tables_end_frame(g_ctx, 1);
+    {
+        struct timespec t0, t1;
+        ohevc_frame_stats fs;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        st = ohevc_tables_end_frame(g_ctx, 1);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        g_end_frame_s += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        if (st == OHEVC_OK && ohevc_frame_get_stats(g_ctx, &fs) == OHEVC_OK) {
+            g_counts[0]++;
+            g_counts[1] += fs.launches; g_counts[2] += fs.n_tu; g_counts[3] += fs.n_mc; g_counts[4] += fs.n_intra;
+            g_counts[5] += fs.n_dbk; g_counts[6] += fs.n_sao; g_counts[7] += fs.upload_bytes;
+        }
+    }
     if (st == OHEVC_OK)
         st = ohevc_tables_status(g_ctx);
     if (st != OHEVC_OK) {
@@ -162,9 +177,13 @@ int ohdec_backend_frame_done(void)
     return g_error ? -1 : 0;
 }
 
-int ohdec_backend_stats(ohevc_frame_stats *st)
+/* cumulative since the last call: seconds inside the frame-end hook and job / launch / upload counters */
+void ohdec_backend_profile(double *end_frame_s, long long counts[8])
 {
-    return g_ctx ? ohevc_frame_get_stats(g_ctx, st) : -1;
+    *end_frame_s = g_end_frame_s;
+    memcpy(counts, g_counts, sizeof(g_counts));
+    g_end_frame_s = 0;
+    memset(g_counts, 0, sizeof(g_counts));
 }
 
 void ohdec_backend_close(void)

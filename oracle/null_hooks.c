@@ -1,0 +1,25 @@
+/*
+ * oracle/null_hooks.c -- TEST INFRASTRUCTURE ONLY (measurement aid).
+ *
+ * Same link-time interposition as hip_hooks.c, but every HEVCDSPContext / HEVCPredContext / VideoDSPContext slot is
+ * replaced by an empty function: _ref/libopenhevc_null.so decodes the syntax and produces no pixels.  Its run time is
+ * the part of the reference decoder NO table back-end can remove (entropy decoding, motion-vector and boundary-strength
+ * derivation, DPB management): the Amdahl floor quoted in DESIGN.md next to the GPU-backed numbers.
+ */
+#include <string.h>
+#include "libavcodec/hevc.h"
+
+static void nop(void) {}
+
+static void fill(void *table, size_t bytes)
+{
+    void (**slot)(void) = table;
+    size_t i;
+    for (i = 0; i < bytes / sizeof(*slot); i++)
+        slot[i] = nop;
+}
+
+void ohhip_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)  { (void)bit_depth; fill(c, sizeof(*c)); }
+void ohhip_videodsp_init(VideoDSPContext *c, int bpc)        { (void)bpc; fill(c, sizeof(*c)); }
+void ohhip_hevc_pred_init(HEVCPredContext *c, int bit_depth) { (void)bit_depth; fill(c, sizeof(*c)); }
+int  ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc) { return ff_hevc_set_new_ref(s, frame, poc); }

@@ -19,7 +19,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBS = {"c": "_ref/libopenhevc_c.so", "gen": "_ref/libopenhevc_gen.so", "hip": "_ref/libopenhevc_hip.so"}
+_LIBS = {"c": "_ref/libopenhevc_c.so", "gen": "_ref/libopenhevc_gen.so", "hip": "_ref/libopenhevc_hip.so",
+         "null": "_ref/libopenhevc_null.so"}
 _loaded = {}
 
 

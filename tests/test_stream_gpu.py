@@ -50,3 +50,19 @@ def test_fresh_larger_streams_hip_backend(kw):
     ref = ps.decode_stream("c", aus)
     assert frames_md5(ref) == frames_md5(gen_frames)
     _compare(ref, ps.decode_stream("hip", aus))
+
+
+def test_fuzzed_streams_hip_backend():
+    """A short run of tools/fuzz_streams.py: random legal parameter sets, every one must decode identically."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "12", "77"], capture_output=True, text=True,
+                       timeout=300)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0, r.stdout[-3000:]
+    import json
+    res = json.loads(last)
+    assert res["failed"] == 0 and res["streams"] > 50, res

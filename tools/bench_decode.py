@@ -59,15 +59,30 @@ def main():
     tgen = time.perf_counter() - t
     ref = ps.decode_stream("c", aus)
     hip = ps.decode_stream("hip", aus)
+    import ctypes as C0
+    _sec, _cnt = C0.c_double(), (C0.c_longlong * 8)()
+    ps._load("hip").ohdec_backend_profile(C0.byref(_sec), _cnt)        # reset the cumulative counters
     exact = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
     res = dict(workload=f"synthetic {a.gop} stream {w}x{h8} {a.bit_depth}-bit, {a.frames} pictures, "
                         f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}",
                bit_exact=bool(exact), generate_s=round(tgen, 2))
     mp = w * h8 * a.frames / 1e6
+    import ctypes as C
     for name, kind, th, tt in (("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
-                               ("hip_backend", "hip", 1, 1)):
+                               ("front_end_only_no_pixels", "null", 1, 1), ("hip_backend", "hip", 1, 1)):
+        if not ps.have(kind):
+            continue
         dt, n = timed_decode(kind, aus, th, tt)
         res[name] = dict(seconds=round(dt, 4), fps=round(a.frames / dt, 2), mpixel_per_s=round(mp / dt, 1), pictures=n)
+        if kind == "hip":       # where the back-end's time goes (last repeat only is not separated: counters are cumulative)
+            L = ps._load("hip")
+            sec = C.c_double()
+            cnt = (C.c_longlong * 8)()
+            L.ohdec_backend_profile(C.byref(sec), cnt)
+            nf = max(1, cnt[0])
+            res[name]["per_picture"] = dict(frame_end_hook_ms=round(1e3 * sec.value / nf, 3), launches=round(cnt[1] / nf, 1),
+                                            tu_jobs=cnt[2] // nf, mc_jobs=cnt[3] // nf, intra_jobs=cnt[4] // nf,
+                                            deblock_jobs=cnt[5] // nf, sao_jobs=cnt[6] // nf, upload_kib=cnt[7] // nf // 1024)
     print(json.dumps(res))
 
 
