@@ -30,6 +30,14 @@ extern "C" {
 typedef struct ohevc_ctx ohevc_ctx;
 
 int  ohevc_ctx_create(ohevc_ctx **out, int device);
+/* One context per decoding thread.  Contexts created with share_with != NULL use share_with's picture store (the slots
+ * of ohevc_pic_alloc are common to all of them) and its device, each on its own stream: a frame thread can predict from
+ * pictures another thread reconstructs.  Ordering between the streams is kept by the library: a frame waits for the
+ * frame_end of every picture it references (blocking the host until that frame_end has been issued by its thread) and
+ * for earlier users of the memory it overwrites.  Destroy the sharing contexts before the one they were created from,
+ * or all of them after the decoding threads have stopped; the pictures are freed with the last context. */
+int  ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *share_with);
+const void *ohevc_ctx_store_id(ohevc_ctx *ctx);            /* identity of the picture store (equal for sharing contexts) */
 void ohevc_ctx_destroy(ohevc_ctx *ctx);
 /* the HIP stream all of this context's copies and launches are issued on (hipStream_t as void*) */
 void *ohevc_ctx_stream(ohevc_ctx *ctx);

@@ -18,6 +18,10 @@ int ohevc_debug_set_tu_pipe_workgroups(int n);
 /* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = 2 + both reference
  * windows staged before the first barrier (shipped) */
 int ohevc_debug_set_mc_variant(int variant);
+/* Profiling aid for the HOST side only: contexts created while this is on need no device and produce NO pixels -- every
+ * ohevc_rec_* call does its normal work, the frame-end executor just drops the recorded jobs.  It exists to time the
+ * recording cost of the table slots (tools/profile_recording.py); never a fallback: pictures stay unwritten. */
+int ohevc_debug_set_record_only(int on);
 #ifdef __cplusplus
 }
 #endif

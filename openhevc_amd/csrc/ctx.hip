@@ -2,11 +2,16 @@
 // Host code only; the kernels it launches live in the *_kernels.hip files and are reached through the same
 // ohevc_dev_* entry points an external caller would use.
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string.h>
 #include <vector>
 #include "common.hpp"
 #include "ohevc_ctx.h"
+#include "ohevc_debug.h"
 
 namespace {
 
@@ -14,6 +19,20 @@ struct Picture {
     bool used = false, owned = true;
     int w = 0, h = 0, cfi = 1, bd = 8;
     ohevc_plane planes[3] = {};
+    // cross-ctx ordering (contexts of several decoding threads share one store and run on their own streams):
+    bool end_issued = true;               // false between frame_begin and the frame_end that reconstructs this picture
+    hipEvent_t written = nullptr;         // recorded on the writer's stream by that frame_end
+    std::vector<hipEvent_t> readers;      // frame-end events of pictures that read this one since it was written
+};
+
+// The device picture store = the decoded picture buffer.  One per ohevc_ctx_create, shared by ohevc_ctx_create_shared.
+constexpr int kMaxPics = 127;
+struct PicStore {
+    std::mutex m;
+    std::condition_variable cv;           // signalled when a picture's end_issued turns true
+    Picture pics[kMaxPics];               // fixed array: pointers to entries stay valid while other threads allocate
+    int npics = 0;
+    unsigned version = 0;                 // bumped whenever a slot's planes change (contexts re-upload their MC table)
 };
 
 struct DevBuf {                       // grow-only device buffer
@@ -48,25 +67,38 @@ struct PinnedBuf {                    // grow-only pinned host staging buffer
     }
 };
 
-inline uint32_t tu_key(int level, int log2, int kind) { return ((uint32_t)level << 8) | ((uint32_t)log2 << 4) | (uint32_t)kind; }
+// jobs of one intra dependency level (level 0 = residuals of inter blocks).  Bins keep their capacity from picture to
+// picture; `touched` lists the (size, kind) bins in use so that clearing and staging never walk the empty ones.
+struct LevelBins {
+    std::vector<ohevc_tu_job> tu[4][OHEVC_TU_NKINDS];
+    std::vector<ohevc_intra_job> intra;
+    uint64_t touched = 0;             // bit (log2 - 2) * 16 + kind
+};
 
 }  // namespace
 
+static bool g_record_only = false;   // ohevc_debug_set_record_only
+
 struct ohevc_ctx {
+    bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t staged = nullptr;      // recorded after the last H2D copy out of `stage`
     bool staged_pending = false;
-    std::vector<Picture> pics;
-    bool table_dirty = true;
+    std::shared_ptr<PicStore> store;
+    unsigned table_version = ~0u;     // store->version the device MC table was built from
     int cur = -1;
+    hipEvent_t ring[16] = {};         // frame-end events handed to the store (a re-recorded event only waits longer)
+    int ring_next = 0;
+    std::vector<int> ref_slots;       // reference pictures the stream already waits for in this frame
+    bool target_guarded = false;      // the stream already waits for earlier readers/writers of the target picture
     Picture twin;                     // deblocked copy for SAO (the reference's sao_frame, hevc.c:369-385)
     Picture lag;                      // picture between the two deblocking passes (only for OHEVC_SAO_LAG_* jobs)
     bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
 
     std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
-    std::map<uint32_t, std::vector<ohevc_tu_job>> tu;     // (level, log2, kind) -> jobs
-    std::map<int, std::vector<ohevc_intra_job>> intra;    // level -> jobs
+    std::vector<LevelBins> levels;                         // [level]; entries 0..max_level are live
+    int max_level = -1;
     std::vector<int16_t> coeffs;
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
@@ -81,17 +113,17 @@ struct ohevc_ctx {
 
 using namespace ohevc;
 
-static int free_picture(Picture &p)
+static int free_picture(Picture &p, bool dry = false)
 {
     for (auto &pl : p.planes) {
-        if (pl.data && p.owned) OHEVC_HIP_TRY(hipFree(pl.data));
+        if (pl.data && p.owned && !dry) OHEVC_HIP_TRY(hipFree(pl.data));
         pl = ohevc_plane{};
     }
     p.used = false; p.owned = true;
     return OHEVC_OK;
 }
 
-static int alloc_picture(Picture &p, int width, int height, int cfi, int bd)
+static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, bool dry = false)
 {
     const int ps = bd > 8 ? 2 : 1;
     p.w = width; p.h = height; p.cfi = cfi; p.bd = bd;
@@ -99,8 +131,8 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd)
         const int hs = i ? (cfi == 1 || cfi == 2) : 0, vs = i ? (cfi == 1) : 0;
         const int w = width >> hs, h = height >> vs;
         const int stride = (w * ps + 255) & ~255;          // 256-byte pitch: whole 128-byte lines per row segment
-        void *d = nullptr;
-        OHEVC_HIP_TRY(hipMalloc(&d, (size_t)stride * h));
+        void *d = reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1));      // never dereferenced in record-only mode
+        if (!dry) OHEVC_HIP_TRY(hipMalloc(&d, (size_t)stride * h));
         p.planes[i] = ohevc_plane{ d, stride, w, h };
     }
     p.used = true;
@@ -110,12 +142,29 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd)
 extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
 {
     OHEVC_REQUIRE(out != nullptr, "out");
+    return ohevc_ctx_create_shared(out, device, nullptr);
+}
+
+extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *share_with)
+{
+    OHEVC_REQUIRE(out != nullptr, "out");
+    if (g_record_only || (share_with && share_with->dry)) {
+        ohevc_ctx *c = new ohevc_ctx();
+        c->dry = true;
+        c->store = share_with ? share_with->store : std::make_shared<PicStore>();
+        *out = c;
+        return OHEVC_OK;
+    }
+    if (share_with) device = share_with->device;
     int rc = ohevc_set_device(device);
     if (rc != OHEVC_OK) return rc;
     ohevc_ctx *c = new ohevc_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) != hipSuccess) {
+    c->store = share_with ? share_with->store : std::make_shared<PicStore>();
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) == hipSuccess;
+    for (auto &e : c->ring) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         set_error("stream/event creation failed");
         delete c;
         return OHEVC_ERR_HIP;
@@ -124,15 +173,22 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
     return OHEVC_OK;
 }
 
+extern "C" const void *ohevc_ctx_store_id(ohevc_ctx *c) { return c ? (const void *)c->store.get() : nullptr; }
+
 extern "C" void ohevc_tables_forget(ohevc_ctx *ctx);      // tables.hip: drop the pointer registry of this ctx
 
 extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
 {
     if (!c) return;
     ohevc_tables_forget(c);
+    if (c->dry) { delete c; return; }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto &p : c->pics) if (p.used) free_picture(p);
+    if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
+        hipDeviceSynchronize();
+        for (int i = 0; i < c->store->npics; i++) if (c->store->pics[i].used) free_picture(c->store->pics[i]);
+    }
+    for (auto &e : c->ring) if (e) hipEventDestroy(e);
     if (c->twin.used) free_picture(c->twin);
     if (c->lag.used) free_picture(c->lag);
     if (c->d_jobs.p) hipFree(c->d_jobs.p);
@@ -144,11 +200,14 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     delete c;
 }
 
+extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
+
 extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
 {
     OHEVC_REQUIRE(c != nullptr, "ctx");
+    if (c->dry) return OHEVC_OK;
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     c->staged_pending = false;
     return OHEVC_OK;
@@ -160,14 +219,16 @@ extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int
     OHEVC_REQUIRE(width > 0 && height > 0 && width <= 65535 && height <= 65535, "picture size");
     OHEVC_REQUIRE(cfi >= 1 && cfi <= 3, "chroma_format_idc must be 1..3");
     OHEVC_REQUIRE(bd >= 8 && bd <= 12, "bit_depth must be 8..12");
-    OHEVC_HIP_TRY(hipSetDevice(c->device));
+    if (!c->dry) OHEVC_HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->store->m);
     int slot = -1;
-    for (size_t i = 0; i < c->pics.size(); i++) if (!c->pics[i].used) { slot = (int)i; break; }
-    if (slot < 0) { c->pics.emplace_back(); slot = (int)c->pics.size() - 1; }
-    OHEVC_REQUIRE(slot < 127, "too many pictures");
-    int rc = alloc_picture(c->pics[slot], width, height, cfi, bd);
+    for (int i = 0; i < c->store->npics; i++) if (!c->store->pics[i].used) { slot = i; break; }
+    if (slot < 0) { OHEVC_REQUIRE(c->store->npics < kMaxPics, "too many pictures"); slot = c->store->npics++; }
+    Picture &np = c->store->pics[slot];
+    np = Picture();
+    int rc = alloc_picture(np, width, height, cfi, bd, c->dry);
     if (rc != OHEVC_OK) return rc;
-    c->table_dirty = true;
+    c->store->version++;
     return slot;
 }
 
@@ -175,41 +236,46 @@ extern "C" int ohevc_pic_adopt(ohevc_ctx *c, const ohevc_plane planes[3], int wi
 {
     OHEVC_REQUIRE(c != nullptr && planes != nullptr, "null argument");
     OHEVC_REQUIRE(width > 0 && height > 0 && cfi >= 1 && cfi <= 3 && bd >= 8 && bd <= 12, "bad picture description");
+    std::lock_guard<std::mutex> g(c->store->m);
     int slot = -1;
-    for (size_t i = 0; i < c->pics.size(); i++) if (!c->pics[i].used) { slot = (int)i; break; }
-    if (slot < 0) { c->pics.emplace_back(); slot = (int)c->pics.size() - 1; }
-    OHEVC_REQUIRE(slot < 127, "too many pictures");
-    Picture &p = c->pics[slot];
+    for (int i = 0; i < c->store->npics; i++) if (!c->store->pics[i].used) { slot = i; break; }
+    if (slot < 0) { OHEVC_REQUIRE(c->store->npics < kMaxPics, "too many pictures"); slot = c->store->npics++; }
+    Picture &p = c->store->pics[slot];
+    p = Picture();
     p.w = width; p.h = height; p.cfi = cfi; p.bd = bd; p.owned = false; p.used = true;
     for (int i = 0; i < 3; i++) {
         OHEVC_REQUIRE(planes[i].data != nullptr && (planes[i].stride & 15) == 0 && (reinterpret_cast<uintptr_t>(planes[i].data) & 15) == 0,
                       "adopted planes must be 16-byte aligned with a 16-byte multiple stride");
         p.planes[i] = planes[i];
     }
-    c->table_dirty = true;
+    c->store->version++;
     return slot;
 }
 
 static Picture *get_pic(ohevc_ctx *c, int slot)
 {
-    if (!c || slot < 0 || slot >= (int)c->pics.size() || !c->pics[slot].used) return nullptr;
-    return &c->pics[slot];
+    if (!c || slot < 0 || slot >= c->store->npics || !c->store->pics[slot].used) return nullptr;
+    return &c->store->pics[slot];
 }
 
 extern "C" int ohevc_pic_release(ohevc_ctx *c, int slot)
 {
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
-    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    // other contexts of the store may still have kernels in flight that read this picture
+    if (!c->dry) OHEVC_HIP_TRY(c->store.use_count() > 1 ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream));
     if (c->cur == slot) c->cur = -1;
-    c->table_dirty = true;
-    return free_picture(*p);
+    std::lock_guard<std::mutex> g(c->store->m);
+    c->store->version++;
+    p->readers.clear();
+    return free_picture(*p, c->dry);
 }
 
 extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *host, ptrdiff_t host_stride)
 {
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
+    if (c->dry) return OHEVC_OK;
     const ohevc_plane &pl = p->planes[plane];
     OHEVC_HIP_TRY(hipMemcpy2DAsync(pl.data, pl.stride, host, host_stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
                                    hipMemcpyHostToDevice, c->stream));
@@ -221,6 +287,7 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
 {
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
+    if (c->dry) return OHEVC_OK;
     const ohevc_plane &pl = p->planes[plane];
     OHEVC_HIP_TRY(hipMemcpy2DAsync(host, host_stride, pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
                                    hipMemcpyDeviceToHost, c->stream));
@@ -249,7 +316,14 @@ extern "C" int ohevc_pic_info(ohevc_ctx *c, int slot, int *width, int *height, i
 
 static void clear_recorded(ohevc_ctx *c)
 {
-    c->mc.clear(); c->mc_small.clear(); c->tu.clear(); c->intra.clear(); c->coeffs.clear(); c->cips.clear();
+    c->mc.clear(); c->mc_small.clear(); c->coeffs.clear(); c->cips.clear();
+    for (int l = 0; l <= c->max_level; l++) {
+        LevelBins &lb = c->levels[l];
+        for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
+        lb.touched = 0;
+        lb.intra.clear();
+    }
+    c->max_level = -1;
     for (int i = 0; i < 3; i++) std::fill(c->level_map[i].begin(), c->level_map[i].end(), 0);
 }
 
@@ -258,6 +332,12 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
     c->cur = slot;
+    {
+        std::lock_guard<std::mutex> g(c->store->m);
+        p->end_issued = false;
+    }
+    c->ref_slots.clear();
+    c->target_guarded = false;
     for (int i = 0; i < 3; i++) {
         c->lm_w[i] = (p->planes[i].width + 3) >> 2;
         c->lm_h[i] = (p->planes[i].height + 3) >> 2;
@@ -267,6 +347,13 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear();
     c->stats = ohevc_frame_stats{};
     return OHEVC_OK;
+}
+
+static inline LevelBins &level_bins(ohevc_ctx *c, int level)
+{
+    if (level >= (int)c->levels.size()) c->levels.resize((size_t)level + 16);
+    if (level > c->max_level) c->max_level = level;
+    return c->levels[level];
 }
 
 extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra)
@@ -286,7 +373,9 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
         c->coeffs.insert(c->coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
-    c->tu[tu_key(level, log2, kind)].push_back(j);
+    LevelBins &lb = level_bins(c, level);
+    lb.tu[log2 - 2][kind].push_back(j);
+    lb.touched |= 1ull << ((log2 - 2) * 16 + kind);
     c->stats.n_tu++;
     return OHEVC_OK;
 }
@@ -354,7 +443,7 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(level < 65535, "intra dependency chain too long");
     for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
         for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) lm[(size_t)cy * W + cx] = (uint16_t)level;
-    c->intra[level].push_back(*job);
+    level_bins(c, level).intra.push_back(*job);
     c->stats.n_intra++;
     return OHEVC_OK;
 }
@@ -429,15 +518,54 @@ static int wait_staging_free(ohevc_ctx *c)
 
 static int upload_table(ohevc_ctx *c)
 {
-    if (!c->table_dirty) return OHEVC_OK;
-    std::vector<ohevc_plane> t(c->pics.size() * 3);
-    for (size_t s = 0; s < c->pics.size(); s++)
-        for (int i = 0; i < 3; i++) t[3 * s + i] = c->pics[s].used ? c->pics[s].planes[i] : ohevc_plane{};
+    std::vector<ohevc_plane> t;
+    {
+        std::lock_guard<std::mutex> g(c->store->m);
+        if (c->table_version == c->store->version) return OHEVC_OK;
+        t.resize((size_t)kMaxPics * 3);
+        for (int s = 0; s < c->store->npics; s++)
+            for (int i = 0; i < 3; i++) t[3 * s + i] = c->store->pics[s].used ? c->store->pics[s].planes[i] : ohevc_plane{};
+        c->table_version = c->store->version;
+    }
     int rc = c->d_table.reserve(t.size() * sizeof(ohevc_plane));
     if (rc != OHEVC_OK) return rc;
     OHEVC_HIP_TRY(hipMemcpyAsync(c->d_table.p, t.data(), t.size() * sizeof(ohevc_plane), hipMemcpyHostToDevice, c->stream));
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-    c->table_dirty = false;
+    return OHEVC_OK;
+}
+
+// Make this context's stream wait for whatever other contexts of the store still do with the pictures this frame
+// touches: the frame that reconstructs a reference picture (possibly not even issued yet by its decoding thread), and
+// earlier readers / the earlier writer of the target picture's memory.
+static int guard_pictures(ohevc_ctx *c, int target)
+{
+    std::vector<int> fresh;
+    for (const auto *v : {&c->mc, &c->mc_small})
+        for (const ohevc_mc_job &j : *v) {
+            const int refs[2] = {j.ref0, (j.flags & OHEVC_MC_BI) ? j.ref1 : -1};
+            for (int r : refs)
+                if (r >= 0 && r != target && std::find(c->ref_slots.begin(), c->ref_slots.end(), r) == c->ref_slots.end()) {
+                    c->ref_slots.push_back(r);
+                    fresh.push_back(r);
+                }
+        }
+    if (fresh.empty() && c->target_guarded) return OHEVC_OK;
+    std::unique_lock<std::mutex> lk(c->store->m);
+    for (int r : fresh) {
+        Picture &rp = c->store->pics[r];
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return rp.end_issued; })) {
+            set_error("reference picture %d was never completed by its decoding thread", r);
+            return OHEVC_ERR_STATE;
+        }
+        if (rp.written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, rp.written, 0));
+    }
+    if (!c->target_guarded) {
+        Picture &tp = c->store->pics[target];
+        if (tp.written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, tp.written, 0));
+        for (hipEvent_t e : tp.readers) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+        tp.readers.clear();
+        c->target_guarded = true;
+    }
     return OHEVC_OK;
 }
 
@@ -468,20 +596,32 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    if (c->dry) { clear_recorded(c); return OHEVC_OK; }
     OHEVC_HIP_TRY(hipSetDevice(c->device));
-    if (c->mc.empty() && c->mc_small.empty() && c->tu.empty() && c->intra.empty()) return OHEVC_OK;
+    if (c->mc.empty() && c->mc_small.empty() && c->max_level < 0) return OHEVC_OK;
     int rc = upload_table(c);
     if (rc != OHEVC_OK) return rc;
+    if ((rc = guard_pictures(c, c->cur)) != OHEVC_OK) return rc;
 
     // ---- stage every job array + the coefficient arena, one H2D copy
     std::vector<std::pair<const void *, size_t>> parts;
     size_t total = 0;
     const size_t off_mc = c->mc.empty() ? 0 : stage_put(parts, total, c->mc.data(), c->mc.size() * sizeof(ohevc_mc_job));
     const size_t off_mcs = c->mc_small.empty() ? 0 : stage_put(parts, total, c->mc_small.data(), c->mc_small.size() * sizeof(ohevc_mc_job));
-    std::map<uint32_t, size_t> off_tu;
-    for (auto &kv : c->tu) off_tu[kv.first] = stage_put(parts, total, kv.second.data(), kv.second.size() * sizeof(ohevc_tu_job));
-    std::map<int, size_t> off_intra;
-    for (auto &kv : c->intra) off_intra[kv.first] = stage_put(parts, total, kv.second.data(), kv.second.size() * sizeof(ohevc_intra_job));
+    // per level: the intra jobs, then every touched (size, kind) bin back to back (one segmented launch per level)
+    struct LevelOff { size_t intra = 0, tu_first = 0; };
+    std::vector<LevelOff> loff((size_t)(c->max_level + 1));
+    for (int l = 0; l <= c->max_level; l++) {
+        LevelBins &lb = c->levels[l];
+        if (!lb.intra.empty()) loff[l].intra = stage_put(parts, total, lb.intra.data(), lb.intra.size() * sizeof(ohevc_intra_job));
+        bool first = true;
+        for (uint64_t m = lb.touched; m; m &= m - 1) {
+            const int b = __builtin_ctzll(m);
+            auto &v = lb.tu[b >> 4][b & 15];
+            const size_t o = stage_put(parts, total, v.data(), v.size() * sizeof(ohevc_tu_job));
+            if (first) { loff[l].tu_first = o; first = false; }
+        }
+    }
     const size_t off_coeffs = c->coeffs.empty() ? 0 : stage_put(parts, total, c->coeffs.data(), c->coeffs.size() * sizeof(int16_t));
     const size_t off_cips = c->cips.empty() ? 0 : stage_put(parts, total, c->cips.data(), c->cips.size() * sizeof(ohevc_intra_cip));
     if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
@@ -490,54 +630,48 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
 
     // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
     if (!c->mc.empty()) {
-        rc = ohevc_dev_mc_batch(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), (int)c->pics.size(), p->bd,
+        rc = ohevc_dev_mc_batch(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), kMaxPics, p->bd,
                                 reinterpret_cast<const ohevc_mc_job *>(base + off_mc), (int)c->mc.size(), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
     }
     if (!c->mc_small.empty()) {
-        rc = ohevc_dev_mc_batch_small(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), (int)c->pics.size(), p->bd,
+        rc = ohevc_dev_mc_batch_small(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), kMaxPics, p->bd,
                                       reinterpret_cast<const ohevc_mc_job *>(base + off_mcs), (int)c->mc_small.size(), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
     }
     // ---- phase 2..: level 0 = residuals of inter blocks; level L >= 1 = intra prediction of level L, then its residuals
-    int max_level = c->intra.empty() ? 0 : c->intra.rbegin()->first;
-    if (!c->tu.empty()) max_level = std::max(max_level, (int)(c->tu.rbegin()->first >> 8));
-    auto tu_it = c->tu.begin();
+    const int max_level = c->max_level;
     for (int level = 0; level <= max_level; level++) {
-        auto it = c->intra.find(level);
-        if (it != c->intra.end()) {
-            rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + off_intra[level]),
-                                           (int)it->second.size(),
+        LevelBins &lb = c->levels[level];
+        if (!lb.intra.empty()) {
+            rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
+                                           (int)lb.intra.size(),
                                            c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), c->stream);
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }
         // every (size, kind) bin of this level in ONE launch (bins are staged back to back, 256-byte = 16-job aligned)
-        std::vector<ohevc_tu_segment> segs;
-        size_t level_base = 0;
-        for (; tu_it != c->tu.end() && (int)(tu_it->first >> 8) == level; ++tu_it) {
-            if (segs.empty()) level_base = off_tu[tu_it->first];
-            ohevc_tu_segment sg;
-            sg.log2_size = (tu_it->first >> 4) & 15; sg.kind = tu_it->first & 15;
-            sg.first_job = (int32_t)((off_tu[tu_it->first] - level_base) / sizeof(ohevc_tu_job));
-            sg.njobs = (int32_t)tu_it->second.size();
-            segs.push_back(sg);
-            if (segs.size() == 40) {          // table full: flush (cannot happen with 4 sizes x 10 kinds, kept for safety)
-                rc = ohevc_dev_tu_multi(p->planes, p->bd, segs.data(), (int)segs.size(), reinterpret_cast<const ohevc_tu_job *>(base + level_base), d_coeffs, c->stream);
-                if (rc != OHEVC_OK) return rc;
-                c->stats.launches++;
-                segs.clear();
-            }
+        ohevc_tu_segment segs[40];
+        int nsegs = 0;
+        size_t job_off = 0;                          // in jobs, relative to the level's first bin
+        for (uint64_t m = lb.touched; m; m &= m - 1) {
+            const int b = __builtin_ctzll(m);
+            const auto &v = lb.tu[b >> 4][b & 15];
+            ohevc_tu_segment &sg = segs[nsegs++];
+            sg.log2_size = (b >> 4) + 2; sg.kind = b & 15;
+            sg.first_job = (int32_t)job_off;
+            sg.njobs = (int32_t)v.size();
+            job_off += ((v.size() * sizeof(ohevc_tu_job) + 255) & ~(size_t)255) / sizeof(ohevc_tu_job);
         }
-        if (!segs.empty()) {
-            rc = ohevc_dev_tu_multi(p->planes, p->bd, segs.data(), (int)segs.size(), reinterpret_cast<const ohevc_tu_job *>(base + level_base), d_coeffs, c->stream);
+        if (nsegs) {
+            rc = ohevc_dev_tu_multi(p->planes, p->bd, segs, nsegs, reinterpret_cast<const ohevc_tu_job *>(base + loff[level].tu_first), d_coeffs, c->stream);
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }
     }
-    c->stats.intra_levels = std::max(c->stats.intra_levels, max_level);
+    c->stats.intra_levels = std::max(c->stats.intra_levels, std::max(max_level, 0));
     clear_recorded(c);
     return OHEVC_OK;
 }
@@ -548,6 +682,7 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     int rc = ohevc_frame_reconstruct(c);
     if (rc != OHEVC_OK) return rc;
+    if (c->dry) { c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; }
     if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty()) {
         std::vector<std::pair<const void *, size_t>> parts;
         size_t total = 0;
@@ -591,6 +726,24 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
         }
         c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
     }
+    if (!c->dry) {
+        // publish: this picture is reconstructed once `ev` fires; the references were read until then
+        if (!c->target_guarded && (rc = guard_pictures(c, c->cur)) != OHEVC_OK) return rc;     // filter-only frames
+        hipEvent_t ev = c->ring[c->ring_next];
+        c->ring_next = (c->ring_next + 1) % 16;
+        OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));
+        std::lock_guard<std::mutex> g(c->store->m);
+        p->written = ev;
+        for (int r : c->ref_slots) {
+            auto &rd = c->store->pics[r].readers;
+            if (std::find(rd.begin(), rd.end(), ev) == rd.end()) rd.push_back(ev);
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(c->store->m);
+        p->end_issued = true;
+    }
+    c->store->cv.notify_all();
     c->last_stats = c->stats;
     return OHEVC_OK;
 }

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <utility>
@@ -32,10 +34,29 @@ struct HostPic {
     uint8_t *data[3] = {};
     int linesize[3] = {};
     int w[3] = {}, h[3] = {};
+    size_t bytes[3] = {};             // linesize * h
+    uint32_t magic[3] = {};           // floor(2^32 / linesize) + 1: row = (offset * magic) >> 32, at most one too high
+    void finish()
+    {
+        for (int c = 0; c < 3; c++) {
+            bytes[c] = (data[c] && linesize[c] > 0) ? (size_t)linesize[c] * h[c] : 0;
+            magic[c] = linesize[c] > 1 ? (uint32_t)((1ull << 32) / (uint32_t)linesize[c]) + 1 : 0;
+        }
+    }
+};
+
+// host-buffer registry: common to all contexts sharing one picture store (frame threads resolve MC source pointers into
+// pictures other threads registered).  Readers take no lock: entries are written before `n` grows and only flip `slot`.
+struct Registry {
+    std::mutex m;
+    HostPic pics[128];
+    std::atomic<int> n{0};
 };
 
 struct TablesState {
-    std::vector<HostPic> pics;
+    std::shared_ptr<Registry> reg;
+    HostPic *pics = nullptr;          // = reg->pics
+    int npics() const { return reg->n.load(std::memory_order_acquire); }
     int cur = -1;                     // index into pics
     int status = OHEVC_OK;
     // ohevc_tables_emulate_filter_lag: call-order bookkeeping of the current frame
@@ -70,23 +91,48 @@ void fail(int rc)
 
 struct Loc { int pic = -1, plane = 0, x = 0, y = 0; };
 
-// which registered picture/plane contains host address p?
+// OHEVC_PROFILE_SLOTS=1: cycle counters per slot family, printed by ohevc_tables_forget (host-side tuning aid)
+enum { K_TU, K_MC_HALF, K_MC, K_EMU, K_DBK, K_SAO, K_INTRA, K_PCM, K_END, K_NFAM };
+const char *const kFamName[K_NFAM] = {"transform_add", "put_hevc_*(first half)", "put_hevc_*_uni/bi", "emulated_edge_mc", "loop_filter",
+                                      "sao", "intra_pred", "put_pcm", "end_frame"};
+unsigned long long g_prof_cycles[K_NFAM], g_prof_calls[K_NFAM];
+const bool g_prof_on = getenv("OHEVC_PROFILE_SLOTS") != nullptr;
+struct Prof {
+    int k; unsigned long long t0;
+    explicit Prof(int kk) : k(kk), t0(g_prof_on ? __builtin_ia32_rdtsc() : 0) {}
+    ~Prof() { if (g_prof_on) { g_prof_cycles[k] += __builtin_ia32_rdtsc() - t0; g_prof_calls[k]++; } }
+};
+
+// which registered picture/plane contains host address p?  (called for every table slot: no divisions)
+inline bool locate_in(const HostPic &hp, const uint8_t *p, Loc &out)
+{
+    for (int c = 0; c < 3; c++) {
+        const size_t off = (size_t)(p - hp.data[c]);             // wraps to a huge value when p is below the plane
+        if (off >= hp.bytes[c]) continue;
+        const uint32_t o = (uint32_t)off, ls = (uint32_t)hp.linesize[c];
+        uint32_t y = (uint32_t)(((uint64_t)o * hp.magic[c]) >> 32);
+        int32_t xb = (int32_t)(o - y * ls);
+        if (xb < 0) { y--; xb += (int32_t)ls; }
+        if (xb >= hp.w[c] * hp.ps) continue;
+        out.plane = c; out.x = hp.ps == 2 ? xb >> 1 : xb; out.y = (int)y;
+        return true;
+    }
+    return false;
+}
+
 bool locate(const uint8_t *p, Loc &out, int only_pic = -1)
 {
     if (!tl_state) return false;
-    for (size_t i = 0; i < tl_state->pics.size(); i++) {
-        if (only_pic >= 0 && (int)i != only_pic) continue;
+    if (only_pic >= 0) {
+        const HostPic &hp = tl_state->pics[only_pic];
+        if (hp.slot < 0 || !locate_in(hp, p, out)) return false;
+        out.pic = only_pic;
+        return true;
+    }
+    for (int i = 0; i < tl_state->npics(); i++) {
         const HostPic &hp = tl_state->pics[i];
         if (hp.slot < 0) continue;
-        for (int c = 0; c < 3; c++) {
-            if (!hp.data[c]) continue;
-            const ptrdiff_t off = p - hp.data[c];
-            if (off < 0 || off >= (ptrdiff_t)hp.linesize[c] * hp.h[c]) continue;
-            const int y = (int)(off / hp.linesize[c]), xb = (int)(off % hp.linesize[c]);
-            if (xb >= hp.w[c] * hp.ps) continue;
-            out.pic = (int)i; out.plane = c; out.x = xb / hp.ps; out.y = y;
-            return true;
-        }
+        if (locate_in(hp, p, out)) { out.pic = (int)i; return true; }
     }
     return false;
 }
@@ -109,6 +155,7 @@ void t_transform_rdpcm(int16_t *coeffs, int16_t, int mode)
 
 template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_t)
 {
+    Prof prof_(K_TU);
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
     // no pending in-place transform on this pointer: the caller handed over a finished residual (transquant bypass)
@@ -120,6 +167,7 @@ template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_
 
 void t_put_pcm(uint8_t *dst, ptrdiff_t, int width, int height, struct GetBitContext *gb, int pcm_bit_depth)
 {
+    Prof prof_(K_PCM);
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
     const HostPic &hp = tl_state->pics[tl_state->cur];
@@ -140,6 +188,7 @@ void t_put_pcm(uint8_t *dst, ptrdiff_t, int width, int height, struct GetBitCont
 void t_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize, ptrdiff_t src_linesize,
                         int, int, int src_x, int src_y, int, int)
 {
+    Prof prof_(K_EMU);
     if (!tl_state) return;
     // src == plane_base + src_y * linesize + src_x * ps  (possibly outside the plane): recover the plane by its base
     int k = -1;
@@ -147,7 +196,7 @@ void t_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize
     if (k < 0) { k = tl_pend.emu_next; tl_pend.emu_next = (tl_pend.emu_next + 1) & 3; }
     Pending::Emu &e = tl_pend.emu[k];
     e.buf = nullptr;
-    for (size_t i = 0; i < tl_state->pics.size(); i++) {
+    for (int i = 0; i < tl_state->npics(); i++) {
         const HostPic &hp = tl_state->pics[i];
         if (hp.slot < 0) continue;
         for (int c = 0; c < 3; c++) {
@@ -186,6 +235,7 @@ bool resolve_src(const uint8_t *src, int ps, int &slot, int &plane, int &sx, int
 
 void mc_first_half(int16_t *tmp, uint8_t *src, int mx, int my)
 {
+    Prof prof_(K_MC_HALF);
     if (!tl_ctx || !tl_state || tl_state->cur < 0) { fail(OHEVC_ERR_STATE); return; }
     const int ps = tl_state->pics[tl_state->cur].ps;
     Pending &p = tl_pend;
@@ -196,6 +246,7 @@ void mc_first_half(int16_t *tmp, uint8_t *src, int mx, int my)
 void mc_record(uint8_t *dst, uint8_t *src, const int16_t *src2, int height, int width, int mx, int my,
                bool weighted, int denom, int wx0, int wx1, int ox0, int ox1)
 {
+    Prof prof_(K_MC);
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
     const int ps = tl_state->pics[tl_state->cur].ps;
@@ -246,6 +297,7 @@ void t_bi_w(uint8_t *dst, ptrdiff_t, uint8_t *src, ptrdiff_t, int16_t *src2, ptr
 // ------------------------------------------------------------------ in-loop filters
 void dbk_record(uint8_t *pix, bool vertical, int beta, const int *tc, const uint8_t *no_p, const uint8_t *no_q)
 {
+    Prof prof_(K_DBK);
     Loc l;
     if (!tl_ctx || !locate_cur(pix, l)) { fail(OHEVC_ERR_STATE); return; }
     ohevc_dbk_job j = {};
@@ -266,6 +318,7 @@ void t_v_chroma(uint8_t *pix, ptrdiff_t, int *tc, uint8_t *no_p, uint8_t *no_q) 
 void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int height, int c_idx, int type, int restore,
                 const uint8_t *ve, const uint8_t *he, const uint8_t *de)
 {
+    Prof prof_(K_SAO);
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
     ohevc_sao_job j = {};
@@ -306,6 +359,8 @@ void t_sao_edge1(uint8_t *dst, uint8_t *, ptrdiff_t, ptrdiff_t, ohevc_SAOParams 
     sao_record(dst, sao, borders, width, height, c_idx, OHEVC_SAO_EDGE, 1, ve, he, de);
 }
 
+std::map<const void *, std::weak_ptr<Registry>> g_registries;    // keyed by ohevc_ctx_store_id
+
 TablesState *state_of(ohevc_ctx *ctx, bool create)
 {
     std::lock_guard<std::mutex> g(g_lock);
@@ -313,6 +368,10 @@ TablesState *state_of(ohevc_ctx *ctx, bool create)
     if (it != g_states.end()) return it->second;
     if (!create) return nullptr;
     TablesState *s = new TablesState();
+    std::weak_ptr<Registry> &w = g_registries[ohevc_ctx_store_id(ctx)];
+    s->reg = w.lock();
+    if (!s->reg) { s->reg = std::make_shared<Registry>(); w = s->reg; }
+    s->pics = s->reg->pics;
     g_states[ctx] = s;
     return s;
 }
@@ -384,9 +443,15 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
         const int hs = c ? (cfi == 1 || cfi == 2) : 0, vs = c ? (cfi == 1) : 0;
         hp.data[c] = data[c]; hp.linesize[c] = linesize[c]; hp.w[c] = w >> hs; hp.h[c] = h >> vs;
     }
-    for (auto &p : s->pics) if (p.slot == slot) { p = hp; return OHEVC_OK; }
-    for (auto &p : s->pics) if (p.slot < 0) { p = hp; return OHEVC_OK; }
-    s->pics.push_back(hp);
+    OHEVC_REQUIRE(linesize[0] > 0 && linesize[1] > 0 && linesize[2] > 0, "host planes must have positive line sizes");
+    hp.finish();
+    std::lock_guard<std::mutex> g(s->reg->m);
+    const int n = s->npics();
+    for (int i = 0; i < n; i++) if (s->pics[i].slot == slot) { s->pics[i] = hp; return OHEVC_OK; }
+    for (int i = 0; i < n; i++) if (s->pics[i].slot < 0) { s->pics[i] = hp; return OHEVC_OK; }
+    OHEVC_REQUIRE(n < 128, "too many registered pictures");
+    s->pics[n] = hp;
+    s->reg->n.store(n + 1, std::memory_order_release);
     return OHEVC_OK;
 }
 
@@ -394,7 +459,7 @@ extern "C" int ohevc_tables_unregister_picture(ohevc_ctx *ctx, int slot)
 {
     TablesState *s = state_of(ctx, false);
     if (!s) return OHEVC_OK;
-    for (size_t i = 0; i < s->pics.size(); i++)
+    for (int i = 0; i < s->npics(); i++)
         if (s->pics[i].slot == slot) {
             s->pics[i].slot = -1;
             if (s->cur == (int)i) s->cur = -1;
@@ -408,7 +473,7 @@ extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
     TablesState *s = state_of(ctx, false);
     OHEVC_REQUIRE(s != nullptr, "no picture registered");
     s->cur = -1;
-    for (size_t i = 0; i < s->pics.size(); i++) if (s->pics[i].slot == slot) s->cur = (int)i;
+    for (int i = 0; i < s->npics(); i++) if (s->pics[i].slot == slot) s->cur = (int)i;
     OHEVC_REQUIRE(s->cur >= 0, "picture not registered");
     s->status = OHEVC_OK;
     s->seq = 0;
@@ -424,6 +489,7 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     TablesState *s = state_of(ctx, false);
     OHEVC_REQUIRE(s != nullptr && s->cur >= 0, "no frame begun");
     if (s->status != OHEVC_OK) { set_error("a table call failed while recording (unknown pointer or call order)"); return s->status; }
+    Prof prof_(K_END);
     int rc;
     // a held SAO job saw, in the reference, the samples right of its block BEFORE a horizontal edge through them was
     // filtered iff that edge's table call came after the SAO call (ohevc_hip.h, OHEVC_SAO_LAG_*)
@@ -454,6 +520,14 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
 // called by ohevc_ctx_destroy: a later ctx may be allocated at the same address and must not inherit this registry
 extern "C" void ohevc_tables_forget(ohevc_ctx *ctx)
 {
+    if (g_prof_on) {
+        for (int k = 0; k < K_NFAM; k++)
+            if (g_prof_calls[k])
+                fprintf(stderr, "slot profile: %-26s %9llu calls %8.2f Mcycles %6.0f cycles/call\n", kFamName[k], g_prof_calls[k],
+                        g_prof_cycles[k] * 1e-6, (double)g_prof_cycles[k] / g_prof_calls[k]);
+        memset(g_prof_cycles, 0, sizeof(g_prof_cycles));
+        memset(g_prof_calls, 0, sizeof(g_prof_calls));
+    }
     std::lock_guard<std::mutex> g(g_lock);
     auto it = g_states.find(ctx);
     if (it != g_states.end()) {
@@ -484,6 +558,7 @@ extern "C" int ohevc_tables_intra_pred_cip(const ohevc_intra_geom *geom, int log
                                            ptrdiff_t pred_flag_stride, int intra_value, int x0, int y0, int log2_size, int c_idx, int mode,
                                            int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right)
 {
+    Prof prof_(K_INTRA);
     if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
     ohevc_intra_job j;
     ohevc_intra_cip cip;

@@ -12,18 +12,29 @@
  * management) is the reference's; every pixel is produced by the HIP kernels behind the recording tables.
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <limits.h>
+#include <pthread.h>
 
 #include "libavcodec/hevc.h"
+#include "libavcodec/thread.h"
 
 #include "ohevc_tables.h"
+#include "ohevc_debug.h"
 
-static ohevc_ctx *g_ctx;
-static int        g_frame_open;
-static int        g_error;
-static double     g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
-static long long  g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
+/* one context per decoding thread, all sharing the root's picture store (ohevc_ctx_create_shared): frame threads
+ * (pthread_frame.c) reconstruct different pictures concurrently and predict from each other's */
+static ohevc_ctx          *g_root;
+static __thread ohevc_ctx *t_ctx;
+static __thread int        t_frame_open;
+static ohevc_ctx          *g_all[64];
+static int                 g_nall;
+static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
+static volatile int        g_error;
+static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
+static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
 
 /* host buffer -> picture-store slot.  Keyed by the luma plane address: libavcodec's buffer pool hands a buffer out
  * again only once no frame references it, so a known address means "the picture that lived there is dead". */
@@ -33,6 +44,24 @@ static struct {
     int slot, w, h, bd, fmt;
 } g_bufs[MAX_BUFS];
 static int g_nbufs;
+
+static ohevc_ctx *thread_ctx(void)
+{
+    if (t_ctx || !g_root)
+        return t_ctx;
+    if (ohevc_ctx_create_shared(&t_ctx, 0, g_root) != OHEVC_OK || ohevc_tables_bind(t_ctx) != OHEVC_OK ||
+        /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
+        ohevc_tables_emulate_filter_lag(t_ctx, 1) != OHEVC_OK) {
+        fprintf(stderr, "ohhip: per-thread context failed: %s\n", ohevc_last_error());
+        g_error = 1;
+        return NULL;
+    }
+    pthread_mutex_lock(&g_lock);
+    if (g_nall < 64)
+        g_all[g_nall++] = t_ctx;
+    pthread_mutex_unlock(&g_lock);
+    return t_ctx;
+}
 
 /* ---- the reference's own entry points (their call sites in hevc.c were renamed, the definitions were not) ---- */
 void ohhip_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)
@@ -86,28 +115,29 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
 {
     int ret = ff_hevc_set_new_ref(s, frame, poc);                   /* hevc_refs.c */
     const AVFrame *f;
+    ohevc_ctx *ctx;
     int i, slot = -1, cfmt;
     if (ret < 0)
         return ret;
+    if (!(ctx = thread_ctx()))
+        return AVERROR(ENOMEM);
     f = s->ref->frame;
     cfmt = s->sps->chroma_array_type ? s->sps->chroma_array_type : 1;
+    pthread_mutex_lock(&g_lock);
     for (i = 0; i < g_nbufs; i++)
         if (g_bufs[i].data0 == f->data[0])
             break;
     if (i < g_nbufs && (g_bufs[i].w != s->sps->width || g_bufs[i].h != s->sps->height ||
                         g_bufs[i].bd != s->sps->bit_depth || g_bufs[i].fmt != cfmt)) {
-        ohevc_tables_unregister_picture(g_ctx, g_bufs[i].slot);
-        ohevc_pic_release(g_ctx, g_bufs[i].slot);
+        ohevc_tables_unregister_picture(ctx, g_bufs[i].slot);
+        ohevc_pic_release(ctx, g_bufs[i].slot);
         g_bufs[i] = g_bufs[--g_nbufs];
         i = g_nbufs;
     }
     if (i == g_nbufs) {
-        if (g_nbufs == MAX_BUFS) {
-            g_error = 1;
-            return AVERROR(ENOMEM);
-        }
-        slot = ohevc_pic_alloc(g_ctx, s->sps->width, s->sps->height, cfmt, s->sps->bit_depth);
+        slot = g_nbufs < MAX_BUFS ? ohevc_pic_alloc(ctx, s->sps->width, s->sps->height, cfmt, s->sps->bit_depth) : -1;
         if (slot < 0) {
+            pthread_mutex_unlock(&g_lock);
             fprintf(stderr, "ohhip: pic_alloc failed: %s\n", ohevc_last_error());
             g_error = 1;
             return AVERROR(ENOMEM);
@@ -121,78 +151,98 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         g_nbufs++;
     }
     slot = g_bufs[i].slot;
-    if (ohevc_tables_register_picture(g_ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
-        ohevc_tables_begin_frame(g_ctx, slot) != OHEVC_OK) {
+    pthread_mutex_unlock(&g_lock);
+    if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
+        ohevc_tables_begin_frame(ctx, slot) != OHEVC_OK) {
         fprintf(stderr, "ohhip: begin_frame failed: %s\n", ohevc_last_error());
         g_error = 1;
         return AVERROR(EINVAL);
     }
-    g_frame_open = 1;
+    t_frame_open = 1;
     return 0;
 }
 
 /* ---- called by decoder_harness.c ---- */
 int ohdec_backend_open(void)
 {
-    if (g_ctx)
+    if (g_root)
         return 0;
-    if (ohevc_ctx_create(&g_ctx, 0) != OHEVC_OK) {
+    ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);   /* host-side profiling, no pixels (ohevc_debug.h) */
+    if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
         return -1;
     }
     g_nbufs = 0;
+    g_nall = 0;
     g_error = 0;
-    if (ohevc_tables_bind(g_ctx) != OHEVC_OK)
-        return -1;
-    /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
-    return ohevc_tables_emulate_filter_lag(g_ctx, 1) == OHEVC_OK ? 0 : -1;
+    return 0;
 }
 
-/* INTEGRATION.md section 3, last row: run the recorded jobs, copy the picture back for output */
+/* INTEGRATION.md section 3, last row: run the recorded jobs, copy the picture back for output.  Runs on the thread that
+ * decoded the picture: called by the harness after avcodec_decode_video2 (one decoding thread) or from the decoder's own
+ * end-of-frame progress report (frame threads, below). */
 int ohdec_backend_frame_done(void)
 {
     int st;
-    if (!g_frame_open)
+    struct timespec t0, t1;
+    ohevc_frame_stats fs;
+    if (!t_frame_open)
         return g_error ? -1 : 0;
-    g_frame_open = 0;
-    {
-        struct timespec t0, t1;
-        ohevc_frame_stats fs;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        st = ohevc_tables_end_frame(g_ctx, 1);
-        clock_gettime(CLOCK_MONOTONIC, &t1);
+    t_frame_open = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    st = ohevc_tables_end_frame(t_ctx, 1);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (st == OHEVC_OK && ohevc_frame_get_stats(t_ctx, &fs) == OHEVC_OK) {
+        pthread_mutex_lock(&g_lock);
         g_end_frame_s += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
-        if (st == OHEVC_OK && ohevc_frame_get_stats(g_ctx, &fs) == OHEVC_OK) {
-            g_counts[0]++;
-            g_counts[1] += fs.launches; g_counts[2] += fs.n_tu; g_counts[3] += fs.n_mc; g_counts[4] += fs.n_intra;
-            g_counts[5] += fs.n_dbk; g_counts[6] += fs.n_sao; g_counts[7] += fs.upload_bytes;
-        }
+        g_counts[0]++;
+        g_counts[1] += fs.launches; g_counts[2] += fs.n_tu; g_counts[3] += fs.n_mc; g_counts[4] += fs.n_intra;
+        g_counts[5] += fs.n_dbk; g_counts[6] += fs.n_sao; g_counts[7] += fs.upload_bytes;
+        pthread_mutex_unlock(&g_lock);
     }
     if (st == OHEVC_OK)
-        st = ohevc_tables_status(g_ctx);
+        st = ohevc_tables_status(t_ctx);
     if (st != OHEVC_OK) {
         fprintf(stderr, "ohhip: frame failed (%d): %s\n", st, ohevc_last_error());
+        g_error = 1;
         return -1;
     }
     return g_error ? -1 : 0;
 }
 
+/* frame threads: decode_nal_units() ends with ff_thread_report_progress(&s->ref->tf, INT_MAX, 0) (hevc.c:4026-4027),
+ * the moment other threads may consider the picture complete -- the frame-end hook of INTEGRATION.md section 3.  The
+ * call sites in hevc.c are renamed to this wrapper; the per-row reports of hevc_filter.c are untouched. */
+void ohhip_report_progress(ThreadFrame *f, int progress, int field)
+{
+    if (progress == INT_MAX)
+        ohdec_backend_frame_done();
+    ff_thread_report_progress(f, progress, field);
+}
+
 /* cumulative since the last call: seconds inside the frame-end hook and job / launch / upload counters */
 void ohdec_backend_profile(double *end_frame_s, long long counts[8])
 {
+    pthread_mutex_lock(&g_lock);
     *end_frame_s = g_end_frame_s;
     memcpy(counts, g_counts, sizeof(g_counts));
     g_end_frame_s = 0;
     memset(g_counts, 0, sizeof(g_counts));
+    pthread_mutex_unlock(&g_lock);
 }
 
+/* after the decoder (and its threads) are gone */
 void ohdec_backend_close(void)
 {
-    if (g_ctx) {
-        ohevc_tables_bind(NULL);
-        ohevc_ctx_destroy(g_ctx);
-        g_ctx = NULL;
+    int i;
+    for (i = 0; i < g_nall; i++)
+        ohevc_ctx_destroy(g_all[i]);
+    g_nall = 0;
+    t_ctx = NULL;
+    if (g_root) {
+        ohevc_ctx_destroy(g_root);
+        g_root = NULL;
     }
     g_nbufs = 0;
-    g_frame_open = 0;
+    t_frame_open = 0;
 }

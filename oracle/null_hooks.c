@@ -8,6 +8,7 @@
  */
 #include <string.h>
 #include "libavcodec/hevc.h"
+#include "libavcodec/thread.h"
 
 static void nop(void) {}
 
@@ -23,3 +24,4 @@ void ohhip_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)  { (void)bit_depth; f
 void ohhip_videodsp_init(VideoDSPContext *c, int bpc)        { (void)bpc; fill(c, sizeof(*c)); }
 void ohhip_hevc_pred_init(HEVCPredContext *c, int bit_depth) { (void)bit_depth; fill(c, sizeof(*c)); }
 int  ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc) { return ff_hevc_set_new_ref(s, frame, poc); }
+void ohhip_report_progress(ThreadFrame *f, int progress, int field) { ff_thread_report_progress(f, progress, field); }

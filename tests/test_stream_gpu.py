@@ -66,3 +66,16 @@ def test_fuzzed_streams_hip_backend():
     import json
     res = json.loads(last)
     assert res["failed"] == 0 and res["streams"] > 50, res
+
+
+@pytest.mark.parametrize("threads", [3, 8])
+def test_frame_threads_share_the_picture_store(threads):
+    """The reference's frame threading (pthread_frame.c): every decoding thread records into its own context, all
+    contexts share one device picture store; cross-stream ordering is the library's job (ohevc_ctx_create_shared)."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    kw = dict(gop="random_access", nframes=25, seed=401 + threads, width=416, height=240, log2_ctb=5, weighted_bipred=1)
+    aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+    ref = ps.decode_stream("c", aus)
+    for _ in range(3):      # scheduling differs from run to run
+        _compare(ref, ps.decode_stream("hip", aus, threads, 1))

@@ -59,17 +59,21 @@ def main():
     tgen = time.perf_counter() - t
     ref = ps.decode_stream("c", aus)
     hip = ps.decode_stream("hip", aus)
+    hip_mt = ps.decode_stream("hip", aus, a.cpu_threads, 1)
+    exact_mt = len(ref) == len(hip_mt) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip_mt) for x, y in zip(fa, fb))
     import ctypes as C0
     _sec, _cnt = C0.c_double(), (C0.c_longlong * 8)()
     ps._load("hip").ohdec_backend_profile(C0.byref(_sec), _cnt)        # reset the cumulative counters
     exact = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
     res = dict(workload=f"synthetic {a.gop} stream {w}x{h8} {a.bit_depth}-bit, {a.frames} pictures, "
                         f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}",
-               bit_exact=bool(exact), generate_s=round(tgen, 2))
+               bit_exact=bool(exact), bit_exact_frame_threads=bool(exact_mt), generate_s=round(tgen, 2))
     mp = w * h8 * a.frames / 1e6
     import ctypes as C
     for name, kind, th, tt in (("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
-                               ("front_end_only_no_pixels", "null", 1, 1), ("hip_backend", "hip", 1, 1)):
+                               ("front_end_only_no_pixels", "null", 1, 1),
+                               (f"front_end_only_{a.cpu_threads}frame_threads", "null", a.cpu_threads, 1),
+                               ("hip_backend", "hip", 1, 1), (f"hip_backend_{a.cpu_threads}frame_threads", "hip", a.cpu_threads, 1)):
         if not ps.have(kind):
             continue
         dt, n = timed_decode(kind, aus, th, tt)
