@@ -447,6 +447,14 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
     hp.finish();
     std::lock_guard<std::mutex> g(s->reg->m);
     const int n = s->npics();
+    // a host plane belongs to one live picture: whoever else still lists one of these buffers is a dead picture whose
+    // buffers went back to the decoder's pool (the pools are per plane, so luma/chroma pairs do get re-mixed)
+    for (int i = 0; i < n; i++) {
+        if (s->pics[i].slot < 0 || s->pics[i].slot == slot) continue;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+                if (s->pics[i].data[a] && s->pics[i].data[a] == hp.data[b]) s->pics[i].slot = -1;
+    }
     for (int i = 0; i < n; i++) if (s->pics[i].slot == slot) { s->pics[i] = hp; return OHEVC_OK; }
     for (int i = 0; i < n; i++) if (s->pics[i].slot < 0) { s->pics[i] = hp; return OHEVC_OK; }
     OHEVC_REQUIRE(n < 128, "too many registered pictures");

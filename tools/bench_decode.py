@@ -73,7 +73,9 @@ def main():
     for name, kind, th, tt in (("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
                                ("front_end_only_no_pixels", "null", 1, 1),
                                (f"front_end_only_{a.cpu_threads}frame_threads", "null", a.cpu_threads, 1),
-                               ("hip_backend", "hip", 1, 1), (f"hip_backend_{a.cpu_threads}frame_threads", "hip", a.cpu_threads, 1)):
+                               ("hip_backend", "hip", 1, 1), (f"hip_backend_{a.cpu_threads}frame_threads", "hip", a.cpu_threads, 1),
+                               (f"reference_c_{2 * a.cpu_threads}frame_threads", "c", 2 * a.cpu_threads, 1),
+                               (f"hip_backend_{2 * a.cpu_threads}frame_threads", "hip", 2 * a.cpu_threads, 1)):
         if not ps.have(kind):
             continue
         dt, n = timed_decode(kind, aus, th, tt)

@@ -36,7 +36,7 @@ for kw in CASES:
     ref = ps.decode_stream("c", aus)
     t = time.time()
     try:
-        hip = ps.decode_stream("hip", aus)
+        hip = ps.decode_stream("hip", aus, int(os.environ.get("DIAG_THREADS", "1")), 1)
     except Exception as e:
         print("HIP FAIL", kw, e); bad += 1; continue
     dt = time.time() - t

@@ -61,7 +61,8 @@ def main():
             continue
         n += 1
         try:
-            hip = ps.decode_stream("hip", aus)
+            threads = int(rng.choice([1, 1, 3, 8]))          # frame threads: one context per thread, shared picture store
+            hip = ps.decode_stream("hip", aus, threads, 1)
             ok = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
             same_gen = all(np.array_equal(x, y) for fa, fb in zip(ref, gen_frames) for x, y in zip(fa, fb))
         except Exception as e:
@@ -69,7 +70,7 @@ def main():
             print("EXC", e)
         if not ok or not same_gen:
             bad += 1
-            print("FAIL" if not ok else "GEN-MISMATCH", json.dumps(kw))
+            print("FAIL" if not ok else "GEN-MISMATCH", "threads", threads, json.dumps(kw))
     print(json.dumps(dict(streams=n, failed=bad, rejected_by_generator=gen_fail, seconds=round(time.time() - t0, 1))))
     sys.exit(1 if bad else 0)
 
