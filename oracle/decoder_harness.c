@@ -37,6 +37,7 @@ typedef struct ohdec {
     uint8_t        *pkt_buf;
     int             pkt_cap;
     int             have_frame;
+    int             threads;
 } ohdec;
 
 /* thread_type: 1 frame threads, 2 slice/WPP threads, 3 both (the -f option of the reference's CLI, main_hm/getopt.c) */
@@ -62,7 +63,8 @@ ohdec *ohdec_open(int threads, int thread_type)
     d->avctx->flags |= CODEC_FLAG_UNALIGNED;
     d->avctx->err_recognition |= AV_EF_EXPLODE;     /* a syntax error fails the call instead of being concealed (hevc.c:3480) */
     av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type == 3 ? "frameslice" : "frame", 0);
-    av_opt_set_int(d->avctx, "threads", threads > 0 ? threads : 1, 0);
+    d->threads = threads > 0 ? threads : 1;
+    av_opt_set_int(d->avctx, "threads", d->threads, 0);
     if (ohdec_backend_open() < 0)
         goto fail;
     if (avcodec_open2(d->avctx, codec, NULL) < 0)
@@ -109,10 +111,14 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
     return got ? 1 : 0;
 }
 
-/* drain the reorder buffer: call until it returns 0 */
+/* drain the decoder: call until it returns 0.  With frame threads an empty packet collects one worker per call and a
+ * worker may have nothing to show (pthread_frame.c), so "nothing" only counts after every worker has been asked. */
 int ohdec_flush(ohdec *d)
 {
-    return ohdec_decode(d, NULL, 0, 0);
+    int i, r = 0;
+    for (i = 0; i <= d->threads && r == 0; i++)
+        r = ohdec_decode(d, NULL, 0, 0);
+    return r;
 }
 
 int ohdec_frame_info(ohdec *d, int *w, int *h, int *bit_depth, int *chroma_w_shift, int *chroma_h_shift)
