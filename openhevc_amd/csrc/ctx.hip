@@ -2,6 +2,8 @@
 // Host code only; the kernels it launches live in the *_kernels.hip files and are reached through the same
 // ohevc_dev_* entry points an external caller would use.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -78,6 +80,7 @@ struct LevelBins {
 }  // namespace
 
 static bool g_record_only = false;   // ohevc_debug_set_record_only
+static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 
 struct ohevc_ctx {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
@@ -332,6 +335,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
     c->cur = slot;
+    if (g_trace_order) fprintf(stderr, "order: ctx %p begins target %d\n", (void *)c, slot);
     {
         std::lock_guard<std::mutex> g(c->store->m);
         p->end_issued = false;
@@ -553,6 +557,7 @@ static int guard_pictures(ohevc_ctx *c, int target)
     std::unique_lock<std::mutex> lk(c->store->m);
     for (int r : fresh) {
         Picture &rp = c->store->pics[r];
+        if (g_trace_order) fprintf(stderr, "order: ctx %p target %d needs ref %d (issued %d, event %p)\n", (void *)c, target, r, (int)rp.end_issued, (void *)rp.written);
         if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return rp.end_issued; })) {
             set_error("reference picture %d was never completed by its decoding thread", r);
             return OHEVC_ERR_STATE;
@@ -730,6 +735,7 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
         // publish: this picture is reconstructed once `ev` fires; the references were read until then
         if (!c->target_guarded && (rc = guard_pictures(c, c->cur)) != OHEVC_OK) return rc;     // filter-only frames
         hipEvent_t ev = c->ring[c->ring_next];
+        if (g_trace_order) fprintf(stderr, "order: ctx %p ends target %d event %p\n", (void *)c, c->cur, (void *)ev);
         c->ring_next = (c->ring_next + 1) % 16;
         OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));
         std::lock_guard<std::mutex> g(c->store->m);

@@ -445,16 +445,23 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
     }
     OHEVC_REQUIRE(linesize[0] > 0 && linesize[1] > 0 && linesize[2] > 0, "host planes must have positive line sizes");
     hp.finish();
+    static const bool trace = getenv("OHEVC_TRACE_REG") != nullptr;
     std::lock_guard<std::mutex> g(s->reg->m);
     const int n = s->npics();
-    // a host plane belongs to one live picture: whoever else still lists one of these buffers is a dead picture whose
-    // buffers went back to the decoder's pool (the pools are per plane, so luma/chroma pairs do get re-mixed)
+    // host memory belongs to one live picture: whoever else still lists memory overlapping these planes is a dead picture
+    // whose buffers went back to the decoder's pool (the pools are per plane, so luma/chroma pairs get re-mixed, and the
+    // plane's start inside a recycled buffer may differ by an alignment offset: compare ranges, not base pointers)
     for (int i = 0; i < n; i++) {
         if (s->pics[i].slot < 0 || s->pics[i].slot == slot) continue;
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++)
-                if (s->pics[i].data[a] && s->pics[i].data[a] == hp.data[b]) s->pics[i].slot = -1;
+                if (s->pics[i].data[a] && hp.data[b] && s->pics[i].data[a] < hp.data[b] + hp.bytes[b] &&
+                    hp.data[b] < s->pics[i].data[a] + s->pics[i].bytes[a]) {
+                    if (trace) fprintf(stderr, "reg: slot %d takes plane %d of entry %d (slot %d, its plane %d)\n", slot, b, i, s->pics[i].slot, a);
+                    s->pics[i].slot = -1;
+                }
     }
+    if (trace) fprintf(stderr, "reg: slot %d = %p %p %p\n", slot, (void *)hp.data[0], (void *)hp.data[1], (void *)hp.data[2]);
     for (int i = 0; i < n; i++) if (s->pics[i].slot == slot) { s->pics[i] = hp; return OHEVC_OK; }
     for (int i = 0; i < n; i++) if (s->pics[i].slot < 0) { s->pics[i] = hp; return OHEVC_OK; }
     OHEVC_REQUIRE(n < 128, "too many registered pictures");

@@ -74,8 +74,10 @@ def test_frame_threads_share_the_picture_store(threads):
     contexts share one device picture store; cross-stream ordering is the library's job (ohevc_ctx_create_shared)."""
     if not (ps.have("gen") and ps.have("c")):
         pytest.skip("generator / reference decoder libraries not present")
-    kw = dict(gop="random_access", nframes=25, seed=401 + threads, width=416, height=240, log2_ctb=5, weighted_bipred=1)
-    aus, gen_frames = ps.generate(ps.StreamParams(**kw))
-    ref = ps.decode_stream("c", aus)
-    for _ in range(3):      # scheduling differs from run to run
-        _compare(ref, ps.decode_stream("hip", aus, threads, 1))
+    # long enough for the decoder's buffer pools to recycle (and re-mix) luma / chroma buffers several times
+    for kw in (dict(gop="random_access", nframes=41, seed=401 + threads, width=416, height=240, log2_ctb=5, weighted_bipred=1),
+               dict(gop="lowdelay_p", nframes=33, seed=411 + threads, width=832, height=480, log2_ctb=6)):
+        aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+        ref = ps.decode_stream("c", aus)
+        for _ in range(2):      # scheduling differs from run to run
+            _compare(ref, ps.decode_stream("hip", aus, threads, 1))
