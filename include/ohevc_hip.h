@@ -221,6 +221,25 @@ int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohev
 int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
                               const ohevc_intra_cip *cip, void *stream);
 
+/* ---- 2.6 a whole chain of intra dependency levels in ONE launch (the ctx layer's executor for intra content).  Work is a list
+ * of phases, each a run of `ohevc_level_phase_workgroups()` virtual workgroups:
+ *   type 0: intra prediction of `njobs` jobs starting at intra_jobs[first_job];
+ *   type 1: residuals of one (log2_size, kind) bin: `njobs` jobs starting at tu_jobs[first_job].
+ * Phases are listed in execution order with their running workgroup offset in first_wg; phases that may run side by
+ * side share a `step`, and every workgroup of step s waits inside the kernel until all workgroups of step s-1 are done
+ * (steps are consecutive from 0).  `sync` = DEVICE array of (number of steps + 1) zeroed uint32 (a ticket counter and
+ * one completion counter per step, consumed by the launch); `need[s]` = DEVICE array, workgroups in step s.  Jobs of one
+ * step must be independent, exactly as for the separate entry points; results are identical to launching the phases
+ * one after the other with ohevc_dev_intra_batch_cip / ohevc_dev_tu_batch. */
+typedef struct ohevc_level_phase {      /* 32 bytes */
+    int32_t first_wg, step, type, first_job, njobs, log2_size, kind, reserved;
+} ohevc_level_phase;
+int ohevc_level_phase_workgroups(int type, int log2_size, int kind, int njobs);
+int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_level_phase *phases, int nphases, int total_wgs,
+                     uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_intra_cip *cips,
+                     const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream);
+
+
 /* Host helper (no GPU work): turn one intra_pred[log2-2](s, x0, y0, c_idx) call of the reference into a job.
  * Inputs are exactly what the reference's front-end holds at the call site (hevc.c:1214-1215): the block position
  * in LUMA samples, HEVClc->na.cand_* (ff_hevc_set_neighbour_available, hevc_mvs.c:41-58), the prediction mode

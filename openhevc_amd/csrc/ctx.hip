@@ -80,7 +80,10 @@ struct LevelBins {
 }  // namespace
 
 static bool g_record_only = false;   // ohevc_debug_set_record_only
+static int g_level_launch = 1;        // ohevc_debug_set_level_launch: 1 = all intra levels in one launch, 0 = two launches per level
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
+static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct ohevc_ctx {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
@@ -101,6 +104,8 @@ struct ohevc_ctx {
 
     std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
     std::vector<LevelBins> levels;                         // [level]; entries 0..max_level are live
+    std::vector<ohevc_level_phase> phases;                // scratch of frame_reconstruct
+    std::vector<uint32_t> need, sync_zero;
     int max_level = -1;
     std::vector<int16_t> coeffs;
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
@@ -112,6 +117,8 @@ struct ohevc_ctx {
     DevBuf d_jobs, d_coeffs, d_table;
     PinnedBuf stage;
     ohevc_frame_stats stats = {}, last_stats = {};
+    double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
+    int n_frames = 0;
 };
 
 using namespace ohevc;
@@ -184,6 +191,9 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
 {
     if (!c) return;
     ohevc_tables_forget(c);
+    if (g_trace_timing && c->n_frames)
+        fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms\n", (void *)c,
+                c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames);
     if (c->dry) { delete c; return; }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -203,6 +213,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     delete c;
 }
 
+extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
 extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
 
 extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -554,6 +565,8 @@ static int guard_pictures(ohevc_ctx *c, int target)
                 }
         }
     if (fresh.empty() && c->target_guarded) return OHEVC_OK;
+    const double t0 = g_trace_timing ? now_s() : 0;
+    struct Acc { ohevc_ctx *c; double t0; ~Acc() { if (g_trace_timing) c->t_wait_refs += now_s() - t0; } } acc{c, t0};
     std::unique_lock<std::mutex> lk(c->store->m);
     for (int r : fresh) {
         Picture &rp = c->store->pics[r];
@@ -627,6 +640,48 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             if (first) { loff[l].tu_first = o; first = false; }
         }
     }
+    // levels >= 1 run as ONE launch (ohevc_dev_levels): phases in execution order, job offsets relative to the first
+    // staged intra / residual array of level 1 (arrays are 256-byte = 16-job aligned, so offsets are whole jobs)
+    std::vector<ohevc_level_phase> &phases = c->phases;
+    std::vector<uint32_t> &need = c->need;
+    phases.clear(); need.clear();
+    size_t intra_base = 0, tu_base = 0;
+    bool have_intra_base = false, have_tu_base = false;
+    int total_wgs = 0;
+    if (g_level_launch == 1) {
+        for (int l = 1; l <= c->max_level; l++) {
+            LevelBins &lb = c->levels[l];
+            if (!lb.intra.empty()) {
+                if (!have_intra_base) { intra_base = loff[l].intra; have_intra_base = true; }
+                ohevc_level_phase ph = {};
+                ph.first_wg = total_wgs; ph.step = (int32_t)need.size(); ph.type = 0;
+                ph.first_job = (int32_t)((loff[l].intra - intra_base) / sizeof(ohevc_intra_job)); ph.njobs = (int32_t)lb.intra.size();
+                const int w = ohevc_level_phase_workgroups(0, 0, 0, ph.njobs);
+                total_wgs += w; need.push_back((uint32_t)w); phases.push_back(ph);
+            }
+            if (lb.touched) {
+                if (!have_tu_base) { tu_base = loff[l].tu_first; have_tu_base = true; }
+                size_t o = loff[l].tu_first;
+                uint32_t wsum = 0;
+                for (uint64_t m = lb.touched; m; m &= m - 1) {
+                    const int b = __builtin_ctzll(m);
+                    const auto &v = lb.tu[b >> 4][b & 15];
+                    ohevc_level_phase ph = {};
+                    ph.first_wg = total_wgs; ph.step = (int32_t)need.size(); ph.type = 1;
+                    ph.first_job = (int32_t)((o - tu_base) / sizeof(ohevc_tu_job)); ph.njobs = (int32_t)v.size();
+                    ph.log2_size = (b >> 4) + 2; ph.kind = b & 15;
+                    const int w = ohevc_level_phase_workgroups(1, ph.log2_size, ph.kind, ph.njobs);
+                    total_wgs += w; wsum += (uint32_t)w; phases.push_back(ph);
+                    o += (v.size() * sizeof(ohevc_tu_job) + 255) & ~(size_t)255;
+                }
+                need.push_back(wsum);
+            }
+        }
+    }
+    c->sync_zero.assign(need.size() + 1, 0u);
+    const size_t off_phases = phases.empty() ? 0 : stage_put(parts, total, phases.data(), phases.size() * sizeof(ohevc_level_phase));
+    const size_t off_need = phases.empty() ? 0 : stage_put(parts, total, need.data(), need.size() * sizeof(uint32_t));
+    const size_t off_sync = phases.empty() ? 0 : stage_put(parts, total, c->sync_zero.data(), c->sync_zero.size() * sizeof(uint32_t));
     const size_t off_coeffs = c->coeffs.empty() ? 0 : stage_put(parts, total, c->coeffs.data(), c->coeffs.size() * sizeof(int16_t));
     const size_t off_cips = c->cips.empty() ? 0 : stage_put(parts, total, c->cips.data(), c->cips.size() * sizeof(ohevc_intra_cip));
     if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
@@ -648,7 +703,11 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     }
     // ---- phase 2..: level 0 = residuals of inter blocks; level L >= 1 = intra prediction of level L, then its residuals
     const int max_level = c->max_level;
-    for (int level = 0; level <= max_level; level++) {
+    const int last_separate = phases.empty() ? max_level : 0;      // level 0 (residuals of inter blocks) keeps its own wide launch
+    if (!phases.empty()) {
+        // (issued after level 0 below; prepared here to keep the offsets together)
+    }
+    for (int level = 0; level <= last_separate; level++) {
         LevelBins &lb = c->levels[level];
         if (!lb.intra.empty()) {
             rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
@@ -676,6 +735,15 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             c->stats.launches++;
         }
     }
+    if (!phases.empty()) {
+        rc = ohevc_dev_levels(p->planes, p->bd, reinterpret_cast<const ohevc_level_phase *>(base + off_phases), (int)phases.size(), total_wgs,
+                              reinterpret_cast<uint32_t *>(base + off_sync), reinterpret_cast<const uint32_t *>(base + off_need),
+                              reinterpret_cast<const ohevc_intra_job *>(base + intra_base),
+                              c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips),
+                              reinterpret_cast<const ohevc_tu_job *>(base + tu_base), d_coeffs, c->stream);
+        if (rc != OHEVC_OK) return rc;
+        c->stats.launches++;
+    }
     c->stats.intra_levels = std::max(c->stats.intra_levels, std::max(max_level, 0));
     clear_recorded(c);
     return OHEVC_OK;
@@ -685,6 +753,8 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    const double t_begin = g_trace_timing ? now_s() : 0;
+    struct Acc { ohevc_ctx *c; double t0; ~Acc() { if (g_trace_timing) { c->t_issue += now_s() - t0; c->n_frames++; } } } acc{c, t_begin};
     int rc = ohevc_frame_reconstruct(c);
     if (rc != OHEVC_OK) return rc;
     if (c->dry) { c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; }

@@ -17,6 +17,7 @@
 //     the butterfly; the final clip_pixel is a saturating packed add + packed max/min.
 // No floating point, no MFMA (int16 x int8 butterflies; the kernel is HBM-bound).
 #include "common.hpp"
+#include "intra_body.hpp"
 
 namespace ohevc {
 
@@ -665,6 +666,75 @@ __global__ __launch_bounds__(256) void tu_multi_kernel(PlaneSet planes, TuSegTab
     else                                         tu_rows_body<5, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
 }
 
+// ------------------------------------------------------------------ intra dependency levels in ONE launch
+// Intra pictures chain ~150 dependency levels per 1080p picture (prediction of level L reads what level L-1
+// reconstructed), each only tens of blocks wide.  Launched level by level that is ~300 kernel boundaries per picture,
+// and kernel boundaries (command-processor dispatch + cache maintenance) are a GPU-wide serial resource: pictures of
+// different decoding threads cannot overlap.  Here the whole chain runs inside one kernel:
+//   * the work is a list of PHASES (intra jobs of a level, or one (size, kind) residual bin of a level), each a run of
+//     virtual workgroups; phases are grouped into STEPS (step 2L = prediction of level L, step 2L+1 = its residuals);
+//   * persistent workgroups draw virtual workgroup numbers from a ticket counter, so numbers are handed out in order
+//     and a holder of number i only ever waits for numbers < i, which are held by workgroups that are already running:
+//     forward progress needs no assumption about residency or dispatch order;
+//   * before running a virtual workgroup of step s, the workgroup waits until all of step s-1 has signalled
+//     (device-scope counter; release = __threadfence + atomic add after the stores, acquire = spin + __threadfence,
+//     which also takes care of the per-XCD L2s).
+struct LevelPhase {                  // mirrors ohevc_level_phase (include/ohevc_hip.h)
+    int first_wg, step, type, first_job, njobs, log2_size, kind, reserved;
+};
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const LevelPhase *__restrict__ phases, int nphases, int total_wgs,
+                                                     unsigned *sync, const unsigned *__restrict__ need,
+                                                     const ohevc_intra_job *__restrict__ intra_jobs, const ohevc_intra_cip *__restrict__ cips,
+                                                     const ohevc_tu_job *__restrict__ tu_jobs, const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<5>::WAVE_BYTES];
+    __shared__ IntraShared ish[4];
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (;;) {
+        if (tid == 0) s_ticket = (int)atomicAdd(&sync[0], 1u);
+        __syncthreads();
+        const int vwg = s_ticket;
+        if (vwg >= total_wgs) return;
+        int lo = 0, hi = nphases - 1;                          // last phase with first_wg <= vwg (workgroup-uniform)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (phases[mid].first_wg <= vwg) lo = mid; else hi = mid - 1;
+        }
+        const LevelPhase ph = phases[lo];
+        if (ph.step > 0) {
+            if (tid == 0) {
+                const unsigned want = need[ph.step - 1];
+                while (__hip_atomic_load(&sync[ph.step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            __threadfence();                                   // acquire: drop stale lines before reading neighbours
+        }
+        const int local = vwg - ph.first_wg;
+        if (ph.type == 0) {                                    // intra prediction: one wavefront per block, four per workgroup
+            const int ji = local * 4 + wave;
+            if (ji < ph.njobs) intra_body<Pixel, true>(ish[wave], lane, planes, intra_jobs[ph.first_job + ji], bit_depth, cips);
+        } else {
+            const ohevc_tu_job *j = tu_jobs + ph.first_job;
+            const int log2 = ph.log2_size, kind = ph.kind, n = ph.njobs;
+            if (kind == OHEVC_TU_IDCT && log2 == 5)      tu_idct_add_body<5, Pixel, 16 + 128>(lds, local, planes, j, n, coeffs, bit_depth);
+            else if (kind == OHEVC_TU_IDCT && log2 == 4) tu_idct_add_body<4, Pixel, 16 + 128>(lds, local, planes, j, n, coeffs, bit_depth);
+            else if (kind == OHEVC_TU_IDCT && log2 == 3) tu_idct_add_body<3, Pixel, 1>(lds, local, planes, j, n, coeffs, bit_depth);
+            else if (kind == OHEVC_TU_IDCT)              tu_4x4_body<Pixel, false>(local, planes, j, n, coeffs, bit_depth);
+            else if (kind == OHEVC_TU_DST4)              tu_4x4_body<Pixel, true>(local, planes, j, n, coeffs, bit_depth);
+            else if (log2 == 2)                          tu_rows_body<2, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
+            else if (log2 == 3)                          tu_rows_body<3, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
+            else if (log2 == 4)                          tu_rows_body<4, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
+            else                                         tu_rows_body<5, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
+        }
+        __threadfence();                                       // release: this workgroup's samples are visible device-wide ...
+        __syncthreads();
+        if (tid == 0) atomicAdd(&sync[ph.step + 1], 1u);       // ... before the step counter says so
+    }
+}
+
 // ------------------------------------------------------------------ launcher
 int g_tu_variant = -1;    // set through ohevc_debug_set_tu_variant(); -1 = shipped configuration (see launch_idct)
 int g_tu_pipe_wgs = 2048; // workgroups of the persistent form (ohevc_debug_set_tu_pipe_workgroups)
@@ -796,6 +866,38 @@ extern "C" int ohevc_dev_tu_multi(const ohevc_plane planes[3], int bit_depth, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bit_depth == 8) hipLaunchKernelGGL((tu_multi_kernel<uint8_t>), dim3(wgs), dim3(256), 0, st, ps, tab, jobs, coeffs, bit_depth);
     else                hipLaunchKernelGGL((tu_multi_kernel<uint16_t>), dim3(wgs), dim3(256), 0, st, ps, tab, jobs, coeffs, bit_depth);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_level_phase_workgroups(int type, int log2_size, int kind, int njobs)
+{
+    if (njobs <= 0) return 0;
+    return type == 0 ? (njobs + 3) / 4 : tu_workgroups(log2_size, kind, njobs);
+}
+
+extern "C" int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_level_phase *phases, int nphases, int total_wgs,
+                                uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_intra_cip *cips,
+                                const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream)
+{
+    using namespace ohevc;
+    static_assert(sizeof(LevelPhase) == sizeof(ohevc_level_phase), "phase record layout");
+    OHEVC_REQUIRE(planes != nullptr, "planes");
+    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(nphases >= 0 && total_wgs >= 0, "negative count");
+    if (nphases == 0 || total_wgs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(phases != nullptr && sync != nullptr && need != nullptr, "null argument");
+    OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(intra_jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(tu_jobs) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0 && (reinterpret_cast<uintptr_t>(cips) & 15) == 0, "job arrays must be 16-byte aligned");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
+    if (rc != OHEVC_OK) return rc;
+    // enough persistent workgroups for the widest steps of a picture, few enough that pictures of other streams fit beside
+    const int grid = total_wgs < 160 ? total_wgs : 160;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LevelPhase *ph = reinterpret_cast<const LevelPhase *>(phases);
+    if (bit_depth == 8) hipLaunchKernelGGL((levels_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
+    else                hipLaunchKernelGGL((levels_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

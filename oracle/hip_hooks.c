@@ -29,7 +29,7 @@
 static ohevc_ctx          *g_root;
 static __thread ohevc_ctx *t_ctx;
 static __thread int        t_frame_open;
-static ohevc_ctx          *g_all[64];
+static ohevc_ctx          *g_all[128];
 static int                 g_nall;
 static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
 static volatile int        g_error;
@@ -38,7 +38,7 @@ static long long           g_counts[8];        /* frames, launches, tu, mc, intr
 
 /* host buffer -> picture-store slot.  Keyed by the luma plane address: libavcodec's buffer pool hands a buffer out
  * again only once no frame references it, so a known address means "the picture that lived there is dead". */
-#define MAX_BUFS 64
+#define MAX_BUFS 120
 static struct {
     const uint8_t *data0;
     int slot, w, h, bd, fmt;
@@ -57,7 +57,7 @@ static ohevc_ctx *thread_ctx(void)
         return NULL;
     }
     pthread_mutex_lock(&g_lock);
-    if (g_nall < 64)
+    if (g_nall < 128)
         g_all[g_nall++] = t_ctx;
     pthread_mutex_unlock(&g_lock);
     return t_ctx;
