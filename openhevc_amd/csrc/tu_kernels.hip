@@ -692,9 +692,16 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<5>::WAVE_BYTES];
     __shared__ IntraShared ish[4];
     __shared__ int s_ticket;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // in an SGPR: the compiler must SEE that it is uniform
+    // Every branch around the barriers below is WAVE-uniform on purpose: a lane-divergent `if (tid == 0)` inside this loop
+    // lets the compiler park lane 0 while the rest of its wavefront runs ahead to the barrier (observed: the ticket was
+    // never refreshed).  Single-lane effects are expressed through the operand instead (add 1 in lane 0, 0 elsewhere).
     for (;;) {
-        if (tid == 0) s_ticket = (int)atomicAdd(&sync[0], 1u);
+        if (wave == 0) {
+            const unsigned got = atomicAdd(&sync[0], lane == 0 ? 1u : 0u);
+            s_ticket = __builtin_amdgcn_readfirstlane((int)got);          // lane 0's return value = the ticket
+        }
         __syncthreads();
         const int vwg = s_ticket;
         if (vwg >= total_wgs) return;
@@ -704,12 +711,10 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
             if (phases[mid].first_wg <= vwg) lo = mid; else hi = mid - 1;
         }
         const LevelPhase ph = phases[lo];
-        if (ph.step > 0) {
-            if (tid == 0) {
-                const unsigned want = need[ph.step - 1];
-                while (__hip_atomic_load(&sync[ph.step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
-            }
-            __syncthreads();
+        if (ph.step > 0) {                                     // every wavefront polls for itself (same address: one request)
+            const unsigned want = need[ph.step - 1];
+            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[ph.step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (int)want)
+                __builtin_amdgcn_s_sleep(2);
             __threadfence();                                   // acquire: drop stale lines before reading neighbours
         }
         const int local = vwg - ph.first_wg;
@@ -730,8 +735,8 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
             else                                         tu_rows_body<5, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
         }
         __threadfence();                                       // release: this workgroup's samples are visible device-wide ...
-        __syncthreads();
-        if (tid == 0) atomicAdd(&sync[ph.step + 1], 1u);       // ... before the step counter says so
+        __syncthreads();                                       // (also: everyone has read s_ticket before wave 0 rewrites it)
+        if (wave == 0) atomicAdd(&sync[ph.step + 1], lane == 0 ? 1u : 0u);   // ... before the step counter says so
     }
 }
 
