@@ -227,8 +227,8 @@ int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_depth, const 
  *   type 1: residuals of one (log2_size, kind) bin: `njobs` jobs starting at tu_jobs[first_job].
  * Phases are listed in execution order with their running workgroup offset in first_wg; phases that may run side by
  * side share a `step`, and every workgroup of step s waits inside the kernel until all workgroups of step s-1 are done
- * (steps are consecutive from 0).  `sync` = DEVICE array of (number of steps + 1) zeroed uint32 (a ticket counter and
- * one completion counter per step, consumed by the launch); `need[s]` = DEVICE array, workgroups in step s.  Jobs of one
+ * (steps are consecutive from 0).  `sync` = DEVICE array of (number of steps + 2) zeroed uint32 (home XCD, ticket
+ * counter, one completion counter per step; consumed by the launch); `need[s]` = DEVICE array, workgroups in step s.  Jobs of one
  * step must be independent, exactly as for the separate entry points; results are identical to launching the phases
  * one after the other with ohevc_dev_intra_batch_cip / ohevc_dev_tu_batch. */
 typedef struct ohevc_level_phase {      /* 32 bytes */

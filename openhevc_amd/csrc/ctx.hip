@@ -678,7 +678,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             }
         }
     }
-    c->sync_zero.assign(need.size() + 1, 0u);
+    c->sync_zero.assign(need.size() + 2, 0u);
     const size_t off_phases = phases.empty() ? 0 : stage_put(parts, total, phases.data(), phases.size() * sizeof(ohevc_level_phase));
     const size_t off_need = phases.empty() ? 0 : stage_put(parts, total, need.data(), need.size() * sizeof(uint32_t));
     const size_t off_sync = phases.empty() ? 0 : stage_put(parts, total, c->sync_zero.data(), c->sync_zero.size() * sizeof(uint32_t));

@@ -16,6 +16,7 @@
 //   * both clip_int16 stages are v_cvt_pk_i16_i32 (saturating pack); rounding constants ride in the DC lane of
 //     the butterfly; the final clip_pixel is a saturating packed add + packed max/min.
 // No floating point, no MFMA (int16 x int8 butterflies; the kernel is HBM-bound).
+#include <atomic>
 #include "common.hpp"
 #include "intra_body.hpp"
 
@@ -669,23 +670,28 @@ __global__ __launch_bounds__(256) void tu_multi_kernel(PlaneSet planes, TuSegTab
 // ------------------------------------------------------------------ intra dependency levels in ONE launch
 // Intra pictures chain ~150 dependency levels per 1080p picture (prediction of level L reads what level L-1
 // reconstructed), each only tens of blocks wide.  Launched level by level that is ~300 kernel boundaries per picture,
-// and kernel boundaries (command-processor dispatch + cache maintenance) are a GPU-wide serial resource: pictures of
-// different decoding threads cannot overlap.  Here the whole chain runs inside one kernel:
+// and kernel boundaries (command-processor dispatch + device-wide cache maintenance) are a GPU-wide serial resource:
+// pictures of different decoding threads cannot overlap.  Here the whole chain runs inside one kernel:
 //   * the work is a list of PHASES (intra jobs of a level, or one (size, kind) residual bin of a level), each a run of
 //     virtual workgroups; phases are grouped into STEPS (step 2L = prediction of level L, step 2L+1 = its residuals);
 //   * persistent workgroups draw virtual workgroup numbers from a ticket counter, so numbers are handed out in order
 //     and a holder of number i only ever waits for numbers < i, which are held by workgroups that are already running:
 //     forward progress needs no assumption about residency or dispatch order;
-//   * before running a virtual workgroup of step s, the workgroup waits until all of step s-1 has signalled
-//     (device-scope counter; release = __threadfence + atomic add after the stores, acquire = spin + __threadfence,
-//     which also takes care of the per-XCD L2s).
+//   * before running a virtual workgroup of step s, a workgroup waits until all of step s-1 has signalled;
+//   * ONE XCD does the whole chain: the workgroup with blockIdx == leader publishes its XCC_ID, workgroups on other
+//     XCDs leave at once.  All participants then share one L2, so handing samples from step to step needs no L2
+//     write-back / invalidate (which costs microseconds per workgroup per step when done device-wide, measured):
+//     stores are complete in L2 after s_waitcnt vmcnt(0) (the vector L1 is write-through), readers only drop their
+//     L1 (buffer_inv).  The kernel boundary publishes the result to the other XCDs as usual.  Chains of different
+//     pictures (decoding threads) pick different leaders and so run on different XCDs side by side.
 struct LevelPhase {                  // mirrors ohevc_level_phase (include/ohevc_hip.h)
     int first_wg, step, type, first_job, njobs, log2_size, kind, reserved;
 };
+enum { LV_HOME = 0, LV_TICKET = 1, LV_DONE = 2 };       // layout of the sync words
 
 template <typename Pixel>
 __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const LevelPhase *__restrict__ phases, int nphases, int total_wgs,
-                                                     unsigned *sync, const unsigned *__restrict__ need,
+                                                     unsigned *sync, const unsigned *__restrict__ need, int leader,
                                                      const ohevc_intra_job *__restrict__ intra_jobs, const ohevc_intra_cip *__restrict__ cips,
                                                      const ohevc_tu_job *__restrict__ tu_jobs, const int16_t *__restrict__ coeffs, int bit_depth)
 {
@@ -697,9 +703,18 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
     // Every branch around the barriers below is WAVE-uniform on purpose: a lane-divergent `if (tid == 0)` inside this loop
     // lets the compiler park lane 0 while the rest of its wavefront runs ahead to the barrier (observed: the ticket was
     // never refreshed).  Single-lane effects are expressed through the operand instead (add 1 in lane 0, 0 elsewhere).
+    const unsigned my_home = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;       // HW_REG_XCC_ID + 1
+    if ((int)blockIdx.x == leader) {
+        if (wave == 0) atomicMax(&sync[LV_HOME], my_home);                                   // was 0
+    } else {
+        unsigned home;
+        while ((home = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[LV_HOME], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) == 0u)
+            __builtin_amdgcn_s_sleep(1);
+        if (home != my_home) return;
+    }
     for (;;) {
         if (wave == 0) {
-            const unsigned got = atomicAdd(&sync[0], lane == 0 ? 1u : 0u);
+            const unsigned got = atomicAdd(&sync[LV_TICKET], lane == 0 ? 1u : 0u);
             s_ticket = __builtin_amdgcn_readfirstlane((int)got);          // lane 0's return value = the ticket
         }
         __syncthreads();
@@ -713,9 +728,9 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
         const LevelPhase ph = phases[lo];
         if (ph.step > 0) {                                     // every wavefront polls for itself (same address: one request)
             const unsigned want = need[ph.step - 1];
-            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[ph.step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (int)want)
-                __builtin_amdgcn_s_sleep(2);
-            __threadfence();                                   // acquire: drop stale lines before reading neighbours
+            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[LV_DONE + ph.step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (int)want)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("buffer_inv sc1" ::: "memory");       // acquire inside the XCD: forget what this CU's L1 holds
         }
         const int local = vwg - ph.first_wg;
         if (ph.type == 0) {                                    // intra prediction: one wavefront per block, four per workgroup
@@ -734,9 +749,9 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
             else if (log2 == 4)                          tu_rows_body<4, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
             else                                         tu_rows_body<5, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
         }
-        __threadfence();                                       // release: this workgroup's samples are visible device-wide ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // release inside the XCD: this wavefront's stores sit in the shared L2 ...
         __syncthreads();                                       // (also: everyone has read s_ticket before wave 0 rewrites it)
-        if (wave == 0) atomicAdd(&sync[ph.step + 1], lane == 0 ? 1u : 0u);   // ... before the step counter says so
+        if (wave == 0) atomicAdd(&sync[LV_DONE + ph.step], lane == 0 ? 1u : 0u);   // ... before the step counter says so
     }
 }
 
@@ -897,12 +912,14 @@ extern "C" int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, cons
     PlaneSet ps;
     int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
-    // enough persistent workgroups for the widest steps of a picture, few enough that pictures of other streams fit beside
-    const int grid = total_wgs < 160 ? total_wgs : 160;
+    // 24 workgroups per XCD are dispatched (8 XCDs, round-robin by workgroup number); the ones on the leader's XCD stay.
+    // Successive launches name different leaders, so the chains of pictures in flight spread over the XCDs.
+    static std::atomic<unsigned> rotation{0};
+    const int grid = 192, leader = (int)(rotation.fetch_add(1) % 8u);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LevelPhase *ph = reinterpret_cast<const LevelPhase *>(phases);
-    if (bit_depth == 8) hipLaunchKernelGGL((levels_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
-    else                hipLaunchKernelGGL((levels_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
+    if (bit_depth == 8) hipLaunchKernelGGL((levels_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, leader, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
+    else                hipLaunchKernelGGL((levels_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, leader, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

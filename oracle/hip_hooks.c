@@ -167,7 +167,9 @@ int ohdec_backend_open(void)
 {
     if (g_root)
         return 0;
-    ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);   /* host-side profiling, no pixels (ohevc_debug.h) */
+    ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);
+    if (getenv("OHHIP_LEVEL_LAUNCH"))
+        ohevc_debug_set_level_launch(atoi(getenv("OHHIP_LEVEL_LAUNCH")));          /* A/B of the two executors */   /* host-side profiling, no pixels (ohevc_debug.h) */
     if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
         return -1;
@@ -215,9 +217,20 @@ int ohdec_backend_frame_done(void)
  * call sites in hevc.c are renamed to this wrapper; the per-row reports of hevc_filter.c are untouched. */
 void ohhip_report_progress(ThreadFrame *f, int progress, int field)
 {
+    /* what other threads wait for on the CPU (motion fields, DPB state) is complete now; the samples are ordered on the
+     * device by the library (ohevc_ctx_create_shared), so the report need not wait for the GPU */
+    ff_thread_report_progress(f, progress, field);
     if (progress == INT_MAX)
         ohdec_backend_frame_done();
-    ff_thread_report_progress(f, progress, field);
+}
+
+/* hevc_await_progress() (hevc.c:1951-1958) makes a frame thread wait until the rows its motion vectors point at have
+ * been RECONSTRUCTED by the thread decoding the reference picture.  With the GPU back-end no sample is read on the CPU
+ * and the device-side ordering is per picture, so this wait is only lost time: the call sites in hevc.c are renamed to
+ * this no-op.  (The waits for collocated motion vectors in hevc_mvs.c are untouched.) */
+void ohhip_await_progress(ThreadFrame *f, int progress, int field)
+{
+    (void)f; (void)progress; (void)field;
 }
 
 /* cumulative since the last call: seconds inside the frame-end hook and job / launch / upload counters */
