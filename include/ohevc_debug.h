@@ -18,8 +18,11 @@ int ohevc_debug_set_tu_pipe_workgroups(int n);
 /* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = 2 + both reference
  * windows staged before the first barrier (shipped) */
 int ohevc_debug_set_mc_variant(int variant);
-/* ctx executor: 1 (shipped) runs all intra dependency levels of a picture in one ohevc_dev_levels launch; 0 issues one
- * prediction launch and one residual launch per level (the first implementation; same results).  Returns the old mode. */
+/* ctx executor for intra dependency levels: 0 (shipped) issues one prediction launch and one residual launch per level;
+ * 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel
+ * step barriers).  Same results.  Measured on MI355X with the real decoder (1080p, profiles/r01n_level_executor_ab.txt):
+ * a step costs about as much as a kernel boundary (both are a chain of L2 round trips), so mode 1 only saves host-side
+ * launch work and is currently the slower one.  Returns the old mode. */
 int ohevc_debug_set_level_launch(int mode);
 /* Profiling aid for the HOST side only: contexts created while this is on need no device and produce NO pixels -- every
  * ohevc_rec_* call does its normal work, the frame-end executor just drops the recorded jobs.  It exists to time the

@@ -80,7 +80,7 @@ struct LevelBins {
 }  // namespace
 
 static bool g_record_only = false;   // ohevc_debug_set_record_only
-static int g_level_launch = 1;        // ohevc_debug_set_level_launch: 1 = all intra levels in one launch, 0 = two launches per level
+static int g_level_launch = 0;        // ohevc_debug_set_level_launch: 0 = two launches per level (shipped), 1 = all intra levels in one launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
