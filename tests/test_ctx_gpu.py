@@ -17,8 +17,19 @@ import synth_stream as S  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=["launch_per_level", "levels_kernel"])
+def level_executor(request):
+    """Both executors of the intra dependency levels (include/ohevc_debug.h) must give the same pictures."""
+    import ctypes
+    lib = L.load_library()
+    lib.ohevc_debug_set_level_launch.argtypes = [ctypes.c_int]
+    prev = lib.ohevc_debug_set_level_launch(request.param)
+    yield request.param
+    lib.ohevc_debug_set_level_launch(prev)
+
+
 @pytest.mark.parametrize("bd,W,H,intra_frac", [(8, 416, 240, 0.15), (10, 192, 136, 0.5), (8, 128, 128, 1.0)])
-def test_synthetic_picture_matches_decode_order_oracle(oracle, bd, W, H, intra_frac):
+def test_synthetic_picture_matches_decode_order_oracle(oracle, level_executor, bd, W, H, intra_frac):
     rng = np.random.default_rng(bd * 1000 + W)
     dt = G.pixdt(bd)
     dims = X.chroma_dims(W, H)
