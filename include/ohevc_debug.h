@@ -22,8 +22,7 @@ int ohevc_debug_set_mc_variant(int variant);
  * 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel
  * step barriers).  Same results.  Measured on MI355X with the real decoder (1080p, profiles/r01n_level_executor_ab.txt):
  * a step costs about as much as a kernel boundary (both are a chain of L2 round trips), so mode 1 only saves host-side
- * launch work and is currently the slower one.  Bit 1 (value 2) additionally turns OFF the fusion of a block's residual
- * into its prediction wavefront (ohevc_dev_intra_recon_batch), i.e. 2 = the very first executor.  Returns the old mode. */
+ * launch work and is currently the slower one.  Returns the old mode. */
 int ohevc_debug_set_level_launch(int mode);
 /* Profiling aid for the HOST side only: contexts created while this is on need no device and produce NO pixels -- every
  * ohevc_rec_* call does its normal work, the frame-end executor just drops the recorded jobs.  It exists to time the

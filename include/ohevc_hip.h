@@ -221,19 +221,9 @@ int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohev
 int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
                               const ohevc_intra_cip *cip, void *stream);
 
-/* Prediction and residual of a block by the same wavefront: jobs[i] is predicted exactly as by ohevc_dev_intra_batch_cip
- * and, when residuals[i].reserved0 != 0, the residual residuals[i] of kind (reserved0 - 1) and size jobs[i].log2_size is
- * added exactly as by ohevc_dev_tu_batch (residuals may be NULL: prediction only).  This is what one level of intra
- * dependencies costs in the ctx executor: one launch instead of a prediction launch plus a residual launch.  Jobs of a
- * batch must be independent of each other, as for the separate entry points. */
-int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs,
-                                const ohevc_tu_job *residuals, int njobs, const ohevc_intra_cip *cip,
-                                const int16_t *coeffs, void *stream);
-
 /* ---- 2.6 a whole chain of intra dependency levels in ONE launch (the ctx layer's executor for intra content).  Work is a list
  * of phases, each a run of `ohevc_level_phase_workgroups()` virtual workgroups:
- *   type 0: intra prediction of `njobs` jobs starting at intra_jobs[first_job], each followed by its own residual
- *           intra_residuals[res_first_job + i] as in ohevc_dev_intra_recon_batch (intra_residuals may be NULL);
+ *   type 0: intra prediction of `njobs` jobs starting at intra_jobs[first_job];
  *   type 1: residuals of one (log2_size, kind) bin: `njobs` jobs starting at tu_jobs[first_job].
  * Phases are listed in execution order with their running workgroup offset in first_wg; phases that may run side by
  * side share a `step`, and every workgroup of step s waits inside the kernel until all workgroups of step s-1 are done
@@ -242,13 +232,12 @@ int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, cons
  * step must be independent, exactly as for the separate entry points; results are identical to launching the phases
  * one after the other with ohevc_dev_intra_batch_cip / ohevc_dev_tu_batch. */
 typedef struct ohevc_level_phase {      /* 32 bytes */
-    int32_t first_wg, step, type, first_job, njobs, log2_size, kind;
-    int32_t res_first_job;              /* type 0: index into intra_residuals of the first job's residual record */
+    int32_t first_wg, step, type, first_job, njobs, log2_size, kind, reserved;
 } ohevc_level_phase;
 int ohevc_level_phase_workgroups(int type, int log2_size, int kind, int njobs);
 int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_level_phase *phases, int nphases, int total_wgs,
-                     uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_tu_job *intra_residuals,
-                     const ohevc_intra_cip *cips, const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream);
+                     uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_intra_cip *cips,
+                     const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream);
 
 
 /* Host helper (no GPU work): turn one intra_pred[log2-2](s, x0, y0, c_idx) call of the reference into a job.

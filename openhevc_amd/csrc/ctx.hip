@@ -74,14 +74,12 @@ struct PinnedBuf {                    // grow-only pinned host staging buffer
 struct LevelBins {
     std::vector<ohevc_tu_job> tu[4][OHEVC_TU_NKINDS];
     std::vector<ohevc_intra_job> intra;
-    std::vector<ohevc_tu_job> intra_res;   // parallel to intra: the block's own residual (reserved0 = kind + 1) or zeros
     uint64_t touched = 0;             // bit (log2 - 2) * 16 + kind
 };
 
 }  // namespace
 
 static bool g_record_only = false;   // ohevc_debug_set_record_only
-static int g_fuse_intra = 1;          // ohevc_debug_set_level_launch bit 1 clear: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 0;        // ohevc_debug_set_level_launch: 0 = two launches per level (shipped), 1 = all intra levels in one launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
@@ -109,7 +107,6 @@ struct ohevc_ctx {
     std::vector<ohevc_level_phase> phases;                // scratch of frame_reconstruct
     std::vector<uint32_t> need, sync_zero;
     int max_level = -1;
-    struct { int level = -1, index = 0, plane = 0, x = 0, y = 0, log2 = 0; } last_intra;   // most recent ohevc_rec_intra
     std::vector<int16_t> coeffs;
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
@@ -216,13 +213,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     delete c;
 }
 
-extern "C" int ohevc_debug_set_level_launch(int mode)
-{
-    const int prev = g_level_launch | (g_fuse_intra ? 0 : 2);
-    g_level_launch = mode & 1;
-    g_fuse_intra = !(mode & 2);
-    return prev;
-}
+extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
 extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
 
 extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -345,10 +336,8 @@ static void clear_recorded(ohevc_ctx *c)
         for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
         lb.touched = 0;
         lb.intra.clear();
-        lb.intra_res.clear();
     }
     c->max_level = -1;
-    c->last_intra.level = -1;
     for (int i = 0; i < 3; i++) std::fill(c->level_map[i].begin(), c->level_map[i].end(), 0);
 }
 
@@ -399,15 +388,6 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
         c->coeffs.insert(c->coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
-    // the residual of the block that was just predicted (hls_transform_unit order) rides with its prediction job
-    auto &li = c->last_intra;
-    if (g_fuse_intra && intra && li.level == level && level > 0 && li.plane == plane && li.x == x && li.y == y && li.log2 == log2) {
-        j.reserved0 = (uint8_t)(kind + 1);
-        c->levels[level].intra_res[li.index] = j;
-        li.level = -1;
-        c->stats.n_tu++;
-        return OHEVC_OK;
-    }
     LevelBins &lb = level_bins(c, level);
     lb.tu[log2 - 2][kind].push_back(j);
     lb.touched |= 1ull << ((log2 - 2) * 16 + kind);
@@ -478,11 +458,7 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(level < 65535, "intra dependency chain too long");
     for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
         for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) lm[(size_t)cy * W + cx] = (uint16_t)level;
-    LevelBins &lbi = level_bins(c, level);
-    lbi.intra.push_back(*job);
-    lbi.intra_res.push_back(ohevc_tu_job{});
-    c->last_intra.level = level; c->last_intra.index = (int)lbi.intra.size() - 1;
-    c->last_intra.plane = pl; c->last_intra.x = job->x; c->last_intra.y = job->y; c->last_intra.log2 = job->log2_size;
+    level_bins(c, level).intra.push_back(*job);
     c->stats.n_intra++;
     return OHEVC_OK;
 }
@@ -651,14 +627,11 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_mc = c->mc.empty() ? 0 : stage_put(parts, total, c->mc.data(), c->mc.size() * sizeof(ohevc_mc_job));
     const size_t off_mcs = c->mc_small.empty() ? 0 : stage_put(parts, total, c->mc_small.data(), c->mc_small.size() * sizeof(ohevc_mc_job));
     // per level: the intra jobs, then every touched (size, kind) bin back to back (one segmented launch per level)
-    struct LevelOff { size_t intra = 0, intra_res = 0, tu_first = 0; };
+    struct LevelOff { size_t intra = 0, tu_first = 0; };
     std::vector<LevelOff> loff((size_t)(c->max_level + 1));
     for (int l = 0; l <= c->max_level; l++) {
         LevelBins &lb = c->levels[l];
-        if (!lb.intra.empty()) {
-            loff[l].intra = stage_put(parts, total, lb.intra.data(), lb.intra.size() * sizeof(ohevc_intra_job));
-            loff[l].intra_res = stage_put(parts, total, lb.intra_res.data(), lb.intra_res.size() * sizeof(ohevc_tu_job));
-        }
+        if (!lb.intra.empty()) loff[l].intra = stage_put(parts, total, lb.intra.data(), lb.intra.size() * sizeof(ohevc_intra_job));
         bool first = true;
         for (uint64_t m = lb.touched; m; m &= m - 1) {
             const int b = __builtin_ctzll(m);
@@ -672,18 +645,17 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     std::vector<ohevc_level_phase> &phases = c->phases;
     std::vector<uint32_t> &need = c->need;
     phases.clear(); need.clear();
-    size_t intra_base = 0, res_base = 0, tu_base = 0;
+    size_t intra_base = 0, tu_base = 0;
     bool have_intra_base = false, have_tu_base = false;
     int total_wgs = 0;
     if (g_level_launch == 1) {
         for (int l = 1; l <= c->max_level; l++) {
             LevelBins &lb = c->levels[l];
             if (!lb.intra.empty()) {
-                if (!have_intra_base) { intra_base = loff[l].intra; res_base = loff[l].intra_res; have_intra_base = true; }
+                if (!have_intra_base) { intra_base = loff[l].intra; have_intra_base = true; }
                 ohevc_level_phase ph = {};
                 ph.first_wg = total_wgs; ph.step = (int32_t)need.size(); ph.type = 0;
                 ph.first_job = (int32_t)((loff[l].intra - intra_base) / sizeof(ohevc_intra_job)); ph.njobs = (int32_t)lb.intra.size();
-                ph.res_first_job = (int32_t)((loff[l].intra_res - res_base) / sizeof(ohevc_tu_job));
                 const int w = ohevc_level_phase_workgroups(0, 0, 0, ph.njobs);
                 total_wgs += w; need.push_back((uint32_t)w); phases.push_back(ph);
             }
@@ -738,10 +710,9 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     for (int level = 0; level <= last_separate; level++) {
         LevelBins &lb = c->levels[level];
         if (!lb.intra.empty()) {
-            rc = ohevc_dev_intra_recon_batch(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
-                                             reinterpret_cast<const ohevc_tu_job *>(base + loff[level].intra_res), (int)lb.intra.size(),
-                                             c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips),
-                                             d_coeffs, c->stream);
+            rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
+                                           (int)lb.intra.size(),
+                                           c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), c->stream);
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }
@@ -767,7 +738,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if (!phases.empty()) {
         rc = ohevc_dev_levels(p->planes, p->bd, reinterpret_cast<const ohevc_level_phase *>(base + off_phases), (int)phases.size(), total_wgs,
                               reinterpret_cast<uint32_t *>(base + off_sync), reinterpret_cast<const uint32_t *>(base + off_need),
-                              reinterpret_cast<const ohevc_intra_job *>(base + intra_base), reinterpret_cast<const ohevc_tu_job *>(base + res_base),
+                              reinterpret_cast<const ohevc_intra_job *>(base + intra_base),
                               c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips),
                               reinterpret_cast<const ohevc_tu_job *>(base + tu_base), d_coeffs, c->stream);
         if (rc != OHEVC_OK) return rc;

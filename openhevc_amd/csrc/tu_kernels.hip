@@ -667,57 +667,6 @@ __global__ __launch_bounds__(256) void tu_multi_kernel(PlaneSet planes, TuSegTab
     else                                         tu_rows_body<5, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
 }
 
-// ------------------------------------------------------------------ intra prediction + its residual, one wavefront per block
-// In the reference a transform block is predicted and its residual added back to back (hls_transform_unit,
-// hevc.c:1214-1215 then :1260-1290).  As two launches per dependency level the residual kernel waits on a kernel boundary
-// for pixels its own wavefront could have kept: here the wavefront that predicted block b immediately runs the residual
-// body for b (same code as the batched kernels, pointed at this one job).  One launch per level instead of two.
-//
-// The residual bodies index their job from (workgroup, wavefront, lane); tu_single_job shifts the job pointer so that
-// the index this wavefront computes lands on `job` and every other index is out of range.
-template <typename Pixel>
-__device__ __forceinline__ void tu_single_job(unsigned char *lds, const PlaneSet planes, const ohevc_tu_job *job, int log2, int kind,
-                                              const int16_t *__restrict__ coeffs, int bit_depth)
-{
-    const int wave = threadIdx.x >> 6;
-    if (kind == OHEVC_TU_IDCT && log2 >= 3) {              // job index of (wg 0, wave, g 0) = wave * blocks-per-wave
-        const int idx = wave * (64 >> log2);
-        if (log2 == 5)      tu_idct_add_body<5, Pixel, 16 + 128>(lds, 0, planes, job - idx, idx + 1, coeffs, bit_depth);
-        else if (log2 == 4) tu_idct_add_body<4, Pixel, 16 + 128>(lds, 0, planes, job - idx, idx + 1, coeffs, bit_depth);
-        else                tu_idct_add_body<3, Pixel, 1>(lds, 0, planes, job - idx, idx + 1, coeffs, bit_depth);
-    } else if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) {      // one lane per 4x4 block: index = thread number
-        const int idx = wave * 64;
-        if (kind == OHEVC_TU_DST4) tu_4x4_body<Pixel, true>(0, planes, job - idx, idx + 1, coeffs, bit_depth);
-        else                       tu_4x4_body<Pixel, false>(0, planes, job - idx, idx + 1, coeffs, bit_depth);
-    } else {                                                // one lane per row: index = thread number >> log2
-        const int idx = (wave * 64) >> log2;
-        if (log2 == 2)      tu_rows_body<2, Pixel>(0, planes, job - idx, idx + 1, coeffs, bit_depth, kind);
-        else if (log2 == 3) tu_rows_body<3, Pixel>(0, planes, job - idx, idx + 1, coeffs, bit_depth, kind);
-        else if (log2 == 4) tu_rows_body<4, Pixel>(0, planes, job - idx, idx + 1, coeffs, bit_depth, kind);
-        else                tu_rows_body<5, Pixel>(0, planes, job - idx, idx + 1, coeffs, bit_depth, kind);
-    }
-}
-
-template <typename Pixel>
-__global__ __launch_bounds__(256) void intra_recon_kernel(PlaneSet planes, const ohevc_intra_job *__restrict__ jobs,
-                                                          const ohevc_tu_job *__restrict__ residuals, int njobs, int bit_depth,
-                                                          const ohevc_intra_cip *__restrict__ cips, const int16_t *__restrict__ coeffs)
-{
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<5>::WAVE_BYTES];
-    __shared__ IntraShared ish[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ji = blockIdx.x * 4 + wave;
-    if (ji >= njobs) return;                                 // wave-uniform; no workgroup barrier below
-    const ohevc_intra_job jb = jobs[ji];
-    intra_body<Pixel, true>(ish[wave], lane, planes, jb, bit_depth, cips);
-    const int kind1 = residuals ? residuals[ji].reserved0 : 0;      // residual kind + 1, 0 = this block has no residual
-    if (kind1 == 0) return;
-    // the prediction this wavefront just stored is what the residual body reads back: same CU, same L1 (write-through,
-    // coherent for one CU) -- the stores only have to be complete
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tu_single_job<Pixel>(lds, planes, residuals + ji, jb.log2_size, kind1 - 1, coeffs, bit_depth);
-}
-
 // ------------------------------------------------------------------ intra dependency levels in ONE launch
 // Intra pictures chain ~150 dependency levels per 1080p picture (prediction of level L reads what level L-1
 // reconstructed), each only tens of blocks wide.  Launched level by level that is ~300 kernel boundaries per picture,
@@ -736,15 +685,14 @@ __global__ __launch_bounds__(256) void intra_recon_kernel(PlaneSet planes, const
 //     L1 (buffer_inv).  The kernel boundary publishes the result to the other XCDs as usual.  Chains of different
 //     pictures (decoding threads) pick different leaders and so run on different XCDs side by side.
 struct LevelPhase {                  // mirrors ohevc_level_phase (include/ohevc_hip.h)
-    int first_wg, step, type, first_job, njobs, log2_size, kind, res_first_job;
+    int first_wg, step, type, first_job, njobs, log2_size, kind, reserved;
 };
 enum { LV_HOME = 0, LV_TICKET = 1, LV_DONE = 2 };       // layout of the sync words
 
 template <typename Pixel>
 __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const LevelPhase *__restrict__ phases, int nphases, int total_wgs,
                                                      unsigned *sync, const unsigned *__restrict__ need, int leader,
-                                                     const ohevc_intra_job *__restrict__ intra_jobs, const ohevc_tu_job *__restrict__ intra_res,
-                                                     const ohevc_intra_cip *__restrict__ cips,
+                                                     const ohevc_intra_job *__restrict__ intra_jobs, const ohevc_intra_cip *__restrict__ cips,
                                                      const ohevc_tu_job *__restrict__ tu_jobs, const int16_t *__restrict__ coeffs, int bit_depth)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<5>::WAVE_BYTES];
@@ -787,16 +735,7 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
         const int local = vwg - ph.first_wg;
         if (ph.type == 0) {                                    // intra prediction: one wavefront per block, four per workgroup
             const int ji = local * 4 + wave;
-            if (ji < ph.njobs) {
-                const ohevc_intra_job jb = intra_jobs[ph.first_job + ji];
-                intra_body<Pixel, true>(ish[wave], lane, planes, jb, bit_depth, cips);
-                const ohevc_tu_job *res = intra_res ? intra_res + ph.res_first_job + ji : nullptr;
-                const int kind1 = res ? res->reserved0 : 0;
-                if (kind1) {                                   // the block's own residual, same wavefront (intra_recon_kernel)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    tu_single_job<Pixel>(lds, planes, res, jb.log2_size, kind1 - 1, coeffs, bit_depth);
-                }
-            }
+            if (ji < ph.njobs) intra_body<Pixel, true>(ish[wave], lane, planes, intra_jobs[ph.first_job + ji], bit_depth, cips);
         } else {
             const ohevc_tu_job *j = tu_jobs + ph.first_job;
             const int log2 = ph.log2_size, kind = ph.kind, n = ph.njobs;
@@ -951,28 +890,6 @@ extern "C" int ohevc_dev_tu_multi(const ohevc_plane planes[3], int bit_depth, co
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs,
-                                           const ohevc_tu_job *residuals, int njobs, const ohevc_intra_cip *cip,
-                                           const int16_t *coeffs, void *stream)
-{
-    using namespace ohevc;
-    OHEVC_REQUIRE(planes != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
-    OHEVC_REQUIRE(njobs >= 0, "njobs");
-    if (njobs == 0) return OHEVC_OK;
-    OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(residuals) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(cip) & 15) == 0 && (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "arrays must be 16-byte aligned");
-    PlaneSet ps;
-    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
-    if (rc != OHEVC_OK) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = (njobs + 3) / 4;
-    if (bit_depth == 8) hipLaunchKernelGGL((intra_recon_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, jobs, residuals, njobs, bit_depth, cip, coeffs);
-    else                hipLaunchKernelGGL((intra_recon_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, jobs, residuals, njobs, bit_depth, cip, coeffs);
-    OHEVC_HIP_TRY(hipGetLastError());
-    return OHEVC_OK;
-}
-
 extern "C" int ohevc_level_phase_workgroups(int type, int log2_size, int kind, int njobs)
 {
     if (njobs <= 0) return 0;
@@ -980,8 +897,8 @@ extern "C" int ohevc_level_phase_workgroups(int type, int log2_size, int kind, i
 }
 
 extern "C" int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_level_phase *phases, int nphases, int total_wgs,
-                                uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_tu_job *intra_residuals,
-                                const ohevc_intra_cip *cips, const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream)
+                                uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_intra_cip *cips,
+                                const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream)
 {
     using namespace ohevc;
     static_assert(sizeof(LevelPhase) == sizeof(ohevc_level_phase), "phase record layout");
@@ -1001,8 +918,8 @@ extern "C" int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, cons
     const int grid = 192, leader = (int)(rotation.fetch_add(1) % 8u);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LevelPhase *ph = reinterpret_cast<const LevelPhase *>(phases);
-    if (bit_depth == 8) hipLaunchKernelGGL((levels_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, leader, intra_jobs, intra_residuals, cips, tu_jobs, coeffs, bit_depth);
-    else                hipLaunchKernelGGL((levels_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, leader, intra_jobs, intra_residuals, cips, tu_jobs, coeffs, bit_depth);
+    if (bit_depth == 8) hipLaunchKernelGGL((levels_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, leader, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
+    else                hipLaunchKernelGGL((levels_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, ph, nphases, total_wgs, sync, need, leader, intra_jobs, cips, tu_jobs, coeffs, bit_depth);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

@@ -201,7 +201,7 @@ class FrameStats(C.Structure):
                 ("n_tu", C.c_int32), ("n_mc", C.c_int32), ("n_intra", C.c_int32), ("n_dbk", C.c_int32), ("n_sao", C.c_int32)]
 
 
-EXPORTED_SYMBOLS += ["ohevc_dev_intra_recon_batch", "ohevc_dev_levels", "ohevc_level_phase_workgroups", "ohevc_ctx_create_shared", "ohevc_ctx_store_id"]
+EXPORTED_SYMBOLS += ["ohevc_dev_levels", "ohevc_level_phase_workgroups", "ohevc_ctx_create_shared", "ohevc_ctx_store_id"]
 EXPORTED_SYMBOLS += ["ohevc_ctx_create", "ohevc_ctx_destroy", "ohevc_ctx_stream", "ohevc_ctx_sync", "ohevc_pic_alloc",
                      "ohevc_pic_release", "ohevc_pic_adopt", "ohevc_pic_upload", "ohevc_pic_download", "ohevc_pic_planes", "ohevc_frame_begin",
                      "ohevc_rec_tu", "ohevc_rec_mc", "ohevc_rec_intra", "ohevc_rec_deblock", "ohevc_rec_sao",

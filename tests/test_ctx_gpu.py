@@ -17,7 +17,7 @@ import synth_stream as S  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["fused_launch_per_level", "levels_kernel", "two_launches_per_level"])
+@pytest.fixture(params=[0, 1], ids=["launch_per_level", "levels_kernel"])
 def level_executor(request):
     """Both executors of the intra dependency levels (include/ohevc_debug.h) must give the same pictures."""
     import ctypes
