@@ -118,3 +118,34 @@ def test_gop_plans_keep_every_reference_alive():
             dpb = rps | {p.poc}
             decoded.add(p.poc)
             assert len(dpb) <= 6
+
+
+needs_hip_lib = pytest.mark.skipif(not (ps.have("c") and ps.have("hip")), reason="oracle/_ref/libopenhevc_hip.so not built")
+
+
+def _record_only_counts(aus, threads, monkeypatch):
+    """Decode with the HIP-backed reference decoder in record-only mode (include/ohevc_debug.h: every table slot and the
+    whole recorder run, no device is touched, no pixels are produced) and return the per-stream job counters."""
+    monkeypatch.setenv("OHHIP_RECORD_ONLY", "1")
+    L = ps._load("hip")
+    sec, cnt = C.c_double(), (C.c_longlong * 8)()
+    L.ohdec_backend_profile(C.byref(sec), cnt)                 # reset
+    out = ps.decode_stream("hip", aus, threads, 1)
+    L.ohdec_backend_profile(C.byref(sec), cnt)
+    return len(out), dict(frames=cnt[0], tu=cnt[2], mc=cnt[3], intra=cnt[4], dbk=cnt[5], sao=cnt[6])
+
+
+@needs_hip_lib
+@pytest.mark.parametrize("name", ["ldb_8b", "ra_10b_odd", "pcm", "cip", "tiles", "slices_dep_wpp", "rext", "small_blocks"])
+def test_recording_front_end_without_a_device(name, monkeypatch):
+    """Host logic of the drop-in on real (synthetic) streams, no GPU: the recording table slots, pointer registry, job
+    builders and the ctx recorder see every call the reference front-end makes; the number of recorded jobs must not
+    depend on the number of frame threads (each thread records into its own context, shared picture store)."""
+    aus, _ = load_golden(name)
+    n1, c1 = _record_only_counts(aus, 1, monkeypatch)
+    n4, c4 = _record_only_counts(aus, 4, monkeypatch)
+    assert n1 == n4 == CASES[name]["nframes"]
+    assert c1 == c4 and c1["frames"] == CASES[name]["nframes"]
+    assert c1["tu"] > 0 and c1["intra"] > 0 and c1["dbk"] > 0
+    if CASES[name]["gop"] != "intra":
+        assert c1["mc"] > 0
