@@ -65,6 +65,14 @@ int  ohevc_rec_intra_cip(ohevc_ctx *ctx, const ohevc_intra_job *job, const ohevc
 int  ohevc_rec_deblock(ohevc_ctx *ctx, const ohevc_dbk_job *job);
 int  ohevc_rec_sao(ohevc_ctx *ctx, const ohevc_sao_job *job);
 
+/* The reference's s->is_pcm map of the picture being recorded (one byte per min-PU block, `stride` bytes per row):
+ * samples of flagged blocks come out of SAO with their deblocked value (restore_tqb_pixels, hevc_filter.c:163-193; see
+ * ohevc_sao_bypass in ohevc_hip.h).  Call any time between ohevc_frame_begin and ohevc_frame_end when
+ * pps->transquant_bypass_enable_flag || (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag); the bytes are copied.
+ * exact_reference: see ohevc_sao_bypass (1 = bit-identical with the reference decoder's partial restore). */
+int  ohevc_frame_set_bypass_map(ohevc_ctx *ctx, const uint8_t *map, int stride, int width_pu, int height_pu, int log2_min_pu_size,
+                                int exact_reference);
+
 /* Bulk forms (one call per CTU row / frame instead of one per block).  Records of different kinds may be handed over
  * in any order EXCEPT that a block's intra job must be recorded before its residual (the residual inherits the
  * prediction's dependency level).  ohevc_rec_tu_bulk: desc = n x {plane, x, y, log2_size, kind, intra} (int32 each),

@@ -167,15 +167,37 @@ typedef struct ohevc_sao_job {          /* 32 bytes */
  *              below) -- every CTB row but the last;
  *   LAG_ABOVE  the samples diagonally above-right and right of the CTB's first row (p0/q0 of the edge above) -- the
  *              last two CTB rows, whose filter calls the reference interleaves (ff_hevc_hls_filters, :1053-1063).
+ *   LAG_MID    4:2:2 only (a 16x16 CTB is 8x16 chroma samples, with a horizontal chroma edge 8 rows below its top): the
+ *              samples right of block rows 7 and 8 (p0/q0 of that edge in the next CTB column).
  * A job carrying a flag reads those samples from `lagged` (the picture as it was between the vertical and the
  * horizontal deblocking pass) and therefore reproduces the reference decoder bit for bit; without flags SAO reads the
  * fully deblocked picture everywhere, as H.265 8.7.3 says. */
-enum { OHEVC_SAO_LAG_BELOW = 1, OHEVC_SAO_LAG_ABOVE = 2 };
+enum { OHEVC_SAO_LAG_BELOW = 1, OHEVC_SAO_LAG_ABOVE = 2, OHEVC_SAO_LAG_MID = 4 };
 
 int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
                         const ohevc_sao_job *jobs, int njobs, void *stream);
 int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3], int bit_depth,
                                const ohevc_sao_job *jobs, int njobs, void *stream);
+
+/* Samples SAO must not change: restore_tqb_pixels (hevc_filter.c:163-193) puts the deblocked samples back over every
+ * min-PU block flagged in the reference's s->is_pcm map (PCM coding units when pcm_loop_filter_disabled_flag is set and
+ * cu_transquant_bypass coding units, set_deblocking_bypass hevc.c:1430-1441) right after each sao_* table call.  `map` is
+ * that array in DEVICE memory: one byte per min-PU block, `stride` bytes per row, nonzero = keep the deblocked sample.
+ * The reference bounds its PU walk with the block's width/height in samples of the plane being filtered while the
+ * origin is in luma samples (sao_filter_CTB passes x, y, width, height, hevc_filter.c:275,316): with subsampled chroma
+ * only PUs in the first half of the CTB are restored; and it copies `min_pu_size >> hshift` BYTES per row (:176,:184), i.e.
+ * only the first half of each PU row when samples are 16 bits wide.  With exact_reference != 0 the kernel reproduces
+ * exactly that (bit-identical with the reference decoder); with 0 every sample of a flagged PU is restored in every plane
+ * (H.265 8.7.1: pcm_loop_filter_disabled / cu_transquant_bypass samples are not modified by the in-loop filters). */
+typedef struct ohevc_sao_bypass {
+    const uint8_t *map;
+    int32_t stride;
+    int32_t log2_min_pu_size;
+    int32_t chroma_hshift, chroma_vshift;   /* sps->hshift[1], sps->vshift[1] */
+    int32_t exact_reference;
+} ohevc_sao_bypass;
+int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3], int bit_depth,
+                               const ohevc_sao_job *jobs, int njobs, const ohevc_sao_bypass *bypass /* may be NULL */, void *stream);
 
 /* ---- 2.5 intra prediction: replaces intra_pred[log2-2] (hevcpred.h:32; hevcpred_template.c:30-357) and the
  * predictors it dispatches to, pred_planar / pred_dc / pred_angular (hevcpred.h:34-40).  Everything the

@@ -101,6 +101,13 @@ void ohevc_videodsp_init_hip(ohevc_VideoDSPContext *c, int bit_depth);
 
 /* ---- per-thread binding and the pointer registry */
 int  ohevc_tables_bind(ohevc_ctx *ctx);                    /* this thread's table calls record into ctx (NULL unbinds) */
+/* Slice threads (the reference's WPP-row / tile workers, hls_decode_entry_wpp / hls_decode_entry_tiles, hevc.c:2744-2920,
+ * run through avctx->execute2): all workers of a picture record into the SAME context.  Turn this on for the context (it
+ * serialises the recorder behind a spin lock, off = no locking at all) and call ohevc_tables_bind(ctx) at the top of each
+ * worker entry function; per-thread call-sequence state (pending transform, first half of a bi-prediction, edge-emulation
+ * windows) is thread-local already.  What makes it safe: WPP / tile decoding never reads a neighbour another worker has
+ * not yet parsed (2-CTB lag, hevc.c:2779), so every intra block still sees its neighbours' dependency levels. */
+int  ohevc_tables_set_concurrent(ohevc_ctx *ctx, int on);
 /* host planes of a picture living in picture-store slot `slot` (a DPB entry): used to resolve MC source pointers */
 int  ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *const data[3], const int linesize[3]);
 int  ohevc_tables_unregister_picture(ohevc_ctx *ctx, int slot);
@@ -109,6 +116,11 @@ int  ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot);
 /* frame end: run everything; with download != 0 the final planes are copied back into the registered host buffers
  * (needed wherever the CPU still reads pixels: output, MD5 check hevc.c:4146-4181) */
 int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
+/* restore_tqb_pixels (hevc_filter.c:163-193) works on host pixels and is lost behind recording tables: before
+ * ohevc_tables_end_frame hand over s->is_pcm (s->sps->min_pu_width x min_pu_height bytes, s->sps->log2_min_pu_size) whenever
+ * pps->transquant_bypass_enable_flag || (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag).  With
+ * ohevc_tables_emulate_filter_lag on, the reference's partial restore is reproduced bit for bit (ohevc_sao_bypass.exact_reference) */
+int  ohevc_tables_set_bypass_map(ohevc_ctx *ctx, const uint8_t *is_pcm, int min_pu_width, int min_pu_height, int log2_min_pu_size);
 /* sticky status of the recording since begin_frame: table slots return void, so failures surface here */
 int  ohevc_tables_status(ohevc_ctx *ctx);
 /* Reproduce the reference front-end's filter lag (ff_hevc_hls_filter / ff_hevc_hls_filters, hevc_filter.c:1027-1063):

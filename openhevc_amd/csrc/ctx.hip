@@ -111,6 +111,8 @@ struct ohevc_ctx {
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
     std::vector<ohevc_sao_job> sao;
+    std::vector<uint8_t> bypass;                           // ohevc_frame_set_bypass_map: is_pcm bytes, row length bypass_w (empty = none)
+    int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
     int lm_w[3] = {}, lm_h[3] = {};
 
@@ -359,7 +361,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
         c->level_map[i].assign((size_t)c->lm_w[i] * c->lm_h[i], 0);
     }
     clear_recorded(c);
-    c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear();
+    c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->bypass.clear();
     c->stats = ohevc_frame_stats{};
     return OHEVC_OK;
 }
@@ -475,8 +477,27 @@ extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
     c->sao.push_back(*job);
-    if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE)) c->sao_lagged = true;
+    if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) c->sao_lagged = true;
     c->stats.n_sao++;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_frame_set_bypass_map(ohevc_ctx *c, const uint8_t *map, int stride, int width_pu, int height_pu, int log2_min_pu_size,
+                                          int exact_reference)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    if (!map) { c->bypass.clear(); return OHEVC_OK; }
+    OHEVC_REQUIRE(log2_min_pu_size >= 2 && log2_min_pu_size <= 6 && width_pu > 0 && height_pu > 0 && stride >= width_pu, "bad map description");
+    OHEVC_REQUIRE(((long long)width_pu << log2_min_pu_size) >= p->w && ((long long)height_pu << log2_min_pu_size) >= p->h, "map smaller than the picture");
+    bool any = false;
+    c->bypass.resize((size_t)width_pu * height_pu);
+    for (int y = 0; y < height_pu; y++) {
+        memcpy(c->bypass.data() + (size_t)y * width_pu, map + (size_t)y * stride, (size_t)width_pu);
+        if (!any) for (int x = 0; x < width_pu; x++) any |= map[(size_t)y * stride + x] != 0;
+    }
+    if (!any) c->bypass.clear();              // nothing flagged: SAO runs as usual
+    c->bypass_w = width_pu; c->bypass_l2 = log2_min_pu_size; c->bypass_exact = exact_reference != 0;
     return OHEVC_OK;
 }
 
@@ -758,12 +779,14 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
     int rc = ohevc_frame_reconstruct(c);
     if (rc != OHEVC_OK) return rc;
     if (c->dry) { c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; }
+    if (c->sao.empty()) c->bypass.clear();
     if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty()) {
         std::vector<std::pair<const void *, size_t>> parts;
         size_t total = 0;
         const size_t off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
         const size_t off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
         const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
+        const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
         if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
         unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
         // all vertical edges, then all horizontal edges: deblocking_filter_CTB, hevc_filter.c:385-580
@@ -796,10 +819,15 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
                 OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
                                              hipMemcpyDeviceToDevice, c->stream));
             ohevc_plane lagp[3] = {c->twin.planes[0], lagged ? c->lag.planes[1] : c->twin.planes[1], lagged ? c->lag.planes[2] : c->twin.planes[2]};
-            if ((rc = ohevc_dev_sao_batch_lagged(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), c->stream)) != OHEVC_OK) return rc;
+            ohevc_sao_bypass bp = {};                     // restore_tqb_pixels, hevc_filter.c:163-193
+            if (!c->bypass.empty()) {
+                bp.map = base + off_b; bp.stride = c->bypass_w; bp.log2_min_pu_size = c->bypass_l2;
+                bp.chroma_hshift = p->cfi == 1 || p->cfi == 2; bp.chroma_vshift = p->cfi == 1; bp.exact_reference = c->bypass_exact;
+            }
+            if ((rc = ohevc_dev_sao_batch_bypass(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), &bp, c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
-        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
+        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
     }
     if (!c->dry) {
         // publish: this picture is reconstructed once `ev` fires; the references were read until then

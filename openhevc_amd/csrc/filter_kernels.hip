@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
 }
 
 template <typename Pixel>
-__global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth)
+__global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth,
+                                                  ohevc_sao_bypass bp)
 {
     const ohevc_sao_job jb = jobs[blockIdx.x];
     const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
@@ -98,6 +99,20 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
     const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
     auto clampi = [](int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; };
     const int bx = jb.x, by = jb.y;
+    // restore_tqb_pixels (hevc_filter.c:163-193): samples of min-PU blocks flagged in the reference's is_pcm map (PCM CUs with
+    // pcm_loop_filter_disabled, cu_transquant_bypass CUs) keep their deblocked value.  The reference walks the PUs of
+    // [x0, x0 + width) x [y0, y0 + height) with x0/y0 in LUMA samples but width/height in samples of THIS plane, so for
+    // subsampled chroma only the PUs of the CTB's first half are restored; reproduced here (xlim / ylim).
+    const unsigned char *const bmap = bp.map;
+    const int b_hs = jb.plane ? bp.chroma_hshift : 0, b_vs = jb.plane ? bp.chroma_vshift : 0, b_l2 = bp.log2_min_pu_size;
+    const int b_xlim = bp.exact_reference ? ((bx << b_hs) + w) >> b_l2 : 0x7fffffff;
+    const int b_ylim = bp.exact_reference ? ((by << b_vs) + h) >> b_l2 : 0x7fffffff;
+    // ... and copies (min_pu_size >> hshift) BYTES per row: half a PU row of 16-bit samples (:176,:184)
+    const int b_len = (bp.exact_reference && sizeof(Pixel) == 2) ? ((1 << b_l2) >> b_hs) >> 1 : 0x7fffffff;
+    auto bypassed = [&](int x, int y) {
+        const int xpu = ((bx + x) << b_hs) >> b_l2, ypu = ((by + y) << b_vs) >> b_l2;
+        return xpu < b_xlim && ypu < b_ylim && (bx + x) - ((xpu << b_l2) >> b_hs) < b_len && bmap[(size_t)ypu * bp.stride + xpu] != 0;
+    };
 #define SRC(px_, py_) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(clampi(by + (py_), ph - 1) - by) * sstride + \
                                                               (ptrdiff_t)(clampi(bx + (px_), pw - 1) - bx) * (int)sizeof(Pixel)))
     if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
@@ -106,7 +121,9 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
             const int y = idx / w, x = idx - y * w;
             const int c = SRC(x, y), k = ((c >> shift) - jb.klass) & 31;
             const int off = k == 0 ? ov1 : k == 1 ? ov2 : k == 2 ? ov3 : k == 3 ? ov4 : 0;
-            *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)iclip(c + off, 0, maxv);
+            int v = iclip(c + off, 0, maxv);
+            if (bmap && bypassed(x, y)) v = c;
+            *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)v;
         }
         return;
     }
@@ -120,7 +137,8 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
     const int sul = !de0 && eo == 2 && !b0 && !b1, sur = !de1 && eo == 3 && !b1 && !b2;
     const int slr = !de2 && eo == 2 && !b2 && !b3, sll = !de3 && eo == 3 && !b0 && !b3;
     const bool lag_below = (jb.quirks & OHEVC_SAO_LAG_BELOW) != 0, lag_above = (jb.quirks & OHEVC_SAO_LAG_ABOVE) != 0;
-    const bool lag_any = (lag_below || lag_above) && eo != 1 && bx + w < pw;
+    const bool lag_mid = (jb.quirks & OHEVC_SAO_LAG_MID) != 0;
+    const bool lag_any = (lag_below || lag_above || lag_mid) && eo != 1 && bx + w < pw;
     for (int idx = threadIdx.x; idx < w * h; idx += 256) {
         const int y = idx / w, x = idx - y * w;
         const int c = SRC(x, y);
@@ -129,7 +147,8 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
             const unsigned char *lbase = PLANE_PTR3(lag, jb.plane) + (size_t)(bx + w) * sizeof(Pixel);
             const int lstride = PLANE_STRIDE3(lag, jb.plane);
             auto stale = [&](int ny) {
-                return by + ny >= 0 && by + ny < ph && ((lag_below && (ny == h - 1 || ny == h)) || (lag_above && (ny == -1 || ny == 0)));
+                return by + ny >= 0 && by + ny < ph && ((lag_below && (ny == h - 1 || ny == h)) || (lag_above && (ny == -1 || ny == 0)) ||
+                                                     (lag_mid && (ny == 7 || ny == 8)));
             };
             if (dxa == 1 && stale(y + dya)) a = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y + dya) * lstride);
             if (dxa == -1 && stale(y - dya)) b = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y - dya) * lstride);
@@ -149,6 +168,7 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
                            (de2 && eo == 2 && x == w2 - 1 && y == h2 - 1) || (de3 && eo == 3 && x == 0 && y == h2 - 1);
             if (r) v = c;
         }
+        if (bmap && bypassed(x, y)) v = c;
         *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)v;
     }
 #undef SRC
@@ -175,8 +195,8 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
-                                          int bit_depth, const ohevc_sao_job *jobs, int njobs, void *stream)
+extern "C" int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
+                                          int bit_depth, const ohevc_sao_job *jobs, int njobs, const ohevc_sao_bypass *bypass, void *stream)
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr && src != nullptr && lagged != nullptr, "planes");
@@ -184,6 +204,12 @@ extern "C" int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
+    ohevc_sao_bypass bp = {};
+    if (bypass && bypass->map) {
+        bp = *bypass;
+        OHEVC_REQUIRE(bp.stride > 0 && bp.log2_min_pu_size >= 2 && bp.log2_min_pu_size <= 6 && (bp.chroma_hshift | 1) == 1 &&
+                      (bp.chroma_vshift | 1) == 1, "bad bypass map description");
+    }
     PlaneSet pd, psrc, plag;
     int rc = make_plane_set(dst, pd, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
@@ -192,15 +218,21 @@ extern "C" int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_
     rc = make_plane_set(lagged, plag, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth);
-    else                hipLaunchKernelGGL((sao_kernel<uint16_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth);
+    if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+    else                hipLaunchKernelGGL((sao_kernel<uint16_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
+                                          int bit_depth, const ohevc_sao_job *jobs, int njobs, void *stream)
+{
+    return ohevc_dev_sao_batch_bypass(dst, src, lagged, bit_depth, jobs, njobs, nullptr, stream);
 }
 
 extern "C" int ohevc_dev_sao_batch(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth,
                                    const ohevc_sao_job *jobs, int njobs, void *stream)
 {
     // without a lagged picture the flag has nothing to read from: jobs carrying it read the deblocked copy
-    return ohevc_dev_sao_batch_lagged(dst, src, src, bit_depth, jobs, njobs, stream);
+    return ohevc_dev_sao_batch_bypass(dst, src, src, bit_depth, jobs, njobs, nullptr, stream);
 }

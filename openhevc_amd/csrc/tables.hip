@@ -64,6 +64,10 @@ struct TablesState {
     uint32_t seq = 0;
     std::unordered_map<uint32_t, uint32_t> h_edge_seq;                    // (plane, x, y) of a chroma horizontal edge -> call number
     std::vector<std::pair<ohevc_sao_job, uint32_t>> held_sao;           // chroma SAO jobs held back until the frame ends
+    // ohevc_tables_set_concurrent: several threads (the reference's slice threads: WPP rows / tiles of ONE picture) record
+    // into this context at the same time; every recorder call then runs under `spin`
+    bool concurrent = false;
+    std::atomic_flag spin = ATOMIC_FLAG_INIT;
     ohevc_HEVCDSPContext saved = {};  // the reference's own C slots (put_pcm is still executed on the host into scratch)
 };
 
@@ -84,10 +88,23 @@ thread_local ohevc_ctx *tl_ctx = nullptr;
 thread_local TablesState *tl_state = nullptr;
 thread_local Pending tl_pend;
 
+std::atomic<int> g_unbound_calls{0};   // table calls from threads without a bound context: reported by ohevc_tables_status
+
 void fail(int rc)
 {
-    if (tl_state && tl_state->status == OHEVC_OK) tl_state->status = rc;
+    if (tl_state) { if (tl_state->status == OHEVC_OK) tl_state->status = rc; }
+    else g_unbound_calls.fetch_add(1, std::memory_order_relaxed);
 }
+
+// serialises the recorder calls of one context when several threads feed it (ohevc_tables_set_concurrent); free otherwise
+struct Guard {
+    TablesState *s;
+    explicit Guard(TablesState *st) : s(st && st->concurrent ? st : nullptr)
+    {
+        if (s) while (s->spin.test_and_set(std::memory_order_acquire)) __builtin_ia32_pause();
+    }
+    ~Guard() { if (s) s->spin.clear(std::memory_order_release); }
+};
 
 struct Loc { int pic = -1, plane = 0, x = 0, y = 0; };
 
@@ -161,6 +178,7 @@ template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_
     // no pending in-place transform on this pointer: the caller handed over a finished residual (transquant bypass)
     const int kind = (tl_pend.coeffs == coeffs && tl_pend.kind >= 0) ? tl_pend.kind : OHEVC_TU_BYPASS;
     tl_pend.coeffs = nullptr; tl_pend.kind = -1;
+    Guard guard_(tl_state);
     int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);
     if (rc != OHEVC_OK) fail(rc);
 }
@@ -171,17 +189,21 @@ void t_put_pcm(uint8_t *dst, ptrdiff_t, int width, int height, struct GetBitCont
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
     const HostPic &hp = tl_state->pics[tl_state->cur];
-    if (!g_ref_put_pcm[hp.bd] || width != height || width < 4 || width > 32) { fail(OHEVC_ERR_STATE); return; }
-    // the bit reader is the reference's: let its own put_pcm unpack into scratch, then ship the samples as a block
-    uint16_t scratch16[32 * 32];
+    // square blocks, or the two-squares-tall chroma block of a 4:2:2 coding block (hls_pcm_sample, hevc.c:1613-1620)
+    if (!g_ref_put_pcm[hp.bd] || (height != width && height != 2 * width) || width < 4 || width > 32) { fail(OHEVC_ERR_STATE); return; }
+    // the bit reader is the reference's: let its own put_pcm unpack into scratch, then ship the samples as square blocks
+    uint16_t scratch16[32 * 64];
     uint8_t *scratch = reinterpret_cast<uint8_t *>(scratch16);
     g_ref_put_pcm[hp.bd](scratch, (ptrdiff_t)width * hp.ps, width, height, gb, pcm_bit_depth);
-    int16_t samples[32 * 32];
+    int16_t samples[32 * 64];
     for (int i = 0; i < width * height; i++) samples[i] = hp.ps == 2 ? (int16_t)scratch16[i] : (int16_t)scratch[i];
     int log2 = 2;
     while ((1 << log2) < width) log2++;
-    int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, log2, OHEVC_TU_PCM, samples, 1);
-    if (rc != OHEVC_OK) fail(rc);
+    Guard guard_(tl_state);
+    for (int half = 0; half * width < height; half++) {
+        int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y + half * width, log2, OHEVC_TU_PCM, samples + half * width * width, 1);
+        if (rc != OHEVC_OK) fail(rc);
+    }
 }
 
 // ------------------------------------------------------------------ motion compensation
@@ -268,6 +290,7 @@ void mc_record(uint8_t *dst, uint8_t *src, const int16_t *src2, int height, int 
         j.flags |= OHEVC_MC_WEIGHTED;
         j.denom = (uint8_t)denom; j.wx0 = (int16_t)wx0; j.wx1 = (int16_t)wx1; j.ox0 = (int16_t)ox0; j.ox1 = (int16_t)ox1;
     }
+    Guard guard_(tl_state);
     int rc = ohevc_rec_mc(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
 }
@@ -305,6 +328,7 @@ void dbk_record(uint8_t *pix, bool vertical, int beta, const int *tc, const uint
     j.tc[0] = (int16_t)tc[0]; j.tc[1] = (int16_t)tc[1];
     j.flags = (uint8_t)((vertical ? OHEVC_DBK_VERTICAL_EDGE : 0) | (no_p[0] ? OHEVC_DBK_NO_P0 : 0) | (no_p[1] ? OHEVC_DBK_NO_P1 : 0) |
                         (no_q[0] ? OHEVC_DBK_NO_Q0 : 0) | (no_q[1] ? OHEVC_DBK_NO_Q1 : 0));
+    Guard guard_(tl_state);
     if (tl_state->lag_on && !vertical && l.plane > 0)
         tl_state->h_edge_seq[((uint32_t)l.plane << 30) | ((uint32_t)l.y << 15) | (uint32_t)l.x] = ++tl_state->seq;
     int rc = ohevc_rec_deblock(tl_ctx, &j);
@@ -336,6 +360,7 @@ void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int
         fprintf(stderr, "sao plane %d x %d y %d w %d h %d type %d klass %d borders %d restore %d edges %d quirks %d off %d %d %d %d %d\n", j.plane, j.x, j.y,
                 j.w, j.h, j.type, j.klass, j.borders, j.restore, j.edges, j.quirks, j.offset_val[0], j.offset_val[1], j.offset_val[2],
                 j.offset_val[3], j.offset_val[4]);
+    Guard guard_(tl_state);
     if (tl_state->lag_on && c_idx > 0) {        // flags depend on calls still to come: decided in ohevc_tables_end_frame
         tl_state->held_sao.emplace_back(j, ++tl_state->seq);
         return;
@@ -429,6 +454,14 @@ extern "C" int ohevc_tables_bind(ohevc_ctx *ctx)
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_tables_set_concurrent(ohevc_ctx *ctx, int on)
+{
+    TablesState *st = state_of(ctx, true);
+    if (!st) return OHEVC_ERR_ARG;
+    st->concurrent = on != 0;
+    return OHEVC_OK;
+}
+
 extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *const data[3], const int linesize[3])
 {
     using namespace ohevc;
@@ -517,7 +550,8 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
                 auto it = s->h_edge_seq.find(((uint32_t)j.plane << 30) | ((uint32_t)y << 15) | (uint32_t)xr);
                 return it != s->h_edge_seq.end() && it->second > held.second;
             };
-            j.quirks = (uint8_t)((later(j.y + j.h) ? OHEVC_SAO_LAG_BELOW : 0) | (later(j.y) ? OHEVC_SAO_LAG_ABOVE : 0));
+            j.quirks = (uint8_t)((later(j.y + j.h) ? OHEVC_SAO_LAG_BELOW : 0) | (later(j.y) ? OHEVC_SAO_LAG_ABOVE : 0) |
+                                 ((j.h > 8 && later(j.y + 8)) ? OHEVC_SAO_LAG_MID : 0));
         }
         if ((rc = ohevc_rec_sao(ctx, &j)) != OHEVC_OK) return rc;
     }
@@ -530,6 +564,13 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
             if ((rc = ohevc_pic_download(ctx, hp.slot, c, hp.data[c], hp.linesize[c])) != OHEVC_OK) return rc;
     }
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_set_bypass_map(ohevc_ctx *ctx, const uint8_t *is_pcm, int min_pu_width, int min_pu_height, int log2_min_pu_size)
+{
+    // the same switch that keeps the filter lag of the reference front-end decides between its partial restore and the standard's
+    TablesState *st = state_of(ctx, false);
+    return ohevc_frame_set_bypass_map(ctx, is_pcm, min_pu_width, min_pu_width, min_pu_height, log2_min_pu_size, st && st->lag_on);
 }
 
 // called by ohevc_ctx_destroy: a later ctx may be allocated at the same address and must not inherit this registry
@@ -555,6 +596,12 @@ extern "C" void ohevc_tables_forget(ohevc_ctx *ctx)
 extern "C" int ohevc_tables_status(ohevc_ctx *ctx)
 {
     TablesState *s = state_of(ctx, false);
+    // a table call from a thread nobody bound produced no job: never let that pass silently
+    if (g_unbound_calls.exchange(0, std::memory_order_relaxed) > 0) {
+        ohevc::set_error("table slots were called from a thread without ohevc_tables_bind (slice threads need a bind per worker)");
+        if (s && s->status == OHEVC_OK) s->status = OHEVC_ERR_STATE;
+        return OHEVC_ERR_STATE;
+    }
     return s ? s->status : OHEVC_OK;
 }
 
@@ -564,6 +611,7 @@ extern "C" int ohevc_tables_intra_pred(const ohevc_intra_geom *geom, int x0, int
     if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
     ohevc_intra_job j;
     int rc = ohevc_intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, &j);
+    Guard guard_(tl_state);
     if (rc == OHEVC_OK) rc = ohevc_rec_intra(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
     return rc;
@@ -579,6 +627,7 @@ extern "C" int ohevc_tables_intra_pred_cip(const ohevc_intra_geom *geom, int log
     ohevc_intra_cip cip;
     int rc = ohevc_intra_make_job_cip(geom, log2_min_pu_size, pred_flag, pred_flag_stride, intra_value, x0, y0, log2_size, c_idx, mode,
                                       cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, &j, &cip);
+    Guard guard_(tl_state);
     if (rc == OHEVC_OK) rc = ohevc_rec_intra_cip(tl_ctx, &j, &cip);
     if (rc != OHEVC_OK) fail(rc);
     return rc;

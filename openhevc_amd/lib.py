@@ -154,6 +154,22 @@ def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_sao_batch(dst_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
+class SaoBypass(C.Structure):
+    """ohevc_sao_bypass (include/ohevc_hip.h)"""
+    _fields_ = [("map", C.c_void_p), ("stride", C.c_int32), ("log2_min_pu_size", C.c_int32),
+                ("chroma_hshift", C.c_int32), ("chroma_vshift", C.c_int32), ("exact_reference", C.c_int32)]
+
+
+EXPORTED_SYMBOLS += ["ohevc_dev_sao_batch_bypass", "ohevc_frame_set_bypass_map", "ohevc_tables_set_bypass_map", "ohevc_tables_set_concurrent"]
+
+
+def dev_sao_batch_bypass(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, map_ptr, map_stride, log2_min_pu_size,
+                         chroma_hshift, chroma_vshift, exact_reference=1, stream=0):
+    bp = SaoBypass(map_ptr, map_stride, log2_min_pu_size, chroma_hshift, chroma_vshift, exact_reference)
+    check(load_library().ohevc_dev_sao_batch_bypass(dst_planes, src_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr),
+                                                    C.c_int(njobs), C.byref(bp), C.c_void_p(stream)))
+
+
 def dev_intra_batch_cip(planes, bit_depth, jobs_ptr, njobs, cip_ptr, stream=0):
     check(load_library().ohevc_dev_intra_batch_cip(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(cip_ptr), C.c_void_p(stream)))
 

@@ -29,6 +29,7 @@
 static ohevc_ctx          *g_root;
 static __thread ohevc_ctx *t_ctx;
 static __thread int        t_frame_open;
+static __thread HEVCContext *t_s;      /* the decoder context this thread's open frame belongs to */
 static ohevc_ctx          *g_all[128];
 static int                 g_nall;
 static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -42,6 +43,7 @@ static long long           g_counts[8];        /* frames, launches, tu, mc, intr
 static struct {
     const uint8_t *data0;
     int slot, w, h, bd, fmt;
+    ohevc_ctx *ctx;            /* the context that is reconstructing (or last reconstructed) this picture */
 } g_bufs[MAX_BUFS];
 static int g_nbufs;
 
@@ -151,7 +153,10 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         g_nbufs++;
     }
     slot = g_bufs[i].slot;
+    g_bufs[i].ctx = ctx;
     pthread_mutex_unlock(&g_lock);
+    /* slice threads: the WPP-row / tile workers of this picture all record into ctx (ohhip_cabac_init binds them) */
+    ohevc_tables_set_concurrent(ctx, (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
     if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
         ohevc_tables_begin_frame(ctx, slot) != OHEVC_OK) {
         fprintf(stderr, "ohhip: begin_frame failed: %s\n", ohevc_last_error());
@@ -159,7 +164,37 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         return AVERROR(EINVAL);
     }
     t_frame_open = 1;
+    t_s = s;
     return 0;
+}
+
+/* Slice threads.  The worker entry functions (hls_decode_entry_wpp / hls_decode_entry_tiles, hevc.c:2744-2920) run on pool
+ * threads with a per-thread COPY of the decoder context (s1->sList[self_id]); INTEGRATION.md section 3 puts one
+ * `ohevc_tables_bind(s->hip)` at their top.  Here the same effect comes from renaming the first call every CTB makes from
+ * hevc.c with the context in hand, ff_hevc_cabac_init (hevc.c:2666,2785,2873): the wrapper binds the calling thread to the
+ * context that is reconstructing s->ref, once per picture and thread. */
+static __thread const uint8_t *t_bound_data0;
+void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts)
+{
+    if ((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1 && s->ref && s->ref->frame) {
+        const uint8_t *d0 = s->ref->frame->data[0];
+        if (d0 != t_bound_data0 || !t_ctx) {
+            ohevc_ctx *ctx = NULL;
+            int i;
+            pthread_mutex_lock(&g_lock);
+            for (i = 0; i < g_nbufs; i++)
+                if (g_bufs[i].data0 == d0)
+                    ctx = g_bufs[i].ctx;
+            pthread_mutex_unlock(&g_lock);
+            if (ctx && ctx != t_ctx) {            /* a pool thread: it never owns a context, it borrows the picture's */
+                if (ohevc_tables_bind(ctx) != OHEVC_OK)
+                    g_error = 1;
+                t_ctx = ctx;
+            }
+            t_bound_data0 = d0;
+        }
+    }
+    ff_hevc_cabac_init(s, ctb_addr_ts);                             /* hevc_cabac.c */
 }
 
 /* ---- called by decoder_harness.c ---- */
@@ -191,6 +226,12 @@ int ohdec_backend_frame_done(void)
     if (!t_frame_open)
         return g_error ? -1 : 0;
     t_frame_open = 0;
+    /* restore_tqb_pixels (hevc_filter.c:163-193) ran on host pixels nobody reads: hand its map to the back-end instead */
+    if (t_s && t_s->sps && t_s->pps && t_s->is_pcm &&
+        (t_s->pps->transquant_bypass_enable_flag || (t_s->sps->pcm_enabled_flag && t_s->sps->pcm.loop_filter_disable_flag)) &&
+        ohevc_tables_set_bypass_map(t_ctx, t_s->is_pcm, t_s->sps->min_pu_width, t_s->sps->min_pu_height,
+                                    t_s->sps->log2_min_pu_size) != OHEVC_OK)
+        g_error = 1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     st = ohevc_tables_end_frame(t_ctx, 1);
     clock_gettime(CLOCK_MONOTONIC, &t1);

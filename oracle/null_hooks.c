@@ -26,3 +26,4 @@ void ohhip_hevc_pred_init(HEVCPredContext *c, int bit_depth) { (void)bit_depth; 
 int  ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc) { return ff_hevc_set_new_ref(s, frame, poc); }
 void ohhip_report_progress(ThreadFrame *f, int progress, int field) { ff_thread_report_progress(f, progress, field); }
 void ohhip_await_progress(ThreadFrame *f, int progress, int field) { (void)f; (void)progress; (void)field; }
+void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts) { ff_hevc_cabac_init(s, ctb_addr_ts); }

@@ -185,3 +185,28 @@ def load(which):
         raise ValueError(which)
     _cache[which] = lib
     return lib
+
+
+def restore_tqb_pixels(frame_plane, deblocked_plane, x0, y0, width, height, is_pcm, log2_min_pu_size, hshift, vshift,
+                       exact_reference=True):
+    """numpy restatement of restore_tqb_pixels (hevc_filter.c:163-193), called by sao_filter_CTB right after each SAO table
+    call (:275,:316): min-PU blocks flagged in `is_pcm` (2-D array, [y_pu, x_pu]) get their deblocked samples back.
+    x0/y0 are the CTB origin in LUMA samples, width/height the size of the filtered block in samples of THIS plane --
+    exactly the reference's argument mix, which bounds the PU walk to the CTB's first half for subsampled chroma; and each
+    row copies `len = min_pu_size >> hshift` BYTES (memcpy(src, dst, len), :176,:184), half a PU row of 16-bit samples.
+    exact_reference=False is the standard's behaviour (every sample of a flagged PU, H.265 8.7.1).
+    Pinned only at bitstream level (tests/test_stream_gpu.py against the untouched decoder): the function is static in
+    the reference, so there is no kernel-level call-through."""
+    l = log2_min_pu_size
+    n, ln = (1 << l) >> vshift, (1 << l) >> hshift
+    if exact_reference:
+        yr, xr = range(y0 >> l, (y0 + height) >> l), range(x0 >> l, (x0 + width) >> l)
+        ln = ln // frame_plane.itemsize
+    else:
+        yr = range(y0 >> l, -(-(y0 + (height << vshift)) >> l))
+        xr = range(x0 >> l, -(-(x0 + (width << hshift)) >> l))
+    for y in yr:
+        for x in xr:
+            if y < is_pcm.shape[0] and x < is_pcm.shape[1] and is_pcm[y, x]:
+                ys, xs = (y << l) >> vshift, (x << l) >> hshift
+                frame_plane[ys:ys + n, xs:xs + ln] = deblocked_plane[ys:ys + n, xs:xs + ln]

@@ -182,6 +182,7 @@ class StreamParams:
     width: int = 192
     height: int = 128
     bit_depth: int = 8
+    chroma_format: int = 1       # chroma_format_idc: 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 (2 and 3 need rext=1: RExt profiles)
     log2_ctb: int = 5
     log2_min_cb: int = 3
     log2_min_tb: int = 2
@@ -193,6 +194,8 @@ class StreamParams:
     pcm: int = 0                 # 0 off, else pcm sample bit depth
     pcm_log2_min: int = 3
     pcm_log2_max: int = 5
+    pcm_loop_filter_disabled: int = 0    # with pcm: PCM CUs skip deblocking and SAO (restore_tqb_pixels, hevc_filter.c:163-193)
+    transquant_bypass: int = 0           # PPS transquant_bypass_enable_flag: lossless CUs (same restore path)
     strong_intra_smoothing: int = 1
     tmvp: int = 1
     sign_hiding: int = 1
@@ -317,7 +320,9 @@ def write_sps(p: StreamParams) -> bytes:
     b.u(1, 1)
     _ptl(b, p)
     b.ue(0)                       # sps_id
-    b.ue(1)                       # chroma_format_idc 4:2:0
+    b.ue(p.chroma_format)         # chroma_format_idc
+    if p.chroma_format == 3:
+        b.u(1, 0)                 # separate_colour_plane_flag
     b.ue(p.width)
     b.ue(p.height)
     b.u(1, 0)                     # conformance window
@@ -344,7 +349,7 @@ def write_sps(p: StreamParams) -> bytes:
         b.u(4, p.pcm - 1)
         b.ue(p.pcm_log2_min - 3)
         b.ue(p.pcm_log2_max - p.pcm_log2_min)
-        b.u(1, 0)                 # pcm_loop_filter_disabled (restore_tqb_pixels path: INTEGRATION.md section 5)
+        b.u(1, p.pcm_loop_filter_disabled)
     b.ue(0)                       # num_short_term_ref_pic_sets: every slice header carries its own
     b.u(1, 0)                     # long-term refs
     b.u(1, p.tmvp)
@@ -391,7 +396,7 @@ def write_pps(p: StreamParams) -> bytes:
     b.u(1, 1)                     # slice-level chroma qp offsets present
     b.u(1, p.weighted_pred)
     b.u(1, p.weighted_bipred)
-    b.u(1, 0)                     # transquant_bypass (restore_tqb_pixels path: INTEGRATION.md section 5)
+    b.u(1, p.transquant_bypass)
     b.u(1, 1 if p.tiles else 0)
     b.u(1, p.wpp)
     if p.tiles:

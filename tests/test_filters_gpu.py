@@ -110,3 +110,55 @@ def test_sao_band_and_edge(oracle, bd):
         got = G.to_host(d_dst[pl], dst[pl].dtype)
         bad = np.argwhere(got != want[pl])
         assert bad.size == 0, f"bd={bd} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("bd,cfi,log2_pu", [(8, 1, 2), (10, 2, 3), (8, 3, 2), (10, 1, 2)])
+def test_sao_bypass_map(oracle, bd, cfi, log2_pu, exact):
+    """SAO with the reference's is_pcm map (restore_tqb_pixels, hevc_filter.c:163-193): flagged min-PU blocks keep their
+    deblocked samples, with the reference's half-CTB bound for subsampled chroma."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(900 + bd + cfi)
+    hs, vs = int(cfi in (1, 2)), int(cfi == 1)
+    H, W, ctb = 64 * 4, 64 * 5, 64
+    shapes = [(H, W), (H >> vs, W >> hs), (H >> vs, W >> hs)]
+    src = [np.ascontiguousarray(rng.integers(0, 1 << bd, size=sh).astype(G.pixdt(bd))) for sh in shapes]
+    dst = [p.copy() for p in src]
+    is_pcm = (rng.random((H >> log2_pu, W >> log2_pu)) < 0.3).astype(np.uint8) * 2
+    jobs = []
+    for pl in range(3):
+        cw, ch = (ctb >> hs, ctb >> vs) if pl else (ctb, ctb)
+        for cy in range(1, 3):                      # interior CTBs only: the ring every job reads stays inside the plane
+            for cx in range(1, 4):
+                j = np.zeros(1, L.SAO_JOB)[0]
+                j["x"], j["y"], j["w"], j["h"], j["plane"] = cx * cw, cy * ch, cw, ch, pl
+                j["type"] = L.SAO_BAND if rng.random() < 0.4 else L.SAO_EDGE
+                j["klass"] = int(rng.integers(0, 32)) if j["type"] == L.SAO_BAND else int(rng.integers(0, 4))
+                j["restore"] = int(rng.random() < 0.3)
+                j["edges"] = int(rng.integers(0, 256)) if j["restore"] else 0
+                j["offset_val"] = np.concatenate([[0], rng.integers(-7, 8, size=4) << (bd - 8)])
+                jobs.append(j)
+    batch = np.array(jobs, dtype=L.SAO_JOB)
+    want = [p.copy() for p in dst]
+    for j in batch:
+        pl = int(j["plane"])
+        x, y, w, h = int(j["x"]), int(j["y"]), int(j["w"]), int(j["h"])
+        ov = [int(v) for v in j["offset_val"]]
+        if j["type"] == L.SAO_BAND:
+            oracle.sao_band(bd, want[pl], src[pl], x, y, w, h, ov, int(j["klass"]))
+        else:
+            e = int(j["edges"])
+            oracle.sao_edge(bd, int(j["restore"]), want[pl], src[pl], x, y, w, h, ov, int(j["klass"]), [0, 0, 0, 0],
+                            [e & 1, (e >> 1) & 1], [(e >> 2) & 1, (e >> 3) & 1], [(e >> 4) & 1, (e >> 5) & 1, (e >> 6) & 1, (e >> 7) & 1])
+        po.restore_tqb_pixels(want[pl], src[pl], x << (hs if pl else 0), y << (vs if pl else 0), w, h, is_pcm, log2_pu,
+                              hs if pl else 0, vs if pl else 0, bool(exact))
+    d_src = [G.to_dev(p) for p in src]; d_dst = [G.to_dev(p) for p in dst]
+    d_jobs = G.to_dev(batch); d_map = G.to_dev(is_pcm)
+    L.dev_sao_batch_bypass(G.planes3(d_dst), G.planes3(d_src), bd, d_jobs.data_ptr(), len(batch), d_map.data_ptr(), is_pcm.shape[1],
+                           log2_pu, hs, vs, exact, G.stream())
+    torch.cuda.synchronize()
+    for pl in range(3):
+        got = G.to_host(d_dst[pl], dst[pl].dtype)
+        bad = np.argwhere(got != want[pl])
+        assert bad.size == 0, f"bd={bd} cfi={cfi} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
+    assert is_pcm.any() and not is_pcm.all()

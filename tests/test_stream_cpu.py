@@ -123,14 +123,14 @@ def test_gop_plans_keep_every_reference_alive():
 needs_hip_lib = pytest.mark.skipif(not (ps.have("c") and ps.have("hip")), reason="oracle/_ref/libopenhevc_hip.so not built")
 
 
-def _record_only_counts(aus, threads, monkeypatch):
+def _record_only_counts(aus, threads, monkeypatch, thread_type=1):
     """Decode with the HIP-backed reference decoder in record-only mode (include/ohevc_debug.h: every table slot and the
     whole recorder run, no device is touched, no pixels are produced) and return the per-stream job counters."""
     monkeypatch.setenv("OHHIP_RECORD_ONLY", "1")
     L = ps._load("hip")
     sec, cnt = C.c_double(), (C.c_longlong * 8)()
     L.ohdec_backend_profile(C.byref(sec), cnt)                 # reset
-    out = ps.decode_stream("hip", aus, threads, 1)
+    out = ps.decode_stream("hip", aus, threads, thread_type)
     L.ohdec_backend_profile(C.byref(sec), cnt)
     return len(out), dict(frames=cnt[0], tu=cnt[2], mc=cnt[3], intra=cnt[4], dbk=cnt[5], sao=cnt[6])
 
@@ -149,3 +149,17 @@ def test_recording_front_end_without_a_device(name, monkeypatch):
     assert c1["tu"] > 0 and c1["intra"] > 0 and c1["dbk"] > 0
     if CASES[name]["gop"] != "intra":
         assert c1["mc"] > 0
+
+
+@needs_hip_lib
+@pytest.mark.parametrize("name", ["wpp", "tiles", "slices_dep_wpp", "tiles_nolf"])
+def test_slice_threads_record_into_one_context(name, monkeypatch):
+    """The reference's slice threads (WPP rows / tiles of one picture decoded by pool threads, hevc.c:2744-2920,3017-3100):
+    every worker binds to the picture's context (ohevc_tables_set_concurrent + ohevc_tables_bind per worker) and no table
+    call may be lost -- same job counts as with one thread, with slice threads and with frame+slice threads."""
+    aus, _ = load_golden(name)
+    n1, c1 = _record_only_counts(aus, 1, monkeypatch)
+    n2, c2 = _record_only_counts(aus, 4, monkeypatch, 2)
+    n4, c4 = _record_only_counts(aus, 4, monkeypatch, 4)
+    assert n1 == n2 == n4 == CASES[name]["nframes"]
+    assert c1 == c2 == c4

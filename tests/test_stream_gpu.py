@@ -81,3 +81,21 @@ def test_frame_threads_share_the_picture_store(threads):
         ref = ps.decode_stream("c", aus)
         for _ in range(2):      # scheduling differs from run to run
             _compare(ref, ps.decode_stream("hip", aus, threads, 1))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(gop="lowdelay_b", nframes=6, seed=501, wpp=1, width=832, height=480, log2_ctb=5),
+    dict(gop="random_access", nframes=9, seed=502, tiles=(3, 2), width=832, height=480, log2_ctb=6, bit_depth=10),
+    dict(gop="lowdelay_b", nframes=5, seed=503, slices_per_picture=3, wpp=1, dependent_slices=1, width=416, height=240,
+         constrained_intra=1),
+])
+def test_slice_threads_hip_backend(kw):
+    """Slice threads (thread_type 2) and frame+slice threads (4): the WPP-row / tile workers of a picture record into one
+    context concurrently (ohevc_tables_set_concurrent)."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    aus, gen_frames = ps.generate(ps.StreamParams(**kw))
+    ref = ps.decode_stream("c", aus)
+    for thread_type in (2, 4):
+        for _ in range(2):
+            _compare(ref, ps.decode_stream("hip", aus, 4, thread_type))

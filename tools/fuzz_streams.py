@@ -28,6 +28,14 @@ def random_params(rng):
     if rng.integers(0, 4) == 0:
         kw["pcm"] = int(rng.integers(5, kw["bit_depth"] + 1))
         kw["pcm_log2_max"] = min(5, log2_ctb)
+    if rng.integers(0, 4) == 0:                      # RExt chroma formats
+        kw["chroma_format"] = int(rng.choice([2, 3]))
+        kw["rext"] = 1
+    if rng.integers(0, 5) == 0:                      # lossless CUs / PCM outside the loop filters: restore_tqb_pixels
+        kw["transquant_bypass"] = 1
+        kw["probs"] = dict(transquant_bypass=float(rng.uniform(0.05, 0.4)))
+    if "pcm" in kw and rng.integers(0, 2):
+        kw["pcm_loop_filter_disabled"] = 1
     mode = int(rng.integers(0, 5))
     ctb_w = -(-kw["width"] >> log2_ctb)
     ctb_h = -(-kw["height"] >> log2_ctb)
@@ -41,7 +49,7 @@ def random_params(rng):
         kw["slices_per_picture"] = int(rng.integers(2, 5))
         kw["dependent_slices"] = int(rng.integers(0, 2))
     if rng.integers(0, 3) == 0:
-        kw["probs"] = dict(rqt_root_cbf=0.85, cbf_luma=0.85, cbf_chroma=0.7, sig_coeff=0.6, skip=0.15, split_cu=float(rng.uniform(0.3, 0.8)),
+        kw["probs"] = dict(kw.get("probs", {}), rqt_root_cbf=0.85, cbf_luma=0.85, cbf_chroma=0.7, sig_coeff=0.6, skip=0.15, split_cu=float(rng.uniform(0.3, 0.8)),
                            split_transform=float(rng.uniform(0.2, 0.8)), pred_mode=float(rng.uniform(0.1, 0.7)))
     return kw
 
@@ -53,6 +61,15 @@ def main():
     n = bad = gen_fail = 0
     while time.time() - t0 < budget:
         kw = random_params(rng)
+        threads = int(rng.choice([1, 1, 3, 8]))          # frame threads: one context per thread, shared picture store
+        thread_type = 1
+        if threads > 1 and (kw.get("wpp") or kw.get("tiles")) and rng.integers(0, 2):
+            thread_type = 2                              # slice threads: WPP rows / tiles of one picture record concurrently
+        # the reference never clears s->is_pcm between pictures (hevc_frame_start, hevc.c:3197-3215, has no memset for it):
+        # with the restore_tqb_pixels tools its OWN output then depends on which thread decoded which picture and even
+        # varies from run to run with frame threads (observed here), so those streams are compared single-threaded
+        if kw.get("transquant_bypass") or kw.get("pcm_loop_filter_disabled"):
+            threads = 1
         try:
             aus, gen_frames = ps.generate(ps.StreamParams(**kw))
             ref = ps.decode_stream("c", aus)
@@ -61,8 +78,7 @@ def main():
             continue
         n += 1
         try:
-            threads = int(rng.choice([1, 1, 3, 8]))          # frame threads: one context per thread, shared picture store
-            hip = ps.decode_stream("hip", aus, threads, 1)
+            hip = ps.decode_stream("hip", aus, threads, thread_type)
             ok = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
             same_gen = all(np.array_equal(x, y) for fa, fb in zip(ref, gen_frames) for x, y in zip(fa, fb))
         except Exception as e:
@@ -70,7 +86,7 @@ def main():
             print("EXC", e)
         if not ok or not same_gen:
             bad += 1
-            print("FAIL" if not ok else "GEN-MISMATCH", "threads", threads, json.dumps(kw))
+            print("FAIL" if not ok else "GEN-MISMATCH", "threads", threads, "type", thread_type, json.dumps(kw))
     print(json.dumps(dict(streams=n, failed=bad, rejected_by_generator=gen_fail, seconds=round(time.time() - t0, 1))))
     sys.exit(1 if bad else 0)
 
