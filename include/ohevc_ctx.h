@@ -58,6 +58,11 @@ int  ohevc_frame_begin(ohevc_ctx *ctx, int slot);
 /* transform_add[..] preceded by its inverse transform (kind = OHEVC_TU_*).  `intra` != 0 when the block was just
  * predicted by ohevc_rec_intra at the same position (it then runs right after that prediction's level). */
 int  ohevc_rec_tu(ohevc_ctx *ctx, int plane, int x, int y, int log2_size, int kind, const int16_t *coeffs, int intra);
+/* a chroma block with cross-component prediction (OHEVC_TU_CROSS): own residual (kind_c, coeffs_c; kind_c = -1 and coeffs_c
+ * NULL when the block has no coded coefficients) plus (res_scale_val * luma residual) >> 3, the luma residual being that of
+ * (kind_y, coeffs_y), the RAW coefficients of the transform unit's luma block.  Both blocks are copied. */
+int  ohevc_rec_tu_cross(ohevc_ctx *ctx, int plane, int x, int y, int log2_size, int kind_c, const int16_t *coeffs_c, int kind_y,
+                        const int16_t *coeffs_y, int res_scale_val, int intra);
 int  ohevc_rec_mc(ohevc_ctx *ctx, const ohevc_mc_job *job);              /* ref0/ref1 are picture-store slots */
 int  ohevc_rec_intra(ohevc_ctx *ctx, const ohevc_intra_job *job);
 /* job marked OHEVC_INTRA2_CIP: `cip` is copied and job->cip_index is assigned by the recorder */

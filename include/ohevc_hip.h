@@ -59,17 +59,22 @@ enum {
     OHEVC_TU_BYPASS = 6, OHEVC_TU_BYPASS_RDPCM_H = 7, OHEVC_TU_BYPASS_RDPCM_V = 8,
     OHEVC_TU_PCM = 9,     /* put_pcm (hevcdsp_template.c:30-43): the arena block holds the N*N samples the host read from
                              the bitstream, already << (bit_depth - pcm_bit_depth); they REPLACE the block */
-    OHEVC_TU_NKINDS = 10
+    OHEVC_TU_CROSS = 10,  /* cross-component prediction (RExt 4:4:4; hevc.c:1291-1365, hevc_cabac.c:1942-1949): a CHROMA block whose
+                             residual is (int16)(rC + ((res_scale_val * rY) >> 3)), rY = residual of the transform unit's luma block,
+                             rC = the block's own residual.  The job carries both: coeff_off = chroma block, reserved1 = luma block
+                             (dense N*N int16 each, also for DC kinds, which read [0]), reserved0 = chroma kind | luma kind << 4
+                             (chroma kind 15 = no coded coefficients, rC = 0), dc = res_scale_val (+-1, 2, 4, 8) */
+    OHEVC_TU_NKINDS = 11
 };
 
 typedef struct ohevc_tu_job {           /* 16 bytes */
     uint16_t x, y;                      /* top-left sample of the block inside its plane; multiples of the block size */
     uint8_t  plane;                     /* index into planes[3] */
-    uint8_t  reserved0;
-    int16_t  dc;                        /* OHEVC_TU_DC: coeffs[0] (no arena storage needed) */
+    uint8_t  reserved0;                 /* OHEVC_TU_CROSS: residual kinds, see the enum */
+    int16_t  dc;                        /* OHEVC_TU_DC: coeffs[0] (no arena storage needed); OHEVC_TU_CROSS: res_scale_val */
     uint32_t coeff_off;                 /* offset of the dense N*N int16 block in the coefficient arena, in int16
                                            units; must be a multiple of 8 (16 bytes).  Ignored for OHEVC_TU_DC */
-    uint32_t reserved1;
+    uint32_t reserved1;                 /* OHEVC_TU_CROSS: offset of the luma block in the arena (int16 units, multiple of 8) */
 } ohevc_tu_job;
 
 /* Runs `njobs` blocks of one size (1 << log2_size, 2..5) and one residual kind.  Blocks of a batch must not

@@ -121,6 +121,12 @@ int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
  * pps->transquant_bypass_enable_flag || (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag).  With
  * ohevc_tables_emulate_filter_lag on, the reference's partial restore is reproduced bit for bit (ohevc_sao_bypass.exact_reference) */
 int  ohevc_tables_set_bypass_map(ohevc_ctx *ctx, const uint8_t *is_pcm, int min_pu_width, int min_pu_height, int log2_min_pu_size);
+/* Cross-component prediction (RExt 4:4:4).  hls_cross_component_pred (hevc.c:1186-1200) decodes lc->tu.res_scale_val right
+ * before each chroma component of a transform unit; the chroma residual then gets (res_scale_val * luma residual) >> 3
+ * added on the host (hevc_cabac.c:1942-1948, hevc.c:1315-1330) -- from a luma residual that does not exist behind recording
+ * tables.  Call this with lc->tu.res_scale_val at the end of hls_cross_component_pred: the next chroma transform_add of the
+ * calling thread becomes an OHEVC_TU_CROSS job (both coefficient blocks travel, the kernel forms both residuals). */
+int  ohevc_tables_cross_component(int res_scale_val);
 /* sticky status of the recording since begin_frame: table slots return void, so failures surface here */
 int  ohevc_tables_status(ohevc_ctx *ctx);
 /* Reproduce the reference front-end's filter lag (ff_hevc_hls_filter / ff_hevc_hls_filters, hevc_filter.c:1027-1063):

@@ -108,6 +108,20 @@ __device__ __forceinline__ unsigned add_clamp_px2(unsigned a, unsigned b, unsign
     return bitcast<unsigned>(s);
 }
 
+// The same for 16-bit PIXELS that may hold anything up to 65535: clamp(px + res, 0, maxv) with px unsigned, res int16.
+// Legal pictures never exceed maxv, but the reference's constrained-intra substitution can leave 0x8080 samples in a
+// prediction (hevcpred_template.c:159-161 memsets BYTES to 128; intra PUs of another slice are "intra" yet never copied),
+// and its transform_add then computes av_clip_pixel(dst + res) with dst read as uint16 (hevcdsp_template.c:45-111).
+// Bias both halves by -32768, add with int16 saturation, undo the bias: below 0 / above 65535 saturate to the right ends.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned add_clamp_upx2(unsigned res, unsigned px, unsigned maxv2)
+{
+    s16x2 s = __builtin_elementwise_add_sat(bitcast<s16x2>(res), bitcast<s16x2>(px ^ 0x80008000u));
+    u16x2 u = bitcast<u16x2>(bitcast<unsigned>(s) ^ 0x80008000u);
+    u = __builtin_elementwise_min(u, bitcast<u16x2>(maxv2));
+    return bitcast<unsigned>(u);
+}
+
 __host__ __device__ constexpr unsigned pack16(int lo, int hi)
 {
     return (static_cast<unsigned>(lo) & 0xffffu) | ((static_cast<unsigned>(hi) & 0xffffu) << 16);

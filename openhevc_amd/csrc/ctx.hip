@@ -83,6 +83,16 @@ static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_level_launch = 0;        // ohevc_debug_set_level_launch: 0 = two launches per level (shipped), 1 = all intra levels in one launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
+// OHEVC_TRACE_AT=plane,x,y: print every recorded job whose block covers that sample (diagnosis of a mismatching block)
+static int g_trace_at[3] = {-1, -1, -1};
+static const bool g_trace_at_on = [] {
+    const char *e = getenv("OHEVC_TRACE_AT");
+    return e && sscanf(e, "%d,%d,%d", &g_trace_at[0], &g_trace_at[1], &g_trace_at[2]) == 3;
+}();
+static inline bool trace_hit(int plane, int x, int y, int w, int h)
+{
+    return g_trace_at_on && plane == g_trace_at[0] && g_trace_at[1] >= x && g_trace_at[1] < x + w && g_trace_at[2] >= y && g_trace_at[2] < y + h;
+}
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct ohevc_ctx {
@@ -390,9 +400,41 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
         c->coeffs.insert(c->coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
+    if (trace_hit(plane, x, y, n, n))
+        fprintf(stderr, "trace: target %d tu plane %d x %d y %d log2 %d kind %d level %d c0 %d\n", c->cur, plane, x, y, log2, kind, level, coeffs[0]);
     LevelBins &lb = level_bins(c, level);
     lb.tu[log2 - 2][kind].push_back(j);
     lb.touched |= 1ull << ((log2 - 2) * 16 + kind);
+    c->stats.n_tu++;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log2, int kind_c, const int16_t *coeffs_c, int kind_y,
+                                  const int16_t *coeffs_y, int res_scale_val, int intra)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    OHEVC_REQUIRE(plane >= 1 && plane < 3 && log2 >= 2 && log2 <= 5, "cross-component prediction applies to chroma blocks");
+    OHEVC_REQUIRE(kind_y >= 0 && kind_y < OHEVC_TU_PCM && kind_c >= -1 && kind_c < OHEVC_TU_PCM && coeffs_y != nullptr && (kind_c < 0 || coeffs_c != nullptr),
+                  "bad residual kinds");
+    OHEVC_REQUIRE((kind_y != OHEVC_TU_DST4 && kind_c != OHEVC_TU_DST4) || log2 == 2, "DST is 4x4 only");
+    OHEVC_REQUIRE(res_scale_val >= -8 && res_scale_val <= 8, "res_scale_val out of range");
+    const int n = 1 << log2;
+    OHEVC_REQUIRE(x >= 0 && y >= 0 && x + n <= p->planes[plane].width && y + n <= p->planes[plane].height, "TU outside plane");
+    ohevc_tu_job j = {};
+    j.x = (uint16_t)x; j.y = (uint16_t)y; j.plane = (uint8_t)plane;
+    j.reserved0 = (uint8_t)((kind_c < 0 ? 15 : kind_c) | (kind_y << 4));
+    j.dc = (int16_t)res_scale_val;
+    j.reserved1 = (uint32_t)c->coeffs.size();
+    c->coeffs.insert(c->coeffs.end(), coeffs_y, coeffs_y + n * n);
+    if (kind_c >= 0) {
+        j.coeff_off = (uint32_t)c->coeffs.size();
+        c->coeffs.insert(c->coeffs.end(), coeffs_c, coeffs_c + n * n);
+    }
+    const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
+    LevelBins &lb = level_bins(c, level);
+    lb.tu[log2 - 2][OHEVC_TU_CROSS].push_back(j);
+    lb.touched |= 1ull << ((log2 - 2) * 16 + OHEVC_TU_CROSS);
     c->stats.n_tu++;
     return OHEVC_OK;
 }
@@ -403,6 +445,10 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
     OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
     OHEVC_REQUIRE(job->plane < 3 && job->w >= 2 && job->w <= 64 && job->h >= 2 && job->h <= 64, "bad MC block");
     OHEVC_REQUIRE(get_pic(c, job->ref0) != nullptr && (!(job->flags & OHEVC_MC_BI) || get_pic(c, job->ref1) != nullptr), "bad reference slot");
+    if (trace_hit(job->plane, job->x, job->y, job->w, job->h))
+        fprintf(stderr, "trace: target %d mc plane %d x %d y %d w %d h %d flags %d ref0 %d (%d,%d)+(%d,%d) ref1 %d (%d,%d)+(%d,%d) denom %d w %d %d o %d %d\n",
+                c->cur, job->plane, job->x, job->y, job->w, job->h, job->flags, job->ref0, job->sx0, job->sy0, job->mx0, job->my0, job->ref1,
+                job->sx1, job->sy1, job->mx1, job->my1, job->denom, job->wx0, job->wx1, job->ox0, job->ox1);
     // Prediction blocks are cut into tiles of at most 16x16 samples (every tile is an independent job: same references,
     // positions shifted by the tile offset), so a 64x64 PU spreads over 16 wavefronts; tiles of at most 8x8 go to the
     // packed small-block kernel (four per wavefront).
@@ -460,6 +506,9 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(level < 65535, "intra dependency chain too long");
     for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
         for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) lm[(size_t)cy * W + cx] = (uint16_t)level;
+    if (trace_hit(pl, job->x, job->y, n, n))
+        fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d level %d\n", c->cur, pl, job->x,
+                job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size, level);
     level_bins(c, level).intra.push_back(*job);
     c->stats.n_intra++;
     return OHEVC_OK;
@@ -741,20 +790,24 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         ohevc_tu_segment segs[40];
         int nsegs = 0;
         size_t job_off = 0;                          // in jobs, relative to the level's first bin
+        auto flush_segs = [&]() -> int {
+            if (!nsegs) return OHEVC_OK;
+            int r = ohevc_dev_tu_multi(p->planes, p->bd, segs, nsegs, reinterpret_cast<const ohevc_tu_job *>(base + loff[level].tu_first), d_coeffs, c->stream);
+            c->stats.launches++;
+            nsegs = 0;
+            return r;
+        };
         for (uint64_t m = lb.touched; m; m &= m - 1) {
             const int b = __builtin_ctzll(m);
             const auto &v = lb.tu[b >> 4][b & 15];
+            if (nsegs == 40 && (rc = flush_segs()) != OHEVC_OK) return rc;      // 4 sizes x 11 kinds can exceed one table
             ohevc_tu_segment &sg = segs[nsegs++];
             sg.log2_size = (b >> 4) + 2; sg.kind = b & 15;
             sg.first_job = (int32_t)job_off;
             sg.njobs = (int32_t)v.size();
             job_off += ((v.size() * sizeof(ohevc_tu_job) + 255) & ~(size_t)255) / sizeof(ohevc_tu_job);
         }
-        if (nsegs) {
-            rc = ohevc_dev_tu_multi(p->planes, p->bd, segs, nsegs, reinterpret_cast<const ohevc_tu_job *>(base + loff[level].tu_first), d_coeffs, c->stream);
-            if (rc != OHEVC_OK) return rc;
-            c->stats.launches++;
-        }
+        if ((rc = flush_segs()) != OHEVC_OK) return rc;
     }
     if (!phases.empty()) {
         rc = ohevc_dev_levels(p->planes, p->bd, reinterpret_cast<const ohevc_level_phase *>(base + off_phases), (int)phases.size(), total_wgs,

@@ -78,6 +78,10 @@ void (*g_ref_put_pcm[15])(uint8_t *, ptrdiff_t, int, int, struct GetBitContext *
 struct Pending {
     const int16_t *coeffs = nullptr;  // residual kind noted by the in-place transform call
     int kind = -1;
+    // cross-component prediction (hevc.c:1291-1365): the transform unit's luma block as last handed to transform_add, and the
+    // res_scale_val announced for the next chroma block (ohevc_tables_cross_component)
+    const int16_t *luma_coeffs = nullptr;
+    int luma_kind = -1, luma_log2 = 0, cross_scale = 0;
     const int16_t *bi_tmp = nullptr;  // first half of a bi-prediction
     int bi_slot = -1, bi_plane = 0, bi_sx = 0, bi_sy = 0, bi_mx = 0, bi_my = 0;
     struct Emu { const uint8_t *buf = nullptr; ptrdiff_t linesize = 0; int slot = -1, plane = 0, x = 0, y = 0; } emu[4];
@@ -176,10 +180,29 @@ template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
     // no pending in-place transform on this pointer: the caller handed over a finished residual (transquant bypass)
-    const int kind = (tl_pend.coeffs == coeffs && tl_pend.kind >= 0) ? tl_pend.kind : OHEVC_TU_BYPASS;
+    const bool pending = tl_pend.coeffs == coeffs && tl_pend.kind >= 0;
+    const int kind = pending ? tl_pend.kind : OHEVC_TU_BYPASS;
     tl_pend.coeffs = nullptr; tl_pend.kind = -1;
-    Guard guard_(tl_state);
-    int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);
+    const int scale = l.plane ? tl_pend.cross_scale : 0;
+    tl_pend.cross_scale = 0;                              // announced for exactly one chroma block
+    if (l.plane == 0) { tl_pend.luma_coeffs = coeffs; tl_pend.luma_kind = kind; tl_pend.luma_log2 = LOG2; }
+    int rc;
+    if (scale) {
+        // The host has already mixed its idea of the luma residual into this buffer -- computed from lc->tu.coeffs[0], which
+        // behind recording tables still holds the RAW luma coefficients y:
+        //   coded chroma block   c' = (int16)(c + ((scale * y) >> 3))      hevc_cabac.c:1942-1948  -> undo it, exactly (mod 2^16)
+        //   no coded coefficients c' = (scale * y) >> 3, no transform call  hevc.c:1315-1330        -> nothing of the block's own
+        const int16_t *y = tl_pend.luma_coeffs;
+        if (!y || tl_pend.luma_log2 != LOG2 || y == coeffs) { fail(OHEVC_ERR_STATE); return; }
+        int16_t own[1 << (2 * LOG2)];
+        if (pending)
+            for (int i = 0; i < (1 << (2 * LOG2)); i++) own[i] = (int16_t)(coeffs[i] - ((scale * y[i]) >> 3));
+        Guard guard_(tl_state);
+        rc = ohevc_rec_tu_cross(tl_ctx, l.plane, l.x, l.y, LOG2, pending ? kind : -1, pending ? own : nullptr, tl_pend.luma_kind, y, scale, 1);
+    } else {
+        Guard guard_(tl_state);
+        rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);
+    }
     if (rc != OHEVC_OK) fail(rc);
 }
 
@@ -451,6 +474,12 @@ extern "C" int ohevc_tables_bind(ohevc_ctx *ctx)
     tl_ctx = ctx;
     tl_state = ctx ? state_of(ctx, true) : nullptr;
     tl_pend = Pending();
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_cross_component(int res_scale_val)
+{
+    tl_pend.cross_scale = res_scale_val;
     return OHEVC_OK;
 }
 

@@ -162,7 +162,7 @@ __device__ __forceinline__ void finish_row(unsigned char *row, unsigned *px, con
             unsigned s23 = add_clamp_px2(sat_pack_i16(res[4 * d + 2], res[4 * d + 3]), u23, max2);
             px[d] = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
         } else {
-            px[d] = add_clamp_px2(sat_pack_i16(res[2 * d], res[2 * d + 1]), px[d], max2);
+            px[d] = add_clamp_upx2(sat_pack_i16(res[2 * d], res[2 * d + 1]), px[d], max2);
         }
     }
     if (valid) {
@@ -322,8 +322,8 @@ __device__ __forceinline__ void tu_idct_add_body(unsigned char *lds, int wg, con
                 o = u32x4{ od[0], od[1], od[2], od[3] };
             } else {
                 const u32x4 ra = rp[0];
-                o = u32x4{ add_clamp_px2(ra.x, pr.x, max2), add_clamp_px2(ra.y, pr.y, max2),
-                           add_clamp_px2(ra.z, pr.z, max2), add_clamp_px2(ra.w, pr.w, max2) };
+                o = u32x4{ add_clamp_upx2(ra.x, pr.x, max2), add_clamp_upx2(ra.y, pr.y, max2),
+                           add_clamp_upx2(ra.z, pr.z, max2), add_clamp_upx2(ra.w, pr.w, max2) };
             }
             if (ovalid) *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
         }
@@ -634,6 +634,120 @@ __global__ __launch_bounds__(256) void tu_rows_kernel(PlaneSet planes, const ohe
     tu_rows_body<LOG2N, Pixel>(blockIdx.x, planes, jobs, njobs, coeffs, bit_depth, kind);
 }
 
+
+// ------------------------------------------------------------------ cross-component prediction (RExt, 4:4:4)
+// hls_transform_unit (hevc.c:1291-1365) + the tail of ff_hevc_hls_residual_coding (hevc_cabac.c:1942-1949): with
+// cross_component_prediction the residual added to a chroma block is
+//     (int16)(rC + ((res_scale_val * rY) >> 3))
+// where rY is the luma residual of the same transform unit AFTER its inverse transform and rC the chroma block's own
+// residual (0 when the block has no coded coefficients).  Behind recording tables the luma residual never exists on the
+// host, so such a chroma block carries both coefficient blocks and both residual kinds (OHEVC_TU_CROSS, ohevc_hip.h) and
+// this body derives the two residuals itself.  A rare tool: generic code, one wavefront per block, two blocks per
+// workgroup (each uses half of the workgroup's LDS), any residual kind in direct matrix form -- exact integer arithmetic
+// identical to the dedicated kernels (no partial sum can overflow int32: 32 terms of at most 2^15 * 90).
+__constant__ signed char kCos128[128] = {       // 64*sqrt(2)*cos(m*pi/64) as the standard rounds it (hevcdsp.c:879-944 spelt out)
+    64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4,
+    0, -4, -9, -13, -18, -22, -25, -31, -36, -38, -43, -46, -50, -54, -57, -61, -64, -67, -70, -73, -75, -78, -80, -82, -83, -85, -87, -88, -89, -90, -90, -90,
+    -64, -90, -90, -90, -89, -88, -87, -85, -83, -82, -80, -78, -75, -73, -70, -67, -64, -61, -57, -54, -50, -46, -43, -38, -36, -31, -25, -22, -18, -13, -9, -4,
+    0, 4, 9, 13, 18, 22, 25, 31, 36, 38, 43, 46, 50, 54, 57, 61, 64, 67, 70, 73, 75, 78, 80, 82, 83, 85, 87, 88, 89, 90, 90, 90 };
+__constant__ signed char kDst4[4][4] = { {29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29} };   // :170-203
+
+#define CROSS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// residual of one dense N x N block of any kind into out[N*N] (wave-private LDS, row-major int16); tmp = same-size scratch
+__device__ __forceinline__ void residual_generic(int kind, int log2, const int16_t *__restrict__ blk, int bit_depth, short *tmp, short *out, int lane)
+{
+    const int N = 1 << log2, NN = N * N, mask = N - 1;
+    auto clip16 = [](int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; };
+    if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) {
+        const bool dst = kind == OHEVC_TU_DST4;
+        const int step = 32 >> log2;
+        // inverse transform: out[k] = sum_j M[j][k] * in[j]; DCT M[j][k] = cos((j * step) * (2k + 1)), :210-301
+        auto coef = [&](int j, int k) { return dst ? (int)kDst4[j][k] : (int)kCos128[(j * step * (2 * k + 1)) & 127]; };
+        for (int o = lane; o < NN; o += 64) {              // pass 1: columns, shift 7
+            const int k = o >> log2, c = o & mask;
+            int acc = 0;
+            for (int j = 0; j < N; j++) acc += coef(j, k) * (int)blk[j * N + c];
+            tmp[o] = (short)clip16((acc + 64) >> 7);
+        }
+        CROSS_SYNC();
+        const int shift = 20 - bit_depth, add = 1 << (shift - 1);
+        for (int o = lane; o < NN; o += 64) {              // pass 2: rows
+            const int r = o >> log2, k = o & mask;
+            int acc = 0;
+            for (int j = 0; j < N; j++) acc += coef(j, k) * (int)tmp[r * N + j];
+            out[o] = (short)clip16((acc + add) >> shift);
+        }
+    } else if (kind == OHEVC_TU_DC) {                      // :303-316
+        const int shift = 14 - bit_depth, add = 1 << (shift - 1);
+        const int v = ((((int)blk[0] + 1) >> 1) + add) >> shift;
+        for (int o = lane; o < NN; o += 64) out[o] = (short)v;
+    } else {                                               // transform_skip :139-163, transquant bypass, + rdpcm :114-136
+        const bool skip = kind == OHEVC_TU_SKIP || kind == OHEVC_TU_SKIP_RDPCM_H || kind == OHEVC_TU_SKIP_RDPCM_V;
+        const bool vert = kind == OHEVC_TU_SKIP_RDPCM_V || kind == OHEVC_TU_BYPASS_RDPCM_V;
+        const bool horz = kind == OHEVC_TU_SKIP_RDPCM_H || kind == OHEVC_TU_BYPASS_RDPCM_H;
+        const int shift = 15 - bit_depth - log2;
+        for (int o = lane; o < NN; o += 64) {
+            int v = blk[o];
+            if (skip) v = shift > 0 ? (v + (1 << (shift - 1))) >> shift : (int)(short)(v << -shift);
+            out[o] = (short)v;
+        }
+        CROSS_SYNC();
+        if ((vert || horz) && lane < N) {                  // running sums with the reference's int16 wrap-around
+            int acc = 0;
+            for (int i = 0; i < N; i++) {
+                const int o = horz ? lane * N + i : i * N + lane;
+                acc = (int)(short)(acc + out[o]);
+                out[o] = (short)acc;
+            }
+        }
+    }
+    CROSS_SYNC();
+}
+
+template <typename Pixel>
+__device__ __forceinline__ void tu_cross_body(unsigned char *lds, int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                              int log2, const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ji = wg * 2 + wave;
+    if (wave >= 2 || ji >= njobs) return;                   // wave-uniform; only wave-level synchronisation below
+    static_assert(4 * TuLayout<5>::WAVE_BYTES >= 2 * 3 * 32 * 32 * 2, "two blocks x three int16 tiles must fit the workgroup's LDS");
+    short *tile = reinterpret_cast<short *>(lds + wave * (2 * TuLayout<5>::WAVE_BYTES));
+    short *tmp = tile, *ry = tile + 1024, *rc = tile + 2048;
+    const ohevc_tu_job jb = jobs[ji];
+    const int N = 1 << log2, NN = N * N;
+    const int kind_c = jb.reserved0 & 15, kind_y = jb.reserved0 >> 4, scale = jb.dc;
+    residual_generic(kind_y, log2, coeffs + jb.reserved1, bit_depth, tmp, ry, lane);
+    if (kind_c != 15) residual_generic(kind_c, log2, coeffs + jb.coeff_off, bit_depth, tmp, rc, lane);
+    unsigned char *base = PLANE_PTR3(planes, jb.plane) + (size_t)jb.y * PLANE_STRIDE3(planes, jb.plane) + (size_t)jb.x * sizeof(Pixel);
+    const int stride = PLANE_STRIDE3(planes, jb.plane), maxv = (1 << bit_depth) - 1;
+    for (int o = lane; o < NN; o += 64) {
+        const int own = kind_c != 15 ? (int)rc[o] : 0;
+        const int res = (int)(short)(own + ((scale * (int)ry[o]) >> 3));            // hevc_cabac.c:1946 / hevc.c:1326 (int16 store)
+        Pixel *px = reinterpret_cast<Pixel *>(base + (size_t)(o >> log2) * stride) + (o & (N - 1));
+        const int v = (int)*px + res;                                                // transform_add, hevcdsp_template.c:45-111
+        *px = (Pixel)(v < 0 ? 0 : v > maxv ? maxv : v);
+    }
+}
+
+// one workgroup of a (size, kind) bin: the dispatch shared by the segmented launch and the level executor
+template <typename Pixel>
+__device__ __forceinline__ void tu_dispatch(unsigned char *lds, int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ j, int n, int log2, int kind,
+                                            const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    if (kind == OHEVC_TU_IDCT && log2 == 5)      tu_idct_add_body<5, Pixel, 16 + 128>(lds, wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_IDCT && log2 == 4) tu_idct_add_body<4, Pixel, 16 + 128>(lds, wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_IDCT && log2 == 3) tu_idct_add_body<3, Pixel, 1>(lds, wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_IDCT)              tu_4x4_body<Pixel, false>(wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_DST4)              tu_4x4_body<Pixel, true>(wg, planes, j, n, coeffs, bit_depth);
+    else if (kind == OHEVC_TU_CROSS)             tu_cross_body<Pixel>(lds, wg, planes, j, n, log2, coeffs, bit_depth);
+    else if (log2 == 2)                          tu_rows_body<2, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    else if (log2 == 3)                          tu_rows_body<3, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    else if (log2 == 4)                          tu_rows_body<4, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    else                                         tu_rows_body<5, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+}
+
 // ------------------------------------------------------------------ one launch for a mix of sizes and kinds
 // A frame's residuals come in up to 4 sizes x 10 kinds.  Launching each (size, kind) bin separately costs a kernel
 // boundary per bin (x every intra dependency level); instead the host passes a small segment table and every workgroup
@@ -655,16 +769,7 @@ __global__ __launch_bounds__(256) void tu_multi_kernel(PlaneSet planes, TuSegTab
     int s = 0;
     while (s + 1 < tab.nsegs && (int)blockIdx.x >= tab.first_wg[s + 1]) s++;      // wave-uniform scan, <= 40 entries
     const int wg = blockIdx.x - tab.first_wg[s], log2 = tab.log2[s], kind = tab.kind[s], n = tab.njobs[s];
-    const ohevc_tu_job *j = jobs + tab.first_job[s];
-    if (kind == OHEVC_TU_IDCT && log2 == 5)      tu_idct_add_body<5, Pixel, 16 + 128>(lds, wg, planes, j, n, coeffs, bit_depth);
-    else if (kind == OHEVC_TU_IDCT && log2 == 4) tu_idct_add_body<4, Pixel, 16 + 128>(lds, wg, planes, j, n, coeffs, bit_depth);
-    else if (kind == OHEVC_TU_IDCT && log2 == 3) tu_idct_add_body<3, Pixel, 1>(lds, wg, planes, j, n, coeffs, bit_depth);
-    else if (kind == OHEVC_TU_IDCT)              tu_4x4_body<Pixel, false>(wg, planes, j, n, coeffs, bit_depth);
-    else if (kind == OHEVC_TU_DST4)              tu_4x4_body<Pixel, true>(wg, planes, j, n, coeffs, bit_depth);
-    else if (log2 == 2)                          tu_rows_body<2, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
-    else if (log2 == 3)                          tu_rows_body<3, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
-    else if (log2 == 4)                          tu_rows_body<4, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
-    else                                         tu_rows_body<5, Pixel>(wg, planes, j, n, coeffs, bit_depth, kind);
+    tu_dispatch<Pixel>(lds, wg, planes, jobs + tab.first_job[s], n, log2, kind, coeffs, bit_depth);
 }
 
 // ------------------------------------------------------------------ intra dependency levels in ONE launch
@@ -737,17 +842,7 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
             const int ji = local * 4 + wave;
             if (ji < ph.njobs) intra_body<Pixel, true>(ish[wave], lane, planes, intra_jobs[ph.first_job + ji], bit_depth, cips);
         } else {
-            const ohevc_tu_job *j = tu_jobs + ph.first_job;
-            const int log2 = ph.log2_size, kind = ph.kind, n = ph.njobs;
-            if (kind == OHEVC_TU_IDCT && log2 == 5)      tu_idct_add_body<5, Pixel, 16 + 128>(lds, local, planes, j, n, coeffs, bit_depth);
-            else if (kind == OHEVC_TU_IDCT && log2 == 4) tu_idct_add_body<4, Pixel, 16 + 128>(lds, local, planes, j, n, coeffs, bit_depth);
-            else if (kind == OHEVC_TU_IDCT && log2 == 3) tu_idct_add_body<3, Pixel, 1>(lds, local, planes, j, n, coeffs, bit_depth);
-            else if (kind == OHEVC_TU_IDCT)              tu_4x4_body<Pixel, false>(local, planes, j, n, coeffs, bit_depth);
-            else if (kind == OHEVC_TU_DST4)              tu_4x4_body<Pixel, true>(local, planes, j, n, coeffs, bit_depth);
-            else if (log2 == 2)                          tu_rows_body<2, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
-            else if (log2 == 3)                          tu_rows_body<3, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
-            else if (log2 == 4)                          tu_rows_body<4, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
-            else                                         tu_rows_body<5, Pixel>(local, planes, j, n, coeffs, bit_depth, kind);
+            tu_dispatch<Pixel>(lds, local, planes, tu_jobs + ph.first_job, ph.njobs, ph.log2_size, ph.kind, coeffs, bit_depth);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // release inside the XCD: this wavefront's stores sit in the shared L2 ...
         __syncthreads();                                       // (also: everyone has read s_ticket before wave 0 rewrites it)
@@ -837,6 +932,10 @@ extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, in
     OHEVC_REQUIRE(kind != OHEVC_TU_DST4 || log2_size == 2, "DST is 4x4 only");
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
+    if (kind == OHEVC_TU_CROSS) {                           // generic two-blocks-per-workgroup body lives in the segmented kernel
+        const ohevc_tu_segment sg = { log2_size, kind, 0, njobs };
+        return ohevc_dev_tu_multi(planes, bit_depth, &sg, 1, jobs, coeffs, stream);
+    }
     OHEVC_REQUIRE(jobs != nullptr, "jobs");
     OHEVC_REQUIRE(kind == OHEVC_TU_DC || coeffs != nullptr, "coeffs");
     OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
@@ -854,6 +953,7 @@ static int tu_workgroups(int log2, int kind, int n)
 {
     if (kind == OHEVC_TU_IDCT && log2 >= 3) { const int per_wg = 4 * (64 >> log2); return (n + per_wg - 1) / per_wg; }
     if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) return (n + 255) / 256;
+    if (kind == OHEVC_TU_CROSS) return (n + 1) / 2;
     return (int)((((long long)n << log2) + 255) / 256);
 }
 
@@ -874,6 +974,7 @@ extern "C" int ohevc_dev_tu_multi(const ohevc_plane planes[3], int bit_depth, co
         const ohevc_tu_segment &sg = segs[i];
         OHEVC_REQUIRE(sg.log2_size >= 2 && sg.log2_size <= 5 && sg.kind < OHEVC_TU_NKINDS && sg.njobs >= 0, "bad segment");
         OHEVC_REQUIRE(sg.kind != OHEVC_TU_DST4 || sg.log2_size == 2, "DST is 4x4 only");
+        OHEVC_REQUIRE(sg.kind != OHEVC_TU_CROSS || coeffs != nullptr, "coeffs");
         if (sg.njobs == 0) continue;
         const int k = tab.nsegs++;
         tab.first_wg[k] = wgs; tab.first_job[k] = sg.first_job; tab.njobs[k] = sg.njobs;

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libohevc_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_NODEV, ERR_STATE = 0, -1, -2, -3, -4
-TU_IDCT, TU_DC, TU_DST4, TU_SKIP, TU_SKIP_RDPCM_H, TU_SKIP_RDPCM_V, TU_BYPASS, TU_BYPASS_RDPCM_H, TU_BYPASS_RDPCM_V, TU_PCM = range(10)
+TU_IDCT, TU_DC, TU_DST4, TU_SKIP, TU_SKIP_RDPCM_H, TU_SKIP_RDPCM_V, TU_BYPASS, TU_BYPASS_RDPCM_H, TU_BYPASS_RDPCM_V, TU_PCM, TU_CROSS = range(11)
 
 
 class OhevcError(RuntimeError):
@@ -160,7 +160,7 @@ class SaoBypass(C.Structure):
                 ("chroma_hshift", C.c_int32), ("chroma_vshift", C.c_int32), ("exact_reference", C.c_int32)]
 
 
-EXPORTED_SYMBOLS += ["ohevc_dev_sao_batch_bypass", "ohevc_frame_set_bypass_map", "ohevc_tables_set_bypass_map", "ohevc_tables_set_concurrent"]
+EXPORTED_SYMBOLS += ["ohevc_dev_sao_batch_bypass", "ohevc_frame_set_bypass_map", "ohevc_tables_set_bypass_map", "ohevc_tables_set_concurrent", "ohevc_tables_cross_component", "ohevc_rec_tu_cross"]
 
 
 def dev_sao_batch_bypass(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, map_ptr, map_stride, log2_min_pu_size,

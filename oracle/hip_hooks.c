@@ -197,6 +197,24 @@ void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts)
     ff_hevc_cabac_init(s, ctb_addr_ts);                             /* hevc_cabac.c */
 }
 
+/* Cross-component prediction: hls_cross_component_pred (hevc.c:1186-1200, static) = the two calls below; INTEGRATION.md adds
+ * `ohevc_tables_cross_component(lc->tu.res_scale_val)` at its end, here the renamed call sites rebuild the value. */
+static __thread int t_log2_res_scale_abs_plus1;
+int ohhip_log2_res_scale_abs(HEVCContext *s, int idx)
+{
+    int v = ff_hevc_log2_res_scale_abs(s, idx);                     /* hevc_cabac.c */
+    t_log2_res_scale_abs_plus1 = v;
+    if (v == 0)
+        ohevc_tables_cross_component(0);
+    return v;
+}
+int ohhip_res_scale_sign_flag(HEVCContext *s, int idx)
+{
+    int f = ff_hevc_res_scale_sign_flag(s, idx);
+    ohevc_tables_cross_component((1 << (t_log2_res_scale_abs_plus1 - 1)) * (1 - 2 * f));      /* hevc.c:1192-1193 */
+    return f;
+}
+
 /* ---- called by decoder_harness.c ---- */
 int ohdec_backend_open(void)
 {

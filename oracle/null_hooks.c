@@ -27,3 +27,5 @@ int  ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc) { return ff_hev
 void ohhip_report_progress(ThreadFrame *f, int progress, int field) { ff_thread_report_progress(f, progress, field); }
 void ohhip_await_progress(ThreadFrame *f, int progress, int field) { (void)f; (void)progress; (void)field; }
 void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts) { ff_hevc_cabac_init(s, ctb_addr_ts); }
+int  ohhip_log2_res_scale_abs(HEVCContext *s, int idx) { return ff_hevc_log2_res_scale_abs(s, idx); }
+int  ohhip_res_scale_sign_flag(HEVCContext *s, int idx) { return ff_hevc_res_scale_sign_flag(s, idx); }

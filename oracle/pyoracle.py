@@ -55,6 +55,21 @@ class OracleLib:
         self._f("tu_residual")(C.c_int(bd), C.c_int(kind), C.c_int(log2), _p(buf), C.c_int(n if col_limit is None else col_limit))
         return buf.reshape(n, n).copy()
 
+    def tu_cross(self, bd, log2, kind_c, coeffs_c, kind_y, coeffs_y, res_scale_val, plane, x, y):
+        """Cross-component prediction of one chroma block (RExt 4:4:4), in place on `plane`: the tail of
+        ff_hevc_hls_residual_coding (hevc_cabac.c:1942-1949: coeffs[i] += (res_scale_val * coeffs_y[i]) >> 3 on the int16
+        residuals, then transform_add) and, for a block without coded coefficients (kind_c None), hls_transform_unit
+        (hevc.c:1315-1330: coeffs[i] = (res_scale_val * coeffs_y[i]) >> 3).  coeffs_y are the luma block's coefficients,
+        whose residual the reference finds in lc->tu.coeffs[0] after the luma block's in-place inverse transform."""
+        n = 1 << log2
+        ry = self.tu_residual(bd, kind_y, log2, coeffs_y).astype(np.int32)
+        rc = self.tu_residual(bd, kind_c, log2, coeffs_c).astype(np.int32) if kind_c is not None else np.zeros((n, n), np.int32)
+        res = (rc + ((res_scale_val * ry) >> 3)).astype(np.int16)         # the reference stores into int16_t coeffs[]
+        buf = _aligned_copy(res.reshape(-1))
+        addr = plane.ctypes.data + y * plane.strides[0] + x * plane.itemsize
+        self._f("transform_add")(C.c_int(bd), C.c_int(log2), C.c_void_p(addr), C.c_ssize_t(plane.strides[0]), _p(buf))
+        return plane
+
     def tu_batch(self, bd, kind, log2, coeffs, plane, xy, col_limit=None, threads=0):
         """In-place on `plane` (2-D uint8/uint16 array): adds the residual of every block at its (x,y)."""
         n = 1 << log2

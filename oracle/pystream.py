@@ -221,6 +221,9 @@ class StreamParams:
     max_merge_cand: int = 5
     slices_per_picture: int = 1
     dependent_slices: int = 0
+    cross_component: int = 0     # PPS range extension: cross_component_prediction_enabled_flag (4:4:4 + rext only)
+    log2_max_ts: int = 2         # PPS range extension: log2_max_transform_skip_block_size (rext + transform_skip)
+    sao_offset_scale: Tuple[int, int] = (0, 0)   # PPS range extension: log2_sao_offset_scale_{luma,chroma} <= bit_depth - 10
     rext: int = 0                # range-extension SPS flags (implicit/explicit rdpcm, ts rotation/context, rice adaptation)
     gop: str = "lowdelay_b"      # intra | lowdelay_p | lowdelay_b | random_access
     gop_size: int = 8
@@ -415,7 +418,18 @@ def write_pps(p: StreamParams) -> bytes:
     b.u(1, 0)                     # lists_modification_present
     b.ue(p.log2_parallel_merge_level - 2)
     b.u(1, 0)                     # slice header extension
-    b.u(1, 0)                     # pps extension
+    if p.rext and (p.cross_component or p.log2_max_ts > 2 or any(p.sao_offset_scale)):
+        b.u(1, 1)                 # pps_extension_present_flag
+        b.u(1, 1)                 # pps_range_extensions_flag (hevc_ps.c:2421-2428, :2086-2150)
+        b.u(7, 0)
+        if p.transform_skip:
+            b.ue(p.log2_max_ts - 2)
+        b.u(1, p.cross_component)
+        b.u(1, 0)                 # chroma_qp_offset_list_enabled_flag ("not yet implemented" in the reference)
+        b.ue(p.sao_offset_scale[0])
+        b.ue(p.sao_offset_scale[1])
+    else:
+        b.u(1, 0)                 # pps extension
     b.trailing()
     return nal(NAL_PPS, b.bytes())
 

@@ -109,3 +109,43 @@ def test_intra_pred_constrained(oracle, bd):
         torch.cuda.synchronize()
         for pl in range(3):
             assert np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]), (it, log2, c_idx, mode, cands, x0, y0, lpu, pl)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_pred_constrained_structured_maps(oracle, bd):
+    """Same check with intra/inter maps made of coding-unit sized patches on a wider picture (what real streams look like:
+    long runs of non-intra neighbours next to fully intra ones), all mismatches reported."""
+    rng = np.random.default_rng(5 + bd)
+    W, H = 448, 232
+    bad = []
+    for it in range(500):
+        log2 = int(rng.integers(2, 6)); n = 1 << log2
+        c_idx = int(rng.integers(0, 3)); sh = 1 if c_idx else 0
+        nl = n << sh
+        x0 = int(rng.integers(0, (W - nl) // nl + 1)) * nl; y0 = int(rng.integers(1, (H - nl) // nl + 1)) * nl
+        mode = int(rng.integers(0, 35)) if it % 3 else 1
+        cands = [int(rng.random() < 0.85) for _ in range(5)]
+        if x0 == 0: cands[0] = cands[1] = cands[2] = 0
+        if x0 + nl >= W: cands[4] = 0
+        if y0 + nl >= H: cands[0] = 0
+        lpu = int(rng.choice([2, 3]))
+        pw, ph = (W + (1 << lpu) - 1) >> lpu, (H + (1 << lpu) - 1) >> lpu
+        g = int(rng.choice([1, 2, 4, 8, 16]))
+        coarse = rng.random((ph // g + 1, pw // g + 1)) < float(rng.choice([0.2, 0.5, 0.8]))
+        is_intra = np.ascontiguousarray(np.kron(coarse, np.ones((g, g)))[:ph, :pw].astype(np.uint8))
+        is_intra[y0 >> lpu:((y0 + nl - 1) >> lpu) + 1, x0 >> lpu:((x0 + nl - 1) >> lpu) + 1] = 1
+        planes = [rng.integers(0, 1 << bd, size=(H + 8, W + 8)).astype(G.pixdt(bd)) for _ in range(3)]
+        strong = int(rng.random() < 0.7)
+        want = [p.copy() for p in planes]
+        oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1, strong=strong, smoothing_disabled=0,
+                          log2_ctb_size=6, log2_min_tb_size=2, log2_min_pu_size=lpu, constrained=1, is_intra=is_intra)
+        geom = L.IntraGeom(W, H, 1, 6, 2, strong, 0, 1)
+        job, cip = L.intra_make_job_cip(geom, lpu, is_intra, x0, y0, log2, c_idx, mode, cands)
+        d = [G.to_dev(p) for p in planes]
+        d_jobs = G.to_dev(job); d_cip = G.to_dev(cip)
+        L.dev_intra_batch_cip(G.planes3(d), bd, d_jobs.data_ptr(), 1, d_cip.data_ptr(), G.stream())
+        torch.cuda.synchronize()
+        for pl in range(3):
+            if not np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]):
+                bad.append((it, log2, c_idx, mode, cands, x0, y0, lpu, g, int(job["flags"][0]), int(job["flags2"][0])))
+    assert not bad, (len(bad), bad[:8])

@@ -13,13 +13,13 @@ def grid_xy(nblk, n, per_row, x0=0, y0=0):
     return np.array([[x0 + (i % per_row) * n, y0 + (i // per_row) * n] for i in range(nblk)], np.int32)
 
 
-def check_batch(oracle, bd, log2, kind, nblk, amp, seed, per_row=7):
+def check_batch(oracle, bd, log2, kind, nblk, amp, seed, per_row=7, pixel_range=None):
     import gpu_util as G
     rng = np.random.default_rng(seed)
     n = 1 << log2
     rows = (nblk + per_row - 1) // per_row
     W = ((per_row * n + 16 + 15) // 16) * 16
-    plane = rng.integers(0, 1 << bd, size=(max(rows, 1) * n + 4, W)).astype(G.pixdt(bd))
+    plane = rng.integers(0, pixel_range or (1 << bd), size=(max(rows, 1) * n + 4, W)).astype(G.pixdt(bd))
     xy = grid_xy(nblk, n, per_row, x0=0, y0=0)
     coeffs = rng.integers(-amp, amp, size=(nblk, n, n)).astype(np.int16)
     dcs = coeffs[:, 0, 0].copy() if kind == po.TU_DC else None
@@ -62,6 +62,56 @@ def test_dst_and_other_kinds(oracle, bd):
         for kind in KINDS_ANY:
             check_batch(oracle, bd, log2, kind, 37, 1 << 15, seed=bd * 7 + log2 + kind)
             check_batch(oracle, bd, log2, kind, 130, 300, seed=bd * 7 + log2 + kind + 1)
+
+
+def test_prediction_samples_above_the_legal_range(oracle):
+    """16-bit pixel storage can hold values no legal picture has; the reference's constrained-intra substitution produces
+    them (0x8080 fill, hevcpred_template.c:159-161) and transform_add reads dst as uint16 (hevcdsp_template.c:45-111):
+    clip(pred + res) must treat the prediction as unsigned up to 65535."""
+    for bd in (10, 12):
+        for log2 in (2, 3, 4, 5):
+            for kind in [po.TU_IDCT, po.TU_DC, po.TU_SKIP, po.TU_BYPASS_RDPCM_H] + ([po.TU_DST4] if log2 == 2 else []):
+                check_batch(oracle, bd, log2, kind, 61, 1 << 15, seed=bd + log2 + kind, pixel_range=1 << 16)
+                check_batch(oracle, bd, log2, kind, 61, 600, seed=bd + log2 + kind + 50, pixel_range=1 << 16)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_cross_component_prediction(oracle, bd):
+    """OHEVC_TU_CROSS: chroma residual = own residual + (res_scale_val * luma residual) >> 3 with every pairing of residual
+    kinds, including chroma blocks without coded coefficients (hevc.c:1291-1365, hevc_cabac.c:1942-1949)."""
+    import gpu_util as G
+    from openhevc_amd import lib as L
+    rng = np.random.default_rng(40 + bd)
+    kinds_any = [po.TU_IDCT, po.TU_DC, po.TU_SKIP, po.TU_SKIP_RDPCM_H, po.TU_SKIP_RDPCM_V, po.TU_BYPASS, po.TU_BYPASS_RDPCM_H,
+                 po.TU_BYPASS_RDPCM_V]
+    for log2 in (2, 3, 4, 5):
+        n = 1 << log2
+        nblk, per_row = 45, 9
+        planes = [rng.integers(0, 1 << bd, size=(5 * n, per_row * n + 16)).astype(G.pixdt(bd)) for _ in range(3)]
+        want = [p.copy() for p in planes]
+        jobs = np.zeros(nblk, L.TU_JOB)
+        arena = []
+        for i in range(nblk):
+            x, y, pl = (i % per_row) * n, (i // per_row) * n, 1 + i % 2
+            ky = int(rng.choice(kinds_any + ([po.TU_DST4] if log2 == 2 else [])))
+            kc = None if i % 5 == 0 else int(rng.choice(kinds_any))
+            amp = int(rng.choice([30, 600, 1 << 15]))
+            cy = rng.integers(-amp, amp, size=(n, n)).astype(np.int16)
+            cc = rng.integers(-amp, amp, size=(n, n)).astype(np.int16)
+            scale = int(rng.choice([1, 2, 4, 8])) * int(rng.choice([-1, 1]))
+            oracle.tu_cross(bd, log2, kc, cc, ky, cy, scale, want[pl], x, y)
+            jobs[i]["x"], jobs[i]["y"], jobs[i]["plane"] = x, y, pl
+            jobs[i]["reserved0"] = (15 if kc is None else kc) | (ky << 4)
+            jobs[i]["dc"] = scale
+            jobs[i]["reserved1"] = len(arena) * n * n
+            arena.append(cy)
+            if kc is not None:
+                jobs[i]["coeff_off"] = len(arena) * n * n
+                arena.append(cc)
+        got = G.run_tu(bd, log2, L.TU_CROSS, planes, jobs, np.stack(arena))
+        for pl in range(3):
+            bad = np.argwhere(got[pl] != want[pl])
+            assert bad.size == 0, f"bd={bd} log2={log2} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
 
 
 def test_empty_batch_and_three_planes(oracle):

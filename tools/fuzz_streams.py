@@ -31,6 +31,15 @@ def random_params(rng):
     if rng.integers(0, 4) == 0:                      # RExt chroma formats
         kw["chroma_format"] = int(rng.choice([2, 3]))
         kw["rext"] = 1
+    if kw["rext"] and rng.integers(0, 2):            # PPS range extension
+        kw["log2_max_ts"] = int(rng.integers(2, 6))
+        if kw.get("chroma_format") == 3:
+            kw["cross_component"] = 1
+        if rng.integers(0, 4) == 0:
+            kw["bit_depth"] = 12
+            kw["sao_offset_scale"] = (int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+            if "pcm" in kw:
+                kw["pcm"] = min(kw["pcm"], 12)
     if rng.integers(0, 5) == 0:                      # lossless CUs / PCM outside the loop filters: restore_tqb_pixels
         kw["transquant_bypass"] = 1
         kw["probs"] = dict(transquant_bypass=float(rng.uniform(0.05, 0.4)))
@@ -73,6 +82,11 @@ def main():
         try:
             aus, gen_frames = ps.generate(ps.StreamParams(**kw))
             ref = ps.decode_stream("c", aus)
+            same_gen = all(np.array_equal(x, y) for fa, fb in zip(ref, gen_frames) for x, y in zip(fa, fb))
+            if thread_type == 2:
+                # with slice threads the reference's own output differs (reproducibly) from its single-threaded output on
+                # some RExt + WPP streams (observed: persistent_rice_adaptation streams): compare like with like
+                ref = ps.decode_stream("c", aus, threads, thread_type)
         except Exception as e:      # an illegal random combination: not a back-end problem
             gen_fail += 1
             continue
@@ -80,9 +94,8 @@ def main():
         try:
             hip = ps.decode_stream("hip", aus, threads, thread_type)
             ok = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
-            same_gen = all(np.array_equal(x, y) for fa, fb in zip(ref, gen_frames) for x, y in zip(fa, fb))
         except Exception as e:
-            ok, same_gen = False, True
+            ok = False
             print("EXC", e)
         if not ok or not same_gen:
             bad += 1
