@@ -190,15 +190,16 @@ template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_
     if (scale) {
         // The host has already mixed its idea of the luma residual into this buffer -- computed from lc->tu.coeffs[0], which
         // behind recording tables still holds the RAW luma coefficients y:
-        //   coded chroma block   c' = (int16)(c + ((scale * y) >> 3))      hevc_cabac.c:1942-1948  -> undo it, exactly (mod 2^16)
-        //   no coded coefficients c' = (scale * y) >> 3, no transform call  hevc.c:1315-1330        -> nothing of the block's own
+        //   coded chroma block    c' = (int16)(c + ((scale * y) >> 3))     hevc_cabac.c:1942-1948
+        //   no coded coefficients c' = (scale * y) >> 3, no transform call  hevc.c:1315-1330
+        // Undo it, exactly (arithmetic mod 2^16): what is left are the block's own coefficients -- all zero in the second
+        // case, which like a transquant-bypass block arrives without a pending transform and is recorded as one.
         const int16_t *y = tl_pend.luma_coeffs;
         if (!y || tl_pend.luma_log2 != LOG2 || y == coeffs) { fail(OHEVC_ERR_STATE); return; }
         int16_t own[1 << (2 * LOG2)];
-        if (pending)
-            for (int i = 0; i < (1 << (2 * LOG2)); i++) own[i] = (int16_t)(coeffs[i] - ((scale * y[i]) >> 3));
+        for (int i = 0; i < (1 << (2 * LOG2)); i++) own[i] = (int16_t)(coeffs[i] - ((scale * y[i]) >> 3));
         Guard guard_(tl_state);
-        rc = ohevc_rec_tu_cross(tl_ctx, l.plane, l.x, l.y, LOG2, pending ? kind : -1, pending ? own : nullptr, tl_pend.luma_kind, y, scale, 1);
+        rc = ohevc_rec_tu_cross(tl_ctx, l.plane, l.x, l.y, LOG2, kind, own, tl_pend.luma_kind, y, scale, 1);
     } else {
         Guard guard_(tl_state);
         rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);

@@ -87,7 +87,7 @@ def test_cross_component_prediction(oracle, bd):
     for log2 in (2, 3, 4, 5):
         n = 1 << log2
         nblk, per_row = 45, 9
-        planes = [rng.integers(0, 1 << bd, size=(5 * n, per_row * n + 16)).astype(G.pixdt(bd)) for _ in range(3)]
+        planes = [rng.integers(0, 1 << bd, size=(5 * n, ((per_row * n + 31) // 16) * 16)).astype(G.pixdt(bd)) for _ in range(3)]
         want = [p.copy() for p in planes]
         jobs = np.zeros(nblk, L.TU_JOB)
         arena = []

@@ -67,13 +67,16 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t0 = time.time()
-    n = bad = gen_fail = 0
+    n = bad = gen_fail = unstable = 0
     while time.time() - t0 < budget:
         kw = random_params(rng)
         threads = int(rng.choice([1, 1, 3, 8]))          # frame threads: one context per thread, shared picture store
         thread_type = 1
-        if threads > 1 and (kw.get("wpp") or kw.get("tiles")) and rng.integers(0, 2):
-            thread_type = 2                              # slice threads: WPP rows / tiles of one picture record concurrently
+        # slice threads: WPP rows / tiles of one picture record concurrently.  Not with 16x16 CTBs: there the reference's
+        # one-CTB filter lag (ohevc_hip.h, OHEVC_SAO_LAG_*) makes its row threads race on the chroma columns they share (a row
+        # reports progress BEFORE it filters, hevc.c:2800-2815), so its own output depends on timing
+        if threads > 1 and (kw.get("wpp") or kw.get("tiles")) and kw["log2_ctb"] > 4 and rng.integers(0, 2):
+            thread_type = 2
         # the reference never clears s->is_pcm between pictures (hevc_frame_start, hevc.c:3197-3215, has no memset for it):
         # with the restore_tqb_pixels tools its OWN output then depends on which thread decoded which picture and even
         # varies from run to run with frame threads (observed here), so those streams are compared single-threaded
@@ -84,9 +87,14 @@ def main():
             ref = ps.decode_stream("c", aus)
             same_gen = all(np.array_equal(x, y) for fa, fb in zip(ref, gen_frames) for x, y in zip(fa, fb))
             if thread_type == 2:
-                # with slice threads the reference's own output differs (reproducibly) from its single-threaded output on
-                # some RExt + WPP streams (observed: persistent_rice_adaptation streams): compare like with like
-                ref = ps.decode_stream("c", aus, threads, thread_type)
+                # With slice threads the reference PARSES some streams differently from its own single-threaded run (seen
+                # with RExt persistent_rice_adaptation + WPP and with dependent slices + WPP: reproducible, other job counts,
+                # other pictures) and then conceals on host pixels no table back-end sees.  Such streams say nothing about
+                # the back-end: only streams the reference decodes identically in both modes are compared.
+                ref_t = ps.decode_stream("c", aus, threads, thread_type)
+                if not (len(ref_t) == len(ref) and all(np.array_equal(x, y) for fa, fb in zip(ref, ref_t) for x, y in zip(fa, fb))):
+                    unstable += 1
+                    continue
         except Exception as e:      # an illegal random combination: not a back-end problem
             gen_fail += 1
             continue
@@ -100,7 +108,7 @@ def main():
         if not ok or not same_gen:
             bad += 1
             print("FAIL" if not ok else "GEN-MISMATCH", "threads", threads, "type", thread_type, json.dumps(kw))
-    print(json.dumps(dict(streams=n, failed=bad, rejected_by_generator=gen_fail, seconds=round(time.time() - t0, 1))))
+    print(json.dumps(dict(streams=n, failed=bad, rejected_by_generator=gen_fail, reference_differs_with_slice_threads=unstable, seconds=round(time.time() - t0, 1))))
     sys.exit(1 if bad else 0)
 
 
