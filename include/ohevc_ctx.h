@@ -53,6 +53,11 @@ int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff
 int  ohevc_pic_planes(ohevc_ctx *ctx, int slot, ohevc_plane out[3]);     /* device views (e.g. for an RCCL broadcast) */
 int  ohevc_pic_info(ohevc_ctx *ctx, int slot, int *width, int *height, int *chroma_format_idc, int *bit_depth);
 
+/* SHVC: resample picture src_slot (a base-layer picture of the store) into picture dst_slot, the enhancement layer's
+ * inter-layer reference picture -- what the 13 upsample_* slots do in the reference (ohevc_upsample_params in ohevc_hip.h).
+ * Ordered against the frames that write src / still read dst's memory like a frame of its own. */
+int  ohevc_pic_upsample(ohevc_ctx *ctx, int dst_slot, int src_slot, const ohevc_upsample_params *params);
+
 /* ---- per-frame recording */
 int  ohevc_frame_begin(ohevc_ctx *ctx, int slot);
 /* transform_add[..] preceded by its inverse transform (kind = OHEVC_TU_*).  `intra` != 0 when the block was just

@@ -302,6 +302,29 @@ int  ohevc_set_device(int device);
 const char *ohevc_tu_kernel_name(int bit_depth, int log2_size, int kind);
 const char *ohevc_version(void);
 
+/* ---- 2.7 SHVC inter-layer up-sampling: replaces upsample_base_layer_frame and upsample_filter_block_{luma,cr}_{h,v}[3]
+ * (hevcdsp.h:106-123; hevcdsp_template.c:1835-2438) together with vdsp.emulated_edge_up_{h,v} (videodsp_template.c:103-166):
+ * the base-layer picture is resampled into the enhancement layer's inter-layer reference picture (4:2:0 planes).
+ * The reference's position / phase rules live in host-built maps (one entry per output column and row); the kernel is a
+ * separable 8-tap (luma) / 4-tap (chroma) gather filter with the reference's int16 intermediate and fixed 12-bit rounding. */
+typedef struct ohevc_upsample_params {
+    int32_t el_width, el_height, bl_width, bl_height;          /* luma samples (FrameEL / FrameBL coded size) */
+    int32_t win_left, win_right, win_top, win_bottom;          /* sps->scaled_ref_layer_window[ref_layer] (HEVCWindow, hevc.h:384-389) */
+    int32_t add_x_luma, add_y_luma, scale_x_luma, scale_y_luma;            /* UpsamplInf, hevc.h:347-357 (set_sps, hevc.c:445-499) */
+    int32_t add_x_chroma, add_y_chroma, scale_x_chroma, scale_y_chroma;
+    int32_t idx;                                               /* UpsamplInf.idx: 0 general, 1 x2, 2 x1.5 (3 = SNR: a copy, not here) */
+    int32_t block_slots;                                       /* 0: upsample_base_layer_frame; 1: the per-block slots [idx], whose x2 /
+                                                                  x1.5 variants use fixed phase patterns (shipped build: hevc.h:117) */
+} ohevc_upsample_params;
+typedef struct ohevc_upsample_tap { int16_t pos; uint8_t phase; uint8_t reserved; } ohevc_upsample_tap;   /* centre tap, phase 0..15 */
+/* HOST helper: maps of one plane (0 luma, 1/2 chroma): cols[w], col_of[w], rows[h] for the plane's EL size; src_cols / src_rows =
+ * the base-layer extent the reference clamps to */
+int ohevc_upsample_make_maps(const ohevc_upsample_params *p, int plane, ohevc_upsample_tap *cols, int16_t *col_of,
+                             ohevc_upsample_tap *rows, int *src_cols, int *src_rows);
+/* one plane; cols / col_of / rows are DEVICE arrays as made above */
+int ohevc_dev_upsample_plane(const ohevc_plane *dst, const ohevc_plane *src, int bit_depth, int chroma, const ohevc_upsample_tap *cols,
+                             const int16_t *col_of, const ohevc_upsample_tap *rows, int src_cols, int src_rows, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

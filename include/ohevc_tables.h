@@ -28,6 +28,10 @@ struct AVFrame;
 struct UpsamplInf;
 struct HEVCWindow;
 
+/* HEVCWindow (hevc.h:384-389) and UpsamplInf (hevc.h:347-357) */
+typedef struct ohevc_HEVCWindow { int left_offset, right_offset, top_offset, bottom_offset; } ohevc_HEVCWindow;
+typedef struct ohevc_UpsamplInf { int addXLum, addYLum, scaleXLum, scaleYLum, addXCr, addYCr, scaleXCr, scaleYCr, idx; } ohevc_UpsamplInf;
+
 /* SAOParams, libavcodec/hevc.h:514-523 */
 typedef struct ohevc_SAOParams {
     uint8_t offset_abs[3][4];
@@ -83,15 +87,31 @@ typedef struct ohevc_HEVCDSPContext {
     void (*hevc_v_loop_filter_luma_c)(uint8_t *pix, ptrdiff_t stride, int beta, int *tc, uint8_t *no_p, uint8_t *no_q);
     void (*hevc_h_loop_filter_chroma_c)(uint8_t *pix, ptrdiff_t stride, int *tc, uint8_t *no_p, uint8_t *no_q);
     void (*hevc_v_loop_filter_chroma_c)(uint8_t *pix, ptrdiff_t stride, int *tc, uint8_t *no_p, uint8_t *no_q);
-    /* SHVC inter-layer slots (hevcdsp.h:106-123): 1 + 4 x 3 pointers, never touched by this back-end */
-    void *shvc_upsample_slots[13];
+    /* SHVC inter-layer slots (hevcdsp.h:106-123).  upsample_base_layer_frame takes AVFrames: left as filled, the reference-side
+     * stub of INTEGRATION.md section 2b calls ohevc_tables_upsample_frame instead; the twelve block slots are overridden. */
+    void *upsample_base_layer_frame;
+    void (*upsample_filter_block_luma_h[3])(int16_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride, int x_EL, int x_BL,
+                                            int block_w, int block_h, int widthEL, const struct ohevc_HEVCWindow *Enhscal,
+                                            struct ohevc_UpsamplInf *up_info);
+    void (*upsample_filter_block_luma_v[3])(uint8_t *dst, ptrdiff_t dststride, int16_t *src, ptrdiff_t srcstride, int y_BL, int x_EL, int y_EL,
+                                            int block_w, int block_h, int widthEL, int heightEL, const struct ohevc_HEVCWindow *Enhscal,
+                                            struct ohevc_UpsamplInf *up_info);
+    void (*upsample_filter_block_cr_h[3])(int16_t *dst, ptrdiff_t dststride, uint8_t *src, ptrdiff_t srcstride, int x_EL, int x_BL,
+                                          int block_w, int block_h, int widthEL, const struct ohevc_HEVCWindow *Enhscal,
+                                          struct ohevc_UpsamplInf *up_info);
+    void (*upsample_filter_block_cr_v[3])(uint8_t *dst, ptrdiff_t dststride, int16_t *src, ptrdiff_t srcstride, int y_BL, int x_EL, int y_EL,
+                                          int block_w, int block_h, int widthEL, int heightEL, const struct ohevc_HEVCWindow *Enhscal,
+                                          struct ohevc_UpsamplInf *up_info);
 } ohevc_HEVCDSPContext;
 
 /* VideoDSPContext, libavcodec/videodsp.h:44-91 */
 typedef struct ohevc_VideoDSPContext {
     void (*emulated_edge_mc)(uint8_t *dst, const uint8_t *src, ptrdiff_t dst_linesize, ptrdiff_t src_linesize,
                              int block_w, int block_h, int src_x, int src_y, int w, int h);
-    void *emulated_edge_up_h, *emulated_edge_up_v;
+    int (*emulated_edge_up_h)(uint8_t *src, ptrdiff_t linesize, const struct ohevc_HEVCWindow *Enhscal, int block_w, int block_h,
+                              int bl_edge_left, int bl_edge_right, int shift);
+    int (*emulated_edge_up_v)(int16_t *src, ptrdiff_t linesize, const struct ohevc_HEVCWindow *Enhscal, int block_w, int block_h,
+                              int src_x, int bl_edge_up, int bl_edge_bottom, int wEL, int shift);
     void (*prefetch)(uint8_t *buf, ptrdiff_t stride, int h);
 } ohevc_VideoDSPContext;
 
@@ -121,6 +141,14 @@ int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
  * pps->transquant_bypass_enable_flag || (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag).  With
  * ohevc_tables_emulate_filter_lag on, the reference's partial restore is reproduced bit for bit (ohevc_sao_bypass.exact_reference) */
 int  ohevc_tables_set_bypass_map(ohevc_ctx *ctx, const uint8_t *is_pcm, int min_pu_width, int min_pu_height, int log2_min_pu_size);
+/* SHVC inter-layer up-sampling.  The twelve upsample_filter_block_* slots and emulated_edge_up_{h,v} are overridden: the first
+ * vertical-pass call that names an enhancement-layer picture since its registration / the last ohevc_tables_begin_frame
+ * resamples the WHOLE base-layer picture into it on the device (ohevc_pic_upsample, block-slot rules); later calls for the same
+ * picture find it done -- the reference's is_upsampled map (hevc.c:3221-3223) per picture instead of per CTB.  Both pictures must
+ * be registered (the inter-layer reference picture is a DPB frame of its own: ff_hevc_set_new_iter_layer_ref, hevc.c:3236).
+ * For builds that resample whole frames (upsample_base_layer_frame, hevc.c:3240-3242) the reference-side stub passes the two
+ * luma plane pointers here. */
+int  ohevc_tables_upsample_frame(const uint8_t *el_data0, const uint8_t *bl_data0, const ohevc_HEVCWindow *Enhscal, const ohevc_UpsamplInf *up_info);
 /* Cross-component prediction (RExt 4:4:4).  hls_cross_component_pred (hevc.c:1186-1200) decodes lc->tu.res_scale_val right
  * before each chroma component of a transform unit; the chroma residual then gets (res_scale_val * luma residual) >> 3
  * added on the host (hevc_cabac.c:1942-1948, hevc.c:1315-1330) -- from a luma residual that does not exist behind recording

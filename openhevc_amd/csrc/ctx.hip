@@ -126,7 +126,7 @@ struct ohevc_ctx {
     std::vector<uint16_t> level_map[3];
     int lm_w[3] = {}, lm_h[3] = {};
 
-    DevBuf d_jobs, d_coeffs, d_table;
+    DevBuf d_jobs, d_coeffs, d_table, d_upsample;
     PinnedBuf stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
@@ -219,6 +219,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->d_jobs.p) hipFree(c->d_jobs.p);
     if (c->d_coeffs.p) hipFree(c->d_coeffs.p);
     if (c->d_table.p) hipFree(c->d_table.p);
+    if (c->d_upsample.p) hipFree(c->d_upsample.p);
     if (c->stage.p) hipHostFree(c->stage.p);
     if (c->staged) hipEventDestroy(c->staged);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -337,6 +338,72 @@ extern "C" int ohevc_pic_info(ohevc_ctx *c, int slot, int *width, int *height, i
     if (height) *height = p->h;
     if (cfi) *cfi = p->cfi;
     if (bd) *bd = p->bd;
+    return OHEVC_OK;
+}
+
+// SHVC: resample picture src_slot (base layer) into picture dst_slot (the enhancement layer's inter-layer reference picture)
+// -- hevc_frame_start / ff_upsample_block, hevc.c:3240-3242, hevc_filter.c:1370-1395.  Ordered like a tiny frame of its own: waits
+// for whoever reconstructs src and for earlier users of dst's memory, publishes dst when done.
+extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, const ohevc_upsample_params *prm)
+{
+    Picture *d = get_pic(c, dst_slot), *sp = get_pic(c, src_slot);
+    OHEVC_REQUIRE(d != nullptr && sp != nullptr && prm != nullptr && dst_slot != src_slot, "bad picture slots");
+    OHEVC_REQUIRE(d->cfi == 1 && sp->cfi == 1 && d->bd == sp->bd, "inter-layer up-sampling is defined for 4:2:0 pictures of one bit depth");
+    OHEVC_REQUIRE(prm->el_width == d->w && prm->el_height == d->h && prm->bl_width <= sp->w && prm->bl_height <= sp->h, "parameters do not match the pictures");
+    if (c->dry) return OHEVC_OK;
+    {
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return sp->end_issued; })) {
+            set_error("base-layer picture %d was never completed by its decoding thread", src_slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (sp->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, sp->written, 0));
+        if (d->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, d->written, 0));
+        for (hipEvent_t e : d->readers) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+        d->readers.clear();
+        d->end_issued = false;
+    }
+    // maps of the three planes, one upload
+    std::vector<unsigned char> host;
+    size_t off_cols[3], off_colof[3], off_rows[3];
+    int src_cols[3], src_rows[3];
+    for (int pl = 0; pl < 3; pl++) {
+        const int w = d->planes[pl].width, h = d->planes[pl].height;
+        auto put = [&](size_t bytes) { size_t o = (host.size() + 15) & ~(size_t)15; host.resize(o + bytes); return o; };
+        off_cols[pl] = put((size_t)w * sizeof(ohevc_upsample_tap));
+        off_colof[pl] = put((size_t)w * sizeof(int16_t));
+        off_rows[pl] = put((size_t)h * sizeof(ohevc_upsample_tap));
+    }
+    for (int pl = 0; pl < 3; pl++) {
+        int rc = ohevc_upsample_make_maps(prm, pl, reinterpret_cast<ohevc_upsample_tap *>(host.data() + off_cols[pl]),
+                                          reinterpret_cast<int16_t *>(host.data() + off_colof[pl]),
+                                          reinterpret_cast<ohevc_upsample_tap *>(host.data() + off_rows[pl]), &src_cols[pl], &src_rows[pl]);
+        if (rc != OHEVC_OK) return rc;
+    }
+    if (host.size() > c->d_upsample.cap) {
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+        int rc = c->d_upsample.reserve(host.size());
+        if (rc != OHEVC_OK) return rc;
+    }
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_upsample.p, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
+    unsigned char *base = static_cast<unsigned char *>(c->d_upsample.p);
+    for (int pl = 0; pl < 3; pl++) {
+        int rc = ohevc_dev_upsample_plane(&d->planes[pl], &sp->planes[pl], d->bd, pl != 0, reinterpret_cast<const ohevc_upsample_tap *>(base + off_cols[pl]),
+                                          reinterpret_cast<const int16_t *>(base + off_colof[pl]),
+                                          reinterpret_cast<const ohevc_upsample_tap *>(base + off_rows[pl]), src_cols[pl], src_rows[pl], c->stream);
+        if (rc != OHEVC_OK) return rc;
+    }
+    hipEvent_t ev = c->ring[c->ring_next];
+    c->ring_next = (c->ring_next + 1) % 16;
+    OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));       // `host` (pageable) must outlive the copy; a once-per-picture operation
+    {
+        std::lock_guard<std::mutex> g(c->store->m);
+        d->written = ev;
+        if (std::find(sp->readers.begin(), sp->readers.end(), ev) == sp->readers.end()) sp->readers.push_back(ev);
+        d->end_issued = true;
+    }
+    c->store->cv.notify_all();
     return OHEVC_OK;
 }
 

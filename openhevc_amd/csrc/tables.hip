@@ -13,6 +13,7 @@
 //   * edge emulation: vdsp.emulated_edge_mc(buf, src - offset, ..., src_x, src_y, w, h) precedes the MC call that reads
 //     `buf + buf_offset` (hevc.c:1660-1675) -> it notes (picture, src_x, src_y) for that buffer and copies nothing; the
 //     MC kernel clamps coordinates instead.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -68,6 +69,7 @@ struct TablesState {
     // into this context at the same time; every recorder call then runs under `spin`
     bool concurrent = false;
     std::atomic_flag spin = ATOMIC_FLAG_INIT;
+    std::vector<int> upsampled;       // SHVC: enhancement-layer picture slots already resampled (cleared by begin_frame / registration)
     ohevc_HEVCDSPContext saved = {};  // the reference's own C slots (put_pcm is still executed on the host into scratch)
 };
 
@@ -82,6 +84,7 @@ struct Pending {
     // res_scale_val announced for the next chroma block (ohevc_tables_cross_component)
     const int16_t *luma_coeffs = nullptr;
     int luma_kind = -1, luma_log2 = 0, cross_scale = 0;
+    int up_bl_slot = -1;              // SHVC: base-layer picture named by the last horizontal-pass slot call
     const int16_t *bi_tmp = nullptr;  // first half of a bi-prediction
     int bi_slot = -1, bi_plane = 0, bi_sx = 0, bi_sy = 0, bi_mx = 0, bi_my = 0;
     struct Emu { const uint8_t *buf = nullptr; ptrdiff_t linesize = 0; int slot = -1, plane = 0, x = 0, y = 0; } emu[4];
@@ -408,6 +411,55 @@ void t_sao_edge1(uint8_t *dst, uint8_t *, ptrdiff_t, ptrdiff_t, ohevc_SAOParams 
     sao_record(dst, sao, borders, width, height, c_idx, OHEVC_SAO_EDGE, 1, ve, he, de);
 }
 
+// ------------------------------------------------------------------ SHVC inter-layer up-sampling
+// Call sequence (upsample_block_luma / upsample_block_mc, hevc_filter.c:1175-1310): emulated_edge_up_h on the base-layer frame,
+// the horizontal slot into a scratch buffer, emulated_edge_up_v on that buffer, the vertical slot into the inter-layer
+// reference picture.  The helpers' return values steer the caller's pointers, so they are reproduced; nothing is written.
+int t_emulated_edge_up_h(uint8_t *, ptrdiff_t, const ohevc_HEVCWindow *, int, int, int bl_edge_left, int, int shift)
+{
+    return bl_edge_left < shift ? 0 : 1;                      // videodsp_template.c:110-126
+}
+int t_emulated_edge_up_v(int16_t *, ptrdiff_t, const ohevc_HEVCWindow *, int, int, int, int bl_edge_up, int, int, int shift)
+{
+    return bl_edge_up < shift ? 0 : 1;                        // videodsp_template.c:141-165
+}
+
+void t_up_h(int16_t *, ptrdiff_t, uint8_t *src, ptrdiff_t, int, int, int, int, int, const ohevc_HEVCWindow *, ohevc_UpsamplInf *)
+{
+    Loc l;
+    tl_pend.up_bl_slot = -1;
+    if (!tl_ctx || !locate(src, l)) { fail(OHEVC_ERR_STATE); return; }
+    tl_pend.up_bl_slot = tl_state->pics[l.pic].slot;
+}
+
+int upsample_once(int el_slot, int bl_slot, const ohevc_HEVCWindow *w, const ohevc_UpsamplInf *u, int block_slots)
+{
+    Guard guard_(tl_state);
+    for (int sdone : tl_state->upsampled) if (sdone == el_slot) return OHEVC_OK;
+    int ew, eh, bw, bh, cfi, bd;
+    int rc = ohevc_pic_info(tl_ctx, el_slot, &ew, &eh, &cfi, &bd);
+    if (rc == OHEVC_OK) rc = ohevc_pic_info(tl_ctx, bl_slot, &bw, &bh, &cfi, &bd);
+    if (rc != OHEVC_OK) return rc;
+    ohevc_upsample_params p = {};
+    p.el_width = ew; p.el_height = eh; p.bl_width = bw; p.bl_height = bh;
+    p.win_left = w->left_offset; p.win_right = w->right_offset; p.win_top = w->top_offset; p.win_bottom = w->bottom_offset;
+    p.add_x_luma = u->addXLum; p.add_y_luma = u->addYLum; p.scale_x_luma = u->scaleXLum; p.scale_y_luma = u->scaleYLum;
+    p.add_x_chroma = u->addXCr; p.add_y_chroma = u->addYCr; p.scale_x_chroma = u->scaleXCr; p.scale_y_chroma = u->scaleYCr;
+    p.idx = u->idx; p.block_slots = block_slots;
+    rc = ohevc_pic_upsample(tl_ctx, el_slot, bl_slot, &p);
+    if (rc == OHEVC_OK) tl_state->upsampled.push_back(el_slot);
+    return rc;
+}
+
+void t_up_v(uint8_t *dst, ptrdiff_t, int16_t *, ptrdiff_t, int, int, int, int, int, int, int, const ohevc_HEVCWindow *w, ohevc_UpsamplInf *u)
+{
+    Loc l;
+    // dst is the BASE of the inter-layer reference picture's plane (the slot adds the block position itself, :1905,1947)
+    if (!tl_ctx || tl_pend.up_bl_slot < 0 || !locate(dst, l)) { fail(OHEVC_ERR_STATE); return; }
+    int rc = upsample_once(tl_state->pics[l.pic].slot, tl_pend.up_bl_slot, w, u, 1);
+    if (rc != OHEVC_OK) fail(rc);
+}
+
 std::map<const void *, std::weak_ptr<Registry>> g_registries;    // keyed by ohevc_ctx_store_id
 
 TablesState *state_of(ohevc_ctx *ctx, bool create)
@@ -459,6 +511,10 @@ extern "C" void ohevc_hevcdsp_init_hip(ohevc_HEVCDSPContext *c, int bit_depth)
                 c->put_hevc_qpel_bi[i][a][b] = t_bi;      c->put_hevc_epel_bi[i][a][b] = t_bi;
                 c->put_hevc_qpel_bi_w[i][a][b] = t_bi_w;  c->put_hevc_epel_bi_w[i][a][b] = t_bi_w;
             }
+    for (int i = 0; i < 3; i++) {
+        c->upsample_filter_block_luma_h[i] = t_up_h; c->upsample_filter_block_cr_h[i] = t_up_h;
+        c->upsample_filter_block_luma_v[i] = t_up_v; c->upsample_filter_block_cr_v[i] = t_up_v;
+    }
     c->hevc_h_loop_filter_luma = c->hevc_h_loop_filter_luma_c = t_h_luma;
     c->hevc_v_loop_filter_luma = c->hevc_v_loop_filter_luma_c = t_v_luma;
     c->hevc_h_loop_filter_chroma = c->hevc_h_loop_filter_chroma_c = t_h_chroma;
@@ -467,7 +523,10 @@ extern "C" void ohevc_hevcdsp_init_hip(ohevc_HEVCDSPContext *c, int bit_depth)
 
 extern "C" void ohevc_videodsp_init_hip(ohevc_VideoDSPContext *c, int)
 {
-    if (c) c->emulated_edge_mc = t_emulated_edge_mc;
+    if (!c) return;
+    c->emulated_edge_mc = t_emulated_edge_mc;
+    c->emulated_edge_up_h = t_emulated_edge_up_h;
+    c->emulated_edge_up_v = t_emulated_edge_up_v;
 }
 
 extern "C" int ohevc_tables_bind(ohevc_ctx *ctx)
@@ -476,6 +535,15 @@ extern "C" int ohevc_tables_bind(ohevc_ctx *ctx)
     tl_state = ctx ? state_of(ctx, true) : nullptr;
     tl_pend = Pending();
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_tables_upsample_frame(const uint8_t *el_data0, const uint8_t *bl_data0, const ohevc_HEVCWindow *w, const ohevc_UpsamplInf *u)
+{
+    Loc le, lb;
+    if (!tl_ctx || !w || !u || !locate(el_data0, le) || !locate(bl_data0, lb)) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
+    int rc = upsample_once(tl_state->pics[le.pic].slot, tl_state->pics[lb.pic].slot, w, u, 0);
+    if (rc != OHEVC_OK) fail(rc);
+    return rc;
 }
 
 extern "C" int ohevc_tables_cross_component(int res_scale_val)
@@ -524,6 +592,7 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
                     s->pics[i].slot = -1;
                 }
     }
+    s->upsampled.erase(std::remove(s->upsampled.begin(), s->upsampled.end(), slot), s->upsampled.end());
     if (trace) fprintf(stderr, "reg: slot %d = %p %p %p\n", slot, (void *)hp.data[0], (void *)hp.data[1], (void *)hp.data[2]);
     for (int i = 0; i < n; i++) if (s->pics[i].slot == slot) { s->pics[i] = hp; return OHEVC_OK; }
     for (int i = 0; i < n; i++) if (s->pics[i].slot < 0) { s->pics[i] = hp; return OHEVC_OK; }
@@ -557,6 +626,7 @@ extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
     s->seq = 0;
     s->h_edge_seq.clear();
     s->held_sao.clear();
+    s->upsampled.clear();
     tl_pend = Pending();
     return ohevc_frame_begin(ctx, slot);
 }

@@ -225,6 +225,23 @@ EXPORTED_SYMBOLS += ["ohevc_ctx_create", "ohevc_ctx_destroy", "ohevc_ctx_stream"
                      "ohevc_rec_intra_bulk", "ohevc_rec_tu_bulk", "ohevc_rec_deblock_bulk", "ohevc_rec_sao_bulk"]
 
 
+class UpsampleParams(C.Structure):
+    """ohevc_upsample_params (include/ohevc_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("el_width", "el_height", "bl_width", "bl_height", "win_left", "win_right", "win_top", "win_bottom",
+                                         "add_x_luma", "add_y_luma", "scale_x_luma", "scale_y_luma",
+                                         "add_x_chroma", "add_y_chroma", "scale_x_chroma", "scale_y_chroma", "idx", "block_slots")]
+
+
+def upsample_params(el_w, el_h, bl_w, bl_h, win, up, block_slots):
+    """win = (left, right, top, bottom); up = the reference's UpsamplInf as 9 ints (addXLum, addYLum, scaleXLum, scaleYLum, addXCr,
+    addYCr, scaleXCr, scaleYCr, idx)"""
+    u = [int(v) for v in up]
+    return UpsampleParams(el_w, el_h, bl_w, bl_h, *[int(v) for v in win], u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], u[8], int(block_slots))
+
+
+EXPORTED_SYMBOLS += ["ohevc_upsample_make_maps", "ohevc_dev_upsample_plane", "ohevc_pic_upsample", "ohevc_tables_upsample_frame"]
+
+
 class Ctx:
     """Thin wrapper over ohevc_ctx_* (one decoding thread's device context)."""
 
@@ -280,6 +297,9 @@ class Ctx:
         arr = (Plane * 3)()
         check(self.lib.ohevc_pic_planes(self.h, slot, arr))
         return arr
+
+    def pic_upsample(self, dst_slot, src_slot, params):
+        check(self.lib.ohevc_pic_upsample(self.h, dst_slot, src_slot, C.byref(params)))
 
     def frame_begin(self, slot):
         check(self.lib.ohevc_frame_begin(self.h, slot))

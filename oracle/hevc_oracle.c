@@ -755,3 +755,99 @@ void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, 
     else                predict_angular(bd, log2, blk, stride, t, l, c_idx, mode);
 #undef REC
 }
+
+/* ------------------------------------------------------------------ SHVC inter-layer up-sampling
+ * upsample_base_layer_frame (hevcdsp_template.c:2165-2438): separable resampling of the base-layer picture into the
+ * enhancement layer's inter-layer reference picture, 16 phases, 8 taps luma / 4 taps chroma (H.265 tables H.1 / H.2 as
+ * hevcdsp.c:948-986 spells them).  The shipped build reaches the same samples block by block through the twelve
+ * upsample_filter_block_* slots and the emulated_edge_up_* helpers (hevc_filter.c:1175-1310, ACTIVE_PU_UPSAMPLING hevc.h:117);
+ * tests/test_oracle_vs_reference.py checks this restatement against BOTH call sequences of the reference.
+ * Reference particulars kept: the horizontal pass stores int16 (wraps above 8 bit); rounding is fixed at 12 bits whatever
+ * the bit depth (N_SHIFT, hevcdsp.h:40-41); the vertical pass walks the intermediate columns with a pointer that only
+ * advances inside [left, right - 2], i.e. column min(i, right - 1) - left rather than i (:2270,2284,2292). */
+static const int8_t kUpLuma[16][8] = {
+    {  0, 0,   0, 64,  0,   0, 0,  0 }, {  0, 1,  -3, 63,  4,  -2, 1,  0 }, { -1, 2,  -5, 62,  8,  -3, 1,  0 }, { -1, 3,  -8, 60, 13,  -4, 1,  0 },
+    { -1, 4, -10, 58, 17,  -5, 1,  0 }, { -1, 4, -11, 52, 26,  -8, 3, -1 }, { -1, 3,  -9, 47, 31, -10, 4, -1 }, { -1, 4, -11, 45, 34, -10, 4, -1 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 }, { -1, 4, -10, 34, 45, -11, 4, -1 }, { -1, 4, -10, 31, 47,  -9, 3, -1 }, { -1, 3,  -8, 26, 52, -11, 4, -1 },
+    {  0, 1,  -5, 17, 58, -10, 4, -1 }, {  0, 1,  -4, 13, 60,  -8, 3, -1 }, {  0, 1,  -3,  8, 62,  -5, 2, -1 }, {  0, 1,  -2,  4, 63,  -3, 1,  0 } };
+static const int8_t kUpChroma[16][4] = {
+    {  0, 64,  0,  0 }, { -2, 62,  4,  0 }, { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
+    { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, {  0,  4, 62, -2 } };
+
+/* Where an enhancement-layer column / row reads the base layer: integer position of the filter's centre tap and the phase
+ * (row of the 16-phase table).  variant 0 = the general formula of upsample_base_layer_frame (:2217-2226,2255-2262,
+ * 2317-2325,2364-2372) and of the *_all block slots (:1835-1953); variants 1 / 2 = what the x2 / x1.5 block slots compute
+ * instead (:1956-2163): fixed phase patterns taken from the sample's parity / residue, which ignore the phase offsets in
+ * add* (so a stream with phase alignment decodes differently through them -- reproduced, not corrected). */
+static void shvc_axis(int variant, int chroma, int vertical, int v, int start, int scale, int add, int *pos, int *phase)
+{
+    int d = v - start;
+    if (variant == 0 || (chroma && vertical)) {                   /* chroma rows keep the scaled position in every variant */
+        int r16 = ((d * scale + add) >> 12) + (chroma && vertical ? -4 : 0);
+        *pos = r16 >> 4; *phase = r16 & 15;
+        if (variant == 1) { static const int ph[2] = { 14, 6 };  *phase = ph[v & 1]; }         /* up_sample_filter_chroma_x2_v[y & 1], :2046 */
+        if (variant == 2) { static const int ph[3] = { 15, 9, 4 }; *phase = ph[v % 3]; }       /* up_sample_filter_x1_5chroma[y % 3], :2149 */
+    } else if (variant == 1) {                                    /* x2: phases 0 / 8 */
+        if (!chroma)         { *phase = ((vertical ? d : v) & 1) * 8; *pos = d >> 1; }           /* :1968-1970 (x & 1), :2018-2019 ((y - top) & 1) */
+        else                 { *phase = (v & 1) * 8;                   *pos = v >> 1; }           /* :1993-1995: x >> 1, not (x - left) >> 1 */
+    } else {                                                      /* x1.5: phases 0 / 11 / 5 */
+        static const int ph[3] = { 0, 11, 5 };
+        *phase = ph[d % 3]; *pos = (d << 1) / 3;                                                  /* :2072-2074, :2097-2099, :2124-2125 */
+    }
+}
+
+/* one plane.  taps 8: luma, 4: chroma.  x window [left, right_end], y window [top, bottom_end - 1] in samples of this plane;
+ * right_clip = the upper bound of the horizontal position clamp (right_end; right_end - 1 in the chroma pass of the frame
+ * function, :2318). */
+static void shvc_plane(int bd, int variant, int taps, uint8_t *el, ptrdiff_t el_stride, int el_w, int el_h, const uint8_t *bl, ptrdiff_t bl_stride,
+                       int bl_w, int bl_h, int left, int right_end, int right_clip, int top, int bottom_end,
+                       int scale_x, int add_x, int scale_y, int add_y)
+{
+    const int half = taps / 2 - 1, chroma = taps == 4;
+    int16_t *tmp = malloc((size_t)el_w * bl_h * sizeof(int16_t));
+    for (int i = 0; i < el_w; i++) {                                  /* horizontal pass */
+        int pos, phase;
+        shvc_axis(variant, chroma, 0, clip3(i, left, right_clip), left, scale_x, add_x, &pos, &phase);
+        const int8_t *c = taps == 8 ? kUpLuma[phase] : kUpChroma[phase];
+        for (int j = 0; j < bl_h; j++) {
+            int acc = 0;
+            for (int k = 0; k < taps; k++)
+                acc += c[k] * ldpx(bl + (ptrdiff_t)j * bl_stride + (ptrdiff_t)clip3(pos - half + k, 0, bl_w - 1) * psz(bd), bd);
+            tmp[(size_t)j * el_w + i] = (int16_t)acc;
+        }
+    }
+    for (int j = 0; j < el_h; j++) {                                  /* vertical pass */
+        int pos, phase;
+        shvc_axis(variant, chroma, 1, clip3(j, top, bottom_end - 1), top, scale_y, add_y, &pos, &phase);
+        const int8_t *c = taps == 8 ? kUpLuma[phase] : kUpChroma[phase];
+        for (int i = 0; i < el_w; i++) {
+            int col = (i < right_end - 1 ? i : right_end - 1) - left, acc = 0;
+            if (col < 0) col = 0;
+            for (int k = 0; k < taps; k++)
+                acc += c[k] * tmp[(size_t)clip3(pos - half + k, 0, bl_h - 1) * el_w + col];
+            stpx(el + (ptrdiff_t)j * el_stride + (ptrdiff_t)i * psz(bd), bd, clip_px((acc + (1 << 11)) >> 12, bd));
+        }
+    }
+    free(tmp);
+}
+
+/* el/bl: 3 planes each (4:2:0).  win = scaled_ref_layer_window {left, right, top, bottom} in luma samples,
+ * up = UpsamplInf {addXLum, addYLum, scaleXLum, scaleYLum, addXCr, addYCr, scaleXCr, scaleYCr, idx} (hevc.h:347-357).
+ * block_slots = 0: upsample_base_layer_frame; 1: the result of the per-block slots upsample_filter_block_*[up.idx], which for
+ * idx 1 (x2) and 2 (x1.5) use their own position / phase rules (shvc_axis). */
+void ohor_shvc_upsample_frame(int bd, int block_slots, uint8_t *const el[3], const int32_t el_stride[3], int el_w, int el_h,
+                              uint8_t *const bl[3], const int32_t bl_stride[3], int bl_w, int bl_h, const int32_t *win, const int32_t *up)
+{
+    const int variant = block_slots && (up[8] == 1 || up[8] == 2) ? up[8] : 0;
+    /* luma: heightBL = min(BL height, EL height) (:2214) */
+    shvc_plane(bd, variant, 8, el[0], el_stride[0], el_w, el_h, bl[0], bl_stride[0], bl_w, bl_h <= el_h ? bl_h : el_h,
+               win[0], el_w - win[1], el_w - win[1], win[2], el_h - win[3], up[2], up[0], up[3], up[1]);
+    /* chroma: sizes halved; heightBL = max(BL height, EL height / 2) / 2 (:2306-2312) */
+    {
+        int cw = el_w >> 1, ch = el_h >> 1, bw = bl_w >> 1, bh = (bl_h > ch ? bl_h : ch) >> 1;
+        int left = win[0] >> 1, right_end = cw - (win[1] >> 1), top = win[2] >> 1, bottom_end = ch - (win[3] >> 1);
+        for (int c = 1; c < 3; c++)
+            shvc_plane(bd, variant, 4, el[c], el_stride[c], cw, ch, bl[c], bl_stride[c], bw, bh, left, right_end,
+                       block_slots ? right_end : right_end - 1, top, bottom_end, up[6], up[4], up[7], up[5]);
+    }
+}

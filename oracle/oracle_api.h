@@ -97,4 +97,10 @@ typedef struct oh_intra_pic {
 void OHX(intra_pred)(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, int c_idx, int mode,
                      int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right);
 
+/* SHVC inter-layer up-sampling of a whole 4:2:0 picture = upsample_base_layer_frame (hevcdsp_template.c:2165-2438), which
+ * the per-block slots upsample_filter_block_{luma,cr}_{h,v}[3] + emulated_edge_up_{h,v} reproduce CTB by CTB
+ * (hevc_filter.c:1175-1310).  Only implemented by the restatement (ohor_); the reference side is oracle/shvc_driver.c. */
+void OHX(shvc_upsample_frame)(int bd, int block_slots, uint8_t *const el[3], const int32_t el_stride[3], int el_w, int el_h,
+                              uint8_t *const bl[3], const int32_t bl_stride[3], int bl_w, int bl_h, const int32_t *win, const int32_t *up);
+
 #endif

@@ -225,3 +225,66 @@ def restore_tqb_pixels(frame_plane, deblocked_plane, x0, y0, width, height, is_p
             if y < is_pcm.shape[0] and x < is_pcm.shape[1] and is_pcm[y, x]:
                 ys, xs = (y << l) >> vshift, (x << l) >> hshift
                 frame_plane[ys:ys + n, xs:xs + ln] = deblocked_plane[ys:ys + n, xs:xs + ln]
+
+
+# ------------------------------------------------------------------------------------------------ SHVC inter-layer up-sampling
+SHVC_DEFAULT, SHVC_X2, SHVC_X1_5, SHVC_SNR = 0, 1, 2, 3      # UpsamplInf.idx, hevc.h:340-345
+
+
+def shvc_params(bl_w, bl_h, el_w, el_h, win=(0, 0, 0, 0), phase_align=0):
+    """UpsamplInf as set_sps derives it (hevc.c:445-499) from the base-layer size, the enhancement-layer size and its
+    scaled_ref_layer_window (left, right, top, bottom): [addXLum, addYLum, scaleXLum, scaleYLum, addXCr, addYCr, scaleXCr, scaleYCr, idx]."""
+    height_el = el_h - win[3] - win[2]
+    width_el = el_w - win[0] - win[1]
+    sx = ((bl_w << 16) + (width_el >> 1)) // width_el
+    sy = ((bl_h << 16) + (height_el >> 1)) // height_el
+    phase_x = phase_y = phase_align << 1
+    add_x = ((phase_x * sx + 2) >> 2) + (1 << 11)
+    add_y = ((phase_y * sy + 2) >> 2) + (1 << 11)
+    add_xc = (((0 + phase_align) * sx + 2) >> 2) + (1 << 11)
+    add_yc = (((1 + phase_align) * sy + 2) >> 2) + (1 << 11)
+    idx = SHVC_SNR if (sx, sy) == (65536, 65536) else SHVC_X2 if (sx, sy) == (32768, 32768) else SHVC_X1_5 if (sx, sy) == (43691, 43691) else SHVC_DEFAULT
+    return np.array([add_x, add_y, sx, sy, add_xc, add_yc, sx, sy, idx], dtype=np.int32)
+
+
+class _DrvPic(C.Structure):
+    _fields_ = [("data", C.c_void_p * 3), ("linesize", C.c_int32 * 3)]
+
+
+def _drv_pic(planes):
+    p = _DrvPic()
+    for c in range(3):
+        p.data[c] = planes[c].ctypes.data
+        p.linesize[c] = planes[c].strides[0]
+    return p
+
+
+def padded_planes(planes, pad=64):
+    """copies of the planes inside `pad` samples of replicated border (the decoder's frame buffers have such edges and the
+    reference's emulated_edge_up_h writes a few samples into them); returns (padded arrays, views of the picture area)"""
+    big = [np.ascontiguousarray(np.pad(p, pad, mode="edge")) for p in planes]
+    return big, [b[pad:-pad, pad:-pad] for b in big]
+
+
+def shvc_reference(path, mode, bd, el_planes, el_w, el_h, bl_planes, bl_w, bl_h, win, up, log2_ctb=6, conf=(0, 0), hooks=(None, None),
+                   frame_helper=None):
+    """Runs the reference's slots (oracle/shvc_driver.c in _ref/libhevcref.so): mode "frame" = upsample_base_layer_frame,
+    "blocks" = the per-CTB sequences of upsample_block_luma / upsample_block_mc.  Planes are modified in place."""
+    L = C.CDLL(path)
+    el, bl = _drv_pic(el_planes), _drv_pic(bl_planes)
+    win = np.asarray(win, np.int32); up = np.asarray(up, np.int32); conf = np.asarray(conf, np.int32)
+    h0 = C.cast(hooks[0], C.c_void_p) if hooks[0] else None
+    h1 = C.cast(hooks[1], C.c_void_p) if hooks[1] else None
+    if mode == "frame":
+        fh = C.cast(frame_helper, C.c_void_p) if frame_helper else None
+        return L.ohref_shvc_frame(C.c_int(bd), C.byref(el), el_w, el_h, C.byref(bl), bl_w, bl_h, _p(win), _p(up), h0, h1, fh)
+    return L.ohref_shvc_blocks(C.c_int(bd), log2_ctb, C.byref(el), el_w, el_h, C.byref(bl), bl_w, bl_h, _p(win), _p(conf), _p(up), h0, h1)
+
+
+def shvc_upsample_frame(oracle_lib_path, bd, el_planes, el_w, el_h, bl_planes, bl_w, bl_h, win, up, block_slots=0):
+    """our restatement (ohor_shvc_upsample_frame in liboracle.so); el_planes are modified in place"""
+    L = C.CDLL(oracle_lib_path)
+    elp = (C.c_void_p * 3)(*[p.ctypes.data for p in el_planes]); els = (C.c_int32 * 3)(*[p.strides[0] for p in el_planes])
+    blp = (C.c_void_p * 3)(*[p.ctypes.data for p in bl_planes]); bls = (C.c_int32 * 3)(*[p.strides[0] for p in bl_planes])
+    win = np.asarray(win, np.int32); up = np.asarray(up, np.int32)
+    L.ohor_shvc_upsample_frame(C.c_int(bd), C.c_int(block_slots), elp, els, el_w, el_h, blp, bls, bl_w, bl_h, _p(win), _p(up))

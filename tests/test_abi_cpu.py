@@ -54,7 +54,13 @@ int main(void) { int bad = 0;
   CHK(offsetof(HEVCDSPContext, put_hevc_epel_bi_w), offsetof(ohevc_HEVCDSPContext, put_hevc_epel_bi_w))
   CHK(offsetof(HEVCDSPContext, hevc_h_loop_filter_luma), offsetof(ohevc_HEVCDSPContext, hevc_h_loop_filter_luma))
   CHK(offsetof(HEVCDSPContext, hevc_v_loop_filter_chroma_c), offsetof(ohevc_HEVCDSPContext, hevc_v_loop_filter_chroma_c))
-  CHK(offsetof(HEVCDSPContext, upsample_base_layer_frame), offsetof(ohevc_HEVCDSPContext, shvc_upsample_slots))
+  CHK(offsetof(HEVCDSPContext, upsample_base_layer_frame), offsetof(ohevc_HEVCDSPContext, upsample_base_layer_frame))
+  CHK(offsetof(HEVCDSPContext, upsample_filter_block_luma_v), offsetof(ohevc_HEVCDSPContext, upsample_filter_block_luma_v))
+  CHK(offsetof(HEVCDSPContext, upsample_filter_block_cr_v), offsetof(ohevc_HEVCDSPContext, upsample_filter_block_cr_v))
+  CHK(offsetof(VideoDSPContext, emulated_edge_up_v), offsetof(ohevc_VideoDSPContext, emulated_edge_up_v))
+  CHK(sizeof(HEVCWindow), sizeof(ohevc_HEVCWindow))
+  CHK(sizeof(UpsamplInf), sizeof(ohevc_UpsamplInf))
+  CHK(offsetof(UpsamplInf, idx), offsetof(ohevc_UpsamplInf, idx))
   CHK(sizeof(VideoDSPContext), sizeof(ohevc_VideoDSPContext))
   CHK(offsetof(VideoDSPContext, prefetch), offsetof(ohevc_VideoDSPContext, prefetch))
   CHK(sizeof(SAOParams), sizeof(ohevc_SAOParams))

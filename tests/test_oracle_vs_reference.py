@@ -243,3 +243,62 @@ def test_intra_pred_constrained(oracle, ref, bd):
         ref.intra_pred(bd, pb, W, H, x0, y0, log2, c_idx, mode, cands, **kw)
         for i in range(3):
             assert np.array_equal(pa[i], pb[i]), (it, log2, c_idx, mode, cands, x0, y0, lpu, p_intra)
+
+
+# ------------------------------------------------------------------ SHVC inter-layer up-sampling
+def _shvc_case(rng, ratios, use_window):
+    bw, bh = int(rng.integers(10, 40)) * 8, int(rng.integers(10, 30)) * 8
+    ratio = float(rng.choice(ratios))
+    ew, eh = int(round(bw * ratio / 8)) * 8, int(round(bh * ratio / 8)) * 8
+    win = (0, 0, 0, 0)
+    if use_window:
+        win = tuple(int(v) * 2 for v in rng.integers(0, 9, size=4))
+    bl = [rand_plane(rng, 8, bh, bw), rand_plane(rng, 8, bh // 2, bw // 2), rand_plane(rng, 8, bh // 2, bw // 2)]
+    return bw, bh, ew, eh, win, bl
+
+
+def _shvc_run(fn, ew, eh):
+    el = [np.zeros((eh, ew), np.uint8), np.zeros((eh // 2, ew // 2), np.uint8), np.zeros((eh // 2, ew // 2), np.uint8)]
+    _, view = po.padded_planes(el)
+    fn(view)
+    return [v.copy() for v in view]
+
+
+def test_shvc_upsample_frame_slot(oracle, ref):
+    """upsample_base_layer_frame (hevcdsp_template.c:2165-2438) driven as at hevc.c:3240-3242 (oracle/shvc_driver.c), any ratio,
+    with and without a scaled reference layer window.  8 bit: above that the reference's function memsets 16-bit samples
+    bytewise at the picture edges (:2233,2243) and corrupts its heap here; SHVC content is 8 bit."""
+    rng = np.random.default_rng(310)
+    for it in range(40):
+        bw, bh, ew, eh, win, bl = _shvc_case(rng, [2.0, 1.5, 1.25, 1.8, 1.0, 3.0], it % 3 == 0)
+        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=int(rng.integers(0, 2)))
+        _, blv = po.padded_planes(bl)
+        a = _shvc_run(lambda v: po.shvc_reference(ref.path, "frame", 8, v, ew, eh, blv, bw, bh, win, up), ew, eh)
+        b = _shvc_run(lambda v: po.shvc_upsample_frame(oracle.path, 8, v, ew, eh, blv, bw, bh, win, up, block_slots=0), ew, eh)
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), (it, (bw, bh, ew, eh), win, list(up), pl)
+
+
+def test_shvc_upsample_block_slots(oracle, ref):
+    """The shipped path (ACTIVE_PU_UPSAMPLING, hevc.h:117): upsample_filter_block_{luma,cr}_{h,v}[idx] + emulated_edge_up_{h,v}
+    called CTB by CTB as upsample_block_luma / upsample_block_mc do (hevc_filter.c:1175-1310, restated in shvc_driver.c),
+    idx 0 (general), 1 (x2), 2 (x1.5), with and without phase alignment -- except x1.5 with phase alignment, where the
+    reference sizes its source window with the general formula (:1194,1197) but the x1.5 slots read other rows: the first
+    row of some CTBs then comes from whatever the previous CTB left in the buffer.  Pictures larger than one CTB (a CTB
+    spanning both picture edges skips the bottom emulation, videodsp_template.c:141-151)."""
+    rng = np.random.default_rng(311)
+    seen = set()
+    for it in range(60):
+        bw, bh, ew, eh, win, bl = _shvc_case(rng, [2.0, 1.5, 1.25, 1.75], False)
+        pa = int(rng.integers(0, 2))
+        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=pa)
+        if up[8] == po.SHVC_X1_5 and pa:
+            continue
+        ctb = int(rng.choice([4, 5, 6]))
+        _, blv = po.padded_planes(bl)
+        a = _shvc_run(lambda v: po.shvc_reference(ref.path, "blocks", 8, v, ew, eh, blv, bw, bh, win, up, log2_ctb=ctb), ew, eh)
+        b = _shvc_run(lambda v: po.shvc_upsample_frame(oracle.path, 8, v, ew, eh, blv, bw, bh, win, up, block_slots=1), ew, eh)
+        for pl in range(3):
+            assert np.array_equal(a[pl], b[pl]), (it, (bw, bh, ew, eh), ctb, list(up), pl)
+        seen.add((int(up[8]), pa))
+    assert {(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)} <= seen

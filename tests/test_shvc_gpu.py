@@ -1,0 +1,93 @@
+"""-m gpu parity of SHVC inter-layer up-sampling (the 13 upsample_* slots, hevcdsp.h:106-123): the HIP path through the ctx
+layer against the oracle restatement, which tests/test_oracle_vs_reference.py pins against both call sequences of the
+reference (whole frame and CTB by CTB)."""
+import os
+
+import numpy as np
+import pytest
+
+from openhevc_amd import lib as L
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so")
+
+
+@pytest.mark.parametrize("block_slots", [0, 1])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_upsample_matches_oracle(bd, block_slots):
+    rng = np.random.default_rng(70 + bd + block_slots)
+    dt = np.uint16 if bd > 8 else np.uint8
+    ctx = L.Ctx(0)
+    for it in range(14):
+        bw, bh = int(rng.integers(10, 60)) * 8, int(rng.integers(10, 40)) * 8
+        ratio = float(rng.choice([2.0, 1.5, 1.25, 1.75, 1.0]))
+        ew, eh = int(round(bw * ratio / 8)) * 8, int(round(bh * ratio / 8)) * 8
+        win = (0, 0, 0, 0)
+        if not block_slots and it % 3 == 0:           # window offsets: the frame function only (the block slots depend on the CTB grid there)
+            win = tuple(int(v) * 2 for v in rng.integers(0, 9, size=4))
+        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=int(rng.integers(0, 2)))
+        if up[8] == po.SHVC_SNR:
+            up[8] = po.SHVC_DEFAULT                   # x1: the general filter is still defined (the block path copies instead)
+        if block_slots and up[8] == po.SHVC_X1_5 and up[0] != 2048:
+            up = po.shvc_params(bw, bh, ew, eh, win, phase_align=0)     # x1.5 + phase alignment: the reference reads rows it never prepared
+        bl = [rng.integers(0, 1 << bd, size=(bh, bw)).astype(dt), rng.integers(0, 1 << bd, size=(bh // 2, bw // 2)).astype(dt),
+              rng.integers(0, 1 << bd, size=(bh // 2, bw // 2)).astype(dt)]
+        want = [np.zeros((eh, ew), dt), np.zeros((eh // 2, ew // 2), dt), np.zeros((eh // 2, ew // 2), dt)]
+        po.shvc_upsample_frame(ORACLE, bd, want, ew, eh, bl, bw, bh, win, up, block_slots=block_slots)
+        s_bl, s_el = ctx.pic_alloc(bw, bh, 1, bd), ctx.pic_alloc(ew, eh, 1, bd)
+        ctx.pic_upload(s_bl, bl)
+        ctx.pic_upsample(s_el, s_bl, L.upsample_params(ew, eh, bw, bh, win, up, block_slots))
+        got = ctx.pic_download(s_el, [w.shape for w in want], dt)
+        for pl in range(3):
+            bad = np.argwhere(got[pl] != want[pl])
+            assert bad.size == 0, f"bd={bd} slots={block_slots} {bw}x{bh}->{ew}x{eh} win={win} up={list(up)} plane {pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
+        ctx.pic_release(s_el); ctx.pic_release(s_bl)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["blocks", "frame"])
+def test_reference_call_sequences_on_hooked_tables(ref, mode):
+    """The drop-in: oracle/shvc_driver.c makes the reference's own call sequences (CTB by CTB through the twelve block slots and
+    emulated_edge_up_{h,v}; or the whole-frame slot through the reference-side stub of INTEGRATION.md) once on the tables as
+    the reference fills them -- host compute -- and once on tables overridden by ohevc_hevcdsp_init_hip / ohevc_videodsp_init_hip,
+    which resample on the device.  8 bit (see tests/test_oracle_vs_reference.py)."""
+    import ctypes as C
+    rng = np.random.default_rng(91 if mode == "blocks" else 92)
+    lib = L.load_library()
+    hook = lambda f: C.cast(f, C.c_void_p).value
+    for it in range(6):
+        bw, bh = int(rng.integers(12, 50)) * 8, int(rng.integers(12, 34)) * 8
+        ratio = float(rng.choice([2.0, 1.5, 1.25]))
+        ew, eh = int(round(bw * ratio / 8)) * 8, int(round(bh * ratio / 8)) * 8
+        win = (0, 0, 0, 0) if mode == "blocks" or it % 2 else tuple(int(v) * 2 for v in rng.integers(0, 6, size=4))
+        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=0 if ratio == 1.5 else int(rng.integers(0, 2)))
+        bl = [rng.integers(0, 256, size=(bh, bw)).astype(np.uint8), rng.integers(0, 256, size=(bh // 2, bw // 2)).astype(np.uint8),
+              rng.integers(0, 256, size=(bh // 2, bw // 2)).astype(np.uint8)]
+        _, blv = po.padded_planes(bl)
+
+        def fresh():
+            el = [np.zeros((eh, ew), np.uint8), np.zeros((eh // 2, ew // 2), np.uint8), np.zeros((eh // 2, ew // 2), np.uint8)]
+            return po.padded_planes(el)
+        _, want = fresh()
+        assert po.shvc_reference(ref.path, mode, 8, want, ew, eh, blv, bw, bh, win, up, log2_ctb=5) == 0
+        keep, got = fresh()
+        ctx = L.Ctx(0)
+        s_bl, s_el = ctx.pic_alloc(bw, bh, 1, 8), ctx.pic_alloc(ew, eh, 1, 8)
+        ctx.pic_upload(s_bl, [np.ascontiguousarray(p) for p in blv])
+        for slot, planes in ((s_bl, blv), (s_el, got)):
+            data = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+            ls = (C.c_int * 3)(*[p.strides[0] for p in planes])
+            L.check(lib.ohevc_tables_register_picture(ctx.h, slot, data, ls))
+        L.check(lib.ohevc_tables_bind(ctx.h))
+        rc = po.shvc_reference(ref.path, mode, 8, got, ew, eh, blv, bw, bh, win, up, log2_ctb=5,
+                               hooks=(hook(lib.ohevc_hevcdsp_init_hip), hook(lib.ohevc_videodsp_init_hip)),
+                               frame_helper=hook(lib.ohevc_tables_upsample_frame) if mode == "frame" else None)
+        assert rc == 0 and lib.ohevc_tables_status(ctx.h) == 0, lib.ohevc_last_error()
+        assert not any(p.any() for p in got)             # nothing was computed on the host
+        out = ctx.pic_download(s_el, [p.shape for p in got], np.uint8)
+        lib.ohevc_tables_bind(None)
+        ctx.close()
+        for pl in range(3):
+            bad = np.argwhere(out[pl] != want[pl])
+            assert bad.size == 0, f"{mode} {bw}x{bh}->{ew}x{eh} win={win} up={list(up)} plane {pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
