@@ -426,10 +426,20 @@ int t_emulated_edge_up_v(int16_t *, ptrdiff_t, const ohevc_HEVCWindow *, int, in
 
 void t_up_h(int16_t *, ptrdiff_t, uint8_t *src, ptrdiff_t, int, int, int, int, int, const ohevc_HEVCWindow *, ohevc_UpsamplInf *)
 {
-    Loc l;
     tl_pend.up_bl_slot = -1;
-    if (!tl_ctx || !locate(src, l)) { fail(OHEVC_ERR_STATE); return; }
-    tl_pend.up_bl_slot = tl_state->pics[l.pic].slot;
+    if (!tl_ctx || !tl_state) { fail(OHEVC_ERR_STATE); return; }
+    // src = plane + (bl_y - edge_top) * stride + bl_x - edge_left (+ shift): inside the plane except for the chroma rows, whose
+    // first block starts at bl_y = -1 (the "- 4" of hevc_filter.c:1268,1280) -- accept a few rows of frame padding around the plane
+    for (int i = 0; i < tl_state->npics() && tl_pend.up_bl_slot < 0; i++) {
+        const HostPic &hp = tl_state->pics[i];
+        if (hp.slot < 0) continue;
+        for (int c = 0; c < 3; c++) {
+            if (!hp.data[c]) continue;
+            const ptrdiff_t margin = (ptrdiff_t)8 * hp.linesize[c], off = src - (hp.data[c] - margin);
+            if (off >= 0 && (size_t)off < hp.bytes[c] + 2 * (size_t)margin) { tl_pend.up_bl_slot = hp.slot; break; }
+        }
+    }
+    if (tl_pend.up_bl_slot < 0) fail(OHEVC_ERR_STATE);
 }
 
 int upsample_once(int el_slot, int bl_slot, const ohevc_HEVCWindow *w, const ohevc_UpsamplInf *u, int block_slots)
