@@ -39,6 +39,12 @@ int  ohevc_ctx_create(ohevc_ctx **out, int device);
 int  ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *share_with);
 const void *ohevc_ctx_store_id(ohevc_ctx *ctx);            /* identity of the picture store (equal for sharing contexts) */
 void ohevc_ctx_destroy(ohevc_ctx *ctx);
+/* Several threads record into this context at once (the reference's slice threads: WPP rows / tiles of ONE picture, all joined
+ * before the frame ends).  The thread that called ohevc_frame_begin keeps recording into the context itself, every other thread
+ * gets a private recorder that ohevc_frame_reconstruct / ohevc_frame_end fold in (jobs keep their dependency levels): no lock on
+ * the recording path.  The caller guarantees what the reference's WPP / tile decoding guarantees: a block is recorded after the
+ * blocks it predicts from.  Off (default): a context is not internally synchronised. */
+int  ohevc_ctx_set_concurrent(ohevc_ctx *ctx, int on);
 /* the HIP stream all of this context's copies and launches are issued on (hipStream_t as void*) */
 void *ohevc_ctx_stream(ohevc_ctx *ctx);
 int  ohevc_ctx_sync(ohevc_ctx *ctx);

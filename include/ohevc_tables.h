@@ -122,11 +122,13 @@ void ohevc_videodsp_init_hip(ohevc_VideoDSPContext *c, int bit_depth);
 /* ---- per-thread binding and the pointer registry */
 int  ohevc_tables_bind(ohevc_ctx *ctx);                    /* this thread's table calls record into ctx (NULL unbinds) */
 /* Slice threads (the reference's WPP-row / tile workers, hls_decode_entry_wpp / hls_decode_entry_tiles, hevc.c:2744-2920,
- * run through avctx->execute2): all workers of a picture record into the SAME context.  Turn this on for the context (it
- * serialises the recorder behind a spin lock, off = no locking at all) and call ohevc_tables_bind(ctx) at the top of each
- * worker entry function; per-thread call-sequence state (pending transform, first half of a bi-prediction, edge-emulation
- * windows) is thread-local already.  What makes it safe: WPP / tile decoding never reads a neighbour another worker has
- * not yet parsed (2-CTB lag, hevc.c:2779), so every intra block still sees its neighbours' dependency levels. */
+ * run through avctx->execute2): all workers of a picture record into the SAME context.  Turn this on for the context and call
+ * ohevc_tables_bind(ctx) at the top of each worker entry function.  Every worker then records into arrays of its own
+ * (ohevc_ctx_set_concurrent: merged when the frame is executed, no lock on the recording path); per-thread call-sequence
+ * state (pending transform, first half of a bi-prediction, edge-emulation windows) is thread-local anyway; only the filter-lag
+ * bookkeeping of 16x16-CTB streams takes a spin lock.  What makes it safe: WPP / tile decoding never reads a neighbour
+ * another worker has not yet parsed (2-CTB lag, hevc.c:2779), so every intra block still sees its neighbours' dependency
+ * levels. */
 int  ohevc_tables_set_concurrent(ohevc_ctx *ctx, int on);
 /* host planes of a picture living in picture-store slot `slot` (a DPB entry): used to resolve MC source pointers */
 int  ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *const data[3], const int linesize[3]);

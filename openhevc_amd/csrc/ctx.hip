@@ -9,6 +9,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include <string.h>
 #include <vector>
 #include "common.hpp"
@@ -79,6 +81,7 @@ struct LevelBins {
 
 }  // namespace
 
+static std::atomic<uint64_t> g_ctx_gen{1};
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_level_launch = 0;        // ohevc_debug_set_level_launch: 0 = two launches per level (shipped), 1 = all intra levels in one launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
@@ -95,7 +98,22 @@ static inline bool trace_hit(int plane, int x, int y, int w, int h)
 }
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-struct ohevc_ctx {
+// What the ohevc_rec_* calls fill.  The context itself is one; with ohevc_ctx_set_concurrent every further thread that
+// records into the context (the reference's slice threads: WPP rows / tiles of ONE picture) gets a private one, merged into
+// the context's own at the next frame_reconstruct -- no lock and no shared cache line on the recording path.
+struct Rec {
+    std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
+    std::vector<LevelBins> levels;                         // [level]; entries 0..max_level are live
+    int max_level = -1;
+    std::vector<int16_t> coeffs;
+    std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
+    std::vector<ohevc_dbk_job> dbk_v, dbk_h;
+    std::vector<ohevc_sao_job> sao;
+    bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
+    int nstat[5] = {};                // tu, mc, intra, dbk, sao calls
+};
+
+struct ohevc_ctx : Rec {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
     int device = 0;
     hipStream_t stream = nullptr;
@@ -110,17 +128,16 @@ struct ohevc_ctx {
     bool target_guarded = false;      // the stream already waits for earlier readers/writers of the target picture
     Picture twin;                     // deblocked copy for SAO (the reference's sao_frame, hevc.c:369-385)
     Picture lag;                      // picture between the two deblocking passes (only for OHEVC_SAO_LAG_* jobs)
-    bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
 
-    std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
-    std::vector<LevelBins> levels;                         // [level]; entries 0..max_level are live
+    // concurrent recording (ohevc_ctx_set_concurrent)
+    bool concurrent = false;
+    uint64_t gen = 0;                                      // identity for the per-thread cache (addresses get reused)
+    std::thread::id owner;                                 // the thread that called frame_begin records into the context itself
+    std::mutex side_m;
+    std::vector<std::pair<std::thread::id, std::unique_ptr<Rec>>> side;
+
     std::vector<ohevc_level_phase> phases;                // scratch of frame_reconstruct
     std::vector<uint32_t> need, sync_zero;
-    int max_level = -1;
-    std::vector<int16_t> coeffs;
-    std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
-    std::vector<ohevc_dbk_job> dbk_v, dbk_h;
-    std::vector<ohevc_sao_job> sao;
     std::vector<uint8_t> bypass;                           // ohevc_frame_set_bypass_map: is_pcm bytes, row length bypass_w (empty = none)
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
@@ -172,6 +189,8 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     OHEVC_REQUIRE(out != nullptr, "out");
     if (g_record_only || (share_with && share_with->dry)) {
         ohevc_ctx *c = new ohevc_ctx();
+    c->gen = g_ctx_gen.fetch_add(1);
+        c->gen = g_ctx_gen.fetch_add(1);
         c->dry = true;
         c->store = share_with ? share_with->store : std::make_shared<PicStore>();
         *out = c;
@@ -224,6 +243,13 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->staged) hipEventDestroy(c->staged);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
+}
+
+extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
+{
+    OHEVC_REQUIRE(c != nullptr, "null context");
+    c->concurrent = on != 0;
+    return OHEVC_OK;
 }
 
 extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
@@ -407,16 +433,89 @@ extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, cons
     return OHEVC_OK;
 }
 
-static void clear_recorded(ohevc_ctx *c)
+// the recorder the calling thread writes to
+static inline Rec &pick(ohevc_ctx *c)
 {
-    c->mc.clear(); c->mc_small.clear(); c->coeffs.clear(); c->cips.clear();
-    for (int l = 0; l <= c->max_level; l++) {
-        LevelBins &lb = c->levels[l];
+    if (!c->concurrent) return *c;
+    struct Cache { uint64_t gen = 0; Rec *r = nullptr; };
+    static thread_local Cache cache;
+    if (cache.gen == c->gen) return *cache.r;
+    Rec *r = c;
+    if (std::this_thread::get_id() != c->owner) {
+        std::lock_guard<std::mutex> g(c->side_m);
+        r = nullptr;
+        for (auto &sd : c->side) if (sd.first == std::this_thread::get_id()) r = sd.second.get();
+        if (!r) { c->side.emplace_back(std::this_thread::get_id(), std::unique_ptr<Rec>(new Rec())); r = c->side.back().second.get(); }
+    }
+    cache.gen = c->gen; cache.r = r;
+    return *r;
+}
+
+static inline LevelBins &level_bins(Rec &r, int level)
+{
+    if (level >= (int)r.levels.size()) r.levels.resize((size_t)level + 16);
+    if (level > r.max_level) r.max_level = level;
+    return r.levels[level];
+}
+
+static void clear_rec(Rec &r)
+{
+    r.mc.clear(); r.mc_small.clear(); r.coeffs.clear(); r.cips.clear();
+    for (int l = 0; l <= r.max_level; l++) {
+        LevelBins &lb = r.levels[l];
         for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
         lb.touched = 0;
         lb.intra.clear();
     }
-    c->max_level = -1;
+    r.max_level = -1;
+}
+
+// Fold what the other threads recorded into the context's own recorder (called by the thread that runs the frame, after
+// the workers are done: the reference joins its slice threads before the frame can end).  Jobs keep their dependency levels;
+// arena offsets and constrained-intra side-record indices are rebased.
+static void merge_side(ohevc_ctx *c)
+{
+    if (c->side.empty()) return;
+    std::lock_guard<std::mutex> g(c->side_m);
+    for (auto &sd : c->side) {
+        Rec &r = *sd.second;
+        c->mc.insert(c->mc.end(), r.mc.begin(), r.mc.end());
+        c->mc_small.insert(c->mc_small.end(), r.mc_small.begin(), r.mc_small.end());
+        const uint32_t cbase = (uint32_t)c->coeffs.size(), ibase = (uint32_t)c->cips.size();
+        c->coeffs.insert(c->coeffs.end(), r.coeffs.begin(), r.coeffs.end());
+        c->cips.insert(c->cips.end(), r.cips.begin(), r.cips.end());
+        for (int l = 0; l <= r.max_level; l++) {
+            LevelBins &src = r.levels[l];
+            if (!src.touched && src.intra.empty()) continue;
+            LevelBins &dst = level_bins(*c, l);
+            for (ohevc_intra_job j : src.intra) {
+                if (j.flags2 & OHEVC_INTRA2_CIP) j.cip_index += ibase;
+                dst.intra.push_back(j);
+            }
+            for (uint64_t m = src.touched; m; m &= m - 1) {
+                const int b = __builtin_ctzll(m), kind = b & 15;
+                auto &dv = dst.tu[b >> 4][kind];
+                for (ohevc_tu_job j : src.tu[b >> 4][kind]) {
+                    if (kind != OHEVC_TU_DC) j.coeff_off += cbase;
+                    if (kind == OHEVC_TU_CROSS) j.reserved1 += cbase;
+                    dv.push_back(j);
+                }
+                dst.touched |= 1ull << b;
+            }
+        }
+        c->dbk_v.insert(c->dbk_v.end(), r.dbk_v.begin(), r.dbk_v.end());
+        c->dbk_h.insert(c->dbk_h.end(), r.dbk_h.begin(), r.dbk_h.end());
+        c->sao.insert(c->sao.end(), r.sao.begin(), r.sao.end());
+        c->sao_lagged |= r.sao_lagged;
+        for (int k = 0; k < 5; k++) { c->nstat[k] += r.nstat[k]; r.nstat[k] = 0; }
+        clear_rec(r);
+        r.dbk_v.clear(); r.dbk_h.clear(); r.sao.clear(); r.sao_lagged = false;
+    }
+}
+
+static void clear_recorded(ohevc_ctx *c)
+{
+    clear_rec(*c);
     for (int i = 0; i < 3; i++) std::fill(c->level_map[i].begin(), c->level_map[i].end(), 0);
 }
 
@@ -440,20 +539,20 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     clear_recorded(c);
     c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->bypass.clear();
     c->stats = ohevc_frame_stats{};
+    for (int &v : c->nstat) v = 0;
+    c->owner = std::this_thread::get_id();
+    {
+        std::lock_guard<std::mutex> g(c->side_m);
+        for (auto &sd : c->side) { clear_rec(*sd.second); sd.second->dbk_v.clear(); sd.second->dbk_h.clear(); sd.second->sao.clear(); for (int &v : sd.second->nstat) v = 0; }
+    }
     return OHEVC_OK;
-}
-
-static inline LevelBins &level_bins(ohevc_ctx *c, int level)
-{
-    if (level >= (int)c->levels.size()) c->levels.resize((size_t)level + 16);
-    if (level > c->max_level) c->max_level = level;
-    return c->levels[level];
 }
 
 extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    Rec &r = pick(c);
     OHEVC_REQUIRE(plane >= 0 && plane < 3 && log2 >= 2 && log2 <= 5 && kind >= 0 && kind < OHEVC_TU_NKINDS, "bad TU");
     OHEVC_REQUIRE(kind != OHEVC_TU_DST4 || log2 == 2, "DST is 4x4 only");
     const int n = 1 << log2;
@@ -463,16 +562,16 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
     if (kind == OHEVC_TU_DC) {
         j.dc = coeffs[0];
     } else {
-        j.coeff_off = (uint32_t)c->coeffs.size();
-        c->coeffs.insert(c->coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
+        j.coeff_off = (uint32_t)r.coeffs.size();
+        r.coeffs.insert(r.coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
     if (trace_hit(plane, x, y, n, n))
         fprintf(stderr, "trace: target %d tu plane %d x %d y %d log2 %d kind %d level %d c0 %d\n", c->cur, plane, x, y, log2, kind, level, coeffs[0]);
-    LevelBins &lb = level_bins(c, level);
+    LevelBins &lb = level_bins(r, level);
     lb.tu[log2 - 2][kind].push_back(j);
     lb.touched |= 1ull << ((log2 - 2) * 16 + kind);
-    c->stats.n_tu++;
+    r.nstat[0]++;
     return OHEVC_OK;
 }
 
@@ -481,6 +580,7 @@ extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    Rec &r = pick(c);
     OHEVC_REQUIRE(plane >= 1 && plane < 3 && log2 >= 2 && log2 <= 5, "cross-component prediction applies to chroma blocks");
     OHEVC_REQUIRE(kind_y >= 0 && kind_y < OHEVC_TU_PCM && kind_c >= -1 && kind_c < OHEVC_TU_PCM && coeffs_y != nullptr && (kind_c < 0 || coeffs_c != nullptr),
                   "bad residual kinds");
@@ -492,17 +592,17 @@ extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log
     j.x = (uint16_t)x; j.y = (uint16_t)y; j.plane = (uint8_t)plane;
     j.reserved0 = (uint8_t)((kind_c < 0 ? 15 : kind_c) | (kind_y << 4));
     j.dc = (int16_t)res_scale_val;
-    j.reserved1 = (uint32_t)c->coeffs.size();
-    c->coeffs.insert(c->coeffs.end(), coeffs_y, coeffs_y + n * n);
+    j.reserved1 = (uint32_t)r.coeffs.size();
+    r.coeffs.insert(r.coeffs.end(), coeffs_y, coeffs_y + n * n);
     if (kind_c >= 0) {
-        j.coeff_off = (uint32_t)c->coeffs.size();
-        c->coeffs.insert(c->coeffs.end(), coeffs_c, coeffs_c + n * n);
+        j.coeff_off = (uint32_t)r.coeffs.size();
+        r.coeffs.insert(r.coeffs.end(), coeffs_c, coeffs_c + n * n);
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
-    LevelBins &lb = level_bins(c, level);
+    LevelBins &lb = level_bins(r, level);
     lb.tu[log2 - 2][OHEVC_TU_CROSS].push_back(j);
     lb.touched |= 1ull << ((log2 - 2) * 16 + OHEVC_TU_CROSS);
-    c->stats.n_tu++;
+    r.nstat[0]++;
     return OHEVC_OK;
 }
 
@@ -510,6 +610,7 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
+    Rec &r = pick(c);
     OHEVC_REQUIRE(job->plane < 3 && job->w >= 2 && job->w <= 64 && job->h >= 2 && job->h <= 64, "bad MC block");
     OHEVC_REQUIRE(get_pic(c, job->ref0) != nullptr && (!(job->flags & OHEVC_MC_BI) || get_pic(c, job->ref1) != nullptr), "bad reference slot");
     if (trace_hit(job->plane, job->x, job->y, job->w, job->h))
@@ -526,9 +627,9 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
             t.w = (uint8_t)std::min(16, job->w - tx); t.h = (uint8_t)std::min(16, job->h - ty);
             t.sx0 = (int16_t)(job->sx0 + tx); t.sy0 = (int16_t)(job->sy0 + ty);
             t.sx1 = (int16_t)(job->sx1 + tx); t.sy1 = (int16_t)(job->sy1 + ty);
-            ((t.w <= 8 && t.h <= 8) ? c->mc_small : c->mc).push_back(t);
+            ((t.w <= 8 && t.h <= 8) ? r.mc_small : r.mc).push_back(t);
         }
-    c->stats.n_mc++;
+    r.nstat[1]++;
     return OHEVC_OK;
 }
 
@@ -537,11 +638,12 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job);
 extern "C" int ohevc_rec_intra_cip(ohevc_ctx *c, const ohevc_intra_job *job, const ohevc_intra_cip *cip)
 {
     OHEVC_REQUIRE(c != nullptr && job != nullptr, "null argument");
+    Rec &r = pick(c);
     ohevc_intra_job j = *job;
     if (j.flags2 & OHEVC_INTRA2_CIP) {
         OHEVC_REQUIRE(cip != nullptr, "CIP job without side record");
-        j.cip_index = (uint32_t)c->cips.size();
-        c->cips.push_back(*cip);
+        j.cip_index = (uint32_t)r.cips.size();
+        r.cips.push_back(*cip);
     }
     return rec_intra_impl(c, &j);
 }
@@ -556,6 +658,7 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr && job != nullptr, "no frame begun");
+    Rec &r = pick(c);
     OHEVC_REQUIRE(job->plane < 3 && job->log2_size >= 2 && job->log2_size <= 5 && job->mode <= 34, "bad intra job");
     const int pl = job->plane, n = 1 << job->log2_size, W = c->lm_w[pl], H = c->lm_h[pl];
     OHEVC_REQUIRE(job->x + n <= p->planes[pl].width && job->y + n <= p->planes[pl].height, "intra block outside plane");
@@ -576,25 +679,27 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     if (trace_hit(pl, job->x, job->y, n, n))
         fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d level %d\n", c->cur, pl, job->x,
                 job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size, level);
-    level_bins(c, level).intra.push_back(*job);
-    c->stats.n_intra++;
+    level_bins(r, level).intra.push_back(*job);
+    r.nstat[2]++;
     return OHEVC_OK;
 }
 
 extern "C" int ohevc_rec_deblock(ohevc_ctx *c, const ohevc_dbk_job *job)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
-    ((job->flags & OHEVC_DBK_VERTICAL_EDGE) ? c->dbk_v : c->dbk_h).push_back(*job);
-    c->stats.n_dbk++;
+    Rec &r = pick(c);
+    ((job->flags & OHEVC_DBK_VERTICAL_EDGE) ? r.dbk_v : r.dbk_h).push_back(*job);
+    r.nstat[3]++;
     return OHEVC_OK;
 }
 
 extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
-    c->sao.push_back(*job);
-    if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) c->sao_lagged = true;
-    c->stats.n_sao++;
+    Rec &r = pick(c);
+    r.sao.push_back(*job);
+    if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) r.sao_lagged = true;
+    r.nstat[4]++;
     return OHEVC_OK;
 }
 
@@ -751,6 +856,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    merge_side(c);
     if (c->dry) { clear_recorded(c); return OHEVC_OK; }
     OHEVC_HIP_TRY(hipSetDevice(c->device));
     if (c->mc.empty() && c->mc_small.empty() && c->max_level < 0) return OHEVC_OK;
@@ -968,6 +1074,7 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
         p->end_issued = true;
     }
     c->store->cv.notify_all();
+    c->stats.n_tu = c->nstat[0]; c->stats.n_mc = c->nstat[1]; c->stats.n_intra = c->nstat[2]; c->stats.n_dbk = c->nstat[3]; c->stats.n_sao = c->nstat[4];
     c->last_stats = c->stats;
     return OHEVC_OK;
 }

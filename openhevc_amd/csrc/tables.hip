@@ -103,7 +103,8 @@ void fail(int rc)
     else g_unbound_calls.fetch_add(1, std::memory_order_relaxed);
 }
 
-// serialises the recorder calls of one context when several threads feed it (ohevc_tables_set_concurrent); free otherwise
+// protects the TABLE layer's shared bookkeeping (filter-lag call order, up-sampling state) when several threads feed one
+// context (ohevc_tables_set_concurrent); the recorder itself gives every thread its own arrays (ohevc_ctx_set_concurrent)
 struct Guard {
     TablesState *s;
     explicit Guard(TablesState *st) : s(st && st->concurrent ? st : nullptr)
@@ -201,10 +202,8 @@ template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_
         if (!y || tl_pend.luma_log2 != LOG2 || y == coeffs) { fail(OHEVC_ERR_STATE); return; }
         int16_t own[1 << (2 * LOG2)];
         for (int i = 0; i < (1 << (2 * LOG2)); i++) own[i] = (int16_t)(coeffs[i] - ((scale * y[i]) >> 3));
-        Guard guard_(tl_state);
         rc = ohevc_rec_tu_cross(tl_ctx, l.plane, l.x, l.y, LOG2, kind, own, tl_pend.luma_kind, y, scale, 1);
     } else {
-        Guard guard_(tl_state);
         rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);
     }
     if (rc != OHEVC_OK) fail(rc);
@@ -226,7 +225,6 @@ void t_put_pcm(uint8_t *dst, ptrdiff_t, int width, int height, struct GetBitCont
     for (int i = 0; i < width * height; i++) samples[i] = hp.ps == 2 ? (int16_t)scratch16[i] : (int16_t)scratch[i];
     int log2 = 2;
     while ((1 << log2) < width) log2++;
-    Guard guard_(tl_state);
     for (int half = 0; half * width < height; half++) {
         int rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y + half * width, log2, OHEVC_TU_PCM, samples + half * width * width, 1);
         if (rc != OHEVC_OK) fail(rc);
@@ -317,7 +315,6 @@ void mc_record(uint8_t *dst, uint8_t *src, const int16_t *src2, int height, int 
         j.flags |= OHEVC_MC_WEIGHTED;
         j.denom = (uint8_t)denom; j.wx0 = (int16_t)wx0; j.wx1 = (int16_t)wx1; j.ox0 = (int16_t)ox0; j.ox1 = (int16_t)ox1;
     }
-    Guard guard_(tl_state);
     int rc = ohevc_rec_mc(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
 }
@@ -355,9 +352,10 @@ void dbk_record(uint8_t *pix, bool vertical, int beta, const int *tc, const uint
     j.tc[0] = (int16_t)tc[0]; j.tc[1] = (int16_t)tc[1];
     j.flags = (uint8_t)((vertical ? OHEVC_DBK_VERTICAL_EDGE : 0) | (no_p[0] ? OHEVC_DBK_NO_P0 : 0) | (no_p[1] ? OHEVC_DBK_NO_P1 : 0) |
                         (no_q[0] ? OHEVC_DBK_NO_Q0 : 0) | (no_q[1] ? OHEVC_DBK_NO_Q1 : 0));
-    Guard guard_(tl_state);
-    if (tl_state->lag_on && !vertical && l.plane > 0)
+    if (tl_state->lag_on && !vertical && l.plane > 0) {       // call-order bookkeeping is shared by the recording threads
+        Guard guard_(tl_state);
         tl_state->h_edge_seq[((uint32_t)l.plane << 30) | ((uint32_t)l.y << 15) | (uint32_t)l.x] = ++tl_state->seq;
+    }
     int rc = ohevc_rec_deblock(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
 }
@@ -387,8 +385,8 @@ void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int
         fprintf(stderr, "sao plane %d x %d y %d w %d h %d type %d klass %d borders %d restore %d edges %d quirks %d off %d %d %d %d %d\n", j.plane, j.x, j.y,
                 j.w, j.h, j.type, j.klass, j.borders, j.restore, j.edges, j.quirks, j.offset_val[0], j.offset_val[1], j.offset_val[2],
                 j.offset_val[3], j.offset_val[4]);
-    Guard guard_(tl_state);
     if (tl_state->lag_on && c_idx > 0) {        // flags depend on calls still to come: decided in ohevc_tables_end_frame
+        Guard guard_(tl_state);
         tl_state->held_sao.emplace_back(j, ++tl_state->seq);
         return;
     }
@@ -567,7 +565,7 @@ extern "C" int ohevc_tables_set_concurrent(ohevc_ctx *ctx, int on)
     TablesState *st = state_of(ctx, true);
     if (!st) return OHEVC_ERR_ARG;
     st->concurrent = on != 0;
-    return OHEVC_OK;
+    return ohevc_ctx_set_concurrent(ctx, on);
 }
 
 extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *const data[3], const int linesize[3])
@@ -721,7 +719,6 @@ extern "C" int ohevc_tables_intra_pred(const ohevc_intra_geom *geom, int x0, int
     if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
     ohevc_intra_job j;
     int rc = ohevc_intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, &j);
-    Guard guard_(tl_state);
     if (rc == OHEVC_OK) rc = ohevc_rec_intra(tl_ctx, &j);
     if (rc != OHEVC_OK) fail(rc);
     return rc;
@@ -737,7 +734,6 @@ extern "C" int ohevc_tables_intra_pred_cip(const ohevc_intra_geom *geom, int log
     ohevc_intra_cip cip;
     int rc = ohevc_intra_make_job_cip(geom, log2_min_pu_size, pred_flag, pred_flag_stride, intra_value, x0, y0, log2_size, c_idx, mode,
                                       cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, &j, &cip);
-    Guard guard_(tl_state);
     if (rc == OHEVC_OK) rc = ohevc_rec_intra_cip(tl_ctx, &j, &cip);
     if (rc != OHEVC_OK) fail(rc);
     return rc;

@@ -239,7 +239,27 @@ def upsample_params(el_w, el_h, bl_w, bl_h, win, up, block_slots):
     return UpsampleParams(el_w, el_h, bl_w, bl_h, *[int(v) for v in win], u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], u[8], int(block_slots))
 
 
-EXPORTED_SYMBOLS += ["ohevc_upsample_make_maps", "ohevc_dev_upsample_plane", "ohevc_pic_upsample", "ohevc_tables_upsample_frame"]
+UPSAMPLE_TAP = np.dtype([("pos", "<i2"), ("phase", "u1"), ("reserved", "u1")])
+
+
+def upsample_maps(params, plane):
+    """ohevc_upsample_make_maps: (cols, col_of, rows, src_cols, src_rows) of one plane as numpy arrays"""
+    w = params.el_width >> (1 if plane else 0)
+    h = params.el_height >> (1 if plane else 0)
+    cols, col_of, rows = np.zeros(w, UPSAMPLE_TAP), np.zeros(w, np.int16), np.zeros(h, UPSAMPLE_TAP)
+    sc, sr = C.c_int(), C.c_int()
+    check(load_library().ohevc_upsample_make_maps(C.byref(params), plane, cols.ctypes.data_as(C.c_void_p), col_of.ctypes.data_as(C.c_void_p),
+                                                  rows.ctypes.data_as(C.c_void_p), C.byref(sc), C.byref(sr)))
+    return cols, col_of, rows, sc.value, sr.value
+
+
+def dev_upsample_plane(dst_tensor, src_tensor, bit_depth, chroma, cols_ptr, col_of_ptr, rows_ptr, src_cols, src_rows, stream=0):
+    d, s = planes_of([dst_tensor]), planes_of([src_tensor])
+    check(load_library().ohevc_dev_upsample_plane(d, s, C.c_int(bit_depth), C.c_int(chroma), C.c_void_p(cols_ptr), C.c_void_p(col_of_ptr),
+                                                  C.c_void_p(rows_ptr), C.c_int(src_cols), C.c_int(src_rows), C.c_void_p(stream)))
+
+
+EXPORTED_SYMBOLS += ["ohevc_upsample_make_maps", "ohevc_dev_upsample_plane", "ohevc_pic_upsample", "ohevc_tables_upsample_frame", "ohevc_ctx_set_concurrent"]
 
 
 class Ctx:

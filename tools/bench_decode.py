@@ -48,10 +48,16 @@ def main():
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--gop", default="random_access")
     ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--wpp", action="store_true", help="entropy_coding_sync stream; adds slice-thread (WPP row) and frame+slice runs")
+    ap.add_argument("--chroma-format", type=int, default=1)
     a = ap.parse_args()
     w, h = map(int, a.size.split("x"))
     h8 = (h + 7) // 8 * 8
     kw = dict(gop=a.gop, nframes=a.frames, seed=7, width=w, height=h8, log2_ctb=6, bit_depth=a.bit_depth)
+    if a.wpp:
+        kw.update(wpp=1)
+    if a.chroma_format != 1:
+        kw.update(chroma_format=a.chroma_format, rext=1)
     if a.dense:
         kw.update(init_qp=38, probs=dict(rqt_root_cbf=0.8, cbf_luma=0.8, sig_coeff=0.6, last_x=0.75, last_y=0.75, skip=0.15))
     t = time.perf_counter()
@@ -70,12 +76,21 @@ def main():
                bit_exact=bool(exact), bit_exact_frame_threads=bool(exact_mt), generate_s=round(tgen, 2))
     mp = w * h8 * a.frames / 1e6
     import ctypes as C
-    for name, kind, th, tt in (("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
+    runs = []
+    if a.wpp:       # the reference's slice threads (one WPP row per pool thread) and frame + slice threads
+        ref_st = ps.decode_stream("c", aus, a.cpu_threads, 2)
+        hip_st = ps.decode_stream("hip", aus, a.cpu_threads, 2)
+        res["reference_agrees_with_itself_with_slice_threads"] = bool(all(np.array_equal(x, y) for fa, fb in zip(ref, ref_st) for x, y in zip(fa, fb)))
+        res["bit_exact_slice_threads"] = bool(len(ref_st) == len(hip_st) and all(np.array_equal(x, y) for fa, fb in zip(ref_st, hip_st) for x, y in zip(fa, fb)))
+        runs = [(f"reference_c_{a.cpu_threads}slice_threads", "c", a.cpu_threads, 2), (f"hip_backend_{a.cpu_threads}slice_threads", "hip", a.cpu_threads, 2),
+                (f"reference_c_{a.cpu_threads}frame_and_slice_threads", "c", a.cpu_threads, 4),
+                (f"hip_backend_{a.cpu_threads}frame_and_slice_threads", "hip", a.cpu_threads, 4)]
+    for name, kind, th, tt in runs + [("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
                                ("front_end_only_no_pixels", "null", 1, 1),
                                (f"front_end_only_{a.cpu_threads}frame_threads", "null", a.cpu_threads, 1),
                                ("hip_backend", "hip", 1, 1), (f"hip_backend_{a.cpu_threads}frame_threads", "hip", a.cpu_threads, 1),
                                (f"reference_c_{2 * a.cpu_threads}frame_threads", "c", 2 * a.cpu_threads, 1),
-                               (f"hip_backend_{2 * a.cpu_threads}frame_threads", "hip", 2 * a.cpu_threads, 1)):
+                               (f"hip_backend_{2 * a.cpu_threads}frame_threads", "hip", 2 * a.cpu_threads, 1)]:
         if not ps.have(kind):
             continue
         dt, n = timed_decode(kind, aus, th, tt)

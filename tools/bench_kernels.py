@@ -138,6 +138,17 @@ def main():
             ms = timeit(lambda pic: L.dev_tu_batch(L.planes_of(pic), bd, log2, kind, d_jobs.data_ptr(), n, coeffs.data_ptr(), st()), pic_aligned)
             alg = n * ((0 if kind == L.TU_DC else 2 * nn * nn) + 2 * P * nn * nn)
             report(f"tu {name} full 4K luma plane, {bd}-bit", ms, W * H, alg, out)
+        # ---- SHVC inter-layer up-sampling: a 1080p base-layer luma plane into the 4K picture (x2, general filter rules)
+        bw, bh = W // 2, H // 2
+        up = [2048, 2048, 32768, 32768, 2048, 10240, 32768, 32768, 0]
+        prm = L.upsample_params(W, H, bw, bh, (0, 0, 0, 0), up, 0)
+        cols, col_of, rows, sc, sr = L.upsample_maps(prm, 0)
+        d_cols, d_colof, d_rows = dev(cols), dev(col_of), dev(rows)
+        dt = torch.uint8 if bd == 8 else torch.int16
+        base = torch.randint(0, 1 << bd, (bh, bw), dtype=dt, device="cuda", generator=g)
+        ms = timeit(lambda pic: L.dev_upsample_plane(pic[0], base, bd, 0, d_cols.data_ptr(), d_colof.data_ptr(), d_rows.data_ptr(), sc, sr, st()),
+                    lambda: rand_pic(bd, g))
+        report(f"shvc upsample x2 luma 1080p -> 4K, {bd}-bit", ms, W * H, P * W * H + P * bw * bh, out)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w"), indent=1)
 
 
