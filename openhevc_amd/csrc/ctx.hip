@@ -189,7 +189,6 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     OHEVC_REQUIRE(out != nullptr, "out");
     if (g_record_only || (share_with && share_with->dry)) {
         ohevc_ctx *c = new ohevc_ctx();
-    c->gen = g_ctx_gen.fetch_add(1);
         c->gen = g_ctx_gen.fetch_add(1);
         c->dry = true;
         c->store = share_with ? share_with->store : std::make_shared<PicStore>();
@@ -200,6 +199,7 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     int rc = ohevc_set_device(device);
     if (rc != OHEVC_OK) return rc;
     ohevc_ctx *c = new ohevc_ctx();
+    c->gen = g_ctx_gen.fetch_add(1);
     c->device = device;
     c->store = share_with ? share_with->store : std::make_shared<PicStore>();
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&

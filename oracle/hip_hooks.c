@@ -17,6 +17,9 @@
 #include <time.h>
 #include <limits.h>
 #include <pthread.h>
+#include <signal.h>
+#include <execinfo.h>
+#include <unistd.h>
 
 #include "libavcodec/hevc.h"
 #include "libavcodec/thread.h"
@@ -215,9 +218,25 @@ int ohhip_res_scale_sign_flag(HEVCContext *s, int idx)
     return f;
 }
 
+/* OHHIP_BACKTRACE=1: native backtrace of a crashing thread on stderr (resolve the offsets with addr2line on the same .so) */
+static void crash_handler(int sig)
+{
+    void *frames[64];
+    int n = backtrace(frames, 64);
+    static const char msg[] = "ohhip: fatal signal, native backtrace:\n";
+    if (write(2, msg, sizeof(msg) - 1) < 0) {}
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 /* ---- called by decoder_harness.c ---- */
 int ohdec_backend_open(void)
 {
+    if (getenv("OHHIP_BACKTRACE")) {
+        signal(SIGSEGV, crash_handler);
+        signal(SIGABRT, crash_handler);
+    }
     if (g_root)
         return 0;
     ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);

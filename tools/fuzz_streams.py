@@ -99,6 +99,8 @@ def main():
             gen_fail += 1
             continue
         n += 1
+        if os.environ.get("FUZZ_VERBOSE"):
+            print("TRY threads", threads, "type", thread_type, json.dumps(kw), flush=True)
         try:
             hip = ps.decode_stream("hip", aus, threads, thread_type)
             ok = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
