@@ -341,6 +341,14 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
     if (c->dry) return OHEVC_OK;
+    {   // the picture may be reconstructed by another context of the store (another decoding thread), possibly not even issued yet
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return p->end_issued; })) {
+            set_error("picture %d was never completed by its decoding thread", slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+    }
     const ohevc_plane &pl = p->planes[plane];
     OHEVC_HIP_TRY(hipMemcpy2DAsync(host, host_stride, pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
                                    hipMemcpyDeviceToHost, c->stream));

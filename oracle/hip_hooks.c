@@ -37,6 +37,7 @@ static ohevc_ctx          *g_all[128];
 static int                 g_nall;
 static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
 static volatile int        g_error;
+static int                 g_defer_download = 1;   /* copy a picture back when it is OUTPUT, not when it ends (OHHIP_DOWNLOAD_AT_FRAME_END=1: old way) */
 static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
 static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
 
@@ -240,6 +241,7 @@ int ohdec_backend_open(void)
     if (g_root)
         return 0;
     ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);
+    g_defer_download = getenv("OHHIP_DOWNLOAD_AT_FRAME_END") == NULL;
     if (getenv("OHHIP_LEVEL_LAUNCH"))
         ohevc_debug_set_level_launch(atoi(getenv("OHHIP_LEVEL_LAUNCH")));          /* A/B of the two executors */   /* host-side profiling, no pixels (ohevc_debug.h) */
     if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
@@ -270,7 +272,7 @@ int ohdec_backend_frame_done(void)
                                     t_s->sps->log2_min_pu_size) != OHEVC_OK)
         g_error = 1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    st = ohevc_tables_end_frame(t_ctx, 1);
+    st = ohevc_tables_end_frame(t_ctx, !g_defer_download);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (st == OHEVC_OK && ohevc_frame_get_stats(t_ctx, &fs) == OHEVC_OK) {
         pthread_mutex_lock(&g_lock);
@@ -300,6 +302,36 @@ void ohhip_report_progress(ThreadFrame *f, int progress, int field)
     ff_thread_report_progress(f, progress, field);
     if (progress == INT_MAX)
         ohdec_backend_frame_done();
+}
+
+/* INTEGRATION.md section 3, "before output": the CPU reads a picture's samples only when it leaves the decoder
+ * (ff_hevc_output_frame, hevc_refs.c:182-267, called at hevc.c:748,3267,4118).  Ending a frame therefore only ISSUES its
+ * device work; the copy-back happens here, for the picture that is actually output, after waiting for whichever context
+ * reconstructed it.  Parsing of the next picture overlaps the device work of this one even with a single decoding thread,
+ * and pictures that are never output are never copied. */
+int ohhip_output_frame(HEVCContext *s, AVFrame *out, int flush)
+{
+    int ret = ff_hevc_output_frame(s, out, flush);
+    if (ret > 0 && g_defer_download && g_root && out->data[0]) {
+        ohevc_ctx *ctx = t_ctx ? t_ctx : g_root;
+        int i, c, slot = -1;
+        pthread_mutex_lock(&g_lock);
+        for (i = 0; i < g_nbufs; i++)
+            if (g_bufs[i].data0 == out->data[0])
+                slot = g_bufs[i].slot;
+        pthread_mutex_unlock(&g_lock);
+        if (slot < 0) {
+            fprintf(stderr, "ohhip: output picture is not in the picture store\n");
+            g_error = 1;
+            return ret;
+        }
+        for (c = 0; c < 3; c++)
+            if (out->data[c] && ohevc_pic_download(ctx, slot, c, out->data[c], out->linesize[c]) != OHEVC_OK) {
+                fprintf(stderr, "ohhip: download failed: %s\n", ohevc_last_error());
+                g_error = 1;
+            }
+    }
+    return ret;
 }
 
 /* hevc_await_progress() (hevc.c:1951-1958) makes a frame thread wait until the rows its motion vectors point at have
