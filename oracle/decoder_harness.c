@@ -24,8 +24,10 @@
 #ifdef OHDEC_HIP
 int  ohdec_backend_open(void);
 int  ohdec_backend_frame_done(void);
+int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
 void ohdec_backend_close(void);
 #else
+static int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]) { (void)data; (void)linesize; return 0; }
 static int  ohdec_backend_open(void) { return 0; }
 static int  ohdec_backend_frame_done(void) { return 0; }
 static void ohdec_backend_close(void) {}
@@ -62,7 +64,7 @@ ohdec *ohdec_open(int threads, int thread_type)
         goto fail;
     d->avctx->flags |= CODEC_FLAG_UNALIGNED;
     d->avctx->err_recognition |= AV_EF_EXPLODE;     /* a syntax error fails the call instead of being concealed (hevc.c:3480) */
-    av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type == 3 ? "frameslice" : "frame", 0);
+    av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type >= 3 ? "frameslice" : "frame", 0);
     d->threads = threads > 0 ? threads : 1;
     av_opt_set_int(d->avctx, "threads", d->threads, 0);
     if (ohdec_backend_open() < 0)
@@ -106,6 +108,9 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
         return -2;
     /* "frame complete, before output" (INTEGRATION.md section 3): a no-op for the CPU builds */
     if (ohdec_backend_frame_done() < 0)
+        return -3;
+    /* the application takes the picture: with a deferred copy-back this is where its samples reach the host */
+    if (got && ohdec_backend_fetch_output(d->frame->data, d->frame->linesize) < 0)
         return -3;
     d->have_frame = got;
     return got ? 1 : 0;

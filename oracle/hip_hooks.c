@@ -37,7 +37,7 @@ static ohevc_ctx          *g_all[128];
 static int                 g_nall;
 static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
 static volatile int        g_error;
-static int                 g_defer_download = 1;   /* copy a picture back when it is OUTPUT, not when it ends (OHHIP_DOWNLOAD_AT_FRAME_END=1: old way) */
+static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
 static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
 static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
 
@@ -241,7 +241,7 @@ int ohdec_backend_open(void)
     if (g_root)
         return 0;
     ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);
-    g_defer_download = getenv("OHHIP_DOWNLOAD_AT_FRAME_END") == NULL;
+    g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
     if (getenv("OHHIP_LEVEL_LAUNCH"))
         ohevc_debug_set_level_launch(atoi(getenv("OHHIP_LEVEL_LAUNCH")));          /* A/B of the two executors */   /* host-side profiling, no pixels (ohevc_debug.h) */
     if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
@@ -304,34 +304,33 @@ void ohhip_report_progress(ThreadFrame *f, int progress, int field)
         ohdec_backend_frame_done();
 }
 
-/* INTEGRATION.md section 3, "before output": the CPU reads a picture's samples only when it leaves the decoder
- * (ff_hevc_output_frame, hevc_refs.c:182-267, called at hevc.c:748,3267,4118).  Ending a frame therefore only ISSUES its
- * device work; the copy-back happens here, for the picture that is actually output, after waiting for whichever context
- * reconstructed it.  Parsing of the next picture overlaps the device work of this one even with a single decoding thread,
- * and pictures that are never output are never copied. */
-int ohhip_output_frame(HEVCContext *s, AVFrame *out, int flush)
+/* INTEGRATION.md section 3, "before output".  With OHHIP_DEFER_DOWNLOAD=1 ending a frame only ISSUES its device work and the
+ * copy-back happens here, when the application takes the picture out of the decoder (the harness calls this right after
+ * avcodec_decode_video2 handed it a frame; in openHEVC proper the place is libOpenHevcGetOutput, openHevcWrapper.c:353-398):
+ * parsing of the next picture then overlaps the device work of this one even with a single decoding thread, and pictures
+ * that are never output are never copied.  (Not inside ff_hevc_output_frame: with no reordering the decoder "outputs" the
+ * current picture at hevc_frame_start, before it is decoded, and relies on the shared buffer being filled afterwards.) */
+int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3])
 {
-    int ret = ff_hevc_output_frame(s, out, flush);
-    if (ret > 0 && g_defer_download && g_root && out->data[0]) {
-        ohevc_ctx *ctx = t_ctx ? t_ctx : g_root;
-        int i, c, slot = -1;
-        pthread_mutex_lock(&g_lock);
-        for (i = 0; i < g_nbufs; i++)
-            if (g_bufs[i].data0 == out->data[0])
-                slot = g_bufs[i].slot;
-        pthread_mutex_unlock(&g_lock);
-        if (slot < 0) {
-            fprintf(stderr, "ohhip: output picture is not in the picture store\n");
-            g_error = 1;
-            return ret;
-        }
-        for (c = 0; c < 3; c++)
-            if (out->data[c] && ohevc_pic_download(ctx, slot, c, out->data[c], out->linesize[c]) != OHEVC_OK) {
-                fprintf(stderr, "ohhip: download failed: %s\n", ohevc_last_error());
-                g_error = 1;
-            }
+    ohevc_ctx *ctx = t_ctx ? t_ctx : g_root;
+    int i, c, slot = -1;
+    if (!g_defer_download || !g_root || !data[0])
+        return 0;
+    pthread_mutex_lock(&g_lock);
+    for (i = 0; i < g_nbufs; i++)
+        if (g_bufs[i].data0 == data[0])
+            slot = g_bufs[i].slot;
+    pthread_mutex_unlock(&g_lock);
+    if (slot < 0) {
+        fprintf(stderr, "ohhip: output picture is not in the picture store\n");
+        return -1;
     }
-    return ret;
+    for (c = 0; c < 3; c++)
+        if (data[c] && ohevc_pic_download(ctx, slot, c, data[c], linesize[c]) != OHEVC_OK) {
+            fprintf(stderr, "ohhip: download failed: %s\n", ohevc_last_error());
+            return -1;
+        }
+    return 0;
 }
 
 /* hevc_await_progress() (hevc.c:1951-1958) makes a frame thread wait until the rows its motion vectors point at have
