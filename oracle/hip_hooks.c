@@ -177,25 +177,23 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
  * `ohevc_tables_bind(s->hip)` at their top.  Here the same effect comes from renaming the first call every CTB makes from
  * hevc.c with the context in hand, ff_hevc_cabac_init (hevc.c:2666,2785,2873): the wrapper binds the calling thread to the
  * context that is reconstructing s->ref, once per picture and thread. */
-static __thread const uint8_t *t_bound_data0;
 void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts)
 {
     if ((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1 && s->ref && s->ref->frame) {
+        /* looked up every time (once per CTB): a host buffer address names a different picture -- and, with frame + slice
+         * threads, a different context -- every time the decoder's pool recycles it */
         const uint8_t *d0 = s->ref->frame->data[0];
-        if (d0 != t_bound_data0 || !t_ctx) {
-            ohevc_ctx *ctx = NULL;
-            int i;
-            pthread_mutex_lock(&g_lock);
-            for (i = 0; i < g_nbufs; i++)
-                if (g_bufs[i].data0 == d0)
-                    ctx = g_bufs[i].ctx;
-            pthread_mutex_unlock(&g_lock);
-            if (ctx && ctx != t_ctx) {            /* a pool thread: it never owns a context, it borrows the picture's */
-                if (ohevc_tables_bind(ctx) != OHEVC_OK)
-                    g_error = 1;
-                t_ctx = ctx;
-            }
-            t_bound_data0 = d0;
+        ohevc_ctx *ctx = NULL;
+        int i;
+        pthread_mutex_lock(&g_lock);
+        for (i = 0; i < g_nbufs; i++)
+            if (g_bufs[i].data0 == d0)
+                ctx = g_bufs[i].ctx;
+        pthread_mutex_unlock(&g_lock);
+        if (ctx && ctx != t_ctx) {            /* a pool thread: it never owns a context, it borrows the picture's */
+            if (ohevc_tables_bind(ctx) != OHEVC_OK)
+                g_error = 1;
+            t_ctx = ctx;
         }
     }
     ff_hevc_cabac_init(s, ctb_addr_ts);                             /* hevc_cabac.c */
