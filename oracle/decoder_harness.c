@@ -120,8 +120,10 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
  * worker may have nothing to show (pthread_frame.c), so "nothing" only counts after every worker has been asked. */
 int ohdec_flush(ohdec *d)
 {
-    int i, r = 0;
-    for (i = 0; i <= d->threads && r == 0; i++)
+    int i, r = 0, workers = d->threads;
+    if (d->avctx->thread_count_frame > workers)     /* frame + slice threads: the frame-thread count is derived from the core count (pthread.c:65-71) */
+        workers = d->avctx->thread_count_frame;
+    for (i = 0; i <= workers && r == 0; i++)
         r = ohdec_decode(d, NULL, 0, 0);
     return r;
 }
