@@ -50,10 +50,15 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--wpp", action="store_true", help="entropy_coding_sync stream; adds slice-thread (WPP row) and frame+slice runs")
     ap.add_argument("--chroma-format", type=int, default=1)
+    ap.add_argument("--natural", action="store_true",
+                    help="syntax statistics closer to an encoder's random-access output: few intra CUs in inter pictures, many skipped / merged CUs")
     a = ap.parse_args()
     w, h = map(int, a.size.split("x"))
     h8 = (h + 7) // 8 * 8
     kw = dict(gop=a.gop, nframes=a.frames, seed=7, width=w, height=h8, log2_ctb=6, bit_depth=a.bit_depth)
+    if a.natural:
+        kw.update(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
+                                          split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
     if a.wpp:
         kw.update(wpp=1)
     if a.chroma_format != 1:
@@ -72,7 +77,7 @@ def main():
     ps._load("hip").ohdec_backend_profile(C0.byref(_sec), _cnt)        # reset the cumulative counters
     exact = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
     res = dict(workload=f"synthetic {a.gop} stream {w}x{h8} {a.bit_depth}-bit, {a.frames} pictures, "
-                        f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}",
+                        f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}{' (encoder-like CU statistics)' if a.natural else ''}",
                bit_exact=bool(exact), bit_exact_frame_threads=bool(exact_mt), generate_s=round(tgen, 2))
     mp = w * h8 * a.frames / 1e6
     import ctypes as C
