@@ -99,3 +99,24 @@ def test_slice_threads_hip_backend(kw):
     for thread_type in (2, 4):
         for _ in range(2):
             _compare(ref, ps.decode_stream("hip", aus, 4, thread_type))
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_parameter_sets_change_mid_stream(threads):
+    """A new IDR with a new SPS: picture size, bit depth and chroma format change inside one decoder session (set_sps re-fills
+    the tables, hevc.c:421-423; the frame pool hands out new buffers; the hooks re-allocate picture-store slots whose host
+    buffer now has another geometry)."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    parts = [dict(gop="random_access", nframes=5, seed=901, width=416, height=240, log2_ctb=6),
+             dict(gop="lowdelay_b", nframes=4, seed=902, width=192, height=128, log2_ctb=4, log2_max_tb=4, bit_depth=10),
+             dict(gop="lowdelay_p", nframes=3, seed=903, width=416, height=240, log2_ctb=5, rext=1, chroma_format=3),
+             dict(gop="random_access", nframes=5, seed=904, width=832, height=480, log2_ctb=6, bit_depth=10)]
+    aus, gen_frames = [], []
+    for kw in parts:
+        a, g = ps.generate(ps.StreamParams(**kw))
+        aus += a
+        gen_frames += g
+    ref = ps.decode_stream("c", aus)
+    assert frames_md5(ref) == frames_md5(gen_frames)
+    _compare(ref, ps.decode_stream("hip", aus, threads, 1))
