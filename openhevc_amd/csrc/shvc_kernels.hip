@@ -7,7 +7,7 @@
 // 12-bit rounding (N_SHIFT, hevcdsp.h:40-41), 16 phases, 8 taps luma / 4 taps chroma (H.265 tables H.1 / H.2); they only
 // differ in how a column / row finds its base-layer position and phase (general formula, or the fixed x2 / x1.5 patterns of
 // the idx 1 / 2 slots).  Here that part is a per-column and per-row MAP built on the host (ohevc_upsample_make_maps, below:
-// the reference's formulas, cited there); the kernel is one gather-filter pass per output sample and never sees a scale
+// the reference's formulas, cited there); the kernel is a gather-filter over a sliding window of horizontally filtered rows and never sees a scale
 // factor.  Coordinates are clamped instead of reading emulated edges.  Bytes per unit: P per written sample + the
 // base-layer picture once (it is re-read through L2: 64 taps per luma sample, 16 per chroma sample).
 #include <algorithm>
@@ -25,36 +25,60 @@ __constant__ signed char kUpChroma[16][4] = {
     {  0, 64,  0,  0 }, { -2, 62,  4,  0 }, { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
     { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, {  0,  4, 62, -2 } };
 
-template <typename Pixel, int TAPS>
+// One thread produces ROWS consecutive output rows of one column.  Consecutive output rows read base-layer rows that advance by
+// at most one per row (the enhancement layer is never smaller than the base layer), so the horizontally filtered values live
+// in a sliding window of TAPS registers: TAPS + ROWS - 1 horizontal filters per thread instead of TAPS * ROWS.  The window is
+// indexed by base-layer row, not by output row, so any monotonic row map works (a jump forces a refill).
+template <typename Pixel, int TAPS, int ROWS>
 __global__ __launch_bounds__(256) void upsample_kernel(ohevc_plane dst, ohevc_plane src, const ohevc_upsample_tap *__restrict__ cols,
                                                        const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
                                                        int src_cols, int src_rows, int bit_depth)
 {
     constexpr int HALF = TAPS / 2 - 1;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= dst.width || y >= dst.height) return;
-    const ohevc_upsample_tap tc = cols[col_of[x]], tr = rows[y];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (x >= dst.width || y0 >= dst.height) return;
+    const ohevc_upsample_tap tc = cols[col_of[x]];
     const unsigned char *sbase = static_cast<const unsigned char *>(src.data);
-    int acc = 0;
+    int cx[TAPS], ch[TAPS];                                    // clamped source columns and this column's horizontal taps
 #pragma unroll
-    for (int kv = 0; kv < TAPS; kv++) {
-        int ry = tr.pos - HALF + kv;
-        ry = ry < 0 ? 0 : ry > src_rows - 1 ? src_rows - 1 : ry;
-        const Pixel *row = reinterpret_cast<const Pixel *>(sbase + (size_t)ry * src.stride);
+    for (int k = 0; k < TAPS; k++) {
+        const int rx = tc.pos - HALF + k;
+        cx[k] = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
+        ch[k] = TAPS == 8 ? (int)kUpLuma[tc.phase][k] : (int)kUpChroma[tc.phase][k];
+    }
+    auto hfilt = [&](int row) {                                 // horizontal pass of one base-layer row (clamped), as int16
+        const int ry = row < 0 ? 0 : row > src_rows - 1 ? src_rows - 1 : row;
+        const Pixel *p = reinterpret_cast<const Pixel *>(sbase + (size_t)ry * src.stride);
         int h = 0;
 #pragma unroll
-        for (int kh = 0; kh < TAPS; kh++) {
-            int rx = tc.pos - HALF + kh;
-            rx = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
-            h += (TAPS == 8 ? (int)kUpLuma[tc.phase][kh] : (int)kUpChroma[tc.phase][kh]) * (int)row[rx];
-        }
-        // the reference keeps the horizontal pass in int16 (short *Buffer / int16_t tmp): it wraps above 8 bit
-        acc += (TAPS == 8 ? (int)kUpLuma[tr.phase][kv] : (int)kUpChroma[tr.phase][kv]) * (int)(short)h;
-    }
+        for (int k = 0; k < TAPS; k++) h += ch[k] * (int)p[cx[k]];
+        return (int)(short)h;                                   // the reference keeps this pass in int16: it wraps above 8 bit
+    };
+    int win[TAPS], base = 0x40000000;                           // win[k] = hfilt(base + k); no window yet
     const int maxv = (1 << bit_depth) - 1;
-    int v = (acc + (1 << 11)) >> 12;                            // I_OFFSET / N_SHIFT, hevcdsp.h:40-41
-    v = v < 0 ? 0 : v > maxv ? maxv : v;
-    *(reinterpret_cast<Pixel *>(static_cast<unsigned char *>(dst.data) + (size_t)y * dst.stride) + x) = (Pixel)v;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= dst.height) break;
+        const ohevc_upsample_tap tr = rows[y];                  // wave-uniform (one row of 64 columns per wavefront)
+        const int first = tr.pos - HALF;
+        if (first == base + 1) {                                // the common step: slide by one row
+#pragma unroll
+            for (int k = 0; k + 1 < TAPS; k++) win[k] = win[k + 1];
+            win[TAPS - 1] = hfilt(first + TAPS - 1);
+            base = first;
+        } else if (first != base) {                             // first row of the strip, or a jump in the row map
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) win[k] = hfilt(first + k);
+            base = first;
+        }
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) acc += (TAPS == 8 ? (int)kUpLuma[tr.phase][k] : (int)kUpChroma[tr.phase][k]) * win[k];
+        int v = (acc + (1 << 11)) >> 12;                        // I_OFFSET / N_SHIFT, hevcdsp.h:40-41
+        v = v < 0 ? 0 : v > maxv ? maxv : v;
+        *(reinterpret_cast<Pixel *>(static_cast<unsigned char *>(dst.data) + (size_t)y * dst.stride) + x) = (Pixel)v;
+    }
 }
 
 // Where an enhancement-layer column / row reads the base layer: centre tap position and phase.
@@ -126,13 +150,14 @@ extern "C" int ohevc_dev_upsample_plane(const ohevc_plane *dst, const ohevc_plan
     // never read below the plane that was handed over (the reference would read its frame padding there, see make_maps)
     src_cols = std::min(src_cols, src->width); src_rows = std::min(src_rows, src->height);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((dst->width + 63) / 64, (dst->height + 3) / 4);
+    constexpr int ROWS = 8;                                     // output rows per thread (sliding window of filtered base-layer rows)
+    const dim3 grid((dst->width + 63) / 64, (dst->height + 4 * ROWS - 1) / (4 * ROWS));
     if (bit_depth == 8) {
-        if (chroma) hipLaunchKernelGGL((upsample_kernel<uint8_t, 4>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
-        else        hipLaunchKernelGGL((upsample_kernel<uint8_t, 8>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+        if (chroma) hipLaunchKernelGGL((upsample_kernel<uint8_t, 4, ROWS>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+        else        hipLaunchKernelGGL((upsample_kernel<uint8_t, 8, ROWS>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
     } else {
-        if (chroma) hipLaunchKernelGGL((upsample_kernel<uint16_t, 4>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
-        else        hipLaunchKernelGGL((upsample_kernel<uint16_t, 8>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+        if (chroma) hipLaunchKernelGGL((upsample_kernel<uint16_t, 4, ROWS>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+        else        hipLaunchKernelGGL((upsample_kernel<uint16_t, 8, ROWS>), grid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
     }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;

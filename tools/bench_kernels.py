@@ -15,6 +15,16 @@ from openhevc_amd import lib as L  # noqa: E402
 
 W, H = 3840, 2160
 PEAK = 8000.0
+# --planes N stacks N 4K pictures vertically into one plane per launch: a single 4K plane is 10-60 us of work for this GPU, i.e.
+# mostly launch latency; N = 8 shows what the kernels sustain.  --only SUBSTR keeps the kernels whose name contains SUBSTR.
+PLANES = 1
+ONLY = None
+for i, a in enumerate(sys.argv):
+    if a == "--planes":
+        PLANES = int(sys.argv[i + 1])
+    if a == "--only":
+        ONLY = sys.argv[i + 1]
+H *= PLANES
 
 
 def dev(a):
@@ -30,7 +40,9 @@ def rand_pic(bd, g):
     return [mk(H, W), mk(H // 2, W // 2), mk(H // 2, W // 2)]
 
 
-def timeit(fn, fresh, reps=12):
+def timeit(fn, fresh, reps=12, name=""):
+    if not wanted(name):
+        return None
     st = torch.cuda.current_stream()
     ts = []
     for r in range(reps + 2):
@@ -44,7 +56,15 @@ def timeit(fn, fresh, reps=12):
     return float(np.median(ts))
 
 
+def wanted(name):
+    return ONLY is None or ONLY in name
+
+
 def report(name, ms, pixels, alg_bytes, out):
+    if PLANES > 1:
+        name += f" [x{PLANES} pictures per launch]"
+    if ms is None:
+        return
     gbs = alg_bytes / ms / 1e6
     row = {"kernel": name, "ms": round(ms, 4), "Mpixel_per_s": round(pixels / ms / 1e3, 1), "alg_GBps": round(gbs, 1),
            "frac_hbm_peak": round(gbs / PEAK, 4)}
@@ -75,7 +95,7 @@ def main():
                 j["mx" + s], j["my" + s] = rng.integers(0, 4, n), rng.integers(0, 4, n)
             j["ref1"] = 1
             d_jobs = dev(j)
-            ms = timeit(lambda pic: L.dev_mc_batch(L.planes_of(pic), table.data_ptr(), 2, bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g))
+            ms = timeit(lambda pic: L.dev_mc_batch(L.planes_of(pic), table.data_ptr(), 2, bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g), name="mc")
             px = n * bw * bh
             alg = n * ((1 + bi) * P * (bw + 7) * (bh + 7) + P * bw * bh)
             report(f"mc luma {bw}x{bh} {'bi' if bi else 'uni'} {bd}-bit (random qpel phases)", ms, px, alg, out)
@@ -86,7 +106,7 @@ def main():
         j["x"], j["y"], j["plane"], j["flags"], j["beta"] = xs.ravel(), ys.ravel(), 0, L.DBK_VERTICAL_EDGE, 40
         j["tc"] = 6
         d_jobs = dev(j)
-        ms = timeit(lambda pic: L.dev_deblock_batch(L.planes_of(pic), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g))
+        ms = timeit(lambda pic: L.dev_deblock_batch(L.planes_of(pic), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g), name="deblock")
         report(f"deblock luma vertical edges, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         n2 = np.meshgrid(np.arange(0, W, 8), np.arange(8, H, 8))[0].size
         j2 = np.zeros(n2, L.DBK_JOB)
@@ -94,7 +114,7 @@ def main():
         j2["x"], j2["y"], j2["plane"], j2["flags"], j2["beta"] = xs.ravel(), ys.ravel(), 0, 0, 40
         j2["tc"] = 6
         d_jobs2 = dev(j2)
-        ms = timeit(lambda pic: L.dev_deblock_batch(L.planes_of(pic), bd, d_jobs2.data_ptr(), n2, st()), lambda: rand_pic(bd, g))
+        ms = timeit(lambda pic: L.dev_deblock_batch(L.planes_of(pic), bd, d_jobs2.data_ptr(), n2, st()), lambda: rand_pic(bd, g), name="deblock")
         report(f"deblock luma horizontal edges, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         # ---- SAO: one job per 64x64 luma CTB, edge class 2 / band
         src = rand_pic(bd, g)
@@ -108,7 +128,7 @@ def main():
             j["borders"] = (j["x"] == 0) * 1 + (j["y"] == 0) * 2 + (j["x"] + j["w"] == W) * 4 + (j["y"] + j["h"] == H) * 8
             j["offset_val"] = [0, 3, 1, -1, -3]
             d_jobs = dev(j)
-            ms = timeit(lambda pic: L.dev_sao_batch(L.planes_of(pic), L.planes_of(src), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g))
+            ms = timeit(lambda pic: L.dev_sao_batch(L.planes_of(pic), L.planes_of(src), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g), name="sao")
             report(f"sao {name} luma, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         # ---- intra: independent blocks on a sparse grid (every other block position), all 35 modes
         for log2 in (2, 3, 4, 5):
@@ -120,7 +140,7 @@ def main():
             j["flags"] = 31 | L.INTRA_STRONG | L.INTRA_LUMA_EDGE
             j["bottom_left_size"] = nn; j["top_right_size"] = nn
             d_jobs = dev(j)
-            ms = timeit(lambda pic: L.dev_intra_batch(L.planes_of(pic), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g))
+            ms = timeit(lambda pic: L.dev_intra_batch(L.planes_of(pic), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g), name="intra")
             report(f"intra {nn}x{nn} independent blocks, {bd}-bit", ms, n * nn * nn, n * (P * (4 * nn + 1) + P * nn * nn), out)
         # ---- small / special residual kinds
         for (log2, kind, name) in [(2, L.TU_IDCT, "idct4x4"), (2, L.TU_DST4, "dst4x4"), (3, L.TU_IDCT, "idct8x8"), (4, L.TU_DC, "dc16x16"), (3, L.TU_SKIP, "skip8x8")]:
@@ -135,7 +155,7 @@ def main():
             def pic_aligned():
                 dt = torch.uint8 if bd == 8 else torch.int16
                 return [torch.randint(0, 1 << bd, (H, W), dtype=dt, device="cuda", generator=g), None, None]
-            ms = timeit(lambda pic: L.dev_tu_batch(L.planes_of(pic), bd, log2, kind, d_jobs.data_ptr(), n, coeffs.data_ptr(), st()), pic_aligned)
+            ms = timeit(lambda pic: L.dev_tu_batch(L.planes_of(pic), bd, log2, kind, d_jobs.data_ptr(), n, coeffs.data_ptr(), st()), pic_aligned, name="tu")
             alg = n * ((0 if kind == L.TU_DC else 2 * nn * nn) + 2 * P * nn * nn)
             report(f"tu {name} full 4K luma plane, {bd}-bit", ms, W * H, alg, out)
         # ---- SHVC inter-layer up-sampling: a 1080p base-layer luma plane into the 4K picture (x2, general filter rules)
@@ -147,9 +167,9 @@ def main():
         dt = torch.uint8 if bd == 8 else torch.int16
         base = torch.randint(0, 1 << bd, (bh, bw), dtype=dt, device="cuda", generator=g)
         ms = timeit(lambda pic: L.dev_upsample_plane(pic[0], base, bd, 0, d_cols.data_ptr(), d_colof.data_ptr(), d_rows.data_ptr(), sc, sr, st()),
-                    lambda: rand_pic(bd, g))
-        report(f"shvc upsample x2 luma 1080p -> 4K, {bd}-bit", ms, W * H, P * W * H + P * bw * bh, out)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w"), indent=1)
+                    lambda: rand_pic(bd, g), name="shvc")
+        report(f"shvc upsample x2 luma {bw}x{bh} -> {W}x{H}, {bd}-bit", ms, W * H, P * W * H + P * bw * bh, out)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_x{PLANES}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
