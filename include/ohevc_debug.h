@@ -2,6 +2,7 @@
  * integration needs lives here; bench/profiling scripts use it to compare kernel variants inside one process. */
 #ifndef OHEVC_DEBUG_H
 #define OHEVC_DEBUG_H
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -28,6 +29,26 @@ int ohevc_debug_set_level_launch(int mode);
  * ohevc_rec_* call does its normal work, the frame-end executor just drops the recorded jobs.  It exists to time the
  * recording cost of the table slots (tools/profile_recording.py); never a fallback: pictures stay unwritten. */
 int ohevc_debug_set_record_only(int on);
+
+/* Inspection of a record-only context, for HOST-LOGIC TESTS without a GPU: before a record-only context drops what was
+ * recorded, it hands itself to this callback -- stage 0 from ohevc_frame_reconstruct (motion compensation, residual and intra
+ * levels), stage 1 from ohevc_frame_end (in-loop filters) -- and the accessors below expose the job arrays exactly as the
+ * executor would stage them (slice-thread recorders already merged).  tests/ uses it to run the recorded jobs through the CPU
+ * oracle on the decoder's own host frames (oracle/sw_exec.c) and compare whole pictures with the untouched decoder: recording
+ * slots, pointer registry, dependency levels, filter flags.  The product never installs a sink and computes nothing on the CPU. */
+struct ohevc_ctx;
+typedef void (*ohevc_debug_sink)(void *user, struct ohevc_ctx *ctx, int stage);
+void ohevc_debug_set_frame_sink(ohevc_debug_sink fn, void *user);
+int ohevc_debug_target(struct ohevc_ctx *ctx, int *slot, int *width, int *height, int *chroma_format_idc, int *bit_depth);
+int ohevc_debug_mc(struct ohevc_ctx *ctx, int small, const struct ohevc_mc_job **jobs, int *n);
+int ohevc_debug_level_count(struct ohevc_ctx *ctx);
+int ohevc_debug_level_intra(struct ohevc_ctx *ctx, int level, const struct ohevc_intra_job **jobs, int *n);
+int ohevc_debug_level_tu(struct ohevc_ctx *ctx, int level, int log2_size, int kind, const struct ohevc_tu_job **jobs, int *n);
+int ohevc_debug_arena(struct ohevc_ctx *ctx, const int16_t **coeffs, const struct ohevc_intra_cip **cips);
+int ohevc_debug_filters(struct ohevc_ctx *ctx, const struct ohevc_dbk_job **vertical, int *n_vertical, const struct ohevc_dbk_job **horizontal,
+                        int *n_horizontal, const struct ohevc_sao_job **sao, int *n_sao, struct ohevc_sao_bypass *bypass /* HOST map */);
+/* block until the frame that reconstructs picture `slot` has ended (frame threads: another context of the store) */
+int ohevc_debug_wait_picture(struct ohevc_ctx *ctx, int slot);
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,8 @@ int  ohevc_tables_upsample_frame(const uint8_t *el_data0, const uint8_t *bl_data
  * tables.  Call this with lc->tu.res_scale_val at the end of hls_cross_component_pred: the next chroma transform_add of the
  * calling thread becomes an OHEVC_TU_CROSS job (both coefficient blocks travel, the kernel forms both residuals). */
 int  ohevc_tables_cross_component(int res_scale_val);
+/* the host planes registered for picture-store slot `slot` (tests: oracle/sw_exec.c executes recorded jobs on them) */
+int  ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[3], int linesize[3]);
 /* sticky status of the recording since begin_frame: table slots return void, so failures surface here */
 int  ohevc_tables_status(ohevc_ctx *ctx);
 /* Reproduce the reference front-end's filter lag (ff_hevc_hls_filter / ff_hevc_hls_filters, hevc_filter.c:1027-1063):

@@ -255,6 +255,11 @@ extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
 extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
 extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
 
+// ---- inspection of record-only contexts (ohevc_debug.h): host-logic tests without a GPU
+static ohevc_debug_sink g_sink = nullptr;
+static void *g_sink_user = nullptr;
+extern "C" void ohevc_debug_set_frame_sink(ohevc_debug_sink fn, void *user) { g_sink = fn; g_sink_user = user; }
+
 extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
@@ -865,7 +870,11 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     merge_side(c);
-    if (c->dry) { clear_recorded(c); return OHEVC_OK; }
+    if (c->dry) {
+        if (g_sink) g_sink(g_sink_user, c, 0);
+        clear_recorded(c);
+        return OHEVC_OK;
+    }
     OHEVC_HIP_TRY(hipSetDevice(c->device));
     if (c->mc.empty() && c->mc_small.empty() && c->max_level < 0) return OHEVC_OK;
     int rc = upload_table(c);
@@ -1012,7 +1021,10 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
     struct Acc { ohevc_ctx *c; double t0; ~Acc() { if (g_trace_timing) { c->t_issue += now_s() - t0; c->n_frames++; } } } acc{c, t_begin};
     int rc = ohevc_frame_reconstruct(c);
     if (rc != OHEVC_OK) return rc;
-    if (c->dry) { c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; }
+    if (c->dry) {
+        if (g_sink) g_sink(g_sink_user, c, 1);
+        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
+    }
     if (c->sao.empty()) c->bypass.clear();
     if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty()) {
         std::vector<std::pair<const void *, size_t>> parts;
@@ -1084,6 +1096,70 @@ extern "C" int ohevc_frame_end(ohevc_ctx *c)
     c->store->cv.notify_all();
     c->stats.n_tu = c->nstat[0]; c->stats.n_mc = c->nstat[1]; c->stats.n_intra = c->nstat[2]; c->stats.n_dbk = c->nstat[3]; c->stats.n_sao = c->nstat[4];
     c->last_stats = c->stats;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_debug_target(ohevc_ctx *c, int *slot, int *width, int *height, int *cfi, int *bd)
+{
+    OHEVC_REQUIRE(c != nullptr && c->cur >= 0, "no frame begun");
+    if (slot) *slot = c->cur;
+    return ohevc_pic_info(c, c->cur, width, height, cfi, bd);
+}
+extern "C" int ohevc_debug_mc(ohevc_ctx *c, int small, const ohevc_mc_job **jobs, int *n)
+{
+    OHEVC_REQUIRE(c != nullptr && jobs != nullptr && n != nullptr, "null argument");
+    const auto &v = small ? c->mc_small : c->mc;
+    *jobs = v.data(); *n = (int)v.size();
+    return OHEVC_OK;
+}
+extern "C" int ohevc_debug_level_count(ohevc_ctx *c) { return c ? c->max_level + 1 : 0; }
+extern "C" int ohevc_debug_level_intra(ohevc_ctx *c, int level, const ohevc_intra_job **jobs, int *n)
+{
+    OHEVC_REQUIRE(c != nullptr && level >= 0 && level <= c->max_level && jobs != nullptr && n != nullptr, "bad level");
+    *jobs = c->levels[level].intra.data(); *n = (int)c->levels[level].intra.size();
+    return OHEVC_OK;
+}
+extern "C" int ohevc_debug_level_tu(ohevc_ctx *c, int level, int log2, int kind, const ohevc_tu_job **jobs, int *n)
+{
+    OHEVC_REQUIRE(c != nullptr && level >= 0 && level <= c->max_level && log2 >= 2 && log2 <= 5 && kind >= 0 && kind < OHEVC_TU_NKINDS &&
+                  jobs != nullptr && n != nullptr, "bad bin");
+    const auto &v = c->levels[level].tu[log2 - 2][kind];
+    *jobs = v.data(); *n = (int)v.size();
+    return OHEVC_OK;
+}
+extern "C" int ohevc_debug_arena(ohevc_ctx *c, const int16_t **coeffs, const ohevc_intra_cip **cips)
+{
+    OHEVC_REQUIRE(c != nullptr, "null context");
+    if (coeffs) *coeffs = c->coeffs.data();
+    if (cips) *cips = c->cips.data();
+    return OHEVC_OK;
+}
+extern "C" int ohevc_debug_filters(ohevc_ctx *c, const ohevc_dbk_job **v, int *nv, const ohevc_dbk_job **h, int *nh, const ohevc_sao_job **sao, int *ns,
+                                   ohevc_sao_bypass *bypass)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr && v && nv && h && nh && sao && ns, "bad argument");
+    *v = c->dbk_v.data(); *nv = (int)c->dbk_v.size();
+    *h = c->dbk_h.data(); *nh = (int)c->dbk_h.size();
+    *sao = c->sao.data(); *ns = (int)c->sao.size();
+    if (bypass) {
+        *bypass = ohevc_sao_bypass{};
+        if (!c->bypass.empty()) {
+            bypass->map = c->bypass.data(); bypass->stride = c->bypass_w; bypass->log2_min_pu_size = c->bypass_l2;
+            bypass->chroma_hshift = p->cfi == 1 || p->cfi == 2; bypass->chroma_vshift = p->cfi == 1; bypass->exact_reference = c->bypass_exact;
+        }
+    }
+    return OHEVC_OK;
+}
+extern "C" int ohevc_debug_wait_picture(ohevc_ctx *c, int slot)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr, "bad picture slot");
+    std::unique_lock<std::mutex> lk(c->store->m);
+    if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return p->end_issued; })) {
+        set_error("picture %d was never completed by its decoding thread", slot);
+        return OHEVC_ERR_STATE;
+    }
     return OHEVC_OK;
 }
 

@@ -554,6 +554,18 @@ extern "C" int ohevc_tables_upsample_frame(const uint8_t *el_data0, const uint8_
     return rc;
 }
 
+extern "C" int ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[3], int linesize[3])
+{
+    TablesState *s = state_of(ctx, false);
+    if (!s || !data || !linesize) return OHEVC_ERR_ARG;
+    for (int i = 0; i < s->npics(); i++)
+        if (s->pics[i].slot == slot) {
+            for (int c = 0; c < 3; c++) { data[c] = s->pics[i].data[c]; linesize[c] = s->pics[i].linesize[c]; }
+            return OHEVC_OK;
+        }
+    return OHEVC_ERR_STATE;
+}
+
 extern "C" int ohevc_tables_cross_component(int res_scale_val)
 {
     tl_pend.cross_scale = res_scale_val;

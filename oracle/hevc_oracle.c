@@ -558,6 +558,162 @@ static int zscan_addr(int x, int y, int bits)
     return v;
 }
 
+/* What the constrained-intra substitution walk needs to know about the block's surroundings: per-sample "is the neighbour
+ * intra-coded" bits (bit k+1 of top: IS_INTRA(k, -1), of left: IS_INTRA(-1, k), k = -1..63), the two scan limits and whether
+ * the block touches the left / top picture border. */
+typedef struct cip_view {
+    int on;
+    uint8_t top[9], left[9];
+    int smx, smy, x0_nonzero, y0_nonzero;
+} cip_view;
+
+/* The part of intra_pred() (hevcpred_template.c:164-357) that no longer looks at the decoder context: neighbour arrays from the
+ * FINAL availability flags, constrained-intra substitution, padding of unavailable runs, smoothing, prediction.
+ * luma_edge = (c_idx == 0): DC / mode 10 / mode 26 boundary smoothing; no_smoothing = intra_smoothing_disabled_flag || chroma
+ * outside 4:4:4; strong = sps_strong_intra_smoothing_enable_flag && luma. */
+static void intra_core(int bd, uint8_t *blk, ptrdiff_t stride, int log2, int mode, int cand_bottom_left, int cand_left, int cand_up_left,
+                       int cand_up, int cand_up_right, int bl_size, int tr_size, int no_smoothing, int strong, int luma_edge,
+                       const cip_view *cv)
+{
+    const int ps = psz(bd), n = 1 << log2, c_idx = luma_edge ? 0 : 1;
+    int lbuf[2 * 32 + 8], tbuf[2 * 32 + 8], flbuf[2 * 32 + 8], ftbuf[2 * 32 + 8];
+    int *l = lbuf + 4, *t = tbuf + 4, *fl = flbuf + 4, *ft = ftbuf + 4;
+#define REC(x, y) ldpx(PX(blk, stride, x, y), bd)
+#define ISTOP(k)  ((cv->top[((k) + 1) >> 3] >> (((k) + 1) & 7)) & 1)
+#define ISLEFT(k) ((cv->left[((k) + 1) >> 3] >> (((k) + 1) & 7)) & 1)
+    if (cv->on) {
+        /* memset(left/top, 128, 2*MAX_TB_SIZE*sizeof(pixel)); top[-1] = 128  (:160-162): BYTES of value 128 */
+        const int fill = bd > 8 ? 0x8080 : 128;
+        for (int i = 0; i < 64; i++) l[i] = t[i] = fill;
+        t[-1] = 128; l[-1] = 128;                               /* left[-1] is uninitialised in the reference here */
+    }
+    if (cand_up_left) { l[-1] = REC(-1, -1); t[-1] = l[-1]; }
+    if (cand_up) for (int i = 0; i < n; i++) t[i] = REC(i, -1);
+    if (cand_up_right) {
+        for (int i = n; i < n + tr_size; i++) t[i] = REC(i, -1);
+        for (int i = n + tr_size; i < 2 * n; i++) t[i] = REC(n + tr_size - 1, -1);
+    }
+    if (cand_left) for (int i = 0; i < n; i++) l[i] = REC(-1, i);
+    if (cand_bottom_left) {
+        for (int i = n; i < n + bl_size; i++) l[i] = REC(-1, i);
+        for (int i = n + bl_size; i < 2 * n; i++) l[i] = REC(-1, n + bl_size - 1);
+    }
+    /* ---- constrained intra prediction, part 2 (:185-249): samples of inter-coded neighbours are overwritten from the
+     * nearest intra-coded ones, in groups of four, in this exact order */
+    if (cv->on && (cand_bottom_left || cand_left || cand_up_left || cand_up || cand_up_right)) {
+        const int smx = cv->smx, smy = cv->smy;
+        int j = n + (cand_bottom_left ? bl_size : 0) - 1;
+        if (cand_bottom_left || cand_left || cand_up_left) {
+            while (j > -1 && !ISLEFT(j)) j--;
+            if (!ISLEFT(j)) {
+                j = 0;
+                while (j < smx && !ISTOP(j)) j++;
+                for (int i = j; i > j - (j + 1); i--) if (!ISTOP(i - 1)) t[i - 1] = t[i];      /* EXTEND_LEFT_CIP */
+                l[-1] = t[-1];
+            }
+        } else {
+            j = 0;
+            while (j < smx && !ISTOP(j)) j++;
+            if (j > 0) {
+                if (cv->x0_nonzero) {
+                    for (int i = j; i > j - (j + 1); i--) if (!ISTOP(i - 1)) t[i - 1] = t[i];
+                } else {
+                    for (int i = j; i > j - j; i--) if (!ISTOP(i - 1)) t[i - 1] = t[i];
+                    t[-1] = t[0];
+                }
+            }
+            l[-1] = t[-1];
+        }
+        l[-1] = t[-1];
+        if (cand_bottom_left || cand_left) {                     /* EXTEND_DOWN_CIP(left, 0, size_max_y) */
+            int a = l[-1];
+            for (int i = 0; i < smy; i += 4) {
+                if (!ISLEFT(i)) { l[i] = l[i + 1] = l[i + 2] = l[i + 3] = a; } else a = l[i + 3];
+            }
+        }
+        if (!cand_left) for (int i = 0; i < n; i++) l[i] = l[-1];
+        if (!cand_bottom_left) for (int i = n; i < 2 * n; i++) l[i] = l[n - 1];
+        if (cv->x0_nonzero && cv->y0_nonzero) {
+            int a = l[smy - 1];
+            for (int i = smy - 1; i > smy - 1 - smy; i -= 4) {   /* EXTEND_UP_CIP(left, size_max_y - 1, size_max_y) */
+                if (!ISLEFT(i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
+            }
+            if (!ISLEFT(-1)) l[-1] = l[0];
+        } else if (!cv->x0_nonzero) {
+            for (int i = 0; i < smy; i++) l[i] = 0;              /* EXTEND(left, 0, size_max_y) */
+        } else {
+            int a = l[smy - 1];
+            for (int i = smy - 1; i > smy - 1 - smy; i -= 4) {
+                if (!ISLEFT(i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
+            }
+        }
+        t[-1] = l[-1];
+        if (cv->y0_nonzero) {                                    /* EXTEND_RIGHT_CIP(top, 0, size_max_x) */
+            int a = l[-1];
+            for (int i = 0; i < smx; i += 4) {
+                if (!ISTOP(i)) { t[i] = t[i + 1] = t[i + 2] = t[i + 3] = a; } else a = t[i + 3];
+            }
+        }
+    }
+#undef ISTOP
+#undef ISLEFT
+    /* substitution of unavailable samples (:251-286) */
+    if (!cand_bottom_left) {
+        if (cand_left) {
+            for (int i = n; i < 2 * n; i++) l[i] = l[n - 1];
+        } else if (cand_up_left) {
+            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
+            cand_left = 1;
+        } else if (cand_up) {
+            l[-1] = t[0];
+            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
+            cand_up_left = cand_left = 1;
+        } else if (cand_up_right) {
+            for (int i = 0; i < n; i++) t[i] = t[n];
+            l[-1] = t[n];
+            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
+            cand_up = cand_up_left = cand_left = 1;
+        } else {
+            l[-1] = 1 << (bd - 1);
+            for (int i = 0; i < 2 * n; i++) t[i] = l[i] = l[-1];
+        }
+    }
+    if (!cand_left) for (int i = 0; i < n; i++) l[i] = l[n];
+    if (!cand_up_left) l[-1] = l[0];
+    if (!cand_up) for (int i = 0; i < n; i++) t[i] = l[-1];
+    if (!cand_up_right) for (int i = n; i < 2 * n; i++) t[i] = t[n - 1];
+    t[-1] = l[-1];
+
+    /* reference-sample smoothing (:289-327) */
+    if (!no_smoothing && mode != 1 && n != 4) {
+        static const int thresh[3] = { 7, 1, 0 };
+        int dv = abs(mode - 26), dh = abs(mode - 10), dist = dv < dh ? dv : dh;
+        if (dist > thresh[log2 - 3]) {
+            int lim = 1 << (bd - 5);
+            if (strong && log2 == 5 &&
+                abs(t[-1] + t[63] - 2 * t[31]) < lim && abs(l[-1] + l[63] - 2 * l[31]) < lim) {
+                ft[-1] = t[-1]; ft[63] = t[63]; fl[-1] = l[-1]; fl[63] = l[63];
+                for (int i = 0; i < 63; i++) {
+                    ft[i] = ((63 - i) * t[-1] + (i + 1) * t[63] + 32) >> 6;
+                    fl[i] = ((63 - i) * l[-1] + (i + 1) * l[63] + 32) >> 6;
+                }
+            } else {
+                fl[2 * n - 1] = l[2 * n - 1]; ft[2 * n - 1] = t[2 * n - 1];
+                for (int i = 2 * n - 2; i >= 0; i--) {
+                    fl[i] = (l[i + 1] + 2 * l[i] + l[i - 1] + 2) >> 2;
+                    ft[i] = (t[i + 1] + 2 * t[i] + t[i - 1] + 2) >> 2;
+                }
+                ft[-1] = fl[-1] = (l[0] + 2 * l[-1] + t[0] + 2) >> 2;
+            }
+            l = fl; t = ft;
+        }
+    }
+    if (mode == 0)      predict_planar(bd, log2, blk, stride, t, l);
+    else if (mode == 1) predict_dc(bd, log2, blk, stride, t, l, c_idx);
+    else                predict_angular(bd, log2, blk, stride, t, l, c_idx, mode);
+#undef REC
+}
+
 void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, int c_idx, int mode,
                      int cand_bottom_left, int cand_left, int cand_up_left, int cand_up, int cand_up_right)
 {
@@ -570,9 +726,8 @@ void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, 
     int cur = zscan_addr(x_tb, y_tb, tb_bits);
     ptrdiff_t stride = pic->linesize[c_idx];
     uint8_t *blk = pic->data[c_idx] + (ptrdiff_t)(y0 >> vs) * stride + (ptrdiff_t)(x0 >> hs) * ps;
-    int lbuf[2 * 32 + 8], tbuf[2 * 32 + 8], flbuf[2 * 32 + 8], ftbuf[2 * 32 + 8];
-    int *l = lbuf + 4, *t = tbuf + 4, *fl = flbuf + 4, *ft = ftbuf + 4;
-#define REC(x, y) ldpx(PX(blk, stride, x, y), bd)
+    cip_view cv;
+    memset(&cv, 0, sizeof(cv));
 
     /* z-scan qualification of the two "ahead" candidates (:105-109) */
     cand_bottom_left = cand_bottom_left &&
@@ -621,139 +776,40 @@ void ohor_intra_pred(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, 
             cand_up_right = 0;
             for (int i = 0; i < max; i += 2) cand_up_right |= ISPU(xr + i, yt);
         }
-        /* memset(left/top, 128, 2*MAX_TB_SIZE*sizeof(pixel)); top[-1] = 128  (:160-162): BYTES of value 128 */
-        const int fill = bd > 8 ? 0x8080 : 128;
-        for (int i = 0; i < 64; i++) l[i] = t[i] = fill;
-        t[-1] = 128; l[-1] = 128;                               /* left[-1] is uninitialised in the reference here */
-    }
-    if (cand_up_left) { l[-1] = REC(-1, -1); t[-1] = l[-1]; }
-    if (cand_up) for (int i = 0; i < n; i++) t[i] = REC(i, -1);
-    if (cand_up_right) {
-        for (int i = n; i < n + tr_size; i++) t[i] = REC(i, -1);
-        for (int i = n + tr_size; i < 2 * n; i++) t[i] = REC(n + tr_size - 1, -1);
-    }
-    if (cand_left) for (int i = 0; i < n; i++) l[i] = REC(-1, i);
-    if (cand_bottom_left) {
-        for (int i = n; i < n + bl_size; i++) l[i] = REC(-1, i);
-        for (int i = n + bl_size; i < 2 * n; i++) l[i] = REC(-1, n + bl_size - 1);
-    }
-    /* ---- constrained intra prediction, part 2 (:185-249): samples of inter-coded neighbours are overwritten from the
-     * nearest intra-coded ones, in groups of four, in this exact order */
-    if (cip && (cand_bottom_left || cand_left || cand_up_left || cand_up || cand_up_right)) {
-        int smx = x0 + ((2 * n) << hs) < pic->width ? 2 * n : (pic->width - x0) >> hs;
-        int smy = y0 + ((2 * n) << vs) < pic->height ? 2 * n : (pic->height - y0) >> vs;
-        int j = n + (cand_bottom_left ? bl_size : 0) - 1;
-        if (!cand_up_right) smx = x0 + (n << hs) < pic->width ? n : (pic->width - x0) >> hs;
-        if (!cand_bottom_left) smy = y0 + (n << vs) < pic->height ? n : (pic->height - y0) >> vs;
-        if (cand_bottom_left || cand_left || cand_up_left) {
-            while (j > -1 && !ISI(-1, j)) j--;
-            if (!ISI(-1, j)) {
-                j = 0;
-                while (j < smx && !ISI(j, -1)) j++;
-                for (int i = j; i > j - (j + 1); i--) if (!ISI(i - 1, -1)) t[i - 1] = t[i];      /* EXTEND_LEFT_CIP */
-                l[-1] = t[-1];
-            }
-        } else {
-            j = 0;
-            while (j < smx && !ISI(j, -1)) j++;
-            if (j > 0) {
-                if (x0 > 0) {
-                    for (int i = j; i > j - (j + 1); i--) if (!ISI(i - 1, -1)) t[i - 1] = t[i];
-                } else {
-                    for (int i = j; i > j - j; i--) if (!ISI(i - 1, -1)) t[i - 1] = t[i];
-                    t[-1] = t[0];
-                }
-            }
-            l[-1] = t[-1];
+        /* what part 2 (in intra_core) reads of the surroundings: the per-sample intra bits and the scan limits, :187-198 */
+        cv.on = 1;
+        for (int k = -1; k < 64; k++) {
+            if (ISI(k, -1)) cv.top[(k + 1) >> 3] |= (uint8_t)(1u << ((k + 1) & 7));
+            if (ISI(-1, k)) cv.left[(k + 1) >> 3] |= (uint8_t)(1u << ((k + 1) & 7));
         }
-        l[-1] = t[-1];
-        if (cand_bottom_left || cand_left) {                     /* EXTEND_DOWN_CIP(left, 0, size_max_y) */
-            int a = l[-1];
-            for (int i = 0; i < smy; i += 4) {
-                if (!ISI(-1, i)) { l[i] = l[i + 1] = l[i + 2] = l[i + 3] = a; } else a = l[i + 3];
-            }
-        }
-        if (!cand_left) for (int i = 0; i < n; i++) l[i] = l[-1];
-        if (!cand_bottom_left) for (int i = n; i < 2 * n; i++) l[i] = l[n - 1];
-        if (x0 != 0 && y0 != 0) {
-            int a = l[smy - 1];
-            for (int i = smy - 1; i > smy - 1 - smy; i -= 4) {   /* EXTEND_UP_CIP(left, size_max_y - 1, size_max_y) */
-                if (!ISI(-1, i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
-            }
-            if (!ISI(-1, -1)) l[-1] = l[0];
-        } else if (x0 == 0) {
-            for (int i = 0; i < smy; i++) l[i] = 0;              /* EXTEND(left, 0, size_max_y) */
-        } else {
-            int a = l[smy - 1];
-            for (int i = smy - 1; i > smy - 1 - smy; i -= 4) {
-                if (!ISI(-1, i - 3)) { l[i - 3] = l[i - 2] = l[i - 1] = l[i] = a; } else a = l[i - 3];
-            }
-        }
-        t[-1] = l[-1];
-        if (y0 != 0) {                                           /* EXTEND_RIGHT_CIP(top, 0, size_max_x) */
-            int a = l[-1];
-            for (int i = 0; i < smx; i += 4) {
-                if (!ISI(i, -1)) { t[i] = t[i + 1] = t[i + 2] = t[i + 3] = a; } else a = t[i + 3];
-            }
-        }
+        cv.smx = x0 + ((2 * n) << hs) < pic->width ? 2 * n : (pic->width - x0) >> hs;
+        cv.smy = y0 + ((2 * n) << vs) < pic->height ? 2 * n : (pic->height - y0) >> vs;
+        if (!cand_up_right) cv.smx = x0 + (n << hs) < pic->width ? n : (pic->width - x0) >> hs;
+        if (!cand_bottom_left) cv.smy = y0 + (n << vs) < pic->height ? n : (pic->height - y0) >> vs;
+        cv.x0_nonzero = x0 != 0; cv.y0_nonzero = y0 != 0;
     }
 #undef ISI
 #undef ISPU
-    /* substitution of unavailable samples (:251-286) */
-    if (!cand_bottom_left) {
-        if (cand_left) {
-            for (int i = n; i < 2 * n; i++) l[i] = l[n - 1];
-        } else if (cand_up_left) {
-            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
-            cand_left = 1;
-        } else if (cand_up) {
-            l[-1] = t[0];
-            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
-            cand_up_left = cand_left = 1;
-        } else if (cand_up_right) {
-            for (int i = 0; i < n; i++) t[i] = t[n];
-            l[-1] = t[n];
-            for (int i = 0; i < 2 * n; i++) l[i] = l[-1];
-            cand_up = cand_up_left = cand_left = 1;
-        } else {
-            l[-1] = 1 << (bd - 1);
-            for (int i = 0; i < 2 * n; i++) t[i] = l[i] = l[-1];
-        }
-    }
-    if (!cand_left) for (int i = 0; i < n; i++) l[i] = l[n];
-    if (!cand_up_left) l[-1] = l[0];
-    if (!cand_up) for (int i = 0; i < n; i++) t[i] = l[-1];
-    if (!cand_up_right) for (int i = n; i < 2 * n; i++) t[i] = t[n - 1];
-    t[-1] = l[-1];
+    intra_core(bd, blk, stride, log2, mode, cand_bottom_left, cand_left, cand_up_left, cand_up, cand_up_right, bl_size, tr_size,
+               pic->intra_smoothing_disabled || !(c_idx == 0 || cfi == 3), pic->strong_intra_smoothing && c_idx == 0, c_idx == 0, &cv);
+}
 
-    /* reference-sample smoothing (:289-327) */
-    if (!pic->intra_smoothing_disabled && (c_idx == 0 || cfi == 3) && mode != 1 && n != 4) {
-        static const int thresh[3] = { 7, 1, 0 };
-        int dv = abs(mode - 26), dh = abs(mode - 10), dist = dv < dh ? dv : dh;
-        if (dist > thresh[log2 - 3]) {
-            int lim = 1 << (bd - 5);
-            if (pic->strong_intra_smoothing && c_idx == 0 && log2 == 5 &&
-                abs(t[-1] + t[63] - 2 * t[31]) < lim && abs(l[-1] + l[63] - 2 * l[31]) < lim) {
-                ft[-1] = t[-1]; ft[63] = t[63]; fl[-1] = l[-1]; fl[63] = l[63];
-                for (int i = 0; i < 63; i++) {
-                    ft[i] = ((63 - i) * t[-1] + (i + 1) * t[63] + 32) >> 6;
-                    fl[i] = ((63 - i) * l[-1] + (i + 1) * l[63] + 32) >> 6;
-                }
-            } else {
-                fl[2 * n - 1] = l[2 * n - 1]; ft[2 * n - 1] = t[2 * n - 1];
-                for (int i = 2 * n - 2; i >= 0; i--) {
-                    fl[i] = (l[i + 1] + 2 * l[i] + l[i - 1] + 2) >> 2;
-                    ft[i] = (t[i + 1] + 2 * t[i] + t[i - 1] + 2) >> 2;
-                }
-                ft[-1] = fl[-1] = (l[0] + 2 * l[-1] + t[0] + 2) >> 2;
-            }
-            l = fl; t = ft;
-        }
+/* The same prediction from a product job record (ohevc_intra_job / ohevc_intra_cip, include/ohevc_hip.h): availability, run
+ * lengths, switches and the constrained-intra side record as the host helper resolved them.  Used by the software executor of
+ * the CPU-only host-logic tests (oracle/sw_exec.c); shares intra_core with ohor_intra_pred, which is what the reference pins.
+ * flags: 1 bottom-left, 2 left, 4 up-left, 8 up, 16 up-right, 32 no smoothing, 64 strong, 128 luma edge. */
+void ohor_intra_job(int bd, uint8_t *blk, ptrdiff_t stride, int log2, int mode, int flags, int bl_size, int tr_size,
+                    const uint8_t *cip_top_bits, const uint8_t *cip_left_bits, int size_max_x, int size_max_y, int x0_nonzero, int y0_nonzero)
+{
+    cip_view cv;
+    memset(&cv, 0, sizeof(cv));
+    if (cip_top_bits && cip_left_bits) {
+        cv.on = 1;
+        memcpy(cv.top, cip_top_bits, 9); memcpy(cv.left, cip_left_bits, 9);
+        cv.smx = size_max_x; cv.smy = size_max_y; cv.x0_nonzero = x0_nonzero; cv.y0_nonzero = y0_nonzero;
     }
-    if (mode == 0)      predict_planar(bd, log2, blk, stride, t, l);
-    else if (mode == 1) predict_dc(bd, log2, blk, stride, t, l, c_idx);
-    else                predict_angular(bd, log2, blk, stride, t, l, c_idx, mode);
-#undef REC
+    intra_core(bd, blk, stride, log2, mode, !!(flags & 1), !!(flags & 2), !!(flags & 4), !!(flags & 8), !!(flags & 16), bl_size, tr_size,
+               !!(flags & 32), !!(flags & 64), !!(flags & 128), &cv);
 }
 
 /* ------------------------------------------------------------------ SHVC inter-layer up-sampling

@@ -51,6 +51,9 @@ static struct {
 } g_bufs[MAX_BUFS];
 static int g_nbufs;
 
+void ohsw_sink(void *user, struct ohevc_ctx *ctx, int stage);      /* sw_exec.c */
+int  ohsw_error(void);
+
 static ohevc_ctx *thread_ctx(void)
 {
     if (t_ctx || !g_root)
@@ -238,7 +241,9 @@ int ohdec_backend_open(void)
     }
     if (g_root)
         return 0;
-    ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL);
+    ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL || getenv("OHHIP_SW_EXEC") != NULL);
+    /* CPU-only host-logic tests: no device, the recorded jobs are executed by the oracle on the decoder's own frames (sw_exec.c) */
+    ohevc_debug_set_frame_sink(getenv("OHHIP_SW_EXEC") ? ohsw_sink : NULL, NULL);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
     if (getenv("OHHIP_LEVEL_LAUNCH"))
         ohevc_debug_set_level_launch(atoi(getenv("OHHIP_LEVEL_LAUNCH")));          /* A/B of the two executors */   /* host-side profiling, no pixels (ohevc_debug.h) */
@@ -282,6 +287,8 @@ int ohdec_backend_frame_done(void)
     }
     if (st == OHEVC_OK)
         st = ohevc_tables_status(t_ctx);
+    if (st == OHEVC_OK && ohsw_error())
+        st = OHEVC_ERR_STATE;
     if (st != OHEVC_OK) {
         fprintf(stderr, "ohhip: frame failed (%d): %s\n", st, ohevc_last_error());
         g_error = 1;

@@ -163,3 +163,47 @@ def test_slice_threads_record_into_one_context(name, monkeypatch):
     n4, c4 = _record_only_counts(aus, 4, monkeypatch, 4)
     assert n1 == n2 == n4 == CASES[name]["nframes"]
     assert c1 == c2 == c4
+
+
+# ------------------------------------------------------------------ the whole host layer, bit-exact, without a GPU
+# OHHIP_SW_EXEC=1: the HIP-backed decoder records as usual (table slots, pointer registry, job builders, dependency levels,
+# filter-lag flags, bypass map, slice-thread recorders) but no device exists; at every frame end the recorded jobs are executed
+# by the CPU oracle on the decoder's own frames (oracle/sw_exec.c through the frame sink of include/ohevc_debug.h).  The pictures
+# must be those of the untouched decoder.  The kernels themselves are what the -m gpu tests check.
+@needs_hip_lib
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_recorded_jobs_executed_by_the_oracle_reproduce_the_reference(name, monkeypatch):
+    monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hip", aus)) == md5
+
+
+@needs_hip_lib
+@pytest.mark.parametrize("threads,thread_type,names", [
+    (3, 1, ["ra_8b_ctb64", "ldb_10b", "weighted", "fmt422_10b_ra", "cross_444_8b", "small_blocks"]),       # frame threads
+    (4, 2, ["wpp", "tiles", "slices_dep_wpp", "tiles_nolf"]),                                                # slice threads
+    (4, 3, ["wpp", "tiles", "ra_8b_ctb64"]),                                                                 # frame x slice threads
+])
+def test_software_executor_in_every_thread_mode(threads, thread_type, names, monkeypatch):
+    monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    for name in names:
+        aus, md5 = load_golden(name)
+        for _ in range(2):
+            assert frames_md5(ps.decode_stream("hip", aus, threads, thread_type)) == md5, (name, threads, thread_type)
+
+
+@needs_gen
+@pytest.mark.skipif(not ps.have("hip"), reason="oracle/_ref/libopenhevc_hip.so not built")
+def test_fuzzed_streams_through_the_software_executor():
+    """tools/fuzz_streams.py for a few seconds with OHHIP_SW_EXEC=1: random legal parameter sets in all thread modes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OHHIP_SW_EXEC="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "12", "4243"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    lines = r.stdout.strip().splitlines()
+    assert lines, r.stderr[-2000:]
+    res = json.loads(lines[-1])
+    assert r.returncode == 0 and res["failed"] == 0 and res["streams"] > 30, r.stdout[-3000:]

@@ -1,5 +1,7 @@
-"""GPU fuzzing of the drop-in: random stream parameters -> synthesiser -> reference decoder (C tables) vs the same
-decoder with HIP tables.  Prints every failing parameter set as JSON (replay with tools/diag_stream.py)."""
+"""Fuzzing of the drop-in: random stream parameters -> synthesiser -> reference decoder (C tables) vs the same decoder with
+HIP tables.  Prints every failing parameter set as JSON (replay with tools/diag_stream.py / diag_block.py).
+On a GPU box the HIP tables run the kernels; with OHHIP_SW_EXEC=1 (no GPU needed) the recorded jobs are executed by the CPU
+oracle instead (oracle/sw_exec.c), which fuzzes everything on the host side of the C ABI."""
 import json
 import os
 import sys
@@ -75,7 +77,11 @@ def main():
         # slice threads: WPP rows / tiles of one picture record concurrently.  Not with 16x16 CTBs: there the reference's
         # one-CTB filter lag (ohevc_hip.h, OHEVC_SAO_LAG_*) makes its row threads race on the chroma columns they share (a row
         # reports progress BEFORE it filters, hevc.c:2800-2815), so its own output depends on timing
-        if threads > 1 and (kw.get("wpp") or kw.get("tiles")) and kw["log2_ctb"] > 4 and rng.integers(0, 2):
+        # ... and not tiles with constrained intra prediction: its substitution walk reads the prediction mode of PUs in the
+        # neighbouring tile (IS_INTRA looks at tab_mvf whatever the availability, hevcpred_template.c:33-40,204-238) while that
+        # tile's thread is still writing them -- the untouched decoder itself flips between two outputs under taskset
+        if threads > 1 and (kw.get("wpp") or kw.get("tiles")) and kw["log2_ctb"] > 4 and rng.integers(0, 2) and \
+                not (kw.get("tiles") and kw.get("constrained_intra")):
             thread_type = 2
         # the reference never clears s->is_pcm between pictures (hevc_frame_start, hevc.c:3197-3215, has no memset for it):
         # with the restore_tqb_pixels tools its OWN output then depends on which thread decoded which picture and even
