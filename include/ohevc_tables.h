@@ -157,6 +157,39 @@ int  ohevc_tables_upsample_frame(const uint8_t *el_data0, const uint8_t *bl_data
  * tables.  Call this with lc->tu.res_scale_val at the end of hls_cross_component_pred: the next chroma transform_add of the
  * calling thread becomes an OHEVC_TU_CROSS job (both coefficient blocks travel, the kernel forms both residuals). */
 int  ohevc_tables_cross_component(int res_scale_val);
+/* The in-loop filter drivers in bulk (host half).  Instead of letting deblocking_filter_CTB / sao_filter_CTB
+ * (hevc_filter.c:197-581) make one table call per 8-sample edge and per CTB plane while the picture is parsed, skip
+ * ff_hevc_hls_filters / ff_hevc_hls_filter altogether (keep their ff_thread_report_progress calls) and hand the arrays they read
+ * over once, before ohevc_tables_end_frame: the same deblocking and SAO jobs are recorded in one pass.  All pointers are the
+ * reference's own arrays, only read during the call:
+ *   horizontal_bs / vertical_bs / bs_width   s->horizontal_bs, s->vertical_bs, s->bs_width   (boundary strengths: still derived
+ *                                            on the CPU by ff_hevc_deblocking_boundary_strengths, which stays)
+ *   qp_y_tab / min_cb_width                  s->qp_y_tab, sps->min_cb_width
+ *   deblock / deblock_stride                 (const int8_t *)s->deblock, sizeof(DBParams): [0] beta_offset, [1] tc_offset per CTB
+ *   sao                                      s->sao (SAOParams per CTB, raster order)
+ *   filter_slice_edges, tab_slice_address    s->filter_slice_edges, s->tab_slice_address
+ *   ctb_addr_rs_to_ts, tile_id               pps arrays
+ *   is_pcm / min_pu_width / min_pu_height    s->is_pcm etc., read when pcm_or_bypass (the reference's `pcmf`, hevc_filter.c:363-365)
+ * Not for 16x16-CTB streams with SAO (the call refuses them): their output depends on the order of the reference's driver
+ * calls (filter lag), so they keep the drivers and the recording slots. */
+typedef struct ohevc_filter_maps {
+    int32_t width, height, log2_ctb_size, log2_min_cb_size, log2_min_pu_size, chroma_format_idc;
+    int32_t cb_qp_offset, cr_qp_offset;                    /* pps->cb_qp_offset, pps->cr_qp_offset */
+    int32_t sao_enabled, tiles_enabled, loop_filter_across_tiles, pcm_or_bypass;
+    const uint8_t *horizontal_bs, *vertical_bs;
+    int32_t bs_width;
+    const int8_t *qp_y_tab;
+    int32_t min_cb_width;
+    const int8_t *deblock;
+    int32_t deblock_stride;
+    const ohevc_SAOParams *sao;
+    const uint8_t *filter_slice_edges;
+    const int32_t *tab_slice_address;
+    const int *ctb_addr_rs_to_ts, *tile_id;
+    const uint8_t *is_pcm;
+    int32_t min_pu_width, min_pu_height;
+} ohevc_filter_maps;
+int  ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *maps);
 /* the host planes registered for picture-store slot `slot` (tests: oracle/sw_exec.c executes recorded jobs on them) */
 int  ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[3], int linesize[3]);
 /* sticky status of the recording since begin_frame: table slots return void, so failures surface here */

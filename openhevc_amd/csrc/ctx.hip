@@ -759,7 +759,10 @@ extern "C" int ohevc_rec_tu_bulk(ohevc_ctx *c, int n, const int32_t *desc, const
 }
 extern "C" int ohevc_rec_deblock_bulk(ohevc_ctx *c, const ohevc_dbk_job *jobs, int n)
 {
-    for (int i = 0; i < n; i++) { int rc = ohevc_rec_deblock(c, jobs + i); if (rc != OHEVC_OK) return rc; }
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && (n == 0 || jobs != nullptr) && n >= 0, "no frame begun");
+    Rec &r = pick(c);
+    for (int i = 0; i < n; i++) ((jobs[i].flags & OHEVC_DBK_VERTICAL_EDGE) ? r.dbk_v : r.dbk_h).push_back(jobs[i]);
+    r.nstat[3] += n;
     return OHEVC_OK;
 }
 extern "C" int ohevc_rec_sao_bulk(ohevc_ctx *c, const ohevc_sao_job *jobs, int n)

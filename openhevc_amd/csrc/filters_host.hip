@@ -1,0 +1,205 @@
+// filters_host.hip -- the in-loop filter DRIVERS of the reference, in bulk (host code; SURVEY.md 8f-3, first half).
+//
+// deblocking_filter_CTB and sao_filter_CTB (hevc_filter.c:197-581) walk every CTB with a one-CTB lag while the picture is being
+// parsed, derive tc / beta / pcm flags per 8-sample edge and the SAO edge / border flags per CTB, and make one table call per edge
+// and per CTB plane -- about a third of all table calls of a picture, plus host-pixel copies (copy_CTB, the sao_frame ring) that
+// nobody reads behind recording tables.  Everything they need is final once the picture is parsed: the boundary-strength maps,
+// qp_y_tab, the per-CTB deblocking offsets and SAO parameters, the slice / tile maps.  ohevc_tables_derive_filters reads those
+// arrays ONCE at the frame end and records the same job set in one tight loop: no per-edge pointer translation, no calls, and the
+// reference's drivers can be skipped altogether.  The parameter derivation itself stays what it is in
+// the reference -- including which offsets an edge next to a CTB boundary gets (see the comments) -- because the job set must
+// be the one the drivers would have produced: tests/test_stream_cpu.py runs both paths through the software executor.
+#include <algorithm>
+#include <vector>
+#include "common.hpp"
+#include "ohevc_tables.h"
+
+namespace {
+
+// H.265 table 8-12 as hevc_filter.c:50-60 spells it
+const uint8_t kTc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+                          5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+const uint8_t kBeta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28,
+                            30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+inline int clip(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+struct Ctx {
+    const ohevc_filter_maps &m;
+    ohevc_ctx *ctx;
+    int rc = OHEVC_OK;
+    std::vector<ohevc_dbk_job> edges;   // handed to the recorder in one call
+    int hs, vs;                    // chroma subsampling shifts
+    int qpy(int x, int y) const { return m.qp_y_tab[(x >> m.log2_min_cb_size) + (y >> m.log2_min_cb_size) * m.min_cb_width]; }    // get_qPy, :144-150
+    int pcm(int x, int y) const                                    // get_pcm, :325-338
+    {
+        if (x < 0 || y < 0) return 2;
+        const int xp = x >> m.log2_min_pu_size, yp = y >> m.log2_min_pu_size;
+        if (xp >= m.min_pu_width || yp >= m.min_pu_height) return 2;
+        return m.is_pcm[yp * m.min_pu_width + xp];
+    }
+    int tc_luma(int qp, int bs, int tc_offset) const { return kTc[clip(qp + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)]; }             // TC_CALC, :340-343
+    int tc_chroma(int qp_y, int c_idx, int tc_offset) const        // chroma_tc, :62-89
+    {
+        static const int qp_c[] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
+        const int qp_i = clip(qp_y + (c_idx == 1 ? m.cb_qp_offset : m.cr_qp_offset), 0, 57);
+        int qp;
+        if (m.chroma_format_idc == 1) qp = qp_i < 30 ? qp_i : qp_i > 43 ? qp_i - 6 : qp_c[qp_i - 30];
+        else                          qp = clip(qp_i, 0, 51);
+        return kTc[clip(qp + 2 + tc_offset, 0, 53)];
+    }
+    void edge(int plane, int x, int y, bool vertical, int beta, int tc0, int tc1, const int *no_p, const int *no_q)
+    {
+        ohevc_dbk_job j = {};
+        j.x = (uint16_t)x; j.y = (uint16_t)y; j.plane = (uint8_t)plane; j.beta = (uint8_t)beta;
+        j.tc[0] = (int16_t)tc0; j.tc[1] = (int16_t)tc1;
+        j.flags = (uint8_t)((vertical ? OHEVC_DBK_VERTICAL_EDGE : 0) | (no_p[0] ? OHEVC_DBK_NO_P0 : 0) | (no_p[1] ? OHEVC_DBK_NO_P1 : 0) |
+                            (no_q[0] ? OHEVC_DBK_NO_Q0 : 0) | (no_q[1] ? OHEVC_DBK_NO_Q1 : 0));
+        edges.push_back(j);
+    }
+
+    // deblocking_filter_CTB, hevc_filter.c:345-581, loop for loop (the order of the calls does not matter to the executor, the
+    // parameters each edge gets do)
+    void deblock_ctb(int x0, int y0)
+    {
+        const int ctb_size = 1 << m.log2_ctb_size, ctb_w = (m.width + ctb_size - 1) >> m.log2_ctb_size;
+        const int ctb = (x0 >> m.log2_ctb_size) + (y0 >> m.log2_ctb_size) * ctb_w;
+        const int cur_beta = m.deblock[(size_t)ctb * m.deblock_stride], cur_tc = m.deblock[(size_t)ctb * m.deblock_stride + 1];
+        const int left_beta = x0 ? m.deblock[(size_t)(ctb - 1) * m.deblock_stride] : 0, left_tc = x0 ? m.deblock[(size_t)(ctb - 1) * m.deblock_stride + 1] : 0;
+        const bool pcmf = m.pcm_or_bypass != 0;
+        int no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+        int x_end = std::min(x0 + ctb_size, m.width), x_end2;
+        const int y_end = std::min(y0 + ctb_size, m.height);
+        int tc_offset = cur_tc, beta_offset = cur_beta;
+        const int h = 1 << hs, v = 1 << vs;
+
+        for (int y = y0; y < y_end; y += 8)                          // vertical edges, luma (:385-420)
+            for (int x = x0 ? x0 : 8; x < x_end; x += 8) {
+                const int bs0 = m.vertical_bs[(x + y * m.bs_width) >> 2], bs1 = m.vertical_bs[(x + (y + 4) * m.bs_width) >> 2];
+                if (!(bs0 || bs1)) continue;
+                const int qp = (qpy(x - 1, y) + qpy(x, y) + 1) >> 1;
+                if (pcmf) { no_p[0] = pcm(x - 1, y); no_p[1] = pcm(x - 1, y + 4); no_q[0] = pcm(x, y); no_q[1] = pcm(x, y + 4); }
+                edge(0, x, y, true, kBeta[clip(qp + beta_offset, 0, 51)], bs0 ? tc_luma(qp, bs0, tc_offset) : 0, bs1 ? tc_luma(qp, bs1, tc_offset) : 0, no_p, no_q);
+            }
+        if (m.chroma_format_idc)                                     // vertical edges, chroma (:423-476): bS 2 only
+            for (int y = y0; y < y_end; y += 8 * v)
+                for (int x = x0 ? x0 : 8 * h; x < x_end; x += 8 * h) {
+                    const int bs0 = m.vertical_bs[(x + y * m.bs_width) >> 2], bs1 = m.vertical_bs[(x + (y + 4 * v) * m.bs_width) >> 2];
+                    if (!(bs0 == 2 || bs1 == 2)) continue;
+                    const int qp0 = (qpy(x - 1, y) + qpy(x, y) + 1) >> 1, qp1 = (qpy(x - 1, y + 4 * v) + qpy(x, y + 4 * v) + 1) >> 1;
+                    if (pcmf) { no_p[0] = pcm(x - 1, y); no_p[1] = pcm(x - 1, y + 4 * v); no_q[0] = pcm(x, y); no_q[1] = pcm(x, y + 4 * v); }
+                    for (int c = 1; c <= 2; c++)
+                        edge(c, x >> hs, y >> vs, true, 0, bs0 == 2 ? tc_chroma(qp0, c, tc_offset) : 0, bs1 == 2 ? tc_chroma(qp1, c, tc_offset) : 0, no_p, no_q);
+                }
+        // horizontal edges, luma (:479-519): the run starts 8 samples inside the CTB to the left and stops 8 samples short of the
+        // next one; the first segment takes the LEFT CTB's beta offset -- and this CTB's tc offset (tc_offset is only switched in
+        // the chroma loop below)
+        x_end2 = x_end;
+        if (x_end != m.width) x_end -= 8;
+        for (int y = y0 ? y0 : 8; y < y_end; y += 8) {
+            beta_offset = x0 ? left_beta : cur_beta;
+            for (int x = x0 ? x0 - 8 : 0; x < x_end; x += 8) {
+                const int bs0 = m.horizontal_bs[(x + y * m.bs_width) >> 2], bs1 = m.horizontal_bs[((x + 4) + y * m.bs_width) >> 2];
+                if (bs0 || bs1) {
+                    const int qp = (qpy(x, y - 1) + qpy(x, y) + 1) >> 1;
+                    if (pcmf) { no_p[0] = pcm(x, y - 1); no_p[1] = pcm(x + 4, y - 1); no_q[0] = pcm(x, y); no_q[1] = pcm(x + 4, y); }
+                    edge(0, x, y, false, kBeta[clip(qp + beta_offset, 0, 51)], bs0 ? tc_luma(qp, bs0, tc_offset) : 0, bs1 ? tc_luma(qp, bs1, tc_offset) : 0, no_p, no_q);
+                }
+                beta_offset = cur_beta;
+            }
+        }
+        // horizontal edges, chroma (:522-579): lag of 8 chroma samples; first segment of the first edge: the left CTB's tc offset,
+        // its second segment and everything after: this CTB's
+        if (m.chroma_format_idc) {
+            if (x_end2 != m.width) x_end = x_end2 - 8 * h;
+            for (int y = y0 ? y0 : 8 * v; y < y_end; y += 8 * v) {
+                tc_offset = x0 ? left_tc : cur_tc;
+                for (int x = x0 ? x0 - 8 * h : 0; x < x_end; x += 8 * h) {
+                    const int bs0 = m.horizontal_bs[(x + y * m.bs_width) >> 2], bs1 = m.horizontal_bs[((x + 4 * h) + y * m.bs_width) >> 2];
+                    if (bs0 == 2 || bs1 == 2) {
+                        const int qp0 = bs0 == 2 ? (qpy(x, y - 1) + qpy(x, y) + 1) >> 1 : 0;
+                        const int qp1 = bs1 == 2 ? (qpy(x + 4 * h, y - 1) + qpy(x + 4 * h, y) + 1) >> 1 : 0;
+                        if (pcmf) { no_p[0] = pcm(x, y - 1); no_p[1] = pcm(x + 4 * h, y - 1); no_q[0] = pcm(x, y); no_q[1] = pcm(x + 4 * h, y); }
+                        for (int c = 1; c <= 2; c++)
+                            edge(c, x >> hs, y >> vs, false, 0, bs0 == 2 ? tc_chroma(qp0, c, tc_offset) : 0, bs1 == 2 ? tc_chroma(qp1, c, cur_tc) : 0, no_p, no_q);
+                    }
+                    tc_offset = cur_tc;
+                }
+            }
+        }
+    }
+
+    // sao_filter_CTB, hevc_filter.c:197-322: what the table calls receive (the host copies around them have no counterpart)
+    void sao_ctb(int x, int y)
+    {
+        const int ctb_size = 1 << m.log2_ctb_size, ctb_w = (m.width + ctb_size - 1) >> m.log2_ctb_size, ctb_h = (m.height + ctb_size - 1) >> m.log2_ctb_size;
+        const int x_ctb = x >> m.log2_ctb_size, y_ctb = y >> m.log2_ctb_size, rs = y_ctb * ctb_w + x_ctb;
+        const ohevc_SAOParams &sao = m.sao[rs];
+        const int ts = m.ctb_addr_rs_to_ts[rs];
+        const bool lfase = m.filter_slice_edges[rs] != 0, no_tile_filter = m.tiles_enabled && !m.loop_filter_across_tiles;
+        const bool restore = no_tile_filter || !lfase;
+        const bool e0 = x_ctb == 0, e1 = y_ctb == 0, e2 = x_ctb == ctb_w - 1, e3 = y_ctb == ctb_h - 1;
+        bool ve[2] = {}, he[2] = {}, de[4] = {}, lt = false, rt = false, ut = false, bt = false;
+        auto slice = [&](int dx, int dy) { return m.tab_slice_address[rs + dx + dy * ctb_w]; };
+        auto tile = [&](int dx, int dy) { return m.tile_id[m.ctb_addr_rs_to_ts[rs + dx + dy * ctb_w]]; };
+        if (restore) {
+            if (!e0) { lt = no_tile_filter && m.tile_id[ts] != tile(-1, 0); ve[0] = (!lfase && slice(0, 0) != slice(-1, 0)) || lt; }
+            if (!e2) { rt = no_tile_filter && m.tile_id[ts] != tile(1, 0);  ve[1] = (!lfase && slice(0, 0) != slice(1, 0)) || rt; }
+            if (!e1) { ut = no_tile_filter && m.tile_id[ts] != tile(0, -1); he[0] = (!lfase && slice(0, 0) != slice(0, -1)) || ut; }
+            if (!e3) { bt = no_tile_filter && m.tile_id[ts] != tile(0, 1);  he[1] = (!lfase && slice(0, 0) != slice(0, 1)) || bt; }
+            if (!e0 && !e1) de[0] = (!lfase && slice(0, 0) != slice(-1, -1)) || lt || ut;
+            if (!e1 && !e2) de[1] = (!lfase && slice(0, 0) != slice(1, -1)) || rt || ut;
+            if (!e2 && !e3) de[2] = (!lfase && slice(0, 0) != slice(1, 1)) || rt || bt;
+            if (!e0 && !e3) de[3] = (!lfase && slice(0, 0) != slice(-1, 1)) || lt || bt;
+        }
+        for (int c = 0; c < (m.chroma_format_idc ? 3 : 1); c++) {
+            const int type = sao.type_idx[c];
+            if (type != 1 && type != 2) continue;                  // SAO_BAND = 1, SAO_EDGE = 2 (hevc.h:498-503)
+            const int chs = c ? hs : 0, cvs = c ? vs : 0;
+            const int xc = x >> chs, yc = y >> cvs;
+            ohevc_sao_job j = {};
+            j.x = (uint16_t)xc; j.y = (uint16_t)yc; j.plane = (uint8_t)c;
+            j.w = (uint16_t)std::min(ctb_size >> chs, (m.width >> chs) - xc);
+            j.h = (uint16_t)std::min(ctb_size >> cvs, (m.height >> cvs) - yc);
+            j.type = (uint8_t)(type == 1 ? OHEVC_SAO_BAND : OHEVC_SAO_EDGE);
+            j.klass = type == 1 ? sao.band_position[c] : sao.eo_class[c];
+            j.borders = (uint8_t)((e0 ? 1 : 0) | (e1 ? 2 : 0) | (e2 ? 4 : 0) | (e3 ? 8 : 0));
+            if (type == 2) {
+                j.restore = restore ? 1 : 0;
+                if (restore)
+                    j.edges = (uint8_t)((ve[0] ? 1 : 0) | (ve[1] ? 2 : 0) | (he[0] ? 4 : 0) | (he[1] ? 8 : 0) | (de[0] ? 16 : 0) | (de[1] ? 32 : 0) |
+                                        (de[2] ? 64 : 0) | (de[3] ? 128 : 0));
+            }
+            for (int k = 0; k < 5; k++) j.offset_val[k] = sao.offset_val[c][k];
+            const int r = ohevc_rec_sao(ctx, &j);
+            if (r != OHEVC_OK && rc == OHEVC_OK) rc = r;
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *m)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(ctx != nullptr && m != nullptr, "null argument");
+    OHEVC_REQUIRE(m->width > 0 && m->height > 0 && m->log2_ctb_size >= 4 && m->log2_ctb_size <= 6 && m->log2_min_cb_size >= 3 && m->log2_min_pu_size >= 2 &&
+                  m->chroma_format_idc >= 0 && m->chroma_format_idc <= 3, "picture geometry");
+    OHEVC_REQUIRE(m->horizontal_bs && m->vertical_bs && m->bs_width > 0 && m->qp_y_tab && m->min_cb_width > 0 && m->deblock && m->deblock_stride >= 2,
+                  "deblocking maps");
+    OHEVC_REQUIRE(!m->sao_enabled || (m->sao && m->filter_slice_edges && m->tab_slice_address && m->ctb_addr_rs_to_ts && m->tile_id), "SAO maps");
+    OHEVC_REQUIRE(!m->pcm_or_bypass || (m->is_pcm && m->min_pu_width > 0 && m->min_pu_height > 0), "pcm map");
+    // With 16x16 CTBs the reference's one-CTB filter lag is visible in its output (ohevc_hip.h, OHEVC_SAO_LAG_*), and that
+    // depends on the ORDER of its driver calls: such streams keep the drivers and the recording slots.
+    OHEVC_REQUIRE(m->log2_ctb_size > 4 || !m->sao_enabled, "16x16 CTBs with SAO: keep the reference's filter drivers (filter lag)");
+    Ctx c{*m, ctx};
+    c.edges.reserve(32768);
+    c.hs = m->chroma_format_idc == 1 || m->chroma_format_idc == 2; c.vs = m->chroma_format_idc == 1;
+    const int ctb_size = 1 << m->log2_ctb_size;
+    for (int y = 0; y < m->height; y += ctb_size)
+        for (int x = 0; x < m->width; x += ctb_size) {
+            c.deblock_ctb(x, y);
+            if (m->sao_enabled) c.sao_ctb(x, y);
+        }
+    const int r = ohevc_rec_deblock_bulk(ctx, c.edges.data(), (int)c.edges.size());
+    return c.rc != OHEVC_OK ? c.rc : r;
+}

@@ -37,6 +37,7 @@ static ohevc_ctx          *g_all[128];
 static int                 g_nall;
 static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
 static volatile int        g_error;
+static int                 g_bulk_filters = 1;     /* OHHIP_BULK_FILTERS=0: keep the reference's filter drivers and the per-edge table calls */
 static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
 static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
 static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
@@ -232,6 +233,73 @@ static void crash_handler(int sig)
     raise(sig);
 }
 
+/* SURVEY.md 8f-3, host half: the in-loop filter drivers are skipped -- ff_hevc_hls_filters /
+ * ff_hevc_hls_filter (hevc_filter.c:1027-1064; call sites hevc.c:2690-2695,2809-2818,2892-2901,3002-3012 renamed to these) keep
+ * only their progress reports -- and the frame-end hook hands the maps they would have read to ohevc_tables_derive_filters.
+ * Streams whose output depends on the ORDER of the driver calls (16x16 CTBs with SAO: the filter lag) keep the drivers. */
+static int bulk_filters(const HEVCContext *s)
+{
+    return g_bulk_filters && !(s->sps->log2_ctb_size == 4 && s->sps->sao_enabled);
+}
+
+void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size)
+{
+    if (!bulk_filters(s)) {
+        ff_hevc_hls_filter(s, x, y, ctb_size);
+        return;
+    }
+    /* what other frame threads wait for (hevc_filter.c:1038-1050): rows whose CTBs have all been through here */
+    if (s->threads_type & FF_THREAD_FRAME) {
+        const int x_end = x >= s->sps->width - ctb_size, y_end = y >= s->sps->height - ctb_size;
+        if (s->sps->sao_enabled) {
+            if (y && x_end)
+                ff_thread_report_progress(&s->ref->tf, y - ctb_size, 0);
+            if (x_end && y_end)
+                ff_thread_report_progress(&s->ref->tf, y, 0);
+        } else if (y && x_end) {
+            ff_thread_report_progress(&s->ref->tf, y, 0);
+        }
+    }
+}
+
+void ohhip_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size)
+{
+    if (!bulk_filters(s)) {
+        ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb_size);
+        return;
+    }
+    {   /* the reference's own dispatch, hevc_filter.c:1053-1063 */
+        const int x_end = x_ctb >= s->sps->width - ctb_size, y_end = y_ctb >= s->sps->height - ctb_size;
+        if (y_ctb && x_ctb)
+            ohhip_hls_filter(s, x_ctb - ctb_size, y_ctb - ctb_size, ctb_size);
+        if (y_ctb && x_end)
+            ohhip_hls_filter(s, x_ctb, y_ctb - ctb_size, ctb_size);
+        if (x_ctb && y_end)
+            ohhip_hls_filter(s, x_ctb - ctb_size, y_ctb, ctb_size);
+    }
+}
+
+static int derive_filters(HEVCContext *s)
+{
+    ohevc_filter_maps m;
+    memset(&m, 0, sizeof(m));
+    m.width = s->sps->width; m.height = s->sps->height;
+    m.log2_ctb_size = s->sps->log2_ctb_size; m.log2_min_cb_size = s->sps->log2_min_cb_size; m.log2_min_pu_size = s->sps->log2_min_pu_size;
+    m.chroma_format_idc = s->sps->chroma_array_type;
+    m.cb_qp_offset = s->pps->cb_qp_offset; m.cr_qp_offset = s->pps->cr_qp_offset;
+    m.sao_enabled = s->sps->sao_enabled;
+    m.tiles_enabled = s->pps->tiles_enabled_flag; m.loop_filter_across_tiles = s->pps->loop_filter_across_tiles_enabled_flag;
+    m.pcm_or_bypass = (s->sps->pcm_enabled_flag && s->sps->pcm.loop_filter_disable_flag) || s->pps->transquant_bypass_enable_flag;
+    m.horizontal_bs = s->horizontal_bs; m.vertical_bs = s->vertical_bs; m.bs_width = s->bs_width;
+    m.qp_y_tab = s->qp_y_tab; m.min_cb_width = s->sps->min_cb_width;
+    m.deblock = (const int8_t *)s->deblock; m.deblock_stride = sizeof(DBParams);
+    m.sao = (const ohevc_SAOParams *)s->sao;
+    m.filter_slice_edges = s->filter_slice_edges; m.tab_slice_address = s->tab_slice_address;
+    m.ctb_addr_rs_to_ts = s->pps->ctb_addr_rs_to_ts; m.tile_id = s->pps->tile_id;
+    m.is_pcm = s->is_pcm; m.min_pu_width = s->sps->min_pu_width; m.min_pu_height = s->sps->min_pu_height;
+    return ohevc_tables_derive_filters(t_ctx, &m);
+}
+
 /* ---- called by decoder_harness.c ---- */
 int ohdec_backend_open(void)
 {
@@ -245,6 +313,7 @@ int ohdec_backend_open(void)
     /* CPU-only host-logic tests: no device, the recorded jobs are executed by the oracle on the decoder's own frames (sw_exec.c) */
     ohevc_debug_set_frame_sink(getenv("OHHIP_SW_EXEC") ? ohsw_sink : NULL, NULL);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
+    g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
     if (getenv("OHHIP_LEVEL_LAUNCH"))
         ohevc_debug_set_level_launch(atoi(getenv("OHHIP_LEVEL_LAUNCH")));          /* A/B of the two executors */   /* host-side profiling, no pixels (ohevc_debug.h) */
     if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
@@ -275,6 +344,10 @@ int ohdec_backend_frame_done(void)
                                     t_s->sps->log2_min_pu_size) != OHEVC_OK)
         g_error = 1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (t_s && t_s->sps && t_s->pps && bulk_filters(t_s) && derive_filters(t_s) != OHEVC_OK) {
+        fprintf(stderr, "ohhip: filter derivation failed: %s\n", ohevc_last_error());
+        g_error = 1;
+    }
     st = ohevc_tables_end_frame(t_ctx, !g_defer_download);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (st == OHEVC_OK && ohevc_frame_get_stats(t_ctx, &fs) == OHEVC_OK) {

@@ -29,3 +29,5 @@ void ohhip_await_progress(ThreadFrame *f, int progress, int field) { (void)f; (v
 void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts) { ff_hevc_cabac_init(s, ctb_addr_ts); }
 int  ohhip_log2_res_scale_abs(HEVCContext *s, int idx) { return ff_hevc_log2_res_scale_abs(s, idx); }
 int  ohhip_res_scale_sign_flag(HEVCContext *s, int idx) { return ff_hevc_res_scale_sign_flag(s, idx); }
+void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size) { ff_hevc_hls_filter(s, x, y, ctb_size); }
+void ohhip_hls_filters(HEVCContext *s, int x, int y, int ctb_size) { ff_hevc_hls_filters(s, x, y, ctb_size); }

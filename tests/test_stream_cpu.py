@@ -171,9 +171,14 @@ def test_slice_threads_record_into_one_context(name, monkeypatch):
 # by the CPU oracle on the decoder's own frames (oracle/sw_exec.c through the frame sink of include/ohevc_debug.h).  The pictures
 # must be those of the untouched decoder.  The kernels themselves are what the -m gpu tests check.
 @needs_hip_lib
+@pytest.mark.parametrize("bulk_filters", ["1", "0"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_recorded_jobs_executed_by_the_oracle_reproduce_the_reference(name, monkeypatch):
+def test_recorded_jobs_executed_by_the_oracle_reproduce_the_reference(name, bulk_filters, monkeypatch):
+    """bulk_filters 1 (the hooks' default): the reference's filter drivers are skipped and ohevc_tables_derive_filters records the
+    deblocking / SAO jobs from the boundary-strength, QP, offset, SAO and slice / tile maps at the frame end (16x16-CTB streams
+    with SAO keep the drivers: filter lag); 0: the drivers run and every edge arrives through its table slot."""
     monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    monkeypatch.setenv("OHHIP_BULK_FILTERS", bulk_filters)
     aus, md5 = load_golden(name)
     assert frames_md5(ps.decode_stream("hip", aus)) == md5
 
