@@ -145,6 +145,8 @@ inline bool locate_in(const HostPic &hp, const uint8_t *p, Loc &out)
     return false;
 }
 
+thread_local int tl_hint[2] = { -1, -1 };      // the registry entries the last two successful look-ups hit (a picture predicts from one or two others)
+
 bool locate(const uint8_t *p, Loc &out, int only_pic = -1)
 {
     if (!tl_state) return false;
@@ -154,10 +156,19 @@ bool locate(const uint8_t *p, Loc &out, int only_pic = -1)
         out.pic = only_pic;
         return true;
     }
-    for (int i = 0; i < tl_state->npics(); i++) {
+    const int n = tl_state->npics();
+    for (int h = 0; h < 2; h++) {
+        const int i = tl_hint[h];
+        if (i >= 0 && i < n && tl_state->pics[i].slot >= 0 && locate_in(tl_state->pics[i], p, out)) { out.pic = i; return true; }
+    }
+    for (int i = 0; i < n; i++) {
         const HostPic &hp = tl_state->pics[i];
         if (hp.slot < 0) continue;
-        if (locate_in(hp, p, out)) { out.pic = (int)i; return true; }
+        if (locate_in(hp, p, out)) {
+            out.pic = (int)i;
+            tl_hint[1] = tl_hint[0]; tl_hint[0] = i;
+            return true;
+        }
     }
     return false;
 }
