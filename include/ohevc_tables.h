@@ -170,8 +170,11 @@ int  ohevc_tables_cross_component(int res_scale_val);
  *   filter_slice_edges, tab_slice_address    s->filter_slice_edges, s->tab_slice_address
  *   ctb_addr_rs_to_ts, tile_id               pps arrays
  *   is_pcm / min_pu_width / min_pu_height    s->is_pcm etc., read when pcm_or_bypass (the reference's `pcmf`, hevc_filter.c:363-365)
- * Not for 16x16-CTB streams with SAO (the call refuses them): their output depends on the order of the reference's driver
- * calls (filter lag), so they keep the drivers and the recording slots. */
+ *   emulate_filter_lag, ctb_addr_ts_to_rs    16x16-CTB streams with SAO: the reference's output depends on the ORDER of its driver calls
+ *                                            (filter lag, OHEVC_SAO_LAG_*); with emulate_filter_lag != 0 the drivers' control flow is
+ *                                            replayed CTB by CTB in decoding order (pps->ctb_addr_ts_to_rs) and the flags derived from
+ *                                            it, exactly as the recording slots do; 0 = every SAO block reads the fully deblocked
+ *                                            picture (H.265 8.7.3) */
 typedef struct ohevc_filter_maps {
     int32_t width, height, log2_ctb_size, log2_min_cb_size, log2_min_pu_size, chroma_format_idc;
     int32_t cb_qp_offset, cr_qp_offset;                    /* pps->cb_qp_offset, pps->cr_qp_offset */
@@ -188,6 +191,8 @@ typedef struct ohevc_filter_maps {
     const int *ctb_addr_rs_to_ts, *tile_id;
     const uint8_t *is_pcm;
     int32_t min_pu_width, min_pu_height;
+    int32_t emulate_filter_lag;
+    const int *ctb_addr_ts_to_rs;
 } ohevc_filter_maps;
 int  ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *maps);
 /* the host planes registered for picture-store slot `slot` (tests: oracle/sw_exec.c executes recorded jobs on them) */

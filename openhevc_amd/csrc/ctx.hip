@@ -96,6 +96,18 @@ static inline bool trace_hit(int plane, int x, int y, int w, int h)
 {
     return g_trace_at_on && plane == g_trace_at[0] && g_trace_at[1] >= x && g_trace_at[1] < x + w && g_trace_at[2] >= y && g_trace_at[2] < y + h;
 }
+static void trace_dbk(int target, const ohevc_dbk_job &j)
+{
+    const bool v = j.flags & OHEVC_DBK_VERTICAL_EDGE;      // an edge segment touches up to 4 samples either side of its line
+    if (trace_hit(j.plane, v ? j.x - 4 : j.x, v ? j.y : j.y - 4, v ? 8 : 8, v ? 8 : 8))
+        fprintf(stderr, "trace: target %d dbk plane %d x %d y %d flags 0x%x beta %d tc %d %d\n", target, j.plane, j.x, j.y, j.flags, j.beta, j.tc[0], j.tc[1]);
+}
+static void trace_sao(int target, const ohevc_sao_job &j)
+{
+    if (trace_hit(j.plane, j.x - 1, j.y - 1, j.w + 2, j.h + 2))
+        fprintf(stderr, "trace: target %d sao plane %d x %d y %d w %d h %d type %d klass %d borders 0x%x restore %d edges 0x%x quirks 0x%x off %d %d %d %d\n", target,
+                j.plane, j.x, j.y, j.w, j.h, j.type, j.klass, j.borders, j.restore, j.edges, j.quirks, j.offset_val[1], j.offset_val[2], j.offset_val[3], j.offset_val[4]);
+}
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // What the ohevc_rec_* calls fill.  The context itself is one; with ohevc_ctx_set_concurrent every further thread that
@@ -702,6 +714,7 @@ extern "C" int ohevc_rec_deblock(ohevc_ctx *c, const ohevc_dbk_job *job)
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
     Rec &r = pick(c);
     ((job->flags & OHEVC_DBK_VERTICAL_EDGE) ? r.dbk_v : r.dbk_h).push_back(*job);
+    if (g_trace_at_on) trace_dbk(c->cur, *job);
     r.nstat[3]++;
     return OHEVC_OK;
 }
@@ -711,6 +724,7 @@ extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && job != nullptr, "no frame begun");
     Rec &r = pick(c);
     r.sao.push_back(*job);
+    if (g_trace_at_on) trace_sao(c->cur, *job);
     if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) r.sao_lagged = true;
     r.nstat[4]++;
     return OHEVC_OK;
@@ -762,6 +776,7 @@ extern "C" int ohevc_rec_deblock_bulk(ohevc_ctx *c, const ohevc_dbk_job *jobs, i
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && (n == 0 || jobs != nullptr) && n >= 0, "no frame begun");
     Rec &r = pick(c);
     for (int i = 0; i < n; i++) ((jobs[i].flags & OHEVC_DBK_VERTICAL_EDGE) ? r.dbk_v : r.dbk_h).push_back(jobs[i]);
+    if (g_trace_at_on) for (int i = 0; i < n; i++) trace_dbk(c->cur, jobs[i]);
     r.nstat[3] += n;
     return OHEVC_OK;
 }

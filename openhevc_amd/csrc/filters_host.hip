@@ -10,6 +10,8 @@
 // the reference -- including which offsets an edge next to a CTB boundary gets (see the comments) -- because the job set must
 // be the one the drivers would have produced: tests/test_stream_cpu.py runs both paths through the software executor.
 #include <algorithm>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 #include "common.hpp"
 #include "ohevc_tables.h"
@@ -28,6 +30,12 @@ struct Ctx {
     ohevc_ctx *ctx;
     int rc = OHEVC_OK;
     std::vector<ohevc_dbk_job> edges;   // handed to the recorder in one call
+    // filter-lag emulation (16x16 CTBs, ohevc_hip.h OHEVC_SAO_LAG_*): the order in which the reference's drivers would have made
+    // their calls, kept exactly like the recording slots keep it (tables.hip)
+    bool lag = false;
+    uint32_t seq = 0;
+    std::unordered_map<uint32_t, uint32_t> h_edge_seq;
+    std::vector<std::pair<ohevc_sao_job, uint32_t>> held_sao;
     int hs, vs;                    // chroma subsampling shifts
     int qpy(int x, int y) const { return m.qp_y_tab[(x >> m.log2_min_cb_size) + (y >> m.log2_min_cb_size) * m.min_cb_width]; }    // get_qPy, :144-150
     int pcm(int x, int y) const                                    // get_pcm, :325-338
@@ -55,6 +63,7 @@ struct Ctx {
         j.flags = (uint8_t)((vertical ? OHEVC_DBK_VERTICAL_EDGE : 0) | (no_p[0] ? OHEVC_DBK_NO_P0 : 0) | (no_p[1] ? OHEVC_DBK_NO_P1 : 0) |
                             (no_q[0] ? OHEVC_DBK_NO_Q0 : 0) | (no_q[1] ? OHEVC_DBK_NO_Q1 : 0));
         edges.push_back(j);
+        if (lag && !vertical && plane > 0) h_edge_seq[((uint32_t)plane << 30) | ((uint32_t)y << 15) | (uint32_t)x] = ++seq;
     }
 
     // deblocking_filter_CTB, hevc_filter.c:345-581, loop for loop (the order of the calls does not matter to the executor, the
@@ -170,9 +179,51 @@ struct Ctx {
                                         (de[2] ? 64 : 0) | (de[3] ? 128 : 0));
             }
             for (int k = 0; k < 5; k++) j.offset_val[k] = sao.offset_val[c][k];
+            if (lag && c > 0) { held_sao.emplace_back(j, ++seq); continue; }      // flags depend on calls still to come
             const int r = ohevc_rec_sao(ctx, &j);
             if (r != OHEVC_OK && rc == OHEVC_OK) rc = r;
         }
+    }
+
+    // ff_hevc_hls_filter / ff_hevc_hls_filters, hevc_filter.c:1027-1064: which CTBs the decoding of CTB (x, y) releases
+    void hls_filter(int x, int y)
+    {
+        const int ctb_size = 1 << m.log2_ctb_size;
+        deblock_ctb(x, y);
+        if (!m.sao_enabled) return;
+        const bool x_end = x >= m.width - ctb_size, y_end = y >= m.height - ctb_size;
+        if (y && x) sao_ctb(x - ctb_size, y - ctb_size);
+        if (x && y_end) sao_ctb(x - ctb_size, y);
+        if (y && x_end) sao_ctb(x, y - ctb_size);
+        if (x_end && y_end) sao_ctb(x, y);
+    }
+    void hls_filters(int x, int y)
+    {
+        const int ctb_size = 1 << m.log2_ctb_size;
+        const bool x_end = x >= m.width - ctb_size, y_end = y >= m.height - ctb_size;
+        if (y && x) hls_filter(x - ctb_size, y - ctb_size);
+        if (y && x_end) hls_filter(x, y - ctb_size);
+        if (x && y_end) hls_filter(x - ctb_size, y);
+    }
+    // a held SAO job saw, in the reference, the samples right of its block BEFORE a horizontal edge through them was filtered iff
+    // that edge's call came after the SAO call (same rule as ohevc_tables_end_frame, tables.hip)
+    void release_held_sao()
+    {
+        for (auto &held : held_sao) {
+            ohevc_sao_job &j = held.first;
+            const int xr = j.x + j.w, plane_w = m.width >> hs;
+            if (xr < plane_w) {
+                auto later = [&](int y) {
+                    auto it = h_edge_seq.find(((uint32_t)j.plane << 30) | ((uint32_t)y << 15) | (uint32_t)xr);
+                    return it != h_edge_seq.end() && it->second > held.second;
+                };
+                j.quirks = (uint8_t)((later(j.y + j.h) ? OHEVC_SAO_LAG_BELOW : 0) | (later(j.y) ? OHEVC_SAO_LAG_ABOVE : 0) |
+                                     ((j.h > 8 && later(j.y + 8)) ? OHEVC_SAO_LAG_MID : 0));
+            }
+            const int r = ohevc_rec_sao(ctx, &j);
+            if (r != OHEVC_OK && rc == OHEVC_OK) rc = r;
+        }
+        held_sao.clear();
     }
 };
 
@@ -188,18 +239,31 @@ extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_ma
                   "deblocking maps");
     OHEVC_REQUIRE(!m->sao_enabled || (m->sao && m->filter_slice_edges && m->tab_slice_address && m->ctb_addr_rs_to_ts && m->tile_id), "SAO maps");
     OHEVC_REQUIRE(!m->pcm_or_bypass || (m->is_pcm && m->min_pu_width > 0 && m->min_pu_height > 0), "pcm map");
-    // With 16x16 CTBs the reference's one-CTB filter lag is visible in its output (ohevc_hip.h, OHEVC_SAO_LAG_*), and that
-    // depends on the ORDER of its driver calls: such streams keep the drivers and the recording slots.
-    OHEVC_REQUIRE(m->log2_ctb_size > 4 || !m->sao_enabled, "16x16 CTBs with SAO: keep the reference's filter drivers (filter lag)");
     Ctx c{*m, ctx};
     c.edges.reserve(32768);
     c.hs = m->chroma_format_idc == 1 || m->chroma_format_idc == 2; c.vs = m->chroma_format_idc == 1;
-    const int ctb_size = 1 << m->log2_ctb_size;
-    for (int y = 0; y < m->height; y += ctb_size)
-        for (int x = 0; x < m->width; x += ctb_size) {
-            c.deblock_ctb(x, y);
-            if (m->sao_enabled) c.sao_ctb(x, y);
+    const int ctb_size = 1 << m->log2_ctb_size, ctb_w = (m->width + ctb_size - 1) >> m->log2_ctb_size, ctb_h = (m->height + ctb_size - 1) >> m->log2_ctb_size;
+    // With 16x16 CTBs the reference's one-CTB filter lag is visible in its output (ohevc_hip.h, OHEVC_SAO_LAG_*): which samples a
+    // chroma SAO block saw before their horizontal edge was filtered depends on the ORDER of the driver calls.  To stay bit-identical
+    // the drivers' control flow is replayed CTB by CTB in decoding order (hls_decode_entry, hevc.c:2644-2698) and the call order kept.
+    c.lag = m->emulate_filter_lag && m->log2_ctb_size == 4 && m->sao_enabled && m->chroma_format_idc != 0 && m->chroma_format_idc != 3;
+    if (c.lag) {
+        OHEVC_REQUIRE(m->ctb_addr_ts_to_rs != nullptr, "filter-lag emulation needs pps->ctb_addr_ts_to_rs");
+        int x = 0, y = 0;
+        for (int ts = 0; ts < ctb_w * ctb_h; ts++) {
+            const int rs = m->ctb_addr_ts_to_rs[ts];
+            x = (rs % ctb_w) << m->log2_ctb_size; y = (rs / ctb_w) << m->log2_ctb_size;
+            c.hls_filters(x, y);
         }
+        c.hls_filter(x, y);                                    // hevc.c:2693-2695: the last CTB of the picture releases itself
+        c.release_held_sao();
+    } else {
+        for (int y = 0; y < m->height; y += ctb_size)
+            for (int x = 0; x < m->width; x += ctb_size) {
+                c.deblock_ctb(x, y);
+                if (m->sao_enabled) c.sao_ctb(x, y);
+            }
+    }
     const int r = ohevc_rec_deblock_bulk(ctx, c.edges.data(), (int)c.edges.size());
     return c.rc != OHEVC_OK ? c.rc : r;
 }

@@ -319,11 +319,13 @@ template <int SLOTS> struct Mc3Shared {
     short tmp[SLOTS][Mc3Cfg<SLOTS>::T][Mc3Cfg<SLOTS>::PITCH];
 };
 
+// returns whether a staged sample lies above `maxv` (possible above 8 bit only: see mc3_exact)
 template <typename Pixel, int SLOTS>
-__device__ __forceinline__ void mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], const ohevc_plane &ref, int wx0, int wy0, int ww, int wh,
-                                          int sub, bool active)
+__device__ __forceinline__ bool mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], const ohevc_plane &ref, int wx0, int wy0, int ww, int wh,
+                                          int sub, bool active, int maxv)
 {
     using C = Mc3Cfg<SLOTS>;
+    bool wild = false;
     const unsigned char *base = static_cast<const unsigned char *>(ref.data);
     constexpr int PPD = 4 / (int)sizeof(Pixel);
     constexpr int DPR = (sizeof(Pixel) == 1 || SLOTS == 4) ? 8 : 16;      // dword slots per window row (>= max ndw)
@@ -331,7 +333,7 @@ __device__ __forceinline__ void mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], co
     const int ndw = (wx0 + ww - xa + PPD - 1) / PPD;
     const bool interior = wx0 >= 0 && wy0 >= 0 && wy0 + wh <= ref.height && xa + ndw * PPD <= ref.width &&
                           ((ref.stride | (int)(reinterpret_cast<uintptr_t>(base))) & 3) == 0;
-    if (!active) return;
+    if (!active) return false;
     if (interior) {
 #pragma unroll 1
         for (int idx = sub; idx < wh * DPR; idx += C::SL) {
@@ -344,6 +346,7 @@ __device__ __forceinline__ void mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], co
                 const int c = c0 + j;
                 const int pv = sizeof(Pixel) == 1 ? (int)((raw >> (8 * j)) & 0xff) : (int)((raw >> (16 * j)) & 0xffff);
                 if (c >= 0 && c < C::PITCH) win[r][c] = (short)pv;
+                if (sizeof(Pixel) == 2) wild |= c >= 0 && c < ww && pv > maxv;
             }
         }
     } else {
@@ -354,9 +357,49 @@ __device__ __forceinline__ void mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], co
             int x = wx0 + wx, y = wy0 + wy;
             x = x < 0 ? 0 : x > xmax ? xmax : x;
             y = y < 0 ? 0 : y > ymax ? ymax : y;
-            win[wy][wx] = (short)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
+            const int pv = (int)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
+            win[wy][wx] = (short)pv;
+            if (sizeof(Pixel) == 2) wild |= pv > maxv;
         }
     }
+    return wild;
+}
+
+// The 14-bit intermediate of ONE sample, in the reference's own arithmetic case by case (put_hevc_{qpel,epel}_{pixels,h,v,hv},
+// hevcdsp_template.c:610-624,731-794,1185-1247), straight from global memory.  Only taken when a window holds a sample above the
+// bit depth's range: above 8 bit the reference's constrained intra prediction leaves samples of up to 0x8080 in its pictures (its
+// byte-wise memset, hevcpred_template.c:117-141), later pictures predict from them, and the int16 LDS tiles of the fast path --
+// exact for every sample that fits the bit depth -- would wrap where the reference computes in int (only the h-pass of the hv case
+// lands in an int16 array there, :763-776).  Slow (up to 64 loads per sample) and rare.
+template <typename Pixel>
+__device__ int mc3_exact(const ohevc_plane &ref, int sx, int sy, const signed char *fh, const signed char *fv, bool frac_x, bool frac_y, int taps,
+                         int before, int bit_depth)
+{
+    const unsigned char *base = static_cast<const unsigned char *>(ref.data);
+    const int xmax = ref.width - 1, ymax = ref.height - 1;
+    auto px = [&](int x, int y) {
+        x = x < 0 ? 0 : x > xmax ? xmax : x;
+        y = y < 0 ? 0 : y > ymax ? ymax : y;
+        return (int)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
+    };
+    if (!frac_x && !frac_y) return px(sx, sy) << (14 - bit_depth);
+    if (!frac_y) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fh[k] * px(sx + k - before, sy);
+        return s >> (bit_depth - 8);
+    }
+    if (!frac_x) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fv[k] * px(sx, sy + k - before);
+        return s >> (bit_depth - 8);
+    }
+    int acc = 0;
+    for (int r = 0; r < taps; r++) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fh[k] * px(sx + k - before, sy + r - before);
+        acc += fv[r] * (int)(short)(s >> (bit_depth - 8));
+    }
+    return acc >> 6;
 }
 
 // horizontal + vertical pass of one staged window -> v[0..3] (4 rows of this lane's column), 14-bit intermediate
@@ -428,18 +471,39 @@ __global__ __launch_bounds__(64) void mc3_kernel(PlaneSet dst, const ohevc_plane
             const int tw = jb.w - tx < C::T ? jb.w - tx : C::T, th = jb.h - ty < C::T ? jb.h - ty : C::T;
             const int ww = tw + taps - 1, wh = th + taps - 1;
             const bool active = have && tw > 0 && th > 0;
-            mc3_stage<Pixel, SLOTS>(sh.win[slot][0], ref0, jb.sx0 + tx - before, jb.sy0 + ty - before, ww, wh, sub, active);
-            mc3_stage<Pixel, SLOTS>(sh.win[slot][1], ref1, jb.sx1 + tx - before, jb.sy1 + ty - before, ww, wh, sub, active && bi);
-            __syncthreads();
+            const bool wild0 = mc3_stage<Pixel, SLOTS>(sh.win[slot][0], ref0, jb.sx0 + tx - before, jb.sy0 + ty - before, ww, wh, sub, active, maxv);
+            const bool wild1 = mc3_stage<Pixel, SLOTS>(sh.win[slot][1], ref1, jb.sx1 + tx - before, jb.sy1 + ty - before, ww, wh, sub, active && bi, maxv);
+            bool wild = false;                    // block-uniform: the barriers below stay uniform
+            if (sizeof(Pixel) == 2) wild = __syncthreads_or(wild0 || wild1) != 0;
+            else __syncthreads();
             int v0[4], v1[4] = { 0, 0, 0, 0 };
-            mc3_filter<SLOTS>(sh.win[slot][0], sh.tmp[slot], fh0, fv0, tw, th, wh, bit_depth, sub, active, v0);
-            mc3_filter<SLOTS>(sh.win[slot][1], sh.tmp[slot], fh1, fv1, tw, th, wh, bit_depth, sub, active && bi, v1);
+            if (!wild) {
+                mc3_filter<SLOTS>(sh.win[slot][0], sh.tmp[slot], fh0, fv0, tw, th, wh, bit_depth, sub, active, v0);
+                mc3_filter<SLOTS>(sh.win[slot][1], sh.tmp[slot], fh1, fv1, tw, th, wh, bit_depth, sub, active && bi, v1);
+            } else {
+                for (int j = 0; j < 4; j++) {
+                    const int y = g * 4 + j;
+                    v0[j] = 0;
+                    if (!active || x >= tw || y >= th) continue;
+                    v0[j] = mc3_exact<Pixel>(ref0, jb.sx0 + tx + x, jb.sy0 + ty + y, fh0, fv0, jb.mx0 != 0, jb.my0 != 0, taps, before, bit_depth);
+                    if (bi) {                     // hevc.c:1761-1773: list 0 goes through the int16 hand-off array, list 1 does not
+                        v0[j] = (int)(short)v0[j];
+                        v1[j] = mc3_exact<Pixel>(ref1, jb.sx1 + tx + x, jb.sy1 + ty + y, fh1, fv1, jb.mx1 != 0, jb.my1 != 0, taps, before, bit_depth);
+                    }
+                }
+                __syncthreads();                  // the next tile's staging may not overtake a wave still reading (uniformity with mc3_filter's tail)
+            }
             if (!active || x >= tw) continue;
+            const bool copy = wild && !bi && !weighted && !jb.mx0 && !jb.my0;      // put_hevc_pel_uni_pixels is a memcpy (:626-640): no clip
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int y = g * 4 + j;
                 if (y >= th) continue;
                 int out;
+                if (copy) {
+                    *reinterpret_cast<Pixel *>(dbase + (size_t)(jb.y + ty + y) * dstride + (size_t)(jb.x + tx + x) * sizeof(Pixel)) = (Pixel)(v0[j] >> (14 - bit_depth));
+                    continue;
+                }
                 if (!bi && !weighted) {
                     const int shift = 14 - bit_depth;
                     out = (v0[j] + (1 << (shift - 1))) >> shift;

@@ -279,9 +279,11 @@ void ohor_mc(int bd, int luma, int variant, uint8_t *dst, ptrdiff_t dststride,
             }
             int out;
             switch (variant) {
-            case OH_MC_UNI: {           /* :626-640,796-820,...: ((v + off) >> shift); full-pel == copy */
+            case OH_MC_UNI: {           /* :626-640: the full-sample case is a memcpy -- a sample above the bit depth's range (the
+                                         * constrained-intra 0x8080 samples above 8 bit) is carried over unclipped; :796-820,...: the
+                                         * interpolating cases clip ((v + off) >> shift) */
                 int shift = 14 - bd, off = bd < 14 ? 1 << (shift - 1) : 0;
-                out = clip_px((v + off) >> shift, bd);
+                out = (mx || my) ? clip_px((v + off) >> shift, bd) : ldpx(PX(src, srcstride, x, y), bd);
                 break;
             }
             case OH_MC_BI: {            /* :642-666,822-848,... */
@@ -404,7 +406,10 @@ void ohor_sao_band(int bd, uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst, ptr
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             int v = ldpx(PX(src, stride_src, x, y), bd);
-            stpx(PX(dst, stride_dst, x, y), bd, clip_px(v + table[v >> shift], bd));
+            /* & 31: a sample above the bit depth's range (constrained intra prediction above 8 bit leaves 0x8080 samples,
+             * hevcpred_template.c:117-141) indexes past the reference's 32-entry table -- whatever lies on ITS stack.  Here, and in
+             * the kernel, the band index wraps instead; such streams cannot be compared with the reference */
+            stpx(PX(dst, stride_dst, x, y), bd, clip_px(v + table[(v >> shift) & 31], bd));
         }
 }
 

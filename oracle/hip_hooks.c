@@ -236,10 +236,12 @@ static void crash_handler(int sig)
 /* SURVEY.md 8f-3, host half: the in-loop filter drivers are skipped -- ff_hevc_hls_filters /
  * ff_hevc_hls_filter (hevc_filter.c:1027-1064; call sites hevc.c:2690-2695,2809-2818,2892-2901,3002-3012 renamed to these) keep
  * only their progress reports -- and the frame-end hook hands the maps they would have read to ohevc_tables_derive_filters.
- * Streams whose output depends on the ORDER of the driver calls (16x16 CTBs with SAO: the filter lag) keep the drivers. */
+ * 16x16-CTB streams with SAO (output depends on the ORDER of the driver calls: filter lag) have that order replayed by the bulk form. */
 static int bulk_filters(const HEVCContext *s)
 {
-    return g_bulk_filters && !(s->sps->log2_ctb_size == 4 && s->sps->sao_enabled);
+    /* 16x16 CTBs with SAO: the reference's output depends on the order of its driver calls (filter lag); the bulk form replays that
+     * order for one decoding thread per picture, slice threads keep the drivers (their order is whatever the row threads make it) */
+    return g_bulk_filters && !(s->sps->log2_ctb_size == 4 && s->sps->sao_enabled && (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
 }
 
 void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size)
@@ -297,6 +299,7 @@ static int derive_filters(HEVCContext *s)
     m.filter_slice_edges = s->filter_slice_edges; m.tab_slice_address = s->tab_slice_address;
     m.ctb_addr_rs_to_ts = s->pps->ctb_addr_rs_to_ts; m.tile_id = s->pps->tile_id;
     m.is_pcm = s->is_pcm; m.min_pu_width = s->sps->min_pu_width; m.min_pu_height = s->sps->min_pu_height;
+    m.emulate_filter_lag = 1; m.ctb_addr_ts_to_rs = s->pps->ctb_addr_ts_to_rs;
     return ohevc_tables_derive_filters(t_ctx, &m);
 }
 

@@ -30,13 +30,27 @@ def expected_block(oracle, bd, luma, job, refs_padded):
                      int(job["mx1"]), int(job["my1"]), src2=src2, **kw)
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
-def test_mc_all_variants_and_edges(oracle, bd):
-    rng = np.random.default_rng(500 + bd)
+def sprinkle_wild(rng, planes, bd):
+    """Samples above the bit depth's range, in patches (so that clean and affected windows both occur): what the reference's
+    constrained intra prediction leaves behind above 8 bit (0x8080 and interpolations of it, hevcpred_template.c:117-141)."""
+    for p in planes:
+        for _ in range(max(2, p.size // 2500)):
+            y, x = int(rng.integers(0, p.shape[0] - 6)), int(rng.integers(0, p.shape[1] - 6))
+            h, w = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+            p[y:y + h, x:x + w] = 0x8080 if rng.random() < 0.3 else rng.integers(1 << bd, 0x8081, size=(h, w))
+        p[0, :9] = 0x8080; p[-1, -5:] = 40000          # picture corners: the clamped (edge-emulated) reads see them too
+
+
+@pytest.mark.parametrize("bd,wild", [(8, 0), (10, 0), (12, 0), (9, 1), (10, 1), (12, 1)])
+def test_mc_all_variants_and_edges(oracle, bd, wild):
+    rng = np.random.default_rng(500 + bd + 50 * wild)
     W, H = 208, 144                                   # luma; chroma planes are half size (4:2:0)
     dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
     nslots = 3
     refs = [[rng.integers(0, 1 << bd, size=d).astype(G.pixdt(bd)) for d in dims] for _ in range(nslots)]
+    if wild:
+        for slot in refs:
+            sprinkle_wild(rng, slot, bd)
     refs_padded = [[np.pad(p, PAD, mode="edge") for p in slot] for slot in refs]
     dst = [rng.integers(0, 1 << bd, size=d).astype(G.pixdt(bd)) for d in dims]
     # lay blocks out on a 64-sample grid so jobs never overlap in the destination
@@ -82,13 +96,16 @@ def test_mc_all_variants_and_edges(oracle, bd):
             assert bad.size == 0, f"bd={bd} rep={rep} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
 
 
-@pytest.mark.parametrize("bd", [8, 10])
-def test_mc_small_blocks_four_per_wave(oracle, bd):
+@pytest.mark.parametrize("bd,wild", [(8, 0), (10, 0), (10, 1)])
+def test_mc_small_blocks_four_per_wave(oracle, bd, wild):
     """ohevc_dev_mc_batch_small: jobs of at most 8x8 samples, four per wavefront, incl. counts that are not multiples of 4."""
-    rng = np.random.default_rng(600 + bd)
+    rng = np.random.default_rng(600 + bd + 50 * wild)
     W, H = 208, 144
     dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
     refs = [[rng.integers(0, 1 << bd, size=d).astype(G.pixdt(bd)) for d in dims] for _ in range(2)]
+    if wild:
+        for slot in refs:
+            sprinkle_wild(rng, slot, bd)
     refs_padded = [[np.pad(p, PAD, mode="edge") for p in slot] for slot in refs]
     dst = [rng.integers(0, 1 << bd, size=d).astype(G.pixdt(bd)) for d in dims]
     for njobs in (1, 3, 4, 157):

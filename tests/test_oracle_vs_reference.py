@@ -108,6 +108,33 @@ def test_mc_all_variants(oracle, ref, bd, luma):
                 assert np.array_equal(a, b), (w, h, mx, my, variant, kw)
 
 
+@pytest.mark.parametrize("bd", [b for b in BDS if b > 8])
+@pytest.mark.parametrize("luma", [1, 0])
+def test_mc_samples_above_the_bit_depth(oracle, ref, bd, luma):
+    """Above 8 bit the reference's constrained intra prediction leaves samples of up to 0x8080 in its pictures (its byte-wise
+    memset, hevcpred_template.c:117-141) and later pictures predict from them: the full-sample uni case copies them through,
+    the int16 intermediates wrap.  What the reference computes there is what the path has to compute."""
+    rng = np.random.default_rng(521 + bd + luma)
+    refp = rand_plane(rng, bd, 96, 112)
+    wild = rng.random(refp.shape) < 0.08
+    refp[wild] = rng.integers(1 << bd, 0x8081, size=int(wild.sum())).astype(refp.dtype)
+    refp[40:44, 40:60] = 0x8080
+    fr = 4 if luma else 8
+    for w in (WIDTHS_LUMA if luma else WIDTHS_CHROMA)[:5]:
+        for (mx, my) in [(0, 0), (1, 0), (0, 2), (3, 1), (fr - 1, fr - 1)]:
+            h = int(rng.choice([4, 8, 16])) if w > 2 else 4
+            sx, sy = int(rng.integers(20, 44)), int(rng.integers(20, 40))
+            kw = dict(denom=int(rng.integers(0, 8)), wx0=int(rng.integers(-128, 128)), wx1=int(rng.integers(-128, 128)),
+                      ox0=int(rng.integers(-128, 128)), ox1=int(rng.integers(-128, 128)))
+            src2 = oracle.mc(bd, luma, po.MC_PUT, refp, sx + 3, sy + 5, w, h, mx, my)
+            assert np.array_equal(src2, ref.mc(bd, luma, po.MC_PUT, refp, sx + 3, sy + 5, w, h, mx, my))
+            s2 = np.zeros((h, 64), np.int16); s2[:, :w] = src2
+            for variant in (po.MC_UNI, po.MC_UNI_W, po.MC_BI, po.MC_BI_W):
+                a = oracle.mc(bd, luma, variant, refp, sx, sy, w, h, mx, my, src2=s2, **kw)
+                b = ref.mc(bd, luma, variant, refp, sx, sy, w, h, mx, my, src2=s2, **kw)
+                assert np.array_equal(a, b), (w, h, mx, my, variant, kw)
+
+
 # ------------------------------------------------------------------ deblocking
 @pytest.mark.parametrize("bd", BDS)
 def test_deblock(oracle, ref, bd):

@@ -48,6 +48,10 @@ def random_params(rng):
     if "pcm" in kw and rng.integers(0, 2):
         kw["pcm_loop_filter_disabled"] = 1
     mode = int(rng.integers(0, 5))
+    if kw["constrained_intra"] and kw["bit_depth"] > 8:
+        # above 8 bit the reference's constrained intra prediction leaves 0x8080 samples (its byte-wise memset); band SAO then indexes
+        # past its 32-entry offset table and adds whatever lies on the stack: not reproducible (reference quirks)
+        kw["sao"] = 0
     ctb_w = -(-kw["width"] >> log2_ctb)
     ctb_h = -(-kw["height"] >> log2_ctb)
     if mode == 1 and ctb_h > 1:
