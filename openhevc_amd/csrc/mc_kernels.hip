@@ -12,6 +12,9 @@
 //   tmp  = mx ? (sum fh*src) >> (BD-8) : src << (14-BD)            (14-bit intermediate, fits int16)
 //   v14  = my ? (sum fv*tmp) >> 6      : tmp                       ((S << (14-BD)) >> 6 == S >> (BD-8) exactly)
 #include "common.hpp"
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace ohevc {
 
@@ -319,13 +322,13 @@ template <int SLOTS> struct Mc3Shared {
     short tmp[SLOTS][Mc3Cfg<SLOTS>::T][Mc3Cfg<SLOTS>::PITCH];
 };
 
-// returns whether a staged sample lies above `maxv` (possible above 8 bit only: see mc3_exact)
+// returns the OR of everything staged (16-bit samples: two per dword) -- the caller tests it against the bit depth's range
 template <typename Pixel, int SLOTS>
-__device__ __forceinline__ bool mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], const ohevc_plane &ref, int wx0, int wy0, int ww, int wh,
-                                          int sub, bool active, int maxv)
+__device__ __forceinline__ unsigned mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], const ohevc_plane &ref, int wx0, int wy0, int ww, int wh,
+                                              int sub, bool active)
 {
     using C = Mc3Cfg<SLOTS>;
-    bool wild = false;
+    unsigned seen = 0;
     const unsigned char *base = static_cast<const unsigned char *>(ref.data);
     constexpr int PPD = 4 / (int)sizeof(Pixel);
     constexpr int DPR = (sizeof(Pixel) == 1 || SLOTS == 4) ? 8 : 16;      // dword slots per window row (>= max ndw)
@@ -333,7 +336,7 @@ __device__ __forceinline__ bool mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], co
     const int ndw = (wx0 + ww - xa + PPD - 1) / PPD;
     const bool interior = wx0 >= 0 && wy0 >= 0 && wy0 + wh <= ref.height && xa + ndw * PPD <= ref.width &&
                           ((ref.stride | (int)(reinterpret_cast<uintptr_t>(base))) & 3) == 0;
-    if (!active) return false;
+    if (!active) return 0;
     if (interior) {
 #pragma unroll 1
         for (int idx = sub; idx < wh * DPR; idx += C::SL) {
@@ -341,12 +344,12 @@ __device__ __forceinline__ bool mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], co
             if (dw >= ndw) continue;
             const unsigned raw = *reinterpret_cast<const unsigned *>(base + (size_t)(wy0 + r) * ref.stride + (size_t)(xa + dw * PPD) * sizeof(Pixel));
             const int c0 = xa + dw * PPD - wx0;
+            if (sizeof(Pixel) == 2) seen |= raw;       // an alignment sample just outside the window may be in it: harmless (mc3_redo is exact)
 #pragma unroll
             for (int j = 0; j < PPD; j++) {
                 const int c = c0 + j;
                 const int pv = sizeof(Pixel) == 1 ? (int)((raw >> (8 * j)) & 0xff) : (int)((raw >> (16 * j)) & 0xffff);
                 if (c >= 0 && c < C::PITCH) win[r][c] = (short)pv;
-                if (sizeof(Pixel) == 2) wild |= c >= 0 && c < ww && pv > maxv;
             }
         }
     } else {
@@ -357,49 +360,12 @@ __device__ __forceinline__ bool mc3_stage(short (*win)[Mc3Cfg<SLOTS>::PITCH], co
             int x = wx0 + wx, y = wy0 + wy;
             x = x < 0 ? 0 : x > xmax ? xmax : x;
             y = y < 0 ? 0 : y > ymax ? ymax : y;
-            const int pv = (int)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
+            const Pixel pv = *reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
             win[wy][wx] = (short)pv;
-            if (sizeof(Pixel) == 2) wild |= pv > maxv;
+            if (sizeof(Pixel) == 2) seen |= (unsigned)pv;
         }
     }
-    return wild;
-}
-
-// The 14-bit intermediate of ONE sample, in the reference's own arithmetic case by case (put_hevc_{qpel,epel}_{pixels,h,v,hv},
-// hevcdsp_template.c:610-624,731-794,1185-1247), straight from global memory.  Only taken when a window holds a sample above the
-// bit depth's range: above 8 bit the reference's constrained intra prediction leaves samples of up to 0x8080 in its pictures (its
-// byte-wise memset, hevcpred_template.c:117-141), later pictures predict from them, and the int16 LDS tiles of the fast path --
-// exact for every sample that fits the bit depth -- would wrap where the reference computes in int (only the h-pass of the hv case
-// lands in an int16 array there, :763-776).  Slow (up to 64 loads per sample) and rare.
-template <typename Pixel>
-__device__ int mc3_exact(const ohevc_plane &ref, int sx, int sy, const signed char *fh, const signed char *fv, bool frac_x, bool frac_y, int taps,
-                         int before, int bit_depth)
-{
-    const unsigned char *base = static_cast<const unsigned char *>(ref.data);
-    const int xmax = ref.width - 1, ymax = ref.height - 1;
-    auto px = [&](int x, int y) {
-        x = x < 0 ? 0 : x > xmax ? xmax : x;
-        y = y < 0 ? 0 : y > ymax ? ymax : y;
-        return (int)*reinterpret_cast<const Pixel *>(base + (size_t)y * ref.stride + (size_t)x * sizeof(Pixel));
-    };
-    if (!frac_x && !frac_y) return px(sx, sy) << (14 - bit_depth);
-    if (!frac_y) {
-        int s = 0;
-        for (int k = 0; k < taps; k++) s += fh[k] * px(sx + k - before, sy);
-        return s >> (bit_depth - 8);
-    }
-    if (!frac_x) {
-        int s = 0;
-        for (int k = 0; k < taps; k++) s += fv[k] * px(sx, sy + k - before);
-        return s >> (bit_depth - 8);
-    }
-    int acc = 0;
-    for (int r = 0; r < taps; r++) {
-        int s = 0;
-        for (int k = 0; k < taps; k++) s += fh[k] * px(sx + k - before, sy + r - before);
-        acc += fv[r] * (int)(short)(s >> (bit_depth - 8));
-    }
-    return acc >> 6;
+    return seen;
 }
 
 // horizontal + vertical pass of one staged window -> v[0..3] (4 rows of this lane's column), 14-bit intermediate
@@ -442,9 +408,17 @@ __device__ __forceinline__ void mc3_filter(short (*win)[Mc3Cfg<SLOTS>::PITCH], s
     __syncthreads();
 }
 
+// Samples above the bit depth's range (16-bit planes only).  Above 8 bit the reference's constrained intra prediction leaves
+// samples of up to 0x8080 in its pictures (its byte-wise memset, hevcpred_template.c:117-141) and later pictures predict from them.
+// The int16 LDS tiles of this kernel are exact for every sample that fits the bit depth; for larger ones they would wrap where the
+// reference computes in int (only the h-pass of its hv case lands in an int16 array, hevcdsp_template.c:763-776) and its full-sample
+// uni case is a memcpy that carries them through unclipped (:626-640).  A tile whose windows hold such a sample is not written here:
+// its bit is set in wild_mask[job] (bit = tile index; every job's word is written, so the buffer needs no clearing) and
+// mc3_redo_kernel, launched right behind, computes it in the reference's arithmetic.
 template <typename Pixel, int SLOTS>
 __global__ __launch_bounds__(64) void mc3_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs,
-                                                 const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth)
+                                                 const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth,
+                                                 unsigned short *__restrict__ wild_mask)
 {
     using C = Mc3Cfg<SLOTS>;
     __shared__ __attribute__((aligned(16))) Mc3Shared<SLOTS> sh;
@@ -465,45 +439,32 @@ __global__ __launch_bounds__(64) void mc3_kernel(PlaneSet dst, const ohevc_plane
     const int x = sub % C::T, g = sub / C::T;
     // all slots iterate the same (maximal) number of tiles so that the barriers stay uniform; SLOTS == 4 jobs fit one tile
     const int ntx = SLOTS == 1 ? (jb.w + C::T - 1) / C::T : 1, nty = SLOTS == 1 ? (jb.h + C::T - 1) / C::T : 1;
+    const unsigned wild_bits = 0x10001u * (unsigned)(0xffff & ~maxv);
+    unsigned tile_mask = 0;
     for (int tyi = 0; tyi < nty; tyi++)
         for (int txi = 0; txi < ntx; txi++) {
             const int tx = txi * C::T, ty = tyi * C::T;
             const int tw = jb.w - tx < C::T ? jb.w - tx : C::T, th = jb.h - ty < C::T ? jb.h - ty : C::T;
             const int ww = tw + taps - 1, wh = th + taps - 1;
             const bool active = have && tw > 0 && th > 0;
-            const bool wild0 = mc3_stage<Pixel, SLOTS>(sh.win[slot][0], ref0, jb.sx0 + tx - before, jb.sy0 + ty - before, ww, wh, sub, active, maxv);
-            const bool wild1 = mc3_stage<Pixel, SLOTS>(sh.win[slot][1], ref1, jb.sx1 + tx - before, jb.sy1 + ty - before, ww, wh, sub, active && bi, maxv);
-            bool wild = false;                    // block-uniform: the barriers below stay uniform
-            if (sizeof(Pixel) == 2) wild = __syncthreads_or(wild0 || wild1) != 0;
-            else __syncthreads();
-            int v0[4], v1[4] = { 0, 0, 0, 0 };
-            if (!wild) {
-                mc3_filter<SLOTS>(sh.win[slot][0], sh.tmp[slot], fh0, fv0, tw, th, wh, bit_depth, sub, active, v0);
-                mc3_filter<SLOTS>(sh.win[slot][1], sh.tmp[slot], fh1, fv1, tw, th, wh, bit_depth, sub, active && bi, v1);
+            unsigned seen = mc3_stage<Pixel, SLOTS>(sh.win[slot][0], ref0, jb.sx0 + tx - before, jb.sy0 + ty - before, ww, wh, sub, active);
+            seen |= mc3_stage<Pixel, SLOTS>(sh.win[slot][1], ref1, jb.sx1 + tx - before, jb.sy1 + ty - before, ww, wh, sub, active && bi);
+            bool wild = false;                    // block-uniform (all job slots of the block share the verdict)
+            if (sizeof(Pixel) == 2) {
+                wild = __syncthreads_or((seen & wild_bits) != 0) != 0;
+                if (wild) { tile_mask |= 1u << (tyi * ntx + txi); continue; }
             } else {
-                for (int j = 0; j < 4; j++) {
-                    const int y = g * 4 + j;
-                    v0[j] = 0;
-                    if (!active || x >= tw || y >= th) continue;
-                    v0[j] = mc3_exact<Pixel>(ref0, jb.sx0 + tx + x, jb.sy0 + ty + y, fh0, fv0, jb.mx0 != 0, jb.my0 != 0, taps, before, bit_depth);
-                    if (bi) {                     // hevc.c:1761-1773: list 0 goes through the int16 hand-off array, list 1 does not
-                        v0[j] = (int)(short)v0[j];
-                        v1[j] = mc3_exact<Pixel>(ref1, jb.sx1 + tx + x, jb.sy1 + ty + y, fh1, fv1, jb.mx1 != 0, jb.my1 != 0, taps, before, bit_depth);
-                    }
-                }
-                __syncthreads();                  // the next tile's staging may not overtake a wave still reading (uniformity with mc3_filter's tail)
+                __syncthreads();
             }
+            int v0[4], v1[4] = { 0, 0, 0, 0 };
+            mc3_filter<SLOTS>(sh.win[slot][0], sh.tmp[slot], fh0, fv0, tw, th, wh, bit_depth, sub, active, v0);
+            mc3_filter<SLOTS>(sh.win[slot][1], sh.tmp[slot], fh1, fv1, tw, th, wh, bit_depth, sub, active && bi, v1);
             if (!active || x >= tw) continue;
-            const bool copy = wild && !bi && !weighted && !jb.mx0 && !jb.my0;      // put_hevc_pel_uni_pixels is a memcpy (:626-640): no clip
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int y = g * 4 + j;
                 if (y >= th) continue;
                 int out;
-                if (copy) {
-                    *reinterpret_cast<Pixel *>(dbase + (size_t)(jb.y + ty + y) * dstride + (size_t)(jb.x + tx + x) * sizeof(Pixel)) = (Pixel)(v0[j] >> (14 - bit_depth));
-                    continue;
-                }
                 if (!bi && !weighted) {
                     const int shift = 14 - bit_depth;
                     out = (v0[j] + (1 << (shift - 1))) >> shift;
@@ -522,11 +483,128 @@ __global__ __launch_bounds__(64) void mc3_kernel(PlaneSet dst, const ohevc_plane
                 *reinterpret_cast<Pixel *>(dbase + (size_t)(jb.y + ty + y) * dstride + (size_t)(jb.x + tx + x) * sizeof(Pixel)) = (Pixel)out;
             }
         }
+    if (sizeof(Pixel) == 2 && have && sub == 0) wild_mask[jidx] = (unsigned short)tile_mask;
+}
+
+// ------------------------------------------------------------------ the tiles mc3_kernel left out (see there)
+// The 14-bit intermediate of ONE sample, in the reference's own arithmetic case by case (put_hevc_{qpel,epel}_{pixels,h,v,hv},
+// hevcdsp_template.c:610-624,731-794,1185-1247), straight from global memory with the coordinates clamped like the staging does.
+__device__ int mc3_exact(const ohevc_plane &ref, int sx, int sy, const signed char *fh, const signed char *fv, bool frac_x, bool frac_y, int taps,
+                         int before, int bit_depth)
+{
+    const unsigned char *base = static_cast<const unsigned char *>(ref.data);
+    const int xmax = ref.width - 1, ymax = ref.height - 1;
+    auto px = [&](int x, int y) {
+        x = x < 0 ? 0 : x > xmax ? xmax : x;
+        y = y < 0 ? 0 : y > ymax ? ymax : y;
+        return (int)*reinterpret_cast<const unsigned short *>(base + (size_t)y * ref.stride + (size_t)x * 2);
+    };
+    if (!frac_x && !frac_y) return px(sx, sy) << (14 - bit_depth);
+    if (!frac_y) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fh[k] * px(sx + k - before, sy);
+        return s >> (bit_depth - 8);
+    }
+    if (!frac_x) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fv[k] * px(sx, sy + k - before);
+        return s >> (bit_depth - 8);
+    }
+    int acc = 0;
+    for (int r = 0; r < taps; r++) {
+        int s = 0;
+        for (int k = 0; k < taps; k++) s += fh[k] * px(sx + k - before, sy + r - before);
+        acc += fv[r] * (int)(short)(s >> (bit_depth - 8));       // the h-pass lands in an int16 tmp[] (:763-776)
+    }
+    return acc >> 6;
+}
+
+// One wavefront per 64 jobs: the lanes read 64 mask words, the wave then works through the (rare) jobs with a bit set, one sample
+// per lane and step.  `tile` = the tile edge of the mc3_kernel instantiation that wrote the masks (16, or 8 for the small-job form).
+__global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs,
+                                                      int njobs, int bit_depth, const unsigned short *__restrict__ wild_mask, int tile)
+{
+    const int lane = threadIdx.x;
+    const int maxv = (1 << bit_depth) - 1;
+    for (int base = blockIdx.x * 64; base < njobs; base += gridDim.x * 64) {
+        const unsigned mine = base + lane < njobs ? wild_mask[base + lane] : 0;
+        unsigned long long todo = __ballot(mine != 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned mask = (unsigned)__shfl((int)mine, src);
+            const ohevc_mc_job jb = jobs[base + src];
+            const bool luma = jb.plane == 0, bi = jb.flags & OHEVC_MC_BI, weighted = jb.flags & OHEVC_MC_WEIGHTED;
+            const ohevc_plane ref0 = refs[3 * jb.ref0 + jb.plane];
+            const ohevc_plane ref1 = refs[3 * (bi ? jb.ref1 : jb.ref0) + jb.plane];
+            unsigned char *dbase = PLANE_PTR3(dst, jb.plane);
+            const int dstride = PLANE_STRIDE3(dst, jb.plane);
+            const int before = luma ? 3 : 1, taps = luma ? 8 : 4;
+            const signed char *fh0 = luma ? kLumaTaps8[jb.mx0] : kChromaTaps8[jb.mx0], *fv0 = luma ? kLumaTaps8[jb.my0] : kChromaTaps8[jb.my0];
+            const signed char *fh1 = luma ? kLumaTaps8[jb.mx1] : kChromaTaps8[jb.mx1], *fv1 = luma ? kLumaTaps8[jb.my1] : kChromaTaps8[jb.my1];
+            const int ntx = (jb.w + tile - 1) / tile;
+            for (unsigned bits = mask; bits; bits &= bits - 1) {
+                const int t = __ffs((int)bits) - 1, tx = (t % ntx) * tile, ty = (t / ntx) * tile;
+                const int tw = jb.w - tx < tile ? jb.w - tx : tile, th = jb.h - ty < tile ? jb.h - ty : tile;
+                for (int i = lane; i < tw * th; i += 64) {
+                    const int x = tx + i % tw, y = ty + i / tw;
+                    unsigned short *out_px = reinterpret_cast<unsigned short *>(dbase + (size_t)(jb.y + y) * dstride + (size_t)(jb.x + x) * 2);
+                    int v0 = mc3_exact(ref0, jb.sx0 + x, jb.sy0 + y, fh0, fv0, jb.mx0 != 0, jb.my0 != 0, taps, before, bit_depth), v1 = 0;
+                    if (bi) {                     // hevc.c:1761-1773: list 0 goes through the int16 hand-off array, list 1 does not
+                        v0 = (int)(short)v0;
+                        v1 = mc3_exact(ref1, jb.sx1 + x, jb.sy1 + y, fh1, fv1, jb.mx1 != 0, jb.my1 != 0, taps, before, bit_depth);
+                    }
+                    int out;
+                    if (!bi && !weighted) {
+                        if (!jb.mx0 && !jb.my0) { *out_px = (unsigned short)(v0 >> (14 - bit_depth)); continue; }      // the memcpy case: no clip
+                        const int shift = 14 - bit_depth;
+                        out = (v0 + (1 << (shift - 1))) >> shift;
+                    } else if (bi && !weighted) {
+                        const int shift = 15 - bit_depth;
+                        out = (v1 + v0 + (1 << (shift - 1))) >> shift;
+                    } else if (!bi) {
+                        const int shift = jb.denom + 14 - bit_depth;
+                        out = ((v0 * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                    } else {
+                        const int log2wd = jb.denom + 14 - bit_depth;
+                        const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
+                        out = (v1 * jb.wx1 + v0 * jb.wx0 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
+                    }
+                    *out_px = (unsigned short)(out < 0 ? 0 : out > maxv ? maxv : out);
+                }
+            }
+        }
+    }
 }
 
 int g_mc_variant = 3;     // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = v2 + dual staging / job slots (shipped)
 
 }  // namespace ohevc
+
+// One mask word per job, written by mc3_kernel<uint16_t> and read by mc3_redo_kernel behind it on the same stream: a buffer per
+// stream, grown on demand (growing waits for the stream: a launch in flight may still use the old one).
+namespace {
+struct WildScratch { int device; hipStream_t stream; unsigned short *buf; size_t cap; };
+std::mutex g_wild_m;
+std::vector<WildScratch> g_wild;
+int wild_scratch(hipStream_t st, int njobs, unsigned short **out)
+{
+    int dev = 0;
+    OHEVC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_wild_m);
+    WildScratch *w = nullptr;
+    for (auto &e : g_wild) if (e.device == dev && e.stream == st) { w = &e; break; }
+    if (!w) { g_wild.push_back({dev, st, nullptr, 0}); w = &g_wild.back(); }
+    if ((size_t)njobs > w->cap) {
+        if (w->buf) { OHEVC_HIP_TRY(hipStreamSynchronize(st)); OHEVC_HIP_TRY(hipFree(w->buf)); w->buf = nullptr; w->cap = 0; }
+        const size_t cap = std::max<size_t>((size_t)njobs * 2, 65536);
+        OHEVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w->buf), cap * sizeof(unsigned short)));
+        w->cap = cap;
+    }
+    *out = w->buf;
+    return OHEVC_OK;
+}
+}  // namespace
 
 static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
                      const ohevc_mc_job *jobs, int njobs, void *stream, bool small)
@@ -542,10 +620,20 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     int rc = make_plane_set(dst, ps, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned short *wild = nullptr;
+    const bool v3 = small || (g_mc_variant != 1 && g_mc_variant != 2);
+    if (bit_depth > 8 && v3) {
+        rc = wild_scratch(st, njobs, &wild);
+        if (rc != OHEVC_OK) return rc;
+    }
+    const int redo_grid = std::min(256, (njobs + 63) / 64);
     if (small) {
         const int grid = (njobs + 3) / 4;
-        if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
-        else                hipLaunchKernelGGL((mc3_kernel<uint16_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+        if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
+        else {
+            hipLaunchKernelGGL((mc3_kernel<uint16_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
+            hipLaunchKernelGGL(mc3_redo_kernel, dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 8);
+        }
     } else if (g_mc_variant == 1) {
         if (bit_depth == 8) hipLaunchKernelGGL((mc_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
         else                hipLaunchKernelGGL((mc_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
@@ -553,8 +641,11 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
         if (bit_depth == 8) hipLaunchKernelGGL((mc2_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
         else                hipLaunchKernelGGL((mc2_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
     } else {
-        if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
-        else                hipLaunchKernelGGL((mc3_kernel<uint16_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+        if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
+        else {
+            hipLaunchKernelGGL((mc3_kernel<uint16_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
+            hipLaunchKernelGGL(mc3_redo_kernel, dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 16);
+        }
     }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
