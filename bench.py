@@ -100,6 +100,8 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     L.check(L.load_library().ohevc_set_device(local_rank))
+    if os.environ.get("OHEVC_TU_VARIANT"):      # A/B of the residual kernel's forms under the bench's own conditions (ohevc_debug.h)
+        L.load_library().ohevc_debug_set_tu_variant(int(os.environ["OHEVC_TU_VARIANT"]))
     dist = None
     if world > 1:
         import torch.distributed as dist

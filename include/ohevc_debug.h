@@ -14,6 +14,15 @@ extern "C" {
  * keep the memory traffic but drop the transform (bit 5: also drop the LDS passes) -- their output is NOT correct;
  * they exist only to locate the bottleneck.  Returns the previous value; -1 restores the shipped default (coalesced epilogue for 16x16/32x32, prefetch for 8x8). */
 int ohevc_debug_set_tu_variant(int variant);
+/* bit 8 of the variant (256): 32x32 blocks run the matrix-core form (tu_idct32_mfma_kernel: v_mfma_i32_32x32x32_i8 on the high and low
+ * byte planes of the int16 inputs, both passes in registers); its grid is the persistent kernel's (ohevc_debug_set_tu_pipe_workgroups).
+ * ohevc_debug_mfma_i8_probe runs one such MFMA per probe on raw lane data (a, b: nprobes x 64 lanes x 16 bytes, d: nprobes x 64 x 16
+ * int32, all device memory): tools/probe_mfma_layout.py recovers the fragment layout the kernel relies on from it. */
+int ohevc_debug_mfma_i8_probe(const void *a, const void *b, void *d, int nprobes, void *stream);
+/* variant bits 9 / 10 (with bit 8): fetch the prediction rows before the transform / no register prefetch of the next block pair.
+ * ohevc_debug_lds_tr16_probe: one ds_read_b64_tr_b16 per lane at byte address addr[probe * 64 + lane] of a 2048-byte LDS image holding
+ * int16 i at index i; out: nprobes x 64 lanes x 8 bytes (device memory). */
+int ohevc_debug_lds_tr16_probe(const void *addr, void *out, int nprobes, void *stream);
 /* bit 2 of the variant selects the persistent, software-pipelined kernel; this sets its grid size (workgroups). */
 int ohevc_debug_set_tu_pipe_workgroups(int n);
 /* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = 2 + both reference

@@ -15,7 +15,8 @@
 //     [row][slot(i)], pass 2 gathers its row with ds_read_b128 already in pair order.
 //   * both clip_int16 stages are v_cvt_pk_i16_i32 (saturating pack); rounding constants ride in the DC lane of
 //     the butterfly; the final clip_pixel is a saturating packed add + packed max/min.
-// No floating point, no MFMA (int16 x int8 butterflies; the kernel is HBM-bound).
+// No floating point.  The shipped kernel uses no MFMA (int16 x int8 butterflies; it runs at the memory system's rate for this
+// read/write mix); tu_idct32_mfma_kernel below is the matrix-core form of the 32x32 case, bit-exact, same speed.
 #include <atomic>
 #include "common.hpp"
 #include "intra_body.hpp"
@@ -339,6 +340,237 @@ __global__ __launch_bounds__(256) void tu_idct_add_kernel(PlaneSet planes, const
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * TuLayout<LOG2N>::WAVE_BYTES];
     tu_idct_add_body<LOG2N, Pixel, VARIANT>(lds, blockIdx.x, planes, jobs, njobs, coeffs, bit_depth);
+}
+
+// ------------------------------------------------------------------ 32x32 IDCT + add on the matrix cores
+// The VALU form above is issue-bound: 737 VALU instructions per wave (2 blocks) x 4 cycles = the 0.93 ms it takes for 2^20 blocks
+// (DESIGN.md 3.1).  The transform IS a matrix product, and v_mfma_i32_32x32x32_i8 multiplies int8 exactly; int16 inputs go in as two
+// byte planes:      x = 256 * hi + (lo + 128),  hi = x >> 8,  lo = (x & 255) - 128  (both int8)
+//   =>  sum_k T[k][y] * x[k] = 256 * sum T*hi + sum T*lo + 128 * sum_k T[k][y]            (|T| <= 90: exact in int32)
+// i.e. two MFMAs per pass and block, the constant and the rounding term preloaded into the accumulator of the second one.
+//
+// Fragment layout (cdna_hip_programming.md "Fragment layout"; tools/probe_mfma_layout.py checks it on the device):
+// A[m = lane & 31][k <- (lane >> 5, byte)], B[k][n = lane & 31] with the same k map, D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31].
+// Which k a (half, byte) slot means is ours to choose as long as both operands agree:
+//   pass 1 (columns):  D1[c][y] = sum_k C[k][c] * T[k][y].  A = the block, read COLUMN-wise out of its plain row-major LDS copy with
+//           ds_read_b64_tr_b16 (each 16-lane group takes a [4 rows][16 columns] piece, a lane ends up with 4 consecutive rows of its
+//           column): lane (c = l & 31, h = l >> 5) holds rows 16h .. 16h + 15, byte j = row k1(h, j) = 16h + j.  B = T in that order
+//           (constant).  D1 comes out with lane = y and registers = c in the order k2(h, r) = (r & 3) + 8 (r >> 2) + 4h - exactly an operand of
+//   pass 2 (rows):     D2[x][y] = sum_c T[c][x] * P1[y][c].  A = T in the k2 order (constant), B = P1 straight from the registers.
+//           D2: lane = y, registers = x (groups of 4 consecutive x) -> 8-byte LDS writes into the strip tile of the coalesced epilogue.
+// Memory side: everything moves in 16-byte accesses (a wave64 memory instruction costs the same address cycles whatever its width -
+// a first version with 2-byte column loads straight from HBM was bit-exact and slower than the VALU kernel).  Each wave loops over block
+// pairs, three deep: pair p is in LDS, pair p+1 in registers on its way to LDS, pair p+2 in flight from HBM (job records one further).
+// tools/emulate_idct32_mfma.py runs the index algebra in numpy against the oracle.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int mfma_k1(int h, int j) { return 16 * h + j; }
+__host__ __device__ constexpr int mfma_k2(int h, int j) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+struct MfmaIdctTabs {
+    int b1[64][4];        // pass-1 B operand of lane l: bytes T[k1(h, j)][l & 31]
+    int a2[64][4];        // pass-2 A operand of lane l: bytes T[k2(h, j)][l & 31]
+    int colsum[32];       // sum_k T[k][y]
+};
+constexpr MfmaIdctTabs make_mfma_idct_tabs()
+{
+    MfmaIdctTabs t{};
+    for (int l = 0; l < 64; l++)
+        for (int d = 0; d < 4; d++) {
+            unsigned b = 0, a = 0;
+            for (int e = 0; e < 4; e++) {
+                const int j = 4 * d + e;
+                b |= (unsigned)(dct32(mfma_k1(l >> 5, j), l & 31) & 0xff) << (8 * e);
+                a |= (unsigned)(dct32(mfma_k2(l >> 5, j), l & 31) & 0xff) << (8 * e);
+            }
+            t.b1[l][d] = (int)b; t.a2[l][d] = (int)a;
+        }
+    for (int y = 0; y < 32; y++) {
+        int sum = 0;
+        for (int k = 0; k < 32; k++) sum += dct32(k, y);
+        t.colsum[y] = sum;
+    }
+    return t;
+}
+__device__ const MfmaIdctTabs kMfmaIdct = make_mfma_idct_tabs();
+
+// two dwords of int16 pairs -> the int8 plane of their high / low bytes (low: - 128, i.e. bit 7 flipped)
+__device__ __forceinline__ int hi_bytes(unsigned w0, unsigned w1) { return (int)__builtin_amdgcn_perm(w1, w0, 0x07050301u); }
+__device__ __forceinline__ int lo_bytes(unsigned w0, unsigned w1) { return (int)(__builtin_amdgcn_perm(w1, w0, 0x06040200u) ^ 0x80808080u); }
+
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane i supplies the (8-byte aligned) address of 4 int16; lane l receives element
+// l & 3 of what lanes (l >> 2), 4 + (l >> 2), 8 + (l >> 2), 12 + (l >> 2) fetched.  With lane i pointing at row i >> 2, columns 4 (i & 3) ..
+// of a [4][16] piece, lane l gets rows 0..3 of column l.
+__device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char *p)
+{
+    const v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (v4s __attribute__((address_space(3))) *)(__attribute__((address_space(3))) unsigned char *)p);
+    return bitcast<u32x2>(r);
+}
+
+// VARIANT bit 0: fetch the prediction rows before the transform; bit 1: no register prefetch of the next pair (for the A/B)
+template <typename Pixel, int VARIANT>
+__global__ __launch_bounds__(256) void tu_idct32_mfma_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                                             const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    constexpr int N = 32, ORS = 144, STRIP = N * ORS, COEF = 2 * N * N * 2, WAVE_BYTES = COEF + STRIP;   // 4096 + 4608 per wave
+    constexpr int PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 64 / CH_PX, RPI = 64 / CPR, ITER = N / RPI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WAVE_BYTES];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    unsigned char *ctile = lds + wave * WAVE_BYTES, *strip = ctile + COEF;
+    const v4i b1 = { kMfmaIdct.b1[lane][0], kMfmaIdct.b1[lane][1], kMfmaIdct.b1[lane][2], kMfmaIdct.b1[lane][3] };
+    const v4i a2 = { kMfmaIdct.a2[lane][0], kMfmaIdct.a2[lane][1], kMfmaIdct.a2[lane][2], kMfmaIdct.a2[lane][3] };
+    const int shift2 = 20 - bit_depth;
+    v16i init1, init2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        init1[r] = 64 + 128 * kMfmaIdct.colsum[n];                                       // + (1 << 6), then >> 7
+        init2[r] = (1 << (shift2 - 1)) + 128 * kMfmaIdct.colsum[mfma_k2(h, r)];
+    }
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // transposing read: this lane's piece of the [4 rows][16 columns] block of its 16-lane group (rows 16h + 4t .., columns 16 * bit 4 ..)
+    const int u = lane & 15;
+    const unsigned char *trp = ctile + (16 * h + (u >> 2)) * (N * 2) + (16 * ((lane >> 4) & 1) + 4 * (u & 3)) * 2;
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+    const int c = lane % CPR, r0 = lane / CPR, gsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+
+    const int npairs = (njobs + 1) >> 1, stride = gridDim.x * 4;
+    const int first = blockIdx.x * 4 + wave;
+    if (first >= npairs) return;
+    auto job_of = [&](int pair, int g) {
+        const int j = pair * 2 + g;
+        return reinterpret_cast<const u32x4 *>(jobs)[j < njobs ? j : njobs - 1];
+    };
+    auto fetch = [&](const u32x4 &j0, const u32x4 &j1, u32x4 *cq) {            // 4 x 16 bytes per lane = 2 blocks
+        const u32x4 *s0 = reinterpret_cast<const u32x4 *>(coeffs + j0.z), *s1 = reinterpret_cast<const u32x4 *>(coeffs + j1.z);
+        cq[0] = s0[lane]; cq[1] = s0[64 + lane]; cq[2] = s1[lane]; cq[3] = s1[64 + lane];
+    };
+    auto to_lds = [&](const u32x4 *cq) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4 *>(ctile + (q * 64 + lane) * 16) = cq[q];
+    };
+    // job records: current pair, +1 (its coefficients are in `cq`), +2 (fetched this iteration), +3 (record load in flight)
+    u32x4 jc[2] = { job_of(first, 0), job_of(first, 1) };
+    u32x4 j1[2] = { job_of(first + stride, 0), job_of(first + stride, 1) };
+    u32x4 j2[2] = { job_of(first + 2 * stride, 0), job_of(first + 2 * stride, 1) };
+    u32x4 cq[4];
+    fetch(jc[0], jc[1], cq);
+    to_lds(cq);
+    fetch(j1[0], j1[1], cq);
+    for (int pair = first; pair < npairs; pair += stride) {
+        const int job0 = pair * 2;
+        const u32x4 j3[2] = { job_of(pair + 3 * stride, 0), job_of(pair + 3 * stride, 1) };
+        __builtin_amdgcn_wave_barrier();
+        unsigned w[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32x2 v = lds_read_tr16(trp + g * (N * N * 2) + t * (4 * N * 2));
+                w[g][2 * t] = v.x; w[g][2 * t + 1] = v.y;
+            }
+        // epilogue addressing of this pair; optionally its prediction rows now
+        const unsigned oxy = gsel ? jc[1].x : jc[0].x, opl = (gsel ? jc[1].y : jc[0].y) & 0xff;
+        const bool ovalid = job0 + gsel < njobs;
+        const int ostride = PLANE_STRIDE3(planes, opl);
+        unsigned char *obase = PLANE_PTR3(planes, opl) + (size_t)(oxy >> 16) * ostride + (size_t)((oxy & 0xffff) + pxoff) * PXB;
+        u32x4 pr[ITER];
+        if constexpr (VARIANT & 1) {
+#pragma unroll
+            for (int k = 0; k < ITER; k++) {
+                pr[k] = u32x4{ 0, 0, 0, 0 };
+                if (ovalid) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the LDS copy is consumed (DS operations of a wave execute in order): the next pair moves in, the one after is requested
+        if constexpr (!(VARIANT & 2)) {
+            to_lds(cq);
+            fetch(j2[0], j2[1], cq);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            // ---- pass 1
+            const v4i ahi = { hi_bytes(w[g][0], w[g][1]), hi_bytes(w[g][2], w[g][3]), hi_bytes(w[g][4], w[g][5]), hi_bytes(w[g][6], w[g][7]) };
+            const v4i alo = { lo_bytes(w[g][0], w[g][1]), lo_bytes(w[g][2], w[g][3]), lo_bytes(w[g][4], w[g][5]), lo_bytes(w[g][6], w[g][7]) };
+            const v16i dhi = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, b1, zero, 0, 0, 0);
+            const v16i dlo = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, b1, init1, 0, 0, 0);
+            unsigned pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                pk[q] = sat_pack_i16(((dhi[2 * q] << 8) + dlo[2 * q]) >> 7, ((dhi[2 * q + 1] << 8) + dlo[2 * q + 1]) >> 7);
+            // ---- pass 2
+            const v4i bhi = { hi_bytes(pk[0], pk[1]), hi_bytes(pk[2], pk[3]), hi_bytes(pk[4], pk[5]), hi_bytes(pk[6], pk[7]) };
+            const v4i blo = { lo_bytes(pk[0], pk[1]), lo_bytes(pk[2], pk[3]), lo_bytes(pk[4], pk[5]), lo_bytes(pk[6], pk[7]) };
+            const v16i ehi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, bhi, zero, 0, 0, 0);
+            const v16i elo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, blo, init2, 0, 0, 0);
+            // ---- residual row y = n of block g: registers 4q'..4q'+3 are x = 8q' + 4h .. + 3
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                u32x2 v;
+                v.x = sat_pack_i16(((ehi[4 * qq] << 8) + elo[4 * qq]) >> shift2, ((ehi[4 * qq + 1] << 8) + elo[4 * qq + 1]) >> shift2);
+                v.y = sat_pack_i16(((ehi[4 * qq + 2] << 8) + elo[4 * qq + 2]) >> shift2, ((ehi[4 * qq + 3] << 8) + elo[4 * qq + 3]) >> shift2);
+                *reinterpret_cast<u32x2 *>(strip + n * ORS + g * (N * 2) + (8 * qq + 4 * h) * 2) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- epilogue: as in tu_idct_add_body (coalesced strip form): lane L takes 16 bytes of pixels of row L / CPR
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            const int rr = r0 + k * RPI;
+            if constexpr (!(VARIANT & 1)) {
+                pr[k] = u32x4{ 0, 0, 0, 0 };
+                if (ovalid) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)rr * ostride);
+            }
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(strip + rr * ORS + c * CH_PX * 2);
+            u32x4 o;
+            if constexpr (PXB == 1) {
+                const u32x4 ra = rp[0], rb = rp[1];
+                const unsigned res[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+                const unsigned pd[4] = { pr[k].x, pr[k].y, pr[k].z, pr[k].w };
+                unsigned od[4];
+#pragma unroll
+                for (int d4 = 0; d4 < 4; d4++) {
+                    const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
+                    const unsigned a01 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4]), bitcast<s16x2>(u01)));
+                    const unsigned a23 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4 + 1]), bitcast<s16x2>(u23)));
+                    od[d4] = sat_pack_u8_i16(a01) | (sat_pack_u8_i16(a23) << 16);
+                }
+                o = u32x4{ od[0], od[1], od[2], od[3] };
+            } else {
+                const u32x4 ra = rp[0];
+                o = u32x4{ add_clamp_upx2(ra.x, pr[k].x, max2), add_clamp_upx2(ra.y, pr[k].y, max2),
+                           add_clamp_upx2(ra.z, pr[k].z, max2), add_clamp_upx2(ra.w, pr[k].w, max2) };
+            }
+            if (ovalid) *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
+        }
+        if constexpr (VARIANT & 2) {               // unpipelined form: fetch the next pair only now
+            __builtin_amdgcn_wave_barrier();
+            to_lds(cq);
+            fetch(j2[0], j2[1], cq);
+        }
+        jc[0] = j1[0]; jc[1] = j1[1]; j1[0] = j2[0]; j1[1] = j2[1]; j2[0] = j3[0]; j2[1] = j3[1];
+    }
+}
+
+// raw ds_read_b64_tr_b16 of a 2048-byte LDS image filled with int16 i at index i, every lane at its own byte address: what
+// tools/probe_mfma_layout.py checks the transposing read of the kernel above against
+__global__ __launch_bounds__(64) void lds_tr16_probe_kernel(const int *__restrict__ addr, u32x2 *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char img[2048];
+    for (int i = threadIdx.x; i < 1024; i += 64) reinterpret_cast<short *>(img)[i] = (short)i;
+    __syncthreads();
+    out[blockIdx.x * 64 + threadIdx.x] = lds_read_tr16(img + addr[blockIdx.x * 64 + threadIdx.x]);
+}
+
+// one v_mfma_i32_32x32x32_i8 per probe on raw lane data (a, b: 64 lanes x 16 bytes; d: 64 lanes x 16 int32): lets a test recover
+// the fragment layout the kernel above relies on (tools/probe_mfma_layout.py)
+__global__ __launch_bounds__(64) void mfma_i8_probe_kernel(const v4i *__restrict__ a, const v4i *__restrict__ b, v16i *__restrict__ d)
+{
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    d[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[i], zero, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------ ablations (NOT bit-exact; bottleneck analysis only)
@@ -860,6 +1092,18 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
     // shipped configuration (A/B on MI355X, profiles/r01*_ab_tu_variants.txt): LDS-transposed, fully coalesced epilogue
     // + non-accumulating chain starts / v_sat_pk_u8_i16 for 16x16 and 32x32; early prediction prefetch for 8x8
     const int variant = g_tu_variant >= 0 ? g_tu_variant : (LOG2N >= 4 ? 16 + 128 : 1);
+    if constexpr (LOG2N == 5) {
+        if (variant & 256) {     // matrix-core form; every wave loops over block pairs so that its constant operands are loaded once
+            const int pairs = (njobs + 1) / 2, need = (pairs + 3) / 4, pgrid = need < g_tu_pipe_wgs ? need : g_tu_pipe_wgs;
+            switch ((variant >> 9) & 3) {      // bit 9: prediction rows fetched early; bit 10: no register prefetch
+            case 0: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 0>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+            case 1: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 1>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+            case 2: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 2>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+            case 3: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 3>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
+            }
+            return;
+        }
+    }
     if (variant & 4) {
         const int pgrid = grid < g_tu_pipe_wgs ? grid : g_tu_pipe_wgs;
         switch (variant & 9) {
@@ -1039,8 +1283,32 @@ extern "C" int ohevc_debug_set_tu_pipe_workgroups(int n)
     return old;
 }
 
+extern "C" int ohevc_debug_mfma_i8_probe(const void *a, const void *b, void *d, int nprobes, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(a && b && d && nprobes > 0, "null argument");
+    hipLaunchKernelGGL(mfma_i8_probe_kernel, dim3(nprobes), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const v4i *>(a),
+                       static_cast<const v4i *>(b), static_cast<v16i *>(d));
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_debug_lds_tr16_probe(const void *addr, void *out, int nprobes, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(addr && out && nprobes > 0, "null argument");
+    hipLaunchKernelGGL(lds_tr16_probe_kernel, dim3(nprobes), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const int *>(addr),
+                       static_cast<u32x2 *>(out));
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
 extern "C" const char *ohevc_tu_kernel_name(int bit_depth, int log2_size, int kind)
 {
+    if (kind == OHEVC_TU_IDCT && log2_size == 5) {
+        const int variant = ohevc::g_tu_variant >= 0 ? ohevc::g_tu_variant : 16 + 128;
+        if (variant & 256) return "tu_idct32_mfma_kernel";
+    }
     if (kind == OHEVC_TU_IDCT && log2_size >= 3) return "tu_idct_add_kernel";
     if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) return "tu_4x4_kernel";
     (void)bit_depth;

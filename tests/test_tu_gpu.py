@@ -37,6 +37,40 @@ def test_idct_add_bit_exact(oracle, bd, log2):
         check_batch(oracle, bd, log2, po.TU_IDCT, nblk, amp, seed=bd * 100 + log2 * 10 + nblk)
 
 
+@pytest.fixture(params=[0, 512, 1024, 1536])
+def mfma_variant(request):
+    """32x32 blocks through the matrix-core kernel (ohevc_debug.h: bit 8 of the TU variant; bits 9 / 10 = its A/B forms)."""
+    from openhevc_amd import lib as L
+    lib = L.load_library()
+    old = lib.ohevc_debug_set_tu_variant(16 + 128 + 256 + request.param)
+    yield
+    lib.ohevc_debug_set_tu_variant(old)
+
+
+@pytest.mark.parametrize("bd", [8, 9, 10, 12])
+def test_idct32_matrix_core_form_bit_exact(oracle, mfma_variant, bd):
+    from openhevc_amd import lib as L
+    assert L.load_library().ohevc_tu_kernel_name(bd, 5, po.TU_IDCT) == b"tu_idct32_mfma_kernel"
+    for nblk, amp in [(1, 1024), (2, 1 << 15), (3, 1 << 15), (64, 1024), (257, 4096), (1000, 200), (40001, 1 << 15)]:
+        check_batch(oracle, bd, 5, po.TU_IDCT, nblk, amp, seed=bd * 1000 + nblk, per_row=7 if nblk < 5000 else 64)
+
+
+def test_idct32_matrix_core_form_extremes(oracle, mfma_variant):
+    import gpu_util as G
+    n = 32
+    pats = [np.full((n, n), 32767), np.full((n, n), -32768), np.where(np.indices((n, n)).sum(0) % 2, 32767, -32768), np.zeros((n, n)),
+            np.where(np.indices((n, n))[0] % 2, -32768, 32767), np.zeros((n, n)), np.zeros((n, n))]
+    pats[3][0, 0] = 32767; pats[5][31, 31] = -32768; pats[6][17, 5] = 255
+    coeffs = np.stack(pats).astype(np.int16)
+    for bd in (8, 10):
+        plane = np.random.default_rng(3).integers(0, 1 << bd, size=(n, len(pats) * n)).astype(G.pixdt(bd))
+        xy = grid_xy(len(pats), n, len(pats))
+        want = oracle.tu_batch(bd, po.TU_IDCT, 5, coeffs, plane.copy(), xy)
+        got = G.run_tu(bd, 5, po.TU_IDCT, [plane], G.make_tu_jobs(xy, n), coeffs)[0]
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (bd, len(bad), bad[:6].tolist())
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_idct_extreme_coefficients(oracle, bd):
     """All-max / all-min / alternating coefficients drive both clip_int16 stages and the pixel clip."""

@@ -38,7 +38,10 @@ def main():
 
     rounds = 8
     results = {}
-    for (log2, bd, nblk) in [(5, 8, 1 << 20), (5, 10, 1 << 20), (4, 8, 1 << 22), (3, 8, 1 << 24)]:
+    configs = [(5, 8, 1 << 20), (5, 10, 1 << 20), (4, 8, 1 << 22), (3, 8, 1 << 24)]
+    if len(sys.argv) > 2 and sys.argv[2] == "32":          # only the 32x32 configurations
+        configs = configs[:2]
+    for (log2, bd, nblk) in configs:
         n = 1 << log2
         plane0, coeffs, d_jobs = setup(log2, bd, nblk)
         st = torch.cuda.current_stream()
