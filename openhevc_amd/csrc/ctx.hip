@@ -238,22 +238,23 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
         fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms\n", (void *)c,
                 c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames);
     if (c->dry) { delete c; return; }
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    // teardown: an error here has nowhere to go
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
-        hipDeviceSynchronize();
+        (void)hipDeviceSynchronize();
         for (int i = 0; i < c->store->npics; i++) if (c->store->pics[i].used) free_picture(c->store->pics[i]);
     }
-    for (auto &e : c->ring) if (e) hipEventDestroy(e);
+    for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
     if (c->twin.used) free_picture(c->twin);
     if (c->lag.used) free_picture(c->lag);
-    if (c->d_jobs.p) hipFree(c->d_jobs.p);
-    if (c->d_coeffs.p) hipFree(c->d_coeffs.p);
-    if (c->d_table.p) hipFree(c->d_table.p);
-    if (c->d_upsample.p) hipFree(c->d_upsample.p);
-    if (c->stage.p) hipHostFree(c->stage.p);
-    if (c->staged) hipEventDestroy(c->staged);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->d_jobs.p) (void)hipFree(c->d_jobs.p);
+    if (c->d_coeffs.p) (void)hipFree(c->d_coeffs.p);
+    if (c->d_table.p) (void)hipFree(c->d_table.p);
+    if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
+    if (c->stage.p) (void)hipHostFree(c->stage.p);
+    if (c->staged) (void)hipEventDestroy(c->staged);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

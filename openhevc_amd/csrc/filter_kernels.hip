@@ -84,10 +84,15 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
 #undef ST
 }
 
+// One workgroup per SAO block.  Fast form (block width a multiple of 4 samples, dword-aligned rows - every block the decoder makes):
+// the (w + 2) x (h + 2) source window goes to LDS with dword loads (edge columns and the lagged samples patched in), every lane then
+// produces 4 neighbouring samples and stores them with one 4- / 8-byte access.  Anything else takes the sample-at-a-time form.
 template <typename Pixel>
 __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth,
                                                   ohevc_sao_bypass bp)
 {
+    constexpr int PXB = (int)sizeof(Pixel), PPD = 4 / PXB, OFF = 4, PITCH = 64 + 2 * OFF;     // window: x = -1 sits at column OFF - 1
+    __shared__ __attribute__((aligned(16))) Pixel win[66][PITCH];
     const ohevc_sao_job jb = jobs[blockIdx.x];
     const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
     const int ov0 = jb.offset_val[0], ov1 = jb.offset_val[1], ov2 = jb.offset_val[2], ov3 = jb.offset_val[3], ov4 = jb.offset_val[4];
@@ -113,17 +118,46 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
         const int xpu = ((bx + x) << b_hs) >> b_l2, ypu = ((by + y) << b_vs) >> b_l2;
         return xpu < b_xlim && ypu < b_ylim && (bx + x) - ((xpu << b_l2) >> b_hs) < b_len && bmap[(size_t)ypu * bp.stride + xpu] != 0;
     };
+    const bool fast = (w & 3) == 0 && w <= 64 && h <= 64 &&
+                      ((reinterpret_cast<uintptr_t>(sbase) | reinterpret_cast<uintptr_t>(dbase) | (unsigned)sstride | (unsigned)dstride) & 3) == 0;
 #define SRC(px_, py_) ((int)*reinterpret_cast<const Pixel *>(sbase + (ptrdiff_t)(clampi(by + (py_), ph - 1) - by) * sstride + \
                                                               (ptrdiff_t)(clampi(bx + (px_), pw - 1) - bx) * (int)sizeof(Pixel)))
+    const int quads = w >> 2;                         // fast form: 4 samples per lane and step
+    auto store4 = [&](int x0, int y, const int *v) {
+        if (sizeof(Pixel) == 1)
+            *reinterpret_cast<unsigned *>(dbase + (size_t)y * dstride + (size_t)x0) = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+        else
+            *reinterpret_cast<u32x2 *>(dbase + (size_t)y * dstride + (size_t)x0 * 2) = u32x2{ (unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16) };
+    };
     if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
         const int shift = bit_depth - 5;
-        for (int idx = threadIdx.x; idx < w * h; idx += 256) {
-            const int y = idx / w, x = idx - y * w;
-            const int c = SRC(x, y), k = ((c >> shift) - jb.klass) & 31;
+        auto band = [&](int c, int x, int y) {
+            const int k = ((c >> shift) - jb.klass) & 31;
             const int off = k == 0 ? ov1 : k == 1 ? ov2 : k == 2 ? ov3 : k == 3 ? ov4 : 0;
             int v = iclip(c + off, 0, maxv);
             if (bmap && bypassed(x, y)) v = c;
-            *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)v;
+            return v;
+        };
+        if (fast) {
+            for (int idx = threadIdx.x; idx < quads * h; idx += 256) {
+                const int y = idx / quads, x0 = (idx - y * quads) * 4;
+                int c[4], v[4];
+                if (sizeof(Pixel) == 1) {
+                    const unsigned raw = *reinterpret_cast<const unsigned *>(sbase + (size_t)y * sstride + (size_t)x0);
+                    c[0] = raw & 0xff; c[1] = (raw >> 8) & 0xff; c[2] = (raw >> 16) & 0xff; c[3] = raw >> 24;
+                } else {
+                    const u32x2 raw = *reinterpret_cast<const u32x2 *>(sbase + (size_t)y * sstride + (size_t)x0 * 2);
+                    c[0] = raw.x & 0xffff; c[1] = raw.x >> 16; c[2] = raw.y & 0xffff; c[3] = raw.y >> 16;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = band(c[e], x0 + e, y);
+                store4(x0, y, v);
+            }
+            return;
+        }
+        for (int idx = threadIdx.x; idx < w * h; idx += 256) {
+            const int y = idx / w, x = idx - y * w;
+            *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)band(SRC(x, y), x, y);
         }
         return;
     }
@@ -139,22 +173,17 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
     const bool lag_below = (jb.quirks & OHEVC_SAO_LAG_BELOW) != 0, lag_above = (jb.quirks & OHEVC_SAO_LAG_ABOVE) != 0;
     const bool lag_mid = (jb.quirks & OHEVC_SAO_LAG_MID) != 0;
     const bool lag_any = (lag_below || lag_above || lag_mid) && eo != 1 && bx + w < pw;
-    for (int idx = threadIdx.x; idx < w * h; idx += 256) {
-        const int y = idx / w, x = idx - y * w;
-        const int c = SRC(x, y);
-        int a = SRC(x + dxa, y + dya), b = SRC(x - dxa, y - dya);
-        if (lag_any && x == w - 1) {                        // samples the reference copies too early (ohevc_hip.h)
-            const unsigned char *lbase = PLANE_PTR3(lag, jb.plane) + (size_t)(bx + w) * sizeof(Pixel);
-            const int lstride = PLANE_STRIDE3(lag, jb.plane);
-            auto stale = [&](int ny) {
-                return by + ny >= 0 && by + ny < ph && ((lag_below && (ny == h - 1 || ny == h)) || (lag_above && (ny == -1 || ny == 0)) ||
-                                                     (lag_mid && (ny == 7 || ny == 8)));
-            };
-            if (dxa == 1 && stale(y + dya)) a = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y + dya) * lstride);
-            if (dxa == -1 && stale(y - dya)) b = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y - dya) * lstride);
-        }
-        const int s = (c > a) - (c < a) + (c > b) - (c < b);                      // -2..2
-        int off = s == -2 ? ov1 : s == -1 ? ov2 : s == 0 ? ov0 : s == 1 ? ov3 : ov4;  // offset_val[edge_idx[2 + s]], edge_idx = {1,2,0,3,4}
+    const unsigned char *lbase = PLANE_PTR3(lag, jb.plane) + (size_t)(bx + w) * sizeof(Pixel);
+    const int lstride = PLANE_STRIDE3(lag, jb.plane);
+    // samples of the column right of the block that the reference copies too early (ohevc_hip.h): rows ny of the block
+    auto stale = [&](int ny) {
+        return by + ny >= 0 && by + ny < ph && ((lag_below && (ny == h - 1 || ny == h)) || (lag_above && (ny == -1 || ny == 0)) ||
+                                             (lag_mid && (ny == 7 || ny == 8)));
+    };
+    // one output sample from its three inputs: everything the reference's border / restore rules say about position (x, y)
+    auto edge_px = [&](int c, int a, int b, int x, int y) {
+        const int s_ = (c > a) - (c < a) + (c > b) - (c < b);                      // -2..2
+        int off = s_ == -2 ? ov1 : s_ == -1 ? ov2 : s_ == 0 ? ov0 : s_ == 1 ? ov3 : ov4;  // offset_val[edge_idx[2 + s]], edge_idx = {1,2,0,3,4}
         const bool on_border = (eo != 1 && ((b0 && x == 0) || (b2 && x == w - 1))) ||
                                (eo != 0 && x >= init_x && x < w2 && ((b1 && y == 0) || (b3 && y == h - 1)));
         if (on_border) off = ov0;
@@ -169,7 +198,47 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
             if (r) v = c;
         }
         if (bmap && bypassed(x, y)) v = c;
-        *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)v;
+        return v;
+    };
+    if (fast) {
+        // ---- window rows -1 .. h (clamped to the plane), columns 0 .. w - 1 with dword loads ...
+        const int dpr = w / PPD;                          // dwords per row
+        for (int idx = threadIdx.x; idx < (h + 2) * dpr; idx += 256) {
+            const int r = idx / dpr, d = idx - r * dpr;
+            const int yy = clampi(by + r - 1, ph - 1) - by;
+            const unsigned raw = *reinterpret_cast<const unsigned *>(sbase + (ptrdiff_t)yy * sstride + (size_t)d * 4);
+            *reinterpret_cast<unsigned *>(&win[r][OFF + d * PPD]) = raw;
+        }
+        // ... and the columns left and right of the block sample by sample (clamped; the lagged ones from the early copy)
+        for (int idx = threadIdx.x; idx < (h + 2) * 2; idx += 256) {
+            const int r = idx >> 1, right = idx & 1, ny = r - 1;
+            const int x = right ? w : -1;
+            int v = SRC(x, ny);
+            if (right && lag_any && stale(ny)) v = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + ny) * lstride);
+            win[r][OFF + x] = (Pixel)v;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < quads * h; idx += 256) {
+            const int y = idx / quads, x0 = (idx - y * quads) * 4;
+            int v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int x = x0 + e;
+                v[e] = edge_px((int)win[y + 1][OFF + x], (int)win[y + 1 + dya][OFF + x + dxa], (int)win[y + 1 - dya][OFF + x - dxa], x, y);
+            }
+            store4(x0, y, v);
+        }
+        return;
+    }
+    for (int idx = threadIdx.x; idx < w * h; idx += 256) {
+        const int y = idx / w, x = idx - y * w;
+        const int c = SRC(x, y);
+        int a = SRC(x + dxa, y + dya), b = SRC(x - dxa, y - dya);
+        if (lag_any && x == w - 1) {
+            if (dxa == 1 && stale(y + dya)) a = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y + dya) * lstride);
+            if (dxa == -1 && stale(y - dya)) b = (int)*reinterpret_cast<const Pixel *>(lbase + (ptrdiff_t)(by + y - dya) * lstride);
+        }
+        *reinterpret_cast<Pixel *>(dbase + (size_t)y * dstride + (size_t)x * sizeof(Pixel)) = (Pixel)edge_px(c, a, b, x, y);
     }
 #undef SRC
 }
