@@ -26,7 +26,8 @@ int ohevc_debug_lds_tr16_probe(const void *addr, void *out, int nprobes, void *s
 /* bit 2 of the variant selects the persistent, software-pipelined kernel; this sets its grid size (workgroups). */
 int ohevc_debug_set_tu_pipe_workgroups(int n);
 /* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = 2 + both reference
- * windows staged before the first barrier (shipped) */
+ * windows staged before the first barrier (shipped).  Only 3 hands tiles with reference samples above the bit depth's range to the
+ * exact redo kernel; 1 and 2 are exact for samples that fit the bit depth. */
 int ohevc_debug_set_mc_variant(int variant);
 /* ctx executor for intra dependency levels: 0 (shipped) issues one prediction launch and one residual launch per level;
  * 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel
