@@ -82,6 +82,7 @@ struct LevelBins {
 }  // namespace
 
 static std::atomic<uint64_t> g_ctx_gen{1};
+void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_level_launch = 0;        // ohevc_debug_set_level_launch: 0 = two launches per level (shipped), 1 = all intra levels in one launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
@@ -254,7 +255,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
     if (c->stage.p) (void)hipHostFree(c->stage.p);
     if (c->staged) (void)hipEventDestroy(c->staged);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
 }
 

@@ -606,6 +606,18 @@ int wild_scratch(hipStream_t st, int njobs, unsigned short **out)
 }
 }  // namespace
 
+// a stream is going away (ohevc_ctx_destroy): its mask buffer with it.  The caller has synchronised the stream.
+void ohevc_mc_forget_stream(void *stream)
+{
+    std::lock_guard<std::mutex> g(g_wild_m);
+    for (size_t i = 0; i < g_wild.size(); i++)
+        if (g_wild[i].stream == static_cast<hipStream_t>(stream)) {
+            if (g_wild[i].buf) (void)hipFree(g_wild[i].buf);
+            g_wild.erase(g_wild.begin() + (long)i);
+            break;
+        }
+}
+
 static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
                      const ohevc_mc_job *jobs, int njobs, void *stream, bool small)
 {
