@@ -34,7 +34,13 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
     unsigned char *pix = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
     const int maxv = (1 << bit_depth) - 1;
 #define LD(i) ((int)*reinterpret_cast<const Pixel *>(pix + (ptrdiff_t)(i) * xs))
-#define ST(i, v) (*reinterpret_cast<Pixel *>(pix + (ptrdiff_t)(i) * xs) = (Pixel)(v))
+    // Vertical luma edges: the 8 samples across the edge are 8 / 16 contiguous bytes of one row - one vector load, one vector store
+    // (samples -4 and +3 are written back unchanged: no other edge of the vertical pass writes within 4 samples of this one).
+    // Horizontal edges and chroma go sample by sample (along a horizontal edge the lanes of a job are neighbours in memory anyway).
+    const bool vec = vertical && jplane == 0 && ((reinterpret_cast<uintptr_t>(pix) - 4 * sizeof(Pixel)) & 3) == 0;
+    int vv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool dirty = false;
+#define ST(i, v) do { if (vec) { vv[(i) + 4] = (v); dirty = true; } else *reinterpret_cast<Pixel *>(pix + (ptrdiff_t)(i) * xs) = (Pixel)(v); } while (0)
     const int tc = tc_in << (bit_depth - 8);
     if (jplane != 0) {                                // hevc_loop_filter_chroma, :1725-1757
         if (tc <= 0) return;
@@ -46,7 +52,30 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
     }
     // hevc_loop_filter_luma, :1629-1723
     const int beta = beta_in << (bit_depth - 8);
-    const int p3 = LD(-4), p2 = LD(-3), p1 = LD(-2), p0 = LD(-1), q0 = LD(0), q1 = LD(1), q2 = LD(2), q3 = LD(3);
+    if (vec) {
+        if (sizeof(Pixel) == 1) {
+            const u32x2 raw = *reinterpret_cast<const u32x2 *>(pix - 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { vv[k] = (raw.x >> (8 * k)) & 0xff; vv[4 + k] = (raw.y >> (8 * k)) & 0xff; }
+        } else {
+            const u32x4 raw = *reinterpret_cast<const u32x4 *>(pix - 8);
+            vv[0] = raw.x & 0xffff; vv[1] = raw.x >> 16; vv[2] = raw.y & 0xffff; vv[3] = raw.y >> 16;
+            vv[4] = raw.z & 0xffff; vv[5] = raw.z >> 16; vv[6] = raw.w & 0xffff; vv[7] = raw.w >> 16;
+        }
+    }
+    const int p3 = vec ? vv[0] : LD(-4), p2 = vec ? vv[1] : LD(-3), p1 = vec ? vv[2] : LD(-2), p0 = vec ? vv[3] : LD(-1);
+    const int q0 = vec ? vv[4] : LD(0), q1 = vec ? vv[5] : LD(1), q2 = vec ? vv[6] : LD(2), q3 = vec ? vv[7] : LD(3);
+    // (every exit below is taken by whole segments or writes nothing; the vector store sits in flush())
+    auto flush = [&]() {
+        if (!vec || !dirty) return;
+        constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;        // the (Pixel) cast of the sample-wise stores
+        if (sizeof(Pixel) == 1)
+            *reinterpret_cast<u32x2 *>(pix - 4) = u32x2{ (vv[0] & M) | ((vv[1] & M) << 8) | ((vv[2] & M) << 16) | ((vv[3] & M) << 24),
+                                                         (vv[4] & M) | ((vv[5] & M) << 8) | ((vv[6] & M) << 16) | ((vv[7] & M) << 24) };
+        else
+            *reinterpret_cast<u32x4 *>(pix - 8) = u32x4{ (vv[0] & M) | ((vv[1] & M) << 16), (vv[2] & M) | ((vv[3] & M) << 16),
+                                                         (vv[4] & M) | ((vv[5] & M) << 16), (vv[6] & M) | ((vv[7] & M) << 16) };
+    };
     const int dp = iabs(p2 - 2 * p1 + p0), dq = iabs(q2 - 2 * q1 + q0);
     const int flat = iabs(p3 - p0) + iabs(q3 - q0), step = iabs(p0 - q0);
     const int l0 = (threadIdx.x & 63) & ~3, l3 = l0 | 3;        // lanes holding lines 0 and 3 of this segment
@@ -80,6 +109,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
         if (!no_p && two_p) ST(-2, iclip(p1 + iclip((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc_2, tc_2), 0, maxv));
         if (!no_q && two_q) ST(1, iclip(q1 + iclip((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2), 0, maxv));
     }
+    flush();
 #undef LD
 #undef ST
 }
