@@ -225,6 +225,7 @@ class StreamParams:
     log2_max_ts: int = 2         # PPS range extension: log2_max_transform_skip_block_size (rext + transform_skip)
     sao_offset_scale: Tuple[int, int] = (0, 0)   # PPS range extension: log2_sao_offset_scale_{luma,chroma} <= bit_depth - 10
     rext: int = 0                # range-extension SPS flags (implicit/explicit rdpcm, ts rotation/context, rice adaptation)
+    intra_smoothing_disabled: int = 0   # SPS range extension: no [1 2 1] / strong filtering of the intra reference samples (rext only)
     gop: str = "lowdelay_b"      # intra | lowdelay_p | lowdelay_b | random_access
     gop_size: int = 8
     nframes: int = 4
@@ -367,7 +368,7 @@ def write_sps(p: StreamParams) -> bytes:
         b.u(1, 1)                 # implicit_rdpcm_enabled
         b.u(1, 1)                 # explicit_rdpcm_enabled
         b.u(1, 0)                 # extended_precision_processing
-        b.u(1, 0)                 # intra_smoothing_disabled
+        b.u(1, p.intra_smoothing_disabled)
         b.u(1, 0)                 # high_precision_offsets
         b.u(1, 1)                 # persistent_rice_adaptation
         b.u(1, 0)                 # cabac_bypass_alignment

@@ -33,6 +33,8 @@ def random_params(rng):
     if rng.integers(0, 4) == 0:                      # RExt chroma formats
         kw["chroma_format"] = int(rng.choice([2, 3]))
         kw["rext"] = 1
+    if kw["rext"] and rng.integers(0, 3) == 0:
+        kw["intra_smoothing_disabled"] = 1
     if kw["rext"] and rng.integers(0, 2):            # PPS range extension
         kw["log2_max_ts"] = int(rng.integers(2, 6))
         if kw.get("chroma_format") == 3:
