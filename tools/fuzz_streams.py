@@ -26,6 +26,7 @@ def random_params(rng):
         loop_filter_across_slices=int(rng.integers(0, 2)), loop_filter_across_tiles=int(rng.integers(0, 2)),
         log2_parallel_merge_level=int(rng.integers(2, log2_ctb + 1)), max_merge_cand=int(rng.integers(1, 6)),
         rext=int(rng.integers(0, 5) == 0), tu_depth_inter=int(rng.integers(0, 3)), tu_depth_intra=int(rng.integers(0, 3)),
+        cb_qp_offset=int(rng.integers(-8, 9)), cr_qp_offset=int(rng.integers(-8, 9)),      # chroma tc of the deblocking filter (chroma_tc, hevc_filter.c:62-89)
     )
     if rng.integers(0, 4) == 0:
         kw["pcm"] = int(rng.integers(5, kw["bit_depth"] + 1))
