@@ -35,7 +35,7 @@ struct PicStore {
     std::mutex m;
     std::condition_variable cv;           // signalled when a picture's end_issued turns true
     Picture pics[kMaxPics];               // fixed array: pointers to entries stay valid while other threads allocate
-    int npics = 0;
+    std::atomic<int> npics{0};            // grows under `m`; read without it by every context of the store (get_pic)
     unsigned version = 0;                 // bumped whenever a slot's planes change (contexts re-upload their MC table)
 };
 
@@ -691,18 +691,23 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(job->x + n <= p->planes[pl].width && job->y + n <= p->planes[pl].height, "intra block outside plane");
     // dependency level = 1 + the highest level among the 4x4 cells this block may read (row above incl. corner and
     // above-right, column to the left incl. below-left): hevcpred_template.c:164-183
-    auto &lm = c->level_map[pl];
+    // With slice threads (ohevc_ctx_set_concurrent) the cells of a neighbouring tile / WPP row are written by another thread while
+    // this one looks at them.  Cells of blocks this block really reads were written before (the reference's own row / tile
+    // synchronisation orders them); the others belong to unavailable neighbours, whose samples the kernel never touches, so any
+    // value read there only makes the level higher than necessary.  Relaxed atomics keep those accesses well defined.
+    uint16_t *lm = c->level_map[pl].data();
+    auto ld = [&](size_t i) { return (int)__atomic_load_n(&lm[i], __ATOMIC_RELAXED); };
     int level = 0;
     const int cx0 = (job->x >> 2) - 1, cx1 = std::min(W - 1, (job->x + 2 * n - 1) >> 2);
     const int cy0 = (job->y >> 2) - 1, cy1 = std::min(H - 1, (job->y + 2 * n - 1) >> 2);
     if (cy0 >= 0)
-        for (int cx = std::max(cx0, 0); cx <= cx1; cx++) level = std::max(level, (int)lm[(size_t)cy0 * W + cx]);
+        for (int cx = std::max(cx0, 0); cx <= cx1; cx++) level = std::max(level, ld((size_t)cy0 * W + cx));
     if (cx0 >= 0)
-        for (int cy = std::max(cy0, 0); cy <= cy1; cy++) level = std::max(level, (int)lm[(size_t)cy * W + cx0]);
+        for (int cy = std::max(cy0, 0); cy <= cy1; cy++) level = std::max(level, ld((size_t)cy * W + cx0));
     level += 1;
     OHEVC_REQUIRE(level < 65535, "intra dependency chain too long");
     for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
-        for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) lm[(size_t)cy * W + cx] = (uint16_t)level;
+        for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) __atomic_store_n(&lm[(size_t)cy * W + cx], (uint16_t)level, __ATOMIC_RELAXED);
     if (trace_hit(pl, job->x, job->y, n, n))
         fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d level %d\n", c->cur, pl, job->x,
                 job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size, level);

@@ -46,17 +46,63 @@ struct HostPic {
     }
 };
 
+// A registry entry as other threads see it.  Writers (one at a time: Registry::m) bump `gen` to an odd value, store the fields,
+// bump it again; readers copy the fields and keep the copy only if `gen` was even and did not move (a seqlock: the table slots
+// look pictures up on every call and must not take a lock).  All accesses are atomic (relaxed: plain moves on x86).
+struct Entry {
+    std::atomic<uint32_t> gen{0};
+    HostPic v;
+    template <typename T> static T ld(const T &f) { return __atomic_load_n(&f, __ATOMIC_RELAXED); }
+    template <typename T> static void st(T &f, T x) { __atomic_store_n(&f, x, __ATOMIC_RELAXED); }
+    int slot() const { return ld(v.slot); }
+    bool snapshot(HostPic &out) const
+    {
+        for (int tries = 0; tries < 64; tries++) {
+            const uint32_t g = gen.load(std::memory_order_acquire);
+            if (g & 1) continue;                               // being rewritten
+            out.slot = ld(v.slot); out.bd = ld(v.bd); out.ps = ld(v.ps);
+            for (int c = 0; c < 3; c++) {
+                out.data[c] = ld(v.data[c]); out.linesize[c] = ld(v.linesize[c]); out.w[c] = ld(v.w[c]); out.h[c] = ld(v.h[c]);
+                out.bytes[c] = ld(v.bytes[c]); out.magic[c] = ld(v.magic[c]);
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (gen.load(std::memory_order_relaxed) == g) return out.slot >= 0;
+        }
+        return false;
+    }
+    void publish(const HostPic &src)                           // under Registry::m
+    {
+        const uint32_t g = gen.load(std::memory_order_relaxed);
+        gen.store(g + 1, std::memory_order_relaxed);
+        std::atomic_thread_fence(std::memory_order_release);
+        st(v.slot, src.slot); st(v.bd, src.bd); st(v.ps, src.ps);
+        for (int c = 0; c < 3; c++) {
+            st(v.data[c], src.data[c]); st(v.linesize[c], src.linesize[c]); st(v.w[c], src.w[c]); st(v.h[c], src.h[c]);
+            st(v.bytes[c], src.bytes[c]); st(v.magic[c], src.magic[c]);
+        }
+        gen.store(g + 2, std::memory_order_release);
+    }
+    void retire()                                              // under Registry::m: the picture is gone, the entry free
+    {
+        const uint32_t g = gen.load(std::memory_order_relaxed);
+        gen.store(g + 1, std::memory_order_relaxed);
+        std::atomic_thread_fence(std::memory_order_release);
+        st(v.slot, -1);
+        gen.store(g + 2, std::memory_order_release);
+    }
+};
+
 // host-buffer registry: common to all contexts sharing one picture store (frame threads resolve MC source pointers into
-// pictures other threads registered).  Readers take no lock: entries are written before `n` grows and only flip `slot`.
+// pictures other threads registered).  Readers take no lock (Entry); writers hold `m`.
 struct Registry {
     std::mutex m;
-    HostPic pics[128];
+    Entry pics[128];
     std::atomic<int> n{0};
 };
 
 struct TablesState {
     std::shared_ptr<Registry> reg;
-    HostPic *pics = nullptr;          // = reg->pics
+    Entry *pics = nullptr;            // = reg->pics
     int npics() const { return reg->n.load(std::memory_order_acquire); }
     int cur = -1;                     // index into pics
     int status = OHEVC_OK;
@@ -114,7 +160,7 @@ struct Guard {
     ~Guard() { if (s) s->spin.clear(std::memory_order_release); }
 };
 
-struct Loc { int pic = -1, plane = 0, x = 0, y = 0; };
+struct Loc { int pic = -1, slot = -1, plane = 0, x = 0, y = 0; };     // registry entry, picture-store slot, position
 
 // OHEVC_PROFILE_SLOTS=1: cycle counters per slot family, printed by ohevc_tables_forget (host-side tuning aid)
 enum { K_TU, K_MC_HALF, K_MC, K_EMU, K_DBK, K_SAO, K_INTRA, K_PCM, K_END, K_NFAM };
@@ -150,22 +196,21 @@ thread_local int tl_hint[2] = { -1, -1 };      // the registry entries the last 
 bool locate(const uint8_t *p, Loc &out, int only_pic = -1)
 {
     if (!tl_state) return false;
+    HostPic hp;
     if (only_pic >= 0) {
-        const HostPic &hp = tl_state->pics[only_pic];
-        if (hp.slot < 0 || !locate_in(hp, p, out)) return false;
-        out.pic = only_pic;
+        if (!tl_state->pics[only_pic].snapshot(hp) || !locate_in(hp, p, out)) return false;
+        out.pic = only_pic; out.slot = hp.slot;
         return true;
     }
     const int n = tl_state->npics();
     for (int h = 0; h < 2; h++) {
         const int i = tl_hint[h];
-        if (i >= 0 && i < n && tl_state->pics[i].slot >= 0 && locate_in(tl_state->pics[i], p, out)) { out.pic = i; return true; }
+        if (i >= 0 && i < n && tl_state->pics[i].snapshot(hp) && locate_in(hp, p, out)) { out.pic = i; out.slot = hp.slot; return true; }
     }
     for (int i = 0; i < n; i++) {
-        const HostPic &hp = tl_state->pics[i];
-        if (hp.slot < 0) continue;
+        if (tl_state->pics[i].slot() < 0 || !tl_state->pics[i].snapshot(hp)) continue;
         if (locate_in(hp, p, out)) {
-            out.pic = (int)i;
+            out.pic = (int)i; out.slot = hp.slot;
             tl_hint[1] = tl_hint[0]; tl_hint[0] = i;
             return true;
         }
@@ -225,13 +270,14 @@ void t_put_pcm(uint8_t *dst, ptrdiff_t, int width, int height, struct GetBitCont
     Prof prof_(K_PCM);
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
-    const HostPic &hp = tl_state->pics[tl_state->cur];
+    const HostPic &hp = tl_state->pics[tl_state->cur].v;      // this thread's own picture
     // square blocks, or the two-squares-tall chroma block of a 4:2:2 coding block (hls_pcm_sample, hevc.c:1613-1620)
-    if (!g_ref_put_pcm[hp.bd] || (height != width && height != 2 * width) || width < 4 || width > 32) { fail(OHEVC_ERR_STATE); return; }
+    auto ref_put_pcm = __atomic_load_n(&g_ref_put_pcm[hp.bd], __ATOMIC_RELAXED);
+    if (!ref_put_pcm || (height != width && height != 2 * width) || width < 4 || width > 32) { fail(OHEVC_ERR_STATE); return; }
     // the bit reader is the reference's: let its own put_pcm unpack into scratch, then ship the samples as square blocks
     uint16_t scratch16[32 * 64];
     uint8_t *scratch = reinterpret_cast<uint8_t *>(scratch16);
-    g_ref_put_pcm[hp.bd](scratch, (ptrdiff_t)width * hp.ps, width, height, gb, pcm_bit_depth);
+    ref_put_pcm(scratch, (ptrdiff_t)width * hp.ps, width, height, gb, pcm_bit_depth);
     int16_t samples[32 * 64];
     for (int i = 0; i < width * height; i++) samples[i] = hp.ps == 2 ? (int16_t)scratch16[i] : (int16_t)scratch[i];
     int log2 = 2;
@@ -255,8 +301,8 @@ void t_emulated_edge_mc(uint8_t *buf, const uint8_t *src, ptrdiff_t buf_linesize
     Pending::Emu &e = tl_pend.emu[k];
     e.buf = nullptr;
     for (int i = 0; i < tl_state->npics(); i++) {
-        const HostPic &hp = tl_state->pics[i];
-        if (hp.slot < 0) continue;
+        HostPic hp;
+        if (tl_state->pics[i].slot() < 0 || !tl_state->pics[i].snapshot(hp)) continue;
         for (int c = 0; c < 3; c++) {
             if (hp.data[c] && hp.linesize[c] == src_linesize &&
                 src - (ptrdiff_t)src_y * src_linesize - (ptrdiff_t)src_x * hp.ps == hp.data[c]) {
@@ -287,7 +333,7 @@ bool resolve_src(const uint8_t *src, int ps, int &slot, int &plane, int &sx, int
     }
     Loc l;
     if (!locate(src, l)) return false;
-    slot = tl_state->pics[l.pic].slot; plane = l.plane; sx = l.x; sy = l.y;
+    slot = l.slot; plane = l.plane; sx = l.x; sy = l.y;
     return true;
 }
 
@@ -295,7 +341,7 @@ void mc_first_half(int16_t *tmp, uint8_t *src, int mx, int my)
 {
     Prof prof_(K_MC_HALF);
     if (!tl_ctx || !tl_state || tl_state->cur < 0) { fail(OHEVC_ERR_STATE); return; }
-    const int ps = tl_state->pics[tl_state->cur].ps;
+    const int ps = tl_state->pics[tl_state->cur].v.ps;
     Pending &p = tl_pend;
     if (!resolve_src(src, ps, p.bi_slot, p.bi_plane, p.bi_sx, p.bi_sy)) { p.bi_tmp = nullptr; fail(OHEVC_ERR_STATE); return; }
     p.bi_tmp = tmp; p.bi_mx = mx; p.bi_my = my;
@@ -307,7 +353,7 @@ void mc_record(uint8_t *dst, uint8_t *src, const int16_t *src2, int height, int 
     Prof prof_(K_MC);
     Loc l;
     if (!tl_ctx || !locate_cur(dst, l)) { fail(OHEVC_ERR_STATE); return; }
-    const int ps = tl_state->pics[tl_state->cur].ps;
+    const int ps = tl_state->pics[tl_state->cur].v.ps;
     ohevc_mc_job j = {};
     j.x = (uint16_t)l.x; j.y = (uint16_t)l.y; j.w = (uint8_t)width; j.h = (uint8_t)height; j.plane = (uint8_t)l.plane;
     int slot, plane, sx, sy;
@@ -440,8 +486,8 @@ void t_up_h(int16_t *, ptrdiff_t, uint8_t *src, ptrdiff_t, int, int, int, int, i
     // src = plane + (bl_y - edge_top) * stride + bl_x - edge_left (+ shift): inside the plane except for the chroma rows, whose
     // first block starts at bl_y = -1 (the "- 4" of hevc_filter.c:1268,1280) -- accept a few rows of frame padding around the plane
     for (int i = 0; i < tl_state->npics() && tl_pend.up_bl_slot < 0; i++) {
-        const HostPic &hp = tl_state->pics[i];
-        if (hp.slot < 0) continue;
+        HostPic hp;
+        if (tl_state->pics[i].slot() < 0 || !tl_state->pics[i].snapshot(hp)) continue;
         for (int c = 0; c < 3; c++) {
             if (!hp.data[c]) continue;
             const ptrdiff_t margin = (ptrdiff_t)8 * hp.linesize[c], off = src - (hp.data[c] - margin);
@@ -475,7 +521,7 @@ void t_up_v(uint8_t *dst, ptrdiff_t, int16_t *, ptrdiff_t, int, int, int, int, i
     Loc l;
     // dst is the BASE of the inter-layer reference picture's plane (the slot adds the block position itself, :1905,1947)
     if (!tl_ctx || tl_pend.up_bl_slot < 0 || !locate(dst, l)) { fail(OHEVC_ERR_STATE); return; }
-    int rc = upsample_once(tl_state->pics[l.pic].slot, tl_pend.up_bl_slot, w, u, 1);
+    int rc = upsample_once(l.slot, tl_pend.up_bl_slot, w, u, 1);
     if (rc != OHEVC_OK) fail(rc);
 }
 
@@ -509,7 +555,8 @@ extern "C" int ohevc_tables_emulate_filter_lag(ohevc_ctx *ctx, int enable)
 extern "C" void ohevc_hevcdsp_init_hip(ohevc_HEVCDSPContext *c, int bit_depth)
 {
     if (!c) return;
-    if (bit_depth >= 8 && bit_depth < 15 && c->put_pcm && c->put_pcm != t_put_pcm) g_ref_put_pcm[bit_depth] = c->put_pcm;
+    // (every decoding thread fills its own table copy and lands here: the same pointer, stored atomically)
+    if (bit_depth >= 8 && bit_depth < 15 && c->put_pcm && c->put_pcm != t_put_pcm) __atomic_store_n(&g_ref_put_pcm[bit_depth], c->put_pcm, __ATOMIC_RELAXED);
     c->put_pcm = t_put_pcm;
     c->transform_add[0] = t_transform_add<2>; c->transform_add[1] = t_transform_add<3>;
     c->transform_add[2] = t_transform_add<4>; c->transform_add[3] = t_transform_add<5>;
@@ -560,7 +607,7 @@ extern "C" int ohevc_tables_upsample_frame(const uint8_t *el_data0, const uint8_
 {
     Loc le, lb;
     if (!tl_ctx || !w || !u || !locate(el_data0, le) || !locate(bl_data0, lb)) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
-    int rc = upsample_once(tl_state->pics[le.pic].slot, tl_state->pics[lb.pic].slot, w, u, 0);
+    int rc = upsample_once(le.slot, lb.slot, w, u, 0);
     if (rc != OHEVC_OK) fail(rc);
     return rc;
 }
@@ -569,11 +616,12 @@ extern "C" int ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[
 {
     TablesState *s = state_of(ctx, false);
     if (!s || !data || !linesize) return OHEVC_ERR_ARG;
-    for (int i = 0; i < s->npics(); i++)
-        if (s->pics[i].slot == slot) {
-            for (int c = 0; c < 3; c++) { data[c] = s->pics[i].data[c]; linesize[c] = s->pics[i].linesize[c]; }
-            return OHEVC_OK;
-        }
+    for (int i = 0; i < s->npics(); i++) {
+        HostPic hp;
+        if (s->pics[i].slot() != slot || !s->pics[i].snapshot(hp) || hp.slot != slot) continue;
+        for (int c = 0; c < 3; c++) { data[c] = hp.data[c]; linesize[c] = hp.linesize[c]; }
+        return OHEVC_OK;
+    }
     return OHEVC_ERR_STATE;
 }
 
@@ -614,21 +662,23 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
     // whose buffers went back to the decoder's pool (the pools are per plane, so luma/chroma pairs get re-mixed, and the
     // plane's start inside a recycled buffer may differ by an alignment offset: compare ranges, not base pointers)
     for (int i = 0; i < n; i++) {
-        if (s->pics[i].slot < 0 || s->pics[i].slot == slot) continue;
+        const HostPic &o = s->pics[i].v;                 // writers are serialised by the lock: a plain view is consistent here
+        if (o.slot < 0 || o.slot == slot) continue;
+        bool dead = false;
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++)
-                if (s->pics[i].data[a] && hp.data[b] && s->pics[i].data[a] < hp.data[b] + hp.bytes[b] &&
-                    hp.data[b] < s->pics[i].data[a] + s->pics[i].bytes[a]) {
-                    if (trace) fprintf(stderr, "reg: slot %d takes plane %d of entry %d (slot %d, its plane %d)\n", slot, b, i, s->pics[i].slot, a);
-                    s->pics[i].slot = -1;
+                if (o.data[a] && hp.data[b] && o.data[a] < hp.data[b] + hp.bytes[b] && hp.data[b] < o.data[a] + o.bytes[a]) {
+                    if (trace) fprintf(stderr, "reg: slot %d takes plane %d of entry %d (slot %d, its plane %d)\n", slot, b, i, o.slot, a);
+                    dead = true;
                 }
+        if (dead) s->pics[i].retire();
     }
     s->upsampled.erase(std::remove(s->upsampled.begin(), s->upsampled.end(), slot), s->upsampled.end());
     if (trace) fprintf(stderr, "reg: slot %d = %p %p %p\n", slot, (void *)hp.data[0], (void *)hp.data[1], (void *)hp.data[2]);
-    for (int i = 0; i < n; i++) if (s->pics[i].slot == slot) { s->pics[i] = hp; return OHEVC_OK; }
-    for (int i = 0; i < n; i++) if (s->pics[i].slot < 0) { s->pics[i] = hp; return OHEVC_OK; }
+    for (int i = 0; i < n; i++) if (s->pics[i].v.slot == slot) { s->pics[i].publish(hp); return OHEVC_OK; }
+    for (int i = 0; i < n; i++) if (s->pics[i].v.slot < 0) { s->pics[i].publish(hp); return OHEVC_OK; }
     OHEVC_REQUIRE(n < 128, "too many registered pictures");
-    s->pics[n] = hp;
+    s->pics[n].publish(hp);
     s->reg->n.store(n + 1, std::memory_order_release);
     return OHEVC_OK;
 }
@@ -637,9 +687,10 @@ extern "C" int ohevc_tables_unregister_picture(ohevc_ctx *ctx, int slot)
 {
     TablesState *s = state_of(ctx, false);
     if (!s) return OHEVC_OK;
+    std::lock_guard<std::mutex> g(s->reg->m);
     for (int i = 0; i < s->npics(); i++)
-        if (s->pics[i].slot == slot) {
-            s->pics[i].slot = -1;
+        if (s->pics[i].v.slot == slot) {
+            s->pics[i].retire();
             if (s->cur == (int)i) s->cur = -1;
         }
     return OHEVC_OK;
@@ -651,7 +702,7 @@ extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
     TablesState *s = state_of(ctx, false);
     OHEVC_REQUIRE(s != nullptr, "no picture registered");
     s->cur = -1;
-    for (int i = 0; i < s->npics(); i++) if (s->pics[i].slot == slot) s->cur = (int)i;
+    for (int i = 0; i < s->npics(); i++) if (s->pics[i].slot() == slot) s->cur = (int)i;
     OHEVC_REQUIRE(s->cur >= 0, "picture not registered");
     s->status = OHEVC_OK;
     s->seq = 0;
@@ -672,7 +723,7 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     int rc;
     // a held SAO job saw, in the reference, the samples right of its block BEFORE a horizontal edge through them was
     // filtered iff that edge's table call came after the SAO call (ohevc_hip.h, OHEVC_SAO_LAG_*)
-    const HostPic &cur = s->pics[s->cur];
+    const HostPic &cur = s->pics[s->cur].v;
     for (auto &held : s->held_sao) {
         ohevc_sao_job &j = held.first;
         const int xr = j.x + j.w;
@@ -690,7 +741,7 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     rc = ohevc_frame_end(ctx);
     if (rc != OHEVC_OK) return rc;
     if (download) {
-        const HostPic &hp = s->pics[s->cur];
+        const HostPic &hp = s->pics[s->cur].v;
         for (int c = 0; c < 3; c++)
             if ((rc = ohevc_pic_download(ctx, hp.slot, c, hp.data[c], hp.linesize[c])) != OHEVC_OK) return rc;
     }
