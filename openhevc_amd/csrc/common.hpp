@@ -75,22 +75,11 @@ __device__ __forceinline__ int dot2_i16(unsigned a, unsigned b, int acc)
     return __builtin_amdgcn_sdot2(bitcast<s16x2>(a), bitcast<s16x2>(b), acc, false);
 }
 
-// first term of a dot-product chain: a.lo*k.lo + a.hi*k.hi with NO accumulator input (VOP3P form, src2 = inline 0),
-// so the chain needs no zero-initialising v_mov; the packed constant travels in an SGPR (s_mov on the scalar unit)
-__device__ __forceinline__ int dot2_i16_first(unsigned a, unsigned kconst)
-{
-    int r;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(kconst));
-    return r;
-}
-
-// {sat_u8(x.i16[0]), sat_u8(x.i16[1])} in the low 16 bits: v_sat_pk_u8_i16 (clamp to [0,255] and pack in one op)
-__device__ __forceinline__ unsigned sat_pack_u8_i16(unsigned x)
-{
-    unsigned r;
-    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
+// dot2_i16_first, sat_pack_u8_i16: the two helpers written as gfx950 instructions (found on the include path, so that the
+// host emulation used by the CPU tests can supply plain-C++ equivalents without touching this file)
+}  // namespace ohevc
+#include <ohevc_gfx950_ops.hpp>
+namespace ohevc {
 
 // {clip_int16(lo), clip_int16(hi)} packed: v_cvt_pk_i16_i32
 __device__ __forceinline__ unsigned sat_pack_i16(int lo, int hi)

@@ -1,0 +1,28 @@
+// ohevc_gfx950_ops.hpp -- helpers spelt as single gfx950 instructions (inline assembly).  Included by common.hpp.
+#pragma once
+
+namespace ohevc {
+
+// first term of a dot-product chain: a.lo*k.lo + a.hi*k.hi with NO accumulator input (VOP3P form, src2 = inline 0),
+// so the chain needs no zero-initialising v_mov; the packed constant travels in an SGPR (s_mov on the scalar unit)
+__device__ __forceinline__ int dot2_i16_first(unsigned a, unsigned kconst)
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(kconst));
+    return r;
+}
+
+// {sat_u8(x.i16[0]), sat_u8(x.i16[1])} in the low 16 bits: v_sat_pk_u8_i16 (clamp to [0,255] and pack in one op)
+__device__ __forceinline__ unsigned sat_pack_u8_i16(unsigned x)
+{
+    unsigned r;
+    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// acquire / release between workgroups of one XCD (they share an L2): drop what this CU's L1 holds; wait until this
+// wavefront's stores have left for the L2
+__device__ __forceinline__ void xcd_acquire() { asm volatile("buffer_inv sc1" ::: "memory"); }
+__device__ __forceinline__ void xcd_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+}  // namespace ohevc

@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
             const unsigned want = need[ph.step - 1];
             while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[LV_DONE + ph.step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (int)want)
                 __builtin_amdgcn_s_sleep(1);
-            asm volatile("buffer_inv sc1" ::: "memory");       // acquire inside the XCD: forget what this CU's L1 holds
+            xcd_acquire();                                     // acquire inside the XCD: forget what this CU's L1 holds
         }
         const int local = vwg - ph.first_wg;
         if (ph.type == 0) {                                    // intra prediction: one wavefront per block, four per workgroup
@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
         } else {
             tu_dispatch<Pixel>(lds, local, planes, tu_jobs + ph.first_job, ph.njobs, ph.log2_size, ph.kind, coeffs, bit_depth);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // release inside the XCD: this wavefront's stores sit in the shared L2 ...
+        xcd_release();                                         // release inside the XCD: this wavefront's stores sit in the shared L2 ...
         __syncthreads();                                       // (also: everyone has read s_ticket before wave 0 rewrites it)
         if (wave == 0) atomicAdd(&sync[LV_DONE + ph.step], lane == 0 ? 1u : 0u);   // ... before the step counter says so
     }

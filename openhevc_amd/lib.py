@@ -31,6 +31,19 @@ def build(verbose=False):
     subprocess.run(["make", "-C", os.path.join(HERE, "csrc")] + ([] if verbose else ["-s"]), check=True)
 
 
+def bind_prototypes(lib):
+    """Declare the result / argument types of the entry points that need them on a loaded libohevc_hip.so."""
+    lib.ohevc_last_error.restype = C.c_char_p
+    lib.ohevc_version.restype = C.c_char_p
+    lib.ohevc_tu_kernel_name.restype = C.c_char_p
+    lib.ohevc_tu_kernel_name.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.ohevc_device_count.restype = C.c_int
+    lib.ohevc_set_device.argtypes = [C.c_int]
+    lib.ohevc_dev_tu_batch.restype = C.c_int
+    lib.ohevc_dev_tu_batch.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
 _lib = None
 
 
@@ -45,15 +58,7 @@ def load_library():
     import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise OhevcError(f"{LIB_PATH} is missing: run `make -C openhevc_amd/csrc` (or __graft_entry__.build()) first")
-    lib = C.CDLL(LIB_PATH)
-    lib.ohevc_last_error.restype = C.c_char_p
-    lib.ohevc_version.restype = C.c_char_p
-    lib.ohevc_tu_kernel_name.restype = C.c_char_p
-    lib.ohevc_tu_kernel_name.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.ohevc_device_count.restype = C.c_int
-    lib.ohevc_set_device.argtypes = [C.c_int]
-    lib.ohevc_dev_tu_batch.restype = C.c_int
-    lib.ohevc_dev_tu_batch.argtypes = [C.POINTER(Plane), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib = bind_prototypes(C.CDLL(LIB_PATH))
     _lib = lib
     return lib
 

@@ -20,7 +20,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {"c": "_ref/libopenhevc_c.so", "gen": "_ref/libopenhevc_gen.so", "hip": "_ref/libopenhevc_hip.so",
-         "null": "_ref/libopenhevc_null.so"}
+         "null": "_ref/libopenhevc_null.so", "hipemu": "_ref/libopenhevc_hipemu.so"}
 _loaded = {}
 
 

@@ -1,8 +1,73 @@
-"""Helpers shared by the -m gpu parity tests: device buffers via torch, calls via the C ABI."""
+"""Helpers shared by the parity tests: device buffers via torch, calls via the C ABI.
+
+Two back-ends.  The default one is the real thing (-m gpu): CUDA tensors, libohevc_hip.so.  tests/test_hipemu_cpu.py switches to
+the kernel emulator (use_emulator()): "device" memory is host numpy memory and the library is tests/hipemu/libohevc_hip_emu.so, the
+same kernel sources compiled for the host - a check of the device code's arithmetic that needs no GPU (tests/hipemu/README.md)."""
+import ctypes as C
+import os
+
 import numpy as np
-import torch
 
 from openhevc_amd import lib as L
+
+_EMU = None
+
+
+class HostTensor:
+    """The few tensor methods the helpers use, over a numpy array (the emulator's device memory)."""
+
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a).copy()
+        self.shape = self.a.shape
+
+    def data_ptr(self):
+        return self.a.ctypes.data
+
+    def dim(self):
+        return self.a.ndim
+
+    def stride(self, i):
+        return self.a.strides[i] // self.a.itemsize
+
+    def element_size(self):
+        return self.a.itemsize
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        return self.a
+
+    def clone(self):
+        return HostTensor(self.a)
+
+
+def emulator_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", "libohevc_hip_emu.so")
+
+
+def use_emulator(on=True):
+    """Point openhevc_amd.lib at the emulator library (tests only; the product never does this).  Returns the previous library."""
+    global _EMU
+    prev = L._lib
+    if on:
+        _EMU = _EMU or L.bind_prototypes(C.CDLL(emulator_path()))
+        L._lib = _EMU
+    return prev
+
+
+def emulating():
+    return _EMU is not None and L._lib is _EMU
+
+
+def sync():
+    if not emulating():
+        import torch
+        torch.cuda.synchronize()
+
+
+def zeros_dev(n, dtype):
+    return HostTensor(np.zeros(n, dtype)) if emulating() else to_dev(np.zeros(n, dtype))
 
 
 def pixdt(bd):
@@ -12,6 +77,9 @@ def pixdt(bd):
 def to_dev(a):
     """numpy -> CUDA tensor (uint16 goes through an int16 view: torch has no full uint16 support)."""
     a = np.ascontiguousarray(a)
+    if emulating():
+        return HostTensor(a.view(np.uint8) if a.dtype.fields is not None else a)
+    import torch
     if a.dtype == np.uint16:
         return torch.from_numpy(a.view(np.int16)).cuda()
     if a.dtype.fields is not None:
@@ -29,11 +97,11 @@ def run_tu(bd, log2, kind, planes_np, jobs, coeffs):
     d_planes = [to_dev(p) if p is not None else None for p in planes_np]
     while len(d_planes) < 3:
         d_planes.append(None)
-    d_jobs = to_dev(jobs) if len(jobs) else torch.zeros(16, dtype=torch.uint8, device="cuda")
-    d_coeffs = to_dev(np.ascontiguousarray(coeffs, dtype=np.int16).reshape(-1)) if coeffs is not None and coeffs.size else torch.zeros(8, dtype=torch.int16, device="cuda")
+    d_jobs = to_dev(jobs) if len(jobs) else zeros_dev(16, np.uint8)
+    d_coeffs = to_dev(np.ascontiguousarray(coeffs, dtype=np.int16).reshape(-1)) if coeffs is not None and coeffs.size else zeros_dev(8, np.int16)
     L.dev_tu_batch(L.planes_of(d_planes), bd, log2, kind, d_jobs.data_ptr(), len(jobs), d_coeffs.data_ptr(),
-                   torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+                   stream())
+    sync()
     return [to_host(t, p.dtype) if t is not None else None for t, p in zip(d_planes, planes_np + [None] * 3)]
 
 
@@ -56,4 +124,7 @@ def planes3(d_planes):
 
 
 def stream():
+    if emulating():
+        return 0
+    import torch
     return torch.cuda.current_stream().cuda_stream

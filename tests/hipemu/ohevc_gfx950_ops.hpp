@@ -1,0 +1,25 @@
+// ohevc_gfx950_ops.hpp of the TEST-ONLY host emulation: what the two single-instruction helpers of
+// openhevc_amd/csrc/ohevc_gfx950_ops.hpp compute, in plain C++ (this directory precedes csrc/ on the emulator's include path).
+#pragma once
+
+namespace ohevc {
+
+// v_dot2_i32_i16 with src2 = 0: a.lo * k.lo + a.hi * k.hi on signed 16-bit halves
+static inline int dot2_i16_first(unsigned a, unsigned kconst)
+{
+    return (int)(short)(a & 0xffff) * (int)(short)(kconst & 0xffff) + (int)(short)(a >> 16) * (int)(short)(kconst >> 16);
+}
+
+// v_sat_pk_u8_i16: both signed 16-bit halves clamped to [0, 255], packed into the low 16 bits
+static inline unsigned sat_pack_u8_i16(unsigned x)
+{
+    const int lo = (short)(x & 0xffff), hi = (short)(x >> 16);
+    const unsigned a = lo < 0 ? 0 : lo > 255 ? 255 : lo, b = hi < 0 ? 0 : hi > 255 ? 255 : hi;
+    return a | (b << 8);
+}
+
+// cache maintenance between workgroups: nothing to do on one coherent host memory
+static inline void xcd_acquire() {}
+static inline void xcd_release() {}
+
+}  // namespace ohevc

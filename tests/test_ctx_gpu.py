@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 def level_executor(request):
     """Both executors of the intra dependency levels (include/ohevc_debug.h) must give the same pictures."""
     import ctypes
+    if request.param == 1 and G.emulating():
+        pytest.skip("the persistent level kernel's workgroups wait for each other; the emulator runs them one after another")
     lib = L.load_library()
     lib.ohevc_debug_set_level_launch.argtypes = [ctypes.c_int]
     prev = lib.ohevc_debug_set_level_launch(request.param)

@@ -1,7 +1,6 @@
 """-m gpu parity tests of deblocking and SAO vs the CPU oracle."""
 import numpy as np
 import pytest
-import torch
 
 from openhevc_amd import lib as L
 import gpu_util as G
@@ -53,7 +52,7 @@ def test_deblock_vertical_then_horizontal(oracle, bd):
         d = [G.to_dev(p) for p in planes]
         d_jobs = G.to_dev(batch)
         L.dev_deblock_batch(G.planes3(d), bd, d_jobs.data_ptr(), len(batch), G.stream())
-        torch.cuda.synchronize()
+        G.sync()
         changed = 0
         for pl in range(3):
             got = G.to_host(d[pl], planes[pl].dtype)
@@ -105,7 +104,7 @@ def test_sao_band_and_edge(oracle, bd):
     d_src = [G.to_dev(p) for p in src]; d_dst = [G.to_dev(p) for p in dst]
     d_jobs = G.to_dev(batch)
     L.dev_sao_batch(G.planes3(d_dst), G.planes3(d_src), bd, d_jobs.data_ptr(), len(batch), G.stream())
-    torch.cuda.synchronize()
+    G.sync()
     for pl in range(3):
         got = G.to_host(d_dst[pl], dst[pl].dtype)
         bad = np.argwhere(got != want[pl])
@@ -156,7 +155,7 @@ def test_sao_bypass_map(oracle, bd, cfi, log2_pu, exact):
     d_jobs = G.to_dev(batch); d_map = G.to_dev(is_pcm)
     L.dev_sao_batch_bypass(G.planes3(d_dst), G.planes3(d_src), bd, d_jobs.data_ptr(), len(batch), d_map.data_ptr(), is_pcm.shape[1],
                            log2_pu, hs, vs, exact, G.stream())
-    torch.cuda.synchronize()
+    G.sync()
     for pl in range(3):
         got = G.to_host(d_dst[pl], dst[pl].dtype)
         bad = np.argwhere(got != want[pl])

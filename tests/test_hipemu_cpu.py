@@ -1,0 +1,109 @@
+"""The device code on the host: the -m gpu parity tests, re-run against tests/hipemu/libohevc_hip_emu.so.
+
+That library is the UNCHANGED kernel and launcher source of openhevc_amd/csrc/ compiled for x86-64 against an emulation of the HIP
+execution model (tests/hipemu/: lanes are fibers, barriers and wave collectives are scheduling points).  It checks the kernels'
+arithmetic and index algebra in `pytest -m "not gpu"`, where no GPU exists; it says nothing about speed, and the parity tests proper
+remain the -m gpu ones.  Test infrastructure only: nothing under openhevc_amd/ knows the emulator exists.
+"""
+import os
+import subprocess
+
+import pytest
+
+import gpu_util as G
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _build():
+    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(HERE, "hipemu")], capture_output=True, text=True)
+    return r.returncode == 0 and os.path.exists(G.emulator_path()), r.stderr[-2000:]
+
+
+_OK, _WHY = _build()
+pytestmark = pytest.mark.skipif(not _OK, reason="kernel emulator did not build: " + _WHY)
+
+
+@pytest.fixture(autouse=True)
+def emulator():
+    from openhevc_amd import lib as L
+    prev = G.use_emulator()
+    yield
+    L._lib = prev
+
+
+# tests that need the real device (full-size inputs generated on it, timing, spin-waits between workgroups)
+SKIP = {
+    "test_tu_gpu": {"test_full_size_batch_sampled_against_oracle"},
+}
+
+
+def _adopt(modname):
+    mod = __import__(modname)
+    for name, obj in vars(mod).items():
+        if name in SKIP.get(modname, ()):
+            continue
+        if name.startswith("test_") and callable(obj):
+            globals()["test_emu_" + modname[5:-4] + "_" + name[5:]] = obj
+        elif hasattr(obj, "_fixture_function_marker") or type(obj).__name__ == "FixtureFunctionDefinition":
+            globals()[name] = obj
+
+
+for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu").split():
+    _adopt(_m)
+
+
+# ---------------------------------------------------------------- the whole decoder over the emulated device code
+# oracle/_ref/libopenhevc_hipemu.so = the reference's decoder with the product's hooks (oracle/hip_hooks.c), linked against the
+# emulator library instead of libohevc_hip.so: parsing, recording, the ctx executor and every kernel, on the host.
+def _stream_lib():
+    from oracle import pystream as ps
+    if not ps.have("hipemu") and ps.have("hip"):
+        subprocess.run(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "hipemu"], capture_output=True)
+    return ps if ps.have("hipemu") else None
+
+
+def _golden_names():
+    from stream_cases import CASES
+    return sorted(CASES)
+
+
+@pytest.mark.parametrize("name", _golden_names())
+def test_emu_golden_stream(name):
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
+
+
+@pytest.mark.parametrize("threads,thread_type,names", [
+    (4, 1, ["ra_8b_ctb64", "ldb_10b", "weighted", "fmt444_8b"]),          # frame threads
+    (4, 2, ["wpp", "tiles", "slices_dep_wpp"]),                            # slice threads
+    (4, 3, ["wpp", "ra_8b_ctb64"]),                                        # both
+])
+def test_emu_golden_stream_thread_modes(threads, thread_type, names):
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    for name in names:
+        aus, md5 = load_golden(name)
+        assert frames_md5(ps.decode_stream("hipemu", aus, threads, thread_type)) == md5, name
+
+
+def test_emu_fuzzed_streams():
+    """tools/fuzz_streams.py for a few seconds with FUZZ_BACKEND=hipemu: random legal parameter sets, all thread modes."""
+    import json
+    import sys
+    from oracle import pystream as ps
+    if _stream_lib() is None or not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder / emulated decoder libraries not present")
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "12", "991"], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, FUZZ_BACKEND="hipemu"))
+    lines = r.stdout.strip().splitlines()
+    assert lines, r.stderr[-2000:]
+    res = json.loads(lines[-1])
+    assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 3, r.stdout[-3000:]

@@ -1,7 +1,6 @@
 """-m gpu parity tests of intra prediction (host job resolution + HIP kernel) vs the CPU oracle's intra_pred()."""
 import numpy as np
 import pytest
-import torch
 
 from openhevc_amd import lib as L
 import gpu_util as G
@@ -40,7 +39,7 @@ def test_intra_pred_random_calls(oracle, bd):
         d = [G.to_dev(p) for p in planes]
         d_jobs = G.to_dev(job)
         L.dev_intra_batch(G.planes3(d), bd, d_jobs.data_ptr(), 1, G.stream())
-        torch.cuda.synchronize()
+        G.sync()
         for pl in range(3):
             got = G.to_host(d[pl], planes[pl].dtype)
             assert np.array_equal(got, want[pl]), (it, log2, c_idx, mode, cands, x0, y0, cfi, strong, dis, ctb, pl)
@@ -67,7 +66,7 @@ def test_intra_batch_of_independent_blocks(oracle):
     d = [G.to_dev(p) for p in planes]
     d_jobs = G.to_dev(batch)
     L.dev_intra_batch(G.planes3(d), bd, d_jobs.data_ptr(), len(batch), G.stream())
-    torch.cuda.synchronize()
+    G.sync()
     assert np.array_equal(G.to_host(d[0], np.uint8), want[0])
 
 
@@ -106,7 +105,7 @@ def test_intra_pred_constrained(oracle, bd):
         d = [G.to_dev(p) for p in planes]
         d_jobs = G.to_dev(job); d_cip = G.to_dev(cip)
         L.dev_intra_batch_cip(G.planes3(d), bd, d_jobs.data_ptr(), 1, d_cip.data_ptr(), G.stream())
-        torch.cuda.synchronize()
+        G.sync()
         for pl in range(3):
             assert np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]), (it, log2, c_idx, mode, cands, x0, y0, lpu, pl)
 
@@ -144,7 +143,7 @@ def test_intra_pred_constrained_structured_maps(oracle, bd):
         d = [G.to_dev(p) for p in planes]
         d_jobs = G.to_dev(job); d_cip = G.to_dev(cip)
         L.dev_intra_batch_cip(G.planes3(d), bd, d_jobs.data_ptr(), 1, d_cip.data_ptr(), G.stream())
-        torch.cuda.synchronize()
+        G.sync()
         for pl in range(3):
             if not np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]):
                 bad.append((it, log2, c_idx, mode, cands, x0, y0, lpu, g, int(job["flags"][0]), int(job["flags2"][0])))

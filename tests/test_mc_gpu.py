@@ -1,7 +1,6 @@
 """-m gpu parity tests of motion compensation (qpel/epel x uni/bi/weighted, edge clamping) vs the CPU oracle."""
 import numpy as np
 import pytest
-import torch
 
 from oracle import pyoracle as po
 from openhevc_amd import lib as L
@@ -86,10 +85,10 @@ def test_mc_all_variants_and_edges(oracle, bd, wild):
             want[pl][j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]] = expected_block(oracle, bd, pl == 0, j, refs_padded)
         d_dst = [G.to_dev(p) for p in dst]
         d_refs = [[G.to_dev(p) for p in slot] for slot in refs]
-        d_table = torch.from_numpy(L.planes_table(d_refs)).cuda()
+        d_table = G.to_dev(L.planes_table(d_refs))
         d_jobs = G.to_dev(batch)
         L.dev_mc_batch(G.planes3(d_dst), d_table.data_ptr(), nslots, bd, d_jobs.data_ptr(), len(batch), G.stream())
-        torch.cuda.synchronize()
+        G.sync()
         for pl in range(3):
             got = G.to_host(d_dst[pl], dst[pl].dtype)
             bad = np.argwhere(got != want[pl])
@@ -138,10 +137,10 @@ def test_mc_small_blocks_four_per_wave(oracle, bd, wild):
             want[pl][j["y"]:j["y"] + j["h"], j["x"]:j["x"] + j["w"]] = expected_block(oracle, bd, pl == 0, j, refs_padded)
         d_dst = [G.to_dev(p) for p in dst]
         d_refs = [[G.to_dev(p) for p in slot] for slot in refs]
-        d_table = torch.from_numpy(L.planes_table(d_refs)).cuda()
+        d_table = G.to_dev(L.planes_table(d_refs))
         d_jobs = G.to_dev(batch)
         L.dev_mc_batch_small(G.planes3(d_dst), d_table.data_ptr(), 2, bd, d_jobs.data_ptr(), len(batch), G.stream())
-        torch.cuda.synchronize()
+        G.sync()
         for pl in range(3):
             got = G.to_host(d_dst[pl], dst[pl].dtype)
             bad = np.argwhere(got != want[pl])

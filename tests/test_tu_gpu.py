@@ -49,10 +49,11 @@ def mfma_variant(request):
 
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_idct32_matrix_core_form_bit_exact(oracle, mfma_variant, bd):
+    import gpu_util as G
     from openhevc_amd import lib as L
     assert L.load_library().ohevc_tu_kernel_name(bd, 5, po.TU_IDCT) == b"tu_idct32_mfma_kernel"
     # (the grid-stride loop of the kernel needs more block pairs than its 2048 x 4 waves to turn over: 20001 blocks, once)
-    for nblk, amp in [(1, 1024), (2, 1 << 15), (3, 1 << 15), (64, 1024), (257, 4096)] + ([(20001, 1 << 15)] if bd == 8 else []):
+    for nblk, amp in [(1, 1024), (2, 1 << 15), (3, 1 << 15), (64, 1024), (257, 4096)] + ([(20001, 1 << 15)] if bd == 8 and not G.emulating() else []):
         check_batch(oracle, bd, 5, po.TU_IDCT, nblk, amp, seed=bd * 1000 + nblk, per_row=7 if nblk < 5000 else 64)
 
 
@@ -216,7 +217,6 @@ def test_full_size_batch_sampled_against_oracle(oracle):
 def test_multi_segment_launch_equals_per_bin_launches(oracle):
     """ohevc_dev_tu_multi: a mix of sizes and kinds in one launch == the oracle applied bin by bin."""
     import ctypes as C
-    import torch
     import gpu_util as G
     from openhevc_amd import lib as L
     rng = np.random.default_rng(2024)
@@ -252,6 +252,6 @@ def test_multi_segment_launch_equals_per_bin_launches(oracle):
     sarr = (Seg * len(segs))(*[Seg(*s) for s in segs])
     d_plane, d_jobs, d_coeffs = G.to_dev(plane), G.to_dev(jobs), G.to_dev(coeffs)
     L.check(L.load_library().ohevc_dev_tu_multi(L.planes_of([d_plane, None, None]), bd, sarr, len(segs), C.c_void_p(d_jobs.data_ptr()),
-                                                C.c_void_p(d_coeffs.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    torch.cuda.synchronize()
+                                                C.c_void_p(d_coeffs.data_ptr()), C.c_void_p(G.stream())))
+    G.sync()
     assert np.array_equal(G.to_host(d_plane, np.uint16), want)

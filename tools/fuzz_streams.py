@@ -72,13 +72,17 @@ def random_params(rng):
     return kw
 
 
+# which build of the hooked decoder runs: "hip" = the GPU; "hipemu" = the same device code on the host emulator (tests/hipemu)
+BACKEND = os.environ.get("FUZZ_BACKEND", "hip")
+
+
 def job_counts(aus, threads, thread_type):
     """(pictures, ..., TU / MC / intra / edge / SAO jobs ...) the front-end recorded in one decode: the fingerprint of what it PARSED."""
     import ctypes as C
-    lib = ps._load("hip")
+    lib = ps._load(BACKEND)
     sec, cnt = C.c_double(), (C.c_longlong * 8)()
     lib.ohdec_backend_profile(C.byref(sec), cnt)         # reset
-    frames = ps.decode_stream("hip", aus, threads, thread_type)
+    frames = ps.decode_stream(BACKEND, aus, threads, thread_type)
     lib.ohdec_backend_profile(C.byref(sec), cnt)
     return frames, list(cnt)[2:7]
 
@@ -126,7 +130,7 @@ def main():
         if os.environ.get("FUZZ_VERBOSE"):
             print("TRY threads", threads, "type", thread_type, json.dumps(kw), flush=True)
         try:
-            hip = ps.decode_stream("hip", aus, threads, thread_type)
+            hip = ps.decode_stream(BACKEND, aus, threads, thread_type)
             ok = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
         except Exception as e:
             ok = False
