@@ -29,6 +29,10 @@ int ohevc_debug_set_tu_pipe_workgroups(int n);
  * windows staged before the first barrier (shipped).  Only 3 hands tiles with reference samples above the bit depth's range to the
  * exact redo kernel; 1 and 2 are exact for samples that fit the bit depth. */
 int ohevc_debug_set_mc_variant(int variant);
+/* SAO kernel: 0 = shipped; bit 0 = the edge classes split a block into its interior (short form: no border / restore predicate can
+ * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and
+ * tests); written after the round's GPU budget was spent, so the A/B on the device is the first thing to do with it. */
+int ohevc_debug_set_sao_variant(int variant);
 /* ctx executor for intra dependency levels: 0 (shipped) issues one prediction launch and one residual launch per level;
  * 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel
  * step barriers).  Same results.  Measured on MI355X with the real decoder (1080p, profiles/r01n_level_executor_ab.txt):

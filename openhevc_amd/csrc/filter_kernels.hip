@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
 // One workgroup per SAO block.  Fast form (block width a multiple of 4 samples, dword-aligned rows - every block the decoder makes):
 // the (w + 2) x (h + 2) source window goes to LDS with dword loads (edge columns and the lagged samples patched in), every lane then
 // produces 4 neighbouring samples and stores them with one 4- / 8-byte access.  Anything else takes the sample-at-a-time form.
-template <typename Pixel>
+// SPLIT (ohevc_debug_set_sao_variant(1); A/B pending): the edge classes run the block's interior - samples no border / restore rule can
+// touch - through a short form, and the outer ring (rows 0, h-2, h-1; the first and last quad of every row) through the full one,
+// enumerated so that all but one wavefront take a single form.
+template <typename Pixel, bool SPLIT>
 __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth,
                                                   ohevc_sao_bypass bp)
 {
@@ -248,6 +251,43 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
             win[r][OFF + x] = (Pixel)v;
         }
         __syncthreads();
+        if (SPLIT && quads >= 3 && h >= 4) {
+            // Which samples can a position rule touch?  x in {0, w-1, w2-1} with w2 in {w-1, w}; y in {0, h-1, h2-1} with h2 in {h-1, h}
+            // (on_border and every term of the restore test name one of them): none inside x in [4, w-5], y in [1, h-3].
+            const int iq = quads - 2, ih = h - 3, n_int = iq * ih, n_all = n_int + 3 * quads + 2 * ih;
+            for (int idx = threadIdx.x; idx < n_all; idx += 256) {
+                int v[4], x0, y;
+                if (idx < n_int) {
+                    const int r = idx / iq;
+                    y = 1 + r; x0 = 4 * (1 + idx - r * iq);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int x = x0 + e;
+                        const int c = (int)win[y + 1][OFF + x], a = (int)win[y + 1 + dya][OFF + x + dxa], b = (int)win[y + 1 - dya][OFF + x - dxa];
+                        const int s_ = (c > a) - (c < a) + (c > b) - (c < b);
+                        const int off = s_ == -2 ? ov1 : s_ == -1 ? ov2 : s_ == 0 ? ov0 : s_ == 1 ? ov3 : ov4;
+                        v[e] = iclip(c + off, 0, maxv);
+                        if (bmap && bypassed(x, y)) v[e] = c;
+                    }
+                } else {
+                    const int k = idx - n_int;
+                    if (k < 3 * quads) {
+                        const int r = k / quads;
+                        y = r == 0 ? 0 : h - 3 + r; x0 = 4 * (k - r * quads);
+                    } else {
+                        const int k2 = k - 3 * quads;
+                        y = 1 + (k2 >> 1); x0 = (k2 & 1) ? w - 4 : 0;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int x = x0 + e;
+                        v[e] = edge_px((int)win[y + 1][OFF + x], (int)win[y + 1 + dya][OFF + x + dxa], (int)win[y + 1 - dya][OFF + x - dxa], x, y);
+                    }
+                }
+                store4(x0, y, v);
+            }
+            return;
+        }
         for (int idx = threadIdx.x; idx < quads * h; idx += 256) {
             const int y = idx / quads, x0 = (idx - y * quads) * 4;
             int v[4];
@@ -273,7 +313,15 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
 #undef SRC
 }
 
+int g_sao_variant = 0;     // ohevc_debug_set_sao_variant
 }  // namespace ohevc
+
+extern "C" int ohevc_debug_set_sao_variant(int variant)
+{
+    const int old = ohevc::g_sao_variant;
+    ohevc::g_sao_variant = variant;
+    return old;
+}
 
 extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_job *jobs, int njobs, void *stream)
 {
@@ -317,8 +365,13 @@ extern "C" int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_
     rc = make_plane_set(lagged, plag, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
-    else                hipLaunchKernelGGL((sao_kernel<uint16_t>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+    if (g_sao_variant & 1) {
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+        else                hipLaunchKernelGGL((sao_kernel<uint16_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+    } else {
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+        else                hipLaunchKernelGGL((sao_kernel<uint16_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+    }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

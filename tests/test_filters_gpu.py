@@ -63,8 +63,17 @@ def test_deblock_vertical_then_horizontal(oracle, bd):
         assert changed > 100, "test content did not trigger the filters"
 
 
+@pytest.fixture(params=[0, 1], ids=["shipped", "interior_ring_split"])
+def sao_variant(request):
+    """Both forms of the SAO kernel (include/ohevc_debug.h) must give the same samples."""
+    lib = L.load_library()
+    prev = lib.ohevc_debug_set_sao_variant(request.param)
+    yield request.param
+    lib.ohevc_debug_set_sao_variant(prev)
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
-def test_sao_band_and_edge(oracle, bd):
+def test_sao_band_and_edge(oracle, sao_variant, bd):
     rng = np.random.default_rng(800 + bd)
     H, W = 136, 208
     src = [np.ascontiguousarray(np.pad(rng.integers(0, 1 << bd, size=(h, w)).astype(G.pixdt(bd)), ((1, 1), (16, 16)), mode="edge"))
@@ -113,7 +122,7 @@ def test_sao_band_and_edge(oracle, bd):
 
 @pytest.mark.parametrize("exact", [1, 0])
 @pytest.mark.parametrize("bd,cfi,log2_pu", [(8, 1, 2), (10, 2, 3), (8, 3, 2), (10, 1, 2)])
-def test_sao_bypass_map(oracle, bd, cfi, log2_pu, exact):
+def test_sao_bypass_map(oracle, sao_variant, bd, cfi, log2_pu, exact):
     """SAO with the reference's is_pcm map (restore_tqb_pixels, hevc_filter.c:163-193): flagged min-PU blocks keep their
     deblocked samples, with the reference's half-CTB bound for subsampled chroma."""
     from oracle import pyoracle as po

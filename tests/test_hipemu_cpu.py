@@ -93,6 +93,23 @@ def test_emu_golden_stream_thread_modes(threads, thread_type, names):
         assert frames_md5(ps.decode_stream("hipemu", aus, threads, thread_type)) == md5, name
 
 
+def test_emu_golden_streams_with_kernel_variants():
+    """The non-default kernel forms (include/ohevc_debug.h) through whole streams: same pictures."""
+    import ctypes
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    lib = ctypes.CDLL(G.emulator_path())
+    prev = lib.ohevc_debug_set_sao_variant(1)
+    try:
+        for name in ["ra_8b_ctb64", "ldb_10b", "tiles", "slices", "tqb", "pcm_nolf_ctb16", "rext_12b_sao_scale", "fmt444_8b", "fmt422_8b"]:
+            aus, md5 = load_golden(name)
+            assert frames_md5(ps.decode_stream("hipemu", aus)) == md5, name
+    finally:
+        lib.ohevc_debug_set_sao_variant(prev)
+
+
 def test_emu_fuzzed_streams():
     """tools/fuzz_streams.py for a few seconds with FUZZ_BACKEND=hipemu: random legal parameter sets, all thread modes."""
     import json
