@@ -43,7 +43,9 @@ class HostTensor:
 
 
 def emulator_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", "libohevc_hip_emu.so")
+    """tests/hipemu/libohevc_hip_emu.so, or the AddressSanitizer build with HIPEMU_ASAN=1 (tests/hipemu/README.md)."""
+    name = "libohevc_hip_emu_asan.so" if os.environ.get("HIPEMU_ASAN") == "1" else "libohevc_hip_emu.so"
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", name)
 
 
 def use_emulator(on=True):

@@ -14,6 +14,15 @@
 #include <ucontext.h>
 #include <vector>
 
+// AddressSanitizer build (make SAN=1): tell the runtime about every stack switch
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+#endif
+#endif
+
 namespace hipemu {
 
 thread_local Lane g_lane;
@@ -26,6 +35,7 @@ struct Fiber {
     void      *stack = nullptr;
     int        state = DONE;
     unsigned   or_calls = 0;
+    void      *fake = nullptr;      // ASan's fake-stack handle while the fiber is switched out
 };
 
 struct Sched {
@@ -40,6 +50,9 @@ struct Sched {
     bool                         running = false;
     int                          or_acc[2] = { 0, 0 };
     unsigned                     spins = 0;
+    const void                  *main_bottom = nullptr;     // ASan: the scheduler's own stack, learnt at the first switch
+    size_t                       main_size = 0;
+    void                        *main_fake = nullptr;
 
     void ensure(int n)
     {
@@ -91,12 +104,21 @@ static void yield(int state)
     Sched &s = *g_sched;
     Fiber &f = s.fibers[s.cur];
     f.state = state;
+#ifdef HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(state == DONE ? nullptr : &f.fake, s.main_bottom, s.main_size);
+#endif
     swapcontext(&f.ctx, &s.main);
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(f.fake, &s.main_bottom, &s.main_size);
+#endif
 }
 
 static void fiber_entry()
 {
     Sched &s = *g_sched;
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &s.main_bottom, &s.main_size);
+#endif
     (*s.body)();
     yield(DONE);
     abort();     // a finished fiber is never resumed
@@ -127,7 +149,13 @@ static void run_block(Sched &s)
                     const int l = s.reverse ? hi - 1 - (li - lo) : li;
                     if (s.fibers[l].state == READY) {
                         set_lane(s, l);
+#ifdef HIPEMU_ASAN
+                        __sanitizer_start_switch_fiber(&s.main_fake, s.fibers[l].stack, kStackBytes);
+#endif
                         swapcontext(&s.main, &s.fibers[l].ctx);
+#ifdef HIPEMU_ASAN
+                        __sanitizer_finish_switch_fiber(s.main_fake, nullptr, nullptr);
+#endif
                     }
                 }
                 bool any = false;

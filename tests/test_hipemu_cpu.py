@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _build():
-    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(HERE, "hipemu")], capture_output=True, text=True)
+    r = subprocess.run(["make", "-s", "-j8", "-C", os.path.join(HERE, "hipemu")] + (["SAN=1"] if os.environ.get("HIPEMU_ASAN") == "1" else []),
+                       capture_output=True, text=True)
     return r.returncode == 0 and os.path.exists(G.emulator_path()), r.stderr[-2000:]
 
 
