@@ -17,13 +17,17 @@ W, H = 3840, 2160
 PEAK = 8000.0
 # --planes N stacks N 4K pictures vertically into one plane per launch: a single 4K plane is 10-60 us of work for this GPU, i.e.
 # mostly launch latency; N = 8 shows what the kernels sustain.  --only SUBSTR keeps the kernels whose name contains SUBSTR.
+# --sao-variant V selects the SAO kernel's form (include/ohevc_debug.h: 0 shipped, 1 interior / ring split) and tags the rows.
 PLANES = 1
 ONLY = None
+SAO_VARIANT = None
 for i, a in enumerate(sys.argv):
     if a == "--planes":
         PLANES = int(sys.argv[i + 1])
     if a == "--only":
         ONLY = sys.argv[i + 1]
+    if a == "--sao-variant":
+        SAO_VARIANT = int(sys.argv[i + 1])
 H *= PLANES
 
 
@@ -63,6 +67,8 @@ def wanted(name):
 def report(name, ms, pixels, alg_bytes, out):
     if PLANES > 1:
         name += f" [x{PLANES} pictures per launch]"
+    if SAO_VARIANT is not None and "sao" in name:
+        name += f" [sao variant {SAO_VARIANT}]"
     if ms is None:
         return
     gbs = alg_bytes / ms / 1e6
@@ -74,6 +80,8 @@ def report(name, ms, pixels, alg_bytes, out):
 
 def main():
     L.load_library()
+    if SAO_VARIANT is not None:
+        L.load_library().ohevc_debug_set_sao_variant(SAO_VARIANT)
     g = torch.Generator(device="cuda").manual_seed(7)
     rng = np.random.default_rng(7)
     st = lambda: torch.cuda.current_stream().cuda_stream
