@@ -74,6 +74,14 @@ def random_params(rng):
 
 # which build of the hooked decoder runs: "hip" = the GPU; "hipemu" = the same device code on the host emulator (tests/hipemu)
 BACKEND = os.environ.get("FUZZ_BACKEND", "hip")
+# FUZZ_SAO_VARIANT=1: run every stream with the SAO kernel's interior / ring form (include/ohevc_debug.h).  The switch lives in the
+# kernel library the hooked decoder is linked against, so it is set through that same shared object.
+if os.environ.get("FUZZ_SAO_VARIANT"):
+    import ctypes as _C
+    _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _klib = {"hip": "openhevc_amd/libohevc_hip.so", "hipemu": "tests/hipemu/libohevc_hip_emu.so",
+             "hipemu_asan": "tests/hipemu/libohevc_hip_emu_asan.so"}[BACKEND]
+    _C.CDLL(os.path.join(_root, _klib), mode=_C.RTLD_GLOBAL).ohevc_debug_set_sao_variant(int(os.environ["FUZZ_SAO_VARIANT"]))
 
 
 def job_counts(aus, threads, thread_type):
