@@ -1,15 +1,18 @@
 /*
- * oracle/hip_hooks.c -- TEST INFRASTRUCTURE ONLY: INTEGRATION.md applied to the real reference decoder.
+ * integration/hip_hooks.c -- the reference-side half of the drop-in: INTEGRATION.md as code.
  *
- * _ref/libopenhevc_hip.so is the reference's full decoder, every source compiled in place and unmodified, with ONE
- * translation unit (libavcodec/hevc.c) compiled with four call-site renames (-Dff_hevc_dsp_init=ohhip_hevc_dsp_init
- * etc., oracle/Makefile) so that the calls at hevc.c:421-423 (table fill in set_sps) and hevc.c:3245
- * (ff_hevc_set_new_ref in hevc_frame_start) land here.  Each wrapper calls the reference's function and then the
- * libohevc_hip.so hook, i.e. exactly the patch INTEGRATION.md sections 1-3 describes, done at link time because
- * /root/reference is read-only.  The frame-end hook is called by oracle/decoder_harness.c after each access unit.
+ * This file is what a maintainer of openHEVC adds to the decoder (it includes the reference's own headers and is compiled
+ * with the reference's flags); together with libohevc_hip.so (include/ohevc_tables.h) it turns the CPU decoder into one
+ * whose every pixel is produced by the gfx950 kernels.  Because /root/reference is read-only, the patch is applied at LINK
+ * time instead of by editing sources: ONE translation unit (libavcodec/hevc.c) is compiled with call-site renames
+ * (-Dff_hevc_dsp_init=ohhip_hevc_dsp_init etc., integration/Makefile.inc) so that the calls at hevc.c:421-423 (table fill
+ * in set_sps), hevc.c:3245/3250 (ff_hevc_set_new_ref / ff_hevc_frame_rps in hevc_frame_start), hevc.c:4148 (right before
+ * the decoded-picture-hash check) ... land here.  Each wrapper calls the reference's function and then the libohevc_hip.so
+ * hook, i.e. exactly the patch INTEGRATION.md sections 1-3 describes.
  *
- * Everything the CPU front-end keeps doing (CABAC, MV/merge derivation, bS/tc/beta, SAO parameter parsing, DPB
- * management) is the reference's; every pixel is produced by the HIP kernels behind the recording tables.
+ * Links against libohevc_hip.so ONLY: no oracle, no CPU pixel path (`nm -u` of the resulting decoder shows no ohor_* /
+ * ohsw_* symbol; tests/test_abi_cpu.py checks that).  Everything the CPU front-end keeps doing (CABAC, MV/merge
+ * derivation, bS, SAO parameter parsing, DPB management) is the reference's.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,6 +26,7 @@
 
 #include "libavcodec/hevc.h"
 #include "libavcodec/thread.h"
+#include "libavutil/pixdesc.h"
 
 #include "ohevc_tables.h"
 #include "ohevc_debug.h"
@@ -48,12 +52,13 @@ static long long           g_counts[8];        /* frames, launches, tu, mc, intr
 static struct {
     const uint8_t *data0;
     int slot, w, h, bd, fmt;
+    int poc, seq;              /* the picture that lives in the buffer: HEVCFrame.poc / .sequence when it was registered */
     ohevc_ctx *ctx;            /* the context that is reconstructing (or last reconstructed) this picture */
 } g_bufs[MAX_BUFS];
 static int g_nbufs;
 
-void ohsw_sink(void *user, struct ohevc_ctx *ctx, int stage);      /* sw_exec.c */
-int  ohsw_error(void);
+int ohdec_backend_frame_done(void);
+int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
 
 static ohevc_ctx *thread_ctx(void)
 {
@@ -120,19 +125,11 @@ void ohhip_hevc_pred_init(HEVCPredContext *hpc, int bit_depth)
     hpc->intra_pred[3] = intra_pred_5;
 }
 
-/* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
-int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
+/* the picture-store slot of a host frame (allocated on first sight or when the geometry of the buffer changed).  `tag` names the
+ * picture that lives in the buffer now: poc + sequence counter.  Returns the g_bufs index with g_lock HELD, or -1 (unlocked). */
+static int slot_of_frame_locked(ohevc_ctx *ctx, const HEVCContext *s, const AVFrame *f, int *fresh)
 {
-    int ret = ff_hevc_set_new_ref(s, frame, poc);                   /* hevc_refs.c */
-    const AVFrame *f;
-    ohevc_ctx *ctx;
-    int i, slot = -1, cfmt;
-    if (ret < 0)
-        return ret;
-    if (!(ctx = thread_ctx()))
-        return AVERROR(ENOMEM);
-    f = s->ref->frame;
-    cfmt = s->sps->chroma_array_type ? s->sps->chroma_array_type : 1;
+    int i, slot, cfmt = s->sps->chroma_array_type ? s->sps->chroma_array_type : 1;
     pthread_mutex_lock(&g_lock);
     for (i = 0; i < g_nbufs; i++)
         if (g_bufs[i].data0 == f->data[0])
@@ -144,13 +141,14 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         g_bufs[i] = g_bufs[--g_nbufs];
         i = g_nbufs;
     }
+    *fresh = i == g_nbufs;
     if (i == g_nbufs) {
         slot = g_nbufs < MAX_BUFS ? ohevc_pic_alloc(ctx, s->sps->width, s->sps->height, cfmt, s->sps->bit_depth) : -1;
         if (slot < 0) {
             pthread_mutex_unlock(&g_lock);
             fprintf(stderr, "ohhip: pic_alloc failed: %s\n", ohevc_last_error());
             g_error = 1;
-            return AVERROR(ENOMEM);
+            return -1;
         }
         g_bufs[i].data0 = f->data[0];
         g_bufs[i].slot = slot;
@@ -158,10 +156,31 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         g_bufs[i].h = s->sps->height;
         g_bufs[i].bd = s->sps->bit_depth;
         g_bufs[i].fmt = cfmt;
+        g_bufs[i].poc = INT_MIN;
+        g_bufs[i].seq = -1;
         g_nbufs++;
     }
+    return i;
+}
+
+/* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
+int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
+{
+    int ret = ff_hevc_set_new_ref(s, frame, poc);                   /* hevc_refs.c */
+    const AVFrame *f;
+    ohevc_ctx *ctx;
+    int i, slot, fresh;
+    if (ret < 0)
+        return ret;
+    if (!(ctx = thread_ctx()))
+        return AVERROR(ENOMEM);
+    f = s->ref->frame;
+    if ((i = slot_of_frame_locked(ctx, s, f, &fresh)) < 0)
+        return AVERROR(ENOMEM);
     slot = g_bufs[i].slot;
     g_bufs[i].ctx = ctx;
+    g_bufs[i].poc = s->ref->poc;
+    g_bufs[i].seq = s->ref->sequence;
     pthread_mutex_unlock(&g_lock);
     /* slice threads: the WPP-row / tile workers of this picture all record into ctx (ohhip_cabac_init binds them) */
     ohevc_tables_set_concurrent(ctx, (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
@@ -174,6 +193,53 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     t_frame_open = 1;
     t_s = s;
     return 0;
+}
+
+/* INTEGRATION.md section 3, row generate_missing_ref.  ff_hevc_frame_rps (hevc_refs.c:637, called at hevc.c:3250 right after
+ * ff_hevc_set_new_ref) synthesises every reference picture the stream names but the DPB does not hold (a stream that starts at a
+ * CRA, lost pictures): generate_missing_ref (hevc_refs.c:538-598) allocates a frame and fills its HOST planes with mid-grey.  No
+ * table call and no frame_begin / frame_end ever touches such a picture, so its samples must be sent to the device here: every
+ * reference of the new picture whose buffer does not hold a picture this back-end reconstructed (other poc / sequence tag, or
+ * never seen) is registered and uploaded. */
+int ohhip_frame_rps(HEVCContext *s)
+{
+    int ret = ff_hevc_frame_rps(s);
+    ohevc_ctx *ctx;
+    int t, k, c;
+    if (ret < 0 || !s->ref)
+        return ret;
+    if (!(ctx = thread_ctx()))
+        return AVERROR(ENOMEM);
+    for (t = 0; t < NB_RPS_TYPE; t++)
+        for (k = 0; k < s->rps[t].nb_refs; k++) {
+            const HEVCFrame *ref = s->rps[t].ref[k];
+            int i, slot, fresh, known;
+            if (!ref || ref == s->ref || !ref->frame || !ref->frame->data[0])
+                continue;
+            if ((i = slot_of_frame_locked(ctx, s, ref->frame, &fresh)) < 0)
+                return AVERROR(ENOMEM);
+            known = !fresh && g_bufs[i].poc == ref->poc && g_bufs[i].seq == ref->sequence;
+            slot = g_bufs[i].slot;
+            if (!known) {
+                g_bufs[i].poc = ref->poc;
+                g_bufs[i].seq = ref->sequence;
+                g_bufs[i].ctx = ctx;
+            }
+            pthread_mutex_unlock(&g_lock);
+            if (known)
+                continue;
+            if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)ref->frame->data, ref->frame->linesize) != OHEVC_OK) {
+                g_error = 1;
+                return AVERROR(EINVAL);
+            }
+            for (c = 0; c < 3; c++)
+                if (ref->frame->data[c] && ohevc_pic_upload(ctx, slot, c, ref->frame->data[c], ref->frame->linesize[c]) != OHEVC_OK) {
+                    fprintf(stderr, "ohhip: upload of a generated reference picture failed: %s\n", ohevc_last_error());
+                    g_error = 1;
+                    return AVERROR(EINVAL);
+                }
+        }
+    return ret;
 }
 
 /* Slice threads.  The worker entry functions (hls_decode_entry_wpp / hls_decode_entry_tiles, hevc.c:2744-2920) run on pool
@@ -312,9 +378,10 @@ int ohdec_backend_open(void)
     }
     if (g_root)
         return 0;
-    ohevc_debug_set_record_only(getenv("OHHIP_RECORD_ONLY") != NULL || getenv("OHHIP_SW_EXEC") != NULL);
-    /* CPU-only host-logic tests: no device, the recorded jobs are executed by the oracle on the decoder's own frames (sw_exec.c) */
-    ohevc_debug_set_frame_sink(getenv("OHHIP_SW_EXEC") ? ohsw_sink : NULL, NULL);
+    /* host-side profiling / host-logic tests without a device (include/ohevc_debug.h): record, produce no pixels.  A test may
+     * have switched record-only mode on itself (and installed a frame sink) before opening the decoder: leave that alone. */
+    if (getenv("OHHIP_RECORD_ONLY"))
+        ohevc_debug_set_record_only(1);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
     g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
     if (getenv("OHHIP_LEVEL_LAUNCH"))
@@ -363,14 +430,27 @@ int ohdec_backend_frame_done(void)
     }
     if (st == OHEVC_OK)
         st = ohevc_tables_status(t_ctx);
-    if (st == OHEVC_OK && ohsw_error())
-        st = OHEVC_ERR_STATE;
     if (st != OHEVC_OK) {
         fprintf(stderr, "ohhip: frame failed (%d): %s\n", st, ohevc_last_error());
         g_error = 1;
         return -1;
     }
     return g_error ? -1 : 0;
+}
+
+/* INTEGRATION.md section 3, last row, one decoding thread: hevc_decode_frame checks the decoded-picture-hash SEI on the HOST planes
+ * right after decode_nal_units (hevc.c:4146-4162; `decode-checksum` option, libOpenHevcSetCheckMD5).  The frame-end hook belongs
+ * in front of that check; its first statement is the only av_pix_fmt_desc_get call of hevc.c that runs (hevc.c:4148), so that call
+ * site carries the hook here.  (With frame threads the frame has already ended in ohhip_report_progress.) */
+const AVPixFmtDescriptor *ohhip_pix_fmt_desc_get(enum AVPixelFormat pix_fmt)
+{
+    HEVCContext *s = t_s;
+    if (ohdec_backend_frame_done() < 0)
+        g_error = 1;
+    if (g_defer_download && s && s->ref && s->ref->frame)           /* the check reads the host planes now */
+        if (ohdec_backend_fetch_output(s->ref->frame->data, s->ref->frame->linesize) < 0)
+            g_error = 1;
+    return av_pix_fmt_desc_get(pix_fmt);
 }
 
 /* frame threads: decode_nal_units() ends with ff_thread_report_progress(&s->ref->tf, INT_MAX, 0) (hevc.c:4026-4027),

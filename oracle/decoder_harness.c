@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdarg.h>
 
 #include "libavcodec/avcodec.h"
 #include "libavutil/opt.h"
@@ -33,6 +34,18 @@ static int  ohdec_backend_frame_done(void) { return 0; }
 static void ohdec_backend_close(void) {}
 #endif
 
+/* the reference's own decoded-picture-hash check (hevc.c:4146-4162) reports through av_log only: count its two messages */
+static int g_md5_ok, g_md5_bad;
+static void log_counter(void *avcl, int level, const char *fmt, va_list vl)
+{
+    if (fmt && !strncmp(fmt, "Correct MD5", 11))
+        __sync_fetch_and_add(&g_md5_ok, 1);
+    else if (fmt && !strncmp(fmt, "Incorrect MD5", 13))
+        __sync_fetch_and_add(&g_md5_bad, 1);
+    if (level <= AV_LOG_ERROR && !(fmt && !strncmp(fmt, "Incorrect MD5", 13)))
+        av_log_default_callback(avcl, level, fmt, vl);
+}
+
 typedef struct ohdec {
     AVCodecContext *avctx;
     AVFrame        *frame;
@@ -43,7 +56,10 @@ typedef struct ohdec {
 } ohdec;
 
 /* thread_type: 1 frame threads, 2 slice/WPP threads, 3 both (the -f option of the reference's CLI, main_hm/getopt.c) */
-ohdec *ohdec_open(int threads, int thread_type)
+/* checksum: the reference's `decode-checksum` option, set BEFORE avcodec_open2 the way main_hm/main.c does (libOpenHevcSetCheckMD5
+ * between libOpenHevcInit and libOpenHevcStartDecoder, openHevcWrapper.c:429-440) so that frame-thread copies inherit it: every
+ * picture is verified against its decoded-picture-hash SEI (hevc.c:4146-4162) */
+ohdec *ohdec_open_ex(int threads, int thread_type, int checksum)
 {
     static int registered;
     ohdec *d = calloc(1, sizeof(*d));
@@ -67,6 +83,14 @@ ohdec *ohdec_open(int threads, int thread_type)
     av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type >= 3 ? "frameslice" : "frame", 0);
     d->threads = threads > 0 ? threads : 1;
     av_opt_set_int(d->avctx, "threads", d->threads, 0);
+    if (checksum) {
+        av_opt_set_int(d->avctx->priv_data, "decode-checksum", 1, 0);
+        g_md5_ok = g_md5_bad = 0;
+        av_log_set_level(AV_LOG_INFO);
+        av_log_set_callback(log_counter);
+    } else {
+        av_log_set_callback(av_log_default_callback);
+    }
     if (ohdec_backend_open() < 0)
         goto fail;
     if (avcodec_open2(d->avctx, codec, NULL) < 0)
@@ -79,6 +103,15 @@ fail:
         av_free(d->avctx);
     free(d);
     return NULL;
+}
+
+ohdec *ohdec_open(int threads, int thread_type) { return ohdec_open_ex(threads, thread_type, 0); }
+
+void ohdec_md5_results(ohdec *d, int *ok, int *bad)
+{
+    (void)d;
+    *ok = g_md5_ok;
+    *bad = g_md5_bad;
 }
 
 /* returns 1 when a picture came out (fetch it with ohdec_frame_*), 0 when none, <0 on a decoder / back-end error */

@@ -9,6 +9,7 @@
 #include <string.h>
 #include "libavcodec/hevc.h"
 #include "libavcodec/thread.h"
+#include "libavutil/pixdesc.h"
 
 static void nop(void) {}
 
@@ -24,6 +25,8 @@ void ohhip_hevc_dsp_init(HEVCDSPContext *c, int bit_depth)  { (void)bit_depth; f
 void ohhip_videodsp_init(VideoDSPContext *c, int bpc)        { (void)bpc; fill(c, sizeof(*c)); }
 void ohhip_hevc_pred_init(HEVCPredContext *c, int bit_depth) { (void)bit_depth; fill(c, sizeof(*c)); }
 int  ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc) { return ff_hevc_set_new_ref(s, frame, poc); }
+int  ohhip_frame_rps(HEVCContext *s) { return ff_hevc_frame_rps(s); }
+const AVPixFmtDescriptor *ohhip_pix_fmt_desc_get(enum AVPixelFormat f) { return av_pix_fmt_desc_get(f); }
 void ohhip_report_progress(ThreadFrame *f, int progress, int field) { ff_thread_report_progress(f, progress, field); }
 void ohhip_await_progress(ThreadFrame *f, int progress, int field) { (void)f; (void)progress; (void)field; }
 void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts) { ff_hevc_cabac_init(s, ctb_addr_ts); }

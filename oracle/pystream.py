@@ -7,7 +7,7 @@ assembles/escapes NAL units.  Slice DATA comes from `_ref/libopenhevc_gen.so` (o
 own parser driven by a seeded random bin source with an arithmetic encoder attached.
 
 `Decoder("c")` is the untouched reference decoder (the bitstream-level oracle), `Decoder("hip")` the same front-end
-with its tables filled by libohevc_hip.so (oracle/hip_hooks.c), `Decoder("gen")` the generator.
+with its tables filled by libohevc_hip.so (integration/hip_hooks.c), `Decoder("gen")` the generator.
 """
 from __future__ import annotations
 
@@ -46,6 +46,9 @@ def _load(kind: str):
     L.ohdec_frame_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
     L.ohdec_frame_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ohdec_close.argtypes = [C.c_void_p]
+    L.ohdec_open_ex.restype = C.c_void_p
+    L.ohdec_open_ex.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ohdec_md5_results.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if kind == "gen":
         L.ohsyn_reset.argtypes = [C.c_uint64]
         L.ohsyn_set_probs.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float]
@@ -59,15 +62,59 @@ def _load(kind: str):
     return L
 
 
+def _product_lib():
+    """libohevc_hip.so as the GPU-backed decoder sees it (same file => same loaded instance as its DT_NEEDED entry)."""
+    if "product" not in _loaded:
+        _loaded["product"] = C.CDLL(os.path.join(os.path.dirname(_HERE), "openhevc_amd", "libohevc_hip.so"), mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    return _loaded["product"]
+
+
+def _software_executor():
+    """oracle/libohsw.so (sw_exec.c + the oracle): executes RECORDED jobs on the decoder's host frames.  CPU tests only."""
+    if "ohsw" not in _loaded:
+        L = C.CDLL(os.path.join(_HERE, "libohsw.so"), mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        L.ohsw_error.restype = C.c_int
+        _loaded["ohsw"] = L
+    return _loaded["ohsw"]
+
+
+def _configure_hip_backend():
+    """OHHIP_SW_EXEC=1 (host-logic tests without a GPU): libohevc_hip.so records only and hands every frame's jobs to the software
+    executor; otherwise no sink, and record-only mode only for OHHIP_RECORD_ONLY (host-side profiling).  The GPU-backed decoder
+    itself (integration/hip_hooks.c) knows nothing of the oracle: this is the only place the two meet."""
+    prod = _product_lib()
+    prod.ohevc_debug_set_frame_sink.argtypes = [C.c_void_p, C.c_void_p]
+    if os.environ.get("OHHIP_SW_EXEC"):
+        sw = _software_executor()
+        prod.ohevc_debug_set_record_only(1)
+        prod.ohevc_debug_set_frame_sink(C.cast(sw.ohsw_sink, C.c_void_p), None)
+        return sw
+    prod.ohevc_debug_set_frame_sink(None, None)
+    prod.ohevc_debug_set_record_only(1 if os.environ.get("OHHIP_RECORD_ONLY") else 0)
+    return None
+
+
 class Decoder:
     """One decoder instance.  decode(au) -> picture (list of 3 numpy planes) or None; flush() -> remaining pictures."""
 
-    def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1):
+    def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1, checksum: bool = False):
         self.kind = kind
         self.L = _load(kind)
-        self.h = self.L.ohdec_open(threads, thread_type)
+        self.sw = _configure_hip_backend() if kind == "hip" else None
+        self.h = self.L.ohdec_open_ex(threads, thread_type, 1 if checksum else 0)
         if not self.h:
             raise RuntimeError(f"ohdec_open failed for {kind}")
+
+    def md5_results(self):
+        """(planes whose decoded-picture-hash SEI matched, planes that did not) since the decoder was opened: the reference's own
+        check, hevc.c:4146-4162, counted through its log lines."""
+        ok, bad = C.c_int(), C.c_int()
+        self.L.ohdec_md5_results(self.h, C.byref(ok), C.byref(bad))
+        return ok.value, bad.value
+
+    def _check_sw(self):
+        if self.sw is not None and self.sw.ohsw_error():
+            raise RuntimeError("software executor reported an error")
 
     def _fetch(self):
         w, h, bd, cw, ch = (C.c_int() for _ in range(5))
@@ -87,6 +134,7 @@ class Decoder:
         r = self.L.ohdec_decode(self.h, au, len(au), pts)
         if r < 0:
             raise RuntimeError(f"decode error {r} ({self.kind})")
+        self._check_sw()
         return self._fetch() if r else None
 
     def flush(self):
@@ -95,6 +143,7 @@ class Decoder:
             r = self.L.ohdec_flush(self.h)
             if r < 0:
                 raise RuntimeError(f"flush error {r}")
+            self._check_sw()
             if not r:
                 return out
             out.append(self._fetch())
@@ -111,16 +160,19 @@ class Decoder:
         self.close()
 
 
-def decode_stream(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1):
-    """Decode a list of access units, return all output pictures in output order."""
+def decode_stream(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1, checksum: bool = False):
+    """Decode a list of access units, return all output pictures in output order.  checksum=True turns the reference's
+    `decode-checksum` option on (libOpenHevcSetCheckMD5, openHevcWrapper.c:429-440) and returns (pictures, (ok, bad)) with the
+    number of planes whose decoded-picture-hash SEI matched / mismatched in the decoder's own check."""
     out = []
-    with Decoder(kind, threads, thread_type) as d:
+    with Decoder(kind, threads, thread_type, checksum) as d:
         for i, au in enumerate(aus):
             f = d.decode(au, i + 1)
             if f is not None:
                 out.append(f)
         out += d.flush()
-    return out
+        res = d.md5_results() if checksum else None
+    return (out, res) if checksum else out
 
 
 # ------------------------------------------------------------------------------------------------ bit writing
@@ -175,6 +227,7 @@ def nal(nal_type: int, rbsp: bytes, tid: int = 0) -> bytes:
 
 NAL_TRAIL_N, NAL_TRAIL_R, NAL_IDR_W_RADL, NAL_CRA = 0, 1, 19, 21
 NAL_VPS, NAL_SPS, NAL_PPS = 32, 33, 34
+NAL_SEI_SUFFIX = 40
 SLICE_B, SLICE_P, SLICE_I = 0, 1, 2
 
 
@@ -231,6 +284,7 @@ class StreamParams:
     gop_size: int = 8
     nframes: int = 4
     seed: int = 1
+    md5_sei: int = 0             # append a decoded-picture-hash SEI (MD5 of the generator's own reconstruction) to every access unit
     probs: dict = field(default_factory=dict)    # overrides of the per-syntax-element bin probabilities
     bypass_prob: float = 0.5
     pcm_prob: float = 0.05
@@ -708,7 +762,25 @@ def generate(p: StreamParams, check: bool = True):
         frames += gen.flush()
     finally:
         gen.close()
+    if p.md5_sei:
+        # pictures come out in output order = increasing POC (one IDR per stream): access unit i carries picture pocs[i]
+        pocs = [pic.poc for pic in plan_gop(p)]
+        rank = {poc: k for k, poc in enumerate(sorted(pocs))}
+        assert len(frames) == len(pocs)
+        aus = [au + md5_sei_nal(frames[rank[poc]]) for au, poc in zip(aus, pocs)]
     return aus, frames
+
+
+def md5_sei_nal(planes) -> bytes:
+    """Suffix SEI, payload type 132 (decoded picture hash, D.2.19), hash_type 0: one MD5 per colour plane over the samples in raster
+    order, 16-bit samples little-endian -- parsed by decode_nal_sei_decoded_picture_hash (hevc_sei.c:28-45), checked against
+    calc_md5 of the decoded planes in hevc_decode_frame (hevc.c:4146-4162, :4623-4637)."""
+    import hashlib
+    body = bytes([0])
+    for pl in planes:
+        body += hashlib.md5(np.ascontiguousarray(pl).astype("<u2" if pl.dtype.itemsize == 2 else np.uint8).tobytes()).digest()
+    rbsp = bytes([132, len(body)]) + body + b"\x80"
+    return nal(NAL_SEI_SUFFIX, rbsp)
 
 
 def _escaped_sizes(header: bytes, payload: bytes, starts: List[int]) -> List[int]:

@@ -105,3 +105,22 @@ def test_product_does_not_touch_the_oracle():
         if os.path.isfile(path) and path.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
             text = open(path, errors="ignore").read()
             assert "pyoracle" not in text and "liboracle" not in text and "hevcref" not in text, path
+
+
+def test_gpu_backed_decoder_links_no_oracle():
+    """oracle/_ref/libopenhevc_hip.so = the reference's objects + integration/hip_hooks.c + libohevc_hip.so and nothing else that
+    could produce a pixel: no symbol of the oracle (ohor_*), of the software executor (ohsw_*) or of the compiled reference kernels'
+    shim (ohref_*) is defined or wanted; the only library it needs besides libc / libm / libpthread is libohevc_hip.so."""
+    import subprocess
+    import pytest
+    so = os.path.join(ROOT, "oracle", "_ref", "libopenhevc_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libopenhevc_hip.so not built (needs /root/reference once)")
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    bad = [ln for ln in syms.splitlines() if re.search(r"\b(ohor_|ohsw_|ohref_|ohsse_)", ln)]
+    assert not bad, bad[:5]
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[(.*?)\]", subprocess.run(["readelf", "-d", so], capture_output=True, text=True, check=True).stdout)
+    assert "libohevc_hip.so" in needed
+    assert all(n.startswith(("libohevc_hip", "libc.", "libm.", "libpthread", "ld-linux")) for n in needed), needed
+    hooks = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "integration", "hip_hooks.c")).read(), flags=re.S)
+    assert "oracle_api.h" not in hooks and "ohsw_" not in hooks and "ohor_" not in hooks

@@ -55,7 +55,7 @@ for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters
 
 
 # ---------------------------------------------------------------- the whole decoder over the emulated device code
-# oracle/_ref/libopenhevc_hipemu.so = the reference's decoder with the product's hooks (oracle/hip_hooks.c), linked against the
+# oracle/_ref/libopenhevc_hipemu.so = the reference's decoder with the product's hooks (integration/hip_hooks.c), linked against the
 # emulator library instead of libohevc_hip.so: parsing, recording, the ctx executor and every kernel, on the host.
 def _stream_lib():
     from oracle import pystream as ps

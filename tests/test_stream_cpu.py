@@ -212,3 +212,53 @@ def test_fuzzed_streams_through_the_software_executor():
     assert lines, r.stderr[-2000:]
     res = json.loads(lines[-1])
     assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 8, r.stdout[-3000:]   # (count: a floor that holds on a loaded box)
+
+
+# ------------------------------------------------------------------ decoded-picture-hash SEI (the reference's only self-check)
+MD5_KW = dict(gop="random_access", nframes=9, seed=611, width=416, height=240, log2_ctb=5, md5_sei=1)
+
+
+@needs_gen
+def test_md5_sei_is_accepted_by_the_untouched_decoder():
+    """every access unit carries a suffix SEI with the MD5 of the generator's own reconstruction; with the
+    `decode-checksum` option on, the reference's check (hevc_sei.c:28-45, hevc.c:4146-4162) must log "Correct MD5" for every plane
+    of every picture -- one thread and frame threads -- and "Incorrect MD5" once a hash byte is flipped."""
+    aus, gen_frames = ps.generate(ps.StreamParams(**MD5_KW))
+    plain, _ = ps.generate(ps.StreamParams(**dict(MD5_KW, md5_sei=0)))
+    assert all(a.startswith(b) and len(a) == len(b) + 4 + 2 + 2 + 1 + 48 + 1 for a, b in zip(aus, plain))   # start code, NAL header, type+size, hash_type, 3 x MD5, trailing
+    for threads in (1, 3):
+        out, (ok, bad) = ps.decode_stream("c", aus, threads, 1, checksum=True)
+        assert frames_md5(out) == frames_md5(gen_frames)
+        assert (ok, bad) == (3 * MD5_KW["nframes"], 0)
+    broken = list(aus)
+    broken[4] = broken[4][:-5] + bytes([broken[4][-5] ^ 0x40]) + broken[4][-4:]      # inside the Cr hash of picture 4
+    _, (ok, bad) = ps.decode_stream("c", broken, checksum=True)
+    assert (ok, bad) == (3 * MD5_KW["nframes"] - 1, 1)
+
+
+@needs_gen
+@needs_hip_lib
+@pytest.mark.parametrize("threads", [1, 3])
+def test_md5_check_runs_behind_the_frame_end_hook(threads, monkeypatch):
+    """The hooked decoder (integration/hip_hooks.c) must end the frame -- run the recorded jobs, copy the picture back -- BEFORE
+    hevc_decode_frame hashes the host planes (INTEGRATION.md section 3, last row).  Here the jobs run through the software executor;
+    tests/test_stream_gpu.py repeats it on the device."""
+    monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    aus, gen_frames = ps.generate(ps.StreamParams(**MD5_KW))
+    out, (ok, bad) = ps.decode_stream("hip", aus, threads, 1, checksum=True)
+    assert frames_md5(out) == frames_md5(gen_frames)
+    assert (ok, bad) == (3 * MD5_KW["nframes"], 0)
+
+
+@needs_gen
+@needs_hip_lib
+def test_stream_starting_at_a_missing_reference(monkeypatch):
+    """A stream cut in front of its IDR's first dependants: the decoder synthesises the missing reference pictures
+    (generate_missing_ref, hevc_refs.c:538-598: mid-grey host planes, no table call).  The hooks must send those samples to the
+    device picture store (ohhip_frame_rps -> ohevc_pic_upload): the pictures predicted from them equal the untouched decoder's."""
+    monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    aus, _ = ps.generate(ps.StreamParams(gop="lowdelay_p", nframes=6, seed=612, width=192, height=128))
+    cut = [aus[0]] + aus[3:]          # pictures 1 and 2 are lost; 3.. predict from them
+    ref = ps.decode_stream("c", cut)
+    assert len(ref) >= 3
+    assert frames_md5(ps.decode_stream("hip", cut)) == frames_md5(ref)

@@ -1,5 +1,5 @@
 """The drop-in, end to end: the reference's real decoder (all 125 sources compiled in place) with its DSP / prediction
-/ videodsp tables filled by libohevc_hip.so (oracle/hip_hooks.c = INTEGRATION.md applied at link time) must output the
+/ videodsp tables filled by libohevc_hip.so (integration/hip_hooks.c = INTEGRATION.md applied at link time) must output the
 same pictures as the untouched reference decoder, on synthetic Annex-B streams."""
 import hashlib
 import os
@@ -120,3 +120,71 @@ def test_parameter_sets_change_mid_stream(threads):
     ref = ps.decode_stream("c", aus)
     assert frames_md5(ref) == frames_md5(gen_frames)
     _compare(ref, ps.decode_stream("hip", aus, threads, 1))
+
+
+# ------------------------------------------------------------------ BASELINE.json configs 3 / 4 / 5 geometry, MD5 SEI on
+def _baseline_case(kw, threads, thread_type):
+    """Synthesise the stream (every access unit ends with a decoded-picture-hash SEI), decode it with the hooked decoder and the
+    `decode-checksum` option on: the reference's own check (hevc.c:4146-4162) must report "Correct MD5" for every plane behind the
+    download hook, and every picture must equal the untouched decoder's sample for sample."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    aus, gen_frames = ps.generate(ps.StreamParams(md5_sei=1, **kw))
+    ref = ps.decode_stream("c", aus)
+    assert frames_md5(ref) == frames_md5(gen_frames)
+    hip, (ok, bad) = ps.decode_stream("hip", aus, threads, thread_type, checksum=True)
+    _compare(ref, hip)
+    assert (ok, bad) == (3 * kw["nframes"], 0)
+
+
+@pytest.mark.parametrize("threads,thread_type", [(1, 1), (4, 1)])
+def test_config3_1080p_main_random_access(threads, thread_type):
+    """BASELINE config 3: 1920x1080 Main 8-bit random-access, full CTU pipeline (intra + MC + IDCT + deblock + SAO) on one GPU."""
+    _baseline_case(dict(gop="random_access", nframes=9, seed=3001, width=1920, height=1080, log2_ctb=6), threads, thread_type)
+
+
+@pytest.mark.parametrize("threads,thread_type", [(1, 1), (8, 2)])
+def test_config4_4k_main10_wpp(threads, thread_type):
+    """BASELINE config 4: 3840x2160 Main10 4:2:0 with wavefront parallel processing; one decoding thread and 8 slice threads (one
+    WPP row each, hls_decode_entry_wpp) recording into one context."""
+    _baseline_case(dict(gop="lowdelay_b", nframes=4, seed=3002, width=3840, height=2160, log2_ctb=6, bit_depth=10, wpp=1), threads, thread_type)
+
+
+@pytest.mark.parametrize("threads,thread_type", [(1, 1), (3, 1)])
+def test_config5_8k_main10_on_one_gpu(threads, thread_type):
+    """BASELINE config 5 geometry on ONE GPU (north star: "bit-exact 8K Main10 decode on 1 GPU"): 7680x4320 Main10, three pictures."""
+    _baseline_case(dict(gop="lowdelay_b", nframes=3, seed=3003, width=7680, height=4320, log2_ctb=6, bit_depth=10), threads, thread_type)
+
+
+def test_missing_reference_pictures_reach_the_device():
+    """generate_missing_ref (hevc_refs.c:538-598) fills HOST planes with mid-grey and makes no table call: the hooks upload such a
+    picture into the device picture store (ohhip_frame_rps), so that what is predicted from it equals the untouched decoder's."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    for kw in (dict(gop="lowdelay_p", nframes=6, seed=612, width=192, height=128),
+               dict(gop="lowdelay_b", nframes=7, seed=613, width=416, height=240, bit_depth=10)):
+        aus, _ = ps.generate(ps.StreamParams(**kw))
+        cut = [aus[0]] + aus[3:]
+        ref = ps.decode_stream("c", cut)
+        for threads in (1, 3):
+            _compare(ref, ps.decode_stream("hip", cut, threads, 1))
+
+
+def test_plain_c_host_links_and_runs():
+    """tests/c_host/host_smoke.c: a C program (no Python, no torch) that links libohevc_hip.so the way INTEGRATION.md section 4 says
+    and runs one batched IDCT through the C ABI."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tempfile.mkdtemp()
+    try:
+        exe = os.path.join(d, "host_smoke")
+        libdir = os.path.join(root, "openhevc_amd")
+        subprocess.run(["gcc", "-O1", os.path.join(root, "tests", "c_host", "host_smoke.c"), "-I" + os.path.join(root, "include"),
+                        "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + libdir, "-lohevc_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+    finally:
+        shutil.rmtree(d)

@@ -1,4 +1,4 @@
-"""GPU diagnostic: synthetic streams through the reference decoder with CPU tables vs HIP tables (oracle/hip_hooks.c)."""
+"""GPU diagnostic: synthetic streams through the reference decoder with CPU tables vs HIP tables (integration/hip_hooks.c)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
