@@ -105,6 +105,11 @@ int  ohevc_frame_reconstruct(ohevc_ctx *ctx);
  * and the stream has drained (ohevc_ctx_sync / ohevc_pic_download) */
 int  ohevc_frame_end(ohevc_ctx *ctx);
 
+/* Give up the frame being recorded (a recording error, a failed launch): drops what was recorded and publishes the picture as
+ * complete-with-error, so that other contexts of the store that reference it -- they block until its frame end has been issued --
+ * fail at once with OHEVC_ERR_STATE instead of timing out.  ohevc_frame_end does this itself when it returns an error. */
+int  ohevc_frame_abort(ohevc_ctx *ctx);
+
 /* statistics of the last ohevc_frame_end, for benches: launches issued, intra dependency levels, bytes uploaded */
 typedef struct ohevc_frame_stats {
     int32_t launches, intra_levels;

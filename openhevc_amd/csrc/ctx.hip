@@ -25,6 +25,7 @@ struct Picture {
     ohevc_plane planes[3] = {};
     // cross-ctx ordering (contexts of several decoding threads share one store and run on their own streams):
     bool end_issued = true;               // false between frame_begin and the frame_end that reconstructs this picture
+    bool failed = false;                  // that frame_end gave up (ohevc_frame_abort): dependents fail at once instead of waiting
     hipEvent_t written = nullptr;         // recorded on the writer's stream by that frame_end
     std::vector<hipEvent_t> readers;      // frame-end events of pictures that read this one since it was written
 };
@@ -145,6 +146,7 @@ struct ohevc_ctx : Rec {
     // concurrent recording (ohevc_ctx_set_concurrent)
     bool concurrent = false;
     uint64_t gen = 0;                                      // identity for the per-thread cache (addresses get reused)
+    std::atomic<uint64_t> epoch{0};                        // bumped by frame_begin: the owner thread may change from picture to picture
     std::thread::id owner;                                 // the thread that called frame_begin records into the context itself
     std::mutex side_m;
     std::vector<std::pair<std::thread::id, std::unique_ptr<Rec>>> side;
@@ -184,7 +186,17 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
         const int w = width >> hs, h = height >> vs;
         const int stride = (w * ps + 255) & ~255;          // 256-byte pitch: whole 128-byte lines per row segment
         void *d = reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1));      // never dereferenced in record-only mode
-        if (!dry) OHEVC_HIP_TRY(hipMalloc(&d, (size_t)stride * h));
+        if (!dry) {
+            // zeroed like the reference's frame pool (av_buffer_allocz, libavcodec/utils.c): a sample nobody ever wrote -- a stream that
+            // predicts from a picture it never sent -- is at least the same sample on every run
+            hipError_t e = hipMalloc(&d, (size_t)stride * h);
+            if (e == hipSuccess) e = hipMemset(d, 0, (size_t)stride * h);
+            if (e != hipSuccess) {
+                set_error("picture plane allocation failed: %s", hipGetErrorString(e));
+                for (int k = 0; k < i; k++) { (void)hipFree(p.planes[k].data); p.planes[k] = ohevc_plane{}; }
+                return OHEVC_ERR_HIP;
+            }
+        }
         p.planes[i] = ohevc_plane{ d, stride, w, h };
     }
     p.used = true;
@@ -245,6 +257,17 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
         (void)hipDeviceSynchronize();
         for (int i = 0; i < c->store->npics; i++) if (c->store->pics[i].used) free_picture(c->store->pics[i]);
+    }
+    {   // pictures of the shared store may still name this context's events (the stream has drained: they have all fired)
+        std::lock_guard<std::mutex> g(c->store->m);
+        for (int i = 0; i < c->store->npics; i++) {
+            Picture &p = c->store->pics[i];
+            for (hipEvent_t e : c->ring) {
+                if (!e) continue;
+                if (p.written == e) p.written = nullptr;
+                p.readers.erase(std::remove(p.readers.begin(), p.readers.end(), e), p.readers.end());
+            }
+        }
     }
     for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
     if (c->twin.used) free_picture(c->twin);
@@ -348,6 +371,14 @@ extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *h
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
     if (c->dry) return OHEVC_OK;
+    {   // frames of other contexts may still read (or write) the picture that lived in this slot's memory
+        std::lock_guard<std::mutex> g(c->store->m);
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+        for (hipEvent_t e : p->readers) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+        p->readers.clear();
+        p->written = nullptr;
+        p->failed = false;
+    }
     const ohevc_plane &pl = p->planes[plane];
     OHEVC_HIP_TRY(hipMemcpy2DAsync(pl.data, pl.stride, host, host_stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
                                    hipMemcpyHostToDevice, c->stream));
@@ -366,6 +397,7 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
+        if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
         if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
     }
     const ohevc_plane &pl = p->planes[plane];
@@ -464,9 +496,10 @@ extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, cons
 static inline Rec &pick(ohevc_ctx *c)
 {
     if (!c->concurrent) return *c;
-    struct Cache { uint64_t gen = 0; Rec *r = nullptr; };
+    struct Cache { uint64_t gen = 0, epoch = 0; Rec *r = nullptr; };
     static thread_local Cache cache;
-    if (cache.gen == c->gen) return *cache.r;
+    const uint64_t epoch = c->epoch.load(std::memory_order_acquire);
+    if (cache.gen == c->gen && cache.epoch == epoch) return *cache.r;
     Rec *r = c;
     if (std::this_thread::get_id() != c->owner) {
         std::lock_guard<std::mutex> g(c->side_m);
@@ -474,7 +507,7 @@ static inline Rec &pick(ohevc_ctx *c)
         for (auto &sd : c->side) if (sd.first == std::this_thread::get_id()) r = sd.second.get();
         if (!r) { c->side.emplace_back(std::this_thread::get_id(), std::unique_ptr<Rec>(new Rec())); r = c->side.back().second.get(); }
     }
-    cache.gen = c->gen; cache.r = r;
+    cache.gen = c->gen; cache.epoch = epoch; cache.r = r;
     return *r;
 }
 
@@ -555,6 +588,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     {
         std::lock_guard<std::mutex> g(c->store->m);
         p->end_issued = false;
+        p->failed = false;
     }
     c->ref_slots.clear();
     c->target_guarded = false;
@@ -568,6 +602,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     c->stats = ohevc_frame_stats{};
     for (int &v : c->nstat) v = 0;
     c->owner = std::this_thread::get_id();
+    c->epoch.fetch_add(1, std::memory_order_release);      // per-thread recorder caches of the previous picture are void
     {
         std::lock_guard<std::mutex> g(c->side_m);
         for (auto &sd : c->side) { clear_rec(*sd.second); sd.second->dbk_v.clear(); sd.second->dbk_h.clear(); sd.second->sao.clear(); for (int &v : sd.second->nstat) v = 0; }
@@ -855,6 +890,7 @@ static int guard_pictures(ohevc_ctx *c, int target)
             set_error("reference picture %d was never completed by its decoding thread", r);
             return OHEVC_ERR_STATE;
         }
+        if (rp.failed) { set_error("reference picture %d: its frame failed", r); return OHEVC_ERR_STATE; }
         if (rp.written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, rp.written, 0));
     }
     if (!c->target_guarded) {
@@ -1038,7 +1074,38 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     return OHEVC_OK;
 }
 
+// A frame that cannot be completed must still be PUBLISHED: other decoding threads block (for up to 20 s each) until the frame_end of
+// every picture they reference has been issued.  Marks the picture complete-and-failed; dependents return OHEVC_ERR_STATE at once.
+extern "C" int ohevc_frame_abort(ohevc_ctx *c)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    clear_recorded(c);
+    c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
+    {
+        std::lock_guard<std::mutex> g(c->store->m);
+        p->failed = true;
+        p->end_issued = true;
+    }
+    c->store->cv.notify_all();
+    return OHEVC_OK;
+}
+
+static int frame_end_impl(ohevc_ctx *c);
 extern "C" int ohevc_frame_end(ohevc_ctx *c)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr, "no frame begun");
+    const int rc = frame_end_impl(c);
+    if (rc != OHEVC_OK) {
+        char keep[512];
+        snprintf(keep, sizeof(keep), "%s", ohevc_last_error());
+        ohevc_frame_abort(c);
+        set_error("%s", keep);
+    }
+    return rc;
+}
+
+static int frame_end_impl(ohevc_ctx *c)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");

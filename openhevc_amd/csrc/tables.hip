@@ -718,7 +718,11 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     using namespace ohevc;
     TablesState *s = state_of(ctx, false);
     OHEVC_REQUIRE(s != nullptr && s->cur >= 0, "no frame begun");
-    if (s->status != OHEVC_OK) { set_error("a table call failed while recording (unknown pointer or call order)"); return s->status; }
+    if (s->status != OHEVC_OK) {
+        ohevc_frame_abort(ctx);           // publish the picture as failed: frame threads that reference it must not wait for it
+        set_error("a table call failed while recording (unknown pointer or call order)");
+        return s->status;
+    }
     Prof prof_(K_END);
     int rc;
     // a held SAO job saw, in the reference, the samples right of its block BEFORE a horizontal edge through them was
@@ -735,7 +739,7 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
             j.quirks = (uint8_t)((later(j.y + j.h) ? OHEVC_SAO_LAG_BELOW : 0) | (later(j.y) ? OHEVC_SAO_LAG_ABOVE : 0) |
                                  ((j.h > 8 && later(j.y + 8)) ? OHEVC_SAO_LAG_MID : 0));
         }
-        if ((rc = ohevc_rec_sao(ctx, &j)) != OHEVC_OK) return rc;
+        if ((rc = ohevc_rec_sao(ctx, &j)) != OHEVC_OK) { ohevc_frame_abort(ctx); return rc; }
     }
     s->held_sao.clear();
     rc = ohevc_frame_end(ctx);
