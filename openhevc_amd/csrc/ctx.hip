@@ -187,10 +187,7 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
         const int stride = (w * ps + 255) & ~255;          // 256-byte pitch: whole 128-byte lines per row segment
         void *d = reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1));      // never dereferenced in record-only mode
         if (!dry) {
-            // zeroed like the reference's frame pool (av_buffer_allocz, libavcodec/utils.c): a sample nobody ever wrote -- a stream that
-            // predicts from a picture it never sent -- is at least the same sample on every run
             hipError_t e = hipMalloc(&d, (size_t)stride * h);
-            if (e == hipSuccess) e = hipMemset(d, 0, (size_t)stride * h);
             if (e != hipSuccess) {
                 set_error("picture plane allocation failed: %s", hipGetErrorString(e));
                 for (int k = 0; k < i; k++) { (void)hipFree(p.planes[k].data); p.planes[k] = ohevc_plane{}; }
@@ -323,6 +320,14 @@ extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int
     np = Picture();
     int rc = alloc_picture(np, width, height, cfi, bd, c->dry);
     if (rc != OHEVC_OK) return rc;
+    if (!c->dry) {
+        // zeroed like the reference's frame pool (av_buffer_allocz, libavcodec/utils.c): a sample nobody ever wrote -- a stream that
+        // predicts from a picture it never sent -- is at least the same sample on every run.  On this context's stream and drained
+        // before the slot is handed out: a memset on the null stream would not be ordered against the (non-blocking) streams
+        // that reconstruct into the picture.
+        for (const ohevc_plane &pl : np.planes) OHEVC_HIP_TRY(hipMemsetAsync(pl.data, 0, (size_t)pl.stride * pl.height, c->stream));
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     c->store->version++;
     return slot;
 }
