@@ -24,7 +24,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md).  What the box sustains: tools/hbm_probe.hip (profiles/r02e_*):
+                               # float4 copy 5.7-6.2 TB/s, this batch's own traffic pattern 5.6-5.7 TB/s (0.70 of the peak at 8 bit)
 
 
 def parse():
@@ -40,50 +41,64 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(log2, bd, target_seconds=12.0):
-    """Reference C tables (oracle/_ref/libhevcref.so, kind 'reference'; falls back to our C port, kind 'port')
-    on all host cores, on a bounded sample of the same workload."""
+def cpu_baseline(log2, bd, leg_seconds=6.0):
+    """The reference's own C tables (oracle/_ref/libhevcref.so, kind 'reference'; our C port if that is absent, kind 'port') on this
+    host's cores, on a bounded sample of the same workload: ONE thread and ALL cores, each leg sized to run >= 5 s, plus the
+    reference's x86 SSE4 intrinsics path (x86/hevc_idct_sse.c) the same way.  `value` = all cores, C tables."""
     from oracle import pyoracle as po
     lib, kind = po.load("ref"), "reference"
     if lib is None:
         lib, kind = po.load("oracle"), "port"
     sse = po.load("sse")
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(os.cpu_count() or 1, 256)
     n = 1 << log2
     rng = np.random.default_rng(1234)
     dt = np.uint16 if bd > 8 else np.uint8
     per_row = 4096 // n
+    # one buffer of 2^17 blocks (256 MiB of coefficients at 32x32, far beyond the host caches), passed over as often as a leg needs
+    nbuf = (1 << 17) if log2 == 5 else (1 << 19) if log2 == 4 else (1 << 20)
+    plane = rng.integers(0, 1 << bd, size=((nbuf + per_row - 1) // per_row * n, 4096), dtype=dt)
+    coeffs = rng.integers(-1024, 1024, size=(nbuf, n, n), dtype=np.int16)
+    idx = np.arange(nbuf)
+    xy = np.stack([(idx % per_row) * n, (idx // per_row) * n], 1).astype(np.int32)
 
-    def make(nblk):
-        plane = rng.integers(0, 1 << bd, size=((nblk + per_row - 1) // per_row * n, 4096)).astype(dt)
-        coeffs = rng.integers(-1024, 1024, size=(nblk, n, n)).astype(np.int16)
-        idx = np.arange(nblk)
-        xy = np.stack([(idx % per_row) * n, (idx // per_row) * n], 1).astype(np.int32)
-        return plane, coeffs, xy
-
-    def run(nblk):
-        plane, coeffs, xy = make(nblk)
+    def run_c(threads, reps):
         t0 = time.perf_counter()
-        lib.tu_batch(bd, po.TU_IDCT, log2, coeffs, plane, xy, threads=cores)
-        return time.perf_counter() - t0, (plane, coeffs, xy)
+        for _ in range(reps):
+            lib.tu_batch(bd, po.TU_IDCT, log2, coeffs, plane, xy, threads=threads)
+        return time.perf_counter() - t0
 
-    probe = 1 << 12
-    t, _ = run(probe)
-    nblk = int(min(1 << 20, max(probe, probe * target_seconds / max(t, 1e-6))))
-    t, data = run(nblk)
-    out = {"value": round(nblk * n * n / t / 1e6, 2), "unit": "Mpixel/s", "cores": cores, "kind": kind,
-           "sample": f"{nblk} blocks {n}x{n} {bd}-bit, reference C tables (idct+transform_add), {cores} threads, {t:.1f} s"}
-    if sse is not None and bd in (8, 10):
+    def run_sse(threads, reps):
         import ctypes as C
-        plane, coeffs, xy = data
         t0 = time.perf_counter()
-        rc = sse.ohsse_idct_add_batch_mt(C.c_int(bd), C.c_int(log2), C.c_int(nblk), coeffs.ctypes.data_as(C.c_void_p),
-                                         plane.ctypes.data_as(C.c_void_p), C.c_ssize_t(plane.strides[0]),
-                                         xy.ctypes.data_as(C.c_void_p), C.c_int(cores))
-        ts = time.perf_counter() - t0
-        if rc == 0:
-            out["simd_value"] = round(nblk * n * n / ts / 1e6, 2)
-            out["simd_note"] = "reference x86 SSE4 intrinsics path (x86/hevc_idct_sse.c), same sample and threads"
+        for _ in range(reps):
+            rc = sse.ohsse_idct_add_batch_mt(C.c_int(bd), C.c_int(log2), C.c_int(nbuf), coeffs.ctypes.data_as(C.c_void_p),
+                                             plane.ctypes.data_as(C.c_void_p), C.c_ssize_t(plane.strides[0]),
+                                             xy.ctypes.data_as(C.c_void_p), C.c_int(threads))
+            if rc != 0:
+                return None
+        return time.perf_counter() - t0
+
+    def leg(run, threads):
+        """passes over the buffer sized from a first pass so that the timed leg takes about leg_seconds (>= 5 s)"""
+        t = run(threads, 1)                            # first touch, thread start-up; also the probe
+        if t is None:
+            return None
+        reps = max(1, int(round(leg_seconds / max(t, 1e-6))))
+        t = run(threads, reps)
+        return {"mpix_s": round(reps * nbuf * n * n / t / 1e6, 2), "blocks": reps * nbuf, "seconds": round(t, 2)}
+
+    c1, cn = leg(run_c, 1), leg(run_c, cores)
+    out = {"value": cn["mpix_s"], "unit": "Mpixel/s", "cores": cores, "kind": kind,
+           "value_1thread": c1["mpix_s"],
+           "sample": f"{n}x{n} {bd}-bit idct + transform_add through the reference's C tables: {cn['blocks']} blocks on {cores} threads in "
+                     f"{cn['seconds']} s; {c1['blocks']} blocks on 1 thread in {c1['seconds']} s (host has {os.cpu_count()} logical cores)"}
+    if sse is not None and bd in (8, 10):
+        s1, sn = leg(run_sse, 1), leg(run_sse, cores)
+        if s1 and sn:
+            out["simd_value"], out["simd_value_1thread"] = sn["mpix_s"], s1["mpix_s"]
+            out["simd_note"] = (f"reference x86 SSE4 intrinsics path (x86/hevc_idct_sse.c): {sn['blocks']} blocks on {cores} threads in "
+                                f"{sn['seconds']} s; {s1['blocks']} blocks on 1 thread in {s1['seconds']} s")
     return out
 
 
@@ -171,11 +186,16 @@ def main():
     bytes_per_px = 2 + 2 * (2 if bd > 8 else 1)
     alg_bytes = nblk * n * n * bytes_per_px
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+    # HBM bytes per launch from the PMC counters: NOT measured by this process (counters need rocprofv3 around it); the stored result of
+    # the separate --pmc passes of this very command (tools/gpu_pmc_traffic.sh -> tools/pmc_traffic.py) is reported, and labelled so
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath) and log2 == 5 and bd == 8 and not args.sparse:
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("kernel", "").startswith(L.load_library().ohevc_tu_kernel_name(bd, log2, L.TU_IDCT).decode()):
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "stored: profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         except Exception:
             traffic = None
 
@@ -193,7 +213,7 @@ def main():
                                    f"16384-wide tiled plane, coeffs U[-1024,1023]{' top-left 8x8 only' if args.sparse else ''}, seed 1234",
                        "blocks_per_gpu": nblk, "block": n, "bit_depth": bd, "parallelism": f"blocks sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": L.load_library().ohevc_tu_kernel_name(bd, log2, L.TU_IDCT).decode(),
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
         }

@@ -14,6 +14,12 @@ extern "C" {
  * keep the memory traffic but drop the transform (bit 5: also drop the LDS passes) -- their output is NOT correct;
  * they exist only to locate the bottleneck.  Returns the previous value; -1 restores the shipped default (coalesced epilogue for 16x16/32x32, prefetch for 8x8). */
 int ohevc_debug_set_tu_variant(int variant);
+/* 1 when the library is the LAB build (make -C openhevc_amd/csrc LAB=1 -> libohevc_hip_lab.so): the product library carries only the
+ * shipped kernels and their direct alternatives -- dot2 forms 0 / 1 / 16 / 16+128 / 16+128+1024 (bit 10: non-temporal coefficient
+ * loads) and, for 32x32, bit 11 (2048): the matrix-core tile kernel, one workgroup per 8 blocks (shipped).  Everything else below
+ * (persistent / software-pipelined forms, ablations, probes, the loop forms of the tile kernel: bits 2, 5, 6, 8, 9, 12-15 with 11) exists
+ * in the lab build only; the product library ignores those bits. */
+int ohevc_debug_has_lab(void);
 /* bit 8 of the variant (256): 32x32 blocks run the matrix-core form (tu_idct32_mfma_kernel: v_mfma_i32_32x32x32_i8 on the high and low
  * byte planes of the int16 inputs, both passes in registers); its grid is the persistent kernel's (ohevc_debug_set_tu_pipe_workgroups).
  * ohevc_debug_mfma_i8_probe runs one such MFMA per probe on raw lane data (a, b: nprobes x 64 lanes x 16 bytes, d: nprobes x 64 x 16

@@ -205,7 +205,8 @@ __device__ __forceinline__ void tu_idct_add_body(unsigned char *lds, int wg, con
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane / N, i = lane % N;
     const int job0 = (wg * 4 + wave) * L::BPW;
-    if (job0 >= njobs) return;                              // wave-uniform; no workgroup barrier is used below
+    constexpr bool WG_EPILOGUE = (VARIANT & 512) && LOG2N >= 4;      // the epilogue below synchronises the whole workgroup
+    if constexpr (!WG_EPILOGUE) { if (job0 >= njobs) return; }         // wave-uniform; no workgroup barrier is used in that form
     const bool valid = job0 + g < njobs;
     const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[valid ? job0 + g : njobs - 1];
     const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
@@ -230,7 +231,9 @@ __device__ __forceinline__ void tu_idct_add_body(unsigned char *lds, int wg, con
 #pragma unroll
         for (int q = 0; q < N / 8; q++) {
             const int c = q * N + i;                        // 16-byte chunk index inside the block
-            const u32x4 v = src[c];
+            u32x4 v;
+            if constexpr (VARIANT & 1024) v = __builtin_nontemporal_load(src + c);      // read exactly once: do not keep it in L2 / MALL
+            else v = src[c];
             *reinterpret_cast<u32x4 *>(blk + (c / (N / 8)) * RS + (c % (N / 8)) * 16) = v;
         }
         __builtin_amdgcn_wave_barrier();
@@ -270,7 +273,67 @@ __device__ __forceinline__ void tu_idct_add_body(unsigned char *lds, int wg, con
     for (int k = 0; k < N; k++) t[k] >>= shift2;
 
     // ---- D. residual row + prediction row -> plane
-    if constexpr ((VARIANT & 16) && LOG2N >= 4) {
+    if constexpr (WG_EPILOGUE) {
+        // Workgroup-wide coalesced epilogue: the 4 * BPW blocks of the workgroup form one strip of 256 samples.  Residual rows go to LDS
+        // as int16, then thread T takes 16 bytes of pixels of strip row T / CPR: a wave instruction covers whole 256-byte (8-bit) /
+        // 512-byte (16-bit) row segments -- full 128-byte lines wherever the blocks of the batch are horizontal neighbours (they are in
+        // z-order / raster job lists).  The 64-sample strips of the wave-private form (VARIANT 16) give the memory pipeline twice as many
+        // line requests per byte at 8 bit; profiles/r02*_ab_tu_variants.txt.
+        constexpr int SRS = 512 + 16;                          // bytes per strip row: 256 samples of int16 + pad
+        constexpr int PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 256 / CH_PX, RPI = 256 / CPR, ITER = N / RPI;
+        static_assert(N * SRS + 4 * L::BPW * 8 <= 4 * L::WAVE_BYTES, "output strip + job records must fit the workgroup's tiles");
+        unsigned *jrec = reinterpret_cast<unsigned *>(lds + N * SRS);
+        __syncthreads();                                       // every wave has consumed its coefficient tile
+        {
+            u32x4 *d = reinterpret_cast<u32x4 *>(lds + i * SRS + (wave * L::BPW + g) * (N * 2));
+#pragma unroll
+            for (int q = 0; q < N / 8; q++) {
+                u32x4 v = { sat_pack_i16(t[8 * q], t[8 * q + 1]), sat_pack_i16(t[8 * q + 2], t[8 * q + 3]),
+                            sat_pack_i16(t[8 * q + 4], t[8 * q + 5]), sat_pack_i16(t[8 * q + 6], t[8 * q + 7]) };
+                d[q] = v;
+            }
+            if (i == 0) { jrec[2 * (wave * L::BPW + g)] = jraw.x; jrec[2 * (wave * L::BPW + g) + 1] = valid ? (jraw.y & 0xffu) : 0xffffffffu; }
+        }
+        __syncthreads();
+        const int tid = threadIdx.x, c = tid % CPR, r0 = tid / CPR;
+        const int bsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+        const unsigned oxy = jrec[2 * bsel], opl = jrec[2 * bsel + 1];
+        const bool ovalid = opl != 0xffffffffu;
+        const int ostride = PLANE_STRIDE3(planes, opl);
+        unsigned char *obase = PLANE_PTR3(planes, opl) + (size_t)(oxy >> 16) * ostride + (size_t)((oxy & 0xffff) + pxoff) * PXB;
+        const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+        u32x4 pr[ITER];
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            pr[k] = u32x4{ 0, 0, 0, 0 };
+            if (ovalid) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride);
+        }
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            const int rr = r0 + k * RPI;
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(lds + rr * SRS + c * CH_PX * 2);
+            u32x4 o;
+            if constexpr (PXB == 1) {
+                const u32x4 ra = rp[0], rb = rp[1];
+                const unsigned res[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+                const unsigned pd[4] = { pr[k].x, pr[k].y, pr[k].z, pr[k].w };
+                unsigned od[4];
+#pragma unroll
+                for (int d4 = 0; d4 < 4; d4++) {
+                    const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
+                    const unsigned a01 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4]), bitcast<s16x2>(u01)));
+                    const unsigned a23 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4 + 1]), bitcast<s16x2>(u23)));
+                    od[d4] = sat_pack_u8_i16(a01) | (sat_pack_u8_i16(a23) << 16);
+                }
+                o = u32x4{ od[0], od[1], od[2], od[3] };
+            } else {
+                const u32x4 ra = rp[0];
+                o = u32x4{ add_clamp_upx2(ra.x, pr[k].x, max2), add_clamp_upx2(ra.y, pr[k].y, max2),
+                           add_clamp_upx2(ra.z, pr[k].z, max2), add_clamp_upx2(ra.w, pr[k].w, max2) };
+            }
+            if (ovalid) *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
+        }
+    } else if constexpr ((VARIANT & 16) && LOG2N >= 4) {
         // Coalesced epilogue: the wave's 64/N blocks form one 64-sample-wide strip.  Residual rows go to LDS as int16
         // (natural order), then lane L takes 16 bytes of pixels of row L / CPR: one wave instruction covers RPI whole
         // rows of the strip, i.e. full 64-byte (8-bit) / 128-byte (16-bit) segments per row instead of 16-byte pieces.
@@ -409,6 +472,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char *p)
     return bitcast<u32x2>(r);
 }
 
+#ifdef OHEVC_LAB      // measurement forms kept for A/B (make LAB=1): the loop kernels the shipped tile kernel was derived from
 // VARIANT bit 0: fetch the prediction rows before the transform; bit 1: no register prefetch of the next pair (for the A/B)
 template <typename Pixel, int VARIANT>
 __global__ __launch_bounds__(256) void tu_idct32_mfma_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
@@ -552,6 +616,452 @@ __global__ __launch_bounds__(256) void tu_idct32_mfma_kernel(PlaneSet planes, co
         }
         jc[0] = j1[0]; jc[1] = j1[1]; j1[0] = j2[0]; j1[1] = j2[1]; j2[0] = j3[0]; j2[1] = j3[1];
     }
+}
+
+// ------------------------------------------------------------------ 32x32 IDCT + add on the matrix cores, workgroup tiles
+// What the measurements of round 2 say about the two kernels above (profiles/r02d_sq_counters_dot2_vs_mfma.txt): the dot2 form is
+// VALU-issue bound (737 VALU instructions per block pair keep the SIMDs 97 % busy: its time does not depend on the memory pattern at
+// all), the matrix-core form above needs 308 but waits 73 % of its life in s_waitcnt: its loop loads and stores under exec masks
+// (`if (ovalid)`), so the compiler cannot count what is in flight and falls back to vmcnt(0) - the prefetch never overlaps anything.
+// And the box itself moves this read/write mix at 5.2-5.3 TB/s when the pixels travel as 64-byte row pieces, 5.65-5.7 TB/s as 128- /
+// 256-byte pieces (tools/hbm_probe.hip, profiles/r02e_hbm_probe.jsonl).  So this form:
+//   * a workgroup owns a TILE of 8 blocks (256 samples wide when the blocks are horizontal neighbours, as they are in z-order / raster
+//     job lists): wave w transforms blocks 2w, 2w + 1 on the matrix cores exactly as above, the residuals of all four waves meet in one
+//     LDS strip and the epilogue moves whole 256-byte (8 bit) / 512-byte (16 bit) row segments;
+//   * the loop body has NO branch and no exec-masked memory operation (the host hands over whole tiles only; prefetch indices are
+//     clamped instead of predicated), so every s_waitcnt is an exact count: the coefficients of tile t + 1 (non-temporal loads: read
+//     exactly once) and the job records of tile t + 2 stay in flight across the transform and the stores of tile t;
+//   * prediction rows are requested at the top of an iteration, before the coefficient hand-over, and consumed at its end.
+template <typename Pixel, int MINW, bool ABLATE = false>
+__global__ __launch_bounds__(256, MINW) void tu_idct32_tile_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int ntiles,
+                                                             const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    constexpr int N = 32, CT = 2 * N * N * 2, SRS = 512 + 16, STRIP = N * SRS;      // 4096 bytes of coefficients per wave; strip rows of 256 int16 + pad
+    constexpr int PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 256 / CH_PX, RPI = 256 / CPR, ITER = N / RPI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * CT + STRIP];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 31, h = lane >> 5;
+    unsigned char *ctile = lds + wave * CT, *strip = lds + 4 * CT;
+    const v4i b1 = { kMfmaIdct.b1[lane][0], kMfmaIdct.b1[lane][1], kMfmaIdct.b1[lane][2], kMfmaIdct.b1[lane][3] };
+    const v4i a2 = { kMfmaIdct.a2[lane][0], kMfmaIdct.a2[lane][1], kMfmaIdct.a2[lane][2], kMfmaIdct.a2[lane][3] };
+    const int shift2 = 20 - bit_depth;
+    v16i init1, init2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        init1[r] = 64 + 128 * kMfmaIdct.colsum[n];                                       // + (1 << 6), then >> 7
+        init2[r] = (1 << (shift2 - 1)) + 128 * kMfmaIdct.colsum[mfma_k2(h, r)];
+    }
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int u = lane & 15;
+    const unsigned char *trp = ctile + (16 * h + (u >> 2)) * (N * 2) + (16 * ((lane >> 4) & 1) + 4 * (u & 3)) * 2;
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+    // epilogue: thread T owns 16 bytes of pixels of strip rows r0 + k * RPI, inside block `bsel` of the tile
+    const int c = tid % CPR, r0 = tid / CPR, bsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+
+    const int stride = gridDim.x, last = ntiles - 1;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;                                  // workgroup-uniform
+    // job records (16 bytes: x | y << 16, plane | .., coeff_off, ..): only the words a role needs are loaded
+    auto coff = [&](int t, int b) { return reinterpret_cast<const unsigned *>(jobs)[((size_t)(t < last ? t : last) * 8 + b) * 4 + 2]; };
+    auto erec = [&](int t) { return reinterpret_cast<const u32x2 *>(jobs)[((size_t)(t < last ? t : last) * 8 + bsel) * 2]; };
+    auto fetch = [&](unsigned o0, unsigned o1, u32x4 *cq) {                    // 4 x 16 bytes per lane = this wave's 2 blocks
+        const u32x4 *s0 = reinterpret_cast<const u32x4 *>(coeffs + o0), *s1 = reinterpret_cast<const u32x4 *>(coeffs + o1);
+        cq[0] = __builtin_nontemporal_load(s0 + lane); cq[1] = __builtin_nontemporal_load(s0 + 64 + lane);
+        cq[2] = __builtin_nontemporal_load(s1 + lane); cq[3] = __builtin_nontemporal_load(s1 + 64 + lane);
+    };
+    auto to_lds = [&](const u32x4 *cq) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4 *>(ctile + (q * 64 + lane) * 16) = cq[q];
+    };
+    // in flight at the top of iteration t: the coefficients of tile t + 1 (registers), the coefficient offsets of tile t + 2 (jn) and,
+    // requested there, of tile t + 3; this thread's epilogue records of tiles t, t + 1 and (requested) t + 2
+    u32x2 je = erec(tile), jen = erec(tile + stride);
+    u32x4 cq[4];
+    fetch(coff(tile, 2 * wave), coff(tile, 2 * wave + 1), cq);
+    to_lds(cq);
+    fetch(coff(tile + stride, 2 * wave), coff(tile + stride, 2 * wave + 1), cq);
+    unsigned jn[2] = { coff(tile + 2 * stride, 2 * wave), coff(tile + 2 * stride, 2 * wave + 1) };     // the tile whose coefficients are requested next
+    for (; tile < ntiles; tile += stride) {
+        const unsigned jnn[2] = { coff(tile + 3 * stride, 2 * wave), coff(tile + 3 * stride, 2 * wave + 1) };
+        const u32x2 jenn = erec(tile + 2 * stride);
+        __syncthreads();                                         // the previous tile's epilogue has read the strip
+        unsigned w[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32x2 v = lds_read_tr16(trp + g * (N * N * 2) + t * (4 * N * 2));
+                w[g][2 * t] = v.x; w[g][2 * t + 1] = v.y;
+            }
+        // prediction rows of this tile: requested now, consumed after the transform
+        const unsigned opl = je.y & 0xff;
+        const int ostride = PLANE_STRIDE3(planes, opl);
+        unsigned char *obase = PLANE_PTR3(planes, opl) + (size_t)(je.x >> 16) * ostride + (size_t)((je.x & 0xffff) + pxoff) * PXB;
+        u32x4 pr[ITER];
+#pragma unroll
+        for (int k = 0; k < ITER; k++) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride);
+        __builtin_amdgcn_wave_barrier();
+        // this wave's LDS copy is consumed (DS operations of a wave execute in order): the next tile's blocks move in, the ones after are requested
+        to_lds(cq);
+        fetch(jn[0], jn[1], cq);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            if constexpr (ABLATE) {          // bottleneck analysis only (NOT a transform): same memory and LDS traffic, no matrix work
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++)
+                    *reinterpret_cast<u32x2 *>(strip + n * SRS + (2 * wave + g) * (N * 2) + (8 * qq + 4 * h) * 2) = u32x2{ w[g][2 * qq], w[g][2 * qq + 1] };
+                continue;
+            }
+            // ---- pass 1
+            const v4i ahi = { hi_bytes(w[g][0], w[g][1]), hi_bytes(w[g][2], w[g][3]), hi_bytes(w[g][4], w[g][5]), hi_bytes(w[g][6], w[g][7]) };
+            const v4i alo = { lo_bytes(w[g][0], w[g][1]), lo_bytes(w[g][2], w[g][3]), lo_bytes(w[g][4], w[g][5]), lo_bytes(w[g][6], w[g][7]) };
+            const v16i dhi = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, b1, zero, 0, 0, 0);
+            const v16i dlo = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, b1, init1, 0, 0, 0);
+            unsigned pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                pk[q] = sat_pack_i16(((dhi[2 * q] << 8) + dlo[2 * q]) >> 7, ((dhi[2 * q + 1] << 8) + dlo[2 * q + 1]) >> 7);
+            // ---- pass 2
+            const v4i bhi = { hi_bytes(pk[0], pk[1]), hi_bytes(pk[2], pk[3]), hi_bytes(pk[4], pk[5]), hi_bytes(pk[6], pk[7]) };
+            const v4i blo = { lo_bytes(pk[0], pk[1]), lo_bytes(pk[2], pk[3]), lo_bytes(pk[4], pk[5]), lo_bytes(pk[6], pk[7]) };
+            const v16i ehi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, bhi, zero, 0, 0, 0);
+            const v16i elo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, blo, init2, 0, 0, 0);
+            // ---- residual row y = n of block 2 * wave + g: registers 4q'..4q'+3 are x = 8q' + 4h .. + 3
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                u32x2 v;
+                v.x = sat_pack_i16(((ehi[4 * qq] << 8) + elo[4 * qq]) >> shift2, ((ehi[4 * qq + 1] << 8) + elo[4 * qq + 1]) >> shift2);
+                v.y = sat_pack_i16(((ehi[4 * qq + 2] << 8) + elo[4 * qq + 2]) >> shift2, ((ehi[4 * qq + 3] << 8) + elo[4 * qq + 3]) >> shift2);
+                *reinterpret_cast<u32x2 *>(strip + n * SRS + (2 * wave + g) * (N * 2) + (8 * qq + 4 * h) * 2) = v;
+            }
+        }
+        __syncthreads();                                         // the strip is complete
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            const int rr = r0 + k * RPI;
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(strip + rr * SRS + c * CH_PX * 2);
+            u32x4 o;
+            if constexpr (PXB == 1) {
+                const u32x4 ra = rp[0], rb = rp[1];
+                const unsigned res[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+                const unsigned pd[4] = { pr[k].x, pr[k].y, pr[k].z, pr[k].w };
+                unsigned od[4];
+#pragma unroll
+                for (int d4 = 0; d4 < 4; d4++) {
+                    const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
+                    const unsigned a01 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4]), bitcast<s16x2>(u01)));
+                    const unsigned a23 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4 + 1]), bitcast<s16x2>(u23)));
+                    od[d4] = sat_pack_u8_i16(a01) | (sat_pack_u8_i16(a23) << 16);
+                }
+                o = u32x4{ od[0], od[1], od[2], od[3] };
+            } else {
+                const u32x4 ra = rp[0];
+                o = u32x4{ add_clamp_upx2(ra.x, pr[k].x, max2), add_clamp_upx2(ra.y, pr[k].y, max2),
+                           add_clamp_upx2(ra.z, pr[k].z, max2), add_clamp_upx2(ra.w, pr[k].w, max2) };
+            }
+            *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
+        }
+        jn[0] = jnn[0]; jn[1] = jnn[1]; je = jen; jen = jenn;
+    }
+}
+
+// ------------------------------------------------------------------ the same tiles, two of them ahead
+// The tile kernel above without its matrix work runs no faster (profiles/r02h): with 3-4 workgroups per CU and one tile of coefficients
+// per workgroup in flight a CU has ~96 KB outstanding, and this memory system needs about twice that to reach the 5.7 TB/s the same
+// access pattern gets from a kernel that is nothing but loads (tools/hbm_probe: mix31_tiled256_nt).  The register file is the only
+// place big enough to park requests (512 KB per CU against 160 KB of LDS), so this form spends registers on prefetch instead of on
+// the transform:
+//   * pass 2 runs TRANSPOSED (A = the pass-1 fragment, B = the constant matrix): the byte-plane correction 128 * sum_c T[c][x] then
+//     depends on the lane only, like pass 1's, and both become one register each instead of sixteen;
+//   * the low-byte product accumulates straight onto (high-byte product << 8) + that constant: 16 v_lshl_add between the two MFMAs of
+//     a pass instead of 16 after them, and only one 16-register accumulator is alive at a time;
+//   * what that frees holds a SECOND tile of coefficients: tiles t + 1 and t + 2 are in registers, t + 3 is requested while t is
+//     transformed; the loop is unrolled by two so that each register set keeps its name (no copies, every s_waitcnt an exact count).
+// Residuals now come out column-wise (lane = x, registers = 16 rows): the strip takes them as 2-byte stores.
+template <typename Pixel>
+__global__ __launch_bounds__(256, 4) void tu_idct32_tile2_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int ntiles,
+                                                                 const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    constexpr int N = 32, CT = 2 * N * N * 2, SRS = 512 + 16, STRIP = N * SRS;
+    constexpr int PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 256 / CH_PX, RPI = 256 / CPR, ITER = N / RPI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * CT + STRIP];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 31, h = lane >> 5;
+    unsigned char *ctile = lds + wave * CT, *strip = lds + 4 * CT;
+    const v4i b1 = { kMfmaIdct.b1[lane][0], kMfmaIdct.b1[lane][1], kMfmaIdct.b1[lane][2], kMfmaIdct.b1[lane][3] };
+    const v4i a2 = { kMfmaIdct.a2[lane][0], kMfmaIdct.a2[lane][1], kMfmaIdct.a2[lane][2], kMfmaIdct.a2[lane][3] };
+    const int shift2 = 20 - bit_depth;
+    const int k1 = 64 + 128 * kMfmaIdct.colsum[n], k2 = (1 << (shift2 - 1)) + 128 * kMfmaIdct.colsum[n];
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int u = lane & 15;
+    const unsigned char *trp = ctile + (16 * h + (u >> 2)) * (N * 2) + (16 * ((lane >> 4) & 1) + 4 * (u & 3)) * 2;
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+    const int c = tid % CPR, r0 = tid / CPR, bsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+    unsigned char *scol = strip + (2 * wave) * (N * 2) + n * 2 + (4 * h) * SRS;          // residual (row 4h, column n) of this wave's first block
+
+    const int stride = gridDim.x, last = ntiles - 1;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;                                  // workgroup-uniform
+    auto coff = [&](int t, int b) { return reinterpret_cast<const unsigned *>(jobs)[((size_t)(t < last ? t : last) * 8 + b) * 4 + 2]; };
+    auto erec = [&](int t) { return reinterpret_cast<const u32x2 *>(jobs)[((size_t)(t < last ? t : last) * 8 + bsel) * 2]; };
+    auto fetch = [&](unsigned o0, unsigned o1, u32x4 (&cq)[4]) {
+        const u32x4 *s0 = reinterpret_cast<const u32x4 *>(coeffs + o0), *s1 = reinterpret_cast<const u32x4 *>(coeffs + o1);
+        cq[0] = __builtin_nontemporal_load(s0 + lane); cq[1] = __builtin_nontemporal_load(s0 + 64 + lane);
+        cq[2] = __builtin_nontemporal_load(s1 + lane); cq[3] = __builtin_nontemporal_load(s1 + 64 + lane);
+    };
+    auto to_lds = [&](const u32x4 (&cq)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4 *>(ctile + (q * 64 + lane) * 16) = cq[q];
+    };
+    // one tile: its coefficients are in LDS; `cq` holds the next tile's and is refilled with the tile at offsets (f0, f1)
+    auto pixel_base = [&](const u32x2 je, int &ostride) {
+        const unsigned opl = je.y & 0xff;
+        ostride = PLANE_STRIDE3(planes, opl);
+        return PLANE_PTR3(planes, opl) + (size_t)(je.x >> 16) * ostride + (size_t)((je.x & 0xffff) + pxoff) * PXB;
+    };
+    auto load_pred = [&](const u32x2 je, u32x4 (&pr)[ITER]) {
+        int ostride;
+        const unsigned char *obase = pixel_base(je, ostride);
+#pragma unroll
+        for (int k = 0; k < ITER; k++) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride);
+    };
+    // One tile: its coefficients are in LDS, its prediction rows in `pr`.  `cq` holds the next tile's coefficients and is refilled with
+    // the tile at offsets (f0, f1); `prn` receives the next tile's prediction rows.  Requests leave in the order they are consumed
+    // (prediction rows of t + 1, then coefficients of t + 3): a wait for the oldest one never drains a younger one.
+    auto body = [&](u32x4 (&cq)[4], unsigned f0, unsigned f1, const u32x2 je, const u32x2 jen, const u32x4 (&pr)[ITER], u32x4 (&prn)[ITER]) {
+        __syncthreads();                                         // the previous tile's epilogue has read the strip
+        unsigned w[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u32x2 v = lds_read_tr16(trp + g * (N * N * 2) + t * (4 * N * 2));
+                w[g][2 * t] = v.x; w[g][2 * t + 1] = v.y;
+            }
+        load_pred(jen, prn);
+        __builtin_amdgcn_wave_barrier();
+        to_lds(cq);
+        fetch(f0, f1, cq);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            // ---- pass 1: D1[c][y], lane = y, registers = c
+            const v4i ahi = { hi_bytes(w[g][0], w[g][1]), hi_bytes(w[g][2], w[g][3]), hi_bytes(w[g][4], w[g][5]), hi_bytes(w[g][6], w[g][7]) };
+            const v4i alo = { lo_bytes(w[g][0], w[g][1]), lo_bytes(w[g][2], w[g][3]), lo_bytes(w[g][4], w[g][5]), lo_bytes(w[g][6], w[g][7]) };
+            v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, b1, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = (d[r] << 8) + k1;
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, b1, d, 0, 0, 0);
+            unsigned pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) pk[q] = sat_pack_i16(d[2 * q] >> 7, d[2 * q + 1] >> 7);
+            // ---- pass 2, transposed: D2[y][x] = sum_c P1[y][c] * T[c][x]: A = the pass-1 fragment, B = the matrix; lane = x, registers = y
+            const v4i phi = { hi_bytes(pk[0], pk[1]), hi_bytes(pk[2], pk[3]), hi_bytes(pk[4], pk[5]), hi_bytes(pk[6], pk[7]) };
+            const v4i plo = { lo_bytes(pk[0], pk[1]), lo_bytes(pk[2], pk[3]), lo_bytes(pk[4], pk[5]), lo_bytes(pk[6], pk[7]) };
+            v16i e = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, a2, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) e[r] = (e[r] << 8) + k2;
+            e = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, a2, e, 0, 0, 0);
+            // ---- register r = row (r & 3) + 8 (r >> 2) + 4 h of column n
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const unsigned v = sat_pack_i16(e[r] >> shift2, e[r + 1] >> shift2);
+                unsigned char *p0 = scol + g * (N * 2) + ((r & 3) + 8 * (r >> 2)) * SRS;
+                *reinterpret_cast<unsigned short *>(p0) = (unsigned short)(v & 0xffffu);
+                *reinterpret_cast<unsigned short *>(p0 + SRS) = (unsigned short)(v >> 16);
+            }
+        }
+        __syncthreads();                                         // the strip is complete
+        int ostride;
+        unsigned char *obase = pixel_base(je, ostride);
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            const int rr = r0 + k * RPI;
+            const u32x4 *rp = reinterpret_cast<const u32x4 *>(strip + rr * SRS + c * CH_PX * 2);
+            u32x4 o;
+            if constexpr (PXB == 1) {
+                const u32x4 ra = rp[0], rb = rp[1];
+                const unsigned res[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+                const unsigned pd[4] = { pr[k].x, pr[k].y, pr[k].z, pr[k].w };
+                unsigned od[4];
+#pragma unroll
+                for (int d4 = 0; d4 < 4; d4++) {
+                    const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
+                    const unsigned a01 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4]), bitcast<s16x2>(u01)));
+                    const unsigned a23 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4 + 1]), bitcast<s16x2>(u23)));
+                    od[d4] = sat_pack_u8_i16(a01) | (sat_pack_u8_i16(a23) << 16);
+                }
+                o = u32x4{ od[0], od[1], od[2], od[3] };
+            } else {
+                const u32x4 ra = rp[0];
+                o = u32x4{ add_clamp_upx2(ra.x, pr[k].x, max2), add_clamp_upx2(ra.y, pr[k].y, max2),
+                           add_clamp_upx2(ra.z, pr[k].z, max2), add_clamp_upx2(ra.w, pr[k].w, max2) };
+            }
+            *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
+        }
+    };
+
+    // at the top of a loop trip for tile t: LDS = t, pra = prediction rows of t, cqa = t + s, cqb = t + 2s; offsets j3 / j4 = tiles t + 3s /
+    // t + 4s; epilogue records je0 / je1 / je2 = tiles t, t + s, t + 2s
+    u32x4 cqa[4], cqb[4], pra[ITER], prb[ITER];
+    fetch(coff(tile, 2 * wave), coff(tile, 2 * wave + 1), cqa);
+    to_lds(cqa);
+    u32x2 je0 = erec(tile), je1 = erec(tile + stride), je2 = erec(tile + 2 * stride);
+    load_pred(je0, pra);
+    fetch(coff(tile + stride, 2 * wave), coff(tile + stride, 2 * wave + 1), cqa);
+    fetch(coff(tile + 2 * stride, 2 * wave), coff(tile + 2 * stride, 2 * wave + 1), cqb);
+    unsigned j3[2] = { coff(tile + 3 * stride, 2 * wave), coff(tile + 3 * stride, 2 * wave + 1) };
+    unsigned j4[2] = { coff(tile + 4 * stride, 2 * wave), coff(tile + 4 * stride, 2 * wave + 1) };
+    auto trip = [&]() {                                          // two tiles
+        const unsigned j5[2] = { coff(tile + 5 * stride, 2 * wave), coff(tile + 5 * stride, 2 * wave + 1) };
+        const unsigned j6[2] = { coff(tile + 6 * stride, 2 * wave), coff(tile + 6 * stride, 2 * wave + 1) };
+        const u32x2 je3 = erec(tile + 3 * stride), je4 = erec(tile + 4 * stride);
+        body(cqa, j3[0], j3[1], je0, je1, pra, prb);
+        body(cqb, j4[0], j4[1], je1, je2, prb, pra);
+        j3[0] = j5[0]; j3[1] = j5[1]; j4[0] = j6[0]; j4[1] = j6[1]; je0 = je2; je1 = je3; je2 = je4;
+        tile += 2 * stride;
+    };
+    // The first trip is peeled: the compiler's s_waitcnt counts at the loop head are the more cautious of "from the prologue" and "from
+    // the previous trip"; behind a whole trip both histories are the same and the counts in the loop stay exact.
+    if (tile + stride < ntiles) {
+        trip();
+        while (tile + stride < ntiles) trip();
+    }
+    if (tile < ntiles) body(cqa, j3[0], j3[1], je0, je1, pra, prb);      // an odd tile is left (what it requests is clamped and never used)
+}
+
+#endif  // OHEVC_LAB
+
+// ------------------------------------------------------------------ one tile per workgroup, no loop
+// The pure-traffic kernel below reaches the batch's ceiling (0.77 ms for 2^20 blocks at 8 bit) with nothing but occupancy: 8 short-lived
+// workgroups per CU, every one with its whole tile in flight from its first instruction.  The persistent forms above stay 9 % short of it
+// whatever their prefetch depth.  This form keeps the matrix-core transform of tile2 (transposed pass 2, chained accumulators: few
+// registers) and drops the loop: the strip re-uses the coefficient tiles' LDS (17 KB per workgroup), registers decide the occupancy.
+template <typename Pixel, int MINW>
+__global__ __launch_bounds__(256, MINW) void tu_idct32_tile1_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int ntiles,
+                                                                    const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    constexpr int N = 32, CT = 2 * N * N * 2, SRS = 512 + 16, STRIP = N * SRS;
+    constexpr int PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 256 / CH_PX, RPI = 256 / CPR, ITER = N / RPI;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STRIP > 4 * CT ? STRIP : 4 * CT];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    unsigned char *ctile = lds + wave * CT, *strip = lds;
+    const int c = tid % CPR, r0 = tid / CPR, bsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+    // ---- everything this workgroup will read from HBM is requested first
+    const unsigned *jw = reinterpret_cast<const unsigned *>(jobs) + (size_t)tile * 32;
+    const unsigned o0 = jw[(2 * wave) * 4 + 2], o1 = jw[(2 * wave + 1) * 4 + 2];
+    const u32x2 je = reinterpret_cast<const u32x2 *>(jw)[bsel * 2];
+    const u32x4 *s0 = reinterpret_cast<const u32x4 *>(coeffs + o0), *s1 = reinterpret_cast<const u32x4 *>(coeffs + o1);
+    u32x4 cq[4] = { __builtin_nontemporal_load(s0 + lane), __builtin_nontemporal_load(s0 + 64 + lane),
+                    __builtin_nontemporal_load(s1 + lane), __builtin_nontemporal_load(s1 + 64 + lane) };
+    const unsigned opl = je.y & 0xff;
+    const int ostride = PLANE_STRIDE3(planes, opl);
+    unsigned char *obase = PLANE_PTR3(planes, opl) + (size_t)(je.x >> 16) * ostride + (size_t)((je.x & 0xffff) + pxoff) * PXB;
+    u32x4 pr[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; k++) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride);
+    // ---- constants (while the loads fly)
+    const v4i b1 = { kMfmaIdct.b1[lane][0], kMfmaIdct.b1[lane][1], kMfmaIdct.b1[lane][2], kMfmaIdct.b1[lane][3] };
+    const v4i a2 = { kMfmaIdct.a2[lane][0], kMfmaIdct.a2[lane][1], kMfmaIdct.a2[lane][2], kMfmaIdct.a2[lane][3] };
+    const int shift2 = 20 - bit_depth;
+    const int k1 = 64 + 128 * kMfmaIdct.colsum[n], k2 = (1 << (shift2 - 1)) + 128 * kMfmaIdct.colsum[n];
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int u = lane & 15;
+    const unsigned char *trp = ctile + (16 * h + (u >> 2)) * (N * 2) + (16 * ((lane >> 4) & 1) + 4 * (u & 3)) * 2;
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+    unsigned char *scol = strip + (2 * wave) * (N * 2) + n * 2 + (4 * h) * SRS;
+#pragma unroll
+    for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4 *>(ctile + (q * 64 + lane) * 16) = cq[q];
+    __builtin_amdgcn_wave_barrier();
+    unsigned w[2][8];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u32x2 v = lds_read_tr16(trp + g * (N * N * 2) + t * (4 * N * 2));
+            w[g][2 * t] = v.x; w[g][2 * t + 1] = v.y;
+        }
+    __syncthreads();                                             // every wave has its coefficients in registers: the strip may overwrite the tiles
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const v4i ahi = { hi_bytes(w[g][0], w[g][1]), hi_bytes(w[g][2], w[g][3]), hi_bytes(w[g][4], w[g][5]), hi_bytes(w[g][6], w[g][7]) };
+        const v4i alo = { lo_bytes(w[g][0], w[g][1]), lo_bytes(w[g][2], w[g][3]), lo_bytes(w[g][4], w[g][5]), lo_bytes(w[g][6], w[g][7]) };
+        v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi, b1, zero, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) d[r] = (d[r] << 8) + k1;
+        d = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo, b1, d, 0, 0, 0);
+        unsigned pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) pk[q] = sat_pack_i16(d[2 * q] >> 7, d[2 * q + 1] >> 7);
+        const v4i phi = { hi_bytes(pk[0], pk[1]), hi_bytes(pk[2], pk[3]), hi_bytes(pk[4], pk[5]), hi_bytes(pk[6], pk[7]) };
+        const v4i plo = { lo_bytes(pk[0], pk[1]), lo_bytes(pk[2], pk[3]), lo_bytes(pk[4], pk[5]), lo_bytes(pk[6], pk[7]) };
+        v16i e = __builtin_amdgcn_mfma_i32_32x32x32_i8(phi, a2, zero, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) e[r] = (e[r] << 8) + k2;
+        e = __builtin_amdgcn_mfma_i32_32x32x32_i8(plo, a2, e, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const unsigned v = sat_pack_i16(e[r] >> shift2, e[r + 1] >> shift2);
+            unsigned char *p0 = scol + g * (N * 2) + ((r & 3) + 8 * (r >> 2)) * SRS;
+            *reinterpret_cast<unsigned short *>(p0) = (unsigned short)(v & 0xffffu);
+            *reinterpret_cast<unsigned short *>(p0 + SRS) = (unsigned short)(v >> 16);
+        }
+    }
+    __syncthreads();                                             // the strip is complete
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+        const int rr = r0 + k * RPI;
+        const u32x4 *rp = reinterpret_cast<const u32x4 *>(strip + rr * SRS + c * CH_PX * 2);
+        u32x4 o;
+        if constexpr (PXB == 1) {
+            const u32x4 ra = rp[0], rb = rp[1];
+            const unsigned res[8] = { ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w };
+            const unsigned pd[4] = { pr[k].x, pr[k].y, pr[k].z, pr[k].w };
+            unsigned od[4];
+#pragma unroll
+            for (int d4 = 0; d4 < 4; d4++) {
+                const unsigned u01 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c010c00u), u23 = __builtin_amdgcn_perm(0u, pd[d4], 0x0c030c02u);
+                const unsigned a01 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4]), bitcast<s16x2>(u01)));
+                const unsigned a23 = bitcast<unsigned>(__builtin_elementwise_add_sat(bitcast<s16x2>(res[2 * d4 + 1]), bitcast<s16x2>(u23)));
+                od[d4] = sat_pack_u8_i16(a01) | (sat_pack_u8_i16(a23) << 16);
+            }
+            o = u32x4{ od[0], od[1], od[2], od[3] };
+        } else {
+            const u32x4 ra = rp[0];
+            o = u32x4{ add_clamp_upx2(ra.x, pr[k].x, max2), add_clamp_upx2(ra.y, pr[k].y, max2),
+                       add_clamp_upx2(ra.z, pr[k].z, max2), add_clamp_upx2(ra.w, pr[k].w, max2) };
+        }
+        *reinterpret_cast<u32x4 *>(obase + (size_t)rr * ostride) = o;
+    }
+    (void)ntiles;
+}
+
+#ifdef OHEVC_LAB      // traffic-only / probe / ablation / software-pipelined dot2 kernels: bottleneck analysis, never shipped
+// Bottleneck analysis only (NOT a transform): the memory traffic of one tile per workgroup - coefficients, prediction rows, result rows at
+// the addresses the job records name - and nothing else: no LDS, no loop, 8 workgroups per CU.  What this reaches under bench.py is the
+// ceiling of the batch's own buffers and addressing for ANY residual kernel.
+template <typename Pixel>
+__global__ __launch_bounds__(256) void tu_tile_traffic_kernel(PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int ntiles,
+                                                              const int16_t *__restrict__ coeffs, int bit_depth)
+{
+    constexpr int N = 32, PXB = (int)sizeof(Pixel), CH_PX = 16 / PXB, CPR = 256 / CH_PX, RPI = 256 / CPR, ITER = N / RPI;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tile = blockIdx.x;
+    const int c = tid % CPR, r0 = tid / CPR, bsel = (c * CH_PX) / N, pxoff = (c * CH_PX) % N;
+    const u32x4 *jobv = reinterpret_cast<const u32x4 *>(jobs) + (size_t)tile * 8;
+    const u32x4 j0 = jobv[2 * wave], j1 = jobv[2 * wave + 1], je = jobv[bsel];
+    const u32x4 *s0 = reinterpret_cast<const u32x4 *>(coeffs + j0.z), *s1 = reinterpret_cast<const u32x4 *>(coeffs + j1.z);
+    const u32x4 c0 = __builtin_nontemporal_load(s0 + lane), c1 = __builtin_nontemporal_load(s0 + 64 + lane);
+    const u32x4 c2 = __builtin_nontemporal_load(s1 + lane), c3 = __builtin_nontemporal_load(s1 + 64 + lane);
+    const unsigned opl = je.y & 0xff;
+    const int ostride = PLANE_STRIDE3(planes, opl);
+    unsigned char *obase = PLANE_PTR3(planes, opl) + (size_t)(je.x >> 16) * ostride + (size_t)((je.x & 0xffff) + pxoff) * PXB;
+    u32x4 pr[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; k++) pr[k] = *reinterpret_cast<const u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride);
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+        pr[k].x += c0.x ^ c2.y; pr[k].y ^= c1.y + c3.z; pr[k].z += c2.z ^ c0.w; pr[k].w ^= c3.w + c1.x;
+        *reinterpret_cast<u32x4 *>(obase + (size_t)(r0 + k * RPI) * ostride) = pr[k];
+    }
+    (void)bit_depth;
 }
 
 // raw ds_read_b64_tr_b16 of a 2048-byte LDS image filled with int16 i at index i, every lane at its own byte address: what
@@ -739,6 +1249,8 @@ __global__ __launch_bounds__(256, (VARIANT & 8) ? 5 : 1) void tu_idct_add_pipe_k
         for (int q = 0; q < NQ; q++) cur[q] = nxt[q];
     }
 }
+
+#endif  // OHEVC_LAB
 
 // ------------------------------------------------------------------ 4x4 IDCT / DST: one lane per block
 template <typename Pixel, bool DST>
@@ -1084,16 +1596,27 @@ __global__ __launch_bounds__(256) void levels_kernel(PlaneSet planes, const Leve
 
 // ------------------------------------------------------------------ launcher
 int g_tu_variant = -1;    // set through ohevc_debug_set_tu_variant(); -1 = shipped configuration (see launch_idct)
-int g_tu_pipe_wgs = 2048; // workgroups of the persistent form (ohevc_debug_set_tu_pipe_workgroups)
+int g_tu_pipe_wgs = 2048; // workgroups of the persistent lab forms (ohevc_debug_set_tu_pipe_workgroups)
 
+#ifdef OHEVC_LAB
+// the A/B forms of the lab build (include/ohevc_debug.h lists the bits); returns false when `variant` names none of them
 template <int LOG2N, typename Pixel>
-static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
+static bool launch_idct_lab(int variant, int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
 {
-    // shipped configuration (A/B on MI355X, profiles/r01*_ab_tu_variants.txt): LDS-transposed, fully coalesced epilogue
-    // + non-accumulating chain starts / v_sat_pk_u8_i16 for 16x16 and 32x32; early prediction prefetch for 8x8
-    const int variant = g_tu_variant >= 0 ? g_tu_variant : (LOG2N >= 4 ? 16 + 128 : 1);
     if constexpr (LOG2N == 5) {
-        if (variant & 256) {     // matrix-core form; every wave loops over block pairs so that its constant operands are loaded once
+        if ((variant & 2048) && (variant & (4096 | 8192 | 16384 | 32768))) {      // loop forms of the tile kernel, its ablation, the traffic-only kernel
+            const int ntiles = njobs / 8, rest = njobs - ntiles * 8;
+            if (ntiles) {
+                const int pgrid = ntiles < g_tu_pipe_wgs ? ntiles : g_tu_pipe_wgs;
+                if (variant & 32768)      hipLaunchKernelGGL((tu_tile_traffic_kernel<Pixel>), dim3(ntiles), dim3(256), 0, st, ps, jobs, ntiles, coeffs, bit_depth);
+                else if (variant & 16384) hipLaunchKernelGGL((tu_idct32_tile2_kernel<Pixel>), dim3(pgrid), dim3(256), 0, st, ps, jobs, ntiles, coeffs, bit_depth);
+                else if (variant & 8192)  hipLaunchKernelGGL((tu_idct32_tile_kernel<Pixel, 3, true>), dim3(pgrid), dim3(256), 0, st, ps, jobs, ntiles, coeffs, bit_depth);
+                else                      hipLaunchKernelGGL((tu_idct32_tile_kernel<Pixel, 3>), dim3(pgrid), dim3(256), 0, st, ps, jobs, ntiles, coeffs, bit_depth);
+            }
+            if (rest) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16 + 128>), dim3(1), dim3(256), 0, st, ps, jobs + ntiles * 8, rest, coeffs, bit_depth);
+            return true;
+        }
+        if (variant & 256) {     // first matrix-core form; every wave loops over block pairs
             const int pairs = (njobs + 1) / 2, need = (pairs + 3) / 4, pgrid = need < g_tu_pipe_wgs ? need : g_tu_pipe_wgs;
             switch ((variant >> 9) & 3) {      // bit 9: prediction rows fetched early; bit 10: no register prefetch
             case 0: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 0>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
@@ -1101,9 +1624,10 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
             case 2: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 2>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
             case 3: hipLaunchKernelGGL((tu_idct32_mfma_kernel<Pixel, 3>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
             }
-            return;
+            return true;
         }
     }
+    if (variant & 2048) return false;
     if (variant & 4) {
         const int pgrid = grid < g_tu_pipe_wgs ? grid : g_tu_pipe_wgs;
         switch (variant & 9) {
@@ -1112,24 +1636,57 @@ static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohev
         case 8: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 8>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         case 9: hipLaunchKernelGGL((tu_idct_add_pipe_kernel<LOG2N, Pixel, 9>), dim3(pgrid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
         }
-        return;
+        return true;
     }
     if (variant & 96) {          // ablations: 32 = no LDS / no transform, 64 = LDS traffic kept, no transform
         if (variant & 32) hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
-        else                   hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
-        return;
+        else              hipLaunchKernelGGL((tu_ablation_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        return true;
+    }
+    if constexpr (LOG2N >= 4) {
+        if (variant & 512) {       // workgroup-wide epilogue of the dot2 form (256-sample strips); bit 10: non-temporal coefficient loads
+            if (variant & 1024) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 512 + 1024 + 128>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+            else                hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 512 + 128>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+            return true;
+        }
+    }
+    if (!(variant & 16) && (variant & 2)) {       // coefficients straight from HBM as int16 columns
+        if (variant & 1) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 3>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        else             hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 2>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        return true;
+    }
+    return false;
+}
+#endif
+
+template <int LOG2N, typename Pixel>
+static void launch_idct(int grid, hipStream_t st, const PlaneSet &ps, const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, int bit_depth)
+{
+    // Shipped configuration (A/B on MI355X, profiles/r02*_ab_tu_variants.txt, r02l_bench_ab.jsonl):
+    //   32x32  matrix-core tiles of 8 blocks, one per workgroup (tu_idct32_tile1_kernel); what is left of the batch (< 8 blocks) and the
+    //          segmented / level launches take the dot2 form;
+    //   16x16  dot2 form, wave-private coalesced epilogue, non-accumulating chain starts, non-temporal coefficient loads;
+    //   8x8    dot2 form with the prediction rows requested before the transform.
+    const int variant = g_tu_variant >= 0 ? g_tu_variant : (LOG2N == 5 ? 2048 + 16 + 128 + 1024 : LOG2N == 4 ? 16 + 128 + 1024 : 1);
+#ifdef OHEVC_LAB
+    if (launch_idct_lab<LOG2N, Pixel>(variant, grid, st, ps, jobs, njobs, coeffs, bit_depth)) return;
+#endif
+    if constexpr (LOG2N == 5) {
+        if (variant & 2048) {
+            const int ntiles = njobs / 8, rest = njobs - ntiles * 8;
+            if (ntiles) hipLaunchKernelGGL((tu_idct32_tile1_kernel<Pixel, 4>), dim3(ntiles), dim3(256), 0, st, ps, jobs, ntiles, coeffs, bit_depth);
+            if (rest) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16 + 128 + 1024>), dim3(1), dim3(256), 0, st, ps, jobs + ntiles * 8, rest, coeffs, bit_depth);
+            return;
+        }
     }
     if (variant & 16) {
-        if (variant & 128) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16 + 128>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
-        else               hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        if (variant & 1024)     hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16 + 128 + 1024>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        else if (variant & 128) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16 + 128>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+        else                    hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 16>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
         return;
     }
-    switch (variant & 3) {
-    case 0: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
-    case 1: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
-    case 2: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 2>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
-    case 3: hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 3>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth); break;
-    }
+    if (variant & 1) hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 1>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
+    else             hipLaunchKernelGGL((tu_idct_add_kernel<LOG2N, Pixel, 0>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, coeffs, bit_depth);
 }
 
 template <typename Pixel>
@@ -1283,31 +1840,56 @@ extern "C" int ohevc_debug_set_tu_pipe_workgroups(int n)
     return old;
 }
 
+extern "C" int ohevc_debug_has_lab(void)
+{
+#ifdef OHEVC_LAB
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int ohevc_debug_mfma_i8_probe(const void *a, const void *b, void *d, int nprobes, void *stream)
 {
     using namespace ohevc;
+#ifdef OHEVC_LAB
     OHEVC_REQUIRE(a && b && d && nprobes > 0, "null argument");
     hipLaunchKernelGGL(mfma_i8_probe_kernel, dim3(nprobes), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const v4i *>(a),
                        static_cast<const v4i *>(b), static_cast<v16i *>(d));
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+#else
+    (void)a; (void)b; (void)d; (void)nprobes; (void)stream;
+    OHEVC_REQUIRE(false, "probe kernels exist in the lab build only (make -C openhevc_amd/csrc LAB=1)");
+#endif
 }
 
 extern "C" int ohevc_debug_lds_tr16_probe(const void *addr, void *out, int nprobes, void *stream)
 {
     using namespace ohevc;
+#ifdef OHEVC_LAB
     OHEVC_REQUIRE(addr && out && nprobes > 0, "null argument");
     hipLaunchKernelGGL(lds_tr16_probe_kernel, dim3(nprobes), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const int *>(addr),
                        static_cast<u32x2 *>(out));
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+#else
+    (void)addr; (void)out; (void)nprobes; (void)stream;
+    OHEVC_REQUIRE(false, "probe kernels exist in the lab build only (make -C openhevc_amd/csrc LAB=1)");
+#endif
 }
 
 extern "C" const char *ohevc_tu_kernel_name(int bit_depth, int log2_size, int kind)
 {
     if (kind == OHEVC_TU_IDCT && log2_size == 5) {
-        const int variant = ohevc::g_tu_variant >= 0 ? ohevc::g_tu_variant : 16 + 128;
+        const int variant = ohevc::g_tu_variant >= 0 ? ohevc::g_tu_variant : 2048;
+#ifdef OHEVC_LAB
+        if ((variant & 2048) && (variant & 32768)) return "tu_tile_traffic_kernel";
+        if ((variant & 2048) && (variant & 16384)) return "tu_idct32_tile2_kernel";
+        if ((variant & 2048) && (variant & (4096 | 8192))) return "tu_idct32_tile_kernel";
         if (variant & 256) return "tu_idct32_mfma_kernel";
+#endif
+        if (variant & 2048) return "tu_idct32_tile1_kernel";
     }
     if (kind == OHEVC_TU_IDCT && log2_size >= 3) return "tu_idct_add_kernel";
     if (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4) return "tu_4x4_kernel";

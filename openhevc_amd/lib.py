@@ -56,9 +56,11 @@ def load_library():
     # first serves the whole process, and torch only works on its own copy -- so in a Python process torch must be
     # imported BEFORE this library is dlopen'ed.  (A plain C host links /opt/rocm's runtime and never sees torch.)
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        raise OhevcError(f"{LIB_PATH} is missing: run `make -C openhevc_amd/csrc` (or __graft_entry__.build()) first")
-    lib = bind_prototypes(C.CDLL(LIB_PATH))
+    # OHEVC_LAB_LIBRARY=1 (A/B sessions of tools/ only): the lab build, which carries the measurement kernels next to the shipped ones
+    path = os.path.join(HERE, "libohevc_hip_lab.so") if os.environ.get("OHEVC_LAB_LIBRARY") == "1" else LIB_PATH
+    if not os.path.exists(path):
+        raise OhevcError(f"{path} is missing: run `make -C openhevc_amd/csrc` (or __graft_entry__.build()) first")
+    lib = bind_prototypes(C.CDLL(path))
     _lib = lib
     return lib
 

@@ -92,11 +92,11 @@ static void *tu_mt_worker(void *p)
 void ohref_tu_batch_mt(int bd, int kind, int log2, int n, const int16_t *coeffs, uint8_t *plane,
                        ptrdiff_t stride, const int32_t *xy, int col_limit, int threads)
 {
-    pthread_t th[64];
-    struct tu_mt_arg a[64];
+    pthread_t th[256];
+    struct tu_mt_arg a[256];
     int nn = 1 << (2 * log2);
     if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
+    if (threads > 256) threads = 256;
     ensure(bd);
     for (int t = 0; t < threads; t++) {
         int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);

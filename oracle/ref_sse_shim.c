@@ -57,12 +57,12 @@ static void *mt_worker(void *p)
 int ohsse_idct_add_batch_mt(int bd, int log2, int n, const int16_t *coeffs, uint8_t *plane,
                             ptrdiff_t stride, const int32_t *xy, int threads)
 {
-    pthread_t th[64];
-    struct mt_arg a[64];
+    pthread_t th[256];
+    struct mt_arg a[256];
     int nn = 1 << (2 * log2);
     if (!pick_idct(bd, log2)) return -1;
     if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
+    if (threads > 256) threads = 256;
     for (int t = 0; t < threads; t++) {
         int lo = (int)((long long)n * t / threads), hi = (int)((long long)n * (t + 1) / threads);
         a[t] = (struct mt_arg){ bd, log2, hi - lo, coeffs + (size_t)lo * nn, plane, stride, xy + 2 * lo };

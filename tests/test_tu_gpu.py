@@ -37,11 +37,38 @@ def test_idct_add_bit_exact(oracle, bd, log2):
         check_batch(oracle, bd, log2, po.TU_IDCT, nblk, amp, seed=bd * 100 + log2 * 10 + nblk)
 
 
+PRODUCT_FORMS = [16 + 128, 16 + 128 + 1024, 2048 + 16 + 128 + 1024]           # dot2 strips, + nt loads, matrix-core tiles (shipped for 32x32)
+LAB_FORMS = [512 + 128, 512 + 128 + 1024, 2048 + 4096 + 144, 2048 + 16384 + 144]   # lab build only (ohevc_debug.h)
+
+
+@pytest.mark.parametrize("variant", PRODUCT_FORMS + LAB_FORMS)
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_idct_add_epilogue_forms_bit_exact(oracle, bd, variant):
+    """The A/B forms of the 16x16 / 32x32 kernel (ohevc_debug.h): wave-private 64-sample strips (16), workgroup-wide 256-sample strips
+    (512), non-temporal coefficient loads (1024) -- same pictures, including ragged tails (block counts that leave waves idle) and
+    blocks that are not horizontal neighbours."""
+    from openhevc_amd import lib as L
+    lib = L.load_library()
+    if variant in LAB_FORMS and not lib.ohevc_debug_has_lab():
+        pytest.skip("measurement kernel: lab build only")
+    old = lib.ohevc_debug_set_tu_variant(variant)
+    old_wgs = lib.ohevc_debug_set_tu_pipe_workgroups(3)      # the lab loop forms: workgroups walk several tiles each
+    try:
+        for log2 in (4, 5):
+            for nblk, amp, per_row in [(1, 1024, 7), (3, 1 << 15, 7), (9, 4096, 3), (64, 1024, 8), (257, 4096, 7), (1000, 200, 16), (48, 1 << 15, 8)]:
+                check_batch(oracle, bd, log2, po.TU_IDCT, nblk, amp, seed=variant + bd * 100 + log2 * 10 + nblk, per_row=per_row)
+    finally:
+        lib.ohevc_debug_set_tu_variant(old)
+        lib.ohevc_debug_set_tu_pipe_workgroups(old_wgs)
+
+
 @pytest.fixture(params=[0, 512, 1024, 1536])
 def mfma_variant(request):
     """32x32 blocks through the matrix-core kernel (ohevc_debug.h: bit 8 of the TU variant; bits 9 / 10 = its A/B forms)."""
     from openhevc_amd import lib as L
     lib = L.load_library()
+    if not lib.ohevc_debug_has_lab():
+        pytest.skip("first matrix-core form: lab build only")
     old = lib.ohevc_debug_set_tu_variant(16 + 128 + 256 + request.param)
     yield
     lib.ohevc_debug_set_tu_variant(old)
@@ -73,18 +100,24 @@ def test_idct32_matrix_core_form_extremes(oracle, mfma_variant):
         assert bad.size == 0, (bd, len(bad), bad[:6].tolist())
 
 
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 12])
 def test_idct_extreme_coefficients(oracle, bd):
-    """All-max / all-min / alternating coefficients drive both clip_int16 stages and the pixel clip."""
+    """All-max / all-min / alternating / single-coefficient blocks drive both clip_int16 stages and the pixel clip -- twelve blocks, so that
+    the 32x32 case goes through the shipped matrix-core tile kernel (8 blocks per workgroup: int16 inputs as two int8 planes, where
+    32767 and -32768 are the corners of the split) and through the dot2 form that takes what is left of a batch."""
     import gpu_util as G
     for log2 in (2, 3, 4, 5):
         n = 1 << log2
-        pats = [np.full((n, n), 32767), np.full((n, n), -32768), np.where(np.indices((n, n)).sum(0) % 2, 32767, -32768),
-                np.zeros((n, n))]
+        ii = np.indices((n, n))
+        pats = [np.full((n, n), 32767), np.full((n, n), -32768), np.where(ii.sum(0) % 2, 32767, -32768), np.zeros((n, n)),
+                np.where(ii[0] % 2, -32768, 32767), np.where(ii[1] % 2, 32640, -129), np.full((n, n), 32639), np.full((n, n), -32641),
+                np.zeros((n, n)), np.zeros((n, n)), np.full((n, n), 127), np.full((n, n), -128)]
         pats[3][0, 0] = 32767
+        pats[8][n - 1, n - 1] = -32768
+        pats[9][n // 2, 1] = 255
         coeffs = np.stack(pats).astype(np.int16)
-        plane = np.random.default_rng(3).integers(0, 1 << bd, size=(n, 4 * n)).astype(G.pixdt(bd))
-        xy = grid_xy(4, n, 4)
+        plane = np.random.default_rng(3).integers(0, 1 << bd, size=(n, len(pats) * n)).astype(G.pixdt(bd))
+        xy = grid_xy(len(pats), n, len(pats))
         want = oracle.tu_batch(bd, po.TU_IDCT, log2, coeffs, plane.copy(), xy)
         got = G.run_tu(bd, log2, po.TU_IDCT, [plane], G.make_tu_jobs(xy, n), coeffs)[0]
         assert np.array_equal(got, want), (bd, log2)

@@ -74,6 +74,32 @@ __global__ __launch_bounds__(256) void mix_kernel(u32x4 *__restrict__ px, const 
     px[i] = p;
 }
 
+// the residual kernel's REAL pixel addressing: a plane 16384 samples wide, cut into tiles of SW x 32 samples; a group of SW lanes
+// (one wave for SW = 64, the whole workgroup for SW = 256) owns a tile, reads its 4 * SW / 64 KB of coefficients linearly and its
+// 32 rows as SW-byte pieces, 16384 bytes apart; pixels updated in place.  SW = 64: the wave-private strips of tu_idct_add_kernel.
+template <int SW, bool NT>
+__global__ __launch_bounds__(256) void mix_tiled_kernel(unsigned char *__restrict__ px, const u32x4 *__restrict__ coef, int tiles)
+{
+    constexpr int LANES = SW;                             // lanes per tile: SW * 32 samples / 16 per chunk / 2 chunks per lane
+    constexpr int TPW = 256 / LANES;                      // tiles per workgroup
+    const int t = blockIdx.x * TPW + threadIdx.x / LANES, l = threadIdx.x % LANES;
+    if (t >= tiles) return;
+    constexpr int CPR = SW / 16;                          // 16-byte chunks per tile row
+    const int tiles_per_row = 16384 / SW;
+    unsigned char *base = px + (size_t)(t / tiles_per_row) * 32 * 16384 + (size_t)(t % tiles_per_row) * SW;
+    const u32x4 *cf = coef + (size_t)t * (SW * 32 * 2 / 16);
+    u32x4 c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = ld16<NT>(cf + k * LANES + l);
+    u32x4 p[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) p[k] = *reinterpret_cast<const u32x4 *>(base + (size_t)(l / CPR + k * (LANES / CPR)) * 16384 + (l % CPR) * 16);
+#pragma unroll
+    for (int k = 0; k < 2; k++) { p[k].x += c[2 * k].x; p[k].y ^= c[2 * k].y; p[k].z += c[2 * k + 1].z; p[k].w ^= c[2 * k + 1].w; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) *reinterpret_cast<u32x4 *>(base + (size_t)(l / CPR + k * (LANES / CPR)) * 16384 + (l % CPR) * 16) = p[k];
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b)); }
@@ -139,5 +165,16 @@ int main(int argc, char **argv)
     report("mix31_nt", s, 4.0 * bytes, "same, non-temporal coefficient loads");
     s = t.run(reps, [&](int r) { hipLaunchKernelGGL((mix_kernel<1, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (u32x4 *)a[r % RING], (const u32x4 *)b[(r + 1) % RING], n); });
     report("mix21", s, 3.0 * bytes, "16-bit residual pattern: 2 B coefficients + 2 B prediction read, 2 B written in place, per sample");
+    {   // tiled addressing: the pixel buffer as a 16384-wide plane
+        const int tiles64 = (int)(bytes / (64 * 32)), tiles128 = (int)(bytes / (128 * 32)), tiles256 = (int)(bytes / (256 * 32));
+        s = t.run(reps, [&](int r) { hipLaunchKernelGGL((mix_tiled_kernel<64, false>), dim3((unsigned)((tiles64 + 3) / 4)), dim3(256), 0, 0, (unsigned char *)a[r % RING], (const u32x4 *)c[(r + 1) % RING], tiles64); });
+        report("mix31_tiled64", s, 4.0 * bytes, "8-bit residual pattern on a 16384-wide plane, 64 x 32 tiles (64-byte row pieces)");
+        s = t.run(reps, [&](int r) { hipLaunchKernelGGL((mix_tiled_kernel<64, true>), dim3((unsigned)((tiles64 + 3) / 4)), dim3(256), 0, 0, (unsigned char *)a[r % RING], (const u32x4 *)c[(r + 1) % RING], tiles64); });
+        report("mix31_tiled64_nt", s, 4.0 * bytes, "same, non-temporal coefficient loads");
+        s = t.run(reps, [&](int r) { hipLaunchKernelGGL((mix_tiled_kernel<128, true>), dim3((unsigned)((tiles128 + 1) / 2)), dim3(256), 0, 0, (unsigned char *)a[r % RING], (const u32x4 *)c[(r + 1) % RING], tiles128); });
+        report("mix31_tiled128_nt", s, 4.0 * bytes, "128 x 32 tiles (one full line per row), nt coefficients");
+        s = t.run(reps, [&](int r) { hipLaunchKernelGGL((mix_tiled_kernel<256, true>), dim3((unsigned)tiles256), dim3(256), 0, 0, (unsigned char *)a[r % RING], (const u32x4 *)c[(r + 1) % RING], tiles256); });
+        report("mix31_tiled256_nt", s, 4.0 * bytes, "256 x 32 tiles (two full lines per row), nt coefficients");
+    }
     return 0;
 }
