@@ -39,8 +39,9 @@ int ohevc_debug_set_mc_variant(int variant);
  * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and
  * tests); written after the round's GPU budget was spent, so the A/B on the device is the first thing to do with it. */
 int ohevc_debug_set_sao_variant(int variant);
-/* ctx executor for intra dependency levels: 0 (shipped) issues one prediction launch and one residual launch per level;
- * 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel
+/* ctx executor for the intra-coded blocks of a picture: 2 (shipped) = ONE ohevc_dev_ctbs launch, coding-tree blocks as tasks with their
+ * samples in LDS (pictures whose intra jobs name no CTB size fall back to 0); 0 issues one prediction launch and one residual launch
+ * per dependency level; 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel
  * step barriers).  Same results.  Measured on MI355X with the real decoder (1080p, profiles/r01n_level_executor_ab.txt):
  * a step costs about as much as a kernel boundary (both are a chain of L2 round trips), so mode 1 only saves host-side
  * launch work and is currently the slower one.  Returns the old mode. */
@@ -64,6 +65,9 @@ int ohevc_debug_mc(struct ohevc_ctx *ctx, int small, const struct ohevc_mc_job *
 int ohevc_debug_level_count(struct ohevc_ctx *ctx);
 int ohevc_debug_level_intra(struct ohevc_ctx *ctx, int level, const struct ohevc_intra_job **jobs, int *n);
 int ohevc_debug_level_tu(struct ohevc_ctx *ctx, int level, int log2_size, int kind, const struct ohevc_tu_job **jobs, int *n);
+/* the intra work of the CTB executor (level launch mode 2): tasks in raster order, their operation words (ohevc_dev_ctbs) and the job arrays they index */
+int ohevc_debug_ctbs(struct ohevc_ctx *ctx, const struct ohevc_ctb_task **tasks, int *ntasks, const uint32_t **ops, const struct ohevc_intra_job **intra_jobs,
+                     const struct ohevc_tu_job **tu_jobs, int *log2_ctb_size);
 int ohevc_debug_arena(struct ohevc_ctx *ctx, const int16_t **coeffs, const struct ohevc_intra_cip **cips);
 int ohevc_debug_filters(struct ohevc_ctx *ctx, const struct ohevc_dbk_job **vertical, int *n_vertical, const struct ohevc_dbk_job **horizontal,
                         int *n_horizontal, const struct ohevc_sao_job **sao, int *n_sao, struct ohevc_sao_bypass *bypass /* HOST map */);

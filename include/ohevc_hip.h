@@ -226,7 +226,8 @@ typedef struct ohevc_intra_job {        /* 16 bytes */
     uint8_t  bottom_left_size;          /* valid samples below the block in the left column (0..N) */
     uint8_t  top_right_size;            /* valid samples right of the block in the top row (0..N) */
     uint8_t  flags2;                    /* OHEVC_INTRA2_* */
-    uint8_t  reserved;
+    uint8_t  log2_ctb_size;             /* 4..6 when the maker knew it (ohevc_intra_make_job*: geom->log2_ctb_size), else 0: the ctx layer
+                                           groups intra work by CTB (2.6b) only when every job of the picture names the same size */
     uint32_t cip_index;                 /* OHEVC_INTRA2_CIP: index of this job's ohevc_intra_cip record */
 } ohevc_intra_job;
 
@@ -266,6 +267,27 @@ int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_lev
                      uint32_t *sync, const uint32_t *need, const ohevc_intra_job *intra_jobs, const ohevc_intra_cip *cips,
                      const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream);
 
+
+/* ---- 2.6b every intra-coded block of a picture in ONE launch, coding-tree blocks as tasks (the ctx layer's executor).  Inside a CTB the
+ * reference reconstructs block after block in decoding order -- intra_pred[..] (hevcpred_template.c:30-357), then the residual of
+ * that block (hevc_cabac.c:1868-1949), whose samples the next block's prediction reads; between CTBs only the wavefront order of
+ * hls_decode_entry_wpp remains (a CTB reads its left, above-left, above and above-right neighbours; hevc.c:2779).  A task is one CTB:
+ *   tasks[t]   CTB position in CTB units, its run of `ops`, and up to four tasks it must wait for (indices < t, -1 = none): tasks
+ *              must be listed so that every dependency comes earlier (raster order of the CTBs does);
+ *   ops[]      the CTB's operations in decoding order: bit 31 = 0: intra prediction of intra_jobs[bits 24..0];
+ *              bit 31 = 1: residual of tu_jobs[bits 24..0], size log2 = 2 + bits 30..29, kind = bits 28..25 (OHEVC_TU_*);
+ *   sync       DEVICE array of ntasks + 2 zeroed uint32 (consumed by the launch).
+ * Job records are the ones of 2.1 / 2.5, positions in plane samples of the whole picture.  Results are identical to running the
+ * operations one after the other through ohevc_dev_intra_batch_cip / ohevc_dev_tu_batch in a valid order. */
+typedef struct ohevc_ctb_task {         /* 32 bytes */
+    uint16_t cx, cy;                    /* CTB position, in CTBs */
+    uint32_t first_op, nops;
+    int32_t  dep[4];                    /* tasks of the left, above-left, above, above-right CTB, or -1 */
+    uint32_t reserved;
+} ohevc_ctb_task;
+int ohevc_dev_ctbs(const ohevc_plane planes[3], int bit_depth, int chroma_format_idc, int log2_ctb_size, const ohevc_ctb_task *tasks, int ntasks,
+                   const uint32_t *ops, const ohevc_intra_job *intra_jobs, const ohevc_intra_cip *cips, const ohevc_tu_job *tu_jobs,
+                   const int16_t *coeffs, uint32_t *sync, void *stream);
 
 /* Host helper (no GPU work): turn one intra_pred[log2-2](s, x0, y0, c_idx) call of the reference into a job.
  * Inputs are exactly what the reference's front-end holds at the call site (hevc.c:1214-1215): the block position

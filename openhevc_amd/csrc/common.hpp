@@ -5,6 +5,13 @@
 #include <stdio.h>
 #include "ohevc_hip.h"
 
+// a constant table defined in a header (one copy per translation unit); the host emulation of tests/hipemu spells __constant__ itself
+#ifdef OHEVC_HIPEMU
+#define OHEVC_CONST_TABLE static const
+#else
+#define OHEVC_CONST_TABLE static __constant__
+#endif
+
 namespace ohevc {
 
 // ---- error plumbing: every HIP failure is recorded (thread-local) and surfaces as OHEVC_ERR_HIP

@@ -83,9 +83,12 @@ struct LevelBins {
 }  // namespace
 
 static std::atomic<uint64_t> g_ctx_gen{1};
+// executor of the intra-coded blocks: 2 (shipped) = one ohevc_dev_ctbs launch per picture, CTBs as tasks with their samples in LDS;
+// 0 = one prediction launch and one residual launch per dependency level; 1 = all levels inside one ohevc_dev_levels launch.
+// Modes 0 / 1 also serve pictures whose intra jobs do not name a CTB size.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
-static int g_level_launch = 0;        // ohevc_debug_set_level_launch: 0 = two launches per level (shipped), 1 = all intra levels in one launch
+static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
 // OHEVC_TRACE_AT=plane,x,y: print every recorded job whose block covers that sample (diagnosis of a mismatching block)
@@ -119,6 +122,11 @@ struct Rec {
     std::vector<ohevc_mc_job> mc, mc_small;              // tiles of at most 16x16 / at most 8x8 samples
     std::vector<LevelBins> levels;                         // [level]; entries 0..max_level are live
     int max_level = -1;
+    // intra work in recording (= decoding) order, for the CTB executor (ohevc_dev_ctbs): one word per operation as the kernel reads it
+    // (bit 31 residual / prediction, size, kind, index into the arrays below) next to the CTB it belongs to
+    std::vector<ohevc_intra_job> ctb_intra;
+    std::vector<ohevc_tu_job> ctb_tu;
+    std::vector<std::pair<uint32_t, uint32_t>> ctb_ops;    // (CTB raster index, operation word)
     std::vector<int16_t> coeffs;
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
@@ -157,6 +165,11 @@ struct ohevc_ctx : Rec {
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
     int lm_w[3] = {}, lm_h[3] = {};
+    int frame_mode = 0;               // g_level_launch as it was at frame_begin (one executor per picture)
+    int log2_ctb = 0;                 // CTB size named by the picture's intra jobs (0: none seen yet, -1: they disagree)
+    std::vector<ohevc_ctb_task> ctb_tasks;                // scratch of frame_reconstruct
+    std::vector<uint32_t> ctb_opwords, ctb_sync_zero;
+    std::vector<int32_t> ctb_task_of;
 
     DevBuf d_jobs, d_coeffs, d_table, d_upsample;
     PinnedBuf stage;
@@ -526,6 +539,7 @@ static inline LevelBins &level_bins(Rec &r, int level)
 static void clear_rec(Rec &r)
 {
     r.mc.clear(); r.mc_small.clear(); r.coeffs.clear(); r.cips.clear();
+    r.ctb_intra.clear(); r.ctb_tu.clear(); r.ctb_ops.clear();
     for (int l = 0; l <= r.max_level; l++) {
         LevelBins &lb = r.levels[l];
         for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
@@ -549,6 +563,27 @@ static void merge_side(ohevc_ctx *c)
         const uint32_t cbase = (uint32_t)c->coeffs.size(), ibase = (uint32_t)c->cips.size();
         c->coeffs.insert(c->coeffs.end(), r.coeffs.begin(), r.coeffs.end());
         c->cips.insert(c->cips.end(), r.cips.begin(), r.cips.end());
+        {   // CTB-ordered intra work: a CTB is decoded by one thread, so its operations stay contiguous and in order
+            const uint32_t jbase = (uint32_t)c->ctb_intra.size(), tbase = (uint32_t)c->ctb_tu.size();
+            for (ohevc_intra_job j : r.ctb_intra) {
+                if (j.flags2 & OHEVC_INTRA2_CIP) j.cip_index += ibase;
+                c->ctb_intra.push_back(j);
+            }
+            c->ctb_tu.insert(c->ctb_tu.end(), r.ctb_tu.begin(), r.ctb_tu.end());      // arena offsets are rebased through the op words below
+            for (auto op : r.ctb_ops) {
+                uint32_t w = op.second;
+                if (w >> 31) {
+                    const int kind = (int)((w >> 25) & 15u);
+                    ohevc_tu_job &j = c->ctb_tu[tbase + (w & 0x1ffffffu)];
+                    if (kind != OHEVC_TU_DC) j.coeff_off += cbase;
+                    if (kind == OHEVC_TU_CROSS) j.reserved1 += cbase;
+                    w += tbase;
+                } else {
+                    w += jbase;
+                }
+                c->ctb_ops.emplace_back(op.first, w);
+            }
+        }
         for (int l = 0; l <= r.max_level; l++) {
             LevelBins &src = r.levels[l];
             if (!src.touched && src.intra.empty()) continue;
@@ -597,6 +632,8 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     }
     c->ref_slots.clear();
     c->target_guarded = false;
+    c->frame_mode = g_level_launch;
+    c->log2_ctb = 0;
     for (int i = 0; i < 3; i++) {
         c->lm_w[i] = (p->planes[i].width + 3) >> 2;
         c->lm_h[i] = (p->planes[i].height + 3) >> 2;
@@ -615,6 +652,17 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     return OHEVC_OK;
 }
 
+// CTB executor (frame_mode 2): the raster index of the CTB that holds sample (x, y) of `plane`
+static inline uint32_t ctb_index(const ohevc_ctx *c, const Picture *p, int plane, int x, int y, int log2_ctb)
+{
+    const int hs = plane ? (p->cfi == 1 || p->cfi == 2) : 0, vs = plane ? (p->cfi == 1) : 0;
+    const int ctb_w = (p->w + (1 << log2_ctb) - 1) >> log2_ctb;
+    (void)c;
+    return (uint32_t)(((y << vs) >> log2_ctb) * ctb_w + ((x << hs) >> log2_ctb));
+}
+// does the residual of an intra-predicted block go to the CTB executor?  (yes once the picture's intra jobs have named a CTB size)
+static inline bool ctb_mode(const ohevc_ctx *c) { return c->frame_mode == 2 && __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED) > 0; }
+
 extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
@@ -631,6 +679,14 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
     } else {
         j.coeff_off = (uint32_t)r.coeffs.size();
         r.coeffs.insert(r.coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
+    }
+    if (intra && ctb_mode(c)) {                               // follows its block's prediction inside the CTB's task
+        if (trace_hit(plane, x, y, n, n))
+            fprintf(stderr, "trace: target %d tu plane %d x %d y %d log2 %d kind %d (ctb task) c0 %d\n", c->cur, plane, x, y, log2, kind, coeffs[0]);
+        r.ctb_ops.emplace_back(ctb_index(c, p, plane, x, y, c->log2_ctb), 0x80000000u | ((uint32_t)(log2 - 2) << 29) | ((uint32_t)kind << 25) | (uint32_t)r.ctb_tu.size());
+        r.ctb_tu.push_back(j);
+        r.nstat[0]++;
+        return OHEVC_OK;
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
     if (trace_hit(plane, x, y, n, n))
@@ -664,6 +720,12 @@ extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log
     if (kind_c >= 0) {
         j.coeff_off = (uint32_t)r.coeffs.size();
         r.coeffs.insert(r.coeffs.end(), coeffs_c, coeffs_c + n * n);
+    }
+    if (intra && ctb_mode(c)) {
+        r.ctb_ops.emplace_back(ctb_index(c, p, plane, x, y, c->log2_ctb), 0x80000000u | ((uint32_t)(log2 - 2) << 29) | ((uint32_t)OHEVC_TU_CROSS << 25) | (uint32_t)r.ctb_tu.size());
+        r.ctb_tu.push_back(j);
+        r.nstat[0]++;
+        return OHEVC_OK;
     }
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
     LevelBins &lb = level_bins(r, level);
@@ -729,6 +791,24 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(job->plane < 3 && job->log2_size >= 2 && job->log2_size <= 5 && job->mode <= 34, "bad intra job");
     const int pl = job->plane, n = 1 << job->log2_size, W = c->lm_w[pl], H = c->lm_h[pl];
     OHEVC_REQUIRE(job->x + n <= p->planes[pl].width && job->y + n <= p->planes[pl].height, "intra block outside plane");
+    if (c->frame_mode == 2) {
+        // the CTB executor needs the CTB size; the picture's first intra job decides (jobs built without it: dependency levels)
+        int l2 = __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED);
+        if (l2 == 0) {
+            l2 = job->log2_ctb_size >= 4 && job->log2_ctb_size <= 6 && n <= (1 << job->log2_ctb_size) ? job->log2_ctb_size : -1;
+            __atomic_store_n(&c->log2_ctb, l2, __ATOMIC_RELAXED);
+        }
+        if (l2 > 0) {
+            OHEVC_REQUIRE(job->log2_ctb_size == l2, "the intra jobs of one picture must name one CTB size");
+            if (trace_hit(pl, job->x, job->y, n, n))
+                fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d (ctb task)\n", c->cur, pl, job->x,
+                        job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size);
+            r.ctb_ops.emplace_back(ctb_index(c, p, pl, job->x, job->y, l2), (uint32_t)r.ctb_intra.size());
+            r.ctb_intra.push_back(*job);
+            r.nstat[2]++;
+            return OHEVC_OK;
+        }
+    }
     // dependency level = 1 + the highest level among the 4x4 cells this block may read (row above incl. corner and
     // above-right, column to the left incl. below-left): hevcpred_template.c:164-183
     // With slice threads (ohevc_ctx_set_concurrent) the cells of a neighbouring tile / WPP row are written by another thread while
@@ -931,18 +1011,48 @@ static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>
     return OHEVC_OK;
 }
 
+// CTB executor: sort the recorded intra operations by CTB (stable: decoding order inside a CTB is kept) and cut them into tasks, one per
+// CTB, in raster order; a task waits for the tasks of its left, above-left, above and above-right CTB (hevc.c:2779).
+static void build_ctb_tasks(ohevc_ctx *c, const Picture *p)
+{
+    c->ctb_tasks.clear(); c->ctb_opwords.clear();
+    if (c->ctb_ops.empty()) return;
+    const int l2 = c->log2_ctb, ctb_w = (p->w + (1 << l2) - 1) >> l2, ctb_h = (p->h + (1 << l2) - 1) >> l2;
+    std::stable_sort(c->ctb_ops.begin(), c->ctb_ops.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
+    c->ctb_task_of.assign((size_t)ctb_w * ctb_h, -1);
+    c->ctb_opwords.reserve(c->ctb_ops.size());
+    for (size_t i = 0; i < c->ctb_ops.size(); i++) {
+        const uint32_t ctb = c->ctb_ops[i].first;
+        if (c->ctb_tasks.empty() || i == 0 || ctb != c->ctb_ops[i - 1].first) {
+            ohevc_ctb_task t = {};
+            t.cx = (uint16_t)(ctb % ctb_w); t.cy = (uint16_t)(ctb / ctb_w);
+            t.first_op = (uint32_t)i;
+            const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+            for (int d = 0; d < 4; d++) {
+                const int x = t.cx + nb[d][0], y = t.cy + nb[d][1];
+                t.dep[d] = x >= 0 && y >= 0 && x < ctb_w ? c->ctb_task_of[(size_t)y * ctb_w + x] : -1;
+            }
+            c->ctb_task_of[ctb] = (int32_t)c->ctb_tasks.size();
+            c->ctb_tasks.push_back(t);
+        }
+        c->ctb_tasks.back().nops++;
+        c->ctb_opwords.push_back(c->ctb_ops[i].second);
+    }
+}
+
 extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     merge_side(c);
+    build_ctb_tasks(c, p);
     if (c->dry) {
         if (g_sink) g_sink(g_sink_user, c, 0);
         clear_recorded(c);
         return OHEVC_OK;
     }
     OHEVC_HIP_TRY(hipSetDevice(c->device));
-    if (c->mc.empty() && c->mc_small.empty() && c->max_level < 0) return OHEVC_OK;
+    if (c->mc.empty() && c->mc_small.empty() && c->max_level < 0 && c->ctb_tasks.empty()) return OHEVC_OK;
     int rc = upload_table(c);
     if (rc != OHEVC_OK) return rc;
     if ((rc = guard_pictures(c, c->cur)) != OHEVC_OK) return rc;
@@ -1010,6 +1120,14 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_sync = phases.empty() ? 0 : stage_put(parts, total, c->sync_zero.data(), c->sync_zero.size() * sizeof(uint32_t));
     const size_t off_coeffs = c->coeffs.empty() ? 0 : stage_put(parts, total, c->coeffs.data(), c->coeffs.size() * sizeof(int16_t));
     const size_t off_cips = c->cips.empty() ? 0 : stage_put(parts, total, c->cips.data(), c->cips.size() * sizeof(ohevc_intra_cip));
+    // CTB executor: tasks, operation words, the jobs they index, zeroed sync words (home XCD, ticket, one done flag per task)
+    const bool ctbs = !c->ctb_tasks.empty();
+    c->ctb_sync_zero.assign(ctbs ? c->ctb_tasks.size() + 2 : 0, 0u);
+    const size_t off_ct = ctbs ? stage_put(parts, total, c->ctb_tasks.data(), c->ctb_tasks.size() * sizeof(ohevc_ctb_task)) : 0;
+    const size_t off_co = ctbs ? stage_put(parts, total, c->ctb_opwords.data(), c->ctb_opwords.size() * sizeof(uint32_t)) : 0;
+    const size_t off_ci = ctbs && !c->ctb_intra.empty() ? stage_put(parts, total, c->ctb_intra.data(), c->ctb_intra.size() * sizeof(ohevc_intra_job)) : 0;
+    const size_t off_cu = ctbs && !c->ctb_tu.empty() ? stage_put(parts, total, c->ctb_tu.data(), c->ctb_tu.size() * sizeof(ohevc_tu_job)) : 0;
+    const size_t off_cs = ctbs ? stage_put(parts, total, c->ctb_sync_zero.data(), c->ctb_sync_zero.size() * sizeof(uint32_t)) : 0;
     if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
     unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
     const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
@@ -1071,6 +1189,14 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
                               reinterpret_cast<const ohevc_intra_job *>(base + intra_base),
                               c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips),
                               reinterpret_cast<const ohevc_tu_job *>(base + tu_base), d_coeffs, c->stream);
+        if (rc != OHEVC_OK) return rc;
+        c->stats.launches++;
+    }
+    if (ctbs) {      // every intra-coded block of the picture: one launch, behind inter prediction and the residuals of inter blocks
+        rc = ohevc_dev_ctbs(p->planes, p->bd, p->cfi, c->log2_ctb, reinterpret_cast<const ohevc_ctb_task *>(base + off_ct), (int)c->ctb_tasks.size(),
+                            reinterpret_cast<const uint32_t *>(base + off_co), reinterpret_cast<const ohevc_intra_job *>(base + off_ci),
+                            c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips),
+                            reinterpret_cast<const ohevc_tu_job *>(base + off_cu), d_coeffs, reinterpret_cast<uint32_t *>(base + off_cs), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
     }
@@ -1222,6 +1348,15 @@ extern "C" int ohevc_debug_level_tu(ohevc_ctx *c, int level, int log2, int kind,
                   jobs != nullptr && n != nullptr, "bad bin");
     const auto &v = c->levels[level].tu[log2 - 2][kind];
     *jobs = v.data(); *n = (int)v.size();
+    return OHEVC_OK;
+}
+extern "C" int ohevc_debug_ctbs(ohevc_ctx *c, const ohevc_ctb_task **tasks, int *ntasks, const uint32_t **ops, const ohevc_intra_job **intra_jobs,
+                                const ohevc_tu_job **tu_jobs, int *log2_ctb_size)
+{
+    OHEVC_REQUIRE(c != nullptr && tasks && ntasks && ops && intra_jobs && tu_jobs, "null argument");
+    *tasks = c->ctb_tasks.data(); *ntasks = (int)c->ctb_tasks.size(); *ops = c->ctb_opwords.data();
+    *intra_jobs = c->ctb_intra.data(); *tu_jobs = c->ctb_tu.data();
+    if (log2_ctb_size) *log2_ctb_size = c->log2_ctb;
     return OHEVC_OK;
 }
 extern "C" int ohevc_debug_arena(ohevc_ctx *c, const int16_t **coeffs, const ohevc_intra_cip **cips)

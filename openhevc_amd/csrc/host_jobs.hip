@@ -120,6 +120,7 @@ static int make_job_common(const ohevc_intra_geom *g, int lpu, const uint8_t *pf
     out->flags = (uint8_t)f;
     out->bottom_left_size = (uint8_t)bl_size;
     out->top_right_size = (uint8_t)tr_size;
+    out->log2_ctb_size = (uint8_t)(g->log2_ctb_size >= 4 && g->log2_ctb_size <= 6 ? g->log2_ctb_size : 0);
     if (cipmode) {
         out->flags2 |= OHEVC_INTRA2_CIP;
         memset(cip, 0, sizeof(*cip));

@@ -116,7 +116,7 @@ assert SAO_JOB.itemsize == 32
 INTRA_BOTTOM_LEFT, INTRA_LEFT, INTRA_UP_LEFT, INTRA_UP, INTRA_UP_RIGHT = 1, 2, 4, 8, 16
 INTRA_NO_SMOOTHING, INTRA_STRONG, INTRA_LUMA_EDGE = 32, 64, 128
 INTRA_JOB = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("log2_size", "u1"), ("mode", "u1"), ("flags", "u1"),
-                      ("bottom_left_size", "u1"), ("top_right_size", "u1"), ("flags2", "u1"), ("reserved", "u1"), ("cip_index", "<u4")])
+                      ("bottom_left_size", "u1"), ("top_right_size", "u1"), ("flags2", "u1"), ("log2_ctb_size", "u1"), ("cip_index", "<u4")])
 assert INTRA_JOB.itemsize == 16
 INTRA2_CIP = 1
 INTRA_CIP = np.dtype([("top_bits", "u1", (9,)), ("left_bits", "u1", (9,)), ("size_max_x", "u1"), ("size_max_y", "u1"),

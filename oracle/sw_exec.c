@@ -261,6 +261,23 @@ void ohsw_sink(void *user, struct ohevc_ctx *ctx, int stage)
                     if (ohevc_debug_level_tu(ctx, level, log2, kind, &tj, &n) == OHEVC_OK && n) exec_tu(&cur, bd, log2, kind, tj, n, coeffs);
                 }
         }
+        {   /* the CTB executor's share (ohevc_dev_ctbs): tasks in raster order, every task's operations in decoding order */
+            const ohevc_ctb_task *tasks;
+            const uint32_t *ops;
+            const ohevc_intra_job *ij;
+            const ohevc_tu_job *tj;
+            int ntasks = 0, l2 = 0;
+            if (ohevc_debug_ctbs(ctx, &tasks, &ntasks, &ops, &ij, &tj, &l2) != OHEVC_OK) { g_sw_error = 1; return; }
+            for (int t = 0; t < ntasks; t++) {
+                for (int d = 0; d < 4; d++)
+                    if (tasks[t].dep[d] >= t) g_sw_error = 1;              /* a task may only wait for earlier ones */
+                for (uint32_t k = 0; k < tasks[t].nops; k++) {
+                    const uint32_t op = ops[tasks[t].first_op + k], idx = op & 0x1ffffffu;
+                    if (!(op >> 31)) exec_intra(&cur, bd, ij + idx, 1, cips);
+                    else exec_tu(&cur, bd, 2 + (int)((op >> 29) & 3), (int)((op >> 25) & 15), tj + idx, 1, coeffs);
+                }
+            }
+        }
     } else {
         exec_filters(ctx, &cur, bd);
     }

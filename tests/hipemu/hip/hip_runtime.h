@@ -224,6 +224,11 @@ template <typename T> static inline T atomicMin(T *p, T v)
     while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
     return old;
 }
+template <typename T> static inline T atomicCAS(T *p, T expected, T desired)
+{
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return expected;
+}
 template <typename T> static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 template <typename T> static inline T atomicExch(T *p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 static inline int min(int a, int b) { return a < b ? a : b; }

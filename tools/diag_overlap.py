@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Do the kernels of different decoding threads overlap on the device?
+
+    rocprofv3 --kernel-trace -d OUT -o t -- python tools/diag_overlap.py decode <threads> [natural]
+    python tools/diag_overlap.py analyze OUT/t_results.db
+
+decode : synthetic 1080p random-access stream (33 pictures) through the hooked reference decoder with <threads> frame threads; prints fps.
+analyze: from the kernel-dispatch timestamps: kernels, sum of their durations, the union of their busy intervals (= device time with at
+         least one kernel running), the span from the first start to the last end, and how many hardware queues carried them."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def decode(threads, natural):
+    from oracle import pystream as ps
+    kw = dict(gop="random_access", nframes=33, seed=7, width=1920, height=1080, log2_ctb=6)
+    if natural:
+        kw.update(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
+                                          split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
+    aus, _ = ps.generate(ps.StreamParams(**kw))
+    ps.decode_stream("hip", aus[:9], threads, 1)                     # warm-up: library load, allocations
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        out = ps.decode_stream("hip", aus, threads, 1)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    print(json.dumps(dict(threads=threads, natural=bool(natural), pictures=len(out), fps=round(len(out) / best, 1))))
+
+
+def analyze(db):
+    import sqlite3
+    con = sqlite3.connect(db)
+    rows = con.execute("select start, end, queue_id, stream_id, name from kernels order by start").fetchall()
+    rows = [r for r in rows if "ohevc" in r[4]]
+    if not rows:
+        print("no ohevc kernels in the trace")
+        return
+    total = sum(e - s for s, e, *_ in rows)
+    union, cur_s, cur_e = 0, rows[0][0], rows[0][1]
+    for s, e, *_ in rows[1:]:
+        if s > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    union += cur_e - cur_s
+    span = max(r[1] for r in rows) - rows[0][0]
+    gaps = sorted(rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1))
+    print(json.dumps(dict(kernels=len(rows), queues=len({r[2] for r in rows}), streams=len({r[3] for r in rows}),
+                          sum_kernel_ms=round(total / 1e6, 3), union_busy_ms=round(union / 1e6, 3), span_ms=round(span / 1e6, 3),
+                          mean_kernel_us=round(total / len(rows) / 1e3, 2), overlap_factor=round(total / union, 3),
+                          busy_share_of_span=round(union / span, 3))))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "decode":
+        decode(int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "natural")
+    else:
+        analyze(sys.argv[2])
