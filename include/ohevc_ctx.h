@@ -115,6 +115,7 @@ typedef struct ohevc_frame_stats {
     int32_t launches, intra_levels;
     int64_t upload_bytes;
     int32_t n_tu, n_mc, n_intra, n_dbk, n_sao;
+    int32_t chose_ctbs;                 /* the picture's intra blocks ran as CTB tasks (one launch) rather than as dependency levels */
 } ohevc_frame_stats;
 int  ohevc_frame_get_stats(ohevc_ctx *ctx, ohevc_frame_stats *out);
 

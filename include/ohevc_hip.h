@@ -276,7 +276,7 @@ int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_lev
  *              must be listed so that every dependency comes earlier (raster order of the CTBs does);
  *   ops[]      the CTB's operations in decoding order: bit 31 = 0: intra prediction of intra_jobs[bits 24..0];
  *              bit 31 = 1: residual of tu_jobs[bits 24..0], size log2 = 2 + bits 30..29, kind = bits 28..25 (OHEVC_TU_*);
- *   sync       DEVICE array of ntasks + 2 zeroed uint32 (consumed by the launch).
+ *   sync       DEVICE array of 2 * ntasks + 2 zeroed uint32 (consumed by the launch: home XCC, ticket, done flags, progress words).
  * Job records are the ones of 2.1 / 2.5, positions in plane samples of the whole picture.  Results are identical to running the
  * operations one after the other through ohevc_dev_intra_batch_cip / ohevc_dev_tu_batch in a valid order. */
 typedef struct ohevc_ctb_task {         /* 32 bytes */

@@ -384,8 +384,8 @@ int ohdec_backend_open(void)
         ohevc_debug_set_record_only(1);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
     g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
-    if (getenv("OHHIP_LEVEL_LAUNCH"))
-        ohevc_debug_set_level_launch(atoi(getenv("OHHIP_LEVEL_LAUNCH")));          /* A/B of the two executors */   /* host-side profiling, no pixels (ohevc_debug.h) */
+    /* A/B of the executors of the intra-coded blocks (include/ohevc_debug.h): 0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture */
+    ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
     if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
         return -1;

@@ -1,4 +1,4 @@
-// ctb_kernels.hip -- every intra-coded block of a picture in ONE launch: coding-tree blocks as tasks, their samples in LDS.
+// ctb_kernels.hpp -- (included at the end of tu_kernels.hip: it runs that file's residual bodies) every intra-coded block of a picture in ONE launch: coding-tree blocks as tasks, their samples in LDS.
 //
 // What it replaces in the executor: the chain of dependency levels (prediction launch + residual launch per level; ~150 levels in a
 // 1080p picture of flat random syntax).  Measured in round 2 (profiles/r02n_*): those ~300 launches are 1.1 ms of kernel time and,
@@ -19,10 +19,7 @@
 //     stay, the first of them claims its XCC id as home and the others check theirs; stores are complete in L2 after
 //     s_waitcnt vmcnt(0), readers drop their L1 (buffer_inv sc1) after seeing the flag.  Successive launches prefer different classes,
 //     so the chains of pictures in flight spread over the XCDs.
-#include <atomic>
-#include "common.hpp"
-#include "intra_body.hpp"
-#include "tu_generic.hpp"
+#pragma once
 
 namespace ohevc {
 
@@ -36,10 +33,12 @@ struct CtbParams {
     int log2_ctb, hshift, vshift, bit_depth;
     int ntasks, preferred;
 };
-enum { CTB_HOME = 0, CTB_TICKET = 1, CTB_DONE = 2 };       // layout of the sync words
+enum { CTB_HOME = 0, CTB_TICKET = 1, CTB_DONE = 2 };       // layout of the sync words: home XCC, ticket counter, one done flag per task,
+                                                            // then one progress word per task (diagnosis: OHEVC_CTB_DEBUG, ctx.hip)
+constexpr unsigned kCtbSpinLimit = 1u << 22;                // polls (of >= 64 cycles each) before a wait gives up: a protocol error must not hang the device
 
-// LDS tile of one colour plane: rows -1 .. H - 1, columns -1 .. W + EXT - 1 of the CTB; column 0 sits at byte 4 of a row (dword
-// aligned), column -1 right below it
+// LDS tile of one colour plane: rows -1 .. H - 1, columns -1 .. W + EXT - 1 of the CTB; column 0 sits at byte 16 of a row and rows are a
+// multiple of 16 bytes apart (the residual bodies move 8- / 16-byte pieces of naturally aligned blocks), column -1 right below it
 struct TileGeom {
     int off, stride;                // byte offset inside the tile area, bytes per row
     int x0, y0, w, h, ext;          // CTB origin / size / above-right extension in samples of this plane
@@ -48,8 +47,8 @@ struct TileGeom {
 template <typename Pixel, bool FULLCHROMA>
 struct CtbLds {
     static constexpr int PXB = (int)sizeof(Pixel);
-    static constexpr int LUMA = 65 * (4 + 96 * PXB);
-    static constexpr int CHROMA = FULLCHROMA ? LUMA : 65 * (4 + 64 * PXB);       // 4:2:2 keeps the full height
+    static constexpr int LUMA = 65 * (16 + 96 * PXB);
+    static constexpr int CHROMA = FULLCHROMA ? LUMA : 65 * (16 + 64 * PXB);      // 4:2:2 keeps the full height
     static constexpr int TILES = LUMA + 2 * CHROMA;
 };
 
@@ -61,18 +60,15 @@ __global__ __launch_bounds__(64) void ctb_kernel(PlaneSet planes, CtbParams prm,
     constexpr int PXB = (int)sizeof(Pixel);
     __shared__ __attribute__((aligned(16))) unsigned char tiles[CtbLds<Pixel, FULLCHROMA>::TILES];
     __shared__ IntraShared ish;
-    __shared__ __attribute__((aligned(16))) short scratch[3 * 1024];          // tmp / luma residual / own residual of tu_generic.hpp
-    __shared__ short dc_slot[8];
+    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[2 * TuLayout<5>::WAVE_BYTES];      // what one wave of the residual bodies needs
     const int lane = threadIdx.x;
     if ((int)(blockIdx.x & 7u) != prm.preferred) return;
     {   // one XCD does the whole chain: whoever of the preferred class comes first names it
         const unsigned mine = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) + 1u;       // HW_REG_XCC_ID + 1
-        unsigned home = 0;
-        if (lane == 0) {
-            home = atomicCAS(&sync[CTB_HOME], 0u, mine);
-            if (home == 0u) home = mine;
-        }
-        home = (unsigned)__builtin_amdgcn_readfirstlane((int)home);
+        // (every lane makes the same attempt: whichever wins, all of them end up with the same answer -- see the note on branches below)
+        unsigned home = atomicCAS(&sync[CTB_HOME], 0u, mine);
+        if (home == 0u) home = mine;
+        home = (unsigned)__builtin_amdgcn_readfirstlane((int)(home & 0x7fffffffu));
         if (home != mine) return;
     }
     const int S = 1 << prm.log2_ctb, bd = prm.bit_depth;
@@ -83,27 +79,41 @@ __global__ __launch_bounds__(64) void ctb_kernel(PlaneSet planes, CtbParams prm,
             const int hs = p ? prm.hshift : 0, vs = p ? prm.vshift : 0;
             tg[p].w = S >> hs; tg[p].h = S >> vs;
             tg[p].ext = tg[p].w < 32 ? tg[p].w : 32;
-            tg[p].stride = 4 + (tg[p].w + tg[p].ext) * PXB;
+            tg[p].stride = 16 + (tg[p].w + tg[p].ext) * PXB;
             tg[p].off = off;
             off += (tg[p].h + 1) * tg[p].stride;
         }
     }
+    // Every branch of this loop is WAVE-uniform on purpose, and single-lane effects are expressed through operands (lane 0 adds 1 to the
+    // ticket, the others 0; all lanes store the same flag).  With an `if (lane == 0)` around the flag store the compiler - for which lanes
+    // are independent threads - is free to let the other 63 lanes run ahead into the next task's wait loop and park lane 0's store behind
+    // it: observed on the device (profiles/r02r_ctb_debug.txt: every wave past its write-back, no flag ever set, the kernel never ends).
     for (;;) {
-        unsigned t = 0;
-        if (lane == 0) t = atomicAdd(&sync[CTB_TICKET], 1u);
-        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        unsigned t = atomicAdd(&sync[CTB_TICKET], lane == 0 ? 1u : 0u);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);          // lane 0's return value = this wave's ticket
         if (t >= (unsigned)prm.ntasks) return;
-        const CtbTask task = tasks[t];
+        CtbTask task = tasks[t];
+        task.nops = (unsigned)__builtin_amdgcn_readfirstlane((int)task.nops);
+        task.first_op = (unsigned)__builtin_amdgcn_readfirstlane((int)task.first_op);
+        unsigned *state = sync + CTB_DONE + prm.ntasks + t;
+        __hip_atomic_store(state, 0x100u | (blockIdx.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- wait for the neighbours this CTB reads from (smaller ticket numbers: their holders are running)
         bool waited = false;
         for (int d = 0; d < 4; d++) {
-            const int dep = task.dep[d];
+            const int dep = __builtin_amdgcn_readfirstlane(task.dep[d]);
             if (dep < 0) continue;
-            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[CTB_DONE + dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
+            unsigned spins = 0;
+            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sync[CTB_DONE + dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
                 __builtin_amdgcn_s_sleep(1);
+                if (++spins > kCtbSpinLimit) {                  // never on a healthy run; the picture is then wrong, and the home word says so
+                    atomicOr(&sync[CTB_HOME], 0x80000000u);
+                    break;
+                }
+            }
             waited = true;
         }
         if (waited) xcd_acquire();                              // forget what this CU's L1 holds of the neighbours' samples
+        __hip_atomic_store(state, 0x200u | (blockIdx.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- the CTB, its row above and its column left -> LDS
         for (int p = 0; p < 3; p++) {
             TileGeom &g = tg[p];
@@ -111,66 +121,51 @@ __global__ __launch_bounds__(64) void ctb_kernel(PlaneSet planes, CtbParams prm,
             const int pw = planes.width[p], ph = planes.height[p], pstride = planes.stride[p];
             const unsigned char *src = planes.data[p];
             unsigned char *tile = tiles + g.off;
-            const int dw_per_row = (g.w + g.ext) * PXB / 4, rows = g.h + 1;
-            for (int i = lane; i < rows * dw_per_row; i += 64) {
-                const int r = i / dw_per_row, dcol = i - r * dw_per_row;
-                const int y = g.y0 - 1 + r, xb = g.x0 * PXB + dcol * 4;          // byte column inside the plane row
-                if (y >= 0 && y < ph && xb < pw * PXB)
-                    *reinterpret_cast<unsigned *>(tile + r * g.stride + 4 + dcol * 4) = *reinterpret_cast<const unsigned *>(src + (size_t)y * pstride + xb);
+            const int dw_per_row = (g.w + g.ext) * PXB / 4, rows = g.h + 1, total = rows * dw_per_row;
+            // eight requests in flight per lane (a load-store-load-store loop would pay one memory latency per dword: measured, 30 us per CTB)
+            for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+                unsigned v[8];
+                int dstoff[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + 64 * u;
+                    const int r = i / dw_per_row, dcol = i - r * dw_per_row;
+                    const int y = g.y0 - 1 + r, xb = g.x0 * PXB + dcol * 4;          // byte column inside the plane row
+                    const bool ok = i < total && y >= 0 && y < ph && xb < pw * PXB;
+                    dstoff[u] = ok ? r * g.stride + 16 + dcol * 4 : -1;
+                    v[u] = ok ? *reinterpret_cast<const unsigned *>(src + (size_t)y * pstride + xb) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (dstoff[u] >= 0) *reinterpret_cast<unsigned *>(tile + dstoff[u]) = v[u];
             }
             if (g.x0 > 0)
                 for (int r = lane; r < rows; r += 64) {
                     const int y = g.y0 - 1 + r;
                     if (y >= 0 && y < ph)
-                        *reinterpret_cast<Pixel *>(tile + r * g.stride + 4 - PXB) = *reinterpret_cast<const Pixel *>(src + (size_t)y * pstride + (size_t)(g.x0 - 1) * PXB);
+                        *reinterpret_cast<Pixel *>(tile + r * g.stride + 16 - PXB) = *reinterpret_cast<const Pixel *>(src + (size_t)y * pstride + (size_t)(g.x0 - 1) * PXB);
                 }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // the kernels' plane view of the tiles: sample (x, y) of plane p at tile + (y - y0 + 1) * stride + 4 + (x - x0) * PXB
+        __hip_atomic_store(state, 0x300u | (blockIdx.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the kernels' plane view of the tiles: sample (x, y) of plane p at tile + (y - y0 + 1) * stride + 16 + (x - x0) * PXB
         PlaneSet lp;
         for (int p = 0; p < 3; p++) {
-            lp.data[p] = tiles + tg[p].off + (ptrdiff_t)(1 - tg[p].y0) * tg[p].stride + 4 - (ptrdiff_t)tg[p].x0 * PXB;
+            lp.data[p] = tiles + tg[p].off + (ptrdiff_t)(1 - tg[p].y0) * tg[p].stride + 16 - (ptrdiff_t)tg[p].x0 * PXB;
             lp.stride[p] = tg[p].stride;
             lp.width[p] = planes.width[p]; lp.height[p] = planes.height[p];
         }
         // ---- the CTB's operations in decoding order
         for (unsigned k = 0; k < task.nops; k++) {
-            const unsigned op = ops[task.first_op + k];
+            const unsigned op = (unsigned)__builtin_amdgcn_readfirstlane((int)ops[task.first_op + k]);
             const unsigned idx = op & 0x1ffffffu;
             if (!(op >> 31)) {
                 intra_body<Pixel, true>(ish, lane, lp, intra_jobs[idx], bd, cips);
             } else {
-                const int log2 = (int)((op >> 29) & 3u) + 2, kind = (int)((op >> 25) & 15u), N = 1 << log2, NN = N * N;
-                const ohevc_tu_job jb = tu_jobs[idx];
-                short *tmp = scratch, *ry = scratch + 1024, *rc = scratch + 2048;
-                int scale = 0;
-                bool have_own = true;
-                if (kind == OHEVC_TU_CROSS) {                   // hevc.c:1291-1365: own residual + (res_scale_val * luma residual) >> 3
-                    const int kind_c = jb.reserved0 & 15, kind_y = jb.reserved0 >> 4;
-                    scale = jb.dc;
-                    residual_generic(kind_y, log2, coeffs + jb.reserved1, bd, tmp, ry, lane);
-                    have_own = kind_c != 15;
-                    if (have_own) residual_generic(kind_c, log2, coeffs + jb.coeff_off, bd, tmp, rc, lane);
-                } else if (kind == OHEVC_TU_DC) {               // the coefficient travels in the job
-                    if (lane == 0) dc_slot[0] = jb.dc;
-                    CROSS_SYNC();
-                    residual_generic(kind, log2, dc_slot, bd, tmp, rc, lane);
-                } else if (kind == OHEVC_TU_PCM) {              // put_pcm: the samples replace the block
-                    for (int o = lane; o < NN; o += 64) rc[o] = (coeffs + jb.coeff_off)[o];
-                    CROSS_SYNC();
-                } else {
-                    residual_generic(kind, log2, coeffs + jb.coeff_off, bd, tmp, rc, lane);
-                }
-                const int stride = PLANE_STRIDE3(lp, jb.plane), maxv = (1 << bd) - 1;
-                unsigned char *base = PLANE_PTR3(lp, jb.plane) + (ptrdiff_t)jb.y * stride + (ptrdiff_t)jb.x * PXB;
-                for (int o = lane; o < NN; o += 64) {
-                    Pixel *px = reinterpret_cast<Pixel *>(base + (ptrdiff_t)(o >> log2) * stride) + (o & (N - 1));
-                    int res = have_own ? (int)rc[o] : 0;
-                    if (kind == OHEVC_TU_CROSS) res = (int)(short)(res + ((scale * (int)ry[o]) >> 3));
-                    const int v = (kind == OHEVC_TU_PCM ? 0 : (int)*px) + res;          // transform_add, hevcdsp_template.c:45-111
-                    *px = (Pixel)(v < 0 ? 0 : v > maxv ? maxv : v);
-                }
+                // the residual of the block just predicted: the same bodies the batched launches run (one block, this wave), on the LDS view
+                const int log2 = (int)((op >> 29) & 3u) + 2, kind = (int)((op >> 25) & 15u);
+                tu_dispatch<Pixel>(tu_lds, 0, lp, tu_jobs + idx, 1, log2, kind, coeffs, bd);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -186,12 +181,13 @@ __global__ __launch_bounds__(64) void ctb_kernel(PlaneSet planes, CtbParams prm,
                 const int r = i / dw_per_row, dcol = i - r * dw_per_row;
                 const int y = g.y0 + r, xb = g.x0 * PXB + dcol * 4;
                 if (y < ph && xb < pw * PXB)
-                    *reinterpret_cast<unsigned *>(dst + (size_t)y * pstride + xb) = *reinterpret_cast<const unsigned *>(tile + (r + 1) * g.stride + 4 + dcol * 4);
+                    *reinterpret_cast<unsigned *>(dst + (size_t)y * pstride + xb) = *reinterpret_cast<const unsigned *>(tile + (r + 1) * g.stride + 16 + dcol * 4);
             }
         }
         xcd_release();                                          // this wave's stores sit in the XCD's L2 ...
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(&sync[CTB_DONE + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the flag says so
+        __hip_atomic_store(&sync[CTB_DONE + t], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                    // ... before the flag says so
+        __hip_atomic_store(state, 0x500u | (blockIdx.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

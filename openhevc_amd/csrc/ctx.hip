@@ -83,9 +83,12 @@ struct LevelBins {
 }  // namespace
 
 static std::atomic<uint64_t> g_ctx_gen{1};
-// executor of the intra-coded blocks: 2 (shipped) = one ohevc_dev_ctbs launch per picture, CTBs as tasks with their samples in LDS;
-// 0 = one prediction launch and one residual launch per dependency level; 1 = all levels inside one ohevc_dev_levels launch.
-// Modes 0 / 1 also serve pictures whose intra jobs do not name a CTB size.
+// executor of the intra-coded blocks (ohevc_debug_set_level_launch):
+//   0  one prediction launch and one residual launch per dependency level;   1  all levels inside one ohevc_dev_levels launch;
+//   3  one ohevc_dev_ctbs launch per picture: CTBs as tasks, their samples in LDS, operations in decoding order;
+//   2  (shipped) both forms are recorded and the cheaper one is chosen per picture from the recorded work itself: the CTB form when
+//      its longest chain of dependent CTBs is short (sparse intra blocks: encoder-like inter pictures), the level form otherwise.
+// Pictures whose intra jobs name no CTB size always take the level form.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
@@ -660,8 +663,9 @@ static inline uint32_t ctb_index(const ohevc_ctx *c, const Picture *p, int plane
     (void)c;
     return (uint32_t)(((y << vs) >> log2_ctb) * ctb_w + ((x << hs) >> log2_ctb));
 }
-// does the residual of an intra-predicted block go to the CTB executor?  (yes once the picture's intra jobs have named a CTB size)
-static inline bool ctb_mode(const ohevc_ctx *c) { return c->frame_mode == 2 && __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED) > 0; }
+// is intra work recorded in CTB order (modes 2 and 3, once the picture's intra jobs have named a CTB size) / in dependency levels?
+static inline bool rec_ctb(const ohevc_ctx *c) { return c->frame_mode >= 2 && __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED) > 0; }
+static inline bool rec_levels(const ohevc_ctx *c) { return c->frame_mode != 3 || __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED) <= 0; }
 
 extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra)
 {
@@ -680,15 +684,14 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
         j.coeff_off = (uint32_t)r.coeffs.size();
         r.coeffs.insert(r.coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
     }
-    if (intra && ctb_mode(c)) {                               // follows its block's prediction inside the CTB's task
-        if (trace_hit(plane, x, y, n, n))
-            fprintf(stderr, "trace: target %d tu plane %d x %d y %d log2 %d kind %d (ctb task) c0 %d\n", c->cur, plane, x, y, log2, kind, coeffs[0]);
+    // `intra`: the block MAY have been predicted by an intra job of this picture (the table slots cannot tell and always say so): the
+    // level map knows -- 0 = no intra job covered it: the residual of an inter block (or PCM samples), level 0
+    const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
+    if (level > 0 && rec_ctb(c)) {                            // follows its block's prediction inside the CTB's task
         r.ctb_ops.emplace_back(ctb_index(c, p, plane, x, y, c->log2_ctb), 0x80000000u | ((uint32_t)(log2 - 2) << 29) | ((uint32_t)kind << 25) | (uint32_t)r.ctb_tu.size());
         r.ctb_tu.push_back(j);
-        r.nstat[0]++;
-        return OHEVC_OK;
+        if (!rec_levels(c)) { r.nstat[0]++; return OHEVC_OK; }
     }
-    const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
     if (trace_hit(plane, x, y, n, n))
         fprintf(stderr, "trace: target %d tu plane %d x %d y %d log2 %d kind %d level %d c0 %d\n", c->cur, plane, x, y, log2, kind, level, coeffs[0]);
     LevelBins &lb = level_bins(r, level);
@@ -721,13 +724,12 @@ extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log
         j.coeff_off = (uint32_t)r.coeffs.size();
         r.coeffs.insert(r.coeffs.end(), coeffs_c, coeffs_c + n * n);
     }
-    if (intra && ctb_mode(c)) {
+    const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
+    if (level > 0 && rec_ctb(c)) {
         r.ctb_ops.emplace_back(ctb_index(c, p, plane, x, y, c->log2_ctb), 0x80000000u | ((uint32_t)(log2 - 2) << 29) | ((uint32_t)OHEVC_TU_CROSS << 25) | (uint32_t)r.ctb_tu.size());
         r.ctb_tu.push_back(j);
-        r.nstat[0]++;
-        return OHEVC_OK;
+        if (!rec_levels(c)) { r.nstat[0]++; return OHEVC_OK; }
     }
-    const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
     LevelBins &lb = level_bins(r, level);
     lb.tu[log2 - 2][OHEVC_TU_CROSS].push_back(j);
     lb.touched |= 1ull << ((log2 - 2) * 16 + OHEVC_TU_CROSS);
@@ -791,7 +793,7 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(job->plane < 3 && job->log2_size >= 2 && job->log2_size <= 5 && job->mode <= 34, "bad intra job");
     const int pl = job->plane, n = 1 << job->log2_size, W = c->lm_w[pl], H = c->lm_h[pl];
     OHEVC_REQUIRE(job->x + n <= p->planes[pl].width && job->y + n <= p->planes[pl].height, "intra block outside plane");
-    if (c->frame_mode == 2) {
+    if (c->frame_mode >= 2) {
         // the CTB executor needs the CTB size; the picture's first intra job decides (jobs built without it: dependency levels)
         int l2 = __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED);
         if (l2 == 0) {
@@ -800,13 +802,18 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
         }
         if (l2 > 0) {
             OHEVC_REQUIRE(job->log2_ctb_size == l2, "the intra jobs of one picture must name one CTB size");
-            if (trace_hit(pl, job->x, job->y, n, n))
-                fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d (ctb task)\n", c->cur, pl, job->x,
-                        job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size);
             r.ctb_ops.emplace_back(ctb_index(c, p, pl, job->x, job->y, l2), (uint32_t)r.ctb_intra.size());
             r.ctb_intra.push_back(*job);
-            r.nstat[2]++;
-            return OHEVC_OK;
+            if (c->frame_mode == 3) {                         // no levels needed: just mark the block's cells as intra-predicted
+                if (trace_hit(pl, job->x, job->y, n, n))
+                    fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d (ctb task)\n", c->cur, pl, job->x,
+                            job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size);
+                uint16_t *lmp = c->level_map[pl].data();
+                for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
+                    for (int cx = job->x >> 2; cx < (job->x + n) >> 2; cx++) __atomic_store_n(&lmp[(size_t)cy * W + cx], (uint16_t)1, __ATOMIC_RELAXED);
+                r.nstat[2]++;
+                return OHEVC_OK;
+            }
         }
     }
     // dependency level = 1 + the highest level among the 4x4 cells this block may read (row above incl. corner and
@@ -1012,32 +1019,59 @@ static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>
 }
 
 // CTB executor: sort the recorded intra operations by CTB (stable: decoding order inside a CTB is kept) and cut them into tasks, one per
-// CTB, in raster order; a task waits for the tasks of its left, above-left, above and above-right CTB (hevc.c:2779).
-static void build_ctb_tasks(ohevc_ctx *c, const Picture *p)
+// CTB, in raster order.  A task waits for the task of a neighbouring CTB (left, above-left, above, above-right: hevc.c:2779) only if
+// one of its blocks really reads samples of that CTB: a prediction block reads the row above / the column left of itself as far as its
+// availability flags say (hevcpred_template.c:164-183), so only blocks on the CTB's top row / left column reach into a neighbour.
+// Returns the length of the longest chain of dependent tasks in estimated microseconds (what the launch will take at least).
+static double build_ctb_tasks(ohevc_ctx *c, const Picture *p)
 {
     c->ctb_tasks.clear(); c->ctb_opwords.clear();
-    if (c->ctb_ops.empty()) return;
+    if (c->ctb_ops.empty()) return 0;
     const int l2 = c->log2_ctb, ctb_w = (p->w + (1 << l2) - 1) >> l2, ctb_h = (p->h + (1 << l2) - 1) >> l2;
     std::stable_sort(c->ctb_ops.begin(), c->ctb_ops.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
     c->ctb_task_of.assign((size_t)ctb_w * ctb_h, -1);
     c->ctb_opwords.reserve(c->ctb_ops.size());
-    for (size_t i = 0; i < c->ctb_ops.size(); i++) {
+    static thread_local std::vector<double> cost;
+    cost.clear();
+    double longest = 0;
+    const size_t nops = c->ctb_ops.size();
+    for (size_t i = 0; i < nops;) {
         const uint32_t ctb = c->ctb_ops[i].first;
-        if (c->ctb_tasks.empty() || i == 0 || ctb != c->ctb_ops[i - 1].first) {
-            ohevc_ctb_task t = {};
-            t.cx = (uint16_t)(ctb % ctb_w); t.cy = (uint16_t)(ctb / ctb_w);
-            t.first_op = (uint32_t)i;
-            const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
-            for (int d = 0; d < 4; d++) {
-                const int x = t.cx + nb[d][0], y = t.cy + nb[d][1];
-                t.dep[d] = x >= 0 && y >= 0 && x < ctb_w ? c->ctb_task_of[(size_t)y * ctb_w + x] : -1;
-            }
-            c->ctb_task_of[ctb] = (int32_t)c->ctb_tasks.size();
-            c->ctb_tasks.push_back(t);
+        ohevc_ctb_task t = {};
+        t.cx = (uint16_t)(ctb % ctb_w); t.cy = (uint16_t)(ctb / ctb_w);
+        t.first_op = (uint32_t)i;
+        unsigned need = 0;                                  // bit 0 left, 1 above-left, 2 above, 3 above-right
+        size_t k = i;
+        for (; k < nops && c->ctb_ops[k].first == ctb; k++) {
+            const uint32_t w = c->ctb_ops[k].second;
+            c->ctb_opwords.push_back(w);
+            if (w >> 31) continue;
+            const ohevc_intra_job &j = c->ctb_intra[w & 0x1ffffffu];
+            const int hs = j.plane ? (p->cfi == 1 || p->cfi == 2) : 0, vs = j.plane ? (p->cfi == 1) : 0;
+            const int cw = (1 << l2) >> hs, ch = (1 << l2) >> vs, n = 1 << j.log2_size;
+            const bool top = j.y == t.cy * ch, left = j.x == t.cx * cw;
+            if (top && (j.flags & OHEVC_INTRA_UP)) need |= 4;
+            if (top && (j.flags & OHEVC_INTRA_UP_RIGHT)) need |= j.x + n >= (t.cx + 1) * cw ? 8 : 4;
+            if (j.flags & OHEVC_INTRA_UP_LEFT) need |= top && left ? 2 : top ? 4 : left ? 1 : 0;
+            if (left && (j.flags & (OHEVC_INTRA_LEFT | OHEVC_INTRA_BOTTOM_LEFT))) need |= 1;
         }
-        c->ctb_tasks.back().nops++;
-        c->ctb_opwords.push_back(c->ctb_ops[i].second);
+        t.nops = (uint32_t)(k - i);
+        const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+        double before = 0;
+        for (int d = 0; d < 4; d++) {
+            const int x = t.cx + nb[d][0], y = t.cy + nb[d][1];
+            t.dep[d] = ((need >> d) & 1) && x >= 0 && y >= 0 && x < ctb_w ? c->ctb_task_of[(size_t)y * ctb_w + x] : -1;
+            if (t.dep[d] >= 0) before = std::max(before, cost[(size_t)t.dep[d]]);
+        }
+        // measured on MI355X (profiles/r02s / r02u): ~6 us to pick a task up, load and store its tiles, ~2.3 us per operation (one wave, latency-bound)
+        const double mine = before + 6.0 + 2.3 * t.nops;
+        cost.push_back(mine);
+        longest = std::max(longest, mine);
+        c->ctb_task_of[ctb] = (int32_t)c->ctb_tasks.size();
+        c->ctb_tasks.push_back(t);
+        i = k;
     }
+    return longest;
 }
 
 extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
@@ -1045,7 +1079,37 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     merge_side(c);
-    build_ctb_tasks(c, p);
+    const double ctb_us = build_ctb_tasks(c, p);
+    if (c->frame_mode == 2 && !c->ctb_tasks.empty()) {
+        // both forms were recorded: keep the cheaper one.  The level form costs a prediction launch and a residual launch per level
+        // (~10.5 us per level on the device and about as much launch work on the host: profiles/r02q, r02t)
+        const double level_us = 10.5 * std::max(c->max_level, 0);
+        c->stats.chose_ctbs = ctb_us < level_us;
+        static const char *force = getenv("OHEVC_CTB_CHOICE");       // diagnosis: "ctb" / "levels" overrides the estimate
+        if (force) c->stats.chose_ctbs = force[0] == 'c';
+    } else {
+        c->stats.chose_ctbs = !c->ctb_tasks.empty();
+    }
+    if (c->stats.chose_ctbs) {                               // drop the level form of the intra work (level 0 = residuals of inter blocks stays)
+        for (int l = 1; l <= c->max_level; l++) {
+            LevelBins &lb = c->levels[l];
+            for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
+            lb.touched = 0;
+            lb.intra.clear();
+        }
+        c->max_level = std::min(c->max_level, c->levels.empty() ? -1 : 0);
+    } else {
+        c->ctb_tasks.clear(); c->ctb_opwords.clear();
+    }
+    if (getenv("OHEVC_TRACE_CTB")) {
+        size_t l0 = 0;
+        if (c->max_level >= 0) for (uint64_t m = c->levels[0].touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); l0 += c->levels[0].tu[b >> 4][b & 15].size(); }
+        unsigned long long h = 1469598103934665603ull;
+        for (uint32_t w : c->ctb_opwords) h = (h ^ w) * 1099511628211ull;
+        for (auto &t : c->ctb_tasks) for (int d = 0; d < 4; d++) h = (h ^ (unsigned)t.dep[d]) * 1099511628211ull;
+        fprintf(stderr, "ctb trace: mode %d chose %d tasks %zu ops %zu intra %zu tu %zu max_level %d level0_tu %zu coeffs %zu hash %llx\n", c->frame_mode, c->stats.chose_ctbs,
+                c->ctb_tasks.size(), c->ctb_opwords.size(), c->ctb_intra.size(), c->ctb_tu.size(), c->max_level, l0, c->coeffs.size(), h);
+    }
     if (c->dry) {
         if (g_sink) g_sink(g_sink_user, c, 0);
         clear_recorded(c);
@@ -1122,7 +1186,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_cips = c->cips.empty() ? 0 : stage_put(parts, total, c->cips.data(), c->cips.size() * sizeof(ohevc_intra_cip));
     // CTB executor: tasks, operation words, the jobs they index, zeroed sync words (home XCD, ticket, one done flag per task)
     const bool ctbs = !c->ctb_tasks.empty();
-    c->ctb_sync_zero.assign(ctbs ? c->ctb_tasks.size() + 2 : 0, 0u);
+    c->ctb_sync_zero.assign(ctbs ? 2 * c->ctb_tasks.size() + 2 : 0, 0u);
     const size_t off_ct = ctbs ? stage_put(parts, total, c->ctb_tasks.data(), c->ctb_tasks.size() * sizeof(ohevc_ctb_task)) : 0;
     const size_t off_co = ctbs ? stage_put(parts, total, c->ctb_opwords.data(), c->ctb_opwords.size() * sizeof(uint32_t)) : 0;
     const size_t off_ci = ctbs && !c->ctb_intra.empty() ? stage_put(parts, total, c->ctb_intra.data(), c->ctb_intra.size() * sizeof(ohevc_intra_job)) : 0;
@@ -1199,6 +1263,30 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
                             reinterpret_cast<const ohevc_tu_job *>(base + off_cu), d_coeffs, reinterpret_cast<uint32_t *>(base + off_cs), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
+        static const bool ctb_debug = getenv("OHEVC_CTB_DEBUG") != nullptr;
+        if (ctb_debug) {       // diagnosis: wait (bounded) for the launch, then look at the sync words: home / ticket / flags / progress
+            const double t0 = now_s();
+            hipError_t q;
+            while ((q = hipStreamQuery(c->stream)) == hipErrorNotReady && now_s() - t0 < 5.0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            std::vector<uint32_t> sw(2 * c->ctb_tasks.size() + 2);
+            hipStream_t side;
+            (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+            (void)hipMemcpyAsync(sw.data(), base + off_cs, sw.size() * 4, hipMemcpyDeviceToHost, side);
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+            const size_t nt = c->ctb_tasks.size();
+            size_t done = 0;
+            for (size_t i = 0; i < nt; i++) done += sw[2 + i] != 0;
+            if (q == hipErrorNotReady || (sw[0] & 0x80000000u) || done != nt) {
+                fprintf(stderr, "ctb debug: launch %s after %.1f s: home 0x%x ticket %u done %zu / %zu tasks\n", q == hipErrorNotReady ? "STILL RUNNING" : "finished",
+                        now_s() - t0, sw[0], sw[1], done, nt);
+                for (size_t i = 0; i < nt && i < 200; i++)
+                    if (!sw[2 + i])
+                        fprintf(stderr, "  task %zu ctb (%u,%u) ops %u deps %d %d %d %d state 0x%x\n", i, c->ctb_tasks[i].cx, c->ctb_tasks[i].cy, c->ctb_tasks[i].nops,
+                                c->ctb_tasks[i].dep[0], c->ctb_tasks[i].dep[1], c->ctb_tasks[i].dep[2], c->ctb_tasks[i].dep[3], sw[2 + nt + i]);
+                if (q == hipErrorNotReady) { fflush(stderr); abort(); }
+            }
+        }
     }
     c->stats.intra_levels = std::max(c->stats.intra_levels, std::max(max_level, 0));
     clear_recorded(c);

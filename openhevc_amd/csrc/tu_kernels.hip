@@ -1663,6 +1663,8 @@ static int launch_tu(const PlaneSet &ps, int bit_depth, int log2, int kind, cons
 
 }  // namespace ohevc
 
+#include "ctb_kernels.hpp"      // the CTB executor runs tu_dispatch on its LDS tiles
+
 extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, int log2_size, int kind,
                                   const ohevc_tu_job *jobs, int njobs, const int16_t *coeffs, void *stream)
 {

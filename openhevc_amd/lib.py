@@ -221,10 +221,11 @@ def intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cands):
 # ---------------------------------------------------------------- ctx layer (include/ohevc_ctx.h)
 class FrameStats(C.Structure):
     _fields_ = [("launches", C.c_int32), ("intra_levels", C.c_int32), ("upload_bytes", C.c_int64),
-                ("n_tu", C.c_int32), ("n_mc", C.c_int32), ("n_intra", C.c_int32), ("n_dbk", C.c_int32), ("n_sao", C.c_int32)]
+                ("n_tu", C.c_int32), ("n_mc", C.c_int32), ("n_intra", C.c_int32), ("n_dbk", C.c_int32), ("n_sao", C.c_int32),
+                ("chose_ctbs", C.c_int32)]
 
 
-EXPORTED_SYMBOLS += ["ohevc_dev_levels", "ohevc_level_phase_workgroups", "ohevc_ctx_create_shared", "ohevc_ctx_store_id"]
+EXPORTED_SYMBOLS += ["ohevc_dev_levels", "ohevc_dev_ctbs", "ohevc_frame_abort", "ohevc_level_phase_workgroups", "ohevc_ctx_create_shared", "ohevc_ctx_store_id"]
 EXPORTED_SYMBOLS += ["ohevc_ctx_create", "ohevc_ctx_destroy", "ohevc_ctx_stream", "ohevc_ctx_sync", "ohevc_pic_alloc",
                      "ohevc_pic_release", "ohevc_pic_adopt", "ohevc_pic_upload", "ohevc_pic_download", "ohevc_pic_planes", "ohevc_frame_begin",
                      "ohevc_rec_tu", "ohevc_rec_mc", "ohevc_rec_intra", "ohevc_rec_deblock", "ohevc_rec_sao",

@@ -316,6 +316,7 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemuS
 hipError_t hipStreamCreate(hipStream_t *s) { *s = new hipemuStream(); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new hipemuEvent(); return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemuEvent(); return hipSuccess; }

@@ -17,9 +17,9 @@ import synth_stream as S  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[0, 1], ids=["launch_per_level", "levels_kernel"])
+@pytest.fixture(params=[0, 1, 3, 2], ids=["launch_per_level", "levels_kernel", "ctb_tasks", "chosen_per_picture"])
 def level_executor(request):
-    """Both executors of the intra dependency levels (include/ohevc_debug.h) must give the same pictures."""
+    """Every executor of the intra-coded blocks (include/ohevc_debug.h) must give the same pictures."""
     import ctypes
     if request.param == 1 and G.emulating():
         pytest.skip("the persistent level kernel's workgroups wait for each other; the emulator runs them one after another")

@@ -69,12 +69,15 @@ def _golden_names():
     return sorted(CASES)
 
 
+@pytest.mark.parametrize("executor", ["3", "0"], ids=["ctb_tasks", "levels"])
 @pytest.mark.parametrize("name", _golden_names())
-def test_emu_golden_stream(name):
+def test_emu_golden_stream(name, executor, monkeypatch):
+    """Both executors of the intra-coded blocks, forced (the default picks one per picture): one CTB-task launch / launches per level."""
     from test_stream_cpu import frames_md5, load_golden
     ps = _stream_lib()
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", executor)
     aus, md5 = load_golden(name)
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 

@@ -184,6 +184,18 @@ def test_recorded_jobs_executed_by_the_oracle_reproduce_the_reference(name, bulk
 
 
 @needs_hip_lib
+@pytest.mark.parametrize("executor", ["3", "0"], ids=["ctb_tasks", "levels"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_both_intra_executors_record_the_same_pictures(name, executor, monkeypatch):
+    """The default records both forms of the intra work and keeps the cheaper one per picture; forced here: CTB tasks (operations in
+    decoding order per CTB, dependencies only where a block reads a neighbouring CTB) / dependency levels."""
+    monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", executor)
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hip", aus)) == md5
+
+
+@needs_hip_lib
 @pytest.mark.parametrize("threads,thread_type,names", [
     (3, 1, ["ra_8b_ctb64", "ldb_10b", "weighted", "fmt422_10b_ra", "cross_444_8b", "small_blocks"]),       # frame threads
     (4, 2, ["wpp", "tiles", "slices_dep_wpp", "tiles_nolf"]),                                                # slice threads

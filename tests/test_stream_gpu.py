@@ -25,9 +25,11 @@ def _compare(ref, hip):
                                      f"ref={fa[c][y, x]} hip={fb[c][y, x]}")
 
 
+@pytest.mark.parametrize("executor", ["2", "3", "0"], ids=["chosen_per_picture", "ctb_tasks", "levels"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_golden_stream_hip_backend(name):
+def test_golden_stream_hip_backend(name, executor, monkeypatch):
     assert ps.have("hip"), "oracle/_ref/libopenhevc_hip.so missing: run __graft_entry__.build() where /root/reference exists"
+    monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", executor)       # executor of the intra-coded blocks (ohevc_debug.h); "2" is the default
     aus, md5 = load_golden(name)
     hip = ps.decode_stream("hip", aus)
     assert frames_md5(hip) == md5            # pinned by the committed digests of the untouched decoder ...
@@ -137,9 +139,11 @@ def _baseline_case(kw, threads, thread_type):
     assert (ok, bad) == (3 * kw["nframes"], 0)
 
 
+@pytest.mark.parametrize("executor", ["2", "3"], ids=["chosen_per_picture", "ctb_tasks"])
 @pytest.mark.parametrize("threads,thread_type", [(1, 1), (4, 1)])
-def test_config3_1080p_main_random_access(threads, thread_type):
+def test_config3_1080p_main_random_access(threads, thread_type, executor, monkeypatch):
     """BASELINE config 3: 1920x1080 Main 8-bit random-access, full CTU pipeline (intra + MC + IDCT + deblock + SAO) on one GPU."""
+    monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", executor)
     _baseline_case(dict(gop="random_access", nframes=9, seed=3001, width=1920, height=1080, log2_ctb=6), threads, thread_type)
 
 
