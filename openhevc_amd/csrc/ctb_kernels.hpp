@@ -97,6 +97,33 @@ __global__ __launch_bounds__(64) void ctb_kernel(PlaneSet planes, CtbParams prm,
         task.first_op = (unsigned)__builtin_amdgcn_readfirstlane((int)task.first_op);
         unsigned *state = sync + CTB_DONE + prm.ntasks + t;
         __hip_atomic_store(state, 0x100u | (blockIdx.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- the CTB's own samples -> LDS.  They are what earlier launches left (inter prediction, residuals of inter blocks): nothing of
+        //      this launch writes them but this task, so they can travel while the neighbours are still at work
+        for (int p = 0; p < 3; p++) {
+            TileGeom &g = tg[p];
+            g.x0 = task.cx * g.w; g.y0 = task.cy * g.h;
+            const int pw = planes.width[p], ph = planes.height[p], pstride = planes.stride[p];
+            const unsigned char *src = planes.data[p];
+            unsigned char *tile = tiles + g.off;
+            const int dw_per_row = g.w * PXB / 4, total = g.h * dw_per_row;
+            // eight requests in flight per lane (a load-store-load-store loop pays one memory latency per dword: measured, 30 us per CTB)
+            for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+                unsigned v[8];
+                int dstoff[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + 64 * u;
+                    const int r = i / dw_per_row, dcol = i - r * dw_per_row;
+                    const int y = g.y0 + r, xb = g.x0 * PXB + dcol * 4;              // byte column inside the plane row
+                    const bool ok = i < total && y < ph && xb < pw * PXB;
+                    dstoff[u] = ok ? (r + 1) * g.stride + 16 + dcol * 4 : -1;
+                    v[u] = ok ? *reinterpret_cast<const unsigned *>(src + (size_t)y * pstride + xb) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (dstoff[u] >= 0) *reinterpret_cast<unsigned *>(tile + dstoff[u]) = v[u];
+            }
+        }
         // ---- wait for the neighbours this CTB reads from (smaller ticket numbers: their holders are running)
         bool waited = false;
         for (int d = 0; d < 4; d++) {
@@ -114,33 +141,20 @@ __global__ __launch_bounds__(64) void ctb_kernel(PlaneSet planes, CtbParams prm,
         }
         if (waited) xcd_acquire();                              // forget what this CU's L1 holds of the neighbours' samples
         __hip_atomic_store(state, 0x200u | (blockIdx.x << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- the CTB, its row above and its column left -> LDS
+        // ---- the row above (with its above-right extension) and the column left: the neighbours' samples
         for (int p = 0; p < 3; p++) {
-            TileGeom &g = tg[p];
-            g.x0 = task.cx * g.w; g.y0 = task.cy * g.h;
+            const TileGeom &g = tg[p];
             const int pw = planes.width[p], ph = planes.height[p], pstride = planes.stride[p];
             const unsigned char *src = planes.data[p];
             unsigned char *tile = tiles + g.off;
-            const int dw_per_row = (g.w + g.ext) * PXB / 4, rows = g.h + 1, total = rows * dw_per_row;
-            // eight requests in flight per lane (a load-store-load-store loop would pay one memory latency per dword: measured, 30 us per CTB)
-            for (int i0 = lane; i0 < total; i0 += 64 * 8) {
-                unsigned v[8];
-                int dstoff[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int i = i0 + 64 * u;
-                    const int r = i / dw_per_row, dcol = i - r * dw_per_row;
-                    const int y = g.y0 - 1 + r, xb = g.x0 * PXB + dcol * 4;          // byte column inside the plane row
-                    const bool ok = i < total && y >= 0 && y < ph && xb < pw * PXB;
-                    dstoff[u] = ok ? r * g.stride + 16 + dcol * 4 : -1;
-                    v[u] = ok ? *reinterpret_cast<const unsigned *>(src + (size_t)y * pstride + xb) : 0u;
+            const int dw_top = (g.w + g.ext) * PXB / 4;
+            if (g.y0 > 0)
+                for (int dcol = lane; dcol < dw_top; dcol += 64) {
+                    const int xb = g.x0 * PXB + dcol * 4;
+                    if (xb < pw * PXB) *reinterpret_cast<unsigned *>(tile + 16 + dcol * 4) = *reinterpret_cast<const unsigned *>(src + (size_t)(g.y0 - 1) * pstride + xb);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (dstoff[u] >= 0) *reinterpret_cast<unsigned *>(tile + dstoff[u]) = v[u];
-            }
             if (g.x0 > 0)
-                for (int r = lane; r < rows; r += 64) {
+                for (int r = lane; r < g.h + 1; r += 64) {
                     const int y = g.y0 - 1 + r;
                     if (y >= 0 && y < ph)
                         *reinterpret_cast<Pixel *>(tile + r * g.stride + 16 - PXB) = *reinterpret_cast<const Pixel *>(src + (size_t)y * pstride + (size_t)(g.x0 - 1) * PXB);
