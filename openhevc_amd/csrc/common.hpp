@@ -27,6 +27,8 @@ void set_error(const char *fmt, ...);
         }                                                                                \
     } while (0)
 
+// The bit depths the reference instantiates (hevcdsp.c:1044-1062: 8, 9, 10, 12, 14), plus 11, which the same formulas cover.
+#define OHEVC_BIT_DEPTH_OK(bd) (((bd) >= 8 && (bd) <= 12) || (bd) == 14)
 #define OHEVC_REQUIRE(cond, msg)                                                         \
     do {                                                                                 \
         if (!(cond)) {                                                                   \

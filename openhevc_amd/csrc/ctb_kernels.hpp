@@ -214,7 +214,7 @@ extern "C" int ohevc_dev_ctbs(const ohevc_plane planes[3], int bit_depth, int ch
     using namespace ohevc;
     static_assert(sizeof(CtbTask) == sizeof(ohevc_ctb_task) && sizeof(CtbTask) == 32, "task record layout");
     OHEVC_REQUIRE(planes != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(chroma_format_idc >= 1 && chroma_format_idc <= 3, "chroma_format_idc must be 1..3");
     OHEVC_REQUIRE(log2_ctb_size >= 4 && log2_ctb_size <= 6, "log2_ctb_size must be 4..6");
     OHEVC_REQUIRE(ntasks >= 0, "ntasks");

@@ -326,7 +326,7 @@ extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int
     OHEVC_REQUIRE(c != nullptr, "ctx");
     OHEVC_REQUIRE(width > 0 && height > 0 && width <= 65535 && height <= 65535, "picture size");
     OHEVC_REQUIRE(cfi >= 1 && cfi <= 3, "chroma_format_idc must be 1..3");
-    OHEVC_REQUIRE(bd >= 8 && bd <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bd), "bit_depth must be 8..12 or 14");
     if (!c->dry) OHEVC_HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::mutex> g(c->store->m);
     int slot = -1;
@@ -351,7 +351,7 @@ extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int
 extern "C" int ohevc_pic_adopt(ohevc_ctx *c, const ohevc_plane planes[3], int width, int height, int cfi, int bd)
 {
     OHEVC_REQUIRE(c != nullptr && planes != nullptr, "null argument");
-    OHEVC_REQUIRE(width > 0 && height > 0 && cfi >= 1 && cfi <= 3 && bd >= 8 && bd <= 12, "bad picture description");
+    OHEVC_REQUIRE(width > 0 && height > 0 && cfi >= 1 && cfi <= 3 && OHEVC_BIT_DEPTH_OK(bd), "bad picture description");
     std::lock_guard<std::mutex> g(c->store->m);
     int slot = -1;
     for (int i = 0; i < c->store->npics; i++) if (!c->store->pics[i].used) { slot = i; break; }

@@ -327,7 +327,7 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
 {
     using namespace ohevc;
     OHEVC_REQUIRE(planes != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");
@@ -347,7 +347,7 @@ extern "C" int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr && src != nullptr && lagged != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");

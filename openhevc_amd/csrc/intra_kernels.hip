@@ -30,7 +30,7 @@ extern "C" int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_de
 {
     using namespace ohevc;
     OHEVC_REQUIRE(planes != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0, "jobs must be 16-byte aligned");

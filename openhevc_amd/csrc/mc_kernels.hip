@@ -40,6 +40,10 @@ struct McShared {
     short tmp[MC_WIN][MC_TILE];
 };
 
+// The rounding term of the final shift.  The reference drops it at BIT_DEPTH 14 ("#if BIT_DEPTH < 14 ... #else int offset = 0",
+// hevcdsp_template.c:653-657, 677-681, 808-812, 835-839, ...), where the uni shift is 0 and the bi shift 1.
+__device__ __forceinline__ int mc_round(int shift, int bit_depth) { return bit_depth < 14 ? 1 << (shift - 1) : 0; }
+
 template <typename Pixel>
 __device__ __forceinline__ void mc_tile_ref(McShared &sh, const ohevc_plane &ref, int sx, int sy, int mx, int my,
                                             bool luma, int tw, int th, int bit_depth, int lane, int *v)
@@ -123,13 +127,13 @@ __global__ __launch_bounds__(64) void mc_kernel(PlaneSet dst, const ohevc_plane 
                 int out;
                 if (!bi && !weighted) {             // put_hevc_*_uni_*: hevcdsp_template.c:626-640,796-943
                     const int shift = 14 - bit_depth;
-                    out = (v0[k4] + (1 << (shift - 1))) >> shift;
+                    out = (v0[k4] + mc_round(shift, bit_depth)) >> shift;
                 } else if (bi && !weighted) {       // put_hevc_*_bi_*: :642-666,822-983
                     const int shift = 15 - bit_depth;
-                    out = (v1[k4] + v0[k4] + (1 << (shift - 1))) >> shift;
+                    out = (v1[k4] + v0[k4] + mc_round(shift, bit_depth)) >> shift;
                 } else if (!bi) {                   // put_hevc_*_uni_w_*: :668-690,985-1134
                     const int shift = jb.denom + 14 - bit_depth;
-                    out = ((v0[k4] * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                    out = ((v0[k4] * jb.wx0 + mc_round(shift, bit_depth)) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
                 } else {                            // put_hevc_*_bi_w_*: :692-716,1012-1174
                     const int log2wd = jb.denom + 14 - bit_depth;
                     const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
@@ -287,13 +291,13 @@ __global__ __launch_bounds__(64) void mc2_kernel(PlaneSet dst, const ohevc_plane
                 int out;
                 if (!bi && !weighted) {
                     const int shift = 14 - bit_depth;
-                    out = (v0[j] + (1 << (shift - 1))) >> shift;
+                    out = (v0[j] + mc_round(shift, bit_depth)) >> shift;
                 } else if (bi && !weighted) {
                     const int shift = 15 - bit_depth;
-                    out = (v1[j] + v0[j] + (1 << (shift - 1))) >> shift;
+                    out = (v1[j] + v0[j] + mc_round(shift, bit_depth)) >> shift;
                 } else if (!bi) {
                     const int shift = jb.denom + 14 - bit_depth;
-                    out = ((v0[j] * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                    out = ((v0[j] * jb.wx0 + mc_round(shift, bit_depth)) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
                 } else {
                     const int log2wd = jb.denom + 14 - bit_depth;
                     const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
@@ -467,13 +471,13 @@ __global__ __launch_bounds__(64) void mc3_kernel(PlaneSet dst, const ohevc_plane
                 int out;
                 if (!bi && !weighted) {
                     const int shift = 14 - bit_depth;
-                    out = (v0[j] + (1 << (shift - 1))) >> shift;
+                    out = (v0[j] + mc_round(shift, bit_depth)) >> shift;
                 } else if (bi && !weighted) {
                     const int shift = 15 - bit_depth;
-                    out = (v1[j] + v0[j] + (1 << (shift - 1))) >> shift;
+                    out = (v1[j] + v0[j] + mc_round(shift, bit_depth)) >> shift;
                 } else if (!bi) {
                     const int shift = jb.denom + 14 - bit_depth;
-                    out = ((v0[j] * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                    out = ((v0[j] * jb.wx0 + mc_round(shift, bit_depth)) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
                 } else {
                     const int log2wd = jb.denom + 14 - bit_depth;
                     const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
@@ -558,13 +562,13 @@ __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_
                     if (!bi && !weighted) {
                         if (!jb.mx0 && !jb.my0) { *out_px = (unsigned short)(v0 >> (14 - bit_depth)); continue; }      // the memcpy case: no clip
                         const int shift = 14 - bit_depth;
-                        out = (v0 + (1 << (shift - 1))) >> shift;
+                        out = (v0 + mc_round(shift, bit_depth)) >> shift;
                     } else if (bi && !weighted) {
                         const int shift = 15 - bit_depth;
-                        out = (v1 + v0 + (1 << (shift - 1))) >> shift;
+                        out = (v1 + v0 + mc_round(shift, bit_depth)) >> shift;
                     } else if (!bi) {
                         const int shift = jb.denom + 14 - bit_depth;
-                        out = ((v0 * jb.wx0 + (1 << (shift - 1))) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
+                        out = ((v0 * jb.wx0 + mc_round(shift, bit_depth)) >> shift) + jb.ox0 * (1 << (bit_depth - 8));
                     } else {
                         const int log2wd = jb.denom + 14 - bit_depth;
                         const int o0 = jb.ox0 * (1 << (bit_depth - 8)), o1 = jb.ox1 * (1 << (bit_depth - 8));
@@ -623,7 +627,7 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr, "dst");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(njobs >= 0, "njobs");
     if (njobs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(refs != nullptr && n_ref_slots > 0, "refs");

@@ -144,7 +144,7 @@ extern "C" int ohevc_dev_upsample_plane(const ohevc_plane *dst, const ohevc_plan
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr && src != nullptr && dst->data != nullptr && src->data != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(cols != nullptr && col_of != nullptr && rows != nullptr, "maps");
     OHEVC_REQUIRE(dst->width > 0 && dst->height > 0 && src_cols > 0 && src_rows > 0, "sizes");
     // never read below the plane that was handed over (the reference would read its frame padding there, see make_maps)

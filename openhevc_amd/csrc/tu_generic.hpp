@@ -39,7 +39,9 @@ __device__ __forceinline__ void residual_generic(int kind, int log2, const int16
             out[o] = (short)clip16((acc + add) >> shift);
         }
     } else if (kind == OHEVC_TU_DC) {                      // :303-316
-        const int shift = 14 - bit_depth, add = 1 << (shift - 1);
+        // at BIT_DEPTH 14 the reference's `1 << (shift - 1)` has a negative count (hevcdsp_template.c:307-308); its gcc build folds
+        // that to 0 (pinned by tests/test_oracle_vs_reference.py against oracle/_ref), which is also the natural reading of shift 0
+        const int shift = 14 - bit_depth, add = shift > 0 ? 1 << (shift - 1) : 0;
         const int v = ((((int)blk[0] + 1) >> 1) + add) >> shift;
         for (int o = lane; o < NN; o += 64) out[o] = (short)v;
     } else {                                               // transform_skip :139-163, transquant bypass, + rdpcm :114-136

@@ -1325,7 +1325,7 @@ __device__ __forceinline__ void tu_rows_body(int wg, const PlaneSet planes, cons
     const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
     int res[N];
     if (kind == OHEVC_TU_DC) {
-        const int dc = (int)jraw.y >> 16, shift = 14 - bit_depth, add = 1 << (shift - 1);
+        const int dc = (int)jraw.y >> 16, shift = 14 - bit_depth, add = shift > 0 ? 1 << (shift - 1) : 0;       // BIT_DEPTH 14: see tu_generic.hpp
         const int v = (((dc + 1) >> 1) + add) >> shift;
 #pragma unroll
         for (int x = 0; x < N; x++) res[x] = v;
@@ -1670,7 +1670,7 @@ extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, in
 {
     using namespace ohevc;
     OHEVC_REQUIRE(planes != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(log2_size >= 2 && log2_size <= 5, "log2_size must be 2..5");
     OHEVC_REQUIRE(kind >= 0 && kind < OHEVC_TU_NKINDS, "unknown residual kind");
     OHEVC_REQUIRE(kind != OHEVC_TU_DST4 || log2_size == 2, "DST is 4x4 only");
@@ -1706,7 +1706,7 @@ extern "C" int ohevc_dev_tu_multi(const ohevc_plane planes[3], int bit_depth, co
 {
     using namespace ohevc;
     OHEVC_REQUIRE(planes != nullptr && (nsegs == 0 || segs != nullptr), "null argument");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(nsegs >= 0 && nsegs <= TU_MAX_SEGMENTS, "too many segments (max 40)");
     OHEVC_REQUIRE((reinterpret_cast<uintptr_t>(jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "jobs/coeffs must be 16-byte aligned");
     PlaneSet ps;
@@ -1748,7 +1748,7 @@ extern "C" int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, cons
     using namespace ohevc;
     static_assert(sizeof(LevelPhase) == sizeof(ohevc_level_phase), "phase record layout");
     OHEVC_REQUIRE(planes != nullptr, "planes");
-    OHEVC_REQUIRE(bit_depth >= 8 && bit_depth <= 12, "bit_depth must be 8..12");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     OHEVC_REQUIRE(nphases >= 0 && total_wgs >= 0, "negative count");
     if (nphases == 0 || total_wgs == 0) return OHEVC_OK;
     OHEVC_REQUIRE(phases != nullptr && sync != nullptr && need != nullptr, "null argument");

@@ -107,7 +107,9 @@ static void idct_full(int bd, int log2, int16_t *c, int col_limit)
 /* idct_NxN_dc: hevcdsp_template.c:303-316 */
 static void idct_dc(int bd, int log2, int16_t *c)
 {
-    int n2 = 1 << (2 * log2), shift = 14 - bd, add = 1 << (shift - 1);
+    /* BIT_DEPTH 14: the reference's `1 << (shift - 1)` (hevcdsp_template.c:308) has a negative count; its gcc build folds it to 0
+     * (pinned against oracle/_ref) */
+    int n2 = 1 << (2 * log2), shift = 14 - bd, add = shift > 0 ? 1 << (shift - 1) : 0;
     int v = (((c[0] + 1) >> 1) + add) >> shift;
     for (int i = 0; i < n2; i++) c[i] = (int16_t)v;
 }

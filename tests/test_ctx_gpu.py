@@ -30,7 +30,7 @@ def level_executor(request):
     lib.ohevc_debug_set_level_launch(prev)
 
 
-@pytest.mark.parametrize("bd,W,H,intra_frac", [(8, 416, 240, 0.15), (10, 192, 136, 0.5), (8, 128, 128, 1.0)])
+@pytest.mark.parametrize("bd,W,H,intra_frac", [(8, 416, 240, 0.15), (10, 192, 136, 0.5), (8, 128, 128, 1.0), (14, 192, 136, 0.3)])
 def test_synthetic_picture_matches_decode_order_oracle(oracle, level_executor, bd, W, H, intra_frac):
     rng = np.random.default_rng(bd * 1000 + W)
     dt = G.pixdt(bd)

@@ -20,7 +20,7 @@ def smooth_plane(rng, bd, h, w):
     return np.clip(p, 0, (1 << bd) - 1).astype(G.pixdt(bd))
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_deblock_vertical_then_horizontal(oracle, bd):
     rng = np.random.default_rng(700 + bd)
     H, W = 96, 160
@@ -72,7 +72,7 @@ def sao_variant(request):
     lib.ohevc_debug_set_sao_variant(prev)
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_sao_band_and_edge(oracle, sao_variant, bd):
     rng = np.random.default_rng(800 + bd)
     H, W = 136, 208

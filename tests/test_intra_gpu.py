@@ -8,7 +8,7 @@ import gpu_util as G
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_intra_pred_random_calls(oracle, bd):
     rng = np.random.default_rng(900 + bd)
     W, H = 136, 72                                      # not CTB aligned -> picture-edge clipping of the 2N neighbours
@@ -70,7 +70,7 @@ def test_intra_batch_of_independent_blocks(oracle):
     assert np.array_equal(G.to_host(d[0], np.uint8), want[0])
 
 
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 def test_intra_pred_constrained(oracle, bd):
     """constrained_intra_pred_flag streams: host re-derivation of availability + the kernel's substitution walk."""
     rng = np.random.default_rng(950 + bd)
@@ -110,7 +110,7 @@ def test_intra_pred_constrained(oracle, bd):
             assert np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]), (it, log2, c_idx, mode, cands, x0, y0, lpu, pl)
 
 
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 def test_intra_pred_constrained_structured_maps(oracle, bd):
     """Same check with intra/inter maps made of coding-unit sized patches on a wider picture (what real streams look like:
     long runs of non-intra neighbours next to fully intra ones), all mismatches reported."""

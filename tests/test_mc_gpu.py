@@ -40,7 +40,7 @@ def sprinkle_wild(rng, planes, bd):
         p[0, :9] = 0x8080; p[-1, -5:] = 40000          # picture corners: the clamped (edge-emulated) reads see them too
 
 
-@pytest.mark.parametrize("bd,wild", [(8, 0), (10, 0), (12, 0), (9, 1), (10, 1), (12, 1)])
+@pytest.mark.parametrize("bd,wild", [(8, 0), (10, 0), (12, 0), (14, 0), (9, 1), (10, 1), (12, 1), (14, 1)])
 def test_mc_all_variants_and_edges(oracle, bd, wild):
     rng = np.random.default_rng(500 + bd + 50 * wild)
     W, H = 208, 144                                   # luma; chroma planes are half size (4:2:0)

@@ -9,7 +9,7 @@ import pytest
 
 from oracle import pyoracle as po
 
-BDS = [8, 10, 12]
+BDS = [8, 10, 12, 14]
 
 
 def pixdt(bd):
@@ -36,7 +36,7 @@ def test_idct_dense(oracle, ref, bd, log2):
         assert np.array_equal(oracle.tu_residual(bd, po.TU_IDCT, log2, c), ref.tu_residual(bd, po.TU_IDCT, log2, c))
 
 
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 @pytest.mark.parametrize("log2", [2, 3, 4, 5])
 def test_idct_col_limit_semantics(oracle, ref, bd, log2):
     """The partial butterflies skip inputs beyond col_limit (hevcdsp_template.c:264-301); the restatement
@@ -200,7 +200,7 @@ def test_pred_modes(oracle, ref, bd, log2):
             assert np.array_equal(a, b), (mode, c_idx)
 
 
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 def test_intra_pred_full(oracle, ref, bd):
     rng = np.random.default_rng(61 + bd)
     W, H = 136, 72                      # not CTB aligned: exercises picture-edge clipping of the 2N neighbours
@@ -234,7 +234,7 @@ def test_intra_pred_full(oracle, ref, bd):
             assert np.array_equal(pa[i], pb[i]), (it, log2, c_idx, mode, cands, x0, y0, kw)
 
 
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 def test_intra_pred_constrained(oracle, ref, bd):
     """constrained_intra_pred_flag = 1: availability re-derivation + substitution walk (hevcpred_template.c:116-163,185-249).
     Positions are kept off the top picture row when the block has left neighbours: there the reference itself reads

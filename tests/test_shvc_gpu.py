@@ -14,7 +14,7 @@ ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 
 
 @pytest.mark.parametrize("block_slots", [0, 1])
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 def test_upsample_matches_oracle(bd, block_slots):
     rng = np.random.default_rng(70 + bd + block_slots)
     dt = np.uint16 if bd > 8 else np.uint8

@@ -30,7 +30,7 @@ def check_batch(oracle, bd, log2, kind, nblk, amp, seed, per_row=7, pixel_range=
     assert bad.size == 0, f"bd={bd} log2={log2} kind={kind} nblk={nblk}: {len(bad)} mismatching samples, first at {bad[:4].tolist()}"
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 @pytest.mark.parametrize("log2", [2, 3, 4, 5])
 def test_idct_add_bit_exact(oracle, bd, log2):
     for nblk, amp in [(1, 1024), (3, 1 << 15), (64, 1024), (257, 4096), (1000, 200)]:
@@ -42,7 +42,7 @@ LAB_FORMS = [512 + 128, 512 + 128 + 1024, 2048 + 4096 + 144, 2048 + 16384 + 144]
 
 
 @pytest.mark.parametrize("variant", PRODUCT_FORMS + LAB_FORMS)
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_idct_add_epilogue_forms_bit_exact(oracle, bd, variant):
     """The A/B forms of the 16x16 / 32x32 kernel (ohevc_debug.h): wave-private 64-sample strips (16), workgroup-wide 256-sample strips
     (512), non-temporal coefficient loads (1024) -- same pictures, including ragged tails (block counts that leave waves idle) and
@@ -74,7 +74,7 @@ def mfma_variant(request):
     lib.ohevc_debug_set_tu_variant(old)
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_idct32_matrix_core_form_bit_exact(oracle, mfma_variant, bd):
     import gpu_util as G
     from openhevc_amd import lib as L
@@ -100,7 +100,7 @@ def test_idct32_matrix_core_form_extremes(oracle, mfma_variant):
         assert bad.size == 0, (bd, len(bad), bad[:6].tolist())
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_idct_extreme_coefficients(oracle, bd):
     """All-max / all-min / alternating / single-coefficient blocks drive both clip_int16 stages and the pixel clip -- twelve blocks, so that
     the 32x32 case goes through the shipped matrix-core tile kernel (8 blocks per workgroup: int16 inputs as two int8 planes, where
@@ -123,7 +123,7 @@ def test_idct_extreme_coefficients(oracle, bd):
         assert np.array_equal(got, want), (bd, log2)
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_dst_and_other_kinds(oracle, bd):
     check_batch(oracle, bd, 2, po.TU_DST4, 333, 1 << 15, seed=bd)
     check_batch(oracle, bd, 2, po.TU_DST4, 5, 500, seed=bd + 1)
@@ -144,7 +144,7 @@ def test_prediction_samples_above_the_legal_range(oracle):
                 check_batch(oracle, bd, log2, kind, 61, 600, seed=bd + log2 + kind + 50, pixel_range=1 << 16)
 
 
-@pytest.mark.parametrize("bd", [8, 10, 12])
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
 def test_cross_component_prediction(oracle, bd):
     """OHEVC_TU_CROSS: chroma residual = own residual + (res_scale_val * luma residual) >> 3 with every pairing of residual
     kinds, including chroma blocks without coded coefficients (hevc.c:1291-1365, hevc_cabac.c:1942-1949)."""
