@@ -98,6 +98,11 @@ int  ohevc_rec_intra_bulk(ohevc_ctx *ctx, const ohevc_intra_job *jobs, int n);
 int  ohevc_rec_tu_bulk(ohevc_ctx *ctx, int n, const int32_t *desc, const int16_t *coeffs);
 int  ohevc_rec_deblock_bulk(ohevc_ctx *ctx, const ohevc_dbk_job *jobs, int n);
 int  ohevc_rec_sao_bulk(ohevc_ctx *ctx, const ohevc_sao_job *jobs, int n);
+/* The deblocking of the whole current picture as the decoder's maps (ohevc_hip.h: ohevc_dbk_maps, HOST pointers here): the arrays
+ * are copied, uploaded at the frame end and the edges derived on the device (ohevc_dev_deblock_maps) - the bulk form of every
+ * ohevc_rec_deblock call of the picture.  Needs a device: record-only contexts (ohevc_ctx_has_device() == 0) refuse it. */
+int  ohevc_rec_deblock_maps(ohevc_ctx *ctx, const ohevc_dbk_maps *maps);
+int  ohevc_ctx_has_device(const ohevc_ctx *ctx);
 
 /* upload + launch prediction/residual work recorded so far (may be called several times per frame) */
 int  ohevc_frame_reconstruct(ohevc_ctx *ctx);

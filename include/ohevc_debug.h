@@ -50,6 +50,10 @@ int ohevc_debug_set_level_launch(int mode);
  * ohevc_rec_* call does its normal work, the frame-end executor just drops the recorded jobs.  It exists to time the
  * recording cost of the table slots (tools/profile_recording.py); never a fallback: pictures stay unwritten. */
 int ohevc_debug_set_record_only(int on);
+/* A/B of ohevc_tables_derive_filters: 1 (default) the deblocking maps travel and the device derives the edges (ohevc_dev_deblock_maps);
+ * 0 the host derives one job per edge (the only form record-only contexts and the filter-lag emulation of 16x16 CTBs have).
+ * Returns the previous setting. */
+int ohevc_debug_set_filters_on_device(int on);
 
 /* Inspection of a record-only context, for HOST-LOGIC TESTS without a GPU: before a record-only context drops what was
  * recorded, it hands itself to this callback -- stage 0 from ohevc_frame_reconstruct (motion compensation, residual and intra

@@ -146,6 +146,28 @@ typedef struct ohevc_dbk_job {          /* 16 bytes */
 int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_job *jobs, int njobs,
                             void *stream);
 
+/* Deblocking straight from the decoder's maps: the device derives what deblocking_filter_CTB (hevc_filter.c:345-581)
+ * derives per edge - which edges exist (boundary strengths), the QP average (get_qPy :144-150), beta / tc (tables :50-60, TC_CALC
+ * :340-343, chroma_tc :62-89), the pcm / bypass flags (get_pcm :325-338) - and filters; no per-edge host work, no job list.
+ * Pointers are DEVICE pointers for ohevc_dev_deblock_maps and HOST pointers for ohevc_rec_deblock_maps (ohevc_ctx.h), which copies
+ * and uploads them.  Array sizes as the reference allocates them (hevc.c:123-171):
+ *   vertical_bs   bs_width * ((height >> 2) + 4 * (1 << vshift))      bs_width = width >> 2
+ *   horizontal_bs (bs_width + 4 * (1 << hshift)) * (height >> 2)
+ *   qp_y_tab      min_cb_width * (height >> log2_min_cb_size)         int8
+ *   deblock       DBParams { int8 beta_offset, tc_offset } per CTB, deblock_stride bytes apart
+ *   is_pcm        min_pu_width * min_pu_height, or NULL when neither pcm loop-filter bypass nor transquant bypass is in use */
+typedef struct ohevc_dbk_maps {
+    const uint8_t *vertical_bs, *horizontal_bs;
+    const int8_t  *qp_y_tab;
+    const int8_t  *deblock;
+    const uint8_t *is_pcm;
+    int32_t bs_width, min_cb_width, deblock_stride, min_pu_width, min_pu_height;
+    int32_t width, height, log2_ctb_size, log2_min_cb_size, log2_min_pu_size, chroma_format_idc;
+    int32_t cb_qp_offset, cr_qp_offset;
+} ohevc_dbk_maps;
+/* one pass: vertical != 0 all vertical edges (luma and chroma), else all horizontal edges; the caller runs both, in that order */
+int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_maps *maps, int vertical, void *stream);
+
 /* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
  * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy
  * (the reference's sao_frame), one job per CTB and colour plane. */

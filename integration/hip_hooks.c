@@ -386,6 +386,9 @@ int ohdec_backend_open(void)
     g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
     /* A/B of the executors of the intra-coded blocks (include/ohevc_debug.h): 0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture */
     ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
+    /* A/B: 0 = the deblocking parameters are derived on the host, one job per edge (default: on the device, from the maps) */
+    if (getenv("OHHIP_DEVICE_FILTERS"))
+        ohevc_debug_set_filters_on_device(atoi(getenv("OHHIP_DEVICE_FILTERS")));
     if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
         return -1;

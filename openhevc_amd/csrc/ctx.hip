@@ -164,6 +164,8 @@ struct ohevc_ctx : Rec {
 
     std::vector<ohevc_level_phase> phases;                // scratch of frame_reconstruct
     std::vector<uint32_t> need, sync_zero;
+    std::vector<uint8_t> dbk_blob;                         // ohevc_rec_deblock_maps: the copied maps back to back (empty = none)
+    ohevc_dbk_maps dbk_maps = {};                          // geometry; the pointers hold offsets into dbk_blob
     std::vector<uint8_t> bypass;                           // ohevc_frame_set_bypass_map: is_pcm bytes, row length bypass_w (empty = none)
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
@@ -178,7 +180,7 @@ struct ohevc_ctx : Rec {
     PinnedBuf stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
-    int n_frames = 0;
+    int n_frames = 0, n_map_frames = 0;
 };
 
 using namespace ohevc;
@@ -261,8 +263,8 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (!c) return;
     ohevc_tables_forget(c);
     if (g_trace_timing && c->n_frames)
-        fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms\n", (void *)c,
-                c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames);
+        fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms; deblocking derived on the device in %d\n",
+                (void *)c, c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames, c->n_map_frames);
     if (c->dry) { delete c; return; }
     // teardown: an error here has nowhere to go
     (void)hipSetDevice(c->device);
@@ -643,7 +645,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
         c->level_map[i].assign((size_t)c->lm_w[i] * c->lm_h[i], 0);
     }
     clear_recorded(c);
-    c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->bypass.clear();
+    c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->bypass.clear();
     c->stats = ohevc_frame_stats{};
     for (int &v : c->nstat) v = 0;
     c->owner = std::this_thread::get_id();
@@ -914,6 +916,40 @@ extern "C" int ohevc_rec_deblock_bulk(ohevc_ctx *c, const ohevc_dbk_job *jobs, i
     r.nstat[3] += n;
     return OHEVC_OK;
 }
+// The deblocking of the current picture, handed over as the decoder's own maps (ohevc_hip.h, ohevc_dbk_maps): copied here (the
+// decoder reuses its arrays for the next picture), uploaded with the frame end's job arrays, derived and filtered on the device.
+extern "C" int ohevc_rec_deblock_maps(ohevc_ctx *c, const ohevc_dbk_maps *m)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && m != nullptr, "no frame begun");
+    OHEVC_REQUIRE(!c->dry, "record-only contexts take deblocking as jobs (no device to derive them)");
+    OHEVC_REQUIRE(m->width > 0 && m->height > 0 && m->log2_ctb_size >= 4 && m->log2_ctb_size <= 6 && m->log2_min_cb_size >= 3 &&
+                  m->chroma_format_idc >= 0 && m->chroma_format_idc <= 3, "picture geometry");
+    OHEVC_REQUIRE(m->horizontal_bs && m->vertical_bs && m->bs_width > 0 && m->qp_y_tab && m->min_cb_width > 0 && m->deblock && m->deblock_stride >= 2,
+                  "deblocking maps");
+    OHEVC_REQUIRE(!m->is_pcm || (m->min_pu_width > 0 && m->min_pu_height > 0 && m->log2_min_pu_size >= 2), "pcm map");
+    const int hs = m->chroma_format_idc == 1 || m->chroma_format_idc == 2, vs = m->chroma_format_idc == 1;
+    const int ctb = 1 << m->log2_ctb_size, ctb_w = (m->width + ctb - 1) >> m->log2_ctb_size, ctb_h = (m->height + ctb - 1) >> m->log2_ctb_size;
+    const size_t bs_h = (size_t)(m->height >> 2);
+    const size_t n_v = (size_t)m->bs_width * (bs_h + (4u << vs)), n_h = ((size_t)m->bs_width + (4u << hs)) * bs_h;          // hevc.c:170-171
+    const size_t n_qp = (size_t)m->min_cb_width * (size_t)(m->height >> m->log2_min_cb_size);
+    const size_t n_db = (size_t)ctb_w * ctb_h * m->deblock_stride, n_pcm = m->is_pcm ? (size_t)m->min_pu_width * m->min_pu_height : 0;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_v = 0, o_h = o_v + up(n_v), o_qp = o_h + up(n_h), o_db = o_qp + up(n_qp), o_pcm = o_db + up(n_db), total = o_pcm + up(n_pcm);
+    c->dbk_blob.resize(total);
+    memcpy(c->dbk_blob.data() + o_v, m->vertical_bs, n_v);
+    memcpy(c->dbk_blob.data() + o_h, m->horizontal_bs, n_h);
+    memcpy(c->dbk_blob.data() + o_qp, m->qp_y_tab, n_qp);
+    memcpy(c->dbk_blob.data() + o_db, m->deblock, n_db);
+    if (n_pcm) memcpy(c->dbk_blob.data() + o_pcm, m->is_pcm, n_pcm);
+    c->dbk_maps = *m;
+    c->dbk_maps.vertical_bs = reinterpret_cast<const uint8_t *>(o_v); c->dbk_maps.horizontal_bs = reinterpret_cast<const uint8_t *>(o_h);
+    c->dbk_maps.qp_y_tab = reinterpret_cast<const int8_t *>(o_qp); c->dbk_maps.deblock = reinterpret_cast<const int8_t *>(o_db);
+    c->dbk_maps.is_pcm = n_pcm ? reinterpret_cast<const uint8_t *>(o_pcm) : nullptr;
+    c->nstat[3]++;
+    c->n_map_frames++;
+    return OHEVC_OK;
+}
+extern "C" int ohevc_ctx_has_device(const ohevc_ctx *c) { return c && !c->dry; }
 extern "C" int ohevc_rec_sao_bulk(ohevc_ctx *c, const ohevc_sao_job *jobs, int n)
 {
     for (int i = 0; i < n; i++) { int rc = ohevc_rec_sao(c, jobs + i); if (rc != OHEVC_OK) return rc; }
@@ -1300,7 +1336,7 @@ extern "C" int ohevc_frame_abort(ohevc_ctx *c)
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     clear_recorded(c);
-    c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
+    c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
     {
         std::lock_guard<std::mutex> g(c->store->m);
         p->failed = true;
@@ -1337,16 +1373,29 @@ static int frame_end_impl(ohevc_ctx *c)
         c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
     }
     if (c->sao.empty()) c->bypass.clear();
-    if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty()) {
+    if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty() || !c->dbk_blob.empty()) {
         std::vector<std::pair<const void *, size_t>> parts;
         size_t total = 0;
+        const size_t off_m = c->dbk_blob.empty() ? 0 : stage_put(parts, total, c->dbk_blob.data(), c->dbk_blob.size());
         const size_t off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
         const size_t off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
         const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
         const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
         if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
         unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
+        ohevc_dbk_maps dm = c->dbk_maps;                  // offsets -> device addresses
+        if (!c->dbk_blob.empty()) {
+            dm.vertical_bs = base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.vertical_bs);
+            dm.horizontal_bs = base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.horizontal_bs);
+            dm.qp_y_tab = reinterpret_cast<const int8_t *>(base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.qp_y_tab));
+            dm.deblock = reinterpret_cast<const int8_t *>(base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.deblock));
+            dm.is_pcm = c->dbk_maps.is_pcm ? base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.is_pcm) : nullptr;      // its offset is never 0
+        }
         // all vertical edges, then all horizontal edges: deblocking_filter_CTB, hevc_filter.c:385-580
+        if (!c->dbk_blob.empty()) {
+            if ((rc = ohevc_dev_deblock_maps(p->planes, p->bd, &dm, 1, c->stream)) != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
         if (!c->dbk_v.empty()) {
             if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_v), (int)c->dbk_v.size(), c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
@@ -1364,6 +1413,10 @@ static int frame_end_impl(ohevc_ctx *c)
             for (int i = 1; i < 3; i++)
                 OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
                                              hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (!c->dbk_blob.empty()) {
+            if ((rc = ohevc_dev_deblock_maps(p->planes, p->bd, &dm, 0, c->stream)) != OHEVC_OK) return rc;
+            c->stats.launches++;
         }
         if (!c->dbk_h.empty()) {
             if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_h), (int)c->dbk_h.size(), c->stream)) != OHEVC_OK) return rc;
@@ -1384,7 +1437,7 @@ static int frame_end_impl(ohevc_ctx *c)
             if ((rc = ohevc_dev_sao_batch_bypass(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), &bp, c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
-        c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
+        c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
     }
     if (!c->dry) {
         // publish: this picture is reconstructed once `ev` fires; the references were read until then

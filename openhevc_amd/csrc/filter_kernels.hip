@@ -15,16 +15,12 @@ namespace ohevc {
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int iclip(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 
+// One line of one 8-sample edge: lane `line` (0..7) of an 8-lane group; every exit is taken by whole 4-line segments.
+// beta_in / tc_in before bit-depth scaling, tc_in of this lane's segment.
 template <typename Pixel>
-__global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohevc_dbk_job *__restrict__ jobs, int njobs, int bit_depth)
+__device__ __forceinline__ void deblock_line(const PlaneSet &planes, int jx, int jy, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth)
 {
-    const int tid = blockIdx.x * 256 + threadIdx.x;
-    const int job = tid >> 3, line = tid & 7, seg = line >> 2;
-    if (job >= njobs) return;                        // whole 8-lane groups leave together
-    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
-    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff, flags = (jraw.y >> 8) & 0xff;
-    const int beta_in = (jraw.y >> 16) & 0xff;
-    const int tc_in = seg ? (int)jraw.z >> 16 : (int)(short)(jraw.z & 0xffff);
+    const int seg = line >> 2;
     const bool vertical = flags & OHEVC_DBK_VERTICAL_EDGE;
     const bool no_p = flags & (seg ? OHEVC_DBK_NO_P1 : OHEVC_DBK_NO_P0);
     const bool no_q = flags & (seg ? OHEVC_DBK_NO_Q1 : OHEVC_DBK_NO_Q0);
@@ -112,6 +108,97 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
     flush();
 #undef LD
 #undef ST
+}
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohevc_dbk_job *__restrict__ jobs, int njobs, int bit_depth)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int job = tid >> 3, line = tid & 7, seg = line >> 2;
+    if (job >= njobs) return;                        // whole 8-lane groups leave together
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff, flags = (jraw.y >> 8) & 0xff;
+    const int beta_in = (jraw.y >> 16) & 0xff;
+    const int tc_in = seg ? (int)jraw.z >> 16 : (int)(short)(jraw.z & 0xffff);
+    deblock_line<Pixel>(planes, jx, jy, jplane, flags, beta_in, tc_in, line, bit_depth);
+}
+
+// ------------------------------------------------------------------ deblocking straight from the decoder's maps
+// The parameter derivation of deblocking_filter_CTB (hevc_filter.c:345-581) per edge instead of per CTB loop: which 8-sample edges
+// exist (boundary-strength maps), QP average of the two sides (get_qPy, :144-150), beta / tc from H.265 table 8-12 (:50-60, TC_CALC
+// :340-343, chroma_tc :62-89), pcm / bypass flags (get_pcm, :325-338).  The reference's loops give an edge next to a CTB boundary
+// offsets of a particular neighbour CTB; restated per edge (the loops: hevc_filter.c:385-579):
+//   vertical edges            beta_offset, tc_offset of the CTB the edge lies in
+//   horizontal luma edge      beta_offset of the CTB holding x, tc_offset of the CTB holding x + 8 (the run of a CTB starts 8 samples
+//                             inside its left neighbour; the last CTB column runs to the picture edge)
+//   horizontal chroma edge    segment 0: tc_offset of the CTB holding x, segment 1: of the CTB holding x + 8 * h
+// One 8-lane group per edge position of the 8x8 luma grid (luma) / the (8h)x(8v) grid (each chroma plane); all lanes of a group derive
+// the same parameters (a handful of byte loads that hit the same cache line) and groups without an edge leave at once.
+OHEVC_CONST_TABLE unsigned char kDbkTc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
+                                               4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+OHEVC_CONST_TABLE unsigned char kDbkBeta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
+                                                 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+OHEVC_CONST_TABLE unsigned char kDbkQpC[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohevc_dbk_maps m, int vertical, int bit_depth, int luma_units, int chroma_units,
+                                                           int luma_uw, int chroma_uw)
+{
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    int unit = tid >> 3;
+    const int line = tid & 7;
+    if (unit >= luma_units + 2 * chroma_units) return;
+    int plane = 0;
+    if (unit >= luma_units) { unit -= luma_units; plane = 1; if (unit >= chroma_units) { unit -= chroma_units; plane = 2; } }
+    const int hs = plane && (m.chroma_format_idc == 1 || m.chroma_format_idc == 2), vs = plane && m.chroma_format_idc == 1;
+    const int uw = plane ? chroma_uw : luma_uw;
+    const int x = (unit % uw) << (3 + hs), y = (unit / uw) << (3 + vs);          // luma coordinates of the edge's first sample
+    if (vertical ? x == 0 : y == 0) return;
+    const int dx = vertical ? 0 : 4 << hs, dy = vertical ? 4 << vs : 0;           // second segment
+    const unsigned char *bsm = vertical ? m.vertical_bs : m.horizontal_bs;
+    const int bs0 = bsm[(x + y * m.bs_width) >> 2], bs1 = bsm[(x + dx + (y + dy) * m.bs_width) >> 2];
+    if (plane ? !(bs0 == 2 || bs1 == 2) : !(bs0 || bs1)) return;
+    const int log2_ctb = m.log2_ctb_size, ctb_w = (m.width + (1 << log2_ctb) - 1) >> log2_ctb;
+    auto qpy = [&](int xx, int yy) { return (int)m.qp_y_tab[(xx >> m.log2_min_cb_size) + (yy >> m.log2_min_cb_size) * m.min_cb_width]; };
+    auto ctb_param = [&](int xx, int k) {                        // DBParams of the CTB holding (xx, y), xx clamped to the last column
+        int cx = xx >> log2_ctb;
+        cx = cx < ctb_w - 1 ? cx : ctb_w - 1;
+        return (int)m.deblock[(size_t)(cx + (y >> log2_ctb) * ctb_w) * m.deblock_stride + k];
+    };
+    auto clipi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
+    const int px = vertical ? x - 1 : x, py = vertical ? y : y - 1;               // the P side of segment 0
+    int flags = vertical ? OHEVC_DBK_VERTICAL_EDGE : 0;
+    if (m.is_pcm) {
+        auto pcm = [&](int xx, int yy) {
+            if (xx < 0 || yy < 0) return 2;
+            const int xp = xx >> m.log2_min_pu_size, yp = yy >> m.log2_min_pu_size;
+            if (xp >= m.min_pu_width || yp >= m.min_pu_height) return 2;
+            return (int)m.is_pcm[yp * m.min_pu_width + xp];
+        };
+        flags |= (pcm(px, py) ? OHEVC_DBK_NO_P0 : 0) | (pcm(px + dx, py + dy) ? OHEVC_DBK_NO_P1 : 0) |
+                 (pcm(x, y) ? OHEVC_DBK_NO_Q0 : 0) | (pcm(x + dx, y + dy) ? OHEVC_DBK_NO_Q1 : 0);
+    }
+    const int seg = line >> 2;
+    int beta = 0, tc;
+    if (plane == 0) {
+        const int qp = (qpy(px, py) + qpy(x, y) + 1) >> 1;
+        const int beta_offset = ctb_param(x, 0), tc_offset = ctb_param(vertical ? x : x + 8, 1);
+        beta = kDbkBeta[clipi(qp + beta_offset, 0, 51)];
+        const int bs = seg ? bs1 : bs0;
+        tc = bs ? kDbkTc[clipi(qp + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)] : 0;
+    } else {
+        const int bs = seg ? bs1 : bs0;
+        tc = 0;
+        if (bs == 2) {
+            const int sx = seg ? dx : 0, sy = seg ? dy : 0;
+            const int qp_y = (qpy(px + sx, py + sy) + qpy(x + sx, y + sy) + 1) >> 1;
+            const int tc_offset = ctb_param(vertical || !seg ? x : x + (8 << hs), 1);
+            const int qp_i = clipi(qp_y + (plane == 1 ? m.cb_qp_offset : m.cr_qp_offset), 0, 57);
+            const int qp = m.chroma_format_idc == 1 ? (qp_i < 30 ? qp_i : qp_i > 43 ? qp_i - 6 : (int)kDbkQpC[qp_i - 30]) : clipi(qp_i, 0, 51);
+            tc = kDbkTc[clipi(qp + 2 + tc_offset, 0, 53)];
+        }
+    }
+    deblock_line<Pixel>(planes, x >> hs, y >> vs, plane, flags, beta, tc, line, bit_depth);
 }
 
 // One workgroup per SAO block.  Fast form (block width a multiple of 4 samples, dword-aligned rows - every block the decoder makes):
@@ -338,6 +425,33 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
     const int grid = (int)(((long long)njobs * 8 + 255) / 256);
     if (bit_depth == 8) hipLaunchKernelGGL((deblock_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, bit_depth);
     else                hipLaunchKernelGGL((deblock_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, jobs, njobs, bit_depth);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_maps *m, int vertical, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(planes != nullptr && m != nullptr, "null argument");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
+    OHEVC_REQUIRE(m->width > 0 && m->height > 0 && m->log2_ctb_size >= 4 && m->log2_ctb_size <= 6 && m->log2_min_cb_size >= 3 &&
+                  m->chroma_format_idc >= 0 && m->chroma_format_idc <= 3, "picture geometry");
+    OHEVC_REQUIRE(m->horizontal_bs && m->vertical_bs && m->bs_width > 0 && m->qp_y_tab && m->min_cb_width > 0 && m->deblock && m->deblock_stride >= 2,
+                  "deblocking maps");
+    OHEVC_REQUIRE(!m->is_pcm || (m->min_pu_width > 0 && m->min_pu_height > 0 && m->log2_min_pu_size >= 2), "pcm map");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
+    if (rc != OHEVC_OK) return rc;
+    const int hs = m->chroma_format_idc == 1 || m->chroma_format_idc == 2, vs = m->chroma_format_idc == 1;
+    // the loops of deblocking_filter_CTB step 8 (luma) / 8h, 8v (chroma) samples from 0 while below the picture size
+    const int luma_uw = (m->width + 7) >> 3, luma_uh = (m->height + 7) >> 3;
+    const int chroma_uw = m->chroma_format_idc ? (m->width + (8 << hs) - 1) >> (3 + hs) : 0, chroma_uh = m->chroma_format_idc ? (m->height + (8 << vs) - 1) >> (3 + vs) : 0;
+    const int luma_units = luma_uw * luma_uh, chroma_units = chroma_uw * chroma_uh;
+    const long long threads = ((long long)luma_units + 2ll * chroma_units) * 8;
+    const int grid = (int)((threads + 255) / 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bit_depth == 8) hipLaunchKernelGGL((deblock_maps_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_units, chroma_units, luma_uw, chroma_uw);
+    else                hipLaunchKernelGGL((deblock_maps_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_units, chroma_units, luma_uw, chroma_uw);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

@@ -15,6 +15,8 @@
 #include <vector>
 #include "common.hpp"
 #include "ohevc_tables.h"
+#include "ohevc_ctx.h"
+#include "ohevc_debug.h"
 
 namespace {
 
@@ -94,7 +96,8 @@ struct Ctx {
                 for (int x = x0 ? x0 : 8 * h; x < x_end; x += 8 * h) {
                     const int bs0 = m.vertical_bs[(x + y * m.bs_width) >> 2], bs1 = m.vertical_bs[(x + (y + 4 * v) * m.bs_width) >> 2];
                     if (!(bs0 == 2 || bs1 == 2)) continue;
-                    const int qp0 = (qpy(x - 1, y) + qpy(x, y) + 1) >> 1, qp1 = (qpy(x - 1, y + 4 * v) + qpy(x, y + 4 * v) + 1) >> 1;
+                    // (the reference evaluates both unconditionally, :440-441 - for bs1 != 2 that can be a row below the picture; the value is unused)
+                    const int qp0 = bs0 == 2 ? (qpy(x - 1, y) + qpy(x, y) + 1) >> 1 : 0, qp1 = bs1 == 2 ? (qpy(x - 1, y + 4 * v) + qpy(x, y + 4 * v) + 1) >> 1 : 0;
                     if (pcmf) { no_p[0] = pcm(x - 1, y); no_p[1] = pcm(x - 1, y + 4 * v); no_q[0] = pcm(x, y); no_q[1] = pcm(x, y + 4 * v); }
                     for (int c = 1; c <= 2; c++)
                         edge(c, x >> hs, y >> vs, true, 0, bs0 == 2 ? tc_chroma(qp0, c, tc_offset) : 0, bs1 == 2 ? tc_chroma(qp1, c, tc_offset) : 0, no_p, no_q);
@@ -227,7 +230,11 @@ struct Ctx {
     }
 };
 
+bool g_filters_on_device = true;
+
 }  // namespace
+
+extern "C" int ohevc_debug_set_filters_on_device(int on) { const int prev = g_filters_on_device; g_filters_on_device = on != 0; return prev; }
 
 extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *m)
 {
@@ -257,7 +264,25 @@ extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_ma
         }
         c.hls_filter(x, y);                                    // hevc.c:2693-2695: the last CTB of the picture releases itself
         c.release_held_sao();
+    } else if (g_filters_on_device && ohevc_ctx_has_device(ctx)) {
+        // the product path: no per-edge host work - the maps travel, ohevc_dev_deblock_maps derives and filters;
+        // what stays here is one SAO record per CTB and plane
+        ohevc_dbk_maps d = {};
+        d.vertical_bs = m->vertical_bs; d.horizontal_bs = m->horizontal_bs; d.bs_width = m->bs_width;
+        d.qp_y_tab = m->qp_y_tab; d.min_cb_width = m->min_cb_width; d.deblock = m->deblock; d.deblock_stride = m->deblock_stride;
+        d.is_pcm = m->pcm_or_bypass ? m->is_pcm : nullptr; d.min_pu_width = m->min_pu_width; d.min_pu_height = m->min_pu_height;
+        d.width = m->width; d.height = m->height; d.log2_ctb_size = m->log2_ctb_size; d.log2_min_cb_size = m->log2_min_cb_size;
+        d.log2_min_pu_size = m->log2_min_pu_size; d.chroma_format_idc = m->chroma_format_idc;
+        d.cb_qp_offset = m->cb_qp_offset; d.cr_qp_offset = m->cr_qp_offset;
+        const int r = ohevc_rec_deblock_maps(ctx, &d);
+        if (r != OHEVC_OK) return r;
+        if (m->sao_enabled)
+            for (int y = 0; y < m->height; y += ctb_size)
+                for (int x = 0; x < m->width; x += ctb_size) c.sao_ctb(x, y);
+        return c.rc;
     } else {
+        // record-only contexts (host-logic tests through the frame sink) and ohevc_debug_set_filters_on_device(0): the same
+        // derivation on the host, one job per edge
         for (int y = 0; y < m->height; y += ctb_size)
             for (int x = 0; x < m->width; x += ctb_size) {
                 c.deblock_ctb(x, y);

@@ -157,6 +157,21 @@ def dev_deblock_batch(planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_deblock_batch(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
+class DbkMaps(C.Structure):
+    """ohevc_dbk_maps (include/ohevc_hip.h)"""
+    _fields_ = [("vertical_bs", C.c_void_p), ("horizontal_bs", C.c_void_p), ("qp_y_tab", C.c_void_p), ("deblock", C.c_void_p), ("is_pcm", C.c_void_p),
+                ("bs_width", C.c_int32), ("min_cb_width", C.c_int32), ("deblock_stride", C.c_int32), ("min_pu_width", C.c_int32), ("min_pu_height", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("log2_ctb_size", C.c_int32), ("log2_min_cb_size", C.c_int32), ("log2_min_pu_size", C.c_int32),
+                ("chroma_format_idc", C.c_int32), ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32)]
+
+
+def dev_deblock_maps(planes, bit_depth, maps, vertical, stream=0):
+    check(load_library().ohevc_dev_deblock_maps(planes, C.c_int(bit_depth), C.byref(maps), C.c_int(vertical), C.c_void_p(stream)))
+
+
+EXPORTED_SYMBOLS += ["ohevc_dev_deblock_maps", "ohevc_rec_deblock_maps", "ohevc_ctx_has_device", "ohevc_debug_set_filters_on_device"]
+
+
 def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_sao_batch(dst_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 

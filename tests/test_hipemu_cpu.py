@@ -50,7 +50,7 @@ def _adopt(modname):
             globals()[name] = obj
 
 
-for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu").split():
+for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_dbk_maps_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu").split():
     _adopt(_m)
 
 
@@ -78,6 +78,18 @@ def test_emu_golden_stream(name, executor, monkeypatch):
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
     monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", executor)
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
+
+
+@pytest.mark.parametrize("name", ["pcm", "tiles_nolf", "slices_nolf", "fmt422_8b", "ra_8b_ctb64", "ra_14b_weighted"])
+def test_emu_golden_stream_filters_derived_on_the_host(name, monkeypatch):
+    """The job form of the deblocking (filters_host.hip, one record per edge) next to the default (maps, derived on the device)."""
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_DEVICE_FILTERS", "0")
     aus, md5 = load_golden(name)
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 

@@ -37,6 +37,15 @@ def test_golden_stream_hip_backend(name, executor, monkeypatch):
         _compare(ps.decode_stream("c", aus), hip)   # ... and sample-exact against it when it is present
 
 
+@pytest.mark.parametrize("name", ["pcm", "pcm_10b", "tiles_nolf", "slices_nolf", "cip", "fmt422_8b", "ra_8b_ctb64", "weighted_p_10b", "ra_14b_weighted"])
+def test_golden_stream_filters_derived_on_the_host(name, monkeypatch):
+    """The default derives the deblocking parameters on the device from the decoder's maps (ohevc_dev_deblock_maps); the job form
+    (one record per edge, derived by filters_host.hip) stays for record-only contexts and the filter-lag emulation and must agree."""
+    monkeypatch.setenv("OHHIP_DEVICE_FILTERS", "0")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hip", aus)) == md5
+
+
 @pytest.mark.parametrize("kw", [
     dict(gop="random_access", nframes=9, seed=301, width=832, height=480, log2_ctb=6),
     dict(gop="random_access", nframes=9, seed=302, width=832, height=480, log2_ctb=6, bit_depth=10, weighted_bipred=1,

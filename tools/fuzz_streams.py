@@ -15,7 +15,7 @@ from oracle import pystream as ps       # noqa: E402
 def random_params(rng):
     log2_ctb = int(rng.choice([4, 5, 6]))
     kw = dict(
-        width=int(rng.integers(8, 60)) * 8, height=int(rng.integers(8, 40)) * 8, bit_depth=int(rng.choice([8, 8, 10, 9])),
+        width=int(rng.integers(8, 60)) * 8, height=int(rng.integers(8, 40)) * 8, bit_depth=int(rng.choice([8, 8, 8, 10, 10, 9, 12, 14])),
         log2_ctb=log2_ctb, log2_max_tb=min(5, log2_ctb), gop=str(rng.choice(["intra", "lowdelay_p", "lowdelay_b", "random_access"])),
         nframes=int(rng.integers(2, 7)), seed=int(rng.integers(1, 1 << 30)),
         amp=int(rng.integers(0, 2)), sao=int(rng.integers(0, 4) != 0), strong_intra_smoothing=int(rng.integers(0, 2)),
