@@ -57,6 +57,13 @@ int  ohevc_pic_release(ohevc_ctx *ctx, int slot);
 int  ohevc_pic_upload(ohevc_ctx *ctx, int slot, int plane, const void *host, ptrdiff_t host_stride);
 int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff_t host_stride);
 int  ohevc_pic_planes(ohevc_ctx *ctx, int slot, ohevc_plane out[3]);     /* device views (e.g. for an RCCL broadcast) */
+/* Frame-parallel decoding across GPUs (one process per GPU; the reference's counterpart is the shared DPB of its frame threads,
+ * pthread_frame.c:479-513 + hevc_await_progress hevc.c:1951-1958): the owner of a picture copies a finished plane out with
+ * ohevc_pic_export, the other processes copy it into their own store with ohevc_pic_import; the transport in between (RCCL
+ * broadcast over xGMI) is the application's.  Buffers are DEVICE memory of exactly stride x height bytes (ohevc_pic_planes); both
+ * calls are ordered against the frames of every context of the store and return when the copy is complete. */
+int  ohevc_pic_export(ohevc_ctx *ctx, int slot, int plane, void *device_dst, size_t bytes);
+int  ohevc_pic_import(ohevc_ctx *ctx, int slot, int plane, const void *device_src, size_t bytes);
 int  ohevc_pic_info(ohevc_ctx *ctx, int slot, int *width, int *height, int *chroma_format_idc, int *bit_depth);
 
 /* SHVC: resample picture src_slot (a base-layer picture of the store) into picture dst_slot, the enhancement layer's

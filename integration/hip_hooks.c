@@ -30,6 +30,7 @@
 
 #include "ohevc_tables.h"
 #include "ohevc_debug.h"
+#include "hip_frames.h"
 
 /* one context per decoding thread, all sharing the root's picture store (ohevc_ctx_create_shared): frame threads
  * (pthread_frame.c) reconstruct different pictures concurrently and predict from each other's */
@@ -54,8 +55,18 @@ static struct {
     int slot, w, h, bd, fmt;
     int poc, seq;              /* the picture that lives in the buffer: HEVCFrame.poc / .sequence when it was registered */
     ohevc_ctx *ctx;            /* the context that is reconstructing (or last reconstructed) this picture */
+    /* frame-parallel decoding over processes (hip_frames.h): decoding-order index, owned elsewhere, what has arrived */
+    int index, remote, have_motion, have_planes;
 } g_bufs[MAX_BUFS];
 static int g_nbufs;
+
+static ohhip_frames_mode   g_fm;
+static int                 g_fm_on;
+static int                 g_fm_index;     /* pictures started so far (decoding order; one decoding thread in this mode) */
+static __thread int        t_remote;       /* the picture being parsed is reconstructed by another process: skip its slice data */
+static __thread int        t_publish;      /* the open frame is exchanged at its end (index of its g_bufs entry + 1) */
+static int (*g_execute)(AVCodecContext *, int (*)(AVCodecContext *, void *), void *, int *, int, int);
+static int (*g_execute2)(AVCodecContext *, int (*)(AVCodecContext *, void *, int, int), void *, int *, int);
 
 int ohdec_backend_frame_done(void);
 int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
@@ -181,6 +192,35 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     g_bufs[i].ctx = ctx;
     g_bufs[i].poc = s->ref->poc;
     g_bufs[i].seq = s->ref->sequence;
+    g_bufs[i].index = -1;
+    g_bufs[i].remote = 0;
+    t_remote = 0;
+    t_publish = 0;
+    if (g_fm_on) {
+        /* a picture nothing can predict from: sub-layer non-reference (even nal_unit_type below 16, H.265 table 7-1) in the
+         * highest temporal sub-layer -- it is not exchanged */
+        const int exchanged = !(s->nal_unit_type < 16 && !(s->nal_unit_type & 1) && s->temporal_id == s->sps->max_sub_layers - 1);
+        const size_t mvf_bytes = (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField);     /* hevc.c:178 */
+        g_bufs[i].index = g_fm_index++;
+        g_bufs[i].remote = g_bufs[i].index % g_fm.world != g_fm.rank;
+        g_bufs[i].have_motion = g_bufs[i].have_planes = !g_bufs[i].remote;
+        if (g_bufs[i].remote) {
+            const int index = g_bufs[i].index;
+            pthread_mutex_unlock(&g_lock);
+            t_remote = 1;
+            t_frame_open = 0;
+            t_s = s;
+            /* later pictures name this one by its host planes (the MC wrappers' src pointers): keep the pointer -> slot map */
+            if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
+                (exchanged && g_fm.subscribe(g_fm.user, index, ctx, slot, mvf_bytes) != 0)) {
+                fprintf(stderr, "ohhip: subscribing to remote picture %d failed: %s\n", index, ohevc_last_error());
+                g_error = 1;
+                return AVERROR(EINVAL);
+            }
+            return 0;
+        }
+        t_publish = exchanged ? i + 1 : 0;
+    }
     pthread_mutex_unlock(&g_lock);
     /* slice threads: the WPP-row / tile workers of this picture all record into ctx (ohhip_cabac_init binds them) */
     ohevc_tables_set_concurrent(ctx, (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
@@ -220,6 +260,18 @@ int ohhip_frame_rps(HEVCContext *s)
                 return AVERROR(ENOMEM);
             known = !fresh && g_bufs[i].poc == ref->poc && g_bufs[i].seq == ref->sequence;
             slot = g_bufs[i].slot;
+            if (known && g_fm_on && !t_remote && g_bufs[i].remote && !g_bufs[i].have_motion) {
+                /* the wait of the reference's frame threads for a collocated picture's motion field (hevc_mvs.c) */
+                const int index = g_bufs[i].index;
+                g_bufs[i].have_motion = 1;
+                pthread_mutex_unlock(&g_lock);
+                if (g_fm.await_motion(g_fm.user, index, ref->tab_mvf, (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField)) != 0) {
+                    fprintf(stderr, "ohhip: the motion field of remote picture %d did not arrive\n", index);
+                    g_error = 1;
+                    return AVERROR(EINVAL);
+                }
+                continue;
+            }
             if (!known) {
                 g_bufs[i].poc = ref->poc;
                 g_bufs[i].seq = ref->sequence;
@@ -402,6 +454,89 @@ int ohdec_backend_open(void)
 /* INTEGRATION.md section 3, last row: run the recorded jobs, copy the picture back for output.  Runs on the thread that
  * decoded the picture: called by the harness after avcodec_decode_video2 (one decoding thread) or from the decoder's own
  * end-of-frame progress report (frame threads, below). */
+/* ---- frame-parallel decoding over processes (hip_frames.h) ---- */
+int ohhip_set_frames_mode(const ohhip_frames_mode *m)
+{
+    g_fm_on = 0;
+    g_fm_index = 0;
+    if (!m)
+        return 0;
+    if (m->world < 1 || m->rank < 0 || m->rank >= m->world || !m->publish || !m->subscribe || !m->await_motion || !m->await_planes)
+        return -1;
+    g_fm = *m;
+    g_fm_on = m->world > 1;
+    return 0;
+}
+
+/* hls_slice_data (hevc.c:3017-3095) hands the slice data to avctx->execute (one decoding thread) or execute2 (slice threads) and
+ * takes the last CTB address from ret[]: a remote picture reports "all CTBs done" without parsing anything */
+static int frames_execute(AVCodecContext *c, int (*func)(AVCodecContext *, void *), void *arg, int *ret, int count, int size)
+{
+    int i;
+    if (!t_remote)
+        return g_execute(c, func, arg, ret, count, size);
+    for (i = 0; ret && i < count; i++)
+        ret[i] = INT_MAX / 2;
+    return 0;
+}
+static int frames_execute2(AVCodecContext *c, int (*func)(AVCodecContext *, void *, int, int), void *arg, int *ret, int count)
+{
+    int i;
+    if (!t_remote)
+        return g_execute2(c, func, arg, ret, count);
+    for (i = 0; ret && i < count; i++)
+        ret[i] = INT_MAX / 2;
+    return 0;
+}
+void ohhip_frames_install(AVCodecContext *avctx)
+{
+    if (avctx->execute != frames_execute) {
+        g_execute = avctx->execute;
+        g_execute2 = avctx->execute2;
+        avctx->execute = frames_execute;
+        avctx->execute2 = frames_execute2;
+    }
+}
+
+int ohhip_frames_is_local(const unsigned char *data0)
+{
+    int i, local = 1;
+    pthread_mutex_lock(&g_lock);
+    for (i = 0; i < g_nbufs; i++)
+        if (g_bufs[i].data0 == data0)
+            local = !g_bufs[i].remote;
+    pthread_mutex_unlock(&g_lock);
+    return local;
+}
+
+/* the wait of the reference's frame threads for the rows their motion vectors point at (hevc_await_progress, hevc.c:1951-1958),
+ * per picture: every reference picture of the frame that is about to launch must have its samples in this process's store */
+static int frames_await_planes(HEVCContext *s)
+{
+    int t, k;
+    for (t = 0; t < NB_RPS_TYPE; t++)
+        for (k = 0; k < s->rps[t].nb_refs; k++) {
+            const HEVCFrame *ref = s->rps[t].ref[k];
+            int i, index = -1, slot = -1;
+            if (!ref || ref == s->ref || !ref->frame || !ref->frame->data[0])
+                continue;
+            pthread_mutex_lock(&g_lock);
+            for (i = 0; i < g_nbufs; i++)
+                if (g_bufs[i].data0 == ref->frame->data[0] && g_bufs[i].poc == ref->poc && g_bufs[i].seq == ref->sequence &&
+                    g_bufs[i].remote && !g_bufs[i].have_planes) {
+                    g_bufs[i].have_planes = 1;
+                    index = g_bufs[i].index;
+                    slot = g_bufs[i].slot;
+                }
+            pthread_mutex_unlock(&g_lock);
+            if (index >= 0 && g_fm.await_planes(g_fm.user, index, t_ctx, slot) != 0) {
+                fprintf(stderr, "ohhip: the planes of remote picture %d did not arrive: %s\n", index, ohevc_last_error());
+                return -1;
+            }
+        }
+    return 0;
+}
+
 int ohdec_backend_frame_done(void)
 {
     int st;
@@ -415,6 +550,8 @@ int ohdec_backend_frame_done(void)
         (t_s->pps->transquant_bypass_enable_flag || (t_s->sps->pcm_enabled_flag && t_s->sps->pcm.loop_filter_disable_flag)) &&
         ohevc_tables_set_bypass_map(t_ctx, t_s->is_pcm, t_s->sps->min_pu_width, t_s->sps->min_pu_height,
                                     t_s->sps->log2_min_pu_size) != OHEVC_OK)
+        g_error = 1;
+    if (g_fm_on && t_s && frames_await_planes(t_s) < 0)
         g_error = 1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     if (t_s && t_s->sps && t_s->pps && bulk_filters(t_s) && derive_filters(t_s) != OHEVC_OK) {
@@ -437,6 +574,16 @@ int ohdec_backend_frame_done(void)
         fprintf(stderr, "ohhip: frame failed (%d): %s\n", st, ohevc_last_error());
         g_error = 1;
         return -1;
+    }
+    if (g_fm_on && t_publish && t_s && t_s->ref) {
+        /* the picture is complete here (the copy-back above drained its device work): hand it to the other processes */
+        const int i = t_publish - 1;
+        t_publish = 0;
+        if (g_fm.publish(g_fm.user, g_bufs[i].index, t_ctx, g_bufs[i].slot, t_s->ref->tab_mvf,
+                         (size_t)t_s->sps->min_pu_width * t_s->sps->min_pu_height * sizeof(MvField)) != 0) {
+            fprintf(stderr, "ohhip: publishing picture %d failed: %s\n", g_bufs[i].index, ohevc_last_error());
+            g_error = 1;
+        }
     }
     return g_error ? -1 : 0;
 }

@@ -430,6 +430,52 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
     return OHEVC_OK;
 }
 
+// Frame-parallel decoding over several GPUs (one process each): a finished picture leaves its owner through ohevc_pic_export and
+// enters every other process's picture store through ohevc_pic_import; what carries the bytes in between (an RCCL broadcast over
+// xGMI, openhevc_amd/dist.py) is the application's.  Both work on DEVICE buffers holding the plane exactly as the store lays it out
+// (stride x height bytes, ohevc_pic_planes), take part in the store's cross-context ordering like upload / download do, and return
+// when the copy is done: the buffer can go straight into a collective / be reused.
+extern "C" int ohevc_pic_export(ohevc_ctx *c, int slot, int plane, void *device_dst, size_t bytes)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && device_dst != nullptr, "bad argument");
+    const ohevc_plane &pl = p->planes[plane];
+    OHEVC_REQUIRE(bytes == (size_t)pl.stride * pl.height, "size must be stride x height of the plane (ohevc_pic_planes)");
+    if (c->dry) return OHEVC_OK;
+    {
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return p->end_issued; })) {
+            set_error("picture %d was never completed by its decoding thread", slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+    }
+    OHEVC_HIP_TRY(hipMemcpyAsync(device_dst, pl.data, bytes, hipMemcpyDeviceToDevice, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_pic_import(ohevc_ctx *c, int slot, int plane, const void *device_src, size_t bytes)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && device_src != nullptr, "bad argument");
+    const ohevc_plane &pl = p->planes[plane];
+    OHEVC_REQUIRE(bytes == (size_t)pl.stride * pl.height, "size must be stride x height of the plane (ohevc_pic_planes)");
+    if (c->dry) return OHEVC_OK;
+    {   // like ohevc_pic_upload: frames of other contexts may still read (or write) what lived in this slot's memory
+        std::lock_guard<std::mutex> g(c->store->m);
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+        for (hipEvent_t e : p->readers) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+        p->readers.clear();
+        p->written = nullptr;
+        p->failed = false;
+    }
+    OHEVC_HIP_TRY(hipMemcpyAsync(pl.data, device_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+
 extern "C" int ohevc_pic_planes(ohevc_ctx *c, int slot, ohevc_plane out[3])
 {
     Picture *p = get_pic(c, slot);

@@ -133,3 +133,171 @@ class FrameParallelRunner:
             for h in handles:
                 h.wait()
         return mine
+
+
+# ---------------------------------------------------------------------------------------------------- the real decoder, frame-parallel
+# integration/hip_frames.h: every process parses the slice headers of the whole stream, the owner of a picture (decoding-order index
+# % world) parses its slice data and reconstructs it on its GPU, and what later pictures need from it - the sample planes and the
+# motion field - travels to the other processes.  FrameExchange is that transport: the four callbacks of ohhip_frames_mode on top of
+# torch.distributed (planes: broadcast on the default group = RCCL over xGMI with device tensors; motion fields, host memory: a gloo
+# group).  Collectives are issued in decoding order on every rank (publish on the owner, subscribe elsewhere), asynchronously;
+# a rank blocks only in await_motion / await_planes, the two waits the reference's frame threads have (hevc_mvs.c; hevc.c:1951-1958).
+import ctypes as _C
+
+import numpy as _np
+
+
+class _FramesMode(_C.Structure):
+    """ohhip_frames_mode (integration/hip_frames.h)"""
+    PUBLISH = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_size_t)
+    SUBSCRIBE = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_size_t)
+    AWAIT_MOTION = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_size_t)
+    AWAIT_PLANES = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int)
+    _fields_ = [("rank", _C.c_int), ("world", _C.c_int), ("user", _C.c_void_p), ("publish", PUBLISH), ("subscribe", SUBSCRIBE),
+                ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES)]
+
+
+class _Plane(_C.Structure):
+    _fields_ = [("data", _C.c_void_p), ("stride", _C.c_int32), ("width", _C.c_int32), ("height", _C.c_int32)]
+
+
+class FrameExchange:
+    """Transport behind integration/hip_frames.h.  `lib` = the loaded libohevc_hip.so (ctypes); pass `mode` (an ohhip_frames_mode)
+    to the decoder's frames-mode switch (ohhip_set_frames_mode + ohhip_frames_install).  Contexts without a device (record-only,
+    the CPU tests' software executor) exchange the HOST planes the decoder registered instead of device pictures."""
+
+    def __init__(self, lib, rank=None, world=None, max_outstanding=32, device=None):
+        self.lib = lib
+        self.device = device                                       # where device pictures are staged (default: the current GPU)
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.planes_group = None                                   # default group
+        # motion fields live in host memory: RCCL cannot carry them
+        self.host_group = dist.new_group(backend="gloo") if self.world > 1 and dist.get_backend() != "gloo" else None
+        self.pending = {}                                          # index -> (plane works, plane tensors, mvf work, mvf tensor)
+        self.outgoing = []                                         # (works, tensors) of published pictures still in flight
+        self.max_outstanding = max_outstanding
+        self.stats = dict(published=0, subscribed=0, awaited_motion=0, awaited_planes=0, bytes=0)
+        self.error = None
+        for name, res, args in (("ohevc_ctx_has_device", _C.c_int, [_C.c_void_p]),
+                                ("ohevc_pic_planes", _C.c_int, [_C.c_void_p, _C.c_int, _C.c_void_p]),
+                                ("ohevc_pic_info", _C.c_int, [_C.c_void_p, _C.c_int] + [_C.c_void_p] * 4),
+                                ("ohevc_pic_export", _C.c_int, [_C.c_void_p, _C.c_int, _C.c_int, _C.c_void_p, _C.c_size_t]),
+                                ("ohevc_pic_import", _C.c_int, [_C.c_void_p, _C.c_int, _C.c_int, _C.c_void_p, _C.c_size_t]),
+                                ("ohevc_tables_host_planes", _C.c_int, [_C.c_void_p, _C.c_int, _C.c_void_p, _C.c_void_p])):
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        self._cb = (_FramesMode.PUBLISH(self._guard(self._publish)), _FramesMode.SUBSCRIBE(self._guard(self._subscribe)),
+                    _FramesMode.AWAIT_MOTION(self._guard(self._await_motion)), _FramesMode.AWAIT_PLANES(self._guard(self._await_planes)))
+        self.mode = _FramesMode(self.rank, self.world, None, *self._cb)
+
+    def _guard(self, fn):
+        def call(user, *a):
+            try:
+                fn(*a)
+                return 0
+            except Exception as e:                                  # an exception must not unwind through the C decoder
+                import traceback
+                self.error = e
+                traceback.print_exc()
+                return -1
+        return call
+
+    # ---- staging: the planes of one picture as flat tensors (device: stride x height of the store's layout; host: tight rows)
+    def _geometry(self, ctx, slot):
+        if self.lib.ohevc_ctx_has_device(ctx):
+            pl = (_Plane * 3)()
+            if self.lib.ohevc_pic_planes(ctx, slot, pl) != 0:
+                raise RuntimeError("ohevc_pic_planes failed")
+            return True, [int(p.stride) * int(p.height) for p in pl]
+        w, h, cfi, bd = (_C.c_int() for _ in range(4))
+        if self.lib.ohevc_pic_info(ctx, slot, _C.byref(w), _C.byref(h), _C.byref(cfi), _C.byref(bd)) != 0:
+            raise RuntimeError("ohevc_pic_info failed")
+        hs, vs, ps = int(cfi.value in (1, 2)), int(cfi.value == 1), 2 if bd.value > 8 else 1
+        self._host_rows = [(h.value, w.value * ps), (h.value >> vs, (w.value >> hs) * ps), (h.value >> vs, (w.value >> hs) * ps)]
+        return False, [r * b for r, b in self._host_rows]
+
+    def _alloc(self, on_device, sizes, mvf_bytes):
+        dev = torch.device("cpu") if not on_device else self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        return [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes], torch.empty(mvf_bytes, dtype=torch.uint8)
+
+    def _host_planes(self, ctx, slot):
+        data, ls = (_C.c_void_p * 3)(), (_C.c_int * 3)()
+        if self.lib.ohevc_tables_host_planes(ctx, slot, data, ls) != 0:
+            raise RuntimeError("ohevc_tables_host_planes failed")
+        views = []
+        for c, (rows, row_bytes) in enumerate(self._host_rows):
+            buf = (_C.c_ubyte * (ls[c] * rows)).from_address(data[c])
+            views.append(_np.frombuffer(buf, dtype=_np.uint8).reshape(rows, ls[c])[:, :row_bytes])
+        return views
+
+    def _post(self, planes, mvf, src):
+        works = [dist.broadcast(t, src=src, group=self.planes_group, async_op=True) for t in planes] if self.world > 1 else []
+        mw = dist.broadcast(mvf, src=src, group=self.host_group, async_op=True) if self.world > 1 else None
+        self.stats["bytes"] += sum(t.numel() for t in planes) + mvf.numel()
+        return works, mw
+
+    # ---- the four callbacks
+    def _publish(self, index, ctx, slot, mvf_ptr, mvf_bytes):
+        on_device, sizes = self._geometry(ctx, slot)
+        planes, mvf = self._alloc(on_device, sizes, mvf_bytes)
+        if on_device:
+            for c, t in enumerate(planes):
+                if self.lib.ohevc_pic_export(ctx, slot, c, t.data_ptr(), t.numel()) != 0:
+                    raise RuntimeError("ohevc_pic_export failed")
+        else:
+            for t, v in zip(planes, self._host_planes(ctx, slot)):
+                t.copy_(torch.from_numpy(_np.ascontiguousarray(v)).reshape(-1))
+        _C.memmove(mvf.data_ptr(), mvf_ptr, mvf_bytes)
+        works, mw = self._post(planes, mvf, self.rank)
+        self.outgoing.append((works + ([mw] if mw is not None else []), planes, mvf))
+        while len(self.outgoing) > self.max_outstanding:
+            for w in self.outgoing.pop(0)[0]:
+                w.wait()
+        self.stats["published"] += 1
+
+    def _subscribe(self, index, ctx, slot, mvf_bytes):
+        on_device, sizes = self._geometry(ctx, slot)
+        planes, mvf = self._alloc(on_device, sizes, mvf_bytes)
+        works, mw = self._post(planes, mvf, index % self.world)
+        self.pending[index] = [works, planes, mw, mvf, on_device]
+        self.stats["subscribed"] += 1
+
+    def _await_motion(self, index, mvf_ptr, mvf_bytes):
+        works, planes, mw, mvf, on_device = self.pending[index]
+        if mw is not None:
+            mw.wait()
+        _C.memmove(mvf_ptr, mvf.data_ptr(), mvf_bytes)
+        self.stats["awaited_motion"] += 1
+
+    def _await_planes(self, index, ctx, slot):
+        works, planes, mw, mvf, on_device = self.pending[index]
+        for w in works:
+            w.wait()
+        if on_device:
+            if planes and planes[0].is_cuda:
+                torch.cuda.current_stream().synchronize()          # work.wait() only orders torch's stream behind the collective
+            for c, t in enumerate(planes):
+                if self.lib.ohevc_pic_import(ctx, slot, c, t.data_ptr(), t.numel()) != 0:
+                    raise RuntimeError("ohevc_pic_import failed")
+        else:
+            self._geometry(ctx, slot)
+            for t, v in zip(planes, self._host_planes(ctx, slot)):
+                v[...] = t.numpy().reshape(v.shape)
+        self.pending[index][1] = []                                # the planes are in the store now; the motion field may still be needed
+        self.stats["awaited_planes"] += 1
+
+    def finish(self):
+        """Every collective this rank issued must complete before the process group goes away."""
+        for works, *_ in self.outgoing:
+            for w in works:
+                w.wait()
+        self.outgoing.clear()
+        for works, _, mw, _, _ in self.pending.values():
+            for w in works:
+                w.wait()
+            if mw is not None:
+                mw.wait()
+        self.pending.clear()
+        if self.world > 1:
+            dist.barrier()

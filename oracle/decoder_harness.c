@@ -27,7 +27,14 @@ int  ohdec_backend_open(void);
 int  ohdec_backend_frame_done(void);
 int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
 void ohdec_backend_close(void);
+/* frame-parallel decoding over processes: integration/hip_frames.h (the struct is passed through opaquely) */
+int  ohhip_set_frames_mode(const void *mode);
+void ohhip_frames_install(AVCodecContext *avctx);
+int  ohhip_frames_is_local(const unsigned char *data0);
 #else
+static int  ohhip_set_frames_mode(const void *mode) { (void)mode; return -1; }
+static void ohhip_frames_install(AVCodecContext *avctx) { (void)avctx; }
+static int  ohhip_frames_is_local(const unsigned char *data0) { (void)data0; return 1; }
 static int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]) { (void)data; (void)linesize; return 0; }
 static int  ohdec_backend_open(void) { return 0; }
 static int  ohdec_backend_frame_done(void) { return 0; }
@@ -106,6 +113,24 @@ fail:
 }
 
 ohdec *ohdec_open(int threads, int thread_type) { return ohdec_open_ex(threads, thread_type, 0); }
+
+/* Frame-parallel decoding over processes (integration/hip_frames.h; openhevc_amd/dist.py drives it): `mode` = ohhip_frames_mode *,
+ * NULL switches it off.  Call right after ohdec_open*; one decoding thread per process.  Returns 0, or -1 for decoders without
+ * the hooks. */
+int ohdec_frames_mode(ohdec *d, const void *mode)
+{
+    if (ohhip_set_frames_mode(mode) != 0)
+        return -1;
+    if (mode)
+        ohhip_frames_install(d->avctx);
+    return 0;
+}
+
+/* the picture ohdec_decode / ohdec_flush just returned: 1 if this process reconstructed it (its samples are valid here) */
+int ohdec_frame_is_local(ohdec *d)
+{
+    return d->have_frame ? ohhip_frames_is_local(d->frame->data[0]) : 0;
+}
 
 void ohdec_md5_results(ohdec *d, int *ok, int *bad)
 {

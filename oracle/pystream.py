@@ -112,6 +112,24 @@ class Decoder:
         self.L.ohdec_md5_results(self.h, C.byref(ok), C.byref(bad))
         return ok.value, bad.value
 
+    def frames_mode(self, mode):
+        """Frame-parallel decoding over processes (integration/hip_frames.h): `mode` = the ohhip_frames_mode of an
+        openhevc_amd.dist.FrameExchange (None switches it off).  Right after opening; one decoding thread."""
+        self.L.ohdec_frames_mode.argtypes = [C.c_void_p, C.c_void_p]
+        if self.L.ohdec_frames_mode(self.h, C.byref(mode) if mode is not None else None) != 0:
+            raise RuntimeError(f"decoder '{self.kind}' has no frames mode")
+
+    def frame_is_local(self):
+        """Whether the picture decode() / flush() just returned was reconstructed by this process."""
+        self.L.ohdec_frame_is_local.argtypes = [C.c_void_p]
+        return bool(self.L.ohdec_frame_is_local(self.h))
+
+    def product_lib(self):
+        """The HIP library this decoder is linked against (ctypes handle), for openhevc_amd.dist.FrameExchange."""
+        if self.kind == "hipemu":
+            return C.CDLL(os.path.join(os.path.dirname(_HERE), "tests", "hipemu", "libohevc_hip_emu.so"), mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        return _product_lib()
+
     def _check_sw(self):
         if self.sw is not None and self.sw.ohsw_error():
             raise RuntimeError("software executor reported an error")
@@ -134,6 +152,14 @@ class Decoder:
         r = self.L.ohdec_decode(self.h, au, len(au), pts)
         if r < 0:
             raise RuntimeError(f"decode error {r} ({self.kind})")
+        self._check_sw()
+        return self._fetch() if r else None
+
+    def flush_one(self):
+        """One more picture from the draining decoder, or None when it is empty."""
+        r = self.L.ohdec_flush(self.h)
+        if r < 0:
+            raise RuntimeError(f"flush error {r}")
         self._check_sw()
         return self._fetch() if r else None
 

@@ -94,3 +94,87 @@ def test_frame_parallel_two_ranks_gloo():
         assert bbytes > 0
         owned += mine
     assert sorted(owned) == list(range(25))           # every picture reconstructed exactly once across ranks
+
+
+# ---------------------------------------------------------------------------------------------------- the real decoder, frame-parallel
+# integration/hip_frames.h + openhevc_amd.dist.FrameExchange: two processes decode ONE stream; each parses every slice header but only
+# the slice data of the pictures it owns (decoding order, round-robin), reconstructs them (here: the recorded jobs executed by the CPU
+# oracle on the decoder's host frames, OHHIP_SW_EXEC=1 - no GPU in this tier) and ships planes + motion field to the other one.
+# Every picture must come out identical to the untouched single-process decoder (the committed digests).
+def decoder_worker(rank, world, port, names, q, kind="hip"):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if kind == "hip":
+        os.environ["OHHIP_SW_EXEC"] = "1"
+    D.init_from_env("gloo")
+    from oracle import pystream as ps
+    from test_stream_cpu import frames_md5, load_golden
+    result = {}
+    for name in names:
+        aus, md5 = load_golden(name)
+        with ps.Decoder(kind) as d:
+            # "hipemu": the device code emulated on the host - pictures live in "device" memory the emulator owns and cross the
+            # processes through ohevc_pic_export / ohevc_pic_import, staged in CPU tensors
+            ex = D.FrameExchange(d.product_lib(), device=torch.device("cpu") if kind == "hipemu" else None)
+            d.frames_mode(ex.mode)
+            out = []                                   # (output position, planes) of the pictures this rank reconstructed
+            pos = 0
+            def take(f):
+                nonlocal pos
+                if f is not None:
+                    if d.frame_is_local():
+                        out.append((pos, f))
+                    pos += 1
+            for i, au in enumerate(aus):
+                take(d.decode(au, i + 1))
+            while True:
+                f = d.flush_one()
+                if f is None:
+                    break
+                take(f)
+            ex.finish()
+            d.frames_mode(None)
+            assert ex.error is None
+        digests = {p: frames_md5([f]) for p, f in out}
+        result[name] = (pos, digests, dict(ex.stats), md5)
+    q.put((rank, result))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,kind", [(2, "hip"), (3, "hip"), (2, "hipemu")])
+def test_decoder_frame_parallel_over_processes(world, kind):
+    from oracle import pystream as ps
+    if not (ps.have(kind) and os.path.exists(os.path.join(os.path.dirname(ps.__file__), "libohsw.so"))):
+        pytest.skip("GPU-backed decoder / software executor / emulator build not present (needs the reference tree once)")
+    names = ["ra_8b_ctb64", "ldb_10b", "weighted", "ra_10b_odd", "intra_8b", "slices", "tiles", "cip", "fmt444_8b"]
+    port = free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=decoder_worker, args=(r, world, port, names, q, kind)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=280) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for name in names:
+        npics = res[0][name][0]
+        want = res[0][name][3]
+        per_pic = len(want) // npics                   # 3 digests (planes) per picture
+        merged = {}
+        for r in range(world):
+            n, digests, stats, _ = res[r][name]
+            assert n == npics
+            for p, dg in digests.items():
+                assert p not in merged, f"{name}: picture {p} reconstructed twice"
+                merged[p] = dg
+        assert sorted(merged) == list(range(npics)), f"{name}: pictures {sorted(set(range(npics)) - set(merged))} reconstructed by nobody"
+        got = [d for p in range(npics) for d in merged[p]]
+        assert got == want, f"{name}: pictures differ from the single-process decoder"
+        assert per_pic == 3
+        if npics > 2 and name != "intra_8b":
+            assert sum(res[r][name][2]["awaited_planes"] for r in range(world)) > 0, f"{name}: no reference picture ever crossed processes"
