@@ -38,6 +38,12 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default 2^20 for 32x32, 2^22 for 16x16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sparse", action="store_true", help="decoder-like coefficients: non-zeros only in the top-left 8x8")
+    ap.add_argument("--mode", choices=["blocks", "frames"], default="blocks",
+                    help="blocks (default): the graded kernel on independent blocks; frames: the whole decoder on a synthetic stream, "
+                         "frame-parallel over the ranks (BASELINE config 5's structure: owner-GPU round-robin, RCCL broadcast of reference planes)")
+    ap.add_argument("--frames-size", default="3840x2160", help="--mode frames: picture size WxH")
+    ap.add_argument("--frames-bit-depth", type=int, default=10)
+    ap.add_argument("--frames-pictures", type=int, default=17)
     return ap.parse_args()
 
 
@@ -102,8 +108,82 @@ def cpu_baseline(log2, bd, leg_seconds=6.0):
     return out
 
 
+def frames_mode(args):
+    """One step = one pass of the hooked reference decoder over a synthetic Annex-B stream, frame-parallel over the ranks
+    (integration/hip_frames.h, openhevc_amd/dist.py FrameExchange).  The stream synthesiser and the decoder harness are the test
+    infrastructure's (oracle/pystream.py; the decoder binary is the reference's own front end linked against libohevc_hip.so,
+    oracle/_ref/libopenhevc_hip.so) - no pixel is computed by anything but the HIP library."""
+    import torch
+    import torch.distributed as dist
+    from openhevc_amd import dist as D
+    from oracle import pystream as ps
+    rank, world = D.init_from_env()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        os.environ["OHHIP_DEVICE"] = str(local_rank)
+    W, H = (int(v) for v in args.frames_size.split("x"))
+    # syntax statistics close to an encoder's random-access output (tools/bench_decode.py --natural)
+    kw = dict(gop="random_access", nframes=args.frames_pictures, seed=4242, width=W, height=(H + 7) // 8 * 8, bit_depth=args.frames_bit_depth, log2_ctb=6,
+              init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
+                                     split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
+    aus, _ = ps.generate(ps.StreamParams(**kw))
+
+    def one_pass():
+        with ps.Decoder("hip") as d:
+            ex = D.FrameExchange(d.product_lib()) if world > 1 else None
+            if ex is not None:
+                d.frames_mode(ex.mode)
+            n = 0
+            for i, au in enumerate(aus):
+                n += d.decode(au, i + 1) is not None
+            while d.flush_one() is not None:
+                n += 1
+            if ex is not None:
+                ex.finish()
+                d.frames_mode(None)
+                if ex.error is not None:
+                    raise ex.error
+            return n, (ex.stats if ex is not None else {})
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        npics, stats = one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "decoded Mpixels/s (fps x W x H), whole decoder, frame-parallel over the ranks",
+            "value": round(npics * W * H * args.steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "fps": round(npics * args.steps / elapsed, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u%d pixels, int16 coefficients" % (16 if args.frames_bit_depth > 8 else 8), "data": "synthetic Annex-B stream (oracle/pystream.py, seed 4242)",
+            "config": {"workload": f"{W}x{H} {args.frames_bit_depth}-bit random-access stream, {npics} pictures per step, reference front end on the host "
+                                   f"cores + HIP back end, pictures owned round-robin by decoding order", "parallelism": f"frame-parallel over {world} process(es)",
+                       "exchange": stats},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "frames":
+        return frames_mode(args)
     import torch
     from openhevc_amd import lib as L
 

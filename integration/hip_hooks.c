@@ -35,6 +35,7 @@
 /* one context per decoding thread, all sharing the root's picture store (ohevc_ctx_create_shared): frame threads
  * (pthread_frame.c) reconstruct different pictures concurrently and predict from each other's */
 static ohevc_ctx          *g_root;
+static int                 g_device;
 static __thread ohevc_ctx *t_ctx;
 static __thread int        t_frame_open;
 static __thread HEVCContext *t_s;      /* the decoder context this thread's open frame belongs to */
@@ -75,7 +76,7 @@ static ohevc_ctx *thread_ctx(void)
 {
     if (t_ctx || !g_root)
         return t_ctx;
-    if (ohevc_ctx_create_shared(&t_ctx, 0, g_root) != OHEVC_OK || ohevc_tables_bind(t_ctx) != OHEVC_OK ||
+    if (ohevc_ctx_create_shared(&t_ctx, g_device, g_root) != OHEVC_OK || ohevc_tables_bind(t_ctx) != OHEVC_OK ||
         /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
         ohevc_tables_emulate_filter_lag(t_ctx, 1) != OHEVC_OK) {
         fprintf(stderr, "ohhip: per-thread context failed: %s\n", ohevc_last_error());
@@ -441,7 +442,9 @@ int ohdec_backend_open(void)
     /* A/B: 0 = the deblocking parameters are derived on the host, one job per edge (default: on the device, from the maps) */
     if (getenv("OHHIP_DEVICE_FILTERS"))
         ohevc_debug_set_filters_on_device(atoi(getenv("OHHIP_DEVICE_FILTERS")));
-    if (ohevc_ctx_create(&g_root, 0) != OHEVC_OK) {
+    /* one process per GPU (frame-parallel decoding over processes, hip_frames.h): OHHIP_DEVICE = this process's device ordinal */
+    g_device = getenv("OHHIP_DEVICE") ? atoi(getenv("OHHIP_DEVICE")) : 0;
+    if (ohevc_ctx_create(&g_root, g_device) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
         return -1;
     }

@@ -161,6 +161,16 @@ class _Plane(_C.Structure):
     _fields_ = [("data", _C.c_void_p), ("stride", _C.c_int32), ("width", _C.c_int32), ("height", _C.c_int32)]
 
 
+_HOST_GROUP = []
+
+
+def _host_group():
+    """One gloo group per process for host-memory payloads when the default backend is RCCL (created once: every rank must take part)."""
+    if not _HOST_GROUP:
+        _HOST_GROUP.append(dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None)
+    return _HOST_GROUP[0]
+
+
 class FrameExchange:
     """Transport behind integration/hip_frames.h.  `lib` = the loaded libohevc_hip.so (ctypes); pass `mode` (an ohhip_frames_mode)
     to the decoder's frames-mode switch (ohhip_set_frames_mode + ohhip_frames_install).  Contexts without a device (record-only,
@@ -173,7 +183,7 @@ class FrameExchange:
         self.world = dist.get_world_size() if world is None else world
         self.planes_group = None                                   # default group
         # motion fields live in host memory: RCCL cannot carry them
-        self.host_group = dist.new_group(backend="gloo") if self.world > 1 and dist.get_backend() != "gloo" else None
+        self.host_group = _host_group() if self.world > 1 else None
         self.pending = {}                                          # index -> (plane works, plane tensors, mvf work, mvf tensor)
         self.outgoing = []                                         # (works, tensors) of published pictures still in flight
         self.max_outstanding = max_outstanding

@@ -169,7 +169,7 @@ def dev_deblock_maps(planes, bit_depth, maps, vertical, stream=0):
     check(load_library().ohevc_dev_deblock_maps(planes, C.c_int(bit_depth), C.byref(maps), C.c_int(vertical), C.c_void_p(stream)))
 
 
-EXPORTED_SYMBOLS += ["ohevc_dev_deblock_maps", "ohevc_rec_deblock_maps", "ohevc_ctx_has_device", "ohevc_debug_set_filters_on_device"]
+EXPORTED_SYMBOLS += ["ohevc_pic_export", "ohevc_pic_import", "ohevc_dev_deblock_maps", "ohevc_rec_deblock_maps", "ohevc_ctx_has_device", "ohevc_debug_set_filters_on_device"]
 
 
 def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):
@@ -340,6 +340,12 @@ class Ctx:
         arr = (Plane * 3)()
         check(self.lib.ohevc_pic_planes(self.h, slot, arr))
         return arr
+
+    def pic_export(self, slot, plane, device_ptr, nbytes):
+        check(self.lib.ohevc_pic_export(self.h, slot, plane, C.c_void_p(device_ptr), C.c_size_t(nbytes)))
+
+    def pic_import(self, slot, plane, device_ptr, nbytes):
+        check(self.lib.ohevc_pic_import(self.h, slot, plane, C.c_void_p(device_ptr), C.c_size_t(nbytes)))
 
     def pic_upsample(self, dst_slot, src_slot, params):
         check(self.lib.ohevc_pic_upsample(self.h, dst_slot, src_slot, C.byref(params)))

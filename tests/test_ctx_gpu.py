@@ -86,3 +86,30 @@ def test_reconstruct_in_several_flushes(oracle):
     ctx.close()
     for c in range(3):
         assert np.array_equal(got[c], want[c]), c
+
+
+@pytest.mark.parametrize("bd,cfi", [(8, 1), (10, 2), (14, 3)])
+def test_picture_export_import_round_trip(bd, cfi):
+    """ohevc_pic_export / ohevc_pic_import (frame-parallel decoding over GPUs, include/ohevc_ctx.h): a picture leaves one store slot
+    through a device buffer laid out like the store's plane (stride x height) and enters another slot bit for bit."""
+    rng = np.random.default_rng(4100 + bd)
+    W, H = 200, 72
+    hs, vs = int(cfi in (1, 2)), int(cfi == 1)
+    dt = G.pixdt(bd)
+    planes = [rng.integers(0, 1 << bd, size=s).astype(dt) for s in ((H, W), (H >> vs, W >> hs), (H >> vs, W >> hs))]
+    ctx = L.Ctx()
+    a, b = ctx.pic_alloc(W, H, cfi, bd), ctx.pic_alloc(W, H, cfi, bd)
+    ctx.pic_upload(a, planes)
+    ctx.pic_upload(b, [np.zeros_like(p) for p in planes])
+    geo = ctx.pic_planes(a)
+    for c in range(3):
+        n = int(geo[c].stride) * int(geo[c].height)
+        buf = G.zeros_dev(n, np.uint8)
+        ctx.pic_export(a, c, buf.data_ptr(), n)
+        ctx.pic_import(b, c, buf.data_ptr(), n)
+        with pytest.raises(RuntimeError):
+            ctx.pic_export(a, c, buf.data_ptr(), n - 1)         # the size is part of the contract
+    got = ctx.pic_download(b, [p.shape for p in planes], dt)
+    for c in range(3):
+        assert np.array_equal(got[c], planes[c]), f"plane {c}"
+    ctx.close()
