@@ -122,6 +122,11 @@ typedef struct ohevc_mc_job {           /* 32 bytes */
  * (slot-major: refs[3 * slot + plane]); width/height there are the picture size used for clamping. */
 int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
                        const ohevc_mc_job *jobs, int njobs, void *stream);
+/* Same contract plus a promise: no job of the batch is wider than max_w or taller than max_h (1..64).  The kernel's unit of work is a
+ * 16x16 tile; with the bound it knows how many tiles a job can have and spreads them over wavefronts (ohevc_dev_mc_batch assumes
+ * 64x64).  Jobs that violate the bound are only partly written. */
+int ohevc_dev_mc_batch_bounded(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                               const ohevc_mc_job *jobs, int njobs, int max_w, int max_h, void *stream);
 /* Same contract for batches in which EVERY job has w <= 8 and h <= 8 (most chroma blocks of 4:2:0 content): four jobs share
  * one wavefront.  Jobs that violate the size limit produce undefined pixels inside their own block. */
 int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,

@@ -1280,8 +1280,8 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
 
     // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
     if (!c->mc.empty()) {
-        rc = ohevc_dev_mc_batch(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), kMaxPics, p->bd,
-                                reinterpret_cast<const ohevc_mc_job *>(base + off_mc), (int)c->mc.size(), c->stream);
+        rc = ohevc_dev_mc_batch_bounded(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), kMaxPics, p->bd,        // the recorder cuts into tiles
+                                        reinterpret_cast<const ohevc_mc_job *>(base + off_mc), (int)c->mc.size(), 16, 16, c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
     }

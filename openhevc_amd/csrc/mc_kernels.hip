@@ -13,6 +13,7 @@
 //   v14  = my ? (sum fv*tmp) >> 6      : tmp                       ((S << (14-BD)) >> 6 == S >> (BD-8) exactly)
 #include "common.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -525,8 +526,9 @@ __device__ int mc3_exact(const ohevc_plane &ref, int sx, int sy, const signed ch
 
 // One wavefront per 64 jobs: the lanes read 64 mask words, the wave then works through the (rare) jobs with a bit set, one sample
 // per lane and step.  `tile` = the tile edge of the mc3_kernel instantiation that wrote the masks (16, or 8 for the small-job form).
+template <typename Mask>
 __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs,
-                                                      int njobs, int bit_depth, const unsigned short *__restrict__ wild_mask, int tile)
+                                                      int njobs, int bit_depth, const Mask *__restrict__ wild_mask, int tile)
 {
     const int lane = threadIdx.x;
     const int maxv = (1 << bit_depth) - 1;
@@ -581,7 +583,10 @@ __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_
     }
 }
 
-int g_mc_variant = 3;     // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = v2 + dual staging / job slots (shipped)
+int g_mc_variant = getenv("OHEVC_MC_VARIANT") ? atoi(getenv("OHEVC_MC_VARIANT")) : 3;   // (env: A/B of whole-decoder runs)
+//     // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = v2 + dual staging / job slots (shipped), 4 = matrix cores
+
+#include "mc4_kernel.hpp"
 
 }  // namespace ohevc
 
@@ -602,7 +607,7 @@ int wild_scratch(hipStream_t st, int njobs, unsigned short **out)
     if ((size_t)njobs > w->cap) {
         if (w->buf) { OHEVC_HIP_TRY(hipStreamSynchronize(st)); OHEVC_HIP_TRY(hipFree(w->buf)); w->buf = nullptr; w->cap = 0; }
         const size_t cap = std::max<size_t>((size_t)njobs * 2, 65536);
-        OHEVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w->buf), cap * sizeof(unsigned short)));
+        OHEVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w->buf), cap * sizeof(unsigned)));       // mc4 uses 32-bit words (atomicOr)
         w->cap = cap;
     }
     *out = w->buf;
@@ -623,7 +628,7 @@ void ohevc_mc_forget_stream(void *stream)
 }
 
 static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
-                     const ohevc_mc_job *jobs, int njobs, void *stream, bool small)
+                     const ohevc_mc_job *jobs, int njobs, void *stream, bool small, int max_w = 64, int max_h = 64)
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr, "dst");
@@ -637,18 +642,33 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned short *wild = nullptr;
-    const bool v3 = small || (g_mc_variant != 1 && g_mc_variant != 2);
+    const bool v4 = g_mc_variant == 4;
+    const bool v3 = v4 || small || (g_mc_variant != 1 && g_mc_variant != 2);
     if (bit_depth > 8 && v3) {
         rc = wild_scratch(st, njobs, &wild);
         if (rc != OHEVC_OK) return rc;
     }
     const int redo_grid = std::min(256, (njobs + 63) / 64);
-    if (small) {
+    if (v4) {                                 // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
+        const bool multi = max_w > 16 || max_h > 16;
+        const int tiles = ((max_w + 15) / 16) * ((max_h + 15) / 16);
+        const dim3 grid = multi ? dim3((njobs + 3) / 4, (tiles + MC4_UNITS - 1) / MC4_UNITS) : dim3((njobs + 4 * MC4_UNITS - 1) / (4 * MC4_UNITS));
+        unsigned *wild32 = reinterpret_cast<unsigned *>(wild);
+        if (bit_depth == 8) {
+            if (multi) hipLaunchKernelGGL((mc4_kernel<uint8_t, true>), grid, dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+            else       hipLaunchKernelGGL((mc4_kernel<uint8_t, false>), grid, dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+        } else {
+            OHEVC_HIP_TRY(hipMemsetAsync(wild32, 0, (size_t)njobs * sizeof(unsigned), st));
+            if (multi) hipLaunchKernelGGL((mc4_kernel<uint16_t, true>), grid, dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+            else       hipLaunchKernelGGL((mc4_kernel<uint16_t, false>), grid, dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+            hipLaunchKernelGGL((mc3_redo_kernel<unsigned>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild32, 16);
+        }
+    } else if (small) {
         const int grid = (njobs + 3) / 4;
         if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
         else {
             hipLaunchKernelGGL((mc3_kernel<uint16_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
-            hipLaunchKernelGGL(mc3_redo_kernel, dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 8);
+            hipLaunchKernelGGL((mc3_redo_kernel<unsigned short>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 8);
         }
     } else if (g_mc_variant == 1) {
         if (bit_depth == 8) hipLaunchKernelGGL((mc_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
@@ -660,7 +680,7 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
         if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
         else {
             hipLaunchKernelGGL((mc3_kernel<uint16_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
-            hipLaunchKernelGGL(mc3_redo_kernel, dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 16);
+            hipLaunchKernelGGL((mc3_redo_kernel<unsigned short>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 16);
         }
     }
     OHEVC_HIP_TRY(hipGetLastError());
@@ -673,15 +693,23 @@ extern "C" int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *r
     return mc_launch(dst, refs, n_ref_slots, bit_depth, jobs, njobs, stream, false);
 }
 
+extern "C" int ohevc_dev_mc_batch_bounded(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
+                                          const ohevc_mc_job *jobs, int njobs, int max_w, int max_h, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(max_w >= 1 && max_w <= 64 && max_h >= 1 && max_h <= 64, "job size bound");
+    return mc_launch(dst, refs, n_ref_slots, bit_depth, jobs, njobs, stream, false, max_w, max_h);
+}
+
 extern "C" int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,
                                         const ohevc_mc_job *jobs, int njobs, void *stream)
 {
-    return mc_launch(dst, refs, n_ref_slots, bit_depth, jobs, njobs, stream, true);
+    return mc_launch(dst, refs, n_ref_slots, bit_depth, jobs, njobs, stream, true, 8, 8);
 }
 
 extern "C" int ohevc_debug_set_mc_variant(int variant)
 {
     int old = ohevc::g_mc_variant;
-    if (variant >= 1 && variant <= 3) ohevc::g_mc_variant = variant;
+    if (variant >= 1 && variant <= 4) ohevc::g_mc_variant = variant;
     return old;
 }

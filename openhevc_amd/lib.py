@@ -147,6 +147,11 @@ def dev_mc_batch(dst_planes, refs_ptr, n_slots, bit_depth, jobs_ptr, njobs, stre
                                  C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
+def dev_mc_batch_bounded(dst_planes, refs_ptr, n_slots, bit_depth, jobs_ptr, njobs, max_w, max_h, stream=0):
+    check(load_library().ohevc_dev_mc_batch_bounded(dst_planes, C.c_void_p(refs_ptr), C.c_int(n_slots), C.c_int(bit_depth),
+                                                    C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_int(max_w), C.c_int(max_h), C.c_void_p(stream)))
+
+
 def dev_mc_batch_small(dst_planes, refs_ptr, n_slots, bit_depth, jobs_ptr, njobs, stream=0):
     lib = load_library()
     check(lib.ohevc_dev_mc_batch_small(dst_planes, C.c_void_p(refs_ptr), C.c_int(n_slots), C.c_int(bit_depth),
@@ -169,7 +174,7 @@ def dev_deblock_maps(planes, bit_depth, maps, vertical, stream=0):
     check(load_library().ohevc_dev_deblock_maps(planes, C.c_int(bit_depth), C.byref(maps), C.c_int(vertical), C.c_void_p(stream)))
 
 
-EXPORTED_SYMBOLS += ["ohevc_pic_export", "ohevc_pic_import", "ohevc_dev_deblock_maps", "ohevc_rec_deblock_maps", "ohevc_ctx_has_device", "ohevc_debug_set_filters_on_device"]
+EXPORTED_SYMBOLS += ["ohevc_dev_mc_batch_bounded", "ohevc_pic_export", "ohevc_pic_import", "ohevc_dev_deblock_maps", "ohevc_rec_deblock_maps", "ohevc_ctx_has_device", "ohevc_debug_set_filters_on_device"]
 
 
 def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):

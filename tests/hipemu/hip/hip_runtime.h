@@ -208,6 +208,10 @@ static inline hipemu_s16x2 hipemu_cvt_pk_i16(int lo, int hi)
 }
 #define __builtin_amdgcn_cvt_pk_i16(lo, hi) hipemu_cvt_pk_i16((lo), (hi))
 
+// 24-bit multiplies (v_mul_i32_i24 / v_mul_u32_u24): the operands' low 24 bits, sign- / zero-extended; low 32 bits of the product
+static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+
 // matrix-core and transposing-LDS-read instructions: wave collectives, emulated in hipemu_mfma.hpp
 #include "hipemu_mfma.hpp"
 

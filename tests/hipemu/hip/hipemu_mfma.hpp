@@ -28,6 +28,47 @@ static inline hipemu_v16i hipemu_mfma_i32_32x32x32_i8(hipemu_v4i a, hipemu_v4i b
 }
 #define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, cbsz, abid, blgp) hipemu_mfma_i32_32x32x32_i8((a), (b), (c))
 
+// v_mfma_i32_16x16x64_i8: A[m = lane & 15][slot group lane >> 4, 16 slots], B[same slots][n = lane & 15],
+// D[m = 4 (lane >> 4) + r][n = lane & 15] (the dtype-independent 16x16 C/D map of gfx950, cdna_hip_programming.md "Fragment layout")
+static inline hipemu_v4i hipemu_mfma_i32_16x16x64_i8(hipemu_v4i a, hipemu_v4i b, hipemu_v4i c)
+{
+    signed char all_a[64][16], all_b[64][16];
+    ::hipemu::wave_gather(&a, 16, all_a);
+    ::hipemu::wave_gather(&b, 16, all_b);
+    const int lane = ::hipemu::g_lane.flat & 63, n = lane & 15;
+    hipemu_v4i d = c;
+    for (int r = 0; r < 4; r++) {
+        const int m = 4 * (lane >> 4) + r;
+        int acc = 0;
+        for (int g = 0; g < 4; g++)
+            for (int j = 0; j < 16; j++)
+                acc += (int)all_a[g * 16 + m][j] * (int)all_b[g * 16 + n][j];
+        d[r] = (int)((unsigned)d[r] + (unsigned)acc);
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) hipemu_mfma_i32_16x16x64_i8((a), (b), (c))
+
+// v_mfma_i32_16x16x32_i8: as above with 8 slots per lane (A, B: 64 bits)
+static inline hipemu_v4i hipemu_mfma_i32_16x16x32_i8(long a, long b, hipemu_v4i c)
+{
+    signed char all_a[64][8], all_b[64][8];
+    ::hipemu::wave_gather(&a, 8, all_a);
+    ::hipemu::wave_gather(&b, 8, all_b);
+    const int lane = ::hipemu::g_lane.flat & 63, n = lane & 15;
+    hipemu_v4i d = c;
+    for (int r = 0; r < 4; r++) {
+        const int m = 4 * (lane >> 4) + r;
+        int acc = 0;
+        for (int g = 0; g < 4; g++)
+            for (int j = 0; j < 8; j++)
+                acc += (int)all_a[g * 16 + m][j] * (int)all_b[g * 16 + n][j];
+        d[r] = (int)((unsigned)d[r] + (unsigned)acc);
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, c, cbsz, abid, blgp) hipemu_mfma_i32_16x16x32_i8((a), (b), (c))
+
 static inline hipemu_v4s hipemu_ds_read_tr16_b64(const void *p)
 {
     uint64_t mine = (uint64_t)(uintptr_t)p, all[64];

@@ -134,9 +134,9 @@ def test_emu_fuzzed_streams():
     if _stream_lib() is None or not (ps.have("gen") and ps.have("c")):
         pytest.skip("generator / reference decoder / emulated decoder libraries not present")
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "12", "991"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "20", "991"], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, FUZZ_BACKEND="hipemu"))
     lines = r.stdout.strip().splitlines()
     assert lines, r.stderr[-2000:]
     res = json.loads(lines[-1])
-    assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 3, r.stdout[-3000:]
+    assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 2, r.stdout[-3000:]

@@ -9,6 +9,16 @@ import gpu_util as G
 pytestmark = pytest.mark.gpu
 
 PAD = 80
+
+
+@pytest.fixture(params=[4, 3], ids=["matrix_cores", "lds_tiles"], autouse=True)
+def mc_variant(request):
+    """Both forms of the motion-compensation kernel (include/ohevc_debug.h): mc4 (v_mfma_i32_16x16x64_i8, no LDS) / mc3 (LDS tiles)."""
+    lib = L.load_library()
+    prev = lib.ohevc_debug_set_mc_variant(request.param)
+    yield request.param
+    lib.ohevc_debug_set_mc_variant(prev)
+
 LUMA_W = [4, 8, 12, 16, 24, 32, 48, 64]
 CHROMA_W = [2, 4, 6, 8, 12, 16, 24, 32]
 

@@ -27,6 +27,8 @@ PEAK = 8000.0
 PLANES = 1
 ONLY = None
 SAO_VARIANT = None
+MC_CONFIG = None
+MC_VARIANT = None           # --mc-variant V: 3 = LDS tiles (mc3), 4 = matrix cores (mc4); tags the rows
 RESIDENT = "--resident" in sys.argv
 RING_BYTES = 2 << 30
 for i, a in enumerate(sys.argv):
@@ -36,6 +38,10 @@ for i, a in enumerate(sys.argv):
         ONLY = sys.argv[i + 1]
     if a == "--sao-variant":
         SAO_VARIANT = int(sys.argv[i + 1])
+    if a == "--mc-variant":
+        MC_VARIANT = int(sys.argv[i + 1])
+    if a == "--mc-config":      # "16,16,0": only this (width, height, bi) of the motion-compensation configurations
+        MC_CONFIG = tuple(int(v) for v in sys.argv[i + 1].split(","))
 H *= PLANES
 
 
@@ -129,6 +135,8 @@ def main():
     L.load_library()
     if SAO_VARIANT is not None:
         L.load_library().ohevc_debug_set_sao_variant(SAO_VARIANT)
+    if MC_VARIANT is not None:
+        L.load_library().ohevc_debug_set_mc_variant(MC_VARIANT)
     g = torch.Generator(device="cuda").manual_seed(7)
     rng = np.random.default_rng(7)
     st = lambda: torch.cuda.current_stream().cuda_stream
@@ -139,6 +147,8 @@ def main():
         table = dev(L.planes_table(refs))
         # ---- MC: tile the luma plane with blocks of one size, random quarter-sample MVs within +-16 samples
         for (bw, bh, bi) in [(8, 8, 0), (16, 16, 0), (16, 16, 1), (32, 32, 1), (64, 64, 1)]:
+            if MC_CONFIG is not None and (bw, bh, bi) != MC_CONFIG:
+                continue
             xs, ys = np.meshgrid(np.arange(0, W - bw + 1, bw), np.arange(0, H - bh + 1, bh))
             n = xs.size
             j = np.zeros(n, L.MC_JOB)
@@ -154,11 +164,16 @@ def main():
             def mc_sources(k):          # the two reference pictures of ring entry k and their table
                 rr = [rand_pic(bd, g) for _ in range(2)]
                 return rr, dev(L.planes_table(rr))
-            ms = timeit(lambda pic, ex: L.dev_mc_batch(L.planes_of(pic), (ex[1] if ex else table).data_ptr(), 2, bd, d_jobs.data_ptr(), n, st()),
+            ms = timeit(lambda pic, ex: L.dev_mc_batch_bounded(L.planes_of(pic), (ex[1] if ex else table).data_ptr(), 2, bd, d_jobs.data_ptr(), n, bw, bh, st()),
                         lambda: rand_pic(bd, g), name="mc", ring_of=RingExtra(mc_sources, 2 * pic_bytes(refs[0])))
             px = n * bw * bh
             alg = n * ((1 + bi) * P * (bw + 7) * (bh + 7) + P * bw * bh)
-            report(f"mc luma {bw}x{bh} {'bi' if bi else 'uni'} {bd}-bit (random qpel phases)", ms, px, alg, out)
+            tag = "" if MC_VARIANT is None else f" [mc variant {MC_VARIANT}]"
+            report(f"mc luma {bw}x{bh} {'bi' if bi else 'uni'} {bd}-bit (random qpel phases){tag}", ms, px, alg, out)
+            if bw == 8:             # the same jobs through the small-block entry point (mc3: four jobs per wavefront)
+                ms = timeit(lambda pic, ex: L.dev_mc_batch_small(L.planes_of(pic), (ex[1] if ex else table).data_ptr(), 2, bd, d_jobs.data_ptr(), n, st()),
+                            lambda: rand_pic(bd, g), name="mc", ring_of=RingExtra(mc_sources, 2 * pic_bytes(refs[0])))
+                report(f"mc luma 8x8 uni {bd}-bit, small-block entry point (random qpel phases){tag}", ms, px, alg, out)
         # ---- deblock: every 8x8-grid luma edge of the picture, vertical pass (bS-like params that filter ~always)
         xs, ys = np.meshgrid(np.arange(8, W, 8), np.arange(0, H, 8))
         n = xs.size
