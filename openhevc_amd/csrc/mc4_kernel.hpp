@@ -58,15 +58,41 @@ __device__ __forceinline__ unsigned mc4_hi(unsigned p0, unsigned p1) { return __
 // ---- one reference of one tile, in two halves so that a wavefront can have the loads of several tiles in flight
 template <typename Pixel> struct Mc4Raw { unsigned w[2][sizeof(Pixel) == 2 ? 4 : 2]; };      // [row block][8 samples of one window row]
 
+#ifdef OHEVC_HIPEMU
+#define MC4_GLOBAL
+#define MC4_CONST
+#else
+#define MC4_GLOBAL __attribute__((address_space(1)))             // the planes live in global memory: global_load / global_store, not flat_*
+#define MC4_CONST __attribute__((address_space(4)))              // read-only for the kernel's lifetime + wave-uniform address: s_load
+#endif
+typedef const MC4_GLOBAL unsigned char *mc4_gptr;
+
+// A window that crosses the left / right picture edge (emulated_edge_mc, videodsp_template.c:26-100): 8 clamped sample loads per lane.
+// Out of line on purpose - inlined, its address arithmetic is hoisted in front of the branch and every tile pays for it.
+template <typename Pixel>
+__device__ __attribute__((noinline)) u32x4 mc4_gather_edge(mc4_gptr row, int col0, int xmax)
+{
+    constexpr bool WIDE = sizeof(Pixel) == 2;
+    unsigned w[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int x = col0 + j;
+        x = x < 0 ? 0 : x > xmax ? xmax : x;
+        const unsigned s = *reinterpret_cast<const MC4_GLOBAL Pixel *>(row + (unsigned)x * (unsigned)sizeof(Pixel));
+        if (WIDE) w[j >> 1] |= s << (16 * (j & 1));
+        else      w[j >> 2] |= s << (8 * (j & 3));
+    }
+    return u32x4{ w[0], w[1], w[2], w[3] };                       // by value: a pointer argument would push the callers' registers to scratch
+}
+
 // (wx0, wy0): picture position of window sample (0, 0); wh: window rows that exist (rows beyond repeat the last one: their taps are 0).
 template <typename Pixel>
 __device__ __forceinline__ void mc4_issue(const ohevc_plane &ref, int wx0, int wy0, int wh, int lane, Mc4Raw<Pixel> &raw)
 {
-    constexpr bool WIDE = sizeof(Pixel) == 2;
     // memory-side lane map: 4 consecutive lanes take 32 consecutive samples of one window row (one 32- / 64-byte piece per quad of
     // lanes; with the operand-side map - lane & 15 = row - every lane of a load would touch its own cache line)
     const int r = lane >> 2, g = lane & 3;
-    const unsigned char *base = static_cast<const unsigned char *>(ref.data);
+    mc4_gptr base = (mc4_gptr)ref.data;
     const int xmax = ref.width - 1, ymax = ref.height - 1;
     const int col0 = wx0 + 8 * g;
     const bool fast = wx0 >= 0 && wx0 + 31 <= xmax;               // wave-uniform: every lane's 8 samples lie inside its row
@@ -78,18 +104,11 @@ __device__ __forceinline__ void mc4_issue(const ohevc_plane &ref, int wx0, int w
         y = y < 0 ? 0 : y > ymax ? ymax : y;
         const unsigned rowoff = __umul24((unsigned)y, (unsigned)ref.stride);                    // rows < 2^16, strides < 2^24, planes far below 4 GiB
         if (fast) {
-            __builtin_memcpy(raw.w[blk], base + (rowoff + (unsigned)col0 * (unsigned)sizeof(Pixel)), sizeof(raw.w[blk]));     // one global_load_dwordx2 / x4, any alignment
-        } else {                                                 // the window crosses the left / right picture edge: emulated_edge_mc
-#pragma unroll
-            for (int k = 0; k < (WIDE ? 4 : 2); k++) raw.w[blk][k] = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int x = col0 + j;
-                x = x < 0 ? 0 : x > xmax ? xmax : x;
-                const unsigned s = *reinterpret_cast<const Pixel *>(base + (rowoff + (unsigned)x * (unsigned)sizeof(Pixel)));
-                if (WIDE) raw.w[blk][j >> 1] |= s << (16 * (j & 1));
-                else      raw.w[blk][j >> 2] |= s << (8 * (j & 3));
-            }
+            __builtin_memcpy(raw.w[blk], (const void *)(base + (rowoff + (unsigned)col0 * (unsigned)sizeof(Pixel))), sizeof(raw.w[blk]));     // one global_load_dwordx2 / x4, any alignment
+        } else {
+            const u32x4 e = mc4_gather_edge<Pixel>(base + rowoff, col0, xmax);
+            raw.w[blk][0] = e.x; raw.w[blk][1] = e.y;
+            if (sizeof(Pixel) == 2) { raw.w[blk][sizeof(Pixel) == 2 ? 2 : 0] = e.z; raw.w[blk][sizeof(Pixel) == 2 ? 3 : 1] = e.w; }
         }
     }
 }
@@ -153,20 +172,29 @@ __global__ __launch_bounds__(256) void mc4_kernel(PlaneSet dst, const ohevc_plan
         const u32x4 t0 = src[tid], t1 = src[256 + tid], t2 = src[512 + tid];
         dl[tid] = t0; dl[256 + tid] = t1; dl[512 + tid] = t2;
     }
-    struct Unit { bool valid, bi; ohevc_mc_job jb; int tx, ty, tw, th, slot; };
+    struct Unit { bool valid, bi; ohevc_mc_job jb; int tx, ty, tw, th, slot; ohevc_plane r0, r1; };
     Unit u[MC4_UNITS];
-    const int q = blockIdx.x * 4 + wave;
+    // Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: give each XCD a CONTIGUOUS eighth of the job list (jobs
+    // arrive in picture order), so that the overlapping reference windows of neighbouring tiles meet in one L2 instead of being
+    // fetched by up to 8.  (The launcher rounds the grid up to a multiple of 8; the surplus workgroups find no job.)
+    const int per_xcd = gridDim.x >> 3;
+    const int q = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave;
+    // Three rounds, each issued for all units before the first result is needed: job records, reference-plane records (both scalar
+    // loads), samples.  Unit by unit the three dependent round trips would add up four times.
+    typedef const MC4_CONST u32x4 *cptr;
+    u32x4 jw[MC4_UNITS][2];
 #pragma unroll
     for (int i = 0; i < MC4_UNITS; i++) {
         const int j = MULTI ? q : q * MC4_UNITS + i;
         u[i].valid = j < njobs;
-        u[i].jb = jobs[u[i].valid ? j : njobs - 1];
-        u[i].slot = j;
+        cptr jp = (cptr)(jobs + (u[i].valid ? j : njobs - 1));
+        jw[i][0] = jp[0]; jw[i][1] = jp[1];
     }
-    Mc4Raw<Pixel> raw[MC4_UNITS][2];
     const int maxv = (1 << bit_depth) - 1;
 #pragma unroll
     for (int i = 0; i < MC4_UNITS; i++) {
+        const unsigned words[8] = { jw[i][0].x, jw[i][0].y, jw[i][0].z, jw[i][0].w, jw[i][1].x, jw[i][1].y, jw[i][1].z, jw[i][1].w };
+        __builtin_memcpy(&u[i].jb, words, sizeof(ohevc_mc_job));
         const ohevc_mc_job &jb = u[i].jb;
         const int ntx = (jb.w + 15) >> 4, nty = (jb.h + 15) >> 4;
         const int t = MULTI ? (int)blockIdx.y * MC4_UNITS + i : 0;
@@ -176,14 +204,20 @@ __global__ __launch_bounds__(256) void mc4_kernel(PlaneSet dst, const ohevc_plan
         u[i].tw = jb.w - u[i].tx < 16 ? jb.w - u[i].tx : 16; u[i].th = jb.h - u[i].ty < 16 ? jb.h - u[i].ty : 16;
         u[i].bi = jb.flags & OHEVC_MC_BI;
         u[i].slot = tyi * ntx + txi;
+        static_assert(sizeof(ohevc_plane) == 24, "plane record");
+        typedef const MC4_CONST unsigned long *lptr;
+        lptr p0 = (lptr)(refs + 3 * jb.ref0 + jb.plane), p1 = (lptr)(refs + 3 * (u[i].bi ? jb.ref1 : jb.ref0) + jb.plane);
+        const unsigned long a0[3] = { p0[0], p0[1], p0[2] }, a1[3] = { p1[0], p1[1], p1[2] };
+        __builtin_memcpy(&u[i].r0, a0, 24); __builtin_memcpy(&u[i].r1, a1, 24);
+    }
+    Mc4Raw<Pixel> raw[MC4_UNITS][2];
+#pragma unroll
+    for (int i = 0; i < MC4_UNITS; i++) {
+        const ohevc_mc_job &jb = u[i].jb;
         if (u[i].valid) {
             const int before = jb.plane == 0 ? 3 : 1, taps = jb.plane == 0 ? 8 : 4;
-            const ohevc_plane ref0 = refs[3 * jb.ref0 + jb.plane];
-            mc4_issue<Pixel>(ref0, jb.sx0 + u[i].tx - before, jb.sy0 + u[i].ty - before, u[i].th + taps - 1, lane, raw[i][0]);
-            if (u[i].bi) {
-                const ohevc_plane ref1 = refs[3 * jb.ref1 + jb.plane];
-                mc4_issue<Pixel>(ref1, jb.sx1 + u[i].tx - before, jb.sy1 + u[i].ty - before, u[i].th + taps - 1, lane, raw[i][1]);
-            }
+            mc4_issue<Pixel>(u[i].r0, jb.sx0 + u[i].tx - before, jb.sy0 + u[i].ty - before, u[i].th + taps - 1, lane, raw[i][0]);
+            if (u[i].bi) mc4_issue<Pixel>(u[i].r1, jb.sx1 + u[i].tx - before, jb.sy1 + u[i].ty - before, u[i].th + taps - 1, lane, raw[i][1]);
         }
     }
     __syncthreads();                                                                             // the tables are in LDS
@@ -230,12 +264,12 @@ __global__ __launch_bounds__(256) void mc4_kernel(PlaneSet dst, const ohevc_plan
         for (int k = 0; k < (sizeof(Pixel) == 2 ? 2 : 1); k++) pk[k] = (unsigned)__shfl((int)pk[k], from);
         const int sy = lane >> 2, sx = 4 * (lane & 3);
         if (sy >= u[i].th || sx >= u[i].tw) continue;
-        unsigned char *p = PLANE_PTR3(dst, jb.plane) + (size_t)(jb.y + u[i].ty + sy) * PLANE_STRIDE3(dst, jb.plane) + (size_t)(jb.x + u[i].tx + sx) * sizeof(Pixel);
+        MC4_GLOBAL unsigned char *p = (MC4_GLOBAL unsigned char *)PLANE_PTR3(dst, jb.plane) + (__umul24((unsigned)(jb.y + u[i].ty + sy), (unsigned)PLANE_STRIDE3(dst, jb.plane)) + (unsigned)(jb.x + u[i].tx + sx) * (unsigned)sizeof(Pixel));
         if (u[i].tw - sx >= 4) {
-            __builtin_memcpy(p, pk, sizeof(pk));                  // one 4- / 8-byte store
+            __builtin_memcpy((void *)p, pk, sizeof(pk));          // one 4- / 8-byte store
         } else {                                                  // widths 2 and 6 (chroma of 4- and 12-wide blocks)
             for (int k = 0; k < u[i].tw - sx; k++)
-                reinterpret_cast<Pixel *>(p)[k] = (Pixel)(sizeof(Pixel) == 2 ? pk[sizeof(Pixel) == 2 ? k >> 1 : 0] >> (16 * (k & 1)) : pk[0] >> (8 * k));
+                reinterpret_cast<MC4_GLOBAL Pixel *>(p)[k] = (Pixel)(sizeof(Pixel) == 2 ? pk[sizeof(Pixel) == 2 ? k >> 1 : 0] >> (16 * (k & 1)) : pk[0] >> (8 * k));
         }
     }
 }

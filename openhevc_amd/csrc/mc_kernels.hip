@@ -652,7 +652,8 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     if (v4) {                                 // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
         const bool multi = max_w > 16 || max_h > 16;
         const int tiles = ((max_w + 15) / 16) * ((max_h + 15) / 16);
-        const dim3 grid = multi ? dim3((njobs + 3) / 4, (tiles + MC4_UNITS - 1) / MC4_UNITS) : dim3((njobs + 4 * MC4_UNITS - 1) / (4 * MC4_UNITS));
+        const auto up8 = [](int v) { return (v + 7) & ~7; };            // XCD-contiguous job ranges (mc4_kernel)
+        const dim3 grid = multi ? dim3(up8((njobs + 3) / 4), (tiles + MC4_UNITS - 1) / MC4_UNITS) : dim3(up8((njobs + 4 * MC4_UNITS - 1) / (4 * MC4_UNITS)));
         unsigned *wild32 = reinterpret_cast<unsigned *>(wild);
         if (bit_depth == 8) {
             if (multi) hipLaunchKernelGGL((mc4_kernel<uint8_t, true>), grid, dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);

@@ -1,5 +1,5 @@
 #!/bin/bash
-TAG=${1:-r02ze}
+TAG=${1:-r02zi}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 ( timeout 300 python -m pytest tests/test_mc_gpu.py -q -p no:cacheprovider -x 2>&1 | tail -3 ) 2>&1 | tee $OUT/pytest_mc.log
 timeout 300 python tools/bench_kernels.py --resident --planes 8 --only mc --mc-variant 4 2>/dev/null | grep '^{' > $OUT/bench_mc_variant4.jsonl
