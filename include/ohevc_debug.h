@@ -31,9 +31,11 @@ int ohevc_debug_mfma_i8_probe(const void *a, const void *b, void *d, int nprobes
 int ohevc_debug_lds_tr16_probe(const void *addr, void *out, int nprobes, void *stream);
 /* bit 2 of the variant selects the persistent, software-pipelined kernel; this sets its grid size (workgroups). */
 int ohevc_debug_set_tu_pipe_workgroups(int n);
-/* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = 2 + both reference
- * windows staged before the first barrier (shipped).  Only 3 hands tiles with reference samples above the bit depth's range to the
- * exact redo kernel; 1 and 2 are exact for samples that fit the bit depth. */
+/* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = LDS tiles with both reference windows
+ * staged before the first barrier (mc3), 4 (shipped) = the matrix-core form (mc4) for tile batches and mc3's
+ * four-jobs-per-wavefront form for the small-block entry point, 5 = mc4 for both.  3, 4 and 5 hand tiles with reference samples above
+ * the bit depth's range to the exact redo kernel; 1 and 2 are exact for samples that fit the bit depth.  Env OHEVC_MC_VARIANT sets
+ * the initial value (A/B of whole-decoder runs). */
 int ohevc_debug_set_mc_variant(int variant);
 /* SAO kernel: 0 = shipped; bit 0 = the edge classes split a block into its interior (short form: no border / restore predicate can
  * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and

@@ -583,8 +583,9 @@ __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_
     }
 }
 
-int g_mc_variant = getenv("OHEVC_MC_VARIANT") ? atoi(getenv("OHEVC_MC_VARIANT")) : 3;   // (env: A/B of whole-decoder runs)
-//     // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = v2 + dual staging / job slots (shipped), 4 = matrix cores
+// 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = LDS tiles (mc3), 4 (shipped) = matrix cores (mc4) for tiles and mc3's four-jobs-per-
+// wavefront form for the small-block batch (it wins there: profiles/r02zi), 5 = mc4 for both.  (env: A/B of whole-decoder runs)
+int g_mc_variant = getenv("OHEVC_MC_VARIANT") ? atoi(getenv("OHEVC_MC_VARIANT")) : 4;
 
 #include "mc4_kernel.hpp"
 
@@ -642,7 +643,7 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned short *wild = nullptr;
-    const bool v4 = g_mc_variant == 4;
+    const bool v4 = g_mc_variant == 5 || (g_mc_variant == 4 && !small);
     const bool v3 = v4 || small || (g_mc_variant != 1 && g_mc_variant != 2);
     if (bit_depth > 8 && v3) {
         rc = wild_scratch(st, njobs, &wild);
@@ -711,6 +712,6 @@ extern "C" int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_pl
 extern "C" int ohevc_debug_set_mc_variant(int variant)
 {
     int old = ohevc::g_mc_variant;
-    if (variant >= 1 && variant <= 4) ohevc::g_mc_variant = variant;
+    if (variant >= 1 && variant <= 5) ohevc::g_mc_variant = variant;
     return old;
 }

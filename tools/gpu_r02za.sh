@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the matrix-core motion compensation (16x16 uni, 8 bit): where do the cycles go
-TAG=${1:-r02zf}
+TAG=${1:-r02zj}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 CMD="python tools/bench_kernels.py --resident --planes 8 --only mc --mc-variant 4 --mc-config 16,16,0"
 i=0
