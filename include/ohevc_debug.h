@@ -37,7 +37,8 @@ int ohevc_debug_set_tu_pipe_workgroups(int n);
  * the bit depth's range to the exact redo kernel; 1 and 2 are exact for samples that fit the bit depth.  Env OHEVC_MC_VARIANT sets
  * the initial value (A/B of whole-decoder runs). */
 int ohevc_debug_set_mc_variant(int variant);
-/* SAO kernel: 0 = shipped; bit 0 = the edge classes split a block into its interior (short form: no border / restore predicate can
+/* SAO kernel: 0 = shipped (wide form: 16 bytes of one row per lane, no LDS, position rules as byte masks; blocks it cannot take fall
+ * back to the LDS-window form); bit 1 = never take the wide form (A/B); bit 0 = the edge classes split a block into its interior (short form: no border / restore predicate can
  * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and
  * tests); written after the round's GPU budget was spent, so the A/B on the device is the first thing to do with it. */
 int ohevc_debug_set_sao_variant(int variant);

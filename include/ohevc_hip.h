@@ -230,6 +230,12 @@ typedef struct ohevc_sao_bypass {
 } ohevc_sao_bypass;
 int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3], int bit_depth,
                                const ohevc_sao_job *jobs, int njobs, const ohevc_sao_bypass *bypass /* may be NULL */, void *stream);
+/* Two kernels serve SAO: a wide form (16 bytes of a row per lane) for blocks with 16-byte row pieces, a power-of-two number of them,
+ * offsets that fit a byte and no filter-lag flag, and a general one.  The entry points above run both over all jobs (each block is taken
+ * by exactly one).  A caller that sorts its jobs - ohevc_sao_job_is_wide() != 0 first - saves the second pass over them: */
+int ohevc_sao_job_is_wide(const ohevc_sao_job *job, const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth);
+int ohevc_dev_sao_batch_sorted(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3], int bit_depth,
+                               const ohevc_sao_job *jobs, int n_wide, int n_other, const ohevc_sao_bypass *bypass, void *stream);
 
 /* ---- 2.5 intra prediction: replaces intra_pred[log2-2] (hevcpred.h:32; hevcpred_template.c:30-357) and the
  * predictors it dispatches to, pred_planar / pred_dc / pred_angular (hevcpred.h:34-40).  Everything the

@@ -1425,6 +1425,10 @@ static int frame_end_impl(ohevc_ctx *c)
         const size_t off_m = c->dbk_blob.empty() ? 0 : stage_put(parts, total, c->dbk_blob.data(), c->dbk_blob.size());
         const size_t off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
         const size_t off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
+        // the blocks the wide SAO kernel takes first (ohevc_dev_sao_batch_sorted); SAO blocks of a picture are independent of each other.
+        // (The deblocked copy they read is allocated like the picture: same alignment, same pitch.)
+        const int n_sao_wide = (int)(std::stable_partition(c->sao.begin(), c->sao.end(), [&](const ohevc_sao_job &j) {
+                                         return ohevc_sao_job_is_wide(&j, p->planes, p->planes, p->bd) != 0; }) - c->sao.begin());
         const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
         const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
         if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
@@ -1480,8 +1484,8 @@ static int frame_end_impl(ohevc_ctx *c)
                 bp.map = base + off_b; bp.stride = c->bypass_w; bp.log2_min_pu_size = c->bypass_l2;
                 bp.chroma_hshift = p->cfi == 1 || p->cfi == 2; bp.chroma_vshift = p->cfi == 1; bp.exact_reference = c->bypass_exact;
             }
-            if ((rc = ohevc_dev_sao_batch_bypass(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), (int)c->sao.size(), &bp, c->stream)) != OHEVC_OK) return rc;
-            c->stats.launches++;
+            if ((rc = ohevc_dev_sao_batch_sorted(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), n_sao_wide, (int)c->sao.size() - n_sao_wide, &bp, c->stream)) != OHEVC_OK) return rc;
+            c->stats.launches += (n_sao_wide > 0) + (n_sao_wide < (int)c->sao.size());
         }
         c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
     }

@@ -201,6 +201,9 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
     deblock_line<Pixel>(planes, x >> hs, y >> vs, plane, flags, beta, tc, line, bit_depth);
 }
 
+template <typename Pixel>
+__device__ __forceinline__ bool sao_wide_ok(const ohevc_sao_job &jb, const unsigned char *sbase, const unsigned char *dbase, int sstride, int dstride, int pw, int bit_depth);
+
 // One workgroup per SAO block.  Fast form (block width a multiple of 4 samples, dword-aligned rows - every block the decoder makes):
 // the (w + 2) x (h + 2) source window goes to LDS with dword loads (edge columns and the lagged samples patched in), every lane then
 // produces 4 neighbouring samples and stores them with one 4- / 8-byte access.  Anything else takes the sample-at-a-time form.
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
 // enumerated so that all but one wavefront take a single form.
 template <typename Pixel, bool SPLIT>
 __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth,
-                                                  ohevc_sao_bypass bp)
+                                                  ohevc_sao_bypass bp, int g_variant)
 {
     constexpr int PXB = (int)sizeof(Pixel), PPD = 4 / PXB, OFF = 4, PITCH = 64 + 2 * OFF;     // window: x = -1 sits at column OFF - 1
     __shared__ __attribute__((aligned(16))) Pixel win[66][PITCH];
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
         else
             *reinterpret_cast<u32x2 *>(dbase + (size_t)y * dstride + (size_t)x0 * 2) = u32x2{ (unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16) };
     };
+    if (!(g_variant & 2) && sao_wide_ok<Pixel>(jb, sbase, dbase, sstride, dstride, pw, bit_depth)) return;       // sao_wide_kernel's job
     if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
         const int shift = bit_depth - 5;
         auto band = [&](int c, int x, int y) {
@@ -400,6 +404,189 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
 #undef SRC
 }
 
+// ------------------------------------------------------------------ SAO, wide form
+// 16 bytes of one row per lane, no LDS, no barrier.  Lane l of the workgroup takes piece l % pieces of row l / pieces (+ passes of 256 / pieces
+// rows).  The class offsets come out of a 5-entry byte table through v_perm_b32; what the reference's position rules change (picture-border
+// samples take offset_val[0], restored samples and bypassed PUs keep the deblocked value: hevcdsp_template.c:419-566, hevc_filter.c:163-193)
+// is decided per lane as byte masks - only in lanes that can hold such a sample - and merged bitwise.  Takes the blocks sao_wide_ok accepts
+// (16-byte row pieces, a power-of-two number of them, offsets that fit a byte, no filter-lag patch); sao_kernel takes the others.
+template <typename Pixel>
+__device__ __forceinline__ bool sao_wide_ok(const ohevc_sao_job &jb, const unsigned char *sbase, const unsigned char *dbase, int sstride, int dstride, int pw, int bit_depth)
+{
+    constexpr int PPL = 16 / (int)sizeof(Pixel);
+    const int w = jb.w, h = jb.h, np = w / PPL;
+    const bool band = jb.type == OHEVC_SAO_BAND;
+    const bool lagq = (jb.quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) != 0 && !band && jb.klass != 1 && jb.x + w < pw;
+    bool fits = true;
+    for (int k = 0; k < 5; k++) fits = fits && jb.offset_val[k] >= -128 && jb.offset_val[k] < 128;
+    return (w % PPL) == 0 && np >= 1 && np <= 8 && (np & (np - 1)) == 0 && h <= 64 && !lagq && fits &&
+           ((reinterpret_cast<uintptr_t>(sbase) | reinterpret_cast<uintptr_t>(dbase) | (unsigned)sstride | (unsigned)dstride) & 15) == 0;
+}
+
+// sign of d as -1 / 0 / 1 (the compiler prefers two compares and two selects)
+__device__ __forceinline__ int sao_sign(int d)
+{
+#ifdef OHEVC_HIPEMU
+    return d < -1 ? -1 : d > 1 ? 1 : d;
+#else
+    int r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(d));
+    return r;
+#endif
+}
+
+// The position rules of one 16-byte row piece as byte masks: bord = samples that take offset_val[0] (picture borders), keep = samples that
+// keep the deblocked value (restored slice / tile edges, bypassed PUs).  Out of line: its two dozen wave-uniform flags would otherwise
+// crowd the scalar registers of the path every lane runs (measured: 850 SGPR spill moves in the kernel).
+struct SaoMasks { u32x4 keep, bord; };
+template <typename Pixel>
+__device__ __attribute__((noinline)) SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao_bypass bp, int x0, int y)
+{
+    constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);
+    constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
+    ohevc_sao_job jb;
+    const unsigned words[8] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w };
+    __builtin_memcpy(&jb, words, sizeof(jb));
+    const int w = jb.w, h = jb.h, eo = jb.klass, bx = jb.x, by = jb.y;
+    const bool rules = jb.type != OHEVC_SAO_BAND && (jb.borders != 0 || jb.restore != 0);
+    const bool b0 = jb.borders & 1, b1 = jb.borders & 2, b2 = jb.borders & 4, b3 = jb.borders & 8;
+    const int init_x = (eo != 1 && b0) ? 1 : 0;
+    const int w2 = w - ((eo != 1 && b2) ? 1 : 0), h2 = h - ((eo != 0 && b3) ? 1 : 0);
+    const bool ve0 = jb.edges & 1, ve1 = jb.edges & 2, he0 = jb.edges & 4, he1 = jb.edges & 8;
+    const bool de0 = jb.edges & 16, de1 = jb.edges & 32, de2 = jb.edges & 64, de3 = jb.edges & 128;
+    const int sul = !de0 && eo == 2 && !b0 && !b1, sur = !de1 && eo == 3 && !b1 && !b2;
+    const int slr = !de2 && eo == 2 && !b2 && !b3, sll = !de3 && eo == 3 && !b0 && !b3;
+    const unsigned char *const bmap = bp.map;        // restore_tqb_pixels: see sao_kernel
+    const int b_hs = jb.plane ? bp.chroma_hshift : 0, b_vs = jb.plane ? bp.chroma_vshift : 0, b_l2 = bp.log2_min_pu_size;
+    const int b_xlim = bp.exact_reference ? ((bx << b_hs) + w) >> b_l2 : 0x7fffffff;
+    const int b_ylim = bp.exact_reference ? ((by << b_vs) + h) >> b_l2 : 0x7fffffff;
+    const int b_len = (bp.exact_reference && sizeof(Pixel) == 2) ? ((1 << b_l2) >> b_hs) >> 1 : 0x7fffffff;
+    unsigned keep[4] = { 0, 0, 0, 0 }, bord[4] = { 0, 0, 0, 0 };
+    for (int e = 0; e < PPL; e++) {
+        const int x = x0 + e, d = e / SPD, k = e % SPD;
+        const bool on_border = rules && ((eo != 1 && ((b0 && x == 0) || (b2 && x == w - 1))) ||
+                                         (eo != 0 && x >= init_x && x < w2 && ((b1 && y == 0) || (b3 && y == h - 1))));
+        bool kp = rules && jb.restore &&
+                  ((ve0 && eo != 1 && x == 0 && y >= sul && y < h2 - sll) || (ve1 && eo != 1 && x == w2 - 1 && y >= sur && y < h2 - slr) ||
+                   (he0 && eo != 0 && y == 0 && x >= init_x + sul && x < w2 - sur) || (he1 && eo != 0 && y == h2 - 1 && x >= init_x + sll && x < w2 - slr) ||
+                   (de0 && eo == 2 && x == 0 && y == 0) || (de1 && eo == 3 && x == w2 - 1 && y == 0) ||
+                   (de2 && eo == 2 && x == w2 - 1 && y == h2 - 1) || (de3 && eo == 3 && x == 0 && y == h2 - 1));
+        if (bmap) {
+            const int xpu = ((bx + x) << b_hs) >> b_l2, ypu = ((by + y) << b_vs) >> b_l2;
+            kp = kp || (xpu < b_xlim && ypu < b_ylim && (bx + x) - ((xpu << b_l2) >> b_hs) < b_len && bmap[(size_t)ypu * bp.stride + xpu] != 0);
+        }
+        const unsigned bit = M << (SB * k);
+        keep[0] |= d == 0 && kp ? bit : 0; keep[1] |= d == 1 && kp ? bit : 0; keep[2] |= d == 2 && kp ? bit : 0; keep[3] |= d == 3 && kp ? bit : 0;
+        bord[0] |= d == 0 && on_border ? bit : 0; bord[1] |= d == 1 && on_border ? bit : 0; bord[2] |= d == 2 && on_border ? bit : 0; bord[3] |= d == 3 && on_border ? bit : 0;
+    }
+    return SaoMasks{ u32x4{ keep[0], keep[1], keep[2], keep[3] }, u32x4{ bord[0], bord[1], bord[2], bord[3] } };
+}
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp)
+{
+    constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);     // samples per lane / dword
+    constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
+    const u32x4 j0 = reinterpret_cast<const u32x4 *>(jobs + blockIdx.x)[0], j1 = reinterpret_cast<const u32x4 *>(jobs + blockIdx.x)[1];
+    ohevc_sao_job jb;
+    {
+        const unsigned words[8] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w };
+        static_assert(sizeof(ohevc_sao_job) == 32, "SAO job record");
+        __builtin_memcpy(&jb, words, sizeof(jb));
+    }
+    const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
+    const int sstride = PLANE_STRIDE3(src, jb.plane), dstride = PLANE_STRIDE3(dst, jb.plane);
+    const unsigned char *splane = PLANE_PTR3(src, jb.plane);
+    const unsigned char *sbase = splane + (size_t)jb.y * sstride + (size_t)jb.x * sizeof(Pixel);
+    unsigned char *dbase = PLANE_PTR3(dst, jb.plane) + (size_t)jb.y * dstride + (size_t)jb.x * sizeof(Pixel);
+    const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
+    if (!sao_wide_ok<Pixel>(jb, sbase, dbase, sstride, dstride, pw, bit_depth)) return;
+    const bool is_band = jb.type == OHEVC_SAO_BAND;
+    const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = 256 >> lp;      // a power of two (sao_wide_ok)
+    const int piece = threadIdx.x & (pieces - 1), row0 = threadIdx.x >> lp, x0 = piece * PPL;
+    const int dxa = eo == 1 ? 0 : eo == 3 ? 1 : -1, dya = eo == 0 ? 0 : -1;       // first neighbour; the second is its mirror
+    // class -> offset table for v_perm_b32: byte k of (tab_lo, tab_hi) = offset of class k.  Edge: k = sign + sign + 2 -> offset_val[{1,2,0,3,4}]
+    // (edge_idx, hevcdsp_template.c:372-378); band: k = band index 0..3 -> offset_val[k + 1], 4 = outside the four bands.
+    const int ov0 = jb.offset_val[0];
+    const int t0 = jb.offset_val[1], t1 = jb.offset_val[2], t2 = is_band ? jb.offset_val[3] : ov0, t3 = is_band ? jb.offset_val[4] : jb.offset_val[3], t4 = is_band ? 0 : jb.offset_val[4];
+    const unsigned tab_lo = (unsigned)(t0 & 0xff) | ((unsigned)(t1 & 0xff) << 8) | ((unsigned)(t2 & 0xff) << 16) | ((unsigned)(t3 & 0xff) << 24), tab_hi = (unsigned)(t4 & 0xff);
+    const int shift = bit_depth - 5, band_pos = jb.klass;
+    const bool rules = !is_band && (jb.borders != 0 || jb.restore != 0);
+    auto finish = [&](int c, int cls) {               // class -> offset (one v_perm_b32), add, clip
+        const int off = (int)(signed char)__builtin_amdgcn_perm(tab_hi, tab_lo, (unsigned)cls | 0x0c0c0c00u);
+        const int v = c + off;
+        return (unsigned)(v < 0 ? 0 : v > maxv ? maxv : v);
+    };
+    for (int y = row0; y < h; y += rows_per_pass) {
+        unsigned cv[4], ov_[4];
+        __builtin_memcpy(cv, sbase + ((unsigned)y * (unsigned)sstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), 16);
+        if (is_band) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int k = 0; k < SPD; k++) {
+                    const int c = (int)((cv[d] >> (SB * k)) & M);
+                    const int kk = ((c >> shift) - band_pos) & 31;
+                    acc |= finish(c, kk < 4 ? kk : 4) << (SB * k);
+                }
+                ov_[d] = acc;
+            }
+        } else {
+            // the two neighbours of every sample: 16 bytes one sample to the left / right of the piece, in the row above / below (clamped to
+            // the plane: what lies beyond only reaches samples that take offset_val[0])
+            unsigned av[4], bv[4];
+            auto fetch = [&](int dx, int dy, unsigned *o) {
+                int yy = jb.y + y + dy;
+                yy = yy < 0 ? 0 : yy > ph - 1 ? ph - 1 : yy;
+                const unsigned char *rowp = splane + (unsigned)yy * (unsigned)sstride;
+                const int xs = jb.x + x0 + dx;
+                if (xs >= 0 && xs + PPL <= pw) {
+                    __builtin_memcpy(o, rowp + (unsigned)xs * (unsigned)sizeof(Pixel), 16);
+                } else {                                 // picture edge: the piece itself shifted by one sample, the outermost one repeated
+                    unsigned t[4];
+                    __builtin_memcpy(t, rowp + (unsigned)(jb.x + x0) * (unsigned)sizeof(Pixel), 16);
+                    if (dx < 0) { o[3] = (t[3] << SB) | (t[2] >> (32 - SB)); o[2] = (t[2] << SB) | (t[1] >> (32 - SB)); o[1] = (t[1] << SB) | (t[0] >> (32 - SB)); o[0] = (t[0] << SB) | (t[0] & M); }
+                    else        { o[0] = (t[0] >> SB) | (t[1] << (32 - SB)); o[1] = (t[1] >> SB) | (t[2] << (32 - SB)); o[2] = (t[2] >> SB) | (t[3] << (32 - SB)); o[3] = (t[3] >> SB) | (t[3] & ~(0xffffffffu >> SB)); }
+                }
+            };
+            fetch(dxa, dya, av);
+            fetch(-dxa, -dya, bv);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                unsigned acc = 0;
+#pragma unroll
+                for (int k = 0; k < SPD; k++) {
+                    const int c = (int)((cv[d] >> (SB * k)) & M), a = (int)((av[d] >> (SB * k)) & M), b = (int)((bv[d] >> (SB * k)) & M);
+                    acc |= finish(c, sao_sign(c - a) + sao_sign(c - b) + 2) << (SB * k);
+                }
+                ov_[d] = acc;
+            }
+        }
+        // position rules: only where a lane can hold such a sample (first / last piece of a row, rows 0, h - 2, h - 1), or with a bypass map
+        if ((rules && (y == 0 || y >= h - 2 || piece == 0 || piece == pieces - 1)) || bp.map != nullptr) {
+            const SaoMasks m = sao_rule_masks<Pixel>(j0, j1, bp, x0, y);
+            const unsigned keep[4] = { m.keep.x, m.keep.y, m.keep.z, m.keep.w }, bord[4] = { m.bord.x, m.bord.y, m.bord.z, m.bord.w };
+            if ((bord[0] | bord[1] | bord[2] | bord[3]) != 0) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    unsigned acc = 0;
+#pragma unroll
+                    for (int k = 0; k < SPD; k++) {
+                        int v = (int)((cv[d] >> (SB * k)) & M) + ov0;
+                        v = v < 0 ? 0 : v > maxv ? maxv : v;
+                        acc |= (unsigned)v << (SB * k);
+                    }
+                    ov_[d] = (ov_[d] & ~bord[d]) | (acc & bord[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) ov_[d] = (ov_[d] & ~keep[d]) | (cv[d] & keep[d]);
+        }
+        __builtin_memcpy(dbase + ((unsigned)y * (unsigned)dstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), ov_, 16);
+    }
+}
+
 int g_sao_variant = 0;     // ohevc_debug_set_sao_variant
 }  // namespace ohevc
 
@@ -456,8 +643,8 @@ extern "C" int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
-                                          int bit_depth, const ohevc_sao_job *jobs, int njobs, const ohevc_sao_bypass *bypass, void *stream)
+static int sao_launch(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
+                      int bit_depth, const ohevc_sao_job *jobs, int njobs, const ohevc_sao_bypass *bypass, void *stream, int n_wide)
 {
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr && src != nullptr && lagged != nullptr, "planes");
@@ -479,15 +666,55 @@ extern "C" int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_
     rc = make_plane_set(lagged, plag, bit_depth > 8 ? 2 : 1);
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // every block goes through exactly one of the two kernels (sao_wide_ok, evaluated by both on the job record): the jobs live in
+    // device memory, the host cannot sort them.  Blocks are disjoint and both kernels read `src` only, so the order does not matter.
+    // n_wide >= 0: the caller sorted the jobs (ohevc_dev_sao_batch_sorted) - the first n_wide go to the wide kernel, the rest to the other
+    const int nw = n_wide >= 0 ? n_wide : njobs;
+    if (!(g_sao_variant & 2) && nw > 0) {
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(nw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp);
+        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(nw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp);
+    }
+    if (n_wide >= 0 && !(g_sao_variant & 2)) { jobs += n_wide; njobs -= n_wide; }
+    if (njobs <= 0) { OHEVC_HIP_TRY(hipGetLastError()); return OHEVC_OK; }
     if (g_sao_variant & 1) {
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
-        else                hipLaunchKernelGGL((sao_kernel<uint16_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
+        else                hipLaunchKernelGGL((sao_kernel<uint16_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
     } else {
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
-        else                hipLaunchKernelGGL((sao_kernel<uint16_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp);
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
+        else                hipLaunchKernelGGL((sao_kernel<uint16_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
     }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_sao_batch_bypass(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],
+                                          int bit_depth, const ohevc_sao_job *jobs, int njobs, const ohevc_sao_bypass *bypass, void *stream)
+{
+    return sao_launch(dst, src, lagged, bit_depth, jobs, njobs, bypass, stream, -1);
+}
+
+extern "C" int ohevc_dev_sao_batch_sorted(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3], int bit_depth,
+                                          const ohevc_sao_job *jobs, int n_wide, int n_other, const ohevc_sao_bypass *bypass, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(n_wide >= 0 && n_other >= 0, "job counts");
+    return sao_launch(dst, src, lagged, bit_depth, jobs, n_wide + n_other, bypass, stream, n_wide);
+}
+
+// host twin of sao_wide_ok (same conditions, same order)
+extern "C" int ohevc_sao_job_is_wide(const ohevc_sao_job *jb, const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth)
+{
+    if (!jb || !dst || !src || jb->plane > 2) return 0;
+    const int ps = bit_depth > 8 ? 2 : 1, ppl = 16 / ps, w = jb->w, h = jb->h, np = w / ppl;
+    const bool band = jb->type == OHEVC_SAO_BAND;
+    const ohevc_plane &sp = src[jb->plane], &dp = dst[jb->plane];
+    const bool lagq = (jb->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) != 0 && !band && jb->klass != 1 && jb->x + w < sp.width;
+    bool fits = true;
+    for (int k = 0; k < 5; k++) fits = fits && jb->offset_val[k] >= -128 && jb->offset_val[k] < 128;
+    const uintptr_t sbase = reinterpret_cast<uintptr_t>(sp.data) + (size_t)jb->y * sp.stride + (size_t)jb->x * ps;
+    const uintptr_t dbase = reinterpret_cast<uintptr_t>(dp.data) + (size_t)jb->y * dp.stride + (size_t)jb->x * ps;
+    return (w % ppl) == 0 && np >= 1 && np <= 8 && (np & (np - 1)) == 0 && h <= 64 && !lagq && fits &&
+           ((sbase | dbase | (unsigned)sp.stride | (unsigned)dp.stride) & 15) == 0;
 }
 
 extern "C" int ohevc_dev_sao_batch_lagged(const ohevc_plane dst[3], const ohevc_plane src[3], const ohevc_plane lagged[3],

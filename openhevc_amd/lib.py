@@ -181,6 +181,14 @@ def dev_sao_batch(dst_planes, src_planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_sao_batch(dst_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
+def dev_sao_batch_sorted(dst_planes, src_planes, bit_depth, jobs_ptr, n_wide, n_other, stream=0):
+    check(load_library().ohevc_dev_sao_batch_sorted(dst_planes, src_planes, src_planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(n_wide), C.c_int(n_other),
+                                                    None, C.c_void_p(stream)))
+
+
+EXPORTED_SYMBOLS += ["ohevc_dev_sao_batch_sorted", "ohevc_sao_job_is_wide"]
+
+
 class SaoBypass(C.Structure):
     """ohevc_sao_bypass (include/ohevc_hip.h)"""
     _fields_ = [("map", C.c_void_p), ("stride", C.c_int32), ("log2_min_pu_size", C.c_int32),

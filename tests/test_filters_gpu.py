@@ -63,7 +63,7 @@ def test_deblock_vertical_then_horizontal(oracle, bd):
         assert changed > 100, "test content did not trigger the filters"
 
 
-@pytest.fixture(params=[0, 1], ids=["shipped", "interior_ring_split"])
+@pytest.fixture(params=[0, 2, 3], ids=["shipped_wide", "lds_window", "lds_window_interior_ring_split"])
 def sao_variant(request):
     """Both forms of the SAO kernel (include/ohevc_debug.h) must give the same samples."""
     lib = L.load_library()

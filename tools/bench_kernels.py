@@ -203,7 +203,10 @@ def main():
             j["borders"] = (j["x"] == 0) * 1 + (j["y"] == 0) * 2 + (j["x"] + j["w"] == W) * 4 + (j["y"] + j["h"] == H) * 8
             j["offset_val"] = [0, 3, 1, -1, -3]
             d_jobs = dev(j)
-            ms = timeit(lambda pic, ex: L.dev_sao_batch(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g),
+            # every block here is 64 x 64 and aligned: what the ctx layer does with such a picture (jobs sorted, one kernel)
+            run_sao = (lambda pic, ex: L.dev_sao_batch_sorted(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, 0, st())) if not SAO_VARIANT else \
+                      (lambda pic, ex: L.dev_sao_batch(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, st()))
+            ms = timeit(run_sao, lambda: rand_pic(bd, g),
                         name="sao", ring_of=RingExtra(lambda k: rand_pic(bd, g), pic_bytes(src)))
             report(f"sao {name} luma, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         # ---- intra: independent blocks on a sparse grid (every other block position), all 35 modes
