@@ -19,6 +19,7 @@
 
 namespace ohevc {
 
+#ifdef OHEVC_LAB
 // ff_hevc_qpel_filters / ff_hevc_epel_filters (libavcodec/hevcdsp.c:1028-1042): the standard's interpolation taps
 __device__ const signed char kLumaTaps[4][8] = {
     { 0, 0, 0, 64, 0, 0, 0, 0 },
@@ -32,19 +33,26 @@ __device__ const signed char kChromaTaps[8][4] = {
     { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 },
 };
 
+#endif
 constexpr int MC_TILE = 16;
 constexpr int MC_WIN  = MC_TILE + 7;        // window rows/cols for the 8-tap case
+#ifdef OHEVC_LAB
 constexpr int MC_WINP = MC_WIN + 1;         // padded LDS row (int16)
+#endif
 
+#ifdef OHEVC_LAB
 struct McShared {
     short win[MC_WIN][MC_WINP];
     short tmp[MC_WIN][MC_TILE];
 };
 
+#endif
+
 // The rounding term of the final shift.  The reference drops it at BIT_DEPTH 14 ("#if BIT_DEPTH < 14 ... #else int offset = 0",
 // hevcdsp_template.c:653-657, 677-681, 808-812, 835-839, ...), where the uni shift is 0 and the bi shift 1.
 __device__ __forceinline__ int mc_round(int shift, int bit_depth) { return bit_depth < 14 ? 1 << (shift - 1) : 0; }
 
+#ifdef OHEVC_LAB          // round 1's first kernel (ohevc_debug_set_mc_variant(1)): the lab build only
 template <typename Pixel>
 __device__ __forceinline__ void mc_tile_ref(McShared &sh, const ohevc_plane &ref, int sx, int sy, int mx, int my,
                                             bool luma, int tw, int th, int bit_depth, int lane, int *v)
@@ -147,6 +155,8 @@ __global__ __launch_bounds__(64) void mc_kernel(PlaneSet dst, const ohevc_plane 
 }
 
 // ------------------------------------------------------------------ v2: packed-pair dot-product form
+#endif  // OHEVC_LAB
+
 // Same semantics as mc_kernel; per 16x16 tile and reference:
 //   1. stage the (tw+7) x (th+7) window into LDS as int16, row-major, window column 0 at LDS column 0.  Interior windows
 //      use aligned dword loads (4 / 2 samples per lane-load); windows touching the picture edge take the clamped
@@ -163,11 +173,13 @@ __device__ const signed char kChromaTaps8[8][8] = {
     { 0, 64, 0, 0, 0, 0, 0, 0 }, { -2, 58, 10, -2, 0, 0, 0, 0 }, { -4, 54, 16, -2, 0, 0, 0, 0 }, { -6, 46, 28, -4, 0, 0, 0, 0 },
     { -4, 36, 36, -4, 0, 0, 0, 0 }, { -4, 28, 46, -6, 0, 0, 0, 0 }, { -2, 16, 54, -4, 0, 0, 0, 0 }, { -2, 10, 58, -2, 0, 0, 0, 0 } };
 
+#ifdef OHEVC_LAB
 constexpr int MC2_PITCH = 24;                 // int16 elements per LDS line (23 used + 1 pad; 48 bytes keeps dwordx2 alignment)
 struct Mc2Shared {
     short win[MC_WIN][MC2_PITCH];             // [window row][window col]
     short tmp[MC_TILE][MC2_PITCH];            // [output col][window row]  (column-major for the vertical pass)
 };
+#endif
 
 __device__ __forceinline__ unsigned tap_pair(const signed char *f, int k)
 {
@@ -186,6 +198,7 @@ __device__ __forceinline__ void filt4(const unsigned *d, unsigned f01, unsigned 
     out[3] = dot2_i16(m4, f67, dot2_i16(m3, f45, dot2_i16(m2, f23, dot2_i16(m1, f01, init))));
 }
 
+#ifdef OHEVC_LAB          // round 1's second kernel (variant 2); its filt4 / tap_pair primitives above live on in mc3
 template <typename Pixel>
 __device__ __forceinline__ void mc2_tile_ref(Mc2Shared &sh, const ohevc_plane &ref, int sx, int sy, const signed char *fh,
                                              const signed char *fv, int before, int taps, int tw, int th, int bit_depth,
@@ -309,6 +322,8 @@ __global__ __launch_bounds__(64) void mc2_kernel(PlaneSet dst, const ohevc_plane
             }
         }
 }
+
+#endif  // OHEVC_LAB
 
 // ------------------------------------------------------------------ v3: v2's arithmetic, more parallelism
 // SLOTS = 1: one job per wavefront in 16x16 tiles.  SLOTS = 4: four jobs of at most 8x8 samples per wavefront (16 lanes
@@ -644,7 +659,11 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned short *wild = nullptr;
     const bool v4 = g_mc_variant == 5 || (g_mc_variant == 4 && !small);
+#ifdef OHEVC_LAB
     const bool v3 = v4 || small || (g_mc_variant != 1 && g_mc_variant != 2);
+#else
+    const bool v3 = true;              // variants 1 and 2 exist in the lab build only: they fall through to mc3 here
+#endif
     if (bit_depth > 8 && v3) {
         rc = wild_scratch(st, njobs, &wild);
         if (rc != OHEVC_OK) return rc;
@@ -672,12 +691,14 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
             hipLaunchKernelGGL((mc3_kernel<uint16_t, 4>), dim3(grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
             hipLaunchKernelGGL((mc3_redo_kernel<unsigned short>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild, 8);
         }
+#ifdef OHEVC_LAB
     } else if (g_mc_variant == 1) {
         if (bit_depth == 8) hipLaunchKernelGGL((mc_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
         else                hipLaunchKernelGGL((mc_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
     } else if (g_mc_variant == 2) {
         if (bit_depth == 8) hipLaunchKernelGGL((mc2_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
         else                hipLaunchKernelGGL((mc2_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth);
+#endif
     } else {
         if (bit_depth == 8) hipLaunchKernelGGL((mc3_kernel<uint8_t, 1>), dim3(njobs), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild);
         else {
