@@ -33,14 +33,9 @@ __device__ const signed char kChromaTaps[8][4] = {
     { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 },
 };
 
-#endif
 constexpr int MC_TILE = 16;
 constexpr int MC_WIN  = MC_TILE + 7;        // window rows/cols for the 8-tap case
-#ifdef OHEVC_LAB
 constexpr int MC_WINP = MC_WIN + 1;         // padded LDS row (int16)
-#endif
-
-#ifdef OHEVC_LAB
 struct McShared {
     short win[MC_WIN][MC_WINP];
     short tmp[MC_WIN][MC_TILE];
