@@ -52,6 +52,9 @@ int ohevc_debug_set_level_launch(int mode);
 /* Profiling aid for the HOST side only: contexts created while this is on need no device and produce NO pixels -- every
  * ohevc_rec_* call does its normal work, the frame-end executor just drops the recorded jobs.  It exists to time the
  * recording cost of the table slots (tools/profile_recording.py); never a fallback: pictures stay unwritten. */
+/* 1 (default): in the levels form a block's residual rides with its intra job (ohevc_dev_intra_recon_batch: one launch per level); 0: two
+ * launches per level.  Env OHEVC_FUSE_INTRA sets the initial value.  Returns the previous setting. */
+int ohevc_debug_set_fuse_intra(int on);
 int ohevc_debug_set_record_only(int on);
 /* A/B of ohevc_tables_derive_filters: 1 (default) the deblocking maps travel and the device derives the edges (ohevc_dev_deblock_maps);
  * 0 the host derives one job per edge (the only form record-only contexts and the filter-lag emulation of 16x16 CTBs have).

@@ -301,6 +301,13 @@ int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_lev
                      const ohevc_tu_job *tu_jobs, const int16_t *coeffs, void *stream);
 
 
+/* Intra prediction of `njobs` mutually independent blocks, each followed - in the same wavefront - by the block's own residual:
+ * residuals[i] is the residual of jobs[i] (same plane, position and size; reserved0 = residual kind + 1, coefficient offsets into
+ * `coeffs`) or all zeros when block i has none.  What hls_transform_unit does per transform block (hevc.c:1214-1215, 1260-1290), one launch
+ * per dependency level instead of ohevc_dev_intra_batch_cip + ohevc_dev_tu_multi.  OHEVC_TU_CROSS residuals are not taken here. */
+int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals, int njobs,
+                                const ohevc_intra_cip *cip, const int16_t *coeffs, void *stream);
+
 /* ---- 2.6b every intra-coded block of a picture in ONE launch, coding-tree blocks as tasks (the ctx layer's executor).  Inside a CTB the
  * reference reconstructs block after block in decoding order -- intra_pred[..] (hevcpred_template.c:30-357), then the residual of
  * that block (hevc_cabac.c:1868-1949), whose samples the next block's prediction reads; between CTBs only the wavefront order of

@@ -77,6 +77,7 @@ struct PinnedBuf {                    // grow-only pinned host staging buffer
 struct LevelBins {
     std::vector<ohevc_tu_job> tu[4][OHEVC_TU_NKINDS];
     std::vector<ohevc_intra_job> intra;
+    std::vector<ohevc_tu_job> intra_res;   // parallel to intra: the block's own residual (reserved0 = kind + 1) or zeros (ohevc_dev_intra_recon_batch)
     uint64_t touched = 0;             // bit (log2 - 2) * 16 + kind
 };
 
@@ -91,6 +92,7 @@ static std::atomic<uint64_t> g_ctx_gen{1};
 // Pictures whose intra jobs name no CTB size always take the level form.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
+static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
@@ -136,6 +138,7 @@ struct Rec {
     std::vector<ohevc_sao_job> sao;
     bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
     int nstat[5] = {};                // tu, mc, intra, dbk, sao calls
+    struct { int level = -1, index = 0, plane = 0, x = 0, y = 0, log2 = 0; } last_intra;   // the most recent intra job of this recorder (levels form)
 };
 
 struct ohevc_ctx : Rec {
@@ -305,6 +308,7 @@ extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
 }
 
 extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
+extern "C" int ohevc_debug_set_fuse_intra(int on) { const int prev = g_fuse_intra; g_fuse_intra = on != 0; return prev; }
 extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
 
 // ---- inspection of record-only contexts (ohevc_debug.h): host-logic tests without a GPU
@@ -596,8 +600,10 @@ static void clear_rec(Rec &r)
         for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
         lb.touched = 0;
         lb.intra.clear();
+        lb.intra_res.clear();
     }
     r.max_level = -1;
+    r.last_intra.level = -1;
 }
 
 // Fold what the other threads recorded into the context's own recorder (called by the thread that runs the frame, after
@@ -642,6 +648,10 @@ static void merge_side(ohevc_ctx *c)
             for (ohevc_intra_job j : src.intra) {
                 if (j.flags2 & OHEVC_INTRA2_CIP) j.cip_index += ibase;
                 dst.intra.push_back(j);
+            }
+            for (ohevc_tu_job j : src.intra_res) {            // (empty when residuals are not paired: parallel to intra otherwise)
+                if (j.reserved0 && j.reserved0 - 1 != OHEVC_TU_DC) j.coeff_off += cbase;
+                dst.intra_res.push_back(j);
             }
             for (uint64_t m = src.touched; m; m &= m - 1) {
                 const int b = __builtin_ctzll(m), kind = b & 15;
@@ -742,6 +752,16 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
     }
     if (trace_hit(plane, x, y, n, n))
         fprintf(stderr, "trace: target %d tu plane %d x %d y %d log2 %d kind %d level %d c0 %d\n", c->cur, plane, x, y, log2, kind, level, coeffs[0]);
+    // the residual of the block that was just predicted (hls_transform_unit predicts a block and adds its residual back to back,
+    // hevc.c:1214-1215, 1260-1290) rides with its prediction job: one launch per dependency level instead of two
+    auto &li = r.last_intra;
+    if (g_fuse_intra && !c->dry && c->frame_mode != 1 && level > 0 && li.level == level && li.plane == plane && li.x == x && li.y == y && li.log2 == log2) {
+        j.reserved0 = (uint8_t)(kind + 1);
+        r.levels[level].intra_res[li.index] = j;
+        li.level = -1;
+        r.nstat[0]++;
+        return OHEVC_OK;
+    }
     LevelBins &lb = level_bins(r, level);
     lb.tu[log2 - 2][kind].push_back(j);
     lb.touched |= 1ull << ((log2 - 2) * 16 + kind);
@@ -886,7 +906,13 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     if (trace_hit(pl, job->x, job->y, n, n))
         fprintf(stderr, "trace: target %d intra plane %d x %d y %d log2 %d mode %d flags 0x%x flags2 0x%x bl %d tr %d level %d\n", c->cur, pl, job->x,
                 job->y, job->log2_size, job->mode, job->flags, job->flags2, job->bottom_left_size, job->top_right_size, level);
-    level_bins(r, level).intra.push_back(*job);
+    LevelBins &lbi = level_bins(r, level);
+    lbi.intra.push_back(*job);
+    if (g_fuse_intra && !c->dry && c->frame_mode != 1) {
+        lbi.intra_res.push_back(ohevc_tu_job{});
+        r.last_intra.level = level; r.last_intra.index = (int)lbi.intra.size() - 1;
+        r.last_intra.plane = pl; r.last_intra.x = job->x; r.last_intra.y = job->y; r.last_intra.log2 = job->log2_size;
+    }
     r.nstat[2]++;
     return OHEVC_OK;
 }
@@ -1165,7 +1191,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if (c->frame_mode == 2 && !c->ctb_tasks.empty()) {
         // both forms were recorded: keep the cheaper one.  The level form costs a prediction launch and a residual launch per level
         // (~10.5 us per level on the device and about as much launch work on the host: profiles/r02q, r02t)
-        const double level_us = 10.5 * std::max(c->max_level, 0);
+        const double level_us = (g_fuse_intra ? 5.5 : 10.5) * std::max(c->max_level, 0);      // one launch per level when the residuals ride with their prediction
         c->stats.chose_ctbs = ctb_us < level_us;
         static const char *force = getenv("OHEVC_CTB_CHOICE");       // diagnosis: "ctb" / "levels" overrides the estimate
         if (force) c->stats.chose_ctbs = force[0] == 'c';
@@ -1178,6 +1204,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); lb.tu[b >> 4][b & 15].clear(); }
             lb.touched = 0;
             lb.intra.clear();
+            lb.intra_res.clear();
         }
         c->max_level = std::min(c->max_level, c->levels.empty() ? -1 : 0);
     } else {
@@ -1209,11 +1236,12 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_mc = c->mc.empty() ? 0 : stage_put(parts, total, c->mc.data(), c->mc.size() * sizeof(ohevc_mc_job));
     const size_t off_mcs = c->mc_small.empty() ? 0 : stage_put(parts, total, c->mc_small.data(), c->mc_small.size() * sizeof(ohevc_mc_job));
     // per level: the intra jobs, then every touched (size, kind) bin back to back (one segmented launch per level)
-    struct LevelOff { size_t intra = 0, tu_first = 0; };
+    struct LevelOff { size_t intra = 0, intra_res = 0, tu_first = 0; };
     std::vector<LevelOff> loff((size_t)(c->max_level + 1));
     for (int l = 0; l <= c->max_level; l++) {
         LevelBins &lb = c->levels[l];
         if (!lb.intra.empty()) loff[l].intra = stage_put(parts, total, lb.intra.data(), lb.intra.size() * sizeof(ohevc_intra_job));
+        if (!lb.intra_res.empty()) loff[l].intra_res = stage_put(parts, total, lb.intra_res.data(), lb.intra_res.size() * sizeof(ohevc_tu_job));
         bool first = true;
         for (uint64_t m = lb.touched; m; m &= m - 1) {
             const int b = __builtin_ctzll(m);
@@ -1300,9 +1328,14 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     for (int level = 0; level <= last_separate; level++) {
         LevelBins &lb = c->levels[level];
         if (!lb.intra.empty()) {
-            rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
-                                           (int)lb.intra.size(),
-                                           c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), c->stream);
+            if (lb.intra_res.size() == lb.intra.size())
+                rc = ohevc_dev_intra_recon_batch(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
+                                                 reinterpret_cast<const ohevc_tu_job *>(base + loff[level].intra_res), (int)lb.intra.size(),
+                                                 c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), d_coeffs, c->stream);
+            else
+                rc = ohevc_dev_intra_batch_cip(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
+                                               (int)lb.intra.size(),
+                                               c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), c->stream);
             if (rc != OHEVC_OK) return rc;
             c->stats.launches++;
         }

@@ -1663,6 +1663,53 @@ static int launch_tu(const PlaneSet &ps, int bit_depth, int log2, int kind, cons
 
 }  // namespace ohevc
 
+// ------------------------------------------------------------------ intra prediction + its residual, one wavefront per block
+// In the reference a transform block is predicted and its residual added back to back (hls_transform_unit, hevc.c:1214-1215 then
+// :1260-1290).  As two launches per dependency level the residual kernel waits on a kernel boundary for samples its own wavefront just
+// stored: here the wavefront that predicted block b runs the residual body for b (the batched bodies, pointed at this one job).  One
+// launch per level instead of two.
+// Round 1 had this kernel and reverted it for "rare stale reads between its two halves".  The cause: s_waitcnt vmcnt(0) makes the
+// prediction stores complete in L2, but the CU's L1 may still hold a line of the block that ANOTHER wavefront of the CU fetched
+// earlier - as neighbour samples of its own block - and stores do not update it: the residual body then adds to old samples.  The
+// read-back needs the same acquire as a hand-off between wavefronts (buffer_inv sc1, the CTB executor's xcd_acquire).
+namespace ohevc {
+template <typename Pixel>
+__global__ __launch_bounds__(64) void intra_recon_kernel(PlaneSet planes, const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals, int njobs,
+                                                         int bit_depth, const ohevc_intra_cip *__restrict__ cips, const int16_t *__restrict__ coeffs)
+{
+    __shared__ IntraShared ish;
+    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[2 * TuLayout<5>::WAVE_BYTES];
+    const ohevc_intra_job jb = jobs[blockIdx.x];
+    intra_body<Pixel, false>(ish, threadIdx.x, planes, jb, bit_depth, cips);
+    const ohevc_tu_job *res = residuals + blockIdx.x;
+    const int kind1 = __builtin_amdgcn_readfirstlane((int)res->reserved0);        // residual kind + 1; 0: this block has none
+    if (kind1 == 0) return;
+    xcd_release();                                              // the prediction is in L2 ...
+    xcd_acquire();                                              // ... and nothing older of it in this CU's L1
+    tu_dispatch<Pixel>(tu_lds, 0, planes, res, 1, jb.log2_size, kind1 - 1, coeffs, bit_depth);
+}
+}  // namespace ohevc
+
+extern "C" int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals, int njobs,
+                                           const ohevc_intra_cip *cip, const int16_t *coeffs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(planes != nullptr, "planes");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
+    OHEVC_REQUIRE(njobs >= 0, "njobs");
+    if (njobs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr && residuals != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(residuals) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(cip) & 15) == 0 && (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "arrays must be 16-byte aligned");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
+    if (rc != OHEVC_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bit_depth == 8) hipLaunchKernelGGL((intra_recon_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, residuals, njobs, bit_depth, cip, coeffs);
+    else                hipLaunchKernelGGL((intra_recon_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, residuals, njobs, bit_depth, cip, coeffs);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
 #include "ctb_kernels.hpp"      // the CTB executor runs tu_dispatch on its LDS tiles
 
 extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, int log2_size, int kind,

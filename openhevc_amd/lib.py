@@ -186,7 +186,7 @@ def dev_sao_batch_sorted(dst_planes, src_planes, bit_depth, jobs_ptr, n_wide, n_
                                                     None, C.c_void_p(stream)))
 
 
-EXPORTED_SYMBOLS += ["ohevc_dev_sao_batch_sorted", "ohevc_sao_job_is_wide"]
+EXPORTED_SYMBOLS += ["ohevc_dev_sao_batch_sorted", "ohevc_sao_job_is_wide", "ohevc_dev_intra_recon_batch", "ohevc_debug_set_fuse_intra"]
 
 
 class SaoBypass(C.Structure):
