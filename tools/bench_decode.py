@@ -87,6 +87,9 @@ def main():
         hip_st = ps.decode_stream("hip", aus, a.cpu_threads, 2)
         res["reference_agrees_with_itself_with_slice_threads"] = bool(all(np.array_equal(x, y) for fa, fb in zip(ref, ref_st) for x, y in zip(fa, fb)))
         res["bit_exact_slice_threads"] = bool(len(ref_st) == len(hip_st) and all(np.array_equal(x, y) for fa, fb in zip(ref_st, hip_st) for x, y in zip(fa, fb)))
+        # (the reference's own slice-thread decode is racy on some streams - reference_agrees_with_itself... False; what matters then is
+        # that the back end still produces the single-thread reference's pictures)
+        res["slice_threads_equal_single_thread_reference"] = bool(len(ref) == len(hip_st) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip_st) for x, y in zip(fa, fb)))
         runs = [(f"reference_c_{a.cpu_threads}slice_threads", "c", a.cpu_threads, 2), (f"hip_backend_{a.cpu_threads}slice_threads", "hip", a.cpu_threads, 2),
                 (f"reference_c_{a.cpu_threads}frame_and_slice_threads", "c", a.cpu_threads, 4),
                 (f"hip_backend_{a.cpu_threads}frame_and_slice_threads", "hip", a.cpu_threads, 4)]
