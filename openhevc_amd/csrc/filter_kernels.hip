@@ -18,16 +18,16 @@ __device__ __forceinline__ int iclip(int v, int lo, int hi) { return v < lo ? lo
 // One line of one 8-sample edge: lane `line` (0..7) of an 8-lane group; every exit is taken by whole 4-line segments.
 // beta_in / tc_in before bit-depth scaling, tc_in of this lane's segment.
 template <typename Pixel>
-__device__ __forceinline__ void deblock_line(const PlaneSet &planes, int jx, int jy, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth)
-{
+__device__ __forceinline__ void deblock_line(unsigned char *plane_base, int stride, int jx, int jy, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth, int l0, int l3)
+{      // l0, l3: the lanes of the wavefront that hold lines 0 and 3 of this line's 4-line segment.  (The plane's base and pitch arrive resolved: picked
+       // from the PlaneSet behind a reference, the selection becomes a load from a scratch copy of the kernel arguments.)
     const int seg = line >> 2;
     const bool vertical = flags & OHEVC_DBK_VERTICAL_EDGE;
     const bool no_p = flags & (seg ? OHEVC_DBK_NO_P1 : OHEVC_DBK_NO_P0);
     const bool no_q = flags & (seg ? OHEVC_DBK_NO_Q1 : OHEVC_DBK_NO_Q0);
-    const int stride = PLANE_STRIDE3(planes, jplane);
     const int xs = vertical ? (int)sizeof(Pixel) : stride;      // step across the edge
     const int ys = vertical ? stride : (int)sizeof(Pixel);      // step along the edge
-    unsigned char *pix = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
+    unsigned char *pix = plane_base + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
     const int maxv = (1 << bit_depth) - 1;
 #define LD(i) ((int)*reinterpret_cast<const Pixel *>(pix + (ptrdiff_t)(i) * xs))
     // Vertical luma edges: the 8 samples across the edge are 8 / 16 contiguous bytes of one row - one vector load, one vector store
@@ -74,7 +74,6 @@ __device__ __forceinline__ void deblock_line(const PlaneSet &planes, int jx, int
     };
     const int dp = iabs(p2 - 2 * p1 + p0), dq = iabs(q2 - 2 * q1 + q0);
     const int flat = iabs(p3 - p0) + iabs(q3 - q0), step = iabs(p0 - q0);
-    const int l0 = (threadIdx.x & 63) & ~3, l3 = l0 | 3;        // lanes holding lines 0 and 3 of this segment
     const int dp0 = __shfl(dp, l0), dp3 = __shfl(dp, l3), dq0 = __shfl(dq, l0), dq3 = __shfl(dq, l3);
     const int flat0 = __shfl(flat, l0), flat3 = __shfl(flat, l3), step0 = __shfl(step, l0), step3 = __shfl(step, l3);
     const int d0 = dp0 + dq0, d3 = dp3 + dq3;
@@ -120,7 +119,8 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
     const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff, flags = (jraw.y >> 8) & 0xff;
     const int beta_in = (jraw.y >> 16) & 0xff;
     const int tc_in = seg ? (int)jraw.z >> 16 : (int)(short)(jraw.z & 0xffff);
-    deblock_line<Pixel>(planes, jx, jy, jplane, flags, beta_in, tc_in, line, bit_depth);
+    const int l0 = (threadIdx.x & 63) & ~3;
+    deblock_line<Pixel>(PLANE_PTR3(planes, jplane), PLANE_STRIDE3(planes, jplane), jx, jy, jplane, flags, beta_in, tc_in, line, bit_depth, l0, l0 | 3);
 }
 
 // ------------------------------------------------------------------ deblocking straight from the decoder's maps
@@ -144,9 +144,13 @@ template <typename Pixel>
 __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohevc_dbk_maps m, int vertical, int bit_depth, int luma_units, int chroma_units,
                                                            int luma_uw, int chroma_uw)
 {
-    const int tid = blockIdx.x * 256 + threadIdx.x;
-    int unit = tid >> 3;
-    const int line = tid & 7;
+    // lane -> (edge, line) inside a wavefront of 8 edges.  Horizontal edges: edge-major (the 8 lanes of an edge are 8 neighbouring samples of
+    // a row).  Vertical edges: LINE-major - the lanes of one line across 8 neighbouring edges then read one contiguous 64- / 128-byte
+    // piece of a row; edge-major, every lane of a load would sit in its own row.
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int line = vertical ? lane >> 3 : lane & 7;
+    int unit = wave * 8 + (vertical ? lane & 7 : lane >> 3);
+    const int l0 = vertical ? ((line & 4) << 3) | (lane & 7) : lane & ~3, l3 = vertical ? l0 + 24 : l0 | 3;
     if (unit >= luma_units + 2 * chroma_units) return;
     int plane = 0;
     if (unit >= luma_units) { unit -= luma_units; plane = 1; if (unit >= chroma_units) { unit -= chroma_units; plane = 2; } }
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
             tc = kDbkTc[clipi(qp + 2 + tc_offset, 0, 53)];
         }
     }
-    deblock_line<Pixel>(planes, x >> hs, y >> vs, plane, flags, beta, tc, line, bit_depth);
+    deblock_line<Pixel>(PLANE_PTR3(planes, plane), PLANE_STRIDE3(planes, plane), x >> hs, y >> vs, plane, flags, beta, tc, line, bit_depth, l0, l3);
 }
 
 template <typename Pixel>

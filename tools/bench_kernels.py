@@ -191,6 +191,23 @@ def main():
         d_jobs2 = dev(j2)
         ms = timeit(lambda pic, ex: L.dev_deblock_batch(L.planes_of(pic), bd, d_jobs2.data_ptr(), n2, st()), lambda: rand_pic(bd, g), name="deblock")
         report(f"deblock luma horizontal edges, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
+        # ---- deblocking derived on the device from the decoder's maps (ohevc_dev_deblock_maps: what the ctx layer runs): every 8x8-grid luma
+        #      edge carries bS 1, chroma planes none (bS 2 only), QP 32 everywhere -> the same luma edges as above, beta 26-ish, tc 1-2
+        bw, bh = W >> 2, H >> 2
+        vb = np.zeros(bw * (bh + 8), np.uint8); hb = np.zeros((bw + 8) * bh, np.uint8)
+        grid = np.zeros((bh, bw), np.uint8); grid[:, ::2] = 1                  # vertical edges at x % 8 == 0 (bs index = x / 4)
+        vb[:bw * bh] = grid.ravel()
+        grid = np.zeros((bh, bw), np.uint8); grid[::2, :] = 1                  # horizontal edges at y % 8 == 0
+        hb[:bw * bh] = grid.ravel()
+        qp = np.full((W >> 3) * (H >> 3), 38, np.int8)
+        dbp = np.zeros((((W + 63) // 64) * ((H + 63) // 64), 2), np.int8)
+        keep = [dev(a) for a in (vb, hb, qp, dbp)]
+        dm = L.DbkMaps(vertical_bs=keep[0].data_ptr(), horizontal_bs=keep[1].data_ptr(), qp_y_tab=keep[2].data_ptr(), deblock=keep[3].data_ptr(), is_pcm=None,
+                       bs_width=bw, min_cb_width=W >> 3, deblock_stride=2, min_pu_width=W >> 2, min_pu_height=H >> 2, width=W, height=H, log2_ctb_size=6,
+                       log2_min_cb_size=3, log2_min_pu_size=2, chroma_format_idc=1, cb_qp_offset=0, cr_qp_offset=0)
+        for vert, nm in ((1, "vertical"), (0, "horizontal")):
+            ms = timeit(lambda pic, ex: L.dev_deblock_maps(L.planes_of(pic), bd, dm, vert, st()), lambda: rand_pic(bd, g), name="deblock")
+            report(f"deblock luma {nm} edges from the decoder's maps, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         # ---- SAO: one job per 64x64 luma CTB, edge class 2 / band
         src = rand_pic(bd, g)
         for (typ, name) in [(L.SAO_EDGE, "edge (135 deg)"), (L.SAO_BAND, "band")]:
