@@ -56,6 +56,10 @@ static void log_counter(void *avcl, int level, const char *fmt, va_list vl)
 typedef struct ohdec {
     AVCodecContext *avctx;
     AVFrame        *frame;
+    /* pipelined output (ohdec_set_pipelined): the application takes a picture one call late, so that with ONE decoding thread the device
+     * reconstructs picture k while the CPU parses picture k + 1 (with OHHIP_DEFER_DOWNLOAD=1 the frame-end hook only issues the work) */
+    AVFrame        *next, *held;
+    int             pipelined, held_valid;
     uint8_t        *pkt_buf;
     int             pkt_cap;
     int             have_frame;
@@ -83,7 +87,9 @@ ohdec *ohdec_open_ex(int threads, int thread_type, int checksum)
         goto fail;
     d->avctx = avcodec_alloc_context3(codec);
     d->frame = av_frame_alloc();
-    if (!d->avctx || !d->frame)
+    d->next = av_frame_alloc();
+    d->held = av_frame_alloc();
+    if (!d->avctx || !d->frame || !d->next || !d->held)
         goto fail;
     d->avctx->flags |= CODEC_FLAG_UNALIGNED;
     d->avctx->err_recognition |= AV_EF_EXPLODE;     /* a syntax error fails the call instead of being concealed (hevc.c:3480) */
@@ -113,6 +119,9 @@ fail:
 }
 
 ohdec *ohdec_open(int threads, int thread_type) { return ohdec_open_ex(threads, thread_type, 0); }
+
+/* pipelined output: see struct ohdec.  Call right after ohdec_open*. */
+void ohdec_set_pipelined(ohdec *d, int on) { d->pipelined = on != 0; }
 
 /* Frame-parallel decoding over processes (integration/hip_frames.h; openhevc_amd/dist.py drives it): `mode` = ohhip_frames_mode *,
  * NULL switches it off.  Call right after ohdec_open*; one decoding thread per process.  Returns 0, or -1 for decoders without
@@ -160,6 +169,29 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
     pkt.data = len ? d->pkt_buf : NULL;
     pkt.size = len;
     pkt.pts  = pts;
+    if (d->pipelined) {
+        int out = 0;
+        av_frame_unref(d->next);
+        ret = avcodec_decode_video2(d->avctx, d->next, &got, &pkt);
+        if (ret < 0)
+            return -2;
+        if (ohdec_backend_frame_done() < 0)
+            return -3;
+        av_frame_unref(d->frame);
+        if (d->held_valid) {                          /* the picture of the previous call: its device work had a whole parse to finish */
+            if (ohdec_backend_fetch_output(d->held->data, d->held->linesize) < 0)
+                return -3;
+            av_frame_move_ref(d->frame, d->held);
+            d->held_valid = 0;
+            out = 1;
+        }
+        if (got) {
+            av_frame_move_ref(d->held, d->next);
+            d->held_valid = 1;
+        }
+        d->have_frame = out;
+        return out;
+    }
     av_frame_unref(d->frame);
     ret = avcodec_decode_video2(d->avctx, d->frame, &got, &pkt);
     if (ret < 0)
@@ -181,7 +213,7 @@ int ohdec_flush(ohdec *d)
     int i, r = 0, workers = d->threads;
     if (d->avctx->thread_count_frame > workers)     /* frame + slice threads: the frame-thread count is derived from the core count (pthread.c:65-71) */
         workers = d->avctx->thread_count_frame;
-    for (i = 0; i <= workers && r == 0; i++)
+    for (i = 0; i <= workers + (d->pipelined ? 1 : 0) && r == 0; i++)
         r = ohdec_decode(d, NULL, 0, 0);
     return r;
 }
@@ -227,6 +259,8 @@ void ohdec_close(ohdec *d)
     avcodec_close(d->avctx);
     av_free(d->avctx);
     av_frame_free(&d->frame);
+    av_frame_free(&d->next);
+    av_frame_free(&d->held);
     ohdec_backend_close();
     free(d->pkt_buf);
     free(d);

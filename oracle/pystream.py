@@ -97,13 +97,16 @@ def _configure_hip_backend():
 class Decoder:
     """One decoder instance.  decode(au) -> picture (list of 3 numpy planes) or None; flush() -> remaining pictures."""
 
-    def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1, checksum: bool = False):
+    def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1, checksum: bool = False, pipelined: bool = False):
         self.kind = kind
         self.L = _load(kind)
         self.sw = _configure_hip_backend() if kind == "hip" else None
         self.h = self.L.ohdec_open_ex(threads, thread_type, 1 if checksum else 0)
         if not self.h:
             raise RuntimeError(f"ohdec_open failed for {kind}")
+        if pipelined:       # the application takes every picture one call late (decoder_harness.c): device work overlaps the next parse
+            self.L.ohdec_set_pipelined.argtypes = [C.c_void_p, C.c_int]
+            self.L.ohdec_set_pipelined(self.h, 1)
 
     def md5_results(self):
         """(planes whose decoded-picture-hash SEI matched, planes that did not) since the decoder was opened: the reference's own
@@ -186,12 +189,12 @@ class Decoder:
         self.close()
 
 
-def decode_stream(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1, checksum: bool = False):
+def decode_stream(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1, checksum: bool = False, pipelined: bool = False):
     """Decode a list of access units, return all output pictures in output order.  checksum=True turns the reference's
     `decode-checksum` option on (libOpenHevcSetCheckMD5, openHevcWrapper.c:429-440) and returns (pictures, (ok, bad)) with the
     number of planes whose decoded-picture-hash SEI matched / mismatched in the decoder's own check."""
     out = []
-    with Decoder(kind, threads, thread_type, checksum) as d:
+    with Decoder(kind, threads, thread_type, checksum, pipelined) as d:
         for i, au in enumerate(aus):
             f = d.decode(au, i + 1)
             if f is not None:

@@ -94,6 +94,19 @@ def test_emu_golden_stream_filters_derived_on_the_host(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 
 
+@pytest.mark.parametrize("name", ["ra_8b_ctb64", "ldb_10b", "pcm", "intra_8b"])
+def test_emu_golden_stream_pipelined_output(name, monkeypatch):
+    """One decoding thread, the frame-end hook only issues the device work (OHHIP_DEFER_DOWNLOAD) and the application takes every picture
+    one call late (decoder_harness.c: ohdec_set_pipelined): the device reconstructs picture k while the CPU parses picture k + 1."""
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_DEFER_DOWNLOAD", "1")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hipemu", aus, pipelined=True)) == md5
+
+
 @pytest.mark.parametrize("threads,thread_type,names", [
     (4, 1, ["ra_8b_ctb64", "ldb_10b", "weighted", "fmt444_8b"]),          # frame threads
     (4, 2, ["wpp", "tiles", "slices_dep_wpp"]),                            # slice threads

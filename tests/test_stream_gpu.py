@@ -46,6 +46,15 @@ def test_golden_stream_filters_derived_on_the_host(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hip", aus)) == md5
 
 
+@pytest.mark.parametrize("name", ["ra_8b_ctb64", "ra_10b_odd", "ldb_10b", "pcm", "intra_8b", "weighted"])
+def test_golden_stream_pipelined_output(name, monkeypatch):
+    """One decoding thread, deferred copy-back, the application takes every picture one call late: the device works on picture k while the
+    CPU parses picture k + 1 (decoder_harness.c: ohdec_set_pipelined)."""
+    monkeypatch.setenv("OHHIP_DEFER_DOWNLOAD", "1")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hip", aus, pipelined=True)) == md5
+
+
 @pytest.mark.parametrize("kw", [
     dict(gop="random_access", nframes=9, seed=301, width=832, height=480, log2_ctb=6),
     dict(gop="random_access", nframes=9, seed=302, width=832, height=480, log2_ctb=6, bit_depth=10, weighted_bipred=1,

@@ -17,11 +17,11 @@ import numpy as np                      # noqa: E402
 from oracle import pystream as ps       # noqa: E402
 
 
-def timed_decode(kind, aus, threads=1, thread_type=1, repeat=2):
+def timed_decode(kind, aus, threads=1, thread_type=1, repeat=2, pipelined=False):
     best = None
     frames = None
     for _ in range(repeat):
-        with ps.Decoder(kind, threads, thread_type) as d:
+        with ps.Decoder(kind, threads, thread_type, pipelined=pipelined) as d:
             t = time.perf_counter()
             n = 0
             for i, au in enumerate(aus):
@@ -96,12 +96,18 @@ def main():
     for name, kind, th, tt in runs + [("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
                                ("front_end_only_no_pixels", "null", 1, 1),
                                (f"front_end_only_{a.cpu_threads}frame_threads", "null", a.cpu_threads, 1),
-                               ("hip_backend", "hip", 1, 1), (f"hip_backend_{a.cpu_threads}frame_threads", "hip", a.cpu_threads, 1),
+                               ("hip_backend", "hip", 1, 1), ("hip_backend_pipelined_output", "hip", 1, -1),
+                               (f"hip_backend_{a.cpu_threads}frame_threads", "hip", a.cpu_threads, 1),
                                (f"reference_c_{2 * a.cpu_threads}frame_threads", "c", 2 * a.cpu_threads, 1),
                                (f"hip_backend_{2 * a.cpu_threads}frame_threads", "hip", 2 * a.cpu_threads, 1)]:
         if not ps.have(kind):
             continue
-        dt, n = timed_decode(kind, aus, th, tt)
+        if tt == -1:            # one decoding thread, the application takes each picture one call late and the frame-end hook only issues the
+            os.environ["OHHIP_DEFER_DOWNLOAD"] = "1"      # device work: the GPU reconstructs picture k while the CPU parses picture k + 1
+            dt, n = timed_decode(kind, aus, 1, 1, pipelined=True)
+            del os.environ["OHHIP_DEFER_DOWNLOAD"]
+        else:
+            dt, n = timed_decode(kind, aus, th, tt)
         res[name] = dict(seconds=round(dt, 4), fps=round(a.frames / dt, 2), mpixel_per_s=round(mp / dt, 1), pictures=n)
         if kind == "hip":       # where the back-end's time goes (last repeat only is not separated: counters are cumulative)
             L = ps._load("hip")
