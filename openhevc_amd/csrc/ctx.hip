@@ -892,13 +892,57 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     // value read there only makes the level higher than necessary.  Relaxed atomics keep those accesses well defined.
     uint16_t *lm = c->level_map[pl].data();
     auto ld = [&](size_t i) { return (int)__atomic_load_n(&lm[i], __ATOMIC_RELAXED); };
+    // Which of the five neighbour groups - in the reference's scan order below-left, left, corner, above, above-right - can reach the
+    // prediction?  (1) what the predictor of this mode reads (hevcpred_template.c:359-537; the whole set whenever the [1 2 1] / strong
+    // smoothing of :289-327 applies, for the negative angles and for constrained intra prediction); (2) an unavailable group is filled
+    // from the group before it in scan order (already resolved), the below-left one from the first available group after it (:251-286).
+    // A block that predicts from the row above only does not wait for its left neighbour: shorter dependency chains, fewer launches.
+    enum { G_BL = 1, G_L = 2, G_UL = 4, G_U = 8, G_UR = 16, G_ALL = 31 };
+    unsigned need;
+    {
+        const int mode = job->mode, log2 = job->log2_size;
+        const bool luma_edge = (job->flags & OHEVC_INTRA_LUMA_EDGE) && n < 32;
+        bool smooth = false;
+        if (!(job->flags & OHEVC_INTRA_NO_SMOOTHING) && mode != 1 && n != 4) {
+            const int dv = mode > 26 ? mode - 26 : 26 - mode, dh = mode > 10 ? mode - 10 : 10 - mode;
+            smooth = (dv < dh ? dv : dh) > (log2 == 3 ? 7 : log2 == 4 ? 1 : 0);
+        }
+        if (smooth || (job->flags2 & OHEVC_INTRA2_CIP)) need = G_ALL;
+        else if (mode == 0) need = G_BL | G_L | G_U | G_UR;
+        else if (mode == 1) need = G_L | G_U;
+        else if (mode < 10) need = G_L | G_BL;
+        else if (mode == 10) need = G_L | (luma_edge ? G_U | G_UL : 0);
+        else if (mode < 26) need = G_ALL;
+        else if (mode == 26) need = G_U | (luma_edge ? G_L | G_UL : 0);
+        else need = G_U | G_UR;
+    }
+    unsigned src = 0;                                          // the available groups the needed ones take their samples from
+    {
+        const unsigned avail = job->flags & 31u;               // OHEVC_INTRA_BOTTOM_LEFT .. OHEVC_INTRA_UP_RIGHT = bits 0..4, scan order
+        for (int g = 0; g < 5; g++) {
+            if (!(need >> g & 1)) continue;
+            int j = g;
+            while (j >= 0 && !(avail >> j & 1)) j--;           // the group itself, or the nearest available one before it ...
+            if (j < 0) { j = g + 1; while (j < 5 && !(avail >> j & 1)) j++; }      // ... or the first one after it
+            if (j < 5) src |= 1u << j;
+        }
+    }
     int level = 0;
-    const int cx0 = (job->x >> 2) - 1, cx1 = std::min(W - 1, (job->x + 2 * n - 1) >> 2);
-    const int cy0 = (job->y >> 2) - 1, cy1 = std::min(H - 1, (job->y + 2 * n - 1) >> 2);
-    if (cy0 >= 0)
-        for (int cx = std::max(cx0, 0); cx <= cx1; cx++) level = std::max(level, ld((size_t)cy0 * W + cx));
-    if (cx0 >= 0)
-        for (int cy = std::max(cy0, 0); cy <= cy1; cy++) level = std::max(level, ld((size_t)cy * W + cx0));
+    const int cx0 = (job->x >> 2) - 1, cy0 = (job->y >> 2) - 1, cn = n >> 2;              // cells: column left of / row above the block
+    const int cxb = job->x >> 2, cyb = job->y >> 2;
+    auto row_cells = [&](int x_first, int x_last) {            // cells [x_first, x_last] of the row above
+        if (cy0 < 0) return;
+        for (int cx = std::max(x_first, 0); cx <= std::min(x_last, W - 1); cx++) level = std::max(level, ld((size_t)cy0 * W + cx));
+    };
+    auto col_cells = [&](int y_first, int y_last) {            // cells [y_first, y_last] of the column to the left
+        if (cx0 < 0) return;
+        for (int cy = std::max(y_first, 0); cy <= std::min(y_last, H - 1); cy++) level = std::max(level, ld((size_t)cy * W + cx0));
+    };
+    if (src & G_BL) col_cells(cyb + cn, cyb + 2 * cn - 1);
+    if (src & G_L) col_cells(cyb, cyb + cn - 1);
+    if (src & G_UL) { if (cx0 >= 0) row_cells(cx0, cx0); }
+    if (src & G_U) row_cells(cxb, cxb + cn - 1);
+    if (src & G_UR) row_cells(cxb + cn, cxb + 2 * cn - 1);
     level += 1;
     OHEVC_REQUIRE(level < 65535, "intra dependency chain too long");
     for (int cy = job->y >> 2; cy < (job->y + n) >> 2; cy++)
