@@ -907,7 +907,11 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
             const int dv = mode > 26 ? mode - 26 : 26 - mode, dh = mode > 10 ? mode - 10 : 10 - mode;
             smooth = (dv < dh ? dv : dh) > (log2 == 3 ? 7 : log2 == 4 ? 1 : 0);
         }
-        if (smooth || (job->flags2 & OHEVC_INTRA2_CIP)) need = G_ALL;
+        // smoothed reference samples: filtered[k] reads k - 1 .. k + 1 of the same array (k = 0: the corner); the strong (bilinear) form of
+        // 32x32 luma blocks decides on both arrays
+        const bool strong = smooth && (job->flags & OHEVC_INTRA_STRONG) && log2 == 5;
+        if ((job->flags2 & OHEVC_INTRA2_CIP) || strong) need = G_ALL;
+        else if (smooth) need = mode >= 27 ? G_UL | G_U | G_UR : (mode >= 2 && mode <= 9) ? G_UL | G_L | G_BL : G_ALL;
         else if (mode == 0) need = G_BL | G_L | G_U | G_UR;
         else if (mode == 1) need = G_L | G_U;
         else if (mode < 10) need = G_L | G_BL;
@@ -1284,6 +1288,14 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     std::vector<LevelOff> loff((size_t)(c->max_level + 1));
     for (int l = 0; l <= c->max_level; l++) {
         LevelBins &lb = c->levels[l];
+        // OHEVC_REVERSE_LEVELS=1 (tests over the emulated device code, whose workgroups run one after the other in launch order): the
+        // jobs of a level are independent, so their order must not matter - a dependency the level computation missed shows up
+        const bool reverse_levels = getenv("OHEVC_REVERSE_LEVELS") != nullptr;          // (looked up per picture: tests switch it inside one process)
+        if (reverse_levels) {
+            std::reverse(lb.intra.begin(), lb.intra.end());
+            std::reverse(lb.intra_res.begin(), lb.intra_res.end());
+            for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); std::reverse(lb.tu[b >> 4][b & 15].begin(), lb.tu[b >> 4][b & 15].end()); }
+        }
         if (!lb.intra.empty()) loff[l].intra = stage_put(parts, total, lb.intra.data(), lb.intra.size() * sizeof(ohevc_intra_job));
         if (!lb.intra_res.empty()) loff[l].intra_res = stage_put(parts, total, lb.intra_res.data(), lb.intra_res.size() * sizeof(ohevc_tu_job));
         bool first = true;

@@ -94,6 +94,20 @@ def test_emu_golden_stream_filters_derived_on_the_host(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 
 
+@pytest.mark.parametrize("name", _golden_names())
+def test_emu_golden_stream_levels_in_reverse_order(name, monkeypatch):
+    """The emulator runs the workgroups of a launch one after the other, in decoding order inside a dependency level - an order that hides a
+    dependency the level computation missed (the device runs them concurrently).  OHEVC_REVERSE_LEVELS submits every level back to front."""
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", "0")
+    monkeypatch.setenv("OHEVC_REVERSE_LEVELS", "1")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
+
+
 @pytest.mark.parametrize("name", ["ra_8b_ctb64", "ldb_10b", "pcm", "intra_8b"])
 def test_emu_golden_stream_pipelined_output(name, monkeypatch):
     """One decoding thread, the frame-end hook only issues the device work (OHHIP_DEFER_DOWNLOAD) and the application takes every picture
