@@ -1381,6 +1381,8 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if (!phases.empty()) {
         // (issued after level 0 below; prepared here to keep the offsets together)
     }
+    const bool trace_launches = getenv("OHEVC_TRACE_LAUNCHES") != nullptr;
+    int n_lv_intra = 0, n_lv_tu = 0;
     for (int level = 0; level <= last_separate; level++) {
         LevelBins &lb = c->levels[level];
         if (!lb.intra.empty()) {
@@ -1416,8 +1418,12 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             sg.njobs = (int32_t)v.size();
             job_off += ((v.size() * sizeof(ohevc_tu_job) + 255) & ~(size_t)255) / sizeof(ohevc_tu_job);
         }
+        if (trace_launches && level > 0) { n_lv_intra += !lb.intra.empty(); n_lv_tu += lb.touched != 0; }
         if ((rc = flush_segs()) != OHEVC_OK) return rc;
     }
+    if (trace_launches)
+        fprintf(stderr, "launches: target %d levels %d: %d prediction(+residual) launches, %d residual launches of unpaired blocks; mc %d+%d jobs, level-0 residual bins %d\n",
+                c->cur, max_level, n_lv_intra, n_lv_tu, (int)c->mc.size(), (int)c->mc_small.size(), max_level >= 0 ? __builtin_popcountll(c->levels[0].touched) : 0);
     if (!phases.empty()) {
         rc = ohevc_dev_levels(p->planes, p->bd, reinterpret_cast<const ohevc_level_phase *>(base + off_phases), (int)phases.size(), total_wgs,
                               reinterpret_cast<uint32_t *>(base + off_sync), reinterpret_cast<const uint32_t *>(base + off_need),
