@@ -29,16 +29,37 @@ __constant__ signed char kUpChroma[16][4] = {
 // at most one per row (the enhancement layer is never smaller than the base layer), so the horizontally filtered values live
 // in a sliding window of TAPS registers: TAPS + ROWS - 1 horizontal filters per thread instead of TAPS * ROWS.  The window is
 // indexed by base-layer row, not by output row, so any monotonic row map works (a jump forces a refill).
+// Round 2: the base-layer samples a workgroup's 64 x (4 ROWS) output tile reads - at most (4 ROWS + TAPS) x (64 + TAPS) of them - are
+// staged in LDS once (clamped coordinates resolved there) instead of being gathered from global memory TAPS times per filtered value
+// (120 one-sample loads per thread before, ~12 now); a tile whose maps jump (window larger than the LDS tile) takes the gather form.
+constexpr int UP_WC = 80, UP_WR = 48;        // LDS window: columns x rows (x1 .. x2 scaling needs 72 x 40)
 template <typename Pixel, int TAPS, int ROWS>
 __global__ __launch_bounds__(256) void upsample_kernel(ohevc_plane dst, ohevc_plane src, const ohevc_upsample_tap *__restrict__ cols,
                                                        const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
                                                        int src_cols, int src_rows, int bit_depth)
 {
     constexpr int HALF = TAPS / 2 - 1;
+    __shared__ Pixel win_lds[UP_WR][UP_WC];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS;
+    const unsigned char *sbase = static_cast<const unsigned char *>(src.data);
+    // ---- the tile's base-layer window (wave-uniform arithmetic on the maps)
+    const int tx0 = blockIdx.x * 64, tx1 = min(tx0 + 63, dst.width - 1), ty0 = blockIdx.y * 4 * ROWS, ty1 = min(ty0 + 4 * ROWS - 1, dst.height - 1);
+    const int cmin = cols[col_of[tx0]].pos - HALF, cmax = cols[col_of[tx1]].pos - HALF + TAPS - 1;
+    const int rmin = rows[ty0].pos - HALF, rmax = rows[ty1].pos - HALF + TAPS - 1;
+    const bool staged = cmax - cmin < UP_WC && rmax - rmin < UP_WR && cmax >= cmin && rmax >= rmin;
+    if (staged) {
+        const int wc = cmax - cmin + 1, wr = rmax - rmin + 1;
+        for (int i = threadIdx.x; i < wc * wr; i += 256) {
+            const int r = i / wc, cc = i - r * wc;
+            int ry = rmin + r, rx = cmin + cc;
+            ry = ry < 0 ? 0 : ry > src_rows - 1 ? src_rows - 1 : ry;
+            rx = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
+            win_lds[r][cc] = reinterpret_cast<const Pixel *>(sbase + (size_t)ry * src.stride)[rx];
+        }
+    }
+    __syncthreads();
     if (x >= dst.width || y0 >= dst.height) return;
     const ohevc_upsample_tap tc = cols[col_of[x]];
-    const unsigned char *sbase = static_cast<const unsigned char *>(src.data);
     int cx[TAPS], ch[TAPS];                                    // clamped source columns and this column's horizontal taps
 #pragma unroll
     for (int k = 0; k < TAPS; k++) {
@@ -46,12 +67,19 @@ __global__ __launch_bounds__(256) void upsample_kernel(ohevc_plane dst, ohevc_pl
         cx[k] = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
         ch[k] = TAPS == 8 ? (int)kUpLuma[tc.phase][k] : (int)kUpChroma[tc.phase][k];
     }
+    const int lc = tc.pos - HALF - cmin;                       // this column's first tap inside the staged window
     auto hfilt = [&](int row) {                                 // horizontal pass of one base-layer row (clamped), as int16
-        const int ry = row < 0 ? 0 : row > src_rows - 1 ? src_rows - 1 : row;
-        const Pixel *p = reinterpret_cast<const Pixel *>(sbase + (size_t)ry * src.stride);
         int h = 0;
+        if (staged && row >= rmin && row <= rmax && lc >= 0 && lc + TAPS <= UP_WC) {
+            const Pixel *p = &win_lds[row - rmin][lc];
 #pragma unroll
-        for (int k = 0; k < TAPS; k++) h += ch[k] * (int)p[cx[k]];
+            for (int k = 0; k < TAPS; k++) h += ch[k] * (int)p[k];
+        } else {
+            const int ry = row < 0 ? 0 : row > src_rows - 1 ? src_rows - 1 : row;
+            const Pixel *p = reinterpret_cast<const Pixel *>(sbase + (size_t)ry * src.stride);
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) h += ch[k] * (int)p[cx[k]];
+        }
         return (int)(short)h;                                   // the reference keeps this pass in int16: it wraps above 8 bit
     };
     int win[TAPS], base = 0x40000000;                           // win[k] = hfilt(base + k); no window yet
