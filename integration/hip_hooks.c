@@ -35,6 +35,7 @@
 /* one context per decoding thread, all sharing the root's picture store (ohevc_ctx_create_shared): frame threads
  * (pthread_frame.c) reconstruct different pictures concurrently and predict from each other's */
 static ohevc_ctx          *g_root;
+static volatile int        g_generation = 1;
 static int                 g_device;
 static __thread ohevc_ctx *t_ctx;
 static __thread int        t_frame_open;
@@ -306,13 +307,22 @@ void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts)
         /* looked up every time (once per CTB): a host buffer address names a different picture -- and, with frame + slice
          * threads, a different context -- every time the decoder's pool recycles it */
         const uint8_t *d0 = s->ref->frame->data[0];
+        static __thread const uint8_t *seen_d0;       /* the last answer of this thread: asked once per CTB, and with frame x slice threads */
+        static __thread int seen_poc, seen_seq;       /* 64 threads would queue on the lock for it */
+        static __thread ohevc_ctx *seen_ctx;
+        static __thread int seen_gen;                 /* contexts die with their decoder: g_generation changes at every open / close */
         ohevc_ctx *ctx = NULL;
         int i;
-        pthread_mutex_lock(&g_lock);
-        for (i = 0; i < g_nbufs; i++)
-            if (g_bufs[i].data0 == d0)
-                ctx = g_bufs[i].ctx;
-        pthread_mutex_unlock(&g_lock);
+        if (seen_gen == g_generation && seen_d0 == d0 && seen_poc == s->ref->poc && seen_seq == s->ref->sequence && seen_ctx) {
+            ctx = seen_ctx;
+        } else {
+            pthread_mutex_lock(&g_lock);
+            for (i = 0; i < g_nbufs; i++)
+                if (g_bufs[i].data0 == d0)
+                    ctx = g_bufs[i].ctx;
+            pthread_mutex_unlock(&g_lock);
+            seen_d0 = d0; seen_poc = s->ref->poc; seen_seq = s->ref->sequence; seen_ctx = ctx; seen_gen = g_generation;
+        }
         if (ctx && ctx != t_ctx) {            /* a pool thread: it never owns a context, it borrows the picture's */
             if (ohevc_tables_bind(ctx) != OHEVC_OK)
                 g_error = 1;
@@ -451,6 +461,7 @@ int ohdec_backend_open(void)
     g_nbufs = 0;
     g_nall = 0;
     g_error = 0;
+    g_generation++;
     return 0;
 }
 
@@ -681,4 +692,5 @@ void ohdec_backend_close(void)
     }
     g_nbufs = 0;
     t_frame_open = 0;
+    g_generation++;
 }
