@@ -231,6 +231,13 @@ class FrameExchange:
         dev = torch.device("cpu") if not on_device else self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
         return [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes], torch.empty(mvf_bytes, dtype=torch.uint8)
 
+    def _wire(self, planes):
+        """What the collective carries: the staging tensors themselves, or host copies when the planes group cannot take device
+        tensors (gloo: several ranks on one GPU in the tests; RCCL carries device memory directly)."""
+        if self.world > 1 and planes and planes[0].is_cuda and dist.get_backend(self.planes_group) == "gloo":
+            return [torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True) for t in planes]
+        return planes
+
     def _host_planes(self, ctx, slot):
         data, ls = (_C.c_void_p * 3)(), (_C.c_int * 3)()
         if self.lib.ohevc_tables_host_planes(ctx, slot, data, ls) != 0:
@@ -259,8 +266,12 @@ class FrameExchange:
             for t, v in zip(planes, self._host_planes(ctx, slot)):
                 t.copy_(torch.from_numpy(_np.ascontiguousarray(v)).reshape(-1))
         _C.memmove(mvf.data_ptr(), mvf_ptr, mvf_bytes)
-        works, mw = self._post(planes, mvf, self.rank)
-        self.outgoing.append((works + ([mw] if mw is not None else []), planes, mvf))
+        wire = self._wire(planes)
+        if wire is not planes:
+            for w, t in zip(wire, planes):
+                w.copy_(t)
+        works, mw = self._post(wire, mvf, self.rank)
+        self.outgoing.append((works + ([mw] if mw is not None else []), wire, mvf))
         while len(self.outgoing) > self.max_outstanding:
             for w in self.outgoing.pop(0)[0]:
                 w.wait()
@@ -269,21 +280,25 @@ class FrameExchange:
     def _subscribe(self, index, ctx, slot, mvf_bytes):
         on_device, sizes = self._geometry(ctx, slot)
         planes, mvf = self._alloc(on_device, sizes, mvf_bytes)
-        works, mw = self._post(planes, mvf, index % self.world)
-        self.pending[index] = [works, planes, mw, mvf, on_device]
+        wire = self._wire(planes)
+        works, mw = self._post(wire, mvf, index % self.world)
+        self.pending[index] = [works, planes, mw, mvf, on_device, wire]
         self.stats["subscribed"] += 1
 
     def _await_motion(self, index, mvf_ptr, mvf_bytes):
-        works, planes, mw, mvf, on_device = self.pending[index]
+        works, planes, mw, mvf, on_device, wire = self.pending[index]
         if mw is not None:
             mw.wait()
         _C.memmove(mvf_ptr, mvf.data_ptr(), mvf_bytes)
         self.stats["awaited_motion"] += 1
 
     def _await_planes(self, index, ctx, slot):
-        works, planes, mw, mvf, on_device = self.pending[index]
+        works, planes, mw, mvf, on_device, wire = self.pending[index]
         for w in works:
             w.wait()
+        if wire is not planes:
+            for w, t in zip(wire, planes):
+                t.copy_(w)
         if on_device:
             if planes and planes[0].is_cuda:
                 torch.cuda.current_stream().synchronize()          # work.wait() only orders torch's stream behind the collective
@@ -295,6 +310,7 @@ class FrameExchange:
             for t, v in zip(planes, self._host_planes(ctx, slot)):
                 v[...] = t.numpy().reshape(v.shape)
         self.pending[index][1] = []                                # the planes are in the store now; the motion field may still be needed
+        self.pending[index][5] = []
         self.stats["awaited_planes"] += 1
 
     def finish(self):
@@ -303,7 +319,7 @@ class FrameExchange:
             for w in works:
                 w.wait()
         self.outgoing.clear()
-        for works, _, mw, _, _ in self.pending.values():
+        for works, _, mw, *_ in self.pending.values():
             for w in works:
                 w.wait()
             if mw is not None:

@@ -108,6 +108,8 @@ def decoder_worker(rank, world, port, names, q, kind="hip"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     if kind == "hip":
         os.environ["OHHIP_SW_EXEC"] = "1"
+    if kind == "hip_device":        # tests/test_dist_gpu.py: the real device, both ranks on cuda:0, planes host-staged through gloo
+        kind = "hip"
     D.init_from_env("gloo")
     from oracle import pystream as ps
     from test_stream_cpu import frames_md5, load_golden
