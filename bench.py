@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--frames-size", default="3840x2160", help="--mode frames: picture size WxH")
     ap.add_argument("--frames-bit-depth", type=int, default=10)
     ap.add_argument("--frames-pictures", type=int, default=17)
+    ap.add_argument("--frames-one-gpu", action="store_true",
+                    help="--mode frames: every rank uses GPU 0 and the planes travel host-staged through gloo (what the slice-data division "
+                         "buys without more GPUs; RCCL needs one GPU per rank)")
     return ap.parse_args()
 
 
@@ -117,8 +120,8 @@ def frames_mode(args):
     import torch.distributed as dist
     from openhevc_amd import dist as D
     from oracle import pystream as ps
-    rank, world = D.init_from_env()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world = D.init_from_env("gloo" if args.frames_one_gpu else None)
+    local_rank = 0 if args.frames_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = torch.cuda.is_available()
     if on_gpu:
         torch.cuda.set_device(local_rank)
@@ -162,7 +165,7 @@ def frames_mode(args):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu and not args.frames_one_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -174,7 +177,7 @@ def frames_mode(args):
             "dtype": "u%d pixels, int16 coefficients" % (16 if args.frames_bit_depth > 8 else 8), "data": "synthetic Annex-B stream (oracle/pystream.py, seed 4242)",
             "config": {"workload": f"{W}x{H} {args.frames_bit_depth}-bit random-access stream, {npics} pictures per step, reference front end on the host "
                                    f"cores + HIP back end, pictures owned round-robin by decoding order", "parallelism": f"frame-parallel over {world} process(es)",
-                       "exchange": stats},
+                       "exchange": stats, "one_gpu": bool(args.frames_one_gpu)},
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()
