@@ -308,6 +308,7 @@ class StreamParams:
     log2_max_ts: int = 2         # PPS range extension: log2_max_transform_skip_block_size (rext + transform_skip)
     sao_offset_scale: Tuple[int, int] = (0, 0)   # PPS range extension: log2_sao_offset_scale_{luma,chroma} <= bit_depth - 10
     rext: int = 0                # range-extension SPS flags (implicit/explicit rdpcm, ts rotation/context, rice adaptation)
+    nonref_leaves: int = 0       # random_access: pictures nothing references are coded as sub-layer non-reference pictures (TRAIL_N)
     intra_smoothing_disabled: int = 0   # SPS range extension: no [1 2 1] / strong filtering of the intra reference samples (rext only)
     gop: str = "lowdelay_b"      # intra | lowdelay_p | lowdelay_b | random_access
     gop_size: int = 8
@@ -578,7 +579,11 @@ def plan_gop(p: StreamParams) -> List[Pic]:
         two_sided = any(q > poc for q in cur)
         st = SLICE_B if (two_sided or poc % 2 == 0) else SLICE_P
         k = max(1, min(2, len(cur)))
-        pics.append(Pic(poc, NAL_TRAIL_R, st, neg, pos, (k, k if st == SLICE_B else 0)))
+        later_refs = set()
+        for q in order[i + 1:]:
+            later_refs.update(refs[q])
+        nt = NAL_TRAIL_N if p.nonref_leaves and poc not in later_refs else NAL_TRAIL_R
+        pics.append(Pic(poc, nt, st, neg, pos, (k, k if st == SLICE_B else 0)))
     return pics
 
 

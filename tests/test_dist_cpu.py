@@ -152,7 +152,7 @@ def test_decoder_frame_parallel_over_processes(world, kind):
     from oracle import pystream as ps
     if not (ps.have(kind) and os.path.exists(os.path.join(os.path.dirname(ps.__file__), "libohsw.so"))):
         pytest.skip("GPU-backed decoder / software executor / emulator build not present (needs the reference tree once)")
-    names = ["ra_8b_ctb64", "ldb_10b", "weighted", "ra_10b_odd", "intra_8b", "slices", "tiles", "cip", "fmt444_8b"]
+    names = ["ra_8b_ctb64", "ldb_10b", "weighted", "ra_10b_odd", "intra_8b", "slices", "tiles", "cip", "fmt444_8b", "ra_8b_nonref_leaves"]
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -178,5 +178,7 @@ def test_decoder_frame_parallel_over_processes(world, kind):
         got = [d for p in range(npics) for d in merged[p]]
         assert got == want, f"{name}: pictures differ from the single-process decoder"
         assert per_pic == 3
+        if name == "ra_8b_nonref_leaves":           # the four leaves of the GOP are nobody's reference: not exchanged
+            assert sum(res[r][name][2]["published"] for r in range(world)) == npics - 4, res[0][name][2]
         if npics > 2 and name != "intra_8b":
             assert sum(res[r][name][2]["awaited_planes"] for r in range(world)) > 0, f"{name}: no reference picture ever crossed processes"
