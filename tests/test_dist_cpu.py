@@ -153,6 +153,8 @@ def test_decoder_frame_parallel_over_processes(world, kind):
     if not (ps.have(kind) and os.path.exists(os.path.join(os.path.dirname(ps.__file__), "libohsw.so"))):
         pytest.skip("GPU-backed decoder / software executor / emulator build not present (needs the reference tree once)")
     names = ["ra_8b_ctb64", "ldb_10b", "weighted", "ra_10b_odd", "intra_8b", "slices", "tiles", "cip", "fmt444_8b", "ra_8b_nonref_leaves"]
+    if kind == "hipemu":                # the emulated device code is slow: the streams that exercise export / import, skipping and reordering
+        names = ["ra_10b_odd", "weighted", "tiles", "ra_8b_nonref_leaves"]
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

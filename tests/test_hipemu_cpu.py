@@ -77,12 +77,19 @@ def test_emu_golden_stream(name, executor, monkeypatch):
     ps = _stream_lib()
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    # CPU-suite time: the emulator is ~1000x slower than the device, which runs every stream in every executor (tests/test_stream_gpu.py)
+    often = ("intra_8b", "intra_10b_ctb16", "ldb_8b", "ra_10b_odd", "cip", "tiles", "slices_dep_wpp", "rext", "small_blocks", "weighted",
+             "fmt422_8b", "fmt444_8b", "fmt444_14b_cip_cross", "cross_444_8b", "pcm", "tqb")
+    levels_too = ("ra_8b_ctb64", "weighted_p_10b", "pcm_10b", "wpp", "tiles_nolf", "slices_nolf", "dense_residual", "ra_14b_weighted", "ra_8b_nonref_leaves",
+                  "rext_12b_sao_scale", "pcm_nolf_ctb16", "tqb_rext_422")
+    if name not in often and not (executor == "0" and name in levels_too):
+        pytest.skip("runs on the device only (CPU-suite time)")
     monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", executor)
     aus, md5 = load_golden(name)
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 
 
-@pytest.mark.parametrize("name", ["pcm", "tiles_nolf", "slices_nolf", "fmt422_8b", "ra_8b_ctb64", "ra_14b_weighted"])
+@pytest.mark.parametrize("name", ["pcm", "tiles_nolf", "slices_nolf", "ra_14b_weighted"])
 def test_emu_golden_stream_filters_derived_on_the_host(name, monkeypatch):
     """The job form of the deblocking (filters_host.hip, one record per edge) next to the default (maps, derived on the device)."""
     from test_stream_cpu import frames_md5, load_golden
@@ -94,7 +101,7 @@ def test_emu_golden_stream_filters_derived_on_the_host(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 
 
-@pytest.mark.parametrize("name", _golden_names())
+@pytest.mark.parametrize("name", ["intra_8b", "intra_10b_ctb16", "ra_10b_odd", "cip", "tiles", "small_blocks", "fmt422_8b", "fmt444_14b_cip_cross"])
 def test_emu_golden_stream_levels_in_reverse_order(name, monkeypatch):
     """The emulator runs the workgroups of a launch one after the other, in decoding order inside a dependency level - an order that hides a
     dependency the level computation missed (the device runs them concurrently).  OHEVC_REVERSE_LEVELS submits every level back to front."""
@@ -108,7 +115,7 @@ def test_emu_golden_stream_levels_in_reverse_order(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 
 
-@pytest.mark.parametrize("name", ["ra_8b_ctb64", "ldb_10b", "pcm", "intra_8b"])
+@pytest.mark.parametrize("name", ["ra_10b_odd", "ldb_10b", "pcm", "intra_8b"])
 def test_emu_golden_stream_pipelined_output(name, monkeypatch):
     """One decoding thread, the frame-end hook only issues the device work (OHHIP_DEFER_DOWNLOAD) and the application takes every picture
     one call late (decoder_harness.c: ohdec_set_pipelined): the device reconstructs picture k while the CPU parses picture k + 1."""
@@ -122,9 +129,9 @@ def test_emu_golden_stream_pipelined_output(name, monkeypatch):
 
 
 @pytest.mark.parametrize("threads,thread_type,names", [
-    (4, 1, ["ra_8b_ctb64", "ldb_10b", "weighted", "fmt444_8b"]),          # frame threads
+    (4, 1, ["ra_10b_odd", "ldb_10b", "weighted", "fmt444_8b"]),           # frame threads
     (4, 2, ["wpp", "tiles", "slices_dep_wpp"]),                            # slice threads
-    (4, 3, ["wpp", "ra_8b_ctb64"]),                                        # both
+    (4, 3, ["wpp", "ra_10b_odd"]),                                            # both
 ])
 def test_emu_golden_stream_thread_modes(threads, thread_type, names):
     from test_stream_cpu import frames_md5, load_golden
@@ -144,9 +151,9 @@ def test_emu_golden_streams_with_kernel_variants():
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
     lib = ctypes.CDLL(G.emulator_path())
-    prev = lib.ohevc_debug_set_sao_variant(1)
+    prev = lib.ohevc_debug_set_sao_variant(3)             # the LDS-window SAO kernel (bit 1) with its interior / ring split (bit 0)
     try:
-        for name in ["ra_8b_ctb64", "ldb_10b", "tiles", "slices", "tqb", "pcm_nolf_ctb16", "rext_12b_sao_scale", "fmt444_8b", "fmt422_8b"]:
+        for name in ["ra_10b_odd", "tiles", "tqb", "pcm_nolf_ctb16", "rext_12b_sao_scale"]:
             aus, md5 = load_golden(name)
             assert frames_md5(ps.decode_stream("hipemu", aus)) == md5, name
     finally:
@@ -161,9 +168,9 @@ def test_emu_fuzzed_streams():
     if _stream_lib() is None or not (ps.have("gen") and ps.have("c")):
         pytest.skip("generator / reference decoder / emulated decoder libraries not present")
     root = os.path.dirname(HERE)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "20", "991"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_streams.py"), "10", "991"], capture_output=True, text=True,
                        timeout=600, env=dict(os.environ, FUZZ_BACKEND="hipemu"))
     lines = r.stdout.strip().splitlines()
     assert lines, r.stderr[-2000:]
     res = json.loads(lines[-1])
-    assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 2, r.stdout[-3000:]
+    assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 1, r.stdout[-3000:]

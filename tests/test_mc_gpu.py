@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 PAD = 80
 
 
-@pytest.fixture(params=[5, 3], ids=["matrix_cores", "lds_tiles"], autouse=True)
+@pytest.fixture(params=[5, 3], ids=["matrix_cores", "lds_tiles"])
 def mc_variant(request):
     """Both forms of the motion-compensation kernel (include/ohevc_debug.h): mc4 (v_mfma_i32_16x16x32_i8, no LDS tiles; variant 5 uses it
     for the small-block entry point too - the shipped variant 4 keeps mc3 there) / mc3 (LDS tiles)."""
@@ -52,7 +52,7 @@ def sprinkle_wild(rng, planes, bd):
 
 
 @pytest.mark.parametrize("bd,wild", [(8, 0), (10, 0), (12, 0), (14, 0), (9, 1), (10, 1), (12, 1), (14, 1)])
-def test_mc_all_variants_and_edges(oracle, bd, wild):
+def test_mc_all_variants_and_edges(oracle, mc_variant, bd, wild):
     rng = np.random.default_rng(500 + bd + 50 * wild)
     W, H = 208, 144                                   # luma; chroma planes are half size (4:2:0)
     dims = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
@@ -107,7 +107,7 @@ def test_mc_all_variants_and_edges(oracle, bd, wild):
 
 
 @pytest.mark.parametrize("bd,wild", [(8, 0), (10, 0), (10, 1)])
-def test_mc_small_blocks_four_per_wave(oracle, bd, wild):
+def test_mc_small_blocks_four_per_wave(oracle, mc_variant, bd, wild):
     """ohevc_dev_mc_batch_small: jobs of at most 8x8 samples, four per wavefront, incl. counts that are not multiples of 4."""
     rng = np.random.default_rng(600 + bd + 50 * wild)
     W, H = 208, 144

@@ -42,11 +42,14 @@ LAB_FORMS = [512 + 128, 512 + 128 + 1024, 2048 + 4096 + 144, 2048 + 16384 + 144]
 
 
 @pytest.mark.parametrize("variant", PRODUCT_FORMS + LAB_FORMS)
-@pytest.mark.parametrize("bd", [8, 10, 12, 14])
+@pytest.mark.parametrize("bd", [8, 10, 14])
 def test_idct_add_epilogue_forms_bit_exact(oracle, bd, variant):
     """The A/B forms of the 16x16 / 32x32 kernel (ohevc_debug.h): wave-private 64-sample strips (16), workgroup-wide 256-sample strips
     (512), non-temporal coefficient loads (1024) -- same pictures, including ragged tails (block counts that leave waves idle) and
     blocks that are not horizontal neighbours."""
+    import gpu_util as _G
+    if _G.emulating() and bd != 8 and variant in LAB_FORMS:
+        pytest.skip("the lab forms run through the emulator at 8 bit only (CPU-suite time); the device runs all of them")
     from openhevc_amd import lib as L
     lib = L.load_library()
     if variant in LAB_FORMS and not lib.ohevc_debug_has_lab():
