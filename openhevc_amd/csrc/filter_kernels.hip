@@ -439,15 +439,36 @@ __device__ __forceinline__ int sao_sign(int d)
 #endif
 }
 
+// the same for two 16-bit lanes (left to the compiler, the two clamps become four compares and four selects)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 sao_sign2(s16x2 d)
+{
+#ifdef OHEVC_HIPEMU
+    return s16x2{ (short)(d.x < -1 ? -1 : d.x > 1 ? 1 : d.x), (short)(d.y < -1 ? -1 : d.y > 1 ? 1 : d.y) };
+#else
+    unsigned r;
+    asm("v_pk_min_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, %3" : "=&v"(r) : "v"(__builtin_bit_cast(unsigned, d)), "s"(0x00010001u), "s"(0xffffffffu));
+    return __builtin_bit_cast(s16x2, r);
+#endif
+}
+
 // The position rules of one 16-byte row piece as byte masks: bord = samples that take offset_val[0] (picture borders), keep = samples that
 // keep the deblocked value (restored slice / tile edges, bypassed PUs).  Out of line: its two dozen wave-uniform flags would otherwise
 // crowd the scalar registers of the path every lane runs (measured: 850 SGPR spill moves in the kernel).
 struct SaoMasks { u32x4 keep, bord; };
 template <typename Pixel>
-__device__ __attribute__((noinline)) SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao_bypass bp, int x0, int y)
+__device__ __forceinline__ SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao_bypass bp, int x0, int y)
 {
     constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);
     constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
+#ifndef OHEVC_HIPEMU
+    // The job record and the bypass description are wave-uniform; passed through vector registers here, the two dozen flags derived from
+    // them live in vector registers too.  As scalars they crowded the registers of the path every lane runs (850 spill moves when this
+    // was part of the row loop), and as an out-of-line call the function gave the kernel a stack - scratch memory per wave at launch.
+    asm volatile("" : "+v"(j0.x), "+v"(j0.y), "+v"(j0.z), "+v"(j0.w), "+v"(j1.x), "+v"(j1.y), "+v"(j1.z), "+v"(j1.w));
+    asm volatile("" : "+v"(bp.stride), "+v"(bp.log2_min_pu_size), "+v"(bp.chroma_hshift), "+v"(bp.chroma_vshift), "+v"(bp.exact_reference));
+#endif
     ohevc_sao_job jb;
     const unsigned words[8] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w };
     __builtin_memcpy(&jb, words, sizeof(jb));
@@ -491,7 +512,8 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
 {
     constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);     // samples per lane / dword
     constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
-    const u32x4 j0 = reinterpret_cast<const u32x4 *>(jobs + blockIdx.x)[0], j1 = reinterpret_cast<const u32x4 *>(jobs + blockIdx.x)[1];
+    typedef const OHEVC_CONST_AS u32x4 *cptr;
+    const u32x4 j0 = ((cptr)(jobs + blockIdx.x))[0], j1 = ((cptr)(jobs + blockIdx.x))[1];
     ohevc_sao_job jb;
     {
         const unsigned words[8] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w };
@@ -509,63 +531,66 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
     const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = 256 >> lp;      // a power of two (sao_wide_ok)
     const int piece = threadIdx.x & (pieces - 1), row0 = threadIdx.x >> lp, x0 = piece * PPL;
     const int dxa = eo == 1 ? 0 : eo == 3 ? 1 : -1, dya = eo == 0 ? 0 : -1;       // first neighbour; the second is its mirror
-    // class -> offset table for v_perm_b32: byte k of (tab_lo, tab_hi) = offset of class k.  Edge: k = sign + sign + 2 -> offset_val[{1,2,0,3,4}]
-    // (edge_idx, hevcdsp_template.c:372-378); band: k = band index 0..3 -> offset_val[k + 1], 4 = outside the four bands.
+    // class -> offset table for v_perm_b32: byte k of (tab_lo, tab_hi) = 128 + offset of class k.  Edge: k = sign + sign + 2 ->
+    // offset_val[{1,2,0,3,4}] (edge_idx, hevcdsp_template.c:372-378); band: k = band index 0..3 -> offset_val[k + 1], 4 = outside the four bands.
     const int ov0 = jb.offset_val[0];
     const int t0 = jb.offset_val[1], t1 = jb.offset_val[2], t2 = is_band ? jb.offset_val[3] : ov0, t3 = is_band ? jb.offset_val[4] : jb.offset_val[3], t4 = is_band ? 0 : jb.offset_val[4];
-    const unsigned tab_lo = (unsigned)(t0 & 0xff) | ((unsigned)(t1 & 0xff) << 8) | ((unsigned)(t2 & 0xff) << 16) | ((unsigned)(t3 & 0xff) << 24), tab_hi = (unsigned)(t4 & 0xff);
+    const unsigned tab_lo = ((unsigned)(t0 + 128) & 0xff) | (((unsigned)(t1 + 128) & 0xff) << 8) | (((unsigned)(t2 + 128) & 0xff) << 16) | (((unsigned)(t3 + 128) & 0xff) << 24);
+    const unsigned tab_hi = (unsigned)(t4 + 128) & 0xff;
     const int shift = bit_depth - 5, band_pos = jb.klass;
     const bool rules = !is_band && (jb.borders != 0 || jb.restore != 0);
-    auto finish = [&](int c, int cls) {               // class -> offset (one v_perm_b32), add, clip
-        const int off = (int)(signed char)__builtin_amdgcn_perm(tab_hi, tab_lo, (unsigned)cls | 0x0c0c0c00u);
-        const int v = c + off;
-        return (unsigned)(v < 0 ? 0 : v > maxv ? maxv : v);
+    // The arithmetic runs on pairs of 16-bit lanes (v_pk_*_i16 / _u16; 8-bit samples are widened with v_perm_b32 first): the kernel's VALU
+    // work, not its memory traffic, was what kept the SIMDs busy (profiles/r02s4_sq_counters_sao_wide.txt: VALU active 70 % of the launch).
+    const u16x2 maxv2 = { (unsigned short)maxv, (unsigned short)maxv };
+    auto finish2 = [&](unsigned c, s16x2 cls) {       // two samples: class -> 128 + offset (one v_perm_b32 for both), add, clip
+        const unsigned offb = __builtin_amdgcn_perm(tab_hi, tab_lo, __builtin_bit_cast(unsigned, cls) | 0x0c000c00u);
+        u16x2 t = __builtin_bit_cast(u16x2, c) + __builtin_bit_cast(u16x2, offb);
+        t = __builtin_elementwise_sub_sat(t, u16x2{ 128, 128 });
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_min(t, maxv2));
     };
+    auto edge2 = [&](unsigned c, unsigned a, unsigned b) {
+        const s16x2 cc = __builtin_bit_cast(s16x2, c);
+        const s16x2 s1 = sao_sign2(cc - __builtin_bit_cast(s16x2, a)), s2 = sao_sign2(cc - __builtin_bit_cast(s16x2, b));
+        return finish2(c, s1 + s2 + s16x2{ 2, 2 });
+    };
+    auto band2 = [&](unsigned c) {
+        const u16x2 k = ((__builtin_bit_cast(u16x2, c) >> (unsigned short)shift) - u16x2{ (unsigned short)band_pos, (unsigned short)band_pos }) & u16x2{ 31, 31 };
+        return finish2(c, __builtin_bit_cast(s16x2, __builtin_elementwise_min(k, u16x2{ 4, 4 })));
+    };
+    // 8-bit samples: bytes 0, 1 / 2, 3 of a dword as two 16-bit lanes, and back
+    auto lo2 = [](unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c010c00u); };
+    auto hi2 = [](unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c030c02u); };
+    auto pack4 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); };
     for (int y = row0; y < h; y += rows_per_pass) {
         unsigned cv[4], ov_[4];
         __builtin_memcpy(cv, sbase + ((unsigned)y * (unsigned)sstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), 16);
         if (is_band) {
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                unsigned acc = 0;
-#pragma unroll
-                for (int k = 0; k < SPD; k++) {
-                    const int c = (int)((cv[d] >> (SB * k)) & M);
-                    const int kk = ((c >> shift) - band_pos) & 31;
-                    acc |= finish(c, kk < 4 ? kk : 4) << (SB * k);
-                }
-                ov_[d] = acc;
-            }
+            for (int d = 0; d < 4; d++)
+                ov_[d] = sizeof(Pixel) == 2 ? band2(cv[d]) : pack4(band2(lo2(cv[d])), band2(hi2(cv[d])));
         } else {
-            // the two neighbours of every sample: 16 bytes one sample to the left / right of the piece, in the row above / below (clamped to
-            // the plane: what lies beyond only reaches samples that take offset_val[0])
+            // the two neighbours of every sample: 16 bytes one sample to the left / right of the piece, in the row above / below, clamped to
+            // the plane (what lies beyond only reaches samples that take offset_val[0]).  Both loads are unconditional and issued together
+            // with the piece's own; a piece that touches the picture's left / right edge loaded itself and is shifted by one sample afterwards
+            // (with the loads inside the branches of that case the compiler serialised them: three memory round trips per row instead of one)
             unsigned av[4], bv[4];
             auto fetch = [&](int dx, int dy, unsigned *o) {
                 int yy = jb.y + y + dy;
                 yy = yy < 0 ? 0 : yy > ph - 1 ? ph - 1 : yy;
-                const unsigned char *rowp = splane + (unsigned)yy * (unsigned)sstride;
-                const int xs = jb.x + x0 + dx;
-                if (xs >= 0 && xs + PPL <= pw) {
-                    __builtin_memcpy(o, rowp + (unsigned)xs * (unsigned)sizeof(Pixel), 16);
-                } else {                                 // picture edge: the piece itself shifted by one sample, the outermost one repeated
-                    unsigned t[4];
-                    __builtin_memcpy(t, rowp + (unsigned)(jb.x + x0) * (unsigned)sizeof(Pixel), 16);
-                    if (dx < 0) { o[3] = (t[3] << SB) | (t[2] >> (32 - SB)); o[2] = (t[2] << SB) | (t[1] >> (32 - SB)); o[1] = (t[1] << SB) | (t[0] >> (32 - SB)); o[0] = (t[0] << SB) | (t[0] & M); }
-                    else        { o[0] = (t[0] >> SB) | (t[1] << (32 - SB)); o[1] = (t[1] >> SB) | (t[2] << (32 - SB)); o[2] = (t[2] >> SB) | (t[3] << (32 - SB)); o[3] = (t[3] >> SB) | (t[3] & ~(0xffffffffu >> SB)); }
-                }
+                const int xs = jb.x + x0 + dx, xc = xs < 0 ? 0 : xs + PPL > pw ? pw - PPL : xs;
+                __builtin_memcpy(o, splane + ((unsigned)yy * (unsigned)sstride + (unsigned)xc * (unsigned)sizeof(Pixel)), 16);
+                return xs - xc;                          // -1 / +1 at the left / right picture edge
             };
-            fetch(dxa, dya, av);
-            fetch(-dxa, -dya, bv);
+            auto shift = [&](unsigned *o, int e) {       // the outermost sample repeated
+                if (e < 0) { o[3] = (o[3] << SB) | (o[2] >> (32 - SB)); o[2] = (o[2] << SB) | (o[1] >> (32 - SB)); o[1] = (o[1] << SB) | (o[0] >> (32 - SB)); o[0] = (o[0] << SB) | (o[0] & M); }
+                if (e > 0) { o[0] = (o[0] >> SB) | (o[1] << (32 - SB)); o[1] = (o[1] >> SB) | (o[2] << (32 - SB)); o[2] = (o[2] >> SB) | (o[3] << (32 - SB)); o[3] = (o[3] >> SB) | (o[3] & ~(0xffffffffu >> SB)); }
+            };
+            const int ea = fetch(dxa, dya, av), eb = fetch(-dxa, -dya, bv);
+            if ((ea | eb) != 0) { shift(av, ea); shift(bv, eb); }
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                unsigned acc = 0;
-#pragma unroll
-                for (int k = 0; k < SPD; k++) {
-                    const int c = (int)((cv[d] >> (SB * k)) & M), a = (int)((av[d] >> (SB * k)) & M), b = (int)((bv[d] >> (SB * k)) & M);
-                    acc |= finish(c, sao_sign(c - a) + sao_sign(c - b) + 2) << (SB * k);
-                }
-                ov_[d] = acc;
-            }
+            for (int d = 0; d < 4; d++)
+                ov_[d] = sizeof(Pixel) == 2 ? edge2(cv[d], av[d], bv[d])
+                                            : pack4(edge2(lo2(cv[d]), lo2(av[d]), lo2(bv[d])), edge2(hi2(cv[d]), hi2(av[d]), hi2(bv[d])));
         }
         // position rules: only where a lane can hold such a sample (first / last piece of a row, rows 0, h - 2, h - 1), or with a bypass map
         if ((rules && (y == 0 || y >= h - 2 || piece == 0 || piece == pieces - 1)) || bp.map != nullptr) {

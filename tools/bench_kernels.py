@@ -221,7 +221,7 @@ def main():
             j["offset_val"] = [0, 3, 1, -1, -3]
             d_jobs = dev(j)
             # every block here is 64 x 64 and aligned: what the ctx layer does with such a picture (jobs sorted, one kernel)
-            run_sao = (lambda pic, ex: L.dev_sao_batch_sorted(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, 0, st())) if not SAO_VARIANT else \
+            run_sao = (lambda pic, ex: L.dev_sao_batch_sorted(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, 0, st())) if not ((SAO_VARIANT or 0) & 3) else \
                       (lambda pic, ex: L.dev_sao_batch(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, st()))
             ms = timeit(run_sao, lambda: rand_pic(bd, g),
                         name="sao", ring_of=RingExtra(lambda k: rand_pic(bd, g), pic_bytes(src)))
