@@ -9,6 +9,7 @@
 // SAO replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp_template.c:340-567): reads the deblocked copy
 // (the reference's sao_frame, hevc_filter.c:269-315), writes the picture; one workgroup per CTB plane block.
 #include "common.hpp"
+#include <type_traits>
 
 namespace ohevc {
 
@@ -17,30 +18,83 @@ __device__ __forceinline__ int iclip(int v, int lo, int hi) { return v < lo ? lo
 
 // One line of one 8-sample edge: lane `line` (0..7) of an 8-lane group; every exit is taken by whole 4-line segments.
 // beta_in / tc_in before bit-depth scaling, tc_in of this lane's segment.
+// The samples of one line across an edge, loaded before the filter's parameters are known (deblock_maps_kernel derives those through
+// several dependent byte loads; the sample loads have to be in flight meanwhile, not behind them).
 template <typename Pixel>
-__device__ __forceinline__ void deblock_line(unsigned char *plane_base, int stride, int jx, int jy, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth, int l0, int l3)
-{      // l0, l3: the lanes of the wavefront that hold lines 0 and 3 of this line's 4-line segment.  (The plane's base and pitch arrive resolved: picked
-       // from the PlaneSet behind a reference, the selection becomes a load from a scratch copy of the kernel arguments.)
-    const int seg = line >> 2;
-    const bool vertical = flags & OHEVC_DBK_VERTICAL_EDGE;
-    const bool no_p = flags & (seg ? OHEVC_DBK_NO_P1 : OHEVC_DBK_NO_P0);
-    const bool no_q = flags & (seg ? OHEVC_DBK_NO_Q1 : OHEVC_DBK_NO_Q0);
-    const int xs = vertical ? (int)sizeof(Pixel) : stride;      // step across the edge
+struct DbkLine {
+    unsigned char *pix;     // sample q0 of the line
+    int xs;                 // step across the edge, bytes
+    bool vec;               // the 8 samples are one vector load / store
+    int v[8];               // p3 p2 p1 p0 q0 q1 q2 q3, luma loaded sample by sample
+    int c[4];               // p1 p0 q0 q1, chroma.  (Own registers per form: forms that share result registers wait for each other's loads.)
+    u32x4 raw;              // luma, vec: the packed samples (unpacked by deblock_filter: touching the data here would put the wait for it here)
+};
+
+// FORM: which of the three load / store forms a line takes - 0 luma sample by sample, 1 luma with one vector access, 2 chroma; -1 decided per
+// lane (deblock_kernel: any mix of jobs in a wavefront).  deblock_maps_kernel knows the form per WAVEFRONT and instantiates its tail once per
+// form: inside one instance the forms would share result registers, and every form's loads would wait for the others'.
+enum { DBK_FORM_ANY = -1, DBK_FORM_SAMPLES = 0, DBK_FORM_VECTOR = 1, DBK_FORM_CHROMA = 2 };
+template <typename Pixel, int FORM = DBK_FORM_ANY>
+__device__ __forceinline__ DbkLine<Pixel> deblock_load(unsigned char *plane_base, int stride, int jx, int jy, int jplane, bool vertical, int line)
+{      // (The plane's base and pitch arrive resolved: picked from the PlaneSet behind a reference, the selection becomes a load from a scratch
+       // copy of the kernel arguments.)
+    DbkLine<Pixel> s;
+    s.xs = vertical ? (int)sizeof(Pixel) : stride;
     const int ys = vertical ? stride : (int)sizeof(Pixel);      // step along the edge
-    unsigned char *pix = plane_base + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
-    const int maxv = (1 << bit_depth) - 1;
-#define LD(i) ((int)*reinterpret_cast<const Pixel *>(pix + (ptrdiff_t)(i) * xs))
+    s.pix = plane_base + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
     // Vertical luma edges: the 8 samples across the edge are 8 / 16 contiguous bytes of one row - one vector load, one vector store
     // (samples -4 and +3 are written back unchanged: no other edge of the vertical pass writes within 4 samples of this one).
     // Horizontal edges and chroma go sample by sample (along a horizontal edge the lanes of a job are neighbours in memory anyway).
-    const bool vec = vertical && jplane == 0 && ((reinterpret_cast<uintptr_t>(pix) - 4 * sizeof(Pixel)) & 3) == 0;
-    int vv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    s.vec = FORM >= 0 ? FORM == DBK_FORM_VECTOR : vertical && jplane == 0 && ((reinterpret_cast<uintptr_t>(s.pix) - 4 * sizeof(Pixel)) & 3) == 0;
+#define LD(i) ((int)*reinterpret_cast<const Pixel *>(s.pix + (ptrdiff_t)(i) * s.xs))
+#pragma unroll
+    for (int k = 0; k < 8; k++) s.v[k] = 0;
+    s.raw = u32x4{ 0, 0, 0, 0 };
+    s.c[0] = s.c[1] = s.c[2] = s.c[3] = 0;
+    if (FORM >= 0 ? FORM == DBK_FORM_CHROMA : jplane != 0) {
+        s.c[0] = LD(-2); s.c[1] = LD(-1); s.c[2] = LD(0); s.c[3] = LD(1);
+    } else if (s.vec) {
+        if (sizeof(Pixel) == 1) {
+            const u32x2 raw = *reinterpret_cast<const u32x2 *>(s.pix - 4);
+            s.raw.x = raw.x; s.raw.y = raw.y;
+        } else {
+            s.raw = *reinterpret_cast<const u32x4 *>(s.pix - 8);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.v[k] = LD(k - 4);
+    }
+#undef LD
+    return s;
+}
+
+template <typename Pixel, int FORM = DBK_FORM_ANY>
+__device__ __forceinline__ void deblock_filter(const DbkLine<Pixel> &s, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth, int l0, int l3)
+{      // l0, l3: the lanes of the wavefront that hold lines 0 and 3 of this line's 4-line segment
+    const int seg = line >> 2;
+    const bool no_p = flags & (seg ? OHEVC_DBK_NO_P1 : OHEVC_DBK_NO_P0);
+    const bool no_q = flags & (seg ? OHEVC_DBK_NO_Q1 : OHEVC_DBK_NO_Q0);
+    unsigned char *const pix = s.pix;
+    const int xs = s.xs, maxv = (1 << bit_depth) - 1;
+    const bool vec = FORM >= 0 ? FORM == DBK_FORM_VECTOR : s.vec;
+    int vv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) vv[k] = s.v[k];
+    if (vec) {
+        if (sizeof(Pixel) == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { vv[k] = (s.raw.x >> (8 * k)) & 0xff; vv[4 + k] = (s.raw.y >> (8 * k)) & 0xff; }
+        } else {
+            vv[0] = s.raw.x & 0xffff; vv[1] = s.raw.x >> 16; vv[2] = s.raw.y & 0xffff; vv[3] = s.raw.y >> 16;
+            vv[4] = s.raw.z & 0xffff; vv[5] = s.raw.z >> 16; vv[6] = s.raw.w & 0xffff; vv[7] = s.raw.w >> 16;
+        }
+    }
     bool dirty = false;
 #define ST(i, v) do { if (vec) { vv[(i) + 4] = (v); dirty = true; } else *reinterpret_cast<Pixel *>(pix + (ptrdiff_t)(i) * xs) = (Pixel)(v); } while (0)
     const int tc = tc_in << (bit_depth - 8);
-    if (jplane != 0) {                                // hevc_loop_filter_chroma, :1725-1757
+    if (FORM >= 0 ? FORM == DBK_FORM_CHROMA : jplane != 0) {                                // hevc_loop_filter_chroma, :1725-1757
         if (tc <= 0) return;
-        const int p1 = LD(-2), p0 = LD(-1), q0 = LD(0), q1 = LD(1);
+        const int p1 = s.c[0], p0 = s.c[1], q0 = s.c[2], q1 = s.c[3];
         const int delta = iclip((((q0 - p0) * 4) + p1 - q1 + 4) >> 3, -tc, tc);
         if (!no_p) ST(-1, iclip(p0 + delta, 0, maxv));
         if (!no_q) ST(0, iclip(q0 - delta, 0, maxv));
@@ -48,19 +102,7 @@ __device__ __forceinline__ void deblock_line(unsigned char *plane_base, int stri
     }
     // hevc_loop_filter_luma, :1629-1723
     const int beta = beta_in << (bit_depth - 8);
-    if (vec) {
-        if (sizeof(Pixel) == 1) {
-            const u32x2 raw = *reinterpret_cast<const u32x2 *>(pix - 4);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { vv[k] = (raw.x >> (8 * k)) & 0xff; vv[4 + k] = (raw.y >> (8 * k)) & 0xff; }
-        } else {
-            const u32x4 raw = *reinterpret_cast<const u32x4 *>(pix - 8);
-            vv[0] = raw.x & 0xffff; vv[1] = raw.x >> 16; vv[2] = raw.y & 0xffff; vv[3] = raw.y >> 16;
-            vv[4] = raw.z & 0xffff; vv[5] = raw.z >> 16; vv[6] = raw.w & 0xffff; vv[7] = raw.w >> 16;
-        }
-    }
-    const int p3 = vec ? vv[0] : LD(-4), p2 = vec ? vv[1] : LD(-3), p1 = vec ? vv[2] : LD(-2), p0 = vec ? vv[3] : LD(-1);
-    const int q0 = vec ? vv[4] : LD(0), q1 = vec ? vv[5] : LD(1), q2 = vec ? vv[6] : LD(2), q3 = vec ? vv[7] : LD(3);
+    const int p3 = vv[0], p2 = vv[1], p1 = vv[2], p0 = vv[3], q0 = vv[4], q1 = vv[5], q2 = vv[6], q3 = vv[7];
     // (every exit below is taken by whole segments or writes nothing; the vector store sits in flush())
     auto flush = [&]() {
         if (!vec || !dirty) return;
@@ -105,8 +147,14 @@ __device__ __forceinline__ void deblock_line(unsigned char *plane_base, int stri
         if (!no_q && two_q) ST(1, iclip(q1 + iclip((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc_2, tc_2), 0, maxv));
     }
     flush();
-#undef LD
 #undef ST
+}
+
+template <typename Pixel>
+__device__ __forceinline__ void deblock_line(unsigned char *plane_base, int stride, int jx, int jy, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth, int l0, int l3)
+{
+    const DbkLine<Pixel> s = deblock_load<Pixel>(plane_base, stride, jx, jy, jplane, (flags & OHEVC_DBK_VERTICAL_EDGE) != 0, line);
+    deblock_filter<Pixel>(s, jplane, flags, beta_in, tc_in, line, bit_depth, l0, l3);
 }
 
 template <typename Pixel>
@@ -136,8 +184,6 @@ __global__ __launch_bounds__(256) void deblock_kernel(PlaneSet planes, const ohe
 // the same parameters (a handful of byte loads that hit the same cache line) and groups without an edge leave at once.
 OHEVC_CONST_TABLE unsigned char kDbkTc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
                                                4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
-OHEVC_CONST_TABLE unsigned char kDbkBeta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
-                                                 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
 OHEVC_CONST_TABLE unsigned char kDbkQpC[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
 
 template <typename Pixel>
@@ -151,58 +197,86 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
     const int line = vertical ? lane >> 3 : lane & 7;
     int unit = wave * 8 + (vertical ? lane & 7 : lane >> 3);
     const int l0 = vertical ? ((line & 4) << 3) | (lane & 7) : lane & ~3, l3 = vertical ? l0 + 24 : l0 | 3;
-    if (unit >= luma_units + 2 * chroma_units) return;
+    // every plane's units start at a multiple of 8 (one wavefront = 8 units): the plane is wave-uniform
+    const int luma_pad = (luma_units + 7) & ~7, chroma_pad = (chroma_units + 7) & ~7;
     int plane = 0;
-    if (unit >= luma_units) { unit -= luma_units; plane = 1; if (unit >= chroma_units) { unit -= chroma_units; plane = 2; } }
+    if (unit >= luma_pad) { unit -= luma_pad; plane = 1; if (unit >= chroma_pad) { unit -= chroma_pad; plane = 2; } }
+    plane = __builtin_amdgcn_readfirstlane(plane);
+    if (unit >= (plane ? chroma_units : luma_units)) return;
     const int hs = plane && (m.chroma_format_idc == 1 || m.chroma_format_idc == 2), vs = plane && m.chroma_format_idc == 1;
     const int uw = plane ? chroma_uw : luma_uw;
     const int x = (unit % uw) << (3 + hs), y = (unit / uw) << (3 + vs);          // luma coordinates of the edge's first sample
     if (vertical ? x == 0 : y == 0) return;
     const int dx = vertical ? 0 : 4 << hs, dy = vertical ? 4 << vs : 0;           // second segment
     const unsigned char *bsm = vertical ? m.vertical_bs : m.horizontal_bs;
-    const int bs0 = bsm[(x + y * m.bs_width) >> 2], bs1 = bsm[(x + dx + (y + dy) * m.bs_width) >> 2];
+    // (map indices as 32-bit unsigned offsets from a scalar base: one VGPR of address per load)
+    const int bs0 = bsm[(unsigned)(x + y * m.bs_width) >> 2], bs1 = bsm[(unsigned)(x + dx + (y + dy) * m.bs_width) >> 2];
     if (plane ? !(bs0 == 2 || bs1 == 2) : !(bs0 || bs1)) return;
+    const int seg = line >> 2;
+    int bs = seg ? bs1 : bs0;
+#ifndef OHEVC_HIPEMU
+    asm volatile("" : "+v"(bs));                     // selected HERE: sunk to its first use, the select waits for every load issued in between
+#endif
     const int log2_ctb = m.log2_ctb_size, ctb_w = (m.width + (1 << log2_ctb) - 1) >> log2_ctb;
-    auto qpy = [&](int xx, int yy) { return (int)m.qp_y_tab[(xx >> m.log2_min_cb_size) + (yy >> m.log2_min_cb_size) * m.min_cb_width]; };
+    auto qpy = [&](int xx, int yy) { return (int)m.qp_y_tab[(unsigned)((xx >> m.log2_min_cb_size) + (yy >> m.log2_min_cb_size) * m.min_cb_width)]; };
     auto ctb_param = [&](int xx, int k) {                        // DBParams of the CTB holding (xx, y), xx clamped to the last column
         int cx = xx >> log2_ctb;
         cx = cx < ctb_w - 1 ? cx : ctb_w - 1;
-        return (int)m.deblock[(size_t)(cx + (y >> log2_ctb) * ctb_w) * m.deblock_stride + k];
+        return (int)m.deblock[(unsigned)((cx + (y >> log2_ctb) * ctb_w) * m.deblock_stride + k)];
     };
     auto clipi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
     const int px = vertical ? x - 1 : x, py = vertical ? y : y - 1;               // the P side of segment 0
-    int flags = vertical ? OHEVC_DBK_VERTICAL_EDGE : 0;
-    if (m.is_pcm) {
-        auto pcm = [&](int xx, int yy) {
-            if (xx < 0 || yy < 0) return 2;
-            const int xp = xx >> m.log2_min_pu_size, yp = yy >> m.log2_min_pu_size;
-            if (xp >= m.min_pu_width || yp >= m.min_pu_height) return 2;
-            return (int)m.is_pcm[yp * m.min_pu_width + xp];
-        };
-        flags |= (pcm(px, py) ? OHEVC_DBK_NO_P0 : 0) | (pcm(px + dx, py + dy) ? OHEVC_DBK_NO_P1 : 0) |
-                 (pcm(x, y) ? OHEVC_DBK_NO_Q0 : 0) | (pcm(x + dx, y + dy) ? OHEVC_DBK_NO_Q1 : 0);
-    }
-    const int seg = line >> 2;
-    int beta = 0, tc;
-    if (plane == 0) {
-        const int qp = (qpy(px, py) + qpy(x, y) + 1) >> 1;
-        const int beta_offset = ctb_param(x, 0), tc_offset = ctb_param(vertical ? x : x + 8, 1);
-        beta = kDbkBeta[clipi(qp + beta_offset, 0, 51)];
-        const int bs = seg ? bs1 : bs0;
-        tc = bs ? kDbkTc[clipi(qp + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)] : 0;
-    } else {
-        const int bs = seg ? bs1 : bs0;
-        tc = 0;
-        if (bs == 2) {
-            const int sx = seg ? dx : 0, sy = seg ? dy : 0;
-            const int qp_y = (qpy(px + sx, py + sy) + qpy(x + sx, y + sy) + 1) >> 1;
-            const int tc_offset = ctb_param(vertical || !seg ? x : x + (8 << hs), 1);
-            const int qp_i = clipi(qp_y + (plane == 1 ? m.cb_qp_offset : m.cr_qp_offset), 0, 57);
-            const int qp = m.chroma_format_idc == 1 ? (qp_i < 30 ? qp_i : qp_i > 43 ? qp_i - 6 : (int)kDbkQpC[qp_i - 30]) : clipi(qp_i, 0, 51);
-            tc = kDbkTc[clipi(qp + 2 + tc_offset, 0, 53)];
+    // Second round of loads, all independent of each other and issued together: the line's samples, the four pcm / bypass flags, the two
+    // QPs, the CTB's offsets.  (First version: every one of them behind its own branch and wait - nine dependent round trips per edge.)
+    unsigned char *const pbase = PLANE_PTR3(planes, plane);
+    const int pstride = PLANE_STRIDE3(planes, plane);
+    const bool vec = vertical && plane == 0 && ((reinterpret_cast<uintptr_t>(pbase) | (unsigned)pstride) & 3) == 0;      // x is a multiple of 8 samples
+    auto tail = [&](auto form_tag) {
+    constexpr int FORM = decltype(form_tag)::value;
+    const DbkLine<Pixel> smp = deblock_load<Pixel, FORM>(pbase, pstride, x >> hs, y >> vs, plane, vertical != 0, line);
+    // get_pcm of the four sides (2 outside the picture).  Loaded unconditionally - without a map, byte 0 of the QP map, not used - so that
+    // these loads, the QP and the offset loads below sit in one basic block and leave together; behind `if (m.is_pcm)` the block waited
+    // for its own four before the next four were issued.
+    const bool has_pcm = m.is_pcm != nullptr;
+    const unsigned char *const pcm_map = has_pcm ? m.is_pcm : reinterpret_cast<const unsigned char *>(m.qp_y_tab);
+    int pcm_v[4];
+    bool pcm_out[4];
+    {
+        const int xs4[4] = { px, px + dx, x, x + dx }, ys4[4] = { py, py + dy, y, y + dy };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xp = xs4[k] >> m.log2_min_pu_size, yp = ys4[k] >> m.log2_min_pu_size;
+            pcm_out[k] = xs4[k] < 0 || ys4[k] < 0 || xp >= m.min_pu_width || yp >= m.min_pu_height;
+            const unsigned idx = (unsigned)(yp * m.min_pu_width + xp);
+            pcm_v[k] = (int)pcm_map[(pcm_out[k] || !has_pcm) ? 0u : idx];
         }
     }
-    deblock_line<Pixel>(PLANE_PTR3(planes, plane), PLANE_STRIDE3(planes, plane), x >> hs, y >> vs, plane, flags, beta, tc, line, bit_depth, l0, l3);
+    // luma: both segments share the QP of segment 0's sides; chroma: each segment its own (and only where bs == 2; elsewhere the address
+    // of segment 0 again - the value is not used)
+    const int sx = plane && seg && bs == 2 ? dx : 0, sy = plane && seg && bs == 2 ? dy : 0;
+    const int qp_p = qpy(px + sx, py + sy), qp_q = qpy(x + sx, y + sy);
+    const int beta_offset = ctb_param(x, 0);
+    const int tc_offset = ctb_param(plane == 0 ? (vertical ? x : x + 8) : (vertical || !seg ? x : x + (8 << hs)), 1);
+    int flags = vertical ? OHEVC_DBK_VERTICAL_EDGE : 0;
+    if (has_pcm)
+        flags |= ((pcm_out[0] || pcm_v[0]) ? OHEVC_DBK_NO_P0 : 0) | ((pcm_out[1] || pcm_v[1]) ? OHEVC_DBK_NO_P1 : 0) |
+                 ((pcm_out[2] || pcm_v[2]) ? OHEVC_DBK_NO_Q0 : 0) | ((pcm_out[3] || pcm_v[3]) ? OHEVC_DBK_NO_Q1 : 0);
+    const int qp_y = (qp_p + qp_q + 1) >> 1;
+    int beta = 0, tc = 0;
+    if (plane == 0) {
+        const int qb = clipi(qp_y + beta_offset, 0, 51);
+        beta = qb < 16 ? 0 : qb < 29 ? qb - 10 : 2 * qb - 38;                    // H.265 table 8-12, the beta' column in closed form
+        tc = bs ? kDbkTc[clipi(qp_y + 2 * (bs - 1) + (tc_offset >> 1 << 1), 0, 53)] : 0;
+    } else if (bs == 2) {
+        const int qp_i = clipi(qp_y + (plane == 1 ? m.cb_qp_offset : m.cr_qp_offset), 0, 57);
+        const int qp = m.chroma_format_idc == 1 ? (qp_i < 30 ? qp_i : qp_i > 43 ? qp_i - 6 : (int)kDbkQpC[qp_i - 30]) : clipi(qp_i, 0, 51);
+        tc = kDbkTc[clipi(qp + 2 + tc_offset, 0, 53)];
+    }
+    deblock_filter<Pixel, FORM>(smp, plane, flags, beta, tc, line, bit_depth, l0, l3);
+    };
+    if (plane != 0) tail(std::integral_constant<int, DBK_FORM_CHROMA>{});          // wave-uniform: scalar branches
+    else if (vec)   tail(std::integral_constant<int, DBK_FORM_VECTOR>{});
+    else            tail(std::integral_constant<int, DBK_FORM_SAMPLES>{});
 }
 
 template <typename Pixel>
@@ -663,7 +737,7 @@ extern "C" int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth
     const int luma_uw = (m->width + 7) >> 3, luma_uh = (m->height + 7) >> 3;
     const int chroma_uw = m->chroma_format_idc ? (m->width + (8 << hs) - 1) >> (3 + hs) : 0, chroma_uh = m->chroma_format_idc ? (m->height + (8 << vs) - 1) >> (3 + vs) : 0;
     const int luma_units = luma_uw * luma_uh, chroma_units = chroma_uw * chroma_uh;
-    const long long threads = ((long long)luma_units + 2ll * chroma_units) * 8;
+    const long long threads = ((long long)((luma_units + 7) & ~7) + 2ll * ((chroma_units + 7) & ~7)) * 8;      // each plane's units padded to whole wavefronts
     const int grid = (int)((threads + 255) / 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bit_depth == 8) hipLaunchKernelGGL((deblock_maps_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_units, chroma_units, luma_uw, chroma_uw);
