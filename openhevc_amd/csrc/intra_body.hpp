@@ -42,14 +42,18 @@ __device__ __forceinline__ void intra_body(IntraShared &sh, const int lane, cons
         INTRA_SYNC();
     }
     // ---- gather what is available (:164-183); samples beyond the picture replicate the last valid one
-    if (lane < n2) {
+    //      Three loads per lane (row above, column left, the corner), unconditional and issued together: a lane with nothing to fetch reads
+    //      sample (0, 0) of the block and drops it.  Behind their conditions each load waited for the one before it - three memory round
+    //      trips at the head of every block, and a dependency level of a picture lasts as long as one block.
+    {
         const int k = lane;
-        if (k < n) { if (c_u) t[k] = REC(k, -1); }
-        else if (c_ur) t[k] = REC(k < n + tr_size ? k : n + tr_size - 1, -1);
-        if (k < n) { if (c_l) l[k] = REC(-1, k); }
-        else if (c_bl) l[k] = REC(-1, k < n + bl_size ? k : n + bl_size - 1);
+        const bool top_ok = k < n2 && (k < n ? c_u : c_ur), left_ok = k < n2 && (k < n ? c_l : c_bl), corner_ok = lane == 63 && c_ul;
+        const int tx = k < n ? k : (k < n + tr_size ? k : n + tr_size - 1), ly = k < n ? k : (k < n + bl_size ? k : n + bl_size - 1);
+        const int tv = REC(top_ok ? tx : 0, top_ok ? -1 : 0), lv = REC(left_ok ? -1 : 0, left_ok ? ly : 0), cv = REC(corner_ok ? -1 : 0, corner_ok ? -1 : 0);
+        if (top_ok) t[k] = tv;
+        if (left_ok) l[k] = lv;
+        if (corner_ok) { l[-1] = cv; t[-1] = cv; }
     }
-    if (lane == 63 && c_ul) { l[-1] = REC(-1, -1); t[-1] = l[-1]; }
     INTRA_SYNC();
 
     // ---- constrained intra prediction (:185-249): samples of inter-coded neighbours are overwritten from the nearest
