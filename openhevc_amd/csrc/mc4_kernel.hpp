@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void mc4_kernel(PlaneSet dst, const ohevc_plan
         cptr jp = (cptr)(jobs + (u[i].valid ? j : njobs - 1));
         jw[i][0] = jp[0]; jw[i][1] = jp[1];
     }
+#ifndef OHEVC_HIPEMU
+    // the words of all four records that the reference-plane addresses are made of (plane | flags, ref0 | ref1), named as operands of ONE
+    // empty asm: the four loads above leave together and are waited for once.  Left alone, the compiler interleaves the records' loads with
+    // branches it makes of the bi / valid selects below - seven dependent scalar round trips in front of the first sample load.
+    asm volatile("" : "+s"(jw[0][0].y), "+s"(jw[0][1].y), "+s"(jw[1][0].y), "+s"(jw[1][1].y), "+s"(jw[2][0].y), "+s"(jw[2][1].y), "+s"(jw[3][0].y), "+s"(jw[3][1].y));
+    static_assert(MC4_UNITS == 4, "the operand list above");
+#endif
     const int maxv = (1 << bit_depth) - 1;
 #pragma unroll
     for (int i = 0; i < MC4_UNITS; i++) {
@@ -206,7 +213,12 @@ __global__ __launch_bounds__(256) void mc4_kernel(PlaneSet dst, const ohevc_plan
         u[i].slot = tyi * ntx + txi;
         static_assert(sizeof(ohevc_plane) == 24, "plane record");
         typedef const MC4_CONST unsigned long *lptr;
-        lptr p0 = (lptr)(refs + 3 * jb.ref0 + jb.plane), p1 = (lptr)(refs + 3 * (u[i].bi ? jb.ref1 : jb.ref0) + jb.plane);
+        const int bimask = -(int)((jb.flags & OHEVC_MC_BI) != 0);                   // (a select here comes back as a branch around slot1)
+        int slot0 = 3 * jb.ref0 + jb.plane, slot1 = 3 * (jb.ref0 ^ ((jb.ref0 ^ jb.ref1) & bimask)) + jb.plane;
+#ifndef OHEVC_HIPEMU
+        asm volatile("" : "+s"(slot0), "+s"(slot1));             // selected, not branched around (see above)
+#endif
+        lptr p0 = (lptr)(refs + slot0), p1 = (lptr)(refs + slot1);
         const unsigned long a0[3] = { p0[0], p0[1], p0[2] }, a1[3] = { p1[0], p1[1], p1[2] };
         __builtin_memcpy(&u[i].r0, a0, 24); __builtin_memcpy(&u[i].r1, a1, 24);
     }
