@@ -57,8 +57,35 @@ def analyze(db):
                           busy_share_of_span=round(union / span, 3))))
 
 
+def chain(db):
+    """Per kernel: launches, mean duration, and the mean idle time of its stream until the next kernel on that stream starts - what one
+    step of a dependent chain (the per-level launches of the intra blocks) costs beyond the kernel itself."""
+    import re
+    import sqlite3
+    con = sqlite3.connect(db)
+    rows = con.execute("select start, end, queue_id, stream_id, name from kernels order by start").fetchall()
+    by_stream = {}
+    for r in rows:
+        by_stream.setdefault(r[3], []).append(r)
+    acc = {}
+    for st, rs in by_stream.items():
+        for i, (s, e, q, _, name) in enumerate(rs):
+            if "ohevc" not in name:
+                continue
+            short = re.sub(r"<.*", "", name.split("ohevc::")[-1])
+            a = acc.setdefault(short, [0, 0, 0, 0])
+            a[0] += 1; a[1] += e - s
+            if i + 1 < len(rs) and "ohevc" in rs[i + 1][4] and rs[i + 1][0] - e < 200000:       # gaps above 0.2 ms: the host was not ready
+                a[2] += 1; a[3] += max(rs[i + 1][0] - e, 0)
+    for k, (n, dur, ng, gap) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        print(json.dumps(dict(kernel=k, launches=n, mean_us=round(dur / n / 1e3, 2), total_ms=round(dur / 1e6, 3),
+                              mean_gap_to_next_on_stream_us=round(gap / ng / 1e3, 2) if ng else None)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "decode":
+    if sys.argv[1] == "chain":
+        chain(sys.argv[2])
+    elif sys.argv[1] == "decode":
         decode(int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "natural")
     else:
         analyze(sys.argv[2])
