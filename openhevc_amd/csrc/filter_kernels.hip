@@ -35,13 +35,15 @@ struct DbkLine {
 // form: inside one instance the forms would share result registers, and every form's loads would wait for the others'.
 enum { DBK_FORM_ANY = -1, DBK_FORM_SAMPLES = 0, DBK_FORM_VECTOR = 1, DBK_FORM_CHROMA = 2 };
 template <typename Pixel, int FORM = DBK_FORM_ANY>
-__device__ __forceinline__ DbkLine<Pixel> deblock_load(unsigned char *plane_base, int stride, int jx, int jy, int jplane, bool vertical, int line)
-{      // (The plane's base and pitch arrive resolved: picked from the PlaneSet behind a reference, the selection becomes a load from a scratch
+__device__ __forceinline__ DbkLine<Pixel> deblock_load(unsigned char *plane_base, int stride, int jx, int jy, int jplane, bool vertical, int line, bool wanted = true)
+{      // wanted = false: this line's segment is not filtered (chroma: its tc is 0).  The second segment of a chroma edge can lie outside the
+       // plane (chroma heights / widths are multiples of 4, edges are 8 long); such a lane reads the matching line of the FIRST segment
+       // instead - inside the plane, not used, never stored - rather than taking a branch around its loads.      // (The plane's base and pitch arrive resolved: picked from the PlaneSet behind a reference, the selection becomes a load from a scratch
        // copy of the kernel arguments.)
     DbkLine<Pixel> s;
     s.xs = vertical ? (int)sizeof(Pixel) : stride;
     const int ys = vertical ? stride : (int)sizeof(Pixel);      // step along the edge
-    s.pix = plane_base + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)line * ys;
+    s.pix = plane_base + (size_t)jy * stride + (size_t)jx * sizeof(Pixel) + (size_t)(wanted ? line : (line & 3)) * ys;
     // Vertical luma edges: the 8 samples across the edge are 8 / 16 contiguous bytes of one row - one vector load, one vector store
     // (samples -4 and +3 are written back unchanged: no other edge of the vertical pass writes within 4 samples of this one).
     // Horizontal edges and chroma go sample by sample (along a horizontal edge the lanes of a job are neighbours in memory anyway).
@@ -153,7 +155,7 @@ __device__ __forceinline__ void deblock_filter(const DbkLine<Pixel> &s, int jpla
 template <typename Pixel>
 __device__ __forceinline__ void deblock_line(unsigned char *plane_base, int stride, int jx, int jy, int jplane, int flags, int beta_in, int tc_in, int line, int bit_depth, int l0, int l3)
 {
-    const DbkLine<Pixel> s = deblock_load<Pixel>(plane_base, stride, jx, jy, jplane, (flags & OHEVC_DBK_VERTICAL_EDGE) != 0, line);
+    const DbkLine<Pixel> s = deblock_load<Pixel>(plane_base, stride, jx, jy, jplane, (flags & OHEVC_DBK_VERTICAL_EDGE) != 0, line, jplane == 0 || tc_in > 0);
     deblock_filter<Pixel>(s, jplane, flags, beta_in, tc_in, line, bit_depth, l0, l3);
 }
 
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
     const bool vec = vertical && plane == 0 && ((reinterpret_cast<uintptr_t>(pbase) | (unsigned)pstride) & 3) == 0;      // x is a multiple of 8 samples
     auto tail = [&](auto form_tag) {
     constexpr int FORM = decltype(form_tag)::value;
-    const DbkLine<Pixel> smp = deblock_load<Pixel, FORM>(pbase, pstride, x >> hs, y >> vs, plane, vertical != 0, line);
+    const DbkLine<Pixel> smp = deblock_load<Pixel, FORM>(pbase, pstride, x >> hs, y >> vs, plane, vertical != 0, line, plane == 0 || bs == 2);
     // get_pcm of the four sides (2 outside the picture).  Loaded unconditionally - without a map, byte 0 of the QP map, not used - so that
     // these loads, the QP and the offset loads below sit in one basic block and leave together; behind `if (m.is_pcm)` the block waited
     // for its own four before the next four were issued.
