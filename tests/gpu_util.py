@@ -13,11 +13,30 @@ from openhevc_amd import lib as L
 _EMU = None
 
 
+def _guarded_copy(a):
+    """HIPEMU_GUARD=1: a copy of `a` whose last 16-byte piece ends where an inaccessible page begins.  A kernel of the emulated device code
+    that reads or writes past the end of a plane / job array / coefficient arena then dies with SIGSEGV instead of reading its
+    neighbour in silence (tests/test_guard_pages_cpu.py; the AddressSanitizer build, tools/hipemu_asan.sh, is the thorough form)."""
+    import mmap
+    a = np.ascontiguousarray(a)
+    page = mmap.PAGESIZE
+    span = max((a.nbytes + 15) // 16 * 16, 16)
+    total = (span + page - 1) // page * page + page
+    m = mmap.mmap(-1, total)
+    addr = C.addressof(C.c_char.from_buffer(m))
+    libc = C.CDLL(None, use_errno=True)
+    if libc.mprotect(C.c_void_p(addr + total - page), C.c_size_t(page), 0) != 0:
+        raise OSError(C.get_errno(), "mprotect")
+    buf = np.frombuffer(m, dtype=np.uint8, count=a.nbytes, offset=total - page - span).view(a.dtype).reshape(a.shape)
+    buf[...] = a
+    return buf                                               # keeps `m` alive through its base
+
+
 class HostTensor:
     """The few tensor methods the helpers use, over a numpy array (the emulator's device memory)."""
 
     def __init__(self, a):
-        self.a = np.ascontiguousarray(a).copy()
+        self.a = _guarded_copy(a) if os.environ.get("HIPEMU_GUARD") == "1" else np.ascontiguousarray(a).copy()
         self.shape = self.a.shape
 
     def data_ptr(self):
