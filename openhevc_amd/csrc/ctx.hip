@@ -96,6 +96,9 @@ static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_I
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
+// how long a frame thread waits for another thread to issue the frame end of a reference picture before it gives up (a decoding thread
+// that died would otherwise hang the pool).  The sanitizer build of the kernel emulator needs minutes where a device needs milliseconds.
+static const int g_ref_wait_s = getenv("OHEVC_REF_WAIT_SECONDS") && atoi(getenv("OHEVC_REF_WAIT_SECONDS")) > 0 ? atoi(getenv("OHEVC_REF_WAIT_SECONDS")) : 20;
 // OHEVC_TRACE_AT=plane,x,y: print every recorded job whose block covers that sample (diagnosis of a mismatching block)
 static int g_trace_at[3] = {-1, -1, -1};
 static const bool g_trace_at_on = [] {
@@ -420,7 +423,7 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
     if (c->dry) return OHEVC_OK;
     {   // the picture may be reconstructed by another context of the store (another decoding thread), possibly not even issued yet
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return p->end_issued; })) {
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
@@ -448,7 +451,7 @@ extern "C" int ohevc_pic_export(ohevc_ctx *c, int slot, int plane, void *device_
     if (c->dry) return OHEVC_OK;
     {
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return p->end_issued; })) {
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
@@ -511,7 +514,7 @@ extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, cons
     if (c->dry) return OHEVC_OK;
     {
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return sp->end_issued; })) {
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return sp->end_issued; })) {
             set_error("base-layer picture %d was never completed by its decoding thread", src_slot);
             return OHEVC_ERR_STATE;
         }
@@ -1134,7 +1137,7 @@ static int guard_pictures(ohevc_ctx *c, int target)
     for (int r : fresh) {
         Picture &rp = c->store->pics[r];
         if (g_trace_order) fprintf(stderr, "order: ctx %p target %d needs ref %d (issued %d, event %p)\n", (void *)c, target, r, (int)rp.end_issued, (void *)rp.written);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return rp.end_issued; })) {
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return rp.end_issued; })) {
             set_error("reference picture %d was never completed by its decoding thread", r);
             return OHEVC_ERR_STATE;
         }
@@ -1674,7 +1677,7 @@ extern "C" int ohevc_debug_wait_picture(ohevc_ctx *c, int slot)
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
     std::unique_lock<std::mutex> lk(c->store->m);
-    if (!c->store->cv.wait_for(lk, std::chrono::seconds(20), [&] { return p->end_issued; })) {
+    if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
         set_error("picture %d was never completed by its decoding thread", slot);
         return OHEVC_ERR_STATE;
     }
