@@ -31,12 +31,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md).  
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2", type=int, default=5, help="block size log2 (5 = 32x32, the graded kernel; 4 = 16x16)")
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default 2^20 for 32x32, 2^22 for 16x16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the whole-decoder leg (BASELINE config 3 geometry) that N=1 runs add to the line")
+    ap.add_argument("--no-zscan", action="store_true", help="skip the second timed loop over the CTB-major (z-scan) job list")
+    ap.add_argument("--check-blocks", type=int, default=512, help="output blocks verified bit-exactly against the oracle after the timed loops")
     ap.add_argument("--sparse", action="store_true", help="decoder-like coefficients: non-zeros only in the top-left 8x8")
     ap.add_argument("--mode", choices=["blocks", "frames"], default="blocks",
                     help="blocks (default): the graded kernel on independent blocks; frames: the whole decoder on a synthetic stream, "
@@ -108,6 +111,95 @@ def cpu_baseline(log2, bd, leg_seconds=6.0):
             out["simd_value"], out["simd_value_1thread"] = sn["mpix_s"], s1["mpix_s"]
             out["simd_note"] = (f"reference x86 SSE4 intrinsics path (x86/hevc_idct_sse.c): {sn['blocks']} blocks on {cores} threads in "
                                 f"{sn['seconds']} s; {s1['blocks']} blocks on 1 thread in {s1['seconds']} s")
+    return out
+
+
+PCIE_PEAK_GBS = 64.0            # PCIe 5.0 x16, one direction: the floor of what crosses the bus per picture
+
+
+def decode_leg(pictures=33, threads=16, size=(1920, 1080)):
+    """BASELINE config 3 (1080p Main 8-bit random-access stream, the full CTU pipeline on one GPU) as a driver-timed number: the reference's
+    own front end (CABAC, syntax, motion data: host cores) linked against libohevc_hip.so (oracle/_ref/libopenhevc_hip.so: the reference's
+    sources + integration/hip_hooks.c), against the same decoder with its own C tables.  No HEVC bitstream exists in this environment: the
+    streams are synthesised (oracle/pystream.py, legal syntax, two statistics: 'natural' = encoder-like random-access output, 'flat' =
+    every syntax element from flat-ish distributions, a quarter of the CUs of inter pictures intra-coded).  Every HIP run is compared
+    sample by sample with the reference decoder's output.  The stream synthesiser and the harness are test infrastructure; every pixel
+    of the 'hip' rows is produced by the HIP library."""
+    import ctypes as C
+    from oracle import pystream as ps
+    if not (ps.have("hip") and ps.have("c") and ps.have("gen")):
+        return {"error": "oracle/_ref decoder builds are missing"}
+    W, H = size
+    natural = dict(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
+                                          split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
+    profiles = [("natural", natural), ("flat", {})]
+    dense = getattr(ps, "DENSE_QP22", None)          # qp22-like residual density (100-300 KB per 1080p picture), when the synthesiser has it
+    if dense is not None:
+        profiles.append(("dense_qp22", dense))
+    hipL = ps._load("hip")
+    hipL.ohdec_backend_alg_bytes.restype = C.c_longlong
+    cores = os.cpu_count() or 1
+
+    def timed(kind, aus, th, repeat=3):
+        best = None
+        for _ in range(repeat):
+            with ps.Decoder(kind, th, 1) as d:
+                t = time.perf_counter()
+                n = 0
+                for i, au in enumerate(aus):
+                    r = d.L.ohdec_decode(d.h, au, len(au), i + 1)
+                    if r < 0:
+                        raise RuntimeError(f"decode error {r}")
+                    n += r
+                while True:
+                    r = d.L.ohdec_flush(d.h)
+                    if r <= 0:
+                        break
+                    n += r
+                dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return best, n
+
+    out = {"workload": f"{W}x{H} 8-bit 4:2:0 random-access GOP, {pictures} pictures, synthetic Annex-B streams (oracle/pystream.py, seed 7); wall clock incl. "
+                       f"entropy decoding on the host and the copy-back of every picture; host has {cores} logical cores",
+           "streams": {}}
+    for name, extra in profiles:
+        kw = dict(gop="random_access", nframes=pictures, seed=7, width=W, height=H, log2_ctb=6, bit_depth=8)
+        kw.update(extra)
+        aus, _ = ps.generate(ps.StreamParams(**kw))
+        ref = ps.decode_stream("c", aus)
+        hip = ps.decode_stream("hip", aus)
+        hip_mt = ps.decode_stream("hip", aus, threads, 1)
+        same = lambda a, b: len(a) == len(b) and all(np.array_equal(x, y) for fa, fb in zip(a, b) for x, y in zip(fa, fb))
+        row = {"bytes_per_picture": sum(map(len, aus)) // len(aus), "bit_exact": bool(same(ref, hip)), f"bit_exact_{threads}_frame_threads": bool(same(ref, hip_mt))}
+        mp = W * H * pictures / 1e6
+        sec, cnt = C.c_double(), (C.c_longlong * 8)()
+        for label, kind, th in (("hip_1thread", "hip", 1), (f"hip_{threads}frame_threads", "hip", threads),
+                                ("reference_c_1thread", "c", 1), (f"reference_c_{threads}frame_threads", "c", threads)):
+            if kind == "hip":
+                hipL.ohdec_backend_profile(C.byref(sec), cnt)          # reset the cumulative counters
+                hipL.ohdec_backend_alg_bytes()
+            dt, npic = timed(kind, aus, th)
+            r = {"fps": round(pictures / dt, 1), "mpixel_per_s": round(mp / dt, 1)}
+            if kind == "hip":
+                hipL.ohdec_backend_profile(C.byref(sec), cnt)
+                alg = hipL.ohdec_backend_alg_bytes()
+                nf = max(1, cnt[0])
+                hook_ms = 1e3 * sec.value / nf
+                down = W * H * 3 // 2                                  # the copy-back of the three planes
+                dev_floor_ms = alg / nf / (HBM_PEAK_GBS * 1e9) * 1e3
+                bus_floor_ms = (cnt[7] / nf + down) / (PCIE_PEAK_GBS * 1e9) * 1e3
+                r["per_picture"] = {"frame_end_hook_ms": round(hook_ms, 3), "launches": round(cnt[1] / nf, 1), "upload_kib": int(cnt[7] / nf / 1024),
+                                    "copy_back_kib": down // 1024, "algorithmic_hbm_bytes": int(alg / nf),
+                                    "device_floor_ms": round(dev_floor_ms, 4), "pcie_floor_ms": round(bus_floor_ms, 4),
+                                    "floor_frac": round((dev_floor_ms + bus_floor_ms) / hook_ms, 4) if hook_ms > 0 else None}
+            row[label] = r
+        out["streams"][name] = row
+    nat = out["streams"]["natural"]
+    out["fps"], out["mpixel_per_s"] = nat["hip_1thread"]["fps"], nat["hip_1thread"]["mpixel_per_s"]
+    out["bit_exact"] = all(v["bit_exact"] and v[f"bit_exact_{threads}_frame_threads"] for v in out["streams"].values())
+    out["floor"] = ("device_floor_ms = algorithmic HBM bytes of the picture's jobs (SURVEY 8d per-unit figures, summed by the recorder) / 8 TB/s; "
+                    "pcie_floor_ms = (job upload + plane copy-back) / 64 GB/s; floor_frac = their sum / the frame-end hook's wall time")
     return out
 
 
@@ -208,6 +300,8 @@ def main():
     log2, bd = args.log2, args.bit_depth
     n = 1 << log2
     nblk = args.blocks or (1 << 20 if log2 == 5 else 1 << 22 if log2 == 4 else 1 << 22)
+    # SURVEY 8(d) names a 4096-sample-wide destination; a job's y is a uint16 (include/ohevc_hip.h), and 2^20 blocks of 32x32 in a
+    # 4096-wide plane are 262144 rows.  16384 samples wide gives 65536 rows: the same 256-byte row segments per tile of 8 blocks.
     per_row = 16384 // n
     assert nblk % per_row == 0
     H, W = nblk // per_row * n, 16384
@@ -216,32 +310,51 @@ def main():
     # ---- synthetic inputs, generated on the device (seed 1234 + rank), resident in HBM before timing.
     # The kernel updates the prediction plane in place; re-running it on the same plane saturates the pixels to 0/255
     # within a few passes, and such low-entropy data lets the chip clock ~15 % higher (DVFS).  So every step gets its OWN
-    # freshly randomised plane (a ring of W+K planes, capped at 96 GiB); coefficients are read-only and shared.
+    # freshly randomised plane (a ring sized to the free HBM, refilled - untimed - before every timed loop); coefficients are read-only.
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    plane_bytes = H * W * (2 if bd > 8 else 1)
-    n_planes = max(1, min(args.warmup + args.steps, (96 << 30) // plane_bytes))
+    px_bytes = 2 if bd > 8 else 1
+    plane_bytes = H * W * px_bytes
+    coeff_bytes = nblk * n * n * 2
+    free_b, _total_b = torch.cuda.mem_get_info()
+    n_planes = max(1, min(args.steps, (free_b - 2 * coeff_bytes - (12 << 30)) // plane_bytes))
 
-    def new_plane():
+    def fill(t):
         if bd == 8:
-            return torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda", generator=g)
-        return torch.randint(0, 1 << bd, (H, W), dtype=torch.int16, device="cuda", generator=g)
-    plane_ring = [new_plane() for _ in range(n_planes)]
+            t.random_(0, 256, generator=g)
+        else:
+            t.random_(0, 1 << bd, generator=g)
+    plane_ring = [torch.empty((H, W), dtype=torch.uint8 if bd == 8 else torch.int16, device="cuda") for _ in range(n_planes)]
     coeffs = torch.randint(-1024, 1024, (nblk, n, n), dtype=torch.int16, device="cuda", generator=g)
     if args.sparse:
         coeffs[:, 8:, :] = 0
         coeffs[:, :, 8:] = 0
     idx = np.arange(nblk)
-    jobs = np.zeros(nblk, L.TU_JOB)
-    jobs["x"], jobs["y"], jobs["coeff_off"] = (idx % per_row) * n, (idx // per_row) * n, idx.astype(np.uint32) * n * n
-    d_jobs = torch.from_numpy(jobs.view(np.uint8)).cuda()
+
+    def job_list(order):
+        """job k reconstructs block order[k] (raster numbering of the plane) from coefficient block k: coefficients lie in job order,
+        as the decoder's recorder appends them"""
+        jobs = np.zeros(nblk, L.TU_JOB)
+        jobs["x"], jobs["y"] = (order % per_row) * n, (order // per_row) * n
+        jobs["coeff_off"] = idx.astype(np.uint32) * n * n
+        return jobs
+
+    def zscan_order():
+        """the order the decoder emits transform blocks in: 64x64 coding-tree blocks in raster order, z-scan inside a CTB"""
+        bpc = 64 // n
+        bx, by = idx % per_row, idx // per_row
+        lx, ly = bx % bpc, by % bpc
+        z = np.zeros(nblk, np.int64)
+        for b in range(3):
+            z |= (((lx >> b) & 1) << (2 * b)) | (((ly >> b) & 1) << (2 * b + 1))
+        key = ((by // bpc) * (per_row // bpc) + bx // bpc) * (bpc * bpc) + z
+        return np.argsort(key, kind="stable")
+
+    orders = {"raster": idx}
+    if not args.no_zscan:
+        orders["zscan"] = zscan_order()
+    d_jobs = {k: torch.from_numpy(job_list(o).view(np.uint8)).cuda() for k, o in orders.items()}
     plane_sets = [L.planes_of([p, None, None]) for p in plane_ring]
     stream = torch.cuda.current_stream()
-    counter = [0]
-
-    def step():
-        planes = plane_sets[counter[0] % n_planes]
-        counter[0] += 1
-        L.dev_tu_batch(planes, bd, log2, L.TU_IDCT, d_jobs.data_ptr(), nblk, coeffs.data_ptr(), stream.cuda_stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -249,28 +362,76 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:                       # events are recorded on the same (current) stream as the launches
-        a.record(stream)
-        step()
-        b.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # ---- the bit-exact check of the timed output: blocks sampled before a loop (their prediction samples are saved), recomputed by the
+    # oracle (oracle/liboracle.so, the CPU restatement of hevcdsp_template.c:45-111,210-301) after it and compared with what the device wrote
+    rng = np.random.default_rng(99 + rank)
+    n_check = max(0, args.check_blocks) if rank == 0 else 0
 
-    bytes_per_px = 2 + 2 * (2 if bd > 8 else 1)
+    def sample_blocks(order):
+        picks = []
+        for _ in range(n_check):
+            pi, k = int(rng.integers(n_planes)), int(rng.integers(nblk))
+            b = int(order[k])
+            x, y = (b % per_row) * n, (b // per_row) * n
+            picks.append((pi, k, x, y, plane_ring[pi][y:y + n, x:x + n].cpu().numpy().copy()))
+        return picks
+
+    def verify_blocks(picks, steps_run):
+        if not picks:
+            return None
+        from oracle import pyoracle as po
+        orc = po.load("oracle")
+        bad = 0
+        for pi, k, x, y, before in picks:
+            uses = len(range(pi, steps_run, n_planes))            # how often the loop passed over this plane
+            want = before.view(np.uint16 if bd > 8 else np.uint8).copy()
+            cf = coeffs[k:k + 1].cpu().numpy()
+            for _ in range(uses):
+                want = orc.tu_batch(bd, po.TU_IDCT, log2, cf, want, np.zeros((1, 2), np.int32))
+            got = plane_ring[pi][y:y + n, x:x + n].cpu().numpy().view(want.dtype)
+            bad += not np.array_equal(got, want)
+        return bad
+
+    def timed_loop(name):
+        """W untimed warm-up steps, ring refilled, then exactly K timed steps between barriers; HIP events around every launch"""
+        jobs_ptr = d_jobs[name].data_ptr()
+        counter = [0]
+
+        def step():
+            planes = plane_sets[counter[0] % n_planes]
+            counter[0] += 1
+            L.dev_tu_batch(planes, bd, log2, L.TU_IDCT, jobs_ptr, nblk, coeffs.data_ptr(), stream.cuda_stream)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        for t in plane_ring:
+            fill(t)
+        picks = sample_blocks(orders[name])
+        counter[0] = 0
+        barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:                       # events are recorded on the same (current) stream as the launches
+            a.record(stream)
+            step()
+            b.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        return elapsed, kernel_ms, verify_blocks(picks, args.steps)
+
+    elapsed, kernel_ms, bad = timed_loop("raster")
+    z = timed_loop("zscan") if "zscan" in orders else None
+
+    bytes_per_px = 2 + 2 * px_bytes
     alg_bytes = nblk * n * n * bytes_per_px
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters: NOT measured by this process (counters need rocprofv3 around it); the stored result of
-    # the separate --pmc passes of this very command (tools/gpu_pmc_traffic.sh -> tools/pmc_traffic.py) is reported, and labelled so
+    # the separate --pmc passes of this very command (tools/gpu.sh step "pmc" -> tools/pmc_traffic.py) is reported, and labelled so
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath) and log2 == 5 and bd == 8 and not args.sparse:
@@ -293,18 +454,36 @@ def main():
             "dtype": "int16 coefficients, u%d pixels, int32 accumulate" % (16 if bd > 8 else 8),
             "data": "synthetic (fresh random prediction plane per step: %d planes in the ring)" % n_planes,
             "config": {"workload": f"synthetic batched {n}x{n} int16 IDCT+add (BASELINE config 2), {nblk} blocks/GPU, {bd}-bit, "
-                                   f"16384-wide tiled plane, coeffs U[-1024,1023]{' top-left 8x8 only' if args.sparse else ''}, seed 1234",
+                                   f"16384-wide tiled plane (a job's y is 16 bits: the 4096-wide plane of SURVEY 8d would be 262144 rows), "
+                                   f"coeffs U[-1024,1023]{' top-left 8x8 only' if args.sparse else ''}, seed 1234, jobs in raster order",
                        "blocks_per_gpu": nblk, "block": n, "bit_depth": bd, "parallelism": f"blocks sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": L.load_library().ohevc_tu_kernel_name(bd, log2, L.TU_IDCT).decode(),
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+            "checked": bool(n_check and bad == 0 and (z is None or z[2] == 0)),
+            "check": {"blocks": n_check * (2 if z else 1), "mismatches": (bad or 0) + ((z[2] or 0) if z else 0),
+                      "how": "blocks sampled over the ring before each timed loop, recomputed by the CPU oracle afterwards"},
         }
+        if z is not None:
+            # the same blocks listed the way the decoder's recorder emits them (CTB-major, z-scan inside a CTB: a tile of 8 jobs is two
+            # CTBs = 128-byte row pieces at 8 bit instead of one 256-byte segment)
+            zach = alg_bytes / (z[1] * 1e-3) / 1e9
+            out["zscan"] = {"value": round(world * nblk * n * n * args.steps / z[0] / 1e6, 1), "ms_per_step": round(z[0] / args.steps * 1e3, 4),
+                            "kernel_ms": round(z[1], 4), "achieved": round(zach, 1), "frac": round(zach / HBM_PEAK_GBS, 4),
+                            "vs_raster": round(kernel_ms / z[1], 4)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(log2, bd)
             except Exception as e:      # the baseline is reporting only; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if world == 1 and not args.no_decode:
+            del plane_ring, plane_sets, coeffs
+            torch.cuda.empty_cache()
+            try:
+                out["decode"] = decode_leg()
+            except Exception as e:
+                out["decode"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

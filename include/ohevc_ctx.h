@@ -128,6 +128,10 @@ typedef struct ohevc_frame_stats {
     int64_t upload_bytes;
     int32_t n_tu, n_mc, n_intra, n_dbk, n_sao;
     int32_t chose_ctbs;                 /* the picture's intra blocks ran as CTB tasks (one launch) rather than as dependency levels */
+    int32_t reserved;
+    int64_t alg_bytes;                  /* algorithmic HBM bytes of the picture's recorded jobs: the per-unit figures of SURVEY.md 8(d) summed over
+                                           the records (residual (2 + 2P) N^2, MC P (w+T-1)(h+T-1) per reference + P w h, intra P (4N+1) + P N^2,
+                                           deblocking 2P per touched sample, SAO P (w+2)(h+2) + P w h) -- the traffic floor of the device work */
 } ohevc_frame_stats;
 int  ohevc_frame_get_stats(ohevc_ctx *ctx, ohevc_frame_stats *out);
 

@@ -48,6 +48,7 @@ static int                 g_bulk_filters = 1;     /* OHHIP_BULK_FILTERS=0: keep
 static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
 static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
 static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
+static long long           g_alg_bytes;        /* algorithmic HBM bytes of the recorded jobs (ohevc_frame_stats.alg_bytes), same period */
 
 /* host buffer -> picture-store slot.  Keyed by the luma plane address: libavcodec's buffer pool hands a buffer out
  * again only once no frame references it, so a known address means "the picture that lived there is dead". */
@@ -580,6 +581,7 @@ int ohdec_backend_frame_done(void)
         g_counts[0]++;
         g_counts[1] += fs.launches; g_counts[2] += fs.n_tu; g_counts[3] += fs.n_mc; g_counts[4] += fs.n_intra;
         g_counts[5] += fs.n_dbk; g_counts[6] += fs.n_sao; g_counts[7] += fs.upload_bytes;
+        g_alg_bytes += fs.alg_bytes;
         pthread_mutex_unlock(&g_lock);
     }
     if (st == OHEVC_OK)
@@ -676,6 +678,17 @@ void ohdec_backend_profile(double *end_frame_s, long long counts[8])
     g_end_frame_s = 0;
     memset(g_counts, 0, sizeof(g_counts));
     pthread_mutex_unlock(&g_lock);
+}
+
+/* algorithmic HBM bytes of the jobs recorded since the last call (the device-side traffic floor of those pictures) */
+long long ohdec_backend_alg_bytes(void)
+{
+    long long v;
+    pthread_mutex_lock(&g_lock);
+    v = g_alg_bytes;
+    g_alg_bytes = 0;
+    pthread_mutex_unlock(&g_lock);
+    return v;
 }
 
 /* after the decoder (and its threads) are gone */

@@ -141,6 +141,7 @@ struct Rec {
     std::vector<ohevc_sao_job> sao;
     bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
     int nstat[5] = {};                // tu, mc, intra, dbk, sao calls
+    int64_t alg = 0;                  // algorithmic bytes of the recorded jobs (ohevc_frame_stats.alg_bytes)
     struct { int level = -1, index = 0, plane = 0, x = 0, y = 0, log2 = 0; } last_intra;   // the most recent intra job of this recorder (levels form)
 };
 
@@ -672,6 +673,7 @@ static void merge_side(ohevc_ctx *c)
         c->sao.insert(c->sao.end(), r.sao.begin(), r.sao.end());
         c->sao_lagged |= r.sao_lagged;
         for (int k = 0; k < 5; k++) { c->nstat[k] += r.nstat[k]; r.nstat[k] = 0; }
+        c->alg += r.alg; r.alg = 0;
         clear_rec(r);
         r.dbk_v.clear(); r.dbk_h.clear(); r.sao.clear(); r.sao_lagged = false;
     }
@@ -707,11 +709,12 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->bypass.clear();
     c->stats = ohevc_frame_stats{};
     for (int &v : c->nstat) v = 0;
+    c->alg = 0;
     c->owner = std::this_thread::get_id();
     c->epoch.fetch_add(1, std::memory_order_release);      // per-thread recorder caches of the previous picture are void
     {
         std::lock_guard<std::mutex> g(c->side_m);
-        for (auto &sd : c->side) { clear_rec(*sd.second); sd.second->dbk_v.clear(); sd.second->dbk_h.clear(); sd.second->sao.clear(); for (int &v : sd.second->nstat) v = 0; }
+        for (auto &sd : c->side) { clear_rec(*sd.second); sd.second->dbk_v.clear(); sd.second->dbk_h.clear(); sd.second->sao.clear(); for (int &v : sd.second->nstat) v = 0; sd.second->alg = 0; }
     }
     return OHEVC_OK;
 }
@@ -739,6 +742,7 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
     OHEVC_REQUIRE(x >= 0 && y >= 0 && x + n <= p->planes[plane].width && y + n <= p->planes[plane].height && coeffs != nullptr, "TU outside plane");
     ohevc_tu_job j = {};
     j.x = (uint16_t)x; j.y = (uint16_t)y; j.plane = (uint8_t)plane;
+    r.alg += (kind == OHEVC_TU_DC ? 2 : 2 * n * n) + (kind == OHEVC_TU_PCM ? 1 : 2) * (p->bd > 8 ? 2 : 1) * n * n;
     if (kind == OHEVC_TU_DC) {
         j.dc = coeffs[0];
     } else {
@@ -790,6 +794,7 @@ extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log
     j.reserved0 = (uint8_t)((kind_c < 0 ? 15 : kind_c) | (kind_y << 4));
     j.dc = (int16_t)res_scale_val;
     j.reserved1 = (uint32_t)r.coeffs.size();
+    r.alg += (kind_c >= 0 ? 4 : 2) * n * n + 2 * (p->bd > 8 ? 2 : 1) * n * n;
     r.coeffs.insert(r.coeffs.end(), coeffs_y, coeffs_y + n * n);
     if (kind_c >= 0) {
         j.coeff_off = (uint32_t)r.coeffs.size();
@@ -831,6 +836,10 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
             t.sx1 = (int16_t)(job->sx1 + tx); t.sy1 = (int16_t)(job->sy1 + ty);
             ((t.w <= 8 && t.h <= 8) ? r.mc_small : r.mc).push_back(t);
         }
+    {
+        const int P = p->bd > 8 ? 2 : 1, T = job->plane ? 4 : 8;
+        r.alg += (int64_t)P * (job->w + T - 1) * (job->h + T - 1) * ((job->flags & OHEVC_MC_BI) ? 2 : 1) + (int64_t)P * job->w * job->h;
+    }
     r.nstat[1]++;
     return OHEVC_OK;
 }
@@ -864,6 +873,7 @@ static int rec_intra_impl(ohevc_ctx *c, const ohevc_intra_job *job)
     OHEVC_REQUIRE(job->plane < 3 && job->log2_size >= 2 && job->log2_size <= 5 && job->mode <= 34, "bad intra job");
     const int pl = job->plane, n = 1 << job->log2_size, W = c->lm_w[pl], H = c->lm_h[pl];
     OHEVC_REQUIRE(job->x + n <= p->planes[pl].width && job->y + n <= p->planes[pl].height, "intra block outside plane");
+    r.alg += (p->bd > 8 ? 2 : 1) * (4 * n + 1 + n * n);
     if (c->frame_mode >= 2) {
         // the CTB executor needs the CTB size; the picture's first intra job decides (jobs built without it: dependency levels)
         int l2 = __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED);
@@ -974,6 +984,7 @@ extern "C" int ohevc_rec_deblock(ohevc_ctx *c, const ohevc_dbk_job *job)
     Rec &r = pick(c);
     ((job->flags & OHEVC_DBK_VERTICAL_EDGE) ? r.dbk_v : r.dbk_h).push_back(*job);
     if (g_trace_at_on) trace_dbk(c->cur, *job);
+    r.alg += 2 * (c->store->pics[c->cur].bd > 8 ? 2 : 1) * (job->plane ? 32 : 64);      // 8 lines x 4 (chroma: 2) samples either side, read + written
     r.nstat[3]++;
     return OHEVC_OK;
 }
@@ -985,6 +996,7 @@ extern "C" int ohevc_rec_sao(ohevc_ctx *c, const ohevc_sao_job *job)
     r.sao.push_back(*job);
     if (g_trace_at_on) trace_sao(c->cur, *job);
     if (job->quirks & (OHEVC_SAO_LAG_BELOW | OHEVC_SAO_LAG_ABOVE | OHEVC_SAO_LAG_MID)) r.sao_lagged = true;
+    r.alg += (int64_t)(c->store->pics[c->cur].bd > 8 ? 2 : 1) * ((job->w + 2) * (job->h + 2) + job->w * job->h);
     r.nstat[4]++;
     return OHEVC_OK;
 }
@@ -1036,6 +1048,7 @@ extern "C" int ohevc_rec_deblock_bulk(ohevc_ctx *c, const ohevc_dbk_job *jobs, i
     Rec &r = pick(c);
     for (int i = 0; i < n; i++) ((jobs[i].flags & OHEVC_DBK_VERTICAL_EDGE) ? r.dbk_v : r.dbk_h).push_back(jobs[i]);
     if (g_trace_at_on) for (int i = 0; i < n; i++) trace_dbk(c->cur, jobs[i]);
+    for (int i = 0; i < n; i++) r.alg += 2 * (c->store->pics[c->cur].bd > 8 ? 2 : 1) * (jobs[i].plane ? 32 : 64);
     r.nstat[3] += n;
     return OHEVC_OK;
 }
@@ -1068,6 +1081,10 @@ extern "C" int ohevc_rec_deblock_maps(ohevc_ctx *c, const ohevc_dbk_maps *m)
     c->dbk_maps.vertical_bs = reinterpret_cast<const uint8_t *>(o_v); c->dbk_maps.horizontal_bs = reinterpret_cast<const uint8_t *>(o_h);
     c->dbk_maps.qp_y_tab = reinterpret_cast<const int8_t *>(o_qp); c->dbk_maps.deblock = reinterpret_cast<const int8_t *>(o_db);
     c->dbk_maps.is_pcm = n_pcm ? reinterpret_cast<const uint8_t *>(o_pcm) : nullptr;
+    {   // the frame bound of deblocking, 2P bytes per sample of every plane
+        const Picture &pp = c->store->pics[c->cur];
+        for (const ohevc_plane &pl : pp.planes) c->alg += 2ll * (pp.bd > 8 ? 2 : 1) * pl.width * pl.height;
+    }
     c->nstat[3]++;
     c->n_map_frames++;
     return OHEVC_OK;
@@ -1606,6 +1623,7 @@ static int frame_end_impl(ohevc_ctx *c)
         p->end_issued = true;
     }
     c->store->cv.notify_all();
+    c->stats.alg_bytes = c->alg;
     c->stats.n_tu = c->nstat[0]; c->stats.n_mc = c->nstat[1]; c->stats.n_intra = c->nstat[2]; c->stats.n_dbk = c->nstat[3]; c->stats.n_sao = c->nstat[4];
     c->last_stats = c->stats;
     return OHEVC_OK;

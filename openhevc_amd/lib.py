@@ -250,7 +250,7 @@ def intra_make_job(geom, x0, y0, log2_size, c_idx, mode, cands):
 class FrameStats(C.Structure):
     _fields_ = [("launches", C.c_int32), ("intra_levels", C.c_int32), ("upload_bytes", C.c_int64),
                 ("n_tu", C.c_int32), ("n_mc", C.c_int32), ("n_intra", C.c_int32), ("n_dbk", C.c_int32), ("n_sao", C.c_int32),
-                ("chose_ctbs", C.c_int32)]
+                ("chose_ctbs", C.c_int32), ("reserved", C.c_int32), ("alg_bytes", C.c_int64)]
 
 
 EXPORTED_SYMBOLS += ["ohevc_dev_levels", "ohevc_dev_ctbs", "ohevc_frame_abort", "ohevc_level_phase_workgroups", "ohevc_ctx_create_shared", "ohevc_ctx_store_id"]
