@@ -1250,6 +1250,35 @@ static double build_ctb_tasks(ohevc_ctx *c, const Picture *p)
     return longest;
 }
 
+// The 32x32 inverse-DCT kernel takes 8 consecutive jobs as one tile and touches the picture in whole row segments of those 8 blocks
+// (tu_idct32_tile1_kernel).  The decoder emits transform blocks CTB by CTB in z-scan, so 8 consecutive jobs are two CTBs - 2 x 2 blocks each,
+// 128-byte row pieces at 8 bit - where 8 horizontal neighbours would be one 256-byte segment: measured 6 % slower on the headline batch
+// (bench.py "zscan": 0.819 against 0.770 ms per 2^20 blocks).  Jobs of a bin are independent and find their coefficients through
+// coeff_off, so their order is free: a stable counting sort by (plane, block row) - inside a block row the CTB order already is the x order -
+// restores raster order for ~2 ns per job.
+static void sort_tile_bin(std::vector<ohevc_tu_job> &v)
+{
+    const size_t n = v.size();
+    if (n < 16) return;
+    static thread_local std::vector<uint32_t> count;
+    static thread_local std::vector<ohevc_tu_job> tmp;
+    constexpr int kRows = 2048;                                // y < 65536: block rows of 32 samples
+    count.assign((size_t)3 * kRows + 1, 0u);
+    bool sorted = true;
+    uint32_t prev = 0;
+    for (const ohevc_tu_job &j : v) {
+        const uint32_t key = (uint32_t)(j.plane % 3) * kRows + (j.y >> 5);
+        sorted = sorted && key >= prev;
+        prev = key;
+        count[key + 1]++;
+    }
+    if (sorted) return;
+    for (size_t k = 1; k < count.size(); k++) count[k] += count[k - 1];
+    tmp.resize(n);
+    for (const ohevc_tu_job &j : v) tmp[count[(uint32_t)(j.plane % 3) * kRows + (j.y >> 5)]++] = j;
+    v.swap(tmp);
+}
+
 extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
@@ -1322,6 +1351,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         for (uint64_t m = lb.touched; m; m &= m - 1) {
             const int b = __builtin_ctzll(m);
             auto &v = lb.tu[b >> 4][b & 15];
+            if (b == 3 * 16 + OHEVC_TU_IDCT) sort_tile_bin(v);
             const size_t o = stage_put(parts, total, v.data(), v.size() * sizeof(ohevc_tu_job));
             if (first) { loff[l].tu_first = o; first = false; }
         }

@@ -53,7 +53,7 @@ step() {
       timeout 900 python bench.py "$@" 2> $OUT/bench_${sfx:-default}.err | tail -1 > $OUT/bench${sfx:+_$sfx}.json
       cut -c1-1500 $OUT/bench${sfx:+_$sfx}.json; tail -3 $OUT/bench_${sfx:-default}.err | grep -v "$NOISE" ;;
     bench_prof)
-      prof_stats /tmp/prof_bench bench python $ROOT/bench.py --no-cpu-baseline --no-decode "$@" | tee $OUT/kernel_stats.txt ;;
+      prof_stats /tmp/prof_bench bench python $ROOT/bench.py --no-cpu-baseline --no-decode --no-zscan "$@" | tee $OUT/kernel_stats.txt ;;
     pmc)
       local CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-decode --no-zscan --check-blocks 0"
       ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_fetch -o p -- $CMD > /tmp/pmc_fetch.log 2>&1
