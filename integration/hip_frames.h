@@ -29,14 +29,20 @@ typedef struct ohhip_frames_mode {
     int rank, world;
     void *user;
     /* owner: picture `index` is complete (device work drained): planes in picture-store slot `slot` of ctx, motion field at mvf.
-     * Must not keep the pointers after returning (copy or send synchronously). */
-    int (*publish)(void *user, int index, ohevc_ctx *ctx, int slot, const void *mvf, size_t mvf_bytes);
+     * Must not keep the pointers after returning (copy or send synchronously).
+     * failed != 0: the owner could not decode / reconstruct the picture.  The transport still issues the picture's collectives - every
+     * rank issues exactly one publish or subscribe per exchanged picture, or the others' receives never complete - with an error mark
+     * that makes await_motion / await_planes of the subscribers return nonzero at once (payload undefined; mvf may be NULL). */
+    int (*publish)(void *user, int index, ohevc_ctx *ctx, int slot, const void *mvf, size_t mvf_bytes, int failed);
     /* everyone else: start receiving picture `index` from rank index % world; must not block */
     int (*subscribe)(void *user, int index, ohevc_ctx *ctx, int slot, size_t mvf_bytes);
     /* block until the motion field of remote picture `index` has arrived and copy it to mvf */
     int (*await_motion)(void *user, int index, void *mvf, size_t mvf_bytes);
     /* block until the planes of remote picture `index` have arrived and put them into picture-store slot `slot` (ohevc_pic_import) */
     int (*await_planes)(void *user, int index, ohevc_ctx *ctx, int slot);
+    /* the decoder dropped the buffer of remote picture `index` (its DPB entry was recycled) or will never look at it again: wait for what
+     * is still in flight for it and free the staging memory.  May be NULL. */
+    int (*release)(void *user, int index);
 } ohhip_frames_mode;
 
 /* switch the mode on (m != NULL) or off; call before the first picture */
@@ -44,6 +50,10 @@ int  ohhip_set_frames_mode(const ohhip_frames_mode *m);
 /* replace avctx->execute / execute2 by versions that skip the slice data of remote pictures (call after avcodec_open2) */
 struct AVCodecContext;
 void ohhip_frames_install(struct AVCodecContext *avctx);
+/* The decoder gave up on the picture it was decoding (avcodec_decode_video2 returned an error after hevc_frame_start): the open frame is
+ * aborted and, in frames mode, published as failed so that no other process waits for it.  In openHEVC proper the call belongs on the
+ * error return of hevc_decode_frame (hevc.c:4138-4144). */
+int  ohdec_backend_frame_failed(void);
 /* 1 if the picture in the host frame whose luma plane is data0 was reconstructed by this process (its samples are valid here) */
 int  ohhip_frames_is_local(const unsigned char *data0);
 #endif

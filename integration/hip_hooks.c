@@ -68,11 +68,25 @@ static int                 g_fm_on;
 static int                 g_fm_index;     /* pictures started so far (decoding order; one decoding thread in this mode) */
 static __thread int        t_remote;       /* the picture being parsed is reconstructed by another process: skip its slice data */
 static __thread int        t_publish;      /* the open frame is exchanged at its end (index of its g_bufs entry + 1) */
+static __thread int        t_publish_index;        /* its decoding-order index and the size of its motion field: what a failure report needs */
+static __thread size_t     t_publish_mvf_bytes;
 static int (*g_execute)(AVCodecContext *, int (*)(AVCodecContext *, void *), void *, int *, int, int);
 static int (*g_execute2)(AVCodecContext *, int (*)(AVCodecContext *, void *, int, int), void *, int *, int);
 
 int ohdec_backend_frame_done(void);
 int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
+
+/* frames mode: every rank issues exactly one collective per exchanged picture.  A picture its owner cannot complete is published all the
+ * same, marked failed (hip_frames.h), so that the subscribers' receives complete and their waits fail at once instead of hanging. */
+static void publish_failed(void)
+{
+    const int i = t_publish - 1;
+    t_publish = 0;
+    if (i < 0 || !g_fm_on)
+        return;
+    if (g_fm.publish(g_fm.user, t_publish_index, t_ctx, g_bufs[i].slot, NULL, t_publish_mvf_bytes, 1) != 0)
+        fprintf(stderr, "ohhip: publishing the failure of picture %d failed: %s\n", t_publish_index, ohevc_last_error());
+}
 
 static ohevc_ctx *thread_ctx(void)
 {
@@ -172,6 +186,9 @@ static int slot_of_frame_locked(ohevc_ctx *ctx, const HEVCContext *s, const AVFr
         g_bufs[i].fmt = cfmt;
         g_bufs[i].poc = INT_MIN;
         g_bufs[i].seq = -1;
+        g_bufs[i].index = -1;
+        g_bufs[i].remote = 0;
+        g_bufs[i].have_motion = g_bufs[i].have_planes = 1;
         g_nbufs++;
     }
     return i;
@@ -184,6 +201,8 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     const AVFrame *f;
     ohevc_ctx *ctx;
     int i, slot, fresh;
+    if (g_fm_on && t_publish)                   /* the previous picture of this thread never reached its frame end (a decoding error) */
+        publish_failed();
     if (ret < 0)
         return ret;
     if (!(ctx = thread_ctx()))
@@ -192,13 +211,26 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     if ((i = slot_of_frame_locked(ctx, s, f, &fresh)) < 0)
         return AVERROR(ENOMEM);
     slot = g_bufs[i].slot;
+    if (g_fm_on && g_bufs[i].remote && g_bufs[i].index >= 0 && g_fm.release) {
+        /* the buffer last held a remote picture: whatever is still in flight for it (planes nobody predicted from, a motion field
+         * nobody asked for) is waited for and freed before the slot's memory gets a new picture */
+        const int old = g_bufs[i].index;
+        g_bufs[i].index = -1;
+        pthread_mutex_unlock(&g_lock);
+        if (g_fm.release(g_fm.user, old) != 0)
+            g_error = 1;
+        pthread_mutex_lock(&g_lock);
+        for (i = 0; i < g_nbufs; i++)             /* the table may have been compacted meanwhile */
+            if (g_bufs[i].data0 == f->data[0])
+                break;
+    }
     g_bufs[i].ctx = ctx;
     g_bufs[i].poc = s->ref->poc;
     g_bufs[i].seq = s->ref->sequence;
     g_bufs[i].index = -1;
     g_bufs[i].remote = 0;
+    g_bufs[i].have_motion = g_bufs[i].have_planes = 1;
     t_remote = 0;
-    t_publish = 0;
     if (g_fm_on) {
         /* a picture nothing can predict from: sub-layer non-reference (even nal_unit_type below 16, H.265 table 7-1) in the
          * highest temporal sub-layer -- it is not exchanged */
@@ -206,7 +238,11 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         const size_t mvf_bytes = (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField);     /* hevc.c:178 */
         g_bufs[i].index = g_fm_index++;
         g_bufs[i].remote = g_bufs[i].index % g_fm.world != g_fm.rank;
-        g_bufs[i].have_motion = g_bufs[i].have_planes = !g_bufs[i].remote;
+        /* a picture that is not exchanged has nothing to wait for - H.265 8.3.2 only bars it from the Curr sets, a stream may keep it in
+         * a Foll set of later pictures */
+        g_bufs[i].have_motion = g_bufs[i].have_planes = !g_bufs[i].remote || !exchanged;
+        if (!exchanged)
+            g_bufs[i].index = -1;                  /* (nothing to release either) */
         if (g_bufs[i].remote) {
             const int index = g_bufs[i].index;
             pthread_mutex_unlock(&g_lock);
@@ -223,6 +259,8 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
             return 0;
         }
         t_publish = exchanged ? i + 1 : 0;
+        t_publish_index = g_bufs[i].index;
+        t_publish_mvf_bytes = mvf_bytes;
     }
     pthread_mutex_unlock(&g_lock);
     /* slice threads: the WPP-row / tile workers of this picture all record into ctx (ohhip_cabac_init binds them) */
@@ -263,7 +301,8 @@ int ohhip_frame_rps(HEVCContext *s)
                 return AVERROR(ENOMEM);
             known = !fresh && g_bufs[i].poc == ref->poc && g_bufs[i].seq == ref->sequence;
             slot = g_bufs[i].slot;
-            if (known && g_fm_on && !t_remote && g_bufs[i].remote && !g_bufs[i].have_motion) {
+            if (known && g_fm_on && !t_remote && g_bufs[i].remote && !g_bufs[i].have_motion && (t == ST_CURR_BEF || t == ST_CURR_AFT || t == LT_CURR)) {
+                /* (only pictures of the Curr sets can be the collocated picture or a prediction reference, H.265 8.3.2) */
                 /* the wait of the reference's frame threads for a collocated picture's motion field (hevc_mvs.c) */
                 const int index = g_bufs[i].index;
                 g_bufs[i].have_motion = 1;
@@ -279,6 +318,10 @@ int ohhip_frame_rps(HEVCContext *s)
                 g_bufs[i].poc = ref->poc;
                 g_bufs[i].seq = ref->sequence;
                 g_bufs[i].ctx = ctx;
+                /* a generated reference lives here now, not the (possibly remote, possibly un-awaited) picture the buffer held before */
+                g_bufs[i].remote = 0;
+                g_bufs[i].index = -1;
+                g_bufs[i].have_motion = g_bufs[i].have_planes = 1;
             }
             pthread_mutex_unlock(&g_lock);
             if (known)
@@ -533,6 +576,8 @@ static int frames_await_planes(HEVCContext *s)
         for (k = 0; k < s->rps[t].nb_refs; k++) {
             const HEVCFrame *ref = s->rps[t].ref[k];
             int i, index = -1, slot = -1;
+            if (t != ST_CURR_BEF && t != ST_CURR_AFT && t != LT_CURR)
+                continue;
             if (!ref || ref == s->ref || !ref->frame || !ref->frame->data[0])
                 continue;
             pthread_mutex_lock(&g_lock);
@@ -575,6 +620,8 @@ int ohdec_backend_frame_done(void)
     }
     st = ohevc_tables_end_frame(t_ctx, !g_defer_download);
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (g_fm_on && t_publish && getenv("OHHIP_TEST_FAIL_INDEX") && atoi(getenv("OHHIP_TEST_FAIL_INDEX")) == t_publish_index)
+        st = OHEVC_ERR_STATE;                   /* fault injection of tests/test_dist_cpu.py: the owner fails on this picture */
     if (st == OHEVC_OK && ohevc_frame_get_stats(t_ctx, &fs) == OHEVC_OK) {
         pthread_mutex_lock(&g_lock);
         g_end_frame_s += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
@@ -589,19 +636,34 @@ int ohdec_backend_frame_done(void)
     if (st != OHEVC_OK) {
         fprintf(stderr, "ohhip: frame failed (%d): %s\n", st, ohevc_last_error());
         g_error = 1;
+        if (g_fm_on && t_publish)
+            publish_failed();
         return -1;
     }
     if (g_fm_on && t_publish && t_s && t_s->ref) {
-        /* the picture is complete here (the copy-back above drained its device work): hand it to the other processes */
+        /* hand the picture to the other processes: ohevc_pic_export orders its copy behind the picture's `written` event (and waits
+         * for it), so this works with and without the deferred copy-back */
         const int i = t_publish - 1;
         t_publish = 0;
         if (g_fm.publish(g_fm.user, g_bufs[i].index, t_ctx, g_bufs[i].slot, t_s->ref->tab_mvf,
-                         (size_t)t_s->sps->min_pu_width * t_s->sps->min_pu_height * sizeof(MvField)) != 0) {
+                         (size_t)t_s->sps->min_pu_width * t_s->sps->min_pu_height * sizeof(MvField), 0) != 0) {
             fprintf(stderr, "ohhip: publishing picture %d failed: %s\n", g_bufs[i].index, ohevc_last_error());
             g_error = 1;
         }
     }
     return g_error ? -1 : 0;
+}
+
+/* hip_frames.h: the decoder gave up on the picture it was decoding */
+int ohdec_backend_frame_failed(void)
+{
+    if (t_frame_open && t_ctx) {
+        t_frame_open = 0;
+        ohevc_frame_abort(t_ctx);
+    }
+    if (g_fm_on && t_publish)
+        publish_failed();
+    return 0;
 }
 
 /* INTEGRATION.md section 3, last row, one decoding thread: hevc_decode_frame checks the decoded-picture-hash SEI on the HOST planes

@@ -78,19 +78,6 @@ inline int make_plane_set(const ohevc_plane planes[3], PlaneSet &ps, int align =
 #define OHEVC_GLOBAL_AS __attribute__((address_space(1)))
 #define OHEVC_CONST_AS __attribute__((address_space(4)))
 #endif
-// address spaces for loads whose kind the compiler cannot prove: global memory (global_load, not flat_load) and memory that is constant
-// for the kernel's lifetime and read at a wave-uniform address (s_load)
-#ifdef OHEVC_HIPEMU
-#define OHEVC_GLOBAL_AS
-#define OHEVC_CONST_AS
-#else
-#define OHEVC_GLOBAL_AS __attribute__((address_space(1)))
-#define OHEVC_CONST_AS __attribute__((address_space(4)))
-#endif
-// A job-driven kernel reads its job record first and most of its arguments only afterwards, and the compiler sinks every argument's
-// s_load to that first use: the workgroup then pays one dependent scalar round trip after the other (arguments -> job record ->
-// arguments -> arguments ...) before its first sample load.  Naming the arguments as operands of an empty asm at the kernel's entry
-// keeps their loads in one batch in front of the job record's (measured on the SAO kernel: profiles/r02s9_*; not in the emulator build).
 
 typedef short          s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int   u32x2 __attribute__((ext_vector_type(2)));

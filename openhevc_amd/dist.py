@@ -23,8 +23,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run). Returns (rank, world)."""
+def init_from_env(backend=None, timeout_s=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run). Returns (rank, world).
+    The process group gets a timeout (OHEVC_DIST_TIMEOUT_SECONDS, default 120 s): a peer that died must not hang the others for
+    gloo's 30 minutes (RCCL: until the watchdog fires)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
@@ -33,7 +35,10 @@ def init_from_env(backend=None):
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend, **kw)
+        import datetime
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("OHEVC_DIST_TIMEOUT_SECONDS", "120"))
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, world
 
 
@@ -149,12 +154,13 @@ import numpy as _np
 
 class _FramesMode(_C.Structure):
     """ohhip_frames_mode (integration/hip_frames.h)"""
-    PUBLISH = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_size_t)
+    PUBLISH = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_size_t, _C.c_int)
     SUBSCRIBE = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_size_t)
     AWAIT_MOTION = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_size_t)
     AWAIT_PLANES = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int)
+    RELEASE = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int)
     _fields_ = [("rank", _C.c_int), ("world", _C.c_int), ("user", _C.c_void_p), ("publish", PUBLISH), ("subscribe", SUBSCRIBE),
-                ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES)]
+                ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES), ("release", RELEASE)]
 
 
 class _Plane(_C.Structure):
@@ -187,7 +193,7 @@ class FrameExchange:
         self.pending = {}                                          # index -> (plane works, plane tensors, mvf work, mvf tensor)
         self.outgoing = []                                         # (works, tensors) of published pictures still in flight
         self.max_outstanding = max_outstanding
-        self.stats = dict(published=0, subscribed=0, awaited_motion=0, awaited_planes=0, bytes=0)
+        self.stats = dict(published=0, subscribed=0, awaited_motion=0, awaited_planes=0, released=0, failed=0, bytes=0)
         self.error = None
         for name, res, args in (("ohevc_ctx_has_device", _C.c_int, [_C.c_void_p]),
                                 ("ohevc_pic_planes", _C.c_int, [_C.c_void_p, _C.c_int, _C.c_void_p]),
@@ -198,7 +204,8 @@ class FrameExchange:
             f = getattr(lib, name)
             f.restype, f.argtypes = res, args
         self._cb = (_FramesMode.PUBLISH(self._guard(self._publish)), _FramesMode.SUBSCRIBE(self._guard(self._subscribe)),
-                    _FramesMode.AWAIT_MOTION(self._guard(self._await_motion)), _FramesMode.AWAIT_PLANES(self._guard(self._await_planes)))
+                    _FramesMode.AWAIT_MOTION(self._guard(self._await_motion)), _FramesMode.AWAIT_PLANES(self._guard(self._await_planes)),
+                    _FramesMode.RELEASE(self._guard(self._release)))
         self.mode = _FramesMode(self.rank, self.world, None, *self._cb)
 
     def _guard(self, fn):
@@ -229,7 +236,8 @@ class FrameExchange:
 
     def _alloc(self, on_device, sizes, mvf_bytes):
         dev = torch.device("cpu") if not on_device else self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
-        return [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes], torch.empty(mvf_bytes, dtype=torch.uint8)
+        # the motion-field message ends with 8 status bytes: [0] != 0 = the owner failed on this picture (hip_frames.h)
+        return [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes], torch.zeros(mvf_bytes + 8, dtype=torch.uint8)
 
     def _wire(self, planes):
         """What the collective carries: the staging tensors themselves, or host copies when the planes group cannot take device
@@ -255,9 +263,18 @@ class FrameExchange:
         return works, mw
 
     # ---- the four callbacks
-    def _publish(self, index, ctx, slot, mvf_ptr, mvf_bytes):
+    def _publish(self, index, ctx, slot, mvf_ptr, mvf_bytes, failed=0):
         on_device, sizes = self._geometry(ctx, slot)
         planes, mvf = self._alloc(on_device, sizes, mvf_bytes)
+        if failed:          # the collectives are issued all the same (one per exchanged picture on every rank), marked as failed
+            mvf[mvf_bytes] = 1
+            for t in planes:
+                t.zero_()
+            wire = self._wire(planes)
+            works, mw = self._post(wire, mvf, self.rank)
+            self.outgoing.append((works + ([mw] if mw is not None else []), wire, mvf))
+            self.stats["failed"] += 1
+            return
         if on_device:
             for c, t in enumerate(planes):
                 if self.lib.ohevc_pic_export(ctx, slot, c, t.data_ptr(), t.numel()) != 0:
@@ -282,18 +299,42 @@ class FrameExchange:
         planes, mvf = self._alloc(on_device, sizes, mvf_bytes)
         wire = self._wire(planes)
         works, mw = self._post(wire, mvf, index % self.world)
-        self.pending[index] = [works, planes, mw, mvf, on_device, wire]
+        self.pending[index] = [works, planes, mw, mvf, on_device, wire, False, False]      # ..., planes consumed, motion consumed
         self.stats["subscribed"] += 1
 
-    def _await_motion(self, index, mvf_ptr, mvf_bytes):
-        works, planes, mw, mvf, on_device, wire = self.pending[index]
+    def _check_failed(self, index, mw, mvf):
         if mw is not None:
             mw.wait()
+        if int(mvf[-8]) != 0:
+            raise RuntimeError(f"picture {index}: its owner (rank {index % self.world}) reported a decoding failure")
+
+    def _drop_if_consumed(self, index):
+        e = self.pending.get(index)
+        if e is not None and e[6] and e[7]:                        # planes and motion field both consumed: nothing left to keep
+            del self.pending[index]
+
+    def _await_motion(self, index, mvf_ptr, mvf_bytes):
+        works, planes, mw, mvf, on_device, wire = self.pending[index][:6]
+        self._check_failed(index, mw, mvf)
         _C.memmove(mvf_ptr, mvf.data_ptr(), mvf_bytes)
+        self.pending[index][7] = True
+        self._drop_if_consumed(index)
         self.stats["awaited_motion"] += 1
 
+    def _release(self, index):
+        """The decoder recycled the buffer of remote picture `index`: complete what is in flight for it, drop the staging tensors."""
+        e = self.pending.pop(index, None)
+        if e is None:
+            return
+        for w in e[0]:
+            w.wait()
+        if e[2] is not None:
+            e[2].wait()
+        self.stats["released"] += 1
+
     def _await_planes(self, index, ctx, slot):
-        works, planes, mw, mvf, on_device, wire = self.pending[index]
+        works, planes, mw, mvf, on_device, wire = self.pending[index][:6]
+        self._check_failed(index, mw, mvf)
         for w in works:
             w.wait()
         if wire is not planes:
@@ -311,6 +352,10 @@ class FrameExchange:
                 v[...] = t.numpy().reshape(v.shape)
         self.pending[index][1] = []                                # the planes are in the store now; the motion field may still be needed
         self.pending[index][5] = []
+        self.pending[index][6] = True
+        # a picture that is only predicted from (never the collocated picture) keeps its motion field until the decoder recycles the
+        # buffer (release); ~1.5 MB per 1080p picture, bounded by the DPB size
+        self._drop_if_consumed(index)
         self.stats["awaited_planes"] += 1
 
     def finish(self):
@@ -319,11 +364,11 @@ class FrameExchange:
             for w in works:
                 w.wait()
         self.outgoing.clear()
-        for works, _, mw, *_ in self.pending.values():
-            for w in works:
+        for e in self.pending.values():
+            for w in e[0]:
                 w.wait()
-            if mw is not None:
-                mw.wait()
+            if e[2] is not None:
+                e[2].wait()
         self.pending.clear()
         if self.world > 1:
             dist.barrier()

@@ -25,6 +25,7 @@
 #ifdef OHDEC_HIP
 int  ohdec_backend_open(void);
 int  ohdec_backend_frame_done(void);
+int  ohdec_backend_frame_failed(void);
 int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
 void ohdec_backend_close(void);
 /* frame-parallel decoding over processes: integration/hip_frames.h (the struct is passed through opaquely) */
@@ -38,6 +39,7 @@ static int  ohhip_frames_is_local(const unsigned char *data0) { (void)data0; ret
 static int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]) { (void)data; (void)linesize; return 0; }
 static int  ohdec_backend_open(void) { return 0; }
 static int  ohdec_backend_frame_done(void) { return 0; }
+static int  ohdec_backend_frame_failed(void) { return 0; }
 static void ohdec_backend_close(void) {}
 #endif
 
@@ -173,8 +175,10 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
         int out = 0;
         av_frame_unref(d->next);
         ret = avcodec_decode_video2(d->avctx, d->next, &got, &pkt);
-        if (ret < 0)
+        if (ret < 0) {
+            ohdec_backend_frame_failed();
             return -2;
+        }
         if (ohdec_backend_frame_done() < 0)
             return -3;
         av_frame_unref(d->frame);
@@ -194,8 +198,10 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
     }
     av_frame_unref(d->frame);
     ret = avcodec_decode_video2(d->avctx, d->frame, &got, &pkt);
-    if (ret < 0)
+    if (ret < 0) {
+        ohdec_backend_frame_failed();         /* the open frame is aborted and, in frames mode, published as failed */
         return -2;
+    }
     /* "frame complete, before output" (INTEGRATION.md section 3): a no-op for the CPU builds */
     if (ohdec_backend_frame_done() < 0)
         return -3;

@@ -309,6 +309,8 @@ class StreamParams:
     sao_offset_scale: Tuple[int, int] = (0, 0)   # PPS range extension: log2_sao_offset_scale_{luma,chroma} <= bit_depth - 10
     rext: int = 0                # range-extension SPS flags (implicit/explicit rdpcm, ts rotation/context, rice adaptation)
     nonref_leaves: int = 0       # random_access: pictures nothing references are coded as sub-layer non-reference pictures (TRAIL_N)
+    foll_leaves: int = 0         # ... and the picture decoded right after such a leaf keeps it in its RPS, not used by the current picture
+                                 # (a Foll set entry: H.265 8.3.2 only bars sub-layer non-reference pictures from the Curr sets)
     intra_smoothing_disabled: int = 0   # SPS range extension: no [1 2 1] / strong filtering of the intra reference samples (rext only)
     gop: str = "lowdelay_b"      # intra | lowdelay_p | lowdelay_b | random_access
     gop_size: int = 8
@@ -583,6 +585,12 @@ def plan_gop(p: StreamParams) -> List[Pic]:
         for q in order[i + 1:]:
             later_refs.update(refs[q])
         nt = NAL_TRAIL_N if p.nonref_leaves and poc not in later_refs else NAL_TRAIL_R
+        if p.foll_leaves and p.nonref_leaves and i >= 2 and pics[-1].nal_type == NAL_TRAIL_N:
+            q = pics[-1].poc                      # the leaf decoded just before: kept, unused (it lands in ST_FOLL)
+            if q < poc:
+                neg = sorted(neg + [(q, 0)], reverse=True)
+            else:
+                pos = sorted(pos + [(q, 0)])
         pics.append(Pic(poc, nt, st, neg, pos, (k, k if st == SLICE_B else 0)))
     return pics
 

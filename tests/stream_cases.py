@@ -59,4 +59,7 @@ CASES = {
                                  cross_component=1),
     # leaf pictures of the hierarchy as sub-layer non-reference pictures (TRAIL_N): the frame-parallel decoder does not exchange them
     "ra_8b_nonref_leaves": dict(gop="random_access", nframes=9, seed=133, nonref_leaves=1, width=208, height=120),
+    # ... and a leaf that stays in the reference picture set of the next picture without being used by it (a Foll entry): the frame-parallel
+    # decoder must neither wait for it nor trip over it
+    "ra_8b_foll_leaf": dict(gop="random_access", nframes=9, seed=134, nonref_leaves=1, foll_leaves=1, width=208, height=120),
 }

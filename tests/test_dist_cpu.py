@@ -152,9 +152,9 @@ def test_decoder_frame_parallel_over_processes(world, kind):
     from oracle import pystream as ps
     if not (ps.have(kind) and os.path.exists(os.path.join(os.path.dirname(ps.__file__), "libohsw.so"))):
         pytest.skip("GPU-backed decoder / software executor / emulator build not present (needs the reference tree once)")
-    names = ["ra_8b_ctb64", "ldb_10b", "weighted", "ra_10b_odd", "intra_8b", "slices", "tiles", "cip", "fmt444_8b", "ra_8b_nonref_leaves"]
+    names = ["ra_8b_ctb64", "ldb_10b", "weighted", "ra_10b_odd", "intra_8b", "slices", "tiles", "cip", "fmt444_8b", "ra_8b_nonref_leaves", "ra_8b_foll_leaf"]
     if kind == "hipemu":                # the emulated device code is slow: the streams that exercise export / import, skipping and reordering
-        names = ["ra_10b_odd", "weighted", "tiles", "ra_8b_nonref_leaves"]
+        names = ["ra_10b_odd", "weighted", "tiles", "ra_8b_nonref_leaves", "ra_8b_foll_leaf"]
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -180,7 +180,56 @@ def test_decoder_frame_parallel_over_processes(world, kind):
         got = [d for p in range(npics) for d in merged[p]]
         assert got == want, f"{name}: pictures differ from the single-process decoder"
         assert per_pic == 3
-        if name == "ra_8b_nonref_leaves":           # the four leaves of the GOP are nobody's reference: not exchanged
+        if name in ("ra_8b_nonref_leaves", "ra_8b_foll_leaf"):           # the four leaves of the GOP are nobody's reference: not exchanged
             assert sum(res[r][name][2]["published"] for r in range(world)) == npics - 4, res[0][name][2]
         if npics > 2 and name != "intra_8b":
             assert sum(res[r][name][2]["awaited_planes"] for r in range(world)) > 0, f"{name}: no reference picture ever crossed processes"
+
+
+# A picture its owner cannot complete is published all the same, marked failed (hip_frames.h): the other process's wait for it fails at
+# once - no hang until the process group's timeout - and nothing is left in flight when the exchange is torn down.
+def failing_worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OHHIP_SW_EXEC="1",
+                      OHHIP_TEST_FAIL_INDEX="1", OHEVC_DIST_TIMEOUT_SECONDS="60")
+    D.init_from_env("gloo")
+    from oracle import pystream as ps
+    from test_stream_cpu import load_golden
+    aus, _ = load_golden("ra_8b_ctb64")
+    import time
+    t0 = time.time()
+    failed_at = None
+    with ps.Decoder("hip") as d:
+        ex = D.FrameExchange(d.product_lib())
+        d.frames_mode(ex.mode)
+        for i, au in enumerate(aus):
+            if d.L.ohdec_decode(d.h, au, len(au), i + 1) < 0:
+                failed_at = i
+                break
+        ex.finish()                                 # must return: every collective issued has a partner
+        d.frames_mode(None)
+    q.put((rank, failed_at, dict(ex.stats), time.time() - t0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_owner_failure_reaches_the_other_process():
+    from oracle import pystream as ps
+    if not (ps.have("hip") and os.path.exists(os.path.join(os.path.dirname(ps.__file__), "libohsw.so"))):
+        pytest.skip("GPU-backed decoder / software executor build not present (needs the reference tree once)")
+    port = free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (f, st, dt) for r, f, st, dt in (q.get(timeout=100) for _ in range(2))}
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert res[1][0] == 1 and res[1][1]["failed"] == 1          # picture 1 (decoding order) is rank 1's: its frame end reports the failure ...
+    assert res[0][0] is not None and res[0][0] >= 2              # ... and rank 0 fails on the first picture that predicts from it
+    assert res[0][2] < 30 and res[1][2] < 30                     # at once, not after a timeout

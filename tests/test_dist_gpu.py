@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_decoder_frame_parallel_two_processes_one_gpu():
     from oracle import pystream as ps
     assert ps.have("hip"), "oracle/_ref/libopenhevc_hip.so missing: run __graft_entry__.build() where /root/reference exists"
-    names = ["ra_8b_ctb64", "ra_10b_odd", "ldb_10b", "weighted", "slices", "tiles", "cip", "fmt444_8b", "ra_14b_weighted", "ra_8b_nonref_leaves"]
+    names = ["ra_8b_ctb64", "ra_10b_odd", "ldb_10b", "weighted", "slices", "tiles", "cip", "fmt444_8b", "ra_14b_weighted", "ra_8b_nonref_leaves", "ra_8b_foll_leaf"]
     world, port = 2, free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
