@@ -56,6 +56,10 @@ int ohevc_debug_set_level_launch(int mode);
  * launches per level.  Env OHEVC_FUSE_INTRA sets the initial value.  Returns the previous setting. */
 int ohevc_debug_set_fuse_intra(int on);
 int ohevc_debug_set_record_only(int on);
+/* 1 (default): the intra blocks of a dependency level go through the packed kernel (ohevc_dev_intra_recon_sorted: N lanes per block,
+ * residual added in registers); 0: one wavefront per block (ohevc_dev_intra_recon_batch).  Pictures with constrained intra prediction
+ * always take the latter.  Returns the previous setting.  Environment: OHEVC_INTRA_PACK. */
+int ohevc_debug_set_intra_pack(int on);
 /* A/B of ohevc_tables_derive_filters: 1 (default) the deblocking maps travel and the device derives the edges (ohevc_dev_deblock_maps);
  * 0 the host derives one job per edge (the only form record-only contexts and the filter-lag emulation of 16x16 CTBs have).
  * Returns the previous setting. */

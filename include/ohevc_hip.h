@@ -308,6 +308,14 @@ int ohevc_dev_levels(const ohevc_plane planes[3], int bit_depth, const ohevc_lev
 int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals, int njobs,
                                 const ohevc_intra_cip *cip, const int16_t *coeffs, void *stream);
 
+/* The same work with the jobs SORTED BY SIZE - count_by_size[0] blocks of 4x4 first, then the 8x8, 16x16 and 32x32 ones; residuals[i]
+ * (NULL: prediction only) belongs to jobs[i] as above.  N lanes serve an N x N block, so 16 / 8 / 4 / 2 blocks share a wavefront; the
+ * neighbour samples are fetched with the substitution rules of hevcpred_template.c:251-286 folded into their addresses, the residual row is
+ * added in registers and every row is stored once (no prediction store, no read-back).  Jobs marked OHEVC_INTRA2_CIP are NOT taken here
+ * (their substitution walk is sequential: ohevc_dev_intra_recon_batch); neither are OHEVC_TU_CROSS / OHEVC_TU_PCM residuals. */
+int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals,
+                                 const int32_t count_by_size[4], const int16_t *coeffs, void *stream);
+
 /* ---- 2.6b every intra-coded block of a picture in ONE launch, coding-tree blocks as tasks (the ctx layer's executor).  Inside a CTB the
  * reference reconstructs block after block in decoding order -- intra_pred[..] (hevcpred_template.c:30-357), then the residual of
  * that block (hevc_cabac.c:1868-1949), whose samples the next block's prediction reads; between CTBs only the wavefront order of

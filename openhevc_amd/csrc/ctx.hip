@@ -94,6 +94,7 @@ void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream sc
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
+static int g_intra_pack = getenv("OHEVC_INTRA_PACK") ? atoi(getenv("OHEVC_INTRA_PACK")) : 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
 // how long a frame thread waits for another thread to issue the frame end of a reference picture before it gives up (a decoding thread
@@ -312,6 +313,7 @@ extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
 }
 
 extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
+extern "C" int ohevc_debug_set_intra_pack(int on) { const int prev = g_intra_pack; g_intra_pack = on != 0; return prev; }
 extern "C" int ohevc_debug_set_fuse_intra(int on) { const int prev = g_fuse_intra; g_fuse_intra = on != 0; return prev; }
 extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
 
@@ -1333,7 +1335,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_mc = c->mc.empty() ? 0 : stage_put(parts, total, c->mc.data(), c->mc.size() * sizeof(ohevc_mc_job));
     const size_t off_mcs = c->mc_small.empty() ? 0 : stage_put(parts, total, c->mc_small.data(), c->mc_small.size() * sizeof(ohevc_mc_job));
     // per level: the intra jobs, then every touched (size, kind) bin back to back (one segmented launch per level)
-    struct LevelOff { size_t intra = 0, intra_res = 0, tu_first = 0; };
+    struct LevelOff { size_t intra = 0, intra_res = 0, tu_first = 0; int32_t count[4] = {0, 0, 0, 0}; bool packed = false; };
     std::vector<LevelOff> loff((size_t)(c->max_level + 1));
     for (int l = 0; l <= c->max_level; l++) {
         LevelBins &lb = c->levels[l];
@@ -1344,6 +1346,29 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             std::reverse(lb.intra.begin(), lb.intra.end());
             std::reverse(lb.intra_res.begin(), lb.intra_res.end());
             for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); std::reverse(lb.tu[b >> 4][b & 15].begin(), lb.tu[b >> 4][b & 15].end()); }
+        }
+        if (!lb.intra.empty() && c->cips.empty() && g_intra_pack) {
+            // the packed kernel (ohevc_dev_intra_recon_sorted) wants the level's blocks by size: N lanes serve an N x N block, so the
+            // blocks of a wavefront must be of one size.  Stable counting sort of the jobs and of the residual records riding with them.
+            const bool paired = lb.intra_res.size() == lb.intra.size();
+            static thread_local std::vector<ohevc_intra_job> tj;
+            static thread_local std::vector<ohevc_tu_job> tr;
+            int cnt[4] = {0, 0, 0, 0}, pos[4];
+            for (const ohevc_intra_job &j : lb.intra) cnt[j.log2_size - 2]++;
+            pos[0] = 0; pos[1] = cnt[0]; pos[2] = pos[1] + cnt[1]; pos[3] = pos[2] + cnt[2];
+            if (cnt[0] != (int)lb.intra.size() && cnt[1] != (int)lb.intra.size() && cnt[2] != (int)lb.intra.size() && cnt[3] != (int)lb.intra.size()) {
+                tj.resize(lb.intra.size());
+                if (paired) tr.resize(lb.intra.size());
+                for (size_t k = 0; k < lb.intra.size(); k++) {
+                    const int d = pos[lb.intra[k].log2_size - 2]++;
+                    tj[d] = lb.intra[k];
+                    if (paired) tr[d] = lb.intra_res[k];
+                }
+                lb.intra.swap(tj);
+                if (paired) lb.intra_res.swap(tr);
+            }
+            for (int k = 0; k < 4; k++) loff[l].count[k] = cnt[k];
+            loff[l].packed = true;
         }
         if (!lb.intra.empty()) loff[l].intra = stage_put(parts, total, lb.intra.data(), lb.intra.size() * sizeof(ohevc_intra_job));
         if (!lb.intra_res.empty()) loff[l].intra_res = stage_put(parts, total, lb.intra_res.data(), lb.intra_res.size() * sizeof(ohevc_tu_job));
@@ -1436,7 +1461,11 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     for (int level = 0; level <= last_separate; level++) {
         LevelBins &lb = c->levels[level];
         if (!lb.intra.empty()) {
-            if (lb.intra_res.size() == lb.intra.size())
+            if (loff[level].packed)
+                rc = ohevc_dev_intra_recon_sorted(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
+                                                  lb.intra_res.size() == lb.intra.size() ? reinterpret_cast<const ohevc_tu_job *>(base + loff[level].intra_res) : nullptr,
+                                                  loff[level].count, d_coeffs, c->stream);
+            else if (lb.intra_res.size() == lb.intra.size())
                 rc = ohevc_dev_intra_recon_batch(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
                                                  reinterpret_cast<const ohevc_tu_job *>(base + loff[level].intra_res), (int)lb.intra.size(),
                                                  c->cips.empty() ? nullptr : reinterpret_cast<const ohevc_intra_cip *>(base + off_cips), d_coeffs, c->stream);

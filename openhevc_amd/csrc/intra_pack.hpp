@@ -1,0 +1,347 @@
+// intra_pack.hpp -- intra prediction + the block's own residual, N lanes per N x N block: 16 / 8 / 4 / 2 blocks share a wavefront.
+// (included by tu_kernels.hip behind the residual bodies it reuses)
+//
+// The first intra kernel (intra_body.hpp) gives a block a whole wavefront: a 4x4 block is 16 samples on 64 lanes, the availability cascade of
+// hevcpred_template.c:251-286 is a chain of LDS hand-offs (~10 barriers), and the block's residual - the other half of what
+// hls_transform_unit does per transform block (hevc.c:1214-1215, 1260-1290) - reads the prediction back from memory behind a cache
+// invalidate.  A dependency level of a picture lasts as long as one block, so that chain of 7-9 dependent memory round trips was the
+// frame-end hook.  Here:
+//   * lane (g, i) = row i of block g.  It loads top[i], top[N + i], left[i], left[N + i] and the corner - five loads, issued together,
+//     whose ADDRESSES already contain the substitution rules: an unavailable group (below-left, left, corner, above, above-right in the
+//     reference's scan order) takes the last sample of the nearest available group before it, else the first sample of the first
+//     available group after it, else 1 << (bit_depth - 1): hevcpred_template.c:251-286 in closed form, no hand-off;
+//   * the coefficient block is requested in the same round (its address comes from the residual record, read next to the job record);
+//   * smoothing (:289-327) is one pass over the block's LDS arrays, the predictors (:359-537) produce row i in registers;
+//   * the residual row comes out of the same lane (the batched bodies' lane map IS lane = (block, row): tu_idct_add_body, tu_rows_body; the
+//     4x4 transforms in a row form), is added in registers and the row is stored once: no prediction store, no read-back.
+// Three dependent memory round trips per level (records -> samples + coefficients -> store).  Constrained-intra jobs keep the first kernel
+// (their substitution walk is sequential, hevcpred_template.c:185-249).
+#pragma once
+
+namespace ohevc {
+
+template <int LOG2N> struct IntraPackLayout {
+    static constexpr int N = 1 << LOG2N, G = 64 / N;       // lanes per block, blocks per wavefront
+    static constexpr int ARR = 2 * N + 2;                  // top / left: element k (-1 .. 2N-1) at [k + 1]; one pad
+    static constexpr int REF = 3 * N + 2;                  // angular reference: element k (-N .. 2N+1) at [k + N]
+    static constexpr int INTS = 4 * ARR + REF;             // top, left, filtered top, filtered left, ref
+};
+constexpr int kIntraPackInts = 16 * IntraPackLayout<2>::INTS;      // the 4x4 form is the largest: 864 ints per wavefront
+static_assert(IntraPackLayout<3>::G * IntraPackLayout<3>::INTS <= kIntraPackInts && IntraPackLayout<4>::G * IntraPackLayout<4>::INTS <= kIntraPackInts &&
+              IntraPackLayout<5>::G * IntraPackLayout<5>::INTS <= kIntraPackInts, "LDS arrays of one wavefront");
+
+#define PACK_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// row i of the 4x4 inverse DCT / DST-VII (hevcdsp_template.c:170-222): pass 1 produces row i of the intermediate from all four
+// columns (the weights T[k][i] depend on the lane), pass 2 is the 4-point transform of that row
+template <bool DST>
+__device__ __forceinline__ void tu4_row(const u32x4 a, const u32x4 b, const int i, const int bit_depth, int *res)
+{
+    const unsigned raw[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+    int c[4][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        c[k / 2][(k % 2) * 2]     = (int)(short)(raw[k] & 0xffffu);
+        c[k / 2][(k % 2) * 2 + 1] = (int)raw[k] >> 16;
+    }
+    int w0, w1, w2, w3;                                   // T[k][i], k = 0..3
+    if constexpr (DST) {
+        w0 = i == 0 ? 29 : i == 1 ? 55 : i == 2 ? 74 : 84;
+        w1 = i == 0 ? 74 : i == 1 ? 74 : i == 2 ? 0 : -74;
+        w2 = i == 0 ? 84 : i == 1 ? -29 : i == 2 ? -74 : 55;
+        w3 = i == 0 ? 55 : i == 1 ? -84 : i == 2 ? 74 : -29;
+    } else {
+        w0 = 64;
+        w1 = i == 0 ? 83 : i == 1 ? 36 : i == 2 ? -36 : -83;
+        w2 = (i == 0 || i == 3) ? 64 : -64;
+        w3 = i == 0 ? 36 : i == 1 ? -83 : i == 2 ? 83 : -36;
+    }
+    auto clip16 = [](int v) { return v < -32768 ? -32768 : v > 32767 ? 32767 : v; };
+    int m[4];
+#pragma unroll
+    for (int col = 0; col < 4; col++) m[col] = clip16((w0 * c[0][col] + w1 * c[1][col] + w2 * c[2][col] + w3 * c[3][col] + 64) >> 7);
+    const int shift2 = 20 - bit_depth, add = 1 << (shift2 - 1);
+    if constexpr (DST) {
+        res[0] = 29 * m[0] + 74 * m[1] + 84 * m[2] + 55 * m[3] + add;
+        res[1] = 55 * m[0] + 74 * m[1] - 29 * m[2] - 84 * m[3] + add;
+        res[2] = 74 * (m[0] - m[2] + m[3]) + add;
+        res[3] = 84 * m[0] - 74 * m[1] + 55 * m[2] - 29 * m[3] + add;
+    } else {
+        const int e0 = 64 * (m[0] + m[2]) + add, e1 = 64 * (m[0] - m[2]) + add;
+        const int o0 = 83 * m[1] + 36 * m[3], o1 = 36 * m[1] - 83 * m[3];
+        res[0] = e0 + o0; res[1] = e1 + o1; res[2] = e1 - o1; res[3] = e0 - o0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) res[k] >>= shift2;
+}
+
+// row i of an 8x8 / 16x16 / 32x32 inverse DCT: steps A-C of tu_idct_add_body on the block's wave-private LDS tile, with the 16-byte
+// coefficient chunks of this lane (chunk q * N + i) already in registers
+template <int LOG2N, bool ASM>
+__device__ __forceinline__ void idct_row(unsigned char *blk, const int i, const u32x4 *cq, const int bit_depth, int *t)
+{
+    using L = TuLayout<LOG2N>;
+    constexpr int N = L::N, RS = L::RS;
+    constexpr PairTab<N> pt{};
+#pragma unroll
+    for (int q = 0; q < N / 8; q++) {
+        const int c = q * N + i;
+        *reinterpret_cast<u32x4 *>(blk + (c / (N / 8)) * RS + (c % (N / 8)) * 16) = cq[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned p[N / 2];
+    {
+        const unsigned short *col = reinterpret_cast<const unsigned short *>(blk) + i;
+#pragma unroll
+        for (int m = 0; m < N / 2; m++)
+            p[m] = (unsigned)col[pt.lo[m] * (RS / 2)] | ((unsigned)col[pt.hi[m] * (RS / 2)] << 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+    Idct1D<N, ASM>::run(p, t, 64);
+    {
+        unsigned short *dst = reinterpret_cast<unsigned short *>(blk) + slot_of_rt(N, i);
+#pragma unroll
+        for (int r = 0; r < N; r += 2) {
+            const unsigned pk = sat_pack_i16(t[r] >> 7, t[r + 1] >> 7);
+            dst[r * (RS / 2)]       = (unsigned short)(pk & 0xffffu);
+            dst[(r + 1) * (RS / 2)] = (unsigned short)(pk >> 16);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const u32x4 *rowp = reinterpret_cast<const u32x4 *>(blk + i * RS);
+#pragma unroll
+        for (int q = 0; q < N / 8; q++) {
+            const u32x4 v = rowp[q];
+            p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+        }
+    }
+    const int shift2 = 20 - bit_depth;
+    Idct1D<N, ASM>::run(p, t, 1 << (shift2 - 1));
+#pragma unroll
+    for (int k = 0; k < N; k++) t[k] >>= shift2;
+}
+
+template <int LOG2N, typename Pixel>
+__device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds, const int lane, const int job0, const int njobs, const PlaneSet planes,
+                                                const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
+                                                const int16_t *__restrict__ coeffs, const int bit_depth)
+{
+    using IL = IntraPackLayout<LOG2N>;
+    constexpr int N = IL::N;
+    const int g = lane / N, i = lane % N;
+    const bool valid = job0 + g < njobs;
+    const int ji = valid ? job0 + g : njobs - 1;           // lanes behind the last job repeat it and do not store
+
+    // ---- round 1: the two records of the block
+    const u32x4 jw = reinterpret_cast<const u32x4 *>(jobs)[ji];
+    u32x4 rw = { 0u, 0u, 0u, 0u };
+    if (residuals != nullptr) rw = reinterpret_cast<const u32x4 *>(residuals)[ji];
+    const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
+    const int bl_size = jw.z & 0xff, tr_size = (jw.z >> 8) & 0xff;
+    const int kind = (int)((rw.y >> 8) & 0xff) - 1;        // -1: no residual
+    const int stride = PLANE_STRIDE3(planes, jplane);
+    unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
+    const bool c_bl = flags & OHEVC_INTRA_BOTTOM_LEFT, c_l = flags & OHEVC_INTRA_LEFT, c_ul = flags & OHEVC_INTRA_UP_LEFT;
+    const bool c_u = flags & OHEVC_INTRA_UP, c_ur = flags & OHEVC_INTRA_UP_RIGHT;
+
+    // ---- round 2: samples and coefficients.  Positions relative to the block's first sample; `none` = 1 << (bit_depth - 1).
+    // Substitutes (:251-286): the last sample of a group in scan order is left[N] / left[0] / corner / top[N-1], the first left[N-1] / top[0] / top[N]
+    struct Pos { int dx, dy; bool none; };
+    auto after_ul = [&]() -> Pos { return c_u ? Pos{0, -1, false} : c_ur ? Pos{N, -1, false} : Pos{0, 0, true}; };             // first available group after the corner
+    auto before_ul = [&]() -> Pos { return c_l ? Pos{-1, 0, false} : c_bl ? Pos{-1, N, false} : Pos{0, 0, true}; };           // nearest available group before the corner
+    Pos p_bl, p_l, p_ul, p_u, p_ur;
+    {
+        const Pos a = after_ul(), b = before_ul();
+        const Pos ul_or_after = c_ul ? Pos{-1, -1, false} : a;
+        p_bl = c_l ? Pos{-1, N - 1, false} : ul_or_after;                                     // nothing before: first available after
+        p_l = c_bl ? Pos{-1, N, false} : ul_or_after;
+        p_ul = !b.none ? b : a;
+        p_u = c_ul ? Pos{-1, -1, false} : !b.none ? b : (c_ur ? Pos{N, -1, false} : Pos{0, 0, true});
+        p_ur = c_u ? Pos{N - 1, -1, false} : c_ul ? Pos{-1, -1, false} : b;                    // nothing after
+    }
+    auto REC = [&](const Pos p) -> int {
+        return (int)*reinterpret_cast<const Pixel *>(blk + (ptrdiff_t)p.dy * stride + (ptrdiff_t)p.dx * (int)sizeof(Pixel));
+    };
+    const int kt = i < tr_size ? i : tr_size - 1, kb = i < bl_size ? i : bl_size - 1;        // beyond the picture: the last valid sample (:111-114, 164-183)
+    const Pos q_t0 = c_u ? Pos{i, -1, false} : p_u, q_t1 = c_ur ? Pos{N + kt, -1, false} : p_ur;
+    const Pos q_l0 = c_l ? Pos{-1, i, false} : p_l, q_l1 = c_bl ? Pos{-1, N + kb, false} : p_bl;
+    const Pos q_c = c_ul ? Pos{-1, -1, false} : p_ul;
+    int v_t0 = REC(q_t0), v_t1 = REC(q_t1), v_l0 = REC(q_l0), v_l1 = REC(q_l1), v_c = REC(q_c);
+    // the coefficients of the transforms (the row kinds read theirs inside tu_rows_residual)
+    constexpr int NCQ = LOG2N == 2 ? 2 : N / 8;
+    u32x4 cq[NCQ];
+    const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + (is_idct ? rw.z : 0u));
+#pragma unroll
+        for (int q = 0; q < NCQ; q++) {
+            cq[q] = u32x4{ 0u, 0u, 0u, 0u };
+            if (is_idct) cq[q] = src[LOG2N == 2 ? q : q * N + i];
+        }
+    }
+    const int dflt = 1 << (bit_depth - 1);
+    if (q_t0.none) v_t0 = dflt;
+    if (q_t1.none) v_t1 = dflt;
+    if (q_l0.none) v_l0 = dflt;
+    if (q_l1.none) v_l1 = dflt;
+    if (q_c.none) v_c = dflt;
+
+    int *top = ish + g * IL::INTS + 1, *left = top + IL::ARR, *ftop = left + IL::ARR, *fleft = ftop + IL::ARR, *ref = fleft + IL::ARR - 1 + N;
+    top[i] = v_t0; top[N + i] = v_t1; left[i] = v_l0; left[N + i] = v_l1;
+    if (i == 0) { top[-1] = v_c; left[-1] = v_c; }
+    PACK_SYNC();
+
+    // ---- reference smoothing (:289-327)
+    const int *t = top, *l = left;
+    if (LOG2N != 2 && !(flags & OHEVC_INTRA_NO_SMOOTHING) && mode != 1) {
+        const int dv = mode > 26 ? mode - 26 : 26 - mode, dh = mode > 10 ? mode - 10 : 10 - mode;
+        const int dist = dv < dh ? dv : dh, thresh = LOG2N == 3 ? 7 : LOG2N == 4 ? 1 : 0;
+        if (dist > thresh) {
+            bool strong = false;
+            if constexpr (LOG2N == 5) {
+                const int lim = 1 << (bit_depth - 5);
+                int a = top[-1] + top[63] - 2 * top[31], b = left[-1] + left[63] - 2 * left[31];
+                a = a < 0 ? -a : a; b = b < 0 ? -b : b;
+                strong = (flags & OHEVC_INTRA_STRONG) && a < lim && b < lim;
+            }
+            if (strong) {
+                const int t0 = top[-1], t63 = top[2 * N - 1], l0 = left[-1], l63 = left[2 * N - 1];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int k = h * N + i;
+                    ftop[k]  = k < 2 * N - 1 ? ((2 * N - 1 - k) * t0 + (k + 1) * t63 + N) >> (LOG2N + 1) : t63;
+                    fleft[k] = k < 2 * N - 1 ? ((2 * N - 1 - k) * l0 + (k + 1) * l63 + N) >> (LOG2N + 1) : l63;
+                }
+                if (i == 0) { ftop[-1] = t0; fleft[-1] = l0; }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int k = h * N + i;
+                    ftop[k]  = k < 2 * N - 1 ? (top[k + 1] + 2 * top[k] + top[k - 1] + 2) >> 2 : top[k];
+                    fleft[k] = k < 2 * N - 1 ? (left[k + 1] + 2 * left[k] + left[k - 1] + 2) >> 2 : left[k];
+                }
+                if (i == 0) ftop[-1] = fleft[-1] = (left[0] + 2 * left[-1] + top[0] + 2) >> 2;
+            }
+            t = ftop; l = fleft;
+            PACK_SYNC();
+        }
+    }
+
+    // ---- prediction of row i
+    int pred[N];
+    const int maxv = (1 << bit_depth) - 1;
+    const bool luma_edge = (flags & OHEVC_INTRA_LUMA_EDGE) && N < 32;
+    if (mode == 0) {                                       // pred_planar, :359-372
+        const int ly = l[i], tn = t[N], ln = l[N];
+#pragma unroll
+        for (int x = 0; x < N; x++) pred[x] = ((N - 1 - x) * ly + (x + 1) * tn + (N - 1 - i) * t[x] + (i + 1) * ln + N) >> (LOG2N + 1);
+    } else if (mode == 1) {                                // pred_dc, :388-417
+        int part = l[i] + t[i];
+#pragma unroll
+        for (int o = N / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+        const int dc = (part + N) >> (LOG2N + 1);
+#pragma unroll
+        for (int x = 0; x < N; x++) pred[x] = dc;
+        if (luma_edge) {
+            if (i == 0) {
+#pragma unroll
+                for (int x = 1; x < N; x++) pred[x] = (t[x] + 3 * dc + 2) >> 2;
+                pred[0] = (l[0] + 2 * dc + t[0] + 2) >> 2;
+            } else {
+                pred[0] = (l[i] + 3 * dc + 2) >> 2;
+            }
+        }
+    } else {                                               // pred_angular, :419-510
+        const int angle = kIntraAngle[mode - 2], last = (N * angle) >> 5;
+        const bool vertical = mode >= 18;
+        const int *mainr = vertical ? t : l, *sider = vertical ? l : t;
+        ref[i] = mainr[i - 1];
+        ref[N + i] = mainr[N + i - 1];
+        if (i == 0) { ref[2 * N] = mainr[2 * N - 1]; ref[2 * N + 1] = 0; }
+        if (angle < 0 && last < -1) {
+            const int inv = kIntraInvAngle[mode - 11];
+            const int k = -1 - i;                           // k = -1 .. last (last >= -N)
+            if (k >= last) ref[k] = sider[-1 + ((k * inv + 128) >> 8)];
+        }
+        PACK_SYNC();
+        if (vertical) {
+            const int pos = (i + 1) * angle, i2 = pos >> 5, fact = pos & 31;
+            int r0 = ref[i2 + 1];
+#pragma unroll
+            for (int x = 0; x < N; x++) {
+                const int r1 = ref[x + i2 + 2];
+                pred[x] = ((32 - fact) * r0 + fact * r1 + 16) >> 5;
+                r0 = r1;
+            }
+            if (luma_edge && mode == 26) { const int v = t[0] + ((l[i] - l[-1]) >> 1); pred[0] = v < 0 ? 0 : v > maxv ? maxv : v; }
+        } else {
+#pragma unroll
+            for (int x = 0; x < N; x++) {
+                const int pos = (x + 1) * angle, i2 = pos >> 5, fact = pos & 31;
+                pred[x] = ((32 - fact) * ref[i + i2 + 1] + fact * ref[i + i2 + 2] + 16) >> 5;
+            }
+            if (luma_edge && mode == 10 && i == 0) {
+#pragma unroll
+                for (int x = 0; x < N; x++) { const int v = l[0] + ((t[x] - t[-1]) >> 1); pred[x] = v < 0 ? 0 : v > maxv ? maxv : v; }
+            }
+        }
+    }
+
+    // ---- the row as it will lie in memory
+    constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
+    unsigned px[ROWDW];
+#pragma unroll
+    for (int d = 0; d < ROWDW; d++) {
+        if constexpr (sizeof(Pixel) == 1) px[d] = (unsigned)pred[4 * d] | ((unsigned)pred[4 * d + 1] << 8) | ((unsigned)pred[4 * d + 2] << 16) | ((unsigned)pred[4 * d + 3] << 24);
+        else px[d] = (unsigned)pred[2 * d] | ((unsigned)pred[2 * d + 1] << 16);
+    }
+    unsigned char *row = blk + (size_t)i * stride;
+
+    // ---- the block's residual, row i (hevc_cabac.c:1868-1949), added in registers (transform_add, hevcdsp_template.c:45-111)
+    if (kind >= 0) {
+        int res[N];
+        if (is_idct) {
+            if constexpr (LOG2N == 2) {
+                if (kind == OHEVC_TU_DST4) tu4_row<true>(cq[0], cq[1], i, bit_depth, res);
+                else                       tu4_row<false>(cq[0], cq[1], i, bit_depth, res);
+            } else {
+                idct_row<LOG2N, LOG2N >= 4>(tu_lds + g * TuLayout<LOG2N>::BLK, i, cq, bit_depth, res);
+            }
+        } else {
+            tu_rows_residual<LOG2N>(rw, i, coeffs, bit_depth, kind, res);
+        }
+        finish_row<N, Pixel>(row, px, res, bit_depth, valid);
+    } else if (valid) {
+        store_row<N, Pixel>(row, px);
+    }
+}
+
+#undef PACK_SYNC
+
+// jobs sorted by size: wavefront w serves 64 / N consecutive blocks of the segment it falls into
+struct IntraPackSegs {
+    int first_wave[5];               // first_wave[s] .. first_wave[s + 1]: the wavefronts of the (4 << s)-sample blocks
+    int first_job[4], njobs[4];
+};
+
+template <typename Pixel>
+__global__ __launch_bounds__(64) void intra_pack_kernel(PlaneSet planes, const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
+                                                        IntraPackSegs segs, int bit_depth, const int16_t *__restrict__ coeffs)
+{
+    __shared__ int ish[kIntraPackInts];
+    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[TuLayout<5>::WAVE_BYTES];
+    static_assert(TuLayout<4>::WAVE_BYTES <= TuLayout<5>::WAVE_BYTES && TuLayout<3>::WAVE_BYTES <= TuLayout<5>::WAVE_BYTES, "transform tile");
+    const int w = blockIdx.x, lane = threadIdx.x;
+    const int s = w >= segs.first_wave[3] ? 3 : w >= segs.first_wave[2] ? 2 : w >= segs.first_wave[1] ? 1 : 0;       // wave-uniform
+    const int local = w - segs.first_wave[s];
+    const ohevc_intra_job *j = jobs + segs.first_job[s];
+    const ohevc_tu_job *r = residuals ? residuals + segs.first_job[s] : nullptr;
+    const int n = segs.njobs[s];
+    if (s == 0)      intra_pack_body<2, Pixel>(ish, tu_lds, lane, local * 16, n, planes, j, r, coeffs, bit_depth);
+    else if (s == 1) intra_pack_body<3, Pixel>(ish, tu_lds, lane, local * 8, n, planes, j, r, coeffs, bit_depth);
+    else if (s == 2) intra_pack_body<4, Pixel>(ish, tu_lds, lane, local * 4, n, planes, j, r, coeffs, bit_depth);
+    else             intra_pack_body<5, Pixel>(ish, tu_lds, lane, local * 2, n, planes, j, r, coeffs, bit_depth);
+}
+
+}  // namespace ohevc

@@ -1313,17 +1313,11 @@ __global__ __launch_bounds__(256) void tu_4x4_kernel(PlaneSet planes, const ohev
 // ------------------------------------------------------------------ DC-only / transform-skip / bypass (+rdpcm): one lane per row
 // idct_dc :303-316, transform_skip :139-163, transform_rdpcm :114-136 (int16 wrap-around of the in-place reference
 // is reproduced by truncating to int16 after the modular prefix sum).
-template <int LOG2N, typename Pixel>
-__device__ __forceinline__ void tu_rows_body(int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
-                                             const int16_t *__restrict__ coeffs, int bit_depth, int kind)
+// residual row r of the block described by job record `jraw` (kind != OHEVC_TU_PCM: those samples replace the block)
+template <int LOG2N>
+__device__ __forceinline__ void tu_rows_residual(const u32x4 jraw, const int r, const int16_t *__restrict__ coeffs, const int bit_depth, const int kind, int *res)
 {
     constexpr int N = 1 << LOG2N;
-    const int tid = wg * 256 + threadIdx.x;
-    const int job = tid >> LOG2N, r = tid & (N - 1);
-    if (job >= njobs) return;
-    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
-    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
-    int res[N];
     if (kind == OHEVC_TU_DC) {
         const int dc = (int)jraw.y >> 16, shift = 14 - bit_depth, add = shift > 0 ? 1 << (shift - 1) : 0;       // BIT_DEPTH 14: see tu_generic.hpp
         const int v = (((dc + 1) >> 1) + add) >> shift;
@@ -1362,6 +1356,40 @@ __device__ __forceinline__ void tu_rows_body(int wg, const PlaneSet planes, cons
 #pragma unroll
         for (int x = 0; x < N; x++) res[x] = (int)(short)res[x];
     }
+}
+
+// a row of packed pixels to the plane (the tail of finish_row)
+template <int N, typename Pixel>
+__device__ __forceinline__ void store_row(unsigned char *row, const unsigned *px)
+{
+    constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
+    constexpr int VEC   = ROWDW >= 4 ? 4 : ROWDW;
+#pragma unroll
+    for (int v = 0; v < ROWDW / VEC; v++) {
+        if constexpr (VEC == 4) {
+            u32x4 t = { px[4 * v], px[4 * v + 1], px[4 * v + 2], px[4 * v + 3] };
+            *reinterpret_cast<u32x4 *>(row + 16 * v) = t;
+        } else if constexpr (VEC == 2) {
+            u32x2 t = { px[2 * v], px[2 * v + 1] };
+            *reinterpret_cast<u32x2 *>(row + 8 * v) = t;
+        } else {
+            *reinterpret_cast<unsigned *>(row + 4 * v) = px[v];
+        }
+    }
+}
+
+template <int LOG2N, typename Pixel>
+__device__ __forceinline__ void tu_rows_body(int wg, const PlaneSet planes, const ohevc_tu_job *__restrict__ jobs, int njobs,
+                                             const int16_t *__restrict__ coeffs, int bit_depth, int kind)
+{
+    constexpr int N = 1 << LOG2N;
+    const int tid = wg * 256 + threadIdx.x;
+    const int job = tid >> LOG2N, r = tid & (N - 1);
+    if (job >= njobs) return;
+    const u32x4 jraw = reinterpret_cast<const u32x4 *>(jobs)[job];
+    const int jx = jraw.x & 0xffff, jy = jraw.x >> 16, jplane = jraw.y & 0xff;
+    int res[N];
+    tu_rows_residual<LOG2N>(jraw, r, coeffs, bit_depth, kind, res);
     unsigned char *row = PLANE_PTR3(planes, jplane) + (size_t)(jy + r) * PLANE_STRIDE3(planes, jplane) + (size_t)jx * sizeof(Pixel);
     if (kind == OHEVC_TU_PCM) {                      // put_pcm: the samples replace the block (clip(0 + sample) == sample)
         unsigned px[N * (int)sizeof(Pixel) / 4];
@@ -1706,6 +1734,40 @@ extern "C" int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bit_depth == 8) hipLaunchKernelGGL((intra_recon_kernel<uint8_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, residuals, njobs, bit_depth, cip, coeffs);
     else                hipLaunchKernelGGL((intra_recon_kernel<uint16_t>), dim3(njobs), dim3(64), 0, st, ps, jobs, residuals, njobs, bit_depth, cip, coeffs);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
+#include "intra_pack.hpp"       // N lanes per N x N block: prediction + residual in registers, one store (uses the residual bodies above)
+
+extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals,
+                                            const int32_t count_by_size[4], const int16_t *coeffs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(planes != nullptr && count_by_size != nullptr, "null argument");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
+    IntraPackSegs sg = {};
+    long long total = 0;
+    for (int s = 0; s < 4; s++) {
+        OHEVC_REQUIRE(count_by_size[s] >= 0, "negative job count");
+        const int per_wave = 16 >> s;
+        sg.first_job[s] = (int)total;
+        sg.njobs[s] = count_by_size[s];
+        sg.first_wave[s + 1] = sg.first_wave[s] + (count_by_size[s] + per_wave - 1) / per_wave;
+        total += count_by_size[s];
+    }
+    OHEVC_REQUIRE(total < (1ll << 30), "too many jobs");
+    if (total == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(residuals) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "arrays must be 16-byte aligned");
+    OHEVC_REQUIRE(residuals == nullptr || coeffs != nullptr, "residual records without a coefficient arena");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
+    if (rc != OHEVC_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int waves = sg.first_wave[4];
+    if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
+    else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

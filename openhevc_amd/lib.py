@@ -213,6 +213,16 @@ def dev_intra_batch(planes, bit_depth, jobs_ptr, njobs, stream=0):
     check(load_library().ohevc_dev_intra_batch(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(stream)))
 
 
+def dev_intra_recon_sorted(planes, bit_depth, jobs_ptr, residuals_ptr, count_by_size, coeffs_ptr, stream=0):
+    """jobs sorted by size (count_by_size[k] blocks of (4 << k) samples); residuals_ptr 0 = prediction only."""
+    counts = (C.c_int32 * 4)(*count_by_size)
+    check(load_library().ohevc_dev_intra_recon_sorted(planes, C.c_int(bit_depth), C.c_void_p(jobs_ptr), C.c_void_p(residuals_ptr or None), counts,
+                                                      C.c_void_p(coeffs_ptr or None), C.c_void_p(stream)))
+
+
+EXPORTED_SYMBOLS += ["ohevc_dev_intra_recon_sorted", "ohevc_dev_intra_recon_batch"]
+
+
 class IntraGeom(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("chroma_format_idc", C.c_int32), ("log2_ctb_size", C.c_int32),
                 ("log2_min_tb_size", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("intra_smoothing_disabled", C.c_int32),

@@ -148,3 +148,112 @@ def test_intra_pred_constrained_structured_maps(oracle, bd):
             if not np.array_equal(G.to_host(d[pl], planes[pl].dtype), want[pl]):
                 bad.append((it, log2, c_idx, mode, cands, x0, y0, lpu, g, int(job["flags"][0]), int(job["flags2"][0])))
     assert not bad, (len(bad), bad[:8])
+
+
+# ---------------------------------------------------------------------------------------------------- the packed kernel (N lanes per block)
+# ohevc_dev_intra_recon_sorted: jobs sorted by size, 16 / 8 / 4 / 2 blocks per wavefront, substitution rules folded into the neighbour
+# addresses, the block's residual added in registers.  Same oracle: intra_pred(), then the residual of the block (tu_batch).
+def _random_block(rng, W, H, bd, log2, cfi=1, all_modes=True):
+    n = 1 << log2
+    c_idx = int(rng.integers(0, 3))
+    sh = 1 if (c_idx and cfi == 1) else 0
+    nl = n << sh
+    x0 = int(rng.integers(0, (W - nl) // nl + 1)) * nl
+    y0 = int(rng.integers(0, (H - nl) // nl + 1)) * nl
+    mode = int(rng.integers(0, 35)) if all_modes else int(rng.choice([0, 1, 10, 26, 2, 18, 34]))
+    cands = [int(rng.random() < 0.7) for _ in range(5)]
+    if x0 == 0: cands[0] = cands[1] = cands[2] = 0
+    if y0 == 0: cands[2] = cands[3] = cands[4] = 0
+    if x0 + nl >= W: cands[4] = 0
+    if y0 + nl >= H: cands[0] = 0
+    return c_idx, x0, y0, mode, cands
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12, 14])
+def test_intra_pack_random_calls(oracle, bd):
+    """one block per launch, prediction only: every size x mode x availability pattern x picture edge, vs intra_pred()"""
+    rng = np.random.default_rng(1900 + bd)
+    W, H = 136, 72
+    for it in range(300):
+        log2 = int(rng.integers(2, 6))
+        cfi = int(rng.choice([1, 1, 1, 3]))
+        c_idx, x0, y0, mode, cands = _random_block(rng, W, H, bd, log2, cfi, all_modes=bool(it % 3))
+        if it % 5 == 0:
+            nl = (1 << log2) << (1 if (c_idx and cfi == 1) else 0)
+            x0, y0 = (W - nl) // nl * nl, (H - nl) // nl * nl
+            cands[4] = 0; cands[0] = 0
+        if it % 11 == 0:
+            cands = [0, 0, 0, 0, 0]
+        if it % 7 == 0:                                 # smooth content: exercises the strong 32x32 filter
+            planes = [np.ascontiguousarray(np.full((H + 8, W + 8), int(rng.integers(0, 1 << bd)), G.pixdt(bd)) + (np.arange(W + 8) // 16).astype(G.pixdt(bd))) for _ in range(3)]
+        else:
+            planes = [rng.integers(0, 1 << bd, size=(H + 8, W + 8)).astype(G.pixdt(bd)) for _ in range(3)]
+        strong = int(rng.random() < 0.7); dis = int(rng.random() < 0.1); ctb = int(rng.choice([4, 5, 6]))
+        want = [p.copy() for p in planes]
+        oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=cfi, strong=strong,
+                          smoothing_disabled=dis, log2_ctb_size=ctb, log2_min_tb_size=2)
+        job = L.intra_make_job(L.IntraGeom(W, H, cfi, ctb, 2, strong, dis, 0), x0, y0, log2, c_idx, mode, cands)
+        d = [G.to_dev(p) for p in planes]
+        d_jobs = G.to_dev(job)
+        counts = [0, 0, 0, 0]; counts[log2 - 2] = 1
+        L.dev_intra_recon_sorted(G.planes3(d), bd, d_jobs.data_ptr(), 0, counts, 0, G.stream())
+        G.sync()
+        for pl in range(3):
+            got = G.to_host(d[pl], planes[pl].dtype)
+            assert np.array_equal(got, want[pl]), (it, log2, c_idx, mode, cands, x0, y0, cfi, strong, dis, ctb, pl)
+
+
+@pytest.mark.parametrize("bd", [8, 10, 14])
+def test_intra_pack_batch_with_residuals(oracle, bd):
+    """many independent blocks of all four sizes in ONE launch, most with a residual of a random kind riding along"""
+    import ctypes as C
+    rng = np.random.default_rng(2900 + bd)
+    W, H = 1024, 512
+    luma = rng.integers(0, 1 << bd, size=(H, W)).astype(G.pixdt(bd))
+    planes = [luma, rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd)), rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd))]
+    want = [p.copy() for p in planes]
+    geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+    kinds = [None, L.TU_IDCT, L.TU_IDCT, L.TU_DC, L.TU_SKIP, L.TU_SKIP_RDPCM_H, L.TU_SKIP_RDPCM_V, L.TU_BYPASS, L.TU_BYPASS_RDPCM_H, L.TU_BYPASS_RDPCM_V]
+    recs = {2: [], 3: [], 4: [], 5: []}
+    arena = []
+    off = 0
+    # one block per 128x128 luma cell, away from the cell's border: no block reads what another writes
+    for cy in range(0, H, 128):
+        for cx in range(0, W, 128):
+            log2 = int(rng.integers(2, 6)); n = 1 << log2
+            c_idx = int(rng.integers(0, 3))
+            sh = 1 if c_idx else 0
+            x0, y0 = cx + 64, cy + 64                      # luma position; chroma blocks sit at half of it
+            mode = int(rng.integers(0, 35))
+            cands = [int(rng.random() < 0.8) for _ in range(5)]
+            oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1, strong=1, smoothing_disabled=0,
+                              log2_ctb_size=6, log2_min_tb_size=2)
+            job = L.intra_make_job(geom, x0, y0, log2, c_idx, mode, cands)[0]
+            kind = kinds[int(rng.integers(0, len(kinds)))]
+            if kind == L.TU_IDCT and log2 == 2 and c_idx == 0 and rng.random() < 0.5:
+                kind = L.TU_DST4
+            res = np.zeros(1, L.TU_JOB)[0]
+            if kind is not None:
+                cf = rng.integers(-512, 512, size=(1, n, n)).astype(np.int16)
+                if kind == L.TU_IDCT and rng.random() < 0.5:
+                    cf[:, n // 2:, :] = 0; cf[:, :, n // 2:] = 0
+                px, py = x0 >> sh, y0 >> sh
+                oracle.tu_batch(bd, kind, log2, cf, want[c_idx], np.array([[px, py]], np.int32))
+                res["x"], res["y"], res["plane"], res["reserved0"] = px, py, c_idx, kind + 1
+                if kind == L.TU_DC:
+                    res["dc"] = cf[0, 0, 0]
+                else:
+                    res["coeff_off"] = off
+                    arena.append(cf.reshape(-1)); off += n * n
+            recs[log2].append((job, res))
+    jobs = np.array([j for k in (2, 3, 4, 5) for j, _ in recs[k]], dtype=L.INTRA_JOB)
+    ress = np.array([r for k in (2, 3, 4, 5) for _, r in recs[k]], dtype=L.TU_JOB)
+    counts = [len(recs[k]) for k in (2, 3, 4, 5)]
+    d = [G.to_dev(p) for p in planes]
+    d_jobs, d_res, d_cf = G.to_dev(jobs), G.to_dev(ress), G.to_dev(np.concatenate(arena))
+    L.dev_intra_recon_sorted(G.planes3(d), bd, d_jobs.data_ptr(), d_res.data_ptr(), counts, d_cf.data_ptr(), G.stream())
+    G.sync()
+    for pl in range(3):
+        got = G.to_host(d[pl], planes[pl].dtype)
+        bad = np.argwhere(got != want[pl])
+        assert bad.size == 0, (pl, counts, bad[:4].tolist())

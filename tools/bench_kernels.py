@@ -237,7 +237,20 @@ def main():
             j["bottom_left_size"] = nn; j["top_right_size"] = nn
             d_jobs = dev(j)
             ms = timeit(lambda pic, ex: L.dev_intra_batch(L.planes_of(pic), bd, d_jobs.data_ptr(), n, st()), lambda: rand_pic(bd, g), name="intra")
-            report(f"intra {nn}x{nn} independent blocks, {bd}-bit", ms, n * nn * nn, n * (P * (4 * nn + 1) + P * nn * nn), out)
+            report(f"intra {nn}x{nn} independent blocks, one wavefront per block (round-1 kernel), {bd}-bit", ms, n * nn * nn, n * (P * (4 * nn + 1) + P * nn * nn), out)
+            # the packed kernel (N lanes per block; what the ctx layer launches per dependency level): prediction only, then with the block's
+            # own inverse-DCT residual added in registers (+ 2 N^2 coefficient bytes per block)
+            counts = [0, 0, 0, 0]; counts[log2 - 2] = n
+            ms = timeit(lambda pic, ex: L.dev_intra_recon_sorted(L.planes_of(pic), bd, d_jobs.data_ptr(), 0, counts, 0, st()), lambda: rand_pic(bd, g), name="intra")
+            report(f"intra {nn}x{nn} independent blocks, packed kernel, {bd}-bit", ms, n * nn * nn, n * (P * (4 * nn + 1) + P * nn * nn), out)
+            r = np.zeros(n, L.TU_JOB)
+            r["x"], r["y"], r["reserved0"], r["coeff_off"] = j["x"], j["y"], L.TU_IDCT + 1, np.arange(n, dtype=np.uint32) * nn * nn
+            d_res = dev(r)
+            cf = torch.randint(-256, 256, (n * nn * nn,), dtype=torch.int16, device="cuda", generator=g)
+            ms = timeit(lambda pic, ex: L.dev_intra_recon_sorted(L.planes_of(pic), bd, d_jobs.data_ptr(), d_res.data_ptr(), counts, cf.data_ptr(), st()),
+                        lambda: rand_pic(bd, g), name="intra")
+            report(f"intra {nn}x{nn} + inverse DCT residual, packed kernel, {bd}-bit", ms, n * nn * nn, n * (P * (4 * nn + 1) + P * nn * nn + 2 * nn * nn), out)
+            del d_res, cf
         # ---- small / special residual kinds
         for (log2, kind, name) in [(2, L.TU_IDCT, "idct4x4"), (2, L.TU_DST4, "dst4x4"), (3, L.TU_IDCT, "idct8x8"), (4, L.TU_DC, "dc16x16"), (3, L.TU_SKIP, "skip8x8")]:
             nn = 1 << log2
