@@ -94,6 +94,7 @@ void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream sc
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
+static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
 static int g_intra_pack = getenv("OHEVC_INTRA_PACK") ? atoi(getenv("OHEVC_INTRA_PACK")) : 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
@@ -170,6 +171,8 @@ struct ohevc_ctx : Rec {
     std::mutex side_m;
     std::vector<std::pair<std::thread::id, std::unique_ptr<Rec>>> side;
 
+    std::vector<ohevc_intra_chain_level> chain_tab;       // scratch of frame_reconstruct: runs of narrow levels
+    std::vector<int> chain_first, chain_len;
     std::vector<ohevc_level_phase> phases;                // scratch of frame_reconstruct
     std::vector<uint32_t> need, sync_zero;
     std::vector<uint8_t> dbk_blob;                         // ohevc_rec_deblock_maps: the copied maps back to back (empty = none)
@@ -313,6 +316,7 @@ extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
 }
 
 extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
+extern "C" int ohevc_debug_set_intra_chain(int on) { const int prev = g_intra_chain; g_intra_chain = on != 0; return prev; }
 extern "C" int ohevc_debug_set_intra_pack(int on) { const int prev = g_intra_pack; g_intra_pack = on != 0; return prev; }
 extern "C" int ohevc_debug_set_fuse_intra(int on) { const int prev = g_fuse_intra; g_fuse_intra = on != 0; return prev; }
 extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
@@ -1318,6 +1322,15 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         fprintf(stderr, "ctb trace: mode %d chose %d tasks %zu ops %zu intra %zu tu %zu max_level %d level0_tu %zu coeffs %zu hash %llx\n", c->frame_mode, c->stats.chose_ctbs,
                 c->ctb_tasks.size(), c->ctb_opwords.size(), c->ctb_intra.size(), c->ctb_tu.size(), c->max_level, l0, c->coeffs.size(), h);
     }
+    if (getenv("OHEVC_TRACE_LEVELS")) {       // diagnosis: how wide the dependency levels are, in wavefronts of the packed intra kernel
+        fprintf(stderr, "levels: target %d max_level %d waves:", c->cur, c->max_level);
+        for (int l = 1; l <= c->max_level; l++) {
+            int cnt[4] = {0, 0, 0, 0};
+            for (const ohevc_intra_job &j : c->levels[l].intra) cnt[j.log2_size - 2]++;
+            fprintf(stderr, " %d", (cnt[0] + 15) / 16 + (cnt[1] + 7) / 8 + (cnt[2] + 3) / 4 + (cnt[3] + 1) / 2);
+        }
+        fprintf(stderr, "\n");
+    }
     if (c->dry) {
         if (g_sink) g_sink(g_sink_user, c, 0);
         clear_recorded(c);
@@ -1381,6 +1394,38 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             if (first) { loff[l].tu_first = o; first = false; }
         }
     }
+    // runs of consecutive NARROW levels (at most 16 wavefronts of the packed kernel each): one ohevc_dev_intra_chain launch per run.  A
+    // level with residual bins of its own (blocks whose residual does not ride with the prediction) can only END a run: its bins launch
+    // behind it and in front of the next level.
+    std::vector<ohevc_intra_chain_level> &chain = c->chain_tab;
+    chain.clear();
+    c->chain_first.assign((size_t)c->max_level + 2, 0);
+    c->chain_len.assign((size_t)c->max_level + 2, 0);
+    if (g_intra_chain && g_level_launch != 1) {
+        auto waves_of = [&](int k) { return (loff[k].count[0] + 15) / 16 + (loff[k].count[1] + 7) / 8 + (loff[k].count[2] + 3) / 4 + (loff[k].count[3] + 1) / 2; };
+        auto narrow = [&](int k) { return loff[k].packed && waves_of(k) > 0 && waves_of(k) <= 16; };
+        for (int l = 1; l <= c->max_level;) {
+            if (!narrow(l)) { l++; continue; }
+            int e = l;
+            while (e + 1 <= c->max_level && c->levels[e].touched == 0 && narrow(e + 1)) e++;
+            if (e > l) {
+                c->chain_first[l] = (int)chain.size();
+                c->chain_len[l] = e - l + 1;
+                for (int k = l; k <= e; k++) {
+                    ohevc_intra_chain_level cl = {};
+                    for (int q = 0; q < 4; q++) {
+                        cl.njobs[q] = loff[k].count[q];
+                        cl.first_wave[q + 1] = cl.first_wave[q] + (loff[k].count[q] + (16 >> q) - 1) / (16 >> q);
+                    }
+                    cl.jobs_off16 = (uint32_t)(loff[k].intra / 16);
+                    cl.res_off16 = c->levels[k].intra_res.size() == c->levels[k].intra.size() ? (uint32_t)(loff[k].intra_res / 16) : 0xffffffffu;
+                    chain.push_back(cl);
+                }
+            }
+            l = e + 1;
+        }
+    }
+    const size_t off_chain = chain.empty() ? 0 : stage_put(parts, total, chain.data(), chain.size() * sizeof(ohevc_intra_chain_level));
     // levels >= 1 run as ONE launch (ohevc_dev_levels): phases in execution order, job offsets relative to the first
     // staged intra / residual array of level 1 (arrays are 256-byte = 16-job aligned, so offsets are whole jobs)
     std::vector<ohevc_level_phase> &phases = c->phases;
@@ -1458,9 +1503,17 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     }
     const bool trace_launches = getenv("OHEVC_TRACE_LAUNCHES") != nullptr;
     int n_lv_intra = 0, n_lv_tu = 0;
+    int chained_until = -1;                          // levels up to here had their intra blocks done by a chain launch
     for (int level = 0; level <= last_separate; level++) {
         LevelBins &lb = c->levels[level];
-        if (!lb.intra.empty()) {
+        if (level < (int)c->chain_len.size() && c->chain_len[level] > 0) {
+            rc = ohevc_dev_intra_chain(p->planes, p->bd, base, reinterpret_cast<const ohevc_intra_chain_level *>(base + off_chain) + c->chain_first[level],
+                                       c->chain_len[level], d_coeffs, c->stream);
+            if (rc != OHEVC_OK) return rc;
+            c->stats.launches++;
+            chained_until = level + c->chain_len[level] - 1;
+        }
+        if (!lb.intra.empty() && level > chained_until) {
             if (loff[level].packed)
                 rc = ohevc_dev_intra_recon_sorted(p->planes, p->bd, reinterpret_cast<const ohevc_intra_job *>(base + loff[level].intra),
                                                   lb.intra_res.size() == lb.intra.size() ? reinterpret_cast<const ohevc_tu_job *>(base + loff[level].intra_res) : nullptr,

@@ -344,4 +344,50 @@ __global__ __launch_bounds__(64) void intra_pack_kernel(PlaneSet planes, const o
     else             intra_pack_body<5, Pixel>(ish, tu_lds, lane, local * 2, n, planes, j, r, coeffs, bit_depth);
 }
 
+// ------------------------------------------------------------------ a run of NARROW dependency levels in one launch
+// Most dependency levels of a picture are narrow: the intra picture of a 1080p stream chains ~1200 levels of 1 .. 16 wavefronts, the tail
+// of every inter picture a dozen of 1 .. 8 (OHEVC_TRACE_LEVELS).  As one launch each they cost a kernel boundary apiece - ~6 us of kernel
+// (start, three dependent memory round trips, end-of-kernel write-back) plus 2 - 4 us until the next one starts.  A level that fits ONE
+// workgroup (16 wavefronts) needs no kernel boundary to hand its samples to the next level: all of its wavefronts sit on one CU, so
+// "stores complete in L2 (s_waitcnt vmcnt(0)) - workgroup barrier - drop this CU's L1 (buffer_inv sc1)" orders them.  The host cuts the
+// chain of levels into runs of consecutive levels of at most 16 wavefronts and launches one workgroup per run.
+struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
+    int first_wave[5];               // as IntraPackSegs
+    int njobs[4];
+    unsigned jobs_off16, res_off16;  // the level's job / residual arrays, offsets from `base` in 16-byte units; res_off16 = 0xffffffff: none
+    int reserved;
+};
+
+template <typename Pixel>
+__global__ __launch_bounds__(1024) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
+                                                           int nlevels, int bit_depth, const int16_t *__restrict__ coeffs)
+{
+    __shared__ int ish[16 * kIntraPackInts];
+    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[16 * TuLayout<5>::WAVE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int l = 0; l < nlevels; l++) {
+        if (l) {
+            xcd_release();                                   // this wavefront's rows are in L2 ...
+            __syncthreads();                                 // ... and so are everybody else's
+            xcd_acquire();                                   // nothing older of them in this CU's L1
+        }
+        const IntraChainLevel lv = levels[l];
+        if (wave < lv.first_wave[4]) {                       // wave-uniform
+            const int s = wave >= lv.first_wave[3] ? 3 : wave >= lv.first_wave[2] ? 2 : wave >= lv.first_wave[1] ? 1 : 0;
+            const int local = wave - lv.first_wave[s];
+            const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
+            const ohevc_intra_job *j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
+            const ohevc_tu_job *r = lv.res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job : nullptr;
+            int *my_ish = ish + wave * kIntraPackInts;
+            unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
+            const int n = lv.njobs[s];
+            if (s == 0)      intra_pack_body<2, Pixel>(my_ish, my_tu, lane, local * 16, n, planes, j, r, coeffs, bit_depth);
+            else if (s == 1) intra_pack_body<3, Pixel>(my_ish, my_tu, lane, local * 8, n, planes, j, r, coeffs, bit_depth);
+            else if (s == 2) intra_pack_body<4, Pixel>(my_ish, my_tu, lane, local * 4, n, planes, j, r, coeffs, bit_depth);
+            else             intra_pack_body<5, Pixel>(my_ish, my_tu, lane, local * 2, n, planes, j, r, coeffs, bit_depth);
+        }
+    }
+}
+
 }  // namespace ohevc

@@ -1772,6 +1772,28 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
+                                    const int16_t *coeffs, void *stream)
+{
+    using namespace ohevc;
+    static_assert(sizeof(ohevc_intra_chain_level) == sizeof(IntraChainLevel) && sizeof(IntraChainLevel) == 48, "level record layout");
+    OHEVC_REQUIRE(planes != nullptr, "planes");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
+    OHEVC_REQUIRE(nlevels >= 0, "nlevels");
+    if (nlevels == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(base != nullptr && levels != nullptr && (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (reinterpret_cast<uintptr_t>(levels) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "arrays must be 16-byte aligned");
+    PlaneSet ps;
+    int rc = make_plane_set(planes, ps, bit_depth > 8 ? 2 : 1);
+    if (rc != OHEVC_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const IntraChainLevel *lv = reinterpret_cast<const IntraChainLevel *>(levels);
+    if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(1024), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
+    else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(1024), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
 #include "ctb_kernels.hpp"      // the CTB executor runs tu_dispatch on its LDS tiles
 
 extern "C" int ohevc_dev_tu_batch(const ohevc_plane planes[3], int bit_depth, int log2_size, int kind,
