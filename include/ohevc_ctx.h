@@ -57,6 +57,15 @@ int  ohevc_pic_release(ohevc_ctx *ctx, int slot);
 int  ohevc_pic_upload(ohevc_ctx *ctx, int slot, int plane, const void *host, ptrdiff_t host_stride);
 int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff_t host_stride);
 int  ohevc_pic_planes(ohevc_ctx *ctx, int slot, ohevc_plane out[3]);     /* device views (e.g. for an RCCL broadcast) */
+/* the three planes of a picture (host[i] NULL: skip) with one wait at the end */
+int  ohevc_pic_download_planes(ohevc_ctx *ctx, int slot, void *const host[3], const ptrdiff_t host_stride[3]);
+/* Page-lock application memory that ohevc_pic_download / ohevc_pic_upload will be given again and again - the decoder's frame buffers
+ * (alloc_frame, hevc_refs.c:75-114: pass the allocations its buffer pool recycles, AVFrame.buf[i]->data / ->size): the copy-back then is
+ * one DMA at the bus rate instead of a staged copy through pageable memory.  A range that overlaps an earlier, different registration
+ * replaces it (that memory was freed and allocated again).  OHEVC_ERR_HIP when the runtime refuses: nothing is lost but the speed.
+ * ohevc_host_unpin_all before the application frees the memory (the decoder: before avcodec_close). */
+int  ohevc_host_pin(ohevc_ctx *ctx, void *ptr, size_t bytes);
+int  ohevc_host_unpin_all(ohevc_ctx *ctx);
 /* Frame-parallel decoding across GPUs (one process per GPU; the reference's counterpart is the shared DPB of its frame threads,
  * pthread_frame.c:479-513 + hevc_await_progress hevc.c:1951-1958): the owner of a picture copies a finished plane out with
  * ohevc_pic_export, the other processes copy it into their own store with ohevc_pic_import; the transport in between (RCCL

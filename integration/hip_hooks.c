@@ -46,6 +46,7 @@ static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
 static volatile int        g_error;
 static int                 g_bulk_filters = 1;     /* OHHIP_BULK_FILTERS=0: keep the reference's filter drivers and the per-edge table calls */
 static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
+static int                 g_pin_frames = 1;       /* OHHIP_PIN_FRAMES=0: leave the decoder's frame buffers pageable */
 static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
 static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
 static long long           g_alg_bytes;        /* algorithmic HBM bytes of the recorded jobs (ohevc_frame_stats.alg_bytes), same period */
@@ -166,6 +167,7 @@ static int slot_of_frame_locked(ohevc_ctx *ctx, const HEVCContext *s, const AVFr
                         g_bufs[i].bd != s->sps->bit_depth || g_bufs[i].fmt != cfmt)) {
         ohevc_tables_unregister_picture(ctx, g_bufs[i].slot);
         ohevc_pic_release(ctx, g_bufs[i].slot);
+        ohevc_host_unpin_all(ctx);                  /* the decoder dropped its buffer pool with the old geometry: forget the page locks */
         g_bufs[i] = g_bufs[--g_nbufs];
         i = g_nbufs;
     }
@@ -208,6 +210,14 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     if (!(ctx = thread_ctx()))
         return AVERROR(ENOMEM);
     f = s->ref->frame;
+    /* INTEGRATION.md section 3, row alloc_frame: page-lock the buffers the decoder's pool recycles (hevc_refs.c:75-114, get_buffer.c), so
+     * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once. */
+    if (g_pin_frames && ohevc_ctx_has_device(ctx))
+        for (i = 0; i < AV_NUM_DATA_POINTERS && f->buf[i]; i++)
+            if (ohevc_host_pin(ctx, f->buf[i]->data, f->buf[i]->size) != OHEVC_OK && g_pin_frames == 1) {
+                fprintf(stderr, "ohhip: frame buffers stay pageable: %s\n", ohevc_last_error());
+                g_pin_frames = 2;                  /* say it once */
+            }
     if ((i = slot_of_frame_locked(ctx, s, f, &fresh)) < 0)
         return AVERROR(ENOMEM);
     slot = g_bufs[i].slot;
@@ -490,6 +500,7 @@ int ohdec_backend_open(void)
     if (getenv("OHHIP_RECORD_ONLY"))
         ohevc_debug_set_record_only(1);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
+    g_pin_frames = !(getenv("OHHIP_PIN_FRAMES") && atoi(getenv("OHHIP_PIN_FRAMES")) == 0);
     g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
     /* A/B of the executors of the intra-coded blocks (include/ohevc_debug.h): 0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture */
     ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
@@ -714,11 +725,15 @@ int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3])
         fprintf(stderr, "ohhip: output picture is not in the picture store\n");
         return -1;
     }
-    for (c = 0; c < 3; c++)
-        if (data[c] && ohevc_pic_download(ctx, slot, c, data[c], linesize[c]) != OHEVC_OK) {
+    {
+        void *const host[3] = { data[0], data[1], data[2] };
+        const ptrdiff_t strides[3] = { linesize[0], linesize[1], linesize[2] };
+        (void)c;
+        if (ohevc_pic_download_planes(ctx, slot, host, strides) != OHEVC_OK) {
             fprintf(stderr, "ohhip: download failed: %s\n", ohevc_last_error());
             return -1;
         }
+    }
     return 0;
 }
 
@@ -751,6 +766,13 @@ long long ohdec_backend_alg_bytes(void)
     g_alg_bytes = 0;
     pthread_mutex_unlock(&g_lock);
     return v;
+}
+
+/* before the decoder frees its frame buffers (avcodec_close): their page locks go first */
+void ohdec_backend_pre_close(void)
+{
+    if (g_root)
+        ohevc_host_unpin_all(g_root);
 }
 
 /* after the decoder (and its threads) are gone */

@@ -38,6 +38,8 @@ struct PicStore {
     Picture pics[kMaxPics];               // fixed array: pointers to entries stay valid while other threads allocate
     std::atomic<int> npics{0};            // grows under `m`; read without it by every context of the store (get_pic)
     unsigned version = 0;                 // bumped whenever a slot's planes change (contexts re-upload their MC table)
+    std::mutex pin_m;
+    std::vector<std::pair<uintptr_t, size_t>> pinned;      // host ranges page-locked through ohevc_host_pin
 };
 
 struct DevBuf {                       // grow-only device buffer
@@ -94,6 +96,7 @@ void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream sc
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
+static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 8;   // widest level a chain takes
 static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
 static int g_intra_pack = getenv("OHEVC_INTRA_PACK") ? atoi(getenv("OHEVC_INTRA_PACK")) : 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
@@ -229,6 +232,8 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
     return OHEVC_OK;
 }
 
+static void unpin_locked(PicStore &st, size_t i);
+
 extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
 {
     OHEVC_REQUIRE(out != nullptr, "out");
@@ -282,6 +287,10 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
         (void)hipDeviceSynchronize();
+        {
+            std::lock_guard<std::mutex> g(c->store->pin_m);
+            while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
+        }
         for (int i = 0; i < c->store->npics; i++) if (c->store->pics[i].used) free_picture(c->store->pics[i]);
     }
     {   // pictures of the shared store may still name this context's events (the stream has drained: they have all fired)
@@ -420,6 +429,83 @@ extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *h
     OHEVC_HIP_TRY(hipMemcpy2DAsync(pl.data, pl.stride, host, host_stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
                                    hipMemcpyHostToDevice, c->stream));
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));      // pageable source: do not return before it has been read
+    return OHEVC_OK;
+}
+
+// ---- page-locked application memory.  The decoder's frame buffers (alloc_frame, hevc_refs.c:75-114) are pageable: a copy-back into them
+// goes through the runtime's staging buffers and a CPU copy - 99.5 MB per 8K Main10 picture.  Registered, the same copy is one DMA at
+// the bus rate.  The application names the ALLOCATIONS (for the decoder: AVFrame.buf[i]->data / ->size, the buffers its pool recycles),
+// so ranges of live buffers never overlap; a range overlapping an earlier, different registration means that memory was freed and
+// allocated again, and replaces it.  Failure to register is not an error of the decoder: the copies stay pageable.
+static void unpin_locked(PicStore &st, size_t i)
+{
+    (void)hipHostUnregister(reinterpret_cast<void *>(st.pinned[i].first));
+    st.pinned[i] = st.pinned.back();
+    st.pinned.pop_back();
+}
+
+extern "C" int ohevc_host_pin(ohevc_ctx *c, void *ptr, size_t bytes)
+{
+    OHEVC_REQUIRE(c != nullptr && ptr != nullptr && bytes > 0, "bad argument");
+    if (c->dry) return OHEVC_OK;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::lock_guard<std::mutex> g(c->store->pin_m);
+    auto &v = c->store->pinned;
+    for (size_t i = 0; i < v.size(); i++) if (v[i].first == a && v[i].second == bytes) return OHEVC_OK;
+    bool drained = false;
+    for (size_t i = 0; i < v.size();) {
+        if (v[i].first < a + bytes && a < v[i].first + v[i].second) {
+            if (!drained) { OHEVC_HIP_TRY(hipSetDevice(c->device)); (void)hipDeviceSynchronize(); drained = true; }   // a copy into the old range may be in flight
+            unpin_locked(*c->store, i);
+        } else {
+            i++;
+        }
+    }
+    OHEVC_HIP_TRY(hipSetDevice(c->device));
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostRegister(%p, %zu) failed: %s (copies into it stay pageable)", ptr, bytes, hipGetErrorString(e));
+        return OHEVC_ERR_HIP;
+    }
+    v.emplace_back(a, bytes);
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_host_unpin_all(ohevc_ctx *c)
+{
+    OHEVC_REQUIRE(c != nullptr, "null context");
+    if (c->dry) return OHEVC_OK;
+    std::lock_guard<std::mutex> g(c->store->pin_m);
+    if (c->store->pinned.empty()) return OHEVC_OK;
+    OHEVC_HIP_TRY(hipSetDevice(c->device));
+    (void)hipDeviceSynchronize();
+    while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
+    return OHEVC_OK;
+}
+
+// the three planes of a picture with ONE wait at the end (ohevc_pic_download waits per plane)
+extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const host[3], const ptrdiff_t host_stride[3])
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && host != nullptr && host_stride != nullptr, "bad argument");
+    if (c->dry) return OHEVC_OK;
+    {
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+            set_error("picture %d was never completed by its decoding thread", slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+    }
+    for (int i = 0; i < 3; i++) {
+        if (!host[i]) continue;
+        const ohevc_plane &pl = p->planes[i];
+        OHEVC_HIP_TRY(hipMemcpy2DAsync(host[i], host_stride[i], pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
+                                       hipMemcpyDeviceToHost, c->stream));
+    }
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     return OHEVC_OK;
 }
 
@@ -1394,7 +1480,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             if (first) { loff[l].tu_first = o; first = false; }
         }
     }
-    // runs of consecutive NARROW levels (at most 16 wavefronts of the packed kernel each): one ohevc_dev_intra_chain launch per run.  A
+    // runs of consecutive NARROW levels (at most 8 wavefronts of the packed kernel each): one ohevc_dev_intra_chain launch per run.  A
     // level with residual bins of its own (blocks whose residual does not ride with the prediction) can only END a run: its bins launch
     // behind it and in front of the next level.
     std::vector<ohevc_intra_chain_level> &chain = c->chain_tab;
@@ -1403,7 +1489,8 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     c->chain_len.assign((size_t)c->max_level + 2, 0);
     if (g_intra_chain && g_level_launch != 1) {
         auto waves_of = [&](int k) { return (loff[k].count[0] + 15) / 16 + (loff[k].count[1] + 7) / 8 + (loff[k].count[2] + 3) / 4 + (loff[k].count[3] + 1) / 2; };
-        auto narrow = [&](int k) { return loff[k].packed && waves_of(k) > 0 && waves_of(k) <= 16; };
+        const int max_waves = std::min(g_intra_chain_waves, ohevc_intra_chain_max_waves());
+        auto narrow = [&](int k) { return loff[k].packed && waves_of(k) > 0 && waves_of(k) <= max_waves; };
         for (int l = 1; l <= c->max_level;) {
             if (!narrow(l)) { l++; continue; }
             int e = l;

@@ -122,24 +122,54 @@ __device__ __forceinline__ void idct_row(unsigned char *blk, const int i, const 
     for (int k = 0; k < N; k++) t[k] >>= shift2;
 }
 
+// The work of lane (g, i) comes in three stages, so that the chain kernel below can have the records and coefficients of LATER levels in
+// flight while a level computes: (R) the two 16-byte records of the block, (C) the coefficient chunks the residual's transform needs
+// (addresses from the residual record), (X) samples -> prediction -> residual -> store.
+struct PackRecs { u32x4 jw, rw; bool valid; };
+
+template <int LOG2N>
+__device__ __forceinline__ PackRecs pack_load_recs(const int lane, const int job0, const int njobs, const ohevc_intra_job *__restrict__ jobs,
+                                                   const ohevc_tu_job *__restrict__ residuals)
+{
+    constexpr int N = 1 << LOG2N;
+    const int g = lane / N;
+    PackRecs r;
+    r.valid = job0 + g < njobs;
+    const int ji = r.valid ? job0 + g : njobs - 1;          // lanes behind the last job repeat it and do not store
+    r.jw = reinterpret_cast<const u32x4 *>(jobs)[ji];
+    r.rw = u32x4{ 0u, 0u, 0u, 0u };
+    if (residuals != nullptr) r.rw = reinterpret_cast<const u32x4 *>(residuals)[ji];
+    return r;
+}
+
+__device__ __forceinline__ int pack_kind(const PackRecs &r) { return (int)((r.rw.y >> 8) & 0xff) - 1; }      // -1: no residual
+
+template <int LOG2N>
+__device__ __forceinline__ void pack_load_coeffs(const PackRecs &r, const int lane, const int16_t *__restrict__ coeffs, u32x4 (&cq)[4])
+{
+    constexpr int N = 1 << LOG2N, NCQ = LOG2N == 2 ? 2 : N / 8;
+    const int i = lane % N, kind = pack_kind(r);
+    const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + (is_idct ? r.rw.z : 0u));
+#pragma unroll
+    for (int q = 0; q < NCQ; q++) {
+        cq[q] = u32x4{ 0u, 0u, 0u, 0u };
+        if (is_idct) cq[q] = src[LOG2N == 2 ? q : q * N + i];
+    }
+}
+
 template <int LOG2N, typename Pixel>
-__device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds, const int lane, const int job0, const int njobs, const PlaneSet planes,
-                                                const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
-                                                const int16_t *__restrict__ coeffs, const int bit_depth)
+__device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const u32x4 (&cq)[4],
+                                             const int16_t *__restrict__ coeffs, const int bit_depth)
 {
     using IL = IntraPackLayout<LOG2N>;
     constexpr int N = IL::N;
     const int g = lane / N, i = lane % N;
-    const bool valid = job0 + g < njobs;
-    const int ji = valid ? job0 + g : njobs - 1;           // lanes behind the last job repeat it and do not store
-
-    // ---- round 1: the two records of the block
-    const u32x4 jw = reinterpret_cast<const u32x4 *>(jobs)[ji];
-    u32x4 rw = { 0u, 0u, 0u, 0u };
-    if (residuals != nullptr) rw = reinterpret_cast<const u32x4 *>(residuals)[ji];
+    const bool valid = recs.valid;
+    const u32x4 jw = recs.jw, rw = recs.rw;
     const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
     const int bl_size = jw.z & 0xff, tr_size = (jw.z >> 8) & 0xff;
-    const int kind = (int)((rw.y >> 8) & 0xff) - 1;        // -1: no residual
+    const int kind = pack_kind(recs);
     const int stride = PLANE_STRIDE3(planes, jplane);
     unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
     const bool c_bl = flags & OHEVC_INTRA_BOTTOM_LEFT, c_l = flags & OHEVC_INTRA_LEFT, c_ul = flags & OHEVC_INTRA_UP_LEFT;
@@ -147,45 +177,30 @@ __device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds,
 
     // ---- round 2: samples and coefficients.  Positions relative to the block's first sample; `none` = 1 << (bit_depth - 1).
     // Substitutes (:251-286): the last sample of a group in scan order is left[N] / left[0] / corner / top[N-1], the first left[N-1] / top[0] / top[N]
-    struct Pos { int dx, dy; bool none; };
-    auto after_ul = [&]() -> Pos { return c_u ? Pos{0, -1, false} : c_ur ? Pos{N, -1, false} : Pos{0, 0, true}; };             // first available group after the corner
-    auto before_ul = [&]() -> Pos { return c_l ? Pos{-1, 0, false} : c_bl ? Pos{-1, N, false} : Pos{0, 0, true}; };           // nearest available group before the corner
-    Pos p_bl, p_l, p_ul, p_u, p_ur;
-    {
-        const Pos a = after_ul(), b = before_ul();
-        const Pos ul_or_after = c_ul ? Pos{-1, -1, false} : a;
-        p_bl = c_l ? Pos{-1, N - 1, false} : ul_or_after;                                     // nothing before: first available after
-        p_l = c_bl ? Pos{-1, N, false} : ul_or_after;
-        p_ul = !b.none ? b : a;
-        p_u = c_ul ? Pos{-1, -1, false} : !b.none ? b : (c_ur ? Pos{N, -1, false} : Pos{0, 0, true});
-        p_ur = c_u ? Pos{N - 1, -1, false} : c_ul ? Pos{-1, -1, false} : b;                    // nothing after
-    }
-    auto REC = [&](const Pos p) -> int {
-        return (int)*reinterpret_cast<const Pixel *>(blk + (ptrdiff_t)p.dy * stride + (ptrdiff_t)p.dx * (int)sizeof(Pixel));
-    };
+    // positions as byte offsets from the block's first sample
+    constexpr int P = (int)sizeof(Pixel), NONE = -0x40000000;
+    const int o_c = -stride - P, o_l0 = -P, o_ln = N * stride - P, o_lm = (N - 1) * stride - P, o_t0 = -stride, o_tn = N * P - stride, o_tm = (N - 1) * P - stride;
+    const int a = c_u ? o_t0 : c_ur ? o_tn : NONE;           // first available group after the corner: its first sample
+    const int b = c_l ? o_l0 : c_bl ? o_ln : NONE;           // nearest available group before the corner: its last sample
+    const int ul_or_after = c_ul ? o_c : a;
+    const int p_bl = c_l ? o_lm : ul_or_after;               // nothing lies before below-left: the first available group after it
+    const int p_l = c_bl ? o_ln : ul_or_after;
+    const int p_ul = b != NONE ? b : a;
+    const int p_u = c_ul ? o_c : b != NONE ? b : (c_ur ? o_tn : NONE);
+    const int p_ur = c_u ? o_tm : c_ul ? o_c : b;            // nothing lies after above-right
+    auto REC = [&](const int off) -> int { return (int)*reinterpret_cast<const Pixel *>(blk + (off == NONE ? 0 : off)); };
     const int kt = i < tr_size ? i : tr_size - 1, kb = i < bl_size ? i : bl_size - 1;        // beyond the picture: the last valid sample (:111-114, 164-183)
-    const Pos q_t0 = c_u ? Pos{i, -1, false} : p_u, q_t1 = c_ur ? Pos{N + kt, -1, false} : p_ur;
-    const Pos q_l0 = c_l ? Pos{-1, i, false} : p_l, q_l1 = c_bl ? Pos{-1, N + kb, false} : p_bl;
-    const Pos q_c = c_ul ? Pos{-1, -1, false} : p_ul;
+    const int q_t0 = c_u ? i * P - stride : p_u, q_t1 = c_ur ? (N + kt) * P - stride : p_ur;
+    const int q_l0 = c_l ? i * stride - P : p_l, q_l1 = c_bl ? (N + kb) * stride - P : p_bl;
+    const int q_c = c_ul ? o_c : p_ul;
     int v_t0 = REC(q_t0), v_t1 = REC(q_t1), v_l0 = REC(q_l0), v_l1 = REC(q_l1), v_c = REC(q_c);
-    // the coefficients of the transforms (the row kinds read theirs inside tu_rows_residual)
-    constexpr int NCQ = LOG2N == 2 ? 2 : N / 8;
-    u32x4 cq[NCQ];
     const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
-    {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + (is_idct ? rw.z : 0u));
-#pragma unroll
-        for (int q = 0; q < NCQ; q++) {
-            cq[q] = u32x4{ 0u, 0u, 0u, 0u };
-            if (is_idct) cq[q] = src[LOG2N == 2 ? q : q * N + i];
-        }
-    }
     const int dflt = 1 << (bit_depth - 1);
-    if (q_t0.none) v_t0 = dflt;
-    if (q_t1.none) v_t1 = dflt;
-    if (q_l0.none) v_l0 = dflt;
-    if (q_l1.none) v_l1 = dflt;
-    if (q_c.none) v_c = dflt;
+    if (q_t0 == NONE) v_t0 = dflt;
+    if (q_t1 == NONE) v_t1 = dflt;
+    if (q_l0 == NONE) v_l0 = dflt;
+    if (q_l1 == NONE) v_l1 = dflt;
+    if (q_c == NONE) v_c = dflt;
 
     int *top = ish + g * IL::INTS + 1, *left = top + IL::ARR, *ftop = left + IL::ARR, *fleft = ftop + IL::ARR, *ref = fleft + IL::ARR - 1 + N;
     top[i] = v_t0; top[N + i] = v_t1; left[i] = v_l0; left[N + i] = v_l1;
@@ -317,6 +332,17 @@ __device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds,
     }
 }
 
+template <int LOG2N, typename Pixel>
+__device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds, const int lane, const int job0, const int njobs, const PlaneSet planes,
+                                                const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
+                                                const int16_t *__restrict__ coeffs, const int bit_depth)
+{
+    const PackRecs r = pack_load_recs<LOG2N>(lane, job0, njobs, jobs, residuals);
+    u32x4 cq[4];
+    pack_load_coeffs<LOG2N>(r, lane, coeffs, cq);
+    pack_compute<LOG2N, Pixel>(ish, tu_lds, lane, planes, r, cq, coeffs, bit_depth);
+}
+
 #undef PACK_SYNC
 
 // jobs sorted by size: wavefront w serves 64 / N consecutive blocks of the segment it falls into
@@ -348,9 +374,9 @@ __global__ __launch_bounds__(64) void intra_pack_kernel(PlaneSet planes, const o
 // Most dependency levels of a picture are narrow: the intra picture of a 1080p stream chains ~1200 levels of 1 .. 16 wavefronts, the tail
 // of every inter picture a dozen of 1 .. 8 (OHEVC_TRACE_LEVELS).  As one launch each they cost a kernel boundary apiece - ~6 us of kernel
 // (start, three dependent memory round trips, end-of-kernel write-back) plus 2 - 4 us until the next one starts.  A level that fits ONE
-// workgroup (16 wavefronts) needs no kernel boundary to hand its samples to the next level: all of its wavefronts sit on one CU, so
+// workgroup (kChainWaves wavefronts) needs no kernel boundary to hand its samples to the next level: all of its wavefronts sit on one CU, so
 // "stores complete in L2 (s_waitcnt vmcnt(0)) - workgroup barrier - drop this CU's L1 (buffer_inv sc1)" orders them.  The host cuts the
-// chain of levels into runs of consecutive levels of at most 16 wavefronts and launches one workgroup per run.
+// chain of levels into runs of consecutive levels of at most kChainWaves wavefronts and launches one workgroup per run.
 struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
     int first_wave[5];               // as IntraPackSegs
     int njobs[4];
@@ -358,35 +384,73 @@ struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
     int reserved;
 };
 
+constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup = the widest level it takes
+
 template <typename Pixel>
-__global__ __launch_bounds__(1024) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
-                                                           int nlevels, int bit_depth, const int16_t *__restrict__ coeffs)
+__global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
+                                                                       int nlevels, int bit_depth, const int16_t *__restrict__ coeffs)
 {
-    __shared__ int ish[16 * kIntraPackInts];
-    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[16 * TuLayout<5>::WAVE_BYTES];
+    __shared__ int ish[kChainWaves * kIntraPackInts];
+    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[kChainWaves * TuLayout<5>::WAVE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int *my_ish = ish + wave * kIntraPackInts;
+    unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
+
+    // what this wavefront does at a level: the size class of its blocks (-1: nothing), its first block, the level's arrays.  All wave-uniform.
+    struct Slot { int s, job0, n; const ohevc_intra_job *j; const ohevc_tu_job *r; };
+    auto slot_of = [&](const int l) -> Slot {
+        Slot sl = { -1, 0, 0, nullptr, nullptr };
+        if (l >= nlevels) return sl;
+        const IntraChainLevel lv = levels[l];
+        if (wave >= lv.first_wave[4]) return sl;
+        const int s = wave >= lv.first_wave[3] ? 3 : wave >= lv.first_wave[2] ? 2 : wave >= lv.first_wave[1] ? 1 : 0;
+        const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
+        sl.s = s;
+        sl.job0 = (wave - lv.first_wave[s]) * (16 >> s);
+        sl.n = lv.njobs[s];
+        sl.j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
+        sl.r = lv.res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job : nullptr;
+        return sl;
+    };
+    auto load_recs = [&](const Slot &sl) -> PackRecs {
+        if (sl.s == 0) return pack_load_recs<2>(lane, sl.job0, sl.n, sl.j, sl.r);
+        if (sl.s == 1) return pack_load_recs<3>(lane, sl.job0, sl.n, sl.j, sl.r);
+        if (sl.s == 2) return pack_load_recs<4>(lane, sl.job0, sl.n, sl.j, sl.r);
+        if (sl.s == 3) return pack_load_recs<5>(lane, sl.job0, sl.n, sl.j, sl.r);
+        return PackRecs{ u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
+    };
+    auto load_cq = [&](const Slot &sl, const PackRecs &r, u32x4 (&cq)[4]) {
+        if (sl.s == 0)      pack_load_coeffs<2>(r, lane, coeffs, cq);
+        else if (sl.s == 1) pack_load_coeffs<3>(r, lane, coeffs, cq);
+        else if (sl.s == 2) pack_load_coeffs<4>(r, lane, coeffs, cq);
+        else if (sl.s == 3) pack_load_coeffs<5>(r, lane, coeffs, cq);
+    };
+
+    // Software pipeline over the levels: while level l computes and its stores drain, the coefficients of level l + 1 and the records of
+    // level l + 2 are in flight (none of them depends on samples), so behind the barrier a level only waits for its neighbour samples -
+    // which the previous level has just left in this XCD's L2.
+    Slot s0 = slot_of(0), s1 = slot_of(1);
+    PackRecs r0 = load_recs(s0), r1 = load_recs(s1);
+    u32x4 cq0[4] = {}, cq1[4] = {};
+    load_cq(s0, r0, cq0);
     for (int l = 0; l < nlevels; l++) {
         if (l) {
-            xcd_release();                                   // this wavefront's rows are in L2 ...
+            xcd_release();                                   // this wavefront's rows are in L2 (and what it prefetched has arrived) ...
             __syncthreads();                                 // ... and so are everybody else's
             xcd_acquire();                                   // nothing older of them in this CU's L1
         }
-        const IntraChainLevel lv = levels[l];
-        if (wave < lv.first_wave[4]) {                       // wave-uniform
-            const int s = wave >= lv.first_wave[3] ? 3 : wave >= lv.first_wave[2] ? 2 : wave >= lv.first_wave[1] ? 1 : 0;
-            const int local = wave - lv.first_wave[s];
-            const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
-            const ohevc_intra_job *j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
-            const ohevc_tu_job *r = lv.res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job : nullptr;
-            int *my_ish = ish + wave * kIntraPackInts;
-            unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
-            const int n = lv.njobs[s];
-            if (s == 0)      intra_pack_body<2, Pixel>(my_ish, my_tu, lane, local * 16, n, planes, j, r, coeffs, bit_depth);
-            else if (s == 1) intra_pack_body<3, Pixel>(my_ish, my_tu, lane, local * 8, n, planes, j, r, coeffs, bit_depth);
-            else if (s == 2) intra_pack_body<4, Pixel>(my_ish, my_tu, lane, local * 4, n, planes, j, r, coeffs, bit_depth);
-            else             intra_pack_body<5, Pixel>(my_ish, my_tu, lane, local * 2, n, planes, j, r, coeffs, bit_depth);
-        }
+        if (s0.s == 0)      pack_compute<2, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        else if (s0.s == 1) pack_compute<3, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        else if (s0.s == 2) pack_compute<4, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        else if (s0.s == 3) pack_compute<5, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        load_cq(s1, r1, cq1);
+        const Slot s2 = slot_of(l + 2);
+        const PackRecs r2 = load_recs(s2);
+        s0 = s1; r0 = r1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cq0[q] = cq1[q];
+        s1 = s2; r1 = r2;
     }
 }
 

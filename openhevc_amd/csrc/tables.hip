@@ -746,8 +746,9 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
     if (rc != OHEVC_OK) return rc;
     if (download) {
         const HostPic &hp = s->pics[s->cur].v;
-        for (int c = 0; c < 3; c++)
-            if ((rc = ohevc_pic_download(ctx, hp.slot, c, hp.data[c], hp.linesize[c])) != OHEVC_OK) return rc;
+        void *const host[3] = { hp.data[0], hp.data[1], hp.data[2] };
+        const ptrdiff_t strides[3] = { hp.linesize[0], hp.linesize[1], hp.linesize[2] };
+        if ((rc = ohevc_pic_download_planes(ctx, hp.slot, host, strides)) != OHEVC_OK) return rc;
     }
     return OHEVC_OK;
 }

@@ -1772,6 +1772,8 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_intra_chain_max_waves(void) { return ohevc::kChainWaves; }
+
 extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                                     const int16_t *coeffs, void *stream)
 {
@@ -1788,8 +1790,8 @@ extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth,
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const IntraChainLevel *lv = reinterpret_cast<const IntraChainLevel *>(levels);
-    if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(1024), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
-    else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(1024), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
+    if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
+    else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

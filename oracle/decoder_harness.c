@@ -26,6 +26,7 @@
 int  ohdec_backend_open(void);
 int  ohdec_backend_frame_done(void);
 int  ohdec_backend_frame_failed(void);
+void ohdec_backend_pre_close(void);
 int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
 void ohdec_backend_close(void);
 /* frame-parallel decoding over processes: integration/hip_frames.h (the struct is passed through opaquely) */
@@ -40,6 +41,7 @@ static int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesiz
 static int  ohdec_backend_open(void) { return 0; }
 static int  ohdec_backend_frame_done(void) { return 0; }
 static int  ohdec_backend_frame_failed(void) { return 0; }
+static void ohdec_backend_pre_close(void) {}
 static void ohdec_backend_close(void) {}
 #endif
 
@@ -262,6 +264,7 @@ void ohdec_close(ohdec *d)
 {
     if (!d)
         return;
+    ohdec_backend_pre_close();          /* page locks of the frame buffers go before the buffers do */
     avcodec_close(d->avctx);
     av_free(d->avctx);
     av_frame_free(&d->frame);

@@ -58,7 +58,7 @@ typedef struct hipemuEvent  *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
 struct hipDeviceProp_t {
     char name[256];
     char gcnArchName[256];
@@ -79,6 +79,8 @@ hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
 hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
 hipError_t hipHostFree(void *p);
+hipError_t hipHostRegister(void *p, size_t n, unsigned flags);
+hipError_t hipHostUnregister(void *p);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t s);

@@ -303,6 +303,8 @@ hipError_t hipMalloc(void **p, size_t n)
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { memmove(dst, src, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memmove(dst, src, n); return hipSuccess; }
 hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t)

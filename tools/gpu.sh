@@ -37,10 +37,21 @@ prof_stats() {      # <dir> <name>: rocprofv3 --kernel-trace --stats summary of 
   python tools/rocpd_summary.py stats $dir/t_results.db 2>/dev/null | cut -c1-170 | head -${STATS_ROWS:-14}
 }
 
+# a step may be preceded by VAR=value words: they are exported for that step only (and become part of its file names)
 step() {
-  local s=$1; shift
   n=$((n + 1))
-  echo "== [$TAG] $s $*"
+  local envs=()
+  while [[ "$1" == [A-Za-z_]*=* ]]; do envs+=("$1"); shift; done
+  if [ ${#envs[@]} -gt 0 ]; then
+    ( export "${envs[@]}"; ENVTAG=$(echo "${envs[*]}" | tr -c 'a-zA-Z0-9\n' '_'); run_step "$@" )
+  else
+    ENVTAG=""; run_step "$@"
+  fi
+}
+
+run_step() {
+  local s=$1; shift
+  echo "== [$TAG] ${ENVTAG:+($ENVTAG) }$s $*"
   case $s in
     suite)
       ( time timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider -x "$@" 2>&1 | grep -v "$NOISE" | tail -12 ) 2>&1 | cut -c1-400 | tee $OUT/pytest_gpu.log ;;
@@ -49,9 +60,20 @@ step() {
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "$NOISE" | tail -3 | tee $OUT/smoke.log ;;
     bench)
-      local sfx=$(echo "$*" | tr -c 'a-zA-Z0-9\n' '_' | sed 's/__*/_/g; s/^_//; s/_$//')
+      local sfx=$(echo "$ENVTAG $*" | tr -c 'a-zA-Z0-9\n' '_' | sed 's/__*/_/g; s/^_//; s/_$//')
       timeout 900 python bench.py "$@" 2> $OUT/bench_${sfx:-default}.err | tail -1 > $OUT/bench${sfx:+_$sfx}.json
-      cut -c1-1500 $OUT/bench${sfx:+_$sfx}.json; tail -3 $OUT/bench_${sfx:-default}.err | grep -v "$NOISE" ;;
+      cut -c1-1200 $OUT/bench${sfx:+_$sfx}.json; tail -3 $OUT/bench_${sfx:-default}.err | grep -v "$NOISE"
+      python - $OUT/bench${sfx:+_$sfx}.json <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print("  frac", d["roofline"]["frac"], "zscan", d.get("zscan", {}).get("frac"), "checked", d.get("checked"))
+    for k, v in d.get("decode", {}).get("streams", {}).items():
+        print("  decode", k, {kk: (vv.get("fps"), vv.get("per_picture", {}).get("frame_end_hook_ms"), vv.get("per_picture", {}).get("launches")) for kk, vv in v.items() if isinstance(vv, dict)})
+except Exception as e:
+    print("  (no summary:", e, ")")
+PY
+      ;;
     bench_prof)
       prof_stats /tmp/prof_bench bench python $ROOT/bench.py --no-cpu-baseline --no-decode --no-zscan "$@" | tee $OUT/kernel_stats.txt ;;
     pmc)
@@ -82,7 +104,7 @@ for l in sys.stdin:
         timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/kpw_$only -o p -- $CMD > /dev/null 2>&1 )
       python tools/pmc_per_kernel.py /tmp/kp_$only/t_results.db /tmp/kpf_$only/p_results.db /tmp/kpw_$only/p_results.db | tee $OUT/pmc_$only.jsonl | cut -c1-300 ;;
     decode)
-      timeout 900 python tools/bench_decode.py "$@" 2>/dev/null | tail -1 > $OUT/decode_$n.json
+      timeout 900 python tools/bench_decode.py "$@" 2>/dev/null | tail -1 > $OUT/decode_$n${ENVTAG:+_$ENVTAG}.json; [ -n "$ENVTAG" ] && cp $OUT/decode_$n${ENVTAG:+_$ENVTAG}.json $OUT/decode_$n.json
       python - $OUT/decode_$n.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
@@ -122,7 +144,7 @@ PY
       [ -x tools/hbm_probe ] && timeout 300 tools/hbm_probe 2 2>&1 | tee $OUT/hbm_probe.jsonl | cut -c1-300
       [ -x tools/probes/dispatch_probe ] && timeout 300 tools/probes/dispatch_probe "$@" 2>&1 | tee $OUT/dispatch_probe.jsonl | cut -c1-300 ;;
     sh)
-      ( timeout 900 "$@" 2>&1 | grep -v "$NOISE" | tail -40 ) | cut -c1-600 | tee $OUT/sh_$n.log ;;
+      ( timeout 900 "$@" 2>&1 | grep -v "$NOISE" | tail -40 ) > $OUT/sh_$n.log; cut -c1-600 $OUT/sh_$n.log ;;
     *)
       echo "unknown step $s" ;;
   esac
