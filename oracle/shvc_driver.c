@@ -80,6 +80,10 @@ int ohref_shvc_blocks(int bd, int log2_ctb, drv_pic *el, int el_width, int el_he
     UpsamplInf u = { up[0], up[1], up[2], up[3], up[4], up[5], up[6], up[7], up[8] };
     const int ps = bd > 8 ? 2 : 1;
     int16_t *edge_emu_buffer_up_v = calloc(MAX_EDGE_BUFFER_SIZE + 64, sizeof(int16_t));     /* hevc.h:1164 */
+    /* OHREF_SHVC_POISON=v: the scratch buffer starts out filled with v instead of zeros.  In the decoder it is a member of the thread's
+     * HEVCLocalContext that every CTB reuses; a result that changes with v was computed from rows no slot call of that CTB wrote. */
+    if (getenv("OHREF_SHVC_POISON"))
+        for (int i = 0; i < MAX_EDGE_BUFFER_SIZE + 64; i++) edge_emu_buffer_up_v[i] = (int16_t)atoi(getenv("OHREF_SHVC_POISON"));
     fill_tables(&dsp, &vdsp, bd, hevcdsp_hook, videodsp_hook);
     if (u.idx == SNR) { free(edge_emu_buffer_up_v); return -1; }    /* x1 (SNR) scalability is a plain copy_block, hevc_filter.c:1187-1190 */
 

@@ -329,3 +329,59 @@ def test_shvc_upsample_block_slots(oracle, ref):
             assert np.array_equal(a[pl], b[pl]), (it, (bw, bh, ew, eh), ctb, list(up), pl)
         seen.add((int(up[8]), pa))
     assert {(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)} <= seen
+
+
+def test_shvc_x1_5_with_phase_alignment_where_the_reference_is_a_function_of_its_inputs(oracle, ref, monkeypatch):
+    """x1.5 with phase alignment through the block slots (the case the test above leaves out).  upsample_block_luma / _mc position and size
+    the source window with the general formula, add{X,Y}{Lum,Cr} included (hevc_filter.c:1193-1197, 1259-1263), but the x1.5 slots index
+    their rows as 2 (y - top) / 3 (hevcdsp_template.c:2063-2160): where the two disagree the vertical slot reads a row of the thread's
+    scratch buffer that no slot call of THIS CTB wrote - whatever an earlier CTB (or nothing) left there.  Shown here by running the
+    reference twice on scratch buffers that start out with different contents (OHREF_SHVC_POISON): the samples that differ between the
+    two runs are not a function of the stream.  Every other sample is, and there the restatement must equal the reference."""
+    rng = np.random.default_rng(313)
+    undetermined = determined = 0
+    for it in range(24):
+        bw, bh = int(rng.integers(5, 20)) * 16, int(rng.integers(5, 15)) * 16          # exactly x1.5
+        ew, eh, win = bw * 3 // 2, bh * 3 // 2, (0, 0, 0, 0)
+        bl = [rand_plane(rng, 8, bh, bw), rand_plane(rng, 8, bh // 2, bw // 2), rand_plane(rng, 8, bh // 2, bw // 2)]
+        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=1)
+        assert up[8] == po.SHVC_X1_5
+        ctb = int(rng.choice([4, 5, 6]))
+        _, blv = po.padded_planes(bl)
+        runs = []
+        for poison in ("0", "1357", "-2468"):
+            monkeypatch.setenv("OHREF_SHVC_POISON", poison)
+            runs.append(_shvc_run(lambda v: po.shvc_reference(ref.path, "blocks", 8, v, ew, eh, blv, bw, bh, win, up, log2_ctb=ctb), ew, eh))
+        monkeypatch.delenv("OHREF_SHVC_POISON")
+        ours = _shvc_run(lambda v: po.shvc_upsample_frame(oracle.path, 8, v, ew, eh, blv, bw, bh, win, up, block_slots=1), ew, eh)
+        for pl in range(3):
+            stable = (runs[0][pl] == runs[1][pl]) & (runs[0][pl] == runs[2][pl])
+            undetermined += int((~stable).sum()); determined += int(stable.sum())
+            bad = np.argwhere(stable & (ours[pl] != runs[0][pl]))
+            assert bad.size == 0, (it, (bw, bh, ew, eh), ctb, list(up), pl, len(bad), bad[:4].tolist())
+    assert undetermined > 0, "the reference never read an unprepared row: the premise of this test is gone"
+    assert determined > 20 * undetermined
+
+
+def test_shvc_reference_above_8_bit_writes_outside_the_picture(ref):
+    """Why SHVC above 8 bit is pinned against the restatement only: the reference's vertical slots add the destination stride - a BYTE
+    count, frame->linesize[] (hevc_filter.c:1232, 1303) - to a `pixel *` (hevcdsp_template.c:1914, 2017, 2116, 2150): with 16-bit samples
+    picture row y lands at row 2y, every other row of the upper half stays unwritten and the lower half goes beyond the plane (in the
+    decoder: into the next allocation).  No valid reference output exists there; the product and the oracle keep the 8-bit semantics
+    in sample units (tests/test_shvc_gpu.py, bit depths 10 and 14)."""
+    rng = np.random.default_rng(314)
+    bd, bw, bh = 10, 64, 48
+    ew, eh = 128, 96
+    up = po.shvc_params(bw, bh, ew, eh, (0, 0, 0, 0), phase_align=0)
+    bl = [rng.integers(1, 1 << bd, size=(bh, bw)).astype(np.uint16), rng.integers(1, 1 << bd, size=(bh // 2, bw // 2)).astype(np.uint16),
+          rng.integers(1, 1 << bd, size=(bh // 2, bw // 2)).astype(np.uint16)]
+    _, blv = po.padded_planes(bl, 256)
+    # the enhancement-layer planes sit at the top of buffers three times their height: room for the stray rows
+    big = [np.full((3 * eh + 512, ew + 512), 0xFFFF, np.uint16), np.full((3 * eh // 2 + 512, ew // 2 + 512), 0xFFFF, np.uint16),
+           np.full((3 * eh // 2 + 512, ew // 2 + 512), 0xFFFF, np.uint16)]
+    view = [b[256:, 256:256 + (ew >> (1 if i else 0))] for i, b in enumerate(big)]
+    assert po.shvc_reference(ref.path, "blocks", bd, view, ew, eh, blv, bw, bh, (0, 0, 0, 0), up, log2_ctb=5) == 0
+    luma = view[0]
+    written = (luma != 0xFFFF).any(axis=1)
+    assert not written[1:eh:2].any(), "odd rows of the picture were written: the stride is no longer applied twice"
+    assert written[0:2 * eh:2].all() and written[eh:2 * eh].any(), "rows beyond the picture's height stayed untouched"

@@ -87,7 +87,7 @@ PY
                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM" \
                  "GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
         i=$((i + 1))
-        ( cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace -d /tmp/ctr_$i -o p -- "$@" > /tmp/ctr_$i.log 2>&1 )
+        ( cd $ROOT && timeout 300 rocprofv3 --pmc $set --kernel-trace -d /tmp/ctr_$i -o p -- "$@" > /tmp/ctr_$i.log 2>&1 )
         python tools/rocpd_summary.py pmc /tmp/ctr_$i/p_results.db $k 2>&1 | cut -c1-220 | tee -a $OUT/counters_$k.txt
       done ;;
     kernels)
