@@ -158,13 +158,9 @@ __device__ __forceinline__ void pack_load_coeffs(const PackRecs &r, const int la
     }
 }
 
-struct PackNoMid { __device__ __forceinline__ void operator()() const {} };
-
-// `mid` runs right behind the issue of the neighbour loads and in front of their first use: the chain kernel puts the loads of later
-// levels there (they then fly while this level waits for its samples and computes)
-template <int LOG2N, typename Pixel, typename Mid = PackNoMid>
+template <int LOG2N, typename Pixel>
 __device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const u32x4 (&cq)[4],
-                                             const int16_t *__restrict__ coeffs, const int bit_depth, Mid &&mid = Mid())
+                                             const int16_t *__restrict__ coeffs, const int bit_depth)
 {
     using IL = IntraPackLayout<LOG2N>;
     constexpr int N = IL::N;
@@ -198,7 +194,6 @@ __device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, co
     const int q_l0 = c_l ? i * stride - P : p_l, q_l1 = c_bl ? (N + kb) * stride - P : p_bl;
     const int q_c = c_ul ? o_c : p_ul;
     int v_t0 = REC(q_t0), v_t1 = REC(q_t1), v_l0 = REC(q_l0), v_l1 = REC(q_l1), v_c = REC(q_c);
-    mid();
     const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
     const int dflt = 1 << (bit_depth - 1);
     if (q_t0 == NONE) v_t0 = dflt;
@@ -445,19 +440,13 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
             __syncthreads();                                 // ... and so are everybody else's
             xcd_acquire();                                   // nothing older of them in this CU's L1
         }
-        // in flight while this level waits for its samples and computes: the coefficients of level l + 1, the records of level l + 2
-        Slot s2 = { -1, 0, 0, nullptr, nullptr };
-        PackRecs r2 = { u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
-        auto mid = [&]() {
-            load_cq(s1, r1, cq1);
-            s2 = slot_of(l + 2);
-            r2 = load_recs(s2);
-        };
-        if (s0.s == 0)      pack_compute<2, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth, mid);
-        else if (s0.s == 1) pack_compute<3, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth, mid);
-        else if (s0.s == 2) pack_compute<4, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth, mid);
-        else if (s0.s == 3) pack_compute<5, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth, mid);
-        else                mid();
+        if (s0.s == 0)      pack_compute<2, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        else if (s0.s == 1) pack_compute<3, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        else if (s0.s == 2) pack_compute<4, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        else if (s0.s == 3) pack_compute<5, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
+        load_cq(s1, r1, cq1);
+        const Slot s2 = slot_of(l + 2);
+        const PackRecs r2 = load_recs(s2);
         s0 = s1; r0 = r1;
 #pragma unroll
         for (int q = 0; q < 4; q++) cq0[q] = cq1[q];

@@ -89,6 +89,11 @@ int ohref_shvc_blocks(int bd, int log2_ctb, drv_pic *el, int el_width, int el_he
 
     for (int y0 = 0; y0 < el_height; y0 += 1 << log2_ctb)
         for (int x0 = 0; x0 < el_width; x0 += 1 << log2_ctb) {
+            /* OHREF_SHVC_POISON_EACH=1: ... and is refilled in front of every CTB.  The decoder up-samples CTBs on demand, in the order
+             * motion compensation happens to reference them (ff_upsample_block, hevc_filter.c:1370-1395): what an earlier CTB left
+             * in the buffer is no more a function of the stream than its initial contents. */
+            if (getenv("OHREF_SHVC_POISON") && getenv("OHREF_SHVC_POISON_EACH"))
+                for (int i = 0; i < MAX_EDGE_BUFFER_SIZE + 64; i++) edge_emu_buffer_up_v[i] = (int16_t)atoi(getenv("OHREF_SHVC_POISON"));
             /* ---- upsample_block_luma, hevc_filter.c:1175-1238 */
             {
                 uint8_t *src, *dst = el->data[0];

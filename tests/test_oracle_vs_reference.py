@@ -335,9 +335,11 @@ def test_shvc_x1_5_with_phase_alignment_where_the_reference_is_a_function_of_its
     """x1.5 with phase alignment through the block slots (the case the test above leaves out).  upsample_block_luma / _mc position and size
     the source window with the general formula, add{X,Y}{Lum,Cr} included (hevc_filter.c:1193-1197, 1259-1263), but the x1.5 slots index
     their rows as 2 (y - top) / 3 (hevcdsp_template.c:2063-2160): where the two disagree the vertical slot reads a row of the thread's
-    scratch buffer that no slot call of THIS CTB wrote - whatever an earlier CTB (or nothing) left there.  Shown here by running the
-    reference twice on scratch buffers that start out with different contents (OHREF_SHVC_POISON): the samples that differ between the
-    two runs are not a function of the stream.  Every other sample is, and there the restatement must equal the reference."""
+    scratch buffer that no slot call of THIS CTB wrote - whatever an earlier CTB (or nothing) left there, and the decoder up-samples
+    CTBs in the order motion compensation happens to reference them (ff_upsample_block, hevc_filter.c:1370-1395).  Shown here by running
+    the reference three times with the scratch buffer refilled with a different value in front of every CTB (OHREF_SHVC_POISON[_EACH]):
+    the samples that differ between the runs are not a function of the stream.  Every other sample is, and there the restatement must
+    equal the reference."""
     rng = np.random.default_rng(313)
     undetermined = determined = 0
     for it in range(24):
@@ -351,11 +353,18 @@ def test_shvc_x1_5_with_phase_alignment_where_the_reference_is_a_function_of_its
         runs = []
         for poison in ("0", "1357", "-2468"):
             monkeypatch.setenv("OHREF_SHVC_POISON", poison)
+            monkeypatch.setenv("OHREF_SHVC_POISON_EACH", "1")
             runs.append(_shvc_run(lambda v: po.shvc_reference(ref.path, "blocks", 8, v, ew, eh, blv, bw, bh, win, up, log2_ctb=ctb), ew, eh))
         monkeypatch.delenv("OHREF_SHVC_POISON")
+        monkeypatch.delenv("OHREF_SHVC_POISON_EACH")
         ours = _shvc_run(lambda v: po.shvc_upsample_frame(oracle.path, 8, v, ew, eh, blv, bw, bh, win, up, block_slots=1), ew, eh)
         for pl in range(3):
             stable = (runs[0][pl] == runs[1][pl]) & (runs[0][pl] == runs[2][pl])
+            # an unprepared scratch row feeds one output row of one CTB: such a row segment is undetermined as a whole (a few of its samples
+            # come out equal all the same - clipped to 0 / 255 whatever the scratch held)
+            seg = (1 << ctb) >> (1 if pl else 0)
+            for x in range(0, stable.shape[1], seg):
+                stable[:, x:x + seg] &= stable[:, x:x + seg].all(axis=1, keepdims=True)
             undetermined += int((~stable).sum()); determined += int(stable.sum())
             bad = np.argwhere(stable & (ours[pl] != runs[0][pl]))
             assert bad.size == 0, (it, (bw, bh, ew, eh), ctb, list(up), pl, len(bad), bad[:4].tolist())

@@ -22,6 +22,8 @@ def test_upsample_matches_oracle(bd, block_slots):
     for it in range(14):
         bw, bh = int(rng.integers(10, 60)) * 8, int(rng.integers(10, 40)) * 8
         ratio = float(rng.choice([2.0, 1.5, 1.25, 1.75, 1.0]))
+        if ratio == 1.5:
+            bw, bh = bw // 16 * 16, bh // 16 * 16     # exactly x1.5: the fixed-pattern slots (UpsamplInf.idx 2)
         ew, eh = int(round(bw * ratio / 8)) * 8, int(round(bh * ratio / 8)) * 8
         win = (0, 0, 0, 0)
         if not block_slots and it % 3 == 0:           # window offsets: the frame function only (the block slots depend on the CTB grid there)
@@ -29,8 +31,8 @@ def test_upsample_matches_oracle(bd, block_slots):
         up = po.shvc_params(bw, bh, ew, eh, win, phase_align=int(rng.integers(0, 2)))
         if up[8] == po.SHVC_SNR:
             up[8] = po.SHVC_DEFAULT                   # x1: the general filter is still defined (the block path copies instead)
-        if block_slots and up[8] == po.SHVC_X1_5 and up[0] != 2048:
-            up = po.shvc_params(bw, bh, ew, eh, win, phase_align=0)     # x1.5 + phase alignment: the reference reads rows it never prepared
+        # (x1.5 with phase alignment through the block slots included: tests/test_oracle_vs_reference.py pins the restatement to the reference
+        #  on every sample the reference computes from rows it prepared; the rest it reads from stale scratch memory)
         bl = [rng.integers(0, 1 << bd, size=(bh, bw)).astype(dt), rng.integers(0, 1 << bd, size=(bh // 2, bw // 2)).astype(dt),
               rng.integers(0, 1 << bd, size=(bh // 2, bw // 2)).astype(dt)]
         want = [np.zeros((eh, ew), dt), np.zeros((eh // 2, ew // 2), dt), np.zeros((eh // 2, ew // 2), dt)]
@@ -61,16 +63,37 @@ def test_reference_call_sequences_on_hooked_tables(ref, mode):
         ratio = float(rng.choice([2.0, 1.5, 1.25]))
         ew, eh = int(round(bw * ratio / 8)) * 8, int(round(bh * ratio / 8)) * 8
         win = (0, 0, 0, 0) if mode == "blocks" or it % 2 else tuple(int(v) * 2 for v in rng.integers(0, 6, size=4))
-        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=0 if ratio == 1.5 else int(rng.integers(0, 2)))
+        if ratio == 1.5:
+            bw, bh = bw // 16 * 16, bh // 16 * 16
+            ew, eh = bw * 3 // 2, bh * 3 // 2
+        pa = int(rng.integers(0, 2))
+        up = po.shvc_params(bw, bh, ew, eh, win, phase_align=pa)
         bl = [rng.integers(0, 256, size=(bh, bw)).astype(np.uint8), rng.integers(0, 256, size=(bh // 2, bw // 2)).astype(np.uint8),
               rng.integers(0, 256, size=(bh // 2, bw // 2)).astype(np.uint8)]
         _, blv = po.padded_planes(bl)
+        # x1.5 + phase alignment through the block slots: the reference reads scratch rows it did not prepare (see
+        # tests/test_oracle_vs_reference.py); compare where its result does not move with the scratch buffer's previous contents
+        stale_prone = mode == "blocks" and up[8] == po.SHVC_X1_5 and pa
 
         def fresh():
             el = [np.zeros((eh, ew), np.uint8), np.zeros((eh // 2, ew // 2), np.uint8), np.zeros((eh // 2, ew // 2), np.uint8)]
             return po.padded_planes(el)
         _, want = fresh()
         assert po.shvc_reference(ref.path, mode, 8, want, ew, eh, blv, bw, bh, win, up, log2_ctb=5) == 0
+        mask = [np.ones(p.shape, bool) for p in want]
+        if stale_prone:
+            os.environ["OHREF_SHVC_POISON_EACH"] = "1"
+            for poison in ("1357", "-2468"):
+                os.environ["OHREF_SHVC_POISON"] = poison
+                _, other = fresh()
+                assert po.shvc_reference(ref.path, mode, 8, other, ew, eh, blv, bw, bh, win, up, log2_ctb=5) == 0
+                for pl in range(3):
+                    mask[pl] &= other[pl] == want[pl]
+            del os.environ["OHREF_SHVC_POISON"], os.environ["OHREF_SHVC_POISON_EACH"]
+            for pl in range(3):
+                seg = 32 >> (1 if pl else 0)
+                for x in range(0, mask[pl].shape[1], seg):
+                    mask[pl][:, x:x + seg] &= mask[pl][:, x:x + seg].all(axis=1, keepdims=True)
         keep, got = fresh()
         ctx = L.Ctx(0)
         s_bl, s_el = ctx.pic_alloc(bw, bh, 1, 8), ctx.pic_alloc(ew, eh, 1, 8)
@@ -89,5 +112,5 @@ def test_reference_call_sequences_on_hooked_tables(ref, mode):
         lib.ohevc_tables_bind(None)
         ctx.close()
         for pl in range(3):
-            bad = np.argwhere(out[pl] != want[pl])
+            bad = np.argwhere((out[pl] != want[pl]) & mask[pl])
             assert bad.size == 0, f"{mode} {bw}x{bh}->{ew}x{eh} win={win} up={list(up)} plane {pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
