@@ -42,6 +42,11 @@ int ohevc_debug_set_mc_variant(int variant);
  * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and
  * tests); written after the round's GPU budget was spent, so the A/B on the device is the first thing to do with it. */
 int ohevc_debug_set_sao_variant(int variant);
+/* Band SAO events on samples ABOVE the bit depth's range since the last reset (all streams of the current device; waits for them).  The
+ * reference's sao_band_filter reads past its 32-entry offset table for such a sample (hevcdsp_template.c:340-365; constrained intra
+ * prediction above 8 bit produces them): its output for that stream is whatever lay on its stack.  The kernels wrap the band index.
+ * 0 = every sample the stream put through the band filter was in range: the stream is comparable with the reference.  -1 on error. */
+long ohevc_debug_sao_band_above_range(int reset);
 /* ctx executor for the intra-coded blocks of a picture: 2 (shipped) = ONE ohevc_dev_ctbs launch, coding-tree blocks as tasks with their
  * samples in LDS (pictures whose intra jobs name no CTB size fall back to 0); 0 issues one prediction launch and one residual launch
  * per dependency level; 1 runs all levels of a picture inside one ohevc_dev_levels launch (persistent ticketed workgroups on one XCD, in-kernel

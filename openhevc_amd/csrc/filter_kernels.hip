@@ -290,6 +290,18 @@ __device__ __forceinline__ bool sao_wide_ok(const ohevc_sao_job &jb, const unsig
 // SPLIT (ohevc_debug_set_sao_variant(1); A/B pending): the edge classes run the block's interior - samples no border / restore rule can
 // touch - through a short form, and the outer ring (rows 0, h-2, h-1; the first and last quad of every row) through the full one,
 // enumerated so that all but one wavefront take a single form.
+// Band SAO of a sample above the bit depth's range: the reference's sao_band_filter indexes its 32-entry offset table with src >> (BIT_DEPTH - 5)
+// (hevcdsp_template.c:340-365) - past the table for such a sample, i.e. it adds whatever lies on its stack.  Constrained intra prediction
+// above 8 bit produces them (0x8080, hevcpred_template.c:159-161).  The kernels wrap the band index (a defined result) and COUNT the event:
+// a stream that never triggers it is decoded bit-identically with the reference, one that does has no reference output to compare with
+// (ohevc_debug_sao_band_above_range; the stream fuzzer asks before it compares instead of switching SAO off for such streams).
+__device__ unsigned g_sao_band_above_range;
+__global__ void sao_band_above_range_fetch(unsigned *out, int reset)
+{
+    *out = g_sao_band_above_range;
+    if (reset) g_sao_band_above_range = 0u;
+}
+
 template <typename Pixel, bool SPLIT>
 __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, PlaneSet lag, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth,
                                                   ohevc_sao_bypass bp, int g_variant)
@@ -336,6 +348,7 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
     if (jb.type == OHEVC_SAO_BAND) {                 // sao_band_filter_0, :340-365
         const int shift = bit_depth - 5;
         auto band = [&](int c, int x, int y) {
+            if (sizeof(Pixel) == 2 && c > maxv) atomicAdd(&g_sao_band_above_range, 1u);
             const int k = ((c >> shift) - jb.klass) & 31;
             const int off = k == 0 ? ov1 : k == 1 ? ov2 : k == 2 ? ov3 : k == 3 ? ov4 : 0;
             int v = iclip(c + off, 0, maxv);
@@ -630,6 +643,8 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
         return finish2(c, s1 + s2 + s16x2{ 2, 2 });
     };
     auto band2 = [&](unsigned c) {
+        if (sizeof(Pixel) == 2 && __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, c), maxv2)) != __builtin_bit_cast(unsigned, maxv2))
+            atomicAdd(&g_sao_band_above_range, 1u);
         const u16x2 k = ((__builtin_bit_cast(u16x2, c) >> (unsigned short)shift) - u16x2{ (unsigned short)band_pos, (unsigned short)band_pos }) & u16x2{ 31, 31 };
         return finish2(c, __builtin_bit_cast(s16x2, __builtin_elementwise_min(k, u16x2{ 4, 4 })));
     };
@@ -694,6 +709,17 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
 
 int g_sao_variant = 0;     // ohevc_debug_set_sao_variant
 }  // namespace ohevc
+
+extern "C" long ohevc_debug_sao_band_above_range(int reset)
+{
+    unsigned *d = nullptr, h = 0;
+    if (hipMalloc((void **)&d, sizeof(unsigned)) != hipSuccess) return -1;
+    (void)hipDeviceSynchronize();                     // every stream's SAO launches have finished
+    hipLaunchKernelGGL(ohevc::sao_band_above_range_fetch, dim3(1), dim3(1), 0, nullptr, d, reset);
+    const bool ok = hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? (long)h : -1;
+}
 
 extern "C" int ohevc_debug_set_sao_variant(int variant)
 {

@@ -399,6 +399,16 @@ void ohor_deblock_chroma(int bd, int vertical_edge, uint8_t *pix, ptrdiff_t stri
 
 /* ------------------------------------------------------------------ SAO
  * sao_band_filter_0: hevcdsp_template.c:340-365 */
+/* samples above the bit depth's range that went through the band filter since the last reset: each of them makes the REFERENCE read
+ * past its offset table, i.e. its output for the stream is not defined (tools/fuzz_streams.py asks before it compares) */
+static long ohor_band_above_range;
+long ohor_sao_band_above_range(int reset)
+{
+    long v = __atomic_load_n(&ohor_band_above_range, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(&ohor_band_above_range, 0, __ATOMIC_RELAXED);
+    return v;
+}
+
 void ohor_sao_band(int bd, uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst, ptrdiff_t stride_src,
                    const int16_t *offset_val, int band_position, int width, int height)
 {
@@ -411,6 +421,7 @@ void ohor_sao_band(int bd, uint8_t *dst, uint8_t *src, ptrdiff_t stride_dst, ptr
             /* & 31: a sample above the bit depth's range (constrained intra prediction above 8 bit leaves 0x8080 samples,
              * hevcpred_template.c:117-141) indexes past the reference's 32-entry table -- whatever lies on ITS stack.  Here, and in
              * the kernel, the band index wraps instead; such streams cannot be compared with the reference */
+            if (v >> bd) __atomic_fetch_add(&ohor_band_above_range, 1, __ATOMIC_RELAXED);
             stpx(PX(dst, stride_dst, x, y), bd, clip_px(v + table[(v >> shift) & 31], bd));
         }
 }

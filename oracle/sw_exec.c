@@ -282,3 +282,7 @@ void ohsw_sink(void *user, struct ohevc_ctx *ctx, int stage)
         exec_filters(ctx, &cur, bd);
     }
 }
+
+/* see ohor_sao_band_above_range (hevc_oracle.c): band SAO on samples above the bit depth's range since the last reset */
+long ohor_sao_band_above_range(int reset);
+long ohsw_sao_band_above_range(int reset) { return ohor_sao_band_above_range(reset); }

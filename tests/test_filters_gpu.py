@@ -170,3 +170,36 @@ def test_sao_bypass_map(oracle, sao_variant, bd, cfi, log2_pu, exact):
         bad = np.argwhere(got != want[pl])
         assert bad.size == 0, f"bd={bd} cfi={cfi} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
     assert is_pcm.any() and not is_pcm.all()
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_band_sao_above_the_range_is_counted_and_wraps(oracle, wide):
+    """A sample above the bit depth's range (constrained intra prediction above 8 bit leaves 0x8080 ones) sends the REFERENCE's band filter past
+    its 32-entry table (hevcdsp_template.c:340-365): no reference output exists for such a stream.  The kernels wrap the band index - the
+    oracle's definition - and count the event, so that the stream fuzzer can keep SAO on for those streams and compare all that never hit it."""
+    import ctypes as C
+    bd = 10
+    lib = L.load_library()
+    lib.ohevc_debug_sao_band_above_range.restype = C.c_long
+    rng = np.random.default_rng(4200 + wide)
+    H, W = 64, 64
+    src = rng.integers(0, 1 << bd, size=(H, W)).astype(np.uint16)
+    hits = [(3, 5), (17, 40), (63, 63)]
+    for y, x in hits:
+        src[y, x] = 0x8080
+    j = np.zeros(1, L.SAO_JOB)
+    j["x"], j["y"], j["w"], j["h"], j["plane"], j["type"], j["klass"] = 0, 0, W, H if wide else H - 1, 0, L.SAO_BAND, 5
+    j["offset_val"] = [0, 12, -7, 30, -28]
+    want = np.zeros_like(src)
+    oracle.sao_band(bd, want, src, 0, 0, W, int(j["h"][0]), [0, 12, -7, 30, -28], 5)
+    d_src, d_dst, d_jobs = G.to_dev(src), G.to_dev(np.zeros_like(src)), G.to_dev(j)
+    G.sync()
+    assert lib.ohevc_debug_sao_band_above_range(1) >= 0             # reset
+    L.dev_sao_batch(G.planes3([d_dst]), G.planes3([d_src]), bd, d_jobs.data_ptr(), 1, G.stream())
+    G.sync()
+    got = G.to_host(d_dst, np.uint16)
+    assert np.array_equal(got, want)
+    n = lib.ohevc_debug_sao_band_above_range(1)
+    expect = sum(1 for y, x in hits if y < int(j["h"][0]))
+    assert expect <= n <= 2 * expect, n                              # the wide kernel counts per pair of samples
+    assert lib.ohevc_debug_sao_band_above_range(0) == 0
