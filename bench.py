@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--frames-size", default="3840x2160", help="--mode frames: picture size WxH")
     ap.add_argument("--frames-bit-depth", type=int, default=10)
     ap.add_argument("--frames-pictures", type=int, default=17)
+    ap.add_argument("--frames-python-transport", action="store_true",
+                    help="--mode frames: exchange pictures through openhevc_amd.dist.FrameExchange (torch.distributed) instead of the native "
+                         "transport of include/ohevc_frames.h (RCCL broadcast in C; TCP with --frames-one-gpu)")
     ap.add_argument("--frames-one-gpu", action="store_true",
                     help="--mode frames: every rank uses GPU 0 and the planes travel host-staged through gloo (what the slice-data division "
                          "buys without more GPUs; RCCL needs one GPU per rank)")
@@ -225,9 +228,23 @@ def frames_mode(args):
                                      split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
     aus, _ = ps.generate(ps.StreamParams(**kw))
 
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    passes = [0]
+
+    def make_exchange(d):
+        if world <= 1:
+            return None
+        if args.frames_python_transport:
+            return D.FrameExchange(d.product_lib())
+        # the native transport: ncclBroadcast over xGMI (one GPU per rank), or TCP between ranks sharing GPU 0.  A fresh rendezvous per pass.
+        passes[0] += 1
+        if args.frames_one_gpu:
+            return D.NativeFrameTransport(d.product_lib(), rank, world, 0, D.NativeFrameTransport.WIRE_SOCKETS, f"127.0.0.1:{port + 100 + 16 * (passes[0] % 50)}")
+        return D.NativeFrameTransport(d.product_lib(), rank, world, local_rank, D.NativeFrameTransport.WIRE_RCCL, f"/tmp/ohevc_frames_rccl_id_{port}_{passes[0]}")
+
     def one_pass():
         with ps.Decoder("hip") as d:
-            ex = D.FrameExchange(d.product_lib()) if world > 1 else None
+            ex = make_exchange(d)
             if ex is not None:
                 d.frames_mode(ex.mode)
             n = 0
@@ -238,9 +255,13 @@ def frames_mode(args):
             if ex is not None:
                 ex.finish()
                 d.frames_mode(None)
+                stats = dict(ex.stats)
+                if hasattr(ex, "close"):
+                    ex.close()
                 if ex.error is not None:
                     raise ex.error
-            return n, (ex.stats if ex is not None else {})
+                return n, stats
+            return n, {}
 
     def barrier():
         if world > 1:
@@ -269,7 +290,8 @@ def frames_mode(args):
             "dtype": "u%d pixels, int16 coefficients" % (16 if args.frames_bit_depth > 8 else 8), "data": "synthetic Annex-B stream (oracle/pystream.py, seed 4242)",
             "config": {"workload": f"{W}x{H} {args.frames_bit_depth}-bit random-access stream, {npics} pictures per step, reference front end on the host "
                                    f"cores + HIP back end, pictures owned round-robin by decoding order", "parallelism": f"frame-parallel over {world} process(es)",
-                       "exchange": stats, "one_gpu": bool(args.frames_one_gpu)},
+                       "exchange": stats, "one_gpu": bool(args.frames_one_gpu),
+                       "transport": "python (torch.distributed)" if args.frames_python_transport else "native (include/ohevc_frames.h: " + ("TCP, host-staged" if args.frames_one_gpu else "ncclBroadcast, device memory") + ")"},
         }), flush=True)
     if world > 1:
         dist.destroy_process_group()

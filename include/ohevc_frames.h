@@ -1,0 +1,69 @@
+/*
+ * ohevc_frames.h -- frame-parallel decoding over several processes, one per GPU: the protocol's callback table and a
+ * native transport for it.
+ *
+ * The reference's frame threads (pthread_frame.c:479-513) give every thread one picture, share the DPB in host memory and wait on the
+ * rows of the pictures they predict from (hevc_await_progress, hevc.c:1951-1958) and on their motion fields (hevc_mvs.c).  Across
+ * processes the owner of a picture - decoding-order index % world - parses its slice data and reconstructs it on its GPU; what later
+ * pictures need from it travels to everyone: the sample planes and the motion field HEVCFrame.tab_mvf.  integration/hip_frames.h is the
+ * decoder-side half (which hooks call the four callbacks when); this header is the application-side half:
+ *
+ *   ohhip_frames_mode          the callback table the hooks drive (any transport can fill it);
+ *   ohevc_frames_transport_*   a transport in C inside libohevc_hip.so - no Python, no torch, no gloo - over one of two wires:
+ *       OHEVC_FRAMES_WIRE_RCCL     ncclBroadcast over xGMI, one GPU per process: planes AND motion fields travel as device memory in one
+ *                                  group call per picture on a stream of their own (librccl is loaded when the transport is created);
+ *       OHEVC_FRAMES_WIRE_SOCKETS  TCP connections between the processes, host-staged: for machines (and tests) where the ranks
+ *                                  share one GPU or have none - RCCL refuses two ranks on one device.
+ *   Collectives are issued in decoding order on every rank (publish by the owner, subscribe by the others: exactly one of the two per
+ *   exchanged picture), asynchronously; a rank blocks only in await_motion / await_planes, the two waits of the reference's frame threads.
+ */
+#ifndef OHEVC_FRAMES_H
+#define OHEVC_FRAMES_H
+#include <stddef.h>
+#include "ohevc_ctx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ohhip_frames_mode {
+    int rank, world;
+    void *user;
+    /* owner: picture `index` is complete (device work drained): planes in picture-store slot `slot` of ctx, motion field at mvf.
+     * Must not keep the pointers after returning (copy or send synchronously).
+     * failed != 0: the owner could not decode / reconstruct the picture.  The transport still issues the picture's collectives - every
+     * rank issues exactly one publish or subscribe per exchanged picture, or the others' receives never complete - with an error mark
+     * that makes await_motion / await_planes of the subscribers return nonzero at once (payload undefined; mvf may be NULL). */
+    int (*publish)(void *user, int index, ohevc_ctx *ctx, int slot, const void *mvf, size_t mvf_bytes, int failed);
+    /* everyone else: start receiving picture `index` from rank index % world; must not block */
+    int (*subscribe)(void *user, int index, ohevc_ctx *ctx, int slot, size_t mvf_bytes);
+    /* block until the motion field of remote picture `index` has arrived and copy it to mvf */
+    int (*await_motion)(void *user, int index, void *mvf, size_t mvf_bytes);
+    /* block until the planes of remote picture `index` have arrived and put them into picture-store slot `slot` (ohevc_pic_import) */
+    int (*await_planes)(void *user, int index, ohevc_ctx *ctx, int slot);
+    /* the decoder dropped the buffer of remote picture `index` (its DPB entry was recycled) or will never look at it again: wait for what
+     * is still in flight for it and free the staging memory.  May be NULL. */
+    int (*release)(void *user, int index);
+} ohhip_frames_mode;
+
+enum { OHEVC_FRAMES_WIRE_RCCL = 0, OHEVC_FRAMES_WIRE_SOCKETS = 1 };
+
+typedef struct ohevc_frames_transport ohevc_frames_transport;
+
+/* rank / world: this process and the number of processes; device: the GPU this process decodes on (RCCL: one per rank).
+ * rendezvous: RCCL: the path of a file (on storage all ranks see) through which rank 0 hands its ncclUniqueId to the others, created by
+ * rank 0 and removed by ohevc_frames_transport_destroy; sockets: "host:port" - rank r listens on port + r of `host`.
+ * timeout_s: how long a rank waits for its peers (rendezvous, a connection, a message) before it gives up with an error. */
+int  ohevc_frames_transport_create(ohevc_frames_transport **out, int rank, int world, int device, int wire, const char *rendezvous, int timeout_s);
+/* the callback table to hand to ohhip_set_frames_mode (valid until the transport is destroyed) */
+const ohhip_frames_mode *ohevc_frames_transport_mode(ohevc_frames_transport *t);
+/* every collective this rank issued has completed (call on all ranks after the last picture, before destroying) */
+int  ohevc_frames_transport_finish(ohevc_frames_transport *t);
+void ohevc_frames_transport_destroy(ohevc_frames_transport *t);
+typedef struct ohevc_frames_stats { long long published, subscribed, awaited_motion, awaited_planes, released, failed, bytes; } ohevc_frames_stats;
+int  ohevc_frames_transport_stats(ohevc_frames_transport *t, ohevc_frames_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

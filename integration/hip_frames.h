@@ -15,7 +15,8 @@
  *   - a process waits for a remote picture's motion field when it starts a picture that may name it (ff_hevc_frame_rps) and for
  *     its planes right before it launches that picture's device work (frame end): the two waits of the reference's frame threads.
  *
- * The transport is the application's (openhevc_amd/dist.py: torch.distributed).  All processes must call the hooks with the same
+ * The transport is the application's: include/ohevc_frames.h has one in C (RCCL broadcast of planes and motion fields over xGMI; a sockets
+ * wire for ranks that share a GPU), openhevc_amd/dist.py one on torch.distributed for the Python tests.  All processes must call the hooks with the same
  * stream; collectives are issued in decoding order on every process (publish by the owner, subscribe by the others, exactly one
  * of the two per exchanged picture).  Pictures nothing can reference (sub-layer non-reference pictures of the highest temporal
  * sub-layer) are not exchanged.  One decoding thread per process.
@@ -24,26 +25,9 @@
 #define OHHIP_FRAMES_H
 #include <stddef.h>
 #include "ohevc_ctx.h"
+#include "ohevc_frames.h"
 
-typedef struct ohhip_frames_mode {
-    int rank, world;
-    void *user;
-    /* owner: picture `index` is complete (device work drained): planes in picture-store slot `slot` of ctx, motion field at mvf.
-     * Must not keep the pointers after returning (copy or send synchronously).
-     * failed != 0: the owner could not decode / reconstruct the picture.  The transport still issues the picture's collectives - every
-     * rank issues exactly one publish or subscribe per exchanged picture, or the others' receives never complete - with an error mark
-     * that makes await_motion / await_planes of the subscribers return nonzero at once (payload undefined; mvf may be NULL). */
-    int (*publish)(void *user, int index, ohevc_ctx *ctx, int slot, const void *mvf, size_t mvf_bytes, int failed);
-    /* everyone else: start receiving picture `index` from rank index % world; must not block */
-    int (*subscribe)(void *user, int index, ohevc_ctx *ctx, int slot, size_t mvf_bytes);
-    /* block until the motion field of remote picture `index` has arrived and copy it to mvf */
-    int (*await_motion)(void *user, int index, void *mvf, size_t mvf_bytes);
-    /* block until the planes of remote picture `index` have arrived and put them into picture-store slot `slot` (ohevc_pic_import) */
-    int (*await_planes)(void *user, int index, ohevc_ctx *ctx, int slot);
-    /* the decoder dropped the buffer of remote picture `index` (its DPB entry was recycled) or will never look at it again: wait for what
-     * is still in flight for it and free the staging memory.  May be NULL. */
-    int (*release)(void *user, int index);
-} ohhip_frames_mode;
+/* the callback table (and a native transport that fills it: ohevc_frames_transport_*) live in the product's public header */
 
 /* switch the mode on (m != NULL) or off; call before the first picture */
 int  ohhip_set_frames_mode(const ohhip_frames_mode *m);

@@ -372,3 +372,44 @@ class FrameExchange:
         self.pending.clear()
         if self.world > 1:
             dist.barrier()
+
+
+class NativeFrameTransport:
+    """include/ohevc_frames.h: the transport in C inside libohevc_hip.so (ncclBroadcast of planes and motion fields over xGMI, or TCP
+    between ranks that share a GPU).  This class only creates / destroys it and hands its callback table to the decoder: no Python runs
+    while pictures are exchanged.  `lib` = the loaded product library (ctypes)."""
+    WIRE_RCCL, WIRE_SOCKETS = 0, 1
+
+    class Stats(_C.Structure):
+        _fields_ = [(n, _C.c_longlong) for n in ("published", "subscribed", "awaited_motion", "awaited_planes", "released", "failed", "bytes")]
+
+    def __init__(self, lib, rank, world, device, wire, rendezvous, timeout_s=120):
+        self.lib = lib
+        lib.ohevc_frames_transport_create.argtypes = [_C.POINTER(_C.c_void_p), _C.c_int, _C.c_int, _C.c_int, _C.c_int, _C.c_char_p, _C.c_int]
+        lib.ohevc_frames_transport_mode.restype = _C.c_void_p
+        lib.ohevc_frames_transport_mode.argtypes = [_C.c_void_p]
+        lib.ohevc_frames_transport_finish.argtypes = [_C.c_void_p]
+        lib.ohevc_frames_transport_destroy.argtypes = [_C.c_void_p]
+        lib.ohevc_frames_transport_stats.argtypes = [_C.c_void_p, _C.c_void_p]
+        lib.ohevc_last_error.restype = _C.c_char_p
+        h = _C.c_void_p()
+        if lib.ohevc_frames_transport_create(_C.byref(h), rank, world, device, wire, rendezvous.encode(), timeout_s) != 0:
+            raise RuntimeError("native frame transport: " + lib.ohevc_last_error().decode())
+        self.h = h
+        self.mode = lib.ohevc_frames_transport_mode(h)          # an address: oracle.pystream.Decoder.frames_mode takes it as is
+        self.error = None
+
+    @property
+    def stats(self):
+        st = self.Stats()
+        self.lib.ohevc_frames_transport_stats(self.h, _C.byref(st))
+        return {n: getattr(st, n) for n, _ in self.Stats._fields_}
+
+    def finish(self):
+        if self.lib.ohevc_frames_transport_finish(self.h) != 0:
+            self.error = RuntimeError("native frame transport: " + self.lib.ohevc_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.ohevc_frames_transport_destroy(self.h)
+            self.h = None

@@ -119,7 +119,9 @@ class Decoder:
         """Frame-parallel decoding over processes (integration/hip_frames.h): `mode` = the ohhip_frames_mode of an
         openhevc_amd.dist.FrameExchange (None switches it off).  Right after opening; one decoding thread."""
         self.L.ohdec_frames_mode.argtypes = [C.c_void_p, C.c_void_p]
-        if self.L.ohdec_frames_mode(self.h, C.byref(mode) if mode is not None else None) != 0:
+        # `mode`: a ctypes structure (FrameExchange.mode) or the address of one (the native transport's, ohevc_frames_transport_mode)
+        arg = None if mode is None else C.c_void_p(mode) if isinstance(mode, int) else C.byref(mode)
+        if self.L.ohdec_frames_mode(self.h, arg) != 0:
             raise RuntimeError(f"decoder '{self.kind}' has no frames mode")
 
     def frame_is_local(self):

@@ -233,3 +233,75 @@ def test_owner_failure_reaches_the_other_process():
     assert res[1][0] == 1 and res[1][1]["failed"] == 1          # picture 1 (decoding order) is rank 1's: its frame end reports the failure ...
     assert res[0][0] is not None and res[0][0] >= 2              # ... and rank 0 fails on the first picture that predicts from it
     assert res[0][2] < 30 and res[1][2] < 30                     # at once, not after a timeout
+
+
+# ---------------------------------------------------------------------------------------------------- the native transport, driven from C
+# include/ohevc_frames.h: the transport in C inside the product library, tests/c_host/frames_host.c: a C host of the frame-parallel
+# decoder - no Python, torch or gloo in the processes that decode.  Here: the emulated device code and the sockets wire (the RCCL wire
+# needs one GPU per rank; the protocol above the wire is the same code).
+def fnv64(b):
+    h = 1469598103934665603
+    for v in np.frombuffer(b, dtype=np.uint8).tolist():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def build_frames_host(tmpdir):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(tmpdir, "frames_host")
+    subprocess.run(["gcc", "-O1", "-Wall", os.path.join(root, "tests", "c_host", "frames_host.c"), "-I" + os.path.join(root, "include"), "-ldl", "-o", exe], check=True)
+    return exe
+
+
+def write_stream_file(path, aus):
+    with open(path, "wb") as f:
+        f.write(np.uint32(len(aus)).tobytes())
+        f.write(np.array([len(a) for a in aus], np.uint32).tobytes())
+        for a in aus:
+            f.write(a)
+
+
+def run_frames_hosts(exe, decoder_so, product_so, stream_file, world, wire, rendezvous, tmpdir, device=0, env=None):
+    import subprocess
+    procs, outs = [], []
+    for r in range(world):
+        out = os.path.join(tmpdir, f"out_{os.path.basename(stream_file)}_{r}.txt")
+        outs.append(out)
+        procs.append(subprocess.Popen([exe, decoder_so, product_so, stream_file, str(r), str(world), wire, rendezvous, str(device), out],
+                                      env=dict(os.environ, **(env or {})), stderr=subprocess.PIPE))
+    errs = [p.communicate(timeout=240)[1].decode(errors="replace") for p in procs]
+    codes = [p.returncode for p in procs]
+    merged, stats = {}, []
+    for out in outs:
+        for line in open(out):
+            w = line.split()
+            if w[0] == "stats":
+                stats.append({w[i]: int(w[i + 1]) for i in range(1, len(w), 2)})
+            else:
+                assert int(w[0]) not in merged, f"picture {w[0]} reconstructed twice"
+                merged[int(w[0])] = [int(v, 16) for v in w[1:]]
+    return codes, errs, merged, stats
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_transport_c_host_over_sockets(world, tmp_path):
+    from oracle import pystream as ps
+    from test_stream_cpu import load_golden
+    if not (ps.have("hipemu") and ps.have("c")):
+        pytest.skip("emulator-backed decoder not built (needs the reference tree once)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = build_frames_host(str(tmp_path))
+    product = os.path.join(root, "tests", "hipemu", "libohevc_hip_emu.so")
+    for k, name in enumerate(["ra_10b_odd", "ra_8b_foll_leaf", "weighted"]):
+        aus, _ = load_golden(name)
+        want = [[fnv64(pl.tobytes()) for pl in f] for f in ps.decode_stream("c", aus)]
+        sf = str(tmp_path / f"{name}.bin")
+        write_stream_file(sf, aus)
+        codes, errs, merged, stats = run_frames_hosts(exe, ps.lib_path("hipemu"), product, sf, world, "sockets", f"127.0.0.1:{free_port() + 16 * k}", str(tmp_path))
+        assert codes == [0] * world, (name, codes, errs)
+        assert sorted(merged) == list(range(len(want))), (name, sorted(merged))
+        assert [merged[p] for p in range(len(want))] == want, f"{name}: pictures differ from the single-process decoder"
+        assert all(s["pictures"] == len(want) for s in stats)
+        assert sum(s["awaited_planes"] for s in stats) > 0 and sum(s["failed"] for s in stats) == 0

@@ -7,7 +7,7 @@ import os
 import pytest
 import torch.multiprocessing as mp
 
-from test_dist_cpu import decoder_worker, free_port
+from test_dist_cpu import build_frames_host, decoder_worker, fnv64, free_port, run_frames_hosts, write_stream_file
 
 pytestmark = pytest.mark.gpu
 
@@ -39,3 +39,26 @@ def test_decoder_frame_parallel_two_processes_one_gpu():
         assert sorted(merged) == list(range(npics))
         assert [d for p in range(npics) for d in merged[p]] == want, f"{name}: pictures differ from the single-process decoder"
         assert sum(res[r][name][2]["awaited_planes"] for r in range(world)) > 0
+
+
+
+@pytest.mark.timeout(300)
+def test_native_transport_c_host_two_processes_one_gpu(tmp_path):
+    """tests/c_host/frames_host.c on the device: two C processes (no Python, torch or gloo in them) decode one stream frame-parallel on
+    GPU 0 through the native transport's sockets wire (RCCL needs one GPU per rank: that wire runs where the ranks have their own,
+    bench.py --mode frames).  Expected pictures: the untouched reference decoder's, hashed here."""
+    from oracle import pystream as ps
+    from test_stream_cpu import load_golden
+    assert ps.have("hip") and ps.have("c")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = build_frames_host(str(tmp_path))
+    product = os.path.join(root, "openhevc_amd", "libohevc_hip.so")
+    for k, name in enumerate(["ra_8b_ctb64", "ra_10b_odd", "ra_8b_foll_leaf", "tiles", "ra_14b_weighted"]):
+        aus, _ = load_golden(name)
+        want = [[fnv64(pl.tobytes()) for pl in f] for f in ps.decode_stream("c", aus)]
+        sf = str(tmp_path / f"{name}.bin")
+        write_stream_file(sf, aus)
+        codes, errs, merged, stats = run_frames_hosts(exe, ps.lib_path("hip"), product, sf, 2, "sockets", f"127.0.0.1:{free_port() + 16 * k}", str(tmp_path))
+        assert codes == [0, 0], (name, codes, errs)
+        assert [merged[p] for p in range(len(want))] == want, f"{name}: pictures differ from the single-process decoder"
+        assert sum(s["awaited_planes"] for s in stats) > 0 and sum(s["failed"] for s in stats) == 0
