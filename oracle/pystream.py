@@ -336,6 +336,12 @@ class StreamParams:
         return (self.height + self.ctb - 1) >> self.log2_ctb
 
 
+# Syntax statistics of a low-QP (qp22-like) encode: most CUs carry a residual, dense significance maps, large coefficient levels -
+# 200-250 KB per 1080p picture (the default distributions give ~35 KB, the encoder-like "natural" set ~8 KB).  BASELINE config 1 (BQMall
+# 832x480 qp22) lives in this regime: the residual kernels and the coefficient upload dominate instead of the launch chain.
+DENSE_QP22 = dict(init_qp=22, probs=dict(pred_mode=0.08, skip=0.2, merge_flag=0.5, split_cu=0.6, rqt_root_cbf=0.92, cbf_luma=0.9, cbf_chroma=0.6,
+                                         split_transform=0.5, sig_coeff=0.6, sig_group=0.75, greater1=0.55, greater2=0.45, last_x=0.75, last_y=0.75))
+
 # context index ranges (elem_offset[], hevc_cabac.c:98-155) and the default P(bin = 1) that shapes the synthetic syntax
 CTX = {
     "sao_merge": (0, 1, 0.3), "sao_type": (1, 2, 0.7), "split_cu": (2, 5, 0.42), "transquant_bypass": (5, 6, 0.1),

@@ -1,4 +1,5 @@
 """Synthetic-stream configurations shared by the CPU and GPU stream tests and tests/golden/make_streams.py."""
+from oracle.pystream import DENSE_QP22
 
 # name -> oracle.pystream.StreamParams keyword arguments.  Small pictures: the point is syntax coverage.
 CASES = {
@@ -61,5 +62,7 @@ CASES = {
     "ra_8b_nonref_leaves": dict(gop="random_access", nframes=9, seed=133, nonref_leaves=1, width=208, height=120),
     # ... and a leaf that stays in the reference picture set of the next picture without being used by it (a Foll entry): the frame-parallel
     # decoder must neither wait for it nor trip over it
+    # BASELINE config 1's geometry and residual density: BQMall's 832x480, qp22-like statistics (~45 KB per picture at this size)
+    "bqmall_geometry_dense_qp22": dict(gop="random_access", nframes=5, seed=135, width=832, height=480, log2_ctb=6, **DENSE_QP22),
     "ra_8b_foll_leaf": dict(gop="random_access", nframes=9, seed=134, nonref_leaves=1, foll_leaves=1, width=208, height=120),
 }

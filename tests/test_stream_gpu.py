@@ -157,6 +157,14 @@ def _baseline_case(kw, threads, thread_type):
     assert (ok, bad) == (3 * kw["nframes"], 0)
 
 
+@pytest.mark.parametrize("threads,thread_type", [(1, 1), (8, 1)])
+def test_config1_bqmall_geometry_dense_residual(threads, thread_type):
+    """BASELINE config 1's geometry and regime: 832x480 Main 8-bit random access with qp22-like syntax statistics (oracle.pystream.DENSE_QP22:
+    nine CUs in ten carry a residual, dense significance maps - ~45 KB per picture here, 200-250 KB at 1080p).  No conformance stream exists in
+    this environment; the synthesiser's stream is decoded by the untouched reference and by the HIP back end, MD5 SEI checked."""
+    _baseline_case(dict(gop="random_access", nframes=17, seed=3000, width=832, height=480, log2_ctb=6, **ps.DENSE_QP22), threads, thread_type)
+
+
 @pytest.mark.parametrize("executor", ["2", "3"], ids=["chosen_per_picture", "ctb_tasks"])
 @pytest.mark.parametrize("threads,thread_type", [(1, 1), (4, 1)])
 def test_config3_1080p_main_random_access(threads, thread_type, executor, monkeypatch):

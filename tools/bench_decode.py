@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--frames", type=int, default=17)
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--qp22", action="store_true", help="qp22-like residual density (oracle.pystream.DENSE_QP22: 200-250 KB per 1080p picture)")
     ap.add_argument("--gop", default="random_access")
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--wpp", action="store_true", help="entropy_coding_sync stream; adds slice-thread (WPP row) and frame+slice runs")
@@ -63,6 +64,8 @@ def main():
         kw.update(wpp=1)
     if a.chroma_format != 1:
         kw.update(chroma_format=a.chroma_format, rext=1)
+    if a.qp22:
+        kw.update(ps.DENSE_QP22)
     if a.dense:
         kw.update(init_qp=38, probs=dict(rqt_root_cbf=0.8, cbf_luma=0.8, sig_coeff=0.6, last_x=0.75, last_y=0.75, skip=0.15))
     t = time.perf_counter()
@@ -77,7 +80,7 @@ def main():
     ps._load("hip").ohdec_backend_profile(C0.byref(_sec), _cnt)        # reset the cumulative counters
     exact = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
     res = dict(workload=f"synthetic {a.gop} stream {w}x{h8} {a.bit_depth}-bit, {a.frames} pictures, "
-                        f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}{' (encoder-like CU statistics)' if a.natural else ''}",
+                        f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}{' (qp22-like residual density)' if a.qp22 else ''}{' (encoder-like CU statistics)' if a.natural else ''}",
                bit_exact=bool(exact), bit_exact_frame_threads=bool(exact_mt), generate_s=round(tgen, 2))
     mp = w * h8 * a.frames / 1e6
     import ctypes as C

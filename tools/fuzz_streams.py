@@ -65,7 +65,10 @@ def random_params(rng):
     if "tiles" not in kw and rng.integers(0, 2) and ctb_w * ctb_h > 3:
         kw["slices_per_picture"] = int(rng.integers(2, 5))
         kw["dependent_slices"] = int(rng.integers(0, 2))
-    if rng.integers(0, 3) == 0:
+    if rng.integers(0, 6) == 0:                      # qp22-like residual density (BASELINE config 1's regime)
+        kw["probs"] = dict(kw.get("probs", {}), **ps.DENSE_QP22["probs"])
+        kw["init_qp"] = ps.DENSE_QP22["init_qp"]
+    elif rng.integers(0, 3) == 0:
         kw["probs"] = dict(kw.get("probs", {}), rqt_root_cbf=0.85, cbf_luma=0.85, cbf_chroma=0.7, sig_coeff=0.6, skip=0.15, split_cu=float(rng.uniform(0.3, 0.8)),
                            split_transform=float(rng.uniform(0.2, 0.8)), pred_mode=float(rng.uniform(0.1, 0.7)))
     return kw
