@@ -65,7 +65,8 @@ int ohevc_debug_set_record_only(int on);
  * residual added in registers); 0: one wavefront per block (ohevc_dev_intra_recon_batch).  Pictures with constrained intra prediction
  * always take the latter.  Returns the previous setting.  Environment: OHEVC_INTRA_PACK. */
 int ohevc_debug_set_intra_pack(int on);
-/* 1 (default): runs of consecutive narrow dependency levels (at most 16 wavefronts each) go out as one ohevc_dev_intra_chain launch;
+/* 1: runs of consecutive narrow dependency levels (at most 8 wavefronts each) go out as one ohevc_dev_intra_chain launch (measured: fewer launches,
+ * not faster - DESIGN.md 5g; default 0);
  * 0: one launch per level.  Environment: OHEVC_INTRA_CHAIN. */
 int ohevc_debug_set_intra_chain(int on);
 /* A/B of ohevc_tables_derive_filters: 1 (default) the deblocking maps travel and the device derives the edges (ohevc_dev_deblock_maps);

@@ -97,7 +97,7 @@ static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 8;   // widest level a chain takes
-static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
+static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 0; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
 static int g_intra_pack = getenv("OHEVC_INTRA_PACK") ? atoi(getenv("OHEVC_INTRA_PACK")) : 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
