@@ -126,6 +126,18 @@ int  ohevc_frame_reconstruct(ohevc_ctx *ctx);
  * and the stream has drained (ohevc_ctx_sync / ohevc_pic_download) */
 int  ohevc_frame_end(ohevc_ctx *ctx);
 
+/* The same frame end WITHOUT its host-side cost in the calling thread (for the reference's frame threads, pthread_frame.c: several decoding
+ * threads, each with a context of one store).  The recorded frame is handed to the store's issuer thread and the call returns; the issuer
+ * issues queued frames one after the other - each as soon as the frame ends of the pictures it references have been issued - on streams of
+ * its own, and queues the copy-back of the three planes into host[] (NULL: none; page-locked memory, ohevc_host_pin, makes it a DMA) behind
+ * it.  The decoding thread can begin its next picture at once.  ohevc_pic_wait_host: the application takes the picture out - returns when
+ * the copy has landed.  Errors of an asynchronous frame end mark the picture failed (dependents fail too) and are reported once by
+ * ohevc_ctx_async_status.  ohevc_ctx_sync / ohevc_pic_release / ohevc_ctx_destroy wait for submitted frames. */
+int  ohevc_frame_end_async(ohevc_ctx *ctx, void *const host[3], const ptrdiff_t host_stride[3]);
+int  ohevc_pic_wait_host(ohevc_ctx *ctx, int slot);
+int  ohevc_ctx_async_status(ohevc_ctx *ctx);
+int  ohevc_ctx_async_profile(ohevc_ctx *ctx, double *busy_seconds, long long *frames);
+
 /* Give up the frame being recorded (a recording error, a failed launch): drops what was recorded and publishes the picture as
  * complete-with-error, so that other contexts of the store that reference it -- they block until its frame end has been issued --
  * fail at once with OHEVC_ERR_STATE instead of timing out.  ohevc_frame_end does this itself when it returns an error. */

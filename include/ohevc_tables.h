@@ -138,6 +138,12 @@ int  ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot);
 /* frame end: run everything; with download != 0 the final planes are copied back into the registered host buffers
  * (needed wherever the CPU still reads pixels: output, MD5 check hevc.c:4146-4181) */
 int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
+/* The same, with the host-side work of the frame end (staging, upload, launches) on the store's issuer thread: returns at once
+ * (ohevc_frame_end_async, ohevc_ctx.h).  For decoders with frame threads.  With download != 0 the copy-back into the registered host
+ * planes is queued behind the picture's device work; ohevc_tables_fetch_picture(ctx, slot) - where the application takes the picture
+ * out - returns when it has landed. */
+int  ohevc_tables_end_frame_async(ohevc_ctx *ctx, int download);
+int  ohevc_tables_fetch_picture(ohevc_ctx *ctx, int slot);
 /* restore_tqb_pixels (hevc_filter.c:163-193) works on host pixels and is lost behind recording tables: before
  * ohevc_tables_end_frame hand over s->is_pcm (s->sps->min_pu_width x min_pu_height bytes, s->sps->log2_min_pu_size) whenever
  * pps->transquant_bypass_enable_flag || (sps->pcm_enabled_flag && sps->pcm.loop_filter_disable_flag).  With

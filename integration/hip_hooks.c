@@ -47,6 +47,11 @@ static volatile int        g_error;
 static int                 g_bulk_filters = 1;     /* OHHIP_BULK_FILTERS=0: keep the reference's filter drivers and the per-edge table calls */
 static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
 static int                 g_pin_frames = 1;       /* OHHIP_PIN_FRAMES=0: leave the decoder's frame buffers pageable */
+static int                 g_async = -1;           /* OHHIP_ASYNC_ISSUE: 1 / 0 = frame ends issued by the library's issuer thread / by the decoding
+                                                      thread; default (-1): asynchronous when the decoder runs frame threads */
+static double              g_issuer_s0;            /* issuer seconds / frames at the last profile call */
+static long long           g_issuer_f0;
+static volatile int        g_async_used;           /* some frame end went through the issuer: fetch_output waits for copy-backs */
 static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
 static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
 static long long           g_alg_bytes;        /* algorithmic HBM bytes of the recorded jobs (ohevc_frame_stats.alg_bytes), same period */
@@ -501,6 +506,7 @@ int ohdec_backend_open(void)
         ohevc_debug_set_record_only(1);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
     g_pin_frames = !(getenv("OHHIP_PIN_FRAMES") && atoi(getenv("OHHIP_PIN_FRAMES")) == 0);
+    g_async = getenv("OHHIP_ASYNC_ISSUE") ? atoi(getenv("OHHIP_ASYNC_ISSUE")) : -1;
     g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
     /* A/B of the executors of the intra-coded blocks (include/ohevc_debug.h): 0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture */
     ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
@@ -516,6 +522,9 @@ int ohdec_backend_open(void)
     g_nbufs = 0;
     g_nall = 0;
     g_error = 0;
+    g_async_used = 0;
+    g_issuer_s0 = 0;
+    g_issuer_f0 = 0;
     g_generation++;
     return 0;
 }
@@ -610,7 +619,7 @@ static int frames_await_planes(HEVCContext *s)
 
 int ohdec_backend_frame_done(void)
 {
-    int st;
+    int st, async;
     struct timespec t0, t1;
     ohevc_frame_stats fs;
     if (!t_frame_open)
@@ -629,7 +638,16 @@ int ohdec_backend_frame_done(void)
         fprintf(stderr, "ohhip: filter derivation failed: %s\n", ohevc_last_error());
         g_error = 1;
     }
-    st = ohevc_tables_end_frame(t_ctx, !g_defer_download);
+    /* Frame threads: the issue of the frame end (stage, upload, launches) and the copy-back leave the decoding thread (ohevc_frame_end_async);
+     * the picture's samples are waited for where it leaves the decoder (ohdec_backend_fetch_output).  Not with the decoded-picture-hash check
+     * on (hevc.c:4146-4162 reads the host planes in this thread right behind this call) and not in frames mode over processes (the picture is
+     * exported right below). */
+    async = g_async > 0 || (g_async < 0 && t_s && (t_s->threads_type & FF_THREAD_FRAME) && t_s->threads_number > 1);
+    if (async && ((t_s && t_s->decode_checksum_sei) || g_fm_on || !ohevc_ctx_has_device(t_ctx)))
+        async = 0;
+    st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame(t_ctx, !g_defer_download);
+    if (async)
+        g_async_used = 1;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (g_fm_on && t_publish && getenv("OHHIP_TEST_FAIL_INDEX") && atoi(getenv("OHHIP_TEST_FAIL_INDEX")) == t_publish_index)
         st = OHEVC_ERR_STATE;                   /* fault injection of tests/test_dist_cpu.py: the owner fails on this picture */
@@ -714,7 +732,7 @@ int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3])
 {
     ohevc_ctx *ctx = t_ctx ? t_ctx : g_root;
     int i, c, slot = -1;
-    if (!g_defer_download || !g_root || !data[0])
+    if ((!g_defer_download && !g_async_used) || !g_root || !data[0])
         return 0;
     pthread_mutex_lock(&g_lock);
     for (i = 0; i < g_nbufs; i++)
@@ -724,6 +742,14 @@ int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3])
     if (slot < 0) {
         fprintf(stderr, "ohhip: output picture is not in the picture store\n");
         return -1;
+    }
+    if (g_async_used && !g_defer_download) {     /* the copy-back was queued by the issuer: wait until it has landed */
+        if (ohevc_tables_fetch_picture(ctx, slot) != OHEVC_OK || ohevc_ctx_async_status(ctx) != OHEVC_OK) {
+            fprintf(stderr, "ohhip: asynchronous frame end failed: %s\n", ohevc_last_error());
+            g_error = 1;
+            return -1;
+        }
+        return 0;
     }
     {
         void *const host[3] = { data[0], data[1], data[2] };
@@ -750,6 +776,15 @@ void ohhip_await_progress(ThreadFrame *f, int progress, int field)
 void ohdec_backend_profile(double *end_frame_s, long long counts[8])
 {
     pthread_mutex_lock(&g_lock);
+    if (g_root && g_async_used) {           /* the issuer's seconds belong to the frame ends too (they just do not block a decoding thread) */
+        double bs = 0;
+        long long fr = 0;
+        if (ohevc_ctx_async_profile(g_root, &bs, &fr) == OHEVC_OK) {
+            g_end_frame_s += bs - g_issuer_s0;
+            g_issuer_s0 = bs;
+            g_issuer_f0 = fr;
+        }
+    }
     *end_frame_s = g_end_frame_s;
     memcpy(counts, g_counts, sizeof(g_counts));
     g_end_frame_s = 0;

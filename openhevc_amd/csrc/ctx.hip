@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -28,6 +29,27 @@ struct Picture {
     bool failed = false;                  // that frame_end gave up (ohevc_frame_abort): dependents fail at once instead of waiting
     hipEvent_t written = nullptr;         // recorded on the writer's stream by that frame_end
     std::vector<hipEvent_t> readers;      // frame-end events of pictures that read this one since it was written
+    // asynchronous frame ends (ohevc_frame_end_async): the copy-back into the application's planes
+    bool host_copy_issued = true;         // false between the submission of a frame end with a copy-back and the issue of that copy
+    hipEvent_t host_copy = nullptr;       // fires when the copy has landed
+};
+
+struct PicStore;
+// the thread that issues asynchronous frame ends (ohevc_frame_end_async, below)
+struct Issuer {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<ohevc_ctx *> queue;         // executor contexts holding a submitted frame, in submission order
+    std::vector<ohevc_ctx *> execs;        // all executor contexts (free ones have exec_busy == false)
+    int in_flight = 0;
+    bool stop = false;
+    int error = OHEVC_OK;                  // sticky: first failure of an asynchronous frame end (ohevc_ctx_async_status)
+    char error_text[256] = {};
+    double busy_s = 0;                     // seconds the issuer spent issuing (OHEVC_TRACE_TIMING)
+    long frames = 0;
+    int device = 0;
+    struct PicStore *store = nullptr;
 };
 
 // The device picture store = the decoded picture buffer.  One per ohevc_ctx_create, shared by ohevc_ctx_create_shared.
@@ -40,6 +62,7 @@ struct PicStore {
     unsigned version = 0;                 // bumped whenever a slot's planes change (contexts re-upload their MC table)
     std::mutex pin_m;
     std::vector<std::pair<uintptr_t, size_t>> pinned;      // host ranges page-locked through ohevc_host_pin
+    Issuer *issuer = nullptr;             // ohevc_frame_end_async: the thread that issues frame ends (created by the first submission)
 };
 
 struct DevBuf {                       // grow-only device buffer
@@ -85,6 +108,8 @@ struct LevelBins {
 
 }  // namespace
 
+static void async_drain(PicStore &st);
+static void issuer_shutdown(PicStore &st);
 static std::atomic<uint64_t> g_ctx_gen{1};
 // executor of the intra-coded blocks (ohevc_debug_set_level_launch):
 //   0  one prediction launch and one residual launch per dependency level;   1  all levels inside one ohevc_dev_levels launch;
@@ -190,6 +215,14 @@ struct ohevc_ctx : Rec {
     std::vector<uint32_t> ctb_opwords, ctb_sync_zero;
     std::vector<int32_t> ctb_task_of;
 
+    // asynchronous frame ends: an EXECUTOR context (owned by the store's issuer) takes over the recorded frame of a decoding thread's context
+    bool is_exec = false, exec_busy = false;
+    ohevc_ctx *async_from = nullptr;                       // the context the frame was recorded into (receives the statistics)
+    std::vector<int> async_refs;                           // reference pictures of the queued frame (it is issued once their frame ends are)
+    void *async_host[3] = {nullptr, nullptr, nullptr};     // copy-back destination, NULL = none
+    ptrdiff_t async_stride[3] = {0, 0, 0};
+    hipEvent_t dl_ring[8] = {};
+    int dl_next = 0;
     DevBuf d_jobs, d_coeffs, d_table, d_upsample;
     PinnedBuf stage;
     ohevc_frame_stats stats = {}, last_stats = {};
@@ -284,6 +317,10 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->dry) { delete c; return; }
     // teardown: an error here has nowhere to go
     (void)hipSetDevice(c->device);
+    if (!c->is_exec && c->store->issuer) {
+        async_drain(*c->store);
+        if (c->store.use_count() == 1 + (long)c->store->issuer->execs.size()) issuer_shutdown(*c->store);      // the last recording context goes
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
         (void)hipDeviceSynchronize();
@@ -313,6 +350,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
     if (c->stage.p) (void)hipHostFree(c->stage.p);
     if (c->staged) (void)hipEventDestroy(c->staged);
+    for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
     if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
 }
@@ -341,6 +379,11 @@ extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
 {
     OHEVC_REQUIRE(c != nullptr, "ctx");
     if (c->dry) return OHEVC_OK;
+    if (c->store->issuer && !c->is_exec) {              // frame ends this context submitted run on the issuer's streams
+        async_drain(*c->store);
+        OHEVC_HIP_TRY(hipSetDevice(c->device));
+        OHEVC_HIP_TRY(hipDeviceSynchronize());
+    }
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     c->staged_pending = false;
     return OHEVC_OK;
@@ -404,6 +447,7 @@ extern "C" int ohevc_pic_release(ohevc_ctx *c, int slot)
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
     // other contexts of the store may still have kernels in flight that read this picture
+    if (!c->dry && !c->is_exec) async_drain(*c->store);
     if (!c->dry) OHEVC_HIP_TRY(c->store.use_count() > 1 ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream));
     if (c->cur == slot) c->cur = -1;
     std::lock_guard<std::mutex> g(c->store->m);
@@ -476,6 +520,7 @@ extern "C" int ohevc_host_unpin_all(ohevc_ctx *c)
 {
     OHEVC_REQUIRE(c != nullptr, "null context");
     if (c->dry) return OHEVC_OK;
+    async_drain(*c->store);                             // queued copy-backs name this memory
     std::lock_guard<std::mutex> g(c->store->pin_m);
     if (c->store->pinned.empty()) return OHEVC_OK;
     OHEVC_HIP_TRY(hipSetDevice(c->device));
@@ -1825,6 +1870,227 @@ static int frame_end_impl(ohevc_ctx *c)
     c->stats.alg_bytes = c->alg;
     c->stats.n_tu = c->nstat[0]; c->stats.n_mc = c->nstat[1]; c->stats.n_intra = c->nstat[2]; c->stats.n_dbk = c->nstat[3]; c->stats.n_sao = c->nstat[4];
     c->last_stats = c->stats;
+    return OHEVC_OK;
+}
+
+// ------------------------------------------------------------------ asynchronous frame ends
+// With the reference's frame threads every decoding thread ends its picture itself: stage, upload, ~30-75 launches, copy-back.  Measured
+// with 8-16 threads: a frame end that takes 0.6-0.9 ms alone takes 3-7 ms, 2.3 ms of it blocked until the threads decoding
+// its REFERENCE pictures have issued theirs (their completion events must exist before this picture's work can be ordered behind them) and
+// the rest issuing against the other threads' HIP calls.  The reference's own frame threads never block like that: they wait row by row
+// (pthread_frame.c:479-513) and only where a motion vector really points.  The remedy here does not cut pictures into bands - it takes the
+// issue out of the decoding threads: ohevc_frame_end_async hands the recorded frame (a swap of vectors) to an executor context of the
+// store's ISSUER thread and returns; the decoding thread goes on parsing.  The issuer takes queued frames in an order in which every
+// reference picture's frame end has been issued before (never blocks on one: it takes another frame), issues them one after the other -
+// no lock contention inside the HIP runtime - on a ring of executor streams, and queues the copy-back into the application's (page-locked)
+// planes behind each.  The host meets the device again only where the application takes the picture out: ohevc_pic_wait_host.
+static void swap_frame_state(ohevc_ctx &a, ohevc_ctx &b)
+{
+    std::swap(static_cast<Rec &>(a), static_cast<Rec &>(b));
+    a.dbk_blob.swap(b.dbk_blob);
+    std::swap(a.dbk_maps, b.dbk_maps);
+    a.bypass.swap(b.bypass);
+    std::swap(a.bypass_w, b.bypass_w); std::swap(a.bypass_l2, b.bypass_l2); std::swap(a.bypass_exact, b.bypass_exact);
+    std::swap(a.cur, b.cur); std::swap(a.frame_mode, b.frame_mode); std::swap(a.log2_ctb, b.log2_ctb);
+    std::swap(a.stats, b.stats);
+}
+
+static void issuer_run(Issuer *is)
+{
+    (void)hipSetDevice(is->device);
+    PicStore &st = *is->store;
+    for (;;) {
+        ohevc_ctx *e = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(is->m);
+            for (;;) {
+                if (is->stop && is->queue.empty()) return;
+                // the first queued frame whose reference pictures have all had their frame ends issued (or failed)
+                {
+                    std::lock_guard<std::mutex> g(st.m);
+                    for (size_t i = 0; i < is->queue.size() && !e; i++) {
+                        bool ready = true;
+                        for (int r : is->queue[i]->async_refs) ready = ready && st.pics[r].end_issued;
+                        if (ready) { e = is->queue[i]; is->queue.erase(is->queue.begin() + (long)i); }
+                    }
+                }
+                if (e) break;
+                if (is->queue.empty()) { is->cv.wait(lk); continue; }
+                // frames are queued but none is ready: a reference is still being parsed by its thread.  Its submission wakes us; a thread
+                // that died would leave us here for ever, so the oldest frame gives up after the reference wait limit
+                if (is->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s)) == std::cv_status::timeout && !is->queue.empty()) {
+                    e = is->queue.front(); is->queue.pop_front();
+                    e->async_refs.clear();             // frame_end_impl's own wait will fail it with the proper message
+                    break;
+                }
+            }
+            is->in_flight++;
+        }
+        const double t0 = now_s();
+        e->ref_slots.clear();
+        e->target_guarded = false;
+        int rc = ohevc_frame_end(e);                   // (aborts and publishes the picture as failed on error)
+        Picture *p = get_pic(e, e->cur);
+        if (p && e->async_host[0]) {
+            hipEvent_t ev = nullptr;
+            if (rc == OHEVC_OK) {
+                ev = e->dl_ring[e->dl_next];
+                e->dl_next = (e->dl_next + 1) % 8;
+                for (int i = 0; i < 3 && rc == OHEVC_OK; i++) {
+                    if (!e->async_host[i]) continue;
+                    const ohevc_plane &pl = p->planes[i];
+                    if (hipMemcpy2DAsync(e->async_host[i], e->async_stride[i], pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
+                                         hipMemcpyDeviceToHost, e->stream) != hipSuccess) { set_error("asynchronous copy-back failed: %s", hipGetErrorString(hipGetLastError())); rc = OHEVC_ERR_HIP; }
+                }
+                if (rc == OHEVC_OK && hipEventRecord(ev, e->stream) != hipSuccess) rc = OHEVC_ERR_HIP;
+            }
+            std::lock_guard<std::mutex> g(st.m);
+            p->host_copy = rc == OHEVC_OK ? ev : nullptr;
+            if (rc != OHEVC_OK) p->failed = true;
+            p->host_copy_issued = true;
+        }
+        st.cv.notify_all();
+        {
+            std::lock_guard<std::mutex> lk(is->m);
+            if (rc != OHEVC_OK && is->error == OHEVC_OK) { is->error = rc; snprintf(is->error_text, sizeof(is->error_text), "%s", ohevc_last_error()); }
+            if (e->async_from) e->async_from->last_stats = e->last_stats;
+            e->exec_busy = false;
+            is->in_flight--;
+            is->busy_s += now_s() - t0;
+            is->frames++;
+        }
+        is->cv.notify_all();
+    }
+}
+
+// wait until every submitted frame end has been issued (not: executed)
+static void async_drain(PicStore &st)
+{
+    Issuer *is = st.issuer;
+    if (!is) return;
+    std::unique_lock<std::mutex> lk(is->m);
+    is->cv.wait(lk, [&] { return is->queue.empty() && is->in_flight == 0; });
+}
+
+static void issuer_shutdown(PicStore &st)
+{
+    Issuer *is = st.issuer;
+    if (!is) return;
+    { std::lock_guard<std::mutex> lk(is->m); is->stop = true; }
+    is->cv.notify_all();
+    if (is->th.joinable()) is->th.join();
+    if (g_trace_timing && is->frames)
+        fprintf(stderr, "timing: issuer of store %p: %ld frame ends, %.3f ms each\n", (void *)&st, is->frames, 1e3 * is->busy_s / is->frames);
+    st.issuer = nullptr;
+    std::vector<ohevc_ctx *> execs;
+    execs.swap(is->execs);
+    delete is;
+    for (ohevc_ctx *e : execs) ohevc_ctx_destroy(e);
+}
+
+extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const ptrdiff_t host_stride[3])
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    OHEVC_REQUIRE(!c->is_exec, "executor contexts do not record");
+    if (c->dry) {                                       // record-only contexts have nothing to overlap
+        int rc = ohevc_frame_end(c);
+        return rc;
+    }
+    PicStore &st = *c->store;
+    merge_side(c);                                      // the slice threads of this picture have been joined: fold their recorders in
+    Issuer *is;
+    {
+        std::lock_guard<std::mutex> g(st.m);
+        if (!st.issuer) {
+            st.issuer = new Issuer();
+            st.issuer->device = c->device;
+            st.issuer->store = &st;
+            st.issuer->th = std::thread(issuer_run, st.issuer);
+        }
+        is = st.issuer;
+    }
+    // a free executor context (its vectors keep their capacity from picture to picture), or a new one
+    ohevc_ctx *e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(is->m);
+        for (ohevc_ctx *x : is->execs) if (!x->exec_busy) { e = x; break; }
+        if (e) e->exec_busy = true;
+    }
+    if (!e) {
+        int rc = ohevc_ctx_create_shared(&e, c->device, c);
+        if (rc != OHEVC_OK) return rc;
+        e->is_exec = true; e->exec_busy = true;
+        for (auto &ev : e->dl_ring) if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("event creation failed"); return OHEVC_ERR_HIP; }
+        std::lock_guard<std::mutex> lk(is->m);
+        is->execs.push_back(e);
+    }
+    swap_frame_state(*c, *e);
+    e->async_from = c;
+    e->async_refs.clear();
+    for (const auto *v : {&e->mc, &e->mc_small})
+        for (const ohevc_mc_job &j : *v) {
+            const int refs[2] = {j.ref0, (j.flags & OHEVC_MC_BI) ? j.ref1 : -1};
+            for (int r : refs)
+                if (r >= 0 && r != e->cur && std::find(e->async_refs.begin(), e->async_refs.end(), r) == e->async_refs.end()) e->async_refs.push_back(r);
+        }
+    for (int i = 0; i < 3; i++) { e->async_host[i] = host ? host[i] : nullptr; e->async_stride[i] = host && host_stride ? host_stride[i] : 0; }
+    {
+        std::lock_guard<std::mutex> g(st.m);
+        p->host_copy_issued = !(host && host[0]);
+        p->host_copy = nullptr;
+    }
+    c->stats = ohevc_frame_stats{};
+    {
+        std::lock_guard<std::mutex> lk(is->m);
+        is->queue.push_back(e);
+    }
+    is->cv.notify_all();
+    return OHEVC_OK;
+}
+
+// the application takes the picture out: its samples are in the planes given to ohevc_frame_end_async when this returns OHEVC_OK
+extern "C" int ohevc_pic_wait_host(ohevc_ctx *c, int slot)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr, "bad picture slot");
+    if (c->dry) return OHEVC_OK;
+    hipEvent_t ev;
+    {
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->host_copy_issued && p->end_issued; })) {
+            set_error("picture %d: its frame end was never issued", slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
+        ev = p->host_copy;
+    }
+    if (ev) OHEVC_HIP_TRY(hipEventSynchronize(ev));
+    return OHEVC_OK;
+}
+
+// first failure of an asynchronous frame end since the last call (OHEVC_OK: none); the text goes to ohevc_last_error()
+extern "C" int ohevc_ctx_async_status(ohevc_ctx *c)
+{
+    OHEVC_REQUIRE(c != nullptr, "null context");
+    Issuer *is = c->store->issuer;
+    if (!is) return OHEVC_OK;
+    std::lock_guard<std::mutex> lk(is->m);
+    const int rc = is->error;
+    if (rc != OHEVC_OK) set_error("%s", is->error_text);
+    is->error = OHEVC_OK;
+    return rc;
+}
+
+// seconds the store's issuer has spent issuing frame ends, and how many (cumulative; for benches)
+extern "C" int ohevc_ctx_async_profile(ohevc_ctx *c, double *busy_s, long long *frames)
+{
+    OHEVC_REQUIRE(c != nullptr && busy_s != nullptr && frames != nullptr, "null argument");
+    *busy_s = 0; *frames = 0;
+    Issuer *is = c->store->issuer;
+    if (!is) return OHEVC_OK;
+    std::lock_guard<std::mutex> lk(is->m);
+    *busy_s = is->busy_s; *frames = is->frames;
     return OHEVC_OK;
 }
 

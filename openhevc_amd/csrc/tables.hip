@@ -713,7 +713,15 @@ extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
     return ohevc_frame_begin(ctx, slot);
 }
 
-extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
+static int end_frame_common(ohevc_ctx *ctx, int download, bool async);
+extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download) { return end_frame_common(ctx, download, false); }
+// the frame end handed to the store's issuer thread (ohevc_frame_end_async): returns at once; the copy-back (download != 0) is queued behind
+// the picture's device work and ohevc_tables_fetch_picture waits for it
+extern "C" int ohevc_tables_end_frame_async(ohevc_ctx *ctx, int download) { return end_frame_common(ctx, download, true); }
+
+extern "C" int ohevc_tables_fetch_picture(ohevc_ctx *ctx, int slot) { return ohevc_pic_wait_host(ctx, slot); }
+
+static int end_frame_common(ohevc_ctx *ctx, int download, bool async)
 {
     using namespace ohevc;
     TablesState *s = state_of(ctx, false);
@@ -742,6 +750,12 @@ extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download)
         if ((rc = ohevc_rec_sao(ctx, &j)) != OHEVC_OK) { ohevc_frame_abort(ctx); return rc; }
     }
     s->held_sao.clear();
+    if (async) {
+        const HostPic &hp = s->pics[s->cur].v;
+        void *const host[3] = { hp.data[0], hp.data[1], hp.data[2] };
+        const ptrdiff_t strides[3] = { hp.linesize[0], hp.linesize[1], hp.linesize[2] };
+        return ohevc_frame_end_async(ctx, download ? host : nullptr, strides);
+    }
     rc = ohevc_frame_end(ctx);
     if (rc != OHEVC_OK) return rc;
     if (download) {
