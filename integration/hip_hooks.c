@@ -642,7 +642,7 @@ int ohdec_backend_frame_done(void)
      * the picture's samples are waited for where it leaves the decoder (ohdec_backend_fetch_output).  Not with the decoded-picture-hash check
      * on (hevc.c:4146-4162 reads the host planes in this thread right behind this call) and not in frames mode over processes (the picture is
      * exported right below). */
-    async = g_async > 0 || (g_async < 0 && t_s && (t_s->threads_type & FF_THREAD_FRAME) && t_s->threads_number > 1);
+    async = g_async > 0 || (g_async < 0 && t_s && (t_s->threads_type & FF_THREAD_FRAME));
     if (async && ((t_s && t_s->decode_checksum_sei) || g_fm_on || !ohevc_ctx_has_device(t_ctx)))
         async = 0;
     st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame(t_ctx, !g_defer_download);

@@ -30,6 +30,11 @@ struct Picture {
     hipEvent_t written = nullptr;         // recorded on the writer's stream by that frame_end
     std::vector<hipEvent_t> readers;      // frame-end events of pictures that read this one since it was written
     // asynchronous frame ends (ohevc_frame_end_async): the copy-back into the application's planes
+    // A slot holds one picture after the other.  `gen` counts them (frame_begin), `issued_gen` is the newest one whose frame end has been
+    // issued: a queued frame end names the VERSION of each reference picture it reads, because the decoder may recycle a reference's
+    // buffer - and begin a new picture in its slot - once the thread that decoded the reader is done with it, i.e. before the reader's
+    // frame end has been issued.
+    uint32_t gen = 0, issued_gen = 0;
     bool host_copy_issued = true;         // false between the submission of a frame end with a copy-back and the issue of that copy
     hipEvent_t host_copy = nullptr;       // fires when the copy has landed
 };
@@ -218,7 +223,8 @@ struct ohevc_ctx : Rec {
     // asynchronous frame ends: an EXECUTOR context (owned by the store's issuer) takes over the recorded frame of a decoding thread's context
     bool is_exec = false, exec_busy = false;
     ohevc_ctx *async_from = nullptr;                       // the context the frame was recorded into (receives the statistics)
-    std::vector<int> async_refs;                           // reference pictures of the queued frame (it is issued once their frame ends are)
+    std::vector<std::pair<int, uint32_t>> async_refs;      // (slot, version) of the reference pictures of the queued frame: it is issued once their frame ends are
+    uint32_t my_gen = 0;                                   // version of the target picture this context is recording / executing
     void *async_host[3] = {nullptr, nullptr, nullptr};     // copy-back destination, NULL = none
     ptrdiff_t async_stride[3] = {0, 0, 0};
     hipEvent_t dl_ring[8] = {};
@@ -461,6 +467,7 @@ extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *h
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && host != nullptr, "bad argument");
     if (c->dry) return OHEVC_OK;
+    async_drain(*c->store);              // queued frame ends may still have to read what lives in this slot
     {   // frames of other contexts may still read (or write) the picture that lived in this slot's memory
         std::lock_guard<std::mutex> g(c->store->m);
         if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
@@ -832,6 +839,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
         std::lock_guard<std::mutex> g(c->store->m);
         p->end_issued = false;
         p->failed = false;
+        c->my_gen = ++p->gen;
     }
     c->ref_slots.clear();
     c->target_guarded = false;
@@ -1291,11 +1299,13 @@ static int guard_pictures(ohevc_ctx *c, int target)
     for (int r : fresh) {
         Picture &rp = c->store->pics[r];
         if (g_trace_order) fprintf(stderr, "order: ctx %p target %d needs ref %d (issued %d, event %p)\n", (void *)c, target, r, (int)rp.end_issued, (void *)rp.written);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return rp.end_issued; })) {
+        // (an executor context was taken from the issuer's queue because the versions of its references had been issued; `end_issued` may
+        // already speak of a NEWER picture begun in the slot, whose work the issuer holds back until this reader has been issued)
+        if (!c->is_exec && !c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return rp.end_issued; })) {
             set_error("reference picture %d was never completed by its decoding thread", r);
             return OHEVC_ERR_STATE;
         }
-        if (rp.failed) { set_error("reference picture %d: its frame failed", r); return OHEVC_ERR_STATE; }
+        if (rp.failed && !c->is_exec) { set_error("reference picture %d: its frame failed", r); return OHEVC_ERR_STATE; }
         if (rp.written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, rp.written, 0));
     }
     if (!c->target_guarded) {
@@ -1744,8 +1754,8 @@ extern "C" int ohevc_frame_abort(ohevc_ctx *c)
     c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
     {
         std::lock_guard<std::mutex> g(c->store->m);
-        p->failed = true;
-        p->end_issued = true;
+        if (p->gen == c->my_gen) { p->failed = true; p->end_issued = true; }
+        if ((int32_t)(c->my_gen - p->issued_gen) > 0) p->issued_gen = c->my_gen;
     }
     c->store->cv.notify_all();
     return OHEVC_OK;
@@ -1864,7 +1874,8 @@ static int frame_end_impl(ohevc_ctx *c)
     }
     {
         std::lock_guard<std::mutex> g(c->store->m);
-        p->end_issued = true;
+        if (p->gen == c->my_gen) p->end_issued = true;      // (else a newer picture has been begun in this slot meanwhile)
+        if ((int32_t)(c->my_gen - p->issued_gen) > 0) p->issued_gen = c->my_gen;
     }
     c->store->cv.notify_all();
     c->stats.alg_bytes = c->alg;
@@ -1893,6 +1904,7 @@ static void swap_frame_state(ohevc_ctx &a, ohevc_ctx &b)
     std::swap(a.bypass_w, b.bypass_w); std::swap(a.bypass_l2, b.bypass_l2); std::swap(a.bypass_exact, b.bypass_exact);
     std::swap(a.cur, b.cur); std::swap(a.frame_mode, b.frame_mode); std::swap(a.log2_ctb, b.log2_ctb);
     std::swap(a.stats, b.stats);
+    std::swap(a.my_gen, b.my_gen);
 }
 
 static void issuer_run(Issuer *is)
@@ -1909,8 +1921,15 @@ static void issuer_run(Issuer *is)
                 {
                     std::lock_guard<std::mutex> g(st.m);
                     for (size_t i = 0; i < is->queue.size() && !e; i++) {
+                        const ohevc_ctx *q = is->queue[i];
                         bool ready = true;
-                        for (int r : is->queue[i]->async_refs) ready = ready && st.pics[r].end_issued;
+                        for (const auto &r : q->async_refs) ready = ready && (int32_t)(st.pics[r.first].issued_gen - r.second) >= 0;
+                        // ... and no frame submitted earlier still has to read (or write) the memory this one overwrites
+                        // (a frame submitted earlier may also read THIS frame's picture - its thread finished parsing first: that one waits for us)
+                        for (size_t k = 0; k < i && ready; k++) {
+                            ready = is->queue[k]->cur != q->cur;
+                            for (const auto &r : is->queue[k]->async_refs) ready = ready && !(r.first == q->cur && (int32_t)(r.second - q->my_gen) < 0);
+                        }
                         if (ready) { e = is->queue[i]; is->queue.erase(is->queue.begin() + (long)i); }
                     }
                 }
@@ -2028,12 +2047,19 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
     swap_frame_state(*c, *e);
     e->async_from = c;
     e->async_refs.clear();
-    for (const auto *v : {&e->mc, &e->mc_small})
-        for (const ohevc_mc_job &j : *v) {
-            const int refs[2] = {j.ref0, (j.flags & OHEVC_MC_BI) ? j.ref1 : -1};
-            for (int r : refs)
-                if (r >= 0 && r != e->cur && std::find(e->async_refs.begin(), e->async_refs.end(), r) == e->async_refs.end()) e->async_refs.push_back(r);
-        }
+    {
+        std::lock_guard<std::mutex> g(st.m);                // the decoder still holds this frame's references: their slots name the right versions
+        for (const auto *v : {&e->mc, &e->mc_small})
+            for (const ohevc_mc_job &j : *v) {
+                const int refs[2] = {j.ref0, (j.flags & OHEVC_MC_BI) ? j.ref1 : -1};
+                for (int r : refs) {
+                    if (r < 0 || r == e->cur) continue;
+                    bool seen = false;
+                    for (const auto &a : e->async_refs) seen = seen || a.first == r;
+                    if (!seen) e->async_refs.emplace_back(r, st.pics[r].gen);
+                }
+            }
+    }
     for (int i = 0; i < 3; i++) { e->async_host[i] = host ? host[i] : nullptr; e->async_stride[i] = host && host_stride ? host_stride[i] : 0; }
     {
         std::lock_guard<std::mutex> g(st.m);
