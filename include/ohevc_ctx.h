@@ -118,6 +118,11 @@ int  ohevc_rec_sao_bulk(ohevc_ctx *ctx, const ohevc_sao_job *jobs, int n);
  * are copied, uploaded at the frame end and the edges derived on the device (ohevc_dev_deblock_maps) - the bulk form of every
  * ohevc_rec_deblock call of the picture.  Needs a device: record-only contexts (ohevc_ctx_has_device() == 0) refuse it. */
 int  ohevc_rec_deblock_maps(ohevc_ctx *ctx, const ohevc_dbk_maps *maps);
+/* ... with the boundary strengths derived on the device too (ohevc_hip.h, ohevc_dev_boundary_strengths): maps->vertical_bs / horizontal_bs are
+ * not read; *bs carries HOST pointers to the picture's motion field and cbf_luma map (copied), and every call the reference would have made
+ * of ff_hevc_deblocking_boundary_strengths is recorded with ohevc_rec_bs_call(ctx, x0, y0, log2_size, OHEVC_BS_* flags). */
+int  ohevc_rec_deblock_maps_bs(ohevc_ctx *ctx, const ohevc_dbk_maps *maps, const ohevc_bs_maps *bs);
+int  ohevc_rec_bs_call(ohevc_ctx *ctx, int x0, int y0, int log2_size, int flags);
 int  ohevc_ctx_has_device(const ohevc_ctx *ctx);
 
 /* upload + launch prediction/residual work recorded so far (may be called several times per frame) */

@@ -73,6 +73,9 @@ int ohevc_debug_set_intra_chain(int on);
  * 0 the host derives one job per edge (the only form record-only contexts and the filter-lag emulation of 16x16 CTBs have).
  * Returns the previous setting. */
 int ohevc_debug_set_filters_on_device(int on);
+/* 1 (default): the boundary strengths are derived on the device as well (ohevc_dev_boundary_strengths; the front end records its
+ * ff_hevc_deblocking_boundary_strengths calls instead of making them); 0: the reference's own host arrays travel.  Environment: OHEVC_DEVICE_BS. */
+int ohevc_debug_set_bs_on_device(int on);
 
 /* Inspection of a record-only context, for HOST-LOGIC TESTS without a GPU: before a record-only context drops what was
  * recorded, it hands itself to this callback -- stage 0 from ohevc_frame_reconstruct (motion compensation, residual and intra

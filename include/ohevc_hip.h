@@ -173,6 +173,33 @@ typedef struct ohevc_dbk_maps {
 /* one pass: vertical != 0 all vertical edges (luma and chroma), else all horizontal edges; the caller runs both, in that order */
 int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_maps *maps, int vertical, void *stream);
 
+/* Boundary strengths on the device (second half): what ff_hevc_deblocking_boundary_strengths (hevc_filter.c:805-941, with
+ * boundary_strength :584-700) computes per transform unit on the host - 15-18 % of the front end's time on 1080p inter content
+ * (profiles/r03cpu_boundary_strength_share.jsonl) - from the decoder's motion field.  The host records one ohevc_bs_call per call of that
+ * function (its arguments and the slice / tile flags of its CTB) and hands over HEVCFrame.tab_mvf and s->cbf_luma as they are at the end
+ * of the picture (every entry is written once per picture, so evaluating the calls then gives what evaluating them in decoding order gave);
+ * the kernel fills vertical_bs / horizontal_bs (zeroed, sized as in ohevc_dbk_maps) for ohevc_dev_deblock_maps. */
+enum { OHEVC_BS_SLICE_UP = 1, OHEVC_BS_TILE_UP = 2, OHEVC_BS_SLICE_LEFT = 4, OHEVC_BS_TILE_LEFT = 8,      /* lc->slice_or_tiles_{up,left}_boundary, hevc.c:2636-2637 */
+       OHEVC_BS_ACROSS_SLICES = 16 };                                                                     /* s->sh.slice_loop_filter_across_slices_enabled_flag */
+typedef struct ohevc_bs_call {          /* 8 bytes */
+    uint16_t x0, y0;                    /* luma position of the transform / coding block */
+    uint8_t  log2_size;                 /* log2_trafo_size / log2_cb_size of the call */
+    uint8_t  flags;                     /* OHEVC_BS_* */
+    uint16_t reserved;
+} ohevc_bs_call;
+typedef struct ohevc_bs_maps {
+    const uint8_t *mvf;                 /* the picture's motion field: min_pu_width * min_pu_height entries, mvf_stride bytes apart (sizeof(MvField)) */
+    int32_t mvf_stride, off_mv, off_poc, off_pred_flag;    /* byte offsets inside an entry: Mv mv[2] (4 x int16), int32 poc[2], pred_flag */
+    int32_t pred_flag_bytes;            /* 4 (TEST_MV_POC builds, hevc.h:1032-1041) or 1; values PF_INTRA 0, PF_L0 1, PF_L1 2, PF_BI 3 */
+    const uint8_t *cbf_luma;            /* s->cbf_luma: min_tb_width * min_tb_height bytes */
+    int32_t min_pu_width, min_pu_height, log2_min_pu_size;
+    int32_t min_tb_width, min_tb_height, log2_min_tb_size;
+    int32_t log2_ctb_size, bs_width, width, height;
+    int32_t loop_filter_across_tiles;   /* pps->loop_filter_across_tiles_enabled_flag */
+} ohevc_bs_maps;
+/* maps->mvf / cbf_luma, calls, vertical_bs, horizontal_bs: DEVICE pointers; the two outputs must have been zeroed (hevc_frame_start memsets them) */
+int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohevc_bs_call *calls, int ncalls, uint8_t *vertical_bs, uint8_t *horizontal_bs, void *stream);
+
 /* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
  * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy
  * (the reference's sao_frame), one job per CTB and colour plane. */

@@ -199,7 +199,20 @@ typedef struct ohevc_filter_maps {
     int32_t min_pu_width, min_pu_height;
     int32_t emulate_filter_lag;
     const int *ctb_addr_ts_to_rs;
+    /* device-side boundary strengths (ohevc_tables_bs_wanted() != 0 for this picture and every call of ff_hevc_deblocking_boundary_strengths
+     * replaced by ohevc_tables_bs_call): the motion field s->ref->tab_mvf (entry layout as ohevc_bs_maps) and s->cbf_luma; tab_mvf NULL:
+     * horizontal_bs / vertical_bs above are the reference's own */
+    const void *tab_mvf;
+    int32_t mvf_stride, mvf_off_mv, mvf_off_poc, mvf_off_pred_flag, mvf_pred_flag_bytes;
+    const uint8_t *cbf_luma;
+    int32_t min_tb_width, min_tb_height, log2_min_tb_size;
 } ohevc_filter_maps;
+/* Will ohevc_tables_derive_filters derive the boundary strengths of a picture with this geometry on the device?  (Then the front end records
+ * its ff_hevc_deblocking_boundary_strengths calls with ohevc_tables_bs_call instead of making them.)  No for record-only contexts, for the
+ * per-edge host derivation (ohevc_debug_set_filters_on_device(0)), for 16x16 CTBs with SAO in 4:2:0 / 4:2:2 (the filter-lag replay reads the
+ * host arrays) and when switched off (ohevc_debug_set_bs_on_device(0); environment OHEVC_DEVICE_BS=0). */
+int  ohevc_tables_bs_wanted(ohevc_ctx *ctx, int log2_ctb_size, int sao_enabled, int chroma_format_idc, int emulate_filter_lag);
+int  ohevc_tables_bs_call(int x0, int y0, int log2_size, int flags);       /* records into the calling thread's bound context */
 int  ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *maps);
 /* the host planes registered for picture-store slot `slot` (tests: oracle/sw_exec.c executes recorded jobs on them) */
 int  ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[3], int linesize[3]);

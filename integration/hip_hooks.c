@@ -23,6 +23,7 @@
 #include <signal.h>
 #include <execinfo.h>
 #include <unistd.h>
+#include <stddef.h>
 
 #include "libavcodec/hevc.h"
 #include "libavcodec/thread.h"
@@ -469,6 +470,37 @@ void ohhip_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size)
     }
 }
 
+/* SURVEY.md 8f-3, second half: the boundary strengths (ff_hevc_deblocking_boundary_strengths, hevc_filter.c:805-941: 15-18 % of the front end's
+ * time on 1080p inter content) are derived on the device from the motion field.  The call sites (hevc.c:1578,1607,2400,2484) land here: the call
+ * is recorded - position, size, the slice / tile flags of its CTB - and the frame-end hook hands s->ref->tab_mvf and s->cbf_luma over instead of
+ * s->horizontal_bs / vertical_bs.  Where the reference's filter drivers still run on the host (they read those arrays) the reference's function
+ * is called as before. */
+static int device_bs(const HEVCContext *s)
+{
+    /* (asked by every thread that parses a part of the picture - slice threads have the picture's context bound by ohhip_cabac_init - and the
+     * answer depends on the picture alone) */
+    return t_ctx && !(s->pps->tiles_enabled_flag && s->threads_number != 1) &&       /* tiles_filters (hevc.c:2967) rewrites entries afterwards */
+           bulk_filters(s) && ohevc_tables_bs_wanted(t_ctx, s->sps->log2_ctb_size, s->sps->sao_enabled, s->sps->chroma_array_type, 1);
+}
+
+static int device_bs_frame(const HEVCContext *s)       /* the same decision at the frame end (the frame is no longer "open" there) */
+{
+    return t_ctx && !(s->pps->tiles_enabled_flag && s->threads_number != 1) && bulk_filters(s) &&
+           ohevc_tables_bs_wanted(t_ctx, s->sps->log2_ctb_size, s->sps->sao_enabled, s->sps->chroma_array_type, 1);
+}
+
+void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size)
+{
+    const HEVCLocalContext *lc = s->HEVClc;
+    if (!device_bs(s)) {
+        ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size);
+        return;
+    }
+    if (ohevc_tables_bs_call(x0, y0, log2_trafo_size, (lc->slice_or_tiles_up_boundary & 3) | ((lc->slice_or_tiles_left_boundary & 3) << 2) |
+                                                      (s->sh.slice_loop_filter_across_slices_enabled_flag ? OHEVC_BS_ACROSS_SLICES : 0)) != OHEVC_OK)
+        g_error = 1;
+}
+
 static int derive_filters(HEVCContext *s)
 {
     ohevc_filter_maps m;
@@ -488,6 +520,12 @@ static int derive_filters(HEVCContext *s)
     m.ctb_addr_rs_to_ts = s->pps->ctb_addr_rs_to_ts; m.tile_id = s->pps->tile_id;
     m.is_pcm = s->is_pcm; m.min_pu_width = s->sps->min_pu_width; m.min_pu_height = s->sps->min_pu_height;
     m.emulate_filter_lag = 1; m.ctb_addr_ts_to_rs = s->pps->ctb_addr_ts_to_rs;
+    if (device_bs_frame(s)) {
+        m.tab_mvf = s->ref->tab_mvf; m.mvf_stride = sizeof(MvField);
+        m.mvf_off_mv = offsetof(MvField, mv); m.mvf_off_poc = offsetof(MvField, poc); m.mvf_off_pred_flag = offsetof(MvField, pred_flag);
+        m.mvf_pred_flag_bytes = sizeof(((MvField *)0)->pred_flag);
+        m.cbf_luma = s->cbf_luma; m.min_tb_width = s->sps->min_tb_width; m.min_tb_height = s->sps->min_tb_height; m.log2_min_tb_size = s->sps->log2_min_tb_size;
+    }
     return ohevc_tables_derive_filters(t_ctx, &m);
 }
 

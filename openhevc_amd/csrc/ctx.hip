@@ -42,7 +42,8 @@ struct Picture {
 struct PicStore;
 // the thread that issues asynchronous frame ends (ohevc_frame_end_async, below)
 struct Issuer {
-    std::thread th;
+    std::vector<std::thread> th;           // OHEVC_ISSUER_THREADS of them (default 4): one thread issues ~1000 1080p frame ends per second
+    std::vector<ohevc_ctx *> executing;    // frames taken from the queue whose frame end has not been published yet
     std::mutex m;
     std::condition_variable cv;
     std::deque<ohevc_ctx *> queue;         // executor contexts holding a submitted frame, in submission order
@@ -173,6 +174,7 @@ struct Rec {
     std::vector<int16_t> coeffs;
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
+    std::vector<ohevc_bs_call> bs_calls;                   // ohevc_rec_bs_call: the picture's calls of ff_hevc_deblocking_boundary_strengths (device-side boundary strengths)
     std::vector<ohevc_sao_job> sao;
     bool sao_lagged = false;          // some recorded SAO job carries OHEVC_SAO_LAG_*
     int nstat[5] = {};                // tu, mc, intra, dbk, sao calls
@@ -210,6 +212,9 @@ struct ohevc_ctx : Rec {
     std::vector<uint32_t> need, sync_zero;
     std::vector<uint8_t> dbk_blob;                         // ohevc_rec_deblock_maps: the copied maps back to back (empty = none)
     ohevc_dbk_maps dbk_maps = {};                          // geometry; the pointers hold offsets into dbk_blob
+    ohevc_bs_maps bs_maps = {};                            // device-side boundary strengths: geometry; mvf / cbf_luma hold offsets into dbk_blob
+    bool have_bs = false;
+    DevBuf d_bs;                                           // the two boundary-strength arrays the kernel fills
     std::vector<uint8_t> bypass;                           // ohevc_frame_set_bypass_map: is_pcm bytes, row length bypass_w (empty = none)
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
@@ -354,6 +359,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->d_coeffs.p) (void)hipFree(c->d_coeffs.p);
     if (c->d_table.p) (void)hipFree(c->d_table.p);
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
+    if (c->d_bs.p) (void)hipFree(c->d_bs.p);
     if (c->stage.p) (void)hipHostFree(c->stage.p);
     if (c->staged) (void)hipEventDestroy(c->staged);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
@@ -814,6 +820,8 @@ static void merge_side(ohevc_ctx *c)
         }
         c->dbk_v.insert(c->dbk_v.end(), r.dbk_v.begin(), r.dbk_v.end());
         c->dbk_h.insert(c->dbk_h.end(), r.dbk_h.begin(), r.dbk_h.end());
+        c->bs_calls.insert(c->bs_calls.end(), r.bs_calls.begin(), r.bs_calls.end());
+        r.bs_calls.clear();
         c->sao.insert(c->sao.end(), r.sao.begin(), r.sao.end());
         c->sao_lagged |= r.sao_lagged;
         for (int k = 0; k < 5; k++) { c->nstat[k] += r.nstat[k]; r.nstat[k] = 0; }
@@ -852,6 +860,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     }
     clear_recorded(c);
     c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->bypass.clear();
+    c->bs_calls.clear(); c->have_bs = false;
     c->stats = ohevc_frame_stats{};
     for (int &v : c->nstat) v = 0;
     c->alg = 0;
@@ -859,7 +868,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     c->epoch.fetch_add(1, std::memory_order_release);      // per-thread recorder caches of the previous picture are void
     {
         std::lock_guard<std::mutex> g(c->side_m);
-        for (auto &sd : c->side) { clear_rec(*sd.second); sd.second->dbk_v.clear(); sd.second->dbk_h.clear(); sd.second->sao.clear(); for (int &v : sd.second->nstat) v = 0; sd.second->alg = 0; }
+        for (auto &sd : c->side) { clear_rec(*sd.second); sd.second->dbk_v.clear(); sd.second->dbk_h.clear(); sd.second->bs_calls.clear(); sd.second->sao.clear(); for (int &v : sd.second->nstat) v = 0; sd.second->alg = 0; }
     }
     return OHEVC_OK;
 }
@@ -1232,6 +1241,45 @@ extern "C" int ohevc_rec_deblock_maps(ohevc_ctx *c, const ohevc_dbk_maps *m)
     }
     c->nstat[3]++;
     c->n_map_frames++;
+    return OHEVC_OK;
+}
+// One call of ff_hevc_deblocking_boundary_strengths (hevc.c:1578,1607,2400,2484), recorded instead of executed: ohevc_dev_boundary_strengths
+// evaluates the picture's calls at its frame end.
+extern "C" int ohevc_rec_bs_call(ohevc_ctx *c, int x0, int y0, int log2_size, int flags)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr, "no frame begun");
+    Rec &r = pick(c);
+    ohevc_bs_call b = { (uint16_t)x0, (uint16_t)y0, (uint8_t)log2_size, (uint8_t)flags, 0 };
+    r.bs_calls.push_back(b);
+    return OHEVC_OK;
+}
+
+// ohevc_rec_deblock_maps with the boundary strengths derived on the device: m->vertical_bs / horizontal_bs are not read; the motion field and
+// the cbf_luma map (HOST pointers in *bs) are copied like the other maps.  The calls come through ohevc_rec_bs_call.
+extern "C" int ohevc_rec_deblock_maps_bs(ohevc_ctx *c, const ohevc_dbk_maps *m, const ohevc_bs_maps *bs)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && m != nullptr && bs != nullptr, "no frame begun");
+    OHEVC_REQUIRE(!c->dry, "record-only contexts take deblocking as jobs (no device to derive them)");
+    OHEVC_REQUIRE(bs->mvf != nullptr && bs->cbf_luma != nullptr && bs->mvf_stride >= 20 && bs->min_pu_width > 0 && bs->min_pu_height > 0 && bs->min_tb_width > 0 &&
+                  bs->min_tb_height > 0, "motion field / cbf map");
+    static thread_local std::vector<uint8_t> zero_bs;
+    ohevc_dbk_maps mm = *m;
+    // the two arrays are written by the device: a zero-length stand-in keeps ohevc_rec_deblock_maps' checks and layout (offsets unused)
+    const size_t bs_h = (size_t)(m->height >> 2), n_v = (size_t)m->bs_width * (bs_h + 8), n_h = ((size_t)m->bs_width + 8) * bs_h;
+    if (zero_bs.size() < std::max(n_v, n_h)) zero_bs.assign(std::max(n_v, n_h), 0);
+    mm.vertical_bs = zero_bs.data(); mm.horizontal_bs = zero_bs.data();
+    int rc = ohevc_rec_deblock_maps(c, &mm);
+    if (rc != OHEVC_OK) return rc;
+    const size_t n_mvf = (size_t)bs->min_pu_width * bs->min_pu_height * (size_t)bs->mvf_stride, n_cbf = (size_t)bs->min_tb_width * bs->min_tb_height;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_mvf = up(c->dbk_blob.size()), o_cbf = o_mvf + up(n_mvf);
+    c->dbk_blob.resize(o_cbf + up(n_cbf));
+    memcpy(c->dbk_blob.data() + o_mvf, bs->mvf, n_mvf);
+    memcpy(c->dbk_blob.data() + o_cbf, bs->cbf_luma, n_cbf);
+    c->bs_maps = *bs;
+    c->bs_maps.mvf = reinterpret_cast<const uint8_t *>(o_mvf);
+    c->bs_maps.cbf_luma = reinterpret_cast<const uint8_t *>(o_cbf);
+    c->have_bs = true;
     return OHEVC_OK;
 }
 extern "C" int ohevc_ctx_has_device(const ohevc_ctx *c) { return c && !c->dry; }
@@ -1792,6 +1840,8 @@ static int frame_end_impl(ohevc_ctx *c)
         std::vector<std::pair<const void *, size_t>> parts;
         size_t total = 0;
         const size_t off_m = c->dbk_blob.empty() ? 0 : stage_put(parts, total, c->dbk_blob.data(), c->dbk_blob.size());
+        const bool dev_bs = c->have_bs && !c->dbk_blob.empty();
+        const size_t off_bsc = dev_bs && !c->bs_calls.empty() ? stage_put(parts, total, c->bs_calls.data(), c->bs_calls.size() * sizeof(ohevc_bs_call)) : 0;
         const size_t off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
         const size_t off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
         // the blocks the wide SAO kernel takes first (ohevc_dev_sao_batch_sorted); SAO blocks of a picture are independent of each other.
@@ -1809,6 +1859,21 @@ static int frame_end_impl(ohevc_ctx *c)
             dm.qp_y_tab = reinterpret_cast<const int8_t *>(base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.qp_y_tab));
             dm.deblock = reinterpret_cast<const int8_t *>(base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.deblock));
             dm.is_pcm = c->dbk_maps.is_pcm ? base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.is_pcm) : nullptr;      // its offset is never 0
+        }
+        if (dev_bs) {          // boundary strengths from the motion field, on the device (hevc_filter.c:805-941)
+            const size_t bs_h = (size_t)(dm.height >> 2), n_v = ((size_t)dm.bs_width * (bs_h + 8) + 255) & ~(size_t)255, n_h = (((size_t)dm.bs_width + 8) * bs_h + 255) & ~(size_t)255;
+            if (n_v + n_h > c->d_bs.cap) {
+                OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+                if ((rc = c->d_bs.reserve(n_v + n_h)) != OHEVC_OK) return rc;
+            }
+            OHEVC_HIP_TRY(hipMemsetAsync(c->d_bs.p, 0, n_v + n_h, c->stream));
+            ohevc_bs_maps bm = c->bs_maps;
+            bm.mvf = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.mvf);
+            bm.cbf_luma = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.cbf_luma);
+            uint8_t *vbs = static_cast<uint8_t *>(c->d_bs.p), *hbs = vbs + n_v;
+            if ((rc = ohevc_dev_boundary_strengths(&bm, reinterpret_cast<const ohevc_bs_call *>(base + off_bsc), (int)c->bs_calls.size(), vbs, hbs, c->stream)) != OHEVC_OK) return rc;
+            if (!c->bs_calls.empty()) c->stats.launches++;
+            dm.vertical_bs = vbs; dm.horizontal_bs = hbs;
         }
         // all vertical edges, then all horizontal edges: deblocking_filter_CTB, hevc_filter.c:385-580
         if (!c->dbk_blob.empty()) {
@@ -1857,6 +1922,7 @@ static int frame_end_impl(ohevc_ctx *c)
             c->stats.launches += (n_sao_wide > 0) + (n_sao_wide < (int)c->sao.size());
         }
         c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
+        c->bs_calls.clear(); c->have_bs = false;
     }
     if (!c->dry) {
         // publish: this picture is reconstructed once `ev` fires; the references were read until then
@@ -1905,6 +1971,7 @@ static void swap_frame_state(ohevc_ctx &a, ohevc_ctx &b)
     std::swap(a.cur, b.cur); std::swap(a.frame_mode, b.frame_mode); std::swap(a.log2_ctb, b.log2_ctb);
     std::swap(a.stats, b.stats);
     std::swap(a.my_gen, b.my_gen);
+    std::swap(a.bs_maps, b.bs_maps); std::swap(a.have_bs, b.have_bs);
 }
 
 static void issuer_run(Issuer *is)
@@ -1926,10 +1993,13 @@ static void issuer_run(Issuer *is)
                         for (const auto &r : q->async_refs) ready = ready && (int32_t)(st.pics[r.first].issued_gen - r.second) >= 0;
                         // ... and no frame submitted earlier still has to read (or write) the memory this one overwrites
                         // (a frame submitted earlier may also read THIS frame's picture - its thread finished parsing first: that one waits for us)
-                        for (size_t k = 0; k < i && ready; k++) {
-                            ready = is->queue[k]->cur != q->cur;
-                            for (const auto &r : is->queue[k]->async_refs) ready = ready && !(r.first == q->cur && (int32_t)(r.second - q->my_gen) < 0);
-                        }
+                        auto blocks = [&](const ohevc_ctx *k) {
+                            if (k->cur == q->cur) return true;
+                            for (const auto &r : k->async_refs) if (r.first == q->cur && (int32_t)(r.second - q->my_gen) < 0) return true;
+                            return false;
+                        };
+                        for (size_t k = 0; k < i && ready; k++) ready = !blocks(is->queue[k]);
+                        for (size_t k = 0; k < is->executing.size() && ready; k++) ready = !blocks(is->executing[k]);      // (other issuer threads)
                         if (ready) { e = is->queue[i]; is->queue.erase(is->queue.begin() + (long)i); }
                     }
                 }
@@ -1944,6 +2014,7 @@ static void issuer_run(Issuer *is)
                 }
             }
             is->in_flight++;
+            is->executing.push_back(e);
         }
         const double t0 = now_s();
         e->ref_slots.clear();
@@ -1974,6 +2045,7 @@ static void issuer_run(Issuer *is)
             if (rc != OHEVC_OK && is->error == OHEVC_OK) { is->error = rc; snprintf(is->error_text, sizeof(is->error_text), "%s", ohevc_last_error()); }
             if (e->async_from) e->async_from->last_stats = e->last_stats;
             e->exec_busy = false;
+            is->executing.erase(std::find(is->executing.begin(), is->executing.end(), e));
             is->in_flight--;
             is->busy_s += now_s() - t0;
             is->frames++;
@@ -1997,7 +2069,7 @@ static void issuer_shutdown(PicStore &st)
     if (!is) return;
     { std::lock_guard<std::mutex> lk(is->m); is->stop = true; }
     is->cv.notify_all();
-    if (is->th.joinable()) is->th.join();
+    for (std::thread &t : is->th) if (t.joinable()) t.join();
     if (g_trace_timing && is->frames)
         fprintf(stderr, "timing: issuer of store %p: %ld frame ends, %.3f ms each\n", (void *)&st, is->frames, 1e3 * is->busy_s / is->frames);
     st.issuer = nullptr;
@@ -2025,7 +2097,8 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
             st.issuer = new Issuer();
             st.issuer->device = c->device;
             st.issuer->store = &st;
-            st.issuer->th = std::thread(issuer_run, st.issuer);
+            static const int n_threads = getenv("OHEVC_ISSUER_THREADS") && atoi(getenv("OHEVC_ISSUER_THREADS")) > 0 ? atoi(getenv("OHEVC_ISSUER_THREADS")) : 4;
+            for (int k = 0; k < n_threads; k++) st.issuer->th.emplace_back(issuer_run, st.issuer);
         }
         is = st.issuer;
     }

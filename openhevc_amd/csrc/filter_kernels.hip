@@ -710,6 +710,112 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
 int g_sao_variant = 0;     // ohevc_debug_set_sao_variant
 }  // namespace ohevc
 
+// ------------------------------------------------------------------ boundary strengths (hevc_filter.c:584-700, 805-941)
+namespace ohevc {
+
+struct BsField { int mv0, mv1, poc0, poc1; unsigned pf; };       // mv: x in the low, y in the high 16 bits
+
+__device__ __forceinline__ BsField bs_load(const ohevc_bs_maps &m, int x_pu, int y_pu)
+{
+    const unsigned char *e = m.mvf + ((size_t)y_pu * m.min_pu_width + x_pu) * (size_t)m.mvf_stride;
+    BsField f;
+    f.mv0 = *reinterpret_cast<const int *>(e + m.off_mv); f.mv1 = *reinterpret_cast<const int *>(e + m.off_mv + 4);
+    f.poc0 = *reinterpret_cast<const int *>(e + m.off_poc); f.poc1 = *reinterpret_cast<const int *>(e + m.off_poc + 4);
+    f.pf = m.pred_flag_bytes == 4 ? *reinterpret_cast<const unsigned *>(e + m.off_pred_flag) : (unsigned)e[m.off_pred_flag];
+    return f;
+}
+// |a.x - b.x| >= 4 || |a.y - b.y| >= 4 on packed int16 pairs
+__device__ __forceinline__ bool bs_far(int a, int b)
+{
+    const int dx = (int)(short)(a & 0xffff) - (int)(short)(b & 0xffff), dy = (a >> 16) - (b >> 16);
+    return (dx < 0 ? -dx : dx) >= 4 || (dy < 0 ? -dy : dy) >= 4;
+}
+// boundary_strength(), :584-700 (its memcmp shortcut returns what the rules below return for identical entries)
+__device__ __forceinline__ int bs_motion(const BsField &c, const BsField &n)
+{
+    if (c.pf == 3u && n.pf == 3u) {
+        if (c.poc0 == n.poc0 && c.poc0 == c.poc1 && n.poc0 == n.poc1)
+            return ((bs_far(n.mv0, c.mv0) || bs_far(n.mv1, c.mv1)) && (bs_far(n.mv1, c.mv0) || bs_far(n.mv0, c.mv1))) ? 1 : 0;
+        if (n.poc0 == c.poc0 && n.poc1 == c.poc1) return (bs_far(n.mv0, c.mv0) || bs_far(n.mv1, c.mv1)) ? 1 : 0;
+        if (n.poc1 == c.poc0 && n.poc0 == c.poc1) return (bs_far(n.mv1, c.mv0) || bs_far(n.mv0, c.mv1)) ? 1 : 0;
+        return 1;
+    }
+    if (c.pf != 3u && n.pf != 3u) {
+        const int a = (c.pf & 1u) ? c.mv0 : c.mv1, ra = (c.pf & 1u) ? c.poc0 : c.poc1;
+        const int b = (n.pf & 1u) ? n.mv0 : n.mv1, rb = (n.pf & 1u) ? n.poc0 : n.poc1;
+        return ra == rb ? (bs_far(a, b) ? 1 : 0) : 1;
+    }
+    return 1;
+}
+
+// one lane per recorded call of ff_hevc_deblocking_boundary_strengths; every (edge, 4-sample segment) is written by exactly one call
+__global__ __launch_bounds__(256) void boundary_strength_kernel(ohevc_bs_maps m, const ohevc_bs_call *__restrict__ calls, int ncalls,
+                                                                unsigned char *__restrict__ vbs, unsigned char *__restrict__ hbs)
+{
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci >= ncalls) return;
+    const ohevc_bs_call cl = calls[ci];
+    const int x0 = cl.x0, y0 = cl.y0, n = 1 << cl.log2_size, l2pu = m.log2_min_pu_size, l2tu = m.log2_min_tb_size;
+    const int ctb_mask = (1 << m.log2_ctb_size) - 1;
+    auto cbf = [&](int x, int y) { return m.cbf_luma[(size_t)(y >> l2tu) * m.min_tb_width + (x >> l2tu)]; };
+    auto edge = [&](int xc, int yc, int xn, int yn) {        // a transform-block edge: current block at (xc, yc), its neighbour at (xn, yn)
+        const BsField c = bs_load(m, xc >> l2pu, yc >> l2pu), nb = bs_load(m, xn >> l2pu, yn >> l2pu);
+        if (c.pf == 0u || nb.pf == 0u) return 2;
+        if (cbf(xc, yc) || cbf(xn, yn)) return 1;
+        return bs_motion(c, nb);
+    };
+    const bool is_intra = bs_load(m, x0 >> l2pu, y0 >> l2pu).pf == 0u;
+    if (y0 > 0 && (y0 & 7) == 0) {                            // the block's top edge, :821-858
+        const bool bd_ctby = (y0 & ctb_mask) != 0;
+        const bool bd_slice = (cl.flags & OHEVC_BS_ACROSS_SLICES) || !(cl.flags & OHEVC_BS_SLICE_UP);
+        const bool bd_tiles = m.loop_filter_across_tiles || !(cl.flags & OHEVC_BS_TILE_UP);
+        if ((bd_slice && bd_tiles) || bd_ctby)
+            for (int i = 0; i < n; i += 4) hbs[((x0 + i) + y0 * m.bs_width) >> 2] = (unsigned char)edge(x0 + i, y0, x0 + i, y0 - 1);
+    }
+    if (x0 > 0 && (x0 & 7) == 0) {                            // its left edge, :861-898
+        const bool bd_ctbx = (x0 & ctb_mask) != 0;
+        const bool bd_slice = (cl.flags & OHEVC_BS_ACROSS_SLICES) || !(cl.flags & OHEVC_BS_SLICE_LEFT);
+        const bool bd_tiles = m.loop_filter_across_tiles || !(cl.flags & OHEVC_BS_TILE_LEFT);
+        if ((bd_slice && bd_tiles) || bd_ctbx)
+            for (int i = 0; i < n; i += 4) vbs[(x0 + (y0 + i) * m.bs_width) >> 2] = (unsigned char)edge(x0, y0 + i, x0 - 1, y0 + i);
+    }
+    if (cl.log2_size > l2pu && !is_intra) {                   // prediction-block edges inside it: motion only, :900-940
+        for (int i = 0; i < n; i += 4) {
+            BsField top = bs_load(m, (x0 + i) >> l2pu, (y0 + 8 - 1) >> l2pu);
+            for (int j = 8; j < n; j += 8) {
+                const BsField cur = bs_load(m, (x0 + i) >> l2pu, (y0 + j) >> l2pu);
+                hbs[((x0 + i) + (y0 + j) * m.bs_width) >> 2] = (unsigned char)bs_motion(cur, top);
+                top = cur;                                    // (the reference keeps the entry at y0 + j, not y0 + j + 7: `top = curr`)
+            }
+        }
+        for (int j = 0; j < n; j += 4) {
+            BsField left = bs_load(m, (x0 + 8 - 1) >> l2pu, (y0 + j) >> l2pu);
+            for (int i = 8; i < n; i += 8) {
+                const BsField cur = bs_load(m, (x0 + i) >> l2pu, (y0 + j) >> l2pu);
+                vbs[((x0 + i) + (y0 + j) * m.bs_width) >> 2] = (unsigned char)bs_motion(cur, left);
+                left = cur;
+            }
+        }
+    }
+}
+
+}  // namespace ohevc
+
+extern "C" int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohevc_bs_call *calls, int ncalls, uint8_t *vertical_bs, uint8_t *horizontal_bs, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(maps != nullptr && ncalls >= 0, "null argument");
+    if (ncalls == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(calls != nullptr && vertical_bs != nullptr && horizontal_bs != nullptr && maps->mvf != nullptr && maps->cbf_luma != nullptr, "null array");
+    OHEVC_REQUIRE(maps->mvf_stride >= 20 && (maps->mvf_stride & 3) == 0 && (maps->off_mv & 3) == 0 && (maps->off_poc & 3) == 0 &&
+                  (maps->pred_flag_bytes == 1 || (maps->pred_flag_bytes == 4 && (maps->off_pred_flag & 3) == 0)), "motion-field entry layout");
+    OHEVC_REQUIRE(maps->log2_min_pu_size >= 2 && maps->log2_min_tb_size >= 2 && maps->log2_ctb_size >= 4 && maps->log2_ctb_size <= 6 && maps->bs_width > 0 &&
+                  maps->min_pu_width > 0 && maps->min_tb_width > 0, "picture geometry");
+    hipLaunchKernelGGL(boundary_strength_kernel, dim3((ncalls + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *maps, calls, ncalls, vertical_bs, horizontal_bs);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
 extern "C" long ohevc_debug_sao_band_above_range(int reset)
 {
     unsigned *d = nullptr, h = 0;

@@ -231,8 +231,17 @@ struct Ctx {
 };
 
 bool g_filters_on_device = true;
+bool g_bs_on_device = !(getenv("OHEVC_DEVICE_BS") && atoi(getenv("OHEVC_DEVICE_BS")) == 0);
 
 }  // namespace
+
+extern "C" int ohevc_debug_set_bs_on_device(int on) { const int prev = g_bs_on_device; g_bs_on_device = on != 0; return prev; }
+
+extern "C" int ohevc_tables_bs_wanted(ohevc_ctx *ctx, int log2_ctb_size, int sao_enabled, int chroma_format_idc, int emulate_filter_lag)
+{
+    const bool lag = emulate_filter_lag && log2_ctb_size == 4 && sao_enabled && chroma_format_idc != 0 && chroma_format_idc != 3;
+    return g_bs_on_device && g_filters_on_device && ctx != nullptr && ohevc_ctx_has_device(ctx) && !lag;
+}
 
 extern "C" int ohevc_debug_set_filters_on_device(int on) { const int prev = g_filters_on_device; g_filters_on_device = on != 0; return prev; }
 
@@ -274,7 +283,20 @@ extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_ma
         d.width = m->width; d.height = m->height; d.log2_ctb_size = m->log2_ctb_size; d.log2_min_cb_size = m->log2_min_cb_size;
         d.log2_min_pu_size = m->log2_min_pu_size; d.chroma_format_idc = m->chroma_format_idc;
         d.cb_qp_offset = m->cb_qp_offset; d.cr_qp_offset = m->cr_qp_offset;
-        const int r = ohevc_rec_deblock_maps(ctx, &d);
+        int r;
+        if (m->tab_mvf != nullptr && g_bs_on_device) {          // boundary strengths on the device too: the motion field travels instead of them
+            OHEVC_REQUIRE(m->cbf_luma != nullptr && m->min_tb_width > 0 && m->min_tb_height > 0 && m->log2_min_tb_size >= 2, "cbf_luma map");
+            ohevc_bs_maps b = {};
+            b.mvf = static_cast<const uint8_t *>(m->tab_mvf); b.mvf_stride = m->mvf_stride; b.off_mv = m->mvf_off_mv; b.off_poc = m->mvf_off_poc;
+            b.off_pred_flag = m->mvf_off_pred_flag; b.pred_flag_bytes = m->mvf_pred_flag_bytes;
+            b.cbf_luma = m->cbf_luma; b.min_pu_width = m->min_pu_width; b.min_pu_height = m->min_pu_height; b.log2_min_pu_size = m->log2_min_pu_size;
+            b.min_tb_width = m->min_tb_width; b.min_tb_height = m->min_tb_height; b.log2_min_tb_size = m->log2_min_tb_size;
+            b.log2_ctb_size = m->log2_ctb_size; b.bs_width = m->bs_width; b.width = m->width; b.height = m->height;
+            b.loop_filter_across_tiles = m->loop_filter_across_tiles;
+            r = ohevc_rec_deblock_maps_bs(ctx, &d, &b);
+        } else {
+            r = ohevc_rec_deblock_maps(ctx, &d);
+        }
         if (r != OHEVC_OK) return r;
         if (m->sao_enabled)
             for (int y = 0; y < m->height; y += ctb_size)

@@ -625,6 +625,14 @@ extern "C" int ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[
     return OHEVC_ERR_STATE;
 }
 
+extern "C" int ohevc_tables_bs_call(int x0, int y0, int log2_size, int flags)
+{
+    if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
+    const int rc = ohevc_rec_bs_call(tl_ctx, x0, y0, log2_size, flags);
+    if (rc != OHEVC_OK) fail(rc);
+    return rc;
+}
+
 extern "C" int ohevc_tables_cross_component(int res_scale_val)
 {
     tl_pend.cross_scale = res_scale_val;

@@ -34,3 +34,11 @@ int  ohhip_log2_res_scale_abs(HEVCContext *s, int idx) { return ff_hevc_log2_res
 int  ohhip_res_scale_sign_flag(HEVCContext *s, int idx) { return ff_hevc_res_scale_sign_flag(s, idx); }
 void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size) { ff_hevc_hls_filter(s, x, y, ctb_size); }
 void ohhip_hls_filters(HEVCContext *s, int x, int y, int ctb_size) { ff_hevc_hls_filters(s, x, y, ctb_size); }
+
+#ifndef OHNULL_NO_BS
+void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size) { ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size); }
+#endif
+#ifdef OHNULL_NO_BS
+/* oracle/Makefile target `nobs`: the boundary strengths are not derived either (measurement of their share of the front end) */
+void ohnull_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size) { (void)s; (void)x0; (void)y0; (void)log2_trafo_size; }
+#endif
