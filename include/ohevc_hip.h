@@ -200,6 +200,16 @@ typedef struct ohevc_bs_maps {
 /* maps->mvf / cbf_luma, calls, vertical_bs, horizontal_bs: DEVICE pointers; the two outputs must have been zeroed (hevc_frame_start memsets them) */
 int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohevc_bs_call *calls, int ncalls, uint8_t *vertical_bs, uint8_t *horizontal_bs, void *stream);
 
+/* The motion field without the upload: every inter prediction block already travels as a luma motion-compensation job whose source
+ * position and phase are its motion vector and whose reference slot names its reference picture (two pictures of one DPB never share a POC,
+ * so "same slot" is the reference's "same POC", hevc_filter.c:584-700).  Writes one OHEVC_MOTION_GRID_ENTRY-byte entry per unit
+ * (1 << log2_unit samples, sps->log2_min_pu_size) covered by a luma job of at most 16x16 samples (the tiles ohevc_rec_mc cuts):
+ * int16 mv[2][2], int32 ref[2], uint32 pred_flag (1: one reference - in mv[0] / ref[0] whatever its list was, which boundary_strength()
+ * does not look at; 3: two) - i.e. ohevc_bs_maps {mvf_stride 20, off_mv 0, off_poc 8, off_pred_flag 16, pred_flag_bytes 4}.  Units no job
+ * covers keep what the grid held: zero it before the first call of a picture (pred_flag 0 = PF_INTRA).  jobs, grid: DEVICE pointers. */
+enum { OHEVC_MOTION_GRID_ENTRY = 20 };
+int ohevc_dev_motion_grid(const ohevc_mc_job *jobs, int njobs, uint8_t *grid, int grid_width, int grid_height, int log2_unit, void *stream);
+
 /* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
  * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy
  * (the reference's sao_frame), one job per CTB and colour plane. */

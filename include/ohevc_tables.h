@@ -200,7 +200,8 @@ typedef struct ohevc_filter_maps {
     int32_t emulate_filter_lag;
     const int *ctb_addr_ts_to_rs;
     /* device-side boundary strengths (ohevc_tables_bs_wanted() != 0 for this picture and every call of ff_hevc_deblocking_boundary_strengths
-     * replaced by ohevc_tables_bs_call): the motion field s->ref->tab_mvf (entry layout as ohevc_bs_maps) and s->cbf_luma; tab_mvf NULL:
+     * replaced by ohevc_tables_bs_call): s->cbf_luma and - ohevc_tables_bs_wanted() == 1 - the motion field s->ref->tab_mvf (entry layout as
+     * ohevc_bs_maps); == 2: tab_mvf NULL, the picture kept the motion of its MC jobs (ohevc_tables_keep_motion).  cbf_luma NULL:
      * horizontal_bs / vertical_bs above are the reference's own */
     const void *tab_mvf;
     int32_t mvf_stride, mvf_off_mv, mvf_off_poc, mvf_off_pred_flag, mvf_pred_flag_bytes;
@@ -212,6 +213,9 @@ typedef struct ohevc_filter_maps {
  * per-edge host derivation (ohevc_debug_set_filters_on_device(0)), for 16x16 CTBs with SAO in 4:2:0 / 4:2:2 (the filter-lag replay reads the
  * host arrays) and when switched off (ohevc_debug_set_bs_on_device(0); environment OHEVC_DEVICE_BS=0). */
 int  ohevc_tables_bs_wanted(ohevc_ctx *ctx, int log2_ctb_size, int sao_enabled, int chroma_format_idc, int emulate_filter_lag);
+/* Returns 0 (no), 1 (from the motion field ohevc_filter_maps.tab_mvf hands over) or 2 (from the picture's own MC jobs: call
+ * ohevc_tables_keep_motion(ctx, sps->log2_min_pu_size) right after ohevc_tables_begin_frame; OHEVC_DEVICE_BS=0|1|2 chooses, default 2). */
+int  ohevc_tables_keep_motion(ohevc_ctx *ctx, int log2_min_pu_size);
 int  ohevc_tables_bs_call(int x0, int y0, int log2_size, int flags);       /* records into the calling thread's bound context */
 int  ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *maps);
 /* the host planes registered for picture-store slot `slot` (tests: oracle/sw_exec.c executes recorded jobs on them) */

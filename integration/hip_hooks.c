@@ -203,6 +203,7 @@ static int slot_of_frame_locked(ohevc_ctx *ctx, const HEVCContext *s, const AVFr
 }
 
 /* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
+static int device_bs_frame(const HEVCContext *s);
 int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
 {
     int ret = ff_hevc_set_new_ref(s, frame, poc);                   /* hevc_refs.c */
@@ -289,6 +290,8 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     }
     t_frame_open = 1;
     t_s = s;
+    if (device_bs_frame(s) == 2 && ohevc_tables_keep_motion(ctx, s->sps->log2_min_pu_size) != OHEVC_OK)     /* boundary strengths from the MC jobs */
+        g_error = 1;
     return 0;
 }
 
@@ -485,8 +488,9 @@ static int device_bs(const HEVCContext *s)
 
 static int device_bs_frame(const HEVCContext *s)       /* the same decision at the frame end (the frame is no longer "open" there) */
 {
-    return t_ctx && !(s->pps->tiles_enabled_flag && s->threads_number != 1) && bulk_filters(s) &&
-           ohevc_tables_bs_wanted(t_ctx, s->sps->log2_ctb_size, s->sps->sao_enabled, s->sps->chroma_array_type, 1);
+    if (!t_ctx || (s->pps->tiles_enabled_flag && s->threads_number != 1) || !bulk_filters(s))
+        return 0;
+    return ohevc_tables_bs_wanted(t_ctx, s->sps->log2_ctb_size, s->sps->sao_enabled, s->sps->chroma_array_type, 1);     /* 1: from tab_mvf, 2: from the MC jobs */
 }
 
 void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size)
@@ -521,7 +525,7 @@ static int derive_filters(HEVCContext *s)
     m.is_pcm = s->is_pcm; m.min_pu_width = s->sps->min_pu_width; m.min_pu_height = s->sps->min_pu_height;
     m.emulate_filter_lag = 1; m.ctb_addr_ts_to_rs = s->pps->ctb_addr_ts_to_rs;
     if (device_bs_frame(s)) {
-        m.tab_mvf = s->ref->tab_mvf; m.mvf_stride = sizeof(MvField);
+        m.tab_mvf = device_bs_frame(s) == 2 ? NULL : s->ref->tab_mvf; m.mvf_stride = sizeof(MvField);
         m.mvf_off_mv = offsetof(MvField, mv); m.mvf_off_poc = offsetof(MvField, poc); m.mvf_off_pred_flag = offsetof(MvField, pred_flag);
         m.mvf_pred_flag_bytes = sizeof(((MvField *)0)->pred_flag);
         m.cbf_luma = s->cbf_luma; m.min_tb_width = s->sps->min_tb_width; m.min_tb_height = s->sps->min_tb_height; m.log2_min_tb_size = s->sps->log2_min_tb_size;

@@ -215,6 +215,9 @@ struct ohevc_ctx : Rec {
     ohevc_bs_maps bs_maps = {};                            // device-side boundary strengths: geometry; mvf / cbf_luma hold offsets into dbk_blob
     bool have_bs = false;
     DevBuf d_bs;                                           // the two boundary-strength arrays the kernel fills
+    DevBuf d_grid;                                         // ohevc_frame_keep_motion: the motion field rebuilt from the luma MC jobs
+    int keep_motion_l2 = 0;                                // log2 of the grid's unit; 0: the frame keeps none
+    bool grid_zeroed = false;                              // ... and it has been cleared for this frame
     std::vector<uint8_t> bypass;                           // ohevc_frame_set_bypass_map: is_pcm bytes, row length bypass_w (empty = none)
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
@@ -360,6 +363,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->d_table.p) (void)hipFree(c->d_table.p);
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
     if (c->d_bs.p) (void)hipFree(c->d_bs.p);
+    if (c->d_grid.p) (void)hipFree(c->d_grid.p);
     if (c->stage.p) (void)hipHostFree(c->stage.p);
     if (c->staged) (void)hipEventDestroy(c->staged);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
@@ -861,6 +865,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     clear_recorded(c);
     c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->bypass.clear();
     c->bs_calls.clear(); c->have_bs = false;
+    c->keep_motion_l2 = 0; c->grid_zeroed = false;
     c->stats = ohevc_frame_stats{};
     for (int &v : c->nstat) v = 0;
     c->alg = 0;
@@ -1260,8 +1265,9 @@ extern "C" int ohevc_rec_deblock_maps_bs(ohevc_ctx *c, const ohevc_dbk_maps *m, 
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && m != nullptr && bs != nullptr, "no frame begun");
     OHEVC_REQUIRE(!c->dry, "record-only contexts take deblocking as jobs (no device to derive them)");
-    OHEVC_REQUIRE(bs->mvf != nullptr && bs->cbf_luma != nullptr && bs->mvf_stride >= 20 && bs->min_pu_width > 0 && bs->min_pu_height > 0 && bs->min_tb_width > 0 &&
-                  bs->min_tb_height > 0, "motion field / cbf map");
+    // bs->mvf NULL: the frame keeps the motion of its MC jobs on the device (ohevc_frame_keep_motion) - nothing to copy
+    OHEVC_REQUIRE((bs->mvf != nullptr ? bs->mvf_stride >= 20 : c->keep_motion_l2 == bs->log2_min_pu_size) && bs->cbf_luma != nullptr && bs->min_pu_width > 0 &&
+                  bs->min_pu_height > 0 && bs->min_tb_width > 0 && bs->min_tb_height > 0, "motion field / cbf map");
     static thread_local std::vector<uint8_t> zero_bs;
     ohevc_dbk_maps mm = *m;
     // the two arrays are written by the device: a zero-length stand-in keeps ohevc_rec_deblock_maps' checks and layout (offsets unused)
@@ -1270,16 +1276,43 @@ extern "C" int ohevc_rec_deblock_maps_bs(ohevc_ctx *c, const ohevc_dbk_maps *m, 
     mm.vertical_bs = zero_bs.data(); mm.horizontal_bs = zero_bs.data();
     int rc = ohevc_rec_deblock_maps(c, &mm);
     if (rc != OHEVC_OK) return rc;
-    const size_t n_mvf = (size_t)bs->min_pu_width * bs->min_pu_height * (size_t)bs->mvf_stride, n_cbf = (size_t)bs->min_tb_width * bs->min_tb_height;
+    const size_t n_mvf = bs->mvf ? (size_t)bs->min_pu_width * bs->min_pu_height * (size_t)bs->mvf_stride : 0, n_cbf = (size_t)bs->min_tb_width * bs->min_tb_height;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_mvf = up(c->dbk_blob.size()), o_cbf = o_mvf + up(n_mvf);
     c->dbk_blob.resize(o_cbf + up(n_cbf));
-    memcpy(c->dbk_blob.data() + o_mvf, bs->mvf, n_mvf);
+    if (n_mvf) memcpy(c->dbk_blob.data() + o_mvf, bs->mvf, n_mvf);
     memcpy(c->dbk_blob.data() + o_cbf, bs->cbf_luma, n_cbf);
     c->bs_maps = *bs;
-    c->bs_maps.mvf = reinterpret_cast<const uint8_t *>(o_mvf);
+    c->bs_maps.mvf = bs->mvf ? reinterpret_cast<const uint8_t *>(o_mvf) : nullptr;
     c->bs_maps.cbf_luma = reinterpret_cast<const uint8_t *>(o_cbf);
     c->have_bs = true;
+    return OHEVC_OK;
+}
+// The frame's boundary strengths will be derived from the motion of its own MC jobs (ohevc_dev_motion_grid): call after ohevc_frame_begin,
+// before the first ohevc_frame_reconstruct.  log2_unit = sps->log2_min_pu_size, the granularity ohevc_bs_maps indexes the field with.
+extern "C" int ohevc_frame_keep_motion(ohevc_ctx *c, int log2_unit)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr, "no frame begun");
+    OHEVC_REQUIRE(!c->dry, "record-only contexts have no device to keep it on");
+    OHEVC_REQUIRE(log2_unit >= 2 && log2_unit <= 5, "log2_unit");
+    OHEVC_REQUIRE(c->keep_motion_l2 == 0 || c->keep_motion_l2 == log2_unit, "the frame already keeps its motion at another granularity");
+    c->keep_motion_l2 = log2_unit;
+    return OHEVC_OK;
+}
+// the grid of the frame in flight, cleared once (units no MC job covers read as intra-predicted: pred_flag 0)
+static int motion_grid_ready(ohevc_ctx *c, const Picture *p, int &gw, int &gh)
+{
+    const int u = 1 << c->keep_motion_l2;
+    gw = (p->w + u - 1) >> c->keep_motion_l2; gh = (p->h + u - 1) >> c->keep_motion_l2;
+    if (c->grid_zeroed) return OHEVC_OK;
+    const size_t bytes = (size_t)gw * gh * OHEVC_MOTION_GRID_ENTRY;
+    if (bytes > c->d_grid.cap) {
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+        int rc = c->d_grid.reserve(bytes);
+        if (rc != OHEVC_OK) return rc;
+    }
+    OHEVC_HIP_TRY(hipMemsetAsync(c->d_grid.p, 0, bytes, c->stream));
+    c->grid_zeroed = true;
     return OHEVC_OK;
 }
 extern "C" int ohevc_ctx_has_device(const ohevc_ctx *c) { return c && !c->dry; }
@@ -1685,6 +1718,17 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
     }
+    if (c->keep_motion_l2 && (!c->mc.empty() || !c->mc_small.empty())) {      // what the boundary strengths will need of these jobs (ohevc_dev_motion_grid)
+        int gw, gh;
+        if ((rc = motion_grid_ready(c, p, gw, gh)) != OHEVC_OK) return rc;
+        for (const auto &v : {std::make_pair(off_mc, &c->mc), std::make_pair(off_mcs, &c->mc_small)}) {
+            if (v.second->empty()) continue;
+            rc = ohevc_dev_motion_grid(reinterpret_cast<const ohevc_mc_job *>(base + v.first), (int)v.second->size(), static_cast<uint8_t *>(c->d_grid.p), gw, gh,
+                                       c->keep_motion_l2, c->stream);
+            if (rc != OHEVC_OK) return rc;
+            c->stats.launches++;
+        }
+    }
     // ---- phase 2..: level 0 = residuals of inter blocks; level L >= 1 = intra prediction of level L, then its residuals
     const int max_level = c->max_level;
     const int last_separate = phases.empty() ? max_level : 0;      // level 0 (residuals of inter blocks) keeps its own wide launch
@@ -1868,7 +1912,16 @@ static int frame_end_impl(ohevc_ctx *c)
             }
             OHEVC_HIP_TRY(hipMemsetAsync(c->d_bs.p, 0, n_v + n_h, c->stream));
             ohevc_bs_maps bm = c->bs_maps;
-            bm.mvf = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.mvf);
+            if (c->bs_maps.mvf) {
+                bm.mvf = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.mvf);
+            } else {                                          // rebuilt from the MC jobs by ohevc_frame_reconstruct
+                int gw, gh;
+                OHEVC_REQUIRE(c->keep_motion_l2 == bm.log2_min_pu_size, "ohevc_frame_keep_motion was not called for this frame");
+                if ((rc = motion_grid_ready(c, p, gw, gh)) != OHEVC_OK) return rc;      // (a picture without inter blocks: cleared here)
+                OHEVC_REQUIRE(gw >= bm.min_pu_width && gh >= bm.min_pu_height, "motion grid smaller than the picture's min_pu map");
+                bm.mvf = static_cast<const uint8_t *>(c->d_grid.p); bm.min_pu_width = gw;
+                bm.mvf_stride = OHEVC_MOTION_GRID_ENTRY; bm.off_mv = 0; bm.off_poc = 8; bm.off_pred_flag = 16; bm.pred_flag_bytes = 4;
+            }
             bm.cbf_luma = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.cbf_luma);
             uint8_t *vbs = static_cast<uint8_t *>(c->d_bs.p), *hbs = vbs + n_v;
             if ((rc = ohevc_dev_boundary_strengths(&bm, reinterpret_cast<const ohevc_bs_call *>(base + off_bsc), (int)c->bs_calls.size(), vbs, hbs, c->stream)) != OHEVC_OK) return rc;
@@ -1972,6 +2025,7 @@ static void swap_frame_state(ohevc_ctx &a, ohevc_ctx &b)
     std::swap(a.stats, b.stats);
     std::swap(a.my_gen, b.my_gen);
     std::swap(a.bs_maps, b.bs_maps); std::swap(a.have_bs, b.have_bs);
+    std::swap(a.keep_motion_l2, b.keep_motion_l2); std::swap(a.grid_zeroed, b.grid_zeroed);      // (d_grid stays: it is only touched on its owner's stream)
 }
 
 static void issuer_run(Issuer *is)
@@ -2088,6 +2142,7 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
         int rc = ohevc_frame_end(c);
         return rc;
     }
+    OHEVC_REQUIRE(!c->grid_zeroed, "a frame that keeps its motion (ohevc_frame_keep_motion) and was partly reconstructed ends with ohevc_frame_end");
     PicStore &st = *c->store;
     merge_side(c);                                      // the slice threads of this picture have been joined: fold their recorders in
     Issuer *is;

@@ -799,7 +799,40 @@ __global__ __launch_bounds__(256) void boundary_strength_kernel(ohevc_bs_maps m,
     }
 }
 
+// The motion field rebuilt from the luma motion-compensation jobs (ohevc_dev_motion_grid): one lane per (job, 4x4 unit of its at most
+// 16x16 tile).  A job's integer source position and phase ARE its motion vector: sx = x + (mv.x >> 2), mx = mv.x & 3 (luma_mc_uni, hevc.c:1693-1703).
+__global__ __launch_bounds__(256) void motion_grid_kernel(const ohevc_mc_job *__restrict__ jobs, int njobs, unsigned char *__restrict__ grid, int grid_w, int grid_h,
+                                                          int log2_unit)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, ji = t >> 4, ux = (t & 3) << 2, uy = ((t >> 2) & 3) << 2;
+    if (ji >= njobs) return;
+    const ohevc_mc_job j = jobs[ji];
+    const int um = (1 << log2_unit) - 1;
+    if (j.plane != 0 || ux >= j.w || uy >= j.h || (((j.x + ux) | (j.y + uy)) & um)) return;
+    const int gx = (j.x + ux) >> log2_unit, gy = (j.y + uy) >> log2_unit;
+    if (gx >= grid_w || gy >= grid_h) return;
+    auto mv = [](int s, int p, int m) { return (((s - p) << 2) | m) & 0xffff; };
+    int *e = reinterpret_cast<int *>(grid + ((size_t)gy * grid_w + gx) * OHEVC_MOTION_GRID_ENTRY);
+    const bool bi = (j.flags & OHEVC_MC_BI) != 0;
+    e[0] = mv(j.sx0, j.x, j.mx0) | (mv(j.sy0, j.y, j.my0) << 16);
+    e[1] = bi ? mv(j.sx1, j.x, j.mx1) | (mv(j.sy1, j.y, j.my1) << 16) : 0;
+    e[2] = j.ref0; e[3] = bi ? j.ref1 : -1;
+    e[4] = bi ? 3 : 1;
+}
+
 }  // namespace ohevc
+
+extern "C" int ohevc_dev_motion_grid(const ohevc_mc_job *jobs, int njobs, uint8_t *grid, int grid_width, int grid_height, int log2_unit, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(njobs >= 0 && grid_width > 0 && grid_height > 0 && log2_unit >= 2 && log2_unit <= 5, "grid geometry");
+    if (njobs == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(jobs != nullptr && grid != nullptr && (reinterpret_cast<uintptr_t>(grid) & 3) == 0, "null / misaligned array");
+    hipLaunchKernelGGL(motion_grid_kernel, dim3((unsigned)(((long long)njobs * 16 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), jobs, njobs, grid,
+                       grid_width, grid_height, log2_unit);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
 
 extern "C" int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohevc_bs_call *calls, int ncalls, uint8_t *vertical_bs, uint8_t *horizontal_bs, void *stream)
 {

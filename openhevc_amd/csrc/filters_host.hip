@@ -231,16 +231,18 @@ struct Ctx {
 };
 
 bool g_filters_on_device = true;
-bool g_bs_on_device = !(getenv("OHEVC_DEVICE_BS") && atoi(getenv("OHEVC_DEVICE_BS")) == 0);
+// boundary strengths on the device: 0 no (the reference's function runs on the host), 1 from the uploaded motion field, 2 from the motion
+// the picture's own MC jobs carry (ohevc_frame_keep_motion: nothing extra travels)
+int g_bs_on_device = getenv("OHEVC_DEVICE_BS") ? atoi(getenv("OHEVC_DEVICE_BS")) : 2;
 
 }  // namespace
 
-extern "C" int ohevc_debug_set_bs_on_device(int on) { const int prev = g_bs_on_device; g_bs_on_device = on != 0; return prev; }
+extern "C" int ohevc_debug_set_bs_on_device(int mode) { const int prev = g_bs_on_device; g_bs_on_device = mode < 0 ? 0 : mode > 2 ? 2 : mode; return prev; }
 
 extern "C" int ohevc_tables_bs_wanted(ohevc_ctx *ctx, int log2_ctb_size, int sao_enabled, int chroma_format_idc, int emulate_filter_lag)
 {
     const bool lag = emulate_filter_lag && log2_ctb_size == 4 && sao_enabled && chroma_format_idc != 0 && chroma_format_idc != 3;
-    return g_bs_on_device && g_filters_on_device && ctx != nullptr && ohevc_ctx_has_device(ctx) && !lag;
+    return g_bs_on_device && g_filters_on_device && ctx != nullptr && ohevc_ctx_has_device(ctx) && !lag ? g_bs_on_device : 0;
 }
 
 extern "C" int ohevc_debug_set_filters_on_device(int on) { const int prev = g_filters_on_device; g_filters_on_device = on != 0; return prev; }
@@ -284,8 +286,8 @@ extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_ma
         d.log2_min_pu_size = m->log2_min_pu_size; d.chroma_format_idc = m->chroma_format_idc;
         d.cb_qp_offset = m->cb_qp_offset; d.cr_qp_offset = m->cr_qp_offset;
         int r;
-        if (m->tab_mvf != nullptr && g_bs_on_device) {          // boundary strengths on the device too: the motion field travels instead of them
-            OHEVC_REQUIRE(m->cbf_luma != nullptr && m->min_tb_width > 0 && m->min_tb_height > 0 && m->log2_min_tb_size >= 2, "cbf_luma map");
+        if (m->cbf_luma != nullptr && g_bs_on_device) {         // boundary strengths on the device too: the motion field travels instead of them,
+            OHEVC_REQUIRE(m->min_tb_width > 0 && m->min_tb_height > 0 && m->log2_min_tb_size >= 2, "cbf_luma map");      // or nothing (tab_mvf NULL)
             ohevc_bs_maps b = {};
             b.mvf = static_cast<const uint8_t *>(m->tab_mvf); b.mvf_stride = m->mvf_stride; b.off_mv = m->mvf_off_mv; b.off_poc = m->mvf_off_poc;
             b.off_pred_flag = m->mvf_off_pred_flag; b.pred_flag_bytes = m->mvf_pred_flag_bytes;

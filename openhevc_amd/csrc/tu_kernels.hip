@@ -1766,8 +1766,13 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int waves = sg.first_wave[4];
-    if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
-    else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
+    if (residuals != nullptr) {
+        if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t, true>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
+        else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t, true>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
+    } else {
+        if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t, false>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
+        else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t, false>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
+    }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

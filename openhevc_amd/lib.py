@@ -225,6 +225,33 @@ EXPORTED_SYMBOLS += ["ohevc_dev_intra_recon_sorted", "ohevc_dev_intra_recon_batc
                      "ohevc_frames_transport_destroy", "ohevc_frames_transport_stats"]
 
 
+class BsMaps(C.Structure):
+    """ohevc_bs_maps (include/ohevc_hip.h): the motion field and cbf_luma map ohevc_dev_boundary_strengths reads (DEVICE pointers)"""
+    _fields_ = [("mvf", C.c_void_p), ("mvf_stride", C.c_int32), ("off_mv", C.c_int32), ("off_poc", C.c_int32), ("off_pred_flag", C.c_int32),
+                ("pred_flag_bytes", C.c_int32), ("cbf_luma", C.c_void_p), ("min_pu_width", C.c_int32), ("min_pu_height", C.c_int32),
+                ("log2_min_pu_size", C.c_int32), ("min_tb_width", C.c_int32), ("min_tb_height", C.c_int32), ("log2_min_tb_size", C.c_int32),
+                ("log2_ctb_size", C.c_int32), ("bs_width", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("loop_filter_across_tiles", C.c_int32)]
+
+
+BS_CALL = np.dtype([("x0", "<u2"), ("y0", "<u2"), ("log2_size", "u1"), ("flags", "u1"), ("reserved", "<u2")])       # ohevc_bs_call
+MOTION_GRID_ENTRY = 20                                                                                             # OHEVC_MOTION_GRID_ENTRY
+assert BS_CALL.itemsize == 8
+
+
+def dev_boundary_strengths(maps, calls_ptr, ncalls, vertical_bs_ptr, horizontal_bs_ptr, stream=0):
+    check(load_library().ohevc_dev_boundary_strengths(C.byref(maps), C.c_void_p(calls_ptr), C.c_int(ncalls), C.c_void_p(vertical_bs_ptr),
+                                                      C.c_void_p(horizontal_bs_ptr), C.c_void_p(stream)))
+
+
+def dev_motion_grid(jobs_ptr, njobs, grid_ptr, grid_width, grid_height, log2_unit, stream=0):
+    check(load_library().ohevc_dev_motion_grid(C.c_void_p(jobs_ptr), C.c_int(njobs), C.c_void_p(grid_ptr), C.c_int(grid_width), C.c_int(grid_height),
+                                               C.c_int(log2_unit), C.c_void_p(stream)))
+
+
+EXPORTED_SYMBOLS += ["ohevc_dev_boundary_strengths", "ohevc_dev_motion_grid", "ohevc_frame_keep_motion", "ohevc_tables_keep_motion", "ohevc_rec_bs_call",
+                     "ohevc_rec_deblock_maps_bs", "ohevc_tables_bs_wanted", "ohevc_tables_bs_call"]
+
+
 class IntraGeom(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("chroma_format_idc", C.c_int32), ("log2_ctb_size", C.c_int32),
                 ("log2_min_tb_size", C.c_int32), ("strong_intra_smoothing", C.c_int32), ("intra_smoothing_disabled", C.c_int32),

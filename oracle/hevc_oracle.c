@@ -925,3 +925,89 @@ void ohor_shvc_upsample_frame(int bd, int block_slots, uint8_t *const el[3], con
                        block_slots ? right_end : right_end - 1, top, bottom_end, up[6], up[4], up[7], up[5]);
     }
 }
+
+/* ------------------------------------------------------------------ boundary strengths
+ * boundary_strength(), hevc_filter.c:584-700 (C branch): 0 when the two blocks predict from the same pictures with motion closer than one
+ * integer sample in both components, 1 otherwise. */
+static int oh_mv_apart(const int16_t *a, const int16_t *b)
+{
+    return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4;
+}
+static int oh_bs_motion(const oh_bs_field *cur, const oh_bs_field *nb)
+{
+    if (cur->pred_flag == 3 && nb->pred_flag == 3) {
+        if (cur->poc[0] == nb->poc[0] && cur->poc[0] == cur->poc[1] && nb->poc[0] == nb->poc[1])        /* :602-628: all four references are one picture */
+            return (oh_mv_apart(nb->mv[0], cur->mv[0]) || oh_mv_apart(nb->mv[1], cur->mv[1])) &&
+                   (oh_mv_apart(nb->mv[1], cur->mv[0]) || oh_mv_apart(nb->mv[0], cur->mv[1]));
+        if (nb->poc[0] == cur->poc[0] && nb->poc[1] == cur->poc[1])                                      /* :629-645 */
+            return oh_mv_apart(nb->mv[0], cur->mv[0]) || oh_mv_apart(nb->mv[1], cur->mv[1]);
+        if (nb->poc[1] == cur->poc[0] && nb->poc[0] == cur->poc[1])                                      /* :646-663 */
+            return oh_mv_apart(nb->mv[1], cur->mv[0]) || oh_mv_apart(nb->mv[0], cur->mv[1]);
+        return 1;
+    }
+    if (cur->pred_flag != 3 && nb->pred_flag != 3) {                                                     /* :667-697: one vector each */
+        const int la = (cur->pred_flag & 1) ? 0 : 1, lb = (nb->pred_flag & 1) ? 0 : 1;
+        if (cur->poc[la] != nb->poc[lb]) return 1;
+        return oh_mv_apart(cur->mv[la], nb->mv[lb]);
+    }
+    return 1;
+}
+/* ff_hevc_deblocking_boundary_strengths(), hevc_filter.c:805-941, for every recorded call */
+void ohor_boundary_strengths(const oh_bs_geom *g, const oh_bs_field *mvf, const uint8_t *cbf_luma, const oh_bs_call *calls, int ncalls,
+                             uint8_t *vertical_bs, uint8_t *horizontal_bs)
+{
+    const int lp = g->log2_min_pu_size, lt = g->log2_min_tb_size, ctb_mask = (1 << g->log2_ctb_size) - 1;
+#define OH_MVF(x, y) (&mvf[((y) >> lp) * g->min_pu_width + ((x) >> lp)])
+#define OH_CBF(x, y) (cbf_luma[((y) >> lt) * g->min_tb_width + ((x) >> lt)])
+    for (int c = 0; c < ncalls; c++) {
+        const int x0 = calls[c].x0, y0 = calls[c].y0, n = 1 << calls[c].log2_size, fl = calls[c].flags;
+        const int across_slices = (fl >> 4) & 1;
+        const int is_intra = OH_MVF(x0, y0)->pred_flag == 0;
+        if (y0 > 0 && (y0 & 7) == 0) {                                   /* :818-858 the edge above the block */
+            const int inside_ctb = y0 & ctb_mask;
+            const int ok_slice = across_slices || !(fl & 1), ok_tiles = g->loop_filter_across_tiles || !(fl & 2);
+            if ((ok_slice && ok_tiles) || inside_ctb)
+                for (int i = 0; i < n; i += 4) {
+                    const oh_bs_field *top = OH_MVF(x0 + i, y0 - 1), *cur = OH_MVF(x0 + i, y0);
+                    int bs;
+                    if (cur->pred_flag == 0 || top->pred_flag == 0) bs = 2;
+                    else if (OH_CBF(x0 + i, y0) || OH_CBF(x0 + i, y0 - 1)) bs = 1;
+                    else bs = oh_bs_motion(cur, top);
+                    horizontal_bs[((x0 + i) + y0 * g->bs_width) >> 2] = (uint8_t)bs;
+                }
+        }
+        if (x0 > 0 && (x0 & 7) == 0) {                                   /* :861-898 the edge left of it */
+            const int inside_ctb = x0 & ctb_mask;
+            const int ok_slice = across_slices || !(fl & 4), ok_tiles = g->loop_filter_across_tiles || !(fl & 8);
+            if ((ok_slice && ok_tiles) || inside_ctb)
+                for (int i = 0; i < n; i += 4) {
+                    const oh_bs_field *left = OH_MVF(x0 - 1, y0 + i), *cur = OH_MVF(x0, y0 + i);
+                    int bs;
+                    if (cur->pred_flag == 0 || left->pred_flag == 0) bs = 2;
+                    else if (OH_CBF(x0, y0 + i) || OH_CBF(x0 - 1, y0 + i)) bs = 1;
+                    else bs = oh_bs_motion(cur, left);
+                    vertical_bs[(x0 + (y0 + i) * g->bs_width) >> 2] = (uint8_t)bs;
+                }
+        }
+        if (calls[c].log2_size > lp && !is_intra) {                      /* :900-940 prediction-block edges inside the transform block */
+            for (int i = 0; i < n; i += 4) {
+                const oh_bs_field *top = OH_MVF(x0 + i, y0 + 7);
+                for (int j = 8; j < n; j += 8) {
+                    const oh_bs_field *cur = OH_MVF(x0 + i, y0 + j);
+                    horizontal_bs[((x0 + i) + (y0 + j) * g->bs_width) >> 2] = (uint8_t)oh_bs_motion(cur, top);
+                    top = cur;                                           /* :916 (not the entry at y0 + j + 7) */
+                }
+            }
+            for (int j = 0; j < n; j += 4) {
+                const oh_bs_field *left = OH_MVF(x0 + 7, y0 + j);
+                for (int i = 8; i < n; i += 8) {
+                    const oh_bs_field *cur = OH_MVF(x0 + i, y0 + j);
+                    vertical_bs[((x0 + i) + (y0 + j) * g->bs_width) >> 2] = (uint8_t)oh_bs_motion(cur, left);
+                    left = cur;
+                }
+            }
+        }
+    }
+#undef OH_MVF
+#undef OH_CBF
+}

@@ -103,4 +103,15 @@ void OHX(intra_pred)(int bd, const oh_intra_pic *pic, int x0, int y0, int log2, 
 void OHX(shvc_upsample_frame)(int bd, int block_slots, uint8_t *const el[3], const int32_t el_stride[3], int el_w, int el_h,
                               uint8_t *const bl[3], const int32_t bl_stride[3], int bl_w, int bl_h, const int32_t *win, const int32_t *up);
 
+/* Boundary strengths of the deblocking filter: ff_hevc_deblocking_boundary_strengths (hevc_filter.c:805-941) with boundary_strength()
+ * (:584-700, the C branch; TEST_MV_POC build: the motion field carries the POCs of its references).  One oh_bs_call per call the reference's
+ * front end makes (hevc.c:1578,1607,2400,2484); flags: bit 0/1 = lc->slice_or_tiles_up_boundary, bit 2/3 = ..._left_boundary, bit 4 =
+ * sh.slice_loop_filter_across_slices_enabled_flag.  The two arrays are only written where a call writes them (zero them first, hevc.c:3207-3208).
+ * Only implemented by the restatement (ohor_); pinned against the reference's own arrays through oracle/null_hooks.c's tap. */
+typedef struct oh_bs_field { int16_t mv[2][2]; int32_t poc[2]; uint32_t pred_flag; } oh_bs_field;       /* pred_flag: 0 intra, 1 L0, 2 L1, 3 both */
+typedef struct oh_bs_call { uint16_t x0, y0; uint8_t log2_size, flags; uint16_t reserved; } oh_bs_call;
+typedef struct oh_bs_geom { int32_t min_pu_width, log2_min_pu_size, min_tb_width, log2_min_tb_size, log2_ctb_size, bs_width, loop_filter_across_tiles; } oh_bs_geom;
+void OHX(boundary_strengths)(const oh_bs_geom *g, const oh_bs_field *mvf, const uint8_t *cbf_luma, const oh_bs_call *calls, int ncalls,
+                             uint8_t *vertical_bs, uint8_t *horizontal_bs);
+
 #endif

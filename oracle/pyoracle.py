@@ -288,3 +288,52 @@ def shvc_upsample_frame(oracle_lib_path, bd, el_planes, el_w, el_h, bl_planes, b
     blp = (C.c_void_p * 3)(*[p.ctypes.data for p in bl_planes]); bls = (C.c_int32 * 3)(*[p.strides[0] for p in bl_planes])
     win = np.asarray(win, np.int32); up = np.asarray(up, np.int32)
     L.ohor_shvc_upsample_frame(C.c_int(bd), C.c_int(block_slots), elp, els, el_w, el_h, blp, bls, bl_w, bl_h, _p(win), _p(up))
+
+
+# ---- boundary strengths (ohor_boundary_strengths; reference side: the tap in oracle/null_hooks.c) ----
+BS_FIELD = np.dtype([("mv", np.int16, (2, 2)), ("poc", np.int32, (2,)), ("pred_flag", np.uint32)])      # oh_bs_field, 20 bytes
+BS_CALL = np.dtype([("x0", np.uint16), ("y0", np.uint16), ("log2_size", np.uint8), ("flags", np.uint8), ("reserved", np.uint16)])
+
+
+class BsGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("min_pu_width", "log2_min_pu_size", "min_tb_width", "log2_min_tb_size", "log2_ctb_size", "bs_width",
+                                         "loop_filter_across_tiles")]
+
+
+def boundary_strengths(oracle_lib_path, geom, mvf, cbf_luma, calls, n_bs):
+    """our restatement over one picture's calls -> (vertical_bs, horizontal_bs), n_bs entries each, zero where no call writes"""
+    L = C.CDLL(oracle_lib_path)
+    assert mvf.dtype == BS_FIELD and calls.dtype == BS_CALL and cbf_luma.dtype == np.uint8
+    g = BsGeom(**geom)
+    v, h = np.zeros(n_bs, np.uint8), np.zeros(n_bs, np.uint8)
+    mvf, cbf_luma, calls = np.ascontiguousarray(mvf), np.ascontiguousarray(cbf_luma), np.ascontiguousarray(calls)
+    L.ohor_boundary_strengths(C.byref(g), _p(mvf), _p(cbf_luma), _p(calls), C.c_int(len(calls)), _p(v), _p(h))
+    return v, h
+
+
+class _BsFrame(C.Structure):
+    _fields_ = [("calls", C.c_void_p), ("ncalls", C.c_int32), ("mvf", C.c_void_p), ("cbf_luma", C.c_void_p), ("vertical_bs", C.c_void_p),
+                ("horizontal_bs", C.c_void_p), ("n_vertical", C.c_int32), ("n_horizontal", C.c_int32)] + \
+               [(n, C.c_int32) for n in ("min_pu_width", "min_pu_height", "log2_min_pu_size", "min_tb_width", "min_tb_height", "log2_min_tb_size",
+                                         "log2_ctb_size", "bs_width", "width", "height", "loop_filter_across_tiles")]
+
+
+def bs_tap(null_lib, on):
+    """oracle/_ref/libopenhevc_null.so: start (a fresh log) / stop logging the reference's ff_hevc_deblocking_boundary_strengths calls"""
+    null_lib.ohnull_bs_tap(C.c_int(1 if on else 0))
+
+
+def bs_tap_fetch(null_lib):
+    """-> None (no call since bs_tap) or dict(calls, mvf, cbf_luma, vertical_bs, horizontal_bs (the reference's), geom, n_bs): copies"""
+    f = _BsFrame()
+    if null_lib.ohnull_bs_fetch(C.byref(f)) != 0:
+        return None
+
+    def arr(ptr, count, dt):
+        return np.frombuffer((C.c_uint8 * (count * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+    geom = dict(min_pu_width=f.min_pu_width, log2_min_pu_size=f.log2_min_pu_size, min_tb_width=f.min_tb_width, log2_min_tb_size=f.log2_min_tb_size,
+                log2_ctb_size=f.log2_ctb_size, bs_width=f.bs_width, loop_filter_across_tiles=f.loop_filter_across_tiles)
+    return dict(calls=arr(f.calls, f.ncalls, BS_CALL), mvf=arr(f.mvf, f.min_pu_width * f.min_pu_height, BS_FIELD),
+                cbf_luma=arr(f.cbf_luma, f.min_tb_width * f.min_tb_height, np.uint8), vertical_bs=arr(f.vertical_bs, f.n_vertical, np.uint8),
+                horizontal_bs=arr(f.horizontal_bs, f.n_horizontal, np.uint8), geom=geom, n_bs=f.n_vertical, width=f.width, height=f.height,
+                min_pu_height=f.min_pu_height, min_tb_height=f.min_tb_height)

@@ -394,3 +394,39 @@ def test_shvc_reference_above_8_bit_writes_outside_the_picture(ref):
     written = (luma != 0xFFFF).any(axis=1)
     assert not written[1:eh:2].any(), "odd rows of the picture were written: the stride is no longer applied twice"
     assert written[0:2 * eh:2].all() and written[eh:2 * eh].any(), "rows beyond the picture's height stayed untouched"
+
+
+# ------------------------------------------------------------------ boundary strengths
+BS_STREAMS = ["ldp_8b", "ldb_8b", "ra_8b_ctb64", "ra_10b_odd", "weighted", "pcm", "cip", "tiles", "tiles_nolf", "slices", "slices_nolf",
+              "slices_dep_wpp", "no_tools", "fmt444_8b", "tqb", "ra_8b_foll_leaf", "bqmall_geometry_dense_qp22"]
+
+
+@pytest.mark.parametrize("name", BS_STREAMS)
+def test_boundary_strengths_against_the_reference_front_end(name):
+    """ohor_boundary_strengths (hevc_filter.c:584-700, 805-941 restated) against the arrays the reference's own function leaves in
+    s->horizontal_bs / vertical_bs, picture by picture, on the committed streams: oracle/null_hooks.c logs every call the reference's front
+    end makes (position, size, the slice / tile flags of its CTB) and shadows the motion-field and cbf_luma entries it reads."""
+    import os
+    from oracle import pystream as ps
+    from test_stream_cpu import load_golden
+    if not ps.have("null"):
+        pytest.skip("oracle/_ref/libopenhevc_null.so not built (needs /root/reference)")
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so")
+    aus, _ = load_golden(name)
+    seen = dict(pictures=0, calls=0, nonzero=0, strength1=0, motion_only=0)
+    with ps.Decoder("null", 1, 1) as d:
+        for i, au in enumerate(aus):
+            po.bs_tap(d.L, True)
+            assert d.L.ohdec_decode(d.h, au, len(au), i + 1) >= 0
+            t = po.bs_tap_fetch(d.L)
+            if t is None:
+                continue                      # parameter sets only, or a picture with deblocking switched off
+            v, h = po.boundary_strengths(lib, t["geom"], t["mvf"], t["cbf_luma"], t["calls"], t["n_bs"])
+            for mine, theirs, what in ((v, t["vertical_bs"], "vertical"), (h, t["horizontal_bs"], "horizontal")):
+                bad = np.flatnonzero(mine != theirs)
+                assert bad.size == 0, f"{name} access unit {i} {what}_bs: {bad.size} entries differ, first {bad[:4].tolist()} " \
+                                      f"mine {mine[bad[:4]].tolist()} reference {theirs[bad[:4]].tolist()}"
+            seen["pictures"] += 1; seen["calls"] += len(t["calls"])
+            seen["nonzero"] += int(np.count_nonzero(v) + np.count_nonzero(h)); seen["strength1"] += int(np.count_nonzero(v == 1) + np.count_nonzero(h == 1))
+        po.bs_tap(d.L, False)
+    assert seen["pictures"] > 0 and seen["calls"] > 0 and seen["nonzero"] > 0, seen
