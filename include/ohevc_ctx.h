@@ -123,6 +123,7 @@ int  ohevc_rec_deblock_maps(ohevc_ctx *ctx, const ohevc_dbk_maps *maps);
  * of ff_hevc_deblocking_boundary_strengths is recorded with ohevc_rec_bs_call(ctx, x0, y0, log2_size, OHEVC_BS_* flags). */
 int  ohevc_rec_deblock_maps_bs(ohevc_ctx *ctx, const ohevc_dbk_maps *maps, const ohevc_bs_maps *bs);
 int  ohevc_rec_bs_call(ohevc_ctx *ctx, int x0, int y0, int log2_size, int flags);
+int  ohevc_rec_bs_calls(ohevc_ctx *ctx, const ohevc_bs_call *calls, int n);
 /* The motion field does not have to travel: every inter prediction block of the frame is recorded as a luma MC job that carries its motion
  * vector (source position, phase) and its reference picture (slot).  After this call (once per frame, after ohevc_frame_begin)
  * ohevc_frame_reconstruct keeps them in a device-side grid of (1 << log2_unit)-sample units (ohevc_dev_motion_grid; log2_unit =

@@ -217,6 +217,7 @@ int  ohevc_tables_bs_wanted(ohevc_ctx *ctx, int log2_ctb_size, int sao_enabled, 
  * ohevc_tables_keep_motion(ctx, sps->log2_min_pu_size) right after ohevc_tables_begin_frame; OHEVC_DEVICE_BS=0|1|2 chooses, default 2). */
 int  ohevc_tables_keep_motion(ohevc_ctx *ctx, int log2_min_pu_size);
 int  ohevc_tables_bs_call(int x0, int y0, int log2_size, int flags);       /* records into the calling thread's bound context */
+int  ohevc_tables_bs_calls(const ohevc_bs_call *calls, int n);                /* the same for calls the front end collected itself (copied) */
 int  ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_maps *maps);
 /* the host planes registered for picture-store slot `slot` (tests: oracle/sw_exec.c executes recorded jobs on them) */
 int  ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[3], int linesize[3]);

@@ -48,8 +48,8 @@ static volatile int        g_error;
 static int                 g_bulk_filters = 1;     /* OHHIP_BULK_FILTERS=0: keep the reference's filter drivers and the per-edge table calls */
 static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
 static int                 g_pin_frames = 1;       /* OHHIP_PIN_FRAMES=0: leave the decoder's frame buffers pageable */
-static int                 g_async = -1;           /* OHHIP_ASYNC_ISSUE: 1 / 0 = frame ends issued by the library's issuer thread / by the decoding
-                                                      thread; default (-1): asynchronous when the decoder runs frame threads */
+static int                 g_async;                /* OHHIP_ASYNC_ISSUE=1: frame ends issued by the library's issuer threads instead of the decoding
+                                                      thread.  Off by default: measured slower with 16 frame threads (profiles/r03j_*) */
 static double              g_issuer_s0;            /* issuer seconds / frames at the last profile call */
 static long long           g_issuer_f0;
 static volatile int        g_async_used;           /* some frame end went through the issuer: fetch_output waits for copy-backs */
@@ -204,6 +204,10 @@ static int slot_of_frame_locked(ohevc_ctx *ctx, const HEVCContext *s, const AVFr
 
 /* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
 static int device_bs_frame(const HEVCContext *s);
+/* boundary-strength calls the picture's own thread records (ohhip_deblocking_boundary_strengths below) */
+static __thread ohevc_bs_call *t_bs_buf;
+static __thread int            t_bs_n, t_bs_cap;
+static __thread const HEVCContext *t_bs_direct;       /* the context whose calls this thread records directly, NULL: none */
 int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
 {
     int ret = ff_hevc_set_new_ref(s, frame, poc);                   /* hevc_refs.c */
@@ -292,6 +296,8 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     t_s = s;
     if (device_bs_frame(s) == 2 && ohevc_tables_keep_motion(ctx, s->sps->log2_min_pu_size) != OHEVC_OK)     /* boundary strengths from the MC jobs */
         g_error = 1;
+    t_bs_n = 0;
+    t_bs_direct = device_bs_frame(s) && !((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1) ? s : NULL;
     return 0;
 }
 
@@ -493,9 +499,28 @@ static int device_bs_frame(const HEVCContext *s)       /* the same decision at t
     return ohevc_tables_bs_wanted(t_ctx, s->sps->log2_ctb_size, s->sps->sao_enabled, s->sps->chroma_array_type, 1);     /* 1: from tab_mvf, 2: from the MC jobs */
 }
 
+/* One call costs the reference ~40 ns on 1080p inter content (10 000 calls, 0.4 ms per picture): recording it must cost far less than that.
+ * The thread that owns the picture (no slice threads: it makes every call) appends 8 bytes to a buffer of its own - the decision was taken at
+ * the picture's start (t_bs_direct) - and the frame-end hook hands the buffer over in one piece; slice threads go through the picture's
+ * context (ohevc_tables_bs_call, a recorder per thread). */
+
 void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log2_trafo_size)
 {
     const HEVCLocalContext *lc = s->HEVClc;
+    if (s == t_bs_direct) {
+        ohevc_bs_call *b;
+        if (t_bs_n == t_bs_cap) {
+            int cap = t_bs_cap ? 2 * t_bs_cap : 16384;
+            ohevc_bs_call *nb = realloc(t_bs_buf, (size_t)cap * sizeof(*nb));
+            if (!nb) { g_error = 1; return; }
+            t_bs_buf = nb; t_bs_cap = cap;
+        }
+        b = &t_bs_buf[t_bs_n++];
+        b->x0 = (uint16_t)x0; b->y0 = (uint16_t)y0; b->log2_size = (uint8_t)log2_trafo_size; b->reserved = 0;
+        b->flags = (uint8_t)((lc->slice_or_tiles_up_boundary & 3) | ((lc->slice_or_tiles_left_boundary & 3) << 2) |
+                             (s->sh.slice_loop_filter_across_slices_enabled_flag ? OHEVC_BS_ACROSS_SLICES : 0));
+        return;
+    }
     if (!device_bs(s)) {
         ff_hevc_deblocking_boundary_strengths(s, x0, y0, log2_trafo_size);
         return;
@@ -525,6 +550,9 @@ static int derive_filters(HEVCContext *s)
     m.is_pcm = s->is_pcm; m.min_pu_width = s->sps->min_pu_width; m.min_pu_height = s->sps->min_pu_height;
     m.emulate_filter_lag = 1; m.ctb_addr_ts_to_rs = s->pps->ctb_addr_ts_to_rs;
     if (device_bs_frame(s)) {
+        if (s == t_bs_direct && t_bs_n > 0 && ohevc_tables_bs_calls(t_bs_buf, t_bs_n) != OHEVC_OK)
+            return OHEVC_ERR_STATE;
+        t_bs_n = 0;
         m.tab_mvf = device_bs_frame(s) == 2 ? NULL : s->ref->tab_mvf; m.mvf_stride = sizeof(MvField);
         m.mvf_off_mv = offsetof(MvField, mv); m.mvf_off_poc = offsetof(MvField, poc); m.mvf_off_pred_flag = offsetof(MvField, pred_flag);
         m.mvf_pred_flag_bytes = sizeof(((MvField *)0)->pred_flag);
@@ -548,7 +576,7 @@ int ohdec_backend_open(void)
         ohevc_debug_set_record_only(1);
     g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
     g_pin_frames = !(getenv("OHHIP_PIN_FRAMES") && atoi(getenv("OHHIP_PIN_FRAMES")) == 0);
-    g_async = getenv("OHHIP_ASYNC_ISSUE") ? atoi(getenv("OHHIP_ASYNC_ISSUE")) : -1;
+    g_async = getenv("OHHIP_ASYNC_ISSUE") ? atoi(getenv("OHHIP_ASYNC_ISSUE")) : 0;
     g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
     /* A/B of the executors of the intra-coded blocks (include/ohevc_debug.h): 0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture */
     ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
@@ -684,7 +712,7 @@ int ohdec_backend_frame_done(void)
      * the picture's samples are waited for where it leaves the decoder (ohdec_backend_fetch_output).  Not with the decoded-picture-hash check
      * on (hevc.c:4146-4162 reads the host planes in this thread right behind this call) and not in frames mode over processes (the picture is
      * exported right below). */
-    async = g_async > 0 || (g_async < 0 && t_s && (t_s->threads_type & FF_THREAD_FRAME));
+    async = g_async > 0;
     if (async && ((t_s && t_s->decode_checksum_sei) || g_fm_on || !ohevc_ctx_has_device(t_ctx)))
         async = 0;
     st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame(t_ctx, !g_defer_download);

@@ -1259,6 +1259,14 @@ extern "C" int ohevc_rec_bs_call(ohevc_ctx *c, int x0, int y0, int log2_size, in
     return OHEVC_OK;
 }
 
+extern "C" int ohevc_rec_bs_calls(ohevc_ctx *c, const ohevc_bs_call *calls, int n)
+{
+    OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && n >= 0 && (n == 0 || calls != nullptr), "no frame begun / null array");
+    Rec &r = pick(c);
+    r.bs_calls.insert(r.bs_calls.end(), calls, calls + n);
+    return OHEVC_OK;
+}
+
 // ohevc_rec_deblock_maps with the boundary strengths derived on the device: m->vertical_bs / horizontal_bs are not read; the motion field and
 // the cbf_luma map (HOST pointers in *bs) are copied like the other maps.  The calls come through ohevc_rec_bs_call.
 extern "C" int ohevc_rec_deblock_maps_bs(ohevc_ctx *c, const ohevc_dbk_maps *m, const ohevc_bs_maps *bs)

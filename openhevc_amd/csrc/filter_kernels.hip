@@ -748,11 +748,13 @@ __device__ __forceinline__ int bs_motion(const BsField &c, const BsField &n)
     return 1;
 }
 
-// one lane per recorded call of ff_hevc_deblocking_boundary_strengths; every (edge, 4-sample segment) is written by exactly one call
+// 16 lanes per recorded call of ff_hevc_deblocking_boundary_strengths; a lane takes the (edge, 4-sample segment) items k, k + 16, ... of its
+// call: the block's top edge, its left edge, the prediction-block edges inside it (a 64x64 coding block has 256 items, an 8x8 transform block 4).
+// Every array entry is written by exactly one item of one call.
 __global__ __launch_bounds__(256) void boundary_strength_kernel(ohevc_bs_maps m, const ohevc_bs_call *__restrict__ calls, int ncalls,
                                                                 unsigned char *__restrict__ vbs, unsigned char *__restrict__ hbs)
 {
-    const int ci = blockIdx.x * 256 + threadIdx.x;
+    const int ci = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (ci >= ncalls) return;
     const ohevc_bs_call cl = calls[ci];
     const int x0 = cl.x0, y0 = cl.y0, n = 1 << cl.log2_size, l2pu = m.log2_min_pu_size, l2tu = m.log2_min_tb_size;
@@ -764,37 +766,37 @@ __global__ __launch_bounds__(256) void boundary_strength_kernel(ohevc_bs_maps m,
         if (cbf(xc, yc) || cbf(xn, yn)) return 1;
         return bs_motion(c, nb);
     };
-    const bool is_intra = bs_load(m, x0 >> l2pu, y0 >> l2pu).pf == 0u;
+    bool top = false, left = false;
     if (y0 > 0 && (y0 & 7) == 0) {                            // the block's top edge, :821-858
         const bool bd_ctby = (y0 & ctb_mask) != 0;
         const bool bd_slice = (cl.flags & OHEVC_BS_ACROSS_SLICES) || !(cl.flags & OHEVC_BS_SLICE_UP);
         const bool bd_tiles = m.loop_filter_across_tiles || !(cl.flags & OHEVC_BS_TILE_UP);
-        if ((bd_slice && bd_tiles) || bd_ctby)
-            for (int i = 0; i < n; i += 4) hbs[((x0 + i) + y0 * m.bs_width) >> 2] = (unsigned char)edge(x0 + i, y0, x0 + i, y0 - 1);
+        top = (bd_slice && bd_tiles) || bd_ctby;
     }
     if (x0 > 0 && (x0 & 7) == 0) {                            // its left edge, :861-898
         const bool bd_ctbx = (x0 & ctb_mask) != 0;
         const bool bd_slice = (cl.flags & OHEVC_BS_ACROSS_SLICES) || !(cl.flags & OHEVC_BS_SLICE_LEFT);
         const bool bd_tiles = m.loop_filter_across_tiles || !(cl.flags & OHEVC_BS_TILE_LEFT);
-        if ((bd_slice && bd_tiles) || bd_ctbx)
-            for (int i = 0; i < n; i += 4) vbs[(x0 + (y0 + i) * m.bs_width) >> 2] = (unsigned char)edge(x0, y0 + i, x0 - 1, y0 + i);
+        left = (bd_slice && bd_tiles) || bd_ctbx;
     }
-    if (cl.log2_size > l2pu && !is_intra) {                   // prediction-block edges inside it: motion only, :900-940
-        for (int i = 0; i < n; i += 4) {
-            BsField top = bs_load(m, (x0 + i) >> l2pu, (y0 + 8 - 1) >> l2pu);
-            for (int j = 8; j < n; j += 8) {
-                const BsField cur = bs_load(m, (x0 + i) >> l2pu, (y0 + j) >> l2pu);
-                hbs[((x0 + i) + (y0 + j) * m.bs_width) >> 2] = (unsigned char)bs_motion(cur, top);
-                top = cur;                                    // (the reference keeps the entry at y0 + j, not y0 + j + 7: `top = curr`)
-            }
-        }
-        for (int j = 0; j < n; j += 4) {
-            BsField left = bs_load(m, (x0 + 8 - 1) >> l2pu, (y0 + j) >> l2pu);
-            for (int i = 8; i < n; i += 8) {
-                const BsField cur = bs_load(m, (x0 + i) >> l2pu, (y0 + j) >> l2pu);
-                vbs[((x0 + i) + (y0 + j) * m.bs_width) >> 2] = (unsigned char)bs_motion(cur, left);
-                left = cur;
-            }
+    // prediction-block edges inside the block: motion only, :900-940 (the neighbour of the edge at offset j is the entry at j - 8 - `top = curr` -
+    // except the first, j = 8, whose neighbour is the entry at 7)
+    const bool inner = cl.log2_size > l2pu && n > 8 && bs_load(m, x0 >> l2pu, y0 >> l2pu).pf != 0u;
+    const int n4 = n >> 2, per_dir = inner ? n4 * ((n >> 3) - 1) : 0, total = 2 * n4 + 2 * per_dir;
+    for (int k = sub; k < total; k += 16) {
+        if (k < n4) {
+            if (top) hbs[((x0 + 4 * k) + y0 * m.bs_width) >> 2] = (unsigned char)edge(x0 + 4 * k, y0, x0 + 4 * k, y0 - 1);
+        } else if (k < 2 * n4) {
+            const int i = 4 * (k - n4);
+            if (left) vbs[(x0 + (y0 + i) * m.bs_width) >> 2] = (unsigned char)edge(x0, y0 + i, x0 - 1, y0 + i);
+        } else if (k < 2 * n4 + per_dir) {                   // horizontal edges: column segment i, edge row j
+            const int q = k - 2 * n4, i = 4 * (q % n4), j = 8 * (1 + q / n4);
+            const BsField cur = bs_load(m, (x0 + i) >> l2pu, (y0 + j) >> l2pu), nb = bs_load(m, (x0 + i) >> l2pu, (y0 + (j == 8 ? 7 : j - 8)) >> l2pu);
+            hbs[((x0 + i) + (y0 + j) * m.bs_width) >> 2] = (unsigned char)bs_motion(cur, nb);
+        } else {                                             // vertical edges: row segment j, edge column i
+            const int q = k - 2 * n4 - per_dir, j = 4 * (q % n4), i = 8 * (1 + q / n4);
+            const BsField cur = bs_load(m, (x0 + i) >> l2pu, (y0 + j) >> l2pu), nb = bs_load(m, (x0 + (i == 8 ? 7 : i - 8)) >> l2pu, (y0 + j) >> l2pu);
+            vbs[((x0 + i) + (y0 + j) * m.bs_width) >> 2] = (unsigned char)bs_motion(cur, nb);
         }
     }
 }
@@ -844,7 +846,7 @@ extern "C" int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohe
                   (maps->pred_flag_bytes == 1 || (maps->pred_flag_bytes == 4 && (maps->off_pred_flag & 3) == 0)), "motion-field entry layout");
     OHEVC_REQUIRE(maps->log2_min_pu_size >= 2 && maps->log2_min_tb_size >= 2 && maps->log2_ctb_size >= 4 && maps->log2_ctb_size <= 6 && maps->bs_width > 0 &&
                   maps->min_pu_width > 0 && maps->min_tb_width > 0, "picture geometry");
-    hipLaunchKernelGGL(boundary_strength_kernel, dim3((ncalls + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), *maps, calls, ncalls, vertical_bs, horizontal_bs);
+    hipLaunchKernelGGL(boundary_strength_kernel, dim3((ncalls + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(stream), *maps, calls, ncalls, vertical_bs, horizontal_bs);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

@@ -625,6 +625,14 @@ extern "C" int ohevc_tables_host_planes(ohevc_ctx *ctx, int slot, uint8_t *data[
     return OHEVC_ERR_STATE;
 }
 
+extern "C" int ohevc_tables_bs_calls(const ohevc_bs_call *calls, int n)
+{
+    if (!tl_ctx) { fail(OHEVC_ERR_STATE); return OHEVC_ERR_STATE; }
+    const int rc = ohevc_rec_bs_calls(tl_ctx, calls, n);
+    if (rc != OHEVC_OK) fail(rc);
+    return rc;
+}
+
 extern "C" int ohevc_tables_keep_motion(ohevc_ctx *ctx, int log2_min_pu_size)
 {
     const int rc = ohevc_frame_keep_motion(ctx, log2_min_pu_size);
