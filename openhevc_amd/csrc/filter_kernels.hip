@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
 {
     constexpr int PXB = (int)sizeof(Pixel), PPD = 4 / PXB, OFF = 4, PITCH = 64 + 2 * OFF;     // window: x = -1 sits at column OFF - 1
     __shared__ __attribute__((aligned(16))) Pixel win[66][PITCH];
-    const ohevc_sao_job jb = jobs[blockIdx.x];
+    const int ji = (g_variant & 4) ? blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));      // see sao_wide_kernel
+    if (ji >= njobs) return;
+    const ohevc_sao_job jb = jobs[ji];
     const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
     const int ov0 = jb.offset_val[0], ov1 = jb.offset_val[1], ov2 = jb.offset_val[2], ov3 = jb.offset_val[3], ov4 = jb.offset_val[4];
     const int sstride = PLANE_STRIDE3(src, jb.plane), dstride = PLANE_STRIDE3(dst, jb.plane);
@@ -597,12 +599,17 @@ __device__ __forceinline__ SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao
 }
 
 template <typename Pixel>
-__global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp)
+__global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp, int xcd_spread)
 {
     constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);     // samples per lane / dword
     constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
     typedef const OHEVC_CONST_AS u32x4 *cptr;
-    const u32x4 j0 = ((cptr)(jobs + blockIdx.x))[0], j1 = ((cptr)(jobs + blockIdx.x))[1];
+    // Workgroups go to the 8 XCDs round-robin by number and every XCD has an L2 of its own: in list order, the two 64-byte halves of a
+    // 128-byte line of an 8-bit picture (two neighbouring CTBs) and the rows a block shares with the CTBs above and below would be fetched
+    // from HBM by several XCDs.  Renumbered, an XCD takes a contiguous range of the list - a band of CTB rows.  (gridDim.x is a multiple of 8.)
+    const int ji = xcd_spread ? blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    if (ji >= njobs) return;
+    const u32x4 j0 = ((cptr)(jobs + ji))[0], j1 = ((cptr)(jobs + ji))[1];
     ohevc_sao_job jb;
     {
         const unsigned words[8] = { j0.x, j0.y, j0.z, j0.w, j1.x, j1.y, j1.z, j1.w };
@@ -943,17 +950,19 @@ static int sao_launch(const ohevc_plane dst[3], const ohevc_plane src[3], const 
     // n_wide >= 0: the caller sorted the jobs (ohevc_dev_sao_batch_sorted) - the first n_wide go to the wide kernel, the rest to the other
     const int nw = n_wide >= 0 ? n_wide : njobs;
     if (!(g_sao_variant & 2) && nw > 0) {
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(nw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp);
-        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(nw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp);
+        const int spread = (g_sao_variant & 4) != 0, gw = spread ? nw : (nw + 7) & ~7;           // ohevc_debug_set_sao_variant(4): list order
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(gw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
+        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(gw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
     }
     if (n_wide >= 0 && !(g_sao_variant & 2)) { jobs += n_wide; njobs -= n_wide; }
     if (njobs <= 0) { OHEVC_HIP_TRY(hipGetLastError()); return OHEVC_OK; }
+    const int gs = (g_sao_variant & 4) ? njobs : (njobs + 7) & ~7;
     if (g_sao_variant & 1) {
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
-        else                hipLaunchKernelGGL((sao_kernel<uint16_t, true>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, true>), dim3(gs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
+        else                hipLaunchKernelGGL((sao_kernel<uint16_t, true>), dim3(gs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
     } else {
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
-        else                hipLaunchKernelGGL((sao_kernel<uint16_t, false>), dim3(njobs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_kernel<uint8_t, false>), dim3(gs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
+        else                hipLaunchKernelGGL((sao_kernel<uint16_t, false>), dim3(gs), dim3(256), 0, st, pd, psrc, plag, jobs, njobs, bit_depth, bp, g_sao_variant);
     }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;

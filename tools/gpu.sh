@@ -14,7 +14,7 @@
 #   pmc                          FETCH_SIZE / WRITE_SIZE passes of the bench command                 -> pmc_traffic.json
 #   counters <kernel> <cmd ...>  SQ / TCP / TCC counter passes of <cmd>, rows of kernels matching    -> counters_<kernel>.txt
 #   kernels <only> [args]        tools/bench_kernels.py --resident --planes 8 --only <only>          -> bench_kernels_<only>.jsonl
-#   kernels_prof <only> [args]   the same command under rocprofv3 (stats + the two PMC passes)       -> kernel_stats_<only>.txt, pmc_<only>.jsonl
+#   kernels_prof <only> [args]   the same command under rocprofv3 (stats + the two PMC passes)       -> kernel_stats_<only>_<n>.txt, pmc_<only>_<n>.jsonl
 #   decode <bench_decode args>   tools/bench_decode.py (whole decoder, all thread modes)             -> decode_<n>.json
 #   chain [flat|natural]         per-launch durations and stream-idle gaps of one decoding thread    -> chain.jsonl, overlap.json
 #   overlap <threads>            kernel overlap between frame threads                                -> overlap_<threads>.jsonl
@@ -99,10 +99,10 @@ for l in sys.stdin:
     kernels_prof)
       local only=$1; shift
       local CMD="python $ROOT/tools/bench_kernels.py --resident --planes 8 --only $only $*"
-      prof_stats /tmp/kp_$only kp_$only $CMD | tee $OUT/kernel_stats_$only.txt
+      prof_stats /tmp/kp_$only kp_$only $CMD | tee $OUT/kernel_stats_${only}_$n.txt
       ( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/kpf_$only -o p -- $CMD > /dev/null 2>&1
         timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/kpw_$only -o p -- $CMD > /dev/null 2>&1 )
-      python tools/pmc_per_kernel.py /tmp/kp_$only/t_results.db /tmp/kpf_$only/p_results.db /tmp/kpw_$only/p_results.db | tee $OUT/pmc_$only.jsonl | cut -c1-300 ;;
+      python tools/pmc_per_kernel.py /tmp/kp_$only/t_results.db /tmp/kpf_$only/p_results.db /tmp/kpw_$only/p_results.db | tee $OUT/pmc_${only}_$n.jsonl | cut -c1-300 ;;
     decode)
       timeout 900 python tools/bench_decode.py "$@" 2>/dev/null | tail -1 > $OUT/decode_$n${ENVTAG:+_$ENVTAG}.json; [ -n "$ENVTAG" ] && cp $OUT/decode_$n${ENVTAG:+_$ENVTAG}.json $OUT/decode_$n.json
       python - $OUT/decode_$n.json <<'PY'
