@@ -40,7 +40,8 @@ int ohevc_debug_set_mc_variant(int variant);
 /* SAO kernel: 0 = shipped (wide form: 16 bytes of one row per lane, no LDS, position rules as byte masks; blocks it cannot take fall
  * back to the LDS-window form); bit 1 = never take the wide form (A/B); bit 0 = the edge classes split a block into its interior (short form: no border / restore predicate can
  * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and
- * tests); written after the round's GPU budget was spent, so the A/B on the device is the first thing to do with it. */
+ * tests).  Which XCD takes which block of the list: default = runs of 16 consecutive list entries per XCD; bit 2 (4) = list order (workgroup
+ * number = list index, i.e. round-robin over the XCDs); bit 3 (8) = one contiguous eighth of the list per XCD (profiles/r03l_*, r03m_*). */
 int ohevc_debug_set_sao_variant(int variant);
 /* Band SAO events on samples ABOVE the bit depth's range since the last reset (all streams of the current device; waits for them).  The
  * reference's sao_band_filter reads past its 32-entry offset table for such a sample (hevcdsp_template.c:340-365; constrained intra

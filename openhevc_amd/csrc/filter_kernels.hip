@@ -606,8 +606,12 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
     typedef const OHEVC_CONST_AS u32x4 *cptr;
     // Workgroups go to the 8 XCDs round-robin by number and every XCD has an L2 of its own: in list order, the two 64-byte halves of a
     // 128-byte line of an 8-bit picture (two neighbouring CTBs) and the rows a block shares with the CTBs above and below would be fetched
-    // from HBM by several XCDs.  Renumbered, an XCD takes a contiguous range of the list - a band of CTB rows.  (gridDim.x is a multiple of 8.)
-    const int ji = xcd_spread ? blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    // by several XCDs (FETCH_SIZE: 4.0x the algorithmic bytes for the 8-bit edge classes, 2.0x for the band filter, profiles/r03l_pmc_sao_*).
+    // Renumbered, an XCD takes runs of 16 consecutive list entries (1.02x; 5-10 % faster on the edge classes, profiles/r03m_*); one contiguous
+    // eighth of the list per XCD reads as little but runs slower on the band filter.  (gridDim.x is a multiple of 128 / 8.)
+    const int vb = blockIdx.x >> 3;
+    const int ji = xcd_spread == 1 ? (int)blockIdx.x : xcd_spread == 2 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3)) + vb
+                                                      : (vb >> 4) * 128 + (int)(blockIdx.x & 7) * 16 + (vb & 15);       // runs of 16 list entries per XCD
     if (ji >= njobs) return;
     const u32x4 j0 = ((cptr)(jobs + ji))[0], j1 = ((cptr)(jobs + ji))[1];
     ohevc_sao_job jb;
@@ -950,7 +954,8 @@ static int sao_launch(const ohevc_plane dst[3], const ohevc_plane src[3], const 
     // n_wide >= 0: the caller sorted the jobs (ohevc_dev_sao_batch_sorted) - the first n_wide go to the wide kernel, the rest to the other
     const int nw = n_wide >= 0 ? n_wide : njobs;
     if (!(g_sao_variant & 2) && nw > 0) {
-        const int spread = (g_sao_variant & 4) != 0, gw = spread ? nw : (nw + 7) & ~7;           // ohevc_debug_set_sao_variant(4): list order
+        // ohevc_debug_set_sao_variant(4): list order; (8): one contiguous eighth of the list per XCD; default: runs of 16 list entries per XCD
+        const int spread = (g_sao_variant & 4) ? 1 : (g_sao_variant & 8) ? 2 : 0, gw = spread == 1 ? nw : spread == 2 ? (nw + 7) & ~7 : (nw + 127) & ~127;
         if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(gw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
         else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(gw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
     }
