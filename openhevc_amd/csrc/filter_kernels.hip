@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void sao_kernel(PlaneSet dst, PlaneSet src, Pl
 }
 
 // ------------------------------------------------------------------ SAO, wide form
-// 16 bytes of one row per lane, no LDS, no barrier.  Lane l of the workgroup takes piece l % pieces of row l / pieces (+ passes of 256 / pieces
+// 16 bytes of one row per lane, no LDS, no barrier.  Lane l of the workgroup takes piece l % pieces of row l / pieces (+ passes of 128 / pieces
 // rows).  The class offsets come out of a 5-entry byte table through v_perm_b32; what the reference's position rules change (picture-border
 // samples take offset_val[0], restored samples and bypassed PUs keep the deblocked value: hevcdsp_template.c:419-566, hevc_filter.c:163-193)
 // is decided per lane as byte masks - only in lanes that can hold such a sample - and merged bitwise.  Takes the blocks sao_wide_ok accepts
@@ -598,8 +598,9 @@ __device__ __forceinline__ SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao
     return SaoMasks{ u32x4{ keep[0], keep[1], keep[2], keep[3] }, u32x4{ bord[0], bord[1], bord[2], bord[3] } };
 }
 
+constexpr int kSaoWideThreads = 128, kSaoWideRows = 2;       // lanes per block of the list; rows a lane has in flight at a time
 template <typename Pixel>
-__global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp, int xcd_spread)
+__global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp, int xcd_spread)
 {
     constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);     // samples per lane / dword
     constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
     const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
     if (!sao_wide_ok<Pixel>(jb, sbase, dbase, sstride, dstride, pw, bit_depth)) return;
     const bool is_band = jb.type == OHEVC_SAO_BAND;
-    const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = 256 >> lp;      // a power of two (sao_wide_ok)
+    const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = kSaoWideThreads >> lp;      // a power of two (sao_wide_ok)
     const int piece = threadIdx.x & (pieces - 1), row0 = threadIdx.x >> lp, x0 = piece * PPL;
     const int dxa = eo == 1 ? 0 : eo == 3 ? 1 : -1, dya = eo == 0 ? 0 : -1;       // first neighbour; the second is its mirror
     // class -> offset table for v_perm_b32: byte k of (tab_lo, tab_hi) = 128 + offset of class k.  Edge: k = sign + sign + 2 ->
@@ -663,59 +664,84 @@ __global__ __launch_bounds__(256) void sao_wide_kernel(PlaneSet dst, PlaneSet sr
     auto lo2 = [](unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c010c00u); };
     auto hi2 = [](unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c030c02u); };
     auto pack4 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); };
-    for (int y = row0; y < h; y += rows_per_pass) {
-        unsigned cv[4], ov_[4];
-        __builtin_memcpy(cv, sbase + ((unsigned)y * (unsigned)sstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), 16);
-        if (is_band) {
+    // A block lives as long as one lane's chain job record -> samples -> store, and the device holds a fixed number of lanes: what a lane has
+    // in flight decides the rate (profiles/r03l_*: 4x less traffic changed nothing).  So a lane takes kSaoWideRows rows at a time, all their
+    // loads issued before the first is used; 128 lanes per block keep twice as many blocks resident as 256 did.
+    // (one copy of the loop per filter type: with `is_band` tested inside, the branch around the neighbour loads made the compiler wait for
+    //  the first row's samples before it issued the second row's loads)
+    auto rows = [&](auto band_tag) {
+    constexpr bool is_band = decltype(band_tag)::value;
+    // (the edge classes are bound by their arithmetic - VALU busy 70 % of the launch, profiles/r02s4_* - and ran 8 % slower with two rows of
+    //  registers per lane: they keep one row; the band filter gained 15 % at 8 bit, profiles/r03n_*)
+    constexpr int U = is_band ? kSaoWideRows : 1;
+    for (int yb = row0; yb < h; yb += U * rows_per_pass) {
+        unsigned cv[U][4], av[U][4], bv[U][4];
+        int ea[U], eb[U];
 #pragma unroll
-            for (int d = 0; d < 4; d++)
-                ov_[d] = sizeof(Pixel) == 2 ? band2(cv[d]) : pack4(band2(lo2(cv[d])), band2(hi2(cv[d])));
-        } else {
-            // the two neighbours of every sample: 16 bytes one sample to the left / right of the piece, in the row above / below, clamped to
-            // the plane (what lies beyond only reaches samples that take offset_val[0]).  Both loads are unconditional and issued together
-            // with the piece's own; a piece that touches the picture's left / right edge loaded itself and is shifted by one sample afterwards
-            // (with the loads inside the branches of that case the compiler serialised them: three memory round trips per row instead of one)
-            unsigned av[4], bv[4];
-            auto fetch = [&](int dx, int dy, unsigned *o) {
-                int yy = jb.y + y + dy;
-                yy = yy < 0 ? 0 : yy > ph - 1 ? ph - 1 : yy;
-                const int xs = jb.x + x0 + dx, xc = xs < 0 ? 0 : xs + PPL > pw ? pw - PPL : xs;
-                __builtin_memcpy(o, splane + ((unsigned)yy * (unsigned)sstride + (unsigned)xc * (unsigned)sizeof(Pixel)), 16);
-                return xs - xc;                          // -1 / +1 at the left / right picture edge
-            };
-            auto shift = [&](unsigned *o, int e) {       // the outermost sample repeated
-                if (e < 0) { o[3] = (o[3] << SB) | (o[2] >> (32 - SB)); o[2] = (o[2] << SB) | (o[1] >> (32 - SB)); o[1] = (o[1] << SB) | (o[0] >> (32 - SB)); o[0] = (o[0] << SB) | (o[0] & M); }
-                if (e > 0) { o[0] = (o[0] >> SB) | (o[1] << (32 - SB)); o[1] = (o[1] >> SB) | (o[2] << (32 - SB)); o[2] = (o[2] >> SB) | (o[3] << (32 - SB)); o[3] = (o[3] >> SB) | (o[3] & ~(0xffffffffu >> SB)); }
-            };
-            const int ea = fetch(dxa, dya, av), eb = fetch(-dxa, -dya, bv);
-            if ((ea | eb) != 0) { shift(av, ea); shift(bv, eb); }
-#pragma unroll
-            for (int d = 0; d < 4; d++)
-                ov_[d] = sizeof(Pixel) == 2 ? edge2(cv[d], av[d], bv[d])
-                                            : pack4(edge2(lo2(cv[d]), lo2(av[d]), lo2(bv[d])), edge2(hi2(cv[d]), hi2(av[d]), hi2(bv[d])));
-        }
-        // position rules: only where a lane can hold such a sample (first / last piece of a row, rows 0, h - 2, h - 1), or with a bypass map
-        if ((rules && (y == 0 || y >= h - 2 || piece == 0 || piece == pieces - 1)) || bp.map != nullptr) {
-            const SaoMasks m = sao_rule_masks<Pixel>(j0, j1, bp, x0, y);
-            const unsigned keep[4] = { m.keep.x, m.keep.y, m.keep.z, m.keep.w }, bord[4] = { m.bord.x, m.bord.y, m.bord.z, m.bord.w };
-            if ((bord[0] | bord[1] | bord[2] | bord[3]) != 0) {
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    unsigned acc = 0;
-#pragma unroll
-                    for (int k = 0; k < SPD; k++) {
-                        int v = (int)((cv[d] >> (SB * k)) & M) + ov0;
-                        v = v < 0 ? 0 : v > maxv ? maxv : v;
-                        acc |= (unsigned)v << (SB * k);
-                    }
-                    ov_[d] = (ov_[d] & ~bord[d]) | (acc & bord[d]);
-                }
+        for (int u = 0; u < U; u++) {
+            const int y = yb + u * rows_per_pass < h ? yb + u * rows_per_pass : yb;      // (a row that does not exist: reloaded, never stored)
+            __builtin_memcpy(cv[u], sbase + ((unsigned)y * (unsigned)sstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), 16);
+            ea[u] = eb[u] = 0;
+            if (!is_band) {
+                // the two neighbours of every sample: 16 bytes one sample to the left / right of the piece, in the row above / below, clamped to
+                // the plane (what lies beyond only reaches samples that take offset_val[0]).  Both loads are unconditional and issued together
+                // with the piece's own; a piece that touches the picture's left / right edge loaded itself and is shifted by one sample afterwards
+                // (with the loads inside the branches of that case the compiler serialised them: three memory round trips per row instead of one)
+                auto fetch = [&](int dx, int dy, unsigned *o) {
+                    int yy = jb.y + y + dy;
+                    yy = yy < 0 ? 0 : yy > ph - 1 ? ph - 1 : yy;
+                    const int xs = jb.x + x0 + dx, xc = xs < 0 ? 0 : xs + PPL > pw ? pw - PPL : xs;
+                    __builtin_memcpy(o, splane + ((unsigned)yy * (unsigned)sstride + (unsigned)xc * (unsigned)sizeof(Pixel)), 16);
+                    return xs - xc;                          // -1 / +1 at the left / right picture edge
+                };
+                ea[u] = fetch(dxa, dya, av[u]); eb[u] = fetch(-dxa, -dya, bv[u]);
             }
-#pragma unroll
-            for (int d = 0; d < 4; d++) ov_[d] = (ov_[d] & ~keep[d]) | (cv[d] & keep[d]);
         }
-        __builtin_memcpy(dbase + ((unsigned)y * (unsigned)dstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), ov_, 16);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int y = yb + u * rows_per_pass;
+            if (y >= h) break;
+            unsigned ov_[4];
+            if (is_band) {
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                    ov_[d] = sizeof(Pixel) == 2 ? band2(cv[u][d]) : pack4(band2(lo2(cv[u][d])), band2(hi2(cv[u][d])));
+            } else {
+                auto shift = [&](unsigned *o, int e) {       // the outermost sample repeated
+                    if (e < 0) { o[3] = (o[3] << SB) | (o[2] >> (32 - SB)); o[2] = (o[2] << SB) | (o[1] >> (32 - SB)); o[1] = (o[1] << SB) | (o[0] >> (32 - SB)); o[0] = (o[0] << SB) | (o[0] & M); }
+                    if (e > 0) { o[0] = (o[0] >> SB) | (o[1] << (32 - SB)); o[1] = (o[1] >> SB) | (o[2] << (32 - SB)); o[2] = (o[2] >> SB) | (o[3] << (32 - SB)); o[3] = (o[3] >> SB) | (o[3] & ~(0xffffffffu >> SB)); }
+                };
+                if ((ea[u] | eb[u]) != 0) { shift(av[u], ea[u]); shift(bv[u], eb[u]); }
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                    ov_[d] = sizeof(Pixel) == 2 ? edge2(cv[u][d], av[u][d], bv[u][d])
+                                                : pack4(edge2(lo2(cv[u][d]), lo2(av[u][d]), lo2(bv[u][d])), edge2(hi2(cv[u][d]), hi2(av[u][d]), hi2(bv[u][d])));
+            }
+            // position rules: only where a lane can hold such a sample (first / last piece of a row, rows 0, h - 2, h - 1), or with a bypass map
+            if ((rules && (y == 0 || y >= h - 2 || piece == 0 || piece == pieces - 1)) || bp.map != nullptr) {
+                const SaoMasks m = sao_rule_masks<Pixel>(j0, j1, bp, x0, y);
+                const unsigned keep[4] = { m.keep.x, m.keep.y, m.keep.z, m.keep.w }, bord[4] = { m.bord.x, m.bord.y, m.bord.z, m.bord.w };
+                if ((bord[0] | bord[1] | bord[2] | bord[3]) != 0) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        unsigned acc = 0;
+#pragma unroll
+                        for (int k = 0; k < SPD; k++) {
+                            int v = (int)((cv[u][d] >> (SB * k)) & M) + ov0;
+                            v = v < 0 ? 0 : v > maxv ? maxv : v;
+                            acc |= (unsigned)v << (SB * k);
+                        }
+                        ov_[d] = (ov_[d] & ~bord[d]) | (acc & bord[d]);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < 4; d++) ov_[d] = (ov_[d] & ~keep[d]) | (cv[u][d] & keep[d]);
+            }
+            __builtin_memcpy(dbase + ((unsigned)y * (unsigned)dstride + (unsigned)x0 * (unsigned)sizeof(Pixel)), ov_, 16);
+        }
     }
+    };
+    if (is_band) rows(std::true_type{}); else rows(std::false_type{});
 }
 
 int g_sao_variant = 0;     // ohevc_debug_set_sao_variant
@@ -956,8 +982,8 @@ static int sao_launch(const ohevc_plane dst[3], const ohevc_plane src[3], const 
     if (!(g_sao_variant & 2) && nw > 0) {
         // ohevc_debug_set_sao_variant(4): list order; (8): one contiguous eighth of the list per XCD; default: runs of 16 list entries per XCD
         const int spread = (g_sao_variant & 4) ? 1 : (g_sao_variant & 8) ? 2 : 0, gw = spread == 1 ? nw : spread == 2 ? (nw + 7) & ~7 : (nw + 127) & ~127;
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(gw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
-        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(gw), dim3(256), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(gw), dim3(kSaoWideThreads), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
+        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(gw), dim3(kSaoWideThreads), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
     }
     if (n_wide >= 0 && !(g_sao_variant & 2)) { jobs += n_wide; njobs -= n_wide; }
     if (njobs <= 0) { OHEVC_HIP_TRY(hipGetLastError()); return OHEVC_OK; }
