@@ -186,12 +186,8 @@ struct ohevc_ctx : Rec {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
     int device = 0;
     hipStream_t stream = nullptr;
-    // Two upload lanes - host staging buffer, device buffer, "copied" event - one for the job arrays of ohevc_frame_reconstruct, one for the
-    // filter maps of the frame end.  With one lane the second staging copy of a picture had to wait on the host until the first H2D copy
-    // had run, and that copy sits in the stream BEHIND the waits for the reference pictures' completion: under frame threads every
-    // decoding thread stood still in the middle of its frame end until its references were reconstructed on the device.
-    hipEvent_t staged[2] = {nullptr, nullptr};      // recorded after the last H2D copy out of stage[k]
-    bool staged_pending[2] = {false, false};
+    hipEvent_t staged = nullptr;      // recorded after the last H2D copy out of `stage`
+    bool staged_pending = false;
     std::shared_ptr<PicStore> store;
     unsigned table_version = ~0u;     // store->version the device MC table was built from
     int cur = -1;
@@ -241,8 +237,8 @@ struct ohevc_ctx : Rec {
     ptrdiff_t async_stride[3] = {0, 0, 0};
     hipEvent_t dl_ring[8] = {};
     int dl_next = 0;
-    DevBuf d_jobs[2], d_coeffs, d_table, d_upsample;
-    PinnedBuf stage[2];
+    DevBuf d_jobs, d_coeffs, d_table, d_upsample;
+    PinnedBuf stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
     int n_frames = 0, n_map_frames = 0;
@@ -310,8 +306,7 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     c->device = device;
     c->store = share_with ? share_with->store : std::make_shared<PicStore>();
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&c->staged[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->staged[1], hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) == hipSuccess;
     for (auto &e : c->ring) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         set_error("stream/event creation failed");
@@ -363,14 +358,14 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
     if (c->twin.used) free_picture(c->twin);
     if (c->lag.used) free_picture(c->lag);
-    for (DevBuf &b : c->d_jobs) if (b.p) (void)hipFree(b.p);
+    if (c->d_jobs.p) (void)hipFree(c->d_jobs.p);
     if (c->d_coeffs.p) (void)hipFree(c->d_coeffs.p);
     if (c->d_table.p) (void)hipFree(c->d_table.p);
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
     if (c->d_bs.p) (void)hipFree(c->d_bs.p);
     if (c->d_grid.p) (void)hipFree(c->d_grid.p);
-    for (PinnedBuf &b : c->stage) if (b.p) (void)hipHostFree(b.p);
-    for (hipEvent_t e : c->staged) if (e) (void)hipEventDestroy(e);
+    if (c->stage.p) (void)hipHostFree(c->stage.p);
+    if (c->staged) (void)hipEventDestroy(c->staged);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
     if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
@@ -406,7 +401,7 @@ extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
         OHEVC_HIP_TRY(hipDeviceSynchronize());
     }
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-    c->staged_pending[0] = c->staged_pending[1] = false;
+    c->staged_pending = false;
     return OHEVC_OK;
 }
 
@@ -1344,11 +1339,11 @@ static size_t stage_put(std::vector<std::pair<const void *, size_t>> &parts, siz
     return off;
 }
 
-static int wait_staging_free(ohevc_ctx *c, int lane)
+static int wait_staging_free(ohevc_ctx *c)
 {
-    if (c->staged_pending[lane]) {
-        OHEVC_HIP_TRY(hipEventSynchronize(c->staged[lane]));
-        c->staged_pending[lane] = false;
+    if (c->staged_pending) {
+        OHEVC_HIP_TRY(hipEventSynchronize(c->staged));
+        c->staged_pending = false;
     }
     return OHEVC_OK;
 }
@@ -1413,24 +1408,24 @@ static int guard_pictures(ohevc_ctx *c, int target)
 }
 
 // upload a set of job arrays in one H2D copy; fills offs[i] with the device offset of parts[i]
-static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>> &parts, size_t total, int lane)
+static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>> &parts, size_t total)
 {
     if (total == 0) return OHEVC_OK;
-    int rc = wait_staging_free(c, lane);
+    int rc = wait_staging_free(c);
     if (rc != OHEVC_OK) return rc;
-    if ((rc = c->stage[lane].reserve(total)) != OHEVC_OK) return rc;
-    if (total > c->d_jobs[lane].cap) {
+    if ((rc = c->stage.reserve(total)) != OHEVC_OK) return rc;
+    if (total > c->d_jobs.cap) {
         OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));     // in-flight kernels may still read the old buffer
-        if ((rc = c->d_jobs[lane].reserve(total)) != OHEVC_OK) return rc;
+        if ((rc = c->d_jobs.reserve(total)) != OHEVC_OK) return rc;
     }
     size_t off = 0;
     for (auto &pr : parts) {
-        memcpy(c->stage[lane].p + off, pr.first, pr.second);
+        memcpy(c->stage.p + off, pr.first, pr.second);
         off += (pr.second + 255) & ~(size_t)255;
     }
-    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs[lane].p, c->stage[lane].p, total, hipMemcpyHostToDevice, c->stream));
-    OHEVC_HIP_TRY(hipEventRecord(c->staged[lane], c->stream));
-    c->staged_pending[lane] = true;
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs.p, c->stage.p, total, hipMemcpyHostToDevice, c->stream));
+    OHEVC_HIP_TRY(hipEventRecord(c->staged, c->stream));
+    c->staged_pending = true;
     c->stats.upload_bytes += (int64_t)total;
     return OHEVC_OK;
 }
@@ -1714,8 +1709,8 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_ci = ctbs && !c->ctb_intra.empty() ? stage_put(parts, total, c->ctb_intra.data(), c->ctb_intra.size() * sizeof(ohevc_intra_job)) : 0;
     const size_t off_cu = ctbs && !c->ctb_tu.empty() ? stage_put(parts, total, c->ctb_tu.data(), c->ctb_tu.size() * sizeof(ohevc_tu_job)) : 0;
     const size_t off_cs = ctbs ? stage_put(parts, total, c->ctb_sync_zero.data(), c->ctb_sync_zero.size() * sizeof(uint32_t)) : 0;
-    if ((rc = upload_jobs(c, parts, total, 0)) != OHEVC_OK) return rc;
-    unsigned char *base = static_cast<unsigned char *>(c->d_jobs[0].p);
+    if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
+    unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
     const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
 
     // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
@@ -1907,8 +1902,8 @@ static int frame_end_impl(ohevc_ctx *c)
                                          return ohevc_sao_job_is_wide(&j, p->planes, p->planes, p->bd) != 0; }) - c->sao.begin());
         const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
         const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
-        if ((rc = upload_jobs(c, parts, total, 1)) != OHEVC_OK) return rc;
-        unsigned char *base = static_cast<unsigned char *>(c->d_jobs[1].p);
+        if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
+        unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
         ohevc_dbk_maps dm = c->dbk_maps;                  // offsets -> device addresses
         if (!c->dbk_blob.empty()) {
             dm.vertical_bs = base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.vertical_bs);
