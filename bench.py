@@ -180,9 +180,13 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080)):
         for label, kind, th in (("hip_1thread", "hip", 1), (f"hip_{threads}frame_threads", "hip", threads),
                                 ("reference_c_1thread", "c", 1), (f"reference_c_{threads}frame_threads", "c", threads),
                                 # the same front end with EMPTY tables (oracle/null_hooks.c: no pixels at all): what no table back end can beat
-                                ("front_end_only_1thread", "null", 1), (f"front_end_only_{threads}frame_threads", "null", threads)):
+                                ("front_end_only_1thread", "null", 1), (f"front_end_only_{threads}frame_threads", "null", threads),
+                                # ... and with the reference's own waits between frame threads kept (rows reported as they are parsed)
+                                (f"front_end_only_{threads}frame_threads_reference_waits", "null", threads)):
             if not ps.have(kind):
                 continue
+            if kind == "null":
+                ps._load("null").ohnull_set_await(1 if label.endswith("reference_waits") else 0)
             if kind == "hip":
                 hipL.ohdec_backend_profile(C.byref(sec), cnt)          # reset the cumulative counters
                 hipL.ohdec_backend_alg_bytes()

@@ -29,7 +29,17 @@ int  ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc) { return ff_hev
 int  ohhip_frame_rps(HEVCContext *s) { return ff_hevc_frame_rps(s); }
 const AVPixFmtDescriptor *ohhip_pix_fmt_desc_get(enum AVPixelFormat f) { return av_pix_fmt_desc_get(f); }
 void ohhip_report_progress(ThreadFrame *f, int progress, int field) { ff_thread_report_progress(f, progress, field); }
-void ohhip_await_progress(ThreadFrame *f, int progress, int field) { (void)f; (void)progress; (void)field; }
+/* OHNULL_AWAIT=1 / ohnull_set_await(1): keep the reference's frame-thread waits (hevc_await_progress, hevc.c:1951-1958: a picture's thread waits until the thread of
+ * a reference picture has reported the rows its motion vectors reach - here reported as that picture is PARSED).  The time of this build is
+ * then what a back end with the reference's own dependency structure could reach at best; without it the pictures do not wait for each
+ * other at all (a bound no decoder reaches). */
+static int g_keep_await = -1;
+void ohnull_set_await(int on) { g_keep_await = on != 0; }            /* between decoders (bench.py) */
+void ohhip_await_progress(ThreadFrame *f, int progress, int field)
+{
+    if (g_keep_await < 0) g_keep_await = getenv("OHNULL_AWAIT") && atoi(getenv("OHNULL_AWAIT")) != 0;
+    if (g_keep_await) ff_thread_await_progress(f, progress, field);
+}
 void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts) { ff_hevc_cabac_init(s, ctb_addr_ts); }
 int  ohhip_log2_res_scale_abs(HEVCContext *s, int idx) { return ff_hevc_log2_res_scale_abs(s, idx); }
 int  ohhip_res_scale_sign_flag(HEVCContext *s, int idx) { return ff_hevc_res_scale_sign_flag(s, idx); }
