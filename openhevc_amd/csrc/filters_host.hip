@@ -6,9 +6,10 @@
 // nobody reads behind recording tables.  Everything they need is final once the picture is parsed: the boundary-strength maps,
 // qp_y_tab, the per-CTB deblocking offsets and SAO parameters, the slice / tile maps.  ohevc_tables_derive_filters reads those
 // arrays ONCE at the frame end and records the same job set in one tight loop: no per-edge pointer translation, no calls, and the
-// reference's drivers can be skipped altogether.  The parameter derivation itself stays what it is in
-// the reference -- including which offsets an edge next to a CTB boundary gets (see the comments) -- because the job set must
-// be the one the drivers would have produced: tests/test_stream_cpu.py runs both paths through the software executor.
+// reference's drivers can be skipped altogether.  On a device the maps themselves travel and the kernels derive
+// everything (ohevc_dev_deblock_maps); this file's per-edge derivation serves record-only contexts (host-logic tests through the software
+// executor: tests/test_stream_cpu.py runs both paths) and the filter-lag replay of 16x16-CTB streams.  It is the kernels' closed form, edge
+// by edge - which offsets an edge next to a CTB boundary gets included - because the job set must be the one the drivers would have produced.
 #include <algorithm>
 #include <unordered_map>
 #include <utility>
@@ -68,75 +69,56 @@ struct Ctx {
         if (lag && !vertical && plane > 0) h_edge_seq[((uint32_t)plane << 30) | ((uint32_t)y << 15) | (uint32_t)x] = ++seq;
     }
 
-    // deblocking_filter_CTB, hevc_filter.c:345-581, loop for loop (the order of the calls does not matter to the executor, the
-    // parameters each edge gets do)
+    // One 8-sample edge of the 8x8 luma grid / the (8h)x(8v) chroma grid, its first sample at luma position (x, y): the same closed form as
+    // deblock_maps_kernel (filter_kernels.hip) - which neighbour CTB's offsets an edge next to a CTB boundary gets follows from where the
+    // reference's loops start and stop (hevc_filter.c:385-579):
+    //   vertical edges          beta and tc offset of the CTB the edge lies in
+    //   horizontal luma edge    beta offset of the CTB holding x, tc offset of the CTB holding x + 8
+    //   horizontal chroma edge  segment 0: tc offset of the CTB holding x, segment 1: of the CTB holding x + 8h   (last column: clamped)
+    void edge_at(bool chroma, bool vertical, int x, int y)
+    {
+        const int h = 1 << hs, v = 1 << vs, step = chroma ? (vertical ? 4 * v : 4 * h) : 4;
+        const int sx = vertical ? 0 : step, sy = vertical ? step : 0;              // from segment 0 to segment 1
+        const int px = vertical ? x - 1 : x, py = vertical ? y : y - 1;            // the P side
+        const uint8_t *bsm = vertical ? m.vertical_bs : m.horizontal_bs;
+        const int bs[2] = { bsm[(x + y * m.bs_width) >> 2], bsm[((x + sx) + (y + sy) * m.bs_width) >> 2] };
+        if (chroma ? !(bs[0] == 2 || bs[1] == 2) : !(bs[0] || bs[1])) return;
+        int no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
+        if (m.pcm_or_bypass)
+            for (int k = 0; k < 2; k++) { no_p[k] = pcm(px + k * sx, py + k * sy); no_q[k] = pcm(x + k * sx, y + k * sy); }
+        const int log2_ctb = m.log2_ctb_size, ctb_w = (m.width + (1 << log2_ctb) - 1) >> log2_ctb;
+        auto offset = [&](int xx, int which) {                                   // slice_beta_offset / slice_tc_offset of the CTB holding (xx, y)
+            const int cx = std::min(xx >> log2_ctb, ctb_w - 1);
+            return (int)m.deblock[(size_t)(cx + (y >> log2_ctb) * ctb_w) * m.deblock_stride + which];
+        };
+        auto qp_at = [&](int k) { return (qpy(px + k * sx, py + k * sy) + qpy(x + k * sx, y + k * sy) + 1) >> 1; };
+        if (!chroma) {                                                            // both segments share segment 0's QP (:398, :497)
+            const int qp = qp_at(0), tco = offset(vertical ? x : x + 8, 1);
+            edge(0, x, y, vertical, kBeta[clip(qp + offset(x, 0), 0, 51)], bs[0] ? tc_luma(qp, bs[0], tco) : 0, bs[1] ? tc_luma(qp, bs[1], tco) : 0, no_p, no_q);
+        } else {                                                                  // bS 2 only, a QP per segment (:440-441, :549-550)
+            const int tco[2] = { offset(x, 1), offset(vertical ? x : x + 8 * h, 1) };
+            const int qp[2] = { bs[0] == 2 ? qp_at(0) : 0, bs[1] == 2 ? qp_at(1) : 0 };
+            for (int c = 1; c <= 2; c++)
+                edge(c, x >> hs, y >> vs, vertical, 0, bs[0] == 2 ? tc_chroma(qp[0], c, tco[0]) : 0, bs[1] == 2 ? tc_chroma(qp[1], c, tco[1]) : 0, no_p, no_q);
+        }
+    }
+
+    // The edges one call of deblocking_filter_CTB (hevc_filter.c:345-581) covers - only the filter-lag replay needs to know which call an
+    // edge belongs to, the executor takes a picture's edges in any order: the vertical edges inside the CTB; the horizontal edges of a run that
+    // begins 8 (chroma: 8h) samples inside the CTB to the left and ends as far short of the next one (the last column runs to the picture edge).
     void deblock_ctb(int x0, int y0)
     {
-        const int ctb_size = 1 << m.log2_ctb_size, ctb_w = (m.width + ctb_size - 1) >> m.log2_ctb_size;
-        const int ctb = (x0 >> m.log2_ctb_size) + (y0 >> m.log2_ctb_size) * ctb_w;
-        const int cur_beta = m.deblock[(size_t)ctb * m.deblock_stride], cur_tc = m.deblock[(size_t)ctb * m.deblock_stride + 1];
-        const int left_beta = x0 ? m.deblock[(size_t)(ctb - 1) * m.deblock_stride] : 0, left_tc = x0 ? m.deblock[(size_t)(ctb - 1) * m.deblock_stride + 1] : 0;
-        const bool pcmf = m.pcm_or_bypass != 0;
-        int no_p[2] = { 0, 0 }, no_q[2] = { 0, 0 };
-        int x_end = std::min(x0 + ctb_size, m.width), x_end2;
-        const int y_end = std::min(y0 + ctb_size, m.height);
-        int tc_offset = cur_tc, beta_offset = cur_beta;
-        const int h = 1 << hs, v = 1 << vs;
-
-        for (int y = y0; y < y_end; y += 8)                          // vertical edges, luma (:385-420)
-            for (int x = x0 ? x0 : 8; x < x_end; x += 8) {
-                const int bs0 = m.vertical_bs[(x + y * m.bs_width) >> 2], bs1 = m.vertical_bs[(x + (y + 4) * m.bs_width) >> 2];
-                if (!(bs0 || bs1)) continue;
-                const int qp = (qpy(x - 1, y) + qpy(x, y) + 1) >> 1;
-                if (pcmf) { no_p[0] = pcm(x - 1, y); no_p[1] = pcm(x - 1, y + 4); no_q[0] = pcm(x, y); no_q[1] = pcm(x, y + 4); }
-                edge(0, x, y, true, kBeta[clip(qp + beta_offset, 0, 51)], bs0 ? tc_luma(qp, bs0, tc_offset) : 0, bs1 ? tc_luma(qp, bs1, tc_offset) : 0, no_p, no_q);
-            }
-        if (m.chroma_format_idc)                                     // vertical edges, chroma (:423-476): bS 2 only
-            for (int y = y0; y < y_end; y += 8 * v)
-                for (int x = x0 ? x0 : 8 * h; x < x_end; x += 8 * h) {
-                    const int bs0 = m.vertical_bs[(x + y * m.bs_width) >> 2], bs1 = m.vertical_bs[(x + (y + 4 * v) * m.bs_width) >> 2];
-                    if (!(bs0 == 2 || bs1 == 2)) continue;
-                    // (the reference evaluates both unconditionally, :440-441 - for bs1 != 2 that can be a row below the picture; the value is unused)
-                    const int qp0 = bs0 == 2 ? (qpy(x - 1, y) + qpy(x, y) + 1) >> 1 : 0, qp1 = bs1 == 2 ? (qpy(x - 1, y + 4 * v) + qpy(x, y + 4 * v) + 1) >> 1 : 0;
-                    if (pcmf) { no_p[0] = pcm(x - 1, y); no_p[1] = pcm(x - 1, y + 4 * v); no_q[0] = pcm(x, y); no_q[1] = pcm(x, y + 4 * v); }
-                    for (int c = 1; c <= 2; c++)
-                        edge(c, x >> hs, y >> vs, true, 0, bs0 == 2 ? tc_chroma(qp0, c, tc_offset) : 0, bs1 == 2 ? tc_chroma(qp1, c, tc_offset) : 0, no_p, no_q);
-                }
-        // horizontal edges, luma (:479-519): the run starts 8 samples inside the CTB to the left and stops 8 samples short of the
-        // next one; the first segment takes the LEFT CTB's beta offset -- and this CTB's tc offset (tc_offset is only switched in
-        // the chroma loop below)
-        x_end2 = x_end;
-        if (x_end != m.width) x_end -= 8;
-        for (int y = y0 ? y0 : 8; y < y_end; y += 8) {
-            beta_offset = x0 ? left_beta : cur_beta;
-            for (int x = x0 ? x0 - 8 : 0; x < x_end; x += 8) {
-                const int bs0 = m.horizontal_bs[(x + y * m.bs_width) >> 2], bs1 = m.horizontal_bs[((x + 4) + y * m.bs_width) >> 2];
-                if (bs0 || bs1) {
-                    const int qp = (qpy(x, y - 1) + qpy(x, y) + 1) >> 1;
-                    if (pcmf) { no_p[0] = pcm(x, y - 1); no_p[1] = pcm(x + 4, y - 1); no_q[0] = pcm(x, y); no_q[1] = pcm(x + 4, y); }
-                    edge(0, x, y, false, kBeta[clip(qp + beta_offset, 0, 51)], bs0 ? tc_luma(qp, bs0, tc_offset) : 0, bs1 ? tc_luma(qp, bs1, tc_offset) : 0, no_p, no_q);
-                }
-                beta_offset = cur_beta;
-            }
+        const int ctb_size = 1 << m.log2_ctb_size, x_end = std::min(x0 + ctb_size, m.width), y_end = std::min(y0 + ctb_size, m.height);
+        for (int chroma = 0; chroma <= (m.chroma_format_idc ? 1 : 0); chroma++) {
+            const int gx = chroma ? 8 << hs : 8, gy = chroma ? 8 << vs : 8;
+            for (int y = y0; y < y_end; y += gy)
+                for (int x = std::max(x0, gx); x < x_end; x += gx) edge_at(chroma != 0, true, x, y);
         }
-        // horizontal edges, chroma (:522-579): lag of 8 chroma samples; first segment of the first edge: the left CTB's tc offset,
-        // its second segment and everything after: this CTB's
-        if (m.chroma_format_idc) {
-            if (x_end2 != m.width) x_end = x_end2 - 8 * h;
-            for (int y = y0 ? y0 : 8 * v; y < y_end; y += 8 * v) {
-                tc_offset = x0 ? left_tc : cur_tc;
-                for (int x = x0 ? x0 - 8 * h : 0; x < x_end; x += 8 * h) {
-                    const int bs0 = m.horizontal_bs[(x + y * m.bs_width) >> 2], bs1 = m.horizontal_bs[((x + 4 * h) + y * m.bs_width) >> 2];
-                    if (bs0 == 2 || bs1 == 2) {
-                        const int qp0 = bs0 == 2 ? (qpy(x, y - 1) + qpy(x, y) + 1) >> 1 : 0;
-                        const int qp1 = bs1 == 2 ? (qpy(x + 4 * h, y - 1) + qpy(x + 4 * h, y) + 1) >> 1 : 0;
-                        if (pcmf) { no_p[0] = pcm(x, y - 1); no_p[1] = pcm(x + 4 * h, y - 1); no_q[0] = pcm(x, y); no_q[1] = pcm(x + 4 * h, y); }
-                        for (int c = 1; c <= 2; c++)
-                            edge(c, x >> hs, y >> vs, false, 0, bs0 == 2 ? tc_chroma(qp0, c, tc_offset) : 0, bs1 == 2 ? tc_chroma(qp1, c, cur_tc) : 0, no_p, no_q);
-                    }
-                    tc_offset = cur_tc;
-                }
-            }
+        for (int chroma = 0; chroma <= (m.chroma_format_idc ? 1 : 0); chroma++) {
+            const int gx = chroma ? 8 << hs : 8, gy = chroma ? 8 << vs : 8;
+            const int run_begin = x0 ? x0 - gx : 0, run_end = x_end == m.width ? m.width : x_end - gx;
+            for (int y = std::max(y0, gy); y < y_end; y += gy)
+                for (int x = run_begin; x < run_end; x += gx) edge_at(chroma != 0, false, x, y);
         }
     }
 
