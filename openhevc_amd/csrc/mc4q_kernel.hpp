@@ -1,0 +1,227 @@
+// mc4q_kernel.hpp -- four blocks of at most 8x8 samples in the matrix-core tile of mc4_kernel (included by mc_kernels.hip inside namespace ohevc,
+// behind mc4_kernel.hpp whose operand tables, plane split and loaders it uses).
+//
+// Most prediction blocks of a real stream are small: 8x8 / 8x4 / 4x8 luma blocks and ALL 4:2:0 chroma of luma blocks up to 16x16.  Through
+// mc4_kernel each of them costs a whole 16x16 tile - two window loads per lane, four MFMAs - for a quarter of its samples (13 % of the HBM
+// roofline on 8x8 blocks where 16x16 blocks reach 25-30 %).  The window of a block of at most 8x8 samples is at most 15x15, so a tile holds four:
+//
+//   pass 1, pair (a, b)     the 8 K slots of slot group g are 8 window columns of ONE block - groups 0, 1: columns 0..15 of a, groups 2, 3: of b - and
+//                           the constant operand is block diagonal: output column n < 8 is x = n of a (taps on a's slots only), n >= 8 is x = n - 8
+//                           of b.  The 15 window rows are the 16 rows of ONE MFMA; the second MFMA of the tile takes the pair (c, d).
+//   pass 2, per pair        the pass-1 result of a pair sits in K slots 0..3 of every slot group (rows 4g .. 4g + 3), slots 4..7 multiply zeros; column
+//                           y < 8 carries the vertical taps of one block of the pair, y >= 8 of the other.  Of the 16 x 16 results the two quadrants
+//                           where the row's block is the column's block are that pair's blocks.  Pair (a, b) is laid out a: (x < 8, y < 8),
+//                           b: (x >= 8, y >= 8) and pair (c, d) the other way round - c: (x < 8, y >= 8), d: (x >= 8, y < 8) - so that EVERY lane of the
+//                           result layout (lane = y, registers = 4 consecutive x) ends up with four samples of exactly one block.
+//
+// Per block everything may differ (plane, phases, references, weights): what mc4_kernel keeps in scalars per tile is selected per lane here.
+// Exactness: the same int8-plane products with the same constants as mc4_kernel (every output column still sees one complete filter whose taps sum to 64).
+
+// the job record of the block a lane works for, as vector registers
+struct Mc4qJob { int x, y, w, h, plane, flags, sx0, sy0, sx1, sy1, mx0, my0, mx1, my1, ref0, ref1, denom, wx0, wx1, ox0, ox1; };
+__device__ __forceinline__ Mc4qJob mc4q_unpack(const ohevc_mc_job &j)
+{
+    return Mc4qJob{ j.x, j.y, j.w, j.h, j.plane, j.flags, j.sx0, j.sy0, j.sx1, j.sy1, j.mx0, j.my0, j.mx1, j.my1, j.ref0, j.ref1, j.denom, j.wx0, j.wx1, j.ox0, j.ox1 };
+}
+__device__ __forceinline__ Mc4qJob mc4q_pick(bool first, const Mc4qJob &a, const Mc4qJob &b)
+{
+    Mc4qJob r;
+#define MC4Q_F(f) r.f = first ? a.f : b.f;
+    MC4Q_F(x) MC4Q_F(y) MC4Q_F(w) MC4Q_F(h) MC4Q_F(plane) MC4Q_F(flags) MC4Q_F(sx0) MC4Q_F(sy0) MC4Q_F(sx1) MC4Q_F(sy1) MC4Q_F(mx0) MC4Q_F(my0) MC4Q_F(mx1)
+    MC4Q_F(my1) MC4Q_F(ref0) MC4Q_F(ref1) MC4Q_F(denom) MC4Q_F(wx0) MC4Q_F(wx1) MC4Q_F(ox0) MC4Q_F(ox1)
+#undef MC4Q_F
+    return r;
+}
+
+// 8 samples of one window row of the lane's block, per-lane plane record (the four blocks of a quad may predict from different pictures)
+template <typename Pixel>
+__device__ __forceinline__ void mc4q_issue(const ohevc_plane *refs, int ref, int plane, int wx0, int wy0, int wh, int r, int half, unsigned (&out)[sizeof(Pixel) == 2 ? 4 : 2])
+{
+    typedef const MC4_GLOBAL unsigned long *lptr;
+    lptr pr = (lptr)(refs + (3 * ref + plane));
+    const unsigned long rec0 = pr[0], rec1 = pr[1], rec2 = pr[2];                // data | stride, width | height
+    mc4_gptr base = (mc4_gptr)rec0;
+    const unsigned stride = (unsigned)rec1;
+    const int xmax = (int)(rec1 >> 32) - 1, ymax = (int)(unsigned)rec2 - 1;
+    const int col0 = wx0 + 8 * half;
+    int wr = r < wh ? r : wh - 1;
+    int y = wy0 + wr;
+    y = y < 0 ? 0 : y > ymax ? ymax : y;
+    const unsigned rowoff = __umul24((unsigned)y, stride);
+    if (col0 >= 0 && col0 + 7 <= xmax) {
+        __builtin_memcpy(out, (const void *)(base + (rowoff + (unsigned)col0 * (unsigned)sizeof(Pixel))), sizeof(out));
+    } else {
+        const u32x4 e = mc4_gather_edge<Pixel>(base + rowoff, col0, xmax);
+        out[0] = e.x; out[1] = e.y;
+        if (sizeof(Pixel) == 2) { out[sizeof(Pixel) == 2 ? 2 : 0] = e.z; out[sizeof(Pixel) == 2 ? 3 : 1] = e.w; }
+    }
+}
+
+// one reference of a quad: raw[pair] = the lane's 8 samples (memory-side lane map) -> v[k] = the 14-bit intermediate of the lane's block at
+// (x = 4 (g & 1) + k, y = lane & 7), g = lane >> 4.  b1[pair] / b2[pair]: the lane's constant operands (see the kernel).
+template <typename Pixel>
+__device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixel) == 2 ? 4 : 2], const u32x2 (&b1)[2], const unsigned (&b2)[2], int bit_depth, int lane,
+                                            unsigned (&seen)[2], int *v)
+{
+    constexpr bool WIDE = sizeof(Pixel) == 2;
+    const mc4_v4i zero = { 0, 0, 0, 0 };
+    const int src = (lane & 15) * 4 + (lane >> 4);               // operand-side lane (row lane & 15, slot group lane >> 4) <- memory-side lane
+    const int K2 = 8192 + (WIDE ? 0 : 8192 * 64);
+    mc4_v4i e[2];
+#pragma unroll
+    for (int pair = 0; pair < 2; pair++) {
+        unsigned w[WIDE ? 4 : 2];
+#pragma unroll
+        for (int k = 0; k < (WIDE ? 4 : 2); k++) w[k] = (unsigned)__shfl((int)raw[pair][k], src);
+        const long bop1 = mc4_op(b1[pair].x, b1[pair].y);
+        mc4_v4i d;
+        int hv[4];
+        if (WIDE) {
+            seen[pair] = w[0] | w[1] | w[WIDE ? 2 : 0] | w[WIDE ? 3 : 1];
+            d = __builtin_amdgcn_mfma_i32_16x16x32_i8(mc4_op(mc4_hi(w[0], w[1]), mc4_hi(w[WIDE ? 2 : 0], w[WIDE ? 3 : 1])), bop1, zero, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = (d[k] << 8) + 8192;
+            d = __builtin_amdgcn_mfma_i32_16x16x32_i8(mc4_op(mc4_lo(w[0], w[1]), mc4_lo(w[WIDE ? 2 : 0], w[WIDE ? 3 : 1])), bop1, d, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) hv[k] = d[k] >> (bit_depth - 8);
+        } else {
+            d = __builtin_amdgcn_mfma_i32_16x16x32_i8(mc4_op(w[0] ^ 0x80808080u, w[1] ^ 0x80808080u), bop1, zero, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) hv[k] = d[k];
+        }
+        // (columns of the other block of the pair multiplied zeros: hv there is 0 resp. the bare plane offset - finite, and never looked at)
+        const unsigned p0 = mc4_pk16(hv[0], hv[1]), p1 = mc4_pk16(hv[2], hv[3]);
+        const long bop2 = mc4_op(b2[pair], 0u);                  // K slots 4..7 of every group: zero taps (and zero samples)
+        e[pair] = __builtin_amdgcn_mfma_i32_16x16x32_i8(mc4_op(mc4_hi(p0, p1), 0u), bop2, zero, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[pair][k] = (e[pair][k] << 8) + K2;
+        e[pair] = __builtin_amdgcn_mfma_i32_16x16x32_i8(mc4_op(mc4_lo(p0, p1), 0x80808080u ^ 0x80808080u), bop2, e[pair], 0, 0, 0);
+    }
+    const bool own = ((lane & 15) < 8) == ((lane >> 4) < 2);     // quadrants of pair (a, b); the other two hold pair (c, d)
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (own ? e[0][k] : e[1][k]) >> 6;
+}
+
+// 256 threads = 4 wavefronts (one LDS copy of the operand tables); a wavefront takes ONE quad: jobs 4q .. 4q + 3.
+template <typename Pixel>
+__global__ __launch_bounds__(256) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth,
+                                                   unsigned *__restrict__ wild_mask)
+{
+    constexpr bool WIDE = sizeof(Pixel) == 2;
+    __shared__ u32x2 tabs[2][12][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(&kMc4);
+        u32x4 *dl = reinterpret_cast<u32x4 *>(&tabs[0][0][0]);
+        const u32x4 t0 = src[tid], t1 = src[256 + tid], t2 = src[512 + tid];
+        dl[tid] = t0; dl[256 + tid] = t1; dl[512 + tid] = t2;
+    }
+    const int per_xcd = gridDim.x >> 3;                                                          // an XCD takes a contiguous eighth of the list (mc4_kernel)
+    const int q = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave;
+    typedef const MC4_CONST u32x4 *cptr;
+    Mc4qJob jb[4];
+    bool valid[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = 4 * q + i;
+        valid[i] = j < njobs;
+        cptr jp = (cptr)(jobs + (valid[i] ? j : njobs - 1));
+        const u32x4 w0 = jp[0], w1 = jp[1];
+        const unsigned words[8] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w };
+        ohevc_mc_job rec;
+        __builtin_memcpy(&rec, words, sizeof(rec));
+        jb[i] = mc4q_unpack(rec);
+    }
+    const bool any = 4 * q < njobs;
+    const bool any_bi = ((jb[0].flags | jb[1].flags | jb[2].flags | jb[3].flags) & OHEVC_MC_BI) != 0;      // wave-uniform
+    // ---- memory side: lane (r = lane >> 2, g = lane & 3) loads 8 samples of window row r, columns 8 (g & 1) .., of block g >> 1 of each pair
+    unsigned raw[2][2][WIDE ? 4 : 2] = {};
+    if (any) {
+        const int r = lane >> 2, half = lane & 1;
+        const bool first = (lane & 3) < 2;
+#pragma unroll
+        for (int pair = 0; pair < 2; pair++) {
+            const Mc4qJob m = mc4q_pick(first, jb[2 * pair], jb[2 * pair + 1]);
+            const int before = m.plane == 0 ? 3 : 1, taps = m.plane == 0 ? 8 : 4;
+            mc4q_issue<Pixel>(refs, m.ref0, m.plane, m.sx0 - before, m.sy0 - before, m.h + taps - 1, r, half, raw[0][pair]);
+            if (any_bi) {
+                const bool bi = (m.flags & OHEVC_MC_BI) != 0;
+                mc4q_issue<Pixel>(refs, bi ? m.ref1 : m.ref0, m.plane, (bi ? m.sx1 : m.sx0) - before, (bi ? m.sy1 : m.sy0) - before, m.h + taps - 1, r, half, raw[1][pair]);
+            }
+        }
+    }
+    __syncthreads();                                                                             // the tables are in LDS
+    if (!any) return;
+    // ---- operand side: lane (n = lane & 15, g = lane >> 4)
+    const int n = lane & 15, g = lane >> 4;
+    const bool lowcol = n < 8, lowgrp = g < 2;
+    u32x2 b1[2][2];
+    unsigned b2[2][2];
+#pragma unroll
+    for (int pair = 0; pair < 2; pair++) {
+        // pass 1: column n belongs to block (n < 8 ? first : second) of the pair, its taps sit on that block's slot groups only
+        const Mc4qJob c1 = mc4q_pick(lowcol, jb[2 * pair], jb[2 * pair + 1]);
+        const int ph1 = c1.plane == 0 ? 0 : 4, tl = (g & 1) * 16 + (n & 7);
+        const bool mine = lowcol == lowgrp;
+        const u32x2 t0 = tabs[0][ph1 + c1.mx0][tl], t1 = tabs[0][ph1 + c1.mx1][tl];
+        b1[0][pair] = mine ? t0 : u32x2{ 0u, 0u };
+        b1[1][pair] = mine ? t1 : u32x2{ 0u, 0u };
+        // pass 2: column y < 8 carries the vertical taps of a (pair 0) / d (pair 1), y >= 8 those of b / c; rows 4g .. 4g + 3 of the 15-row window
+        const Mc4qJob c2 = mc4q_pick(lowcol == (pair == 0), jb[2 * pair], jb[2 * pair + 1]);
+        const int ph2 = c2.plane == 0 ? 0 : 4, tl2 = g * 16 + (n & 7);
+        b2[0][pair] = tabs[1][ph2 + c2.my0][tl2].x;
+        b2[1][pair] = tabs[1][ph2 + c2.my1][tl2].x;
+    }
+    unsigned seen0[2] = { 0, 0 }, seen1[2] = { 0, 0 };
+    int v0[4], v1[4] = { 0, 0, 0, 0 };
+    mc4q_finish<Pixel>(raw[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
+    if (any_bi) mc4q_finish<Pixel>(raw[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
+    // ---- result side: lane (y = lane & 15, g): four samples x = 4 (g & 1) .. + 3 of row y & 7 of block  a: y < 8, g < 2   d: y < 8, g >= 2   c: y >= 8, g < 2   b: y >= 8, g >= 2
+    const int blk = lowcol ? (lowgrp ? 0 : 3) : (lowgrp ? 2 : 1);
+    const Mc4qJob m = mc4q_pick(lowcol, mc4q_pick(lowgrp, jb[0], jb[3]), mc4q_pick(lowgrp, jb[2], jb[1]));
+    bool skip = !(lowcol ? (lowgrp ? valid[0] : valid[3]) : (lowgrp ? valid[2] : valid[1]));
+    const int maxv = (1 << bit_depth) - 1;
+    if (WIDE) {
+        // samples above the bit depth's range: mc3_redo_kernel computes the block (mc4_kernel).  `seen` lives on the operand side: rows of the
+        // pair's first block in slot groups 0, 1, of its second block in groups 2, 3
+        const unsigned wild_bits = 0x10001u * (unsigned)(0xffff & ~maxv);
+        const bool s0 = ((seen0[0] | seen1[0]) & wild_bits) != 0, s1 = ((seen0[1] | seen1[1]) & wild_bits) != 0;
+        const bool wa = __ballot(s0 && lowgrp) != 0, wb = __ballot(s0 && !lowgrp) != 0, wc = __ballot(s1 && lowgrp) != 0, wd = __ballot(s1 && !lowgrp) != 0;
+        if (lane < 4) {
+            const bool wl = lane == 0 ? wa : lane == 1 ? wb : lane == 2 ? wc : wd;
+            if (wl && 4 * q + lane < njobs) atomicOr(&wild_mask[4 * q + lane], 1u);
+        }
+        skip = skip || (blk == 0 ? wa : blk == 1 ? wb : blk == 2 ? wc : wd);
+    }
+    const bool bi = (m.flags & OHEVC_MC_BI) != 0, weighted = (m.flags & OHEVC_MC_WEIGHTED) != 0;
+    int w0, w1, off, sh, add;
+    if (!weighted) {
+        sh = (bi ? 15 : 14) - bit_depth; w0 = 1; w1 = bi ? 1 : 0; off = mc_round(sh, bit_depth); add = 0;
+    } else if (!bi) {
+        sh = m.denom + 14 - bit_depth; w0 = m.wx0; w1 = 0; off = mc_round(sh, bit_depth); add = m.ox0 * (1 << (bit_depth - 8));
+    } else {
+        const int log2wd = m.denom + 14 - bit_depth;
+        sh = log2wd + 1; w0 = m.wx0; w1 = m.wx1; off = (m.ox0 * (1 << (bit_depth - 8)) + m.ox1 * (1 << (bit_depth - 8)) + 1) << log2wd; add = 0;
+    }
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int t = __mul24(v1[k], w1) + (__mul24(v0[k], w0) + off);
+        const int out = (t >> sh) + add;
+        o[k] = (unsigned)(out < 0 ? 0 : out > maxv ? maxv : out);
+    }
+    const int sy = n & 7, sx = 4 * (g & 1);
+    if (skip || sy >= m.h || sx >= m.w) return;
+    unsigned pk[WIDE ? 2 : 1];
+    if (WIDE) { pk[0] = o[0] | (o[1] << 16); pk[WIDE ? 1 : 0] = o[2] | (o[3] << 16); }
+    else      pk[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    const unsigned char *const pbase = m.plane == 0 ? PLANE_PTR3(dst, 0) : m.plane == 1 ? PLANE_PTR3(dst, 1) : PLANE_PTR3(dst, 2);
+    const int pstride = m.plane == 0 ? PLANE_STRIDE3(dst, 0) : m.plane == 1 ? PLANE_STRIDE3(dst, 1) : PLANE_STRIDE3(dst, 2);
+    MC4_GLOBAL unsigned char *p = (MC4_GLOBAL unsigned char *)pbase + (__umul24((unsigned)(m.y + sy), (unsigned)pstride) + (unsigned)(m.x + sx) * (unsigned)sizeof(Pixel));
+    if (m.w - sx >= 4) {
+        __builtin_memcpy((void *)p, pk, sizeof(pk));
+    } else {                                                      // widths 2 and 6 (chroma of 4- and 12-wide blocks)
+        for (int k = 0; k < m.w - sx; k++)
+            reinterpret_cast<MC4_GLOBAL Pixel *>(p)[k] = (Pixel)(WIDE ? pk[WIDE ? k >> 1 : 0] >> (16 * (k & 1)) : pk[0] >> (8 * k));
+    }
+}

@@ -598,6 +598,7 @@ __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_
 int g_mc_variant = getenv("OHEVC_MC_VARIANT") ? atoi(getenv("OHEVC_MC_VARIANT")) : 4;
 
 #include "mc4_kernel.hpp"
+#include "mc4q_kernel.hpp"
 
 }  // namespace ohevc
 
@@ -653,9 +654,10 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned short *wild = nullptr;
-    const bool v4 = g_mc_variant == 5 || (g_mc_variant == 4 && !small);
+    const bool v4q = small && g_mc_variant == 6;                      // four small blocks per matrix-core tile (mc4q_kernel)
+    const bool v4 = !v4q && (g_mc_variant == 5 || ((g_mc_variant == 4 || g_mc_variant == 6) && !small));
 #ifdef OHEVC_LAB
-    const bool v3 = v4 || small || (g_mc_variant != 1 && g_mc_variant != 2);
+    const bool v3 = v4 || v4q || small || (g_mc_variant != 1 && g_mc_variant != 2);
 #else
     const bool v3 = true;              // variants 1 and 2 exist in the lab build only: they fall through to mc3 here
 #endif
@@ -664,7 +666,16 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
         if (rc != OHEVC_OK) return rc;
     }
     const int redo_grid = std::min(256, (njobs + 63) / 64);
-    if (v4) {                                 // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
+    if (v4q) {
+        const int grid = (((njobs + 3) / 4 + 3) / 4 + 7) & ~7;          // quads of jobs, 4 wavefronts per workgroup, XCD-contiguous ranges
+        unsigned *wild32 = reinterpret_cast<unsigned *>(wild);
+        if (bit_depth == 8) hipLaunchKernelGGL((mc4q_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+        else {
+            OHEVC_HIP_TRY(hipMemsetAsync(wild32, 0, (size_t)njobs * sizeof(unsigned), st));
+            hipLaunchKernelGGL((mc4q_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+            hipLaunchKernelGGL((mc3_redo_kernel<unsigned>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild32, 16);
+        }
+    } else if (v4) {                          // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
         const bool multi = max_w > 16 || max_h > 16;
         const int tiles = ((max_w + 15) / 16) * ((max_h + 15) / 16);
         const auto up8 = [](int v) { return (v + 7) & ~7; };            // XCD-contiguous job ranges (mc4_kernel)
@@ -728,6 +739,6 @@ extern "C" int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_pl
 extern "C" int ohevc_debug_set_mc_variant(int variant)
 {
     int old = ohevc::g_mc_variant;
-    if (variant >= 1 && variant <= 5) ohevc::g_mc_variant = variant;
+    if (variant >= 1 && variant <= 6) ohevc::g_mc_variant = variant;
     return old;
 }
