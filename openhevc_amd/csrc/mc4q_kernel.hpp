@@ -33,16 +33,21 @@ __device__ __forceinline__ Mc4qJob mc4q_pick(bool first, const Mc4qJob &a, const
     return r;
 }
 
-// 8 samples of one window row of the lane's block, per-lane plane record (the four blocks of a quad may predict from different pictures)
-template <typename Pixel>
-__device__ __forceinline__ void mc4q_issue(const ohevc_plane *refs, int ref, int plane, int wx0, int wy0, int wh, int r, int half, unsigned (&out)[sizeof(Pixel) == 2 ? 4 : 2])
+// The plane record of a lane's reference picture (the four blocks of a quad may predict from different pictures): a vector load per lane.
+struct Mc4qRef { unsigned long w0, w1, w2; };                    // data | stride, width | height, -
+__device__ __forceinline__ Mc4qRef mc4q_ref(const ohevc_plane *refs, int ref, int plane)
 {
     typedef const MC4_GLOBAL unsigned long *lptr;
     lptr pr = (lptr)(refs + (3 * ref + plane));
-    const unsigned long rec0 = pr[0], rec1 = pr[1], rec2 = pr[2];                // data | stride, width | height
-    mc4_gptr base = (mc4_gptr)rec0;
-    const unsigned stride = (unsigned)rec1;
-    const int xmax = (int)(rec1 >> 32) - 1, ymax = (int)(unsigned)rec2 - 1;
+    return Mc4qRef{ pr[0], pr[1], pr[2] };
+}
+// 8 samples of window row r of the lane's block, columns 8 * half ..
+template <typename Pixel>
+__device__ __forceinline__ void mc4q_issue(const Mc4qRef &rec, int wx0, int wy0, int wh, int r, int half, unsigned (&out)[sizeof(Pixel) == 2 ? 4 : 2])
+{
+    mc4_gptr base = (mc4_gptr)rec.w0;
+    const unsigned stride = (unsigned)rec.w1;
+    const int xmax = (int)(rec.w1 >> 32) - 1, ymax = (int)(unsigned)rec.w2 - 1;
     const int col0 = wx0 + 8 * half;
     int wr = r < wh ? r : wh - 1;
     int y = wy0 + wr;
@@ -102,8 +107,9 @@ __device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixe
     for (int k = 0; k < 4; k++) v[k] = (own ? e[0][k] : e[1][k]) >> 6;
 }
 
-// 256 threads = 4 wavefronts (one LDS copy of the operand tables); a wavefront takes ONE quad: jobs 4q .. 4q + 3.
-template <typename Pixel>
+// 256 threads = 4 wavefronts (one LDS copy of the operand tables); a wavefront takes UNITS quads (quad u of the wavefront: jobs 4q .. 4q + 3,
+// q = first + u) and has the loads of all of them in flight before it computes the first (mc4_kernel).
+template <typename Pixel, int UNITS>
 __global__ __launch_bounds__(256) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth,
                                                    unsigned *__restrict__ wild_mask)
 {
@@ -117,111 +123,128 @@ __global__ __launch_bounds__(256) void mc4q_kernel(PlaneSet dst, const ohevc_pla
         dl[tid] = t0; dl[256 + tid] = t1; dl[512 + tid] = t2;
     }
     const int per_xcd = gridDim.x >> 3;                                                          // an XCD takes a contiguous eighth of the list (mc4_kernel)
-    const int q = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave;
+    const int q0 = ((((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave) * UNITS;
     typedef const MC4_CONST u32x4 *cptr;
-    Mc4qJob jb[4];
-    bool valid[4];
+    Mc4qJob jb[UNITS][4];
+    bool any[UNITS], any_bi[UNITS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int j = 4 * q + i;
-        valid[i] = j < njobs;
-        cptr jp = (cptr)(jobs + (valid[i] ? j : njobs - 1));
-        const u32x4 w0 = jp[0], w1 = jp[1];
-        const unsigned words[8] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w };
-        ohevc_mc_job rec;
-        __builtin_memcpy(&rec, words, sizeof(rec));
-        jb[i] = mc4q_unpack(rec);
+    for (int u = 0; u < UNITS; u++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = 4 * (q0 + u) + i;
+            cptr jp = (cptr)(jobs + (j < njobs ? j : njobs - 1));
+            const u32x4 w0 = jp[0], w1 = jp[1];
+            const unsigned words[8] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w };
+            ohevc_mc_job rec;
+            __builtin_memcpy(&rec, words, sizeof(rec));
+            jb[u][i] = mc4q_unpack(rec);
+        }
+        any[u] = 4 * (q0 + u) < njobs;
+        any_bi[u] = ((jb[u][0].flags | jb[u][1].flags | jb[u][2].flags | jb[u][3].flags) & OHEVC_MC_BI) != 0;      // wave-uniform
     }
-    const bool any = 4 * q < njobs;
-    const bool any_bi = ((jb[0].flags | jb[1].flags | jb[2].flags | jb[3].flags) & OHEVC_MC_BI) != 0;      // wave-uniform
     // ---- memory side: lane (r = lane >> 2, g = lane & 3) loads 8 samples of window row r, columns 8 (g & 1) .., of block g >> 1 of each pair
-    unsigned raw[2][2][WIDE ? 4 : 2] = {};
-    if (any) {
+    // (three dependent rounds - job records, plane records, samples - each issued for every quad, pair and reference before the first use)
+    unsigned raw[UNITS][2][2][WIDE ? 4 : 2] = {};
+    {
         const int r = lane >> 2, half = lane & 1;
         const bool first = (lane & 3) < 2;
+        Mc4qJob m[UNITS][2];
+        Mc4qRef rec[UNITS][2][2];
 #pragma unroll
-        for (int pair = 0; pair < 2; pair++) {
-            const Mc4qJob m = mc4q_pick(first, jb[2 * pair], jb[2 * pair + 1]);
-            const int before = m.plane == 0 ? 3 : 1, taps = m.plane == 0 ? 8 : 4;
-            mc4q_issue<Pixel>(refs, m.ref0, m.plane, m.sx0 - before, m.sy0 - before, m.h + taps - 1, r, half, raw[0][pair]);
-            if (any_bi) {
-                const bool bi = (m.flags & OHEVC_MC_BI) != 0;
-                mc4q_issue<Pixel>(refs, bi ? m.ref1 : m.ref0, m.plane, (bi ? m.sx1 : m.sx0) - before, (bi ? m.sy1 : m.sy0) - before, m.h + taps - 1, r, half, raw[1][pair]);
+        for (int u = 0; u < UNITS; u++)
+#pragma unroll
+            for (int pair = 0; pair < 2; pair++) {
+                m[u][pair] = mc4q_pick(first, jb[u][2 * pair], jb[u][2 * pair + 1]);
+                const bool bi = (m[u][pair].flags & OHEVC_MC_BI) != 0;
+                if (!bi) { m[u][pair].ref1 = m[u][pair].ref0; m[u][pair].sx1 = m[u][pair].sx0; m[u][pair].sy1 = m[u][pair].sy0; }       // (loaded again, weighted 0)
+                if (any[u]) rec[u][0][pair] = mc4q_ref(refs, m[u][pair].ref0, m[u][pair].plane);
+                if (any[u] && any_bi[u]) rec[u][1][pair] = mc4q_ref(refs, m[u][pair].ref1, m[u][pair].plane);
             }
-        }
+#pragma unroll
+        for (int u = 0; u < UNITS; u++)
+#pragma unroll
+            for (int pair = 0; pair < 2; pair++) {
+                const int before = m[u][pair].plane == 0 ? 3 : 1, taps = m[u][pair].plane == 0 ? 8 : 4;
+                if (any[u]) mc4q_issue<Pixel>(rec[u][0][pair], m[u][pair].sx0 - before, m[u][pair].sy0 - before, m[u][pair].h + taps - 1, r, half, raw[u][0][pair]);
+                if (any[u] && any_bi[u])
+                    mc4q_issue<Pixel>(rec[u][1][pair], m[u][pair].sx1 - before, m[u][pair].sy1 - before, m[u][pair].h + taps - 1, r, half, raw[u][1][pair]);
+            }
     }
     __syncthreads();                                                                             // the tables are in LDS
-    if (!any) return;
     // ---- operand side: lane (n = lane & 15, g = lane >> 4)
-    const int n = lane & 15, g = lane >> 4;
+    const int n = lane & 15, g = lane >> 4, maxv = (1 << bit_depth) - 1;
     const bool lowcol = n < 8, lowgrp = g < 2;
-    u32x2 b1[2][2];
-    unsigned b2[2][2];
 #pragma unroll
-    for (int pair = 0; pair < 2; pair++) {
-        // pass 1: column n belongs to block (n < 8 ? first : second) of the pair, its taps sit on that block's slot groups only
-        const Mc4qJob c1 = mc4q_pick(lowcol, jb[2 * pair], jb[2 * pair + 1]);
-        const int ph1 = c1.plane == 0 ? 0 : 4, tl = (g & 1) * 16 + (n & 7);
-        const bool mine = lowcol == lowgrp;
-        const u32x2 t0 = tabs[0][ph1 + c1.mx0][tl], t1 = tabs[0][ph1 + c1.mx1][tl];
-        b1[0][pair] = mine ? t0 : u32x2{ 0u, 0u };
-        b1[1][pair] = mine ? t1 : u32x2{ 0u, 0u };
-        // pass 2: column y < 8 carries the vertical taps of a (pair 0) / d (pair 1), y >= 8 those of b / c; rows 4g .. 4g + 3 of the 15-row window
-        const Mc4qJob c2 = mc4q_pick(lowcol == (pair == 0), jb[2 * pair], jb[2 * pair + 1]);
-        const int ph2 = c2.plane == 0 ? 0 : 4, tl2 = g * 16 + (n & 7);
-        b2[0][pair] = tabs[1][ph2 + c2.my0][tl2].x;
-        b2[1][pair] = tabs[1][ph2 + c2.my1][tl2].x;
-    }
-    unsigned seen0[2] = { 0, 0 }, seen1[2] = { 0, 0 };
-    int v0[4], v1[4] = { 0, 0, 0, 0 };
-    mc4q_finish<Pixel>(raw[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
-    if (any_bi) mc4q_finish<Pixel>(raw[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
-    // ---- result side: lane (y = lane & 15, g): four samples x = 4 (g & 1) .. + 3 of row y & 7 of block  a: y < 8, g < 2   d: y < 8, g >= 2   c: y >= 8, g < 2   b: y >= 8, g >= 2
-    const int blk = lowcol ? (lowgrp ? 0 : 3) : (lowgrp ? 2 : 1);
-    const Mc4qJob m = mc4q_pick(lowcol, mc4q_pick(lowgrp, jb[0], jb[3]), mc4q_pick(lowgrp, jb[2], jb[1]));
-    bool skip = !(lowcol ? (lowgrp ? valid[0] : valid[3]) : (lowgrp ? valid[2] : valid[1]));
-    const int maxv = (1 << bit_depth) - 1;
-    if (WIDE) {
-        // samples above the bit depth's range: mc3_redo_kernel computes the block (mc4_kernel).  `seen` lives on the operand side: rows of the
-        // pair's first block in slot groups 0, 1, of its second block in groups 2, 3
-        const unsigned wild_bits = 0x10001u * (unsigned)(0xffff & ~maxv);
-        const bool s0 = ((seen0[0] | seen1[0]) & wild_bits) != 0, s1 = ((seen0[1] | seen1[1]) & wild_bits) != 0;
-        const bool wa = __ballot(s0 && lowgrp) != 0, wb = __ballot(s0 && !lowgrp) != 0, wc = __ballot(s1 && lowgrp) != 0, wd = __ballot(s1 && !lowgrp) != 0;
-        if (lane < 4) {
-            const bool wl = lane == 0 ? wa : lane == 1 ? wb : lane == 2 ? wc : wd;
-            if (wl && 4 * q + lane < njobs) atomicOr(&wild_mask[4 * q + lane], 1u);
+    for (int u = 0; u < UNITS; u++) {
+        if (!any[u]) continue;
+        const int q = q0 + u;
+        u32x2 b1[2][2];
+        unsigned b2[2][2];
+#pragma unroll
+        for (int pair = 0; pair < 2; pair++) {
+            // pass 1: column n belongs to block (n < 8 ? first : second) of the pair, its taps sit on that block's slot groups only
+            const Mc4qJob c1 = mc4q_pick(lowcol, jb[u][2 * pair], jb[u][2 * pair + 1]);
+            const int ph1 = c1.plane == 0 ? 0 : 4, tl = (g & 1) * 16 + (n & 7);
+            const bool mine = lowcol == lowgrp;
+            const u32x2 t0 = tabs[0][ph1 + c1.mx0][tl], t1 = tabs[0][ph1 + c1.mx1][tl];
+            b1[0][pair] = mine ? t0 : u32x2{ 0u, 0u };
+            b1[1][pair] = mine ? t1 : u32x2{ 0u, 0u };
+            // pass 2: column y < 8 carries the vertical taps of a (pair 0) / d (pair 1), y >= 8 those of b / c; rows 4g .. 4g + 3 of the 15-row window
+            const Mc4qJob c2 = mc4q_pick(lowcol == (pair == 0), jb[u][2 * pair], jb[u][2 * pair + 1]);
+            const int ph2 = c2.plane == 0 ? 0 : 4, tl2 = g * 16 + (n & 7);
+            b2[0][pair] = tabs[1][ph2 + c2.my0][tl2].x;
+            b2[1][pair] = tabs[1][ph2 + c2.my1][tl2].x;
         }
-        skip = skip || (blk == 0 ? wa : blk == 1 ? wb : blk == 2 ? wc : wd);
-    }
-    const bool bi = (m.flags & OHEVC_MC_BI) != 0, weighted = (m.flags & OHEVC_MC_WEIGHTED) != 0;
-    int w0, w1, off, sh, add;
-    if (!weighted) {
-        sh = (bi ? 15 : 14) - bit_depth; w0 = 1; w1 = bi ? 1 : 0; off = mc_round(sh, bit_depth); add = 0;
-    } else if (!bi) {
-        sh = m.denom + 14 - bit_depth; w0 = m.wx0; w1 = 0; off = mc_round(sh, bit_depth); add = m.ox0 * (1 << (bit_depth - 8));
-    } else {
-        const int log2wd = m.denom + 14 - bit_depth;
-        sh = log2wd + 1; w0 = m.wx0; w1 = m.wx1; off = (m.ox0 * (1 << (bit_depth - 8)) + m.ox1 * (1 << (bit_depth - 8)) + 1) << log2wd; add = 0;
-    }
-    unsigned o[4];
+        unsigned seen0[2] = { 0, 0 }, seen1[2] = { 0, 0 };
+        int v0[4], v1[4] = { 0, 0, 0, 0 };
+        mc4q_finish<Pixel>(raw[u][0], b1[0], b2[0], bit_depth, lane, seen0, v0);
+        if (any_bi[u]) mc4q_finish<Pixel>(raw[u][1], b1[1], b2[1], bit_depth, lane, seen1, v1);
+        // ---- result side: lane (y = lane & 15, g): four samples x = 4 (g & 1) .. + 3 of row y & 7 of block  a: y < 8, g < 2   d: y < 8, g >= 2   c: y >= 8, g < 2   b: y >= 8, g >= 2
+        const int blk = lowcol ? (lowgrp ? 0 : 3) : (lowgrp ? 2 : 1);
+        const Mc4qJob m = mc4q_pick(lowcol, mc4q_pick(lowgrp, jb[u][0], jb[u][3]), mc4q_pick(lowgrp, jb[u][2], jb[u][1]));
+        bool skip = 4 * q + blk >= njobs;
+        if (WIDE) {
+            // samples above the bit depth's range: mc3_redo_kernel computes the block (mc4_kernel).  `seen` lives on the operand side: rows of the
+            // pair's first block in slot groups 0, 1, of its second block in groups 2, 3
+            const unsigned wild_bits = 0x10001u * (unsigned)(0xffff & ~maxv);
+            const bool s0 = ((seen0[0] | seen1[0]) & wild_bits) != 0, s1 = ((seen0[1] | seen1[1]) & wild_bits) != 0;
+            const bool wa = __ballot(s0 && lowgrp) != 0, wb = __ballot(s0 && !lowgrp) != 0, wc = __ballot(s1 && lowgrp) != 0, wd = __ballot(s1 && !lowgrp) != 0;
+            if (lane < 4) {
+                const bool wl = lane == 0 ? wa : lane == 1 ? wb : lane == 2 ? wc : wd;
+                if (wl && 4 * q + lane < njobs) atomicOr(&wild_mask[4 * q + lane], 1u);
+            }
+            skip = skip || (blk == 0 ? wa : blk == 1 ? wb : blk == 2 ? wc : wd);
+        }
+        const bool bi = (m.flags & OHEVC_MC_BI) != 0, weighted = (m.flags & OHEVC_MC_WEIGHTED) != 0;
+        int w0, w1, off, sh, add;
+        if (!weighted) {
+            sh = (bi ? 15 : 14) - bit_depth; w0 = 1; w1 = bi ? 1 : 0; off = mc_round(sh, bit_depth); add = 0;
+        } else if (!bi) {
+            sh = m.denom + 14 - bit_depth; w0 = m.wx0; w1 = 0; off = mc_round(sh, bit_depth); add = m.ox0 * (1 << (bit_depth - 8));
+        } else {
+            const int log2wd = m.denom + 14 - bit_depth;
+            sh = log2wd + 1; w0 = m.wx0; w1 = m.wx1; off = (m.ox0 * (1 << (bit_depth - 8)) + m.ox1 * (1 << (bit_depth - 8)) + 1) << log2wd; add = 0;
+        }
+        unsigned o[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int t = __mul24(v1[k], w1) + (__mul24(v0[k], w0) + off);
-        const int out = (t >> sh) + add;
-        o[k] = (unsigned)(out < 0 ? 0 : out > maxv ? maxv : out);
-    }
-    const int sy = n & 7, sx = 4 * (g & 1);
-    if (skip || sy >= m.h || sx >= m.w) return;
-    unsigned pk[WIDE ? 2 : 1];
-    if (WIDE) { pk[0] = o[0] | (o[1] << 16); pk[WIDE ? 1 : 0] = o[2] | (o[3] << 16); }
-    else      pk[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-    const unsigned char *const pbase = m.plane == 0 ? PLANE_PTR3(dst, 0) : m.plane == 1 ? PLANE_PTR3(dst, 1) : PLANE_PTR3(dst, 2);
-    const int pstride = m.plane == 0 ? PLANE_STRIDE3(dst, 0) : m.plane == 1 ? PLANE_STRIDE3(dst, 1) : PLANE_STRIDE3(dst, 2);
-    MC4_GLOBAL unsigned char *p = (MC4_GLOBAL unsigned char *)pbase + (__umul24((unsigned)(m.y + sy), (unsigned)pstride) + (unsigned)(m.x + sx) * (unsigned)sizeof(Pixel));
-    if (m.w - sx >= 4) {
-        __builtin_memcpy((void *)p, pk, sizeof(pk));
-    } else {                                                      // widths 2 and 6 (chroma of 4- and 12-wide blocks)
-        for (int k = 0; k < m.w - sx; k++)
-            reinterpret_cast<MC4_GLOBAL Pixel *>(p)[k] = (Pixel)(WIDE ? pk[WIDE ? k >> 1 : 0] >> (16 * (k & 1)) : pk[0] >> (8 * k));
+        for (int k = 0; k < 4; k++) {
+            const int t = __mul24(v1[k], w1) + (__mul24(v0[k], w0) + off);
+            const int out = (t >> sh) + add;
+            o[k] = (unsigned)(out < 0 ? 0 : out > maxv ? maxv : out);
+        }
+        const int sy = n & 7, sx = 4 * (g & 1);
+        if (skip || sy >= m.h || sx >= m.w) continue;
+        unsigned pk[WIDE ? 2 : 1];
+        if (WIDE) { pk[0] = o[0] | (o[1] << 16); pk[WIDE ? 1 : 0] = o[2] | (o[3] << 16); }
+        else      pk[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+        const unsigned char *const pbase = m.plane == 0 ? PLANE_PTR3(dst, 0) : m.plane == 1 ? PLANE_PTR3(dst, 1) : PLANE_PTR3(dst, 2);
+        const int pstride = m.plane == 0 ? PLANE_STRIDE3(dst, 0) : m.plane == 1 ? PLANE_STRIDE3(dst, 1) : PLANE_STRIDE3(dst, 2);
+        MC4_GLOBAL unsigned char *p = (MC4_GLOBAL unsigned char *)pbase + (__umul24((unsigned)(m.y + sy), (unsigned)pstride) + (unsigned)(m.x + sx) * (unsigned)sizeof(Pixel));
+        if (m.w - sx >= 4) {
+            __builtin_memcpy((void *)p, pk, sizeof(pk));
+        } else {                                                      // widths 2 and 6 (chroma of 4- and 12-wide blocks)
+            for (int k = 0; k < m.w - sx; k++)
+                reinterpret_cast<MC4_GLOBAL Pixel *>(p)[k] = (Pixel)(WIDE ? pk[WIDE ? k >> 1 : 0] >> (16 * (k & 1)) : pk[0] >> (8 * k));
+        }
     }
 }
