@@ -109,8 +109,13 @@ __device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixe
 
 // 256 threads = 4 wavefronts (one LDS copy of the operand tables); a wavefront takes UNITS quads (quad u of the wavefront: jobs 4q .. 4q + 3,
 // q = first + u) and has the loads of all of them in flight before it computes the first (mc4_kernel).
+#ifdef OHEVC_HIPEMU
+#define MC4Q_OCCUPANCY(units)
+#else
+#define MC4Q_OCCUPANCY(units) __attribute__((amdgpu_waves_per_eu((units) == 1 ? 8 : 4, 8)))     // one quad per wavefront: 8 wavefronts per SIMD (<= 64 VGPRs)
+#endif
 template <typename Pixel, int UNITS>
-__global__ __launch_bounds__(256) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth,
+__global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth,
                                                    unsigned *__restrict__ wild_mask)
 {
     constexpr bool WIDE = sizeof(Pixel) == 2;
