@@ -90,12 +90,12 @@ struct DevBuf {                       // grow-only device buffer
 struct PinnedBuf {                    // grow-only pinned host staging buffer
     unsigned char *p = nullptr;
     size_t cap = 0;
-    int reserve(size_t n)
+    int reserve(size_t n, size_t at_least = (size_t)1 << 20)
     {
         if (n <= cap) return OHEVC_OK;
         if (p) OHEVC_HIP_TRY(hipHostFree(p));
         p = nullptr; cap = 0;
-        size_t want = std::max(n, (size_t)1 << 20);
+        size_t want = std::max(n, at_least);
         want = (want + (want >> 1) + 255) & ~(size_t)255;
         OHEVC_HIP_TRY(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
         cap = want;
@@ -238,7 +238,7 @@ struct ohevc_ctx : Rec {
     hipEvent_t dl_ring[8] = {};
     int dl_next = 0;
     DevBuf d_jobs, d_coeffs, d_table, d_upsample;
-    PinnedBuf stage;
+    PinnedBuf stage, table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
     int n_frames = 0, n_map_frames = 0;
@@ -365,6 +365,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->d_bs.p) (void)hipFree(c->d_bs.p);
     if (c->d_grid.p) (void)hipFree(c->d_grid.p);
     if (c->stage.p) (void)hipHostFree(c->stage.p);
+    if (c->table_stage.p) (void)hipHostFree(c->table_stage.p);
     if (c->staged) (void)hipEventDestroy(c->staged);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
     if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
@@ -1361,7 +1362,12 @@ static int upload_table(ohevc_ctx *c)
     }
     int rc = c->d_table.reserve(t.size() * sizeof(ohevc_plane));
     if (rc != OHEVC_OK) return rc;
-    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_table.p, t.data(), t.size() * sizeof(ohevc_plane), hipMemcpyHostToDevice, c->stream));
+    // through page-locked memory of our own: a pageable source makes the runtime look the address up among the registered host ranges
+    // (ohevc_host_pin: the decoder's frame buffers, registered and recycled by other decoding threads at this very moment) - seen once as
+    // "invalid argument" out of this copy on a frame-threaded stream (profiles/r03end_pytest_gpu_flake.log)
+    if ((rc = c->table_stage.reserve(t.size() * sizeof(ohevc_plane), 16384)) != OHEVC_OK) return rc;
+    memcpy(c->table_stage.p, t.data(), t.size() * sizeof(ohevc_plane));      // (the previous copy out of it was waited for below)
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_table.p, c->table_stage.p, t.size() * sizeof(ohevc_plane), hipMemcpyHostToDevice, c->stream));
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     return OHEVC_OK;
 }
