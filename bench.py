@@ -120,7 +120,7 @@ def cpu_baseline(log2, bd, leg_seconds=6.0):
 PCIE_PEAK_GBS = 64.0            # PCIe 5.0 x16, one direction: the floor of what crosses the bus per picture
 
 
-def decode_leg(pictures=33, threads=16, size=(1920, 1080)):
+def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4):
     """BASELINE config 3 (1080p Main 8-bit random-access stream, the full CTU pipeline on one GPU) as a driver-timed number: the reference's
     own front end (CABAC, syntax, motion data: host cores) linked against libohevc_hip.so (oracle/_ref/libopenhevc_hip.so: the reference's
     sources + integration/hip_hooks.c), against the same decoder with its own C tables.  No HEVC bitstream exists in this environment: the
@@ -149,7 +149,9 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080)):
             with ps.Decoder(kind, th, 1) as d:
                 t = time.perf_counter()
                 n = 0
-                for i, au in enumerate(aus):
+                # the stream `passes` times through ONE decoder instance (it starts with an IDR picture): a decoder opened for 33 pictures on
+                # 16 threads spends most of its 30 ms creating contexts, streams and buffers - every thread sees two pictures
+                for i, au in enumerate(aus * passes):
                     r = d.L.ohdec_decode(d.h, au, len(au), i + 1)
                     if r < 0:
                         raise RuntimeError(f"decode error {r}")
@@ -163,7 +165,7 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080)):
             best = dt if best is None else min(best, dt)
         return best, n
 
-    out = {"workload": f"{W}x{H} 8-bit 4:2:0 random-access GOP, {pictures} pictures, synthetic Annex-B streams (oracle/pystream.py, seed 7); wall clock incl. "
+    out = {"workload": f"{W}x{H} 8-bit 4:2:0 random-access GOP, {pictures} pictures x {passes} passes through one decoder instance, synthetic Annex-B streams (oracle/pystream.py, seed 7); wall clock incl. "
                        f"entropy decoding on the host and the copy-back of every picture; host has {cores} logical cores",
            "streams": {}}
     for name, extra in profiles:
@@ -191,7 +193,9 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080)):
                 hipL.ohdec_backend_profile(C.byref(sec), cnt)          # reset the cumulative counters
                 hipL.ohdec_backend_alg_bytes()
             dt, npic = timed(kind, aus, th)
-            r = {"fps": round(pictures / dt, 1), "mpixel_per_s": round(mp / dt, 1)}
+            if npic != pictures * passes:
+                raise RuntimeError(f"{label}: {npic} pictures out of {pictures * passes}")
+            r = {"fps": round(pictures * passes / dt, 1), "mpixel_per_s": round(mp * passes / dt, 1)}
             if kind == "hip":
                 hipL.ohdec_backend_profile(C.byref(sec), cnt)
                 alg = hipL.ohdec_backend_alg_bytes()
