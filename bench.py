@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default 2^20 for 32x32, 2^22 for 16x16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-hip-only", action="store_true", help="decode block: only the HIP rows (A/B runs of the back end's switches)")
     ap.add_argument("--no-decode", action="store_true", help="skip the whole-decoder leg (BASELINE config 3 geometry) that N=1 runs add to the line")
     ap.add_argument("--no-zscan", action="store_true", help="skip the second timed loop over the CTB-major (z-scan) job list")
     ap.add_argument("--check-blocks", type=int, default=512, help="output blocks verified bit-exactly against the oracle after the timed loops")
@@ -120,7 +121,7 @@ def cpu_baseline(log2, bd, leg_seconds=6.0):
 PCIE_PEAK_GBS = 64.0            # PCIe 5.0 x16, one direction: the floor of what crosses the bus per picture
 
 
-def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4):
+def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=False):
     """BASELINE config 3 (1080p Main 8-bit random-access stream, the full CTU pipeline on one GPU) as a driver-timed number: the reference's
     own front end (CABAC, syntax, motion data: host cores) linked against libohevc_hip.so (oracle/_ref/libopenhevc_hip.so: the reference's
     sources + integration/hip_hooks.c), against the same decoder with its own C tables.  No HEVC bitstream exists in this environment: the
@@ -185,7 +186,7 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4):
                                 ("front_end_only_1thread", "null", 1), (f"front_end_only_{threads}frame_threads", "null", threads),
                                 # ... and with the reference's own waits between frame threads kept (rows reported as they are parsed)
                                 (f"front_end_only_{threads}frame_threads_reference_waits", "null", threads)):
-            if not ps.have(kind):
+            if not ps.have(kind) or (hip_only and kind != "hip"):
                 continue
             if kind == "null":
                 ps._load("null").ohnull_set_await(1 if label.endswith("reference_waits") else 0)
@@ -517,7 +518,7 @@ def main():
             del plane_ring, plane_sets, coeffs
             torch.cuda.empty_cache()
             try:
-                out["decode"] = decode_leg()
+                out["decode"] = decode_leg(hip_only=args.decode_hip_only)
             except Exception as e:
                 out["decode"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
