@@ -129,6 +129,9 @@ static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_I
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 8;   // widest level a chain takes
 static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 0; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
+// OHEVC_UPLOAD_LANES=2: the filter maps of a frame end travel through a staging / device buffer pair of their own, so their staging copy does
+// not wait on the host for the job arrays' H2D copy (which sits in the stream behind the reference pictures' completion).  1 (default): one pair.
+static int g_upload_lanes = getenv("OHEVC_UPLOAD_LANES") ? atoi(getenv("OHEVC_UPLOAD_LANES")) : 1;
 static int g_intra_pack = getenv("OHEVC_INTRA_PACK") ? atoi(getenv("OHEVC_INTRA_PACK")) : 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
 static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
 static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
@@ -186,8 +189,12 @@ struct ohevc_ctx : Rec {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t staged = nullptr;      // recorded after the last H2D copy out of `stage`
-    bool staged_pending = false;
+    // Two upload lanes - host staging buffer, device buffer, "copied" event - one for the job arrays of ohevc_frame_reconstruct, one for the
+    // filter maps of the frame end.  With one lane the second staging copy of a picture had to wait on the host until the first H2D copy
+    // had run, and that copy sits in the stream BEHIND the waits for the reference pictures' completion: under frame threads every
+    // decoding thread stood still in the middle of its frame end until its references were reconstructed on the device.
+    hipEvent_t staged[2] = {nullptr, nullptr};      // recorded after the last H2D copy out of stage[k]
+    bool staged_pending[2] = {false, false};
     std::shared_ptr<PicStore> store;
     unsigned table_version = ~0u;     // store->version the device MC table was built from
     int cur = -1;
@@ -237,8 +244,8 @@ struct ohevc_ctx : Rec {
     ptrdiff_t async_stride[3] = {0, 0, 0};
     hipEvent_t dl_ring[8] = {};
     int dl_next = 0;
-    DevBuf d_jobs, d_coeffs, d_table, d_upsample;
-    PinnedBuf stage, table_stage;
+    DevBuf d_jobs[2], d_coeffs, d_table, d_upsample;
+    PinnedBuf stage[2], table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
     int n_frames = 0, n_map_frames = 0;
@@ -306,7 +313,8 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     c->device = device;
     c->store = share_with ? share_with->store : std::make_shared<PicStore>();
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&c->staged, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->staged[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->staged[1], hipEventDisableTiming) == hipSuccess;
     for (auto &e : c->ring) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         set_error("stream/event creation failed");
@@ -358,15 +366,15 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
     if (c->twin.used) free_picture(c->twin);
     if (c->lag.used) free_picture(c->lag);
-    if (c->d_jobs.p) (void)hipFree(c->d_jobs.p);
+    for (DevBuf &b : c->d_jobs) if (b.p) (void)hipFree(b.p);
     if (c->d_coeffs.p) (void)hipFree(c->d_coeffs.p);
     if (c->d_table.p) (void)hipFree(c->d_table.p);
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
     if (c->d_bs.p) (void)hipFree(c->d_bs.p);
     if (c->d_grid.p) (void)hipFree(c->d_grid.p);
-    if (c->stage.p) (void)hipHostFree(c->stage.p);
+    for (PinnedBuf &b : c->stage) if (b.p) (void)hipHostFree(b.p);
     if (c->table_stage.p) (void)hipHostFree(c->table_stage.p);
-    if (c->staged) (void)hipEventDestroy(c->staged);
+    for (hipEvent_t e : c->staged) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
     if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
@@ -402,7 +410,7 @@ extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
         OHEVC_HIP_TRY(hipDeviceSynchronize());
     }
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-    c->staged_pending = false;
+    c->staged_pending[0] = c->staged_pending[1] = false;
     return OHEVC_OK;
 }
 
@@ -1340,11 +1348,11 @@ static size_t stage_put(std::vector<std::pair<const void *, size_t>> &parts, siz
     return off;
 }
 
-static int wait_staging_free(ohevc_ctx *c)
+static int wait_staging_free(ohevc_ctx *c, int lane)
 {
-    if (c->staged_pending) {
-        OHEVC_HIP_TRY(hipEventSynchronize(c->staged));
-        c->staged_pending = false;
+    if (c->staged_pending[lane]) {
+        OHEVC_HIP_TRY(hipEventSynchronize(c->staged[lane]));
+        c->staged_pending[lane] = false;
     }
     return OHEVC_OK;
 }
@@ -1414,24 +1422,24 @@ static int guard_pictures(ohevc_ctx *c, int target)
 }
 
 // upload a set of job arrays in one H2D copy; fills offs[i] with the device offset of parts[i]
-static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>> &parts, size_t total)
+static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>> &parts, size_t total, int lane)
 {
     if (total == 0) return OHEVC_OK;
-    int rc = wait_staging_free(c);
+    int rc = wait_staging_free(c, lane);
     if (rc != OHEVC_OK) return rc;
-    if ((rc = c->stage.reserve(total)) != OHEVC_OK) return rc;
-    if (total > c->d_jobs.cap) {
+    if ((rc = c->stage[lane].reserve(total)) != OHEVC_OK) return rc;
+    if (total > c->d_jobs[lane].cap) {
         OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));     // in-flight kernels may still read the old buffer
-        if ((rc = c->d_jobs.reserve(total)) != OHEVC_OK) return rc;
+        if ((rc = c->d_jobs[lane].reserve(total)) != OHEVC_OK) return rc;
     }
     size_t off = 0;
     for (auto &pr : parts) {
-        memcpy(c->stage.p + off, pr.first, pr.second);
+        memcpy(c->stage[lane].p + off, pr.first, pr.second);
         off += (pr.second + 255) & ~(size_t)255;
     }
-    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs.p, c->stage.p, total, hipMemcpyHostToDevice, c->stream));
-    OHEVC_HIP_TRY(hipEventRecord(c->staged, c->stream));
-    c->staged_pending = true;
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs[lane].p, c->stage[lane].p, total, hipMemcpyHostToDevice, c->stream));
+    OHEVC_HIP_TRY(hipEventRecord(c->staged[lane], c->stream));
+    c->staged_pending[lane] = true;
     c->stats.upload_bytes += (int64_t)total;
     return OHEVC_OK;
 }
@@ -1715,8 +1723,8 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_ci = ctbs && !c->ctb_intra.empty() ? stage_put(parts, total, c->ctb_intra.data(), c->ctb_intra.size() * sizeof(ohevc_intra_job)) : 0;
     const size_t off_cu = ctbs && !c->ctb_tu.empty() ? stage_put(parts, total, c->ctb_tu.data(), c->ctb_tu.size() * sizeof(ohevc_tu_job)) : 0;
     const size_t off_cs = ctbs ? stage_put(parts, total, c->ctb_sync_zero.data(), c->ctb_sync_zero.size() * sizeof(uint32_t)) : 0;
-    if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
-    unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
+    if ((rc = upload_jobs(c, parts, total, 0)) != OHEVC_OK) return rc;
+    unsigned char *base = static_cast<unsigned char *>(c->d_jobs[0].p);
     const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
 
     // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
@@ -1908,8 +1916,9 @@ static int frame_end_impl(ohevc_ctx *c)
                                          return ohevc_sao_job_is_wide(&j, p->planes, p->planes, p->bd) != 0; }) - c->sao.begin());
         const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
         const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
-        if ((rc = upload_jobs(c, parts, total)) != OHEVC_OK) return rc;
-        unsigned char *base = static_cast<unsigned char *>(c->d_jobs.p);
+        const int lane = g_upload_lanes == 2 ? 1 : 0;
+        if ((rc = upload_jobs(c, parts, total, lane)) != OHEVC_OK) return rc;
+        unsigned char *base = static_cast<unsigned char *>(c->d_jobs[lane].p);
         ohevc_dbk_maps dm = c->dbk_maps;                  // offsets -> device addresses
         if (!c->dbk_blob.empty()) {
             dm.vertical_bs = base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.vertical_bs);
