@@ -17,6 +17,9 @@ import numpy as np                      # noqa: E402
 from oracle import pystream as ps       # noqa: E402
 
 
+PASSES = 1
+
+
 def timed_decode(kind, aus, threads=1, thread_type=1, repeat=2, pipelined=False):
     best = None
     frames = None
@@ -24,7 +27,7 @@ def timed_decode(kind, aus, threads=1, thread_type=1, repeat=2, pipelined=False)
         with ps.Decoder(kind, threads, thread_type, pipelined=pipelined) as d:
             t = time.perf_counter()
             n = 0
-            for i, au in enumerate(aus):
+            for i, au in enumerate(aus * PASSES):      # the stream PASSES times through one decoder instance (it starts with an IDR picture)
                 r = d.L.ohdec_decode(d.h, au, len(au), i + 1)
                 if r < 0:
                     raise RuntimeError(f"decode error {r}")
@@ -47,6 +50,8 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--qp22", action="store_true", help="qp22-like residual density (oracle.pystream.DENSE_QP22: 200-250 KB per 1080p picture)")
+    ap.add_argument("--passes", type=int, default=4, help="feed the stream this many times through one decoder instance: a 33-picture run on 16 "
+                    "threads mostly measures the creation of contexts, streams and buffers (DESIGN.md 5g)")
     ap.add_argument("--gop", default="random_access")
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--wpp", action="store_true", help="entropy_coding_sync stream; adds slice-thread (WPP row) and frame+slice runs")
@@ -54,6 +59,8 @@ def main():
     ap.add_argument("--natural", action="store_true",
                     help="syntax statistics closer to an encoder's random-access output: few intra CUs in inter pictures, many skipped / merged CUs")
     a = ap.parse_args()
+    global PASSES
+    PASSES = max(1, a.passes)
     w, h = map(int, a.size.split("x"))
     h8 = (h + 7) // 8 * 8
     kw = dict(gop=a.gop, nframes=a.frames, seed=7, width=w, height=h8, log2_ctb=6, bit_depth=a.bit_depth)
@@ -80,7 +87,7 @@ def main():
     ps._load("hip").ohdec_backend_profile(C0.byref(_sec), _cnt)        # reset the cumulative counters
     exact = len(ref) == len(hip) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip) for x, y in zip(fa, fb))
     res = dict(workload=f"synthetic {a.gop} stream {w}x{h8} {a.bit_depth}-bit, {a.frames} pictures, "
-                        f"{sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}{' (qp22-like residual density)' if a.qp22 else ''}{' (encoder-like CU statistics)' if a.natural else ''}",
+                        f"x {PASSES} passes through one decoder, {sum(map(len, aus)) // len(aus)} bytes/picture{' (dense residual)' if a.dense else ''}{' (qp22-like residual density)' if a.qp22 else ''}{' (encoder-like CU statistics)' if a.natural else ''}",
                bit_exact=bool(exact), bit_exact_frame_threads=bool(exact_mt), generate_s=round(tgen, 2))
     mp = w * h8 * a.frames / 1e6
     import ctypes as C
@@ -111,7 +118,7 @@ def main():
             del os.environ["OHHIP_DEFER_DOWNLOAD"]
         else:
             dt, n = timed_decode(kind, aus, th, tt)
-        res[name] = dict(seconds=round(dt, 4), fps=round(a.frames / dt, 2), mpixel_per_s=round(mp / dt, 1), pictures=n)
+        res[name] = dict(seconds=round(dt, 4), fps=round(a.frames * PASSES / dt, 2), mpixel_per_s=round(mp * PASSES / dt, 1), pictures=n)
         if kind == "hip":       # where the back-end's time goes (last repeat only is not separated: counters are cumulative)
             L = ps._load("hip")
             sec = C.c_double()
