@@ -209,6 +209,9 @@ int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohevc_bs_call 
  * covers keep what the grid held: zero it before the first call of a picture (pred_flag 0 = PF_INTRA).  jobs, grid: DEVICE pointers. */
 enum { OHEVC_MOTION_GRID_ENTRY = 20 };
 int ohevc_dev_motion_grid(const ohevc_mc_job *jobs, int njobs, uint8_t *grid, int grid_width, int grid_height, int log2_unit, void *stream);
+/* the same over two job arrays in one launch */
+int ohevc_dev_motion_grid2(const ohevc_mc_job *jobs, int njobs, const ohevc_mc_job *more, int nmore, uint8_t *grid, int grid_width, int grid_height,
+                           int log2_unit, void *stream);
 
 /* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
  * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy

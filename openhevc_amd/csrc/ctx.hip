@@ -128,7 +128,7 @@ static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 8;   // widest level a chain takes
-static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 0; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
+static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
 // OHEVC_UPLOAD_LANES=2: the filter maps of a frame end travel through a staging / device buffer pair of their own, so their staging copy does
 // not wait on the host for the job arrays' H2D copy (which sits in the stream behind the reference pictures' completion).  1 (default): one pair.
 static int g_upload_lanes = getenv("OHEVC_UPLOAD_LANES") ? atoi(getenv("OHEVC_UPLOAD_LANES")) : 1;
@@ -225,6 +225,7 @@ struct ohevc_ctx : Rec {
     DevBuf d_grid;                                         // ohevc_frame_keep_motion: the motion field rebuilt from the luma MC jobs
     int keep_motion_l2 = 0;                                // log2 of the grid's unit; 0: the frame keeps none
     bool grid_zeroed = false;                              // ... and it has been cleared for this frame
+    size_t grid_bs_off = 0, grid_bs_cap = 0;               // ... together with room behind it for the boundary-strength arrays
     std::vector<uint8_t> bypass;                           // ohevc_frame_set_bypass_map: is_pcm bytes, row length bypass_w (empty = none)
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
@@ -1322,14 +1323,17 @@ static int motion_grid_ready(ohevc_ctx *c, const Picture *p, int &gw, int &gh)
     const int u = 1 << c->keep_motion_l2;
     gw = (p->w + u - 1) >> c->keep_motion_l2; gh = (p->h + u - 1) >> c->keep_motion_l2;
     if (c->grid_zeroed) return OHEVC_OK;
-    const size_t bytes = (size_t)gw * gh * OHEVC_MOTION_GRID_ENTRY;
-    if (bytes > c->d_grid.cap) {
+    // behind the grid, room for the two boundary-strength arrays the frame end fills (they want zeros too, hevc.c:3207-3208): one memset for both
+    const size_t grid_bytes = ((size_t)gw * gh * OHEVC_MOTION_GRID_ENTRY + 255) & ~(size_t)255;
+    const size_t bs_bytes = 2 * ((((size_t)(p->w >> 2) + 8) * ((size_t)(p->h >> 2) + 8) + 255) & ~(size_t)255);
+    if (grid_bytes + bs_bytes > c->d_grid.cap) {
         OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-        int rc = c->d_grid.reserve(bytes);
+        int rc = c->d_grid.reserve(grid_bytes + bs_bytes);
         if (rc != OHEVC_OK) return rc;
     }
-    OHEVC_HIP_TRY(hipMemsetAsync(c->d_grid.p, 0, bytes, c->stream));
+    OHEVC_HIP_TRY(hipMemsetAsync(c->d_grid.p, 0, grid_bytes + bs_bytes, c->stream));
     c->grid_zeroed = true;
+    c->grid_bs_off = grid_bytes; c->grid_bs_cap = bs_bytes;
     return OHEVC_OK;
 }
 extern "C" int ohevc_ctx_has_device(const ohevc_ctx *c) { return c && !c->dry; }
@@ -1743,13 +1747,10 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if (c->keep_motion_l2 && (!c->mc.empty() || !c->mc_small.empty())) {      // what the boundary strengths will need of these jobs (ohevc_dev_motion_grid)
         int gw, gh;
         if ((rc = motion_grid_ready(c, p, gw, gh)) != OHEVC_OK) return rc;
-        for (const auto &v : {std::make_pair(off_mc, &c->mc), std::make_pair(off_mcs, &c->mc_small)}) {
-            if (v.second->empty()) continue;
-            rc = ohevc_dev_motion_grid(reinterpret_cast<const ohevc_mc_job *>(base + v.first), (int)v.second->size(), static_cast<uint8_t *>(c->d_grid.p), gw, gh,
-                                       c->keep_motion_l2, c->stream);
-            if (rc != OHEVC_OK) return rc;
-            c->stats.launches++;
-        }
+        rc = ohevc_dev_motion_grid2(reinterpret_cast<const ohevc_mc_job *>(base + off_mc), (int)c->mc.size(), reinterpret_cast<const ohevc_mc_job *>(base + off_mcs),
+                                    (int)c->mc_small.size(), static_cast<uint8_t *>(c->d_grid.p), gw, gh, c->keep_motion_l2, c->stream);
+        if (rc != OHEVC_OK) return rc;
+        c->stats.launches++;
     }
     // ---- phase 2..: level 0 = residuals of inter blocks; level L >= 1 = intra prediction of level L, then its residuals
     const int max_level = c->max_level;
@@ -1929,11 +1930,20 @@ static int frame_end_impl(ohevc_ctx *c)
         }
         if (dev_bs) {          // boundary strengths from the motion field, on the device (hevc_filter.c:805-941)
             const size_t bs_h = (size_t)(dm.height >> 2), n_v = ((size_t)dm.bs_width * (bs_h + 8) + 255) & ~(size_t)255, n_h = (((size_t)dm.bs_width + 8) * bs_h + 255) & ~(size_t)255;
-            if (n_v + n_h > c->d_bs.cap) {
-                OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-                if ((rc = c->d_bs.reserve(n_v + n_h)) != OHEVC_OK) return rc;
+            uint8_t *vbs = nullptr;
+            if (!c->bs_maps.mvf) {                            // the grid's clearing covered the room behind it (motion_grid_ready)
+                int gw0, gh0;
+                if ((rc = motion_grid_ready(c, p, gw0, gh0)) != OHEVC_OK) return rc;
+                if (n_v + n_h <= c->grid_bs_cap) vbs = static_cast<uint8_t *>(c->d_grid.p) + c->grid_bs_off;
             }
-            OHEVC_HIP_TRY(hipMemsetAsync(c->d_bs.p, 0, n_v + n_h, c->stream));
+            if (!vbs) {
+                if (n_v + n_h > c->d_bs.cap) {
+                    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+                    if ((rc = c->d_bs.reserve(n_v + n_h)) != OHEVC_OK) return rc;
+                }
+                OHEVC_HIP_TRY(hipMemsetAsync(c->d_bs.p, 0, n_v + n_h, c->stream));
+                vbs = static_cast<uint8_t *>(c->d_bs.p);
+            }
             ohevc_bs_maps bm = c->bs_maps;
             if (c->bs_maps.mvf) {
                 bm.mvf = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.mvf);
@@ -1946,7 +1956,7 @@ static int frame_end_impl(ohevc_ctx *c)
                 bm.mvf_stride = OHEVC_MOTION_GRID_ENTRY; bm.off_mv = 0; bm.off_poc = 8; bm.off_pred_flag = 16; bm.pred_flag_bytes = 4;
             }
             bm.cbf_luma = base + off_m + reinterpret_cast<uintptr_t>(c->bs_maps.cbf_luma);
-            uint8_t *vbs = static_cast<uint8_t *>(c->d_bs.p), *hbs = vbs + n_v;
+            uint8_t *hbs = vbs + n_v;
             if ((rc = ohevc_dev_boundary_strengths(&bm, reinterpret_cast<const ohevc_bs_call *>(base + off_bsc), (int)c->bs_calls.size(), vbs, hbs, c->stream)) != OHEVC_OK) return rc;
             if (!c->bs_calls.empty()) c->stats.launches++;
             dm.vertical_bs = vbs; dm.horizontal_bs = hbs;

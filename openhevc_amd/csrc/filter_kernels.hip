@@ -840,12 +840,12 @@ __global__ __launch_bounds__(256) void boundary_strength_kernel(ohevc_bs_maps m,
 
 // The motion field rebuilt from the luma motion-compensation jobs (ohevc_dev_motion_grid): one lane per (job, 4x4 unit of its at most
 // 16x16 tile).  A job's integer source position and phase ARE its motion vector: sx = x + (mv.x >> 2), mx = mv.x & 3 (luma_mc_uni, hevc.c:1693-1703).
-__global__ __launch_bounds__(256) void motion_grid_kernel(const ohevc_mc_job *__restrict__ jobs, int njobs, unsigned char *__restrict__ grid, int grid_w, int grid_h,
-                                                          int log2_unit)
+__global__ __launch_bounds__(256) void motion_grid_kernel(const ohevc_mc_job *__restrict__ jobs, int njobs, const ohevc_mc_job *__restrict__ more, int nmore,
+                                                          unsigned char *__restrict__ grid, int grid_w, int grid_h, int log2_unit)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, ji = t >> 4, ux = (t & 3) << 2, uy = ((t >> 2) & 3) << 2;
-    if (ji >= njobs) return;
-    const ohevc_mc_job j = jobs[ji];
+    if (ji >= njobs + nmore) return;
+    const ohevc_mc_job j = ji < njobs ? jobs[ji] : more[ji - njobs];      // (the ctx layer keeps its tiles in two arrays: one launch for both)
     const int um = (1 << log2_unit) - 1;
     if (j.plane != 0 || ux >= j.w || uy >= j.h || (((j.x + ux) | (j.y + uy)) & um)) return;
     const int gx = (j.x + ux) >> log2_unit, gy = (j.y + uy) >> log2_unit;
@@ -861,16 +861,21 @@ __global__ __launch_bounds__(256) void motion_grid_kernel(const ohevc_mc_job *__
 
 }  // namespace ohevc
 
-extern "C" int ohevc_dev_motion_grid(const ohevc_mc_job *jobs, int njobs, uint8_t *grid, int grid_width, int grid_height, int log2_unit, void *stream)
+extern "C" int ohevc_dev_motion_grid2(const ohevc_mc_job *jobs, int njobs, const ohevc_mc_job *more, int nmore, uint8_t *grid, int grid_width, int grid_height,
+                                      int log2_unit, void *stream)
 {
     using namespace ohevc;
-    OHEVC_REQUIRE(njobs >= 0 && grid_width > 0 && grid_height > 0 && log2_unit >= 2 && log2_unit <= 5, "grid geometry");
-    if (njobs == 0) return OHEVC_OK;
-    OHEVC_REQUIRE(jobs != nullptr && grid != nullptr && (reinterpret_cast<uintptr_t>(grid) & 3) == 0, "null / misaligned array");
-    hipLaunchKernelGGL(motion_grid_kernel, dim3((unsigned)(((long long)njobs * 16 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), jobs, njobs, grid,
-                       grid_width, grid_height, log2_unit);
+    OHEVC_REQUIRE(njobs >= 0 && nmore >= 0 && grid_width > 0 && grid_height > 0 && log2_unit >= 2 && log2_unit <= 5, "grid geometry");
+    if (njobs + nmore == 0) return OHEVC_OK;
+    OHEVC_REQUIRE((njobs == 0 || jobs != nullptr) && (nmore == 0 || more != nullptr) && grid != nullptr && (reinterpret_cast<uintptr_t>(grid) & 3) == 0, "null / misaligned array");
+    hipLaunchKernelGGL(motion_grid_kernel, dim3((unsigned)(((long long)(njobs + nmore) * 16 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), jobs, njobs, more, nmore,
+                       grid, grid_width, grid_height, log2_unit);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
+}
+extern "C" int ohevc_dev_motion_grid(const ohevc_mc_job *jobs, int njobs, uint8_t *grid, int grid_width, int grid_height, int log2_unit, void *stream)
+{
+    return ohevc_dev_motion_grid2(jobs, njobs, nullptr, 0, grid, grid_width, grid_height, log2_unit, stream);
 }
 
 extern "C" int ohevc_dev_boundary_strengths(const ohevc_bs_maps *maps, const ohevc_bs_call *calls, int ncalls, uint8_t *vertical_bs, uint8_t *horizontal_bs, void *stream)
