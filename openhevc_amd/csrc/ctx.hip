@@ -22,6 +22,7 @@ namespace {
 
 struct Picture {
     bool used = false, owned = true;
+    bool single = false;                  // the three planes are one allocation, back to back (alloc_picture): one copy moves the picture
     int w = 0, h = 0, cfi = 1, bd = 8;
     ohevc_plane planes[3] = {};
     // cross-ctx ordering (contexts of several decoding threads share one store and run on their own streams):
@@ -256,11 +257,16 @@ using namespace ohevc;
 
 static int free_picture(Picture &p, bool dry = false)
 {
-    for (auto &pl : p.planes) {
-        if (pl.data && p.owned && !dry) OHEVC_HIP_TRY(hipFree(pl.data));
-        pl = ohevc_plane{};
+    if (p.single) {
+        if (p.planes[0].data && p.owned && !dry) OHEVC_HIP_TRY(hipFree(p.planes[0].data));
+        for (auto &pl : p.planes) pl = ohevc_plane{};
+    } else {
+        for (auto &pl : p.planes) {
+            if (pl.data && p.owned && !dry) OHEVC_HIP_TRY(hipFree(pl.data));
+            pl = ohevc_plane{};
+        }
     }
-    p.used = false; p.owned = true;
+    p.used = false; p.owned = true; p.single = false;
     return OHEVC_OK;
 }
 
@@ -268,22 +274,28 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
 {
     const int ps = bd > 8 ? 2 : 1;
     p.w = width; p.h = height; p.cfi = cfi; p.bd = bd;
+    size_t off[4] = { 0, 0, 0, 0 };
     for (int i = 0; i < 3; i++) {
         const int hs = i ? (cfi == 1 || cfi == 2) : 0, vs = i ? (cfi == 1) : 0;
         const int w = width >> hs, h = height >> vs;
         const int stride = (w * ps + 255) & ~255;          // 256-byte pitch: whole 128-byte lines per row segment
-        void *d = reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1));      // never dereferenced in record-only mode
-        if (!dry) {
-            hipError_t e = hipMalloc(&d, (size_t)stride * h);
-            if (e != hipSuccess) {
-                set_error("picture plane allocation failed: %s", hipGetErrorString(e));
-                for (int k = 0; k < i; k++) { (void)hipFree(p.planes[k].data); p.planes[k] = ohevc_plane{}; }
-                return OHEVC_ERR_HIP;
-            }
-        }
-        p.planes[i] = ohevc_plane{ d, stride, w, h };
+        p.planes[i] = ohevc_plane{ nullptr, stride, w, h };
+        off[i + 1] = off[i] + (size_t)stride * h;
     }
-    p.used = true;
+    unsigned char *d = reinterpret_cast<unsigned char *>((uintptr_t)0x1000000);      // never dereferenced in record-only mode
+    if (!dry) {
+        // one allocation, the planes back to back: the deblocked copy SAO reads (and the filter-lag snapshot) is one device copy, not three
+        void *m = nullptr;
+        const hipError_t e = hipMalloc(&m, off[3]);
+        if (e != hipSuccess) {
+            set_error("picture allocation failed: %s", hipGetErrorString(e));
+            for (auto &pl : p.planes) pl = ohevc_plane{};
+            return OHEVC_ERR_HIP;
+        }
+        d = static_cast<unsigned char *>(m);
+    }
+    for (int i = 0; i < 3; i++) p.planes[i].data = dry ? reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1)) : static_cast<void *>(d + off[i]);
+    p.used = true; p.single = !dry;
     return OHEVC_OK;
 }
 
@@ -452,7 +464,7 @@ extern "C" int ohevc_pic_adopt(ohevc_ctx *c, const ohevc_plane planes[3], int wi
     if (slot < 0) { OHEVC_REQUIRE(c->store->npics < kMaxPics, "too many pictures"); slot = c->store->npics++; }
     Picture &p = c->store->pics[slot];
     p = Picture();
-    p.w = width; p.h = height; p.cfi = cfi; p.bd = bd; p.owned = false; p.used = true;
+    p.w = width; p.h = height; p.cfi = cfi; p.bd = bd; p.owned = false; p.single = false; p.used = true;
     for (int i = 0; i < 3; i++) {
         OHEVC_REQUIRE(planes[i].data != nullptr && (planes[i].stride & 15) == 0 && (reinterpret_cast<uintptr_t>(planes[i].data) & 15) == 0,
                       "adopted planes must be 16-byte aligned with a 16-byte multiple stride");
@@ -1980,9 +1992,14 @@ static int frame_end_impl(ohevc_ctx *c)
         };
         if (lagged) {          // the state the reference's early copy saw (ohevc_hip.h, OHEVC_SAO_LAG_*): chroma only
             if ((rc = ensure_like(c->lag)) != OHEVC_OK) return rc;
-            for (int i = 1; i < 3; i++)
-                OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
-                                             hipMemcpyDeviceToDevice, c->stream));
+            const size_t chroma = (size_t)p->planes[1].stride * p->planes[1].height + (size_t)p->planes[2].stride * p->planes[2].height;
+            if (p->single && c->lag.single) {
+                OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[1].data, p->planes[1].data, chroma, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                for (int i = 1; i < 3; i++)
+                    OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
+                                                 hipMemcpyDeviceToDevice, c->stream));
+            }
         }
         if (!c->dbk_blob.empty()) {
             if ((rc = ohevc_dev_deblock_maps(p->planes, p->bd, &dm, 0, c->stream)) != OHEVC_OK) return rc;
@@ -1995,9 +2012,15 @@ static int frame_end_impl(ohevc_ctx *c)
         if (!c->sao.empty()) {
             // SAO reads a deblocked copy and writes the picture: sao_filter_CTB, hevc_filter.c:269-315
             if ((rc = ensure_like(c->twin)) != OHEVC_OK) return rc;
-            for (int i = 0; i < 3; i++)
-                OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
-                                             hipMemcpyDeviceToDevice, c->stream));
+            if (p->single && c->twin.single) {              // (same geometry: ensure_like)
+                size_t all = 0;
+                for (int i = 0; i < 3; i++) all += (size_t)p->planes[i].stride * p->planes[i].height;
+                OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[0].data, p->planes[0].data, all, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                for (int i = 0; i < 3; i++)
+                    OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
+                                                 hipMemcpyDeviceToDevice, c->stream));
+            }
             ohevc_plane lagp[3] = {c->twin.planes[0], lagged ? c->lag.planes[1] : c->twin.planes[1], lagged ? c->lag.planes[2] : c->twin.planes[2]};
             ohevc_sao_bypass bp = {};                     // restore_tqb_pixels, hevc_filter.c:163-193
             if (!c->bypass.empty()) {
