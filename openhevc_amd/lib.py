@@ -248,6 +248,11 @@ def dev_motion_grid(jobs_ptr, njobs, grid_ptr, grid_width, grid_height, log2_uni
                                                C.c_int(log2_unit), C.c_void_p(stream)))
 
 
+def dev_motion_grid2(jobs_ptr, njobs, more_ptr, nmore, grid_ptr, grid_width, grid_height, log2_unit, stream=0):
+    check(load_library().ohevc_dev_motion_grid2(C.c_void_p(jobs_ptr or None), C.c_int(njobs), C.c_void_p(more_ptr or None), C.c_int(nmore), C.c_void_p(grid_ptr),
+                                                C.c_int(grid_width), C.c_int(grid_height), C.c_int(log2_unit), C.c_void_p(stream)))
+
+
 EXPORTED_SYMBOLS += ["ohevc_dev_boundary_strengths", "ohevc_dev_motion_grid", "ohevc_dev_motion_grid2", "ohevc_frame_keep_motion", "ohevc_tables_keep_motion", "ohevc_rec_bs_call",
                      "ohevc_rec_deblock_maps_bs", "ohevc_tables_bs_wanted", "ohevc_tables_bs_call", "ohevc_tables_bs_calls", "ohevc_rec_bs_calls"]
 

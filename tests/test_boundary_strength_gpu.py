@@ -134,10 +134,16 @@ def device_bs(geom, d_field, d_cbf, calls, n_bs, pu_w, pu_h, tb_w, tb_h, W, H):
     return G.to_host(d_v, np.uint8).copy(), G.to_host(d_h, np.uint8).copy()
 
 
-def grid_of_jobs(jobs, pu_w, pu_h, l2pu):
-    d_jobs = G.to_dev(jobs)
+def grid_of_jobs(jobs, pu_w, pu_h, l2pu, split=None):
+    """split = k: the jobs as two arrays (the first k, the rest) through the one-launch-for-both entry point, as the ctx layer calls it"""
     d_grid = G.zeros_dev(pu_w * pu_h * L.MOTION_GRID_ENTRY, np.uint8)
-    L.dev_motion_grid(d_jobs.data_ptr(), len(jobs), d_grid.data_ptr(), pu_w, pu_h, l2pu, G.stream())
+    if split is None:
+        d_jobs = G.to_dev(jobs)
+        L.dev_motion_grid(d_jobs.data_ptr(), len(jobs), d_grid.data_ptr(), pu_w, pu_h, l2pu, G.stream())
+    else:
+        d_a, d_b = G.to_dev(jobs[:max(split, 1)]), G.to_dev(jobs[split:] if split < len(jobs) else jobs[:1])
+        L.dev_motion_grid2(d_a.data_ptr() if split else 0, split, d_b.data_ptr() if split < len(jobs) else 0, len(jobs) - split, d_grid.data_ptr(), pu_w, pu_h, l2pu,
+                           G.stream())
     G.sync()
     return d_grid
 
@@ -161,7 +167,8 @@ def test_boundary_strengths_from_field_and_from_mc_jobs(W, H, log2_ctb, l2pu):
         assert W * H < 20000 or (np.count_nonzero(want[0] == 1) > 10 and np.count_nonzero(want[0] == 2) > 10 and np.count_nonzero(want[1] == 0) > 10)
         d_cbf = G.to_dev(cbf)
         compare(f"{W}x{H} field", device_bs(geom, G.to_dev(field), d_cbf, calls, n_bs, pu_w, pu_h, tb_w, tb_h, W, H), want)
-        d_grid = grid_of_jobs(jobs_of_pus(rng, pus), pu_w, pu_h, l2pu)
+        jobs = jobs_of_pus(rng, pus)
+        d_grid = grid_of_jobs(jobs, pu_w, pu_h, l2pu, split=None if across_tiles else int(rng.choice([0, len(jobs) // 3, len(jobs)])))
         grid = G.to_host(d_grid, np.uint8).view(po.BS_FIELD)
         assert np.array_equal(grid["pred_flag"] != 0, field["pred_flag"] != 0)           # exactly the inter-predicted units were written
         compare(f"{W}x{H} MC jobs", device_bs(geom, d_grid, d_cbf, calls, n_bs, pu_w, pu_h, tb_w, tb_h, W, H), want)
