@@ -34,7 +34,7 @@ int ohevc_debug_set_tu_pipe_workgroups(int n);
 /* motion-compensation kernel: 1 = first scalar kernel, 2 = packed-pair dot-product kernel, 3 = LDS tiles with both reference windows
  * staged before the first barrier (mc3), 4 = the matrix-core form (mc4) for tile batches and mc3's
  * four-jobs-per-wavefront form for the small-block entry point, 5 = mc4 for both, 6 (shipped since round 3) = mc4 for tile batches and mc4q
- * - four blocks of at most 8x8 per matrix-core tile - for the small-block entry point, 7 = the same with two quads per wavefront.  3, 4 and 5 hand tiles with reference samples above
+ * - four blocks of at most 8x8 per matrix-core tile - for the small-block entry point.  3, 4 and 5 hand tiles with reference samples above
  * the bit depth's range to the exact redo kernel; 1 and 2 are exact for samples that fit the bit depth.  Env OHEVC_MC_VARIANT sets
  * the initial value (A/B of whole-decoder runs). */
 int ohevc_debug_set_mc_variant(int variant);

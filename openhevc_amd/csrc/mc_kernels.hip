@@ -654,8 +654,8 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned short *wild = nullptr;
-    const bool v4q = small && (g_mc_variant == 6 || g_mc_variant == 7);                     // four small blocks per matrix-core tile (mc4q_kernel)
-    const bool v4 = !v4q && (g_mc_variant == 5 || ((g_mc_variant == 4 || g_mc_variant == 6 || g_mc_variant == 7) && !small));
+    const bool v4q = small && g_mc_variant == 6;                      // four small blocks per matrix-core tile (mc4q_kernel)
+    const bool v4 = !v4q && (g_mc_variant == 5 || ((g_mc_variant == 4 || g_mc_variant == 6) && !small));
 #ifdef OHEVC_LAB
     const bool v3 = v4 || v4q || small || (g_mc_variant != 1 && g_mc_variant != 2);
 #else
@@ -667,14 +667,11 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
     }
     const int redo_grid = std::min(256, (njobs + 63) / 64);
     if (v4q) {
-        const int units = g_mc_variant == 7 ? 2 : 1;                    // quads per wavefront
-        const int grid = ((((njobs + 3) / 4 + units - 1) / units + 3) / 4 + 7) & ~7;     // quads of jobs, 4 wavefronts per workgroup, XCD-contiguous ranges
+        const int grid = (((njobs + 3) / 4 + 3) / 4 + 7) & ~7;          // quads of jobs, 4 wavefronts per workgroup, XCD-contiguous ranges
         unsigned *wild32 = reinterpret_cast<unsigned *>(wild);
         if (bit_depth > 8) OHEVC_HIP_TRY(hipMemsetAsync(wild32, 0, (size_t)njobs * sizeof(unsigned), st));
-        if (bit_depth == 8 && units == 1)      hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
-        else if (bit_depth == 8)               hipLaunchKernelGGL((mc4q_kernel<uint8_t, 2>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
-        else if (units == 1)                   hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
-        else                                   hipLaunchKernelGGL((mc4q_kernel<uint16_t, 2>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+        if (bit_depth == 8) hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+        else                hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
         if (bit_depth > 8) hipLaunchKernelGGL((mc3_redo_kernel<unsigned>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild32, 16);
     } else if (v4) {                          // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
         const bool multi = max_w > 16 || max_h > 16;
@@ -740,6 +737,6 @@ extern "C" int ohevc_dev_mc_batch_small(const ohevc_plane dst[3], const ohevc_pl
 extern "C" int ohevc_debug_set_mc_variant(int variant)
 {
     int old = ohevc::g_mc_variant;
-    if (variant >= 1 && variant <= 7) ohevc::g_mc_variant = variant;
+    if (variant >= 1 && variant <= 6) ohevc::g_mc_variant = variant;
     return old;
 }

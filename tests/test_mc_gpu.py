@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 PAD = 80
 
 
-@pytest.fixture(params=[5, 3, 6, 7], ids=["matrix_cores", "lds_tiles", "matrix_cores_quads", "matrix_cores_quads_x2"])
+@pytest.fixture(params=[5, 3, 6], ids=["matrix_cores", "lds_tiles", "matrix_cores_quads"])
 def mc_variant(request):
     """Both forms of the motion-compensation kernel (include/ohevc_debug.h): mc4 (v_mfma_i32_16x16x32_i8, no LDS tiles; variant 5 uses it
     for the small-block entry point too - variant 4 keeps mc3 there) / mc3 (LDS tiles) / mc4 + mc4q (variant 6: the small-block entry point
