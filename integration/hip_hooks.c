@@ -687,13 +687,24 @@ static int frames_await_planes(HEVCContext *s)
     return 0;
 }
 
+/* A failure is reported ONCE, by the frame end that sees it, and then forgotten: the pictures that predict from the failed one fail on
+ * their own (the library marks it, ohevc_frame_abort), and after the next IDR picture the decoder is whole again - a damaged access unit must
+ * not silence the rest of the stream. */
+static int take_error(void)
+{
+    if (!g_error)
+        return 0;
+    g_error = 0;
+    return -1;
+}
+
 int ohdec_backend_frame_done(void)
 {
     int st, async;
     struct timespec t0, t1;
     ohevc_frame_stats fs;
     if (!t_frame_open)
-        return g_error ? -1 : 0;
+        return take_error();
     t_frame_open = 0;
     /* restore_tqb_pixels (hevc_filter.c:163-193) ran on host pixels nobody reads: hand its map to the back-end instead */
     if (t_s && t_s->sps && t_s->pps && t_s->is_pcm &&
@@ -750,7 +761,7 @@ int ohdec_backend_frame_done(void)
             g_error = 1;
         }
     }
-    return g_error ? -1 : 0;
+    return take_error();
 }
 
 /* hip_frames.h: the decoder gave up on the picture it was decoding */

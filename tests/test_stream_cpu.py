@@ -274,3 +274,56 @@ def test_stream_starting_at_a_missing_reference(monkeypatch):
     ref = ps.decode_stream("c", cut)
     assert len(ref) >= 3
     assert frames_md5(ps.decode_stream("hip", cut)) == frames_md5(ref)
+
+
+@needs_c
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name", ["ra_8b_ctb64", "ldb_8b", "tiles", "slices_dep_wpp"])
+def test_damaged_access_units_do_not_silence_the_stream(name, threads, monkeypatch):
+    """Bit flips, a truncation and a run of 0xff in the slice data of two access units, then the clean stream again (it starts with an IDR
+    picture) through the same decoder: no crash, no hang, whatever the damaged pass yields is equal to what the untouched decoder yields for
+    the same bytes or is reported as an error, and the pictures of the clean pass are the golden ones.  (The recording slots, the frame
+    life-cycle hooks and the software executor: host logic only.)"""
+    if not ps.have("hip"):
+        pytest.skip("oracle/_ref/libopenhevc_hip.so not built")
+    import random
+    monkeypatch.setenv("OHHIP_SW_EXEC", "1")
+    aus, md5 = load_golden(name)
+    rnd = random.Random(hash(name) & 0xffff)
+    for mode in range(3):
+        bad = [bytearray(a) for a in aus]
+        for k in rnd.sample(range(1, len(bad)), min(2, len(bad) - 1)):
+            a = bad[k]
+            if mode == 0:
+                for _ in range(8):
+                    a[rnd.randrange(len(a) // 2, len(a))] ^= 1 << rnd.randrange(8)
+            elif mode == 1:
+                del a[len(a) * 2 // 3:]
+            else:
+                i = rnd.randrange(len(a) // 3, len(a) - 4)
+                a[i:i + 4] = b"\xff\xff\xff\xff"
+        seq = [bytes(a) for a in bad] + list(aus)
+        results = {}
+        for kind in ("c", "hip"):
+            pics, errors = [], 0
+            with ps.Decoder(kind, threads, 1) as d:
+                for i, au in enumerate(seq):
+                    r = d.L.ohdec_decode(d.h, au, len(au), i + 1)
+                    if r < 0:
+                        errors += 1
+                    elif r:
+                        pics.append(d._fetch())
+                while True:
+                    r = d.L.ohdec_flush(d.h)
+                    if r <= 0:
+                        break
+                    pics.append(d._fetch())
+            results[kind] = (pics, errors)
+        ref_pics, _ = results["c"]
+        hip_pics, hip_errors = results["hip"]
+        n_clean = len(md5) // 3
+        assert len(ref_pics) >= n_clean
+        # the clean pass: the last n_clean pictures, from both decoders, are the golden ones
+        assert frames_md5(ref_pics[-n_clean:]) == md5, f"{name} mode {mode}: the reference itself did not recover"
+        assert len(hip_pics) >= n_clean and frames_md5(hip_pics[-n_clean:]) == md5, \
+            f"{name} mode {mode} threads {threads}: {len(hip_pics)} pictures, {hip_errors} errors after the damaged pass"

@@ -218,3 +218,18 @@ def test_plain_c_host_links_and_runs():
         assert r.returncode == 0, r.stdout + r.stderr
     finally:
         shutil.rmtree(d)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name", ["ra_8b_ctb64", "ldb_8b", "tiles"])
+def test_damaged_access_units_do_not_silence_the_stream(name, threads, monkeypatch):
+    """tests/test_stream_cpu.py's damaged-stream test on the device: after two damaged access units (bit flips / truncation / 0xff run) the
+    clean stream, fed through the same decoder, comes out as the golden pictures - the device work of failed or concealed pictures must not
+    poison the picture store, the waits between frame threads or the error state."""
+    from test_stream_cpu import test_damaged_access_units_do_not_silence_the_stream as body
+    monkeypatch.delenv("OHHIP_SW_EXEC", raising=False)
+
+    class KeepEnv:                      # the CPU test switches the software executor on: not here
+        def setenv(self, *a, **k):
+            pass
+    body.__wrapped__(name, threads, KeepEnv()) if hasattr(body, "__wrapped__") else body(name, threads, KeepEnv())
