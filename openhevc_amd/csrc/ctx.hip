@@ -1751,7 +1751,8 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         c->stats.launches++;
     }
     if (!c->mc_small.empty()) {
-        rc = ohevc_dev_mc_batch_small(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), kMaxPics, p->bd,
+        // (the slots in use, not the table's capacity: the kernel keeps the plane records of that many pictures in LDS)
+        rc = ohevc_dev_mc_batch_small(p->planes, static_cast<const ohevc_plane *>(c->d_table.p), std::max(1, std::min(kMaxPics, (int)c->store->npics)), p->bd,
                                       reinterpret_cast<const ohevc_mc_job *>(base + off_mcs), (int)c->mc_small.size(), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;

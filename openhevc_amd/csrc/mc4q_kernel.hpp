@@ -115,17 +115,32 @@ __device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixe
 #define MC4Q_OCCUPANCY(units) __attribute__((amdgpu_waves_per_eu((units) == 1 ? 8 : 4, 8)))     // one quad per wavefront: 8 wavefronts per SIMD (<= 64 VGPRs)
 #endif
 template <typename Pixel, int UNITS>
-__global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, const ohevc_mc_job *__restrict__ jobs, int njobs, int bit_depth,
-                                                   unsigned *__restrict__ wild_mask)
+__global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, int n_ref_slots, const ohevc_mc_job *__restrict__ jobs,
+                                                   int njobs, int bit_depth, unsigned *__restrict__ wild_mask)
 {
     constexpr bool WIDE = sizeof(Pixel) == 2;
+    constexpr int kRefSlots = 64;                                                                // plane records kept in LDS (3 x 24 bytes per picture)
     __shared__ u32x2 tabs[2][12][64];
+    __shared__ unsigned long ref_tab[kRefSlots * 9];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The plane records of the reference pictures come with the operand tables, i.e. together with the job records: a quad is then two dependent
+    // rounds of loads (records, samples) instead of three (job records, plane records, samples).  (More pictures than kRefSlots: from memory.)
+    const bool refs_in_lds = n_ref_slots <= kRefSlots;
     {
         const u32x4 *src = reinterpret_cast<const u32x4 *>(&kMc4);
         u32x4 *dl = reinterpret_cast<u32x4 *>(&tabs[0][0][0]);
         const u32x4 t0 = src[tid], t1 = src[256 + tid], t2 = src[512 + tid];
+        const int words = refs_in_lds ? n_ref_slots * 9 : 0;
+        typedef const MC4_GLOBAL unsigned long *lptr;
+        unsigned long r0 = 0, r1 = 0, r2 = 0;
+        if (tid < words) r0 = ((lptr)refs)[tid];
+        if (tid + 256 < words) r1 = ((lptr)refs)[tid + 256];
+        if (tid + 512 < words) r2 = ((lptr)refs)[tid + 512];
         dl[tid] = t0; dl[256 + tid] = t1; dl[512 + tid] = t2;
+        if (tid < words) ref_tab[tid] = r0;
+        if (tid + 256 < words) ref_tab[tid + 256] = r1;
+        if (tid + 512 < words) ref_tab[tid + 512] = r2;
+        static_assert(kRefSlots * 9 <= 768, "three rounds of 256 words");
     }
     const int per_xcd = gridDim.x >> 3;                                                          // an XCD takes a contiguous eighth of the list (mc4_kernel)
     const int q0 = ((((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave) * UNITS;
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
     // ---- memory side: lane (r = lane >> 2, g = lane & 3) loads 8 samples of window row r, columns 8 (g & 1) .., of block g >> 1 of each pair
     // (three dependent rounds - job records, plane records, samples - each issued for every quad, pair and reference before the first use)
     unsigned raw[UNITS][2][2][WIDE ? 4 : 2] = {};
+    __syncthreads();                                                                             // the tables are in LDS
     {
         const int r = lane >> 2, half = lane & 1;
         const bool first = (lane & 3) < 2;
@@ -162,8 +178,13 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
                 m[u][pair] = mc4q_pick(first, jb[u][2 * pair], jb[u][2 * pair + 1]);
                 const bool bi = (m[u][pair].flags & OHEVC_MC_BI) != 0;
                 if (!bi) { m[u][pair].ref1 = m[u][pair].ref0; m[u][pair].sx1 = m[u][pair].sx0; m[u][pair].sy1 = m[u][pair].sy0; }       // (loaded again, weighted 0)
-                if (any[u]) rec[u][0][pair] = mc4q_ref(refs, m[u][pair].ref0, m[u][pair].plane);
-                if (any[u] && any_bi[u]) rec[u][1][pair] = mc4q_ref(refs, m[u][pair].ref1, m[u][pair].plane);
+                auto plane_record = [&](int ref) {
+                    if (!refs_in_lds) return mc4q_ref(refs, ref, m[u][pair].plane);
+                    const unsigned long *e = &ref_tab[(3 * ref + m[u][pair].plane) * 3];
+                    return Mc4qRef{ e[0], e[1], e[2] };
+                };
+                if (any[u]) rec[u][0][pair] = plane_record(m[u][pair].ref0);
+                if (any[u] && any_bi[u]) rec[u][1][pair] = plane_record(m[u][pair].ref1);
             }
 #pragma unroll
         for (int u = 0; u < UNITS; u++)
@@ -175,7 +196,6 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
                     mc4q_issue<Pixel>(rec[u][1][pair], m[u][pair].sx1 - before, m[u][pair].sy1 - before, m[u][pair].h + taps - 1, r, half, raw[u][1][pair]);
             }
     }
-    __syncthreads();                                                                             // the tables are in LDS
     // ---- operand side: lane (n = lane & 15, g = lane >> 4)
     const int n = lane & 15, g = lane >> 4, maxv = (1 << bit_depth) - 1;
     const bool lowcol = n < 8, lowgrp = g < 2;

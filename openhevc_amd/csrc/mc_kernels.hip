@@ -670,8 +670,8 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
         const int grid = (((njobs + 3) / 4 + 3) / 4 + 7) & ~7;          // quads of jobs, 4 wavefronts per workgroup, XCD-contiguous ranges
         unsigned *wild32 = reinterpret_cast<unsigned *>(wild);
         if (bit_depth > 8) OHEVC_HIP_TRY(hipMemsetAsync(wild32, 0, (size_t)njobs * sizeof(unsigned), st));
-        if (bit_depth == 8) hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
-        else                hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, jobs, njobs, bit_depth, wild32);
+        if (bit_depth == 8) hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+        else                hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
         if (bit_depth > 8) hipLaunchKernelGGL((mc3_redo_kernel<unsigned>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild32, 16);
     } else if (v4) {                          // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
         const bool multi = max_w > 16 || max_h > 16;
