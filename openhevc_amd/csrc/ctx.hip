@@ -250,6 +250,7 @@ struct ohevc_ctx : Rec {
     PinnedBuf stage[2], table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
+    double t_part[5] = {0, 0, 0, 0, 0};    // ... of which: staging copies, copy / launch calls of the reconstruction, the same of the filters, waits for a free staging buffer, copy-back
     int n_frames = 0, n_map_frames = 0;
 };
 
@@ -347,8 +348,10 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (!c) return;
     ohevc_tables_forget(c);
     if (g_trace_timing && c->n_frames)
-        fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms; deblocking derived on the device in %d\n",
-                (void *)c, c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames, c->n_map_frames);
+        fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms; deblocking derived on the device in %d; "
+                        "staging copies %.3f, reconstruction calls %.3f, filter calls %.3f, waiting for the staging buffer %.3f, copy-back incl. wait %.3f ms/frame\n",
+                (void *)c, c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames, c->n_map_frames, 1e3 * c->t_part[0] / c->n_frames,
+                1e3 * c->t_part[1] / c->n_frames, 1e3 * c->t_part[2] / c->n_frames, 1e3 * c->t_part[3] / c->n_frames, 1e3 * c->t_part[4] / c->n_frames);
     if (c->dry) { delete c; return; }
     // teardown: an error here has nowhere to go
     (void)hipSetDevice(c->device);
@@ -583,6 +586,7 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
         if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
         if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
     }
+    const double t0 = g_trace_timing ? now_s() : 0;
     for (int i = 0; i < 3; i++) {
         if (!host[i]) continue;
         const ohevc_plane &pl = p->planes[i];
@@ -590,6 +594,7 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
                                        hipMemcpyDeviceToHost, c->stream));
     }
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (g_trace_timing) c->t_part[4] += now_s() - t0;          // (the wait covers the picture's device work as well: nothing waited for it before)
     return OHEVC_OK;
 }
 
@@ -1367,7 +1372,9 @@ static size_t stage_put(std::vector<std::pair<const void *, size_t>> &parts, siz
 static int wait_staging_free(ohevc_ctx *c, int lane)
 {
     if (c->staged_pending[lane]) {
+        const double t0 = g_trace_timing ? now_s() : 0;
         OHEVC_HIP_TRY(hipEventSynchronize(c->staged[lane]));
+        if (g_trace_timing) c->t_part[3] += now_s() - t0;
         c->staged_pending[lane] = false;
     }
     return OHEVC_OK;
@@ -1449,10 +1456,12 @@ static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>
         if ((rc = c->d_jobs[lane].reserve(total)) != OHEVC_OK) return rc;
     }
     size_t off = 0;
+    const double t_copy = g_trace_timing ? now_s() : 0;
     for (auto &pr : parts) {
         memcpy(c->stage[lane].p + off, pr.first, pr.second);
         off += (pr.second + 255) & ~(size_t)255;
     }
+    if (g_trace_timing) c->t_part[0] += now_s() - t_copy;
     OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs[lane].p, c->stage[lane].p, total, hipMemcpyHostToDevice, c->stream));
     OHEVC_HIP_TRY(hipEventRecord(c->staged[lane], c->stream));
     c->staged_pending[lane] = true;
@@ -1740,6 +1749,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_cu = ctbs && !c->ctb_tu.empty() ? stage_put(parts, total, c->ctb_tu.data(), c->ctb_tu.size() * sizeof(ohevc_tu_job)) : 0;
     const size_t off_cs = ctbs ? stage_put(parts, total, c->ctb_sync_zero.data(), c->ctb_sync_zero.size() * sizeof(uint32_t)) : 0;
     if ((rc = upload_jobs(c, parts, total, 0)) != OHEVC_OK) return rc;
+    struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 1, g_trace_timing ? now_s() : 0};
     unsigned char *base = static_cast<unsigned char *>(c->d_jobs[0].p);
     const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
 
@@ -1932,6 +1942,7 @@ static int frame_end_impl(ohevc_ctx *c)
         const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
         const int lane = g_upload_lanes == 2 ? 1 : 0;
         if ((rc = upload_jobs(c, parts, total, lane)) != OHEVC_OK) return rc;
+        struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 2, g_trace_timing ? now_s() : 0};
         unsigned char *base = static_cast<unsigned char *>(c->d_jobs[lane].p);
         ohevc_dbk_maps dm = c->dbk_maps;                  // offsets -> device addresses
         if (!c->dbk_blob.empty()) {
