@@ -213,6 +213,9 @@ int ohevc_dev_motion_grid(const ohevc_mc_job *jobs, int njobs, uint8_t *grid, in
 int ohevc_dev_motion_grid2(const ohevc_mc_job *jobs, int njobs, const ohevc_mc_job *more, int nmore, uint8_t *grid, int grid_width, int grid_height,
                            int log2_unit, void *stream);
 
+/* device-to-device copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) as a kernel launch: the deblocked copy SAO reads */
+int ohevc_dev_copy(void *dst, const void *src, size_t bytes, void *stream);
+
 /* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
  * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy
  * (the reference's sao_frame), one job per CTB and colour plane. */

@@ -2006,7 +2006,7 @@ static int frame_end_impl(ohevc_ctx *c)
             if ((rc = ensure_like(c->lag)) != OHEVC_OK) return rc;
             const size_t chroma = (size_t)p->planes[1].stride * p->planes[1].height + (size_t)p->planes[2].stride * p->planes[2].height;
             if (p->single && c->lag.single) {
-                OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[1].data, p->planes[1].data, chroma, hipMemcpyDeviceToDevice, c->stream));
+                if ((rc = ohevc_dev_copy(c->lag.planes[1].data, p->planes[1].data, chroma, c->stream)) != OHEVC_OK) return rc;
             } else {
                 for (int i = 1; i < 3; i++)
                     OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
@@ -2027,7 +2027,7 @@ static int frame_end_impl(ohevc_ctx *c)
             if (p->single && c->twin.single) {              // (same geometry: ensure_like)
                 size_t all = 0;
                 for (int i = 0; i < 3; i++) all += (size_t)p->planes[i].stride * p->planes[i].height;
-                OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[0].data, p->planes[0].data, all, hipMemcpyDeviceToDevice, c->stream));
+                if ((rc = ohevc_dev_copy(c->twin.planes[0].data, p->planes[0].data, all, c->stream)) != OHEVC_OK) return rc;
             } else {
                 for (int i = 0; i < 3; i++)
                     OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
