@@ -250,6 +250,11 @@ struct ohevc_ctx : Rec {
     PinnedBuf stage[2], table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
+    // the filter maps / records of the frame end, staged by frame_end_impl BEFORE it calls ohevc_frame_reconstruct so that they travel in the
+    // same host-to-device copy as the job arrays (tail_base: where they landed in that upload; SIZE_MAX: they did not travel yet)
+    std::vector<std::pair<const void *, size_t>> tail_parts;
+    size_t tail_total = 0, tail_base = SIZE_MAX;
+    double t_f[6] = {0, 0, 0, 0, 0, 0};     // ... the filter calls one by one: boundary strengths, deblocking (vertical), deblocking (horizontal), the deblocked copy, SAO, the rest
     double t_part[5] = {0, 0, 0, 0, 0};    // ... of which: staging copies, copy / launch calls of the reconstruction, the same of the filters, waits for a free staging buffer, copy-back
     int n_frames = 0, n_map_frames = 0;
 };
@@ -349,9 +354,11 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     ohevc_tables_forget(c);
     if (g_trace_timing && c->n_frames)
         fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms; deblocking derived on the device in %d; "
-                        "staging copies %.3f, reconstruction calls %.3f, filter calls %.3f, waiting for the staging buffer %.3f, copy-back incl. wait %.3f ms/frame\n",
+                        "staging copies %.3f, reconstruction calls %.3f, filter calls %.3f (bs %.3f, vertical edges %.3f, horizontal edges %.3f, copy %.3f, SAO %.3f), "
+                        "waiting for the staging buffer %.3f, copy-back incl. wait %.3f ms/frame\n",
                 (void *)c, c->n_frames, 1e3 * c->t_issue / c->n_frames, 1e3 * c->t_wait_refs / c->n_frames, c->n_map_frames, 1e3 * c->t_part[0] / c->n_frames,
-                1e3 * c->t_part[1] / c->n_frames, 1e3 * c->t_part[2] / c->n_frames, 1e3 * c->t_part[3] / c->n_frames, 1e3 * c->t_part[4] / c->n_frames);
+                1e3 * c->t_part[1] / c->n_frames, 1e3 * c->t_part[2] / c->n_frames, 1e3 * c->t_f[0] / c->n_frames, 1e3 * c->t_f[1] / c->n_frames, 1e3 * c->t_f[2] / c->n_frames,
+                1e3 * c->t_f[3] / c->n_frames, 1e3 * c->t_f[4] / c->n_frames, 1e3 * c->t_part[3] / c->n_frames, 1e3 * c->t_part[4] / c->n_frames);
     if (c->dry) { delete c; return; }
     // teardown: an error here has nowhere to go
     (void)hipSetDevice(c->device);
@@ -1748,6 +1755,12 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_ci = ctbs && !c->ctb_intra.empty() ? stage_put(parts, total, c->ctb_intra.data(), c->ctb_intra.size() * sizeof(ohevc_intra_job)) : 0;
     const size_t off_cu = ctbs && !c->ctb_tu.empty() ? stage_put(parts, total, c->ctb_tu.data(), c->ctb_tu.size() * sizeof(ohevc_tu_job)) : 0;
     const size_t off_cs = ctbs ? stage_put(parts, total, c->ctb_sync_zero.data(), c->ctb_sync_zero.size() * sizeof(uint32_t)) : 0;
+    if (!c->tail_parts.empty()) {                       // the frame end's filter maps ride along (frame_end_impl)
+        c->tail_base = total;
+        parts.insert(parts.end(), c->tail_parts.begin(), c->tail_parts.end());
+        total += c->tail_total;
+        c->tail_parts.clear();
+    }
     if ((rc = upload_jobs(c, parts, total, 0)) != OHEVC_OK) return rc;
     struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 1, g_trace_timing ? now_s() : 0};
     unsigned char *base = static_cast<unsigned char *>(c->d_jobs[0].p);
@@ -1919,31 +1932,51 @@ static int frame_end_impl(ohevc_ctx *c)
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
     const double t_begin = g_trace_timing ? now_s() : 0;
     struct Acc { ohevc_ctx *c; double t0; ~Acc() { if (g_trace_timing) { c->t_issue += now_s() - t0; c->n_frames++; } } } acc{c, t_begin};
+    // The filter maps and records are staged FIRST and handed to ohevc_frame_reconstruct, which puts them behind its job arrays in ONE host-to-
+    // device copy.  A second copy issued while the stream was busy with the reconstruction cost the host ~0.14 ms per picture: the first launch
+    // behind it did not return before the stream had drained (OHEVC_TRACE_TIMING, profiles/r04o_*).
+    merge_side(c);                                      // (slice threads: their recorders hold filter records too; the arrays must not move after this)
+    if (c->sao.empty()) c->bypass.clear();
+    const bool filters = !c->dry && (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty() || !c->dbk_blob.empty());
+    std::vector<std::pair<const void *, size_t>> parts;
+    size_t total = 0, off_m = 0, off_bsc = 0, off_v = 0, off_h = 0, off_s = 0, off_b = 0;
+    bool dev_bs = false;
+    int n_sao_wide = 0;
+    if (filters) {
+        off_m = c->dbk_blob.empty() ? 0 : stage_put(parts, total, c->dbk_blob.data(), c->dbk_blob.size());
+        dev_bs = c->have_bs && !c->dbk_blob.empty();
+        off_bsc = dev_bs && !c->bs_calls.empty() ? stage_put(parts, total, c->bs_calls.data(), c->bs_calls.size() * sizeof(ohevc_bs_call)) : 0;
+        off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
+        off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
+        // the blocks the wide SAO kernel takes first (ohevc_dev_sao_batch_sorted); SAO blocks of a picture are independent of each other.
+        // (The deblocked copy they read is allocated like the picture: same alignment, same pitch.)
+        n_sao_wide = (int)(std::stable_partition(c->sao.begin(), c->sao.end(), [&](const ohevc_sao_job &j) {
+                               return ohevc_sao_job_is_wide(&j, p->planes, p->planes, p->bd) != 0; }) - c->sao.begin());
+        off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
+        off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
+        if (g_upload_lanes != 2) { c->tail_parts = parts; c->tail_total = total; }
+    }
+    c->tail_base = SIZE_MAX;
     int rc = ohevc_frame_reconstruct(c);
+    c->tail_parts.clear();
     if (rc != OHEVC_OK) return rc;
     if (c->dry) {
         if (g_sink) g_sink(g_sink_user, c, 1);
         c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
     }
-    if (c->sao.empty()) c->bypass.clear();
-    if (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty() || !c->dbk_blob.empty()) {
-        std::vector<std::pair<const void *, size_t>> parts;
-        size_t total = 0;
-        const size_t off_m = c->dbk_blob.empty() ? 0 : stage_put(parts, total, c->dbk_blob.data(), c->dbk_blob.size());
-        const bool dev_bs = c->have_bs && !c->dbk_blob.empty();
-        const size_t off_bsc = dev_bs && !c->bs_calls.empty() ? stage_put(parts, total, c->bs_calls.data(), c->bs_calls.size() * sizeof(ohevc_bs_call)) : 0;
-        const size_t off_v = c->dbk_v.empty() ? 0 : stage_put(parts, total, c->dbk_v.data(), c->dbk_v.size() * sizeof(ohevc_dbk_job));
-        const size_t off_h = c->dbk_h.empty() ? 0 : stage_put(parts, total, c->dbk_h.data(), c->dbk_h.size() * sizeof(ohevc_dbk_job));
-        // the blocks the wide SAO kernel takes first (ohevc_dev_sao_batch_sorted); SAO blocks of a picture are independent of each other.
-        // (The deblocked copy they read is allocated like the picture: same alignment, same pitch.)
-        const int n_sao_wide = (int)(std::stable_partition(c->sao.begin(), c->sao.end(), [&](const ohevc_sao_job &j) {
-                                         return ohevc_sao_job_is_wide(&j, p->planes, p->planes, p->bd) != 0; }) - c->sao.begin());
-        const size_t off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
-        const size_t off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
-        const int lane = g_upload_lanes == 2 ? 1 : 0;
-        if ((rc = upload_jobs(c, parts, total, lane)) != OHEVC_OK) return rc;
+    if (filters) {
+        int lane = 0;
+        size_t tail = c->tail_base;
+        if (tail == SIZE_MAX) {                           // nothing was reconstructed (or OHEVC_UPLOAD_LANES=2): an upload of their own
+            lane = g_upload_lanes == 2 ? 1 : 0;
+            if ((rc = upload_jobs(c, parts, total, lane)) != OHEVC_OK) return rc;
+            tail = 0;
+        }
+        c->tail_base = SIZE_MAX;
         struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 2, g_trace_timing ? now_s() : 0};
-        unsigned char *base = static_cast<unsigned char *>(c->d_jobs[lane].p);
+        double t_lap = g_trace_timing ? now_s() : 0;
+        auto lap = [&](int k) { if (g_trace_timing) { const double t = now_s(); c->t_f[k] += t - t_lap; t_lap = t; } };
+        unsigned char *base = static_cast<unsigned char *>(c->d_jobs[lane].p) + tail;
         ohevc_dbk_maps dm = c->dbk_maps;                  // offsets -> device addresses
         if (!c->dbk_blob.empty()) {
             dm.vertical_bs = base + off_m + reinterpret_cast<uintptr_t>(c->dbk_maps.vertical_bs);
@@ -1985,6 +2018,7 @@ static int frame_end_impl(ohevc_ctx *c)
             if (!c->bs_calls.empty()) c->stats.launches++;
             dm.vertical_bs = vbs; dm.horizontal_bs = hbs;
         }
+        lap(0);
         // all vertical edges, then all horizontal edges: deblocking_filter_CTB, hevc_filter.c:385-580
         if (!c->dbk_blob.empty()) {
             if ((rc = ohevc_dev_deblock_maps(p->planes, p->bd, &dm, 1, c->stream)) != OHEVC_OK) return rc;
@@ -1994,6 +2028,7 @@ static int frame_end_impl(ohevc_ctx *c)
             if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_v), (int)c->dbk_v.size(), c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
+        lap(1);
         const bool lagged = c->sao_lagged && !c->sao.empty() && !c->dbk_h.empty();
         auto ensure_like = [&](Picture &q) -> int {
             if (q.used && q.w == p->w && q.h == p->h && q.cfi == p->cfi && q.bd == p->bd) return OHEVC_OK;
@@ -2021,6 +2056,7 @@ static int frame_end_impl(ohevc_ctx *c)
             if ((rc = ohevc_dev_deblock_batch(p->planes, p->bd, reinterpret_cast<const ohevc_dbk_job *>(base + off_h), (int)c->dbk_h.size(), c->stream)) != OHEVC_OK) return rc;
             c->stats.launches++;
         }
+        lap(2);
         if (!c->sao.empty()) {
             // SAO reads a deblocked copy and writes the picture: sao_filter_CTB, hevc_filter.c:269-315
             if ((rc = ensure_like(c->twin)) != OHEVC_OK) return rc;
@@ -2033,6 +2069,7 @@ static int frame_end_impl(ohevc_ctx *c)
                     OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
                                                  hipMemcpyDeviceToDevice, c->stream));
             }
+            lap(3);
             ohevc_plane lagp[3] = {c->twin.planes[0], lagged ? c->lag.planes[1] : c->twin.planes[1], lagged ? c->lag.planes[2] : c->twin.planes[2]};
             ohevc_sao_bypass bp = {};                     // restore_tqb_pixels, hevc_filter.c:163-193
             if (!c->bypass.empty()) {
@@ -2041,6 +2078,7 @@ static int frame_end_impl(ohevc_ctx *c)
             }
             if ((rc = ohevc_dev_sao_batch_sorted(p->planes, c->twin.planes, lagp, p->bd, reinterpret_cast<const ohevc_sao_job *>(base + off_s), n_sao_wide, (int)c->sao.size() - n_sao_wide, &bp, c->stream)) != OHEVC_OK) return rc;
             c->stats.launches += (n_sao_wide > 0) + (n_sao_wide < (int)c->sao.size());
+            lap(4);
         }
         c->dbk_v.clear(); c->dbk_h.clear(); c->dbk_blob.clear(); c->sao.clear(); c->sao_lagged = false; c->bypass.clear();
         c->bs_calls.clear(); c->have_bs = false;
