@@ -1933,8 +1933,9 @@ static int frame_end_impl(ohevc_ctx *c)
     const double t_begin = g_trace_timing ? now_s() : 0;
     struct Acc { ohevc_ctx *c; double t0; ~Acc() { if (g_trace_timing) { c->t_issue += now_s() - t0; c->n_frames++; } } } acc{c, t_begin};
     // The filter maps and records are staged FIRST and handed to ohevc_frame_reconstruct, which puts them behind its job arrays in ONE host-to-
-    // device copy.  A second copy issued while the stream was busy with the reconstruction cost the host ~0.14 ms per picture: the first launch
-    // behind it did not return before the stream had drained (OHEVC_TRACE_TIMING, profiles/r04o_*).
+    // device copy (one staging pass, one copy, one event less per picture).  (It does not shorten the frame end: about a dozen launches into a
+    // picture some call blocks until the device has caught up - whichever call it is, with or without a second copy in front of it - so the
+    // calls of a frame end take as long as the device needs for its work, OHEVC_TRACE_TIMING, profiles/r04o_* - r04q_*.)
     merge_side(c);                                      // (slice threads: their recorders hold filter records too; the arrays must not move after this)
     if (c->sao.empty()) c->bypass.clear();
     const bool filters = !c->dry && (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty() || !c->dbk_blob.empty());

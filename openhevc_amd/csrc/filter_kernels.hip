@@ -861,9 +861,8 @@ __global__ __launch_bounds__(256) void motion_grid_kernel(const ohevc_mc_job *__
 
 }  // namespace ohevc
 
-// A device-to-device copy as a plain kernel.  hipMemcpyAsync(DeviceToDevice) costs the host ~100 us per call here (measured through
-// OHEVC_TRACE_TIMING: the filter calls of a frame end, 0.15 ms for six launches and one such copy) - the picture's deblocked copy is made
-// once per picture, on the critical path of every frame end.
+// A device-to-device copy as a plain kernel: the picture's deblocked copy is made once per picture on the critical path of every frame end,
+// and a launch is the cheapest thing to put there (no copy-engine hand-over, 3-4 us of host time).
 namespace ohevc {
 __global__ __launch_bounds__(256) void copy16_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, unsigned n16)
 {
