@@ -509,23 +509,22 @@ def main():
                             "vs_raster": round(kernel_ms / z[1], 4),
                             "note": "device entry point fed the z-scan list as is; the ctx layer (ohevc_frame_reconstruct) puts every 32x32 bin back into "
                                     "raster order with a counting sort before it launches, so the decoder runs the raster figure"}
-        decode = None
         if world == 1 and not args.no_decode:
-            # right behind the timed loops, while the device is busy: after the ~12 s of host-only work of the CPU baseline the first stream of
-            # the decode block ran 10-25 % slower (frame-end hook 0.86 instead of 0.54 ms: an idle device takes its time to come back up)
+            # the ring (most of the device's memory) goes back to the driver NOW, and the host-only CPU baseline runs in between: the decode
+            # block used to start right behind the release, and its first stream ran 10-25 % slower than the same stream a second later
+            # (frame-end hook 0.86 instead of 0.54 ms) - the unmapping of ~250 GB goes on in the background for a while
             del plane_ring, plane_sets, coeffs
             torch.cuda.empty_cache()
-            try:
-                decode = decode_leg(hip_only=args.decode_hip_only)
-            except Exception as e:
-                decode = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(log2, bd)
             except Exception as e:      # the baseline is reporting only; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        if decode is not None:
-            out["decode"] = decode
+        if world == 1 and not args.no_decode:
+            try:
+                out["decode"] = decode_leg(hip_only=args.decode_hip_only)
+            except Exception as e:
+                out["decode"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
