@@ -203,3 +203,17 @@ def test_band_sao_above_the_range_is_counted_and_wraps(oracle, wide):
     expect = sum(1 for y, x in hits if y < int(j["h"][0]))
     assert expect <= n <= 2 * expect, n                              # the wide kernel counts per pair of samples
     assert lib.ohevc_debug_sao_band_above_range(0) == 0
+
+
+def test_device_copy_kernel():
+    """ohevc_dev_copy: the launch that makes the deblocked copy SAO reads (sizes from one 16-byte piece to several launches' worth of grid-stride)."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    lib = L.load_library()
+    for nbytes in (16, 4096, 3 * 1920 * 1088 // 2 // 16 * 16, (256 * 16 * 256 + 5) * 16):
+        src = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+        d_src, d_dst = G.to_dev(src), G.zeros_dev(nbytes + 16, np.uint8)
+        L.check(lib.ohevc_dev_copy(C.c_void_p(d_dst.data_ptr()), C.c_void_p(d_src.data_ptr()), C.c_size_t(nbytes), C.c_void_p(G.stream())))
+        G.sync()
+        out = G.to_host(d_dst, np.uint8)
+        assert np.array_equal(out[:nbytes], src) and not out[nbytes:].any()
