@@ -66,6 +66,19 @@ def test_golden_stream_decodes_to_recorded_md5(name):
     assert frames_md5(out) == md5
 
 
+@pytest.mark.skipif(not ps.have("sse"), reason="oracle/_ref/libopenhevc_sse.so not built (needs /root/reference)")
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_sse_decoder_matches_recorded_md5(name):
+    """The reference AS SHIPPED ON x86 (oracle/_ref/libopenhevc_sse.so: ARCH_X86 1, the SSE4 intrinsics of libavcodec/x86/hevcdsp_init.c:403-640
+    and x86/hevcpred_init.c:31-41 wired in, deblocking forwarded to C because there is no yasm here - oracle/sse_stubs.c) is the CPU baseline
+    beside every whole-decoder number: pinned, picture for picture, to what the pure-C decoder outputs on every golden stream.  Above 10 bit
+    and for 4:2:2 / 4:4:4 its init leaves the C functions in place (x86/hevcdsp_init.c only knows depths 8 and 10)."""
+    aus, md5 = load_golden(name)
+    out = ps.decode_stream("sse", aus)
+    assert len(out) == CASES[name]["nframes"]
+    assert frames_md5(out) == md5
+
+
 @needs_gen
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_generator_is_deterministic_and_pinned(name):

@@ -26,9 +26,22 @@ def decode(threads, natural):
     passes = int(os.environ.get("DIAG_PASSES", "4"))                 # the stream several times through ONE decoder: steady state
     best = None
     for _ in range(2):
-        t = time.perf_counter()
-        out = ps.decode_stream("hip", aus * passes, threads, 1)
-        dt = time.perf_counter() - t
+        # (no picture is copied out into Python: ps.decode_stream's per-picture numpy copies cap the main thread at ~1500 pictures a second
+        # and were what the first overlap profiles of round 3 measured)
+        with ps.Decoder("hip", threads, 1) as d:
+            t = time.perf_counter()
+            n = 0
+            for i, au in enumerate(aus * passes):
+                r = d.L.ohdec_decode(d.h, au, len(au), i + 1)
+                assert r >= 0, r
+                n += r
+            while True:
+                r = d.L.ohdec_flush(d.h)
+                if r <= 0:
+                    break
+                n += r
+            dt = time.perf_counter() - t
+        out = [None] * n
         best = dt if best is None else min(best, dt)
     print(json.dumps(dict(threads=threads, natural=bool(natural), passes=passes, pictures=len(out), fps=round(len(out) / best, 1))))
 
@@ -83,8 +96,38 @@ def chain(db):
                               mean_gap_to_next_on_stream_us=round(gap / ng / 1e3, 2) if ng else None)))
 
 
+def dump(db, out):
+    """The whole trace as a compact gzip'd CSV: kernel dispatches (k), memory copies (m) and - when the HIP runtime was traced - API calls (a):
+    start, end, queue / thread, stream, kind, name."""
+    import gzip
+    import re
+    import sqlite3
+    con = sqlite3.connect(db)
+    names = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+    info = {}
+    with gzip.open(out, "wt") as f:
+        for s, e, q, st, name in con.execute("select start, end, queue_id, stream_id, name from kernels order by start"):
+            short = re.sub(r"<.*", "", name.split("ohevc::")[-1]).split("(")[0][-40:]
+            f.write(f"{s},{e},{q},{st},k,{short}\n")
+        for v, kind in (("memory_copies", "m"), ("regions", "a")):
+            if v not in names:
+                continue
+            cols = [c[1] for c in con.execute(f"pragma table_info({v})")]
+            info[v] = cols
+            want = [c for c in ("start", "end", "tid", "queue_id", "stream_id", "name", "size") if c in cols]
+            try:
+                for row in con.execute(f"select {','.join(want)} from {v} order by start"):
+                    d = dict(zip(want, row))
+                    f.write(f"{d.get('start')},{d.get('end')},{d.get('tid', d.get('queue_id'))},{d.get('stream_id')},{kind},{d.get('name')}:{d.get('size', '')}\n")
+            except Exception as ex:      # a view whose base tables are missing in this trace
+                info[v + "_error"] = str(ex)
+    print(json.dumps(dict(tables=[n for n in names if not n.startswith("rocpd_")][:40], columns=info)))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "chain":
+    if sys.argv[1] == "dump":
+        dump(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "chain":
         chain(sys.argv[2])
     elif sys.argv[1] == "decode":
         decode(int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "natural")
