@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-hip-only", action="store_true", help="decode block: only the HIP rows (A/B runs of the back end's switches)")
     ap.add_argument("--no-decode", action="store_true", help="skip the whole-decoder leg (BASELINE config 3 geometry) that N=1 runs add to the line")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel rows of the other kernel families (the `kernels` object N=1 runs add to the line)")
     ap.add_argument("--no-zscan", action="store_true", help="skip the second timed loop over the CTB-major (z-scan) job list")
     ap.add_argument("--check-blocks", type=int, default=512, help="output blocks verified bit-exactly against the oracle after the timed loops")
     ap.add_argument("--sparse", action="store_true", help="decoder-like coefficients: non-zeros only in the top-left 8x8")
@@ -178,10 +179,16 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
         hip_mt = ps.decode_stream("hip", aus, threads, 1)
         same = lambda a, b: len(a) == len(b) and all(np.array_equal(x, y) for fa, fb in zip(a, b) for x, y in zip(fa, fb))
         row = {"bytes_per_picture": sum(map(len, aus)) // len(aus), "bit_exact": bool(same(ref, hip)), f"bit_exact_{threads}_frame_threads": bool(same(ref, hip_mt))}
+        if ps.have("sse") and not hip_only:
+            row["reference_sse_equals_reference_c"] = bool(same(ref, ps.decode_stream("sse", aus)))
         mp = W * H * pictures / 1e6
         sec, cnt = C.c_double(), (C.c_longlong * 8)()
         for label, kind, th in (("hip_1thread", "hip", 1), (f"hip_{threads}frame_threads", "hip", threads),
                                 ("reference_c_1thread", "c", 1), (f"reference_c_{threads}frame_threads", "c", threads),
+                                # the reference AS SHIPPED ON x86 (oracle/_ref/libopenhevc_sse.so: SSE4 intrinsics for the inverse transforms, all
+                                # motion-compensation variants, SAO and planar / angular intra prediction, x86/hevcdsp_init.c:403-640; deblocking
+                                # runs as C because the image has no yasm): the CPU baseline every HIP row is to be read against
+                                ("reference_sse_1thread", "sse", 1), (f"reference_sse_{threads}frame_threads", "sse", threads),
                                 # the same front end with EMPTY tables (oracle/null_hooks.c: no pixels at all): what no table back end can beat
                                 ("front_end_only_1thread", "null", 1), (f"front_end_only_{threads}frame_threads", "null", threads),
                                 # ... and with the reference's own waits between frame threads kept (rows reported as they are parsed)
@@ -214,6 +221,9 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
     nat = out["streams"]["natural"]
     out["fps"], out["mpixel_per_s"] = nat["hip_1thread"]["fps"], nat["hip_1thread"]["mpixel_per_s"]
     out["bit_exact"] = all(v["bit_exact"] and v[f"bit_exact_{threads}_frame_threads"] for v in out["streams"].values())
+    out["cpu_baseline_note"] = ("reference_sse_* = the reference decoder as shipped on x86 (ARCH_X86 1, SSE2..SSE4.2 intrinsics wired in by libavcodec/x86/hevcdsp_init.c "
+                                "and hevcpred_init.c, inline-assembly CABAC), built by oracle/Makefile from the sources in place; its deblocking runs as C (no yasm in "
+                                "the image: oracle/sse_stubs.c); reference_c_* = the same sources with ARCH_X86 0")
     out["floor"] = ("device_floor_ms = algorithmic HBM bytes of the picture's jobs (SURVEY 8d per-unit figures, summed by the recorder) / 8 TB/s; "
                     "pcie_floor_ms = (job upload + plane copy-back) / 64 GB/s; floor_frac = their sum / the frame-end hook's wall time")
     return out
@@ -514,6 +524,17 @@ def main():
             # block used to start right behind the release, and its first stream ran 10-25 % slower than the same stream a second later
             # (frame-end hook 0.86 instead of 0.54 ms) - the unmapping of ~250 GB goes on in the background for a while
             del plane_ring, plane_sets, coeffs
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_kernels:
+            # every other kernel family of the hot path out of HBM-resident rings (>= 1 GiB each), 8 and 10 bit, each row with a sampled bit-exact
+            # check against the CPU oracle: tools/kernel_rows.py (timed with HIP events on the launch stream, like the headline)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import kernel_rows
+                from oracle import pyoracle as po
+                out["kernels"] = kernel_rows.run(po.load("oracle"), po)
+            except Exception as e:
+                out["kernels"] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             try:

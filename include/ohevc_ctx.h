@@ -66,6 +66,9 @@ int  ohevc_pic_download_planes(ohevc_ctx *ctx, int slot, void *const host[3], co
  * ohevc_host_unpin_all before the application frees the memory (the decoder: before avcodec_close). */
 int  ohevc_host_pin(ohevc_ctx *ctx, void *ptr, size_t bytes);
 int  ohevc_host_unpin_all(ohevc_ctx *ctx);
+/* ... or of one allocation only (every registered range overlapping it): the application returned THAT memory to its allocator, e.g. the decoder's
+ * buffer pool changed geometry and a buffer address came back with another size.  Copies into other ranges that are in flight are not disturbed. */
+int  ohevc_host_unpin(ohevc_ctx *ctx, void *ptr, size_t bytes);
 /* Frame-parallel decoding across GPUs (one process per GPU; the reference's counterpart is the shared DPB of its frame threads,
  * pthread_frame.c:479-513 + hevc_await_progress hevc.c:1951-1958): the owner of a picture copies a finished plane out with
  * ohevc_pic_export, the other processes copy it into their own store with ohevc_pic_import; the transport in between (RCCL

@@ -101,6 +101,11 @@ int ohevc_debug_filters(struct ohevc_ctx *ctx, const struct ohevc_dbk_job **vert
                         int *n_horizontal, const struct ohevc_sao_job **sao, int *n_sao, struct ohevc_sao_bypass *bypass /* HOST map */);
 /* block until the frame that reconstructs picture `slot` has ended (frame threads: another context of the store) */
 int ohevc_debug_wait_picture(struct ohevc_ctx *ctx, int slot);
+/* The file-system rendezvous of the native transport's RCCL wire (ohevc_frames.h) without RCCL: rank 0 hands the 128 bytes in `id` to the
+ * other ranks (who receive them in `id`), through `path`, with the nonce handshake that keeps a file of an earlier run from being accepted.
+ * Tests only. */
+int ohevc_debug_frames_rendezvous(const char *path, int rank, int world, int timeout_s, unsigned char id[128]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,8 +51,10 @@ enum { OHEVC_FRAMES_WIRE_RCCL = 0, OHEVC_FRAMES_WIRE_SOCKETS = 1 };
 typedef struct ohevc_frames_transport ohevc_frames_transport;
 
 /* rank / world: this process and the number of processes; device: the GPU this process decodes on (RCCL: one per rank).
- * rendezvous: RCCL: the path of a file (on storage all ranks see) through which rank 0 hands its ncclUniqueId to the others, created by
- * rank 0 and removed by ohevc_frames_transport_destroy; sockets: "host:port" - rank r listens on port + r of `host`.
+ * rendezvous: RCCL: the path of a file (on storage all ranks see) through which rank 0 hands its ncclUniqueId to the others - every rank
+ * first leaves a nonce in <path>.ready.<rank> and only accepts an id file that carries it, so a file left behind by a crashed run is never
+ * mistaken for this run's; all of these files are removed once the communicator exists; sockets: "host:port" - all ranks run on `host`,
+ * rank r listens on port + r of that address only, and a peer must present the run's token (OHEVC_FRAMES_TOKEN, or derived from this string).
  * timeout_s: how long a rank waits for its peers (rendezvous, a connection, a message) before it gives up with an error. */
 int  ohevc_frames_transport_create(ohevc_frames_transport **out, int rank, int world, int device, int wire, const char *rendezvous, int timeout_s);
 /* the callback table to hand to ohhip_set_frames_mode (valid until the transport is destroyed) */
@@ -60,6 +62,12 @@ const ohhip_frames_mode *ohevc_frames_transport_mode(ohevc_frames_transport *t);
 /* every collective this rank issued has completed (call on all ranks after the last picture, before destroying) */
 int  ohevc_frames_transport_finish(ohevc_frames_transport *t);
 void ohevc_frames_transport_destroy(ohevc_frames_transport *t);
+/* One picture through the wire, called by EVERY rank: `root` sends the picture in its src_slot and the mvf_bytes at mvf_in; every rank, the
+ * root included, receives into its dst_slot (same geometry) and mvf_out.  Exactly the steps of publish on the owner and subscribe + await on
+ * the others; a start-up check of the wire - and with world 1, where the decoder never exchanges a picture, what executes the RCCL calls
+ * (ncclCommInitRank, one ncclGroup of four ncclBroadcast on device memory) on a single GPU (tests/test_dist_gpu.py). */
+int  ohevc_frames_transport_selftest(ohevc_frames_transport *t, ohevc_ctx *ctx, int src_slot, int dst_slot, int root, const void *mvf_in, void *mvf_out,
+                                     size_t mvf_bytes);
 typedef struct ohevc_frames_stats { long long published, subscribed, awaited_motion, awaited_planes, released, failed, bytes; } ohevc_frames_stats;
 int  ohevc_frames_transport_stats(ohevc_frames_transport *t, ohevc_frames_stats *out);
 

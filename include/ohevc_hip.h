@@ -359,9 +359,10 @@ int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_depth, cons
 int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals,
                                  const int32_t count_by_size[4], const int16_t *coeffs, void *stream);
 
-/* A run of consecutive NARROW dependency levels in one launch: every level must fit one workgroup of ohevc_intra_chain_max_waves()
- * wavefronts (16 blocks of 4x4, 8 of 8x8, 4 of 16x16 or 2 of 32x32 per wavefront; first_wave[4] <= that many) and is handed to the next one inside the kernel (workgroup barrier + L1
- * invalidate: all of a level's wavefronts run on one CU), so a level costs three memory round trips instead of a kernel boundary.
+/* A run of consecutive NARROW dependency levels in one launch: ONE workgroup of ohevc_intra_chain_workgroup_waves() wavefronts (16 blocks of
+ * 4x4, 8 of 8x8, 4 of 16x16 or 2 of 32x32 per wavefront) takes level after level and hands each to the next inside the kernel (workgroup
+ * barrier + L1 invalidate: all of a level's wavefronts run on one CU), so a level costs its memory round trips instead of a kernel boundary.
+ * A level of more wavefronts than the workgroup has (first_wave[4] up to ohevc_intra_chain_max_waves()) takes further passes of the workgroup.
  * levels[l] (DEVICE array, 16-byte aligned) describes level l like ohevc_dev_intra_recon_sorted's arguments: its jobs sorted by size,
  * njobs[k] blocks of (4 << k) samples, first_wave[k] = running wavefront count, jobs / residuals found at base + 16 * jobs_off16 /
  * res_off16 (res_off16 = 0xffffffff: prediction only).  Same results as one ohevc_dev_intra_recon_sorted launch per level. */
@@ -372,6 +373,7 @@ typedef struct ohevc_intra_chain_level {   /* 48 bytes */
     int32_t  reserved;
 } ohevc_intra_chain_level;
 int ohevc_intra_chain_max_waves(void);
+int ohevc_intra_chain_workgroup_waves(void);
 int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                           const int16_t *coeffs, void *stream);
 

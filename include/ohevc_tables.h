@@ -138,6 +138,9 @@ int  ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot);
 /* frame end: run everything; with download != 0 the final planes are copied back into the registered host buffers
  * (needed wherever the CPU still reads pixels: output, MD5 check hevc.c:4146-4181) */
 int  ohevc_tables_end_frame(ohevc_ctx *ctx, int download);
+/* the same; *issued_at (may be NULL) = CLOCK_MONOTONIC seconds at which the issue of the frame end was over - the rest of the call is the
+ * wait for the device and the copy-back (per-picture timelines: integration/hip_backend.h, trace_path) */
+int  ohevc_tables_end_frame2(ohevc_ctx *ctx, int download, double *issued_at);
 /* The same, with the host-side work of the frame end (staging, upload, launches) on the store's issuer thread: returns at once
  * (ohevc_frame_end_async, ohevc_ctx.h).  For decoders with frame threads.  With download != 0 the copy-back into the registered host
  * planes is queued behind the picture's device work; ohevc_tables_fetch_picture(ctx, slot) - where the application takes the picture

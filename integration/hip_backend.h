@@ -1,0 +1,68 @@
+/*
+ * integration/hip_backend.h -- what the APPLICATION side of openHEVC (gpac/modules/openhevc_dec/openHevcWrapper.c, main_hm/main.c) calls to
+ * give a decoder instance the gfx950 back end: one ohhip_backend per AVCodecContext it opens.
+ *
+ * The reference's public API opens several decoders per handle (openHevcWrapper.c:27,47-93: MAX_DECODERS 2, one AVCodecContext each) and its
+ * frame threads copy contexts (pthread_frame.c:276: the copies inherit avctx->opaque; hevc.c:4502-4513), and it configures a decoder through
+ * AVOptions set before avcodec_open2 (hevc.c:4534-4546: "decode-checksum", "decoder-id", ...).  The back end follows that shape:
+ *
+ *     ohhip_options o;
+ *     ohhip_options_default(&o);                 // environment variables only supply the defaults
+ *     o.device = 3;                              // ... everything can be chosen per decoder
+ *     ohhip_backend *be = ohhip_backend_new(&o);
+ *     ohhip_backend_attach(be, avctx);           // BEFORE avcodec_open2 (sets avctx->opaque, which every thread copy inherits)
+ *     avcodec_open2(avctx, codec, NULL);
+ *     ... avcodec_decode_video2(avctx, frame, &got, &pkt); ohhip_backend_frame_done(be); ohhip_backend_fetch_output(be, frame->data, frame->linesize); ...
+ *     ohhip_backend_pre_close(be); avcodec_close(avctx); ohhip_backend_free(be);
+ *
+ * Every hook in hip_hooks.c finds its instance through the decoder context it is handed (s->avctx->opaque, checked against the registry of
+ * live back ends) - nothing hangs off file-scope state, so two decoders of one process, each with its own threads, never see each other's
+ * pictures, errors, modes or device.  A decoder nobody attached a back end to gets the process default (created on first use from the
+ * environment defaults; this is what a three-line patch of the reference gets).
+ */
+#ifndef OHHIP_BACKEND_H
+#define OHHIP_BACKEND_H
+#include <stdint.h>
+#include <stddef.h>
+#include "ohevc_ctx.h"
+#include "ohevc_frames.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct AVCodecContext;
+typedef struct ohhip_backend ohhip_backend;
+
+typedef struct ohhip_options {
+    int device;              /* HIP device ordinal of this decoder                                     (default: OHHIP_DEVICE or 0) */
+    int bulk_filters;        /* 1: the in-loop filter drivers in bulk at the frame end, 0: per-edge calls (default 1; OHHIP_BULK_FILTERS) */
+    int defer_download;      /* 1: a picture is copied back when the application fetches it            (default 0; OHHIP_DEFER_DOWNLOAD) */
+    int pin_frames;          /* 1: page-lock the decoder's frame buffers                               (default 1; OHHIP_PIN_FRAMES) */
+    int async_issue;         /* 1: frame ends issued by the library's issuer threads                   (default 0; OHHIP_ASYNC_ISSUE) */
+    int record_only;         /* 1: no device, no pixels: host-side profiling / software-executor tests (default 0; OHHIP_RECORD_ONLY) */
+    int test_fail_index;     /* fault injection of the multi-process tests: the owner fails on this picture (default -1; OHHIP_TEST_FAIL_INDEX) */
+    const char *trace_path;  /* per-picture host timeline (parse start, hook start, issue end, hook end) written here at free (default OHHIP_TRACE_FRAMES) */
+} ohhip_options;
+
+void ohhip_options_default(ohhip_options *o);
+ohhip_backend *ohhip_backend_new(const ohhip_options *o);                 /* NULL: ohevc_last_error() says why */
+int  ohhip_backend_attach(ohhip_backend *be, struct AVCodecContext *avctx);   /* before avcodec_open2 */
+/* "frame complete, before output" for one decoding thread (with frame threads the decoder's own end-of-frame report has done it already) */
+int  ohhip_backend_frame_done(ohhip_backend *be);
+int  ohhip_backend_frame_failed(ohhip_backend *be);         /* avcodec_decode_video2 returned an error after hevc_frame_start */
+/* the application takes a picture out: with a deferred / asynchronous copy-back this is where its samples reach the host */
+int  ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const int linesize[3]);
+void ohhip_backend_pre_close(ohhip_backend *be);            /* before avcodec_close: the page locks of the frame buffers go first */
+void ohhip_backend_free(ohhip_backend *be);                 /* after the decoder and its threads are gone */
+/* frame-parallel decoding over processes (hip_frames.h): switch on (m != NULL) before the first picture; ..._install after avcodec_open2 */
+int  ohhip_backend_frames_mode(ohhip_backend *be, const ohhip_frames_mode *m);
+void ohhip_backend_frames_install(ohhip_backend *be, struct AVCodecContext *avctx);
+int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
+int  ohhip_backend_device(const ohhip_backend *be);
+int  ohhip_backend_live_count(void);                        /* back ends alive in this process (tests: open / close must not leak) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -27,17 +27,11 @@
 #include "ohevc_ctx.h"
 #include "ohevc_frames.h"
 
-/* the callback table (and a native transport that fills it: ohevc_frames_transport_*) live in the product's public header */
-
-/* switch the mode on (m != NULL) or off; call before the first picture */
-int  ohhip_set_frames_mode(const ohhip_frames_mode *m);
-/* replace avctx->execute / execute2 by versions that skip the slice data of remote pictures (call after avcodec_open2) */
-struct AVCodecContext;
-void ohhip_frames_install(struct AVCodecContext *avctx);
-/* The decoder gave up on the picture it was decoding (avcodec_decode_video2 returned an error after hevc_frame_start): the open frame is
- * aborted and, in frames mode, published as failed so that no other process waits for it.  In openHEVC proper the call belongs on the
- * error return of hevc_decode_frame (hevc.c:4138-4144). */
-int  ohdec_backend_frame_failed(void);
-/* 1 if the picture in the host frame whose luma plane is data0 was reconstructed by this process (its samples are valid here) */
-int  ohhip_frames_is_local(const unsigned char *data0);
+/* the callback table (and a native transport that fills it: ohevc_frames_transport_*) live in the product's public header; the per-decoder
+ * entry points - ohhip_backend_frames_mode (switch the mode on before the first picture), ohhip_backend_frames_install (replace
+ * avctx->execute / execute2 by versions that skip the slice data of remote pictures, after avcodec_open2), ohhip_backend_frame_failed (the
+ * decoder gave up on the picture it was decoding: the open frame is aborted and published as failed so that no other process waits for it;
+ * in openHEVC proper the call belongs on the error return of hevc_decode_frame, hevc.c:4138-4144) and ohhip_backend_frame_is_local - in
+ * hip_backend.h */
+#include "hip_backend.h"
 #endif

@@ -31,86 +31,175 @@
 
 #include "ohevc_tables.h"
 #include "ohevc_debug.h"
+#include "hip_backend.h"
 #include "hip_frames.h"
 
-/* one context per decoding thread, all sharing the root's picture store (ohevc_ctx_create_shared): frame threads
- * (pthread_frame.c) reconstruct different pictures concurrently and predict from each other's */
-static ohevc_ctx          *g_root;
-static volatile int        g_generation = 1;
-static int                 g_device;
-static __thread ohevc_ctx *t_ctx;
-static __thread int        t_frame_open;
-static __thread HEVCContext *t_s;      /* the decoder context this thread's open frame belongs to */
-static ohevc_ctx          *g_all[128];
-static int                 g_nall;
-static pthread_mutex_t     g_lock = PTHREAD_MUTEX_INITIALIZER;
-static volatile int        g_error;
-static int                 g_bulk_filters = 1;     /* OHHIP_BULK_FILTERS=0: keep the reference's filter drivers and the per-edge table calls */
-static int                 g_defer_download;       /* OHHIP_DEFER_DOWNLOAD=1: copy a picture back when the application fetches it, not when it ends */
-static int                 g_pin_frames = 1;       /* OHHIP_PIN_FRAMES=0: leave the decoder's frame buffers pageable */
-static int                 g_async;                /* OHHIP_ASYNC_ISSUE=1: frame ends issued by the library's issuer threads instead of the decoding
-                                                      thread.  Off by default: measured slower with 16 frame threads (profiles/r03j_*) */
-static double              g_issuer_s0;            /* issuer seconds / frames at the last profile call */
-static long long           g_issuer_f0;
-static volatile int        g_async_used;           /* some frame end went through the issuer: fetch_output waits for copy-backs */
-static double              g_end_frame_s;      /* wall time inside ohevc_tables_end_frame (upload, launches, drain, copy-back) */
-static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
-static long long           g_alg_bytes;        /* algorithmic HBM bytes of the recorded jobs (ohevc_frame_stats.alg_bytes), same period */
-
-/* host buffer -> picture-store slot.  Keyed by the luma plane address: libavcodec's buffer pool hands a buffer out
- * again only once no frame references it, so a known address means "the picture that lived there is dead". */
+/* ---- per-instance state (design 1).  Everything that used to hang off file scope lives in one ohhip_backend per decoder
+ * instance; the hooks reach it through the decoder context they are handed (s->avctx->opaque: pthread_frame.c:276 copies it into every
+ * frame-thread context) after checking it against the registry of live back ends.  File scope keeps only: that registry, the process
+ * default for decoders nobody attached a back end to, and process-wide profiling counters. */
 #define MAX_BUFS 120
-static struct {
+#define MAX_TRACE 8192
+typedef struct ohhip_buf {
     const uint8_t *data0;
     int slot, w, h, bd, fmt;
     int poc, seq;              /* the picture that lives in the buffer: HEVCFrame.poc / .sequence when it was registered */
     ohevc_ctx *ctx;            /* the context that is reconstructing (or last reconstructed) this picture */
     /* frame-parallel decoding over processes (hip_frames.h): decoding-order index, owned elsewhere, what has arrived */
     int index, remote, have_motion, have_planes;
-} g_bufs[MAX_BUFS];
-static int g_nbufs;
+    /* the page-locked allocations behind this frame (AVFrame.buf[i]): unpinned when the address comes back with another geometry */
+    void *pin_ptr[3];
+    size_t pin_bytes[3];
+} ohhip_buf;
 
-static ohhip_frames_mode   g_fm;
-static int                 g_fm_on;
-static int                 g_fm_index;     /* pictures started so far (decoding order; one decoding thread in this mode) */
+typedef struct ohhip_trace_rec { int tid, poc; double t_start, t_hook, t_issued, t_end; } ohhip_trace_rec;
+
+struct ohhip_backend {
+    uint32_t           magic;
+    unsigned           id;             /* never reused: thread-local caches name (pointer, id) */
+    ohhip_options      opt;
+    ohevc_ctx         *root;           /* owns the picture store; one context per decoding thread shares it (ohevc_ctx_create_shared) */
+    ohevc_ctx         *all[128];
+    int                nall;
+    pthread_mutex_t    lock;
+    volatile int       error;          /* failures seen by threads that do not own a picture (slice workers) */
+    volatile int       async_used;     /* some frame end went through the issuer: fetch_output waits for copy-backs */
+    double             issuer_s0;
+    long long          issuer_f0;
+    ohhip_buf          bufs[MAX_BUFS];
+    int                nbufs;
+    /* frames mode (hip_frames.h) */
+    ohhip_frames_mode  fm;
+    int                fm_on, fm_index;
+    int (*execute)(AVCodecContext *, int (*)(AVCodecContext *, void *), void *, int *, int, int);
+    int (*execute2)(AVCodecContext *, int (*)(AVCodecContext *, void *, int, int), void *, int *, int);
+    /* OHHIP_TRACE_FRAMES: host timeline of every picture */
+    ohhip_trace_rec   *trace;
+    int                ntrace;
+    struct ohhip_backend *next;
+};
+#define OHHIP_MAGIC 0x6f686862u
+
+static pthread_mutex_t     g_reg_lock = PTHREAD_MUTEX_INITIALIZER;
+static ohhip_backend      *g_backends;             /* live back ends */
+static ohhip_backend      *g_default;              /* for decoders without an attached back end (ohdec_backend_open / first use) */
+static volatile unsigned   g_epoch = 1;            /* bumped whenever the registry changes: invalidates the per-thread look-up caches */
+static unsigned            g_next_id = 1;
+/* process-wide profiling counters (all instances; ohdec_backend_profile) */
+static pthread_mutex_t     g_prof_lock = PTHREAD_MUTEX_INITIALIZER;
+static double              g_end_frame_s;      /* wall time inside the frame-end hook (upload, launches, drain, copy-back) */
+static long long           g_counts[8];        /* frames, launches, tu, mc, intra, dbk, sao jobs, upload bytes */
+static long long           g_alg_bytes;        /* algorithmic HBM bytes of the recorded jobs (ohevc_frame_stats.alg_bytes), same period */
+
+/* ---- what the calling thread is doing right now ---- */
+static __thread ohhip_backend *t_be;   /* the instance of this thread's open frame */
+static __thread ohevc_ctx *t_ctx;
+static __thread int        t_frame_open;
+static __thread int        t_error;    /* a hook of the OPEN frame failed on this thread: reported by this picture's frame end, nobody else's */
+static __thread HEVCContext *t_s;      /* the decoder context this thread's open frame belongs to */
 static __thread int        t_remote;       /* the picture being parsed is reconstructed by another process: skip its slice data */
-static __thread int        t_publish;      /* the open frame is exchanged at its end (index of its g_bufs entry + 1) */
+static __thread int        t_publish;      /* the open frame is exchanged at its end (index of its bufs entry + 1) */
 static __thread int        t_publish_index;        /* its decoding-order index and the size of its motion field: what a failure report needs */
 static __thread size_t     t_publish_mvf_bytes;
-static int (*g_execute)(AVCodecContext *, int (*)(AVCodecContext *, void *), void *, int *, int, int);
-static int (*g_execute2)(AVCodecContext *, int (*)(AVCodecContext *, void *, int, int), void *, int *, int);
+static __thread double     t_trace_start;
+static __thread int        t_trace_poc;
+/* this thread's context in each instance it has decoded for (an application thread may drive several one-thread decoders in turn) */
+static __thread struct { ohhip_backend *be; unsigned id; ohevc_ctx *ctx; } t_ctxs[4];
+/* look-up cache: the decoder context this thread was last asked about */
+static __thread struct { const void *avctx; unsigned epoch; ohhip_backend *be; } t_seen;
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+static ohhip_backend *default_backend(void);
+
+/* the instance a decoder context belongs to: avctx->opaque if it names a live back end, else the process default */
+static ohhip_backend *backend_of(const AVCodecContext *avctx)
+{
+    ohhip_backend *b, *found = NULL;
+    if (avctx && t_seen.avctx == avctx && t_seen.epoch == g_epoch)
+        return t_seen.be;
+    pthread_mutex_lock(&g_reg_lock);
+    for (b = g_backends; b && avctx; b = b->next)
+        if ((void *)b == avctx->opaque)
+            found = b;
+    pthread_mutex_unlock(&g_reg_lock);
+    if (!found)
+        found = default_backend();
+    if (avctx) {
+        t_seen.avctx = avctx; t_seen.epoch = g_epoch; t_seen.be = found;
+    }
+    return found;
+}
+
+static void note_error(ohhip_backend *be)
+{
+    /* the picture's own thread marks its picture; anybody else (slice workers record into a picture they do not own) marks the instance */
+    if (t_frame_open)
+        t_error = 1;
+    else if (be)
+        be->error = 1;
+}
 
 int ohdec_backend_frame_done(void);
-int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
 
 /* frames mode: every rank issues exactly one collective per exchanged picture.  A picture its owner cannot complete is published all the
  * same, marked failed (hip_frames.h), so that the subscribers' receives complete and their waits fail at once instead of hanging. */
-static void publish_failed(void)
+static void publish_failed(ohhip_backend *be)
 {
     const int i = t_publish - 1;
     t_publish = 0;
-    if (i < 0 || !g_fm_on)
+    if (i < 0 || !be || !be->fm_on)
         return;
-    if (g_fm.publish(g_fm.user, t_publish_index, t_ctx, g_bufs[i].slot, NULL, t_publish_mvf_bytes, 1) != 0)
+    if (be->fm.publish(be->fm.user, t_publish_index, t_ctx, be->bufs[i].slot, NULL, t_publish_mvf_bytes, 1) != 0)
         fprintf(stderr, "ohhip: publishing the failure of picture %d failed: %s\n", t_publish_index, ohevc_last_error());
 }
 
-static ohevc_ctx *thread_ctx(void)
+/* this thread's context in instance `be` (created on first use; all of them share the root's picture store) */
+static ohevc_ctx *thread_ctx(ohhip_backend *be)
 {
-    if (t_ctx || !g_root)
-        return t_ctx;
-    if (ohevc_ctx_create_shared(&t_ctx, g_device, g_root) != OHEVC_OK || ohevc_tables_bind(t_ctx) != OHEVC_OK ||
+    int k, free_k = -1;
+    ohevc_ctx *ctx = NULL;
+    if (!be || !be->root)
+        return NULL;
+    for (k = 0; k < 4; k++) {
+        if (t_ctxs[k].be == be && t_ctxs[k].id == be->id)
+            return t_ctxs[k].ctx;
+        if (free_k < 0 && !t_ctxs[k].be)
+            free_k = k;
+    }
+    if (free_k < 0) {             /* four other instances used this thread before: forget the dead ones, else the oldest */
+        unsigned live[4] = {0, 0, 0, 0};
+        ohhip_backend *b;
+        pthread_mutex_lock(&g_reg_lock);
+        for (b = g_backends; b; b = b->next)
+            for (k = 0; k < 4; k++)
+                if (t_ctxs[k].be == b && t_ctxs[k].id == b->id)
+                    live[k] = 1;
+        pthread_mutex_unlock(&g_reg_lock);
+        for (k = 0; k < 4 && free_k < 0; k++)
+            if (!live[k])
+                free_k = k;
+        if (free_k < 0)
+            free_k = 0;           /* (its context stays registered in its instance and dies with it) */
+    }
+    if (ohevc_ctx_create_shared(&ctx, be->opt.device, be->root) != OHEVC_OK ||
         /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
-        ohevc_tables_emulate_filter_lag(t_ctx, 1) != OHEVC_OK) {
+        ohevc_tables_bind(ctx) != OHEVC_OK || ohevc_tables_emulate_filter_lag(ctx, 1) != OHEVC_OK) {
         fprintf(stderr, "ohhip: per-thread context failed: %s\n", ohevc_last_error());
-        g_error = 1;
+        note_error(be);
         return NULL;
     }
-    pthread_mutex_lock(&g_lock);
-    if (g_nall < 128)
-        g_all[g_nall++] = t_ctx;
-    pthread_mutex_unlock(&g_lock);
-    return t_ctx;
+    pthread_mutex_lock(&be->lock);
+    if (be->nall < 128)
+        be->all[be->nall++] = ctx;
+    pthread_mutex_unlock(&be->lock);
+    t_ctxs[free_k].be = be; t_ctxs[free_k].id = be->id; t_ctxs[free_k].ctx = ctx;
+    return ctx;
 }
 
 /* ---- the reference's own entry points (their call sites in hevc.c were renamed, the definitions were not) ---- */
@@ -146,7 +235,7 @@ static void intra_pred_hip(HEVCContext *s, int x0, int y0, int log2_size, int c_
                                     c_idx ? lc->tu.intra_pred_mode_c : lc->tu.intra_pred_mode,
                                     lc->na.cand_bottom_left, lc->na.cand_left, lc->na.cand_up_left,
                                     lc->na.cand_up, lc->na.cand_up_right) != OHEVC_OK)
-        g_error = 1;
+        note_error(backend_of(s->avctx));
 }
 #define STUB(n) static void intra_pred_##n(HEVCContext *s, int x0, int y0, int c) { intra_pred_hip(s, x0, y0, n, c); }
 STUB(2) STUB(3) STUB(4) STUB(5)
@@ -160,46 +249,62 @@ void ohhip_hevc_pred_init(HEVCPredContext *hpc, int bit_depth)
     hpc->intra_pred[3] = intra_pred_5;
 }
 
-/* the picture-store slot of a host frame (allocated on first sight or when the geometry of the buffer changed).  `tag` names the
- * picture that lives in the buffer now: poc + sequence counter.  Returns the g_bufs index with g_lock HELD, or -1 (unlocked). */
-static int slot_of_frame_locked(ohevc_ctx *ctx, const HEVCContext *s, const AVFrame *f, int *fresh)
+/* the picture-store slot of a host frame (allocated on first sight or when the geometry of the buffer changed).  Returns the bufs
+ * index with be->lock HELD, or -1 (unlocked). */
+static int slot_of_frame_locked(ohhip_backend *be, ohevc_ctx *ctx, const HEVCContext *s, const AVFrame *f, int *fresh)
 {
-    int i, slot, cfmt = s->sps->chroma_array_type ? s->sps->chroma_array_type : 1;
-    pthread_mutex_lock(&g_lock);
-    for (i = 0; i < g_nbufs; i++)
-        if (g_bufs[i].data0 == f->data[0])
+    int i, k, slot, cfmt = s->sps->chroma_array_type ? s->sps->chroma_array_type : 1;
+    pthread_mutex_lock(&be->lock);
+    for (i = 0; i < be->nbufs; i++)
+        if (be->bufs[i].data0 == f->data[0])
             break;
-    if (i < g_nbufs && (g_bufs[i].w != s->sps->width || g_bufs[i].h != s->sps->height ||
-                        g_bufs[i].bd != s->sps->bit_depth || g_bufs[i].fmt != cfmt)) {
-        ohevc_tables_unregister_picture(ctx, g_bufs[i].slot);
-        ohevc_pic_release(ctx, g_bufs[i].slot);
-        ohevc_host_unpin_all(ctx);                  /* the decoder dropped its buffer pool with the old geometry: forget the page locks */
-        g_bufs[i] = g_bufs[--g_nbufs];
-        i = g_nbufs;
+    if (i < be->nbufs && (be->bufs[i].w != s->sps->width || be->bufs[i].h != s->sps->height ||
+                          be->bufs[i].bd != s->sps->bit_depth || be->bufs[i].fmt != cfmt)) {
+        ohevc_tables_unregister_picture(ctx, be->bufs[i].slot);
+        ohevc_pic_release(ctx, be->bufs[i].slot);
+        /* The decoder dropped its buffer pool with the old geometry and this address came back from the allocator: the page locks taken for
+         * the OLD picture of this buffer go - only those.  (Round 3 dropped every page lock of the store here, under frame threads while
+         * other threads' copy-backs into their still-living buffers were in flight.)  Nobody copies into this buffer now: the decoder
+         * recycles a buffer only after the application has let go of the picture. */
+        for (k = 0; k < 3; k++)
+            if (be->bufs[i].pin_ptr[k])
+                ohevc_host_unpin(ctx, be->bufs[i].pin_ptr[k], be->bufs[i].pin_bytes[k]);
+        be->bufs[i] = be->bufs[--be->nbufs];
+        i = be->nbufs;
     }
-    *fresh = i == g_nbufs;
-    if (i == g_nbufs) {
-        slot = g_nbufs < MAX_BUFS ? ohevc_pic_alloc(ctx, s->sps->width, s->sps->height, cfmt, s->sps->bit_depth) : -1;
+    *fresh = i == be->nbufs;
+    if (i == be->nbufs) {
+        slot = be->nbufs < MAX_BUFS ? ohevc_pic_alloc(ctx, s->sps->width, s->sps->height, cfmt, s->sps->bit_depth) : -1;
         if (slot < 0) {
-            pthread_mutex_unlock(&g_lock);
+            pthread_mutex_unlock(&be->lock);
             fprintf(stderr, "ohhip: pic_alloc failed: %s\n", ohevc_last_error());
-            g_error = 1;
+            note_error(be);
             return -1;
         }
-        g_bufs[i].data0 = f->data[0];
-        g_bufs[i].slot = slot;
-        g_bufs[i].w = s->sps->width;
-        g_bufs[i].h = s->sps->height;
-        g_bufs[i].bd = s->sps->bit_depth;
-        g_bufs[i].fmt = cfmt;
-        g_bufs[i].poc = INT_MIN;
-        g_bufs[i].seq = -1;
-        g_bufs[i].index = -1;
-        g_bufs[i].remote = 0;
-        g_bufs[i].have_motion = g_bufs[i].have_planes = 1;
-        g_nbufs++;
+        memset(&be->bufs[i], 0, sizeof(be->bufs[i]));
+        be->bufs[i].data0 = f->data[0];
+        be->bufs[i].slot = slot;
+        be->bufs[i].w = s->sps->width;
+        be->bufs[i].h = s->sps->height;
+        be->bufs[i].bd = s->sps->bit_depth;
+        be->bufs[i].fmt = cfmt;
+        be->bufs[i].poc = INT_MIN;
+        be->bufs[i].seq = -1;
+        be->bufs[i].index = -1;
+        be->bufs[i].remote = 0;
+        be->bufs[i].have_motion = be->bufs[i].have_planes = 1;
+        be->nbufs++;
     }
     return i;
+}
+
+static int find_buf_locked(ohhip_backend *be, const uint8_t *data0)
+{
+    int i;
+    for (i = 0; i < be->nbufs; i++)
+        if (be->bufs[i].data0 == data0)
+            return i;
+    return -1;
 }
 
 /* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
@@ -211,91 +316,110 @@ static __thread const HEVCContext *t_bs_direct;       /* the context whose calls
 int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
 {
     int ret = ff_hevc_set_new_ref(s, frame, poc);                   /* hevc_refs.c */
+    ohhip_backend *be = backend_of(s->avctx);
     const AVFrame *f;
     ohevc_ctx *ctx;
-    int i, slot, fresh;
-    if (g_fm_on && t_publish)                   /* the previous picture of this thread never reached its frame end (a decoding error) */
-        publish_failed();
+    int i, k, slot, fresh;
+    if (be && be->fm_on && t_publish && t_be == be)    /* the previous picture of this thread never reached its frame end (a decoding error) */
+        publish_failed(be);
     if (ret < 0)
         return ret;
-    if (!(ctx = thread_ctx()))
+    if (!be || !(ctx = thread_ctx(be)))
         return AVERROR(ENOMEM);
+    /* an application thread may drive several decoders in turn: this thread's table calls belong to THIS instance's context from here on */
+    if (t_ctx != ctx && ohevc_tables_bind(ctx) != OHEVC_OK)
+        return AVERROR(EINVAL);
+    t_be = be;
+    t_ctx = ctx;
+    t_error = 0;
+    t_trace_start = be->trace ? now_s() : 0;
+    t_trace_poc = poc;
     f = s->ref->frame;
-    /* INTEGRATION.md section 3, row alloc_frame: page-lock the buffers the decoder's pool recycles (hevc_refs.c:75-114, get_buffer.c), so
-     * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once. */
-    if (g_pin_frames && ohevc_ctx_has_device(ctx))
-        for (i = 0; i < AV_NUM_DATA_POINTERS && f->buf[i]; i++)
-            if (ohevc_host_pin(ctx, f->buf[i]->data, f->buf[i]->size) != OHEVC_OK && g_pin_frames == 1) {
-                fprintf(stderr, "ohhip: frame buffers stay pageable: %s\n", ohevc_last_error());
-                g_pin_frames = 2;                  /* say it once */
-            }
-    if ((i = slot_of_frame_locked(ctx, s, f, &fresh)) < 0)
+    if ((i = slot_of_frame_locked(be, ctx, s, f, &fresh)) < 0)
         return AVERROR(ENOMEM);
-    slot = g_bufs[i].slot;
-    if (g_fm_on && g_bufs[i].remote && g_bufs[i].index >= 0 && g_fm.release) {
+    /* INTEGRATION.md section 3, row alloc_frame: page-lock the buffers the decoder's pool recycles (hevc_refs.c:75-114, get_buffer.c), so
+     * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once.  (After the
+     * slot look-up: a buffer that came back with another geometry had its old page locks dropped there.) */
+    if (be->opt.pin_frames && ohevc_ctx_has_device(ctx))
+        for (k = 0; k < 3 && k < AV_NUM_DATA_POINTERS && f->buf[k]; k++) {
+            if (be->bufs[i].pin_ptr[k] == f->buf[k]->data && be->bufs[i].pin_bytes[k] == (size_t)f->buf[k]->size)
+                continue;
+            if (ohevc_host_pin(ctx, f->buf[k]->data, f->buf[k]->size) != OHEVC_OK) {
+                if (be->opt.pin_frames == 1)
+                    fprintf(stderr, "ohhip: frame buffers stay pageable: %s\n", ohevc_last_error());
+                be->opt.pin_frames = 2;                  /* say it once */
+                break;
+            }
+            be->bufs[i].pin_ptr[k] = f->buf[k]->data;
+            be->bufs[i].pin_bytes[k] = (size_t)f->buf[k]->size;
+        }
+    slot = be->bufs[i].slot;
+    if (be->fm_on && be->bufs[i].remote && be->bufs[i].index >= 0 && be->fm.release) {
         /* the buffer last held a remote picture: whatever is still in flight for it (planes nobody predicted from, a motion field
          * nobody asked for) is waited for and freed before the slot's memory gets a new picture */
-        const int old = g_bufs[i].index;
-        g_bufs[i].index = -1;
-        pthread_mutex_unlock(&g_lock);
-        if (g_fm.release(g_fm.user, old) != 0)
-            g_error = 1;
-        pthread_mutex_lock(&g_lock);
-        for (i = 0; i < g_nbufs; i++)             /* the table may have been compacted meanwhile */
-            if (g_bufs[i].data0 == f->data[0])
-                break;
+        const int old = be->bufs[i].index;
+        be->bufs[i].index = -1;
+        pthread_mutex_unlock(&be->lock);
+        if (be->fm.release(be->fm.user, old) != 0)
+            note_error(be);
+        pthread_mutex_lock(&be->lock);
+        i = find_buf_locked(be, f->data[0]);             /* the table may have been compacted meanwhile */
+        if (i < 0) {
+            pthread_mutex_unlock(&be->lock);
+            return AVERROR(EINVAL);
+        }
     }
-    g_bufs[i].ctx = ctx;
-    g_bufs[i].poc = s->ref->poc;
-    g_bufs[i].seq = s->ref->sequence;
-    g_bufs[i].index = -1;
-    g_bufs[i].remote = 0;
-    g_bufs[i].have_motion = g_bufs[i].have_planes = 1;
+    be->bufs[i].ctx = ctx;
+    be->bufs[i].poc = s->ref->poc;
+    be->bufs[i].seq = s->ref->sequence;
+    be->bufs[i].index = -1;
+    be->bufs[i].remote = 0;
+    be->bufs[i].have_motion = be->bufs[i].have_planes = 1;
     t_remote = 0;
-    if (g_fm_on) {
+    if (be->fm_on) {
         /* a picture nothing can predict from: sub-layer non-reference (even nal_unit_type below 16, H.265 table 7-1) in the
          * highest temporal sub-layer -- it is not exchanged */
         const int exchanged = !(s->nal_unit_type < 16 && !(s->nal_unit_type & 1) && s->temporal_id == s->sps->max_sub_layers - 1);
         const size_t mvf_bytes = (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField);     /* hevc.c:178 */
-        g_bufs[i].index = g_fm_index++;
-        g_bufs[i].remote = g_bufs[i].index % g_fm.world != g_fm.rank;
+        be->bufs[i].index = be->fm_index++;
+        be->bufs[i].remote = be->bufs[i].index % be->fm.world != be->fm.rank;
         /* a picture that is not exchanged has nothing to wait for - H.265 8.3.2 only bars it from the Curr sets, a stream may keep it in
          * a Foll set of later pictures */
-        g_bufs[i].have_motion = g_bufs[i].have_planes = !g_bufs[i].remote || !exchanged;
+        be->bufs[i].have_motion = be->bufs[i].have_planes = !be->bufs[i].remote || !exchanged;
         if (!exchanged)
-            g_bufs[i].index = -1;                  /* (nothing to release either) */
-        if (g_bufs[i].remote) {
-            const int index = g_bufs[i].index;
-            pthread_mutex_unlock(&g_lock);
+            be->bufs[i].index = -1;                  /* (nothing to release either) */
+        if (be->bufs[i].remote) {
+            const int index = be->bufs[i].index;
+            pthread_mutex_unlock(&be->lock);
             t_remote = 1;
             t_frame_open = 0;
             t_s = s;
             /* later pictures name this one by its host planes (the MC wrappers' src pointers): keep the pointer -> slot map */
             if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
-                (exchanged && g_fm.subscribe(g_fm.user, index, ctx, slot, mvf_bytes) != 0)) {
+                (exchanged && be->fm.subscribe(be->fm.user, index, ctx, slot, mvf_bytes) != 0)) {
                 fprintf(stderr, "ohhip: subscribing to remote picture %d failed: %s\n", index, ohevc_last_error());
-                g_error = 1;
+                note_error(be);
                 return AVERROR(EINVAL);
             }
             return 0;
         }
         t_publish = exchanged ? i + 1 : 0;
-        t_publish_index = g_bufs[i].index;
+        t_publish_index = be->bufs[i].index;
         t_publish_mvf_bytes = mvf_bytes;
     }
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&be->lock);
     /* slice threads: the WPP-row / tile workers of this picture all record into ctx (ohhip_cabac_init binds them) */
     ohevc_tables_set_concurrent(ctx, (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
     if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)f->data, f->linesize) != OHEVC_OK ||
         ohevc_tables_begin_frame(ctx, slot) != OHEVC_OK) {
         fprintf(stderr, "ohhip: begin_frame failed: %s\n", ohevc_last_error());
-        g_error = 1;
+        note_error(be);
         return AVERROR(EINVAL);
     }
     t_frame_open = 1;
     t_s = s;
     if (device_bs_frame(s) == 2 && ohevc_tables_keep_motion(ctx, s->sps->log2_min_pu_size) != OHEVC_OK)     /* boundary strengths from the MC jobs */
-        g_error = 1;
+        note_error(be);
     t_bs_n = 0;
     t_bs_direct = device_bs_frame(s) && !((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1) ? s : NULL;
     return 0;
@@ -310,11 +434,12 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
 int ohhip_frame_rps(HEVCContext *s)
 {
     int ret = ff_hevc_frame_rps(s);
+    ohhip_backend *be = backend_of(s->avctx);
     ohevc_ctx *ctx;
     int t, k, c;
     if (ret < 0 || !s->ref)
         return ret;
-    if (!(ctx = thread_ctx()))
+    if (!be || !(ctx = thread_ctx(be)))
         return AVERROR(ENOMEM);
     for (t = 0; t < NB_RPS_TYPE; t++)
         for (k = 0; k < s->rps[t].nb_refs; k++) {
@@ -322,43 +447,43 @@ int ohhip_frame_rps(HEVCContext *s)
             int i, slot, fresh, known;
             if (!ref || ref == s->ref || !ref->frame || !ref->frame->data[0])
                 continue;
-            if ((i = slot_of_frame_locked(ctx, s, ref->frame, &fresh)) < 0)
+            if ((i = slot_of_frame_locked(be, ctx, s, ref->frame, &fresh)) < 0)
                 return AVERROR(ENOMEM);
-            known = !fresh && g_bufs[i].poc == ref->poc && g_bufs[i].seq == ref->sequence;
-            slot = g_bufs[i].slot;
-            if (known && g_fm_on && !t_remote && g_bufs[i].remote && !g_bufs[i].have_motion && (t == ST_CURR_BEF || t == ST_CURR_AFT || t == LT_CURR)) {
+            known = !fresh && be->bufs[i].poc == ref->poc && be->bufs[i].seq == ref->sequence;
+            slot = be->bufs[i].slot;
+            if (known && be->fm_on && !t_remote && be->bufs[i].remote && !be->bufs[i].have_motion && (t == ST_CURR_BEF || t == ST_CURR_AFT || t == LT_CURR)) {
                 /* (only pictures of the Curr sets can be the collocated picture or a prediction reference, H.265 8.3.2) */
                 /* the wait of the reference's frame threads for a collocated picture's motion field (hevc_mvs.c) */
-                const int index = g_bufs[i].index;
-                g_bufs[i].have_motion = 1;
-                pthread_mutex_unlock(&g_lock);
-                if (g_fm.await_motion(g_fm.user, index, ref->tab_mvf, (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField)) != 0) {
+                const int index = be->bufs[i].index;
+                be->bufs[i].have_motion = 1;
+                pthread_mutex_unlock(&be->lock);
+                if (be->fm.await_motion(be->fm.user, index, ref->tab_mvf, (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField)) != 0) {
                     fprintf(stderr, "ohhip: the motion field of remote picture %d did not arrive\n", index);
-                    g_error = 1;
+                    note_error(be);
                     return AVERROR(EINVAL);
                 }
                 continue;
             }
             if (!known) {
-                g_bufs[i].poc = ref->poc;
-                g_bufs[i].seq = ref->sequence;
-                g_bufs[i].ctx = ctx;
+                be->bufs[i].poc = ref->poc;
+                be->bufs[i].seq = ref->sequence;
+                be->bufs[i].ctx = ctx;
                 /* a generated reference lives here now, not the (possibly remote, possibly un-awaited) picture the buffer held before */
-                g_bufs[i].remote = 0;
-                g_bufs[i].index = -1;
-                g_bufs[i].have_motion = g_bufs[i].have_planes = 1;
+                be->bufs[i].remote = 0;
+                be->bufs[i].index = -1;
+                be->bufs[i].have_motion = be->bufs[i].have_planes = 1;
             }
-            pthread_mutex_unlock(&g_lock);
+            pthread_mutex_unlock(&be->lock);
             if (known)
                 continue;
             if (ohevc_tables_register_picture(ctx, slot, (uint8_t *const *)ref->frame->data, ref->frame->linesize) != OHEVC_OK) {
-                g_error = 1;
+                note_error(be);
                 return AVERROR(EINVAL);
             }
             for (c = 0; c < 3; c++)
                 if (ref->frame->data[c] && ohevc_pic_upload(ctx, slot, c, ref->frame->data[c], ref->frame->linesize[c]) != OHEVC_OK) {
                     fprintf(stderr, "ohhip: upload of a generated reference picture failed: %s\n", ohevc_last_error());
-                    g_error = 1;
+                    note_error(be);
                     return AVERROR(EINVAL);
                 }
         }
@@ -379,22 +504,25 @@ void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts)
         static __thread const uint8_t *seen_d0;       /* the last answer of this thread: asked once per CTB, and with frame x slice threads */
         static __thread int seen_poc, seen_seq;       /* 64 threads would queue on the lock for it */
         static __thread ohevc_ctx *seen_ctx;
-        static __thread int seen_gen;                 /* contexts die with their decoder: g_generation changes at every open / close */
+        static __thread unsigned seen_epoch;          /* contexts die with their instance: the registry's epoch changes at every open / close */
         ohevc_ctx *ctx = NULL;
         int i;
-        if (seen_gen == g_generation && seen_d0 == d0 && seen_poc == s->ref->poc && seen_seq == s->ref->sequence && seen_ctx) {
+        if (seen_epoch == g_epoch && seen_d0 == d0 && seen_poc == s->ref->poc && seen_seq == s->ref->sequence && seen_ctx) {
             ctx = seen_ctx;
         } else {
-            pthread_mutex_lock(&g_lock);
-            for (i = 0; i < g_nbufs; i++)
-                if (g_bufs[i].data0 == d0)
-                    ctx = g_bufs[i].ctx;
-            pthread_mutex_unlock(&g_lock);
-            seen_d0 = d0; seen_poc = s->ref->poc; seen_seq = s->ref->sequence; seen_ctx = ctx; seen_gen = g_generation;
+            ohhip_backend *be = backend_of(s->avctx);
+            const unsigned epoch = g_epoch;
+            if (be) {
+                pthread_mutex_lock(&be->lock);
+                if ((i = find_buf_locked(be, d0)) >= 0)
+                    ctx = be->bufs[i].ctx;
+                pthread_mutex_unlock(&be->lock);
+            }
+            seen_d0 = d0; seen_poc = s->ref->poc; seen_seq = s->ref->sequence; seen_ctx = ctx; seen_epoch = epoch;
         }
         if (ctx && ctx != t_ctx) {            /* a pool thread: it never owns a context, it borrows the picture's */
             if (ohevc_tables_bind(ctx) != OHEVC_OK)
-                g_error = 1;
+                note_error(backend_of(s->avctx));
             t_ctx = ctx;
         }
     }
@@ -437,9 +565,11 @@ static void crash_handler(int sig)
  * 16x16-CTB streams with SAO (output depends on the ORDER of the driver calls: filter lag) have that order replayed by the bulk form. */
 static int bulk_filters(const HEVCContext *s)
 {
+    const ohhip_backend *be = backend_of(s->avctx);
     /* 16x16 CTBs with SAO: the reference's output depends on the order of its driver calls (filter lag); the bulk form replays that
      * order for one decoding thread per picture, slice threads keep the drivers (their order is whatever the row threads make it) */
-    return g_bulk_filters && !(s->sps->log2_ctb_size == 4 && s->sps->sao_enabled && (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
+    return be && be->opt.bulk_filters &&
+           !(s->sps->log2_ctb_size == 4 && s->sps->sao_enabled && (s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1);
 }
 
 void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size)
@@ -512,7 +642,7 @@ void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log
         if (t_bs_n == t_bs_cap) {
             int cap = t_bs_cap ? 2 * t_bs_cap : 16384;
             ohevc_bs_call *nb = realloc(t_bs_buf, (size_t)cap * sizeof(*nb));
-            if (!nb) { g_error = 1; return; }
+            if (!nb) { note_error(t_be); return; }
             t_bs_buf = nb; t_bs_cap = cap;
         }
         b = &t_bs_buf[t_bs_n++];
@@ -527,7 +657,7 @@ void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log
     }
     if (ohevc_tables_bs_call(x0, y0, log2_trafo_size, (lc->slice_or_tiles_up_boundary & 3) | ((lc->slice_or_tiles_left_boundary & 3) << 2) |
                                                       (s->sh.slice_loop_filter_across_slices_enabled_flag ? OHEVC_BS_ACROSS_SLICES : 0)) != OHEVC_OK)
-        g_error = 1;
+        note_error(backend_of(s->avctx));
 }
 
 static int derive_filters(HEVCContext *s)
@@ -561,58 +691,168 @@ static int derive_filters(HEVCContext *s)
     return ohevc_tables_derive_filters(t_ctx, &m);
 }
 
-/* ---- called by decoder_harness.c ---- */
-int ohdec_backend_open(void)
+/* ---- instances ---- */
+void ohhip_options_default(ohhip_options *o)
 {
+    memset(o, 0, sizeof(*o));
+    o->device = getenv("OHHIP_DEVICE") ? atoi(getenv("OHHIP_DEVICE")) : 0;
+    o->bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
+    o->defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
+    o->pin_frames = !(getenv("OHHIP_PIN_FRAMES") && atoi(getenv("OHHIP_PIN_FRAMES")) == 0);
+    o->async_issue = getenv("OHHIP_ASYNC_ISSUE") ? atoi(getenv("OHHIP_ASYNC_ISSUE")) : 0;
+    o->record_only = getenv("OHHIP_RECORD_ONLY") != NULL;
+    o->test_fail_index = getenv("OHHIP_TEST_FAIL_INDEX") ? atoi(getenv("OHHIP_TEST_FAIL_INDEX")) : -1;
+    o->trace_path = getenv("OHHIP_TRACE_FRAMES");
+}
+
+ohhip_backend *ohhip_backend_new(const ohhip_options *o)
+{
+    ohhip_options def;
+    ohhip_backend *be = calloc(1, sizeof(*be));
+    if (!be)
+        return NULL;
+    if (!o) {
+        ohhip_options_default(&def);
+        o = &def;
+    }
     if (getenv("OHHIP_BACKTRACE")) {
         signal(SIGSEGV, crash_handler);
         signal(SIGABRT, crash_handler);
     }
-    if (g_root)
-        return 0;
+    be->magic = OHHIP_MAGIC;
+    be->opt = *o;
+    pthread_mutex_init(&be->lock, NULL);
     /* host-side profiling / host-logic tests without a device (include/ohevc_debug.h): record, produce no pixels.  A test may
      * have switched record-only mode on itself (and installed a frame sink) before opening the decoder: leave that alone. */
-    if (getenv("OHHIP_RECORD_ONLY"))
+    if (o->record_only)
         ohevc_debug_set_record_only(1);
-    g_defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
-    g_pin_frames = !(getenv("OHHIP_PIN_FRAMES") && atoi(getenv("OHHIP_PIN_FRAMES")) == 0);
-    g_async = getenv("OHHIP_ASYNC_ISSUE") ? atoi(getenv("OHHIP_ASYNC_ISSUE")) : 0;
-    g_bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
-    /* A/B of the executors of the intra-coded blocks (include/ohevc_debug.h): 0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture */
+    /* process-wide A/B switches of the library (include/ohevc_debug.h), kept as environment variables: the executor of the intra-coded
+     * blocks (0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture) and the host derivation of the deblocking parameters */
     ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
-    /* A/B: 0 = the deblocking parameters are derived on the host, one job per edge (default: on the device, from the maps) */
     if (getenv("OHHIP_DEVICE_FILTERS"))
         ohevc_debug_set_filters_on_device(atoi(getenv("OHHIP_DEVICE_FILTERS")));
-    /* one process per GPU (frame-parallel decoding over processes, hip_frames.h): OHHIP_DEVICE = this process's device ordinal */
-    g_device = getenv("OHHIP_DEVICE") ? atoi(getenv("OHHIP_DEVICE")) : 0;
-    if (ohevc_ctx_create(&g_root, g_device) != OHEVC_OK) {
+    if (ohevc_ctx_create(&be->root, o->device) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
-        return -1;
+        pthread_mutex_destroy(&be->lock);
+        free(be);
+        return NULL;
     }
-    g_nbufs = 0;
-    g_nall = 0;
-    g_error = 0;
-    g_async_used = 0;
-    g_issuer_s0 = 0;
-    g_issuer_f0 = 0;
-    g_generation++;
+    if (o->trace_path)
+        be->trace = calloc(MAX_TRACE, sizeof(*be->trace));
+    pthread_mutex_lock(&g_reg_lock);
+    be->id = g_next_id++;
+    be->next = g_backends;
+    g_backends = be;
+    g_epoch++;
+    pthread_mutex_unlock(&g_reg_lock);
+    return be;
+}
+
+int ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx)
+{
+    if (!be || be->magic != OHHIP_MAGIC || !avctx)
+        return -1;
+    avctx->opaque = be;          /* inherited by every frame-thread copy (pthread_frame.c:276 and the `*copy = *src` of its init) */
     return 0;
 }
 
-/* INTEGRATION.md section 3, last row: run the recorded jobs, copy the picture back for output.  Runs on the thread that
- * decoded the picture: called by the harness after avcodec_decode_video2 (one decoding thread) or from the decoder's own
- * end-of-frame progress report (frame threads, below). */
-/* ---- frame-parallel decoding over processes (hip_frames.h) ---- */
-int ohhip_set_frames_mode(const ohhip_frames_mode *m)
+int ohhip_backend_device(const ohhip_backend *be) { return be ? be->opt.device : -1; }
+
+int ohhip_backend_live_count(void)
 {
-    g_fm_on = 0;
-    g_fm_index = 0;
+    int n = 0;
+    ohhip_backend *b;
+    pthread_mutex_lock(&g_reg_lock);
+    for (b = g_backends; b; b = b->next)
+        n++;
+    pthread_mutex_unlock(&g_reg_lock);
+    return n;
+}
+
+static ohhip_backend *default_backend(void)
+{
+    ohhip_backend *be;
+    pthread_mutex_lock(&g_reg_lock);
+    be = g_default;
+    pthread_mutex_unlock(&g_reg_lock);
+    if (be)
+        return be;
+    be = ohhip_backend_new(NULL);
+    pthread_mutex_lock(&g_reg_lock);
+    if (!g_default) {
+        g_default = be;
+        be = NULL;
+    }
+    pthread_mutex_unlock(&g_reg_lock);
+    if (be)                        /* another thread was faster */
+        ohhip_backend_free(be);
+    return g_default;
+}
+
+/* before the decoder frees its frame buffers (avcodec_close): their page locks go first */
+void ohhip_backend_pre_close(ohhip_backend *be)
+{
+    if (be && be->root)
+        ohevc_host_unpin_all(be->root);
+}
+
+/* after the decoder (and its threads) are gone */
+void ohhip_backend_free(ohhip_backend *be)
+{
+    ohhip_backend **pp;
+    int i, k;
+    if (!be || be->magic != OHHIP_MAGIC)
+        return;
+    pthread_mutex_lock(&g_reg_lock);
+    for (pp = &g_backends; *pp; pp = &(*pp)->next)
+        if (*pp == be) {
+            *pp = be->next;
+            break;
+        }
+    if (g_default == be)
+        g_default = NULL;
+    g_epoch++;
+    pthread_mutex_unlock(&g_reg_lock);
+    if (be->trace && be->opt.trace_path) {
+        FILE *f = fopen(be->opt.trace_path, "a");
+        if (f) {
+            for (i = 0; i < be->ntrace && i < MAX_TRACE; i++)
+                fprintf(f, "%u %d %d %.6f %.6f %.6f %.6f\n", be->id, be->trace[i].tid, be->trace[i].poc, be->trace[i].t_start, be->trace[i].t_hook,
+                        be->trace[i].t_issued, be->trace[i].t_end);
+            fclose(f);
+        }
+    }
+    free(be->trace);
+    for (i = 0; i < be->nall; i++)
+        ohevc_ctx_destroy(be->all[i]);
+    if (be->root)
+        ohevc_ctx_destroy(be->root);
+    for (k = 0; k < 4; k++)
+        if (t_ctxs[k].be == be)
+            t_ctxs[k].be = NULL;
+    if (t_be == be) {
+        t_be = NULL;
+        t_ctx = NULL;
+        t_frame_open = 0;
+    }
+    be->magic = 0;
+    pthread_mutex_destroy(&be->lock);
+    free(be);
+}
+
+/* ---- frame-parallel decoding over processes (hip_frames.h) ---- */
+int ohhip_backend_frames_mode(ohhip_backend *be, const ohhip_frames_mode *m)
+{
+    if (!be)
+        return -1;
+    be->fm_on = 0;
+    be->fm_index = 0;
     if (!m)
         return 0;
     if (m->world < 1 || m->rank < 0 || m->rank >= m->world || !m->publish || !m->subscribe || !m->await_motion || !m->await_planes)
         return -1;
-    g_fm = *m;
-    g_fm_on = m->world > 1;
+    be->fm = *m;
+    be->fm_on = m->world > 1;
     return 0;
 }
 
@@ -620,46 +860,49 @@ int ohhip_set_frames_mode(const ohhip_frames_mode *m)
  * takes the last CTB address from ret[]: a remote picture reports "all CTBs done" without parsing anything */
 static int frames_execute(AVCodecContext *c, int (*func)(AVCodecContext *, void *), void *arg, int *ret, int count, int size)
 {
+    ohhip_backend *be = backend_of(c);
     int i;
     if (!t_remote)
-        return g_execute(c, func, arg, ret, count, size);
+        return be->execute(c, func, arg, ret, count, size);
     for (i = 0; ret && i < count; i++)
         ret[i] = INT_MAX / 2;
     return 0;
 }
 static int frames_execute2(AVCodecContext *c, int (*func)(AVCodecContext *, void *, int, int), void *arg, int *ret, int count)
 {
+    ohhip_backend *be = backend_of(c);
     int i;
     if (!t_remote)
-        return g_execute2(c, func, arg, ret, count);
+        return be->execute2(c, func, arg, ret, count);
     for (i = 0; ret && i < count; i++)
         ret[i] = INT_MAX / 2;
     return 0;
 }
-void ohhip_frames_install(AVCodecContext *avctx)
+void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx)
 {
-    if (avctx->execute != frames_execute) {
-        g_execute = avctx->execute;
-        g_execute2 = avctx->execute2;
+    if (be && avctx->execute != frames_execute) {
+        be->execute = avctx->execute;
+        be->execute2 = avctx->execute2;
         avctx->execute = frames_execute;
         avctx->execute2 = frames_execute2;
     }
 }
 
-int ohhip_frames_is_local(const unsigned char *data0)
+int ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0)
 {
     int i, local = 1;
-    pthread_mutex_lock(&g_lock);
-    for (i = 0; i < g_nbufs; i++)
-        if (g_bufs[i].data0 == data0)
-            local = !g_bufs[i].remote;
-    pthread_mutex_unlock(&g_lock);
+    if (!be)
+        return 1;
+    pthread_mutex_lock(&be->lock);
+    if ((i = find_buf_locked(be, data0)) >= 0)
+        local = !be->bufs[i].remote;
+    pthread_mutex_unlock(&be->lock);
     return local;
 }
 
 /* the wait of the reference's frame threads for the rows their motion vectors point at (hevc_await_progress, hevc.c:1951-1958),
  * per picture: every reference picture of the frame that is about to launch must have its samples in this process's store */
-static int frames_await_planes(HEVCContext *s)
+static int frames_await_planes(ohhip_backend *be, HEVCContext *s)
 {
     int t, k;
     for (t = 0; t < NB_RPS_TYPE; t++)
@@ -670,16 +913,16 @@ static int frames_await_planes(HEVCContext *s)
                 continue;
             if (!ref || ref == s->ref || !ref->frame || !ref->frame->data[0])
                 continue;
-            pthread_mutex_lock(&g_lock);
-            for (i = 0; i < g_nbufs; i++)
-                if (g_bufs[i].data0 == ref->frame->data[0] && g_bufs[i].poc == ref->poc && g_bufs[i].seq == ref->sequence &&
-                    g_bufs[i].remote && !g_bufs[i].have_planes) {
-                    g_bufs[i].have_planes = 1;
-                    index = g_bufs[i].index;
-                    slot = g_bufs[i].slot;
+            pthread_mutex_lock(&be->lock);
+            for (i = 0; i < be->nbufs; i++)
+                if (be->bufs[i].data0 == ref->frame->data[0] && be->bufs[i].poc == ref->poc && be->bufs[i].seq == ref->sequence &&
+                    be->bufs[i].remote && !be->bufs[i].have_planes) {
+                    be->bufs[i].have_planes = 1;
+                    index = be->bufs[i].index;
+                    slot = be->bufs[i].slot;
                 }
-            pthread_mutex_unlock(&g_lock);
-            if (index >= 0 && g_fm.await_planes(g_fm.user, index, t_ctx, slot) != 0) {
+            pthread_mutex_unlock(&be->lock);
+            if (index >= 0 && be->fm.await_planes(be->fm.user, index, t_ctx, slot) != 0) {
                 fprintf(stderr, "ohhip: the planes of remote picture %d did not arrive: %s\n", index, ohevc_last_error());
                 return -1;
             }
@@ -687,92 +930,120 @@ static int frames_await_planes(HEVCContext *s)
     return 0;
 }
 
-/* A failure is reported ONCE, by the frame end that sees it, and then forgotten: the pictures that predict from the failed one fail on
- * their own (the library marks it, ohevc_frame_abort), and after the next IDR picture the decoder is whole again - a damaged access unit must
- * not silence the rest of the stream. */
-static int take_error(void)
+/* A failure is reported ONCE, by the frame end of the picture it happened in (t_error: set by hooks on the picture's own thread), and then
+ * forgotten: the pictures that predict from the failed one fail on their own (the library marks it, ohevc_frame_abort), and after the next
+ * IDR picture the decoder is whole again - a damaged access unit must not silence the rest of the stream.  Failures of threads that own no
+ * picture (slice workers) are the instance's and surface at the next frame end of that instance. */
+static int take_error(ohhip_backend *be)
 {
-    if (!g_error)
-        return 0;
-    g_error = 0;
-    return -1;
+    int e = t_error;
+    t_error = 0;
+    if (be && be->error) {
+        be->error = 0;
+        e = 1;
+    }
+    return e ? -1 : 0;
 }
 
-int ohdec_backend_frame_done(void)
+/* INTEGRATION.md section 3, last row: run the recorded jobs, copy the picture back for output.  Runs on the thread that
+ * decoded the picture: called by the application after avcodec_decode_video2 (one decoding thread) or from the decoder's own
+ * end-of-frame progress report (frame threads, below). */
+static int frame_done(ohhip_backend *be)
 {
     int st, async;
-    struct timespec t0, t1;
+    double t0, t1, t_issued = 0;
     ohevc_frame_stats fs;
-    if (!t_frame_open)
-        return take_error();
-    t_frame_open = 0;
+    if (!be)
+        return 0;
+    if (!t_frame_open || t_be != be)
+        return take_error(be);
     /* restore_tqb_pixels (hevc_filter.c:163-193) ran on host pixels nobody reads: hand its map to the back-end instead */
     if (t_s && t_s->sps && t_s->pps && t_s->is_pcm &&
         (t_s->pps->transquant_bypass_enable_flag || (t_s->sps->pcm_enabled_flag && t_s->sps->pcm.loop_filter_disable_flag)) &&
         ohevc_tables_set_bypass_map(t_ctx, t_s->is_pcm, t_s->sps->min_pu_width, t_s->sps->min_pu_height,
                                     t_s->sps->log2_min_pu_size) != OHEVC_OK)
-        g_error = 1;
-    if (g_fm_on && t_s && frames_await_planes(t_s) < 0)
-        g_error = 1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
+        t_error = 1;
+    if (be->fm_on && t_s && frames_await_planes(be, t_s) < 0)
+        t_error = 1;
+    t0 = now_s();
     if (t_s && t_s->sps && t_s->pps && bulk_filters(t_s) && derive_filters(t_s) != OHEVC_OK) {
         fprintf(stderr, "ohhip: filter derivation failed: %s\n", ohevc_last_error());
-        g_error = 1;
+        t_error = 1;
     }
+    t_frame_open = 0;
     /* Frame threads: the issue of the frame end (stage, upload, launches) and the copy-back leave the decoding thread (ohevc_frame_end_async);
-     * the picture's samples are waited for where it leaves the decoder (ohdec_backend_fetch_output).  Not with the decoded-picture-hash check
+     * the picture's samples are waited for where it leaves the decoder (ohhip_backend_fetch_output).  Not with the decoded-picture-hash check
      * on (hevc.c:4146-4162 reads the host planes in this thread right behind this call) and not in frames mode over processes (the picture is
      * exported right below). */
-    async = g_async > 0;
-    if (async && ((t_s && t_s->decode_checksum_sei) || g_fm_on || !ohevc_ctx_has_device(t_ctx)))
+    async = be->opt.async_issue > 0;
+    if (async && ((t_s && t_s->decode_checksum_sei) || be->fm_on || !ohevc_ctx_has_device(t_ctx)))
         async = 0;
-    st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame(t_ctx, !g_defer_download);
+    st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame2(t_ctx, !be->opt.defer_download, &t_issued);
     if (async)
-        g_async_used = 1;
-    clock_gettime(CLOCK_MONOTONIC, &t1);
-    if (g_fm_on && t_publish && getenv("OHHIP_TEST_FAIL_INDEX") && atoi(getenv("OHHIP_TEST_FAIL_INDEX")) == t_publish_index)
+        be->async_used = 1;
+    t1 = now_s();
+    if (be->fm_on && t_publish && be->opt.test_fail_index >= 0 && be->opt.test_fail_index == t_publish_index)
         st = OHEVC_ERR_STATE;                   /* fault injection of tests/test_dist_cpu.py: the owner fails on this picture */
     if (st == OHEVC_OK && ohevc_frame_get_stats(t_ctx, &fs) == OHEVC_OK) {
-        pthread_mutex_lock(&g_lock);
-        g_end_frame_s += (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        pthread_mutex_lock(&g_prof_lock);
+        g_end_frame_s += t1 - t0;
         g_counts[0]++;
         g_counts[1] += fs.launches; g_counts[2] += fs.n_tu; g_counts[3] += fs.n_mc; g_counts[4] += fs.n_intra;
         g_counts[5] += fs.n_dbk; g_counts[6] += fs.n_sao; g_counts[7] += fs.upload_bytes;
         g_alg_bytes += fs.alg_bytes;
-        pthread_mutex_unlock(&g_lock);
+        pthread_mutex_unlock(&g_prof_lock);
+    }
+    if (be->trace) {
+        int k;
+        pthread_mutex_lock(&be->lock);
+        k = be->ntrace < MAX_TRACE ? be->ntrace++ : -1;
+        pthread_mutex_unlock(&be->lock);
+        if (k >= 0) {
+            static int next_tid;
+            static __thread int my_tid;
+            if (!my_tid)
+                my_tid = __sync_add_and_fetch(&next_tid, 1);
+            ohhip_trace_rec r = { my_tid, t_trace_poc, t_trace_start, t0, t_issued ? t_issued : t1, t1 };
+            be->trace[k] = r;
+        }
     }
     if (st == OHEVC_OK)
         st = ohevc_tables_status(t_ctx);
     if (st != OHEVC_OK) {
         fprintf(stderr, "ohhip: frame failed (%d): %s\n", st, ohevc_last_error());
-        g_error = 1;
-        if (g_fm_on && t_publish)
-            publish_failed();
+        if (be->fm_on && t_publish)
+            publish_failed(be);
+        take_error(be);
         return -1;
     }
-    if (g_fm_on && t_publish && t_s && t_s->ref) {
+    if (be->fm_on && t_publish && t_s && t_s->ref) {
         /* hand the picture to the other processes: ohevc_pic_export orders its copy behind the picture's `written` event (and waits
          * for it), so this works with and without the deferred copy-back */
         const int i = t_publish - 1;
         t_publish = 0;
-        if (g_fm.publish(g_fm.user, g_bufs[i].index, t_ctx, g_bufs[i].slot, t_s->ref->tab_mvf,
-                         (size_t)t_s->sps->min_pu_width * t_s->sps->min_pu_height * sizeof(MvField), 0) != 0) {
-            fprintf(stderr, "ohhip: publishing picture %d failed: %s\n", g_bufs[i].index, ohevc_last_error());
-            g_error = 1;
+        if (be->fm.publish(be->fm.user, be->bufs[i].index, t_ctx, be->bufs[i].slot, t_s->ref->tab_mvf,
+                           (size_t)t_s->sps->min_pu_width * t_s->sps->min_pu_height * sizeof(MvField), 0) != 0) {
+            fprintf(stderr, "ohhip: publishing picture %d failed: %s\n", be->bufs[i].index, ohevc_last_error());
+            t_error = 1;
         }
     }
-    return take_error();
+    return take_error(be);
 }
 
+int ohhip_backend_frame_done(ohhip_backend *be) { return frame_done(be ? be : t_be); }
+
 /* hip_frames.h: the decoder gave up on the picture it was decoding */
-int ohdec_backend_frame_failed(void)
+int ohhip_backend_frame_failed(ohhip_backend *be)
 {
-    if (t_frame_open && t_ctx) {
+    if (!be)
+        be = t_be;
+    if (t_frame_open && t_ctx && t_be == be) {
         t_frame_open = 0;
         ohevc_frame_abort(t_ctx);
     }
-    if (g_fm_on && t_publish)
-        publish_failed();
+    if (be && be->fm_on && t_publish && t_be == be)
+        publish_failed(be);
+    t_error = 0;
     return 0;
 }
 
@@ -783,11 +1054,12 @@ int ohdec_backend_frame_failed(void)
 const AVPixFmtDescriptor *ohhip_pix_fmt_desc_get(enum AVPixelFormat pix_fmt)
 {
     HEVCContext *s = t_s;
-    if (ohdec_backend_frame_done() < 0)
-        g_error = 1;
-    if (g_defer_download && s && s->ref && s->ref->frame)           /* the check reads the host planes now */
-        if (ohdec_backend_fetch_output(s->ref->frame->data, s->ref->frame->linesize) < 0)
-            g_error = 1;
+    ohhip_backend *be = t_be;
+    if (be && frame_done(be) < 0)
+        t_error = 1;                                                /* (reported by the application's own ohhip_backend_frame_done call) */
+    if (be && be->opt.defer_download && s && s->ref && s->ref->frame)           /* the check reads the host planes now */
+        if (ohhip_backend_fetch_output(be, s->ref->frame->data, s->ref->frame->linesize) < 0)
+            t_error = 1;
     return av_pix_fmt_desc_get(pix_fmt);
 }
 
@@ -799,35 +1071,36 @@ void ohhip_report_progress(ThreadFrame *f, int progress, int field)
     /* what other threads wait for on the CPU (motion fields, DPB state) is complete now; the samples are ordered on the
      * device by the library (ohevc_ctx_create_shared), so the report need not wait for the GPU */
     ff_thread_report_progress(f, progress, field);
-    if (progress == INT_MAX)
-        ohdec_backend_frame_done();
+    if (progress == INT_MAX && t_be && frame_done(t_be) < 0)
+        t_be->error = 1;             /* nobody reads this thread's return value: the instance's next frame end reports it */
 }
 
-/* INTEGRATION.md section 3, "before output".  With OHHIP_DEFER_DOWNLOAD=1 ending a frame only ISSUES its device work and the
+/* INTEGRATION.md section 3, "before output".  With defer_download ending a frame only ISSUES its device work and the
  * copy-back happens here, when the application takes the picture out of the decoder (the harness calls this right after
  * avcodec_decode_video2 handed it a frame; in openHEVC proper the place is libOpenHevcGetOutput, openHevcWrapper.c:353-398):
  * parsing of the next picture then overlaps the device work of this one even with a single decoding thread, and pictures
  * that are never output are never copied.  (Not inside ff_hevc_output_frame: with no reordering the decoder "outputs" the
  * current picture at hevc_frame_start, before it is decoded, and relies on the shared buffer being filled afterwards.) */
-int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3])
+int ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const int linesize[3])
 {
-    ohevc_ctx *ctx = t_ctx ? t_ctx : g_root;
-    int i, c, slot = -1;
-    if ((!g_defer_download && !g_async_used) || !g_root || !data[0])
+    ohevc_ctx *ctx;
+    int i, slot = -1;
+    if (!be)
+        be = t_be;
+    if (!be || (!be->opt.defer_download && !be->async_used) || !be->root || !data[0])
         return 0;
-    pthread_mutex_lock(&g_lock);
-    for (i = 0; i < g_nbufs; i++)
-        if (g_bufs[i].data0 == data[0])
-            slot = g_bufs[i].slot;
-    pthread_mutex_unlock(&g_lock);
+    ctx = t_be == be && t_ctx ? t_ctx : be->root;
+    pthread_mutex_lock(&be->lock);
+    if ((i = find_buf_locked(be, data[0])) >= 0)
+        slot = be->bufs[i].slot;
+    pthread_mutex_unlock(&be->lock);
     if (slot < 0) {
         fprintf(stderr, "ohhip: output picture is not in the picture store\n");
         return -1;
     }
-    if (g_async_used && !g_defer_download) {     /* the copy-back was queued by the issuer: wait until it has landed */
+    if (be->async_used && !be->opt.defer_download) {     /* the copy-back was queued by the issuer: wait until it has landed */
         if (ohevc_tables_fetch_picture(ctx, slot) != OHEVC_OK || ohevc_ctx_async_status(ctx) != OHEVC_OK) {
             fprintf(stderr, "ohhip: asynchronous frame end failed: %s\n", ohevc_last_error());
-            g_error = 1;
             return -1;
         }
         return 0;
@@ -835,7 +1108,6 @@ int ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3])
     {
         void *const host[3] = { data[0], data[1], data[2] };
         const ptrdiff_t strides[3] = { linesize[0], linesize[1], linesize[2] };
-        (void)c;
         if (ohevc_pic_download_planes(ctx, slot, host, strides) != OHEVC_OK) {
             fprintf(stderr, "ohhip: download failed: %s\n", ohevc_last_error());
             return -1;
@@ -853,57 +1125,38 @@ void ohhip_await_progress(ThreadFrame *f, int progress, int field)
     (void)f; (void)progress; (void)field;
 }
 
+/* ---- process-wide profiling (all instances) ---- */
 /* cumulative since the last call: seconds inside the frame-end hook and job / launch / upload counters */
 void ohdec_backend_profile(double *end_frame_s, long long counts[8])
 {
-    pthread_mutex_lock(&g_lock);
-    if (g_root && g_async_used) {           /* the issuer's seconds belong to the frame ends too (they just do not block a decoding thread) */
-        double bs = 0;
-        long long fr = 0;
-        if (ohevc_ctx_async_profile(g_root, &bs, &fr) == OHEVC_OK) {
-            g_end_frame_s += bs - g_issuer_s0;
-            g_issuer_s0 = bs;
-            g_issuer_f0 = fr;
+    ohhip_backend *b;
+    pthread_mutex_lock(&g_reg_lock);
+    pthread_mutex_lock(&g_prof_lock);
+    for (b = g_backends; b; b = b->next)
+        if (b->root && b->async_used) {           /* the issuer's seconds belong to the frame ends too (they just do not block a decoding thread) */
+            double bs = 0;
+            long long fr = 0;
+            if (ohevc_ctx_async_profile(b->root, &bs, &fr) == OHEVC_OK) {
+                g_end_frame_s += bs - b->issuer_s0;
+                b->issuer_s0 = bs;
+                b->issuer_f0 = fr;
+            }
         }
-    }
     *end_frame_s = g_end_frame_s;
     memcpy(counts, g_counts, sizeof(g_counts));
     g_end_frame_s = 0;
     memset(g_counts, 0, sizeof(g_counts));
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&g_prof_lock);
+    pthread_mutex_unlock(&g_reg_lock);
 }
 
 /* algorithmic HBM bytes of the jobs recorded since the last call (the device-side traffic floor of those pictures) */
 long long ohdec_backend_alg_bytes(void)
 {
     long long v;
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(&g_prof_lock);
     v = g_alg_bytes;
     g_alg_bytes = 0;
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(&g_prof_lock);
     return v;
-}
-
-/* before the decoder frees its frame buffers (avcodec_close): their page locks go first */
-void ohdec_backend_pre_close(void)
-{
-    if (g_root)
-        ohevc_host_unpin_all(g_root);
-}
-
-/* after the decoder (and its threads) are gone */
-void ohdec_backend_close(void)
-{
-    int i;
-    for (i = 0; i < g_nall; i++)
-        ohevc_ctx_destroy(g_all[i]);
-    g_nall = 0;
-    t_ctx = NULL;
-    if (g_root) {
-        ohevc_ctx_destroy(g_root);
-        g_root = NULL;
-    }
-    g_nbufs = 0;
-    t_frame_open = 0;
-    g_generation++;
 }

@@ -10,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <atomic>
 #include <string.h>
@@ -67,7 +68,9 @@ struct PicStore {
     Picture pics[kMaxPics];               // fixed array: pointers to entries stay valid while other threads allocate
     std::atomic<int> npics{0};            // grows under `m`; read without it by every context of the store (get_pic)
     unsigned version = 0;                 // bumped whenever a slot's planes change (contexts re-upload their MC table)
-    std::mutex pin_m;
+    // Page locks: taken and dropped under the exclusive lock; a copy-back into application memory holds the shared lock from its issue to
+    // its completion, so dropping a page lock (which first drains the device) can never pull a range from under a copy in flight.
+    std::shared_mutex pin_m;
     std::vector<std::pair<uintptr_t, size_t>> pinned;      // host ranges page-locked through ohevc_host_pin
     Issuer *issuer = nullptr;             // ohevc_frame_end_async: the thread that issues frame ends (created by the first submission)
 };
@@ -128,7 +131,9 @@ void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream sc
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static int g_level_launch = 2;        // ohevc_debug_set_level_launch
-static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 8;   // widest level a chain takes
+// The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
+// launch of its own ~6.6 us of kernel plus 2 - 4 us until the next one starts, whatever its width: up to four passes the chain is cheaper.
+static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 32;
 static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
 // OHEVC_UPLOAD_LANES=2: the filter maps of a frame end travel through a staging / device buffer pair of their own, so their staging copy does
 // not wait on the host for the job arrays' H2D copy (which sits in the stream behind the reference pictures' completion).  1 (default): one pair.
@@ -370,7 +375,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
         (void)hipDeviceSynchronize();
         {
-            std::lock_guard<std::mutex> g(c->store->pin_m);
+            std::unique_lock<std::shared_mutex> g(c->store->pin_m);
             while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
         }
         for (int i = 0; i < c->store->npics; i++) if (c->store->pics[i].used) free_picture(c->store->pics[i]);
@@ -542,7 +547,11 @@ extern "C" int ohevc_host_pin(ohevc_ctx *c, void *ptr, size_t bytes)
     OHEVC_REQUIRE(c != nullptr && ptr != nullptr && bytes > 0, "bad argument");
     if (c->dry) return OHEVC_OK;
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
-    std::lock_guard<std::mutex> g(c->store->pin_m);
+    {   // the common case - a buffer of the decoder's pool seen again - takes the shared lock only
+        std::shared_lock<std::shared_mutex> g(c->store->pin_m);
+        for (const auto &r : c->store->pinned) if (r.first == a && r.second == bytes) return OHEVC_OK;
+    }
+    std::unique_lock<std::shared_mutex> g(c->store->pin_m);
     auto &v = c->store->pinned;
     for (size_t i = 0; i < v.size(); i++) if (v[i].first == a && v[i].second == bytes) return OHEVC_OK;
     bool drained = false;
@@ -570,11 +579,28 @@ extern "C" int ohevc_host_unpin_all(ohevc_ctx *c)
     OHEVC_REQUIRE(c != nullptr, "null context");
     if (c->dry) return OHEVC_OK;
     async_drain(*c->store);                             // queued copy-backs name this memory
-    std::lock_guard<std::mutex> g(c->store->pin_m);
+    std::unique_lock<std::shared_mutex> g(c->store->pin_m);
     if (c->store->pinned.empty()) return OHEVC_OK;
     OHEVC_HIP_TRY(hipSetDevice(c->device));
     (void)hipDeviceSynchronize();
     while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
+    return OHEVC_OK;
+}
+
+// Drop the page locks of ONE allocation (every registered range that overlaps [ptr, ptr + bytes)): the decoder gave the memory back to the
+// allocator.  The caller knows no copy into THAT range is pending (the decoder recycles a buffer only after the application let go of the
+// picture); copies into other ranges go on undisturbed - they hold the shared lock, and nothing but this range is touched.
+extern "C" int ohevc_host_unpin(ohevc_ctx *c, void *ptr, size_t bytes)
+{
+    OHEVC_REQUIRE(c != nullptr && ptr != nullptr && bytes > 0, "bad argument");
+    if (c->dry) return OHEVC_OK;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    std::unique_lock<std::shared_mutex> g(c->store->pin_m);        // (waits for copy-backs in flight: they hold the shared lock)
+    auto &v = c->store->pinned;
+    for (size_t i = 0; i < v.size();) {
+        if (v[i].first < a + bytes && a < v[i].first + v[i].second) unpin_locked(*c->store, i);
+        else i++;
+    }
     return OHEVC_OK;
 }
 
@@ -594,6 +620,7 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
         if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
     }
     const double t0 = g_trace_timing ? now_s() : 0;
+    std::shared_lock<std::shared_mutex> pins(c->store->pin_m);     // no page lock is dropped between the issue of these copies and their completion
     for (int i = 0; i < 3; i++) {
         if (!host[i]) continue;
         const ohevc_plane &pl = p->planes[i];
@@ -620,6 +647,7 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
         if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
     }
     const ohevc_plane &pl = p->planes[plane];
+    std::shared_lock<std::shared_mutex> pins(c->store->pin_m);
     OHEVC_HIP_TRY(hipMemcpy2DAsync(host, host_stride, pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
                                    hipMemcpyDeviceToHost, c->stream));
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1670,7 +1698,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             if (first) { loff[l].tu_first = o; first = false; }
         }
     }
-    // runs of consecutive NARROW levels (at most 8 wavefronts of the packed kernel each): one ohevc_dev_intra_chain launch per run.  A
+    // runs of consecutive NARROW levels (at most g_intra_chain_waves wavefronts of the packed kernel each): one ohevc_dev_intra_chain launch per run.  A
     // level with residual bins of its own (blocks whose residual does not ride with the prediction) can only END a run: its bins launch
     // behind it and in front of the next level.
     std::vector<ohevc_intra_chain_level> &chain = c->chain_tab;

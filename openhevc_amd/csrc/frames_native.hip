@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -34,6 +35,7 @@
 #include <unistd.h>
 #include "common.hpp"
 #include "ohevc_frames.h"
+#include "ohevc_debug.h"
 
 using namespace ohevc;
 
@@ -131,11 +133,22 @@ struct SockWire {
         if (listen_fd < 0) return false;
         int one = 1;
         setsockopt(listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-        sockaddr_in a = {};
-        a.sin_family = AF_INET; a.sin_port = htons((uint16_t)(port + rank)); a.sin_addr.s_addr = htonl(INADDR_ANY);
-        if (bind(listen_fd, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || listen(listen_fd, world) != 0) return false;
+        // The ranks of this wire share one host (ohevc_frames.h): listen on the rendezvous host's address only - loopback by default - not on
+        // every interface, and let a peer in only if it presents the run's token (OHEVC_FRAMES_TOKEN when the launcher sets one for all
+        // ranks, else derived from the rendezvous string: it keeps two runs on one machine apart, it is not a secret).
         hostent *he = gethostbyname(host.c_str());
         if (!he) return false;
+        sockaddr_in a = {};
+        a.sin_family = AF_INET; a.sin_port = htons((uint16_t)(port + rank));
+        memcpy(&a.sin_addr, he->h_addr_list[0], sizeof(a.sin_addr));
+        if (bind(listen_fd, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || listen(listen_fd, world) != 0) return false;
+        uint64_t token = 1469598103934665603ull;
+        {
+            const char *env = getenv("OHEVC_FRAMES_TOKEN");
+            const std::string src = env && env[0] ? std::string(env) : std::string(rendezvous ? rendezvous : "127.0.0.1:29700");
+            for (unsigned char ch : src) token = (token ^ ch) * 1099511628211ull;
+        }
+        struct Hello { int32_t rank; uint32_t pad; uint64_t token; };
         // a rank connects to every lower rank and accepts from every higher one
         for (int p = 0; p < rank; p++) {
             const double t0 = now_s();
@@ -146,7 +159,7 @@ struct SockWire {
                 memcpy(&b.sin_addr, he->h_addr_list[0], sizeof(b.sin_addr));
                 if (connect(s, reinterpret_cast<sockaddr *>(&b), sizeof(b)) == 0) {
                     setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-                    const int32_t me = rank;
+                    const Hello me = { rank, 0u, token };
                     if (send(s, &me, sizeof(me), MSG_NOSIGNAL) != (ssize_t)sizeof(me)) { close(s); return false; }
                     fd[(size_t)p] = s;
                     break;
@@ -156,15 +169,24 @@ struct SockWire {
                 usleep(20000);
             }
         }
-        for (int k = rank + 1; k < world; k++) {
+        for (int k = rank + 1; k < world;) {
+            const double t0 = now_s();
             pollfd pf = { listen_fd, POLLIN, 0 };
             if (poll(&pf, 1, timeout_s * 1000) <= 0) return false;
             const int s = accept(listen_fd, nullptr, nullptr);
             if (s < 0) return false;
             setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            int32_t who = -1;
-            if (recv(s, &who, sizeof(who), MSG_WAITALL) != (ssize_t)sizeof(who) || who <= rank || who >= world || fd[(size_t)who] >= 0) { close(s); return false; }
-            fd[(size_t)who] = s;
+            // a connection that says nothing, the wrong thing or the wrong token is dropped and the slot stays open for the real peer
+            Hello who = { -1, 0u, 0ull };
+            pollfd hf = { s, POLLIN, 0 };
+            const bool talks = poll(&hf, 1, 2000) > 0 && recv(s, &who, sizeof(who), MSG_WAITALL) == (ssize_t)sizeof(who);
+            if (!talks || who.token != token || who.rank <= rank || who.rank >= world || fd[(size_t)who.rank] >= 0) {
+                close(s);
+                if (now_s() - t0 > timeout_s) return false;
+                continue;
+            }
+            fd[(size_t)who.rank] = s;
+            k++;
         }
         worker = std::thread([this] { run(); });
         return true;
@@ -416,9 +438,146 @@ static int cb_release(void *user, int index)
     Msg *m = it->second;
     const bool ok = t->complete(m);
     t->pending.erase(it);
-    t->recycle(m);
     t->stats.released++;
-    return ok ? 0 : -1;
+    if (!ok) {
+        // the transfer timed out: it may still land (a late RCCL write, a socket read in progress), so its buffers must never be handed to
+        // another picture - they are leaked on purpose - and the transport is done for
+        t->broken = true;
+        set_error("frames transport: picture %d was still in flight after %d s when its buffer was released", index, t->timeout_s);
+        return -1;
+    }
+    t->recycle(m);
+    return 0;
+}
+
+// ------------------------------------------------------------------ RCCL rendezvous through the file system
+// ncclCommInitRank needs the same ncclUniqueId on every rank and hangs - without a timeout - when a rank brings another one.  A file left
+// behind by a crashed run (or a second run reusing the path before rank 0 has replaced it) must therefore never be mistaken for this run's:
+//   rank r > 0   writes <path>.ready.<r> = a nonce of its own (16 random bytes), then polls <path> until it carries THAT nonce in slot r,
+//                answers with <path>.ack.<r> = nonce ^ rank 0's run nonce, and only then calls ncclCommInitRank;
+//   rank 0       removes a stale <path>, collects the nonces of all ready files, writes <path> = magic, run nonce, the nonces it saw, the id
+//                (whole or not at all: tmp + rename) and waits for every ack to match; while it waits it re-reads the ready files - a ready
+//                file it read too early (stale, from an earlier run) is replaced by its rank a moment later - and rewrites <path> if one
+//                changed.  Every wait is bounded by timeout_s: a missing peer is an error, not a hang.
+struct Nonce { unsigned char b[16]; };
+static bool read_file(const std::string &path, void *dst, size_t n)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    const bool ok = f && fread(dst, n, 1, f) == 1;
+    if (f) fclose(f);
+    return ok;
+}
+static bool write_file_atomically(const std::string &path, const void *src, size_t n)
+{
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    const bool ok = f && fwrite(src, n, 1, f) == 1;
+    if (f) fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { (void)remove(tmp.c_str()); return false; }
+    return true;
+}
+static Nonce fresh_nonce()
+{
+    Nonce n;
+    memset(&n, 0, sizeof(n));
+    FILE *f = fopen("/dev/urandom", "rb");
+    if (!f || fread(n.b, sizeof(n.b), 1, f) != 1) {            // no entropy source: pid, time and an address still tell two runs apart
+        const unsigned long long v[2] = { (unsigned long long)getpid() * 0x9e3779b97f4a7c15ull ^ (unsigned long long)(now_s() * 1e9), (unsigned long long)(uintptr_t)&n };
+        memcpy(n.b, v, sizeof(n.b));
+    }
+    if (f) fclose(f);
+    return n;
+}
+static constexpr unsigned kRendezvousMagic = 0x6f687276u;
+// `id` is filled by make_id on rank 0 (after the stale file is gone) and received on the others
+template <class MakeId>
+static bool rendezvous_exchange(const std::string &path, int rank, int world, int timeout_s, NcclUniqueId *id, MakeId make_id)
+{
+    const size_t file_bytes = 8 + 16 + 16 * (size_t)world + sizeof(NcclUniqueId);
+    std::vector<unsigned char> blob(file_bytes);
+    const double t0 = now_s();
+    auto expired = [&] { return now_s() - t0 > timeout_s; };
+    if (rank != 0) {
+        const Nonce mine = fresh_nonce();
+        if (!write_file_atomically(path + ".ready." + std::to_string(rank), &mine, sizeof(mine))) { set_error("frames transport: cannot write %s.ready.%d", path.c_str(), rank); return false; }
+        for (;;) {
+            unsigned magic = 0;
+            if (read_file(path, blob.data(), file_bytes) && (memcpy(&magic, blob.data(), 4), magic == kRendezvousMagic) &&
+                memcmp(blob.data() + 8 + 16 + 16 * (size_t)rank, mine.b, 16) == 0)
+                break;
+            if (expired()) { set_error("frames transport: rank 0 never published an id for this run in %s", path.c_str()); return false; }
+            usleep(20000);
+        }
+        Nonce ack;
+        for (int i = 0; i < 16; i++) ack.b[i] = mine.b[i] ^ blob[8 + (size_t)i];
+        memcpy(id, blob.data() + 8 + 16 + 16 * (size_t)world, sizeof(*id));
+        if (!write_file_atomically(path + ".ack." + std::to_string(rank), &ack, sizeof(ack))) { set_error("frames transport: cannot write %s.ack.%d", path.c_str(), rank); return false; }
+        return true;
+    }
+    (void)remove(path.c_str());                                // whatever an earlier run left behind
+    if (!make_id(id)) { set_error("frames transport: ncclGetUniqueId failed"); return false; }
+    const Nonce run = fresh_nonce();
+    std::vector<Nonce> seen((size_t)world), written((size_t)world);
+    memset(seen.data(), 0, sizeof(Nonce) * (size_t)world);
+    memset(written.data(), 0xff, sizeof(Nonce) * (size_t)world);
+    bool published = false;
+    for (;;) {
+        bool all_ready = true, all_acked = published;
+        for (int r = 1; r < world; r++) {
+            Nonce n;
+            if (!read_file(path + ".ready." + std::to_string(r), &n, sizeof(n))) { all_ready = false; continue; }
+            seen[(size_t)r] = n;
+        }
+        if (all_ready && (!published || memcmp(seen.data(), written.data(), sizeof(Nonce) * (size_t)world) != 0)) {
+            memcpy(blob.data(), &kRendezvousMagic, 4);
+            memset(blob.data() + 4, 0, 4);
+            memcpy(blob.data() + 8, run.b, 16);
+            memcpy(blob.data() + 8 + 16, seen.data(), 16 * (size_t)world);
+            memcpy(blob.data() + 8 + 16 + 16 * (size_t)world, id, sizeof(*id));
+            if (!write_file_atomically(path, blob.data(), file_bytes)) { set_error("frames transport: cannot publish %s", path.c_str()); return false; }
+            written = seen;
+            published = true;
+            all_acked = false;
+        }
+        if (published) {
+            all_acked = true;
+            for (int r = 1; r < world && all_acked; r++) {
+                Nonce a, want;
+                for (int i = 0; i < 16; i++) want.b[i] = written[(size_t)r].b[i] ^ run.b[i];
+                all_acked = read_file(path + ".ack." + std::to_string(r), &a, sizeof(a)) && memcmp(a.b, want.b, 16) == 0;
+            }
+        }
+        if (all_acked) return true;
+        if (expired()) { set_error("frames transport: not every rank answered the rendezvous in %s within %d s", path.c_str(), timeout_s); (void)remove(path.c_str()); return false; }
+        usleep(20000);
+    }
+}
+static bool rendezvous_id(ohevc_frames_transport *t, NcclUniqueId *id)
+{
+    return rendezvous_exchange(t->rendezvous, t->rank, t->world, t->timeout_s, id, [t](NcclUniqueId *out) { return t->rccl.GetUniqueId(out) == 0; });
+}
+// the handshake alone, for tests without RCCL (ohevc_debug.h): rank 0 distributes the 128 bytes it is given, the others receive them
+extern "C" int ohevc_debug_frames_rendezvous(const char *path, int rank, int world, int timeout_s, unsigned char id[128])
+{
+    OHEVC_REQUIRE(path != nullptr && id != nullptr && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    NcclUniqueId v;
+    memcpy(&v, id, sizeof(v));
+    const NcclUniqueId given = v;
+    if (!rendezvous_exchange(path, rank, world, timeout_s, &v, [&given](NcclUniqueId *out) { *out = given; return true; })) return OHEVC_ERR_STATE;
+    memcpy(id, &v, sizeof(v));
+    // (the transport removes each rank's files after ncclCommInitRank, a collective: nobody still reads them.  Here rank 0, the last one out of
+    // the handshake, clears the path for all.)
+    if (rank == 0) {
+        (void)remove(path);
+        for (int r = 1; r < world; r++) { (void)remove((std::string(path) + ".ready." + std::to_string(r)).c_str()); (void)remove((std::string(path) + ".ack." + std::to_string(r)).c_str()); }
+    }
+    return OHEVC_OK;
+}
+static void rendezvous_cleanup(ohevc_frames_transport *t)
+{
+    if (t->rank == 0) { (void)remove(t->rendezvous.c_str()); return; }
+    (void)remove((t->rendezvous + ".ready." + std::to_string(t->rank)).c_str());
+    (void)remove((t->rendezvous + ".ack." + std::to_string(t->rank)).c_str());
 }
 
 // ------------------------------------------------------------------ life cycle
@@ -444,26 +603,34 @@ extern "C" int ohevc_frames_transport_create(ohevc_frames_transport **out, int r
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return fail(OHEVC_ERR_HIP);
     NcclUniqueId id;
     memset(&id, 0, sizeof(id));
-    if (rank == 0) {                                           // hand the id to the others through a file, written whole or not at all
-        if (t->rccl.GetUniqueId(&id) != 0) { set_error("frames transport: ncclGetUniqueId failed"); return fail(OHEVC_ERR_STATE); }
-        const std::string tmp = t->rendezvous + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { if (f) fclose(f); set_error("frames transport: cannot write %s", tmp.c_str()); return fail(OHEVC_ERR_STATE); }
-        fclose(f);
-        if (rename(tmp.c_str(), t->rendezvous.c_str()) != 0) { set_error("frames transport: cannot publish %s", t->rendezvous.c_str()); return fail(OHEVC_ERR_STATE); }
-    } else {
-        const double t0 = now_s();
-        for (;;) {
-            FILE *f = fopen(t->rendezvous.c_str(), "rb");
-            const bool ok = f && fread(&id, sizeof(id), 1, f) == 1;
-            if (f) fclose(f);
-            if (ok) break;
-            if (now_s() - t0 > t->timeout_s) { set_error("frames transport: rank 0 never published %s", t->rendezvous.c_str()); return fail(OHEVC_ERR_STATE); }
-            usleep(20000);
+    if (world > 1 && !rendezvous_id(t, &id)) return fail(OHEVC_ERR_STATE);
+    if (world == 1 && t->rccl.GetUniqueId(&id) != 0) { set_error("frames transport: ncclGetUniqueId failed"); return fail(OHEVC_ERR_STATE); }
+    // ncclCommInitRank has no timeout of its own: a peer that died between the handshake and this call would hang the rank for ever.  It runs
+    // on a helper thread; the caller waits for timeout_s and then gives up with an error (the helper, stuck inside RCCL, is left behind).
+    struct Init { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; NcclComm comm = nullptr; };
+    auto st = std::make_shared<Init>();
+    {
+        const Rccl r = t->rccl;
+        std::thread([st, r, world, id, rank, device] {
+            (void)hipSetDevice(device);
+            NcclComm c = nullptr;
+            const int rc = r.CommInitRank(&c, world, id, rank);
+            std::lock_guard<std::mutex> g(st->m);
+            st->rc = rc; st->comm = c; st->done = true;
+            st->cv.notify_all();
+        }).detach();
+    }
+    {
+        std::unique_lock<std::mutex> lk(st->m);
+        if (!st->cv.wait_for(lk, std::chrono::seconds(t->timeout_s), [&] { return st->done; })) {
+            set_error("frames transport: ncclCommInitRank did not return within %d s (a peer died after the rendezvous?)", t->timeout_s);
+            t->rccl.lib = nullptr;                             // (the helper still runs inside librccl: never unload it)
+            return fail(OHEVC_ERR_STATE);
         }
     }
-    const int rc = t->rccl.CommInitRank(&t->comm, world, id, rank);
-    if (rc != 0) { set_error("frames transport: ncclCommInitRank failed: %s", t->rccl.GetErrorString(rc)); t->comm = nullptr; return fail(OHEVC_ERR_STATE); }
+    if (st->rc != 0) { set_error("frames transport: ncclCommInitRank failed: %s", t->rccl.GetErrorString(st->rc)); t->comm = nullptr; return fail(OHEVC_ERR_STATE); }
+    t->comm = st->comm;
+    if (world > 1) rendezvous_cleanup(t);
     *out = t;
     return OHEVC_OK;
 }
@@ -497,6 +664,50 @@ extern "C" void ohevc_frames_transport_destroy(ohevc_frames_transport *t)
     if (t->wire == OHEVC_FRAMES_WIRE_RCCL && t->rank == 0 && !t->rendezvous.empty()) (void)remove(t->rendezvous.c_str());
     if (t->rccl.lib) dlclose(t->rccl.lib);
     delete t;
+}
+
+// One picture through the wire, on every rank at once: `root` sends the picture in its src_slot and `mvf_in`, every rank - root included -
+// puts what arrived into its dst_slot and mvf_out.  The same steps as publish on the owner and subscribe + await_planes + await_motion on the
+// others (stage, ohevc_pic_export, one group of four broadcasts, the wait, ohevc_pic_import); a start-up check of the wire, and - with
+// world 1, where the decoder itself never exchanges anything - the only way to execute the RCCL calls on a single GPU.
+extern "C" int ohevc_frames_transport_selftest(ohevc_frames_transport *t, ohevc_ctx *ctx, int src_slot, int dst_slot, int root, const void *mvf_in, void *mvf_out,
+                                               size_t mvf_bytes)
+{
+    OHEVC_REQUIRE(t != nullptr && ctx != nullptr && root >= 0 && root < t->world && mvf_out != nullptr, "bad argument");
+    OHEVC_REQUIRE(t->rank != root || mvf_in != nullptr, "the root needs a motion field to send");
+    if (t->broken) { set_error("frames transport: broken"); return OHEVC_ERR_STATE; }
+    (void)hipSetDevice(t->device);
+    const bool me = t->rank == root;
+    Msg *m = t->stage(-1, ctx, me ? src_slot : dst_slot, mvf_bytes, root);
+    if (!m) return OHEVC_ERR_STATE;
+    m->outgoing = false;                                       // (every rank copies the motion field back, the root too)
+    int rc = OHEVC_OK;
+    if (me) {
+        memcpy(m->h_mvf, mvf_in, mvf_bytes);
+        memset(m->h_mvf + mvf_bytes, 0, 8);
+        for (int c = 0; c < 3 && rc == OHEVC_OK; c++) {
+            rc = ohevc_pic_export(ctx, src_slot, c, m->d_plane[c], m->plane_bytes[c]);
+            if (rc == OHEVC_OK && t->wire == OHEVC_FRAMES_WIRE_SOCKETS && hipMemcpy(m->h_plane[c], m->d_plane[c], m->plane_bytes[c], hipMemcpyDeviceToHost) != hipSuccess) rc = OHEVC_ERR_HIP;
+        }
+        if (rc == OHEVC_OK && t->wire == OHEVC_FRAMES_WIRE_RCCL && hipMemcpyAsync(m->d_mvf, m->h_mvf, mvf_bytes + 8, hipMemcpyHostToDevice, t->stream) != hipSuccess) rc = OHEVC_ERR_HIP;
+        if (rc == OHEVC_OK && t->wire == OHEVC_FRAMES_WIRE_RCCL) {
+            if (hipStreamSynchronize(t->stream) != hipSuccess) rc = OHEVC_ERR_HIP;     // (the copy above reads the host buffer asynchronously)
+            memset(m->h_mvf, 0xee, mvf_bytes + 8);                                     // what comes back must come off the wire
+        }
+    }
+    if (rc == OHEVC_OK && !t->post(m)) rc = OHEVC_ERR_STATE;
+    if (rc == OHEVC_OK && !t->complete(m)) { set_error("frames transport: the self-test picture did not arrive from rank %d within %d s", root, t->timeout_s); t->broken = true; return OHEVC_ERR_STATE; }
+    for (int c = 0; c < 3 && rc == OHEVC_OK; c++) {
+        if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && !me && hipMemcpy(m->d_plane[c], m->h_plane[c], m->plane_bytes[c], hipMemcpyHostToDevice) != hipSuccess) rc = OHEVC_ERR_HIP;
+        if (rc == OHEVC_OK) rc = ohevc_pic_import(ctx, dst_slot, c, m->d_plane[c], m->plane_bytes[c]);
+    }
+    if (rc == OHEVC_OK) {
+        if (m->h_mvf[mvf_bytes] != 0) { set_error("frames transport: the self-test message carries an error mark"); rc = OHEVC_ERR_STATE; }
+        memcpy(mvf_out, m->h_mvf, mvf_bytes);
+    }
+    t->stats.bytes += 0;
+    t->recycle(m);
+    return rc;
 }
 
 extern "C" int ohevc_frames_transport_stats(ohevc_frames_transport *t, ohevc_frames_stats *out)

@@ -158,26 +158,26 @@ __device__ __forceinline__ void pack_load_coeffs(const PackRecs &r, const int la
     }
 }
 
+// The five neighbour samples of lane (g, i) - top[i], top[N + i], left[i], left[N + i], the corner - as loaded; bit k of `none` set: sample k
+// has no source (no neighbour group is available) and takes 1 << (bit_depth - 1).  Loading them is a stage of its own so that the chain
+// kernel can issue the loads of a level FIRST behind the level's barrier and its prefetches for later levels behind them (vector memory
+// returns in order: a prefetch from HBM in front of them would delay every level by an HBM round trip).
+struct PackSamples { int v[5]; int none; };
+
 template <int LOG2N, typename Pixel>
-__device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const u32x4 (&cq)[4],
-                                             const int16_t *__restrict__ coeffs, const int bit_depth)
+__device__ __forceinline__ PackSamples pack_load_samples(const int lane, const PlaneSet planes, const PackRecs &recs)
 {
-    using IL = IntraPackLayout<LOG2N>;
-    constexpr int N = IL::N;
-    const int g = lane / N, i = lane % N;
-    const bool valid = recs.valid;
-    const u32x4 jw = recs.jw, rw = recs.rw;
-    const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
+    constexpr int N = 1 << LOG2N;
+    const int i = lane % N;
+    const u32x4 jw = recs.jw;
+    const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, flags = jw.y >> 24;
     const int bl_size = jw.z & 0xff, tr_size = (jw.z >> 8) & 0xff;
-    const int kind = pack_kind(recs);
     const int stride = PLANE_STRIDE3(planes, jplane);
-    unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
+    const unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
     const bool c_bl = flags & OHEVC_INTRA_BOTTOM_LEFT, c_l = flags & OHEVC_INTRA_LEFT, c_ul = flags & OHEVC_INTRA_UP_LEFT;
     const bool c_u = flags & OHEVC_INTRA_UP, c_ur = flags & OHEVC_INTRA_UP_RIGHT;
-
-    // ---- round 2: samples and coefficients.  Positions relative to the block's first sample; `none` = 1 << (bit_depth - 1).
+    // Positions relative to the block's first sample, as byte offsets.
     // Substitutes (:251-286): the last sample of a group in scan order is left[N] / left[0] / corner / top[N-1], the first left[N-1] / top[0] / top[N]
-    // positions as byte offsets from the block's first sample
     constexpr int P = (int)sizeof(Pixel), NONE = -0x40000000;
     const int o_c = -stride - P, o_l0 = -P, o_ln = N * stride - P, o_lm = (N - 1) * stride - P, o_t0 = -stride, o_tn = N * P - stride, o_tm = (N - 1) * P - stride;
     const int a = c_u ? o_t0 : c_ur ? o_tn : NONE;           // first available group after the corner: its first sample
@@ -193,14 +193,29 @@ __device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, co
     const int q_t0 = c_u ? i * P - stride : p_u, q_t1 = c_ur ? (N + kt) * P - stride : p_ur;
     const int q_l0 = c_l ? i * stride - P : p_l, q_l1 = c_bl ? (N + kb) * stride - P : p_bl;
     const int q_c = c_ul ? o_c : p_ul;
-    int v_t0 = REC(q_t0), v_t1 = REC(q_t1), v_l0 = REC(q_l0), v_l1 = REC(q_l1), v_c = REC(q_c);
+    PackSamples sm;
+    sm.v[0] = REC(q_t0); sm.v[1] = REC(q_t1); sm.v[2] = REC(q_l0); sm.v[3] = REC(q_l1); sm.v[4] = REC(q_c);
+    sm.none = (q_t0 == NONE ? 1 : 0) | (q_t1 == NONE ? 2 : 0) | (q_l0 == NONE ? 4 : 0) | (q_l1 == NONE ? 8 : 0) | (q_c == NONE ? 16 : 0);
+    return sm;
+}
+
+template <int LOG2N, typename Pixel>
+__device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const PackSamples &sm,
+                                            const u32x4 (&cq)[4], const int16_t *__restrict__ coeffs, const int bit_depth)
+{
+    using IL = IntraPackLayout<LOG2N>;
+    constexpr int N = IL::N;
+    const int g = lane / N, i = lane % N;
+    const bool valid = recs.valid;
+    const u32x4 jw = recs.jw, rw = recs.rw;
+    const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
+    const int kind = pack_kind(recs);
+    const int stride = PLANE_STRIDE3(planes, jplane);
+    unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
     const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
     const int dflt = 1 << (bit_depth - 1);
-    if (q_t0 == NONE) v_t0 = dflt;
-    if (q_t1 == NONE) v_t1 = dflt;
-    if (q_l0 == NONE) v_l0 = dflt;
-    if (q_l1 == NONE) v_l1 = dflt;
-    if (q_c == NONE) v_c = dflt;
+    const int v_t0 = (sm.none & 1) ? dflt : sm.v[0], v_t1 = (sm.none & 2) ? dflt : sm.v[1], v_l0 = (sm.none & 4) ? dflt : sm.v[2];
+    const int v_l1 = (sm.none & 8) ? dflt : sm.v[3], v_c = (sm.none & 16) ? dflt : sm.v[4];
 
     int *top = ish + g * IL::INTS + 1, *left = top + IL::ARR, *ftop = left + IL::ARR, *fleft = ftop + IL::ARR, *ref = fleft + IL::ARR - 1 + N;
     top[i] = v_t0; top[N + i] = v_t1; left[i] = v_l0; left[N + i] = v_l1;
@@ -333,6 +348,14 @@ __device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, co
 }
 
 template <int LOG2N, typename Pixel>
+__device__ __forceinline__ void pack_compute(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const u32x4 (&cq)[4],
+                                             const int16_t *__restrict__ coeffs, const int bit_depth)
+{
+    const PackSamples sm = pack_load_samples<LOG2N, Pixel>(lane, planes, recs);
+    pack_finish<LOG2N, Pixel>(ish, tu_lds, lane, planes, recs, sm, cq, coeffs, bit_depth);
+}
+
+template <int LOG2N, typename Pixel>
 __device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds, const int lane, const int job0, const int njobs, const PlaneSet planes,
                                                 const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
                                                 const int16_t *__restrict__ coeffs, const int bit_depth)
@@ -386,8 +409,17 @@ struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
     int reserved;
 };
 
-constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup = the widest level it takes
+constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup; a wider level takes ceil(width / 8) passes of it
 
+// Round 4.  (a) A level may be WIDER than the workgroup: its wavefront slots 8, 9, ... are served by wavefronts 0, 1, ... in further passes
+// behind the first (no barrier in between: the blocks of a level do not depend on each other), so a run no longer ends at every level of
+// 9 .. 17 wavefronts - the intra picture of a 1080p stream was 15 chain launches and 205 single-level launches, 5.5 ms on the device, and
+// every other picture of the GOP waits for it.  (b) The order of the memory operations inside a level: vector memory returns IN ORDER, so
+// whatever is issued in front of a level's neighbour-sample loads delays them, and whatever is outstanding at the end of the level is
+// waited for by the release.  Round 3 issued the prefetches (coefficients of level l + 1, records of level l + 2: HBM round trips, they
+// were uploaded by DMA) behind the level's stores, i.e. every level waited a whole HBM latency for them before its barrier.  Now: barrier,
+// the level's sample loads (L2 hits: the previous level has just written them), THEN the prefetches, then the arithmetic - by the time the
+// rows are stored the prefetches have had the whole level to arrive.
 template <typename Pixel>
 __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
                                                                        int nlevels, int bit_depth, const int16_t *__restrict__ coeffs)
@@ -399,17 +431,18 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     int *my_ish = ish + wave * kIntraPackInts;
     unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
 
-    // what this wavefront does at a level: the size class of its blocks (-1: nothing), its first block, the level's arrays.  All wave-uniform.
-    struct Slot { int s, job0, n; const ohevc_intra_job *j; const ohevc_tu_job *r; };
-    auto slot_of = [&](const int l) -> Slot {
-        Slot sl = { -1, 0, 0, nullptr, nullptr };
+    // what wavefront slot w does at a level: the size class of its blocks (-1: nothing), its first block, the level's arrays.  All wave-uniform.
+    struct Slot { int s, job0, n, nwaves; const ohevc_intra_job *j; const ohevc_tu_job *r; };
+    auto slot_at = [&](const int l, const int w) -> Slot {
+        Slot sl = { -1, 0, 0, 0, nullptr, nullptr };
         if (l >= nlevels) return sl;
         const IntraChainLevel lv = levels[l];
-        if (wave >= lv.first_wave[4]) return sl;
-        const int s = wave >= lv.first_wave[3] ? 3 : wave >= lv.first_wave[2] ? 2 : wave >= lv.first_wave[1] ? 1 : 0;
+        sl.nwaves = lv.first_wave[4];
+        if (w >= lv.first_wave[4]) return sl;
+        const int s = w >= lv.first_wave[3] ? 3 : w >= lv.first_wave[2] ? 2 : w >= lv.first_wave[1] ? 1 : 0;
         const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
         sl.s = s;
-        sl.job0 = (wave - lv.first_wave[s]) * (16 >> s);
+        sl.job0 = (w - lv.first_wave[s]) * (16 >> s);
         sl.n = lv.njobs[s];
         sl.j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
         sl.r = lv.res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job : nullptr;
@@ -428,11 +461,22 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         else if (sl.s == 2) pack_load_coeffs<4>(r, lane, coeffs, cq);
         else if (sl.s == 3) pack_load_coeffs<5>(r, lane, coeffs, cq);
     };
+    auto load_samples = [&](const Slot &sl, const PackRecs &r) -> PackSamples {
+        if (sl.s == 0) return pack_load_samples<2, Pixel>(lane, planes, r);
+        if (sl.s == 1) return pack_load_samples<3, Pixel>(lane, planes, r);
+        if (sl.s == 2) return pack_load_samples<4, Pixel>(lane, planes, r);
+        if (sl.s == 3) return pack_load_samples<5, Pixel>(lane, planes, r);
+        return PackSamples{ { 0, 0, 0, 0, 0 }, 0 };
+    };
+    auto finish = [&](const Slot &sl, const PackRecs &r, const PackSamples &sm, const u32x4 (&cq)[4]) {
+        if (sl.s == 0)      pack_finish<2, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 1) pack_finish<3, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 2) pack_finish<4, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 3) pack_finish<5, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+    };
 
-    // Software pipeline over the levels: while level l computes and its stores drain, the coefficients of level l + 1 and the records of
-    // level l + 2 are in flight (none of them depends on samples), so behind the barrier a level only waits for its neighbour samples -
-    // which the previous level has just left in this XCD's L2.
-    Slot s0 = slot_of(0), s1 = slot_of(1);
+    // Software pipeline over the levels (slot `wave` of each level; the further slots of a wide level are served plainly, below).
+    Slot s0 = slot_at(0, wave), s1 = slot_at(1, wave);
     PackRecs r0 = load_recs(s0), r1 = load_recs(s1);
     u32x4 cq0[4] = {}, cq1[4] = {};
     load_cq(s0, r0, cq0);
@@ -442,13 +486,27 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
             __syncthreads();                                 // ... and so are everybody else's
             xcd_acquire();                                   // nothing older of them in this CU's L1
         }
-        if (s0.s == 0)      pack_compute<2, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
-        else if (s0.s == 1) pack_compute<3, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
-        else if (s0.s == 2) pack_compute<4, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
-        else if (s0.s == 3) pack_compute<5, Pixel>(my_ish, my_tu, lane, planes, r0, cq0, coeffs, bit_depth);
-        load_cq(s1, r1, cq1);
-        const Slot s2 = slot_of(l + 2);
+        const PackSamples sm = load_samples(s0, r0);         // first: they hit the L2 the previous level wrote
+        issue_order_fence();
+        load_cq(s1, r1, cq1);                                // behind them: what later levels need, from HBM
+        const Slot s2 = slot_at(l + 2, wave);
         const PackRecs r2 = load_recs(s2);
+        issue_order_fence();
+        finish(s0, r0, sm, cq0);
+        // A level wider than the workgroup: further passes.  The blocks of a level do not depend on each other, so no release / acquire in
+        // between; the workgroup barrier only keeps a wavefront's LDS arrays from being rewritten while some of its lanes still read them
+        // (lanes take different numbers of wave-level scheduling points inside a pass: the residual's transform is per block).  Every
+        // wavefront takes every pass's barrier, with or without a slot of its own (s0.nwaves is the level's: the same for all of them).
+        for (int w0 = kChainWaves; w0 < s0.nwaves; w0 += kChainWaves) {
+            __syncthreads();
+            const Slot sx = slot_at(l, w0 + wave);
+            if (sx.s < 0) continue;
+            const PackRecs rx = load_recs(sx);
+            u32x4 cqx[4] = {};
+            load_cq(sx, rx, cqx);
+            const PackSamples smx = load_samples(sx, rx);
+            finish(sx, rx, smx, cqx);
+        }
         s0 = s1; r0 = r1;
 #pragma unroll
         for (int q = 0; q < 4; q++) cq0[q] = cq1[q];

@@ -14,6 +14,7 @@
 //     `buf + buf_offset` (hevc.c:1660-1675) -> it notes (picture, src_x, src_y) for that buffer and copies nothing; the
 //     MC kernel clamps coordinates instead.
 #include <algorithm>
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -26,6 +27,7 @@
 #include <string.h>
 #include <vector>
 #include "common.hpp"
+#include <time.h>
 #include "ohevc_tables.h"
 
 namespace {
@@ -736,15 +738,17 @@ extern "C" int ohevc_tables_begin_frame(ohevc_ctx *ctx, int slot)
     return ohevc_frame_begin(ctx, slot);
 }
 
-static int end_frame_common(ohevc_ctx *ctx, int download, bool async);
+static int end_frame_common(ohevc_ctx *ctx, int download, bool async, double *issued_at = nullptr);
 extern "C" int ohevc_tables_end_frame(ohevc_ctx *ctx, int download) { return end_frame_common(ctx, download, false); }
+// ... and says when the issue ended (CLOCK_MONOTONIC seconds): what follows in the call is the wait for the device and the copy-back
+extern "C" int ohevc_tables_end_frame2(ohevc_ctx *ctx, int download, double *issued_at) { return end_frame_common(ctx, download, false, issued_at); }
 // the frame end handed to the store's issuer thread (ohevc_frame_end_async): returns at once; the copy-back (download != 0) is queued behind
 // the picture's device work and ohevc_tables_fetch_picture waits for it
 extern "C" int ohevc_tables_end_frame_async(ohevc_ctx *ctx, int download) { return end_frame_common(ctx, download, true); }
 
 extern "C" int ohevc_tables_fetch_picture(ohevc_ctx *ctx, int slot) { return ohevc_pic_wait_host(ctx, slot); }
 
-static int end_frame_common(ohevc_ctx *ctx, int download, bool async)
+static int end_frame_common(ohevc_ctx *ctx, int download, bool async, double *issued_at)
 {
     using namespace ohevc;
     TablesState *s = state_of(ctx, false);
@@ -780,6 +784,11 @@ static int end_frame_common(ohevc_ctx *ctx, int download, bool async)
         return ohevc_frame_end_async(ctx, download ? host : nullptr, strides);
     }
     rc = ohevc_frame_end(ctx);
+    if (issued_at) {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        *issued_at = ts.tv_sec + 1e-9 * ts.tv_nsec;
+    }
     if (rc != OHEVC_OK) return rc;
     if (download) {
         const HostPic &hp = s->pics[s->cur].v;

@@ -1777,7 +1777,10 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_intra_chain_max_waves(void) { return ohevc::kChainWaves; }
+// the widest level (in wavefronts of the packed kernel) ohevc_dev_intra_chain takes: since round 4 any - a level wider than the kernel's
+// one workgroup costs further passes of it (the caller decides from which width on a launch of its own is cheaper)
+extern "C" int ohevc_intra_chain_max_waves(void) { return 1 << 20; }
+extern "C" int ohevc_intra_chain_workgroup_waves(void) { return ohevc::kChainWaves; }
 
 extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                                     const int16_t *coeffs, void *stream)

@@ -405,6 +405,15 @@ class NativeFrameTransport:
         self.lib.ohevc_frames_transport_stats(self.h, _C.byref(st))
         return {n: getattr(st, n) for n, _ in self.Stats._fields_}
 
+    def selftest(self, ctx_handle, src_slot, dst_slot, root, mvf_in):
+        """ohevc_frames_transport_selftest: one picture (and `mvf_in`, bytes) from `root` to every rank's dst_slot; returns the motion-field
+        bytes that arrived.  Collective: every rank calls it."""
+        self.lib.ohevc_frames_transport_selftest.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.c_int, _C.c_int, _C.c_char_p, _C.c_void_p, _C.c_size_t]
+        out = _C.create_string_buffer(len(mvf_in))
+        if self.lib.ohevc_frames_transport_selftest(self.h, ctx_handle, src_slot, dst_slot, root, mvf_in, out, len(mvf_in)) != 0:
+            raise RuntimeError("native frame transport self-test: " + self.lib.ohevc_last_error().decode())
+        return out.raw
+
     def finish(self):
         if self.lib.ohevc_frames_transport_finish(self.h) != 0:
             self.error = RuntimeError("native frame transport: " + self.lib.ohevc_last_error().decode())

@@ -23,26 +23,34 @@
 #include "libavutil/mem.h"
 
 #ifdef OHDEC_HIP
-int  ohdec_backend_open(void);
-int  ohdec_backend_frame_done(void);
-int  ohdec_backend_frame_failed(void);
-void ohdec_backend_pre_close(void);
-int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]);
-void ohdec_backend_close(void);
-/* frame-parallel decoding over processes: integration/hip_frames.h (the struct is passed through opaquely) */
-int  ohhip_set_frames_mode(const void *mode);
-void ohhip_frames_install(AVCodecContext *avctx);
-int  ohhip_frames_is_local(const unsigned char *data0);
+/* integration/hip_backend.h: one back end per decoder instance, attached before avcodec_open2 (the structs are passed through opaquely) */
+typedef struct ohhip_backend ohhip_backend;
+typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index; const char *trace_path; } ohdec_options;
+void ohhip_options_default(ohdec_options *o);
+ohhip_backend *ohhip_backend_new(const ohdec_options *o);
+int  ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx);
+int  ohhip_backend_frame_done(ohhip_backend *be);
+int  ohhip_backend_frame_failed(ohhip_backend *be);
+int  ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const int linesize[3]);
+void ohhip_backend_pre_close(ohhip_backend *be);
+void ohhip_backend_free(ohhip_backend *be);
+int  ohhip_backend_frames_mode(ohhip_backend *be, const void *mode);
+void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx);
+int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 #else
-static int  ohhip_set_frames_mode(const void *mode) { (void)mode; return -1; }
-static void ohhip_frames_install(AVCodecContext *avctx) { (void)avctx; }
-static int  ohhip_frames_is_local(const unsigned char *data0) { (void)data0; return 1; }
-static int  ohdec_backend_fetch_output(uint8_t *const data[3], const int linesize[3]) { (void)data; (void)linesize; return 0; }
-static int  ohdec_backend_open(void) { return 0; }
-static int  ohdec_backend_frame_done(void) { return 0; }
-static int  ohdec_backend_frame_failed(void) { return 0; }
-static void ohdec_backend_pre_close(void) {}
-static void ohdec_backend_close(void) {}
+typedef struct ohhip_backend ohhip_backend;
+typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index; const char *trace_path; } ohdec_options;
+static void ohhip_options_default(ohdec_options *o) { memset(o, 0, sizeof(*o)); }
+static ohhip_backend *ohhip_backend_new(const ohdec_options *o) { (void)o; return NULL; }
+static int  ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx) { (void)be; (void)avctx; return 0; }
+static int  ohhip_backend_frame_done(ohhip_backend *be) { (void)be; return 0; }
+static int  ohhip_backend_frame_failed(ohhip_backend *be) { (void)be; return 0; }
+static int  ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const int linesize[3]) { (void)be; (void)data; (void)linesize; return 0; }
+static void ohhip_backend_pre_close(ohhip_backend *be) { (void)be; }
+static void ohhip_backend_free(ohhip_backend *be) { (void)be; }
+static int  ohhip_backend_frames_mode(ohhip_backend *be, const void *mode) { (void)be; (void)mode; return -1; }
+static void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx) { (void)be; (void)avctx; }
+static int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0) { (void)be; (void)data0; return 1; }
 #endif
 
 /* the reference's own decoded-picture-hash check (hevc.c:4146-4162) reports through av_log only: count its two messages */
@@ -59,6 +67,7 @@ static void log_counter(void *avcl, int level, const char *fmt, va_list vl)
 
 typedef struct ohdec {
     AVCodecContext *avctx;
+    ohhip_backend  *backend;       /* this decoder's instance of the gfx950 back end (NULL in the CPU builds) */
     AVFrame        *frame;
     /* pipelined output (ohdec_set_pipelined): the application takes a picture one call late, so that with ONE decoding thread the device
      * reconstructs picture k while the CPU parses picture k + 1 (with OHHIP_DEFER_DOWNLOAD=1 the frame-end hook only issues the work) */
@@ -74,7 +83,10 @@ typedef struct ohdec {
 /* checksum: the reference's `decode-checksum` option, set BEFORE avcodec_open2 the way main_hm/main.c does (libOpenHevcSetCheckMD5
  * between libOpenHevcInit and libOpenHevcStartDecoder, openHevcWrapper.c:429-440) so that frame-thread copies inherit it: every
  * picture is verified against its decoded-picture-hash SEI (hevc.c:4146-4162) */
-ohdec *ohdec_open_ex(int threads, int thread_type, int checksum)
+/* `device` < 0: the back end's defaults (environment); else this decoder's HIP device.  Every decoder gets a back end of its own. */
+ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device);
+ohdec *ohdec_open_ex(int threads, int thread_type, int checksum) { return ohdec_open_dev(threads, thread_type, checksum, -1); }
+ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device)
 {
     static int registered;
     ohdec *d = calloc(1, sizeof(*d));
@@ -108,12 +120,23 @@ ohdec *ohdec_open_ex(int threads, int thread_type, int checksum)
     } else {
         av_log_set_callback(av_log_default_callback);
     }
-    if (ohdec_backend_open() < 0)
-        goto fail;
+#ifdef OHDEC_HIP
+    {
+        ohdec_options o;
+        ohhip_options_default(&o);
+        if (device >= 0)
+            o.device = device;
+        if (!(d->backend = ohhip_backend_new(&o)) || ohhip_backend_attach(d->backend, d->avctx) != 0)
+            goto fail;
+    }
+#else
+    (void)device;
+#endif
     if (avcodec_open2(d->avctx, codec, NULL) < 0)
         goto fail;
     return d;
 fail:
+    ohhip_backend_free(d->backend);
     if (d->frame)
         av_frame_free(&d->frame);
     if (d->avctx)
@@ -132,17 +155,17 @@ void ohdec_set_pipelined(ohdec *d, int on) { d->pipelined = on != 0; }
  * the hooks. */
 int ohdec_frames_mode(ohdec *d, const void *mode)
 {
-    if (ohhip_set_frames_mode(mode) != 0)
+    if (ohhip_backend_frames_mode(d->backend, mode) != 0)
         return -1;
     if (mode)
-        ohhip_frames_install(d->avctx);
+        ohhip_backend_frames_install(d->backend, d->avctx);
     return 0;
 }
 
 /* the picture ohdec_decode / ohdec_flush just returned: 1 if this process reconstructed it (its samples are valid here) */
 int ohdec_frame_is_local(ohdec *d)
 {
-    return d->have_frame ? ohhip_frames_is_local(d->frame->data[0]) : 0;
+    return d->have_frame ? ohhip_backend_frame_is_local(d->backend, d->frame->data[0]) : 0;
 }
 
 void ohdec_md5_results(ohdec *d, int *ok, int *bad)
@@ -178,14 +201,14 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
         av_frame_unref(d->next);
         ret = avcodec_decode_video2(d->avctx, d->next, &got, &pkt);
         if (ret < 0) {
-            ohdec_backend_frame_failed();
+            ohhip_backend_frame_failed(d->backend);
             return -2;
         }
-        if (ohdec_backend_frame_done() < 0)
+        if (ohhip_backend_frame_done(d->backend) < 0)
             return -3;
         av_frame_unref(d->frame);
         if (d->held_valid) {                          /* the picture of the previous call: its device work had a whole parse to finish */
-            if (ohdec_backend_fetch_output(d->held->data, d->held->linesize) < 0)
+            if (ohhip_backend_fetch_output(d->backend, d->held->data, d->held->linesize) < 0)
                 return -3;
             av_frame_move_ref(d->frame, d->held);
             d->held_valid = 0;
@@ -201,14 +224,14 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
     av_frame_unref(d->frame);
     ret = avcodec_decode_video2(d->avctx, d->frame, &got, &pkt);
     if (ret < 0) {
-        ohdec_backend_frame_failed();         /* the open frame is aborted and, in frames mode, published as failed */
+        ohhip_backend_frame_failed(d->backend);         /* the open frame is aborted and, in frames mode, published as failed */
         return -2;
     }
     /* "frame complete, before output" (INTEGRATION.md section 3): a no-op for the CPU builds */
-    if (ohdec_backend_frame_done() < 0)
+    if (ohhip_backend_frame_done(d->backend) < 0)
         return -3;
     /* the application takes the picture: with a deferred copy-back this is where its samples reach the host */
-    if (got && ohdec_backend_fetch_output(d->frame->data, d->frame->linesize) < 0)
+    if (got && ohhip_backend_fetch_output(d->backend, d->frame->data, d->frame->linesize) < 0)
         return -3;
     d->have_frame = got;
     return got ? 1 : 0;
@@ -264,13 +287,13 @@ void ohdec_close(ohdec *d)
 {
     if (!d)
         return;
-    ohdec_backend_pre_close();          /* page locks of the frame buffers go before the buffers do */
+    ohhip_backend_pre_close(d->backend);          /* page locks of the frame buffers go before the buffers do */
     avcodec_close(d->avctx);
     av_free(d->avctx);
     av_frame_free(&d->frame);
     av_frame_free(&d->next);
     av_frame_free(&d->held);
-    ohdec_backend_close();
+    ohhip_backend_free(d->backend);
     free(d->pkt_buf);
     free(d);
 }

@@ -8,7 +8,7 @@
  *
  *   - eight HEVC deblocking functions (x86/hevc_deblock.asm; assigned at x86/hevcdsp_init.c:441-442,471-472,533-534,556-557).  They are
  *     forwarded to the reference's own C implementation of the same slots (hevcdsp_template.c:1629-1787): hevcdsp.c is compiled a second
- *     time with ARCH_X86 0 and its init symbol renamed (ohsse_c_dsp_init), and the forwarders call through that table.  So: in
+ *     time with ARCH_X86 0 and its init symbol renamed (ohx86_c_dsp_init), and the forwarders call through that table.  So: in
  *     libopenhevc_sse.so DEBLOCKING RUNS AS C.  Every report that quotes this build says so.
  *   - nine symbols of code an HEVC stream never reaches (half-pel / quarter-pel DSP of other codecs, FFT / MDCT / DCT-32 of the audio
  *     decoders, the deinterlacer): empty init functions, and bodies that abort if anything ever calls them.
@@ -22,14 +22,14 @@
 
 #include "libavcodec/hevcdsp.h"
 
-/* hevcdsp.c, ARCH_X86 0, -Dff_hevc_dsp_init=ohsse_c_dsp_init (oracle/Makefile) */
-void ohsse_c_dsp_init(HEVCDSPContext *c, int bit_depth);
+/* hevcdsp.c, ARCH_X86 0, -Dff_hevc_dsp_init=ohx86_c_dsp_init (oracle/Makefile) */
+void ohx86_c_dsp_init(HEVCDSPContext *c, int bit_depth);
 
 static HEVCDSPContext c8, c10;
 static void __attribute__((constructor)) fill_c_tables(void)
 {
-    ohsse_c_dsp_init(&c8, 8);
-    ohsse_c_dsp_init(&c10, 10);
+    ohx86_c_dsp_init(&c8, 8);
+    ohx86_c_dsp_init(&c10, 10);
 }
 
 #define LUMA(dir, depth, tab)                                                                                                  \

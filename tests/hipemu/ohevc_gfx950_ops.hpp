@@ -21,5 +21,6 @@ static inline unsigned sat_pack_u8_i16(unsigned x)
 // cache maintenance between workgroups: nothing to do on one coherent host memory
 static inline void xcd_acquire() {}
 static inline void xcd_release() {}
+static inline void issue_order_fence() {}
 
 }  // namespace ohevc

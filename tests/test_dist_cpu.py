@@ -305,3 +305,61 @@ def test_native_transport_c_host_over_sockets(world, tmp_path):
         assert [merged[p] for p in range(len(want))] == want, f"{name}: pictures differ from the single-process decoder"
         assert all(s["pictures"] == len(want) for s in stats)
         assert sum(s["awaited_planes"] for s in stats) > 0 and sum(s["failed"] for s in stats) == 0
+
+
+def test_rccl_rendezvous_never_accepts_a_stale_id(tmp_path):
+    """The file through which rank 0 hands its ncclUniqueId to the other ranks (frames_native.hip) - ncclCommInitRank hangs without a timeout
+    when a rank brings another id, so a file left behind by a crashed run must never be taken for this run's.  Three ranks (threads of this
+    process; the handshake is plain file I/O) meet through a path where an earlier run left an id file, a ready file and an ack file: every
+    rank must come out with THIS run's id, whichever rank starts first, and the path must be clean afterwards."""
+    import ctypes as C
+    import threading
+    import time
+    from openhevc_amd import lib as L
+    lib = L.load_library()
+    lib.ohevc_debug_frames_rendezvous.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    path = str(tmp_path / "id")
+    world = 3
+    for order in ([0, 1, 2], [2, 1, 0], [1, 0, 2]):
+        # debris of an earlier run: a complete, well-formed id file with other nonces, and the files of its rank 1
+        stale = bytes([0x76, 0x72, 0x68, 0x6f, 0, 0, 0, 0]) + bytes(16) + bytes(16 * world) + bytes([0xAA] * 128)
+        with open(path, "wb") as f:
+            f.write(stale)
+        with open(path + ".ready.1", "wb") as f:
+            f.write(bytes([7] * 16))
+        with open(path + ".ack.1", "wb") as f:
+            f.write(bytes([9] * 16))
+        want = bytes((37 * k + order[0]) & 0xff for k in range(128))
+        got, rcs = {}, {}
+
+        def run(rank):
+            buf = C.create_string_buffer(want if rank == 0 else bytes(128), 128)
+            rcs[rank] = lib.ohevc_debug_frames_rendezvous(path.encode(), rank, world, 30, buf)
+            got[rank] = buf.raw
+
+        ths = []
+        for rank in order:
+            ths.append(threading.Thread(target=run, args=(rank,)))
+            ths[-1].start()
+            time.sleep(0.15)                         # the ranks arrive one after the other: late rank 0, late readers
+        for t in ths:
+            t.join()
+        assert rcs == {0: 0, 1: 0, 2: 0}, (order, rcs, lib.ohevc_last_error())
+        assert all(got[r] == want for r in range(world)), f"order {order}: a rank came out with another id"
+        assert sorted(os.listdir(tmp_path)) == [], sorted(os.listdir(tmp_path))
+
+
+def test_rccl_rendezvous_times_out_instead_of_hanging(tmp_path):
+    import ctypes as C
+    from openhevc_amd import lib as L
+    lib = L.load_library()
+    lib.ohevc_debug_frames_rendezvous.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.ohevc_last_error.restype = C.c_char_p
+    path = str(tmp_path / "id")
+    with open(path, "wb") as f:                      # only a stale id file is there: rank 1 must not take it
+        f.write(bytes([0x76, 0x72, 0x68, 0x6f, 0, 0, 0, 0]) + bytes(16 + 32 + 128))
+    buf = C.create_string_buffer(128)
+    assert lib.ohevc_debug_frames_rendezvous(path.encode(), 1, 2, 1, buf) != 0
+    assert b"never published" in lib.ohevc_last_error()
+    assert lib.ohevc_debug_frames_rendezvous(path.encode(), 0, 2, 1, buf) != 0      # ... and rank 0 gives up when nobody answers
+    assert b"not every rank" in lib.ohevc_last_error()

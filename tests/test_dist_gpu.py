@@ -62,3 +62,43 @@ def test_native_transport_c_host_two_processes_one_gpu(tmp_path):
         assert codes == [0, 0], (name, codes, errs)
         assert [merged[p] for p in range(len(want))] == want, f"{name}: pictures differ from the single-process decoder"
         assert sum(s["awaited_planes"] for s in stats) > 0 and sum(s["failed"] for s in stats) == 0
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("geometry", [(416, 240, 1, 8), (1920, 1080, 1, 10)], ids=["416x240_8b", "1080p_10b"])
+def test_rccl_wire_executes_on_one_rank(tmp_path, geometry):
+    """The RCCL wire of the native transport (openhevc_amd/csrc/frames_native.hip: hand-declared rccl.h entry points loaded with dlopen) on the
+    one GPU this box has: a 1-rank communicator (the rendezvous, ncclCommInitRank behind its watchdog), then one picture through
+    ohevc_frames_transport_selftest - stage, ohevc_pic_export, ONE ncclGroup of four ncclBroadcast on device memory (three planes + the
+    motion field), the completion event, ohevc_pic_import - and what lands in a second picture-store slot and in the motion-field buffer
+    must be what was sent.  With more GPUs the same calls move the bytes over xGMI (bench.py --mode frames --gpus N)."""
+    import numpy as np
+    from openhevc_amd import lib as L
+    from openhevc_amd.dist import NativeFrameTransport
+    w, h, cfi, bd = geometry
+    rng = np.random.default_rng(77)
+    dt = np.uint16 if bd > 8 else np.uint8
+    shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+    planes = [rng.integers(0, 1 << bd, size=s).astype(dt) for s in shapes]
+    mvf = rng.integers(0, 256, size=((w + 3) // 4) * ((h + 3) // 4) * 24, dtype=np.uint8).tobytes()     # a TEST_MV_POC MvField is 24 bytes (hevc.h:1032-1041)
+    ctx = L.Ctx(0)
+    try:
+        src = ctx.pic_alloc(w, h, cfi, bd)
+        dst = ctx.pic_alloc(w, h, cfi, bd)
+        ctx.pic_upload(src, planes)
+        ctx.pic_upload(dst, [np.zeros_like(p) for p in planes])
+        t = NativeFrameTransport(L.load_library(), 0, 1, 0, NativeFrameTransport.WIRE_RCCL, str(tmp_path / "rccl_id"), timeout_s=60)
+        try:
+            for _ in range(3):                      # the pools of staging buffers are reused from the second picture on
+                got_mvf = t.selftest(ctx.h, src, dst, 0, mvf)
+                assert got_mvf == mvf, "the motion field changed on its way through ncclBroadcast"
+                got = ctx.pic_download(dst, shapes, dt)
+                for c in range(3):
+                    assert np.array_equal(got[c], planes[c]), f"plane {c} changed on its way through ncclBroadcast"
+            t.finish()
+            assert t.error is None
+        finally:
+            t.close()
+        assert not os.path.exists(str(tmp_path / "rccl_id"))
+    finally:
+        ctx.close()

@@ -174,3 +174,24 @@ def test_emu_fuzzed_streams():
     assert lines, r.stderr[-2000:]
     res = json.loads(lines[-1])
     assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 1, r.stdout[-3000:]
+
+
+# ---------------------------------------------------------------- decoder instances (integration/hip_backend.h), over the emulated device code
+def _instances():
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    import instance_cases
+    return instance_cases
+
+
+def test_emu_two_decoders_decode_different_streams_concurrently():
+    _instances().two_streams_concurrently("hipemu", ("ra_10b_odd", "ldb_10b"), threads=3)
+
+
+def test_emu_two_decoders_interleaved_on_one_application_thread():
+    _instances().interleaved_on_one_thread("hipemu", ("intra_8b", "ra_10b_odd"))
+
+
+def test_emu_decoders_opened_and_closed_leave_nothing_behind():
+    _instances().open_close_many("hipemu", 14)

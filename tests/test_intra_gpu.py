@@ -257,3 +257,93 @@ def test_intra_pack_batch_with_residuals(oracle, bd):
         got = G.to_host(d[pl], planes[pl].dtype)
         bad = np.argwhere(got != want[pl])
         assert bad.size == 0, (pl, counts, bad[:4].tolist())
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_chain_hands_levels_over_including_levels_wider_than_its_workgroup(oracle, bd):
+    """ohevc_dev_intra_chain: a run of dependency levels in one launch, ONE workgroup of 8 wavefronts.  Level l + 1 here predicts from what
+    level l has just written (blocks of a level sit in one row of 64-sample cells, the next level's right below: its above / above-right
+    neighbours are the previous level's rows), levels are 1 .. 40 wavefronts wide - wider than the workgroup, so they take further passes -
+    and mix all four block sizes, most blocks with a residual.  Must equal the oracle run level by level (and so one
+    ohevc_dev_intra_recon_sorted launch per level)."""
+    import ctypes as C
+    rng = np.random.default_rng(4100 + bd)
+    nlev = 14
+    W, H = 16384, 64 + 32 * nlev
+    planes = [rng.integers(0, 1 << bd, size=(H, W)).astype(G.pixdt(bd)), rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd)),
+              rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd))]
+    want = [p.copy() for p in planes]
+    geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+    blobs, chain, arena, off = [], [], [], 0
+    pos16 = 0                                                # running offset of the staged arrays, in 16-byte units
+
+    def put(a):
+        nonlocal pos16
+        o = pos16
+        b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        pad = (-b.size) % 256
+        blobs.append(np.concatenate([b, np.zeros(pad, np.uint8)]))
+        pos16 += (b.size + pad) // 16
+        return o
+
+    widths = [1, 3, 8, 9, 17, 40, 2, 16, 24, 5, 33, 1, 12, 7]
+    ncells = W // 64
+    ycell = np.full((3, ncells), 64)                         # per plane and 64-sample column: the luma row its next block starts at
+    for lv in range(nlev):
+        recs = {2: [], 3: [], 4: [], 5: []}
+        # choose sizes until the level has the wanted number of wavefronts (16 / 8 / 4 / 2 blocks per wavefront)
+        cells = rng.permutation(ncells)
+        target, k = widths[lv], 0
+        def waves():
+            return sum((len(recs[q]) + (16 >> (q - 2)) - 1) // (16 >> (q - 2)) for q in (2, 3, 4, 5))
+        while waves() < target and k < ncells:
+            log2 = int(rng.integers(2, 6)) if target <= 16 else int(rng.choice([3, 4, 5, 5, 5]))      # (a wide level needs blocks that fill wavefronts fast)
+            n = 1 << log2
+            c_idx = int(rng.integers(0, 3)) if log2 < 5 else 0
+            sh = 1 if c_idx else 0
+            nl = n << sh
+            cell = int(cells[k]); k += 1
+            x0 = cell * 64
+            y0 = -(-int(ycell[c_idx, cell]) // nl) * nl      # right below the column's previous block (rounded up to the block size)
+            if y0 + nl > H:
+                continue
+            ycell[c_idx, cell] = y0 + nl
+            mode = int(rng.integers(0, 35))
+            cands = [0, 0, 0, 1, 0]                           # only the row above: written by an EARLIER level, never by this one
+            oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1, strong=1, smoothing_disabled=0, log2_ctb_size=6, log2_min_tb_size=2)
+            job = L.intra_make_job(geom, x0, y0, log2, c_idx, mode, cands)[0]
+            res = np.zeros(1, L.TU_JOB)[0]
+            if rng.random() < 0.8:
+                kind = L.TU_DST4 if (log2 == 2 and c_idx == 0 and rng.random() < 0.5) else int(rng.choice([L.TU_IDCT, L.TU_IDCT, L.TU_DC, L.TU_SKIP]))
+                cf = rng.integers(-512, 512, size=(1, n, n)).astype(np.int16)
+                px, py = x0 >> sh, y0 >> sh
+                oracle.tu_batch(bd, kind, log2, cf, want[c_idx], np.array([[px, py]], np.int32))
+                res["x"], res["y"], res["plane"], res["reserved0"] = px, py, c_idx, kind + 1
+                if kind == L.TU_DC:
+                    res["dc"] = cf[0, 0, 0]
+                else:
+                    res["coeff_off"] = off
+                    arena.append(cf.reshape(-1)); off += n * n
+            recs[log2].append((job, res))
+        jobs = np.array([j for q in (2, 3, 4, 5) for j, _ in recs[q]], dtype=L.INTRA_JOB)
+        ress = np.array([r for q in (2, 3, 4, 5) for _, r in recs[q]], dtype=L.TU_JOB)
+        counts = [len(recs[q]) for q in (2, 3, 4, 5)]
+        fw = [0]
+        for q in range(4):
+            fw.append(fw[-1] + (counts[q] + (16 >> q) - 1) // (16 >> q))
+        assert fw[4] >= min(target, 1)
+        chain.append((fw, counts, put(jobs), put(ress)))
+    lev = np.zeros(nlev, np.dtype([("first_wave", np.int32, 5), ("njobs", np.int32, 4), ("jobs_off16", np.uint32), ("res_off16", np.uint32), ("reserved", np.int32)]))
+    for i, (fw, counts, jo, ro) in enumerate(chain):
+        lev[i]["first_wave"], lev[i]["njobs"], lev[i]["jobs_off16"], lev[i]["res_off16"] = fw, counts, jo, ro
+    assert lev.itemsize == 48
+    assert max(int(l["first_wave"][4]) for l in lev) > 2 * L.load_library().ohevc_intra_chain_workgroup_waves()
+    d = [G.to_dev(p) for p in planes]
+    d_base, d_lev, d_cf = G.to_dev(np.concatenate(blobs)), G.to_dev(lev), G.to_dev(np.concatenate(arena))
+    L.check(L.load_library().ohevc_dev_intra_chain(G.planes3(d), C.c_int(bd), C.c_void_p(d_base.data_ptr()), C.c_void_p(d_lev.data_ptr()), C.c_int(nlev),
+                                                   C.c_void_p(d_cf.data_ptr()), C.c_void_p(G.stream())))
+    G.sync()
+    for pl in range(3):
+        got = G.to_host(d[pl], planes[pl].dtype)
+        bad = np.argwhere(got != want[pl])
+        assert bad.size == 0, (pl, bad[:4].tolist())

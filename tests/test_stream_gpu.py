@@ -233,3 +233,19 @@ def test_damaged_access_units_do_not_silence_the_stream(name, threads, monkeypat
         def setenv(self, *a, **k):
             pass
     body.__wrapped__(name, threads, KeepEnv()) if hasattr(body, "__wrapped__") else body(name, threads, KeepEnv())
+
+
+# ---------------------------------------------------------------- decoder instances (integration/hip_backend.h)
+def test_two_decoders_decode_different_streams_concurrently():
+    import instance_cases
+    instance_cases.two_streams_concurrently("hip")
+
+
+def test_two_decoders_interleaved_on_one_application_thread():
+    import instance_cases
+    instance_cases.interleaved_on_one_thread("hip")
+
+
+def test_fifty_decoders_opened_and_closed_leave_nothing_behind():
+    import instance_cases
+    instance_cases.open_close_many("hip", 50)

@@ -101,9 +101,15 @@ def main():
         # that the back end still produces the single-thread reference's pictures)
         res["slice_threads_equal_single_thread_reference"] = bool(len(ref) == len(hip_st) and all(np.array_equal(x, y) for fa, fb in zip(ref, hip_st) for x, y in zip(fa, fb)))
         runs = [(f"reference_c_{a.cpu_threads}slice_threads", "c", a.cpu_threads, 2), (f"hip_backend_{a.cpu_threads}slice_threads", "hip", a.cpu_threads, 2),
+                (f"reference_sse_{a.cpu_threads}slice_threads", "sse", a.cpu_threads, 2), (f"reference_sse_{a.cpu_threads}frame_and_slice_threads", "sse", a.cpu_threads, 4),
                 (f"reference_c_{a.cpu_threads}frame_and_slice_threads", "c", a.cpu_threads, 4),
                 (f"hip_backend_{a.cpu_threads}frame_and_slice_threads", "hip", a.cpu_threads, 4)]
+    # reference_sse_*: the reference as shipped on x86 (oracle/_ref/libopenhevc_sse.so; SSE4 intrinsics, deblocking in C - no yasm here)
+    if ps.have("sse"):
+        res["reference_sse_equals_reference_c"] = bool(all(np.array_equal(x, y) for fa, fb in zip(ref, ps.decode_stream("sse", aus)) for x, y in zip(fa, fb)))
     for name, kind, th, tt in runs + [("reference_c_1thread", "c", 1, 1), (f"reference_c_{a.cpu_threads}frame_threads", "c", a.cpu_threads, 1),
+                               ("reference_sse_1thread", "sse", 1, 1), (f"reference_sse_{a.cpu_threads}frame_threads", "sse", a.cpu_threads, 1),
+                               (f"reference_sse_{2 * a.cpu_threads}frame_threads", "sse", 2 * a.cpu_threads, 1),
                                ("front_end_only_no_pixels", "null", 1, 1),
                                (f"front_end_only_{a.cpu_threads}frame_threads", "null", a.cpu_threads, 1),
                                ("hip_backend", "hip", 1, 1), ("hip_backend_pipelined_output", "hip", 1, -1),

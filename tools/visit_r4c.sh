@@ -1,0 +1,12 @@
+TAG=r4c; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+NOISE='^\[MD5\|^POC\|^[0-9a-f]\{32\}$\|^\]$\|The cu_qp_delta\|PPS extension\|partially impl\|amdgpu.ids'
+( time timeout 1500 python -m pytest tests/test_stream_gpu.py tests/test_dist_gpu.py tests/test_ctx_gpu.py tests/test_tables_gpu.py -m gpu -q -p no:cacheprovider -x 2>&1 | grep -v "$NOISE" | tail -15 ) 2>&1 | cut -c1-400 | tee $OUT/pytest_host_side.log
+for th in 16 1; do for kind in natural flat; do
+  arg=$([ $kind = natural ] && echo natural)
+  rm -f /tmp/ft.txt
+  OHHIP_TRACE_FRAMES=/tmp/ft.txt python tools/diag_overlap.py decode $th $arg 2>/dev/null | grep fps | tee $OUT/frames_${th}_$kind.jsonl
+  python tools/frame_trace.py /tmp/ft.txt | tee -a $OUT/frames_${th}_$kind.jsonl
+  gzip -c /tmp/ft.txt > $OUT/frame_trace_${th}_$kind.txt.gz
+done; done
+timeout 900 python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-600 $OUT/bench.json; tail -3 $OUT/bench.err | grep -v "$NOISE"
+nproc
