@@ -8,8 +8,8 @@
  * ohevc_ctx (include/ohevc_ctx.h) instead of computing on host memory.  INTEGRATION.md shows the three-line patch.
  *
  * The structs here mirror the reference's layouts slot for slot (same order, same signatures); they are ABI
- * declarations, not code.  Only the slots on the hot path are overridden; SHVC up-sampling slots are left as filled
- * by the reference.
+ * declarations, not code.  Every slot is overridden, the thirteen SHVC up-sampling slots and vdsp.emulated_edge_up_{h,v} included
+ * (ohevc_tables_upsample_frame below); put_pcm keeps the reference's bit reader on the host and ships the samples as blocks.
  *
  * Pointer arguments are HOST addresses inside the reference's frame buffers; they are translated to (picture slot,
  * plane, x, y) through the registry fed by ohevc_tables_begin_frame / ohevc_tables_register_picture.

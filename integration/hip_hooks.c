@@ -5,7 +5,7 @@
  * with the reference's flags); together with libohevc_hip.so (include/ohevc_tables.h) it turns the CPU decoder into one
  * whose every pixel is produced by the gfx950 kernels.  Because /root/reference is read-only, the patch is applied at LINK
  * time instead of by editing sources: ONE translation unit (libavcodec/hevc.c) is compiled with call-site renames
- * (-Dff_hevc_dsp_init=ohhip_hevc_dsp_init etc., integration/Makefile.inc) so that the calls at hevc.c:421-423 (table fill
+ * (-Dff_hevc_dsp_init=ohhip_hevc_dsp_init etc., integration/renames.mk) so that the calls at hevc.c:421-423 (table fill
  * in set_sps), hevc.c:3245/3250 (ff_hevc_set_new_ref / ff_hevc_frame_rps in hevc_frame_start), hevc.c:4148 (right before
  * the decoded-picture-hash check) ... land here.  Each wrapper calls the reference's function and then the libohevc_hip.so
  * hook, i.e. exactly the patch INTEGRATION.md sections 1-3 describes.
@@ -660,6 +660,26 @@ void ohhip_deblocking_boundary_strengths(HEVCContext *s, int x0, int y0, int log
         note_error(backend_of(s->avctx));
 }
 
+/* Boundary strengths from the picture's own MC jobs (mode 2) rest on "every inter prediction unit made its MC calls".  The reference writes
+ * tab_mvf BEFORE hls_prediction_unit gives up on a unit whose reference picture is missing (hevc.c:2068-2075,2089-2091: `if (!ref0) return;`):
+ * such a unit keeps its inter pred_flag in tab_mvf but never reaches a table slot, the device-side grid would show it as intra (bS 2) and
+ * the deblocking would differ from the reference's on damaged streams.  A picture whose slices name a reference that is not there therefore
+ * hands its motion field over (mode 1) - decided here, at the frame end, when all of its slice headers have been seen. */
+static int any_missing_reference(const HEVCContext *s)
+{
+    int i, l, k;
+    for (i = 0; i <= s->slice_idx && i < MAX_SLICES_IN_FRAME; i++) {
+        const RefPicList *rpl = s->ref->refPicList[i];
+        if (!rpl)
+            continue;
+        for (l = 0; l < 2; l++)
+            for (k = 0; k < rpl[l].nb_refs && k < MAX_REFS; k++)
+                if (!rpl[l].ref[k])
+                    return 1;
+    }
+    return 0;
+}
+
 static int derive_filters(HEVCContext *s)
 {
     ohevc_filter_maps m;
@@ -683,7 +703,7 @@ static int derive_filters(HEVCContext *s)
         if (s == t_bs_direct && t_bs_n > 0 && ohevc_tables_bs_calls(t_bs_buf, t_bs_n) != OHEVC_OK)
             return OHEVC_ERR_STATE;
         t_bs_n = 0;
-        m.tab_mvf = device_bs_frame(s) == 2 ? NULL : s->ref->tab_mvf; m.mvf_stride = sizeof(MvField);
+        m.tab_mvf = device_bs_frame(s) == 2 && !any_missing_reference(s) ? NULL : s->ref->tab_mvf; m.mvf_stride = sizeof(MvField);
         m.mvf_off_mv = offsetof(MvField, mv); m.mvf_off_poc = offsetof(MvField, poc); m.mvf_off_pred_flag = offsetof(MvField, pred_flag);
         m.mvf_pred_flag_bytes = sizeof(((MvField *)0)->pred_flag);
         m.cbf_luma = s->cbf_luma; m.min_tb_width = s->sps->min_tb_width; m.min_tb_height = s->sps->min_tb_height; m.log2_min_tb_size = s->sps->log2_min_tb_size;

@@ -144,13 +144,24 @@ __device__ __forceinline__ PackRecs pack_load_recs(const int lane, const int job
 
 __device__ __forceinline__ int pack_kind(const PackRecs &r) { return (int)((r.rw.y >> 8) & 0xff) - 1; }      // -1: no residual
 
-template <int LOG2N>
+// READY: the arena holds the block's RESIDUAL (row-major int16, written in place over the coefficients by intra_chain_residual_kernel): the
+// lane takes row i of it instead of its coefficient chunks
+template <int LOG2N, bool READY = false>
 __device__ __forceinline__ void pack_load_coeffs(const PackRecs &r, const int lane, const int16_t *__restrict__ coeffs, u32x4 (&cq)[4])
 {
     constexpr int N = 1 << LOG2N, NCQ = LOG2N == 2 ? 2 : N / 8;
     const int i = lane % N, kind = pack_kind(r);
     const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
     const u32x4 *src = reinterpret_cast<const u32x4 *>(coeffs + (is_idct ? r.rw.z : 0u));
+    if constexpr (READY) {
+        constexpr int NR = LOG2N == 2 ? 1 : N / 8;             // 16-byte pieces of a row of N int16 (a 4x4 row is half a piece)
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            cq[q] = u32x4{ 0u, 0u, 0u, 0u };
+            if (is_idct) cq[q] = src[LOG2N == 2 ? i / 2 : i * NR + q];
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NCQ; q++) {
         cq[q] = u32x4{ 0u, 0u, 0u, 0u };
@@ -199,7 +210,7 @@ __device__ __forceinline__ PackSamples pack_load_samples(const int lane, const P
     return sm;
 }
 
-template <int LOG2N, typename Pixel>
+template <int LOG2N, typename Pixel, bool READY = false>
 __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const PackSamples &sm,
                                             const u32x4 (&cq)[4], const int16_t *__restrict__ coeffs, const int bit_depth)
 {
@@ -331,7 +342,19 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
     // ---- the block's residual, row i (hevc_cabac.c:1868-1949), added in registers (transform_add, hevcdsp_template.c:45-111)
     if (kind >= 0) {
         int res[N];
-        if (is_idct) {
+        if (is_idct && READY) {                            // row i of the residual as the pre-pass left it in the arena
+            if constexpr (LOG2N == 2) {
+                const unsigned lo = (i & 1) ? cq[0].z : cq[0].x, hi = (i & 1) ? cq[0].w : cq[0].y;
+                res[0] = (int)(short)(lo & 0xffffu); res[1] = (int)lo >> 16; res[2] = (int)(short)(hi & 0xffffu); res[3] = (int)hi >> 16;
+            } else {
+#pragma unroll
+                for (int q = 0; q < N / 8; q++) {
+                    const unsigned w4[4] = { cq[q].x, cq[q].y, cq[q].z, cq[q].w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { res[8 * q + 2 * k] = (int)(short)(w4[k] & 0xffffu); res[8 * q + 2 * k + 1] = (int)w4[k] >> 16; }
+                }
+            }
+        } else if (is_idct) {
             if constexpr (LOG2N == 2) {
                 if (kind == OHEVC_TU_DST4) tu4_row<true>(cq[0], cq[1], i, bit_depth, res);
                 else                       tu4_row<false>(cq[0], cq[1], i, bit_depth, res);
@@ -420,6 +443,67 @@ constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one wor
 // were uploaded by DMA) behind the level's stores, i.e. every level waited a whole HBM latency for them before its barrier.  Now: barrier,
 // the level's sample loads (L2 hits: the previous level has just written them), THEN the prefetches, then the arithmetic - by the time the
 // rows are stored the prefetches have had the whole level to arrive.
+// The residual of an intra-coded block (hevc_cabac.c:1868-1949: idct / idct_4x4_luma of its coefficients) does not depend on any sample: only
+// its prediction does.  Inside the chain it was the larger part of a level's instructions - a lane of a 32x32 block runs two 32-point
+// transforms, ~2500 instructions on one wavefront, 4 us of issue time - and a level lasts as long as its largest block.  So the transforms
+// of ALL levels of a run are taken out of the chain: one launch in front of it, a wavefront per 16 / 8 / 4 / 2 blocks over the whole GPU,
+// same lane map and same transform bodies as the packed kernel, writes every block's residual IN PLACE over its coefficients (row-major
+// int16, what the reference's in-place idct leaves, hevcdsp_template.c:264-301); the chain then adds row i of it to the prediction
+// (transform_add, :45-111).  Blocks with other residual kinds (DC, transform-skip, rdpcm, bypass: a few instructions per row) are left as
+// they are.  grid = (wavefront slots, levels); a level wider than gridDim.x takes more than one slot per workgroup.
+__global__ __launch_bounds__(64) void intra_chain_residual_kernel(const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels, int nlevels,
+                                                                  int bit_depth, int16_t *__restrict__ coeffs)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char tu_lds[TuLayout<5>::WAVE_BYTES];
+    const int lane = threadIdx.x;
+    const int l = blockIdx.y;
+    if (l >= nlevels) return;
+    const IntraChainLevel lv = levels[l];
+    if (lv.res_off16 == 0xffffffffu) return;
+    for (int w = blockIdx.x; w < lv.first_wave[4]; w += gridDim.x) {
+        const int s = w >= lv.first_wave[3] ? 3 : w >= lv.first_wave[2] ? 2 : w >= lv.first_wave[1] ? 1 : 0;
+        const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
+        const int job0 = (w - lv.first_wave[s]) * (16 >> s), n = lv.njobs[s];
+        const ohevc_intra_job *j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
+        const ohevc_tu_job *r = reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job;
+        auto one = [&](auto log2c) {
+            constexpr int LOG2N = decltype(log2c)::value, N = 1 << LOG2N;
+            const int g = lane / N, i = lane % N;
+            const PackRecs rec = pack_load_recs<LOG2N>(lane, job0, n, j, r);
+            const int kind = pack_kind(rec);
+            const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
+            u32x4 cq[4] = {};
+            pack_load_coeffs<LOG2N>(rec, lane, coeffs, cq);
+            int res[N];
+            if constexpr (LOG2N == 2) {
+                if (kind == OHEVC_TU_DST4) tu4_row<true>(cq[0], cq[1], i, bit_depth, res);
+                else                       tu4_row<false>(cq[0], cq[1], i, bit_depth, res);
+            } else {
+                // (every lane takes the transform's wave-level scheduling points, also those of blocks without such a residual)
+                idct_row<LOG2N, LOG2N >= 4>(tu_lds + g * TuLayout<LOG2N>::BLK, i, cq, bit_depth, res);
+            }
+            // in place: no lane stores before every lane of the wavefront has its coefficients (in lockstep anyway; said for the record)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (rec.valid && is_idct) {
+                unsigned *dst = reinterpret_cast<unsigned *>(coeffs + rec.rw.z + i * N);
+#pragma unroll
+                for (int k = 0; k < N / 2; k++) {
+                    const int a = res[2 * k] < -32768 ? -32768 : res[2 * k] > 32767 ? 32767 : res[2 * k];
+                    const int b = res[2 * k + 1] < -32768 ? -32768 : res[2 * k + 1] > 32767 ? 32767 : res[2 * k + 1];
+                    dst[k] = ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (s == 0)      one(std::integral_constant<int, 2>{});
+        else if (s == 1) one(std::integral_constant<int, 3>{});
+        else if (s == 2) one(std::integral_constant<int, 4>{});
+        else             one(std::integral_constant<int, 5>{});
+    }
+}
+
 template <typename Pixel>
 __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
                                                                        int nlevels, int bit_depth, const int16_t *__restrict__ coeffs)
@@ -456,10 +540,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         return PackRecs{ u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
     };
     auto load_cq = [&](const Slot &sl, const PackRecs &r, u32x4 (&cq)[4]) {
-        if (sl.s == 0)      pack_load_coeffs<2>(r, lane, coeffs, cq);
-        else if (sl.s == 1) pack_load_coeffs<3>(r, lane, coeffs, cq);
-        else if (sl.s == 2) pack_load_coeffs<4>(r, lane, coeffs, cq);
-        else if (sl.s == 3) pack_load_coeffs<5>(r, lane, coeffs, cq);
+        if (sl.s == 0)      pack_load_coeffs<2, true>(r, lane, coeffs, cq);
+        else if (sl.s == 1) pack_load_coeffs<3, true>(r, lane, coeffs, cq);
+        else if (sl.s == 2) pack_load_coeffs<4, true>(r, lane, coeffs, cq);
+        else if (sl.s == 3) pack_load_coeffs<5, true>(r, lane, coeffs, cq);
     };
     auto load_samples = [&](const Slot &sl, const PackRecs &r) -> PackSamples {
         if (sl.s == 0) return pack_load_samples<2, Pixel>(lane, planes, r);
@@ -469,10 +553,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         return PackSamples{ { 0, 0, 0, 0, 0 }, 0 };
     };
     auto finish = [&](const Slot &sl, const PackRecs &r, const PackSamples &sm, const u32x4 (&cq)[4]) {
-        if (sl.s == 0)      pack_finish<2, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
-        else if (sl.s == 1) pack_finish<3, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
-        else if (sl.s == 2) pack_finish<4, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
-        else if (sl.s == 3) pack_finish<5, Pixel>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        if (sl.s == 0)      pack_finish<2, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 1) pack_finish<3, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 2) pack_finish<4, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 3) pack_finish<5, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
     };
 
     // Software pipeline over the levels (slot `wave` of each level; the further slots of a wide level are served plainly, below).

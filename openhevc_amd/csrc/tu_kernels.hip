@@ -1798,6 +1798,10 @@ extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth,
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const IntraChainLevel *lv = reinterpret_cast<const IntraChainLevel *>(levels);
+    // the transforms of the run's blocks first, over the whole GPU, in place (the arena is the caller's device buffer: written here)
+    if (coeffs != nullptr)
+        hipLaunchKernelGGL(intra_chain_residual_kernel, dim3(32, nlevels), dim3(64), 0, st, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth,
+                           const_cast<int16_t *>(coeffs));
     if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
     else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
     OHEVC_HIP_TRY(hipGetLastError());

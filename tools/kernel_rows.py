@@ -142,13 +142,23 @@ def intra_rows(bd, orc, po, g, rng, st, out):
     P = 2 if bd > 8 else 1
     for log2 in (2, 5):
         nn = 1 << log2
-        xs, ys = np.meshgrid(np.arange(nn, W - 2 * nn, 2 * nn), np.arange(nn, H - 2 * nn, 2 * nn))
+        # blocks on a sparse grid (every other block position) inside the picture's interior coding-tree blocks.  Which neighbour groups a block may
+        # use follows from the z-scan order of its position inside the 64x64 CTB (hevcpred_template.c:105-114) - the job builder of the C ABI
+        # derives it, once per position of one interior CTB; the pattern repeats from CTB to CTB
+        xs, ys = np.meshgrid(np.arange(64 + nn, W - 64 - nn, 2 * nn), np.arange(64 + nn, H - 64 - nn, 2 * nn))
         n = xs.size
+        geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+        pattern = {}
+        for py in range(nn % 64, 64, 2 * nn):
+            for px_ in range(nn % 64, 64, 2 * nn):
+                pattern[(px_, py)] = L.intra_make_job(geom, 64 + px_, 64 + py, log2, 0, 0, [1, 1, 1, 1, 1])[0]
         j = np.zeros(n, L.INTRA_JOB)
+        fx, fy = xs.ravel() % 64, ys.ravel() % 64
+        for (px_, py), jb in pattern.items():
+            m = (fx == px_) & (fy == py)
+            for f in ("flags", "bottom_left_size", "top_right_size", "flags2", "log2_ctb_size"):
+                j[f][m] = jb[f]
         j["x"], j["y"], j["log2_size"], j["mode"] = xs.ravel(), ys.ravel(), log2, rng.integers(0, 35, n)
-        j["flags"] = 31 | L.INTRA_STRONG | L.INTRA_LUMA_EDGE
-        j["bottom_left_size"] = nn
-        j["top_right_size"] = nn
         d_jobs = _dev(j)
         counts = [0, 0, 0, 0]
         counts[log2 - 2] = n
