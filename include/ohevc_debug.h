@@ -101,6 +101,14 @@ int ohevc_debug_filters(struct ohevc_ctx *ctx, const struct ohevc_dbk_job **vert
                         int *n_horizontal, const struct ohevc_sao_job **sao, int *n_sao, struct ohevc_sao_bypass *bypass /* HOST map */);
 /* block until the frame that reconstructs picture `slot` has ended (frame threads: another context of the store) */
 int ohevc_debug_wait_picture(struct ohevc_ctx *ctx, int slot);
+/* Where the intra chain kernel (ohevc_dev_intra_chain) spends a level: on != 0 switches the counters on (they add up over all launches of
+ * the process); out (may be NULL) receives {clocks waiting for stores + barrier, clocks issuing the level's loads and prefetches, clocks in
+ * the level's arithmetic incl. the wait for its samples, clocks in further passes of wide levels, levels} of wavefront 0; on == 0 frees them.
+ * Shader clock (s_memtime).  Diagnosis only. */
+int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8]);      /* [5..7]: inside the issue phase - after the sample loads, after the residual prefetch, after the level record */
+/* SHVC up-sampling kernel: 0 = the tile form (shipped: a workgroup per 64 x 32 output tile, both passes through LDS, dot instructions),
+ * 1 = the round-2 strip form (a thread per column strip).  Returns the previous value.  Environment: OHEVC_UPSAMPLE_VARIANT. */
+int ohevc_debug_set_upsample_variant(int variant);
 /* The file-system rendezvous of the native transport's RCCL wire (ohevc_frames.h) without RCCL: rank 0 hands the 128 bytes in `id` to the
  * other ranks (who receive them in `id`), through `path`, with the nonce handshake that keeps a file of an earlier run from being accepted.
  * Tests only. */

@@ -374,6 +374,7 @@ typedef struct ohevc_intra_chain_level {   /* 48 bytes */
 } ohevc_intra_chain_level;
 int ohevc_intra_chain_max_waves(void);
 int ohevc_intra_chain_workgroup_waves(void);
+int ohevc_intra_chain_max_levels(void);        /* levels per launch (nlevels <= this) */
 int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                           const int16_t *coeffs, void *stream);
 

@@ -1712,7 +1712,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         for (int l = 1; l <= c->max_level;) {
             if (!narrow(l)) { l++; continue; }
             int e = l;
-            while (e + 1 <= c->max_level && c->levels[e].touched == 0 && narrow(e + 1)) e++;
+            while (e + 1 <= c->max_level && c->levels[e].touched == 0 && narrow(e + 1) && e - l + 1 < ohevc_intra_chain_max_levels()) e++;
             if (e > l) {
                 c->chain_first[l] = (int)chain.size();
                 c->chain_len[l] = e - l + 1;

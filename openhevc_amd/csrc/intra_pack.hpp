@@ -433,6 +433,7 @@ struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
 };
 
 constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup; a wider level takes ceil(width / 8) passes of it
+constexpr int kChainMaxLevels = 1024;   // levels per launch: their records (48 bytes each) are copied to LDS at the kernel's start
 
 // Round 4.  (a) A level may be WIDER than the workgroup: its wavefront slots 8, 9, ... are served by wavefronts 0, 1, ... in further passes
 // behind the first (no barrier in between: the blocks of a level do not depend on each other), so a run no longer ends at every level of
@@ -506,21 +507,38 @@ __global__ __launch_bounds__(64) void intra_chain_residual_kernel(const unsigned
 
 template <typename Pixel>
 __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
-                                                                       int nlevels, int bit_depth, const int16_t *__restrict__ coeffs)
+                                                                       int nlevels, int bit_depth, const int16_t *__restrict__ coeffs, int agent_acquire,
+                                                                       unsigned long long *__restrict__ phase_clocks)
 {
     __shared__ int ish[kChainWaves * kIntraPackInts];
     __shared__ __attribute__((aligned(16))) unsigned char tu_lds[kChainWaves * TuLayout<5>::WAVE_BYTES];
+    // The level records, all of them, in LDS before the first level starts.  Read from memory as a level needs them (a scalar load whose
+    // result the record loads of level l + 2 wait for) they cost every level an HBM round trip on its critical path - the records arrive
+    // by DMA, nothing has them in a cache: 4500 of a level's 11 800 shader clocks (ohevc_debug_intra_chain_clocks, profiles/r4g_*).
+    __shared__ int slev[kChainMaxLevels * 12];
+    static_assert(sizeof(IntraChainLevel) == 48, "12 dwords per level record");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int *my_ish = ish + wave * kIntraPackInts;
     unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
+    for (int i = threadIdx.x; i < nlevels * 12; i += 64 * kChainWaves) slev[i] = reinterpret_cast<const int *>(levels)[i];
+    __syncthreads();
 
     // what wavefront slot w does at a level: the size class of its blocks (-1: nothing), its first block, the level's arrays.  All wave-uniform.
     struct Slot { int s, job0, n, nwaves; const ohevc_intra_job *j; const ohevc_tu_job *r; };
     auto slot_at = [&](const int l, const int w) -> Slot {
         Slot sl = { -1, 0, 0, 0, nullptr, nullptr };
         if (l >= nlevels) return sl;
-        const IntraChainLevel lv = levels[l];
+        IntraChainLevel lv;
+        {
+            const int *rec = slev + l * 12;
+#pragma unroll
+            for (int k = 0; k < 5; k++) lv.first_wave[k] = __builtin_amdgcn_readfirstlane(rec[k]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) lv.njobs[k] = __builtin_amdgcn_readfirstlane(rec[5 + k]);
+            lv.jobs_off16 = (unsigned)__builtin_amdgcn_readfirstlane(rec[9]);
+            lv.res_off16 = (unsigned)__builtin_amdgcn_readfirstlane(rec[10]);
+        }
         sl.nwaves = lv.first_wave[4];
         if (w >= lv.first_wave[4]) return sl;
         const int s = w >= lv.first_wave[3] ? 3 : w >= lv.first_wave[2] ? 2 : w >= lv.first_wave[1] ? 1 : 0;
@@ -564,37 +582,72 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     PackRecs r0 = load_recs(s0), r1 = load_recs(s1);
     u32x4 cq0[4] = {}, cq1[4] = {};
     load_cq(s0, r0, cq0);
+    // phase_clocks != NULL (diagnosis, ohevc_debug_intra_chain_clocks): wavefront 0 adds up, over the levels, the shader clocks it spends
+    // [0] waiting for its stores + in the barrier, [1] issuing the level's loads and prefetches, [2] in the level's arithmetic (incl. the
+    // wait for the samples), [3] in further passes of wide levels; [4] = levels
+    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pcx[3] = { 0, 0, 0 };
     for (int l = 0; l < nlevels; l++) {
+        const unsigned long long tk0 = phase_clocks ? clock64() : 0;
         if (l) {
-            xcd_release();                                   // this wavefront's rows are in L2 (and what it prefetched has arrived) ...
-            __syncthreads();                                 // ... and so are everybody else's
-            xcd_acquire();                                   // nothing older of them in this CU's L1
-        }
-        const PackSamples sm = load_samples(s0, r0);         // first: they hit the L2 the previous level wrote
-        issue_order_fence();
-        load_cq(s1, r1, cq1);                                // behind them: what later levels need, from HBM
-        const Slot s2 = slot_at(l + 2, wave);
-        const PackRecs r2 = load_recs(s2);
-        issue_order_fence();
-        finish(s0, r0, sm, cq0);
-        // A level wider than the workgroup: further passes.  The blocks of a level do not depend on each other, so no release / acquire in
-        // between; the workgroup barrier only keeps a wavefront's LDS arrays from being rewritten while some of its lanes still read them
-        // (lanes take different numbers of wave-level scheduling points inside a pass: the residual's transform is per block).  Every
-        // wavefront takes every pass's barrier, with or without a slot of its own (s0.nwaves is the level's: the same for all of them).
-        for (int w0 = kChainWaves; w0 < s0.nwaves; w0 += kChainWaves) {
+            // The hand-over between two levels is a release / acquire at WORKGROUP scope: every wavefront of the workgroup runs on one CU
+            // and shares its vector L1 (no thread-group split), stores go through that L1, so "my stores have completed" + the barrier is
+            // all it takes (the gfx942 memory model: workgroup-scope acquire needs no cache invalidate).  Rounds 2 - 3 issued the AGENT-scope
+            // acquire here (buffer_inv sc1, what a hand-over between workgroups on different CUs needs): it costs every level microseconds -
+            // a level of twelve 4x4 blocks took as long as one of 32x32 blocks, ~4.5 us (agent_acquire != 0 keeps that form for A/B runs).
+            xcd_release();
             __syncthreads();
-            const Slot sx = slot_at(l, w0 + wave);
-            if (sx.s < 0) continue;
-            const PackRecs rx = load_recs(sx);
-            u32x4 cqx[4] = {};
-            load_cq(sx, rx, cqx);
-            const PackSamples smx = load_samples(sx, rx);
-            finish(sx, rx, smx, cqx);
+            if (agent_acquire) xcd_acquire();
         }
+        const unsigned long long tk1 = phase_clocks ? clock64() : 0;
+        // ONE copy of the level's code serves the pipelined slot (pass 0) and the further passes of a level wider than the workgroup: the
+        // kernel is 4 block sizes x (sample addressing + smoothing + 35 predictors + residual kinds) of straight-line code, and two inlined
+        // copies of it (65 KB) did not fit the 64 KB instruction cache two CUs share - a level spent more time fetching instructions than
+        // waiting for memory.  The blocks of a level do not depend on each other, so there is no release / acquire between passes; the
+        // workgroup barrier only keeps a wavefront's LDS arrays from being rewritten while some of its lanes still read them (lanes take
+        // different numbers of wave-level scheduling points inside a pass).  Every wavefront takes every pass's barrier, with or without a
+        // slot of its own (s0.nwaves is the level's: the same for all of them).
+        Slot sc = s0;
+        PackRecs rc = r0;
+        u32x4 cqc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) cqc[q] = cq0[q];
+        Slot s2 = { -1, 0, 0, 0, nullptr, nullptr };
+        PackRecs r2 = { u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
+        unsigned long long tk2 = 0, tk3 = 0;
+        const int level_waves = s0.nwaves > 0 ? s0.nwaves : 1;
+        for (int w0 = 0; w0 < level_waves; w0 += kChainWaves) {
+            if (w0) __syncthreads();
+            const PackSamples sm = load_samples(sc, rc);     // first: they hit the L2 the previous level wrote
+            if (w0) load_cq(sc, rc, cqc);                    // (pass 0 has had its residual rows prefetched a level ago)
+            issue_order_fence();
+            if (w0 == 0 && phase_clocks) pcx[0] += clock64() - tk1;
+            if (w0 == 0) {                                   // behind them: what later levels need, from HBM
+                load_cq(s1, r1, cq1);
+                issue_order_fence();
+                if (phase_clocks) pcx[1] += clock64() - tk1;
+                s2 = slot_at(l + 2, wave);
+                issue_order_fence();
+                if (phase_clocks) pcx[2] += clock64() - tk1;
+                r2 = load_recs(s2);
+            }
+            const Slot sxn = slot_at(l, w0 + kChainWaves + wave);      // ... and the records of this wavefront's slot in the next pass
+            const PackRecs rxn = load_recs(sxn);
+            issue_order_fence();
+            if (w0 == 0 && phase_clocks) tk2 = clock64();
+            finish(sc, rc, sm, cqc);
+            if (w0 == 0 && phase_clocks) tk3 = clock64();
+            sc = sxn; rc = rxn;
+        }
+        if (phase_clocks) { const unsigned long long tk4 = clock64(); pc0 += tk1 - tk0; pc1 += tk2 - tk1; pc2 += tk3 - tk2; pc3 += tk4 - tk3; }
         s0 = s1; r0 = r1;
 #pragma unroll
         for (int q = 0; q < 4; q++) cq0[q] = cq1[q];
         s1 = s2; r1 = r2;
+    }
+    if (phase_clocks && threadIdx.x == 0) {
+        atomicAdd(&phase_clocks[0], pc0); atomicAdd(&phase_clocks[1], pc1); atomicAdd(&phase_clocks[2], pc2); atomicAdd(&phase_clocks[3], pc3);
+        atomicAdd(&phase_clocks[4], (unsigned long long)nlevels);
+        atomicAdd(&phase_clocks[5], pcx[0]); atomicAdd(&phase_clocks[6], pcx[1]); atomicAdd(&phase_clocks[7], pcx[2]);
     }
 }
 

@@ -20,6 +20,15 @@ __device__ __forceinline__ unsigned sat_pack_u8_i16(unsigned x)
     return r;
 }
 
+// bytes sh .. sh + 3 of the eight bytes hi:lo (v_alignbyte_b32); four signed bytes against four signed bytes plus an accumulator
+// (v_dot4_i32_i8); four small constants as the bytes of a dword
+__device__ __forceinline__ unsigned align_bytes(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ int dot4_i8(unsigned a, unsigned b, int acc) { return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false); }
+__device__ __forceinline__ unsigned pack_i8x4(int a, int b, int c, int d)
+{
+    return ((unsigned)a & 0xffu) | (((unsigned)b & 0xffu) << 8) | (((unsigned)c & 0xffu) << 16) | ((unsigned)d << 24);
+}
+
 // acquire / release between workgroups of one XCD (they share an L2): drop what this CU's L1 holds; wait until this
 // wavefront's stores have left for the L2
 __device__ __forceinline__ void xcd_acquire() { asm volatile("buffer_inv sc1" ::: "memory"); }

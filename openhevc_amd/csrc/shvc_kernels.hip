@@ -11,6 +11,7 @@
 // factor.  Coordinates are clamped instead of reading emulated edges.  Bytes per unit: P per written sample + the
 // base-layer picture once (it is re-read through L2: 64 taps per luma sample, 16 per chroma sample).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "common.hpp"
 
@@ -109,6 +110,166 @@ __global__ __launch_bounds__(256) void upsample_kernel(ohevc_plane dst, ohevc_pl
     }
 }
 
+// ---- round 4: the tile form.  The kernel above gives every thread a column strip and lets it run BOTH passes on its own: 11 horizontal
+// filters of 8 one-byte LDS reads for 8 output rows (the strips of a workgroup overlap by 7 base-layer rows each), a sliding register
+// window, ~30 scalar multiply-adds per output sample - it was bound by instruction issue at 4.6 % of the HBM rate (profiles/r03end_*).
+// Here a workgroup of 256 threads owns a tile of 64 columns x 64 output rows and the passes are separate:
+//   1. the tile's base-layer window (at most 72 rows x 76 columns) goes to LDS once, four samples per load;
+//   2. every (base row, output column) pair is filtered horizontally ONCE: the eight samples come out of three aligned LDS dwords
+//      (v_alignbyte) and meet the taps in two v_dot4_i32_i8 (8 bit: samples biased by -128, the taps of a phase sum to 64) / four
+//      v_dot2_i32_i16 (above 8 bit); the int16 results lie column-major in LDS, a column's rows next to each other;
+//   3. an output sample is four LDS dwords (its column's eight consecutive rows: the row map is wave-uniform, so is their alignment) and
+//      four v_dot2_i32_i16 against the row's packed taps.
+// A tile whose maps jump (window larger than the LDS arrays) is left to the gather form above.
+constexpr int UPT_ROWS = 64, UPT_WR = 72, UPT_WC = 72 + 8, UPT_HS = 2 * UPT_WR + 4;     // H column stride in bytes: 37 dwords, odd (x1 needs 64 + 7 rows)
+template <typename Pixel, int TAPS>
+__global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohevc_plane src, const ohevc_upsample_tap *__restrict__ cols,
+                                                            const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
+                                                            int src_cols, int src_rows, int bit_depth)
+{
+    constexpr int HALF = TAPS / 2 - 1, P = (int)sizeof(Pixel);
+    __shared__ __attribute__((aligned(16))) unsigned char win[UPT_WR * UPT_WC * P];
+    __shared__ __attribute__((aligned(16))) unsigned char hcol[64 * UPT_HS];
+    // the tile's row-map entries and the 16 phases' taps (as int16 pairs, and for 8-bit samples as int8 quads): a row of the vertical pass
+    // otherwise costs two dependent scalar loads from memory (rows[y], then the constant table) - the kernel was bound by that latency
+    __shared__ ohevc_upsample_tap srow[UPT_ROWS];
+    __shared__ unsigned stap16[16][4], stap8[16][2];
+    const int tid = threadIdx.x, lx = tid & 63, part = tid >> 6;
+    const int tx0 = blockIdx.x * 64, tx1 = min(tx0 + 63, dst.width - 1), ty0 = blockIdx.y * UPT_ROWS, ty1 = min(ty0 + UPT_ROWS - 1, dst.height - 1);
+    // the tile's base-layer window; its first column rounded down to a multiple of four samples
+    const int cmin = (cols[col_of[tx0]].pos - HALF) & ~3, cmax = cols[col_of[tx1]].pos - HALF + TAPS - 1;
+    const int rmin = rows[ty0].pos - HALF, rmax = rows[ty1].pos - HALF + TAPS - 1;
+    const int wc = cmax - cmin + 1, wr = rmax - rmin + 1;
+    const unsigned char *sbase = static_cast<const unsigned char *>(src.data);
+    const int x = min(tx0 + lx, dst.width - 1);
+    const ohevc_upsample_tap tc = cols[col_of[x]];                  // (asked for here: two dependent loads that the window's staging hides)
+    if (wc > UPT_WC - 4 || wr > UPT_WR || wc <= 0 || wr <= 0) {
+        // maps that jump (never the reference's x1 .. x2 patterns): every output sample on its own, straight from memory
+        const int xg = tx0 + lx;
+        if (xg >= dst.width) return;
+        const int maxv = (1 << bit_depth) - 1;
+        for (int k = 0; k < UPT_ROWS / 4; k++) {
+            const int y = ty0 + part * (UPT_ROWS / 4) + k;
+            if (y >= dst.height) break;
+            const ohevc_upsample_tap tr = rows[y];
+            int acc = 1 << 11;
+            for (int q = 0; q < TAPS; q++) {
+                int ry = tr.pos - HALF + q;
+                ry = ry < 0 ? 0 : ry > src_rows - 1 ? src_rows - 1 : ry;
+                const Pixel *prow = reinterpret_cast<const Pixel *>(sbase + (size_t)ry * src.stride);
+                int h = 0;
+                for (int t = 0; t < TAPS; t++) {
+                    int rx = tc.pos - HALF + t;
+                    rx = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
+                    h += (TAPS == 8 ? (int)kUpLuma[tc.phase][t] : (int)kUpChroma[tc.phase][t]) * (int)prow[rx];
+                }
+                acc += (TAPS == 8 ? (int)kUpLuma[tr.phase][q] : (int)kUpChroma[tr.phase][q]) * (int)(short)h;
+            }
+            int v = acc >> 12;
+            v = v < 0 ? 0 : v > maxv ? maxv : v;
+            *(reinterpret_cast<Pixel *>(static_cast<unsigned char *>(dst.data) + (size_t)y * dst.stride) + xg) = (Pixel)v;
+        }
+        return;
+    }
+    if (tid < UPT_ROWS) srow[tid] = rows[min(ty0 + tid, dst.height - 1)];
+    else if (tid >= 64 && tid < 128) {
+        const int ph = (tid - 64) >> 2, q = (tid - 64) & 3;
+        const int a = 2 * q < TAPS ? (TAPS == 8 ? (int)kUpLuma[ph][2 * q] : (int)kUpChroma[ph][2 * q]) : 0;
+        const int b = 2 * q + 1 < TAPS ? (TAPS == 8 ? (int)kUpLuma[ph][2 * q + 1] : (int)kUpChroma[ph][2 * q + 1]) : 0;
+        stap16[ph][q] = pack16(a, b);
+    } else if (tid >= 128 && tid < 160) {
+        const int ph = (tid - 128) >> 1, q = (tid - 128) & 1;
+        const signed char *t8 = TAPS == 8 ? kUpLuma[ph] : kUpChroma[ph];
+        stap8[ph][q] = 4 * q < TAPS ? pack_i8x4(t8[4 * q], t8[4 * q + 1], t8[4 * q + 2], t8[4 * q + 3]) : 0u;
+    }
+    // ---- 1. the window, four samples per thread and step
+    {
+        const int wc4 = (wc + 3) >> 2;
+        const bool inside = cmin >= 0 && cmin + 4 * wc4 <= src_cols;
+        for (int i = tid; i < wc4 * wr; i += 256) {
+            const int r = i / wc4, c4 = i - r * wc4;
+            int ry = rmin + r;
+            ry = ry < 0 ? 0 : ry > src_rows - 1 ? src_rows - 1 : ry;
+            const unsigned char *srow = sbase + (size_t)ry * src.stride;
+            Pixel v[4];
+            if (inside) {
+                if constexpr (P == 1) *reinterpret_cast<unsigned *>(v) = *reinterpret_cast<const unsigned *>(srow + cmin + 4 * c4);
+                else                  *reinterpret_cast<u32x2 *>(v) = *reinterpret_cast<const u32x2 *>(srow + (size_t)(cmin + 4 * c4) * 2);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int rx = cmin + 4 * c4 + k;
+                    rx = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
+                    v[k] = reinterpret_cast<const Pixel *>(srow)[rx];
+                }
+            }
+            if constexpr (P == 1) *reinterpret_cast<unsigned *>(win + r * UPT_WC + 4 * c4) = *reinterpret_cast<const unsigned *>(v);
+            else                  *reinterpret_cast<u32x2 *>(win + (r * UPT_WC + 4 * c4) * 2) = *reinterpret_cast<const u32x2 *>(v);
+        }
+    }
+    __syncthreads();
+    // ---- 2. horizontal pass: thread = (output column lx, base rows part, part + 4, ...)
+    {
+        const int lc = tc.pos - HALF - cmin;                       // first tap's column inside the window (>= 0)
+        unsigned tp[4];                                             // the phase's taps, packed
+        if constexpr (P == 1) { tp[0] = stap8[tc.phase][0]; tp[1] = stap8[tc.phase][1]; tp[2] = tp[3] = 0u; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) tp[k] = stap16[tc.phase][k];
+        }
+        for (int r = part; r < wr; r += 4) {
+            int h;
+            if constexpr (P == 1) {
+                const unsigned *w32 = reinterpret_cast<const unsigned *>(win + r * UPT_WC) + (lc >> 2);
+                const unsigned a0 = w32[0], a1 = w32[1], a2 = TAPS == 8 ? w32[2] : 0u;
+                const unsigned sh = (unsigned)(lc & 3);
+                const unsigned lo = align_bytes(a1, a0, sh) ^ 0x80808080u;       // samples - 128 as int8
+                h = dot4_i8(lo, tp[0], 128 * 64);
+                if constexpr (TAPS == 8) h = dot4_i8(align_bytes(a2, a1, sh) ^ 0x80808080u, tp[1], h);
+            } else {
+                const unsigned *w32 = reinterpret_cast<const unsigned *>(win + (r * UPT_WC) * 2) + (lc >> 1);
+                const bool odd = lc & 1;
+                unsigned a[5];
+#pragma unroll
+                for (int k = 0; k < TAPS / 2 + 1; k++) a[k] = w32[k];
+                h = 0;
+#pragma unroll
+                for (int k = 0; k < TAPS / 2; k++) h = dot2_i16(odd ? align_bytes(a[k + 1], a[k], 2u) : a[k], tp[k], h);
+            }
+            *reinterpret_cast<short *>(hcol + lx * UPT_HS + 2 * r) = (short)h;      // the reference keeps this pass in int16: it wraps above 8 bit
+        }
+    }
+    __syncthreads();
+    // ---- 3. vertical pass: thread = (output column lx, output rows part * 8 .. + 7)
+    if (tx0 + lx >= dst.width) return;
+    const int maxv = (1 << bit_depth) - 1;
+    const unsigned *hc = reinterpret_cast<const unsigned *>(hcol + lx * UPT_HS);
+    unsigned a[5] = {};
+    int have = -1;                                                  // the first row a[] holds (wave-uniform): consecutive output rows mostly share it
+#pragma unroll
+    for (int k = 0; k < UPT_ROWS / 4; k++) {
+        const int yy = part * (UPT_ROWS / 4) + k, y = ty0 + yy;
+        if (y >= dst.height) break;
+        const ohevc_upsample_tap tr = srow[yy];                     // wave-uniform
+        const int f = tr.pos - HALF - rmin;                         // first of the TAPS rows
+        if (f != have) {
+#pragma unroll
+            for (int q = 0; q < TAPS / 2 + 1; q++) a[q] = hc[(f >> 1) + q];
+            if (f & 1) {
+#pragma unroll
+                for (int q = 0; q < TAPS / 2; q++) a[q] = align_bytes(a[q + 1], a[q], 2u);
+            }
+            have = f;
+        }
+        int acc = 1 << 11;                                          // I_OFFSET, hevcdsp.h:40-41
+#pragma unroll
+        for (int q = 0; q < TAPS / 2; q++) acc = dot2_i16(a[q], stap16[tr.phase][q], acc);
+        int v = acc >> 12;                                          // N_SHIFT
+        v = v < 0 ? 0 : v > maxv ? maxv : v;
+        *(reinterpret_cast<Pixel *>(static_cast<unsigned char *>(dst.data) + (size_t)y * dst.stride) + tx0 + lx) = (Pixel)v;
+    }
+}
+
 // Where an enhancement-layer column / row reads the base layer: centre tap position and phase.
 //   variant 0: the general formula of upsample_base_layer_frame (hevcdsp_template.c:2217-2226, 2255-2262, 2317-2325, 2364-2372)
 //              and of the *_all block slots (:1835-1953);
@@ -135,6 +296,9 @@ static void axis_map(int variant, bool chroma, bool vertical, int v, int start, 
 }
 
 }  // namespace ohevc
+
+static int g_upsample_variant = getenv("OHEVC_UPSAMPLE_VARIANT") ? atoi(getenv("OHEVC_UPSAMPLE_VARIANT")) : 0;      // 0: tile form (shipped), 1: round-2 strip form
+extern "C" int ohevc_debug_set_upsample_variant(int v) { const int prev = g_upsample_variant; g_upsample_variant = v; return prev; }
 
 extern "C" int ohevc_upsample_make_maps(const ohevc_upsample_params *p, int plane, ohevc_upsample_tap *cols, int16_t *col_of,
                                         ohevc_upsample_tap *rows, int *src_cols, int *src_rows)
@@ -178,6 +342,18 @@ extern "C" int ohevc_dev_upsample_plane(const ohevc_plane *dst, const ohevc_plan
     // never read below the plane that was handed over (the reference would read its frame padding there, see make_maps)
     src_cols = std::min(src_cols, src->width); src_rows = std::min(src_rows, src->height);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_upsample_variant == 0) {
+        const dim3 tgrid((dst->width + 63) / 64, (dst->height + UPT_ROWS - 1) / UPT_ROWS);
+        if (bit_depth == 8) {
+            if (chroma) hipLaunchKernelGGL((upsample_tile_kernel<uint8_t, 4>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+            else        hipLaunchKernelGGL((upsample_tile_kernel<uint8_t, 8>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+        } else {
+            if (chroma) hipLaunchKernelGGL((upsample_tile_kernel<uint16_t, 4>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+            else        hipLaunchKernelGGL((upsample_tile_kernel<uint16_t, 8>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+        }
+        OHEVC_HIP_TRY(hipGetLastError());
+        return OHEVC_OK;
+    }
     constexpr int ROWS = 8;                                     // output rows per thread (sliding window of filtered base-layer rows)
     const dim3 grid((dst->width + 63) / 64, (dst->height + 4 * ROWS - 1) / (4 * ROWS));
     if (bit_depth == 8) {

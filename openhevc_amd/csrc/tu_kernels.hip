@@ -1781,6 +1781,23 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
 // one workgroup costs further passes of it (the caller decides from which width on a launch of its own is cheaper)
 extern "C" int ohevc_intra_chain_max_waves(void) { return 1 << 20; }
 extern "C" int ohevc_intra_chain_workgroup_waves(void) { return ohevc::kChainWaves; }
+extern "C" int ohevc_intra_chain_max_levels(void) { return ohevc::kChainMaxLevels; }      // levels one launch takes (their records sit in LDS)
+// diagnosis: five 64-bit counters in device memory the chain kernel's wavefront 0 adds its phase clocks to (ohevc_debug.h)
+static unsigned long long *g_chain_clocks = nullptr;
+extern "C" int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8])
+{
+    if (on && !g_chain_clocks) {
+        OHEVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_chain_clocks), 8 * sizeof(unsigned long long)));
+        OHEVC_HIP_TRY(hipMemset(g_chain_clocks, 0, 8 * sizeof(unsigned long long)));
+    }
+    if (out && g_chain_clocks) {
+        OHEVC_HIP_TRY(hipDeviceSynchronize());
+        OHEVC_HIP_TRY(hipMemcpy(out, g_chain_clocks, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (!on && g_chain_clocks) { (void)hipFree(g_chain_clocks); g_chain_clocks = nullptr; }
+    return OHEVC_OK;
+}
+static int g_chain_agent_acquire = getenv("OHEVC_CHAIN_AGENT_ACQUIRE") ? atoi(getenv("OHEVC_CHAIN_AGENT_ACQUIRE")) : 0;      // A/B: the round-3 hand-over (buffer_inv sc1 per level)
 
 extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                                     const int16_t *coeffs, void *stream)
@@ -1789,7 +1806,7 @@ extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth,
     static_assert(sizeof(ohevc_intra_chain_level) == sizeof(IntraChainLevel) && sizeof(IntraChainLevel) == 48, "level record layout");
     OHEVC_REQUIRE(planes != nullptr, "planes");
     OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
-    OHEVC_REQUIRE(nlevels >= 0, "nlevels");
+    OHEVC_REQUIRE(nlevels >= 0 && nlevels <= kChainMaxLevels, "nlevels (at most ohevc_intra_chain_max_levels() per launch)");
     if (nlevels == 0) return OHEVC_OK;
     OHEVC_REQUIRE(base != nullptr && levels != nullptr && (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (reinterpret_cast<uintptr_t>(levels) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "arrays must be 16-byte aligned");
@@ -1802,8 +1819,8 @@ extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth,
     if (coeffs != nullptr)
         hipLaunchKernelGGL(intra_chain_residual_kernel, dim3(32, nlevels), dim3(64), 0, st, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth,
                            const_cast<int16_t *>(coeffs));
-    if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
-    else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs);
+    if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs, g_chain_agent_acquire, g_chain_clocks);
+    else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs, g_chain_agent_acquire, g_chain_clocks);
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }

@@ -218,6 +218,7 @@ static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu)
 #include "hipemu_mfma.hpp"
 
 // ---------------------------------------------------------------- atomics / small math
+static inline unsigned long long clock64() { return 0; }      // (no device clock on the host: the phase counters of diagnosis builds read 0)
 template <typename T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <typename T> static inline T atomicMax(T *p, T v)
 {

@@ -18,6 +18,21 @@ static inline unsigned sat_pack_u8_i16(unsigned x)
     return a | (b << 8);
 }
 
+static inline unsigned align_bytes(unsigned hi, unsigned lo, unsigned sh)
+{
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    return (unsigned)(v >> (8 * (sh & 3)));
+}
+static inline int dot4_i8(unsigned a, unsigned b, int acc)
+{
+    for (int k = 0; k < 4; k++) acc += (int)(signed char)(a >> (8 * k)) * (int)(signed char)(b >> (8 * k));
+    return acc;
+}
+static inline unsigned pack_i8x4(int a, int b, int c, int d)
+{
+    return ((unsigned)a & 0xffu) | (((unsigned)b & 0xffu) << 8) | (((unsigned)c & 0xffu) << 16) | ((unsigned)d << 24);
+}
+
 // cache maintenance between workgroups: nothing to do on one coherent host memory
 static inline void xcd_acquire() {}
 static inline void xcd_release() {}
