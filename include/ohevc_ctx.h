@@ -136,6 +136,12 @@ int  ohevc_ctx_has_device(const ohevc_ctx *ctx);
 
 /* upload + launch prediction/residual work recorded so far (may be called several times per frame) */
 int  ohevc_frame_reconstruct(ohevc_ctx *ctx);
+/* The same, for the end of a CTU row of a picture WITHOUT inter prediction so far (an intra picture: one long dependency chain on the device
+ * that the rest of its GOP waits for): hands the recorded work over if at least min_pending_kib KiB of job records and coefficients are waiting, so that the device
+ * works on the picture's first rows while the host parses its last.  A no-op for frames that have recorded inter prediction (their reference
+ * pictures' frame ends may not be issued yet: that wait belongs at the frame end), for contexts several threads record into, and for
+ * record-only contexts. */
+int  ohevc_frame_flush_intra(ohevc_ctx *ctx, int min_pending_kib);
 /* reconstruct + in-loop filters (vertical edges, horizontal edges, SAO); the picture is final when this returns OK
  * and the stream has drained (ohevc_ctx_sync / ohevc_pic_download) */
 int  ohevc_frame_end(ohevc_ctx *ctx);

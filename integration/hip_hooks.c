@@ -592,8 +592,20 @@ void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size)
     }
 }
 
+/* End of a CTU row of a picture this thread parses alone: what has been recorded of an intra picture goes to the device now
+ * (ohevc_frame_flush_intra: a no-op once the picture has inter prediction, and until flush_intra_kib KiB of records and coefficients are
+ * waiting - a flush cuts the picture's dependency chain into bands that run one after the other, so it only pays for pictures whose
+ * parsing takes much longer than their chain: dense residuals, 4K / 8K; ohevc_ctx.h has the measurement). */
+static void row_end(HEVCContext *s, int x_ctb, int ctb_size)
+{
+    if (t_frame_open && t_ctx && t_be && s == t_s && t_be->opt.flush_intra_kib > 0 && x_ctb >= s->sps->width - ctb_size &&
+        !((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1) && ohevc_frame_flush_intra(t_ctx, t_be->opt.flush_intra_kib) != OHEVC_OK)
+        note_error(t_be);
+}
+
 void ohhip_hls_filters(HEVCContext *s, int x_ctb, int y_ctb, int ctb_size)
 {
+    row_end(s, x_ctb, ctb_size);
     if (!bulk_filters(s)) {
         ff_hevc_hls_filters(s, x_ctb, y_ctb, ctb_size);
         return;
@@ -723,6 +735,7 @@ void ohhip_options_default(ohhip_options *o)
     o->record_only = getenv("OHHIP_RECORD_ONLY") != NULL;
     o->test_fail_index = getenv("OHHIP_TEST_FAIL_INDEX") ? atoi(getenv("OHHIP_TEST_FAIL_INDEX")) : -1;
     o->trace_path = getenv("OHHIP_TRACE_FRAMES");
+    o->flush_intra_kib = getenv("OHHIP_FLUSH_INTRA_KIB") ? atoi(getenv("OHHIP_FLUSH_INTRA_KIB")) : 4096;
 }
 
 ohhip_backend *ohhip_backend_new(const ohhip_options *o)

@@ -134,6 +134,7 @@ static int g_level_launch = 2;        // ohevc_debug_set_level_launch
 // The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
 // launch of its own ~6.6 us of kernel plus 2 - 4 us until the next one starts, whatever its width: up to four passes the chain is cheaper.
 static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 32;
+static int g_intra_chain_min_run = getenv("OHEVC_INTRA_CHAIN_MIN_RUN") ? atoi(getenv("OHEVC_INTRA_CHAIN_MIN_RUN")) : 2;      // shortest run (levels) worth a chain launch
 static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
 // OHEVC_UPLOAD_LANES=2: the filter maps of a frame end travel through a staging / device buffer pair of their own, so their staging copy does
 // not wait on the host for the job arrays' H2D copy (which sits in the stream behind the reference pictures' completion).  1 (default): one pair.
@@ -236,6 +237,9 @@ struct ohevc_ctx : Rec {
     int bypass_w = 0, bypass_l2 = 0, bypass_exact = 0;
     std::vector<uint16_t> level_map[3];
     int lm_w[3] = {}, lm_h[3] = {};
+    int recon_lane = 0, last_recon_lane = 0;      // the staging / device buffer pair the next / the last ohevc_frame_reconstruct upload takes
+    int flushed_intra = 0;            // ohevc_frame_flush_intra: intra jobs of this frame already handed to the device by an early flush
+    bool flush_closed = false;        // ... and no further early flush for this frame (it has inter prediction: its references may not be issued yet)
     int frame_mode = 0;               // g_level_launch as it was at frame_begin (one executor per picture)
     int log2_ctb = 0;                 // CTB size named by the picture's intra jobs (0: none seen yet, -1: they disagree)
     std::vector<ohevc_ctb_task> ctb_tasks;                // scratch of frame_reconstruct
@@ -918,6 +922,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     c->ref_slots.clear();
     c->target_guarded = false;
     c->frame_mode = g_level_launch;
+    c->flushed_intra = 0; c->flush_closed = false;
     c->log2_ctb = 0;
     for (int i = 0; i < 3; i++) {
         c->lm_w[i] = (p->planes[i].width + 3) >> 2;
@@ -1713,7 +1718,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             if (!narrow(l)) { l++; continue; }
             int e = l;
             while (e + 1 <= c->max_level && c->levels[e].touched == 0 && narrow(e + 1) && e - l + 1 < ohevc_intra_chain_max_levels()) e++;
-            if (e > l) {
+            if (e - l + 1 >= g_intra_chain_min_run) {       // (a run costs two launches - the transforms, then the chain: short ones go level by level)
                 c->chain_first[l] = (int)chain.size();
                 c->chain_len[l] = e - l + 1;
                 for (int k = l; k <= e; k++) {
@@ -1789,9 +1794,16 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         total += c->tail_total;
         c->tail_parts.clear();
     }
-    if ((rc = upload_jobs(c, parts, total, 0)) != OHEVC_OK) return rc;
+    // Early flushes of one picture (ohevc_frame_flush_intra) alternate between the two staging / device buffer pairs: with one pair the
+    // parsing thread stood still in every flush until the device had finished the chain of the flush before (the arena that chain reads
+    // is what this upload overwrites, and the staging copy waits for the upload in front of it).  OHEVC_UPLOAD_LANES=2 gives the second
+    // pair to the filter maps instead.
+    const int rlane = g_upload_lanes != 2 ? c->recon_lane : 0;
+    if (g_upload_lanes != 2) c->recon_lane ^= 1;
+    c->last_recon_lane = rlane;
+    if ((rc = upload_jobs(c, parts, total, rlane)) != OHEVC_OK) return rc;
     struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 1, g_trace_timing ? now_s() : 0};
-    unsigned char *base = static_cast<unsigned char *>(c->d_jobs[0].p);
+    unsigned char *base = static_cast<unsigned char *>(c->d_jobs[rlane].p);
     const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
 
     // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
@@ -1923,6 +1935,30 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     return OHEVC_OK;
 }
 
+// An intra-coded picture is one long dependency chain on the device (a 1080p picture: ~1000 levels, milliseconds) and, in a random-access
+// stream, what every other picture of its GOP waits for.  Its blocks do not have to wait for the picture's last CTU to be parsed: whatever
+// has been recorded can run while the host parses on (ohevc_frame_reconstruct may be called any number of times per frame; the levels of a
+// later call start behind the earlier call's in the stream).  The front end calls this at the end of every CTU row; it hands the recorded
+// work over when the frame has no inter prediction so far (a frame with references would have to wait here, on the parsing thread, for
+// their frame ends to be issued - that wait belongs at the frame end) and at least min_pending_kib KiB of records and coefficients are
+// waiting.  The price of a flush: the blocks of a band form a chain of their own - a picture's dependency levels run along diagonals
+// through ALL of its CTU rows (level ~ x / 4 + 2 y / 4), a band of h rows still has W / 4 + 2 h / 4 of them - so cutting a 1080p intra
+// picture into its 17 CTU rows makes ~8700 levels out of ~1000 and the device falls behind the parser instead of keeping up with it
+// (measured: profiles/r4n_*; 1414 against 1576 fps with 16 frame threads on the encoder-like stream).  It pays where a picture's parsing
+// takes much longer than its chain: dense residuals, 4K / 8K pictures - hence a threshold in bytes, not in rows.
+extern "C" int ohevc_frame_flush_intra(ohevc_ctx *c, int min_pending_kib)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    if (c->dry || c->concurrent || c->flush_closed) return OHEVC_OK;
+    if (!c->mc.empty() || !c->mc_small.empty()) { c->flush_closed = true; return OHEVC_OK; }
+    // what an upload of the recorded work would carry: the coefficient arena and ~32 bytes of records per intra block
+    const size_t pending = c->coeffs.size() * sizeof(int16_t) + (size_t)(c->nstat[2] - c->flushed_intra) * 32;
+    if (pending < (size_t)min_pending_kib * 1024) return OHEVC_OK;
+    c->flushed_intra = c->nstat[2];
+    return ohevc_frame_reconstruct(c);
+}
+
 // A frame that cannot be completed must still be PUBLISHED: other decoding threads block (for up to 20 s each) until the frame_end of
 // every picture they reference has been issued.  Marks the picture complete-and-failed; dependents return OHEVC_ERR_STATE at once.
 extern "C" int ohevc_frame_abort(ohevc_ctx *c)
@@ -1994,10 +2030,11 @@ static int frame_end_impl(ohevc_ctx *c)
         c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
     }
     if (filters) {
-        int lane = 0;
+        int lane = c->last_recon_lane;                  // (the maps rode with the job arrays of the reconstruction above)
         size_t tail = c->tail_base;
         if (tail == SIZE_MAX) {                           // nothing was reconstructed (or OHEVC_UPLOAD_LANES=2): an upload of their own
-            lane = g_upload_lanes == 2 ? 1 : 0;
+            lane = g_upload_lanes == 2 ? 1 : c->recon_lane;
+            if (g_upload_lanes != 2) c->recon_lane ^= 1;
             if ((rc = upload_jobs(c, parts, total, lane)) != OHEVC_OK) return rc;
             tail = 0;
         }

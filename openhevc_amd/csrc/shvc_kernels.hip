@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
     // the tile's row-map entries and the 16 phases' taps (as int16 pairs, and for 8-bit samples as int8 quads): a row of the vertical pass
     // otherwise costs two dependent scalar loads from memory (rows[y], then the constant table) - the kernel was bound by that latency
     __shared__ ohevc_upsample_tap srow[UPT_ROWS];
-    __shared__ unsigned stap16[16][4], stap8[16][2];
+    __shared__ __attribute__((aligned(16))) unsigned stap16[16][4];
+    __shared__ unsigned stap8[16][2];
     const int tid = threadIdx.x, lx = tid & 63, part = tid >> 6;
     const int tx0 = blockIdx.x * 64, tx1 = min(tx0 + 63, dst.width - 1), ty0 = blockIdx.y * UPT_ROWS, ty1 = min(ty0 + UPT_ROWS - 1, dst.height - 1);
     // the tile's base-layer window; its first column rounded down to a multiple of four samples
@@ -262,8 +263,10 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
             have = f;
         }
         int acc = 1 << 11;                                          // I_OFFSET, hevcdsp.h:40-41
+        const u32x4 tq = *reinterpret_cast<const u32x4 *>(&stap16[tr.phase][0]);       // the row's four tap pairs in one LDS read
+        const unsigned tqa[4] = { tq.x, tq.y, tq.z, tq.w };
 #pragma unroll
-        for (int q = 0; q < TAPS / 2; q++) acc = dot2_i16(a[q], stap16[tr.phase][q], acc);
+        for (int q = 0; q < TAPS / 2; q++) acc = dot2_i16(a[q], tqa[q], acc);
         int v = acc >> 12;                                          // N_SHIFT
         v = v < 0 ? 0 : v > maxv ? maxv : v;
         *(reinterpret_cast<Pixel *>(static_cast<unsigned char *>(dst.data) + (size_t)y * dst.stride) + tx0 + lx) = (Pixel)v;

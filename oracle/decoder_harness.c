@@ -25,7 +25,7 @@
 #ifdef OHDEC_HIP
 /* integration/hip_backend.h: one back end per decoder instance, attached before avcodec_open2 (the structs are passed through opaquely) */
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index; const char *trace_path; } ohdec_options;
+typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib; const char *trace_path; } ohdec_options;
 void ohhip_options_default(ohdec_options *o);
 ohhip_backend *ohhip_backend_new(const ohdec_options *o);
 int  ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx);
@@ -39,7 +39,7 @@ void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx);
 int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 #else
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index; const char *trace_path; } ohdec_options;
+typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib; const char *trace_path; } ohdec_options;
 static void ohhip_options_default(ohdec_options *o) { memset(o, 0, sizeof(*o)); }
 static ohhip_backend *ohhip_backend_new(const ohdec_options *o) { (void)o; return NULL; }
 static int  ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx) { (void)be; (void)avctx; return 0; }

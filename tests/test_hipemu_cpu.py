@@ -176,6 +176,18 @@ def test_emu_fuzzed_streams():
     assert r.returncode == 0 and res["failed"] == 0 and res["streams"] >= 1, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("name", ["intra_8b", "intra_10b_ctb16", "ra_8b_ctb64", "cip", "pcm", "tiles", "small_blocks", "fmt444_14b_cip_cross", "slices"])
+def test_emu_golden_stream_with_an_early_flush_at_every_ctu_row(name, monkeypatch):
+    """ohevc_frame_flush_intra (see tests/test_stream_gpu.py): every CTU row of a picture without inter prediction is a flush of its own."""
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_FLUSH_INTRA_KIB", "1")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
+
+
 # ---------------------------------------------------------------- decoder instances (integration/hip_backend.h), over the emulated device code
 def _instances():
     ps = _stream_lib()

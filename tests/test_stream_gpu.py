@@ -235,6 +235,15 @@ def test_damaged_access_units_do_not_silence_the_stream(name, threads, monkeypat
     body.__wrapped__(name, threads, KeepEnv()) if hasattr(body, "__wrapped__") else body(name, threads, KeepEnv())
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_stream_with_an_early_flush_at_every_ctu_row(name, monkeypatch):
+    """ohevc_frame_flush_intra: what has been recorded of a picture without inter prediction goes to the device at the end of every CTU row
+    (threshold 1 KiB instead of 4 MiB: these pictures are small), so the levels of later rows start behind the earlier rows' in the stream."""
+    monkeypatch.setenv("OHHIP_FLUSH_INTRA_KIB", "1")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hip", aus)) == md5
+
+
 # ---------------------------------------------------------------- decoder instances (integration/hip_backend.h)
 def test_two_decoders_decode_different_streams_concurrently():
     import instance_cases
