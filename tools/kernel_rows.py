@@ -5,15 +5,19 @@ Workloads are those of tools/bench_kernels.py --resident --planes 8 (the rows of
 plane (eight 4K pictures stacked) tiled with jobs of one kind; every launch takes the next entry of a ring of pictures that is at least
 RING_BYTES large (destinations, and for motion compensation / SAO their sources too), written once at set-up, so nothing a launch touches is
 cache-resident from the launch before: the GB/s are HBM numbers.  Time = median over the launches of HIP events recorded on the launch
-stream (torch's current stream: the launches are issued on it).  `achieved` = algorithmic bytes per launch (SURVEY.md 8d per-unit figures
+stream (torch's current stream: the launches are issued on it), around bursts of four launches.  `achieved` = algorithmic bytes per launch (SURVEY.md 8d per-unit figures
 x units) / that time; `frac` = achieved / 8 TB/s.
 
 Check: one more launch on a fresh picture whose state before the launch was kept; a sample of the launch's units (blocks, edges, CTBs) is
 recomputed by the oracle from that state and compared sample by sample with what the device wrote."""
+import os
+import sys
+
 import numpy as np
 import torch
 
-from openhevc_amd import lib as L
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openhevc_amd import lib as L  # noqa: E402
 
 W, H = 3840, 2160 * 8
 PEAK = 8000.0
@@ -46,24 +50,30 @@ def _bytes(pic):
     return sum(t.numel() * t.element_size() for t in pic if t is not None)
 
 
-def _time(launch, fresh, extra=None, extra_bytes=0, reps=10):
-    """launch(pic, ex); ring of fresh() pictures (+ extra(k) sources) of at least RING_BYTES; median ms over reps launches after 2 warm-ups"""
+def _time(launch, fresh, extra=None, extra_bytes=0, reps=10, burst=4):
+    """launch(pic, ex); ring of fresh() pictures (+ extra(k) sources) of at least RING_BYTES.  One measurement = HIP events around a BURST of
+    launches on consecutive ring entries, divided by their number (a lone 50-150 us kernel between two events reads 10-15 us long: the events'
+    own latency; rocprofv3's per-dispatch durations - profiles/r4p_* - are what the burst form agrees with); median over reps bursts after
+    one warm-up burst."""
     st = torch.cuda.current_stream()
     first = fresh()
     n_ring = max(2, -(-RING_BYTES // max(1, _bytes(first) + extra_bytes)))
     ring = [first] + [fresh() for _ in range(n_ring - 1)]
     ex = [extra(k) for k in range(n_ring)] if extra else [None] * n_ring
+    burst = max(1, min(burst, n_ring))
     torch.cuda.synchronize()
     ts = []
-    for r in range(reps + 2):
-        k = r % n_ring
+    k = 0
+    for r in range(reps + 1):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(st)
-        launch(ring[k], ex[k])
+        for _ in range(burst):
+            launch(ring[k % n_ring], ex[k % n_ring])
+            k += 1
         b.record(st)
         torch.cuda.synchronize()
-        if r >= 2:
-            ts.append(a.elapsed_time(b))
+        if r >= 1:
+            ts.append(a.elapsed_time(b) / burst)
     ring_bytes = n_ring * (_bytes(first) + extra_bytes)
     del ring, ex
     torch.cuda.empty_cache()
