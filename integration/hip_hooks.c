@@ -760,8 +760,10 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
     if (o->record_only)
         ohevc_debug_set_record_only(1);
     /* process-wide A/B switches of the library (include/ohevc_debug.h), kept as environment variables: the executor of the intra-coded
-     * blocks (0 levels, 1 level kernel, 3 CTB tasks, default 2 = chosen per picture) and the host derivation of the deblocking parameters */
-    ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 2);
+     * blocks (0 levels - the default since the chain kernel takes a picture's levels in one launch: recording the CTB form beside them cost the
+     * parser 1-5 % for a choice the levels now always win, profiles/r4q_levelmode_ab_summary.txt -, 1 level kernel, 3 CTB tasks, 2 = both
+     * recorded, chosen per picture) and the host derivation of the deblocking parameters */
+    ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 0);
     if (getenv("OHHIP_DEVICE_FILTERS"))
         ohevc_debug_set_filters_on_device(atoi(getenv("OHHIP_DEVICE_FILTERS")));
     if (ohevc_ctx_create(&be->root, o->device) != OHEVC_OK) {

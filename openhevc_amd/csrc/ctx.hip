@@ -124,13 +124,15 @@ static std::atomic<uint64_t> g_ctx_gen{1};
 // executor of the intra-coded blocks (ohevc_debug_set_level_launch):
 //   0  one prediction launch and one residual launch per dependency level;   1  all levels inside one ohevc_dev_levels launch;
 //   3  one ohevc_dev_ctbs launch per picture: CTBs as tasks, their samples in LDS, operations in decoding order;
-//   2  (shipped) both forms are recorded and the cheaper one is chosen per picture from the recorded work itself: the CTB form when
+//   0 is the default since round 4 (the chain kernel takes the levels of a picture in one launch or a few; recording both forms costs the
+//      parser 1-5 %, profiles/r4q_levelmode_ab_summary.txt).
+//   2  both forms are recorded and the cheaper one is chosen per picture from the recorded work itself: the CTB form when
 //      its longest chain of dependent CTBs is short (sparse intra blocks: encoder-like inter pictures), the level form otherwise.
 // Pictures whose intra jobs name no CTB size always take the level form.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
-static int g_level_launch = 2;        // ohevc_debug_set_level_launch
+static int g_level_launch = 0;        // ohevc_debug_set_level_launch
 // The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
 // launch of its own ~6.6 us of kernel plus 2 - 4 us until the next one starts, whatever its width: up to four passes the chain is cheaper.
 static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 32;

@@ -630,8 +630,9 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
                 if (phase_clocks) pcx[2] += clock64() - tk1;
                 r2 = load_recs(s2);
             }
-            const Slot sxn = slot_at(l, w0 + kChainWaves + wave);      // ... and the records of this wavefront's slot in the next pass
-            const PackRecs rxn = load_recs(sxn);
+            Slot sxn = { -1, 0, 0, 0, nullptr, nullptr };             // ... and the records of this wavefront's slot in the next pass, if there is one
+            PackRecs rxn = { u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
+            if (w0 + kChainWaves < level_waves) { sxn = slot_at(l, w0 + kChainWaves + wave); rxn = load_recs(sxn); }
             issue_order_fence();
             if (w0 == 0 && phase_clocks) tk2 = clock64();
             finish(sc, rc, sm, cqc);

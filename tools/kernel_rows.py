@@ -5,7 +5,7 @@ Workloads are those of tools/bench_kernels.py --resident --planes 8 (the rows of
 plane (eight 4K pictures stacked) tiled with jobs of one kind; every launch takes the next entry of a ring of pictures that is at least
 RING_BYTES large (destinations, and for motion compensation / SAO their sources too), written once at set-up, so nothing a launch touches is
 cache-resident from the launch before: the GB/s are HBM numbers.  Time = median over the launches of HIP events recorded on the launch
-stream (torch's current stream: the launches are issued on it), around bursts of four launches.  `achieved` = algorithmic bytes per launch (SURVEY.md 8d per-unit figures
+stream (torch's current stream: the launches are issued on it), around bursts of eight launches.  `achieved` = algorithmic bytes per launch (SURVEY.md 8d per-unit figures
 x units) / that time; `frac` = achieved / 8 TB/s.
 
 Check: one more launch on a fresh picture whose state before the launch was kept; a sample of the launch's units (blocks, edges, CTBs) is
@@ -50,7 +50,7 @@ def _bytes(pic):
     return sum(t.numel() * t.element_size() for t in pic if t is not None)
 
 
-def _time(launch, fresh, extra=None, extra_bytes=0, reps=10, burst=4):
+def _time(launch, fresh, extra=None, extra_bytes=0, reps=8, burst=8):
     """launch(pic, ex); ring of fresh() pictures (+ extra(k) sources) of at least RING_BYTES.  One measurement = HIP events around a BURST of
     launches on consecutive ring entries, divided by their number (a lone 50-150 us kernel between two events reads 10-15 us long: the events'
     own latency; rocprofv3's per-dispatch durations - profiles/r4p_* - are what the burst form agrees with); median over reps bursts after
@@ -60,7 +60,7 @@ def _time(launch, fresh, extra=None, extra_bytes=0, reps=10, burst=4):
     n_ring = max(2, -(-RING_BYTES // max(1, _bytes(first) + extra_bytes)))
     ring = [first] + [fresh() for _ in range(n_ring - 1)]
     ex = [extra(k) for k in range(n_ring)] if extra else [None] * n_ring
-    burst = max(1, min(burst, n_ring))
+    burst = max(1, burst if n_ring >= 3 else n_ring)       # (the ring is passed over more than once per burst: an entry is 100-300 MB, the caches hold none of it by then)
     torch.cuda.synchronize()
     ts = []
     k = 0
