@@ -109,6 +109,11 @@ int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8]);      /* [
 /* SHVC up-sampling kernel: 0 = the tile form (shipped: a workgroup per 64 x 32 output tile, both passes through LDS, dot instructions),
  * 1 = the round-2 strip form (a thread per column strip).  Returns the previous value.  Environment: OHEVC_UPSAMPLE_VARIANT. */
 int ohevc_debug_set_upsample_variant(int variant);
+/* Deblocking from the maps (ohevc_dev_deblock_maps): 0 = a lane per 4-line luma segment with packed 16-bit arithmetic (shipped, up to 10 bit),
+ * 1 = a lane per line (rounds 2-3; what deeper pictures and unaligned planes take anyway).  Returns the previous value.
+ * Environment: OHEVC_DEBLOCK_VARIANT. */
+int ohevc_debug_set_deblock_variant(int variant);
+long long ohevc_debug_deblock_segment_launches(void);       /* launches that took form 0 so far (tests: which form ran) */
 /* The file-system rendezvous of the native transport's RCCL wire (ohevc_frames.h) without RCCL: rank 0 hands the 128 bytes in `id` to the
  * other ranks (who receive them in `id`), through `path`, with the nonce handshake that keeps a file of an earlier run from being accepted.
  * Tests only. */

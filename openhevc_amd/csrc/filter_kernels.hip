@@ -10,6 +10,7 @@
 // (the reference's sao_frame, hevc_filter.c:269-315), writes the picture; one workgroup per CTB plane block.
 #include "common.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace ohevc {
 
@@ -188,14 +189,16 @@ OHEVC_CONST_TABLE unsigned char kDbkTc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 
                                                4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
 OHEVC_CONST_TABLE unsigned char kDbkQpC[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
 
-template <typename Pixel>
-__global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohevc_dbk_maps m, int vertical, int bit_depth, int luma_units, int chroma_units,
-                                                           int luma_uw, int chroma_uw)
-{
+// `wave`: which run of 8 units this wavefront takes (the kernels below number their wavefronts differently)
+template <typename Pixel, bool CHROMA_ONLY = false>
+__device__ __forceinline__ void deblock_maps_lines(unsigned char *base0, unsigned char *base1, unsigned char *base2, int stride0, int stride1, int stride2,
+                                                   const ohevc_dbk_maps &m, int vertical, int bit_depth, int luma_units, int chroma_units,
+                                                   int luma_uw, int chroma_uw, int wave)
+{      // (the planes arrive as scalars: a PlaneSet behind a reference becomes a scratch copy of the kernel arguments, indexed at run time)
     // lane -> (edge, line) inside a wavefront of 8 edges.  Horizontal edges: edge-major (the 8 lanes of an edge are 8 neighbouring samples of
     // a row).  Vertical edges: LINE-major - the lanes of one line across 8 neighbouring edges then read one contiguous 64- / 128-byte
     // piece of a row; edge-major, every lane of a load would sit in its own row.
-    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     const int line = vertical ? lane >> 3 : lane & 7;
     int unit = wave * 8 + (vertical ? lane & 7 : lane >> 3);
     const int l0 = vertical ? ((line & 4) << 3) | (lane & 7) : lane & ~3, l3 = vertical ? l0 + 24 : l0 | 3;
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
     const int px = vertical ? x - 1 : x, py = vertical ? y : y - 1;               // the P side of segment 0
     // Second round of loads, all independent of each other and issued together: the line's samples, the four pcm / bypass flags, the two
     // QPs, the CTB's offsets.  (First version: every one of them behind its own branch and wait - nine dependent round trips per edge.)
-    unsigned char *const pbase = PLANE_PTR3(planes, plane);
-    const int pstride = PLANE_STRIDE3(planes, plane);
+    unsigned char *const pbase = plane == 0 ? base0 : plane == 1 ? base1 : base2;
+    const int pstride = plane == 0 ? stride0 : plane == 1 ? stride1 : stride2;
     const bool vec = vertical && plane == 0 && ((reinterpret_cast<uintptr_t>(pbase) | (unsigned)pstride) & 3) == 0;      // x is a multiple of 8 samples
     auto tail = [&](auto form_tag) {
     constexpr int FORM = decltype(form_tag)::value;
@@ -276,9 +279,42 @@ __global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohev
     }
     deblock_filter<Pixel, FORM>(smp, plane, flags, beta, tc, line, bit_depth, l0, l3);
     };
-    if (plane != 0) tail(std::integral_constant<int, DBK_FORM_CHROMA>{});          // wave-uniform: scalar branches
+    if (CHROMA_ONLY || plane != 0) tail(std::integral_constant<int, DBK_FORM_CHROMA>{});          // wave-uniform: scalar branches
     else if (vec)   tail(std::integral_constant<int, DBK_FORM_VECTOR>{});
     else            tail(std::integral_constant<int, DBK_FORM_SAMPLES>{});
+}
+
+template <typename Pixel>
+__global__ __launch_bounds__(256) void deblock_maps_kernel(PlaneSet planes, ohevc_dbk_maps m, int vertical, int bit_depth, int luma_units, int chroma_units,
+                                                           int luma_uw, int chroma_uw)
+{
+    deblock_maps_lines<Pixel>(planes.data[0], planes.data[1], planes.data[2], planes.stride[0], planes.stride[1], planes.stride[2], m, vertical, bit_depth,
+                              luma_units, chroma_units, luma_uw, chroma_uw, (int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+}
+
+}  // namespace ohevc
+#include "dbk4_kernel.hpp"
+namespace ohevc {
+
+// The shipped form up to 10 bit: workgroups [0, luma_groups) take the luma segments, one per lane (dbk4_kernel.hpp); the rest run the chroma
+// edges line by line (deblock_maps_lines with no luma units).
+template <typename Pixel>
+__global__ __launch_bounds__(256) void deblock_maps_segments_kernel(PlaneSet planes, ohevc_dbk_maps m, int vertical, int bit_depth, int luma_groups, int luma_segments,
+                                                                    int segments_per_row, int chroma_units, int chroma_uw)
+{
+    __shared__ unsigned char tc_tab[64];
+    if (threadIdx.x < 54) tc_tab[threadIdx.x] = kDbkTc[threadIdx.x];
+    __syncthreads();
+    if ((int)blockIdx.x >= luma_groups) {
+        deblock_maps_lines<Pixel, true>(planes.data[0], planes.data[1], planes.data[2], planes.stride[0], planes.stride[1], planes.stride[2], m, vertical, bit_depth,
+                                        0, chroma_units, 0, chroma_uw, (int)(((blockIdx.x - luma_groups) * 256 + threadIdx.x) >> 6));
+        return;
+    }
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= luma_segments) return;
+    const int ux = u % segments_per_row, uy = u / segments_per_row;
+    if (vertical) { if (ux) deblock_maps_luma4<Pixel, true>(planes.data[0], planes.stride[0], m, bit_depth, ux << 3, uy << 2, tc_tab); }
+    else          { if (uy) deblock_maps_luma4<Pixel, false>(planes.data[0], planes.stride[0], m, bit_depth, ux << 2, uy << 3, tc_tab); }
 }
 
 template <typename Pixel>
@@ -951,6 +987,11 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
     return OHEVC_OK;
 }
 
+static int g_deblock_variant = getenv("OHEVC_DEBLOCK_VARIANT") ? atoi(getenv("OHEVC_DEBLOCK_VARIANT")) : 0;      // 0: a lane per luma segment (shipped), 1: a lane per line (rounds 2-3)
+static long long g_deblock_segment_launches;
+extern "C" int ohevc_debug_set_deblock_variant(int v) { const int prev = g_deblock_variant; g_deblock_variant = v; return prev; }
+extern "C" long long ohevc_debug_deblock_segment_launches(void) { return g_deblock_segment_launches; }
+
 extern "C" int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth, const ohevc_dbk_maps *m, int vertical, void *stream)
 {
     using namespace ohevc;
@@ -972,6 +1013,21 @@ extern "C" int ohevc_dev_deblock_maps(const ohevc_plane planes[3], int bit_depth
     const long long threads = ((long long)((luma_units + 7) & ~7) + 2ll * ((chroma_units + 7) & ~7)) * 8;      // each plane's units padded to whole wavefronts
     const int grid = (int)((threads + 255) / 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // one lane per luma segment (dbk4_kernel.hpp): 16-bit arithmetic holds up to 10-bit samples; whole 8x8 blocks (every picture the decoder
+    // makes: the minimum coding block is 8x8) and rows that can be read a dword at a time
+    const bool segments = g_deblock_variant == 0 && bit_depth <= 10 && ((m->width | m->height) & 7) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(ps.data[0]) | (unsigned)ps.stride[0]) & 3) == 0;
+    if (segments) {
+        const int per_row = vertical ? m->width >> 3 : m->width >> 2;
+        const int nseg = per_row * (vertical ? m->height >> 2 : m->height >> 3);
+        const int luma_groups = (nseg + 255) / 256;
+        const int chroma_groups = (int)((2ll * ((chroma_units + 7) & ~7) * 8 + 255) / 256);
+        if (bit_depth == 8) hipLaunchKernelGGL((deblock_maps_segments_kernel<uint8_t>), dim3(luma_groups + chroma_groups), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_groups, nseg, per_row, chroma_units, chroma_uw);
+        else                hipLaunchKernelGGL((deblock_maps_segments_kernel<uint16_t>), dim3(luma_groups + chroma_groups), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_groups, nseg, per_row, chroma_units, chroma_uw);
+        OHEVC_HIP_TRY(hipGetLastError());
+        g_deblock_segment_launches++;
+        return OHEVC_OK;
+    }
     if (bit_depth == 8) hipLaunchKernelGGL((deblock_maps_kernel<uint8_t>), dim3(grid), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_units, chroma_units, luma_uw, chroma_uw);
     else                hipLaunchKernelGGL((deblock_maps_kernel<uint16_t>), dim3(grid), dim3(256), 0, st, ps, *m, vertical != 0, bit_depth, luma_units, chroma_units, luma_uw, chroma_uw);
     OHEVC_HIP_TRY(hipGetLastError());

@@ -24,6 +24,8 @@ __device__ __forceinline__ unsigned sat_pack_u8_i16(unsigned x)
 // (v_dot4_i32_i8); four small constants as the bytes of a dword
 __device__ __forceinline__ unsigned align_bytes(unsigned hi, unsigned lo, unsigned sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 __device__ __forceinline__ int dot4_i8(unsigned a, unsigned b, int acc) { return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false); }
+// v_perm_b32: byte i of the result is picked by byte i of sel - 0..3: that byte of lo, 4..7: of hi, 0x0c: zero
+__device__ __forceinline__ unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ unsigned pack_i8x4(int a, int b, int c, int d)
 {
     return ((unsigned)a & 0xffu) | (((unsigned)b & 0xffu) << 8) | (((unsigned)c & 0xffu) << 16) | ((unsigned)d << 24);

@@ -28,6 +28,17 @@ static inline int dot4_i8(unsigned a, unsigned b, int acc)
     for (int k = 0; k < 4; k++) acc += (int)(signed char)(a >> (8 * k)) * (int)(signed char)(b >> (8 * k));
     return acc;
 }
+static inline unsigned perm_b32(unsigned hi, unsigned lo, unsigned sel)
+{
+    const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned s = (sel >> (8 * i)) & 0xff;
+        const unsigned b = s < 8 ? (unsigned)(v >> (8 * s)) & 0xff : s == 0x0c ? 0u : 0xffu;      // (the sign-replicating selectors 8..11 are not used)
+        r |= b << (8 * i);
+    }
+    return r;
+}
 static inline unsigned pack_i8x4(int a, int b, int c, int d)
 {
     return ((unsigned)a & 0xffu) | (((unsigned)b & 0xffu) << 8) | (((unsigned)c & 0xffu) << 16) | ((unsigned)d << 24);

@@ -5,6 +5,8 @@ table calls the reference would make (plane, position, beta, tc[2], no_p[2], no_
 kernel derives the same parameters per edge in closed form (which neighbour CTB's offsets an edge next to a CTB boundary gets is the
 part worth pinning), so random per-CTB offsets, random boundary strengths, a random QP map and a random pcm map are used.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -108,9 +110,13 @@ def reference_calls(m):
     return calls
 
 
+# form: 0 = a lane per 4-line luma segment, packed 16-bit arithmetic (what pictures up to 10 bit take), 1 = a lane per line (deeper
+# pictures, and every chroma edge)
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("bd,cfi,log2_ctb,W,H,with_pcm", [(8, 1, 4, 208, 120, 0), (8, 1, 6, 416, 240, 1), (10, 1, 5, 200, 136, 1), (8, 2, 5, 208, 120, 0),
-                                                          (10, 3, 4, 136, 72, 1), (14, 1, 6, 192, 136, 0), (8, 1, 6, 64, 64, 0)])
-def test_deblocking_derived_on_the_device(oracle, bd, cfi, log2_ctb, W, H, with_pcm):
+                                                          (10, 3, 4, 136, 72, 1), (14, 1, 6, 192, 136, 0), (8, 1, 6, 64, 64, 0), (9, 0, 4, 80, 48, 1),
+                                                          (8, 1, 5, 1032, 40, 1)])
+def test_deblocking_derived_on_the_device(oracle, bd, cfi, log2_ctb, W, H, with_pcm, form):
     rng = np.random.default_rng(900 + bd + 10 * cfi + log2_ctb + W)
     hs, vs = int(cfi in (1, 2)), int(cfi == 1)
     planes = [smooth_plane(rng, bd, H, W), smooth_plane(rng, bd, H >> vs, W >> hs), smooth_plane(rng, bd, H >> vs, W >> hs)]
@@ -149,9 +155,17 @@ def test_deblocking_derived_on_the_device(oracle, bd, cfi, log2_ctb, W, H, with_
                    is_pcm=keep[4].data_ptr() if with_pcm else None, bs_width=bw, min_cb_width=W >> 3, deblock_stride=2, min_pu_width=W >> 2, min_pu_height=H >> 2,
                    width=W, height=H, log2_ctb_size=log2_ctb, log2_min_cb_size=3, log2_min_pu_size=2, chroma_format_idc=cfi,
                    cb_qp_offset=m["cb_qp_offset"], cr_qp_offset=m["cr_qp_offset"])
-    for vertical in (1, 0):
-        L.dev_deblock_maps(G.planes3(d), bd, dm, vertical, G.stream())
-    G.sync()
+    lib = L.load_library()
+    lib.ohevc_debug_deblock_segment_launches.restype = C.c_longlong
+    before = lib.ohevc_debug_deblock_segment_launches()
+    previous = lib.ohevc_debug_set_deblock_variant(form)
+    try:
+        for vertical in (1, 0):
+            L.dev_deblock_maps(G.planes3(d), bd, dm, vertical, G.stream())
+        G.sync()
+    finally:
+        lib.ohevc_debug_set_deblock_variant(previous)
+    assert lib.ohevc_debug_deblock_segment_launches() - before == (2 if form == 0 and bd <= 10 else 0), "not the form this case is about"
     changed = 0
     for pl in range(3):
         got = G.to_host(d[pl], planes[pl].dtype)

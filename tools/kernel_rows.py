@@ -209,6 +209,9 @@ def deblock_rows(bd, orc, po, g, rng, st, out):
     grid = np.zeros((bh, bw), np.uint8)
     grid[:, ::2] = 1                                  # vertical edges at x % 8 == 0 (bs index = x / 4)
     vb[:bw * bh] = grid.ravel()
+    hgrid = np.zeros((bh, bw), np.uint8)
+    hgrid[::2, :] = 1                                 # horizontal edges at y % 8 == 0 (bs row = y / 4)
+    hb[:bw * bh] = hgrid.ravel()
     qp_y = 38
     qp = np.full((W >> 3) * (H >> 3), qp_y, np.int8)
     dbp = np.zeros((((W + 63) // 64) * ((H + 63) // 64), 2), np.int8)
@@ -217,26 +220,33 @@ def deblock_rows(bd, orc, po, g, rng, st, out):
                    bs_width=bw, min_cb_width=W >> 3, deblock_stride=2, min_pu_width=W >> 2, min_pu_height=H >> 2, width=W, height=H, log2_ctb_size=6,
                    log2_min_cb_size=3, log2_min_pu_size=2, chroma_format_idc=1, cb_qp_offset=0, cr_qp_offset=0)
 
-    def launch(pic, ex):
-        L.dev_deblock_maps(L.planes_of(pic), bd, dm, 1, st())
-    ms, ring = _time(launch, lambda: _smooth_pic(bd, g))
-    pic = _smooth_pic(bd, g)
-    before = _np(pic[0], bd).copy()
-    launch(pic, None)
-    torch.cuda.synchronize()
-    got = _np(pic[0], bd)
     # deblocking_filter_CTB (hevc_filter.c:385-470): bS 1, QP 38 on both sides, no offsets -> beta = betatable[38], tc = tctable[38 + 2 (bS - 1)]
     beta, tc = BETA_TABLE[qp_y], TC_TABLE[qp_y]
-    bad = 0
-    for _ in range(N_CHECK):
-        x, y = 8 * int(rng.integers(1, W // 8)), 8 * int(rng.integers(0, H // 8))
-        want = before[y:y + 8, x - 8:x + 8].copy()
-        orc.deblock_luma(bd, 1, want, 8, 0, beta, (tc, tc), (0, 0), (0, 0))
-        bad += not np.array_equal(got[y:y + 8, x - 4:x + 4], want[:, 4:12])
-    out[f"deblock_luma_vertical_from_maps_{bd}bit"] = _row(
-        ms, ring, 2 * P * W * H, W * H, bad, N_CHECK,
-        "every vertical 8x8-grid luma edge of eight stacked 4K pictures, parameters derived on the device from the decoder's maps (bS 1, QP 38); "
-        "deblocking_filter_CTB + hevc_v_loop_filter_luma (hevc_filter.c:345-581, hevcdsp_template.c:1629-1723)")
+    for vertical, word, fn in ((1, "vertical", "hevc_v_loop_filter_luma"), (0, "horizontal", "hevc_h_loop_filter_luma")):
+        def launch(pic, ex):
+            L.dev_deblock_maps(L.planes_of(pic), bd, dm, vertical, st())
+        ms, ring = _time(launch, lambda: _smooth_pic(bd, g))
+        pic = _smooth_pic(bd, g)
+        before = _np(pic[0], bd).copy()
+        launch(pic, None)
+        torch.cuda.synchronize()
+        got = _np(pic[0], bd)
+        bad = 0
+        for _ in range(N_CHECK):
+            if vertical:
+                x, y = 8 * int(rng.integers(1, W // 8)), 8 * int(rng.integers(0, H // 8))
+                want = before[y:y + 8, x - 8:x + 8].copy()
+                orc.deblock_luma(bd, 1, want, 8, 0, beta, (tc, tc), (0, 0), (0, 0))
+                bad += not np.array_equal(got[y:y + 8, x - 4:x + 4], want[:, 4:12])
+            else:
+                x, y = 8 * int(rng.integers(0, W // 8)), 8 * int(rng.integers(1, H // 8))
+                want = before[y - 8:y + 8, x:x + 8].copy()
+                orc.deblock_luma(bd, 0, want, 0, 8, beta, (tc, tc), (0, 0), (0, 0))
+                bad += not np.array_equal(got[y - 4:y + 4, x:x + 8], want[4:12, :])
+        out[f"deblock_luma_{word}_from_maps_{bd}bit"] = _row(
+            ms, ring, 2 * P * W * H, W * H, bad, N_CHECK,
+            f"every {word} 8x8-grid luma edge of eight stacked 4K pictures, parameters derived on the device from the decoder's maps (bS 1, QP 38); "
+            f"deblocking_filter_CTB + {fn} (hevc_filter.c:345-581, hevcdsp_template.c:1629-1723)")
 
 
 def sao_rows(bd, orc, po, g, rng, st, out):
