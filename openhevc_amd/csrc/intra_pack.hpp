@@ -184,7 +184,7 @@ __device__ __forceinline__ PackSamples pack_load_samples(const int lane, const P
     const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, flags = jw.y >> 24;
     const int bl_size = jw.z & 0xff, tr_size = (jw.z >> 8) & 0xff;
     const int stride = PLANE_STRIDE3(planes, jplane);
-    const unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
+    const unsigned char *blk = PLANE_PTR3(planes, jplane) + (__umul24((unsigned)jy, (unsigned)stride) + (unsigned)jx * (unsigned)sizeof(Pixel));      // (a plane is < 4 GiB: 32-bit offsets, 24-bit multiplies)
     const bool c_bl = flags & OHEVC_INTRA_BOTTOM_LEFT, c_l = flags & OHEVC_INTRA_LEFT, c_ul = flags & OHEVC_INTRA_UP_LEFT;
     const bool c_u = flags & OHEVC_INTRA_UP, c_ur = flags & OHEVC_INTRA_UP_RIGHT;
     // Positions relative to the block's first sample, as byte offsets.
@@ -222,7 +222,7 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
     const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
     const int kind = pack_kind(recs);
     const int stride = PLANE_STRIDE3(planes, jplane);
-    unsigned char *blk = PLANE_PTR3(planes, jplane) + (size_t)jy * stride + (size_t)jx * sizeof(Pixel);
+    unsigned char *blk = PLANE_PTR3(planes, jplane) + (__umul24((unsigned)jy, (unsigned)stride) + (unsigned)jx * (unsigned)sizeof(Pixel));
     const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
     const int dflt = 1 << (bit_depth - 1);
     const int v_t0 = (sm.none & 1) ? dflt : sm.v[0], v_t1 = (sm.none & 2) ? dflt : sm.v[1], v_l0 = (sm.none & 4) ? dflt : sm.v[2];
@@ -251,8 +251,8 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int k = h * N + i;
-                    ftop[k]  = k < 2 * N - 1 ? ((2 * N - 1 - k) * t0 + (k + 1) * t63 + N) >> (LOG2N + 1) : t63;
-                    fleft[k] = k < 2 * N - 1 ? ((2 * N - 1 - k) * l0 + (k + 1) * l63 + N) >> (LOG2N + 1) : l63;
+                    ftop[k]  = k < 2 * N - 1 ? (__mul24(2 * N - 1 - k, t0) + __mul24(k + 1, t63) + N) >> (LOG2N + 1) : t63;
+                    fleft[k] = k < 2 * N - 1 ? (__mul24(2 * N - 1 - k, l0) + __mul24(k + 1, l63) + N) >> (LOG2N + 1) : l63;
                 }
                 if (i == 0) { ftop[-1] = t0; fleft[-1] = l0; }
             } else {
@@ -274,9 +274,14 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
     const int maxv = (1 << bit_depth) - 1;
     const bool luma_edge = (flags & OHEVC_INTRA_LUMA_EDGE) && N < 32;
     if (mode == 0) {                                       // pred_planar, :359-372
+        // (N-1-x) ly + (x+1) tn is linear in x: one add per sample; (N-1-i) t[x] a 24-bit multiply-add (v_mad_i32_i24, full rate - the
+        // 32-bit v_mul_lo_u32 the plain expressions compile to runs at a quarter of it, and a level of the chain lasts as long as its
+        // slowest wavefront's instruction stream)
         const int ly = l[i], tn = t[N], ln = l[N];
+        const int step = tn - ly, wy = N - 1 - i;
+        int acc = __mul24(N - 1, ly) + tn + __mul24(i + 1, ln) + N;
 #pragma unroll
-        for (int x = 0; x < N; x++) pred[x] = ((N - 1 - x) * ly + (x + 1) * tn + (N - 1 - i) * t[x] + (i + 1) * ln + N) >> (LOG2N + 1);
+        for (int x = 0; x < N; x++) { pred[x] = (acc + __mul24(wy, t[x])) >> (LOG2N + 1); acc += step; }
     } else if (mode == 1) {                                // pred_dc, :388-417
         int part = l[i] + t[i];
 #pragma unroll
@@ -312,7 +317,7 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
 #pragma unroll
             for (int x = 0; x < N; x++) {
                 const int r1 = ref[x + i2 + 2];
-                pred[x] = ((32 - fact) * r0 + fact * r1 + 16) >> 5;
+                pred[x] = (__mul24(32 - fact, r0) + __mul24(fact, r1) + 16) >> 5;
                 r0 = r1;
             }
             if (luma_edge && mode == 26) { const int v = t[0] + ((l[i] - l[-1]) >> 1); pred[0] = v < 0 ? 0 : v > maxv ? maxv : v; }
@@ -320,7 +325,7 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
 #pragma unroll
             for (int x = 0; x < N; x++) {
                 const int pos = (x + 1) * angle, i2 = pos >> 5, fact = pos & 31;
-                pred[x] = ((32 - fact) * ref[i + i2 + 1] + fact * ref[i + i2 + 2] + 16) >> 5;
+                pred[x] = (__mul24(32 - fact, ref[i + i2 + 1]) + __mul24(fact, ref[i + i2 + 2]) + 16) >> 5;
             }
             if (luma_edge && mode == 10 && i == 0) {
 #pragma unroll
@@ -337,7 +342,7 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
         if constexpr (sizeof(Pixel) == 1) px[d] = (unsigned)pred[4 * d] | ((unsigned)pred[4 * d + 1] << 8) | ((unsigned)pred[4 * d + 2] << 16) | ((unsigned)pred[4 * d + 3] << 24);
         else px[d] = (unsigned)pred[2 * d] | ((unsigned)pred[2 * d + 1] << 16);
     }
-    unsigned char *row = blk + (size_t)i * stride;
+    unsigned char *row = blk + __umul24((unsigned)i, (unsigned)stride);
 
     // ---- the block's residual, row i (hevc_cabac.c:1868-1949), added in registers (transform_add, hevcdsp_template.c:45-111)
     if (kind >= 0) {
