@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
         const signed char *t8 = TAPS == 8 ? kUpLuma[ph] : kUpChroma[ph];
         stap8[ph][q] = 4 * q < TAPS ? pack_i8x4(t8[4 * q], t8[4 * q + 1], t8[4 * q + 2], t8[4 * q + 3]) : 0u;
     }
-    // ---- 1. the window, four samples per thread and step
+    // ---- 1. the window, four samples per thread and step.  8-bit samples are stored as sample - 128 (the horizontal pass multiplies signed
+    // bytes: one xor per four samples here instead of two per filtered sample there).  (A 16 x 16 thread layout without the division
+    // ran slower, r4u2: a third of its lanes idle at the x2 window's 11 dwords per row.)
     {
         const int wc4 = (wc + 3) >> 2;
         const bool inside = cmin >= 0 && cmin + 4 * wc4 <= src_cols;
@@ -191,20 +193,20 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
             const int r = i / wc4, c4 = i - r * wc4;
             int ry = rmin + r;
             ry = ry < 0 ? 0 : ry > src_rows - 1 ? src_rows - 1 : ry;
-            const unsigned char *srow = sbase + (size_t)ry * src.stride;
+            const unsigned char *srow_p = sbase + __umul24((unsigned)ry, (unsigned)src.stride);
             Pixel v[4];
             if (inside) {
-                if constexpr (P == 1) *reinterpret_cast<unsigned *>(v) = *reinterpret_cast<const unsigned *>(srow + cmin + 4 * c4);
-                else                  *reinterpret_cast<u32x2 *>(v) = *reinterpret_cast<const u32x2 *>(srow + (size_t)(cmin + 4 * c4) * 2);
+                if constexpr (P == 1) *reinterpret_cast<unsigned *>(v) = *reinterpret_cast<const unsigned *>(srow_p + cmin + 4 * c4);
+                else                  *reinterpret_cast<u32x2 *>(v) = *reinterpret_cast<const u32x2 *>(srow_p + (size_t)(cmin + 4 * c4) * 2);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     int rx = cmin + 4 * c4 + k;
                     rx = rx < 0 ? 0 : rx > src_cols - 1 ? src_cols - 1 : rx;
-                    v[k] = reinterpret_cast<const Pixel *>(srow)[rx];
+                    v[k] = reinterpret_cast<const Pixel *>(srow_p)[rx];
                 }
             }
-            if constexpr (P == 1) *reinterpret_cast<unsigned *>(win + r * UPT_WC + 4 * c4) = *reinterpret_cast<const unsigned *>(v);
+            if constexpr (P == 1) *reinterpret_cast<unsigned *>(win + r * UPT_WC + 4 * c4) = *reinterpret_cast<const unsigned *>(v) ^ 0x80808080u;
             else                  *reinterpret_cast<u32x2 *>(win + (r * UPT_WC + 4 * c4) * 2) = *reinterpret_cast<const u32x2 *>(v);
         }
     }
@@ -224,9 +226,8 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
                 const unsigned *w32 = reinterpret_cast<const unsigned *>(win + r * UPT_WC) + (lc >> 2);
                 const unsigned a0 = w32[0], a1 = w32[1], a2 = TAPS == 8 ? w32[2] : 0u;
                 const unsigned sh = (unsigned)(lc & 3);
-                const unsigned lo = align_bytes(a1, a0, sh) ^ 0x80808080u;       // samples - 128 as int8
-                h = dot4_i8(lo, tp[0], 128 * 64);
-                if constexpr (TAPS == 8) h = dot4_i8(align_bytes(a2, a1, sh) ^ 0x80808080u, tp[1], h);
+                h = dot4_i8(align_bytes(a1, a0, sh), tp[0], 128 * 64);       // (the window holds samples - 128 as int8; the taps sum to 64)
+                if constexpr (TAPS == 8) h = dot4_i8(align_bytes(a2, a1, sh), tp[1], h);
             } else {
                 const unsigned *w32 = reinterpret_cast<const unsigned *>(win + (r * UPT_WC) * 2) + (lc >> 1);
                 const bool odd = lc & 1;
@@ -241,35 +242,52 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
         }
     }
     __syncthreads();
-    // ---- 3. vertical pass: thread = (output column lx, output rows part * 8 .. + 7)
-    if (tx0 + lx >= dst.width) return;
+    // ---- 3. vertical pass: thread = (four neighbouring output columns, four consecutive output rows).  One store per four samples (a lane
+    // per column stored single bytes: 64 bytes per store instruction of a wavefront), and what depends on the row only - the row's map
+    // entry, its taps, the address - once per four samples.
+    const int lq = tid & 15, rg = tid >> 4, xq = tx0 + 4 * lq;
+    if (xq >= dst.width) return;
     const int maxv = (1 << bit_depth) - 1;
-    const unsigned *hc = reinterpret_cast<const unsigned *>(hcol + lx * UPT_HS);
-    unsigned a[5] = {};
-    int have = -1;                                                  // the first row a[] holds (wave-uniform): consecutive output rows mostly share it
+    const bool whole = xq + 4 <= dst.width && ((reinterpret_cast<uintptr_t>(dst.data) | (unsigned)dst.stride) & 3) == 0;
+    unsigned a[4][5] = {};
+    int have = -1;                                                  // the first row a[][] holds: consecutive output rows mostly share it
 #pragma unroll
-    for (int k = 0; k < UPT_ROWS / 4; k++) {
-        const int yy = part * (UPT_ROWS / 4) + k, y = ty0 + yy;
+    for (int k = 0; k < 4; k++) {
+        const int yy = rg * 4 + k, y = ty0 + yy;
         if (y >= dst.height) break;
-        const ohevc_upsample_tap tr = srow[yy];                     // wave-uniform
+        const ohevc_upsample_tap tr = srow[yy];
         const int f = tr.pos - HALF - rmin;                         // first of the TAPS rows
         if (f != have) {
 #pragma unroll
-            for (int q = 0; q < TAPS / 2 + 1; q++) a[q] = hc[(f >> 1) + q];
-            if (f & 1) {
+            for (int j = 0; j < 4; j++) {
+                const unsigned *hc = reinterpret_cast<const unsigned *>(hcol + (4 * lq + j) * UPT_HS) + (f >> 1);
 #pragma unroll
-                for (int q = 0; q < TAPS / 2; q++) a[q] = align_bytes(a[q + 1], a[q], 2u);
+                for (int q = 0; q < TAPS / 2 + 1; q++) a[j][q] = hc[q];
+#pragma unroll
+                for (int q = 0; q < TAPS / 2; q++) a[j][q] = align_bytes(a[j][q + 1], a[j][q], (unsigned)(f & 1) * 2u);      // (no branch: a shift of 0 or 2 bytes)
             }
             have = f;
         }
-        int acc = 1 << 11;                                          // I_OFFSET, hevcdsp.h:40-41
         const u32x4 tq = *reinterpret_cast<const u32x4 *>(&stap16[tr.phase][0]);       // the row's four tap pairs in one LDS read
         const unsigned tqa[4] = { tq.x, tq.y, tq.z, tq.w };
+        int v[4];
 #pragma unroll
-        for (int q = 0; q < TAPS / 2; q++) acc = dot2_i16(a[q], tqa[q], acc);
-        int v = acc >> 12;                                          // N_SHIFT
-        v = v < 0 ? 0 : v > maxv ? maxv : v;
-        *(reinterpret_cast<Pixel *>(static_cast<unsigned char *>(dst.data) + (size_t)y * dst.stride) + tx0 + lx) = (Pixel)v;
+        for (int j = 0; j < 4; j++) {
+            int acc = 1 << 11;                                      // I_OFFSET, hevcdsp.h:40-41
+#pragma unroll
+            for (int q = 0; q < TAPS / 2; q++) acc = dot2_i16(a[j][q], tqa[q], acc);
+            acc >>= 12;                                             // N_SHIFT
+            v[j] = acc < 0 ? 0 : acc > maxv ? maxv : acc;
+        }
+        unsigned char *out = static_cast<unsigned char *>(dst.data) + (__umul24((unsigned)y, (unsigned)dst.stride) + (unsigned)xq * (unsigned)P);
+        if (whole) {
+            if constexpr (P == 1) *reinterpret_cast<unsigned *>(out) = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+            else                  *reinterpret_cast<u32x2 *>(out) = u32x2{ (unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16) };
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (xq + j < dst.width) reinterpret_cast<Pixel *>(out)[j] = (Pixel)v[j];
+        }
     }
 }
 
