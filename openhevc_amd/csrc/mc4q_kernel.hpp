@@ -14,24 +14,9 @@
 //                           b: (x >= 8, y >= 8) and pair (c, d) the other way round - c: (x < 8, y >= 8), d: (x >= 8, y < 8) - so that EVERY lane of the
 //                           result layout (lane = y, registers = 4 consecutive x) ends up with four samples of exactly one block.
 //
-// Per block everything may differ (plane, phases, references, weights): what mc4_kernel keeps in scalars per tile is selected per lane here.
+// Per block everything may differ (plane, phases, references, weights): what mc4_kernel keeps in scalars per tile every lane fetches for the
+// block its role works for (see the kernel).
 // Exactness: the same int8-plane products with the same constants as mc4_kernel (every output column still sees one complete filter whose taps sum to 64).
-
-// the job record of the block a lane works for, as vector registers
-struct Mc4qJob { int x, y, w, h, plane, flags, sx0, sy0, sx1, sy1, mx0, my0, mx1, my1, ref0, ref1, denom, wx0, wx1, ox0, ox1; };
-__device__ __forceinline__ Mc4qJob mc4q_unpack(const ohevc_mc_job &j)
-{
-    return Mc4qJob{ j.x, j.y, j.w, j.h, j.plane, j.flags, j.sx0, j.sy0, j.sx1, j.sy1, j.mx0, j.my0, j.mx1, j.my1, j.ref0, j.ref1, j.denom, j.wx0, j.wx1, j.ox0, j.ox1 };
-}
-__device__ __forceinline__ Mc4qJob mc4q_pick(bool first, const Mc4qJob &a, const Mc4qJob &b)
-{
-    Mc4qJob r;
-#define MC4Q_F(f) r.f = first ? a.f : b.f;
-    MC4Q_F(x) MC4Q_F(y) MC4Q_F(w) MC4Q_F(h) MC4Q_F(plane) MC4Q_F(flags) MC4Q_F(sx0) MC4Q_F(sy0) MC4Q_F(sx1) MC4Q_F(sy1) MC4Q_F(mx0) MC4Q_F(my0) MC4Q_F(mx1)
-    MC4Q_F(my1) MC4Q_F(ref0) MC4Q_F(ref1) MC4Q_F(denom) MC4Q_F(wx0) MC4Q_F(wx1) MC4Q_F(ox0) MC4Q_F(ox1)
-#undef MC4Q_F
-    return r;
-}
 
 // The plane record of a lane's reference picture (the four blocks of a quad may predict from different pictures): a vector load per lane.
 struct Mc4qRef { unsigned long w0, w1, w2; };                    // data | stride, width | height, -
@@ -143,90 +128,90 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
         static_assert(kRefSlots * 9 <= 768, "three rounds of 256 words");
     }
     const int per_xcd = gridDim.x >> 3;                                                          // an XCD takes a contiguous eighth of the list (mc4_kernel)
-    const int q0 = ((((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave) * UNITS;
-    typedef const MC4_CONST u32x4 *cptr;
-    Mc4qJob jb[UNITS][4];
-    bool any[UNITS], any_bi[UNITS];
-#pragma unroll
-    for (int u = 0; u < UNITS; u++) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int j = 4 * (q0 + u) + i;
-            cptr jp = (cptr)(jobs + (j < njobs ? j : njobs - 1));
-            const u32x4 w0 = jp[0], w1 = jp[1];
-            const unsigned words[8] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w };
-            ohevc_mc_job rec;
-            __builtin_memcpy(&rec, words, sizeof(rec));
-            jb[u][i] = mc4q_unpack(rec);
-        }
-        any[u] = 4 * (q0 + u) < njobs;
-        any_bi[u] = ((jb[u][0].flags | jb[u][1].flags | jb[u][2].flags | jb[u][3].flags) & OHEVC_MC_BI) != 0;      // wave-uniform
+    const int q = (((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3)) * 4 + wave;
+    static_assert(UNITS == 1, "one quad per wavefront");
+    // The quad's four job records, 32 dwords, one per lane (lane L: dword L & 7 of job 4q + ((L & 31) >> 3); a job behind the list: the last
+    // one again, never stored).  Every lane then FETCHES the dwords of the block its role works for through the cross-lane network
+    // (ds_bpermute_b32: no LDS memory involved) and unpacks them itself.  Rounds 3's form read the records with scalar loads, unpacked them on
+    // the scalar unit and SELECTED per lane, field by field - v_mov + v_cndmask per field and role: 264 of the kernel's 593 vector
+    // instructions, and the kernel is bound by vector-instruction issue (SQ_ACTIVE_INST_VALU 95 % of the launch, profiles/r03x_*).
+    static_assert(sizeof(ohevc_mc_job) == 32, "eight dwords per job record");
+    unsigned jw;
+    {
+        const int j = 4 * q + ((lane & 31) >> 3);
+        typedef const MC4_GLOBAL unsigned *gq;
+        jw = ((gq)(jobs + (j < njobs ? j : njobs - 1)))[lane & 7];
     }
-    // ---- memory side: lane (r = lane >> 2, g = lane & 3) loads 8 samples of window row r, columns 8 (g & 1) .., of block g >> 1 of each pair
-    // (three dependent rounds - job records, plane records, samples - each issued for every quad, pair and reference before the first use)
-    unsigned raw[UNITS][2][2][WIDE ? 4 : 2] = {};
     __syncthreads();                                                                             // the tables are in LDS
+    if (4 * q >= njobs) return;
+    auto field = [&](int block_bytes, int k) -> unsigned { return (unsigned)__builtin_amdgcn_ds_bpermute(block_bytes + 4 * k, (int)jw); };      // dword k of block
+    // ---- memory side: lane (r = lane >> 2, g = lane & 3) loads 8 samples of window row r, columns 8 (g & 1) .., of block g >> 1 of each pair
+    // (two dependent rounds - job records, samples - each issued for every pair and reference before the first use)
+    unsigned raw[2][2][WIDE ? 4 : 2] = {};
+    // any job of the quad bi-predicted (wave-uniform): dword 1 of the four records
+    const bool any_bi = __ballot(lane < 32 && (lane & 7) == 1 && ((jw >> 24) & OHEVC_MC_BI) != 0) != 0;
     {
         const int r = lane >> 2, half = lane & 1;
-        const bool first = (lane & 3) < 2;
-        Mc4qJob m[UNITS][2];
-        Mc4qRef rec[UNITS][2][2];
+        const int first_off = (lane & 3) < 2 ? 0 : 32;
+        int plane_m[2], h_m[2], sx0[2], sy0[2], sx1[2], sy1[2];
+        Mc4qRef rec[2][2];
 #pragma unroll
-        for (int u = 0; u < UNITS; u++)
+        for (int pair = 0; pair < 2; pair++) {
+            const int blk = 64 * pair + first_off;                                               // the lane's block of the pair, as a byte offset into the 32 lanes
+            const unsigned d1 = field(blk, 1), d2 = field(blk, 2), d3 = field(blk, 3), d5 = field(blk, 5);
+            const bool bi = ((d1 >> 24) & OHEVC_MC_BI) != 0;
+            plane_m[pair] = (int)((d1 >> 16) & 0xff); h_m[pair] = (int)((d1 >> 8) & 0xff);
+            sx0[pair] = (int)(short)(d2 & 0xffff); sy0[pair] = (int)d2 >> 16;
+            sx1[pair] = bi ? (int)(short)(d3 & 0xffff) : sx0[pair]; sy1[pair] = bi ? (int)d3 >> 16 : sy0[pair];       // (uni: loaded again, weighted 0)
+            const int ref0 = (int)(signed char)(d5 & 0xff), ref1 = bi ? (int)(signed char)((d5 >> 8) & 0xff) : ref0;
+            auto plane_record = [&](int ref) {
+                if (!refs_in_lds) return mc4q_ref(refs, ref, plane_m[pair]);
+                const unsigned long *e = &ref_tab[(3 * ref + plane_m[pair]) * 3];
+                return Mc4qRef{ e[0], e[1], e[2] };
+            };
+            rec[0][pair] = plane_record(ref0);
+            if (any_bi) rec[1][pair] = plane_record(ref1);
+        }
 #pragma unroll
-            for (int pair = 0; pair < 2; pair++) {
-                m[u][pair] = mc4q_pick(first, jb[u][2 * pair], jb[u][2 * pair + 1]);
-                const bool bi = (m[u][pair].flags & OHEVC_MC_BI) != 0;
-                if (!bi) { m[u][pair].ref1 = m[u][pair].ref0; m[u][pair].sx1 = m[u][pair].sx0; m[u][pair].sy1 = m[u][pair].sy0; }       // (loaded again, weighted 0)
-                auto plane_record = [&](int ref) {
-                    if (!refs_in_lds) return mc4q_ref(refs, ref, m[u][pair].plane);
-                    const unsigned long *e = &ref_tab[(3 * ref + m[u][pair].plane) * 3];
-                    return Mc4qRef{ e[0], e[1], e[2] };
-                };
-                if (any[u]) rec[u][0][pair] = plane_record(m[u][pair].ref0);
-                if (any[u] && any_bi[u]) rec[u][1][pair] = plane_record(m[u][pair].ref1);
-            }
-#pragma unroll
-        for (int u = 0; u < UNITS; u++)
-#pragma unroll
-            for (int pair = 0; pair < 2; pair++) {
-                const int before = m[u][pair].plane == 0 ? 3 : 1, taps = m[u][pair].plane == 0 ? 8 : 4;
-                if (any[u]) mc4q_issue<Pixel>(rec[u][0][pair], m[u][pair].sx0 - before, m[u][pair].sy0 - before, m[u][pair].h + taps - 1, r, half, raw[u][0][pair]);
-                if (any[u] && any_bi[u])
-                    mc4q_issue<Pixel>(rec[u][1][pair], m[u][pair].sx1 - before, m[u][pair].sy1 - before, m[u][pair].h + taps - 1, r, half, raw[u][1][pair]);
-            }
+        for (int pair = 0; pair < 2; pair++) {
+            const int before = plane_m[pair] == 0 ? 3 : 1, taps = plane_m[pair] == 0 ? 8 : 4;
+            mc4q_issue<Pixel>(rec[0][pair], sx0[pair] - before, sy0[pair] - before, h_m[pair] + taps - 1, r, half, raw[0][pair]);
+            if (any_bi) mc4q_issue<Pixel>(rec[1][pair], sx1[pair] - before, sy1[pair] - before, h_m[pair] + taps - 1, r, half, raw[1][pair]);
+        }
     }
     // ---- operand side: lane (n = lane & 15, g = lane >> 4)
     const int n = lane & 15, g = lane >> 4, maxv = (1 << bit_depth) - 1;
     const bool lowcol = n < 8, lowgrp = g < 2;
-#pragma unroll
-    for (int u = 0; u < UNITS; u++) {
-        if (!any[u]) continue;
-        const int q = q0 + u;
+    {
         u32x2 b1[2][2];
         unsigned b2[2][2];
 #pragma unroll
         for (int pair = 0; pair < 2; pair++) {
             // pass 1: column n belongs to block (n < 8 ? first : second) of the pair, its taps sit on that block's slot groups only
-            const Mc4qJob c1 = mc4q_pick(lowcol, jb[u][2 * pair], jb[u][2 * pair + 1]);
-            const int ph1 = c1.plane == 0 ? 0 : 4, tl = (g & 1) * 16 + (n & 7);
+            const int blk1 = 64 * pair + (lowcol ? 0 : 32);
+            const unsigned c1d1 = field(blk1, 1), c1d4 = field(blk1, 4);
+            const int ph1 = ((c1d1 >> 16) & 0xff) == 0 ? 0 : 4, tl = (g & 1) * 16 + (n & 7);
             const bool mine = lowcol == lowgrp;
-            const u32x2 t0 = tabs[0][ph1 + c1.mx0][tl], t1 = tabs[0][ph1 + c1.mx1][tl];
+            const u32x2 t0 = tabs[0][ph1 + (int)(c1d4 & 0xff)][tl], t1 = tabs[0][ph1 + (int)((c1d4 >> 16) & 0xff)][tl];
             b1[0][pair] = mine ? t0 : u32x2{ 0u, 0u };
             b1[1][pair] = mine ? t1 : u32x2{ 0u, 0u };
             // pass 2: column y < 8 carries the vertical taps of a (pair 0) / d (pair 1), y >= 8 those of b / c; rows 4g .. 4g + 3 of the 15-row window
-            const Mc4qJob c2 = mc4q_pick(lowcol == (pair == 0), jb[u][2 * pair], jb[u][2 * pair + 1]);
-            const int ph2 = c2.plane == 0 ? 0 : 4, tl2 = g * 16 + (n & 7);
-            b2[0][pair] = tabs[1][ph2 + c2.my0][tl2].x;
-            b2[1][pair] = tabs[1][ph2 + c2.my1][tl2].x;
+            const int blk2 = 64 * pair + ((lowcol == (pair == 0)) ? 0 : 32);
+            const unsigned c2d1 = field(blk2, 1), c2d4 = field(blk2, 4);
+            const int ph2 = ((c2d1 >> 16) & 0xff) == 0 ? 0 : 4, tl2 = g * 16 + (n & 7);
+            b2[0][pair] = tabs[1][ph2 + (int)((c2d4 >> 8) & 0xff)][tl2].x;
+            b2[1][pair] = tabs[1][ph2 + (int)(c2d4 >> 24)][tl2].x;
         }
         unsigned seen0[2] = { 0, 0 }, seen1[2] = { 0, 0 };
         int v0[4], v1[4] = { 0, 0, 0, 0 };
-        mc4q_finish<Pixel>(raw[u][0], b1[0], b2[0], bit_depth, lane, seen0, v0);
-        if (any_bi[u]) mc4q_finish<Pixel>(raw[u][1], b1[1], b2[1], bit_depth, lane, seen1, v1);
+        mc4q_finish<Pixel>(raw[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
+        if (any_bi) mc4q_finish<Pixel>(raw[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
         // ---- result side: lane (y = lane & 15, g): four samples x = 4 (g & 1) .. + 3 of row y & 7 of block  a: y < 8, g < 2   d: y < 8, g >= 2   c: y >= 8, g < 2   b: y >= 8, g >= 2
         const int blk = lowcol ? (lowgrp ? 0 : 3) : (lowgrp ? 2 : 1);
-        const Mc4qJob m = mc4q_pick(lowcol, mc4q_pick(lowgrp, jb[u][0], jb[u][3]), mc4q_pick(lowgrp, jb[u][2], jb[u][1]));
+        const unsigned m0 = field(32 * blk, 0), m1 = field(32 * blk, 1), m5 = field(32 * blk, 5), m6 = field(32 * blk, 6), m7 = field(32 * blk, 7);
+        const int m_x = (int)(m0 & 0xffff), m_y = (int)(m0 >> 16), m_w = (int)(m1 & 0xff), m_h = (int)((m1 >> 8) & 0xff), m_plane = (int)((m1 >> 16) & 0xff);
+        const int m_flags = (int)(m1 >> 24), m_denom = (int)((m5 >> 16) & 0xff);
+        const int m_wx0 = (int)(short)(m6 & 0xffff), m_wx1 = (int)m6 >> 16, m_ox0 = (int)(short)(m7 & 0xffff), m_ox1 = (int)m7 >> 16;
         bool skip = 4 * q + blk >= njobs;
         if (WIDE) {
             // samples above the bit depth's range: mc3_redo_kernel computes the block (mc4_kernel).  `seen` lives on the operand side: rows of the
@@ -240,15 +225,15 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
             }
             skip = skip || (blk == 0 ? wa : blk == 1 ? wb : blk == 2 ? wc : wd);
         }
-        const bool bi = (m.flags & OHEVC_MC_BI) != 0, weighted = (m.flags & OHEVC_MC_WEIGHTED) != 0;
+        const bool bi = (m_flags & OHEVC_MC_BI) != 0, weighted = (m_flags & OHEVC_MC_WEIGHTED) != 0;
         int w0, w1, off, sh, add;
         if (!weighted) {
             sh = (bi ? 15 : 14) - bit_depth; w0 = 1; w1 = bi ? 1 : 0; off = mc_round(sh, bit_depth); add = 0;
         } else if (!bi) {
-            sh = m.denom + 14 - bit_depth; w0 = m.wx0; w1 = 0; off = mc_round(sh, bit_depth); add = m.ox0 * (1 << (bit_depth - 8));
+            sh = m_denom + 14 - bit_depth; w0 = m_wx0; w1 = 0; off = mc_round(sh, bit_depth); add = m_ox0 * (1 << (bit_depth - 8));
         } else {
-            const int log2wd = m.denom + 14 - bit_depth;
-            sh = log2wd + 1; w0 = m.wx0; w1 = m.wx1; off = (m.ox0 * (1 << (bit_depth - 8)) + m.ox1 * (1 << (bit_depth - 8)) + 1) << log2wd; add = 0;
+            const int log2wd = m_denom + 14 - bit_depth;
+            sh = log2wd + 1; w0 = m_wx0; w1 = m_wx1; off = (m_ox0 * (1 << (bit_depth - 8)) + m_ox1 * (1 << (bit_depth - 8)) + 1) << log2wd; add = 0;
         }
         unsigned o[4];
 #pragma unroll
@@ -258,17 +243,17 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
             o[k] = (unsigned)(out < 0 ? 0 : out > maxv ? maxv : out);
         }
         const int sy = n & 7, sx = 4 * (g & 1);
-        if (skip || sy >= m.h || sx >= m.w) continue;
+        if (skip || sy >= m_h || sx >= m_w) return;
         unsigned pk[WIDE ? 2 : 1];
         if (WIDE) { pk[0] = o[0] | (o[1] << 16); pk[WIDE ? 1 : 0] = o[2] | (o[3] << 16); }
         else      pk[0] = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-        const unsigned char *const pbase = m.plane == 0 ? PLANE_PTR3(dst, 0) : m.plane == 1 ? PLANE_PTR3(dst, 1) : PLANE_PTR3(dst, 2);
-        const int pstride = m.plane == 0 ? PLANE_STRIDE3(dst, 0) : m.plane == 1 ? PLANE_STRIDE3(dst, 1) : PLANE_STRIDE3(dst, 2);
-        MC4_GLOBAL unsigned char *p = (MC4_GLOBAL unsigned char *)pbase + (__umul24((unsigned)(m.y + sy), (unsigned)pstride) + (unsigned)(m.x + sx) * (unsigned)sizeof(Pixel));
-        if (m.w - sx >= 4) {
+        const unsigned char *const pbase = m_plane == 0 ? PLANE_PTR3(dst, 0) : m_plane == 1 ? PLANE_PTR3(dst, 1) : PLANE_PTR3(dst, 2);
+        const int pstride = m_plane == 0 ? PLANE_STRIDE3(dst, 0) : m_plane == 1 ? PLANE_STRIDE3(dst, 1) : PLANE_STRIDE3(dst, 2);
+        MC4_GLOBAL unsigned char *p = (MC4_GLOBAL unsigned char *)pbase + (__umul24((unsigned)(m_y + sy), (unsigned)pstride) + (unsigned)(m_x + sx) * (unsigned)sizeof(Pixel));
+        if (m_w - sx >= 4) {
             __builtin_memcpy((void *)p, pk, sizeof(pk));
         } else {                                                      // widths 2 and 6 (chroma of 4- and 12-wide blocks)
-            for (int k = 0; k < m.w - sx; k++)
+            for (int k = 0; k < m_w - sx; k++)
                 reinterpret_cast<MC4_GLOBAL Pixel *>(p)[k] = (Pixel)(WIDE ? pk[WIDE ? k >> 1 : 0] >> (16 * (k & 1)) : pk[0] >> (8 * k));
         }
     }

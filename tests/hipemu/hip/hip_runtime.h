@@ -174,6 +174,7 @@ template <typename T> static inline T hipemu_readfirstlane(T v)
 }
 #define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
 #define __builtin_amdgcn_readlane(v, l) __shfl((v), (l), 64)
+#define __builtin_amdgcn_ds_bpermute(addr, v) __shfl((int)(v), (int)(((unsigned)(addr)) >> 2) & 63, 64)
 
 // v_perm_b32: bytes of {a (7..4), b (3..0)} picked by the four selector bytes (0x0c = 0x00, 0x0d.. = 0xff for >=0x0d per ISA: 12 -> 0, >=13 -> 0xff)
 static inline unsigned hipemu_perm(unsigned a, unsigned b, unsigned sel)
