@@ -634,7 +634,7 @@ __device__ __forceinline__ SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao
     return SaoMasks{ u32x4{ keep[0], keep[1], keep[2], keep[3] }, u32x4{ bord[0], bord[1], bord[2], bord[3] } };
 }
 
-constexpr int kSaoWideThreads = 128, kSaoWideRows = 2;       // lanes per block of the list; rows a lane has in flight at a time
+constexpr int kSaoWideThreads = 256, kSaoWideRows = 2;       // lanes per block of the list (band filter: half of them); rows a lane of the band filter has in flight at a time
 template <typename Pixel>
 __global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp, int xcd_spread)
 {
@@ -665,7 +665,13 @@ __global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst,
     const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
     if (!sao_wide_ok<Pixel>(jb, sbase, dbase, sstride, dstride, pw, bit_depth)) return;
     const bool is_band = jb.type == OHEVC_SAO_BAND;
-    const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = kSaoWideThreads >> lp;      // a power of two (sao_wide_ok)
+    // The edge classes take all 256 lanes of the workgroup - a 64x64 block of 8-bit samples is then ONE row per lane, every load of the block
+    // in flight at once (r4z2: +7-8 % at both depths over 128 lanes; the kernel waits for memory more than it computes since the arithmetic
+    // went to packed 16-bit, profiles/r4y_sq_counters_sao_wide.txt).  The band filter keeps 128 lanes with two rows each in flight (-12 % at
+    // 8 bit with 256, r4z3): its other two wavefronts leave.
+    const int nthreads = is_band ? 128 : kSaoWideThreads;
+    if ((int)threadIdx.x >= nthreads) return;
+    const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = nthreads >> lp;      // a power of two (sao_wide_ok)
     const int piece = threadIdx.x & (pieces - 1), row0 = threadIdx.x >> lp, x0 = piece * PPL;
     const int dxa = eo == 1 ? 0 : eo == 3 ? 1 : -1, dya = eo == 0 ? 0 : -1;       // first neighbour; the second is its mirror
     // class -> offset table for v_perm_b32: byte k of (tab_lo, tab_hi) = 128 + offset of class k.  Edge: k = sign + sign + 2 ->
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst,
     auto pack4 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); };
     // A block lives as long as one lane's chain job record -> samples -> store, and the device holds a fixed number of lanes: what a lane has
     // in flight decides the rate (profiles/r03l_*: 4x less traffic changed nothing).  So a lane takes kSaoWideRows rows at a time, all their
-    // loads issued before the first is used; 128 lanes per block keep twice as many blocks resident as 256 did.
+    // loads issued before the first is used (the band filter; the edge classes: see `nthreads` above).
     // (one copy of the loop per filter type: with `is_band` tested inside, the branch around the neighbour loads made the compiler wait for
     //  the first row's samples before it issued the second row's loads)
     auto rows = [&](auto band_tag) {
