@@ -61,6 +61,10 @@ struct ohhip_backend {
     ohevc_ctx         *root;           /* owns the picture store; one context per decoding thread shares it (ohevc_ctx_create_shared) */
     ohevc_ctx         *all[128];
     int                nall;
+    ohevc_ctx         *spare[64];      /* contexts made at attach time, one per decoding thread the decoder will start: a context is a stream,
+                                          events and page-locked buffers - milliseconds of driver calls that would otherwise sit in front of
+                                          each thread's first picture */
+    int                nspare;
     pthread_mutex_t    lock;
     volatile int       error;          /* failures seen by threads that do not own a picture (slice workers) */
     volatile int       async_used;     /* some frame end went through the issuer: fetch_output waits for copy-backs */
@@ -160,6 +164,23 @@ static void publish_failed(ohhip_backend *be)
 }
 
 /* this thread's context in instance `be` (created on first use; all of them share the root's picture store) */
+static ohevc_ctx *new_thread_ctx(ohhip_backend *be)
+{
+    ohevc_ctx *ctx = NULL;
+    if (ohevc_ctx_create_shared(&ctx, be->opt.device, be->root) != OHEVC_OK)
+        return NULL;
+    /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
+    if (ohevc_tables_bind(ctx) != OHEVC_OK || ohevc_tables_emulate_filter_lag(ctx, 1) != OHEVC_OK) {
+        ohevc_ctx_destroy(ctx);
+        return NULL;
+    }
+    pthread_mutex_lock(&be->lock);
+    if (be->nall < 128)
+        be->all[be->nall++] = ctx;
+    pthread_mutex_unlock(&be->lock);
+    return ctx;
+}
+
 static ohevc_ctx *thread_ctx(ohhip_backend *be)
 {
     int k, free_k = -1;
@@ -187,17 +208,15 @@ static ohevc_ctx *thread_ctx(ohhip_backend *be)
         if (free_k < 0)
             free_k = 0;           /* (its context stays registered in its instance and dies with it) */
     }
-    if (ohevc_ctx_create_shared(&ctx, be->opt.device, be->root) != OHEVC_OK ||
-        /* stay bit-identical with the CTB lag of hevc_filter.c:1027-1063 (see ohevc_tables.h) */
-        ohevc_tables_bind(ctx) != OHEVC_OK || ohevc_tables_emulate_filter_lag(ctx, 1) != OHEVC_OK) {
+    pthread_mutex_lock(&be->lock);
+    if (be->nspare > 0)
+        ctx = be->spare[--be->nspare];                              /* (registered in be->all when it was made) */
+    pthread_mutex_unlock(&be->lock);
+    if (!ctx && !(ctx = new_thread_ctx(be))) {
         fprintf(stderr, "ohhip: per-thread context failed: %s\n", ohevc_last_error());
         note_error(be);
         return NULL;
     }
-    pthread_mutex_lock(&be->lock);
-    if (be->nall < 128)
-        be->all[be->nall++] = ctx;
-    pthread_mutex_unlock(&be->lock);
     t_ctxs[free_k].be = be; t_ctxs[free_k].id = be->id; t_ctxs[free_k].ctx = ctx;
     return ctx;
 }
@@ -788,6 +807,25 @@ int ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx)
     if (!be || be->magic != OHHIP_MAGIC || !avctx)
         return -1;
     avctx->opaque = be;          /* inherited by every frame-thread copy (pthread_frame.c:276 and the `*copy = *src` of its init) */
+    /* one context per decoding thread the decoder is about to start (the "threads" option is set before avcodec_open2, like this call):
+       made here, at open time, instead of in front of every thread's first picture */
+    if (be->root && !be->opt.record_only) {
+        int want = avctx->thread_count > 1 ? avctx->thread_count : 1, have;
+        if (want > 64)
+            want = 64;
+        pthread_mutex_lock(&be->lock);
+        have = be->nspare;
+        pthread_mutex_unlock(&be->lock);
+        for (; have < want; have++) {
+            ohevc_ctx *ctx = new_thread_ctx(be);
+            if (!ctx)
+                break;                      /* (a thread that finds no spare context makes its own and reports the failure) */
+            pthread_mutex_lock(&be->lock);
+            be->spare[be->nspare++] = ctx;
+            pthread_mutex_unlock(&be->lock);
+        }
+        ohevc_tables_bind(t_ctx);           /* (making a context binds the calling thread's table calls to it: back to what they were) */
+    }
     return 0;
 }
 

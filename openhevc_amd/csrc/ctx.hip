@@ -204,6 +204,14 @@ struct ohevc_ctx : Rec {
     // decoding thread stood still in the middle of its frame end until its references were reconstructed on the device.
     hipEvent_t staged[2] = {nullptr, nullptr};      // recorded after the last H2D copy out of stage[k]
     bool staged_pending[2] = {false, false};
+    // The uploads run on a stream of their own.  In `stream` they sat behind the waits for the reference pictures' frame ends
+    // (hipStreamWaitEvent on events of other decoding threads' streams), and hipMemcpyAsync behind an unresolved cross-stream wait does not
+    // return on this runtime until the wait is over - and then only after a wake-up latency of ~4 ms during which NOTHING is submitted
+    // (profiles/r5b_*: three decoding threads inside hipMemcpyAsync for 7.7-9.8 ms, the device idle for the last 4.1 ms of it, once per
+    // level of the GOP's reference hierarchy).  An upload depends on nothing but the earlier readers of its device buffer (lane_done).
+    hipStream_t up_stream = nullptr;
+    hipEvent_t lane_done[2] = {nullptr, nullptr};   // recorded in `stream` behind the last kernel that reads d_jobs[k]
+    bool lane_done_pending[2] = {false, false};
     std::shared_ptr<PicStore> store;
     unsigned table_version = ~0u;     // store->version the device MC table was built from
     int cur = -1;
@@ -343,8 +351,11 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     c->device = device;
     c->store = share_with ? share_with->store : std::make_shared<PicStore>();
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->staged[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->staged[1], hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&c->staged[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->lane_done[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->lane_done[1], hipEventDisableTiming) == hipSuccess;
     for (auto &e : c->ring) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         set_error("stream/event creation failed");
@@ -377,6 +388,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
         async_drain(*c->store);
         if (c->store.use_count() == 1 + (long)c->store->issuer->execs.size()) issuer_shutdown(*c->store);      // the last recording context goes
     }
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
         (void)hipDeviceSynchronize();
@@ -409,6 +421,8 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     for (PinnedBuf &b : c->stage) if (b.p) (void)hipHostFree(b.p);
     if (c->table_stage.p) (void)hipHostFree(c->table_stage.p);
     for (hipEvent_t e : c->staged) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->lane_done) if (e) (void)hipEventDestroy(e);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
     if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
@@ -1494,7 +1508,8 @@ static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>
     if (rc != OHEVC_OK) return rc;
     if ((rc = c->stage[lane].reserve(total)) != OHEVC_OK) return rc;
     if (total > c->d_jobs[lane].cap) {
-        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));     // in-flight kernels may still read the old buffer
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->up_stream));  // an upload may still write the old buffer ...
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));     // ... and in-flight kernels may still read it
         if ((rc = c->d_jobs[lane].reserve(total)) != OHEVC_OK) return rc;
     }
     size_t off = 0;
@@ -1504,8 +1519,11 @@ static int upload_jobs(ohevc_ctx *c, std::vector<std::pair<const void *, size_t>
         off += (pr.second + 255) & ~(size_t)255;
     }
     if (g_trace_timing) c->t_part[0] += now_s() - t_copy;
-    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs[lane].p, c->stage[lane].p, total, hipMemcpyHostToDevice, c->stream));
-    OHEVC_HIP_TRY(hipEventRecord(c->staged[lane], c->stream));
+    // on the upload stream (see ohevc_ctx::up_stream): behind the earlier readers of this lane's device buffer, in front of this call's kernels
+    if (c->lane_done_pending[lane]) OHEVC_HIP_TRY(hipStreamWaitEvent(c->up_stream, c->lane_done[lane], 0));
+    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_jobs[lane].p, c->stage[lane].p, total, hipMemcpyHostToDevice, c->up_stream));
+    OHEVC_HIP_TRY(hipEventRecord(c->staged[lane], c->up_stream));
+    OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, c->staged[lane], 0));
     c->staged_pending[lane] = true;
     c->stats.upload_bytes += (int64_t)total;
     return OHEVC_OK;
@@ -1934,6 +1952,9 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     }
     c->stats.intra_levels = std::max(c->stats.intra_levels, std::max(max_level, 0));
     clear_recorded(c);
+    // (the frame end's filter kernels read the same lane: it records the event again behind them)
+    OHEVC_HIP_TRY(hipEventRecord(c->lane_done[rlane], c->stream));
+    c->lane_done_pending[rlane] = true;
     return OHEVC_OK;
 }
 
@@ -2158,6 +2179,11 @@ static int frame_end_impl(ohevc_ctx *c)
         if (g_trace_order) fprintf(stderr, "order: ctx %p ends target %d event %p\n", (void *)c, c->cur, (void *)ev);
         c->ring_next = (c->ring_next + 1) % 16;
         OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));
+        // the filter kernels above read the maps out of one of the two upload lanes (whichever carried them): no upload into either before they are done
+        for (int k = 0; k < 2; k++) {
+            OHEVC_HIP_TRY(hipEventRecord(c->lane_done[k], c->stream));
+            c->lane_done_pending[k] = true;
+        }
         std::lock_guard<std::mutex> g(c->store->m);
         p->written = ev;
         for (int r : c->ref_slots) {
