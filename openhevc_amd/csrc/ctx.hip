@@ -332,6 +332,26 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
     return ohevc_ctx_create_shared(out, device, nullptr);
 }
 
+// The first use of things costs milliseconds on this runtime - the first host-to-device copy of a process 8.7 ms, the second context's 5.6 ms,
+// the first device-to-host copy 7.7 ms, the first kernel launch 3.5 ms (code object load), every page-locked staging buffer 0.5-2 ms
+// (profiles/r5f_*: all of it inside the first pictures' frame ends).  A context does them when it is made - the sample hooks make one per
+// decoding thread when the decoder is opened (ohhip_backend_attach) - instead of in front of its thread's first picture.  Best effort: a
+// failure here shows up again, with its message, where the buffers are needed.
+static const int g_prewarm_kib = getenv("OHEVC_PREWARM_KIB") ? atoi(getenv("OHEVC_PREWARM_KIB")) : 3072;      // 0: off; the upload buffers' first size (x 1.5)
+static void prewarm(ohevc_ctx *c)
+{
+    if (g_prewarm_kib <= 0) return;
+    for (int lane = 0; lane < 2; lane++)
+        if (c->stage[lane].reserve((size_t)g_prewarm_kib << 10) != OHEVC_OK || c->d_jobs[lane].reserve((size_t)g_prewarm_kib << 10) != OHEVC_OK) return;
+    memset(c->stage[0].p, 0, 4096);
+    if (hipMemcpyAsync(c->d_jobs[0].p, c->stage[0].p, 4096, hipMemcpyHostToDevice, c->up_stream) != hipSuccess) return;
+    if (hipStreamSynchronize(c->up_stream) != hipSuccess) return;
+    if (ohevc_dev_copy(static_cast<unsigned char *>(c->d_jobs[1].p), c->d_jobs[0].p, 4096, c->stream) != OHEVC_OK) return;
+    if (hipMemcpy2DAsync(c->stage[1].p, 1024, c->d_jobs[1].p, 1024, 1024, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
+    (void)hipStreamSynchronize(c->stream);
+}
+
+
 extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *share_with)
 {
     OHEVC_REQUIRE(out != nullptr, "out");
@@ -362,6 +382,7 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
         delete c;
         return OHEVC_ERR_HIP;
     }
+    prewarm(c);
     *out = c;
     return OHEVC_OK;
 }
