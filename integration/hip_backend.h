@@ -42,7 +42,7 @@ typedef struct ohhip_options {
     int async_issue;         /* 1: frame ends issued by the library's issuer threads                   (default 0; OHHIP_ASYNC_ISSUE) */
     int record_only;         /* 1: no device, no pixels: host-side profiling / software-executor tests (default 0; OHHIP_RECORD_ONLY) */
     int test_fail_index;     /* fault injection of the multi-process tests: the owner fails on this picture (default -1; OHHIP_TEST_FAIL_INDEX) */
-    int flush_intra_kib;     /* an intra picture's recorded work goes to the device at the end of a CTU row once this many KiB are waiting; 0: only at the frame end (default 4096; OHHIP_FLUSH_INTRA_KIB) */
+    int flush_intra_kib;     /* an intra picture's recorded work goes to the device at the end of a CTU row once this many KiB are waiting; 0: only at the frame end; -1 (default): by the picture's size - 0.45 bytes per luma sample, 512 .. 4096 KiB: 911 KiB at 1080p (OHHIP_FLUSH_INTRA_KIB) */
     const char *trace_path;  /* per-picture host timeline (parse start, hook start, issue end, hook end) written here at free (default OHHIP_TRACE_FRAMES) */
 } ohhip_options;
 

@@ -617,8 +617,20 @@ void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size)
  * parsing takes much longer than their chain: dense residuals, 4K / 8K; ohevc_ctx.h has the measurement). */
 static void row_end(HEVCContext *s, int x_ctb, int ctb_size)
 {
-    if (t_frame_open && t_ctx && t_be && s == t_s && t_be->opt.flush_intra_kib > 0 && x_ctb >= s->sps->width - ctb_size &&
-        !((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1) && ohevc_frame_flush_intra(t_ctx, t_be->opt.flush_intra_kib) != OHEVC_OK)
+    int kib;
+    if (!(t_frame_open && t_ctx && t_be && s == t_s && t_be->opt.flush_intra_kib != 0 && x_ctb >= s->sps->width - ctb_size) ||
+        ((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1))
+        return;
+    kib = t_be->opt.flush_intra_kib;
+    if (kib < 0) {
+        /* by the picture's size: two or three hand-overs per encoder-like intra picture (its records and coefficients are ~0.8 bytes per luma
+           sample), so that the first half's dependency chain runs while the second half is parsed; more of them and the bands' chains add up
+           (a picture's levels run along diagonals through all of its CTU rows: DESIGN.md 5h) */
+        const long long px = (long long)s->sps->width * s->sps->height;
+        kib = (int)(px * 45 / 100 / 1024);
+        kib = kib < 512 ? 512 : kib > 4096 ? 4096 : kib;
+    }
+    if (ohevc_frame_flush_intra(t_ctx, kib) != OHEVC_OK)
         note_error(t_be);
 }
 
@@ -754,7 +766,7 @@ void ohhip_options_default(ohhip_options *o)
     o->record_only = getenv("OHHIP_RECORD_ONLY") != NULL;
     o->test_fail_index = getenv("OHHIP_TEST_FAIL_INDEX") ? atoi(getenv("OHHIP_TEST_FAIL_INDEX")) : -1;
     o->trace_path = getenv("OHHIP_TRACE_FRAMES");
-    o->flush_intra_kib = getenv("OHHIP_FLUSH_INTRA_KIB") ? atoi(getenv("OHHIP_FLUSH_INTRA_KIB")) : 4096;
+    o->flush_intra_kib = getenv("OHHIP_FLUSH_INTRA_KIB") ? atoi(getenv("OHHIP_FLUSH_INTRA_KIB")) : -1;
 }
 
 ohhip_backend *ohhip_backend_new(const ohhip_options *o)
