@@ -25,7 +25,7 @@
 #ifdef OHDEC_HIP
 /* integration/hip_backend.h: one back end per decoder instance, attached before avcodec_open2 (the structs are passed through opaquely) */
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib; const char *trace_path; } ohdec_options;
+typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib; const char *trace_path; ohhip_backend *base_layer; } ohdec_options;
 void ohhip_options_default(ohdec_options *o);
 ohhip_backend *ohhip_backend_new(const ohdec_options *o);
 int  ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx);
@@ -39,7 +39,7 @@ void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx);
 int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 #else
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib; const char *trace_path; } ohdec_options;
+typedef struct ohdec_options { int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib; const char *trace_path; ohhip_backend *base_layer; } ohdec_options;
 static void ohhip_options_default(ohdec_options *o) { memset(o, 0, sizeof(*o)); }
 static ohhip_backend *ohhip_backend_new(const ohdec_options *o) { (void)o; return NULL; }
 static int  ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx) { (void)be; (void)avctx; return 0; }
@@ -84,9 +84,14 @@ typedef struct ohdec {
  * between libOpenHevcInit and libOpenHevcStartDecoder, openHevcWrapper.c:429-440) so that frame-thread copies inherit it: every
  * picture is verified against its decoded-picture-hash SEI (hevc.c:4146-4162) */
 /* `device` < 0: the back end's defaults (environment); else this decoder's HIP device.  Every decoder gets a back end of its own. */
-ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device);
+/* SHVC (openHevcWrapper.c:47-103): the wrapper opens MAX_DECODERS = 2 decoders per handle, sets each one's "decoder-id" option before
+ * avcodec_open2 and points the enhancement layer's BL_avcontext at the base layer's context.  `decoder_id` 0 / `base` NULL: a single-layer
+ * decoder, as before.  With the gfx950 back end the enhancement-layer decoder's back end shares the base layer's picture store (the
+ * inter-layer reference picture is resampled from a base-layer picture on the device). */
+ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, int decoder_id, ohdec *base);
+ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device) { return ohdec_open_layer(threads, thread_type, checksum, device, 0, NULL); }
 ohdec *ohdec_open_ex(int threads, int thread_type, int checksum) { return ohdec_open_dev(threads, thread_type, checksum, -1); }
-ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device)
+ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, int decoder_id, ohdec *base)
 {
     static int registered;
     ohdec *d = calloc(1, sizeof(*d));
@@ -112,6 +117,8 @@ ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device)
     av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type >= 3 ? "frameslice" : "frame", 0);
     d->threads = threads > 0 ? threads : 1;
     av_opt_set_int(d->avctx, "threads", d->threads, 0);
+    av_opt_set_int(d->avctx->priv_data, "decoder-id", decoder_id, 0);          /* openHevcWrapper.c:92 */
+    d->avctx->quality_id = base || decoder_id ? 1 : 0;                          /* the wrapper's active_layer (openHevcWrapper.c:120) */
     if (checksum) {
         av_opt_set_int(d->avctx->priv_data, "decode-checksum", 1, 0);
         g_md5_ok = g_md5_bad = 0;
@@ -126,6 +133,7 @@ ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device)
         ohhip_options_default(&o);
         if (device >= 0)
             o.device = device;
+        o.base_layer = base ? base->backend : NULL;
         if (!(d->backend = ohhip_backend_new(&o)) || ohhip_backend_attach(d->backend, d->avctx) != 0)
             goto fail;
     }
@@ -134,6 +142,8 @@ ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device)
 #endif
     if (avcodec_open2(d->avctx, codec, NULL) < 0)
         goto fail;
+    if (base)
+        d->avctx->BL_avcontext = base->avctx;                                   /* openHevcWrapper.c:107-108 */
     return d;
 fail:
     ohhip_backend_free(d->backend);
@@ -173,6 +183,16 @@ void ohdec_md5_results(ohdec *d, int *ok, int *bad)
     (void)d;
     *ok = g_md5_ok;
     *bad = g_md5_bad;
+}
+
+/* SHVC: the wrapper's active_layer, written into every decoder's quality_id before each access unit (openHevcWrapper.c:120) */
+void ohdec_set_active_layer(ohdec *d, int layer) { d->avctx->quality_id = layer; }
+
+/* SHVC: what libOpenHevcDecode does between the two decoders of an access unit (openHevcWrapper.c:131-132): the enhancement-layer decoder
+ * is handed the base-layer picture the base-layer decoder has just reconstructed (its s->ref, hevc.c:3249). */
+void ohdec_take_base_frame(ohdec *el, ohdec *bl)
+{
+    el->avctx->BL_frame = bl->avctx->BL_frame;
 }
 
 /* returns 1 when a picture came out (fetch it with ohdec_frame_*), 0 when none, <0 on a decoder / back-end error */

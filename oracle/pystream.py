@@ -49,6 +49,11 @@ def _load(kind: str):
     L.ohdec_open_ex.restype = C.c_void_p
     L.ohdec_open_ex.argtypes = [C.c_int, C.c_int, C.c_int]
     L.ohdec_md5_results.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    if hasattr(L, "ohdec_open_layer"):
+        L.ohdec_open_layer.restype = C.c_void_p
+        L.ohdec_open_layer.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ohdec_take_base_frame.argtypes = [C.c_void_p, C.c_void_p]
+        L.ohdec_set_active_layer.argtypes = [C.c_void_p, C.c_int]
     if kind == "gen":
         L.ohsyn_reset.argtypes = [C.c_uint64]
         L.ohsyn_set_probs.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float]
@@ -97,16 +102,30 @@ def _configure_hip_backend():
 class Decoder:
     """One decoder instance.  decode(au) -> picture (list of 3 numpy planes) or None; flush() -> remaining pictures."""
 
-    def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1, checksum: bool = False, pipelined: bool = False):
+    def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1, checksum: bool = False, pipelined: bool = False,
+                 decoder_id: int = 0, base: "Optional[Decoder]" = None):
+        """decoder_id / base: SHVC, the way openHevcWrapper.c:47-108 opens its two decoders - the enhancement-layer decoder has
+        decoder_id 1 and `base` = the base-layer decoder (its BL_avcontext); see take_base()."""
         self.kind = kind
         self.L = _load(kind)
         self.sw = _configure_hip_backend() if kind == "hip" else None
-        self.h = self.L.ohdec_open_ex(threads, thread_type, 1 if checksum else 0)
+        if decoder_id or base is not None:
+            self.h = self.L.ohdec_open_layer(threads, thread_type, 1 if checksum else 0, -1, decoder_id, base.h if base is not None else None)
+        else:
+            self.h = self.L.ohdec_open_ex(threads, thread_type, 1 if checksum else 0)
         if not self.h:
             raise RuntimeError(f"ohdec_open failed for {kind}")
         if pipelined:       # the application takes every picture one call late (decoder_harness.c): device work overlaps the next parse
             self.L.ohdec_set_pipelined.argtypes = [C.c_void_p, C.c_int]
             self.L.ohdec_set_pipelined(self.h, 1)
+
+    def take_base(self, bl: "Decoder"):
+        """SHVC: hand this (enhancement-layer) decoder the picture the base-layer decoder has just reconstructed - what
+        libOpenHevcDecode does between its two avcodec_decode_video2 calls (openHevcWrapper.c:131-132)."""
+        self.L.ohdec_take_base_frame(self.h, bl.h)
+
+    def set_active_layer(self, layer: int):
+        self.L.ohdec_set_active_layer(self.h, layer)
 
     def md5_results(self):
         """(planes whose decoded-picture-hash SEI matched, planes that did not) since the decoder was opened: the reference's own
@@ -251,8 +270,8 @@ def escape(rbsp: bytes) -> bytes:
     return bytes(out)
 
 
-def nal(nal_type: int, rbsp: bytes, tid: int = 0) -> bytes:
-    hdr = bytes([(nal_type << 1) & 0x7E, 1 + tid])   # forbidden_zero, type(6), layer_id(6) = 0, tid_plus1(3)
+def nal(nal_type: int, rbsp: bytes, tid: int = 0, layer: int = 0) -> bytes:
+    hdr = bytes([((nal_type << 1) & 0x7E) | (layer >> 5), ((layer & 31) << 3) | (1 + tid)])   # forbidden_zero, type(6), nuh_layer_id(6), tid_plus1(3)
     return b"\x00\x00\x00\x01" + hdr + escape(rbsp)
 
 
@@ -389,44 +408,108 @@ def _dpb(p: StreamParams):
     return 4, 0
 
 
-def write_vps(p: StreamParams) -> bytes:
+def write_vps(p: StreamParams, el: Optional[StreamParams] = None, phase_align: int = 0) -> bytes:
+    """`el`: a second (spatial enhancement) layer - vps_max_layers_minus1 = 1 and the vps_extension() of the SHVC draft the
+    reference parses (parse_vps_extension, hevc_ps.c:714-1095, with the macro set of hevc_defs.h)."""
     b = Bits()
     b.u(4, 0)
     b.u(2, 3)
-    b.u(6, 0)
+    b.u(6, 1 if el else 0)
     b.u(3, 0)
     b.u(1, 1)
-    b.u(16, 0xFFFF)
+    b.u(16, 0xFFFF)   # vps_extension_offset / reserved (read, not used: hevc_ps.c:1136-1138)
     _ptl(b, p)
     dpb, reorder = _dpb(p)
     b.u(1, 1)
     b.ue(dpb - 1)
     b.ue(reorder)
     b.ue(0)
-    b.u(6, 0)    # vps_max_layer_id
-    b.ue(0)      # vps_num_layer_sets_minus1
+    b.u(6, 1 if el else 0)    # vps_max_layer_id
+    b.ue(1 if el else 0)      # vps_num_layer_sets_minus1
+    if el:
+        b.u(1, 1)             # layer_id_included_flag[1][0..1]
+        b.u(1, 1)
     b.u(1, 0)    # timing info
-    b.u(1, 0)    # extension
+    b.u(1, 1 if el else 0)    # extension
+    if el:
+        while len(b.b) & 7:   # vps_extension_alignment_bit_equal_to_one (align_get_bits, hevc_ps.c:1215)
+            b.u(1, 1)
+        _vps_extension(b, p, el, phase_align)
     b.trailing()
     return nal(NAL_VPS, b.bytes())
 
 
-def write_sps(p: StreamParams) -> bytes:
+def _vps_extension(b: Bits, p: StreamParams, el: StreamParams, phase_align: int):
+    """Two layers, layer 1 depends on layer 0 (hevc_ps.c:714-1095, in parse order)."""
+    b.u(1, 0)                 # avc_base_layer_flag
+    b.u(1, 0)                 # splitting_flag
+    for i in range(16):       # scalability_mask: dependency (spatial / quality) scalability only
+        b.u(1, 1 if i == 1 else 0)
+    b.u(3, 0)                 # dimension_id_len_minus1[0]
+    b.u(1, 0)                 # vps_nuh_layer_id_present_flag
+    b.u(1, 1)                 # dimension_id[1][0]
+    b.u(4, 0)                 # view_id_len_minus1
+    b.u(1, 0)                 # view_id_val[0] (one view)
+    b.u(1, 1)                 # direct_dependency_flag[1][0]
+    b.u(1, 0)                 # vps_sub_layers_max_minus1_present_flag
+    b.u(1, 0)                 # max_tid_ref_present_flag
+    b.u(1, 1)                 # all_ref_layers_active_flag
+    b.u(10, 1)                # vps_number_layer_sets_minus1 (must repeat the VPS's)
+    b.u(6, 0)                 # vps_num_profile_tier_level_minus1
+    b.u(1, 0)                 # more_output_layer_sets_than_default_flag
+    b.u(1, 0)                 # default_one_target_output_layer_flag (two output layer sets)
+    b.u(1, 0)                 # profile_level_tier_idx[1]
+    b.u(1, 0)                 # alt_output_layer_flag
+    b.u(1, 0)                 # rep_format_idx_present_flag: one rep_format() per layer, layer i uses format i
+    for q in (p, el):         # rep_format() (parseRepFormat, hevc_ps.c:411-465)
+        b.u(1, 1)             # chroma_and_bit_depth_vps_present_flag
+        b.u(16, q.width)
+        b.u(16, q.height)
+        b.u(2, q.chroma_format)
+        if q.chroma_format == 3:
+            b.u(1, 0)
+        b.u(4, q.bit_depth - 8)
+        b.u(4, q.bit_depth - 8)
+    b.u(1, 1)                 # max_one_active_ref_layer_flag
+    b.u(1, phase_align)       # cross_layer_phase_alignment_flag
+    b.u(1, 0)                 # sub_layer_flag_info_present_flag[1]
+    dpb, reorder = _dpb(el)
+    b.ue(dpb - 1)             # max_vps_dec_pic_buffering_minus1[1][0..1][0]: one value per layer of the set
+    b.ue(dpb - 1)
+    b.ue(reorder)             # max_vps_num_reorder_pics[1][0]
+    b.ue(0)                   # max_vps_latency_increase_plus1[1][0]
+    b.ue(0)                   # direct_dep_type_len_minus2
+    b.u(1, 1)                 # default_direct_dependency_type_flag
+    b.u(2, 2)                 # default_direct_dependency_type: sample and motion prediction
+    b.u(1, 0)                 # single_layer_for_non_irap_flag
+    b.u(1, 0)                 # higher_layer_irap_skip_flag
+    b.u(1, 0)                 # vps_vui_present_flag
+
+
+def write_sps(p: StreamParams, layer: int = 0, sps_id: int = 0) -> bytes:
+    """layer > 0: the enhancement-layer form of the SHVC draft the reference parses (hevc_ps.c:1556-1662,1695-1725): no sub-layer /
+    profile fields, update_rep_format_flag = 0 - size, chroma format and bit depth come from the VPS's rep_format() of the layer."""
     assert p.width % (1 << p.log2_min_cb) == 0 and p.height % (1 << p.log2_min_cb) == 0
     b = Bits()
     b.u(4, 0)
-    b.u(3, 0)
-    b.u(1, 1)
-    _ptl(b, p)
-    b.ue(0)                       # sps_id
-    b.ue(p.chroma_format)         # chroma_format_idc
-    if p.chroma_format == 3:
-        b.u(1, 0)                 # separate_colour_plane_flag
-    b.ue(p.width)
-    b.ue(p.height)
+    if layer == 0:
+        b.u(3, 0)
+        b.u(1, 1)
+        _ptl(b, p)
+    b.ue(sps_id)                  # sps_id
+    if layer == 0:
+        b.ue(p.chroma_format)         # chroma_format_idc
+        if p.chroma_format == 3:
+            b.u(1, 0)                 # separate_colour_plane_flag
+        b.ue(p.width)
+        b.ue(p.height)
+    else:
+        assert p.chroma_format == 1 and not p.rext
+        b.u(1, 0)                 # update_rep_format_flag
     b.u(1, 0)                     # conformance window
-    b.ue(p.bit_depth - 8)
-    b.ue(p.bit_depth - 8)
+    if layer == 0:
+        b.ue(p.bit_depth - 8)
+        b.ue(p.bit_depth - 8)
     b.ue(4)                       # log2_max_poc_lsb = 8
     dpb, reorder = _dpb(p)
     b.u(1, 1)
@@ -470,13 +553,13 @@ def write_sps(p: StreamParams) -> bytes:
     else:
         b.u(1, 0)
     b.trailing()
-    return nal(NAL_SPS, b.bytes())
+    return nal(NAL_SPS, b.bytes(), layer=layer)
 
 
-def write_pps(p: StreamParams) -> bytes:
+def write_pps(p: StreamParams, layer: int = 0, pps_id: int = 0, sps_id: int = 0) -> bytes:
     b = Bits()
-    b.ue(0)
-    b.ue(0)
+    b.ue(pps_id)
+    b.ue(sps_id)
     b.u(1, p.dependent_slices)
     b.u(1, 0)                     # output_flag_present
     b.u(3, 0)                     # extra slice header bits
@@ -510,6 +593,8 @@ def write_pps(p: StreamParams) -> bytes:
         b.u(1, 0)
         b.se(p.pps_beta_div2)
         b.se(p.pps_tc_div2)
+    if layer:
+        b.u(1, 0)                 # pps_infer_scaling_list_flag (hevc_ps.c:2381-2385)
     b.u(1, 0)                     # scaling list data
     b.u(1, 0)                     # lists_modification_present
     b.ue(p.log2_parallel_merge_level - 2)
@@ -527,7 +612,7 @@ def write_pps(p: StreamParams) -> bytes:
     else:
         b.u(1, 0)                 # pps extension
     b.trailing()
-    return nal(NAL_PPS, b.bytes())
+    return nal(NAL_PPS, b.bytes(), layer=layer)
 
 
 # ------------------------------------------------------------------------------------------------ GOP plan
@@ -605,14 +690,16 @@ def plan_gop(p: StreamParams) -> List[Pic]:
 
 # ------------------------------------------------------------------------------------------------ slice header
 def write_slice_header(p: StreamParams, pic: Pic, rng: np.random.Generator, seg_addr: int, dependent: int,
-                       entry_points: Optional[Sequence[int]], fixed: dict) -> Bits:
-    """`fixed` carries the per-picture choices (qp delta, flags) so that all segments of a picture agree."""
+                       entry_points: Optional[Sequence[int]], fixed: dict, layer: int = 0, pps_id: int = 0) -> Bits:
+    """`fixed` carries the per-picture choices (qp delta, flags) so that all segments of a picture agree.  layer > 0: an SHVC
+    enhancement-layer slice - slice_pic_order_cnt_lsb in IDR pictures too (hevc.c:728-729) and inter_layer_pred_enabled_flag = 1
+    behind the reference picture sets (hevc.c:804-831: one direct reference layer, nothing else to send)."""
     b = Bits()
     first = seg_addr == 0
     b.u(1, 1 if first else 0)
     if 16 <= pic.nal_type <= 23:
         b.u(1, 0)                                 # no_output_of_prior_pics
-    b.ue(0)                                       # pps id
+    b.ue(pps_id)                                  # pps id
     if not first:
         if p.dependent_slices:
             b.u(1, dependent)
@@ -620,6 +707,8 @@ def write_slice_header(p: StreamParams, pic: Pic, rng: np.random.Generator, seg_
     if not dependent:
         b.ue(pic.slice_type)
         idr = pic.nal_type in (19, 20)
+        if idr and layer:
+            b.u(8, pic.poc & 0xFF)
         if not idr:
             b.u(8, pic.poc & 0xFF)
             b.u(1, 0)                             # short_term_ref_pic_set_sps_flag
@@ -637,6 +726,8 @@ def write_slice_header(p: StreamParams, pic: Pic, rng: np.random.Generator, seg_
                 prev = q
             if p.tmvp:
                 b.u(1, fixed["tmvp"])
+        if layer:
+            b.u(1, 1)                             # inter_layer_pred_enabled_flag
         if p.sao:
             b.u(1, fixed["sao_luma"])
             b.u(1, fixed["sao_chroma"])
@@ -760,55 +851,65 @@ def _entry_point_count(p: StreamParams, first_ctb: int, count: int) -> int:
     return 0
 
 
+def _generate_picture(L, gen: "Decoder", p: StreamParams, pic: Pic, rng, pts: int, prefix: bytes, layer: int = 0, pps_id: int = 0):
+    """One picture of one layer through the generator: returns (its slice NAL units, the picture the generator put out or None).
+    `prefix`: parameter sets the generator's decoder has to see in front of the slices (not part of the returned bytes)."""
+    fixed = _fixed_choices(p, pic, rng)
+    layout = _slice_layout(p, rng)
+    # pass 1: headers with placeholder entry points + a dummy payload, through the generator
+    hdr_bits, au = [], prefix
+    for first_ctb, count, dep in layout:
+        nep = _entry_point_count(p, first_ctb, count)
+        hb = write_slice_header(p, pic, rng, first_ctb, dep, [1] * nep if nep else None, fixed, layer, pps_id)
+        hdr_bits.append((hb, nep))
+        au += nal(pic.nal_type, hb.bytes() + b"\xff" * (8 + 4 * nep), layer=layer)
+    counts = (C.c_int * len(layout))(*[c for _, c, _ in layout])
+    L.ohsyn_begin_au(counts, len(layout))
+    f = gen.decode(au, pts)
+    if L.ohsyn_num_slices() != len(layout):
+        raise RuntimeError(f"generator produced {L.ohsyn_num_slices()} slice payloads, planned {len(layout)}")
+    # pass 2: real NAL units
+    out = b""
+    for k, ((first_ctb, count, dep), (hb, nep)) in enumerate(zip(layout, hdr_bits)):
+        ptr = C.POINTER(C.c_uint8)()
+        n = L.ohsyn_slice_payload(k, C.byref(ptr))
+        if n < 0:
+            raise RuntimeError("slice segment incomplete: the reference parser rejected the random syntax")
+        payload = bytes(np.ctypeslib.as_array(ptr, shape=(n,))) if n else b""
+        if nep:
+            sp = C.POINTER(C.c_uint32)()
+            ns = L.ohsyn_slice_substreams(k, C.byref(sp))
+            starts = [int(sp[j]) for j in range(ns)] + [n]
+            if ns != nep + 1:
+                raise RuntimeError(f"{ns} substreams for {nep} entry points")
+            # entry points count the bytes of the ESCAPED substreams (7.4.7.1)
+            sizes = _escaped_sizes(hb.bytes(), payload, starts)
+            hb = write_slice_header(p, pic, rng, first_ctb, dep, sizes[:-1], fixed, layer, pps_id)
+            # rewriting the sizes can move emulation-prevention bytes of the header only, not of the data
+        out += nal(pic.nal_type, hb.bytes() + payload, layer=layer)
+    return out, f
+
+
+def _set_probs(L, p: StreamParams):
+    probs = prob_table(p.probs)
+    L.ohsyn_set_probs(probs.ctypes.data_as(C.POINTER(C.c_float)), len(probs), p.bypass_prob, p.pcm_prob if p.pcm else 0.0)
+
+
 def generate(p: StreamParams, check: bool = True):
     """Returns (list of access units as bytes, list of pictures the generator reconstructed in output order)."""
     L = _load("gen")
     rng = np.random.default_rng(p.seed)
     L.ohsyn_reset(p.seed)
-    probs = prob_table(p.probs)
-    L.ohsyn_set_probs(probs.ctypes.data_as(C.POINTER(C.c_float)), len(probs), p.bypass_prob,
-                      p.pcm_prob if p.pcm else 0.0)
+    _set_probs(L, p)
     headers = write_vps(p) + write_sps(p) + write_pps(p)
     aus, frames = [], []
     gen = Decoder("gen")
     try:
         for i, pic in enumerate(plan_gop(p)):
-            fixed = _fixed_choices(p, pic, rng)
-            layout = _slice_layout(p, rng)
-            # pass 1: headers with placeholder entry points + a dummy payload, through the generator
-            hdr_bits, au = [], headers if i == 0 else b""
-            for first_ctb, count, dep in layout:
-                nep = _entry_point_count(p, first_ctb, count)
-                hb = write_slice_header(p, pic, rng, first_ctb, dep, [1] * nep if nep else None, fixed)
-                hdr_bits.append((hb, nep))
-                au += nal(pic.nal_type, hb.bytes() + b"\xff" * (8 + 4 * nep))
-            counts = (C.c_int * len(layout))(*[c for _, c, _ in layout])
-            L.ohsyn_begin_au(counts, len(layout))
-            f = gen.decode(au, i + 1)
+            out, f = _generate_picture(L, gen, p, pic, rng, i + 1, headers if i == 0 else b"")
             if f is not None:
                 frames.append(f)
-            if L.ohsyn_num_slices() != len(layout):
-                raise RuntimeError(f"generator produced {L.ohsyn_num_slices()} slice payloads, planned {len(layout)}")
-            # pass 2: real NAL units
-            out = headers if i == 0 else b""
-            for k, ((first_ctb, count, dep), (hb, nep)) in enumerate(zip(layout, hdr_bits)):
-                ptr = C.POINTER(C.c_uint8)()
-                n = L.ohsyn_slice_payload(k, C.byref(ptr))
-                if n < 0:
-                    raise RuntimeError("slice segment incomplete: the reference parser rejected the random syntax")
-                payload = bytes(np.ctypeslib.as_array(ptr, shape=(n,))) if n else b""
-                if nep:
-                    sp = C.POINTER(C.c_uint32)()
-                    ns = L.ohsyn_slice_substreams(k, C.byref(sp))
-                    starts = [int(sp[j]) for j in range(ns)] + [n]
-                    if ns != nep + 1:
-                        raise RuntimeError(f"{ns} substreams for {nep} entry points")
-                    # entry points count the bytes of the ESCAPED substreams (7.4.7.1)
-                    sizes = _escaped_sizes(hb.bytes(), payload, starts)
-                    hb = write_slice_header(p, pic, rng, first_ctb, dep, sizes[:-1], fixed)
-                    # rewriting the sizes can move emulation-prevention bytes of the header only, not of the data
-                out += nal(pic.nal_type, hb.bytes() + payload)
-            aus.append(out)
+            aus.append((headers if i == 0 else b"") + out)
         frames += gen.flush()
     finally:
         gen.close()
@@ -819,6 +920,94 @@ def generate(p: StreamParams, check: bool = True):
         assert len(frames) == len(pocs)
         aus = [au + md5_sei_nal(frames[rank[poc]]) for au, poc in zip(aus, pocs)]
     return aus, frames
+
+
+# ------------------------------------------------------------------------------------------------ SHVC: two spatial layers
+def enhancement_plan(pics: List[Pic]) -> List[Pic]:
+    """The enhancement layer's pictures: the base layer's plan (same POCs, same decoding order, same short-term reference picture
+    sets) with one more active reference - the inter-layer reference picture, the resampled base-layer picture of the same access unit
+    (list order: ST_CURR_BEF, inter-layer, ST_CURR_AFT for L0; ST_CURR_AFT, ST_CURR_BEF, inter-layer for L1 - ff_hevc_slice_rpl,
+    hevc_refs.c:443-449).  Intra base-layer pictures become P pictures predicted from the inter-layer picture alone (an IRAP with P
+    slices is what decoder_id > 0 admits, hevc.c:712)."""
+    out = []
+    for pic in pics:
+        used = sum(u for _, u in pic.rps_neg) + sum(u for _, u in pic.rps_pos)
+        if pic.slice_type == SLICE_I:
+            out.append(Pic(pic.poc, pic.nal_type, SLICE_P, pic.rps_neg, pic.rps_pos, (1 if pic.nal_type in (19, 20, 21) else used + 1, 0)))
+        else:
+            n = used + 1
+            out.append(Pic(pic.poc, pic.nal_type, pic.slice_type, pic.rps_neg, pic.rps_pos, (n, n if pic.slice_type == SLICE_B else 0)))
+    return out
+
+
+def shvc_headers(pb: StreamParams, pe: StreamParams, phase_align: int = 0) -> bytes:
+    """VPS with its extension, base-layer SPS 0 / PPS 0, enhancement-layer SPS 1 / PPS 1 (nuh_layer_id 1).  The enhancement-layer decoder
+    looks the base layer's SPS up as sps_list[decoder_id - 1] (hevc.c:453): SPS 0 must be the base layer's."""
+    return (write_vps(pb, pe, phase_align) + write_sps(pb) + write_pps(pb) + write_sps(pe, layer=1, sps_id=1)
+            + write_pps(pe, layer=1, pps_id=1, sps_id=1))
+
+
+def generate_shvc(pb: StreamParams, pe: StreamParams, phase_align: int = 0):
+    """A two-layer (spatially scalable) stream: returns (access units, base-layer pictures, enhancement-layer pictures) - the pictures as
+    the generator's own two decoders reconstructed them, in output order.  Every access unit holds the base-layer slices (nuh_layer_id 0)
+    and the enhancement-layer slices (nuh_layer_id 1) of one picture; two decoders opened the way openHevcWrapper.c does take them
+    (decode_stream_shvc).  Vectors into the inter-layer reference picture are zero (oracle/synth_gen.c: ohsyn_mvd_coding)."""
+    assert pe.bit_depth == pb.bit_depth == 8 and pe.chroma_format == pb.chroma_format == 1, "the reference's rep_format path: 8-bit 4:2:0"
+    assert not pe.tmvp, "enhancement layer: no temporal motion vector prediction (the motion field of the inter-layer picture is filled CTB by CTB on demand)"
+    L = _load("gen")
+    rng = np.random.default_rng(pb.seed)
+    L.ohsyn_reset(pb.seed)
+    headers = shvc_headers(pb, pe, phase_align)
+    aus, frames_bl, frames_el = [], [], []
+    gen_bl = Decoder("gen")
+    gen_el = Decoder("gen", decoder_id=1, base=gen_bl)
+    gen_bl.set_active_layer(1)
+    try:
+        plan_bl = plan_gop(pb)
+        plan_el = enhancement_plan(plan_bl)
+        for i, (pic_b, pic_e) in enumerate(zip(plan_bl, plan_el)):
+            pre = headers if i == 0 else b""
+            _set_probs(L, pb)
+            out_b, f = _generate_picture(L, gen_bl, pb, pic_b, rng, i + 1, pre)
+            if f is not None:
+                frames_bl.append(f)
+            _set_probs(L, pe)
+            gen_el.take_base(gen_bl)
+            out_e, f = _generate_picture(L, gen_el, pe, pic_e, rng, i + 1, pre, layer=1, pps_id=1)
+            if f is not None:
+                frames_el.append(f)
+            aus.append(pre + out_b + out_e)
+        frames_bl += gen_bl.flush()
+        frames_el += gen_el.flush()
+    finally:
+        gen_el.close()
+        gen_bl.close()
+    return aus, frames_bl, frames_el
+
+
+def decode_stream_shvc(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1):
+    """Both layers of a two-layer stream, the way libOpenHevcDecode drives its two decoders (openHevcWrapper.c:110-156): every access unit
+    goes to the base-layer decoder, then - with the base-layer picture handed over - to the enhancement-layer decoder.  Returns
+    (base-layer pictures, enhancement-layer pictures) in output order."""
+    out_b, out_e = [], []
+    bl = Decoder(kind, threads, thread_type)
+    el = Decoder(kind, threads, thread_type, decoder_id=1, base=bl)
+    bl.set_active_layer(1)
+    try:
+        for i, au in enumerate(aus):
+            f = bl.decode(au, i + 1)
+            if f is not None:
+                out_b.append(f)
+            el.take_base(bl)
+            f = el.decode(au, i + 1)
+            if f is not None:
+                out_e.append(f)
+        out_b += bl.flush()
+        out_e += el.flush()
+    finally:
+        el.close()
+        bl.close()
+    return out_b, out_e
 
 
 def md5_sei_nal(planes) -> bytes:

@@ -183,6 +183,8 @@ static struct {
     uint8_t  scratch[2 * 64 * 64 * 2 + 64];  /* raw pcm bytes of one CU (the reference reads them through a pointer) */
     uint64_t nbins, nbypass;
     int      error;
+    int      last_ref_idx;              /* SHVC: the ref_idx_lX parsed in front of the mvd_coding() in progress */
+    int      zero_mvd;                  /* SHVC: abs_mvd_greater0_flag bins are 0 (vector into the inter-layer reference picture) */
 } G;
 
 static uint32_t rnd16(void)
@@ -288,6 +290,8 @@ int ohsyn_bin(CABACContext *c, uint8_t *state)
     HEVCLocalContext *lc = (HEVCLocalContext *)((uint8_t *)c - offsetof(HEVCLocalContext, cc));
     ptrdiff_t idx = state - lc->cabac_state;
     int bin = rnd16() < ((idx >= 0 && idx < HEVC_CONTEXTS) ? G.prob[idx] : 32768u);
+    if (G.zero_mvd)                 /* the only context-coded bins of mvd_coding() that matter: abs_mvd_greater0_flag[0..1] (hevc_cabac.c:898-900) */
+        bin = 0;
     enc_decision(&G.enc, cur_sink(), state, bin);
     G.flushed = 0;
     G.nbins++;
@@ -373,4 +377,24 @@ int ohsyn_pcm_flag(HEVCContext *s)
         G.flushed = 0;
     }
     return bin;
+}
+
+/* ---- SHVC: ref_idx_lX and mvd_coding() (hevc.c:2027-2060).  In an enhancement-layer slice a prediction unit that names the inter-layer
+ *      reference picture gets a zero motion vector difference; its predictor is zero already (every vector into that picture is, and a
+ *      candidate never crosses from a short-term to a long-term reference: hevc_mvs.c) ---- */
+int ohsyn_ref_idx_lx(HEVCContext *s, int num_ref_idx_lx)
+{
+    G.last_ref_idx = ff_hevc_ref_idx_lx_decode(s, num_ref_idx_lx);
+    return G.last_ref_idx;
+}
+
+void ohsyn_mvd_coding(HEVCContext *s, int x0, int y0, int log2_cb_size /* the reference passes the list here */)
+{
+    int lx = log2_cb_size;
+    if (s->nuh_layer_id && s->inter_layer_ref && s->ref && s->ref->refPicList[s->slice_idx] && (lx == 0 || lx == 1) &&
+        s->ref->refPicList[s->slice_idx][lx].ref[G.last_ref_idx] == s->inter_layer_ref)
+        G.zero_mvd = 1;
+    ff_hevc_hls_mvd_coding(s, x0, y0, log2_cb_size);
+    G.zero_mvd = 0;
+    G.last_ref_idx = 0;
 }

@@ -36,6 +36,11 @@ static inline const uint8_t *skip_bytes(CABACContext *c, int n) { return ohsyn_s
  * (end_of_slice_segment_flag hevc.c:2582, pcm_flag hevc.c:2415) */
 #define ff_hevc_end_of_slice_flag_decode ohsyn_end_of_slice_flag
 #define ff_hevc_pcm_flag_decode          ohsyn_pcm_flag
+/* SHVC enhancement layers: a motion vector into the inter-layer reference picture must be zero (H.265 F.8.5.3 / H.8.1.4; the reference
+ * only resamples the CTBs a ZERO vector reaches, hevc.c:2077-2099, hevc_filter.c:1377-1430).  All its predictors are zero by construction;
+ * these two wrappers make the coded difference zero as well (hevc.c:2027,2034,2046,2056). */
+#define ff_hevc_ref_idx_lx_decode        ohsyn_ref_idx_lx
+#define ff_hevc_hls_mvd_coding           ohsyn_mvd_coding
 #endif
 
 #endif /* OH_SYNTH_HOOKS_H */
