@@ -44,6 +44,11 @@ typedef struct ohhip_options {
     int test_fail_index;     /* fault injection of the multi-process tests: the owner fails on this picture (default -1; OHHIP_TEST_FAIL_INDEX) */
     int flush_intra_kib;     /* an intra picture's recorded work goes to the device at the end of a CTU row once this many KiB are waiting; 0: only at the frame end; -1 (default): by the picture's size - 0.45 bytes per luma sample, 512 .. 4096 KiB: 911 KiB at 1080p (OHHIP_FLUSH_INTRA_KIB) */
     const char *trace_path;  /* per-picture host timeline (parse start, hook start, issue end, hook end) written here at free (default OHHIP_TRACE_FRAMES) */
+    struct ohhip_backend *base_layer;   /* SHVC: this decoder is an enhancement-layer decoder (decoder-id > 0, openHevcWrapper.c:92) and names the
+                                           back end of the decoder its BL_avcontext points at (openHevcWrapper.c:107-108).  The two then share one
+                                           device picture store: the inter-layer reference picture is resampled on the device from the base-layer
+                                           picture where it lies (hevc.c:2077-2099, hevc_filter.c:1377-1430).  Free the enhancement layer's back end
+                                           before the base layer's.  (default NULL) */
 } ohhip_options;
 
 void ohhip_options_default(ohhip_options *o);

@@ -499,6 +499,10 @@ int ohhip_frame_rps(HEVCContext *s)
                 note_error(be);
                 return AVERROR(EINVAL);
             }
+            /* SHVC: the inter-layer reference picture (ff_hevc_set_new_iter_layer_ref, hevc_refs.c:149-180) has no samples yet - the first
+             * prediction unit that names it makes the up-sampling slots fill it (hevc.c:2077-2099), on the device, whole */
+            if (ref == s->inter_layer_ref)
+                continue;
             for (c = 0; c < 3; c++)
                 if (ref->frame->data[c] && ohevc_pic_upload(ctx, slot, c, ref->frame->data[c], ref->frame->linesize[c]) != OHEVC_OK) {
                     fprintf(stderr, "ohhip: upload of a generated reference picture failed: %s\n", ohevc_last_error());
@@ -797,7 +801,17 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
     ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 0);
     if (getenv("OHHIP_DEVICE_FILTERS"))
         ohevc_debug_set_filters_on_device(atoi(getenv("OHHIP_DEVICE_FILTERS")));
-    if (ohevc_ctx_create(&be->root, o->device) != OHEVC_OK) {
+    if (o->base_layer && (o->base_layer->magic != OHHIP_MAGIC || !o->base_layer->root)) {
+        fprintf(stderr, "ohhip: base_layer does not name a live back end\n");
+        pthread_mutex_destroy(&be->lock);
+        free(be);
+        return NULL;
+    }
+    if (o->base_layer)
+        be->opt.device = o->base_layer->opt.device;
+    /* SHVC: the enhancement layer's contexts use the base layer's picture store (and, through it, its table-level picture registry:
+     * the up-sampling slots find the base-layer picture by its host address) */
+    if ((o->base_layer ? ohevc_ctx_create_shared(&be->root, be->opt.device, o->base_layer->root) : ohevc_ctx_create(&be->root, o->device)) != OHEVC_OK) {
         fprintf(stderr, "ohhip: ctx_create failed: %s\n", ohevc_last_error());
         pthread_mutex_destroy(&be->lock);
         free(be);
@@ -877,8 +891,22 @@ static ohhip_backend *default_backend(void)
 /* before the decoder frees its frame buffers (avcodec_close): their page locks go first */
 void ohhip_backend_pre_close(ohhip_backend *be)
 {
-    if (be && be->root)
+    int i, k;
+    if (!be || !be->root)
+        return;
+    if (!be->opt.base_layer) {
         ohevc_host_unpin_all(be->root);
+        return;
+    }
+    /* SHVC enhancement layer: the store is the base layer's too, whose decoder may still be decoding - only this decoder's buffers */
+    pthread_mutex_lock(&be->lock);
+    for (i = 0; i < be->nbufs; i++)
+        for (k = 0; k < 3; k++)
+            if (be->bufs[i].pin_ptr[k]) {
+                ohevc_host_unpin(be->root, be->bufs[i].pin_ptr[k], be->bufs[i].pin_bytes[k]);
+                be->bufs[i].pin_ptr[k] = NULL;
+            }
+    pthread_mutex_unlock(&be->lock);
 }
 
 /* after the decoder (and its threads) are gone */
@@ -908,6 +936,11 @@ void ohhip_backend_free(ohhip_backend *be)
         }
     }
     free(be->trace);
+    if (be->opt.base_layer && be->root)         /* the store outlives this back end: give its pictures back */
+        for (i = 0; i < be->nbufs; i++) {
+            ohevc_tables_unregister_picture(be->root, be->bufs[i].slot);
+            ohevc_pic_release(be->root, be->bufs[i].slot);
+        }
     for (i = 0; i < be->nall; i++)
         ohevc_ctx_destroy(be->all[i]);
     if (be->root)
@@ -1207,7 +1240,32 @@ int ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const 
  * this no-op.  (The waits for collocated motion vectors in hevc_mvs.c are untouched.) */
 void ohhip_await_progress(ThreadFrame *f, int progress, int field)
 {
-    (void)f; (void)progress; (void)field;
+    /* SHVC: the one wait that is about HOST data - the enhancement layer scales the base-layer picture's motion field into the inter-layer
+     * picture's (ff_upscale_mv_block, hevc_filter.c:1312-1375) once the base-layer decoder's thread has parsed those rows
+     * (hevc_await_progress_bl, hevc.c:1959-1966) */
+    if (t_s && t_s->BL_frame && f == &t_s->BL_frame->tf)
+        ff_thread_await_progress(f, progress, field);
+}
+
+/* SHVC, quality (SNR) scalability: at ratio 1 ff_upsample_block (hevc_filter.c:1377-1430; call sites hevc.c:2082,2097) copies the base-layer
+ * CTB into the inter-layer reference picture with memcpy (copy_block, hevc_filter.c:1165-1173,1189-1192,1262-1266) - no table slot is called,
+ * so the device picture would stay empty.  The wrapper lets the reference do its host work (the motion field of the inter-layer picture) and,
+ * at ratio 1, resamples the picture on the device once: the general filter at phase 0 is the identity ({0,0,0,64,0,0,0,0}, 64 * 64 * x + 2048 >> 12). */
+void ohhip_upsample_block(HEVCContext *s, HEVCFrame *ref0, int x0, int y0, int nPbW, int nPbH)
+{
+    ff_upsample_block(s, ref0, x0, y0, nPbW, nPbH);
+    if (s->up_filter_inf.idx == SNR && s->BL_frame && ref0 && ref0->frame && t_frame_open) {
+        ohevc_UpsamplInf u;
+        const HEVCWindow *w = &s->sps->scaled_ref_layer_window[s->vps->m_refLayerId[s->nuh_layer_id][0]];
+        ohevc_HEVCWindow win = { w->left_offset, w->right_offset, w->top_offset, w->bottom_offset };
+        u.addXLum = s->up_filter_inf.addXLum; u.addYLum = s->up_filter_inf.addYLum;
+        u.scaleXLum = s->up_filter_inf.scaleXLum; u.scaleYLum = s->up_filter_inf.scaleYLum;
+        u.addXCr = s->up_filter_inf.addXCr; u.addYCr = s->up_filter_inf.addYCr;
+        u.scaleXCr = s->up_filter_inf.scaleXCr; u.scaleYCr = s->up_filter_inf.scaleYCr;
+        u.idx = DEFAULT;
+        if (ohevc_tables_upsample_frame(ref0->frame->data[0], s->BL_frame->frame->data[0], &win, &u) != OHEVC_OK)
+            note_error(backend_of(s->avctx));
+    }
 }
 
 /* ---- process-wide profiling (all instances) ---- */

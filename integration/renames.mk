@@ -15,6 +15,7 @@
 #   ff_hevc_log2_res_scale_abs / _res_scale_sign_flag     ohhip_*                      section 2b: cross-component prediction
 #   ff_hevc_hls_filters / ff_hevc_hls_filter              ohhip_hls_filter(s)          section 3: filter drivers in bulk
 #   ff_hevc_deblocking_boundary_strengths (hevc.c:1578,1607,2400,2484)  ohhip_deblocking_boundary_strengths   section 3: boundary strengths on the device
+#   ff_upsample_block        (hevc.c:2082,2097)           ohhip_upsample_block         section 2b: SHVC at ratio 1 (the reference copies with memcpy)
 HIPRENAMES := -Dff_hevc_dsp_init=ohhip_hevc_dsp_init -Dff_hevc_pred_init=ohhip_hevc_pred_init \
               -Dff_videodsp_init=ohhip_videodsp_init -Dff_hevc_set_new_ref=ohhip_set_new_ref \
               -Dff_hevc_frame_rps=ohhip_frame_rps -Dav_pix_fmt_desc_get=ohhip_pix_fmt_desc_get \
@@ -22,4 +23,5 @@ HIPRENAMES := -Dff_hevc_dsp_init=ohhip_hevc_dsp_init -Dff_hevc_pred_init=ohhip_h
               -Dff_hevc_cabac_init=ohhip_cabac_init -Dff_hevc_log2_res_scale_abs=ohhip_log2_res_scale_abs \
               -Dff_hevc_res_scale_sign_flag=ohhip_res_scale_sign_flag \
               -Dff_hevc_hls_filters=ohhip_hls_filters -Dff_hevc_hls_filter=ohhip_hls_filter \
-              -Dff_hevc_deblocking_boundary_strengths=ohhip_deblocking_boundary_strengths
+              -Dff_hevc_deblocking_boundary_strengths=ohhip_deblocking_boundary_strengths \
+              -Dff_upsample_block=ohhip_upsample_block

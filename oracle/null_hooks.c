@@ -45,6 +45,7 @@ int  ohhip_log2_res_scale_abs(HEVCContext *s, int idx) { return ff_hevc_log2_res
 int  ohhip_res_scale_sign_flag(HEVCContext *s, int idx) { return ff_hevc_res_scale_sign_flag(s, idx); }
 void ohhip_hls_filter(HEVCContext *s, int x, int y, int ctb_size) { ff_hevc_hls_filter(s, x, y, ctb_size); }
 void ohhip_hls_filters(HEVCContext *s, int x, int y, int ctb_size) { ff_hevc_hls_filters(s, x, y, ctb_size); }
+void ohhip_upsample_block(HEVCContext *s, HEVCFrame *ref0, int x0, int y0, int nPbW, int nPbH) { ff_upsample_block(s, ref0, x0, y0, nPbW, nPbH); }
 
 #ifndef OHNULL_NO_BS
 /* The tap that pins oracle/hevc_oracle.c's ohor_boundary_strengths (tests/test_oracle_vs_reference.py): with it on, every call of
