@@ -953,7 +953,6 @@ def generate_shvc(pb: StreamParams, pe: StreamParams, phase_align: int = 0):
     and the enhancement-layer slices (nuh_layer_id 1) of one picture; two decoders opened the way openHevcWrapper.c does take them
     (decode_stream_shvc).  Vectors into the inter-layer reference picture are zero (oracle/synth_gen.c: ohsyn_mvd_coding)."""
     assert pe.bit_depth == pb.bit_depth == 8 and pe.chroma_format == pb.chroma_format == 1, "the reference's rep_format path: 8-bit 4:2:0"
-    assert not pe.tmvp, "enhancement layer: no temporal motion vector prediction (the motion field of the inter-layer picture is filled CTB by CTB on demand)"
     L = _load("gen")
     rng = np.random.default_rng(pb.seed)
     L.ohsyn_reset(pb.seed)
