@@ -266,6 +266,11 @@ struct ohevc_ctx : Rec {
     hipEvent_t dl_ring[8] = {};
     int dl_next = 0;
     DevBuf d_jobs[2], d_coeffs, d_table, d_upsample;
+    // SHVC: the tap maps in d_upsample belong to these parameters (a stream resamples every picture with the same ones: one upload per geometry)
+    ohevc_upsample_params up_prm = {};
+    bool up_valid = false;
+    size_t up_off_cols[3] = {}, up_off_colof[3] = {}, up_off_rows[3] = {};
+    int up_src_cols[3] = {}, up_src_rows[3] = {};
     PinnedBuf stage[2], table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
@@ -782,40 +787,43 @@ extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, cons
         d->readers.clear();
         d->end_issued = false;
     }
-    // maps of the three planes, one upload
-    std::vector<unsigned char> host;
-    size_t off_cols[3], off_colof[3], off_rows[3];
-    int src_cols[3], src_rows[3];
-    for (int pl = 0; pl < 3; pl++) {
-        const int w = d->planes[pl].width, h = d->planes[pl].height;
-        auto put = [&](size_t bytes) { size_t o = (host.size() + 15) & ~(size_t)15; host.resize(o + bytes); return o; };
-        off_cols[pl] = put((size_t)w * sizeof(ohevc_upsample_tap));
-        off_colof[pl] = put((size_t)w * sizeof(int16_t));
-        off_rows[pl] = put((size_t)h * sizeof(ohevc_upsample_tap));
+    // maps of the three planes, one upload per geometry (the parameters of a layer pair do not change inside a stream)
+    if (!c->up_valid || memcmp(&c->up_prm, prm, sizeof(*prm)) != 0) {
+        std::vector<unsigned char> host;
+        c->up_valid = false;
+        for (int pl = 0; pl < 3; pl++) {
+            const int w = d->planes[pl].width, h = d->planes[pl].height;
+            auto put = [&](size_t bytes) { size_t o = (host.size() + 15) & ~(size_t)15; host.resize(o + bytes); return o; };
+            c->up_off_cols[pl] = put((size_t)w * sizeof(ohevc_upsample_tap));
+            c->up_off_colof[pl] = put((size_t)w * sizeof(int16_t));
+            c->up_off_rows[pl] = put((size_t)h * sizeof(ohevc_upsample_tap));
+        }
+        for (int pl = 0; pl < 3; pl++) {
+            int rc = ohevc_upsample_make_maps(prm, pl, reinterpret_cast<ohevc_upsample_tap *>(host.data() + c->up_off_cols[pl]),
+                                              reinterpret_cast<int16_t *>(host.data() + c->up_off_colof[pl]),
+                                              reinterpret_cast<ohevc_upsample_tap *>(host.data() + c->up_off_rows[pl]), &c->up_src_cols[pl], &c->up_src_rows[pl]);
+            if (rc != OHEVC_OK) return rc;
+        }
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));   // launches of the previous geometry may still read the old maps
+        if (host.size() > c->d_upsample.cap) {
+            int rc = c->d_upsample.reserve(host.size());
+            if (rc != OHEVC_OK) return rc;
+        }
+        OHEVC_HIP_TRY(hipMemcpyAsync(c->d_upsample.p, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
+        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));   // `host` (pageable) must outlive the copy; once per geometry
+        c->up_prm = *prm;
+        c->up_valid = true;
     }
-    for (int pl = 0; pl < 3; pl++) {
-        int rc = ohevc_upsample_make_maps(prm, pl, reinterpret_cast<ohevc_upsample_tap *>(host.data() + off_cols[pl]),
-                                          reinterpret_cast<int16_t *>(host.data() + off_colof[pl]),
-                                          reinterpret_cast<ohevc_upsample_tap *>(host.data() + off_rows[pl]), &src_cols[pl], &src_rows[pl]);
-        if (rc != OHEVC_OK) return rc;
-    }
-    if (host.size() > c->d_upsample.cap) {
-        OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-        int rc = c->d_upsample.reserve(host.size());
-        if (rc != OHEVC_OK) return rc;
-    }
-    OHEVC_HIP_TRY(hipMemcpyAsync(c->d_upsample.p, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
     unsigned char *base = static_cast<unsigned char *>(c->d_upsample.p);
     for (int pl = 0; pl < 3; pl++) {
-        int rc = ohevc_dev_upsample_plane(&d->planes[pl], &sp->planes[pl], d->bd, pl != 0, reinterpret_cast<const ohevc_upsample_tap *>(base + off_cols[pl]),
-                                          reinterpret_cast<const int16_t *>(base + off_colof[pl]),
-                                          reinterpret_cast<const ohevc_upsample_tap *>(base + off_rows[pl]), src_cols[pl], src_rows[pl], c->stream);
+        int rc = ohevc_dev_upsample_plane(&d->planes[pl], &sp->planes[pl], d->bd, pl != 0, reinterpret_cast<const ohevc_upsample_tap *>(base + c->up_off_cols[pl]),
+                                          reinterpret_cast<const int16_t *>(base + c->up_off_colof[pl]),
+                                          reinterpret_cast<const ohevc_upsample_tap *>(base + c->up_off_rows[pl]), c->up_src_cols[pl], c->up_src_rows[pl], c->stream);
         if (rc != OHEVC_OK) return rc;
     }
     hipEvent_t ev = c->ring[c->ring_next];
     c->ring_next = (c->ring_next + 1) % 16;
-    OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));
-    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));       // `host` (pageable) must outlive the copy; a once-per-picture operation
+    OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));         // (no host wait: the parsing thread goes on, the picture's own launches queue behind)
     {
         std::lock_guard<std::mutex> g(c->store->m);
         d->written = ev;

@@ -117,6 +117,10 @@ ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, 
     av_opt_set(d->avctx, "thread_type", thread_type == 2 ? "slice" : thread_type >= 3 ? "frameslice" : "frame", 0);
     d->threads = threads > 0 ? threads : 1;
     av_opt_set_int(d->avctx, "threads", d->threads, 0);
+    if (getenv("OHDEC_DEBUG_THREADS")) {                                         /* the reference's own thread-synchronisation log lines */
+        d->avctx->debug |= FF_DEBUG_THREADS;
+        av_log_set_level(AV_LOG_DEBUG);
+    }
     av_opt_set_int(d->avctx->priv_data, "decoder-id", decoder_id, 0);          /* openHevcWrapper.c:92 */
     d->avctx->quality_id = base || decoder_id ? 1 : 0;                          /* the wrapper's active_layer (openHevcWrapper.c:120) */
     if (checksum) {
