@@ -236,6 +236,16 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
     out["cpu_baseline_note"] = ("reference_sse_* = the reference decoder as shipped on x86 (ARCH_X86 1, SSE2..SSE4.2 intrinsics wired in by libavcodec/x86/hevcdsp_init.c "
                                 "and hevcpred_init.c, inline-assembly CABAC), built by oracle/Makefile from the sources in place; its deblocking runs as C (no yasm in "
                                 "the image: oracle/sse_stubs.c); reference_c_* = the same sources with ARCH_X86 0")
+    # SHVC: a two-layer stream, base layer 960x544 and enhancement layer 1920x1088 (x2), both layers through the reference's
+    # pair of decoders (openHevcWrapper.c:47-156) - its C tables, the reference as shipped on x86, the gfx950 back end (tools/bench_shvc.py)
+    if not hip_only:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_shvc
+            out["shvc"] = bench_shvc.run((1920, 1088), 17, 3, ("c", "sse", "hip"))
+            out["bit_exact"] = bool(out["bit_exact"] and all(v["exact"] for v in out["shvc"].values() if isinstance(v, dict)))
+        except Exception as e:                       # noqa: BLE001  (the rows above stay valid)
+            out["shvc"] = {"error": f"{type(e).__name__}: {e}"}
     out["floor"] = ("device_floor_ms = algorithmic HBM bytes of the picture's jobs (SURVEY 8d per-unit figures, summed by the recorder) / 8 TB/s; "
                     "pcie_floor_ms = (job upload + plane copy-back) / 64 GB/s; floor_frac = their sum / the frame-end hook's wall time")
     return out

@@ -981,17 +981,25 @@ def generate_shvc(pb: StreamParams, pe: StreamParams, phase_align: int = 0):
     finally:
         gen_el.close()
         gen_bl.close()
+    if pb.md5_sei:
+        # one decoded-picture-hash SEI per layer and access unit (nuh_layer_id 0 / 1: each decoder takes its own, hevc.c:3303); pictures come
+        # out in increasing POC order, access unit i carries the pictures of pocs[i]
+        pocs = [pic.poc for pic in plan_bl]
+        rank = {poc: k for k, poc in enumerate(sorted(pocs))}
+        assert len(frames_bl) == len(frames_el) == len(pocs)
+        aus = [au + md5_sei_nal(frames_bl[rank[poc]]) + md5_sei_nal(frames_el[rank[poc]], layer=1) for au, poc in zip(aus, pocs)]
     return aus, frames_bl, frames_el
 
 
-def decode_stream_shvc(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1):
+def decode_stream_shvc(kind: str, aus: Sequence[bytes], threads: int = 1, thread_type: int = 1, checksum: bool = False):
     """Both layers of a two-layer stream, the way libOpenHevcDecode drives its two decoders (openHevcWrapper.c:110-156): every access unit
     goes to the base-layer decoder, then - with the base-layer picture handed over - to the enhancement-layer decoder.  Returns
     (base-layer pictures, enhancement-layer pictures) in output order."""
     out_b, out_e = [], []
-    bl = Decoder(kind, threads, thread_type)
-    el = Decoder(kind, threads, thread_type, decoder_id=1, base=bl)
+    bl = Decoder(kind, threads, thread_type, checksum)
+    el = Decoder(kind, threads, thread_type, checksum, decoder_id=1, base=bl)
     bl.set_active_layer(1)
+    res = None
     try:
         for i, au in enumerate(aus):
             f = bl.decode(au, i + 1)
@@ -1003,13 +1011,14 @@ def decode_stream_shvc(kind: str, aus: Sequence[bytes], threads: int = 1, thread
                 out_e.append(f)
         out_b += bl.flush()
         out_e += el.flush()
+        res = el.md5_results() if checksum else None      # (the counters are the library's: both decoders' checks)
     finally:
         el.close()
         bl.close()
-    return out_b, out_e
+    return (out_b, out_e, res) if checksum else (out_b, out_e)
 
 
-def md5_sei_nal(planes) -> bytes:
+def md5_sei_nal(planes, layer: int = 0) -> bytes:
     """Suffix SEI, payload type 132 (decoded picture hash, D.2.19), hash_type 0: one MD5 per colour plane over the samples in raster
     order, 16-bit samples little-endian -- parsed by decode_nal_sei_decoded_picture_hash (hevc_sei.c:28-45), checked against
     calc_md5 of the decoded planes in hevc_decode_frame (hevc.c:4146-4162, :4623-4637)."""
@@ -1018,7 +1027,7 @@ def md5_sei_nal(planes) -> bytes:
     for pl in planes:
         body += hashlib.md5(np.ascontiguousarray(pl).astype("<u2" if pl.dtype.itemsize == 2 else np.uint8).tobytes()).digest()
     rbsp = bytes([132, len(body)]) + body + b"\x80"
-    return nal(NAL_SEI_SUFFIX, rbsp)
+    return nal(NAL_SEI_SUFFIX, rbsp, layer=layer)
 
 
 def _escaped_sizes(header: bytes, payload: bytes, starts: List[int]) -> List[int]:

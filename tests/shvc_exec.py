@@ -47,3 +47,14 @@ def open_close_layer_pairs(kind, product, rounds=8):
         bl.close()
     live = product.ohhip_backend_live_count() if hasattr(product, "ohhip_backend_live_count") else 0
     assert live == 0, f"{live} back ends alive after closing every decoder"
+
+
+def check_reference_md5_verdict(kind):
+    """A two-layer stream with a decoded-picture-hash SEI per layer and access unit: the reference's own verification (`decode-checksum`,
+    hevc.c:4146-4162) must say "Correct MD5" for every plane of both layers - with the gfx950 back end, for pictures it never computed."""
+    pb = ps.StreamParams(width=128, height=96, gop="random_access", nframes=6, gop_size=4, seed=41, md5_sei=1)
+    pe = ps.StreamParams(width=256, height=192, gop="random_access", nframes=6, gop_size=4, seed=41, tmvp=1)
+    aus, _, _ = ps.generate_shvc(pb, pe)
+    bl, el, (ok, bad) = ps.decode_stream_shvc(kind, aus, checksum=True)
+    assert len(bl) == 6 and len(el) == 6
+    assert (ok, bad) == (36, 0), f"'{kind}': {ok} planes verified, {bad} rejected by the reference's MD5 check (36 / 0 expected)"

@@ -18,7 +18,7 @@ import pytest
 from oracle import pystream as ps
 from oracle import pyoracle as po
 from shvc_cases import SHVC_CASES
-from shvc_exec import check_both_layers, load_shvc, open_close_layer_pairs
+from shvc_exec import check_both_layers, check_reference_md5_verdict, load_shvc, open_close_layer_pairs
 
 ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so")
 needs_c = pytest.mark.skipif(not ps.have("c"), reason="oracle/_ref/libopenhevc_c.so not built (needs /root/reference)")
@@ -77,6 +77,11 @@ def test_skipped_enhancement_layer_is_the_resampled_base_layer(geom):
         assert np.array_equal(want[pl], el[0][pl]), f"plane {pl}: {int(np.count_nonzero(want[pl] != el[0][pl]))} samples differ"
 
 
+@needs_gen
+def test_shvc_reference_md5_check_on_both_layers():
+    check_reference_md5_verdict("c")
+
+
 # ---------------------------------------------------------------- the hooked decoder over the emulated device code
 def _emu():
     import subprocess
@@ -103,3 +108,10 @@ def test_emu_shvc_slice_threads():
 def test_emu_shvc_decoder_pairs_leave_nothing_behind():
     _emu()
     open_close_layer_pairs("hipemu", ps._load("hipemu"))
+
+
+def test_emu_shvc_reference_md5_check_on_both_layers():
+    _emu()
+    if not ps.have("gen"):
+        pytest.skip("the stream is generated on the spot: needs oracle/_ref/libopenhevc_gen.so")
+    check_reference_md5_verdict("hipemu")

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import pystream as ps
 from shvc_cases import SHVC_CASES
-from shvc_exec import check_both_layers, load_shvc, open_close_layer_pairs
+from shvc_exec import check_both_layers, check_reference_md5_verdict, load_shvc, open_close_layer_pairs
 
 pytestmark = pytest.mark.gpu
 
@@ -39,3 +39,8 @@ def test_shvc_deferred_copy_back(name, monkeypatch):
 
 def test_shvc_decoder_pairs_leave_nothing_behind():
     open_close_layer_pairs("hip", ps._load("hip"))
+
+
+def test_shvc_reference_md5_check_on_both_layers():
+    assert ps.have("gen"), "oracle/_ref/libopenhevc_gen.so missing (the stream is generated on the spot)"
+    check_reference_md5_verdict("hip")

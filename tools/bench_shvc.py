@@ -53,6 +53,36 @@ def timed(kind, aus, passes, repeat=2):
     return best, out
 
 
+def run(size=(1920, 1088), frames=17, passes=3, kinds=("c", "sse", "hip"), dense=False):
+    ew, eh = size
+    assert ew % 16 == 0 and eh % 16 == 0, "the enhancement layer's size must be a multiple of 16 (the base layer's of 8)"
+    stats = ps.DENSE_QP22 if dense else NATURAL
+    common = dict(gop="random_access", nframes=frames, gop_size=8, seed=7, log2_ctb=6)
+    pb = ps.StreamParams(width=ew // 2, height=eh // 2, **common, **stats)
+    pe = ps.StreamParams(width=ew, height=eh, tmvp=1, **common, **stats)
+    t = time.perf_counter()
+    aus, gen_bl, gen_el = ps.generate_shvc(pb, pe)
+    tgen = time.perf_counter() - t
+    res = dict(workload=f"synthetic two-layer random-access stream, base layer {ew // 2}x{eh // 2}, enhancement layer {ew}x{eh} (x2), 8 bit, {frames} access units x "
+                        f"{passes} passes, {sum(map(len, aus)) // len(aus)} bytes / access unit ({'qp22-like density' if dense else 'encoder-like CU statistics'})",
+               generate_s=round(tgen, 1), unit="access units/s (one decoding thread per layer; the enhancement layer's pictures per second)")
+    ref = None
+    for kind in kinds:
+        if not ps.have(kind):
+            res[kind] = None
+            continue
+        bl, el = ps.decode_stream_shvc(kind, aus)
+        if ref is None:
+            ref = (bl, el)
+            want = (gen_bl, gen_el)           # the first decoder is checked against the generator's own reconstruction, the others against the first
+        else:
+            want = ref
+        exact = all(len(got) == len(w) and all(np.array_equal(x, y) for fa, fb in zip(got, w) for x, y in zip(fa, fb)) for got, w in ((bl, want[0]), (el, want[1])))
+        dt, n = timed(kind, aus, passes)
+        res[kind] = dict(aus_per_s=round(len(aus) * passes / dt, 2), pictures=n, exact=bool(exact))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1088")
@@ -61,32 +91,7 @@ def main():
     ap.add_argument("--kinds", default="c,sse,hip")
     ap.add_argument("--dense", action="store_true", help="qp22-like residual density in both layers instead of the encoder-like statistics")
     a = ap.parse_args()
-    ew, eh = map(int, a.size.split("x"))
-    assert ew % 16 == 0 and eh % 16 == 0, "the enhancement layer's size must be a multiple of 16 (the base layer's of 8)"
-    stats = ps.DENSE_QP22 if a.dense else NATURAL
-    common = dict(gop="random_access", nframes=a.frames, gop_size=8, seed=7, log2_ctb=6)
-    pb = ps.StreamParams(width=ew // 2, height=eh // 2, **common, **stats)
-    pe = ps.StreamParams(width=ew, height=eh, tmvp=1, **common, **stats)
-    t = time.perf_counter()
-    aus, gen_bl, gen_el = ps.generate_shvc(pb, pe)
-    tgen = time.perf_counter() - t
-    res = dict(workload=f"synthetic two-layer random-access stream, base layer {ew // 2}x{eh // 2}, enhancement layer {ew}x{eh} (x2), 8 bit, {a.frames} access units x "
-                        f"{a.passes} passes, {sum(map(len, aus)) // len(aus)} bytes / access unit ({'qp22-like density' if a.dense else 'encoder-like CU statistics'})",
-               generate_s=round(tgen, 1), unit="access units/s (one decoding thread per layer)")
-    ref = None
-    for kind in a.kinds.split(","):
-        if not ps.have(kind):
-            res[kind] = None
-            continue
-        bl, el = ps.decode_stream_shvc(kind, aus)
-        if ref is None:
-            ref = (bl, el)
-            exact = all(np.array_equal(x, y) for got, want in ((bl, gen_bl), (el, gen_el)) for fa, fb in zip(got, want) for x, y in zip(fa, fb))
-        else:
-            exact = all(np.array_equal(x, y) for got, want in ((bl, ref[0]), (el, ref[1])) for fa, fb in zip(got, want) for x, y in zip(fa, fb))
-        dt, n = timed(kind, aus, a.passes)
-        res[kind] = dict(aus_per_s=round(len(aus) * a.passes / dt, 2), pictures=n, exact=bool(exact))
-    print(json.dumps(res))
+    print(json.dumps(run(tuple(map(int, a.size.split("x"))), a.frames, a.passes, a.kinds.split(","), a.dense)))
 
 
 if __name__ == "__main__":
