@@ -281,6 +281,28 @@ def shvc_reference(path, mode, bd, el_planes, el_w, el_h, bl_planes, bl_w, bl_h,
     return L.ohref_shvc_blocks(C.c_int(bd), log2_ctb, C.byref(el), el_w, el_h, C.byref(bl), bl_w, bl_h, _p(win), _p(conf), _p(up), h0, h1)
 
 
+def shvc_reference_reads_outside_the_picture(path, el_w, el_h, bl_w, bl_h, phase_align=0, log2_ctb=6, seed=1):
+    """Whether the reference's CTB-by-CTB sequence (upsample_block_luma / _mc, hevc_filter.c:1175-1310) reads base-layer samples OUTSIDE the
+    picture for this pair of sizes: its source window (bPbW = ((ePbW + 1) * scaleX + addX) >> 16 columns plus at most MAX_EDGE on the right,
+    :1194-1210) is one column short for some horizontal ratios, and the 8-tap window of a CTB's last columns then reaches into the frame
+    buffer's edge - zeros, or whatever an emulated_edge_up_h call of ANOTHER CTB (possibly of an earlier picture living in that buffer) left
+    there.  The decoder's output for such a geometry depends on the order CTBs were resampled in and on the buffer's history, not on the stream
+    alone.  Found by running the sequence twice on one random picture, inside a replicated border and inside a border of zeros: returns the
+    number of samples per plane that differ."""
+    rng = np.random.default_rng(seed)
+    bl = [rng.integers(1, 256, size=(bl_h >> (c > 0), bl_w >> (c > 0))).astype(np.uint8) for c in range(3)]
+    up = shvc_params(bl_w, bl_h, el_w, el_h, (0, 0, 0, 0), phase_align=phase_align)
+    res = []
+    for mode in ("edge", "constant"):
+        big = [np.ascontiguousarray(np.pad(p, 64, mode=mode)) for p in bl]
+        blv = [b[64:-64, 64:-64] for b in big]
+        el = [np.zeros((el_h >> (c > 0), el_w >> (c > 0)), np.uint8) for c in range(3)]
+        _, view = padded_planes(el)
+        shvc_reference(path, "blocks", 8, view, el_w, el_h, blv, bl_w, bl_h, (0, 0, 0, 0), up, log2_ctb=log2_ctb)
+        res.append([v.copy() for v in view])
+    return [int(np.count_nonzero(a != b)) for a, b in zip(*res)]
+
+
 def shvc_upsample_frame(oracle_lib_path, bd, el_planes, el_w, el_h, bl_planes, bl_w, bl_h, win, up, block_slots=0):
     """our restatement (ohor_shvc_upsample_frame in liboracle.so); el_planes are modified in place"""
     L = C.CDLL(oracle_lib_path)
