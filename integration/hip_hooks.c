@@ -1258,10 +1258,11 @@ void ohhip_upsample_block(HEVCContext *s, HEVCFrame *ref0, int x0, int y0, int n
         ohevc_UpsamplInf u;
         const HEVCWindow *w = &s->sps->scaled_ref_layer_window[s->vps->m_refLayerId[s->nuh_layer_id][0]];
         ohevc_HEVCWindow win = { w->left_offset, w->right_offset, w->top_offset, w->bottom_offset };
-        u.addXLum = s->up_filter_inf.addXLum; u.addYLum = s->up_filter_inf.addYLum;
-        u.scaleXLum = s->up_filter_inf.scaleXLum; u.scaleYLum = s->up_filter_inf.scaleYLum;
-        u.addXCr = s->up_filter_inf.addXCr; u.addYCr = s->up_filter_inf.addYCr;
-        u.scaleXCr = s->up_filter_inf.scaleXCr; u.scaleYCr = s->up_filter_inf.scaleYCr;
+        /* a COPY whatever cross_layer_phase_alignment_flag says (the reference tests the scale alone, hevc.c:486-487): the offsets of phase
+         * alignment 0 (set_sps, hevc.c:476-484: the chroma row offset of a quarter sample is taken back by the "- 4" of the chroma mapping) */
+        u.scaleXLum = u.scaleYLum = u.scaleXCr = u.scaleYCr = 65536;
+        u.addXLum = u.addYLum = u.addXCr = 1 << 11;
+        u.addYCr = ((1 * 65536 + 2) >> 2) + (1 << 11);
         u.idx = DEFAULT;
         if (ohevc_tables_upsample_frame(ref0->frame->data[0], s->BL_frame->frame->data[0], &win, &u) != OHEVC_OK)
             note_error(backend_of(s->avctx));

@@ -144,10 +144,13 @@ ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, 
 #else
     (void)device;
 #endif
+    /* openHevcWrapper.c:100-108: decoder i is opened, THEN decoder i + 1's BL_avcontext is set, then decoder i + 1 is opened - i.e. before its
+     * avcodec_open2, which is what lets its frame-thread copies inherit the pointer (frame_thread_init copies the context; update_context_from_user,
+     * pthread_frame.c:262-300, does not carry this field) */
+    if (base)
+        d->avctx->BL_avcontext = base->avctx;
     if (avcodec_open2(d->avctx, codec, NULL) < 0)
         goto fail;
-    if (base)
-        d->avctx->BL_avcontext = base->avctx;                                   /* openHevcWrapper.c:107-108 */
     return d;
 fail:
     ohhip_backend_free(d->backend);

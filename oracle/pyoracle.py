@@ -281,26 +281,39 @@ def shvc_reference(path, mode, bd, el_planes, el_w, el_h, bl_planes, bl_w, bl_h,
     return L.ohref_shvc_blocks(C.c_int(bd), log2_ctb, C.byref(el), el_w, el_h, C.byref(bl), bl_w, bl_h, _p(win), _p(conf), _p(up), h0, h1)
 
 
-def shvc_reference_reads_outside_the_picture(path, el_w, el_h, bl_w, bl_h, phase_align=0, log2_ctb=6, seed=1):
-    """Whether the reference's CTB-by-CTB sequence (upsample_block_luma / _mc, hevc_filter.c:1175-1310) reads base-layer samples OUTSIDE the
-    picture for this pair of sizes: its source window (bPbW = ((ePbW + 1) * scaleX + addX) >> 16 columns plus at most MAX_EDGE on the right,
-    :1194-1210) is one column short for some horizontal ratios, and the 8-tap window of a CTB's last columns then reaches into the frame
-    buffer's edge - zeros, or whatever an emulated_edge_up_h call of ANOTHER CTB (possibly of an earlier picture living in that buffer) left
-    there.  The decoder's output for such a geometry depends on the order CTBs were resampled in and on the buffer's history, not on the stream
-    alone.  Found by running the sequence twice on one random picture, inside a replicated border and inside a border of zeros: returns the
-    number of samples per plane that differ."""
+def shvc_reference_not_a_function_of_its_inputs(path, el_w, el_h, bl_w, bl_h, phase_align=0, log2_ctb=6, seed=1):
+    """Whether the reference's CTB-by-CTB sequence (upsample_block_luma / _mc, hevc_filter.c:1175-1310) computes, for this pair of sizes, samples
+    from memory that is not the base-layer picture: it sizes a CTB's source window as ((ePb + 1 or 2) * scale + add) >> 16 columns / rows plus at
+    most MAX_EDGE / MAX_EDGE_CR more (:1194-1210, :1262-1283; the chroma window is positioned with the LUMA offsets addXLum / addYLum), and for
+    some ratios that is one column or row short of what the filter taps of the CTB's last columns / rows read.  A missing column lies in the
+    base-layer frame buffer's edge (zeros, or what emulated_edge_up_h wrote there for another CTB, possibly of an earlier picture of that
+    buffer); a missing row in the thread's scratch buffer (what the previous slot calls - of another CTB, in the decoder's on-demand order -
+    left there).  Found by running the sequence three times on one random picture: inside a replicated border and inside a border of zeros,
+    with the scratch buffer refilled with three different values in front of every plane of every CTB (oracle/shvc_driver.c).  Returns the
+    number of samples per plane that differ between the runs: the decoder's output there depends on the order CTBs were resampled in and on
+    the buffers' history, not on the stream alone."""
     rng = np.random.default_rng(seed)
     bl = [rng.integers(1, 256, size=(bl_h >> (c > 0), bl_w >> (c > 0))).astype(np.uint8) for c in range(3)]
     up = shvc_params(bl_w, bl_h, el_w, el_h, (0, 0, 0, 0), phase_align=phase_align)
     res = []
-    for mode in ("edge", "constant"):
-        big = [np.ascontiguousarray(np.pad(p, 64, mode=mode)) for p in bl]
-        blv = [b[64:-64, 64:-64] for b in big]
-        el = [np.zeros((el_h >> (c > 0), el_w >> (c > 0)), np.uint8) for c in range(3)]
-        _, view = padded_planes(el)
-        shvc_reference(path, "blocks", 8, view, el_w, el_h, blv, bl_w, bl_h, (0, 0, 0, 0), up, log2_ctb=log2_ctb)
-        res.append([v.copy() for v in view])
-    return [int(np.count_nonzero(a != b)) for a, b in zip(*res)]
+    keep = {k: os.environ.get(k) for k in ("OHREF_SHVC_POISON", "OHREF_SHVC_POISON_EACH")}
+    try:
+        for mode, poison in (("edge", "0"), ("constant", "1357"), ("edge", "-2468")):
+            os.environ["OHREF_SHVC_POISON"] = poison
+            os.environ["OHREF_SHVC_POISON_EACH"] = "2"
+            big = [np.ascontiguousarray(np.pad(p, 64, mode=mode)) for p in bl]
+            blv = [b[64:-64, 64:-64] for b in big]
+            el = [np.zeros((el_h >> (c > 0), el_w >> (c > 0)), np.uint8) for c in range(3)]
+            _, view = padded_planes(el)
+            shvc_reference(path, "blocks", 8, view, el_w, el_h, blv, bl_w, bl_h, (0, 0, 0, 0), up, log2_ctb=log2_ctb)
+            res.append([v.copy() for v in view])
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return [int(np.count_nonzero((a != b) | (b != c))) for a, b, c in zip(*res)]
 
 
 def shvc_upsample_frame(oracle_lib_path, bd, el_planes, el_w, el_h, bl_planes, bl_w, bl_h, win, up, block_slots=0):

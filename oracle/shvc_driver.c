@@ -152,6 +152,11 @@ int ohref_shvc_blocks(int bd, int log2_ctb, drv_pic *el, int el_width, int el_he
                 bl_edge_right  = MAX_EDGE_CR < (bl_width  - bl_x - bPbW) ? MAX_EDGE_CR : bl_width  - bl_x - bPbW;
                 bl_edge_bottom = MAX_EDGE_CR < (bl_height - bl_y - bPbH) ? MAX_EDGE_CR : bl_height - bl_y - bPbH;
                 for (cr = 1; cr <= 2; cr++) {
+                    /* OHREF_SHVC_POISON_EACH=2: ... and in front of each chroma plane as well.  The decoder resamples a CTB's chroma BEFORE
+                     * its luma (ff_upsample_block, hevc_filter.c:1381-1395), this driver after it: a chroma row read from scratch memory
+                     * comes from the luma pass of ANOTHER CTB there, from this CTB's here - and from the poison with this setting */
+                    if (getenv("OHREF_SHVC_POISON") && getenv("OHREF_SHVC_POISON_EACH") && atoi(getenv("OHREF_SHVC_POISON_EACH")) >= 2)
+                        for (int i = 0; i < MAX_EDGE_BUFFER_SIZE + 64; i++) edge_emu_buffer_up_v[i] = (int16_t)atoi(getenv("OHREF_SHVC_POISON"));
                     src = bl->data[cr] + (bl_y - bl_edge_top) * bl_stride + (bl_x - bl_edge_left) * ps;
                     ret = vdsp.emulated_edge_up_h(src, bl_stride, &w, bPbW + bl_edge_left + bl_edge_right, bPbH + bl_edge_top + bl_edge_bottom,
                                                   bl_edge_left, bl_edge_right, MAX_EDGE_CR - 1);

@@ -82,6 +82,25 @@ def test_shvc_reference_md5_check_on_both_layers():
     check_reference_md5_verdict("c")
 
 
+REFLIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libhevcref.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REFLIB), reason="oracle/_ref/libhevcref.so not built (needs /root/reference)")
+def test_geometries_where_the_reference_is_not_a_function_of_the_stream():
+    """The reference sizes a CTB's source window a column / a row short for some ratios (hevc_filter.c:1194-1210,1262-1283) and then filters
+    the base-layer frame buffer's edge or scratch rows other slot calls left behind.  The detector (three runs of the
+    reference's sequence: replicated / zero border, scratch refilled with different values in front of every plane of every CTB) must flag the
+    two geometries the fuzzer stumbled over, and none of the committed fixtures' - their digests are functions of the streams."""
+    assert po.shvc_reference_not_a_function_of_its_inputs(REFLIB, 264, 288, 112, 144, 1, 6)[0] > 0          # luma columns from the frame edge
+    bad = po.shvc_reference_not_a_function_of_its_inputs(REFLIB, 104, 280, 48, 152, 0, 5)
+    assert bad[0] == 0 and bad[1] > 0 and bad[2] > 0                                                        # chroma rows from the scratch buffer
+    for name, (kb, ke, pa) in SHVC_CASES.items():
+        if (kb["width"], kb["height"]) == (ke["width"], ke["height"]):
+            continue                                                                                        # ratio 1: a copy, no slot
+        assert not any(po.shvc_reference_not_a_function_of_its_inputs(REFLIB, ke["width"], ke["height"], kb["width"], kb["height"], pa,
+                                                                      ke.get("log2_ctb", 5))), name
+
+
 # ---------------------------------------------------------------- the hooked decoder over the emulated device code
 def _emu():
     import subprocess

@@ -91,9 +91,9 @@ def main():
     kinds = {}
     while time.time() - t0 < budget:
         kb, ke, pa, kind = random_layers(rng)
-        # geometries for which the reference's own CTB-by-CTB resampling reads the base-layer frame buffer's edge (oracle/pyoracle.py): its
-        # output then depends on the order CTBs were resampled in and on what the buffer held before - nothing to compare with
-        if kind == "general" and any(po.shvc_reference_reads_outside_the_picture(REFLIB, ke["width"], ke["height"], kb["width"], kb["height"], pa, ke["log2_ctb"])):
+        # geometries for which the reference's own CTB-by-CTB resampling reads the base-layer frame buffer's edge or rows of its scratch buffer it
+        # did not prepare (oracle/pyoracle.py): its output then depends on the order CTBs were resampled in and on what the buffers held before
+        if kind in ("general", "x1_5", "x2") and any(po.shvc_reference_not_a_function_of_its_inputs(REFLIB, ke["width"], ke["height"], kb["width"], kb["height"], pa, ke["log2_ctb"])):
             outside += 1
             continue
         try:
@@ -121,7 +121,7 @@ def main():
         if not ok:
             bad += 1
             print("FAIL", why, json.dumps([kb, ke, pa]), flush=True)
-    print(json.dumps(dict(backend=BACKEND, streams=n, failures=bad, rejected_by_the_synthesiser=gen_fail, reference_reads_outside_the_picture=outside, by_ratio=kinds, seconds=round(time.time() - t0, 1))))
+    print(json.dumps(dict(backend=BACKEND, streams=n, failures=bad, rejected_by_the_synthesiser=gen_fail, reference_not_a_function_of_its_inputs=outside, by_ratio=kinds, seconds=round(time.time() - t0, 1))))
 
 
 if __name__ == "__main__":
