@@ -5,7 +5,7 @@ enhancement layer's back end shares the base layer's device picture store; the i
     python tools/bench_shvc.py [--size 1920x1088] [--frames 17] [--passes 3] [--kinds c,sse,hip]
 
 --size is the ENHANCEMENT layer; the base layer is half of it in each direction.  One decoding thread per layer (the reference's frame-threaded
-two-decoder mode does not come back from the first access unit in this harness, on its own tables either).  Prints one JSON line: access units
+two-decoder mode gives run-to-run different pictures on its own tables).  Prints one JSON line: access units
 per second (= pictures per second of each layer), wall clock, entropy decoding of both layers and the copy-back of every picture included."""
 import argparse
 import json
