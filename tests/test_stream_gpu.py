@@ -186,6 +186,20 @@ def test_config5_8k_main10_on_one_gpu(threads, thread_type):
     _baseline_case(dict(gop="lowdelay_b", nframes=3, seed=3003, width=7680, height=4320, log2_ctb=6, bit_depth=10), threads, thread_type)
 
 
+@pytest.mark.parametrize("threads,thread_type", [(1, 1), (8, 1)])
+def test_config4_4k_main10_dense_residual(threads, thread_type):
+    """Config 4's geometry in the regime a real 4K Main10 stream lives in: qp22-like syntax statistics (oracle.pystream.DENSE_QP22), ~1 MB of
+    slice data and ~23 MB of job records and coefficients per picture."""
+    _baseline_case(dict(gop="lowdelay_b", nframes=3, seed=3004, width=3840, height=2160, log2_ctb=6, bit_depth=10, **ps.DENSE_QP22), threads, thread_type)
+
+
+@pytest.mark.parametrize("threads,thread_type", [(1, 1), (2, 1)])
+def test_config5_8k_main10_dense_residual_on_one_gpu(threads, thread_type):
+    """Config 5's geometry at qp22-like density: ~4 MB of slice data per 7680x4320 Main10 picture, ~100 MB uploaded per picture - the dense
+    regime at size (the sparse three-picture stream above carries 134 KB per picture)."""
+    _baseline_case(dict(gop="lowdelay_b", nframes=2, seed=3005, width=7680, height=4320, log2_ctb=6, bit_depth=10, **ps.DENSE_QP22), threads, thread_type)
+
+
 def test_missing_reference_pictures_reach_the_device():
     """generate_missing_ref (hevc_refs.c:538-598) fills HOST planes with mid-grey and makes no table call: the hooks upload such a
     picture into the device picture store (ohhip_frame_rps), so that what is predicted from it equals the untouched decoder's."""
