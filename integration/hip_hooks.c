@@ -1254,7 +1254,7 @@ void ohhip_await_progress(ThreadFrame *f, int progress, int field)
 void ohhip_upsample_block(HEVCContext *s, HEVCFrame *ref0, int x0, int y0, int nPbW, int nPbH)
 {
     ff_upsample_block(s, ref0, x0, y0, nPbW, nPbH);
-    if (s->up_filter_inf.idx == SNR && s->BL_frame && ref0 && ref0->frame && t_frame_open) {
+    if (s->up_filter_inf.idx == SNR && s->BL_frame && ref0 && ref0->frame) {      /* (also from a slice worker: ohhip_cabac_init bound it to the picture's context) */
         ohevc_UpsamplInf u;
         const HEVCWindow *w = &s->sps->scaled_ref_layer_window[s->vps->m_refLayerId[s->nuh_layer_id][0]];
         ohevc_HEVCWindow win = { w->left_offset, w->right_offset, w->top_offset, w->bottom_offset };

@@ -30,6 +30,8 @@ SHVC_CASES = {
     # ... and with cross_layer_phase_alignment_flag set: still a copy (the reference tests the scale alone, hevc.c:486-487) - the two-layer
     # fuzzer's first real find (the back end resampled with the phase offsets)
     "snr_phase": _pair(dict(gop="lowdelay_p", nframes=3, seed=18, width=136, height=88), dict(), dict(init_qp=26), 1),
+    # ratio 1 with wavefront substreams: under slice threads the copy is asked for by a row worker, not by the picture's own thread
+    "snr_wpp": _pair(dict(gop="lowdelay_b", nframes=3, seed=19, width=192, height=160, wpp=1), dict(), dict(init_qp=25)),
     # wavefront substreams in both layers
     "x2_wpp": _pair(dict(gop="lowdelay_b", nframes=4, seed=14, wpp=1), dict(width=128, height=96), dict(width=256, height=192)),
     # several slices per picture (the base layer at least as many as the enhancement layer: set_refindex_data, hevc_refs.c:373-394,

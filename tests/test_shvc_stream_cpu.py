@@ -119,9 +119,11 @@ def test_emu_shvc_both_layers(name):
     check_both_layers("hipemu", name)
 
 
-def test_emu_shvc_slice_threads():
+@pytest.mark.parametrize("name", ["x2_wpp", "snr_wpp"])
+def test_emu_shvc_slice_threads(name):
+    """The row workers of one picture record into one context; at ratio 1 it is a worker that asks for the device-side copy."""
     _emu()
-    check_both_layers("hipemu", "x2_wpp", threads=4, thread_type=2)
+    check_both_layers("hipemu", name, threads=4, thread_type=2)
 
 
 def test_emu_shvc_decoder_pairs_leave_nothing_behind():

@@ -25,8 +25,9 @@ def test_shvc_both_layers_hip_backend(name):
                     assert np.array_equal(x, y)
 
 
-def test_shvc_slice_threads_hip_backend():
-    check_both_layers("hip", "x2_wpp", threads=4, thread_type=2)
+@pytest.mark.parametrize("name", ["x2_wpp", "snr_wpp"])
+def test_shvc_slice_threads_hip_backend(name):
+    check_both_layers("hip", name, threads=4, thread_type=2)
 
 
 @pytest.mark.parametrize("name", ["x2_ra", "x1_5_dense", "snr"])
