@@ -137,7 +137,8 @@ ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, 
         ohhip_options_default(&o);
         if (device >= 0)
             o.device = device;
-        o.base_layer = base ? base->backend : NULL;
+        /* OHDEC_SHVC_SEPARATE_STORES=1 (a test): the integration mistake of two unrelated back ends - must fail loudly, not decode garbage */
+        o.base_layer = base && !getenv("OHDEC_SHVC_SEPARATE_STORES") ? base->backend : NULL;
         if (!(d->backend = ohhip_backend_new(&o)) || ohhip_backend_attach(d->backend, d->avctx) != 0)
             goto fail;
     }

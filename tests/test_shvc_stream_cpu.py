@@ -136,3 +136,12 @@ def test_emu_shvc_reference_md5_check_on_both_layers():
     if not ps.have("gen"):
         pytest.skip("the stream is generated on the spot: needs oracle/_ref/libopenhevc_gen.so")
     check_reference_md5_verdict("hipemu")
+
+
+def test_emu_shvc_two_unrelated_back_ends_fail_loudly(monkeypatch):
+    """The integration mistake: the enhancement-layer decoder's back end does not name the base layer's (two picture stores).  The resampling
+    slot call cannot find the base-layer picture: the enhancement-layer picture fails at its frame end - no CPU fallback, no garbage."""
+    _emu()
+    monkeypatch.setenv("OHDEC_SHVC_SEPARATE_STORES", "1")
+    with pytest.raises(RuntimeError, match="decode error"):
+        check_both_layers("hipemu", "x2_ldp")
