@@ -67,7 +67,7 @@ struct ohhip_backend {
     int                nspare;
     pthread_mutex_t    lock;
     volatile int       error;          /* failures seen by threads that do not own a picture (slice workers) */
-    volatile int       async_used;     /* some frame end went through the issuer: fetch_output waits for copy-backs */
+    int                async_used;     /* some frame end went through the issuer: fetch_output waits for copy-backs (several decoding threads set it: atomic accesses) */
     double             issuer_s0;
     long long          issuer_f0;
     ohhip_buf          bufs[MAX_BUFS];
@@ -789,6 +789,10 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
     }
     be->magic = OHHIP_MAGIC;
     be->opt = *o;
+    /* an asynchronous frame end queues the copy-back behind the picture's launches itself: a second, deferred one at fetch time would write
+     * the same host planes from another thread at the same moment (ThreadSanitizer pass, tools/hipemu_tsan.sh) */
+    if (be->opt.async_issue > 0)
+        be->opt.defer_download = 0;
     pthread_mutex_init(&be->lock, NULL);
     /* host-side profiling / host-logic tests without a device (include/ohevc_debug.h): record, produce no pixels.  A test may
      * have switched record-only mode on itself (and installed a frame sink) before opening the decoder: leave that alone. */
@@ -1098,7 +1102,7 @@ static int frame_done(ohhip_backend *be)
         async = 0;
     st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame2(t_ctx, !be->opt.defer_download, &t_issued);
     if (async)
-        be->async_used = 1;
+        __atomic_store_n(&be->async_used, 1, __ATOMIC_RELAXED);
     t1 = now_s();
     if (be->fm_on && t_publish && be->opt.test_fail_index >= 0 && be->opt.test_fail_index == t_publish_index)
         st = OHEVC_ERR_STATE;                   /* fault injection of tests/test_dist_cpu.py: the owner fails on this picture */
@@ -1205,7 +1209,7 @@ int ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const 
     int i, slot = -1;
     if (!be)
         be = t_be;
-    if (!be || (!be->opt.defer_download && !be->async_used) || !be->root || !data[0])
+    if (!be || (!be->opt.defer_download && !__atomic_load_n(&be->async_used, __ATOMIC_RELAXED)) || !be->root || !data[0])
         return 0;
     ctx = t_be == be && t_ctx ? t_ctx : be->root;
     pthread_mutex_lock(&be->lock);
@@ -1216,7 +1220,7 @@ int ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const 
         fprintf(stderr, "ohhip: output picture is not in the picture store\n");
         return -1;
     }
-    if (be->async_used && !be->opt.defer_download) {     /* the copy-back was queued by the issuer: wait until it has landed */
+    if (__atomic_load_n(&be->async_used, __ATOMIC_RELAXED) && !be->opt.defer_download) {     /* the copy-back was queued by the issuer: wait until it has landed */
         if (ohevc_tables_fetch_picture(ctx, slot) != OHEVC_OK || ohevc_ctx_async_status(ctx) != OHEVC_OK) {
             fprintf(stderr, "ohhip: asynchronous frame end failed: %s\n", ohevc_last_error());
             return -1;
@@ -1277,7 +1281,7 @@ void ohdec_backend_profile(double *end_frame_s, long long counts[8])
     pthread_mutex_lock(&g_reg_lock);
     pthread_mutex_lock(&g_prof_lock);
     for (b = g_backends; b; b = b->next)
-        if (b->root && b->async_used) {           /* the issuer's seconds belong to the frame ends too (they just do not block a decoding thread) */
+        if (b->root && __atomic_load_n(&b->async_used, __ATOMIC_RELAXED)) {           /* the issuer's seconds belong to the frame ends too (they just do not block a decoding thread) */
             double bs = 0;
             long long fr = 0;
             if (ohevc_ctx_async_profile(b->root, &bs, &fr) == OHEVC_OK) {

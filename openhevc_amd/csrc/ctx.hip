@@ -273,6 +273,7 @@ struct ohevc_ctx : Rec {
     int up_src_cols[3] = {}, up_src_rows[3] = {};
     PinnedBuf stage[2], table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
+    std::mutex stats_m;                    // last_stats: written by the context's own thread or, for an asynchronous frame end, by the issuer thread; read by ohevc_frame_get_stats
     double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
     // the filter maps / records of the frame end, staged by frame_end_impl BEFORE it calls ohevc_frame_reconstruct so that they travel in the
     // same host-to-device copy as the job arrays (tail_base: where they landed in that upload; SIZE_MAX: they did not travel yet)
@@ -2228,7 +2229,7 @@ static int frame_end_impl(ohevc_ctx *c)
     c->store->cv.notify_all();
     c->stats.alg_bytes = c->alg;
     c->stats.n_tu = c->nstat[0]; c->stats.n_mc = c->nstat[1]; c->stats.n_intra = c->nstat[2]; c->stats.n_dbk = c->nstat[3]; c->stats.n_sao = c->nstat[4];
-    c->last_stats = c->stats;
+    { std::lock_guard<std::mutex> g(c->stats_m); c->last_stats = c->stats; }
     return OHEVC_OK;
 }
 
@@ -2326,7 +2327,12 @@ static void issuer_run(Issuer *is)
         {
             std::lock_guard<std::mutex> lk(is->m);
             if (rc != OHEVC_OK && is->error == OHEVC_OK) { is->error = rc; snprintf(is->error_text, sizeof(is->error_text), "%s", ohevc_last_error()); }
-            if (e->async_from) e->async_from->last_stats = e->last_stats;
+            if (e->async_from) {
+                ohevc_frame_stats done;
+                { std::lock_guard<std::mutex> g(e->stats_m); done = e->last_stats; }
+                std::lock_guard<std::mutex> g(e->async_from->stats_m);
+                e->async_from->last_stats = done;
+            }
             e->exec_busy = false;
             is->executing.erase(std::find(is->executing.begin(), is->executing.end(), e));
             is->in_flight--;
@@ -2553,6 +2559,7 @@ extern "C" int ohevc_debug_wait_picture(ohevc_ctx *c, int slot)
 extern "C" int ohevc_frame_get_stats(ohevc_ctx *c, ohevc_frame_stats *out)
 {
     OHEVC_REQUIRE(c != nullptr && out != nullptr, "bad argument");
+    std::lock_guard<std::mutex> g(c->stats_m);
     *out = c->last_stats;
     return OHEVC_OK;
 }

@@ -21,7 +21,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {"c": "_ref/libopenhevc_c.so", "gen": "_ref/libopenhevc_gen.so", "hip": "_ref/libopenhevc_hip.so",
          "null": "_ref/libopenhevc_null.so", "sse": "_ref/libopenhevc_sse.so", "null_nobs": "_ref/libopenhevc_null_nobs.so", "hipemu": "_ref/libopenhevc_hipemu.so",
-         "hipemu_asan": "_ref/libopenhevc_hipemu_asan.so"}
+         "hipemu_asan": "_ref/libopenhevc_hipemu_asan.so", "hipemu_tsan": "_ref/libopenhevc_hipemu_tsan.so"}
 _loaded = {}
 
 
