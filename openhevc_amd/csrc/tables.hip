@@ -487,16 +487,23 @@ void t_up_h(int16_t *, ptrdiff_t, uint8_t *src, ptrdiff_t, int, int, int, int, i
     if (!tl_ctx || !tl_state) { fail(OHEVC_ERR_STATE); return; }
     // src = plane + (bl_y - edge_top) * stride + bl_x - edge_left (+ shift): inside the plane except for the chroma rows, whose
     // first block starts at bl_y = -1 (the "- 4" of hevc_filter.c:1268,1280) -- accept a few rows of frame padding around the plane
-    for (int i = 0; i < tl_state->npics() && tl_pend.up_bl_slot < 0; i++) {
+    auto inside = [&](int i) {
         HostPic hp;
-        if (tl_state->pics[i].slot() < 0 || !tl_state->pics[i].snapshot(hp)) continue;
+        if (tl_state->pics[i].slot() < 0 || !tl_state->pics[i].snapshot(hp)) return false;
         for (int c = 0; c < 3; c++) {
             if (!hp.data[c]) continue;
             const ptrdiff_t margin = (ptrdiff_t)8 * hp.linesize[c], off = src - (hp.data[c] - margin);
-            if (off >= 0 && (size_t)off < hp.bytes[c] + 2 * (size_t)margin) { tl_pend.up_bl_slot = hp.slot; break; }
+            if (off >= 0 && (size_t)off < hp.bytes[c] + 2 * (size_t)margin) { tl_pend.up_bl_slot = hp.slot; return true; }
         }
-    }
-    if (tl_pend.up_bl_slot < 0) fail(OHEVC_ERR_STATE);
+        return false;
+    };
+    // called three times per enhancement-layer CTB, always for the same base-layer picture: the registry entry of the last hit first
+    static thread_local int up_hint = -1;
+    const int n = tl_state->npics();
+    if (up_hint >= 0 && up_hint < n && inside(up_hint)) return;
+    for (int i = 0; i < n; i++)
+        if (inside(i)) { up_hint = i; return; }
+    fail(OHEVC_ERR_STATE);
 }
 
 int upsample_once(int el_slot, int bl_slot, const ohevc_HEVCWindow *w, const ohevc_UpsamplInf *u, int block_slots)

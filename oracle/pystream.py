@@ -150,8 +150,8 @@ class Decoder:
 
     def product_lib(self):
         """The HIP library this decoder is linked against (ctypes handle), for openhevc_amd.dist.FrameExchange."""
-        if self.kind == "hipemu":
-            return C.CDLL(os.path.join(os.path.dirname(_HERE), "tests", "hipemu", "libohevc_hip_emu.so"), mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        if self.kind.startswith("hipemu"):      # hipemu, hipemu_asan, hipemu_tsan: the emulator build the decoder of that name is linked against
+            return C.CDLL(os.path.join(os.path.dirname(_HERE), "tests", "hipemu", "libohevc_hip_emu" + self.kind[len("hipemu"):] + ".so"), mode=os.RTLD_LOCAL | os.RTLD_NOW)
         return _product_lib()
 
     def _check_sw(self):
