@@ -75,8 +75,8 @@ def random_layers(rng):
     if ne > 1:
         ke["slices_per_picture"] = ne
         ke["dependent_slices"] = int(rng.integers(0, 2))
-    return dict(common, **kb), dict(common, **ke), int(rng.integers(0, 2)) if kind != "x1_5" else 0, kind
     # (x1.5 with phase alignment through the block slots: the reference reads scratch rows it did not prepare)
+    return dict(common, **kb), dict(common, **ke), int(rng.integers(0, 2)) if kind != "x1_5" else 0, kind
 
 
 def same(a, b):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Memory-safety pass over the TWO-LAYER (SHVC) path without a device: the 15 two-layer fixtures, slice threads, decoder pairs opened and closed, and the
+# Memory-safety pass over the TWO-LAYER (SHVC) path without a device: the two-layer fixtures, slice threads, decoder pairs opened and closed, and the
 # two-layer fuzzer, through the hooked decoder linked against the AddressSanitizer build of the kernel emulator (see tools/hipemu_asan.sh).
 #   tools/hipemu_asan_shvc.sh > profiles/<name>.txt
 set -e
