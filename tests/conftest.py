@@ -10,6 +10,20 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU tier (-m "not gpu") is ~800 tests, half of them whole decodes over the emulated device code: ~13 minutes on one core, ~4 on four.
+    # When nobody asked for a number of workers, spread it over four pytest-xdist workers (the tests are independent processes' worth of work:
+    # every session of this repository has run them with -n 8).  Never for the device tier (one GPU), never inside a worker;
+    # OHEVC_TEST_WORKERS=0 switches it off, OHEVC_TEST_WORKERS=n picks another number.
+    want = os.environ.get("OHEVC_TEST_WORKERS", "4")
+    if (hasattr(config, "workerinput") or not want.isdigit() or int(want) < 2 or (os.cpu_count() or 1) < 4
+            or "not gpu" not in (getattr(config.option, "markexpr", "") or "") or getattr(config.option, "collectonly", False)):
+        return
+    if getattr(config.option, "numprocesses", None) or getattr(config.option, "dist", "no") != "no" or not config.pluginmanager.hasplugin("xdist"):
+        return
+    n = min(int(want), os.cpu_count() or 1)
+    config.option.numprocesses = n           # what "-n 4" sets (xdist/plugin.py: pytest_cmdline_main); xdist's own pytest_configure runs after this one
+    config.option.dist = "load"
+    config.option.tx = ["popen"] * n
 
 
 @pytest.fixture(scope="session")

@@ -21,8 +21,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_kernels_stay_inside_their_buffers(modules):
     env = dict(os.environ, HIPEMU_GUARD="1", HIPEMU_MODULES=modules)
     env.pop("HIPEMU_ASAN", None)
+    # (four worker processes: the repeat is pure CPU work, the suite's own run is serial)
+    workers = ["-n", str(min(4, os.cpu_count() or 1))] if (os.cpu_count() or 1) > 1 else []
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_hipemu_cpu.py"), "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "not stream"], capture_output=True, text=True, env=env, timeout=1500, cwd=HERE)
+                        "-k", "not stream and not decoders"] + workers,      # (kernel, ctx and table tests: the whole-decoder ones run once, in the suite itself)
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=HERE)
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, f"the emulated kernels of {modules} left their buffers (or a test failed):\n{tail}"
     assert " passed" in r.stdout, tail

@@ -117,7 +117,7 @@ def test_emu_shvc_both_layers(name):
     """Parsing, recording, the shared picture store, the device-side resampling of the inter-layer picture and every kernel, on the host."""
     _emu()
     # CPU-suite time: the emulator is ~1000x slower than the device, which runs every stream (tests/test_shvc_stream_gpu.py)
-    if name in ("x2_ctb64", "x2_wpp", "snr_wpp", "x2_odd", "x1_5_dense", "x1_5_tmvp"):
+    if name in ("x2_ctb64", "x2_wpp", "snr_wpp", "x2_odd", "x1_5_dense", "x1_5_tmvp", "x2_ra", "x2_slices", "snr", "x2_phase"):
         pytest.skip("runs on the device only (CPU-suite time; x2_wpp / snr_wpp run under slice threads below)")
     check_both_layers("hipemu", name)
 
