@@ -60,6 +60,8 @@ def main():
     out["first_pass_slowest_hooks"] = [dict(poc=r[1], thread=r[0], parse_start_ms=round(1e3 * (r[2] - t_first), 2), parse_ms=round(1e3 * (r[3] - r[2]), 2),
                                             issue_ms=round(1e3 * (r[4] - r[3]), 2), device_wait_ms=round(1e3 * (r[5] - r[4]), 2))
                                        for r in sorted(first, key=lambda r: r[3] - r[5])[:10]]
+    if os.environ.get("DIAG_DUMP"):      # every picture of the first pass: [poc, thread, parse start, parse end, issued, landed] in ms from the first parse start
+        out["first_pass_pictures"] = [[r[1], r[0]] + [round(1e3 * (r[k] - t_first), 2) for k in (2, 3, 4, 5)] for r in first]
     print(json.dumps(out))
 
 
