@@ -73,6 +73,16 @@ struct PicStore {
     std::shared_mutex pin_m;
     std::vector<std::pair<uintptr_t, size_t>> pinned;      // host ranges page-locked through ohevc_host_pin
     Issuer *issuer = nullptr;             // ohevc_frame_end_async: the thread that issues frame ends (created by the first submission)
+    // Device pictures come in batches: one hipMalloc, one memset and one wait for 4, 8, 16, 32 pictures of a size instead of one of each per
+    // picture.  A decoder's pool of frame buffers grows through its first dozens of pictures, every new buffer wants a device picture, and the
+    // sample hooks ask for it in the serial prologue of the picture (hevc_frame_start, before the next access unit is let in): 0.3-0.5 ms of
+    // driver calls there spaced a fresh decoder's picture starts 0.8-1.2 ms apart instead of 0.43 (profiles/r13_*).  Pieces are zeroed when their
+    // batch is made; a piece whose picture is released is not handed out again (it would need zeroing) - its memory goes with the store.
+    std::mutex spare_m;
+    struct Piece { unsigned char *base; size_t bytes; };
+    std::vector<Piece> spare;             // zeroed pieces nobody uses yet, all of one size
+    std::vector<void *> batches;          // the allocations behind all pieces ever made
+    int next_batch = 4;
 };
 
 struct DevBuf {                       // grow-only device buffer
@@ -301,7 +311,31 @@ static int free_picture(Picture &p, bool dry = false)
     return OHEVC_OK;
 }
 
-static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, bool dry = false)
+// OHEVC_PICTURE_BATCH=0: every picture its own allocation (the AddressSanitizer pass over the emulated device code wants red zones around each)
+static const int g_picture_batch = getenv("OHEVC_PICTURE_BATCH") ? atoi(getenv("OHEVC_PICTURE_BATCH")) : 1;
+
+// a zeroed piece of `bytes` bytes out of the store's batches (PicStore::spare); nullptr: none to be had, allocate the old way
+static unsigned char *take_piece(PicStore &st, size_t bytes, hipStream_t stream)
+{
+    if (!g_picture_batch || bytes > ((size_t)256 << 20)) return nullptr;
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    std::lock_guard<std::mutex> g(st.spare_m);
+    if (!st.spare.empty() && st.spare.back().bytes != bytes) st.spare.clear();      // another geometry: the old pieces stay in their batches, unused
+    if (st.spare.empty()) {
+        const int n = (int)std::max<size_t>(1, std::min<size_t>((size_t)st.next_batch, ((size_t)1 << 30) / bytes));
+        void *m = nullptr;
+        if (hipMalloc(&m, n * bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemsetAsync(m, 0, n * bytes, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(m); return nullptr; }
+        st.batches.push_back(m);
+        for (int i = n - 1; i >= 0; i--) st.spare.push_back(PicStore::Piece{ static_cast<unsigned char *>(m) + (size_t)i * bytes, bytes });
+        st.next_batch = std::min(st.next_batch * 2, 32);
+    }
+    unsigned char *d = st.spare.back().base;
+    st.spare.pop_back();
+    return d;
+}
+
+static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, bool dry = false, PicStore *store = nullptr, hipStream_t stream = nullptr)
 {
     const int ps = bd > 8 ? 2 : 1;
     p.w = width; p.h = height; p.cfi = cfi; p.bd = bd;
@@ -314,7 +348,10 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
         off[i + 1] = off[i] + (size_t)stride * h;
     }
     unsigned char *d = reinterpret_cast<unsigned char *>((uintptr_t)0x1000000);      // never dereferenced in record-only mode
-    if (!dry) {
+    unsigned char *piece = !dry && store ? take_piece(*store, off[3], stream) : nullptr;
+    if (piece) {
+        d = piece;
+    } else if (!dry) {
         // one allocation, the planes back to back: the deblocked copy SAO reads (and the filter-lag snapshot) is one device copy, not three
         void *m = nullptr;
         const hipError_t e = hipMalloc(&m, off[3]);
@@ -327,6 +364,7 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
     }
     for (int i = 0; i < 3; i++) p.planes[i].data = dry ? reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1)) : static_cast<void *>(d + off[i]);
     p.used = true; p.single = !dry;
+    p.owned = piece == nullptr;           // a piece belongs to its batch (freed with the store)
     return OHEVC_OK;
 }
 
@@ -424,6 +462,11 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
             while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
         }
         for (int i = 0; i < c->store->npics; i++) if (c->store->pics[i].used) free_picture(c->store->pics[i]);
+        {
+            std::lock_guard<std::mutex> g(c->store->spare_m);
+            for (void *b : c->store->batches) (void)hipFree(b);
+            c->store->batches.clear(); c->store->spare.clear();
+        }
     }
     {   // pictures of the shared store may still name this context's events (the stream has drained: they have all fired)
         std::lock_guard<std::mutex> g(c->store->m);
@@ -502,9 +545,9 @@ extern "C" int ohevc_pic_alloc(ohevc_ctx *c, int width, int height, int cfi, int
     if (slot < 0) { OHEVC_REQUIRE(c->store->npics < kMaxPics, "too many pictures"); slot = c->store->npics++; }
     Picture &np = c->store->pics[slot];
     np = Picture();
-    int rc = alloc_picture(np, width, height, cfi, bd, c->dry);
+    int rc = alloc_picture(np, width, height, cfi, bd, c->dry, c->store.get(), c->stream);
     if (rc != OHEVC_OK) return rc;
-    if (!c->dry) {
+    if (!c->dry && np.owned) {            // (a piece of a batch was zeroed with its batch)
         // zeroed like the reference's frame pool (av_buffer_allocz, libavcodec/utils.c): a sample nobody ever wrote -- a stream that
         // predicts from a picture it never sent -- is at least the same sample on every run.  On this context's stream and drained
         // before the slot is handed out: a memset on the null stream would not be ordered against the (non-blocking) streams
@@ -2151,10 +2194,12 @@ static int frame_end_impl(ohevc_ctx *c)
         const bool lagged = c->sao_lagged && !c->sao.empty() && !c->dbk_h.empty();
         auto ensure_like = [&](Picture &q) -> int {
             if (q.used && q.w == p->w && q.h == p->h && q.cfi == p->cfi && q.bd == p->bd) return OHEVC_OK;
-            OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
             int r;
-            if (q.used && (r = free_picture(q)) != OHEVC_OK) return r;
-            return alloc_picture(q, p->w, p->h, p->cfi, p->bd);
+            if (q.used) {                 // another geometry: launches that read the old copy may still be in flight
+                OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+                if ((r = free_picture(q)) != OHEVC_OK) return r;
+            }
+            return alloc_picture(q, p->w, p->h, p->cfi, p->bd, false, c->store.get(), c->stream);
         };
         if (lagged) {          // the state the reference's early copy saw (ohevc_hip.h, OHEVC_SAO_LAG_*): chroma only
             if ((rc = ensure_like(c->lag)) != OHEVC_OK) return rc;

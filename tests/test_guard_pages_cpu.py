@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.parametrize("modules", ["test_filters_gpu test_dbk_maps_gpu", "test_intra_gpu test_mc_gpu test_shvc_gpu"])
 def test_kernels_stay_inside_their_buffers(modules):
-    env = dict(os.environ, HIPEMU_GUARD="1", HIPEMU_MODULES=modules)
+    env = dict(os.environ, HIPEMU_GUARD="1", HIPEMU_MODULES=modules, OHEVC_PICTURE_BATCH="0")      # (every device picture its own allocation, ending at its own guard page)
     env.pop("HIPEMU_ASAN", None)
     # (four worker processes: the repeat is pure CPU work, the suite's own run is serial)
     workers = ["-n", str(min(4, os.cpu_count() or 1))] if (os.cpu_count() or 1) > 1 else []

@@ -7,6 +7,7 @@ cd "$(dirname "$0")/.."
 RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0
 export OHEVC_REF_WAIT_SECONDS=900
+export OHEVC_PICTURE_BATCH=0          # every device picture its own allocation: red zones around each (ctx.hip: take_piece)
 make -s -j6 -C tests/hipemu SAN=1
 make -s -C oracle hipemu_asan
 echo "== two-layer streams on libopenhevc_hipemu_asan.so"
