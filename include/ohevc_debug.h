@@ -109,6 +109,11 @@ int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8]);      /* [
 /* SHVC up-sampling kernel: 0 = the tile form (shipped: a workgroup per 64 x 32 output tile, both passes through LDS, dot instructions),
  * 1 = the round-2 strip form (a thread per column strip).  Returns the previous value.  Environment: OHEVC_UPSAMPLE_VARIANT. */
 int ohevc_debug_set_upsample_variant(int variant);
+
+/* Device pictures come in batches (ctx.hip: PicStore::spare; OHEVC_PICTURE_BATCH=0 switches it off): how many batch allocations the picture
+ * store of `ctx` has made so far.  A test hook: two picture sizes taking turns (the two layers of an SHVC stream share a store) must not make
+ * one batch per picture. */
+int ohevc_debug_picture_batches(struct ohevc_ctx *ctx);
 /* Deblocking from the maps (ohevc_dev_deblock_maps): 0 = a lane per 4-line luma segment with packed 16-bit arithmetic (shipped, up to 10 bit),
  * 1 = a lane per line (rounds 2-3; what deeper pictures and unaligned planes take anyway).  Returns the previous value.
  * Environment: OHEVC_DEBLOCK_VARIANT. */

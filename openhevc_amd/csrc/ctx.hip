@@ -79,10 +79,9 @@ struct PicStore {
     // driver calls there spaced a fresh decoder's picture starts 0.8-1.2 ms apart instead of 0.43 (profiles/r13_*).  Pieces are zeroed when their
     // batch is made; a piece whose picture is released is not handed out again (it would need zeroing) - its memory goes with the store.
     std::mutex spare_m;
-    struct Piece { unsigned char *base; size_t bytes; };
-    std::vector<Piece> spare;             // zeroed pieces nobody uses yet, all of one size
+    struct Spare { std::vector<unsigned char *> pieces; int next_batch = 4; };
+    std::map<size_t, Spare> spare;        // by piece size: zeroed pieces nobody uses yet (two layers of an SHVC stream share a store: two sizes take turns)
     std::vector<void *> batches;          // the allocations behind all pieces ever made
-    int next_batch = 4;
 };
 
 struct DevBuf {                       // grow-only device buffer
@@ -320,19 +319,26 @@ static unsigned char *take_piece(PicStore &st, size_t bytes, hipStream_t stream)
     if (!g_picture_batch || bytes > ((size_t)256 << 20)) return nullptr;
     bytes = (bytes + 4095) & ~(size_t)4095;
     std::lock_guard<std::mutex> g(st.spare_m);
-    if (!st.spare.empty() && st.spare.back().bytes != bytes) st.spare.clear();      // another geometry: the old pieces stay in their batches, unused
-    if (st.spare.empty()) {
-        const int n = (int)std::max<size_t>(1, std::min<size_t>((size_t)st.next_batch, ((size_t)1 << 30) / bytes));
+    PicStore::Spare &sp = st.spare[bytes];
+    if (sp.pieces.empty()) {
+        const int n = (int)std::max<size_t>(1, std::min<size_t>((size_t)sp.next_batch, ((size_t)1 << 30) / bytes));
         void *m = nullptr;
         if (hipMalloc(&m, n * bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         if (hipMemsetAsync(m, 0, n * bytes, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(m); return nullptr; }
         st.batches.push_back(m);
-        for (int i = n - 1; i >= 0; i--) st.spare.push_back(PicStore::Piece{ static_cast<unsigned char *>(m) + (size_t)i * bytes, bytes });
-        st.next_batch = std::min(st.next_batch * 2, 32);
+        for (int i = n - 1; i >= 0; i--) sp.pieces.push_back(static_cast<unsigned char *>(m) + (size_t)i * bytes);
+        sp.next_batch = std::min(sp.next_batch * 2, 32);
     }
-    unsigned char *d = st.spare.back().base;
-    st.spare.pop_back();
+    unsigned char *d = sp.pieces.back();
+    sp.pieces.pop_back();
     return d;
+}
+
+extern "C" int ohevc_debug_picture_batches(ohevc_ctx *c)
+{
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->store->spare_m);
+    return (int)c->store->batches.size();
 }
 
 static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, bool dry = false, PicStore *store = nullptr, hipStream_t stream = nullptr)

@@ -113,3 +113,40 @@ def test_picture_export_import_round_trip(bd, cfi):
     for c in range(3):
         assert np.array_equal(got[c], planes[c]), f"plane {c}"
     ctx.close()
+
+
+def test_device_pictures_come_in_batches_per_size():
+    """Device pictures are allocated, zeroed and waited for in batches of 4, 8, 16, 32 per piece size (ctx.hip: PicStore::spare): a decoder's
+    frame-buffer pool grows one picture at a time, in the serial prologue of its pictures.  Two sizes taking turns - the two layers of an SHVC
+    stream share a store - must not start a new batch with every picture; pictures of a batch are distinct memory, zeroed, and stay usable
+    after neighbours were released."""
+    import ctypes
+    lib = L.load_library()
+    lib.ohevc_debug_picture_batches.argtypes = [ctypes.c_void_p]
+    if os.environ.get("OHEVC_PICTURE_BATCH") == "0":
+        pytest.skip("batches are switched off in this run")
+    ctx = L.Ctx(0)
+    assert lib.ohevc_debug_picture_batches(ctx.h) == 0
+    sizes = [(192, 128), (384, 256)]
+    slots = []
+    for i in range(40):
+        w, h = sizes[i & 1]
+        slots.append((ctx.pic_alloc(w, h, 1, 8), w, h))
+    # 20 pictures of each size: batches of 4 + 8 + 16 per size
+    assert lib.ohevc_debug_picture_batches(ctx.h) == 6
+    rng = np.random.default_rng(5)
+    kept = {}
+    for k, (slot, w, h) in enumerate(slots):
+        shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+        got = ctx.pic_download(slot, shapes, np.uint8)
+        assert all(not pl.any() for pl in got), "a fresh device picture is zeroed (like the reference's frame pool)"
+        planes = [rng.integers(0, 256, size=sh).astype(np.uint8) for sh in shapes]
+        ctx.pic_upload(slot, planes)
+        kept[slot] = (planes, shapes)
+    for slot, w, h in slots[::3]:
+        ctx.pic_release(slot)
+        kept.pop(slot)
+    for slot, (planes, shapes) in kept.items():             # every picture still holds what was written to it: the pieces do not overlap
+        got = ctx.pic_download(slot, shapes, np.uint8)
+        assert all(np.array_equal(a, b) for a, b in zip(got, planes))
+    ctx.close()
