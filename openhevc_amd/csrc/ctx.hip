@@ -141,7 +141,7 @@ static std::atomic<uint64_t> g_ctx_gen{1};
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
-static int g_level_launch = 0;        // ohevc_debug_set_level_launch
+static std::atomic<int> g_level_launch{0};      // ohevc_debug_set_level_launch (the sample hooks set it, to the same value, from every decoder that is opened: atomic)
 // The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
 // launch of its own ~6.6 us of kernel plus 2 - 4 us until the next one starts, whatever its width: up to four passes the chain is cheaper.
 static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 32;
@@ -511,7 +511,7 @@ extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_debug_set_level_launch(int mode) { const int prev = g_level_launch; g_level_launch = mode; return prev; }
+extern "C" int ohevc_debug_set_level_launch(int mode) { return g_level_launch.exchange(mode, std::memory_order_relaxed); }
 extern "C" int ohevc_debug_set_intra_chain(int on) { const int prev = g_intra_chain; g_intra_chain = on != 0; return prev; }
 extern "C" int ohevc_debug_set_intra_pack(int on) { const int prev = g_intra_pack; g_intra_pack = on != 0; return prev; }
 extern "C" int ohevc_debug_set_fuse_intra(int on) { const int prev = g_fuse_intra; g_fuse_intra = on != 0; return prev; }
