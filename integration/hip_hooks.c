@@ -329,8 +329,6 @@ static int find_buf_locked(ohhip_backend *be, const uint8_t *data0)
 /* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
 static int device_bs_frame(const HEVCContext *s);
 /* boundary-strength calls the picture's own thread records (ohhip_deblocking_boundary_strengths below) */
-/* page locks of the open frame's buffers that are still to be taken (ohhip_set_new_ref notes them, frame_done takes them) */
-static __thread struct { const uint8_t *data0; void *ptr[3]; size_t bytes[3]; int idx[3]; int n; } t_pin;
 static __thread ohevc_bs_call *t_bs_buf;
 static __thread int            t_bs_n, t_bs_cap;
 static __thread const HEVCContext *t_bs_direct;       /* the context whose calls this thread records directly, NULL: none */
@@ -361,23 +359,10 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     /* INTEGRATION.md section 3, row alloc_frame: page-lock the buffers the decoder's pool recycles (hevc_refs.c:75-114, get_buffer.c), so
      * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once.  (After the
      * slot look-up: a buffer that came back with another geometry had its old page locks dropped there.) */
-    /* ... NOT here, though, where round 4 first had it: this function runs in the picture's serial prologue (hevc_frame_start, before
-     * ff_thread_finish_setup lets the next access unit in) and under the instance's lock - three hipHostRegister calls per new buffer stretched the
-     * distance between picture starts of a fresh decoder (profiles/r13_*).  The ranges are noted; the picture's own thread takes the locks at its
-     * frame end, right before the copy-back that wants them is issued (frame_done).  Frames mode over processes keeps the immediate form (a
-     * remote picture has no frame end here). */
-    t_pin.n = 0;
-    if (be->opt.pin_frames && ohevc_ctx_has_device(ctx)) {
-        t_pin.data0 = f->data[0];
+    if (be->opt.pin_frames && ohevc_ctx_has_device(ctx))
         for (k = 0; k < 3 && k < AV_NUM_DATA_POINTERS && f->buf[k]; k++) {
             if (be->bufs[i].pin_ptr[k] == f->buf[k]->data && be->bufs[i].pin_bytes[k] == (size_t)f->buf[k]->size)
                 continue;
-            if (!be->fm_on) {
-                t_pin.ptr[t_pin.n] = f->buf[k]->data;
-                t_pin.idx[t_pin.n] = k;
-                t_pin.bytes[t_pin.n++] = (size_t)f->buf[k]->size;
-                continue;
-            }
             if (ohevc_host_pin(ctx, f->buf[k]->data, f->buf[k]->size) != OHEVC_OK) {
                 if (be->opt.pin_frames == 1)
                     fprintf(stderr, "ohhip: frame buffers stay pageable: %s\n", ohevc_last_error());
@@ -387,7 +372,10 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
             be->bufs[i].pin_ptr[k] = f->buf[k]->data;
             be->bufs[i].pin_bytes[k] = (size_t)f->buf[k]->size;
         }
-    }
+    /* (Taking these locks later - at the picture's frame end, out of this serial prologue - was tried at the end of round 4 and gave a fresh
+     * decoder's first pass 4.5 ms back (profiles/r14_*), but a page lock wants the store's table exclusively, i.e. waits for every copy-back in
+     * flight, and at a frame end other threads are already waiting for THIS picture: when the decoder re-created its buffer pool under four frame
+     * threads, one run in six stood still until the reference wait timed out.  Here, before anything can depend on the picture, the wait is harmless.) */
     slot = be->bufs[i].slot;
     if (be->fm_on && be->bufs[i].remote && be->bufs[i].index >= 0 && be->fm.release) {
         /* the buffer last held a remote picture: whatever is still in flight for it (planes nobody predicted from, a motion field
@@ -1109,27 +1097,6 @@ static int frame_done(ohhip_backend *be)
         t_error = 1;
     }
     t_frame_open = 0;
-    /* the page locks ohhip_set_new_ref noted for this picture's buffers: taken here, by the picture's own thread, in front of the copy-back */
-    if (t_pin.n > 0) {
-        int k, j, done = 0;
-        for (k = 0; k < t_pin.n; k++, done++)
-            if (ohevc_host_pin(t_ctx, t_pin.ptr[k], t_pin.bytes[k]) != OHEVC_OK) {
-                if (be->opt.pin_frames == 1)
-                    fprintf(stderr, "ohhip: frame buffers stay pageable: %s\n", ohevc_last_error());
-                be->opt.pin_frames = 2;                  /* say it once */
-                break;
-            }
-        if (done) {                                      /* remembered per buffer: dropped when the address comes back with another geometry */
-            pthread_mutex_lock(&be->lock);
-            j = find_buf_locked(be, t_pin.data0);
-            for (k = 0; j >= 0 && k < done; k++) {
-                be->bufs[j].pin_ptr[t_pin.idx[k]] = t_pin.ptr[k];
-                be->bufs[j].pin_bytes[t_pin.idx[k]] = t_pin.bytes[k];
-            }
-            pthread_mutex_unlock(&be->lock);
-        }
-        t_pin.n = 0;
-    }
     /* Frame threads: the issue of the frame end (stage, upload, launches) and the copy-back leave the decoding thread (ohevc_frame_end_async);
      * the picture's samples are waited for where it leaves the decoder (ohhip_backend_fetch_output).  Not with the decoded-picture-hash check
      * on (hevc.c:4146-4162 reads the host planes in this thread right behind this call) and not in frames mode over processes (the picture is
