@@ -46,12 +46,17 @@ def parse():
     ap.add_argument("--mode", choices=["blocks", "frames"], default="blocks",
                     help="blocks (default): the graded kernel on independent blocks; frames: the whole decoder on a synthetic stream, "
                          "frame-parallel over the ranks (BASELINE config 5's structure: owner-GPU round-robin, RCCL broadcast of reference planes)")
-    ap.add_argument("--frames-size", default="3840x2160", help="--mode frames: picture size WxH")
+    ap.add_argument("--frames-size", default="7680x4320", help="the frame-parallel leg's picture size WxH (default: BASELINE config 5, 8K)")
     ap.add_argument("--frames-bit-depth", type=int, default=10)
-    ap.add_argument("--frames-pictures", type=int, default=17)
+    ap.add_argument("--frames-pictures", type=int, default=9)
+    ap.add_argument("--frames-steps", type=int, default=3, help="timed passes of the `frames` object's stream (the line's --steps is the kernel bench's)")
     ap.add_argument("--frames-python-transport", action="store_true",
                     help="--mode frames: exchange pictures through openhevc_amd.dist.FrameExchange (torch.distributed) instead of the native "
                          "transport of include/ohevc_frames.h (RCCL broadcast in C; TCP with --frames-one-gpu)")
+    ap.add_argument("--frames-baseline", action="store_true",
+                    help="--mode frames with more than one rank: rank 0 also decodes the stream alone first (the N = 1 value beside the N-rank one) and "
+                         "every rank's pictures are compared with that run's")
+    ap.add_argument("--no-frames", action="store_true", help="skip the `frames` object (BASELINE config 5, the frame-parallel decoder) of the line")
     ap.add_argument("--frames-one-gpu", action="store_true",
                     help="--mode frames: every rank uses GPU 0 and the planes travel host-staged through gloo (what the slice-data division "
                          "buys without more GPUs; RCCL needs one GPU per rank)")
@@ -119,10 +124,12 @@ def cpu_baseline(log2, bd, leg_seconds=6.0):
     return out
 
 
+NATURAL = dict(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
+                                      split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))   # encoder-like random-access statistics
 PCIE_PEAK_GBS = 64.0            # PCIe 5.0 x16, one direction: the floor of what crosses the bus per picture
 
 
-def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=False):
+def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=False, sizes=True):
     """BASELINE config 3 (1080p Main 8-bit random-access stream, the full CTU pipeline on one GPU) as a driver-timed number: the reference's
     own front end (CABAC, syntax, motion data: host cores) linked against libohevc_hip.so (oracle/_ref/libopenhevc_hip.so: the reference's
     sources + integration/hip_hooks.c), against the same decoder with its own C tables.  No HEVC bitstream exists in this environment: the
@@ -135,9 +142,10 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
     if not (ps.have("hip") and ps.have("c") and ps.have("gen")):
         return {"error": "oracle/_ref decoder builds are missing"}
     W, H = size
-    natural = dict(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
-                                          split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
-    profiles = [("natural", natural), ("flat", {})]
+    profiles = [("natural", NATURAL), ("flat", {})]
+    # the two GOP structures the random-access rows do not show: every picture intra (the back end's dependency chain of prediction levels is
+    # the whole picture: VERDICT r4 item 2) and low-delay P (every picture waits for the one before it: no two pictures of the stream overlap)
+    extra_gops = [("intra_only", dict(gop="intra", nframes=17, **NATURAL)), ("lowdelay_p", dict(gop="lowdelay_p", **NATURAL))]
     dense = getattr(ps, "DENSE_QP22", None)          # qp22-like residual density (100-300 KB per 1080p picture), when the synthesiser has it
     if dense is not None:
         profiles.append(("dense_qp22", dense))
@@ -145,7 +153,7 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
     hipL.ohdec_backend_alg_bytes.restype = C.c_longlong
     cores = os.cpu_count() or 1
 
-    def timed(kind, aus, th, repeat=3):
+    def timed(kind, aus, th, repeat=3, tt=1, passes=passes):
         """(wall time of all passes, pictures out, pictures per second after the first pass), best of `repeat` decoder instances.  The third
         number: pictures that came out between the moment the first access unit of the SECOND pass went in and the end, over that time - the
         first pass of any of these decoders is its start-up (with frame threads every thread's first picture allocates its tables; behind the
@@ -153,7 +161,7 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
         decoders have far less of it"""
         best, best_steady = None, 0.0
         for _ in range(repeat):
-            with ps.Decoder(kind, th, 1) as d:
+            with ps.Decoder(kind, th, tt) as d:
                 t = time.perf_counter()
                 n = 0
                 t_mid, n_mid = None, 0
@@ -182,15 +190,17 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
     out = {"workload": f"{W}x{H} 8-bit 4:2:0 random-access GOP, {pictures} pictures x {passes} passes through one decoder instance, synthetic Annex-B streams (oracle/pystream.py, seed 7); wall clock incl. "
                        f"entropy decoding on the host and the copy-back of every picture; host has {cores} logical cores",
            "streams": {}}
-    for name, extra in profiles:
-        kw = dict(gop="random_access", nframes=pictures, seed=7, width=W, height=H, log2_ctb=6, bit_depth=8)
+    all_pictures = pictures
+    for name, extra in profiles + extra_gops:
+        kw = dict(gop="random_access", nframes=all_pictures, seed=7, width=W, height=H, log2_ctb=6, bit_depth=8)
         kw.update(extra)
+        pictures = kw["nframes"]
         aus, _ = ps.generate(ps.StreamParams(**kw))
         ref = ps.decode_stream("c", aus)
         hip = ps.decode_stream("hip", aus)
         hip_mt = ps.decode_stream("hip", aus, threads, 1)
         same = lambda a, b: len(a) == len(b) and all(np.array_equal(x, y) for fa, fb in zip(a, b) for x, y in zip(fa, fb))
-        row = {"bytes_per_picture": sum(map(len, aus)) // len(aus), "bit_exact": bool(same(ref, hip)), f"bit_exact_{threads}_frame_threads": bool(same(ref, hip_mt))}
+        row = {"gop": kw["gop"], "pictures": pictures, "bytes_per_picture": sum(map(len, aus)) // len(aus), "bit_exact": bool(same(ref, hip)), f"bit_exact_{threads}_frame_threads": bool(same(ref, hip_mt))}
         if ps.have("sse") and not hip_only:
             row["reference_sse_equals_reference_c"] = bool(same(ref, ps.decode_stream("sse", aus)))
         mp = W * H * pictures / 1e6
@@ -246,57 +256,155 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
             out["bit_exact"] = bool(out["bit_exact"] and all(v["exact"] for v in out["shvc"].values() if isinstance(v, dict)))
         except Exception as e:                       # noqa: BLE001  (the rows above stay valid)
             out["shvc"] = {"error": f"{type(e).__name__}: {e}"}
+    # BASELINE configs 4 and 5 on ONE GPU, driver-timed: 4K Main10 with wavefront (WPP) CTU rows on slice threads, 8K Main10 - encoder-like
+    # statistics, the stream several times through one decoder instance (fps = all passes incl. the decoder's start-up, fps_after_first_pass
+    # = steady state), the HIP back end next to the reference as shipped on x86 and to the front end alone; every HIP mode compared picture
+    # by picture with the reference's C decoder
+    out["sizes"] = {}
+    pictures = all_pictures
+    same = lambda a, b: len(a) == len(b) and all(np.array_equal(x, y) for fa, fb in zip(a, b) for x, y in zip(fa, fb))
+    for name, (w, h), bd, npic, npass, wpp, modes in (
+            ("config4_4k_main10_wpp", (3840, 2160), 10, 9, 3, 1, (("1thread", 1, 1), ("8slice_threads", 8, 2), ("8frame_threads", 8, 1))),
+            ("config5_8k_main10", (7680, 4320), 10, 5, 2, 0, (("1thread", 1, 1), ("8frame_threads", 8, 1)))):
+        if not sizes:
+            continue
+        try:
+            kw = dict(gop="random_access", nframes=npic, seed=7, width=w, height=(h + 7) // 8 * 8, log2_ctb=6, bit_depth=bd, **NATURAL)
+            if wpp:
+                kw["wpp"] = 1
+            aus, _ = ps.generate(ps.StreamParams(**kw))
+            ref = ps.decode_stream("c", aus)
+            row = {"workload": f"{w}x{kw['height']} {bd}-bit 4:2:0 random-access stream{' with entropy_coding_sync (WPP rows)' if wpp else ''}, {npic} pictures x {npass} passes, "
+                               f"{sum(map(len, aus)) // len(aus)} bytes/picture, encoder-like statistics (oracle/pystream.py, seed 7)"}
+            mp = w * h * npic / 1e6
+            for label, th, tt in modes:
+                row[f"bit_exact_hip_{label}"] = bool(same(ref, ps.decode_stream("hip", aus, th, tt)))
+                for kind, kname in (("hip", "hip"), ("sse", "reference_sse"), ("null", "front_end_only")):
+                    if not ps.have(kind) or (hip_only and kind != "hip"):
+                        continue
+                    if kind == "null":
+                        ps._load("null").ohnull_set_await(0)
+                    dt, n, steady = timed(kind, aus, th, repeat=2, tt=tt, passes=npass)
+                    if n != npic * npass:
+                        raise RuntimeError(f"{name} {kname}_{label}: {n} pictures out of {npic * npass}")
+                    row[f"{kname}_{label}"] = {"fps": round(npic * npass / dt, 2), "mpixel_per_s": round(mp * npass / dt, 1), "fps_after_first_pass": round(steady, 2)}
+            row["bit_exact"] = all(v for k, v in row.items() if k.startswith("bit_exact_hip_"))
+            out["sizes"][name] = row
+            out["bit_exact"] = bool(out["bit_exact"] and row["bit_exact"])
+        except Exception as e:                       # noqa: BLE001  (the rows above stay valid)
+            out["sizes"][name] = {"error": f"{type(e).__name__}: {e}"}
     out["floor"] = ("device_floor_ms = algorithmic HBM bytes of the picture's jobs (SURVEY 8d per-unit figures, summed by the recorder) / 8 TB/s; "
                     "pcie_floor_ms = (job upload + plane copy-back) / 64 GB/s; floor_frac = their sum / the frame-end hook's wall time")
     return out
 
 
-def frames_mode(args):
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` from a bare shell (no torch.distributed.run): start one rank per GPU ourselves - the same processes, with
+    the same environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), that `python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N` starts - pass rank 0's one JSON line through, and take every rank down if one of them fails.  On a box with fewer GPUs
+    than N every rank uses GPU 0 (--frames-one-gpu: gloo for the barrier, the transport's sockets wire for the pictures; RCCL refuses two
+    ranks on one device), which the line says ("one_gpu": true): that run exercises the launcher and the protocol, it is not a scaling result."""
+    import subprocess
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    argv = [a for a in sys.argv[1:]]
+    if have < n and "--frames-one-gpu" not in argv:
+        argv.append("--frames-one-gpu")
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:               # exactly the processes started above, by pid
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    raise SystemExit(rc)
+
+
+def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, steps, warmup, python_transport=False, baseline=False, port=None):
     """One step = one pass of the hooked reference decoder over a synthetic Annex-B stream, frame-parallel over the ranks
-    (integration/hip_frames.h, openhevc_amd/dist.py FrameExchange).  The stream synthesiser and the decoder harness are the test
-    infrastructure's (oracle/pystream.py; the decoder binary is the reference's own front end linked against libohevc_hip.so,
-    oracle/_ref/libopenhevc_hip.so) - no pixel is computed by anything but the HIP library."""
+    (integration/hip_frames.h): the owner of a picture - decoding-order index mod world - parses its slice data and reconstructs it on its
+    GPU; planes and motion fields reach the other ranks through the native transport (include/ohevc_frames.h: ncclBroadcast over xGMI; TCP
+    when the ranks share one GPU).  torch.distributed is used for the barriers and the max-over-ranks clock only (the caller initialised it).
+    baseline: rank 0 first decodes the same stream ALONE, no exchange (the N = 1 value of this very stream, next to the N-rank one), and
+    every rank's own pictures of an untimed N-rank pass are compared with that run's.
+    The stream synthesiser and the decoder harness are the test infrastructure's (oracle/pystream.py; the decoder binary is the reference's
+    own front end linked against libohevc_hip.so, oracle/_ref/libopenhevc_hip.so) - no pixel is computed by anything but the HIP library."""
+    import zlib
     import torch
     import torch.distributed as dist
     from openhevc_amd import dist as D
     from oracle import pystream as ps
-    rank, world = D.init_from_env("gloo" if args.frames_one_gpu else None)
-    local_rank = 0 if args.frames_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     on_gpu = torch.cuda.is_available()
+    dev = 0 if one_gpu else local_rank
     if on_gpu:
-        torch.cuda.set_device(local_rank)
-        os.environ["OHHIP_DEVICE"] = str(local_rank)
-    W, H = (int(v) for v in args.frames_size.split("x"))
-    # syntax statistics close to an encoder's random-access output (tools/bench_decode.py --natural)
-    kw = dict(gop="random_access", nframes=args.frames_pictures, seed=4242, width=W, height=(H + 7) // 8 * 8, bit_depth=args.frames_bit_depth, log2_ctb=6,
-              init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
-                                     split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
+        torch.cuda.set_device(dev)
+        os.environ["OHHIP_DEVICE"] = str(dev)
+    W, H = size
+    kw = dict(gop="random_access", nframes=pictures, seed=4242, width=W, height=(H + 7) // 8 * 8, bit_depth=bit_depth, log2_ctb=6, nonref_leaves=1, **NATURAL)
     aus, _ = ps.generate(ps.StreamParams(**kw))
-
-    port = int(os.environ.get("MASTER_PORT", "29500"))
+    port = port or int(os.environ.get("MASTER_PORT", "29500"))
     passes = [0]
+    wire_ranks = [None]
 
     def make_exchange(d):
         if world <= 1:
             return None
-        if args.frames_python_transport:
+        if python_transport:
             return D.FrameExchange(d.product_lib())
         # the native transport: ncclBroadcast over xGMI (one GPU per rank), or TCP between ranks sharing GPU 0.  A fresh rendezvous per pass.
         passes[0] += 1
-        if args.frames_one_gpu:
+        if one_gpu:
             return D.NativeFrameTransport(d.product_lib(), rank, world, 0, D.NativeFrameTransport.WIRE_SOCKETS, f"127.0.0.1:{port + 100 + 16 * (passes[0] % 50)}")
         return D.NativeFrameTransport(d.product_lib(), rank, world, local_rank, D.NativeFrameTransport.WIRE_RCCL, f"/tmp/ohevc_frames_rccl_id_{port}_{passes[0]}")
 
-    def one_pass():
+    def one_pass(exchange=True, digests=None):
         with ps.Decoder("hip") as d:
-            ex = make_exchange(d)
+            ex = make_exchange(d) if exchange else None
             if ex is not None:
                 d.frames_mode(ex.mode)
             n = 0
+
+            def took(pic):
+                if digests is not None and (ex is None or d.frame_is_local()):
+                    digests[len(digests_seen)] = [zlib.crc32(pl.tobytes()) for pl in pic]
+                digests_seen.append(1)
+            digests_seen = []
             for i, au in enumerate(aus):
-                n += d.decode(au, i + 1) is not None
-            while d.flush_one() is not None:
+                pic = d.decode(au, i + 1)
+                if pic is not None:
+                    n += 1
+                    took(pic)
+            while True:
+                pic = d.flush_one()
+                if pic is None:
+                    break
                 n += 1
+                took(pic)
             if ex is not None:
                 ex.finish()
                 d.frames_mode(None)
@@ -314,32 +422,100 @@ def frames_mode(args):
         if on_gpu:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    base = None
+    if baseline and world > 1:
+        want = [{}]
+        if rank == 0:
+            one_pass(exchange=False)                                   # start-up of the library, the kernels' first launches
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                nb, _ = one_pass(exchange=False)
+            tb = time.perf_counter() - t0
+            one_pass(exchange=False, digests=want[0])
+            base = {"fps": round(nb * steps / tb, 2), "mpixel_per_s": round(nb * W * H * steps / tb / 1e6, 1), "ms_per_step": round(tb / steps * 1e3, 2),
+                    "note": "rank 0 alone, no exchange, the other ranks waiting: the N = 1 value of this stream on this box"}
+        dist.broadcast_object_list(want, src=0)
+        mine = {}
+        one_pass(digests=mine)                                         # (also the first warm-up pass of the N-rank configuration)
+        bad = [k for k, v in mine.items() if want[0].get(k) != v]
+        counts = [None] * world
+        dist.all_gather_object(counts, (len(mine), len(bad)))
+        if rank == 0:
+            base["pictures_checked"] = sum(c[0] for c in counts)
+            base["pictures_differing"] = sum(c[1] for c in counts)
+    for _ in range(warmup):
         one_pass()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         npics, stats = one_pass()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu and not args.frames_one_gpu else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank != 0:
+        return None
+    exchanged = stats.get("published", 0) + stats.get("subscribed", 0)
+    out = {
+        "metric": "decoded Mpixels/s (fps x W x H), whole decoder, frame-parallel over the ranks",
+        "value": round(npics * W * H * steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "fps": round(npics * steps / elapsed, 2),
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u%d pixels, int16 coefficients" % (16 if bit_depth > 8 else 8), "data": "synthetic Annex-B stream (oracle/pystream.py, seed 4242)",
+        "config": {"workload": f"{W}x{kw['height']} {bit_depth}-bit random-access stream (encoder-like statistics, {sum(map(len, aus)) // len(aus)} bytes/picture), {npics} pictures per "
+                               f"step, reference front end on the host cores + HIP back end, pictures owned round-robin by decoding order",
+                   "parallelism": f"frame-parallel over {world} process(es)", "one_gpu": bool(one_gpu and world > 1),
+                   "transport": "none (one rank)" if world <= 1 else "python (torch.distributed)" if python_transport else
+                                "native (include/ohevc_frames.h: " + ("TCP, host-staged" if one_gpu else "ncclBroadcast, device memory") + ")"},
+        # rank 0's view of the last timed pass: pictures it published / subscribed to, bytes through the wire per exchanged picture, the
+        # communicator's size as the wire reports it (ncclCommCount; the connected peers + 1 of the sockets wire)
+        "exchange": dict(stats, pictures_exchanged=exchanged, bytes_per_exchanged_picture=int(stats.get("bytes", 0) / exchanged) if exchanged else 0),
+        "wire_ranks": stats.get("wire_ranks"),
+    }
+    if base is not None:
+        out["one_rank"] = base
+        out["speedup_vs_one_rank"] = round(out["fps"] / base["fps"], 3) if base["fps"] else None
+        out["bit_exact"] = base["pictures_differing"] == 0 and base["pictures_checked"] == npics
+    return out
+
+
+def frames_mode(args):
+    """bench.py --mode frames: the frame-parallel decoder alone (frames_leg), one JSON line on rank 0"""
+    from openhevc_amd import dist as D
+    rank, world = D.init_from_env("gloo" if args.frames_one_gpu else None)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    W, H = (int(v) for v in args.frames_size.split("x"))
+    out = frames_leg(rank, world, local_rank, args.frames_one_gpu, (W, H), args.frames_bit_depth, args.frames_pictures, args.steps, args.warmup,
+                     python_transport=args.frames_python_transport, baseline=args.frames_baseline)
     if rank == 0:
-        print(json.dumps({
-            "metric": "decoded Mpixels/s (fps x W x H), whole decoder, frame-parallel over the ranks",
-            "value": round(npics * W * H * args.steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "fps": round(npics * args.steps / elapsed, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u%d pixels, int16 coefficients" % (16 if args.frames_bit_depth > 8 else 8), "data": "synthetic Annex-B stream (oracle/pystream.py, seed 4242)",
-            "config": {"workload": f"{W}x{H} {args.frames_bit_depth}-bit random-access stream, {npics} pictures per step, reference front end on the host "
-                                   f"cores + HIP back end, pictures owned round-robin by decoding order", "parallelism": f"frame-parallel over {world} process(es)",
-                       "exchange": stats, "one_gpu": bool(args.frames_one_gpu),
-                       "transport": "python (torch.distributed)" if args.frames_python_transport else "native (include/ohevc_frames.h: " + ("TCP, host-staged" if args.frames_one_gpu else "ncclBroadcast, device memory") + ")"},
-        }), flush=True)
+        print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def frames_child(args, rank, world, local_rank, one_gpu, timeout_s=600):
+    """BASELINE config 5 (8K Main10, frame-parallel over the GPUs) next to the kernel bench, in a process of its own per rank: a wire that
+    hangs or dies (the RCCL path has never met a second GPU: DESIGN.md 6) costs the `frames` object, not the line.  Every rank calls this at
+    the same point; returns rank 0's JSON object (None elsewhere)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 7
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               OHEVC_DIST_TIMEOUT_SECONDS="300")
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "frames", "--gpus", str(world), "--frames-size", args.frames_size, "--frames-bit-depth", str(args.frames_bit_depth),
+           "--frames-pictures", str(args.frames_pictures), "--steps", str(args.frames_steps), "--warmup", "1", "--frames-baseline"] + (["--frames-one-gpu"] if one_gpu else [])
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the frame-parallel leg did not finish within {timeout_s} s"} if rank == 0 else None
+    if rank != 0:
+        return None
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"rc {r.returncode}: " + " | ".join(r.stderr.strip().splitlines()[-3:])[:600]}
+    return json.loads(lines[-1])
 
 
 def main():
@@ -349,20 +525,25 @@ def main():
     import torch
     from openhevc_amd import lib as L
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_spawn(args)                 # a bare `python bench.py --gpus N`: one rank per GPU, started here
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    L.check(L.load_library().ohevc_set_device(local_rank))
+    # fewer GPUs than ranks (the 1-GPU test box): every rank on GPU 0, gloo for the barrier and the clock - RCCL refuses two ranks on one device
+    one_gpu = bool(args.frames_one_gpu or (world > 1 and torch.cuda.device_count() < world))
+    device = 0 if one_gpu else local_rank
+    torch.cuda.set_device(device)
+    L.check(L.load_library().ohevc_set_device(device))
     if os.environ.get("OHEVC_TU_VARIANT"):      # A/B of the residual kernel's forms under the bench's own conditions (ohevc_debug.h)
         L.load_library().ohevc_debug_set_tu_variant(int(os.environ["OHEVC_TU_VARIANT"]))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     log2, bd = args.log2, args.bit_depth
     n = 1 << log2
@@ -384,6 +565,8 @@ def main():
     coeff_bytes = nblk * n * n * 2
     free_b, _total_b = torch.cuda.mem_get_info()
     n_planes = max(1, min(args.steps, (free_b - 2 * coeff_bytes - (12 << 30)) // plane_bytes))
+    if one_gpu and world > 1:                   # the ranks share one device's memory
+        n_planes = max(1, min(n_planes, 16 // world))
 
     def fill(t):
         if bd == 8:
@@ -485,7 +668,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
@@ -510,6 +693,18 @@ def main():
         except Exception:
             traffic = None
 
+    frames = None
+    if not args.no_frames and (world > 1 or not args.no_decode):
+        # BASELINE config 5's structure next to the kernel figure: the whole decoder on an 8K Main10 stream, frame-parallel over the ranks, planes
+        # and motion fields over the transport's wire (RCCL / xGMI with one GPU per rank) - in child processes (frames_child), after this
+        # process has given its device memory back
+        plane_ring = plane_sets = coeffs = d_jobs = None
+        torch.cuda.empty_cache()
+        if dist is not None:
+            dist.barrier()
+        frames = frames_child(args, rank, world, local_rank, one_gpu)
+        if dist is not None:
+            dist.barrier()
     if rank == 0:
         out = {
             "metric": "decoded Mpixels/s (fps x W x H) + per-kernel GB/s vs HBM roofline",
@@ -523,7 +718,8 @@ def main():
             "config": {"workload": f"synthetic batched {n}x{n} int16 IDCT+add (BASELINE config 2), {nblk} blocks/GPU, {bd}-bit, "
                                    f"16384-wide tiled plane (a job's y is 16 bits: the 4096-wide plane of SURVEY 8d would be 262144 rows), "
                                    f"coeffs U[-1024,1023]{' top-left 8x8 only' if args.sparse else ''}, seed 1234, jobs in raster order",
-                       "blocks_per_gpu": nblk, "block": n, "bit_depth": bd, "parallelism": f"blocks sharded over {world} GPU(s), no collective"},
+                       "blocks_per_gpu": nblk, "block": n, "bit_depth": bd, "parallelism": f"blocks sharded over {world} GPU(s), no collective" + (f" - {world} ranks time-sharing ONE GPU (the box has fewer GPUs than ranks): a launcher / protocol run, not a scaling result" if one_gpu and world > 1 else ""),
+                       "one_gpu": bool(one_gpu and world > 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": L.load_library().ohevc_tu_kernel_name(bd, log2, L.TU_IDCT).decode(),
@@ -545,8 +741,10 @@ def main():
             # the ring (most of the device's memory) goes back to the driver NOW, and the host-only CPU baseline runs in between: the decode
             # block used to start right behind the release, and its first stream ran 10-25 % slower than the same stream a second later
             # (frame-end hook 0.86 instead of 0.54 ms) - the unmapping of ~250 GB goes on in the background for a while
-            del plane_ring, plane_sets, coeffs
+            plane_ring = plane_sets = coeffs = None
             torch.cuda.empty_cache()
+        if frames is not None:
+            out["frames"] = frames
         if world == 1 and not args.no_kernels:
             # every other kernel family of the hot path out of HBM-resident rings (>= 1 GiB each), 8 and 10 bit, each row with a sampled bit-exact
             # check against the CPU oracle: tools/kernel_rows.py (timed with HIP events on the launch stream, like the headline)

@@ -76,6 +76,15 @@ int  ohevc_host_unpin(ohevc_ctx *ctx, void *ptr, size_t bytes);
  * calls are ordered against the frames of every context of the store and return when the copy is complete. */
 int  ohevc_pic_export(ohevc_ctx *ctx, int slot, int plane, void *device_dst, size_t bytes);
 int  ohevc_pic_import(ohevc_ctx *ctx, int slot, int plane, const void *device_src, size_t bytes);
+/* The same by CTU-row bands (the reference's frame threads publish a picture row by row, ff_thread_report_progress at the end of every CTB row,
+ * hevc_filter.c / hevc.c:2934-2937, and a dependent picture waits for the rows its motion vectors reach, hevc.c:1951-1958): rows
+ * [row0, row0 + rows) of the plane; device_plane_base addresses a buffer laid out like the WHOLE plane, the band lies at row0 * stride in it.
+ * first != 0 on the first import of a picture: it orders the slot's memory against its earlier readers / writers. */
+int  ohevc_pic_export_rows(ohevc_ctx *ctx, int slot, int plane, int row0, int rows, void *device_plane_base);
+int  ohevc_pic_import_rows(ohevc_ctx *ctx, int slot, int plane, int row0, int rows, const void *device_plane_base, int first);
+/* The deepest LUMA row of reference picture `slot` that the motion compensation recorded for the open frame reads, filter taps included
+ * (-1: the frame does not predict from it): how much of a remote picture must have arrived before the frame launches. */
+int  ohevc_frame_ref_reach(ohevc_ctx *ctx, int slot);
 int  ohevc_pic_info(ohevc_ctx *ctx, int slot, int *width, int *height, int *chroma_format_idc, int *bit_depth);
 
 /* SHVC: resample picture src_slot (a base-layer picture of the store) into picture dst_slot, the enhancement layer's

@@ -44,6 +44,10 @@ typedef struct ohhip_frames_mode {
     /* the decoder dropped the buffer of remote picture `index` (its DPB entry was recycled) or will never look at it again: wait for what
      * is still in flight for it and free the staging memory.  May be NULL. */
     int (*release)(void *user, int index);
+    /* like await_planes, but only rows 0 .. last_luma_row of the picture have to be in the store when it returns (last_luma_row < 0 or beyond the
+     * picture: all of it) - the wait of hevc_await_progress (hevc.c:1951-1958) for the rows a picture's motion vectors reach, at the granularity
+     * of the transport's bands.  Calls for one picture may come with growing row numbers.  May be NULL: the hooks then use await_planes. */
+    int (*await_rows)(void *user, int index, ohevc_ctx *ctx, int slot, int last_luma_row);
 } ohhip_frames_mode;
 
 enum { OHEVC_FRAMES_WIRE_RCCL = 0, OHEVC_FRAMES_WIRE_SOCKETS = 1 };
@@ -57,6 +61,10 @@ typedef struct ohevc_frames_transport ohevc_frames_transport;
  * rank r listens on port + r of that address only, and a peer must present the run's token (OHEVC_FRAMES_TOKEN, or derived from this string).
  * timeout_s: how long a rank waits for its peers (rendezvous, a connection, a message) before it gives up with an error. */
 int  ohevc_frames_transport_create(ohevc_frames_transport **out, int rank, int world, int device, int wire, const char *rendezvous, int timeout_s);
+/* A picture crosses the wire as its motion field followed by bands of whole CTU rows (at most 8, the default; 1 = whole pictures): the owner
+ * exports band b + 1 while band b is on the wire, a subscriber imports band b while band b + 1 arrives, and await_rows returns as soon as the
+ * bands a dependent picture reaches are in.  Every rank must use the same value; only between pictures (nothing in flight). */
+int  ohevc_frames_transport_set_bands(ohevc_frames_transport *t, int max_bands);
 /* the callback table to hand to ohhip_set_frames_mode (valid until the transport is destroyed) */
 const ohhip_frames_mode *ohevc_frames_transport_mode(ohevc_frames_transport *t);
 /* every collective this rank issued has completed (call on all ranks after the last picture, before destroying) */
@@ -68,7 +76,9 @@ void ohevc_frames_transport_destroy(ohevc_frames_transport *t);
  * (ncclCommInitRank, one ncclGroup of four ncclBroadcast on device memory) on a single GPU (tests/test_dist_gpu.py). */
 int  ohevc_frames_transport_selftest(ohevc_frames_transport *t, ohevc_ctx *ctx, int src_slot, int dst_slot, int root, const void *mvf_in, void *mvf_out,
                                      size_t mvf_bytes);
-typedef struct ohevc_frames_stats { long long published, subscribed, awaited_motion, awaited_planes, released, failed, bytes; } ohevc_frames_stats;
+/* wire_ranks: the size of the communicator as the wire itself reports it - ncclCommCount of the RCCL communicator; 1 + the connected peers
+ * of the sockets wire (not the `world` argument echoed back) */
+typedef struct ohevc_frames_stats { long long published, subscribed, awaited_motion, awaited_planes, released, failed, bytes, wire_ranks, bands_imported; } ohevc_frames_stats;
 int  ohevc_frames_transport_stats(ohevc_frames_transport *t, ohevc_frames_stats *out);
 
 #ifdef __cplusplus

@@ -47,6 +47,7 @@ typedef struct ohhip_buf {
     ohevc_ctx *ctx;            /* the context that is reconstructing (or last reconstructed) this picture */
     /* frame-parallel decoding over processes (hip_frames.h): decoding-order index, owned elsewhere, what has arrived */
     int index, remote, have_motion, have_planes;
+    int have_rows;             /* remote picture: luma rows 0 .. have_rows - 1 are in this process's store (bands of the transport, await_rows) */
     /* the page-locked allocations behind this frame (AVFrame.buf[i]): unpinned when the address comes back with another geometry */
     void *pin_ptr[3];
     size_t pin_bytes[3];
@@ -409,6 +410,7 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
         /* a picture that is not exchanged has nothing to wait for - H.265 8.3.2 only bars it from the Curr sets, a stream may keep it in
          * a Foll set of later pictures */
         be->bufs[i].have_motion = be->bufs[i].have_planes = !be->bufs[i].remote || !exchanged;
+        be->bufs[i].have_rows = 0;
         if (!exchanged)
             be->bufs[i].index = -1;                  /* (nothing to release either) */
         if (be->bufs[i].remote) {
@@ -1034,7 +1036,7 @@ static int frames_await_planes(ohhip_backend *be, HEVCContext *s)
     for (t = 0; t < NB_RPS_TYPE; t++)
         for (k = 0; k < s->rps[t].nb_refs; k++) {
             const HEVCFrame *ref = s->rps[t].ref[k];
-            int i, index = -1, slot = -1;
+            int i, index = -1, slot = -1, have = 0, height = 0, need, bi = -1;
             if (t != ST_CURR_BEF && t != ST_CURR_AFT && t != LT_CURR)
                 continue;
             if (!ref || ref == s->ref || !ref->frame || !ref->frame->data[0])
@@ -1043,15 +1045,36 @@ static int frames_await_planes(ohhip_backend *be, HEVCContext *s)
             for (i = 0; i < be->nbufs; i++)
                 if (be->bufs[i].data0 == ref->frame->data[0] && be->bufs[i].poc == ref->poc && be->bufs[i].seq == ref->sequence &&
                     be->bufs[i].remote && !be->bufs[i].have_planes) {
-                    be->bufs[i].have_planes = 1;
+                    bi = i;
                     index = be->bufs[i].index;
                     slot = be->bufs[i].slot;
+                    have = be->bufs[i].have_rows;
+                    height = be->bufs[i].h;
                 }
             pthread_mutex_unlock(&be->lock);
-            if (index >= 0 && be->fm.await_planes(be->fm.user, index, t_ctx, slot) != 0) {
+            if (index < 0)
+                continue;
+            /* With a transport that moves pictures in bands of CTU rows (await_rows), wait for the rows this picture's motion compensation reads
+             * - the recorder kept the deepest one per reference picture, filter taps included - not for the whole picture: what
+             * hevc_await_progress (hevc.c:1951-1958) does per prediction block.  A picture of the Curr sets nothing was predicted from is
+             * not waited for at all (a later picture that does predict from it asks again). */
+            need = be->fm.await_rows ? ohevc_frame_ref_reach(t_ctx, slot) : height;
+            if (need < 0 || need < have)
+                continue;
+            if (need >= height - 1)
+                need = -1;                                   /* all of it */
+            if ((be->fm.await_rows ? be->fm.await_rows(be->fm.user, index, t_ctx, slot, need) : be->fm.await_planes(be->fm.user, index, t_ctx, slot)) != 0) {
                 fprintf(stderr, "ohhip: the planes of remote picture %d did not arrive: %s\n", index, ohevc_last_error());
                 return -1;
             }
+            pthread_mutex_lock(&be->lock);
+            if (be->bufs[bi].index == index) {
+                if (need < 0)
+                    be->bufs[bi].have_planes = 1;
+                else
+                    be->bufs[bi].have_rows = need + 1;
+            }
+            pthread_mutex_unlock(&be->lock);
         }
     return 0;
 }

@@ -201,6 +201,8 @@ struct Rec {
     int nstat[5] = {};                // tu, mc, intra, dbk, sao calls
     int64_t alg = 0;                  // algorithmic bytes of the recorded jobs (ohevc_frame_stats.alg_bytes)
     struct { int level = -1, index = 0, plane = 0, x = 0, y = 0, log2 = 0; } last_intra;   // the most recent intra job of this recorder (levels form)
+    int16_t reach[128];               // [reference slot]: the deepest LUMA row of that picture the recorded motion compensation reads, -1: none (ohevc_frame_ref_reach)
+    Rec() { for (int16_t &v : reach) v = -1; }
 };
 
 struct ohevc_ctx : Rec {
@@ -796,6 +798,67 @@ extern "C" int ohevc_pic_import(ohevc_ctx *c, int slot, int plane, const void *d
     return OHEVC_OK;
 }
 
+// Row ranges of the two calls above (band-chunked exchange, include/ohevc_frames.h): rows [row0, row0 + rows) of the plane, the buffer
+// laid out like the whole plane (the band sits at row0 * stride).  The first export of a picture is the one that waits for its device
+// work; the first import of a picture (first != 0) is the one that orders the slot's memory against its earlier users.
+extern "C" int ohevc_pic_export_rows(ohevc_ctx *c, int slot, int plane, int row0, int rows, void *device_plane_base)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && device_plane_base != nullptr, "bad argument");
+    const ohevc_plane &pl = p->planes[plane];
+    OHEVC_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= pl.height, "row range outside the plane");
+    if (c->dry || rows == 0) return OHEVC_OK;
+    {
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+            set_error("picture %d was never completed by its decoding thread", slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+    }
+    const size_t off = (size_t)row0 * pl.stride;
+    OHEVC_HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(device_plane_base) + off, static_cast<const unsigned char *>(pl.data) + off, (size_t)rows * pl.stride,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_pic_import_rows(ohevc_ctx *c, int slot, int plane, int row0, int rows, const void *device_plane_base, int first)
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && device_plane_base != nullptr, "bad argument");
+    const ohevc_plane &pl = p->planes[plane];
+    OHEVC_REQUIRE(row0 >= 0 && rows >= 0 && row0 + rows <= pl.height, "row range outside the plane");
+    if (c->dry) return OHEVC_OK;
+    if (first) {
+        std::lock_guard<std::mutex> g(c->store->m);
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+        for (hipEvent_t e : p->readers) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
+        p->readers.clear();
+        p->written = nullptr;
+        p->failed = false;
+    }
+    if (rows == 0) return OHEVC_OK;
+    const size_t off = (size_t)row0 * pl.stride;
+    OHEVC_HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(pl.data) + off, static_cast<const unsigned char *>(device_plane_base) + off, (size_t)rows * pl.stride,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+
+// The deepest luma row of reference picture `slot` that the motion compensation recorded for the open frame reads (-1: none of it).
+extern "C" int ohevc_frame_ref_reach(ohevc_ctx *c, int slot)
+{
+    if (!c || slot < 0 || slot >= 128) return -1;
+    int reach = c->reach[slot];
+    if (!c->side.empty()) {
+        std::lock_guard<std::mutex> g(c->side_m);
+        for (auto &sd : c->side) reach = std::max(reach, (int)sd.second->reach[slot]);
+    }
+    return reach;
+}
+
 extern "C" int ohevc_pic_planes(ohevc_ctx *c, int slot, ohevc_plane out[3])
 {
     Picture *p = get_pic(c, slot);
@@ -923,6 +986,7 @@ static void clear_rec(Rec &r)
     }
     r.max_level = -1;
     r.last_intra.level = -1;
+    for (int16_t &v : r.reach) v = -1;
 }
 
 // Fold what the other threads recorded into the context's own recorder (called by the thread that runs the frame, after
@@ -1160,6 +1224,18 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
     {
         const int P = p->bd > 8 ? 2 : 1, T = job->plane ? 4 : 8;
         r.alg += (int64_t)P * (job->w + T - 1) * (job->h + T - 1) * ((job->flags & OHEVC_MC_BI) ? 2 : 1) + (int64_t)P * job->w * job->h;
+        // the deepest reference row the block's filter taps touch (luma: 4 rows below the block, chroma: 2), in luma rows; rows beyond the
+        // picture are the clamped last row.  What a frame-parallel subscriber has to have received before this picture launches
+        // (hevc_await_progress waits for y0 + (mv.y >> 2) + nPbH + 9, hevc.c:1951-1958).
+        const int vs = (job->plane && p->planes[0].height > p->planes[job->plane].height) ? 1 : 0;
+        const int below = job->plane ? 2 : 4;
+        auto note = [&](int slot, int sy) {
+            int row = ((sy + job->h + below) << vs) + vs;
+            row = row < 0 ? 0 : row > 32767 ? 32767 : row;
+            if ((unsigned)slot < 128u && row > r.reach[slot]) r.reach[slot] = (int16_t)row;
+        };
+        note(job->ref0, job->sy0);
+        if (job->flags & OHEVC_MC_BI) note(job->ref1, job->sy1);
     }
     r.nstat[1]++;
     return OHEVC_OK;

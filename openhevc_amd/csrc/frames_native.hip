@@ -50,6 +50,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclUniqueId *) = nullptr;
     int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommCount)(NcclComm, int *) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     int (*GroupStart)(void) = nullptr;
     int (*GroupEnd)(void) = nullptr;
@@ -61,6 +62,7 @@ struct Rccl {
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));      // rccl.h: ncclCommCount(comm, int *count)
         Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
@@ -212,16 +214,31 @@ struct SockWire {
     }
 };
 
+// A picture travels as 1 + nb messages, in this order on every rank: the motion-field message (HEVCFrame.tab_mvf + 8 status bytes - what a
+// dependent picture needs FIRST, when its parse starts), then nb bands of CTU rows, each band = the three planes' row ranges.  The reference's
+// frame threads publish a picture CTB row by CTB row (ff_thread_report_progress, hevc.c:2934-2937) and a dependent picture waits for the rows its
+// motion vectors reach (hevc_await_progress, hevc.c:1951-1958: y0 + mv.y + nPbH + 9); here a band is the unit of both.
+constexpr int kMaxBands = 8;
 struct Msg {
     int index = -1, root = 0;
     bool outgoing = false, planes_done = false, motion_done = false;
     size_t plane_bytes[3] = {0, 0, 0}, mvf_bytes = 0;
+    int nb = 1;                                // bands
+    int row0[3][kMaxBands + 1] = {};           // band b of plane c = rows [row0[c][b], row0[c][b + 1])
+    int stride[3] = {0, 0, 0};
+    int luma_rows = 0;
+    int bands_imported = 0;                    // subscriber: bands 0 .. bands_imported - 1 are in the picture store
     void *d_plane[3] = {nullptr, nullptr, nullptr};
     void *d_mvf = nullptr;                     // RCCL: the motion-field message in device memory
     unsigned char *h_mvf = nullptr;            // pinned: the motion-field message, mvf_bytes + 8 status bytes
     unsigned char *h_plane[3] = {nullptr, nullptr, nullptr};      // sockets: host staging of the planes
-    hipEvent_t ev = nullptr;                   // RCCL: the picture's collectives (and the copy into h_mvf) are done
-    SockOp op[4];                              // sockets: planes 0..2, motion field
+    hipEvent_t ev_mvf = nullptr;               // RCCL: the motion-field broadcast (and, on a subscriber, its copy into h_mvf) is done
+    hipEvent_t ev_band[kMaxBands] = {};        // RCCL: band b's three broadcasts are done
+    SockOp op_mvf;                             // sockets
+    SockOp op_band[kMaxBands][3];
+    size_t band_off(int c, int b) const { return (size_t)row0[c][b] * (size_t)stride[c]; }
+    size_t band_bytes(int c, int b) const { return (size_t)(row0[c][b + 1] - row0[c][b]) * (size_t)stride[c]; }
+    int band_of_luma_row(int row) const { int b = 0; while (b + 1 < nb && row >= row0[0][b + 1]) b++; return b; }
 };
 
 }  // namespace
@@ -239,6 +256,7 @@ struct ohevc_frames_transport {
     std::deque<Msg *> outgoing;                // published pictures whose transfers may still be in flight
     std::vector<std::pair<size_t, void *>> dev_pool, host_pool;
     bool broken = false;
+    int max_bands = kMaxBands;                 // 1: whole pictures (OHEVC_FRAMES_BANDS / ohevc_frames_transport_set_bands)
 
     void *dev_alloc(size_t n)
     {
@@ -268,59 +286,107 @@ struct ohevc_frames_transport {
             usleep(50);
         }
     }
-    // the message's transfers are complete on this rank (outgoing: sent; incoming: arrived)
+    // band b (b < 0: the motion-field message) of the picture is complete on this rank (outgoing: sent; incoming: arrived)
+    bool part_complete(Msg *m, int b)
+    {
+        if (wire == OHEVC_FRAMES_WIRE_RCCL) return wait_event(b < 0 ? m->ev_mvf : m->ev_band[b]);
+        if (b < 0) return sock.wait(&m->op_mvf);
+        bool ok = true;
+        for (int c = 0; c < 3; c++) if (m->op_band[b][c].buf) ok = sock.wait(&m->op_band[b][c]) && ok;
+        return ok;
+    }
+    // ... all of it
     bool complete(Msg *m)
     {
-        if (wire == OHEVC_FRAMES_WIRE_RCCL) return wait_event(m->ev);
-        bool ok = true;
-        for (SockOp &o : m->op) if (o.buf) ok = sock.wait(&o) && ok;
+        bool ok = part_complete(m, -1);
+        for (int b = 0; b < m->nb; b++) ok = part_complete(m, b) && ok;
         return ok;
+    }
+    bool is_complete_now(Msg *m)
+    {
+        if (wire == OHEVC_FRAMES_WIRE_RCCL) {
+            if (hipEventQuery(m->ev_band[m->nb - 1]) == hipSuccess) return true;
+            (void)hipGetLastError();
+            return false;
+        }
+        std::lock_guard<std::mutex> g(sock.m);
+        bool done = m->op_mvf.done;
+        for (int c = 0; c < 3; c++) done = done && (!m->op_band[m->nb - 1][c].buf || m->op_band[m->nb - 1][c].done);
+        return done;                                               // (the wire is in order: the last band done = everything done)
     }
     void recycle(Msg *m)
     {
         for (int c = 0; c < 3; c++) { dev_free(m->plane_bytes[c], m->d_plane[c]); host_free(m->plane_bytes[c], m->h_plane[c]); m->d_plane[c] = nullptr; m->h_plane[c] = nullptr; }
         dev_free(m->mvf_bytes + 8, m->d_mvf); m->d_mvf = nullptr;
         host_free(m->mvf_bytes + 8, m->h_mvf); m->h_mvf = nullptr;
-        if (m->ev) { (void)hipEventDestroy(m->ev); m->ev = nullptr; }
+        if (m->ev_mvf) { (void)hipEventDestroy(m->ev_mvf); m->ev_mvf = nullptr; }
+        for (hipEvent_t &e : m->ev_band) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         delete m;
     }
-    // staging of one picture: plane sizes from the store, buffers from the pools
+    // staging of one picture: plane sizes and the band grid from the store, buffers from the pools
     Msg *stage(int index, ohevc_ctx *ctx, int slot, size_t mvf_bytes, int root)
     {
         ohevc_plane pl[3];
         if (ohevc_pic_planes(ctx, slot, pl) != OHEVC_OK) return nullptr;
         Msg *m = new Msg();
         m->index = index; m->root = root; m->mvf_bytes = mvf_bytes;
+        // bands of whole 64-row CTU rows, at most kMaxBands of them (8K: 68 CTU rows -> 8 bands of 9 rows, 12 MB each at 10 bit); max_bands 1 =
+        // the whole picture as one band
+        const int ctu_rows = std::max(1, (pl[0].height + 63) / 64);
+        const int limit = std::max(1, std::min(max_bands, kMaxBands));
+        const int per_band = (ctu_rows + limit - 1) / limit;
+        m->nb = (ctu_rows + per_band - 1) / per_band;
+        m->luma_rows = pl[0].height;
         bool ok = true;
         for (int c = 0; c < 3; c++) {
             m->plane_bytes[c] = (size_t)pl[c].stride * pl[c].height;
+            m->stride[c] = pl[c].stride;
+            const int vs = (c && pl[0].height > pl[c].height) ? 1 : 0;
+            for (int b = 0; b <= m->nb; b++) m->row0[c][b] = b == m->nb ? pl[c].height : std::min(pl[c].height, (b * per_band * 64) >> vs);
             ok = ok && (m->d_plane[c] = dev_alloc(m->plane_bytes[c])) != nullptr;
             if (wire == OHEVC_FRAMES_WIRE_SOCKETS) ok = ok && (m->h_plane[c] = host_alloc(m->plane_bytes[c])) != nullptr;
         }
         ok = ok && (m->h_mvf = host_alloc(mvf_bytes + 8)) != nullptr;
         if (wire == OHEVC_FRAMES_WIRE_RCCL) {
             ok = ok && (m->d_mvf = dev_alloc(mvf_bytes + 8)) != nullptr;
-            ok = ok && hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&m->ev_mvf, hipEventDisableTiming) == hipSuccess;
+            for (int b = 0; b < m->nb; b++) ok = ok && hipEventCreateWithFlags(&m->ev_band[b], hipEventDisableTiming) == hipSuccess;
         }
         if (!ok) { set_error("frames transport: staging of picture %d failed (out of memory?)", index); recycle(m); return nullptr; }
         return m;
     }
-    // issue the picture's broadcasts (same sequence on every rank)
-    bool post(Msg *m)
+    // issue the picture's motion-field message (same sequence on every rank: post_mvf, then post_band 0 .. nb - 1)
+    bool post_mvf(Msg *m)
     {
-        stats.bytes += (long long)(m->plane_bytes[0] + m->plane_bytes[1] + m->plane_bytes[2] + m->mvf_bytes + 8);
+        stats.bytes += (long long)(m->mvf_bytes + 8);
+        if (wire == OHEVC_FRAMES_WIRE_RCCL) {
+            const int rc = rccl.Broadcast(m->d_mvf, m->d_mvf, m->mvf_bytes + 8, kNcclUint8, m->root, comm, stream);
+            if (rc != 0) { set_error("frames transport: ncclBroadcast failed: %s", rccl.GetErrorString(rc)); return false; }
+            if (!m->outgoing && hipMemcpyAsync(m->h_mvf, m->d_mvf, m->mvf_bytes + 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+            return hipEventRecord(m->ev_mvf, stream) == hipSuccess;
+        }
+        m->op_mvf = SockOp{ m->h_mvf, m->mvf_bytes + 8, m->root, false };
+        sock.post(&m->op_mvf);
+        return true;
+    }
+    bool post_band(Msg *m, int b)
+    {
+        for (int c = 0; c < 3; c++) stats.bytes += (long long)m->band_bytes(c, b);
         if (wire == OHEVC_FRAMES_WIRE_RCCL) {
             int rc = rccl.GroupStart();
-            for (int c = 0; c < 3 && rc == 0; c++) rc = rccl.Broadcast(m->d_plane[c], m->d_plane[c], m->plane_bytes[c], kNcclUint8, m->root, comm, stream);
-            if (rc == 0) rc = rccl.Broadcast(m->d_mvf, m->d_mvf, m->mvf_bytes + 8, kNcclUint8, m->root, comm, stream);
+            for (int c = 0; c < 3 && rc == 0; c++) {
+                if (!m->band_bytes(c, b)) continue;
+                unsigned char *at = static_cast<unsigned char *>(m->d_plane[c]) + m->band_off(c, b);
+                rc = rccl.Broadcast(at, at, m->band_bytes(c, b), kNcclUint8, m->root, comm, stream);
+            }
             const int rc2 = rccl.GroupEnd();
             if (rc != 0 || rc2 != 0) { set_error("frames transport: ncclBroadcast failed: %s", rccl.GetErrorString(rc ? rc : rc2)); return false; }
-            if (!m->outgoing && hipMemcpyAsync(m->h_mvf, m->d_mvf, m->mvf_bytes + 8, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
-            return hipEventRecord(m->ev, stream) == hipSuccess;
+            return hipEventRecord(m->ev_band[b], stream) == hipSuccess;
         }
-        for (int c = 0; c < 3; c++) { m->op[c] = SockOp{ m->h_plane[c], m->plane_bytes[c], m->root, false }; sock.post(&m->op[c]); }
-        m->op[3] = SockOp{ m->h_mvf, m->mvf_bytes + 8, m->root, false };
-        sock.post(&m->op[3]);
+        for (int c = 0; c < 3; c++) {
+            m->op_band[b][c] = SockOp{ m->band_bytes(c, b) ? m->h_plane[c] + m->band_off(c, b) : nullptr, m->band_bytes(c, b), m->root, true };
+            if (m->op_band[b][c].buf) sock.post(&m->op_band[b][c]);
+        }
         return true;
     }
     void reap_outgoing(bool all)
@@ -328,16 +394,29 @@ struct ohevc_frames_transport {
         while (!outgoing.empty()) {
             Msg *m = outgoing.front();
             if (!all) {
-                bool done;
-                if (wire == OHEVC_FRAMES_WIRE_RCCL) done = hipEventQuery(m->ev) == hipSuccess;
-                else { std::lock_guard<std::mutex> g(sock.m); done = m->op[0].done && m->op[1].done && m->op[2].done && m->op[3].done; }
-                if (!done) { (void)hipGetLastError(); break; }
+                if (!is_complete_now(m)) break;
             } else if (!complete(m)) {
                 broken = true;
             }
             outgoing.pop_front();
             recycle(m);
         }
+    }
+    // subscriber: bands [bands_imported, upto] of the picture into the store, each as soon as it has arrived
+    bool import_bands(Msg *m, ohevc_ctx *ctx, int slot, int upto)
+    {
+        for (int b = m->bands_imported; b <= upto; b++) {
+            if (!part_complete(m, b)) { set_error("frames transport: band %d of picture %d did not arrive from rank %d within %d s", b, m->index, m->root, timeout_s); broken = true; return false; }
+            for (int c = 0; c < 3; c++) {
+                const int r0 = m->row0[c][b], nr = m->row0[c][b + 1] - r0;
+                if (wire == OHEVC_FRAMES_WIRE_SOCKETS && nr &&
+                    hipMemcpy(static_cast<unsigned char *>(m->d_plane[c]) + m->band_off(c, b), m->h_plane[c] + m->band_off(c, b), m->band_bytes(c, b), hipMemcpyHostToDevice) != hipSuccess) return false;
+                if (ohevc_pic_import_rows(ctx, slot, c, r0, nr, m->d_plane[c], b == 0) != OHEVC_OK) return false;
+            }
+            m->bands_imported = b + 1;
+            stats.bands_imported++;
+        }
+        return true;
     }
 };
 
@@ -352,21 +431,36 @@ static int cb_publish(void *user, int index, ohevc_ctx *ctx, int slot, const voi
     if (!m) { t->broken = true; return -1; }
     m->outgoing = true;
     memset(m->h_mvf + mvf_bytes, 0, 8);
-    if (failed || !mvf) {
+    // band b leaves the picture store (and, sockets, the device) while band b - 1 is on the wire.  The export of band 0 is the one that waits
+    // for the picture's device work and learns whether it failed: it runs BEFORE the motion-field message, which carries the error mark.
+    auto export_band = [&](int b) {
+        for (int c = 0; c < 3; c++) {
+            const int r0 = m->row0[c][b], nr = m->row0[c][b + 1] - r0;
+            if (ohevc_pic_export_rows(ctx, slot, c, r0, nr, m->d_plane[c]) != OHEVC_OK) return false;
+            if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && nr &&
+                hipMemcpy(m->h_plane[c] + m->band_off(c, b), static_cast<unsigned char *>(m->d_plane[c]) + m->band_off(c, b), m->band_bytes(c, b), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        }
+        return true;
+    };
+    bool bad = failed || !mvf;
+    if (!bad) {
+        memcpy(m->h_mvf, mvf, mvf_bytes);
+        bad = !export_band(0);
+    }
+    if (bad) {
         m->h_mvf[mvf_bytes] = 1;                              // the error mark; the payload is whatever the buffers hold
         t->stats.failed++;
-    } else {
-        memcpy(m->h_mvf, mvf, mvf_bytes);
-        for (int c = 0; c < 3; c++) {
-            if (ohevc_pic_export(ctx, slot, c, m->d_plane[c], m->plane_bytes[c]) != OHEVC_OK) { m->h_mvf[mvf_bytes] = 1; t->stats.failed++; break; }
-            if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && hipMemcpy(m->h_plane[c], m->d_plane[c], m->plane_bytes[c], hipMemcpyDeviceToHost) != hipSuccess) { m->h_mvf[mvf_bytes] = 1; break; }
-        }
     }
-    if (t->wire == OHEVC_FRAMES_WIRE_RCCL && hipMemcpyAsync(m->d_mvf, m->h_mvf, mvf_bytes + 8, hipMemcpyHostToDevice, t->stream) != hipSuccess) { t->recycle(m); t->broken = true; return -1; }
-    if (!t->post(m)) { t->recycle(m); t->broken = true; return -1; }
+    auto give_up = [&] { t->recycle(m); t->broken = true; return -1; };
+    if (t->wire == OHEVC_FRAMES_WIRE_RCCL && hipMemcpyAsync(m->d_mvf, m->h_mvf, mvf_bytes + 8, hipMemcpyHostToDevice, t->stream) != hipSuccess) return give_up();
+    if (!t->post_mvf(m)) return give_up();
+    for (int b = 0; b < m->nb; b++) {
+        if (b && !bad && !export_band(b)) { set_error("frames transport: exporting band %d of picture %d failed", b, index); t->broken = true; }   // (cannot happen after band 0 worked: a device error)
+        if (!t->post_band(m, b)) return give_up();             // every rank issues every band, whatever happened to the picture
+    }
     t->outgoing.push_back(m);
     t->stats.published++;
-    return 0;
+    return t->broken ? -1 : 0;
 }
 
 static int cb_subscribe(void *user, int index, ohevc_ctx *ctx, int slot, size_t mvf_bytes)
@@ -376,19 +470,22 @@ static int cb_subscribe(void *user, int index, ohevc_ctx *ctx, int slot, size_t 
     (void)hipSetDevice(t->device);
     Msg *m = t->stage(index, ctx, slot, mvf_bytes, index % t->world);
     if (!m) { t->broken = true; return -1; }
-    if (!t->post(m)) { t->recycle(m); t->broken = true; return -1; }
+    bool ok = t->post_mvf(m);
+    for (int b = 0; b < m->nb && ok; b++) ok = t->post_band(m, b);
+    if (!ok) { t->recycle(m); t->broken = true; return -1; }
     if (t->pending.count(index)) { t->complete(t->pending[index]); t->recycle(t->pending[index]); }
     t->pending[index] = m;
     t->stats.subscribed++;
     return 0;
 }
 
+// the picture's first message - motion field + status - has arrived and says the owner succeeded
 static Msg *arrived(ohevc_frames_transport *t, int index)
 {
     auto it = t->pending.find(index);
     if (it == t->pending.end()) { set_error("frames transport: picture %d was never subscribed to", index); return nullptr; }
     Msg *m = it->second;
-    if (!t->complete(m)) { set_error("frames transport: picture %d did not arrive from rank %d within %d s", index, m->root, t->timeout_s); t->broken = true; return nullptr; }
+    if (!t->part_complete(m, -1)) { set_error("frames transport: picture %d did not arrive from rank %d within %d s", index, m->root, t->timeout_s); t->broken = true; return nullptr; }
     if (m->h_mvf[m->mvf_bytes] != 0) { set_error("frames transport: picture %d: its owner (rank %d) reported a decoding failure", index, m->root); return nullptr; }
     return m;
 }
@@ -410,25 +507,30 @@ static int cb_await_motion(void *user, int index, void *mvf, size_t mvf_bytes)
     return 0;
 }
 
-static int cb_await_planes(void *user, int index, ohevc_ctx *ctx, int slot)
+// rows 0 .. last_luma_row of remote picture `index` into picture-store slot `slot` (bands already imported are not touched again); once the
+// last band is in, the staging memory goes back to the pools
+static int cb_await_rows(void *user, int index, ohevc_ctx *ctx, int slot, int last_luma_row)
 {
     ohevc_frames_transport *t = static_cast<ohevc_frames_transport *>(user);
     Msg *m = arrived(t, index);
     if (!m) return -1;
+    if (m->planes_done) return 0;
     (void)hipSetDevice(t->device);
-    for (int c = 0; c < 3; c++) {
-        if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && hipMemcpy(m->d_plane[c], m->h_plane[c], m->plane_bytes[c], hipMemcpyHostToDevice) != hipSuccess) return -1;
-        if (ohevc_pic_import(ctx, slot, c, m->d_plane[c], m->plane_bytes[c]) != OHEVC_OK) return -1;
+    const int upto = last_luma_row < 0 || last_luma_row >= m->luma_rows ? m->nb - 1 : m->band_of_luma_row(last_luma_row);
+    if (upto >= m->bands_imported) t->stats.awaited_planes++;
+    if (!t->import_bands(m, ctx, slot, upto)) return -1;
+    if (m->bands_imported == m->nb) {
+        for (int c = 0; c < 3; c++) {                          // the planes are in the store now; the motion field may still be asked for
+            t->dev_free(m->plane_bytes[c], m->d_plane[c]); t->host_free(m->plane_bytes[c], m->h_plane[c]);
+            m->d_plane[c] = nullptr; m->h_plane[c] = nullptr;
+        }
+        m->planes_done = true;
+        drop_if_consumed(t, m);
     }
-    for (int c = 0; c < 3; c++) {                              // the planes are in the store now; the motion field may still be asked for
-        t->dev_free(m->plane_bytes[c], m->d_plane[c]); t->host_free(m->plane_bytes[c], m->h_plane[c]);
-        m->d_plane[c] = nullptr; m->h_plane[c] = nullptr;
-    }
-    m->planes_done = true;
-    t->stats.awaited_planes++;
-    drop_if_consumed(t, m);
     return 0;
 }
+
+static int cb_await_planes(void *user, int index, ohevc_ctx *ctx, int slot) { return cb_await_rows(user, index, ctx, slot, -1); }
 
 static int cb_release(void *user, int index)
 {
@@ -588,7 +690,7 @@ extern "C" int ohevc_frames_transport_create(ohevc_frames_transport **out, int r
     ohevc_frames_transport *t = new ohevc_frames_transport();
     t->rank = rank; t->world = world; t->device = device; t->wire = wire; t->timeout_s = timeout_s > 0 ? timeout_s : 60;
     t->rendezvous = rendezvous ? rendezvous : "";
-    t->mode = ohhip_frames_mode{ rank, world, t, cb_publish, cb_subscribe, cb_await_motion, cb_await_planes, cb_release };
+    t->mode = ohhip_frames_mode{ rank, world, t, cb_publish, cb_subscribe, cb_await_motion, cb_await_planes, cb_release, cb_await_rows };
     auto fail = [&](int rc) { ohevc_frames_transport_destroy(t); return rc; };
     if (hipSetDevice(device) != hipSuccess) { set_error("frames transport: no device %d", device); return fail(OHEVC_ERR_NODEV); }
     if (wire == OHEVC_FRAMES_WIRE_SOCKETS) {
@@ -632,6 +734,14 @@ extern "C" int ohevc_frames_transport_create(ohevc_frames_transport **out, int r
     t->comm = st->comm;
     if (world > 1) rendezvous_cleanup(t);
     *out = t;
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_frames_transport_set_bands(ohevc_frames_transport *t, int max_bands)
+{
+    OHEVC_REQUIRE(t != nullptr && max_bands >= 1, "bad argument");
+    OHEVC_REQUIRE(t->pending.empty() && t->outgoing.empty(), "pictures are in flight: every rank must change the band grid at the same point of the stream");
+    t->max_bands = std::min(max_bands, kMaxBands);
     return OHEVC_OK;
 }
 
@@ -695,11 +805,13 @@ extern "C" int ohevc_frames_transport_selftest(ohevc_frames_transport *t, ohevc_
             memset(m->h_mvf, 0xee, mvf_bytes + 8);                                     // what comes back must come off the wire
         }
     }
-    if (rc == OHEVC_OK && !t->post(m)) rc = OHEVC_ERR_STATE;
+    if (rc == OHEVC_OK && !t->post_mvf(m)) rc = OHEVC_ERR_STATE;
+    for (int b = 0; b < m->nb && rc == OHEVC_OK; b++) if (!t->post_band(m, b)) rc = OHEVC_ERR_STATE;
     if (rc == OHEVC_OK && !t->complete(m)) { set_error("frames transport: the self-test picture did not arrive from rank %d within %d s", root, t->timeout_s); t->broken = true; return OHEVC_ERR_STATE; }
     for (int c = 0; c < 3 && rc == OHEVC_OK; c++) {
         if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && !me && hipMemcpy(m->d_plane[c], m->h_plane[c], m->plane_bytes[c], hipMemcpyHostToDevice) != hipSuccess) rc = OHEVC_ERR_HIP;
-        if (rc == OHEVC_OK) rc = ohevc_pic_import(ctx, dst_slot, c, m->d_plane[c], m->plane_bytes[c]);
+        for (int b = 0; b < m->nb && rc == OHEVC_OK; b++)      // band by band, like a subscriber's await_rows
+            rc = ohevc_pic_import_rows(ctx, dst_slot, c, m->row0[c][b], m->row0[c][b + 1] - m->row0[c][b], m->d_plane[c], b == 0);
     }
     if (rc == OHEVC_OK) {
         if (m->h_mvf[mvf_bytes] != 0) { set_error("frames transport: the self-test message carries an error mark"); rc = OHEVC_ERR_STATE; }
@@ -714,5 +826,13 @@ extern "C" int ohevc_frames_transport_stats(ohevc_frames_transport *t, ohevc_fra
 {
     OHEVC_REQUIRE(t != nullptr && out != nullptr, "null argument");
     *out = t->stats;
+    out->wire_ranks = 0;
+    if (t->wire == OHEVC_FRAMES_WIRE_RCCL) {
+        int n = 0;
+        if (t->comm && t->rccl.CommCount && t->rccl.CommCount(t->comm, &n) == 0) out->wire_ranks = n;
+    } else {
+        out->wire_ranks = 1;
+        for (int f : t->sock.fd) out->wire_ranks += f >= 0;
+    }
     return OHEVC_OK;
 }

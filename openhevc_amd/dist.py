@@ -159,8 +159,10 @@ class _FramesMode(_C.Structure):
     AWAIT_MOTION = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_size_t)
     AWAIT_PLANES = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int)
     RELEASE = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int)
+    AWAIT_ROWS = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_int)
     _fields_ = [("rank", _C.c_int), ("world", _C.c_int), ("user", _C.c_void_p), ("publish", PUBLISH), ("subscribe", SUBSCRIBE),
-                ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES), ("release", RELEASE)]
+                ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES), ("release", RELEASE),
+                ("await_rows", AWAIT_ROWS)]      # NULL here: this Python transport moves whole pictures (the native one has bands)
 
 
 class _Plane(_C.Structure):
@@ -381,7 +383,7 @@ class NativeFrameTransport:
     WIRE_RCCL, WIRE_SOCKETS = 0, 1
 
     class Stats(_C.Structure):
-        _fields_ = [(n, _C.c_longlong) for n in ("published", "subscribed", "awaited_motion", "awaited_planes", "released", "failed", "bytes")]
+        _fields_ = [(n, _C.c_longlong) for n in ("published", "subscribed", "awaited_motion", "awaited_planes", "released", "failed", "bytes", "wire_ranks", "bands_imported")]
 
     def __init__(self, lib, rank, world, device, wire, rendezvous, timeout_s=120):
         self.lib = lib

@@ -3,7 +3,7 @@
  * include/ohevc_frames.h between the processes.  What an application built on openHEVC's C API would do (libOpenHevcInit /
  * libOpenHevcDecode, gpac/modules/openhevc_dec/openHevcWrapper.c:47-155) after linking the drop-in.
  *
- *   frames_host <decoder .so> <product .so> <stream file> <rank> <world> <wire: rccl|sockets> <rendezvous> <device> <out file>
+ *   frames_host <decoder .so> <product .so> <stream file> <rank> <world> <wire: rccl|sockets> <rendezvous> <device> <out file> [max bands]
  *
  * stream file : uint32 count, count x uint32 sizes, then the access units back to back (tests write it from tests/golden/streams.npz).
  * out file    : one line per picture THIS rank reconstructed: "<output position> <fnv64 of plane 0> <plane 1> <plane 2>", then a
@@ -29,7 +29,7 @@ static uint64_t fnv64(const uint8_t *p, size_t n)
 int main(int argc, char **argv)
 {
     int rank = argc > 4 ? atoi(argv[4]) : 0;
-    if (argc != 10) FAIL("usage: frames_host <decoder.so> <product.so> <stream> <rank> <world> <rccl|sockets> <rendezvous> <device> <out>");
+    if (argc != 10 && argc != 11) FAIL("usage: frames_host <decoder.so> <product.so> <stream> <rank> <world> <rccl|sockets> <rendezvous> <device> <out> [max bands]");
     const int world = atoi(argv[5]), device = atoi(argv[8]);
     const int wire = strcmp(argv[6], "rccl") == 0 ? OHEVC_FRAMES_WIRE_RCCL : OHEVC_FRAMES_WIRE_SOCKETS;
 
@@ -42,6 +42,7 @@ int main(int argc, char **argv)
     typedef int (*ohevc_frames_transport_create_fn)(ohevc_frames_transport **, int, int, int, int, const char *, int);
     typedef const ohhip_frames_mode *(*ohevc_frames_transport_mode_fn)(ohevc_frames_transport *);
     typedef int (*ohevc_frames_transport_finish_fn)(ohevc_frames_transport *);
+    typedef int (*ohevc_frames_transport_set_bands_fn)(ohevc_frames_transport *, int);
     typedef void (*ohevc_frames_transport_destroy_fn)(ohevc_frames_transport *);
     typedef int (*ohevc_frames_transport_stats_fn)(ohevc_frames_transport *, ohevc_frames_stats *);
     typedef const char *(*ohevc_last_error_fn)(void);
@@ -54,7 +55,7 @@ int main(int argc, char **argv)
     typedef int (*ohdec_frame_copy_fn)(void *, int, uint8_t *);
     typedef void (*ohdec_close_fn)(void *);
     SYM(prod, ohevc_frames_transport_create); SYM(prod, ohevc_frames_transport_mode); SYM(prod, ohevc_frames_transport_finish);
-    SYM(prod, ohevc_frames_transport_destroy); SYM(prod, ohevc_frames_transport_stats); SYM(prod, ohevc_last_error);
+    SYM(prod, ohevc_frames_transport_set_bands); SYM(prod, ohevc_frames_transport_destroy); SYM(prod, ohevc_frames_transport_stats); SYM(prod, ohevc_last_error);
     SYM(dec, ohdec_open_ex); SYM(dec, ohdec_frames_mode); SYM(dec, ohdec_decode); SYM(dec, ohdec_flush); SYM(dec, ohdec_frame_is_local);
     SYM(dec, ohdec_frame_info); SYM(dec, ohdec_frame_copy); SYM(dec, ohdec_close);
 
@@ -68,6 +69,7 @@ int main(int argc, char **argv)
     if (device >= 0) { char buf[16]; snprintf(buf, sizeof(buf), "%d", device); setenv("OHHIP_DEVICE", buf, 1); }
     ohevc_frames_transport *t = NULL;
     if (ohevc_frames_transport_create(&t, rank, world, device < 0 ? 0 : device, wire, argv[7], 60) != OHEVC_OK) FAIL("transport: %s", ohevc_last_error());
+    if (argc == 11 && ohevc_frames_transport_set_bands(t, atoi(argv[10])) != OHEVC_OK) FAIL("set_bands: %s", ohevc_last_error());
     void *d = ohdec_open_ex(1, 1, 0);
     if (!d) FAIL("ohdec_open failed");
     if (world > 1 && ohdec_frames_mode(d, ohevc_frames_transport_mode(t)) != 0) FAIL("decoder has no frames mode");
@@ -110,8 +112,8 @@ int main(int argc, char **argv)
     const int fin = ohevc_frames_transport_finish(t);
     ohevc_frames_stats st;
     ohevc_frames_transport_stats(t, &st);
-    fprintf(out, "stats pictures %d published %lld subscribed %lld awaited_motion %lld awaited_planes %lld released %lld failed %lld bytes %lld\n", pos, st.published,
-            st.subscribed, st.awaited_motion, st.awaited_planes, st.released, st.failed, st.bytes);
+    fprintf(out, "stats pictures %d published %lld subscribed %lld awaited_motion %lld awaited_planes %lld released %lld failed %lld bytes %lld wire_ranks %lld bands_imported %lld\n", pos, st.published,
+            st.subscribed, st.awaited_motion, st.awaited_planes, st.released, st.failed, st.bytes, st.wire_ranks, st.bands_imported);
     fclose(out);
     if (world > 1) ohdec_frames_mode(d, NULL);
     ohdec_close(d);

@@ -262,13 +262,13 @@ def write_stream_file(path, aus):
             f.write(a)
 
 
-def run_frames_hosts(exe, decoder_so, product_so, stream_file, world, wire, rendezvous, tmpdir, device=0, env=None):
+def run_frames_hosts(exe, decoder_so, product_so, stream_file, world, wire, rendezvous, tmpdir, device=0, env=None, bands=None):
     import subprocess
     procs, outs = [], []
     for r in range(world):
         out = os.path.join(tmpdir, f"out_{os.path.basename(stream_file)}_{r}.txt")
         outs.append(out)
-        procs.append(subprocess.Popen([exe, decoder_so, product_so, stream_file, str(r), str(world), wire, rendezvous, str(device), out],
+        procs.append(subprocess.Popen([exe, decoder_so, product_so, stream_file, str(r), str(world), wire, rendezvous, str(device), out] + ([str(bands)] if bands else []),
                                       env=dict(os.environ, **(env or {})), stderr=subprocess.PIPE))
     errs = [p.communicate(timeout=240)[1].decode(errors="replace") for p in procs]
     codes = [p.returncode for p in procs]
@@ -285,8 +285,8 @@ def run_frames_hosts(exe, decoder_so, product_so, stream_file, world, wire, rend
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_native_transport_c_host_over_sockets(world, tmp_path):
+@pytest.mark.parametrize("world,bands", [(2, None), (3, None), (2, 1)], ids=["2", "3", "2_whole_pictures"])
+def test_native_transport_c_host_over_sockets(world, bands, tmp_path):
     from oracle import pystream as ps
     from test_stream_cpu import load_golden
     if not (ps.have("hipemu") and ps.have("c")):
@@ -299,12 +299,18 @@ def test_native_transport_c_host_over_sockets(world, tmp_path):
         want = [[fnv64(pl.tobytes()) for pl in f] for f in ps.decode_stream("c", aus)]
         sf = str(tmp_path / f"{name}.bin")
         write_stream_file(sf, aus)
-        codes, errs, merged, stats = run_frames_hosts(exe, ps.lib_path("hipemu"), product, sf, world, "sockets", f"127.0.0.1:{free_port() + 16 * k}", str(tmp_path))
+        codes, errs, merged, stats = run_frames_hosts(exe, ps.lib_path("hipemu"), product, sf, world, "sockets", f"127.0.0.1:{free_port() + 16 * k}", str(tmp_path), bands=bands)
         assert codes == [0] * world, (name, codes, errs)
         assert sorted(merged) == list(range(len(want))), (name, sorted(merged))
         assert [merged[p] for p in range(len(want))] == want, f"{name}: pictures differ from the single-process decoder"
         assert all(s["pictures"] == len(want) for s in stats)
         assert sum(s["awaited_planes"] for s in stats) > 0 and sum(s["failed"] for s in stats) == 0
+        assert all(s["wire_ranks"] == world for s in stats)
+        # pictures cross the wire in bands of CTU rows (default) or whole (bands 1): with bands, more of them are imported than pictures waited for
+        if bands == 1:
+            assert sum(s["bands_imported"] for s in stats) == sum(s["awaited_planes"] for s in stats)
+        else:
+            assert sum(s["bands_imported"] for s in stats) > sum(s["awaited_planes"] for s in stats)
 
 
 def test_rccl_rendezvous_never_accepts_a_stale_id(tmp_path):

@@ -50,7 +50,7 @@ def _adopt(modname):
             globals()[name] = obj
 
 
-for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_dbk_maps_gpu test_boundary_strength_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu").split():
+for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_dbk_maps_gpu test_boundary_strength_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu test_frames_bands_gpu").split():
     _adopt(_m)
 
 
