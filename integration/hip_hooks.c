@@ -102,6 +102,7 @@ static __thread ohevc_ctx *t_ctx;
 static __thread int        t_frame_open;
 static __thread int        t_error;    /* a hook of the OPEN frame failed on this thread: reported by this picture's frame end, nobody else's */
 static __thread HEVCContext *t_s;      /* the decoder context this thread's open frame belongs to */
+static __thread ThreadFrame *t_bl_tf;   /* SHVC: the base-layer picture's ThreadFrame of the picture this thread is parsing (ohhip_cabac_init, set_new_ref) */
 static __thread int        t_remote;       /* the picture being parsed is reconstructed by another process: skip its slice data */
 static __thread int        t_publish;      /* the open frame is exchanged at its end (index of its bufs entry + 1) */
 static __thread int        t_publish_index;        /* its decoding-order index and the size of its motion field: what a failure report needs */
@@ -126,7 +127,10 @@ static ohhip_backend *default_backend(void);
 static ohhip_backend *backend_of(const AVCodecContext *avctx)
 {
     ohhip_backend *b, *found = NULL;
-    if (avctx && t_seen.avctx == avctx && t_seen.epoch == g_epoch)
+    /* the epoch BEFORE the lookup: a back end freed or made between the lookup and the stamp must leave a stale stamp, not a stale pointer
+     * under the current one (ohhip_cabac_init reads it the same way) */
+    const unsigned epoch = g_epoch;
+    if (avctx && t_seen.avctx == avctx && t_seen.epoch == epoch)
         return t_seen.be;
     pthread_mutex_lock(&g_reg_lock);
     for (b = g_backends; b && avctx; b = b->next)
@@ -136,7 +140,7 @@ static ohhip_backend *backend_of(const AVCodecContext *avctx)
     if (!found)
         found = default_backend();
     if (avctx) {
-        t_seen.avctx = avctx; t_seen.epoch = g_epoch; t_seen.be = found;
+        t_seen.avctx = avctx; t_seen.epoch = epoch; t_seen.be = found;
     }
     return found;
 }
@@ -176,10 +180,16 @@ static ohevc_ctx *new_thread_ctx(ohhip_backend *be)
         return NULL;
     }
     pthread_mutex_lock(&be->lock);
-    if (be->nall < 128)
+    if (be->nall < 128) {
         be->all[be->nall++] = ctx;
+        pthread_mutex_unlock(&be->lock);
+        return ctx;
+    }
     pthread_mutex_unlock(&be->lock);
-    return ctx;
+    /* a context the instance cannot list would never be destroyed: fail instead (128 contexts = 128 threads recording into one decoder) */
+    ohevc_ctx_destroy(ctx);
+    fprintf(stderr, "ohhip: more than 128 per-thread contexts for one decoder instance\n");
+    return NULL;
 }
 
 static ohevc_ctx *thread_ctx(ohhip_backend *be)
@@ -202,12 +212,21 @@ static ohevc_ctx *thread_ctx(ohhip_backend *be)
             for (k = 0; k < 4; k++)
                 if (t_ctxs[k].be == b && t_ctxs[k].id == b->id)
                     live[k] = 1;
-        pthread_mutex_unlock(&g_reg_lock);
         for (k = 0; k < 4 && free_k < 0; k++)
             if (!live[k])
                 free_k = k;
-        if (free_k < 0)
-            free_k = 0;           /* (its context stays registered in its instance and dies with it) */
+        if (free_k < 0) {
+            /* all four belong to live instances: entry 0 goes, and its context goes back to its instance's spare list (under the registry lock:
+             * the instance cannot die meanwhile) - whoever next needs a context for that instance takes it from there instead of making one */
+            ohhip_backend *old = t_ctxs[0].be;
+            free_k = 0;
+            pthread_mutex_lock(&old->lock);
+            if (old->nspare < (int)(sizeof(old->spare) / sizeof(old->spare[0])))
+                old->spare[old->nspare++] = t_ctxs[0].ctx;
+            pthread_mutex_unlock(&old->lock);
+        }
+        pthread_mutex_unlock(&g_reg_lock);
+        t_ctxs[free_k].be = NULL;
     }
     pthread_mutex_lock(&be->lock);
     if (be->nspare > 0)
@@ -443,6 +462,7 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     }
     t_frame_open = 1;
     t_s = s;
+    t_bl_tf = s->BL_frame ? &s->BL_frame->tf : NULL;
     if (device_bs_frame(s) == 2 && ohevc_tables_keep_motion(ctx, s->sps->log2_min_pu_size) != OHEVC_OK)     /* boundary strengths from the MC jobs */
         note_error(be);
     t_bs_n = 0;
@@ -526,6 +546,9 @@ int ohhip_frame_rps(HEVCContext *s)
  * context that is reconstructing s->ref, once per picture and thread. */
 void ohhip_cabac_init(HEVCContext *s, int ctb_addr_ts)
 {
+    /* SHVC: the base-layer frame whose row progress THIS thread's prediction units wait for (ohhip_await_progress).  Set here, on every thread
+     * that parses CTBs - with frame x slice threads the prediction units run on WPP pool workers that never opened a frame (t_s is NULL there) */
+    t_bl_tf = s->BL_frame ? &s->BL_frame->tf : NULL;
     if ((s->threads_type & FF_THREAD_SLICE) && s->threads_number > 1 && s->ref && s->ref->frame) {
         /* looked up every time (once per CTB): a host buffer address names a different picture -- and, with frame + slice
          * threads, a different context -- every time the decoder's pool recycles it */
@@ -1274,7 +1297,7 @@ void ohhip_await_progress(ThreadFrame *f, int progress, int field)
     /* SHVC: the one wait that is about HOST data - the enhancement layer scales the base-layer picture's motion field into the inter-layer
      * picture's (ff_upscale_mv_block, hevc_filter.c:1312-1375) once the base-layer decoder's thread has parsed those rows
      * (hevc_await_progress_bl, hevc.c:1959-1966) */
-    if (t_s && t_s->BL_frame && f == &t_s->BL_frame->tf)
+    if (t_bl_tf && f == t_bl_tf)
         ff_thread_await_progress(f, progress, field);
 }
 
@@ -1287,8 +1310,9 @@ void ohhip_upsample_block(HEVCContext *s, HEVCFrame *ref0, int x0, int y0, int n
     ff_upsample_block(s, ref0, x0, y0, nPbW, nPbH);
     if (s->up_filter_inf.idx == SNR && s->BL_frame && ref0 && ref0->frame) {      /* (also from a slice worker: ohhip_cabac_init bound it to the picture's context) */
         ohevc_UpsamplInf u;
-        const HEVCWindow *w = &s->sps->scaled_ref_layer_window[s->vps->m_refLayerId[s->nuh_layer_id][0]];
-        ohevc_HEVCWindow win = { w->left_offset, w->right_offset, w->top_offset, w->bottom_offset };
+        /* the reference's ratio-1 path (copy_block, hevc_filter.c:1165-1192) copies base-layer (x0, y0) to the same position with memcpy: the
+         * scaled reference layer offsets of the SPS play no part in it - a zero window makes the general filter that copy */
+        ohevc_HEVCWindow win = { 0, 0, 0, 0 };
         /* a COPY whatever cross_layer_phase_alignment_flag says (the reference tests the scale alone, hevc.c:486-487): the offsets of phase
          * alignment 0 (set_sps, hevc.c:476-484: the chroma row offset of a quarter sample is taken back by the "- 4" of the chroma mapping) */
         u.scaleXLum = u.scaleYLum = u.scaleXCr = u.scaleYCr = 65536;

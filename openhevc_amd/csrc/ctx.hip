@@ -77,9 +77,10 @@ struct PicStore {
     // picture.  A decoder's pool of frame buffers grows through its first dozens of pictures, every new buffer wants a device picture, and the
     // sample hooks ask for it in the serial prologue of the picture (hevc_frame_start, before the next access unit is let in): 0.3-0.5 ms of
     // driver calls there spaced a fresh decoder's picture starts 0.8-1.2 ms apart instead of 0.43 (profiles/r13_*).  Pieces are zeroed when their
-    // batch is made; a piece whose picture is released is not handed out again (it would need zeroing) - its memory goes with the store.
+    // batch is made; a piece whose picture is released waits in `dirty` and is zeroed when it is handed out again (take_piece), before any new
+    // batch is made.
     std::mutex spare_m;
-    struct Spare { std::vector<unsigned char *> pieces; int next_batch = 4; };
+    struct Spare { std::vector<unsigned char *> pieces, dirty; int next_batch = 4; };
     std::map<size_t, Spare> spare;        // by piece size: zeroed pieces nobody uses yet (two layers of an SHVC stream share a store: two sizes take turns)
     std::vector<void *> batches;          // the allocations behind all pieces ever made
 };
@@ -297,10 +298,19 @@ struct ohevc_ctx : Rec {
 
 using namespace ohevc;
 
-static int free_picture(Picture &p, bool dry = false)
+// store: where a picture that was cut out of a batch (take_piece) gives its piece back.  The caller has made sure that nothing on the device
+// still reads or writes the picture (ohevc_pic_release drains; ensure_like synchronises the one stream that used the copy).
+static int free_picture(Picture &p, bool dry = false, PicStore *store = nullptr)
 {
     if (p.single) {
         if (p.planes[0].data && p.owned && !dry) OHEVC_HIP_TRY(hipFree(p.planes[0].data));
+        if (p.planes[0].data && !p.owned && !dry && store) {
+            // (a released piece used to be dropped until the store died: every release + alloc pair - a decoder's pool changing geometry, an
+            // enhancement layer reopened on a live base store, the scratch copies of ensure_like - grew device memory by one picture)
+            const size_t bytes = ((size_t)((unsigned char *)p.planes[2].data - (unsigned char *)p.planes[0].data) + (size_t)p.planes[2].stride * p.planes[2].height + 4095) & ~(size_t)4095;
+            std::lock_guard<std::mutex> g(store->spare_m);
+            store->spare[bytes].dirty.push_back(static_cast<unsigned char *>(p.planes[0].data));
+        }
         for (auto &pl : p.planes) pl = ohevc_plane{};
     } else {
         for (auto &pl : p.planes) {
@@ -322,6 +332,12 @@ static unsigned char *take_piece(PicStore &st, size_t bytes, hipStream_t stream)
     bytes = (bytes + 4095) & ~(size_t)4095;
     std::lock_guard<std::mutex> g(st.spare_m);
     PicStore::Spare &sp = st.spare[bytes];
+    if (sp.pieces.empty() && !sp.dirty.empty()) {
+        // a released picture's piece: nothing on the device touches it any more (free_picture's contract); zero it like a fresh batch's
+        unsigned char *d = sp.dirty.back();
+        if (hipMemsetAsync(d, 0, bytes, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) { sp.dirty.pop_back(); return d; }
+        (void)hipGetLastError();
+    }
     if (sp.pieces.empty()) {
         const int n = (int)std::max<size_t>(1, std::min<size_t>((size_t)sp.next_batch, ((size_t)1 << 30) / bytes));
         void *m = nullptr;
@@ -488,8 +504,9 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
         }
     }
     for (auto &e : c->ring) if (e) (void)hipEventDestroy(e);
-    if (c->twin.used) free_picture(c->twin);
-    if (c->lag.used) free_picture(c->lag);
+    // (scratch copies cut out of the store's batches go back to it: the store may outlive this context.  The stream has drained above.)
+    if (c->twin.used) free_picture(c->twin, false, c->store.get());
+    if (c->lag.used) free_picture(c->lag, false, c->store.get());
     for (DevBuf &b : c->d_jobs) if (b.p) (void)hipFree(b.p);
     if (c->d_coeffs.p) (void)hipFree(c->d_coeffs.p);
     if (c->d_table.p) (void)hipFree(c->d_table.p);
@@ -604,7 +621,7 @@ extern "C" int ohevc_pic_release(ohevc_ctx *c, int slot)
     std::lock_guard<std::mutex> g(c->store->m);
     c->store->version++;
     p->readers.clear();
-    return free_picture(*p, c->dry);
+    return free_picture(*p, c->dry, c->store.get());
 }
 
 extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *host, ptrdiff_t host_stride)
@@ -693,7 +710,14 @@ extern "C" int ohevc_host_unpin(ohevc_ctx *c, void *ptr, size_t bytes)
     OHEVC_REQUIRE(c != nullptr && ptr != nullptr && bytes > 0, "bad argument");
     if (c->dry) return OHEVC_OK;
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
-    std::unique_lock<std::shared_mutex> g(c->store->pin_m);        // (waits for copy-backs in flight: they hold the shared lock)
+    // Copy-backs issued by the library's issuer threads (ohevc_frame_end_async) hold no lock while they are queued or in flight: with an
+    // issuer, first let it issue what it holds and wait for the device - a page lock must not go while a DMA may still target the range.
+    if (c->store->issuer) {
+        async_drain(*c->store);
+        OHEVC_HIP_TRY(hipSetDevice(c->device));
+        (void)hipDeviceSynchronize();
+    }
+    std::unique_lock<std::shared_mutex> g(c->store->pin_m);        // (waits for the synchronous copy-backs in flight: they hold the shared lock)
     auto &v = c->store->pinned;
     for (size_t i = 0; i < v.size();) {
         if (v[i].first < a + bytes && a < v[i].first + v[i].second) unpin_locked(*c->store, i);
@@ -1845,25 +1869,13 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             for (uint64_t m = lb.touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); std::reverse(lb.tu[b >> 4][b & 15].begin(), lb.tu[b >> 4][b & 15].end()); }
         }
         if (!lb.intra.empty() && c->cips.empty() && g_intra_pack) {
-            // the packed kernel (ohevc_dev_intra_recon_sorted) wants the level's blocks by size: N lanes serve an N x N block, so the
-            // blocks of a wavefront must be of one size.  Stable counting sort of the jobs and of the residual records riding with them.
+            // the packed kernel (ohevc_dev_intra_recon_sorted) wants the level's blocks by size - N lanes serve an N x N block, so the blocks of
+            // a wavefront must be of one size - and, inside a size, by prediction mode, so that a wavefront's blocks take one path through the
+            // predictors (ohevc_intra_sort_level, host_jobs.hip).  The residual records ride with their jobs.
             const bool paired = lb.intra_res.size() == lb.intra.size();
-            static thread_local std::vector<ohevc_intra_job> tj;
-            static thread_local std::vector<ohevc_tu_job> tr;
-            int cnt[4] = {0, 0, 0, 0}, pos[4];
-            for (const ohevc_intra_job &j : lb.intra) cnt[j.log2_size - 2]++;
-            pos[0] = 0; pos[1] = cnt[0]; pos[2] = pos[1] + cnt[1]; pos[3] = pos[2] + cnt[2];
-            if (cnt[0] != (int)lb.intra.size() && cnt[1] != (int)lb.intra.size() && cnt[2] != (int)lb.intra.size() && cnt[3] != (int)lb.intra.size()) {
-                tj.resize(lb.intra.size());
-                if (paired) tr.resize(lb.intra.size());
-                for (size_t k = 0; k < lb.intra.size(); k++) {
-                    const int d = pos[lb.intra[k].log2_size - 2]++;
-                    tj[d] = lb.intra[k];
-                    if (paired) tr[d] = lb.intra_res[k];
-                }
-                lb.intra.swap(tj);
-                if (paired) lb.intra_res.swap(tr);
-            }
+            int32_t cnt[4];
+            const int src = ohevc_intra_sort_level(lb.intra.data(), paired ? lb.intra_res.data() : nullptr, (int)lb.intra.size(), cnt);
+            if (src != OHEVC_OK) return src;
             for (int k = 0; k < 4; k++) loff[l].count[k] = cnt[k];
             loff[l].packed = true;
         }
@@ -2279,7 +2291,7 @@ static int frame_end_impl(ohevc_ctx *c)
             int r;
             if (q.used) {                 // another geometry: launches that read the old copy may still be in flight
                 OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
-                if ((r = free_picture(q)) != OHEVC_OK) return r;
+                if ((r = free_picture(q, false, c->store.get())) != OHEVC_OK) return r;
             }
             return alloc_picture(q, p->w, p->h, p->cfi, p->bd, false, c->store.get(), c->stream);
         };

@@ -171,8 +171,10 @@ struct SockWire {
                 usleep(20000);
             }
         }
-        for (int k = rank + 1; k < world;) {
-            const double t0 = now_s();
+        const double t_accept = now_s();                   // one deadline for the whole rendezvous: a local peer that keeps connecting with bad
+        for (int k = rank + 1; k < world;) {               // hellos must not hold this rank here for ever
+            const double t0 = t_accept;
+            if (now_s() - t0 > timeout_s) return false;
             pollfd pf = { listen_fd, POLLIN, 0 };
             if (poll(&pf, 1, timeout_s * 1000) <= 0) return false;
             const int s = accept(listen_fd, nullptr, nullptr);

@@ -1,6 +1,7 @@
 // host_jobs.hip -- host-side (CPU) job construction helpers of the C ABI; no device code.
 #include <algorithm>
 #include <string.h>
+#include <vector>
 #include "common.hpp"
 
 namespace {
@@ -139,5 +140,40 @@ static int make_job_common(const ohevc_intra_geom *g, int lpu, const uint8_t *pf
         cip->size_max_x = (uint8_t)smx; cip->size_max_y = (uint8_t)smy;
         cip->x0_nonzero = x0 != 0; cip->y0_nonzero = y0 != 0;
     }
+    return OHEVC_OK;
+}
+
+// The order the packed intra kernel wants a dependency level's blocks in (intra_pack.hpp: N lanes per N x N block, 16 / 8 / 4 / 2 blocks per
+// wavefront): by size - a wavefront's blocks must be of one size - and, inside a size, by prediction mode: planar, DC, then the angular modes
+// ascending (2..17 predict from the left column, 18..34 from the row above).  The predictors (hevcpred_template.c:359-537), the smoothing
+// decision (:289-327, a function of mode and size) and the negative-angle extension of the reference array (:443-460) are branches of ONE
+// instruction stream shared by a wavefront's blocks: blocks of one mode take one path through it, a random mix takes all of them.
+// Stable counting sort of the jobs and of the residual records riding with them (residuals may be NULL); count_by_size[k] = blocks of (4 << k).
+extern "C" int ohevc_intra_sort_level(ohevc_intra_job *jobs, ohevc_tu_job *residuals, int n, int32_t count_by_size[4])
+{
+    OHEVC_REQUIRE(n >= 0 && (n == 0 || jobs != nullptr) && count_by_size != nullptr, "bad argument");
+    int cnt[4 * 35] = {};
+    for (int k = 0; k < n; k++) {
+        OHEVC_REQUIRE(jobs[k].log2_size >= 2 && jobs[k].log2_size <= 5 && jobs[k].mode <= 34, "bad intra job");
+        cnt[(jobs[k].log2_size - 2) * 35 + jobs[k].mode]++;
+    }
+    for (int sz = 0; sz < 4; sz++) { count_by_size[sz] = 0; for (int m = 0; m < 35; m++) count_by_size[sz] += cnt[sz * 35 + m]; }
+    bool sorted = true;
+    for (int k = 1; k < n && sorted; k++)
+        sorted = (jobs[k].log2_size - 2) * 35 + jobs[k].mode >= (jobs[k - 1].log2_size - 2) * 35 + jobs[k - 1].mode;
+    if (sorted) return OHEVC_OK;
+    int pos[4 * 35];
+    for (int b = 0, at = 0; b < 4 * 35; b++) { pos[b] = at; at += cnt[b]; }
+    static thread_local std::vector<ohevc_intra_job> tj;
+    static thread_local std::vector<ohevc_tu_job> tr;
+    tj.resize((size_t)n);
+    if (residuals) tr.resize((size_t)n);
+    for (int k = 0; k < n; k++) {
+        const int d = pos[(jobs[k].log2_size - 2) * 35 + jobs[k].mode]++;
+        tj[(size_t)d] = jobs[k];
+        if (residuals) tr[(size_t)d] = residuals[k];
+    }
+    memcpy(jobs, tj.data(), (size_t)n * sizeof(*jobs));
+    if (residuals) memcpy(residuals, tr.data(), (size_t)n * sizeof(*residuals));
     return OHEVC_OK;
 }

@@ -150,3 +150,33 @@ def test_device_pictures_come_in_batches_per_size():
         got = ctx.pic_download(slot, shapes, np.uint8)
         assert all(np.array_equal(a, b) for a, b in zip(got, planes))
     ctx.close()
+
+
+def test_released_pieces_are_handed_out_again_zeroed():
+    """release + alloc cycles (a decoder's pool changing geometry, an enhancement layer reopened on a live base store) must not grow device
+    memory: the piece of a released picture goes back to the store and is zeroed when it is handed out again - before any new batch is made."""
+    import ctypes
+    lib = L.load_library()
+    lib.ohevc_debug_picture_batches.argtypes = [ctypes.c_void_p]
+    if os.environ.get("OHEVC_PICTURE_BATCH") == "0":
+        pytest.skip("batches are switched off in this run")
+    ctx = L.Ctx(0)
+    w, h = 320, 192
+    shapes = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+    rng = np.random.default_rng(9)
+    live = [ctx.pic_alloc(w, h, 1, 8) for _ in range(4)]    # the first batch of 4
+    assert lib.ohevc_debug_picture_batches(ctx.h) == 1
+    keep_planes = [rng.integers(1, 256, size=sh).astype(np.uint8) for sh in shapes]
+    ctx.pic_upload(live[0], keep_planes)
+    for cycle in range(100):                                 # 100 pictures come and go through the other three pieces
+        slot = live.pop()
+        ctx.pic_upload(slot, [np.full(sh, 1 + cycle % 255, np.uint8) for sh in shapes])
+        ctx.pic_release(slot)
+        slot = ctx.pic_alloc(w, h, 1, 8)
+        got = ctx.pic_download(slot, shapes, np.uint8)
+        assert all(not pl.any() for pl in got), "a recycled piece is zeroed like a fresh one"
+        live.append(slot)
+    assert lib.ohevc_debug_picture_batches(ctx.h) == 1, "release + alloc cycles made new batches: released pieces are not reused"
+    got = ctx.pic_download(live[0], shapes, np.uint8)
+    assert all(np.array_equal(a, b) for a, b in zip(got, keep_planes)), "a neighbour's piece was touched by the recycling"
+    ctx.close()

@@ -17,7 +17,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def decode(threads, natural):
     from oracle import pystream as ps
-    kw = dict(gop="random_access", nframes=33, seed=7, width=1920, height=1080, log2_ctb=6)
+    natural = natural or os.environ.get("DIAG_NATURAL") == "1"
+    kw = dict(gop=os.environ.get("DIAG_GOP", "random_access"), nframes=33, seed=7, width=1920, height=1080, log2_ctb=6)      # DIAG_GOP=intra: every picture intra
+    if kw["gop"] == "intra":
+        kw["nframes"] = 17
     if natural:
         kw.update(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
                                           split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
@@ -65,6 +68,21 @@ def analyze(db):
     union += cur_e - cur_s
     span = max(r[1] for r in rows) - rows[0][0]
     gaps = sorted(rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1))
+    # the long kernels (the intra chains: one workgroup each, milliseconds): how many of them run at the same time, and on which queues
+    longk = [r for r in rows if r[1] - r[0] > 200000]
+    if longk:
+        ev = sorted([(r[0], 1) for r in longk] + [(r[1], -1) for r in longk])
+        cur, last, at = 0, ev[0][0], {}
+        for t, d in ev:
+            at[cur] = at.get(cur, 0) + (t - last)
+            cur += d; last = t
+        busy = sum(v for k, v in at.items() if k > 0)
+        per_queue = {}
+        for r in longk:
+            per_queue[r[2]] = per_queue.get(r[2], 0) + 1
+        print(json.dumps(dict(long_kernels=len(longk), mean_long_ms=round(sum(r[1] - r[0] for r in longk) / len(longk) / 1e6, 3),
+                              share_of_time_with_n_long_kernels_running={k: round(v / busy, 3) for k, v in sorted(at.items()) if k > 0},
+                              long_kernels_per_queue=per_queue, names=sorted({r[4].split("ohevc::")[-1][:40] for r in longk}))))
     print(json.dumps(dict(kernels=len(rows), queues=len({r[2] for r in rows}), streams=len({r[3] for r in rows}),
                           sum_kernel_ms=round(total / 1e6, 3), union_busy_ms=round(union / 1e6, 3), span_ms=round(span / 1e6, 3),
                           mean_kernel_us=round(total / len(rows) / 1e3, 2), overlap_factor=round(total / union, 3),
