@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--blocks", type=int, default=0, help="blocks per GPU (default 2^20 for 32x32, 2^22 for 16x16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-hip-only", action="store_true", help="decode block: only the HIP rows (A/B runs of the back end's switches)")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B runs: call ohevc_debug_set_NAME(VALUE) of the product library (include/ohevc_debug.h) before the decode block, e.g. "
+                         "long_chain_levels=0, compact_coeffs=0")
+    ap.add_argument("--no-sizes", action="store_true", help="decode block without the 4K / 8K rows (configs 4 and 5 on one GPU)")
     ap.add_argument("--no-decode", action="store_true", help="skip the whole-decoder leg (BASELINE config 3 geometry) that N=1 runs add to the line")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel rows of the other kernel families (the `kernels` object N=1 runs add to the line)")
     ap.add_argument("--no-zscan", action="store_true", help="skip the second timed loop over the CTB-major (z-scan) job list")
@@ -762,8 +766,12 @@ def main():
             except Exception as e:      # the baseline is reporting only; never let it kill the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if world == 1 and not args.no_decode:
+            for kv in args.debug_set:
+                name, value = kv.split("=")
+                getattr(L.load_library(), "ohevc_debug_set_" + name)(int(value))
+                out.setdefault("debug_set", {})[name] = int(value)
             try:
-                out["decode"] = decode_leg(hip_only=args.decode_hip_only)
+                out["decode"] = decode_leg(hip_only=args.decode_hip_only, sizes=not args.no_sizes)
             except Exception as e:
                 out["decode"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)

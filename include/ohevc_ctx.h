@@ -97,6 +97,11 @@ int  ohevc_frame_begin(ohevc_ctx *ctx, int slot);
 /* transform_add[..] preceded by its inverse transform (kind = OHEVC_TU_*).  `intra` != 0 when the block was just
  * predicted by ohevc_rec_intra at the same position (it then runs right after that prediction's level). */
 int  ohevc_rec_tu(ohevc_ctx *ctx, int plane, int x, int y, int log2_size, int kind, const int16_t *coeffs, int intra);
+/* ... with the caller's promise that every coefficient outside the top-left cols x rows rectangle of the block is zero: only that rectangle is
+ * copied, staged and uploaded (the device rebuilds the dense block, ohevc_expand_rec in ohevc_hip.h).  For inverse-DCT blocks the reference
+ * hands its idct slot the bound as col_limit (hevc_cabac.c:1923-1934): cols = min(col_limit, N), rows = min(col_limit + 4, N), the very
+ * ranges its own transforms read (hevcdsp_template.c:271-291).  Other kinds are recorded whole whatever is passed. */
+int  ohevc_rec_tu_limited(ohevc_ctx *ctx, int plane, int x, int y, int log2_size, int kind, const int16_t *coeffs, int intra, int cols, int rows);
 /* a chroma block with cross-component prediction (OHEVC_TU_CROSS): own residual (kind_c, coeffs_c; kind_c = -1 and coeffs_c
  * NULL when the block has no coded coefficients) plus (res_scale_val * luma residual) >> 3, the luma residual being that of
  * (kind_y, coeffs_y), the RAW coefficients of the transform unit's luma block.  Both blocks are copied. */

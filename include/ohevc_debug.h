@@ -96,6 +96,11 @@ int ohevc_debug_level_tu(struct ohevc_ctx *ctx, int level, int log2_size, int ki
 /* the intra work of the CTB executor (level launch mode 2): tasks in raster order, their operation words (ohevc_dev_ctbs) and the job arrays they index */
 int ohevc_debug_ctbs(struct ohevc_ctx *ctx, const struct ohevc_ctb_task **tasks, int *ntasks, const uint32_t **ops, const struct ohevc_intra_job **intra_jobs,
                      const struct ohevc_tu_job **tu_jobs, int *log2_ctb_size);
+/* a frame with at least this many recorded dependency levels is issued on the context's long-chain stream (highest stream priority: a hardware
+ * queue pool of its own); 0: never (rounds 1-4).  Default 96. */
+int ohevc_debug_set_long_chain_levels(int levels);
+/* 0: every recorded coefficient block crosses the bus whole, as in rounds 1-4 (A/B of the compact upload; default 1) */
+int ohevc_debug_set_compact_coeffs(int on);
 int ohevc_debug_arena(struct ohevc_ctx *ctx, const int16_t **coeffs, const struct ohevc_intra_cip **cips);
 int ohevc_debug_filters(struct ohevc_ctx *ctx, const struct ohevc_dbk_job **vertical, int *n_vertical, const struct ohevc_dbk_job **horizontal,
                         int *n_horizontal, const struct ohevc_sao_job **sao, int *n_sao, struct ohevc_sao_bypass *bypass /* HOST map */);

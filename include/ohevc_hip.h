@@ -118,6 +118,17 @@ typedef struct ohevc_mc_job {           /* 32 bytes */
     int16_t  ox0, ox1;
 } ohevc_mc_job;
 
+/* Coefficients cross the bus COMPACT and are expanded on the device into the dense arena the TU jobs index (coeff_off): of an inverse-DCT
+ * block only the top-left cols x rows rectangle that can hold non-zero coefficients travels - the bound the reference computes from the last
+ * significant coefficient and hands its idct slot as col_limit (hevc_cabac.c:1923-1934; its C transforms skip the rest,
+ * hevcdsp_template.c:271-277,288-291).  One record per piece of the compact stream, offsets and sizes in int16 elements:
+ *   kind 0     : dims elements copied as they are (whole blocks; dims a multiple of 16, at most 1024);
+ *   kind 3,4,5 : an (1 << kind)-sample block; its compact form is rows rows of cols coefficients (dims = cols | rows << 8, multiples of 4),
+ *                everything else of the block is written as zero.
+ * src: offset in the compact stream (a multiple of 4), dst: offset of the block in the dense arena (a multiple of 16). */
+typedef struct ohevc_expand_rec { uint32_t src, dst, dims, kind; } ohevc_expand_rec;
+int ohevc_dev_expand_coeffs(const int16_t *compact, const ohevc_expand_rec *recs, int nrecs, int16_t *dense, void *stream);
+
 /* dst: the 3 planes of the picture being reconstructed.  refs: DEVICE array of n_ref_slots * 3 ohevc_plane
  * (slot-major: refs[3 * slot + plane]); width/height there are the picture size used for clamping. */
 int ohevc_dev_mc_batch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_ref_slots, int bit_depth,

@@ -141,6 +141,8 @@ static std::atomic<uint64_t> g_ctx_gen{1};
 // Pictures whose intra jobs name no CTB size always take the level form.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static bool g_record_only = false;   // ohevc_debug_set_record_only
+static int g_compact_coeffs = 1;     // ohevc_debug_set_compact_coeffs: 0 = every block crosses the bus whole (rounds 1-4; A/B and tests)
+extern "C" int ohevc_debug_set_compact_coeffs(int on) { g_compact_coeffs = on != 0; return OHEVC_OK; }
 static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static std::atomic<int> g_level_launch{0};      // ohevc_debug_set_level_launch (the sample hooks set it, to the same value, from every decoder that is opened: atomic)
 // The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
@@ -193,7 +195,13 @@ struct Rec {
     std::vector<ohevc_intra_job> ctb_intra;
     std::vector<ohevc_tu_job> ctb_tu;
     std::vector<std::pair<uint32_t, uint32_t>> ctb_ops;    // (CTB raster index, operation word)
+    // Coefficients cross the bus COMPACT: of an inverse-DCT block only the top-left cols x rows rectangle that can hold non-zero coefficients (the
+    // reference computes the bound from the last significant coefficient, hevc_cabac.c:1923-1934, and its own transforms skip what lies
+    // outside, hevcdsp_template.c:271-277,288-291); everything else whole.  `coeffs` is that stream, `expand` says where each piece goes in the
+    // DENSE arena the kernels index (ohevc_tu_job.coeff_off: block-major N x N int16, as before) - the device rebuilds it (ohevc_dev_expand_coeffs).
     std::vector<int16_t> coeffs;
+    std::vector<ohevc_expand_rec> expand;
+    uint32_t dense = 0;                                    // int16 elements of the dense arena so far
     std::vector<ohevc_intra_cip> cips;                     // side records of constrained-intra jobs
     std::vector<ohevc_dbk_job> dbk_v, dbk_h;
     std::vector<ohevc_bs_call> bs_calls;                   // ohevc_rec_bs_call: the picture's calls of ff_hevc_deblocking_boundary_strengths (device-side boundary strengths)
@@ -208,8 +216,11 @@ struct Rec {
 
 struct ohevc_ctx : Rec {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
+    std::vector<int16_t> dense_host;  // ohevc_debug_arena: the dense arena for host-side consumers of the recorded jobs
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // where this context's frames are issued: stream_norm, or - pictures with long dependency chains - stream_long (select_stream)
+    hipStream_t stream_norm = nullptr, stream_long = nullptr;
+    hipEvent_t switch_ev = nullptr;   // hand-over between the two: what was issued on the one is ordered before what follows on the other
     // Two upload lanes - host staging buffer, device buffer, "copied" event - one for the job arrays of ohevc_frame_reconstruct, one for the
     // filter maps of the frame end.  With one lane the second staging copy of a picture had to wait on the host until the first H2D copy
     // had run, and that copy sits in the stream BEHIND the waits for the reference pictures' completion: under frame threads every
@@ -277,7 +288,7 @@ struct ohevc_ctx : Rec {
     ptrdiff_t async_stride[3] = {0, 0, 0};
     hipEvent_t dl_ring[8] = {};
     int dl_next = 0;
-    DevBuf d_jobs[2], d_coeffs, d_table, d_upsample;
+    DevBuf d_jobs[2], d_dense[2], d_table, d_upsample;
     // SHVC: the tap maps in d_upsample belong to these parameters (a stream resamples every picture with the same ones: one upload per geometry)
     ohevc_upsample_params up_prm = {};
     bool up_valid = false;
@@ -405,6 +416,32 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
 // (profiles/r5f_*: all of it inside the first pictures' frame ends).  A context does them when it is made - the sample hooks make one per
 // decoding thread when the decoder is opened (ohhip_backend_attach) - instead of in front of its thread's first picture.  Best effort: a
 // failure here shows up again, with its message, where the buffers are needed.
+// Pictures with a long chain of dependency levels (an intra picture: ~1000 levels, one 8-wavefront workgroup for 3-5 ms) are issued on a
+// stream of their own, created at the highest stream priority.  Why: the runtime spreads the streams of one priority over a pool of 4 hardware
+// queues, least-used first; a context makes a kernel stream and an upload stream, so the kernel streams of a frame-threaded decoder all land on
+// two of the four queues, a hardware queue runs its packets in order, and whatever shares a queue with such a chain waits for it - an
+// all-intra stream ran two pictures at a time on 16 frame threads (345 fps against the reference's 2066 on its SSE tables;
+// profiles/r5b_overlap_intra_only_16.jsonl: share of time with n chains running {1: 0.25, 2: 0.75}).  Raising GPU_MAX_HW_QUEUES fixes that
+// stream and costs every other one 15-50 % (profiles/r5c_stream_priority_hw_queues_ab.txt).  Streams of another priority come out of another
+// pool: long chains get up to four queues of their own and leave the regular ones to the short frames.
+// ohevc_debug_set_long_chain_levels: a frame whose recorded dependency levels reach this many goes to the long-chain stream (0: never).
+static int g_long_chain_levels = 96;
+extern "C" int ohevc_debug_set_long_chain_levels(int levels) { g_long_chain_levels = levels < 0 ? 0 : levels; return OHEVC_OK; }
+static int select_stream(ohevc_ctx *c, bool long_chain)
+{
+    if (long_chain && !c->stream_long) {
+        int least = 0, greatest = 0;
+        OHEVC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, greatest));
+    }
+    hipStream_t want = long_chain ? c->stream_long : c->stream_norm;
+    if (want == c->stream) return OHEVC_OK;
+    OHEVC_HIP_TRY(hipEventRecord(c->switch_ev, c->stream));
+    OHEVC_HIP_TRY(hipStreamWaitEvent(want, c->switch_ev, 0));
+    c->stream = want;
+    return OHEVC_OK;
+}
+
 static const int g_prewarm_kib = getenv("OHEVC_PREWARM_KIB") ? atoi(getenv("OHEVC_PREWARM_KIB")) : 3072;      // 0: off; the upload buffers' first size (x 1.5)
 static void prewarm(ohevc_ctx *c)
 {
@@ -440,6 +477,7 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
     c->store = share_with ? share_with->store : std::make_shared<PicStore>();
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->switch_ev, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->staged[0], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->staged[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->lane_done[0], hipEventDisableTiming) == hipSuccess &&
@@ -450,6 +488,7 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
         delete c;
         return OHEVC_ERR_HIP;
     }
+    c->stream_norm = c->stream;
     prewarm(c);
     *out = c;
     return OHEVC_OK;
@@ -478,7 +517,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
         if (c->store.use_count() == 1 + (long)c->store->issuer->execs.size()) issuer_shutdown(*c->store);      // the last recording context goes
     }
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t st : { c->stream_norm, c->stream_long }) if (st) (void)hipStreamSynchronize(st);
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
         (void)hipDeviceSynchronize();
         {
@@ -508,7 +547,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->twin.used) free_picture(c->twin, false, c->store.get());
     if (c->lag.used) free_picture(c->lag, false, c->store.get());
     for (DevBuf &b : c->d_jobs) if (b.p) (void)hipFree(b.p);
-    if (c->d_coeffs.p) (void)hipFree(c->d_coeffs.p);
+    for (DevBuf &b : c->d_dense) if (b.p) (void)hipFree(b.p);
     if (c->d_table.p) (void)hipFree(c->d_table.p);
     if (c->d_upsample.p) (void)hipFree(c->d_upsample.p);
     if (c->d_bs.p) (void)hipFree(c->d_bs.p);
@@ -519,7 +558,8 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     for (hipEvent_t e : c->lane_done) if (e) (void)hipEventDestroy(e);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
-    if (c->stream) { ohevc_mc_forget_stream(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (hipStream_t st : { c->stream_norm, c->stream_long }) if (st) { ohevc_mc_forget_stream(st); (void)hipStreamDestroy(st); }
+    if (c->switch_ev) (void)hipEventDestroy(c->switch_ev);
     delete c;
 }
 
@@ -999,7 +1039,7 @@ static inline LevelBins &level_bins(Rec &r, int level)
 
 static void clear_rec(Rec &r)
 {
-    r.mc.clear(); r.mc_small.clear(); r.coeffs.clear(); r.cips.clear();
+    r.mc.clear(); r.mc_small.clear(); r.coeffs.clear(); r.cips.clear(); r.expand.clear(); r.dense = 0;
     r.ctb_intra.clear(); r.ctb_tu.clear(); r.ctb_ops.clear();
     for (int l = 0; l <= r.max_level; l++) {
         LevelBins &lb = r.levels[l];
@@ -1024,8 +1064,10 @@ static void merge_side(ohevc_ctx *c)
         Rec &r = *sd.second;
         c->mc.insert(c->mc.end(), r.mc.begin(), r.mc.end());
         c->mc_small.insert(c->mc_small.end(), r.mc_small.begin(), r.mc_small.end());
-        const uint32_t cbase = (uint32_t)c->coeffs.size(), ibase = (uint32_t)c->cips.size();
+        const uint32_t cbase = c->dense, sbase = (uint32_t)c->coeffs.size(), ibase = (uint32_t)c->cips.size();     // dense-arena base of this recorder's blocks; base of its compact stream
         c->coeffs.insert(c->coeffs.end(), r.coeffs.begin(), r.coeffs.end());
+        for (ohevc_expand_rec e : r.expand) { e.src += sbase; e.dst += cbase; c->expand.push_back(e); }
+        c->dense += r.dense;
         c->cips.insert(c->cips.end(), r.cips.begin(), r.cips.end());
         {   // CTB-ordered intra work: a CTB is decoded by one thread, so its operations stay contiguous and in order
             const uint32_t jbase = (uint32_t)c->ctb_intra.size(), tbase = (uint32_t)c->ctb_tu.size();
@@ -1102,6 +1144,10 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
         p->failed = false;
         c->my_gen = ++p->gen;
     }
+    if (!c->dry && c->stream != c->stream_norm && c->stream_norm) {   // the previous picture ran on the long-chain stream
+        int rc = select_stream(c, false);
+        if (rc != OHEVC_OK) return rc;
+    }
     c->ref_slots.clear();
     c->target_guarded = false;
     c->frame_mode = g_level_launch;
@@ -1140,7 +1186,45 @@ static inline uint32_t ctb_index(const ohevc_ctx *c, const Picture *p, int plane
 static inline bool rec_ctb(const ohevc_ctx *c) { return c->frame_mode >= 2 && __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED) > 0; }
 static inline bool rec_levels(const ohevc_ctx *c) { return c->frame_mode != 3 || __atomic_load_n(&c->log2_ctb, __ATOMIC_RELAXED) <= 0; }
 
+// one N x N block into the recorder's arena; returns its offset in the DENSE arena.  cols / rows: the rectangle that can hold non-zero
+// coefficients (multiples of 4; N x N = everything)
+static inline uint32_t arena_put(Rec &r, const int16_t *coeffs, int log2, int cols, int rows)
+{
+    const int n = 1 << log2;
+    const uint32_t dst = r.dense, src = (uint32_t)r.coeffs.size();
+    r.dense += (uint32_t)(n * n);
+    if (log2 >= 3 && (cols < n || rows < n)) {
+        r.coeffs.resize((size_t)src + (size_t)cols * rows);
+        int16_t *d = r.coeffs.data() + src;
+        for (int y = 0; y < rows; y++) memcpy(d + (size_t)y * cols, coeffs + (size_t)y * n, (size_t)cols * sizeof(int16_t));
+        r.expand.push_back(ohevc_expand_rec{ src, dst, (uint32_t)cols | ((uint32_t)rows << 8), (uint32_t)log2 });
+        return dst;
+    }
+    r.coeffs.insert(r.coeffs.end(), coeffs, coeffs + n * n);     // whole: runs of whole blocks share a record (at most 1024 elements: one wavefront's work)
+    if (!r.expand.empty()) {
+        ohevc_expand_rec &e = r.expand.back();
+        if (e.kind == 0 && e.src + e.dims == src && e.dst + e.dims == dst && e.dims + (uint32_t)(n * n) <= 1024u) { e.dims += (uint32_t)(n * n); return dst; }
+    }
+    r.expand.push_back(ohevc_expand_rec{ src, dst, (uint32_t)(n * n), 0u });
+    return dst;
+}
+
+static int rec_tu_impl(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra, int cols, int rows);
+
 extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra)
+{
+    return rec_tu_impl(c, plane, x, y, log2, kind, coeffs, intra, 64, 64);
+}
+
+// ohevc_rec_tu with the caller's promise that every coefficient outside the top-left cols x rows rectangle is zero (inverse-DCT blocks: what
+// the reference passes to its idct slot as col_limit bounds them, hevc_cabac.c:1923-1934: cols = min(col_limit, N), rows = min(col_limit + 4, N))
+extern "C" int ohevc_rec_tu_limited(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra, int cols, int rows)
+{
+    OHEVC_REQUIRE(cols >= 1 && rows >= 1, "empty coefficient rectangle");
+    return rec_tu_impl(c, plane, x, y, log2, kind, coeffs, intra, cols, rows);
+}
+
+static int rec_tu_impl(ohevc_ctx *c, int plane, int x, int y, int log2, int kind, const int16_t *coeffs, int intra, int cols, int rows)
 {
     Picture *p = get_pic(c, c ? c->cur : -1);
     OHEVC_REQUIRE(p != nullptr, "no frame begun");
@@ -1155,8 +1239,9 @@ extern "C" int ohevc_rec_tu(ohevc_ctx *c, int plane, int x, int y, int log2, int
     if (kind == OHEVC_TU_DC) {
         j.dc = coeffs[0];
     } else {
-        j.coeff_off = (uint32_t)r.coeffs.size();
-        r.coeffs.insert(r.coeffs.end(), coeffs, coeffs + n * n);     // the caller's buffer is reused by the next TU
+        // (the caller's buffer is reused by the next TU: copied now).  Only the plain inverse DCT has a known-zero remainder.
+        const bool limited = kind == OHEVC_TU_IDCT && g_compact_coeffs;
+        j.coeff_off = arena_put(r, coeffs, log2, limited ? std::min(n, (cols + 3) & ~3) : n, limited ? std::min(n, (rows + 3) & ~3) : n);
     }
     // `intra`: the block MAY have been predicted by an intra job of this picture (the table slots cannot tell and always say so): the
     // level map knows -- 0 = no intra job covered it: the residual of an inter block (or PCM samples), level 0
@@ -1202,13 +1287,9 @@ extern "C" int ohevc_rec_tu_cross(ohevc_ctx *c, int plane, int x, int y, int log
     j.x = (uint16_t)x; j.y = (uint16_t)y; j.plane = (uint8_t)plane;
     j.reserved0 = (uint8_t)((kind_c < 0 ? 15 : kind_c) | (kind_y << 4));
     j.dc = (int16_t)res_scale_val;
-    j.reserved1 = (uint32_t)r.coeffs.size();
+    j.reserved1 = arena_put(r, coeffs_y, log2, n, n);
     r.alg += (kind_c >= 0 ? 4 : 2) * n * n + 2 * (p->bd > 8 ? 2 : 1) * n * n;
-    r.coeffs.insert(r.coeffs.end(), coeffs_y, coeffs_y + n * n);
-    if (kind_c >= 0) {
-        j.coeff_off = (uint32_t)r.coeffs.size();
-        r.coeffs.insert(r.coeffs.end(), coeffs_c, coeffs_c + n * n);
-    }
+    if (kind_c >= 0) j.coeff_off = arena_put(r, coeffs_c, log2, n, n);
     const int level = intra ? c->level_map[plane][(size_t)(y >> 2) * c->lm_w[plane] + (x >> 2)] : 0;
     if (level > 0 && rec_ctb(c)) {
         r.ctb_ops.emplace_back(ctb_index(c, p, plane, x, y, c->log2_ctb), 0x80000000u | ((uint32_t)(log2 - 2) << 29) | ((uint32_t)OHEVC_TU_CROSS << 25) | (uint32_t)r.ctb_tu.size());
@@ -1846,8 +1927,9 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     }
     OHEVC_HIP_TRY(hipSetDevice(c->device));
     if (c->mc.empty() && c->mc_small.empty() && c->max_level < 0 && c->ctb_tasks.empty()) return OHEVC_OK;
-    int rc = upload_table(c);
-    if (rc != OHEVC_OK) return rc;
+    int rc;
+    if (!c->is_exec && g_long_chain_levels > 0 && c->max_level >= g_long_chain_levels && (rc = select_stream(c, true)) != OHEVC_OK) return rc;
+    if ((rc = upload_table(c)) != OHEVC_OK) return rc;
     if ((rc = guard_pictures(c, c->cur)) != OHEVC_OK) return rc;
 
     // ---- stage every job array + the coefficient arena, one H2D copy
@@ -1966,6 +2048,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     const size_t off_need = phases.empty() ? 0 : stage_put(parts, total, need.data(), need.size() * sizeof(uint32_t));
     const size_t off_sync = phases.empty() ? 0 : stage_put(parts, total, c->sync_zero.data(), c->sync_zero.size() * sizeof(uint32_t));
     const size_t off_coeffs = c->coeffs.empty() ? 0 : stage_put(parts, total, c->coeffs.data(), c->coeffs.size() * sizeof(int16_t));
+    const size_t off_expand = c->expand.empty() ? 0 : stage_put(parts, total, c->expand.data(), c->expand.size() * sizeof(ohevc_expand_rec));
     const size_t off_cips = c->cips.empty() ? 0 : stage_put(parts, total, c->cips.data(), c->cips.size() * sizeof(ohevc_intra_cip));
     // CTB executor: tasks, operation words, the jobs they index, zeroed sync words (home XCD, ticket, one done flag per task)
     const bool ctbs = !c->ctb_tasks.empty();
@@ -1991,7 +2074,22 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if ((rc = upload_jobs(c, parts, total, rlane)) != OHEVC_OK) return rc;
     struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 1, g_trace_timing ? now_s() : 0};
     unsigned char *base = static_cast<unsigned char *>(c->d_jobs[rlane].p);
-    const int16_t *d_coeffs = reinterpret_cast<const int16_t *>(base + off_coeffs);
+    // the dense arena the kernels index, rebuilt on the device from the compact stream that crossed the bus (one buffer per upload lane, like
+    // the job arrays: an early flush's chain may still read the other one)
+    const int16_t *d_coeffs = nullptr;
+    if (!c->expand.empty()) {
+        DevBuf &dn = c->d_dense[rlane];
+        const size_t need_bytes = (size_t)c->dense * sizeof(int16_t);
+        if (need_bytes > dn.cap) {
+            OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));     // launches of an earlier frame may still read the old buffer
+            if ((rc = dn.reserve(need_bytes)) != OHEVC_OK) return rc;
+        }
+        rc = ohevc_dev_expand_coeffs(reinterpret_cast<const int16_t *>(base + off_coeffs), reinterpret_cast<const ohevc_expand_rec *>(base + off_expand),
+                                     (int)c->expand.size(), static_cast<int16_t *>(dn.p), c->stream);
+        if (rc != OHEVC_OK) return rc;
+        c->stats.launches++;
+        d_coeffs = static_cast<const int16_t *>(dn.p);
+    }
 
     // ---- phase 1: inter prediction (reads other pictures only) -- hevc.c:2430-2464
     if (!c->mc.empty()) {
@@ -2662,7 +2760,15 @@ extern "C" int ohevc_debug_ctbs(ohevc_ctx *c, const ohevc_ctb_task **tasks, int 
 extern "C" int ohevc_debug_arena(ohevc_ctx *c, const int16_t **coeffs, const ohevc_intra_cip **cips)
 {
     OHEVC_REQUIRE(c != nullptr, "null context");
-    if (coeffs) *coeffs = c->coeffs.data();
+    if (coeffs) {              // the DENSE arena the jobs index, rebuilt on the host from the compact stream (what ohevc_dev_expand_coeffs does on the device)
+        c->dense_host.assign((size_t)c->dense, (int16_t)0);
+        for (const ohevc_expand_rec &e : c->expand) {
+            if (e.kind == 0) { memcpy(c->dense_host.data() + e.dst, c->coeffs.data() + e.src, (size_t)e.dims * sizeof(int16_t)); continue; }
+            const int n = 1 << e.kind, cols = (int)(e.dims & 0xff), rows = (int)(e.dims >> 8);
+            for (int y = 0; y < rows; y++) memcpy(c->dense_host.data() + e.dst + (size_t)y * n, c->coeffs.data() + e.src + (size_t)y * cols, (size_t)cols * sizeof(int16_t));
+        }
+        *coeffs = c->dense_host.data();
+    }
     if (cips) *cips = c->cips.data();
     return OHEVC_OK;
 }

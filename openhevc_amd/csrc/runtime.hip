@@ -37,3 +37,45 @@ extern "C" int ohevc_set_device(int device)
 }
 
 extern "C" const char *ohevc_version(void) { return "ohevc_hip 0.1 (gfx950)"; }
+
+// ---- coefficients cross the bus compact, the kernels index a dense arena (include/ohevc_hip.h: ohevc_expand_rec) ------------------------------
+// One wavefront per record; a lane writes 16-byte pieces of the dense block: coefficients where the record's rectangle covers them, zeros
+// elsewhere.  A record is at most 1024 elements (a 32 x 32 block / a run of whole small blocks): two pieces per lane.  Pure HBM traffic:
+// reads the compact stream once, writes the dense arena once (the H2D copy used to write exactly that much).
+static __global__ __launch_bounds__(256) void expand_coeffs_kernel(const int16_t *__restrict__ compact, const ohevc_expand_rec *__restrict__ recs, int nrecs,
+                                                                    int16_t *__restrict__ dense)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nrecs) return;
+    const ohevc_expand_rec e = recs[w];
+    ohevc::u32x4 *out = reinterpret_cast<ohevc::u32x4 *>(dense + e.dst);                  // (dense offsets are whole blocks: 32-byte aligned)
+    if (e.kind == 0) {
+        const ohevc::u32x2 *in = reinterpret_cast<const ohevc::u32x2 *>(compact + e.src);  // (compact offsets are multiples of 4 elements: 8-byte aligned)
+        for (unsigned k = lane; k < e.dims / 8u; k += 64u) {
+            const ohevc::u32x2 a = in[2 * k], b = in[2 * k + 1];
+            out[k] = ohevc::u32x4{ a.x, a.y, b.x, b.y };
+        }
+        return;
+    }
+    const unsigned log2n = e.kind, n = 1u << log2n, cols = e.dims & 0xffu, rows = e.dims >> 8;
+    for (unsigned k = lane; k < (n * n) / 8u; k += 64u) {
+        const unsigned row = (8u * k) >> log2n, col = (8u * k) & (n - 1u);
+        ohevc::u32x2 a = ohevc::u32x2{ 0u, 0u }, b = ohevc::u32x2{ 0u, 0u };
+        if (row < rows) {
+            const int16_t *src = compact + e.src + row * cols + col;
+            if (col < cols) a = *reinterpret_cast<const ohevc::u32x2 *>(src);
+            if (col + 4u < cols) b = *reinterpret_cast<const ohevc::u32x2 *>(src + 4);
+        }
+        out[k] = ohevc::u32x4{ a.x, a.y, b.x, b.y };
+    }
+}
+
+extern "C" int ohevc_dev_expand_coeffs(const int16_t *compact, const ohevc_expand_rec *recs, int nrecs, int16_t *dense, void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(nrecs >= 0 && (nrecs == 0 || (compact != nullptr && recs != nullptr && dense != nullptr)), "null argument");
+    if (nrecs == 0) return OHEVC_OK;
+    hipLaunchKernelGGL(expand_coeffs_kernel, dim3((unsigned)((nrecs + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), compact, recs, nrecs, dense);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}

@@ -128,6 +128,7 @@ void (*g_ref_put_pcm[15])(uint8_t *, ptrdiff_t, int, int, struct GetBitContext *
 struct Pending {
     const int16_t *coeffs = nullptr;  // residual kind noted by the in-place transform call
     int kind = -1;
+    int col_limit = 0;                // inverse DCT: the bound the reference passed with it (0: none)
     // cross-component prediction (hevc.c:1291-1365): the transform unit's luma block as last handed to transform_add, and the
     // res_scale_val announced for the next chroma block (ohevc_tables_cross_component)
     const int16_t *luma_coeffs = nullptr;
@@ -225,7 +226,9 @@ bool locate_cur(const uint8_t *p, Loc &out) { return tl_state && tl_state->cur >
 // ------------------------------------------------------------------ residuals
 void note_kind(const int16_t *coeffs, int kind) { tl_pend.coeffs = coeffs; tl_pend.kind = kind; }
 
-template <int LOG2> void t_idct(int16_t *coeffs, int) { note_kind(coeffs, OHEVC_TU_IDCT); }
+// col_limit (hevc_cabac.c:1923-1934): the reference's bound on where the block's non-zero coefficients lie - columns below min(col_limit, N), rows
+// below min(col_limit + 4, N), the ranges its own transforms read (hevcdsp_template.c:271-291).  Only that rectangle is recorded and uploaded.
+template <int LOG2> void t_idct(int16_t *coeffs, int col_limit) { note_kind(coeffs, OHEVC_TU_IDCT); tl_pend.col_limit = col_limit; }
 template <int LOG2> void t_idct_dc(int16_t *coeffs) { note_kind(coeffs, OHEVC_TU_DC); }
 void t_idct_4x4_luma(int16_t *coeffs) { note_kind(coeffs, OHEVC_TU_DST4); }
 void t_transform_skip(int16_t *coeffs, int16_t) { note_kind(coeffs, OHEVC_TU_SKIP); }
@@ -262,8 +265,10 @@ template <int LOG2> void t_transform_add(uint8_t *dst, int16_t *coeffs, ptrdiff_
         for (int i = 0; i < (1 << (2 * LOG2)); i++) own[i] = (int16_t)(coeffs[i] - ((scale * y[i]) >> 3));
         rc = ohevc_rec_tu_cross(tl_ctx, l.plane, l.x, l.y, LOG2, kind, own, tl_pend.luma_kind, y, scale, 1);
     } else {
-        rc = ohevc_rec_tu(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1);
+        const int lim = kind == OHEVC_TU_IDCT && pending && tl_pend.col_limit > 0 ? tl_pend.col_limit : 64;
+        rc = ohevc_rec_tu_limited(tl_ctx, l.plane, l.x, l.y, LOG2, kind, coeffs, 1, lim, lim + 4);
     }
+    tl_pend.col_limit = 0;
     if (rc != OHEVC_OK) fail(rc);
 }
 

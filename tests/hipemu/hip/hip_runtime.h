@@ -87,6 +87,8 @@ hipError_t hipMemcpy2DAsync(void *dst, size_t dpitch, const void *src, size_t sp
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s);
 hipError_t hipMemset(void *dst, int v, size_t n);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int priority);
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);

@@ -264,3 +264,24 @@ def drive_tables(reflib, bd, W, H, cur, refs, enc, hevcdsp_hook=None, videodsp_h
            ops.ctypes.data_as(C.c_void_p), C.c_int(len(ops)), coeffs.ctypes.data_as(C.c_void_p), bits.ctypes.data_as(C.c_void_p),
            C.c_void_p(hevcdsp_hook), C.c_void_p(videodsp_hook), C.c_void_p(intra_hook), C.c_void_p(geom))
     return rc
+
+
+def check_switches(kind, product, names, threads=1):
+    """Round-5 switches of the product library that no small stream trips on its own, forced: (a) every frame with intra levels goes to the
+    context's long-chain stream (a picture of the golden streams has a few dozen levels, the default threshold is 96) - the hand-over between a
+    context's two streams at every picture; (b) coefficients uploaded whole, as in rounds 1-4, against the compact default.  Same pictures."""
+    import ctypes as C
+    from oracle import pystream as ps
+    from test_stream_cpu import frames_md5, load_golden
+    product.ohevc_debug_set_long_chain_levels.argtypes = [C.c_int]
+    product.ohevc_debug_set_compact_coeffs.argtypes = [C.c_int]
+    try:
+        for levels, compact in ((1, 1), (96, 0), (1, 0)):
+            product.ohevc_debug_set_long_chain_levels(levels)
+            product.ohevc_debug_set_compact_coeffs(compact)
+            for name in names:
+                aus, md5 = load_golden(name)
+                assert frames_md5(ps.decode_stream(kind, aus, threads, 1)) == md5, f"{name}: long_chain_levels {levels}, compact {compact}, {threads} thread(s)"
+    finally:
+        product.ohevc_debug_set_long_chain_levels(96)
+        product.ohevc_debug_set_compact_coeffs(1)

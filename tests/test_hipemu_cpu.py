@@ -188,6 +188,17 @@ def test_emu_golden_stream_with_an_early_flush_at_every_ctu_row(name, monkeypatc
     assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
 
 
+@pytest.mark.parametrize("threads", [1, 3])
+def test_emu_long_chain_stream_and_whole_coefficient_upload(threads):
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    from stream_exec import check_switches
+    with ps.Decoder("hipemu") as d:
+        product = d.product_lib()
+    check_switches("hipemu", product, ["intra_8b", "ra_8b_ctb64", "ra_10b_odd", "small_blocks", "fmt444_14b_cip_cross", "pcm"], threads)
+
+
 # ---------------------------------------------------------------- decoder instances (integration/hip_backend.h), over the emulated device code
 def _instances():
     ps = _stream_lib()

@@ -258,6 +258,12 @@ def test_golden_stream_with_an_early_flush_at_every_ctu_row(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hip", aus)) == md5
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+def test_long_chain_stream_and_whole_coefficient_upload(threads):
+    from stream_exec import check_switches
+    check_switches("hip", ps._product_lib(), sorted(CASES), threads)
+
+
 # ---------------------------------------------------------------- decoder instances (integration/hip_backend.h)
 def test_two_decoders_decode_different_streams_concurrently():
     import instance_cases
