@@ -69,6 +69,13 @@ int  ohevc_host_unpin_all(ohevc_ctx *ctx);
 /* ... or of one allocation only (every registered range overlapping it): the application returned THAT memory to its allocator, e.g. the decoder's
  * buffer pool changed geometry and a buffer address came back with another size.  Copies into other ranges that are in flight are not disturbed. */
 int  ohevc_host_unpin(ohevc_ctx *ctx, void *ptr, size_t bytes);
+/* Choices a decoder instance makes for the contexts it creates (value < 0: back to the process default, which include/ohevc_debug.h's setters
+ * move for tests).  OHEVC_OPT_LEVEL_LAUNCH: executor of the intra-coded blocks - 0 dependency levels (chain kernel; default), 1 all levels in one
+ * launch, 2 chosen per picture, 3 CTB tasks; OHEVC_OPT_FILTERS_ON_DEVICE: 1 deblocking parameters derived on the device from the decoder's maps
+ * (default), 0 one job per edge derived on the host. */
+enum { OHEVC_OPT_LEVEL_LAUNCH = 0, OHEVC_OPT_FILTERS_ON_DEVICE = 1 };
+int  ohevc_ctx_set_option(ohevc_ctx *ctx, int option, int value);
+int  ohevc_ctx_get_option(const ohevc_ctx *ctx, int option);
 /* Frame-parallel decoding across GPUs (one process per GPU; the reference's counterpart is the shared DPB of its frame threads,
  * pthread_frame.c:479-513 + hevc_await_progress hevc.c:1951-1958): the owner of a picture copies a finished plane out with
  * ohevc_pic_export, the other processes copy it into their own store with ohevc_pic_import; the transport in between (RCCL

@@ -96,6 +96,9 @@ int ohevc_debug_level_tu(struct ohevc_ctx *ctx, int level, int log2_size, int ki
 /* the intra work of the CTB executor (level launch mode 2): tasks in raster order, their operation words (ohevc_dev_ctbs) and the job arrays they index */
 int ohevc_debug_ctbs(struct ohevc_ctx *ctx, const struct ohevc_ctb_task **tasks, int *ntasks, const uint32_t **ops, const struct ohevc_intra_job **intra_jobs,
                      const struct ohevc_tu_job **tu_jobs, int *log2_ctb_size);
+/* 1: the jobs of every dependency level are staged back to front (the kernel emulator runs the workgroups of a launch one after the other in
+ * launch order: an order that hides a dependency the level computation missed; the jobs of a level are independent, so any order must do) */
+int ohevc_debug_set_reverse_levels(int on);
 /* a frame with at least this many recorded dependency levels is issued on the context's long-chain stream (highest stream priority: a hardware
  * queue pool of its own); 0: never (rounds 1-4).  Default 96. */
 int ohevc_debug_set_long_chain_levels(int levels);

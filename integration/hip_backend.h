@@ -43,6 +43,9 @@ typedef struct ohhip_options {
     int record_only;         /* 1: no device, no pixels: host-side profiling / software-executor tests (default 0; OHHIP_RECORD_ONLY) */
     int test_fail_index;     /* fault injection of the multi-process tests: the owner fails on this picture (default -1; OHHIP_TEST_FAIL_INDEX) */
     int flush_intra_kib;     /* an intra picture's recorded work goes to the device at the end of a CTU row once this many KiB are waiting; 0: only at the frame end; -1 (default): by the picture's size - 0.45 bytes per luma sample, 512 .. 4096 KiB: 911 KiB at 1080p (OHHIP_FLUSH_INTRA_KIB) */
+    int level_launch;        /* executor of the intra-coded blocks of THIS decoder's contexts (OHEVC_OPT_LEVEL_LAUNCH, ohevc_ctx.h): 0 levels, 1 one level kernel, 2 chosen per picture, 3 CTB tasks; -1 (default): the library's default (OHHIP_LEVEL_LAUNCH) */
+    int device_filters;      /* 1: deblocking parameters derived on the device from the decoder's maps, 0: one job per edge derived on the host; -1 (default): the library's default (OHHIP_DEVICE_FILTERS) */
+    int crash_backtrace;     /* 1: SIGSEGV / SIGABRT print a backtrace (debugging aid; default 0; OHHIP_BACKTRACE) */
     const char *trace_path;  /* per-picture host timeline (parse start, hook start, issue end, hook end) written here at free (default OHHIP_TRACE_FRAMES) */
     struct ohhip_backend *base_layer;   /* SHVC: this decoder is an enhancement-layer decoder (decoder-id > 0, openHevcWrapper.c:92) and names the
                                            back end of the decoder its BL_avcontext points at (openHevcWrapper.c:107-108).  The two then share one
@@ -52,6 +55,7 @@ typedef struct ohhip_options {
 } ohhip_options;
 
 void ohhip_options_default(ohhip_options *o);
+size_t ohhip_options_size(void);                            /* sizeof(ohhip_options) as the back end was compiled: a host built against another version must not go on */
 ohhip_backend *ohhip_backend_new(const ohhip_options *o);                 /* NULL: ohevc_last_error() says why */
 int  ohhip_backend_attach(ohhip_backend *be, struct AVCodecContext *avctx);   /* before avcodec_open2 */
 /* "frame complete, before output" for one decoding thread (with frame threads the decoder's own end-of-frame report has done it already) */

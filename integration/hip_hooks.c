@@ -169,6 +169,7 @@ static void publish_failed(ohhip_backend *be)
 }
 
 /* this thread's context in instance `be` (created on first use; all of them share the root's picture store) */
+static void apply_ctx_options(const ohhip_backend *be, ohevc_ctx *ctx);
 static ohevc_ctx *new_thread_ctx(ohhip_backend *be)
 {
     ohevc_ctx *ctx = NULL;
@@ -179,6 +180,7 @@ static ohevc_ctx *new_thread_ctx(ohhip_backend *be)
         ohevc_ctx_destroy(ctx);
         return NULL;
     }
+    apply_ctx_options(be, ctx);
     pthread_mutex_lock(&be->lock);
     if (be->nall < 128) {
         be->all[be->nall++] = ctx;
@@ -788,18 +790,35 @@ static int derive_filters(HEVCContext *s)
 }
 
 /* ---- instances ---- */
+/* The environment supplies DEFAULTS for ohhip_options and nothing else: this is the only place of the back end that looks at it.  An
+ * application that fills ohhip_options itself (hip_backend.h) never depends on the environment of its process. */
+static const char *env_str(const char *name) { const char *v = getenv(name); return v && v[0] ? v : NULL; }
+static int env_int(const char *name, int dflt) { const char *v = env_str(name); return v ? atoi(v) : dflt; }
+
+size_t ohhip_options_size(void) { return sizeof(ohhip_options); }     /* for hosts that mirror the struct instead of including hip_backend.h */
+
 void ohhip_options_default(ohhip_options *o)
 {
     memset(o, 0, sizeof(*o));
-    o->device = getenv("OHHIP_DEVICE") ? atoi(getenv("OHHIP_DEVICE")) : 0;
-    o->bulk_filters = !(getenv("OHHIP_BULK_FILTERS") && atoi(getenv("OHHIP_BULK_FILTERS")) == 0);
-    o->defer_download = getenv("OHHIP_DEFER_DOWNLOAD") != NULL;
-    o->pin_frames = !(getenv("OHHIP_PIN_FRAMES") && atoi(getenv("OHHIP_PIN_FRAMES")) == 0);
-    o->async_issue = getenv("OHHIP_ASYNC_ISSUE") ? atoi(getenv("OHHIP_ASYNC_ISSUE")) : 0;
-    o->record_only = getenv("OHHIP_RECORD_ONLY") != NULL;
-    o->test_fail_index = getenv("OHHIP_TEST_FAIL_INDEX") ? atoi(getenv("OHHIP_TEST_FAIL_INDEX")) : -1;
-    o->trace_path = getenv("OHHIP_TRACE_FRAMES");
-    o->flush_intra_kib = getenv("OHHIP_FLUSH_INTRA_KIB") ? atoi(getenv("OHHIP_FLUSH_INTRA_KIB")) : -1;
+    o->device = env_int("OHHIP_DEVICE", 0);
+    o->bulk_filters = env_int("OHHIP_BULK_FILTERS", 1) != 0;
+    o->defer_download = env_str("OHHIP_DEFER_DOWNLOAD") != NULL;
+    o->pin_frames = env_int("OHHIP_PIN_FRAMES", 1) != 0;
+    o->async_issue = env_int("OHHIP_ASYNC_ISSUE", 0);
+    o->record_only = env_str("OHHIP_RECORD_ONLY") != NULL;
+    o->test_fail_index = env_int("OHHIP_TEST_FAIL_INDEX", -1);
+    o->trace_path = env_str("OHHIP_TRACE_FRAMES");
+    o->flush_intra_kib = env_int("OHHIP_FLUSH_INTRA_KIB", -1);
+    o->level_launch = env_int("OHHIP_LEVEL_LAUNCH", -1);
+    o->device_filters = env_int("OHHIP_DEVICE_FILTERS", -1);
+    o->crash_backtrace = env_str("OHHIP_BACKTRACE") != NULL;
+}
+
+/* this instance's choices on a context it has made (the library's process-wide debug setters stay what they are: defaults for tests) */
+static void apply_ctx_options(const ohhip_backend *be, ohevc_ctx *ctx)
+{
+    ohevc_ctx_set_option(ctx, OHEVC_OPT_LEVEL_LAUNCH, be->opt.level_launch);
+    ohevc_ctx_set_option(ctx, OHEVC_OPT_FILTERS_ON_DEVICE, be->opt.device_filters);
 }
 
 ohhip_backend *ohhip_backend_new(const ohhip_options *o)
@@ -812,7 +831,7 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
         ohhip_options_default(&def);
         o = &def;
     }
-    if (getenv("OHHIP_BACKTRACE")) {
+    if (o->crash_backtrace) {
         signal(SIGSEGV, crash_handler);
         signal(SIGABRT, crash_handler);
     }
@@ -827,13 +846,6 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
      * have switched record-only mode on itself (and installed a frame sink) before opening the decoder: leave that alone. */
     if (o->record_only)
         ohevc_debug_set_record_only(1);
-    /* process-wide A/B switches of the library (include/ohevc_debug.h), kept as environment variables: the executor of the intra-coded
-     * blocks (0 levels - the default since the chain kernel takes a picture's levels in one launch: recording the CTB form beside them cost the
-     * parser 1-5 % for a choice the levels now always win, profiles/r4q_levelmode_ab_summary.txt -, 1 level kernel, 3 CTB tasks, 2 = both
-     * recorded, chosen per picture) and the host derivation of the deblocking parameters */
-    ohevc_debug_set_level_launch(getenv("OHHIP_LEVEL_LAUNCH") ? atoi(getenv("OHHIP_LEVEL_LAUNCH")) : 0);
-    if (getenv("OHHIP_DEVICE_FILTERS"))
-        ohevc_debug_set_filters_on_device(atoi(getenv("OHHIP_DEVICE_FILTERS")));
     if (o->base_layer && (o->base_layer->magic != OHHIP_MAGIC || !o->base_layer->root)) {
         fprintf(stderr, "ohhip: base_layer does not name a live back end\n");
         pthread_mutex_destroy(&be->lock);
@@ -850,6 +862,7 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
         free(be);
         return NULL;
     }
+    apply_ctx_options(be, be->root);
     if (o->trace_path)
         be->trace = calloc(MAX_TRACE, sizeof(*be->trace));
     pthread_mutex_lock(&g_reg_lock);

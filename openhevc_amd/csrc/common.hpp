@@ -100,6 +100,23 @@ __device__ __forceinline__ int dot2_i16(unsigned a, unsigned b, int acc)
 #include <ohevc_gfx950_ops.hpp>
 namespace ohevc {
 
+// The library's ONE place that looks at the process environment (runtime.hip: config()), read once.  Everything a decoder can choose per
+// instance is an option of the context (ohevc_ctx_set_option) or of the sample back end (ohhip_options); kernel forms and executors that lost
+// their A/B comparisons are selectable through include/ohevc_debug.h only (tests, the lab build).  What is left here is what belongs to the
+// process: timeouts for slow (sanitizer) builds, start-up sizes, diagnosis output.
+struct Config {
+    int ref_wait_seconds = 20;        // OHEVC_REF_WAIT_SECONDS: how long a frame thread waits for another thread's frame end before it gives up
+    int prewarm_kib = 3072;           // OHEVC_PREWARM_KIB: first size of a context's upload buffers, touched when the context is made (0: off)
+    int picture_batch = 1;            // OHEVC_PICTURE_BATCH=0: every device picture its own allocation (AddressSanitizer / guard-page runs)
+    const char *frames_token = nullptr;    // OHEVC_FRAMES_TOKEN: what the ranks of the sockets wire present to each other (set by the launcher)
+    // OHEVC_TRACE=word[,word...]: diagnosis output on stderr
+    bool trace_order = false, trace_timing = false, trace_ctb = false, trace_levels = false, trace_launches = false, trace_sao = false, trace_reg = false;
+    bool profile_slots = false;       // "slots": cycle counters per table-slot family, printed when a context forgets its tables
+    bool ctb_debug = false;           // "ctbdebug": the CTB executor's sync words after every launch
+    int trace_at[3] = {-1, -1, -1};   // "at=plane:x:y": every recorded job whose block covers that sample
+};
+const Config &config();
+
 // {clip_int16(lo), clip_int16(hi)} packed: v_cvt_pk_i16_i32
 __device__ __forceinline__ unsigned sat_pack_i16(int lo, int hi)
 {

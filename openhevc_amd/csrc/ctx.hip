@@ -54,7 +54,7 @@ struct Issuer {
     bool stop = false;
     int error = OHEVC_OK;                  // sticky: first failure of an asynchronous frame end (ohevc_ctx_async_status)
     char error_text[256] = {};
-    double busy_s = 0;                     // seconds the issuer spent issuing (OHEVC_TRACE_TIMING)
+    double busy_s = 0;                     // seconds the issuer spent issuing (OHEVC_TRACE=timing)
     long frames = 0;
     int device = 0;
     struct PicStore *store = nullptr;
@@ -143,28 +143,24 @@ void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream sc
 static bool g_record_only = false;   // ohevc_debug_set_record_only
 static int g_compact_coeffs = 1;     // ohevc_debug_set_compact_coeffs: 0 = every block crosses the bus whole (rounds 1-4; A/B and tests)
 extern "C" int ohevc_debug_set_compact_coeffs(int on) { g_compact_coeffs = on != 0; return OHEVC_OK; }
-static int g_fuse_intra = getenv("OHEVC_FUSE_INTRA") ? atoi(getenv("OHEVC_FUSE_INTRA")) : 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
+static int g_fuse_intra = 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static std::atomic<int> g_level_launch{0};      // ohevc_debug_set_level_launch (the sample hooks set it, to the same value, from every decoder that is opened: atomic)
 // The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
 // launch of its own ~6.6 us of kernel plus 2 - 4 us until the next one starts, whatever its width: up to four passes the chain is cheaper.
-static int g_intra_chain_waves = getenv("OHEVC_INTRA_CHAIN_WAVES") ? atoi(getenv("OHEVC_INTRA_CHAIN_WAVES")) : 32;
-static int g_intra_chain_min_run = getenv("OHEVC_INTRA_CHAIN_MIN_RUN") ? atoi(getenv("OHEVC_INTRA_CHAIN_MIN_RUN")) : 2;      // shortest run (levels) worth a chain launch
-static int g_intra_chain = getenv("OHEVC_INTRA_CHAIN") ? atoi(getenv("OHEVC_INTRA_CHAIN")) : 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
-// OHEVC_UPLOAD_LANES=2: the filter maps of a frame end travel through a staging / device buffer pair of their own, so their staging copy does
-// not wait on the host for the job arrays' H2D copy (which sits in the stream behind the reference pictures' completion).  1 (default): one pair.
-static int g_upload_lanes = getenv("OHEVC_UPLOAD_LANES") ? atoi(getenv("OHEVC_UPLOAD_LANES")) : 1;
-static int g_intra_pack = getenv("OHEVC_INTRA_PACK") ? atoi(getenv("OHEVC_INTRA_PACK")) : 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
-static const bool g_trace_order = getenv("OHEVC_TRACE_ORDER") != nullptr;
-static const bool g_trace_timing = getenv("OHEVC_TRACE_TIMING") != nullptr;
+static int g_intra_chain_waves = 32;             // ohevc_debug_set_intra_chain_limits
+static int g_intra_chain_min_run = 2;      // shortest run (levels) worth a chain launch
+static int g_intra_chain = 1; // ohevc_debug_set_intra_chain: runs of narrow levels in one launch (ohevc_dev_intra_chain)
+static bool g_reverse_levels = false;       // ohevc_debug_set_reverse_levels: the jobs of every level in reverse order (tests: their order must not matter)
+extern "C" int ohevc_debug_set_reverse_levels(int on) { g_reverse_levels = on != 0; return OHEVC_OK; }
+static int g_intra_pack = 1;   // ohevc_debug_set_intra_pack: the packed intra kernel (N lanes per block) serves the levels
+static const bool g_trace_order = ohevc::config().trace_order;         // OHEVC_TRACE=order / timing (common.hpp: Config)
+static const bool g_trace_timing = ohevc::config().trace_timing;
 // how long a frame thread waits for another thread to issue the frame end of a reference picture before it gives up (a decoding thread
 // that died would otherwise hang the pool).  The sanitizer build of the kernel emulator needs minutes where a device needs milliseconds.
-static const int g_ref_wait_s = getenv("OHEVC_REF_WAIT_SECONDS") && atoi(getenv("OHEVC_REF_WAIT_SECONDS")) > 0 ? atoi(getenv("OHEVC_REF_WAIT_SECONDS")) : 20;
-// OHEVC_TRACE_AT=plane,x,y: print every recorded job whose block covers that sample (diagnosis of a mismatching block)
-static int g_trace_at[3] = {-1, -1, -1};
-static const bool g_trace_at_on = [] {
-    const char *e = getenv("OHEVC_TRACE_AT");
-    return e && sscanf(e, "%d,%d,%d", &g_trace_at[0], &g_trace_at[1], &g_trace_at[2]) == 3;
-}();
+static const int g_ref_wait_s = ohevc::config().ref_wait_seconds;
+// OHEVC_TRACE=at=plane:x:y: print every recorded job whose block covers that sample (diagnosis of a mismatching block)
+static const int *const g_trace_at = ohevc::config().trace_at;
+static const bool g_trace_at_on = ohevc::config().trace_at[0] >= 0;
 static inline bool trace_hit(int plane, int x, int y, int w, int h)
 {
     return g_trace_at_on && plane == g_trace_at[0] && g_trace_at[1] >= x && g_trace_at[1] < x + w && g_trace_at[2] >= y && g_trace_at[2] < y + h;
@@ -273,7 +269,8 @@ struct ohevc_ctx : Rec {
     int recon_lane = 0, last_recon_lane = 0;      // the staging / device buffer pair the next / the last ohevc_frame_reconstruct upload takes
     int flushed_intra = 0;            // ohevc_frame_flush_intra: intra jobs of this frame already handed to the device by an early flush
     bool flush_closed = false;        // ... and no further early flush for this frame (it has inter prediction: its references may not be issued yet)
-    int frame_mode = 0;               // g_level_launch as it was at frame_begin (one executor per picture)
+    int frame_mode = 0;               // the executor of the intra-coded blocks as chosen at frame_begin (one executor per picture)
+    int opt[2] = { -1, -1 };          // ohevc_ctx_set_option: OHEVC_OPT_LEVEL_LAUNCH, OHEVC_OPT_FILTERS_ON_DEVICE (-1: the process default)
     int log2_ctb = 0;                 // CTB size named by the picture's intra jobs (0: none seen yet, -1: they disagree)
     std::vector<ohevc_ctb_task> ctb_tasks;                // scratch of frame_reconstruct
     std::vector<uint32_t> ctb_opwords, ctb_sync_zero;
@@ -297,7 +294,7 @@ struct ohevc_ctx : Rec {
     PinnedBuf stage[2], table_stage;
     ohevc_frame_stats stats = {}, last_stats = {};
     std::mutex stats_m;                    // last_stats: written by the context's own thread or, for an asynchronous frame end, by the issuer thread; read by ohevc_frame_get_stats
-    double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE_TIMING: host seconds blocked on other threads' frame ends / spent issuing
+    double t_wait_refs = 0, t_issue = 0;   // OHEVC_TRACE=timing: host seconds blocked on other threads' frame ends / spent issuing
     // the filter maps / records of the frame end, staged by frame_end_impl BEFORE it calls ohevc_frame_reconstruct so that they travel in the
     // same host-to-device copy as the job arrays (tail_base: where they landed in that upload; SIZE_MAX: they did not travel yet)
     std::vector<std::pair<const void *, size_t>> tail_parts;
@@ -334,7 +331,7 @@ static int free_picture(Picture &p, bool dry = false, PicStore *store = nullptr)
 }
 
 // OHEVC_PICTURE_BATCH=0: every picture its own allocation (the AddressSanitizer pass over the emulated device code wants red zones around each)
-static const int g_picture_batch = getenv("OHEVC_PICTURE_BATCH") ? atoi(getenv("OHEVC_PICTURE_BATCH")) : 1;
+static const int g_picture_batch = ohevc::config().picture_batch;
 
 // a zeroed piece of `bytes` bytes out of the store's batches (PicStore::spare); nullptr: none to be had, allocate the old way
 static unsigned char *take_piece(PicStore &st, size_t bytes, hipStream_t stream)
@@ -442,7 +439,7 @@ static int select_stream(ohevc_ctx *c, bool long_chain)
     return OHEVC_OK;
 }
 
-static const int g_prewarm_kib = getenv("OHEVC_PREWARM_KIB") ? atoi(getenv("OHEVC_PREWARM_KIB")) : 3072;      // 0: off; the upload buffers' first size (x 1.5)
+static const int g_prewarm_kib = ohevc::config().prewarm_kib;      // 0: off; the upload buffers' first size (x 1.5)
 static void prewarm(ohevc_ctx *c)
 {
     if (g_prewarm_kib <= 0) return;
@@ -571,6 +568,18 @@ extern "C" int ohevc_ctx_set_concurrent(ohevc_ctx *c, int on)
 }
 
 extern "C" int ohevc_debug_set_level_launch(int mode) { return g_level_launch.exchange(mode, std::memory_order_relaxed); }
+// per-context choices (a decoder instance sets them on the contexts it makes; the process-wide debug setters only supply the defaults)
+extern "C" int ohevc_ctx_set_option(ohevc_ctx *c, int option, int value)
+{
+    OHEVC_REQUIRE(c != nullptr && (option == OHEVC_OPT_LEVEL_LAUNCH || option == OHEVC_OPT_FILTERS_ON_DEVICE), "unknown option");
+    OHEVC_REQUIRE(option != OHEVC_OPT_LEVEL_LAUNCH || value <= 3, "level-launch mode 0..3");
+    c->opt[option] = value < 0 ? -1 : value;
+    return OHEVC_OK;
+}
+extern "C" int ohevc_ctx_get_option(const ohevc_ctx *c, int option)
+{
+    return c && (option == OHEVC_OPT_LEVEL_LAUNCH || option == OHEVC_OPT_FILTERS_ON_DEVICE) ? c->opt[option] : -1;
+}
 extern "C" int ohevc_debug_set_intra_chain(int on) { const int prev = g_intra_chain; g_intra_chain = on != 0; return prev; }
 extern "C" int ohevc_debug_set_intra_pack(int on) { const int prev = g_intra_pack; g_intra_pack = on != 0; return prev; }
 extern "C" int ohevc_debug_set_fuse_intra(int on) { const int prev = g_fuse_intra; g_fuse_intra = on != 0; return prev; }
@@ -1150,7 +1159,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
     }
     c->ref_slots.clear();
     c->target_guarded = false;
-    c->frame_mode = g_level_launch;
+    c->frame_mode = c->opt[OHEVC_OPT_LEVEL_LAUNCH] >= 0 ? c->opt[OHEVC_OPT_LEVEL_LAUNCH] : (int)g_level_launch;
     c->flushed_intra = 0; c->flush_closed = false;
     c->log2_ctb = 0;
     for (int i = 0; i < 3; i++) {
@@ -1885,8 +1894,6 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         // (~10.5 us per level on the device and about as much launch work on the host: profiles/r02q, r02t)
         const double level_us = (g_fuse_intra ? 5.5 : 10.5) * std::max(c->max_level, 0);      // one launch per level when the residuals ride with their prediction
         c->stats.chose_ctbs = ctb_us < level_us;
-        static const char *force = getenv("OHEVC_CTB_CHOICE");       // diagnosis: "ctb" / "levels" overrides the estimate
-        if (force) c->stats.chose_ctbs = force[0] == 'c';
     } else {
         c->stats.chose_ctbs = !c->ctb_tasks.empty();
     }
@@ -1902,7 +1909,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     } else {
         c->ctb_tasks.clear(); c->ctb_opwords.clear();
     }
-    if (getenv("OHEVC_TRACE_CTB")) {
+    if (ohevc::config().trace_ctb) {
         size_t l0 = 0;
         if (c->max_level >= 0) for (uint64_t m = c->levels[0].touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); l0 += c->levels[0].tu[b >> 4][b & 15].size(); }
         unsigned long long h = 1469598103934665603ull;
@@ -1911,7 +1918,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         fprintf(stderr, "ctb trace: mode %d chose %d tasks %zu ops %zu intra %zu tu %zu max_level %d level0_tu %zu coeffs %zu hash %llx\n", c->frame_mode, c->stats.chose_ctbs,
                 c->ctb_tasks.size(), c->ctb_opwords.size(), c->ctb_intra.size(), c->ctb_tu.size(), c->max_level, l0, c->coeffs.size(), h);
     }
-    if (getenv("OHEVC_TRACE_LEVELS")) {       // diagnosis: how wide the dependency levels are, in wavefronts of the packed intra kernel
+    if (ohevc::config().trace_levels) {       // diagnosis: how wide the dependency levels are, in wavefronts of the packed intra kernel
         fprintf(stderr, "levels: target %d max_level %d waves:", c->cur, c->max_level);
         for (int l = 1; l <= c->max_level; l++) {
             int cnt[4] = {0, 0, 0, 0};
@@ -1944,7 +1951,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         LevelBins &lb = c->levels[l];
         // OHEVC_REVERSE_LEVELS=1 (tests over the emulated device code, whose workgroups run one after the other in launch order): the
         // jobs of a level are independent, so their order must not matter - a dependency the level computation missed shows up
-        const bool reverse_levels = getenv("OHEVC_REVERSE_LEVELS") != nullptr;          // (looked up per picture: tests switch it inside one process)
+        const bool reverse_levels = g_reverse_levels;          // ohevc_debug_set_reverse_levels
         if (reverse_levels) {
             std::reverse(lb.intra.begin(), lb.intra.end());
             std::reverse(lb.intra_res.begin(), lb.intra_res.end());
@@ -1979,7 +1986,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     chain.clear();
     c->chain_first.assign((size_t)c->max_level + 2, 0);
     c->chain_len.assign((size_t)c->max_level + 2, 0);
-    if (g_intra_chain && g_level_launch != 1) {
+    if (g_intra_chain && c->frame_mode != 1) {
         auto waves_of = [&](int k) { return (loff[k].count[0] + 15) / 16 + (loff[k].count[1] + 7) / 8 + (loff[k].count[2] + 3) / 4 + (loff[k].count[3] + 1) / 2; };
         const int max_waves = std::min(g_intra_chain_waves, ohevc_intra_chain_max_waves());
         auto narrow = [&](int k) { return loff[k].packed && waves_of(k) > 0 && waves_of(k) <= max_waves; };
@@ -2013,7 +2020,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     size_t intra_base = 0, tu_base = 0;
     bool have_intra_base = false, have_tu_base = false;
     int total_wgs = 0;
-    if (g_level_launch == 1) {
+    if (c->frame_mode == 1) {
         for (int l = 1; l <= c->max_level; l++) {
             LevelBins &lb = c->levels[l];
             if (!lb.intra.empty()) {
@@ -2066,10 +2073,10 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     }
     // Early flushes of one picture (ohevc_frame_flush_intra) alternate between the two staging / device buffer pairs: with one pair the
     // parsing thread stood still in every flush until the device had finished the chain of the flush before (the arena that chain reads
-    // is what this upload overwrites, and the staging copy waits for the upload in front of it).  OHEVC_UPLOAD_LANES=2 gives the second
-    // pair to the filter maps instead.
-    const int rlane = g_upload_lanes != 2 ? c->recon_lane : 0;
-    if (g_upload_lanes != 2) c->recon_lane ^= 1;
+    // is what this upload overwrites, and the staging copy waits for the upload in front of it).  (Giving the second pair to the filter maps
+    // of the frame end instead tied in two rounds of A/B runs and is gone.)
+    const int rlane = c->recon_lane;
+    c->recon_lane ^= 1;
     c->last_recon_lane = rlane;
     if ((rc = upload_jobs(c, parts, total, rlane)) != OHEVC_OK) return rc;
     struct CallTime { ohevc_ctx *c; int k; double t0; ~CallTime() { if (g_trace_timing) c->t_part[k] += now_s() - t0; } } call_time{c, 1, g_trace_timing ? now_s() : 0};
@@ -2119,7 +2126,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
     if (!phases.empty()) {
         // (issued after level 0 below; prepared here to keep the offsets together)
     }
-    const bool trace_launches = getenv("OHEVC_TRACE_LAUNCHES") != nullptr;
+    const bool trace_launches = ohevc::config().trace_launches;
     int n_lv_intra = 0, n_lv_tu = 0;
     int chained_until = -1;                          // levels up to here had their intra blocks done by a chain launch
     for (int level = 0; level <= last_separate; level++) {
@@ -2190,7 +2197,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
                             reinterpret_cast<const ohevc_tu_job *>(base + off_cu), d_coeffs, reinterpret_cast<uint32_t *>(base + off_cs), c->stream);
         if (rc != OHEVC_OK) return rc;
         c->stats.launches++;
-        static const bool ctb_debug = getenv("OHEVC_CTB_DEBUG") != nullptr;
+        static const bool ctb_debug = ohevc::config().ctb_debug;
         if (ctb_debug) {       // diagnosis: wait (bounded) for the launch, then look at the sync words: home / ticket / flags / progress
             const double t0 = now_s();
             hipError_t q;
@@ -2287,7 +2294,7 @@ static int frame_end_impl(ohevc_ctx *c)
     // The filter maps and records are staged FIRST and handed to ohevc_frame_reconstruct, which puts them behind its job arrays in ONE host-to-
     // device copy (one staging pass, one copy, one event less per picture).  (It does not shorten the frame end: about a dozen launches into a
     // picture some call blocks until the device has caught up - whichever call it is, with or without a second copy in front of it - so the
-    // calls of a frame end take as long as the device needs for its work, OHEVC_TRACE_TIMING, profiles/r04o_* - r04q_*.)
+    // calls of a frame end take as long as the device needs for its work, OHEVC_TRACE=timing, profiles/r04o_* - r04q_*.)
     merge_side(c);                                      // (slice threads: their recorders hold filter records too; the arrays must not move after this)
     if (c->sao.empty()) c->bypass.clear();
     const bool filters = !c->dry && (!c->dbk_v.empty() || !c->dbk_h.empty() || !c->sao.empty() || !c->dbk_blob.empty());
@@ -2307,7 +2314,7 @@ static int frame_end_impl(ohevc_ctx *c)
                                return ohevc_sao_job_is_wide(&j, p->planes, p->planes, p->bd) != 0; }) - c->sao.begin());
         off_s = c->sao.empty() ? 0 : stage_put(parts, total, c->sao.data(), c->sao.size() * sizeof(ohevc_sao_job));
         off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
-        if (g_upload_lanes != 2) { c->tail_parts = parts; c->tail_total = total; }
+        c->tail_parts = parts; c->tail_total = total;
     }
     c->tail_base = SIZE_MAX;
     int rc = ohevc_frame_reconstruct(c);
@@ -2320,9 +2327,9 @@ static int frame_end_impl(ohevc_ctx *c)
     if (filters) {
         int lane = c->last_recon_lane;                  // (the maps rode with the job arrays of the reconstruction above)
         size_t tail = c->tail_base;
-        if (tail == SIZE_MAX) {                           // nothing was reconstructed (or OHEVC_UPLOAD_LANES=2): an upload of their own
-            lane = g_upload_lanes == 2 ? 1 : c->recon_lane;
-            if (g_upload_lanes != 2) c->recon_lane ^= 1;
+        if (tail == SIZE_MAX) {                           // nothing was reconstructed: an upload of their own
+            lane = c->recon_lane;
+            c->recon_lane ^= 1;
             if ((rc = upload_jobs(c, parts, total, lane)) != OHEVC_OK) return rc;
             tail = 0;
         }
@@ -2624,7 +2631,7 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
             st.issuer = new Issuer();
             st.issuer->device = c->device;
             st.issuer->store = &st;
-            static const int n_threads = getenv("OHEVC_ISSUER_THREADS") && atoi(getenv("OHEVC_ISSUER_THREADS")) > 0 ? atoi(getenv("OHEVC_ISSUER_THREADS")) : 4;
+            static const int n_threads = 4;
             for (int k = 0; k < n_threads; k++) st.issuer->th.emplace_back(issuer_run, st.issuer);
         }
         is = st.issuer;

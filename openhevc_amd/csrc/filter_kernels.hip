@@ -993,7 +993,7 @@ extern "C" int ohevc_dev_deblock_batch(const ohevc_plane planes[3], int bit_dept
     return OHEVC_OK;
 }
 
-static int g_deblock_variant = getenv("OHEVC_DEBLOCK_VARIANT") ? atoi(getenv("OHEVC_DEBLOCK_VARIANT")) : 0;      // 0: a lane per luma segment (shipped), 1: a lane per line (rounds 2-3)
+static int g_deblock_variant = 0;      // 0: a lane per luma segment (shipped), 1: a lane per line (rounds 2-3)
 static long long g_deblock_segment_launches;
 extern "C" int ohevc_debug_set_deblock_variant(int v) { const int prev = g_deblock_variant; g_deblock_variant = v; return prev; }
 extern "C" long long ohevc_debug_deblock_segment_launches(void) { return g_deblock_segment_launches; }

@@ -215,16 +215,23 @@ struct Ctx {
 bool g_filters_on_device = true;
 // boundary strengths on the device: 0 no (the reference's function runs on the host), 1 from the uploaded motion field, 2 from the motion
 // the picture's own MC jobs carry (ohevc_frame_keep_motion: nothing extra travels)
-int g_bs_on_device = getenv("OHEVC_DEVICE_BS") ? atoi(getenv("OHEVC_DEVICE_BS")) : 2;
+int g_bs_on_device = 2;
 
 }  // namespace
+
+// the context's own choice (ohevc_ctx_set_option) or the process default
+static inline bool filters_on_device(const ohevc_ctx *ctx)
+{
+    const int o = ohevc_ctx_get_option(ctx, OHEVC_OPT_FILTERS_ON_DEVICE);
+    return o >= 0 ? o != 0 : g_filters_on_device;
+}
 
 extern "C" int ohevc_debug_set_bs_on_device(int mode) { const int prev = g_bs_on_device; g_bs_on_device = mode < 0 ? 0 : mode > 2 ? 2 : mode; return prev; }
 
 extern "C" int ohevc_tables_bs_wanted(ohevc_ctx *ctx, int log2_ctb_size, int sao_enabled, int chroma_format_idc, int emulate_filter_lag)
 {
     const bool lag = emulate_filter_lag && log2_ctb_size == 4 && sao_enabled && chroma_format_idc != 0 && chroma_format_idc != 3;
-    return g_bs_on_device && g_filters_on_device && ctx != nullptr && ohevc_ctx_has_device(ctx) && !lag ? g_bs_on_device : 0;
+    return g_bs_on_device && filters_on_device(ctx) && ctx != nullptr && ohevc_ctx_has_device(ctx) && !lag ? g_bs_on_device : 0;
 }
 
 extern "C" int ohevc_debug_set_filters_on_device(int on) { const int prev = g_filters_on_device; g_filters_on_device = on != 0; return prev; }
@@ -257,7 +264,7 @@ extern "C" int ohevc_tables_derive_filters(ohevc_ctx *ctx, const ohevc_filter_ma
         }
         c.hls_filter(x, y);                                    // hevc.c:2693-2695: the last CTB of the picture releases itself
         c.release_held_sao();
-    } else if (g_filters_on_device && ohevc_ctx_has_device(ctx)) {
+    } else if (filters_on_device(ctx) && ohevc_ctx_has_device(ctx)) {
         // the product path: no per-edge host work - the maps travel, ohevc_dev_deblock_maps derives and filters;
         // what stays here is one SAO record per CTB and plane
         ohevc_dbk_maps d = {};

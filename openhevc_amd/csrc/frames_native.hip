@@ -146,7 +146,7 @@ struct SockWire {
         if (bind(listen_fd, reinterpret_cast<sockaddr *>(&a), sizeof(a)) != 0 || listen(listen_fd, world) != 0) return false;
         uint64_t token = 1469598103934665603ull;
         {
-            const char *env = getenv("OHEVC_FRAMES_TOKEN");
+            const char *env = ohevc::config().frames_token;
             const std::string src = env && env[0] ? std::string(env) : std::string(rendezvous ? rendezvous : "127.0.0.1:29700");
             for (unsigned char ch : src) token = (token ^ ch) * 1099511628211ull;
         }

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_
 
 // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = LDS tiles (mc3), 4 (shipped) = matrix cores (mc4) for tiles and mc3's four-jobs-per-
 // wavefront form for the small-block batch (it wins there: profiles/r02zi), 5 = mc4 for both.  (env: A/B of whole-decoder runs)
-int g_mc_variant = getenv("OHEVC_MC_VARIANT") ? atoi(getenv("OHEVC_MC_VARIANT")) : 6;
+int g_mc_variant = 6;
 
 #include "mc4_kernel.hpp"
 #include "mc4q_kernel.hpp"

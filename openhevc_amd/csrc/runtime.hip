@@ -1,5 +1,7 @@
 // runtime.hip -- library management entry points of libohevc_hip.so (error text, device selection).
 #include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "common.hpp"
 
@@ -11,6 +13,28 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+}  // namespace ohevc
+
+namespace ohevc {
+const Config &config()
+{
+    static const Config cfg = [] {
+        Config c;
+        auto env = [](const char *name) { const char *v = getenv(name); return v && v[0] ? v : nullptr; };
+        if (const char *v = env("OHEVC_REF_WAIT_SECONDS")) if (atoi(v) > 0) c.ref_wait_seconds = atoi(v);
+        if (const char *v = env("OHEVC_PREWARM_KIB")) c.prewarm_kib = atoi(v);
+        if (const char *v = env("OHEVC_PICTURE_BATCH")) c.picture_batch = atoi(v);
+        c.frames_token = env("OHEVC_FRAMES_TOKEN");
+        if (const char *v = env("OHEVC_TRACE")) {
+            auto has = [v](const char *w) { const char *p = strstr(v, w); return p && (p == v || p[-1] == ',') && (p[strlen(w)] == 0 || p[strlen(w)] == ','); };
+            c.trace_order = has("order"); c.trace_timing = has("timing"); c.trace_ctb = has("ctb"); c.trace_levels = has("levels");
+            c.trace_launches = has("launches"); c.trace_sao = has("sao"); c.trace_reg = has("reg"); c.profile_slots = has("slots"); c.ctb_debug = has("ctbdebug");
+            if (const char *at = strstr(v, "at=")) if (sscanf(at + 3, "%d:%d:%d", &c.trace_at[0], &c.trace_at[1], &c.trace_at[2]) != 3) c.trace_at[0] = -1;
+        }
+        return c;
+    }();
+    return cfg;
 }
 }  // namespace ohevc
 

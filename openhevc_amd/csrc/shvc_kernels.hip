@@ -318,7 +318,7 @@ static void axis_map(int variant, bool chroma, bool vertical, int v, int start, 
 
 }  // namespace ohevc
 
-static int g_upsample_variant = getenv("OHEVC_UPSAMPLE_VARIANT") ? atoi(getenv("OHEVC_UPSAMPLE_VARIANT")) : 0;      // 0: tile form (shipped), 1: round-2 strip form
+static int g_upsample_variant = 0;      // 0: tile form (shipped), 1: round-2 strip form
 extern "C" int ohevc_debug_set_upsample_variant(int v) { const int prev = g_upsample_variant; g_upsample_variant = v; return prev; }
 
 extern "C" int ohevc_upsample_make_maps(const ohevc_upsample_params *p, int plane, ohevc_upsample_tap *cols, int16_t *col_of,

@@ -165,12 +165,12 @@ struct Guard {
 
 struct Loc { int pic = -1, slot = -1, plane = 0, x = 0, y = 0; };     // registry entry, picture-store slot, position
 
-// OHEVC_PROFILE_SLOTS=1: cycle counters per slot family, printed by ohevc_tables_forget (host-side tuning aid)
+// OHEVC_TRACE=slots: cycle counters per slot family, printed by ohevc_tables_forget (host-side tuning aid)
 enum { K_TU, K_MC_HALF, K_MC, K_EMU, K_DBK, K_SAO, K_INTRA, K_PCM, K_END, K_NFAM };
 const char *const kFamName[K_NFAM] = {"transform_add", "put_hevc_*(first half)", "put_hevc_*_uni/bi", "emulated_edge_mc", "loop_filter",
                                       "sao", "intra_pred", "put_pcm", "end_frame"};
 unsigned long long g_prof_cycles[K_NFAM], g_prof_calls[K_NFAM];
-const bool g_prof_on = getenv("OHEVC_PROFILE_SLOTS") != nullptr;
+const bool g_prof_on = ohevc::config().profile_slots;       // OHEVC_TRACE=slots
 struct Prof {
     int k; unsigned long long t0;
     explicit Prof(int kk) : k(kk), t0(g_prof_on ? __builtin_ia32_rdtsc() : 0) {}
@@ -444,7 +444,7 @@ void sao_record(uint8_t *dst, ohevc_SAOParams *sao, int *borders, int width, int
         j.edges = (uint8_t)((ve[0] ? 1 : 0) | (ve[1] ? 2 : 0) | (he[0] ? 4 : 0) | (he[1] ? 8 : 0) |
                             (de[0] ? 16 : 0) | (de[1] ? 32 : 0) | (de[2] ? 64 : 0) | (de[3] ? 128 : 0));
     for (int k = 0; k < 5; k++) j.offset_val[k] = sao->offset_val[c_idx][k];
-    static const bool trace = getenv("OHEVC_TRACE_SAO") != nullptr;
+    static const bool trace = ohevc::config().trace_sao;
     if (trace)
         fprintf(stderr, "sao plane %d x %d y %d w %d h %d type %d klass %d borders %d restore %d edges %d quirks %d off %d %d %d %d %d\n", j.plane, j.x, j.y,
                 j.w, j.h, j.type, j.klass, j.borders, j.restore, j.edges, j.quirks, j.offset_val[0], j.offset_val[1], j.offset_val[2],
@@ -692,7 +692,7 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
     }
     OHEVC_REQUIRE(linesize[0] > 0 && linesize[1] > 0 && linesize[2] > 0, "host planes must have positive line sizes");
     hp.finish();
-    static const bool trace = getenv("OHEVC_TRACE_REG") != nullptr;
+    static const bool trace = ohevc::config().trace_reg;
     std::lock_guard<std::mutex> g(s->reg->m);
     const int n = s->npics();
     // host memory belongs to one live picture: whoever else still lists memory overlapping these planes is a dead picture

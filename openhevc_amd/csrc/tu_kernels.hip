@@ -1797,7 +1797,7 @@ extern "C" int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8])
     if (!on && g_chain_clocks) { (void)hipFree(g_chain_clocks); g_chain_clocks = nullptr; }
     return OHEVC_OK;
 }
-static int g_chain_agent_acquire = getenv("OHEVC_CHAIN_AGENT_ACQUIRE") ? atoi(getenv("OHEVC_CHAIN_AGENT_ACQUIRE")) : 0;      // A/B: the round-3 hand-over (buffer_inv sc1 per level)
+static int g_chain_agent_acquire = 0;      // A/B: the round-3 hand-over (buffer_inv sc1 per level)
 
 extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                                     const int16_t *coeffs, void *stream)

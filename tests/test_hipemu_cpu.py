@@ -104,15 +104,20 @@ def test_emu_golden_stream_filters_derived_on_the_host(name, monkeypatch):
 @pytest.mark.parametrize("name", ["intra_8b", "intra_10b_ctb16", "ra_10b_odd", "cip", "tiles", "small_blocks", "fmt422_8b", "fmt444_14b_cip_cross"])
 def test_emu_golden_stream_levels_in_reverse_order(name, monkeypatch):
     """The emulator runs the workgroups of a launch one after the other, in decoding order inside a dependency level - an order that hides a
-    dependency the level computation missed (the device runs them concurrently).  OHEVC_REVERSE_LEVELS submits every level back to front."""
+    dependency the level computation missed (the device runs them concurrently).  ohevc_debug_set_reverse_levels submits every level back to front."""
     from test_stream_cpu import frames_md5, load_golden
     ps = _stream_lib()
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
     monkeypatch.setenv("OHHIP_LEVEL_LAUNCH", "0")
-    monkeypatch.setenv("OHEVC_REVERSE_LEVELS", "1")
-    aus, md5 = load_golden(name)
-    assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
+    with ps.Decoder("hipemu") as d:
+        product = d.product_lib()
+    product.ohevc_debug_set_reverse_levels(1)
+    try:
+        aus, md5 = load_golden(name)
+        assert frames_md5(ps.decode_stream("hipemu", aus)) == md5
+    finally:
+        product.ohevc_debug_set_reverse_levels(0)
 
 
 @pytest.mark.parametrize("name", ["ra_10b_odd", "ldb_10b", "pcm", "intra_8b"])

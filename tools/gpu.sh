@@ -18,7 +18,7 @@
 #   decode <bench_decode args>   tools/bench_decode.py (whole decoder, all thread modes)             -> decode_<n>.json
 #   chain [flat|natural]         per-launch durations and stream-idle gaps of one decoding thread    -> chain.jsonl, overlap.json
 #   overlap <threads>            kernel overlap between frame threads                                -> overlap_<threads>.jsonl
-#   timing <threads> [args]      OHEVC_TRACE_TIMING split of the frame-end hook                      -> timing_<threads>.txt
+#   timing <threads> [args]      OHEVC_TRACE=timing split of the frame-end hook                      -> timing_<threads>.txt
 #   fuzz <seconds> [seed]        tools/fuzz_streams.py on the device                                 -> fuzz.json
 #   frames <ranks> [args]        bench.py --mode frames (ranks > 1: --frames-one-gpu through gloo)   -> frames_<ranks>.json
 #   ab <variants> [size]         tools/ab_tu_variants.py (lab build)                                 -> ab_tu_variants.txt
@@ -128,7 +128,7 @@ PY
       python tools/diag_overlap.py analyze /tmp/ov$th/t_results.db | tee -a $OUT/overlap_$th.jsonl | cut -c1-600 ;;
     timing)
       local th=${1:-16}; shift
-      OHEVC_TRACE_TIMING=1 timeout 300 python tools/diag_overlap.py decode $th "$@" 2>&1 | grep -v "$NOISE" | grep "timing:\|fps" | sort | uniq -c | sort -rn | head -40 | cut -c1-300 | tee $OUT/timing_$th.txt ;;
+      OHEVC_TRACE=timing timeout 300 python tools/diag_overlap.py decode $th "$@" 2>&1 | grep -v "$NOISE" | grep "timing:\|fps" | sort | uniq -c | sort -rn | head -40 | cut -c1-300 | tee $OUT/timing_$th.txt ;;
     fuzz)
       ( timeout $((${1:-60} + 60)) python tools/fuzz_streams.py ${1:-60} ${2:-$RANDOM} 2>&1 | grep -v "$NOISE" | tail -2 ) | tee $OUT/fuzz.json | cut -c1-600 ;;
     frames)
