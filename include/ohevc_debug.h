@@ -102,6 +102,9 @@ int ohevc_debug_set_reverse_levels(int on);
 /* a frame with at least this many recorded dependency levels is issued on the context's long-chain stream (highest stream priority: a hardware
  * queue pool of its own); 0: never (rounds 1-4).  Default 96. */
 int ohevc_debug_set_long_chain_levels(int levels);
+/* 2 (default): the long-chain streams of a store's contexts alternate between the highest and the lowest stream priority (two hardware-queue
+ * pools); 1: the highest only */
+int ohevc_debug_set_long_chain_pools(int n);
 /* 0: every recorded coefficient block crosses the bus whole, as in rounds 1-4 (A/B of the compact upload; default 1) */
 int ohevc_debug_set_compact_coeffs(int on);
 int ohevc_debug_arena(struct ohevc_ctx *ctx, const int16_t **coeffs, const struct ohevc_intra_cip **cips);

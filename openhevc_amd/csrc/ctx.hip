@@ -423,13 +423,17 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
 // pool: long chains get up to four queues of their own and leave the regular ones to the short frames.
 // ohevc_debug_set_long_chain_levels: a frame whose recorded dependency levels reach this many goes to the long-chain stream (0: never).
 static int g_long_chain_levels = 96;
+static int g_long_chain_pools = 2;       // ohevc_debug_set_long_chain_pools (1: the highest priority only)
+extern "C" int ohevc_debug_set_long_chain_pools(int n) { g_long_chain_pools = n < 1 ? 1 : n > 2 ? 2 : n; return OHEVC_OK; }
 extern "C" int ohevc_debug_set_long_chain_levels(int levels) { g_long_chain_levels = levels < 0 ? 0 : levels; return OHEVC_OK; }
 static int select_stream(ohevc_ctx *c, bool long_chain)
 {
     if (long_chain && !c->stream_long) {
         int least = 0, greatest = 0;
         OHEVC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, greatest));
+        // (contexts alternate between the highest and the lowest priority: two more pools, eight hardware queues for long chains)
+        static std::atomic<unsigned> n_long{0};
+        OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, (n_long.fetch_add(1) & 1u) && g_long_chain_pools > 1 ? least : greatest));
     }
     hipStream_t want = long_chain ? c->stream_long : c->stream_norm;
     if (want == c->stream) return OHEVC_OK;
@@ -2248,7 +2252,9 @@ extern "C" int ohevc_frame_flush_intra(ohevc_ctx *c, int min_pending_kib)
     if (c->dry || c->concurrent || c->flush_closed) return OHEVC_OK;
     if (!c->mc.empty() || !c->mc_small.empty()) { c->flush_closed = true; return OHEVC_OK; }
     // what an upload of the recorded work would carry: the coefficient arena and ~32 bytes of records per intra block
-    const size_t pending = c->coeffs.size() * sizeof(int16_t) + (size_t)(c->nstat[2] - c->flushed_intra) * 32;
+    // (the coefficients counted as they will lie in the dense arena, not as the compact stream that crosses the bus: the threshold stands for
+    // "enough device work to start on", and was tuned - 2 or 3 hand-overs per intra picture - on dense bytes)
+    const size_t pending = (size_t)c->dense * sizeof(int16_t) + (size_t)(c->nstat[2] - c->flushed_intra) * 32;
     if (pending < (size_t)min_pending_kib * 1024) return OHEVC_OK;
     c->flushed_intra = c->nstat[2];
     return ohevc_frame_reconstruct(c);

@@ -275,6 +275,12 @@ def check_switches(kind, product, names, threads=1):
     from test_stream_cpu import frames_md5, load_golden
     product.ohevc_debug_set_long_chain_levels.argtypes = [C.c_int]
     product.ohevc_debug_set_compact_coeffs.argtypes = [C.c_int]
+    if threads > 1 and ps.have("c"):
+        # the reference's own frame threads do not reproduce its single-thread pictures on every stream (cross_444_10b_tqb: 3 runs of 3 differ, on
+        # its C and on its SSE tables alike): such a stream says nothing about the back end
+        names = [n for n in names if frames_md5(ps.decode_stream("c", load_golden(n)[0], threads, 1)) == load_golden(n)[1]]
+    elif threads > 1:
+        names = [n for n in names if n != "cross_444_10b_tqb"]
     try:
         for levels, compact in ((1, 1), (96, 0), (1, 0)):
             product.ohevc_debug_set_long_chain_levels(levels)

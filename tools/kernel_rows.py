@@ -13,6 +13,8 @@ recomputed by the oracle from that state and compared sample by sample with what
 import os
 import sys
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -169,11 +171,15 @@ def intra_rows(bd, orc, po, g, rng, st, out):
             for f in ("flags", "bottom_left_size", "top_right_size", "flags2", "log2_ctb_size"):
                 j[f][m] = jb[f]
         j["x"], j["y"], j["log2_size"], j["mode"] = xs.ravel(), ys.ravel(), log2, rng.integers(0, 35, n)
-        d_jobs = _dev(j)
-        counts = [0, 0, 0, 0]
-        counts[log2 - 2] = n
         r = np.zeros(n, L.TU_JOB)
         r["x"], r["y"], r["reserved0"], r["coeff_off"] = j["x"], j["y"], L.TU_IDCT + 1, np.arange(n, dtype=np.uint32) * nn * nn
+        # the order the ctx layer stages a dependency level in (ohevc_intra_sort_level, include/ohevc_hip.h): by size and, inside a size, by
+        # prediction mode - the blocks that share a wavefront take one path through the predictors
+        cnt = (C.c_int32 * 4)()
+        L.check(L.load_library().ohevc_intra_sort_level(j.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.c_int(n), cnt))
+        counts = list(cnt)
+        assert counts[log2 - 2] == n
+        d_jobs = _dev(j)
         d_res = _dev(r)
         cf = torch.randint(-256, 256, (n * nn * nn,), dtype=torch.int16, device="cuda", generator=g)
 
@@ -196,8 +202,8 @@ def intra_rows(bd, orc, po, g, rng, st, out):
         alg = n * (P * (4 * nn + 1) + P * nn * nn + 2 * nn * nn)
         out[f"intra_{nn}x{nn}_with_residual_{bd}bit"] = _row(
             ms, ring, alg, n * nn * nn, bad, N_CHECK,
-            f"{n} independent luma blocks {nn}x{nn}, all 35 modes, prediction + the block's inverse-DCT residual in one pass (packed kernel, N lanes per "
-            f"block); intra_pred / pred_planar / pred_dc / pred_angular (hevcpred_template.c:30-537) + idct + transform_add")
+            f"{n} independent luma blocks {nn}x{nn}, all 35 modes (uniform), in the order the ctx layer stages a level: sorted by mode; prediction + the block's "
+            f"inverse-DCT residual in one pass (packed kernel, N lanes per block); intra_pred / pred_planar / pred_dc / pred_angular (hevcpred_template.c:30-537) + idct + transform_add")
         del d_res, cf
 
 
