@@ -197,7 +197,8 @@ def intra_rows(bd, orc, po, g, rng, st, out):
             # (blocks sit on a sparse grid: a block's neighbours are untouched samples, the oracle may work on the picture as it was)
             orc.intra_pred(bd, before, W, H, x, y, log2, 0, mode, (1, 1, 1, 1, 1), chroma_format_idc=1, strong=1, smoothing_disabled=0,
                            log2_ctb_size=6, log2_min_tb_size=2)
-            orc.tu_batch(bd, po.TU_IDCT, log2, cf[k * nn * nn:(k + 1) * nn * nn].cpu().numpy().reshape(1, nn, nn), before[0], np.array([[x, y]], np.int32))
+            co = int(r["coeff_off"][k])                     # (the level sort permuted jobs and residual records together)
+            orc.tu_batch(bd, po.TU_IDCT, log2, cf[co:co + nn * nn].cpu().numpy().reshape(1, nn, nn), before[0], np.array([[x, y]], np.int32))
             bad += not np.array_equal(got[y:y + nn, x:x + nn], before[0][y:y + nn, x:x + nn])
         alg = n * (P * (4 * nn + 1) + P * nn * nn + 2 * nn * nn)
         out[f"intra_{nn}x{nn}_with_residual_{bd}bit"] = _row(
