@@ -83,7 +83,24 @@ struct PicStore {
     struct Spare { std::vector<unsigned char *> pieces, dirty; int next_batch = 4; };
     std::map<size_t, Spare> spare;        // by piece size: zeroed pieces nobody uses yet (two layers of an SHVC stream share a store: two sizes take turns)
     std::vector<void *> batches;          // the allocations behind all pieces ever made
+    // every stream of every live context of this store: what "wait until nothing of this decoder is in flight" means (store_sync) - the other
+    // decoders of the process, on their own stores and streams, are not waited for (hipDeviceSynchronize used to do that)
+    std::mutex streams_m;
+    std::vector<hipStream_t> streams;
 };
+static void store_add_stream(PicStore &st, hipStream_t s) { if (s) { std::lock_guard<std::mutex> g(st.streams_m); st.streams.push_back(s); } }
+static void store_remove_stream(PicStore &st, hipStream_t s)
+{
+    std::lock_guard<std::mutex> g(st.streams_m);
+    st.streams.erase(std::remove(st.streams.begin(), st.streams.end(), s), st.streams.end());
+}
+static hipError_t store_sync(PicStore &st)
+{
+    std::lock_guard<std::mutex> g(st.streams_m);          // (held throughout: a context that dies meanwhile waits with destroying its streams)
+    hipError_t rc = hipSuccess;
+    for (hipStream_t s : st.streams) { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess && rc == hipSuccess) rc = e; }
+    return rc;
+}
 
 struct DevBuf {                       // grow-only device buffer
     void *p = nullptr;
@@ -434,6 +451,7 @@ static int select_stream(ohevc_ctx *c, bool long_chain)
         // (contexts alternate between the highest and the lowest priority: two more pools, eight hardware queues for long chains)
         static std::atomic<unsigned> n_long{0};
         OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, (n_long.fetch_add(1) & 1u) && g_long_chain_pools > 1 ? least : greatest));
+        store_add_stream(*c->store, c->stream_long);
     }
     hipStream_t want = long_chain ? c->stream_long : c->stream_norm;
     if (want == c->stream) return OHEVC_OK;
@@ -490,6 +508,8 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
         return OHEVC_ERR_HIP;
     }
     c->stream_norm = c->stream;
+    store_add_stream(*c->store, c->stream);
+    store_add_stream(*c->store, c->up_stream);
     prewarm(c);
     *out = c;
     return OHEVC_OK;
@@ -520,7 +540,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     for (hipStream_t st : { c->stream_norm, c->stream_long }) if (st) (void)hipStreamSynchronize(st);
     if (c->store.use_count() == 1) {            // last context of this store: the pictures go with it
-        (void)hipDeviceSynchronize();
+        (void)store_sync(*c->store);
         {
             std::unique_lock<std::shared_mutex> g(c->store->pin_m);
             while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
@@ -557,6 +577,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
     if (c->table_stage.p) (void)hipHostFree(c->table_stage.p);
     for (hipEvent_t e : c->staged) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->lane_done) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : { c->stream_norm, c->stream_long, c->up_stream }) if (st) store_remove_stream(*c->store, st);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     for (auto &e : c->dl_ring) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : { c->stream_norm, c->stream_long }) if (st) { ohevc_mc_forget_stream(st); (void)hipStreamDestroy(st); }
@@ -603,7 +624,7 @@ extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
     if (c->store->issuer && !c->is_exec) {              // frame ends this context submitted run on the issuer's streams
         async_drain(*c->store);
         OHEVC_HIP_TRY(hipSetDevice(c->device));
-        OHEVC_HIP_TRY(hipDeviceSynchronize());
+        OHEVC_HIP_TRY(store_sync(*c->store));
     }
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     c->staged_pending[0] = c->staged_pending[1] = false;
@@ -669,7 +690,7 @@ extern "C" int ohevc_pic_release(ohevc_ctx *c, int slot)
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
     // other contexts of the store may still have kernels in flight that read this picture
     if (!c->dry && !c->is_exec) async_drain(*c->store);
-    if (!c->dry) OHEVC_HIP_TRY(c->store.use_count() > 1 ? hipDeviceSynchronize() : hipStreamSynchronize(c->stream));
+    if (!c->dry) OHEVC_HIP_TRY(c->store.use_count() > 1 ? store_sync(*c->store) : hipStreamSynchronize(c->stream));
     if (c->cur == slot) c->cur = -1;
     std::lock_guard<std::mutex> g(c->store->m);
     c->store->version++;
@@ -725,7 +746,7 @@ extern "C" int ohevc_host_pin(ohevc_ctx *c, void *ptr, size_t bytes)
     bool drained = false;
     for (size_t i = 0; i < v.size();) {
         if (v[i].first < a + bytes && a < v[i].first + v[i].second) {
-            if (!drained) { OHEVC_HIP_TRY(hipSetDevice(c->device)); (void)hipDeviceSynchronize(); drained = true; }   // a copy into the old range may be in flight
+            if (!drained) { OHEVC_HIP_TRY(hipSetDevice(c->device)); (void)store_sync(*c->store); drained = true; }   // a copy into the old range may be in flight
             unpin_locked(*c->store, i);
         } else {
             i++;
@@ -750,7 +771,7 @@ extern "C" int ohevc_host_unpin_all(ohevc_ctx *c)
     std::unique_lock<std::shared_mutex> g(c->store->pin_m);
     if (c->store->pinned.empty()) return OHEVC_OK;
     OHEVC_HIP_TRY(hipSetDevice(c->device));
-    (void)hipDeviceSynchronize();
+    (void)store_sync(*c->store);
     while (!c->store->pinned.empty()) unpin_locked(*c->store, c->store->pinned.size() - 1);
     return OHEVC_OK;
 }
@@ -768,7 +789,7 @@ extern "C" int ohevc_host_unpin(ohevc_ctx *c, void *ptr, size_t bytes)
     if (c->store->issuer) {
         async_drain(*c->store);
         OHEVC_HIP_TRY(hipSetDevice(c->device));
-        (void)hipDeviceSynchronize();
+        (void)store_sync(*c->store);
     }
     std::unique_lock<std::shared_mutex> g(c->store->pin_m);        // (waits for the synchronous copy-backs in flight: they hold the shared lock)
     auto &v = c->store->pinned;
