@@ -91,6 +91,11 @@ typedef struct ohdec {
  * decoder, as before.  With the gfx950 back end the enhancement-layer decoder's back end shares the base layer's picture store (the
  * inter-layer reference picture is resampled from a base-layer picture on the device). */
 ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, int decoder_id, ohdec *base);
+/* per-instance options of the NEXT decoder this thread opens (ohhip_options.level_launch / device_filters; -2: leave the default): how a test
+ * gives two decoders of one process different options without touching the environment */
+static __thread int t_next_level_launch = -2, t_next_device_filters = -2;
+void ohdec_set_next_options(int level_launch, int device_filters) { t_next_level_launch = level_launch; t_next_device_filters = device_filters; }
+
 ohdec *ohdec_open_dev(int threads, int thread_type, int checksum, int device) { return ohdec_open_layer(threads, thread_type, checksum, device, 0, NULL); }
 ohdec *ohdec_open_ex(int threads, int thread_type, int checksum) { return ohdec_open_dev(threads, thread_type, checksum, -1); }
 ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, int decoder_id, ohdec *base)
@@ -143,6 +148,9 @@ ohdec *ohdec_open_layer(int threads, int thread_type, int checksum, int device, 
         ohhip_options_default(&o);
         if (device >= 0)
             o.device = device;
+        if (t_next_level_launch != -2) o.level_launch = t_next_level_launch;
+        if (t_next_device_filters != -2) o.device_filters = t_next_device_filters;
+        t_next_level_launch = t_next_device_filters = -2;
         /* OHDEC_SHVC_SEPARATE_STORES=1 (a test): the integration mistake of two unrelated back ends - must fail loudly, not decode garbage */
         o.base_layer = base && !getenv("OHDEC_SHVC_SEPARATE_STORES") ? base->backend : NULL;
         if (!(d->backend = ohhip_backend_new(&o)) || ohhip_backend_attach(d->backend, d->avctx) != 0)

@@ -103,12 +103,14 @@ class Decoder:
     """One decoder instance.  decode(au) -> picture (list of 3 numpy planes) or None; flush() -> remaining pictures."""
 
     def __init__(self, kind: str = "c", threads: int = 1, thread_type: int = 1, checksum: bool = False, pipelined: bool = False,
-                 decoder_id: int = 0, base: "Optional[Decoder]" = None):
+                 decoder_id: int = 0, base: "Optional[Decoder]" = None, options: Optional[dict] = None):
         """decoder_id / base: SHVC, the way openHevcWrapper.c:47-108 opens its two decoders - the enhancement-layer decoder has
         decoder_id 1 and `base` = the base-layer decoder (its BL_avcontext); see take_base()."""
         self.kind = kind
         self.L = _load(kind)
         self.sw = _configure_hip_backend() if kind == "hip" else None
+        if options:         # per-instance ohhip_options of this decoder (integration/hip_backend.h): level_launch, device_filters
+            self.L.ohdec_set_next_options(int(options.get("level_launch", -2)), int(options.get("device_filters", -2)))
         if decoder_id or base is not None:
             self.h = self.L.ohdec_open_layer(threads, thread_type, 1 if checksum else 0, -1, decoder_id, base.h if base is not None else None)
         else:

@@ -9,9 +9,9 @@ from oracle import pystream as ps
 from test_stream_cpu import frames_md5, load_golden
 
 
-def _decode_all(kind, aus, threads, out, key, barrier):
+def _decode_all(kind, aus, threads, out, key, barrier, options=None):
     try:
-        with ps.Decoder(kind, threads, 1) as d:
+        with ps.Decoder(kind, threads, 1, options=options) as d:
             barrier.wait()                          # both decoders are open before either decodes: their lifetimes overlap fully
             frames = []
             for i, au in enumerate(aus):
@@ -41,6 +41,39 @@ def two_streams_concurrently(kind, names=("ra_8b_ctb64", "ldb_10b"), threads=4):
     for k, (aus, md5) in enumerate(streams):
         assert not isinstance(out.get(k), Exception), out.get(k)
         assert frames_md5(out[k]) == md5, f"stream {names[k]} decoded beside {names[1 - k]} differs from the reference"
+
+
+def two_decoders_with_different_options(kind, names=("ra_8b_ctb64", "cip"), threads=3):
+    """One configuration surface: two decoders of one process, opened with DIFFERENT ohhip_options - one runs its
+    intra-coded blocks as CTB tasks and derives the deblocking parameters on the host, the other takes dependency levels and derives them on
+    the device - decode at the same time.  The options are per instance (ohevc_ctx_set_option on the contexts each back end makes); nothing
+    process-wide is touched, the environment plays no part.  That each choice really is in force shows in the launches its decoder makes."""
+    L = ps._load(kind)
+    L.ohdec_backend_profile.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    streams = [load_golden(n) for n in names]
+    opts = [dict(level_launch=3, device_filters=0), dict(level_launch=0, device_filters=1)]
+    # (a) each set of options alone: same pictures, different launch counts (CTB tasks: one launch for all intra work; host-derived filters: more)
+    launches = []
+    for o in opts:
+        sec, cnt = C.c_double(), (C.c_longlong * 8)()
+        L.ohdec_backend_profile(C.byref(sec), cnt)
+        with ps.Decoder(kind, 1, 1, options=o) as d:
+            frames = [f for i, au in enumerate(streams[0][0]) if (f := d.decode(au, i + 1)) is not None]
+            frames += d.flush()
+        assert frames_md5(frames) == streams[0][1], o
+        L.ohdec_backend_profile(C.byref(sec), cnt)
+        launches.append(cnt[1])
+    assert launches[0] != launches[1], f"both option sets made {launches[0]} launches: the per-instance options did not reach the contexts"
+    # (b) both at once, each with its own frame threads
+    out, barrier = {}, threading.Barrier(2)
+    ths = [threading.Thread(target=_decode_all, args=(kind, aus, threads, out, k, barrier, opts[k])) for k, (aus, _) in enumerate(streams)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k, (aus, md5) in enumerate(streams):
+        assert not isinstance(out.get(k), Exception), out.get(k)
+        assert frames_md5(out[k]) == md5, f"stream {names[k]} with options {opts[k]} beside the other decoder differs from the reference"
 
 
 def interleaved_on_one_thread(kind, names=("intra_8b", "ra_10b_odd")):

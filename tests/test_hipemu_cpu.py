@@ -217,6 +217,10 @@ def test_emu_two_decoders_decode_different_streams_concurrently():
     _instances().two_streams_concurrently("hipemu", ("ra_10b_odd", "ldb_10b"), threads=3)
 
 
+def test_emu_two_decoders_with_different_options_in_one_process():
+    _instances().two_decoders_with_different_options("hipemu")
+
+
 def test_emu_two_decoders_interleaved_on_one_application_thread():
     _instances().interleaved_on_one_thread("hipemu", ("intra_8b", "ra_10b_odd"))
 

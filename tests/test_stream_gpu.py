@@ -270,6 +270,11 @@ def test_two_decoders_decode_different_streams_concurrently():
     instance_cases.two_streams_concurrently("hip")
 
 
+def test_two_decoders_with_different_options_in_one_process():
+    import instance_cases
+    instance_cases.two_decoders_with_different_options("hip")
+
+
 def test_two_decoders_interleaved_on_one_application_thread():
     import instance_cases
     instance_cases.interleaved_on_one_thread("hip")
