@@ -333,9 +333,9 @@ typedef struct ohevc_intra_cip {        /* 32 bytes */
 int ohevc_dev_intra_batch(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,
                           void *stream);
 /* HOST helper: put the blocks of one dependency level (mutually independent) into the order ohevc_dev_intra_recon_sorted / ohevc_dev_intra_chain
- * want - by size, and inside a size by prediction mode (planar, DC, angular 2..34), so that the blocks sharing a wavefront take one path through
- * the predictors of hevcpred_template.c:359-537.  Stable; `residuals` (parallel to jobs, may be NULL) is permuted alike; count_by_size[k] =
- * number of (4 << k)-sample blocks.  The ctx layer calls it per level; callers of the device entry points may. */
+ * want - by size, otherwise as given (decoding order: neighbours in the picture stay neighbours in a wavefront; sorting by prediction mode as
+ * well was measured and lost to its cache misses, host_jobs.hip).  Stable; `residuals` (parallel to jobs, may be NULL) is permuted alike;
+ * count_by_size[k] = number of (4 << k)-sample blocks.  The ctx layer calls it per level; callers of the device entry points may. */
 int ohevc_intra_sort_level(ohevc_intra_job *jobs, ohevc_tu_job *residuals, int n, int32_t count_by_size[4]);
 /* same, with the side records of the OHEVC_INTRA2_CIP jobs (device pointer, 16-byte aligned) */
 int ohevc_dev_intra_batch_cip(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, int njobs,

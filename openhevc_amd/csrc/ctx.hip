@@ -1984,8 +1984,7 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
         }
         if (!lb.intra.empty() && c->cips.empty() && g_intra_pack) {
             // the packed kernel (ohevc_dev_intra_recon_sorted) wants the level's blocks by size - N lanes serve an N x N block, so the blocks of
-            // a wavefront must be of one size - and, inside a size, by prediction mode, so that a wavefront's blocks take one path through the
-            // predictors (ohevc_intra_sort_level, host_jobs.hip).  The residual records ride with their jobs.
+            // a wavefront must be of one size (ohevc_intra_sort_level, host_jobs.hip: stable, the residual records ride with their jobs)
             const bool paired = lb.intra_res.size() == lb.intra.size();
             int32_t cnt[4];
             const int src = ohevc_intra_sort_level(lb.intra.data(), paired ? lb.intra_res.data() : nullptr, (int)lb.intra.size(), cnt);

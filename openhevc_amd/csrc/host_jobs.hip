@@ -144,32 +144,34 @@ static int make_job_common(const ohevc_intra_geom *g, int lpu, const uint8_t *pf
 }
 
 // The order the packed intra kernel wants a dependency level's blocks in (intra_pack.hpp: N lanes per N x N block, 16 / 8 / 4 / 2 blocks per
-// wavefront): by size - a wavefront's blocks must be of one size - and, inside a size, by prediction mode: planar, DC, then the angular modes
-// ascending (2..17 predict from the left column, 18..34 from the row above).  The predictors (hevcpred_template.c:359-537), the smoothing
-// decision (:289-327, a function of mode and size) and the negative-angle extension of the reference array (:443-460) are branches of ONE
-// instruction stream shared by a wavefront's blocks: blocks of one mode take one path through it, a random mix takes all of them.
+// wavefront): by size - a wavefront's blocks must be of one size - and otherwise as recorded, i.e. in decoding order: neighbours in the picture
+// stay neighbours in a wavefront.
+// (Round 5 also sorted by prediction mode inside a size, so that the blocks sharing a wavefront take one path through the predictors of
+// hevcpred_template.c:359-537.  Measured on 130 000 independent blocks, all 35 modes: 17 % fewer vector instructions - and 2.4x the time for
+// 4x4 blocks (0.061 -> 0.147 ms), because blocks of one mode lie all over the picture: L2 misses 1.25 M -> 4.9 M per launch, fabric read requests
+// 1.09 M -> 3.44 M, SQ_WAIT_ANY 62 M -> 151 M wave cycles (profiles/r5a_sq_counters_intra_pack_before.txt, r5g_sq_counters_intra_pack_mode_sorted.txt).
+// The kernel waits for memory 60 % of its wave cycles; its instruction stream is not what bounds it.  Size only, again.)
 // Stable counting sort of the jobs and of the residual records riding with them (residuals may be NULL); count_by_size[k] = blocks of (4 << k).
 extern "C" int ohevc_intra_sort_level(ohevc_intra_job *jobs, ohevc_tu_job *residuals, int n, int32_t count_by_size[4])
 {
     OHEVC_REQUIRE(n >= 0 && (n == 0 || jobs != nullptr) && count_by_size != nullptr, "bad argument");
-    int cnt[4 * 35] = {};
+    int cnt[4] = {};
     for (int k = 0; k < n; k++) {
         OHEVC_REQUIRE(jobs[k].log2_size >= 2 && jobs[k].log2_size <= 5 && jobs[k].mode <= 34, "bad intra job");
-        cnt[(jobs[k].log2_size - 2) * 35 + jobs[k].mode]++;
+        cnt[jobs[k].log2_size - 2]++;
     }
-    for (int sz = 0; sz < 4; sz++) { count_by_size[sz] = 0; for (int m = 0; m < 35; m++) count_by_size[sz] += cnt[sz * 35 + m]; }
+    for (int sz = 0; sz < 4; sz++) count_by_size[sz] = cnt[sz];
     bool sorted = true;
-    for (int k = 1; k < n && sorted; k++)
-        sorted = (jobs[k].log2_size - 2) * 35 + jobs[k].mode >= (jobs[k - 1].log2_size - 2) * 35 + jobs[k - 1].mode;
+    for (int k = 1; k < n && sorted; k++) sorted = jobs[k].log2_size >= jobs[k - 1].log2_size;
     if (sorted) return OHEVC_OK;
-    int pos[4 * 35];
-    for (int b = 0, at = 0; b < 4 * 35; b++) { pos[b] = at; at += cnt[b]; }
+    int pos[4];
+    for (int b = 0, at = 0; b < 4; b++) { pos[b] = at; at += cnt[b]; }
     static thread_local std::vector<ohevc_intra_job> tj;
     static thread_local std::vector<ohevc_tu_job> tr;
     tj.resize((size_t)n);
     if (residuals) tr.resize((size_t)n);
     for (int k = 0; k < n; k++) {
-        const int d = pos[(jobs[k].log2_size - 2) * 35 + jobs[k].mode]++;
+        const int d = pos[jobs[k].log2_size - 2]++;
         tj[(size_t)d] = jobs[k];
         if (residuals) tr[(size_t)d] = residuals[k];
     }

@@ -173,8 +173,7 @@ def intra_rows(bd, orc, po, g, rng, st, out):
         j["x"], j["y"], j["log2_size"], j["mode"] = xs.ravel(), ys.ravel(), log2, rng.integers(0, 35, n)
         r = np.zeros(n, L.TU_JOB)
         r["x"], r["y"], r["reserved0"], r["coeff_off"] = j["x"], j["y"], L.TU_IDCT + 1, np.arange(n, dtype=np.uint32) * nn * nn
-        # the order the ctx layer stages a dependency level in (ohevc_intra_sort_level, include/ohevc_hip.h): by size and, inside a size, by
-        # prediction mode - the blocks that share a wavefront take one path through the predictors
+        # the order the ctx layer stages a dependency level in (ohevc_intra_sort_level, include/ohevc_hip.h): by size, otherwise as recorded
         cnt = (C.c_int32 * 4)()
         L.check(L.load_library().ohevc_intra_sort_level(j.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.c_int(n), cnt))
         counts = list(cnt)
@@ -203,7 +202,7 @@ def intra_rows(bd, orc, po, g, rng, st, out):
         alg = n * (P * (4 * nn + 1) + P * nn * nn + 2 * nn * nn)
         out[f"intra_{nn}x{nn}_with_residual_{bd}bit"] = _row(
             ms, ring, alg, n * nn * nn, bad, N_CHECK,
-            f"{n} independent luma blocks {nn}x{nn}, all 35 modes (uniform), in the order the ctx layer stages a level: sorted by mode; prediction + the block's "
+            f"{n} independent luma blocks {nn}x{nn}, all 35 modes (uniform), staged like a level of the ctx layer; prediction + the block's "
             f"inverse-DCT residual in one pass (packed kernel, N lanes per block); intra_pred / pred_planar / pred_dc / pred_angular (hevcpred_template.c:30-537) + idct + transform_add")
         del d_res, cf
 
