@@ -426,35 +426,67 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
         if on_gpu:
             torch.cuda.synchronize()
 
+    def timed_run(exchange, sync):
+        """The stream (warmup + steps) times through ONE decoder instance (and one transport): the rate of the last `steps` passes - a decoder's
+        first pass is its start-up (page locks of 99.5 MB frame buffers, device pictures, the kernels' first launches), which a rank pays
+        whatever share of the pictures it owns.  Between the passes the ranks meet at a barrier (they all feed the same access units, so they
+        are at the same point of the stream).  Returns (seconds of the timed passes, the transport's counters over those passes)."""
+        with ps.Decoder("hip") as d:
+            ex = make_exchange(d) if exchange else None
+            if ex is not None:
+                d.frames_mode(ex.mode)
+            pts = 0
+            for _ in range(max(1, warmup)):
+                for au in aus:
+                    pts += 1
+                    d.L.ohdec_decode(d.h, au, len(au), pts)
+            if sync:
+                barrier()
+            before = dict(ex.stats) if ex is not None else {}
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                for au in aus:
+                    pts += 1
+                    if d.L.ohdec_decode(d.h, au, len(au), pts) < 0:
+                        raise RuntimeError("decode error in the timed passes")
+            while d.L.ohdec_flush(d.h) > 0:
+                pass
+            if ex is not None:
+                ex.finish()
+            if sync:
+                barrier()
+            dt = time.perf_counter() - t0
+            st = {}
+            if ex is not None:
+                d.frames_mode(None)
+                after = dict(ex.stats)
+                st = {k: (after[k] - before.get(k, 0) if k != "wire_ranks" else after[k]) for k in after}
+                if hasattr(ex, "close"):
+                    ex.close()
+                if ex.error is not None:
+                    raise ex.error
+            return dt, st
+
     base = None
+    npics = len(aus)
     if baseline and world > 1:
         want = [{}]
         if rank == 0:
-            one_pass(exchange=False)                                   # start-up of the library, the kernels' first launches
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                nb, _ = one_pass(exchange=False)
-            tb = time.perf_counter() - t0
+            tb, _ = timed_run(False, False)
             one_pass(exchange=False, digests=want[0])
-            base = {"fps": round(nb * steps / tb, 2), "mpixel_per_s": round(nb * W * H * steps / tb / 1e6, 1), "ms_per_step": round(tb / steps * 1e3, 2),
-                    "note": "rank 0 alone, no exchange, the other ranks waiting: the N = 1 value of this stream on this box"}
+            base = {"fps": round(npics * steps / tb, 2), "mpixel_per_s": round(npics * W * H * steps / tb / 1e6, 1), "ms_per_step": round(tb / steps * 1e3, 2),
+                    "note": "rank 0 alone, no exchange, the other ranks waiting: the N = 1 value of this stream on this box (same passes through one decoder)"}
         dist.broadcast_object_list(want, src=0)
         mine = {}
-        one_pass(digests=mine)                                         # (also the first warm-up pass of the N-rank configuration)
+        one_pass(digests=mine)                                         # a fresh decoder per rank, every picture this rank owns compared
         bad = [k for k, v in mine.items() if want[0].get(k) != v]
         counts = [None] * world
         dist.all_gather_object(counts, (len(mine), len(bad)))
         if rank == 0:
             base["pictures_checked"] = sum(c[0] for c in counts)
             base["pictures_differing"] = sum(c[1] for c in counts)
-    for _ in range(warmup):
-        one_pass()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        npics, stats = one_pass()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, stats = timed_run(world > 1, True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -465,15 +497,16 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
     out = {
         "metric": "decoded Mpixels/s (fps x W x H), whole decoder, frame-parallel over the ranks",
         "value": round(npics * W * H * steps / elapsed / 1e6, 1), "unit": "Mpixel/s", "fps": round(npics * steps / elapsed, 2),
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
+        "n_gpus": world, "steps": steps, "warmup": max(1, warmup), "ms_per_step": round(elapsed / steps * 1e3, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u%d pixels, int16 coefficients" % (16 if bit_depth > 8 else 8), "data": "synthetic Annex-B stream (oracle/pystream.py, seed 4242)",
         "config": {"workload": f"{W}x{kw['height']} {bit_depth}-bit random-access stream (encoder-like statistics, {sum(map(len, aus)) // len(aus)} bytes/picture), {npics} pictures per "
-                               f"step, reference front end on the host cores + HIP back end, pictures owned round-robin by decoding order",
+                               f"step (the stream warmup + steps times through one decoder instance per rank; the last `steps` passes timed), reference front end on the "
+                               f"host cores + HIP back end, pictures owned round-robin by decoding order",
                    "parallelism": f"frame-parallel over {world} process(es)", "one_gpu": bool(one_gpu and world > 1),
                    "transport": "none (one rank)" if world <= 1 else "python (torch.distributed)" if python_transport else
                                 "native (include/ohevc_frames.h: " + ("TCP, host-staged" if one_gpu else "ncclBroadcast, device memory") + ")"},
-        # rank 0's view of the last timed pass: pictures it published / subscribed to, bytes through the wire per exchanged picture, the
+        # rank 0's view of the timed passes: pictures it published / subscribed to, bytes through the wire per exchanged picture, the
         # communicator's size as the wire reports it (ncclCommCount; the connected peers + 1 of the sockets wire)
         "exchange": dict(stats, pictures_exchanged=exchanged, bytes_per_exchanged_picture=int(stats.get("bytes", 0) / exchanged) if exchanged else 0),
         "wire_ranks": stats.get("wire_ranks"),
