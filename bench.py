@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--frames-size", default="7680x4320", help="the frame-parallel leg's picture size WxH (default: BASELINE config 5, 8K)")
     ap.add_argument("--frames-bit-depth", type=int, default=10)
     ap.add_argument("--frames-pictures", type=int, default=9)
-    ap.add_argument("--frames-steps", type=int, default=3, help="timed passes of the `frames` object's stream (the line's --steps is the kernel bench's)")
+    ap.add_argument("--frames-steps", type=int, default=4, help="timed passes of the `frames` object's stream (the line's --steps is the kernel bench's)")
     ap.add_argument("--frames-python-transport", action="store_true",
                     help="--mode frames: exchange pictures through openhevc_amd.dist.FrameExchange (torch.distributed) instead of the native "
                          "transport of include/ohevc_frames.h (RCCL broadcast in C; TCP with --frames-one-gpu)")
@@ -375,7 +375,7 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
     passes = [0]
     wire_ranks = [None]
 
-    def make_exchange(d):
+    def make_exchange(d, segments=False):
         if world <= 1:
             return None
         if python_transport:
@@ -383,12 +383,16 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
         # the native transport: ncclBroadcast over xGMI (one GPU per rank), or TCP between ranks sharing GPU 0.  A fresh rendezvous per pass.
         passes[0] += 1
         if one_gpu:
-            return D.NativeFrameTransport(d.product_lib(), rank, world, 0, D.NativeFrameTransport.WIRE_SOCKETS, f"127.0.0.1:{port + 100 + 16 * (passes[0] % 50)}")
-        return D.NativeFrameTransport(d.product_lib(), rank, world, local_rank, D.NativeFrameTransport.WIRE_RCCL, f"/tmp/ohevc_frames_rccl_id_{port}_{passes[0]}")
+            t = D.NativeFrameTransport(d.product_lib(), rank, world, 0, D.NativeFrameTransport.WIRE_SOCKETS, f"127.0.0.1:{port + 100 + 16 * (passes[0] % 50)}")
+        else:
+            t = D.NativeFrameTransport(d.product_lib(), rank, world, local_rank, D.NativeFrameTransport.WIRE_RCCL, f"/tmp/ohevc_frames_rccl_id_{port}_{passes[0]}")
+        if segments:
+            t.set_ownership(True)
+        return t
 
-    def one_pass(exchange=True, digests=None):
+    def one_pass(exchange=True, digests=None, segments=False, repeat=1):
         with ps.Decoder("hip") as d:
-            ex = make_exchange(d) if exchange else None
+            ex = make_exchange(d, segments) if exchange else None
             if ex is not None:
                 d.frames_mode(ex.mode)
             n = 0
@@ -398,7 +402,7 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
                     digests[len(digests_seen)] = [zlib.crc32(pl.tobytes()) for pl in pic]
                 digests_seen.append(1)
             digests_seen = []
-            for i, au in enumerate(aus):
+            for i, au in enumerate(aus * repeat):
                 pic = d.decode(au, i + 1)
                 if pic is not None:
                     n += 1
@@ -426,13 +430,13 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
         if on_gpu:
             torch.cuda.synchronize()
 
-    def timed_run(exchange, sync):
+    def timed_run(exchange, sync, segments=False):
         """The stream (warmup + steps) times through ONE decoder instance (and one transport): the rate of the last `steps` passes - a decoder's
         first pass is its start-up (page locks of 99.5 MB frame buffers, device pictures, the kernels' first launches), which a rank pays
         whatever share of the pictures it owns.  Between the passes the ranks meet at a barrier (they all feed the same access units, so they
         are at the same point of the stream).  Returns (seconds of the timed passes, the transport's counters over those passes)."""
         with ps.Decoder("hip") as d:
-            ex = make_exchange(d) if exchange else None
+            ex = make_exchange(d, segments) if exchange else None
             if ex is not None:
                 d.frames_mode(ex.mode)
             pts = 0
@@ -491,6 +495,35 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The same stream, ownership per IDR SEGMENT instead of per picture (ohhip_frames_mode.segment_ownership): every pass of the stream opens with
+    # an IDR picture, a rank decodes whole passes, nothing crosses the wire.  `steps` rounded up to a multiple of the ranks: equal shares.
+    seg = None
+    if world > 1 and not python_transport:
+        steps_all, steps = steps, -(-steps // world) * world
+        seg_bad = None
+        if baseline:
+            mine = {}
+            one_pass(digests=mine, segments=True, repeat=world)        # `world` segments through a fresh decoder per rank: every rank owns one
+            wrap = {k: v for k, v in want[0].items()} if rank == 0 else None
+            box = [wrap]
+            dist.broadcast_object_list(box, src=0)
+            bad = [k for k, v in mine.items() if box[0].get(k % npics) != v]
+            counts = [None] * world
+            dist.all_gather_object(counts, (len(mine), len(bad)))
+            seg_bad = (sum(c[0] for c in counts), sum(c[1] for c in counts))
+        barrier()
+        seg_elapsed, seg_stats = timed_run(True, True, segments=True)
+        t = torch.tensor([seg_elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seg_elapsed = float(t.item())
+        seg = {"fps": round(npics * steps / seg_elapsed, 2), "mpixel_per_s": round(npics * W * H * steps / seg_elapsed / 1e6, 1), "steps": steps,
+               "ms_per_step": round(seg_elapsed / steps * 1e3, 2), "pictures_exchanged": seg_stats.get("published", 0) + seg_stats.get("subscribed", 0),
+               "note": "ownership per IDR segment (ohhip_frames_mode.segment_ownership): every pass of the stream opens with an IDR picture, a rank decodes whole passes, "
+                       "nothing is exchanged; one_rank = the same passes on rank 0 alone"}
+        if seg_bad is not None:
+            seg["pictures_checked"], seg["pictures_differing"] = seg_bad
+            seg["bit_exact"] = seg_bad[1] == 0 and seg_bad[0] == npics * world
+        steps = steps_all
     if rank != 0:
         return None
     exchanged = stats.get("published", 0) + stats.get("subscribed", 0)
@@ -511,6 +544,10 @@ def frames_leg(rank, world, local_rank, one_gpu, size, bit_depth, pictures, step
         "exchange": dict(stats, pictures_exchanged=exchanged, bytes_per_exchanged_picture=int(stats.get("bytes", 0) / exchanged) if exchanged else 0),
         "wire_ranks": stats.get("wire_ranks"),
     }
+    if seg is not None:
+        if base is not None and base["fps"]:
+            seg["speedup_vs_one_rank"] = round(seg["fps"] / base["fps"], 3)
+        out["idr_segments"] = seg
     if base is not None:
         out["one_rank"] = base
         out["speedup_vs_one_rank"] = round(out["fps"] / base["fps"], 3) if base["fps"] else None

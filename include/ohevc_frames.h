@@ -48,6 +48,11 @@ typedef struct ohhip_frames_mode {
      * picture: all of it) - the wait of hevc_await_progress (hevc.c:1951-1958) for the rows a picture's motion vectors reach, at the granularity
      * of the transport's bands.  Calls for one picture may come with growing row numbers.  May be NULL: the hooks then use await_planes. */
     int (*await_rows)(void *user, int index, ohevc_ctx *ctx, int slot, int last_luma_row);
+    /* 0: a picture's owner is its decoding-order index % world and exchanged pictures cross the wire (any stream).  1: ownership per IDR SEGMENT -
+     * segment number % world, a segment = an IDR picture and everything up to the next one: nothing after an IDR picture predicts from
+     * anything before it, so a segment needs nothing from the other ranks and NOTHING is exchanged; the ranks decode different segments at the
+     * same time.  For streams with regular IDR pictures (closed GOPs); a stream without them stays on one rank. */
+    int segment_ownership;
 } ohhip_frames_mode;
 
 enum { OHEVC_FRAMES_WIRE_RCCL = 0, OHEVC_FRAMES_WIRE_SOCKETS = 1 };
@@ -65,6 +70,8 @@ int  ohevc_frames_transport_create(ohevc_frames_transport **out, int rank, int w
  * exports band b + 1 while band b is on the wire, a subscriber imports band b while band b + 1 arrives, and await_rows returns as soon as the
  * bands a dependent picture reaches are in.  Every rank must use the same value; only between pictures (nothing in flight). */
 int  ohevc_frames_transport_set_bands(ohevc_frames_transport *t, int max_bands);
+/* ohhip_frames_mode.segment_ownership of this transport's callback table (above); before the first picture, the same on every rank */
+int  ohevc_frames_transport_set_ownership(ohevc_frames_transport *t, int per_idr_segment);
 /* the callback table to hand to ohhip_set_frames_mode (valid until the transport is destroyed) */
 const ohhip_frames_mode *ohevc_frames_transport_mode(ohevc_frames_transport *t);
 /* every collective this rank issued has completed (call on all ranks after the last picture, before destroying) */

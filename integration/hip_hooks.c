@@ -75,7 +75,7 @@ struct ohhip_backend {
     int                nbufs;
     /* frames mode (hip_frames.h) */
     ohhip_frames_mode  fm;
-    int                fm_on, fm_index;
+    int                fm_on, fm_index, fm_segment;       /* fm_segment: IDR pictures seen so far - 1 (segment_ownership) */
     int (*execute)(AVCodecContext *, int (*)(AVCodecContext *, void *), void *, int *, int, int);
     int (*execute2)(AVCodecContext *, int (*)(AVCodecContext *, void *, int, int), void *, int *, int);
     /* OHHIP_TRACE_FRAMES: host timeline of every picture */
@@ -424,10 +424,21 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     if (be->fm_on) {
         /* a picture nothing can predict from: sub-layer non-reference (even nal_unit_type below 16, H.265 table 7-1) in the
          * highest temporal sub-layer -- it is not exchanged */
-        const int exchanged = !(s->nal_unit_type < 16 && !(s->nal_unit_type & 1) && s->temporal_id == s->sps->max_sub_layers - 1);
+        const int exchanged_pic = !(s->nal_unit_type < 16 && !(s->nal_unit_type & 1) && s->temporal_id == s->sps->max_sub_layers - 1);
         const size_t mvf_bytes = (size_t)s->sps->min_pu_width * s->sps->min_pu_height * sizeof(MvField);     /* hevc.c:178 */
+        int exchanged = exchanged_pic, owner;
         be->bufs[i].index = be->fm_index++;
-        be->bufs[i].remote = be->bufs[i].index % be->fm.world != be->fm.rank;
+        /* Who reconstructs the picture.  Per picture: decoding-order index mod world - every exchanged picture crosses the wire.  Per IDR segment
+         * (ohhip_frames_mode.segment_ownership): an IDR picture empties the decoded picture buffer and nothing after it predicts from
+         * anything before it (H.265 8.3.1, 8.3.2), so a segment - an IDR picture and everything up to the next one - is decoded by ONE
+         * rank, start to end, and nothing of it is needed anywhere else: no exchange at all, the ranks work on different segments of the
+         * stream at the same time (the random-access points every broadcast / streaming encoder puts in once a second or two). */
+        if (IS_IDR(s) || be->fm_segment < 0)
+            be->fm_segment++;
+        owner = be->fm.segment_ownership ? be->fm_segment % be->fm.world : be->bufs[i].index % be->fm.world;
+        if (be->fm.segment_ownership)
+            exchanged = 0;
+        be->bufs[i].remote = owner != be->fm.rank;
         /* a picture that is not exchanged has nothing to wait for - H.265 8.3.2 only bars it from the Curr sets, a stream may keep it in
          * a Foll set of later pictures */
         be->bufs[i].have_motion = be->bufs[i].have_planes = !be->bufs[i].remote || !exchanged;
@@ -1011,6 +1022,7 @@ int ohhip_backend_frames_mode(ohhip_backend *be, const ohhip_frames_mode *m)
         return -1;
     be->fm_on = 0;
     be->fm_index = 0;
+    be->fm_segment = -1;
     if (!m)
         return 0;
     if (m->world < 1 || m->rank < 0 || m->rank >= m->world || !m->publish || !m->subscribe || !m->await_motion || !m->await_planes)

@@ -692,7 +692,7 @@ extern "C" int ohevc_frames_transport_create(ohevc_frames_transport **out, int r
     ohevc_frames_transport *t = new ohevc_frames_transport();
     t->rank = rank; t->world = world; t->device = device; t->wire = wire; t->timeout_s = timeout_s > 0 ? timeout_s : 60;
     t->rendezvous = rendezvous ? rendezvous : "";
-    t->mode = ohhip_frames_mode{ rank, world, t, cb_publish, cb_subscribe, cb_await_motion, cb_await_planes, cb_release, cb_await_rows };
+    t->mode = ohhip_frames_mode{ rank, world, t, cb_publish, cb_subscribe, cb_await_motion, cb_await_planes, cb_release, cb_await_rows, 0 };
     auto fail = [&](int rc) { ohevc_frames_transport_destroy(t); return rc; };
     if (hipSetDevice(device) != hipSuccess) { set_error("frames transport: no device %d", device); return fail(OHEVC_ERR_NODEV); }
     if (wire == OHEVC_FRAMES_WIRE_SOCKETS) {
@@ -744,6 +744,14 @@ extern "C" int ohevc_frames_transport_set_bands(ohevc_frames_transport *t, int m
     OHEVC_REQUIRE(t != nullptr && max_bands >= 1, "bad argument");
     OHEVC_REQUIRE(t->pending.empty() && t->outgoing.empty(), "pictures are in flight: every rank must change the band grid at the same point of the stream");
     t->max_bands = std::min(max_bands, kMaxBands);
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_frames_transport_set_ownership(ohevc_frames_transport *t, int per_idr_segment)
+{
+    OHEVC_REQUIRE(t != nullptr, "null transport");
+    OHEVC_REQUIRE(t->pending.empty() && t->outgoing.empty(), "pictures are in flight");
+    t->mode.segment_ownership = per_idr_segment != 0;
     return OHEVC_OK;
 }
 

@@ -162,7 +162,8 @@ class _FramesMode(_C.Structure):
     AWAIT_ROWS = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_int)
     _fields_ = [("rank", _C.c_int), ("world", _C.c_int), ("user", _C.c_void_p), ("publish", PUBLISH), ("subscribe", SUBSCRIBE),
                 ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES), ("release", RELEASE),
-                ("await_rows", AWAIT_ROWS)]      # NULL here: this Python transport moves whole pictures (the native one has bands)
+                ("await_rows", AWAIT_ROWS),      # NULL here: this Python transport moves whole pictures (the native one has bands)
+                ("segment_ownership", _C.c_int)]
 
 
 class _Plane(_C.Structure):
@@ -415,6 +416,12 @@ class NativeFrameTransport:
         if self.lib.ohevc_frames_transport_selftest(self.h, ctx_handle, src_slot, dst_slot, root, mvf_in, out, len(mvf_in)) != 0:
             raise RuntimeError("native frame transport self-test: " + self.lib.ohevc_last_error().decode())
         return out.raw
+
+    def set_ownership(self, per_idr_segment):
+        """ohhip_frames_mode.segment_ownership: pictures owned per IDR segment (nothing exchanged) instead of per picture"""
+        self.lib.ohevc_frames_transport_set_ownership.argtypes = [_C.c_void_p, _C.c_int]
+        if self.lib.ohevc_frames_transport_set_ownership(self.h, 1 if per_idr_segment else 0) != 0:
+            raise RuntimeError("native frame transport: " + self.lib.ohevc_last_error().decode())
 
     def finish(self):
         if self.lib.ohevc_frames_transport_finish(self.h) != 0:

@@ -36,3 +36,5 @@ def test_bench_gpus_2_from_a_bare_shell():
     assert f["wire_ranks"] == 2
     assert f["exchange"]["pictures_exchanged"] > 0 and f["exchange"]["bands_imported"] > 0 and f["exchange"]["bytes_per_exchanged_picture"] > 1920 * 1080 * 2
     assert f["fps"] > 0 and f["one_rank"]["fps"] > 0
+    g = f["idr_segments"]                                   # the same stream, ownership per IDR segment: nothing crosses the wire
+    assert g["bit_exact"] is True and g["pictures_exchanged"] == 0 and g["pictures_checked"] == 18 and g["fps"] > 0

@@ -369,3 +369,91 @@ def test_rccl_rendezvous_times_out_instead_of_hanging(tmp_path):
     assert b"never published" in lib.ohevc_last_error()
     assert lib.ohevc_debug_frames_rendezvous(path.encode(), 0, 2, 1, buf) != 0      # ... and rank 0 gives up when nobody answers
     assert b"not every rank" in lib.ohevc_last_error()
+
+
+# ---------------------------------------------------------------- ownership per IDR segment (ohhip_frames_mode.segment_ownership)
+def segment_worker(rank, world, port, names, repeat, q, kind):
+    """every stream `repeat` times through one decoder (each repetition opens with an IDR picture = one segment), frame-parallel with
+    ownership per IDR segment over the native transport's sockets wire; reports, per stream, which output positions this rank reconstructed,
+    their digests, and the transport's counters"""
+    import zlib
+    from oracle import pystream as ps
+    from openhevc_amd import dist as D
+    from test_stream_cpu import load_golden
+    res = {}
+    try:
+        for k, name in enumerate(names):
+            aus, _ = load_golden(name)
+            got = {}
+            with ps.Decoder(kind) as d:
+                ex = D.NativeFrameTransport(d.product_lib(), rank, world, 0, D.NativeFrameTransport.WIRE_SOCKETS, f"127.0.0.1:{port + 16 * k}", timeout_s=60)
+                ex.set_ownership(True)
+                d.frames_mode(ex.mode)
+                n = 0
+
+                def took(pic):
+                    nonlocal n
+                    if d.frame_is_local():
+                        got[n] = [zlib.crc32(pl.tobytes()) for pl in pic]
+                    n += 1
+                for r in range(repeat):
+                    for i, au in enumerate(aus):
+                        pic = d.decode(au, r * 1000 + i + 1)
+                        if pic is not None:
+                            took(pic)
+                while True:
+                    pic = d.flush_one()
+                    if pic is None:
+                        break
+                    took(pic)
+                ex.finish()
+                d.frames_mode(None)
+                st = ex.stats
+                err = ex.error
+                ex.close()
+            res[name] = (n, got, st, None if err is None else str(err))
+        q.put((rank, res))
+    except Exception as e:          # noqa: BLE001
+        import traceback
+        q.put((rank, {"error": traceback.format_exc() + str(e)}))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_idr_segments_are_decoded_by_one_rank_each_and_nothing_is_exchanged(world):
+    """An IDR picture empties the decoded picture buffer: a segment needs nothing from before it.  With ohhip_frames_mode.segment_ownership the
+    ranks take whole segments in turn (segment number % world), every picture is reconstructed exactly once, equals the single-process
+    decoder's, and the wire carries nothing."""
+    import zlib
+    from oracle import pystream as ps
+    from test_stream_cpu import load_golden
+    if not ps.have("hipemu"):
+        pytest.skip("emulator-backed decoder not built (needs the reference tree once)")
+    names, repeat = ["ra_8b_ctb64", "ldb_10b", "ra_8b_nonref_leaves"], 4
+    port = free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=segment_worker, args=(r, world, port, names, repeat, q, "hipemu")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=280) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert "error" not in res[r], res[r]["error"]
+    for name in names:
+        aus, _ = load_golden(name)
+        one = [[zlib.crc32(pl.tobytes()) for pl in f] for f in ps.decode_stream("hipemu", aus)]
+        per = len(one)
+        merged = {}
+        for r in range(world):
+            n, got, st, err = res[r][name]
+            assert err is None and n == per * repeat
+            assert st["published"] == 0 and st["subscribed"] == 0 and st["bytes"] == 0, f"{name}: segment ownership exchanged pictures: {st}"
+            for pos, dg in got.items():
+                assert pos not in merged, f"{name}: picture {pos} reconstructed twice"
+                merged[pos] = dg
+                assert (pos // per) % world == r, f"{name}: output position {pos} (segment {pos // per}) reconstructed by rank {r}"
+        assert sorted(merged) == list(range(per * repeat)), f"{name}: pictures nobody reconstructed"
+        assert all(merged[pos] == one[pos % per] for pos in merged), f"{name}: pictures differ from the single-process decoder"
