@@ -125,7 +125,7 @@ __device__ __forceinline__ void idct_row(unsigned char *blk, const int i, const 
 // The work of lane (g, i) comes in three stages, so that the chain kernel below can have the records and coefficients of LATER levels in
 // flight while a level computes: (R) the two 16-byte records of the block, (C) the coefficient chunks the residual's transform needs
 // (addresses from the residual record), (X) samples -> prediction -> residual -> store.
-struct PackRecs { u32x4 jw, rw; bool valid; };
+struct PackRecs { u32x4 jw, rw; bool valid; bool has_res = true; };      // has_res false: rw is not a residual record (the chain's branch-free loader)
 
 template <int LOG2N>
 __device__ __forceinline__ PackRecs pack_load_recs(const int lane, const int job0, const int njobs, const ohevc_intra_job *__restrict__ jobs,
@@ -142,7 +142,7 @@ __device__ __forceinline__ PackRecs pack_load_recs(const int lane, const int job
     return r;
 }
 
-__device__ __forceinline__ int pack_kind(const PackRecs &r) { return (int)((r.rw.y >> 8) & 0xff) - 1; }      // -1: no residual
+__device__ __forceinline__ int pack_kind(const PackRecs &r) { return r.has_res ? (int)((r.rw.y >> 8) & 0xff) - 1 : -1; }      // -1: no residual
 
 // READY: the arena holds the block's RESIDUAL (row-major int16, written in place over the coefficients by intra_chain_residual_kernel): the
 // lane takes row i of it instead of its coefficient chunks
@@ -469,7 +469,9 @@ __global__ __launch_bounds__(64) void intra_chain_residual_kernel(const unsigned
     for (int w = blockIdx.x; w < lv.first_wave[4]; w += gridDim.x) {
         const int s = w >= lv.first_wave[3] ? 3 : w >= lv.first_wave[2] ? 2 : w >= lv.first_wave[1] ? 1 : 0;
         const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
-        const int job0 = (w - lv.first_wave[s]) * (16 >> s), n = lv.njobs[s];
+        // (selects, not lv.first_wave[s] / lv.njobs[s]: an array indexed at run time lives in scratch memory)
+        const int fws = s == 0 ? lv.first_wave[0] : s == 1 ? lv.first_wave[1] : s == 2 ? lv.first_wave[2] : lv.first_wave[3];
+        const int job0 = (w - fws) * (16 >> s), n = s == 0 ? lv.njobs[0] : s == 1 ? lv.njobs[1] : s == 2 ? lv.njobs[2] : lv.njobs[3];
         const ohevc_intra_job *j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
         const ohevc_tu_job *r = reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job;
         auto one = [&](auto log2c) {
@@ -534,39 +536,58 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     auto slot_at = [&](const int l, const int w) -> Slot {
         Slot sl = { -1, 0, 0, 0, nullptr, nullptr };
         if (l >= nlevels) return sl;
-        IntraChainLevel lv;
-        {
-            const int *rec = slev + l * 12;
-#pragma unroll
-            for (int k = 0; k < 5; k++) lv.first_wave[k] = __builtin_amdgcn_readfirstlane(rec[k]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) lv.njobs[k] = __builtin_amdgcn_readfirstlane(rec[5 + k]);
-            lv.jobs_off16 = (unsigned)__builtin_amdgcn_readfirstlane(rec[9]);
-            lv.res_off16 = (unsigned)__builtin_amdgcn_readfirstlane(rec[10]);
-        }
-        sl.nwaves = lv.first_wave[4];
-        if (w >= lv.first_wave[4]) return sl;
-        const int s = w >= lv.first_wave[3] ? 3 : w >= lv.first_wave[2] ? 2 : w >= lv.first_wave[1] ? 1 : 0;
-        const int first_job = s == 0 ? 0 : s == 1 ? lv.njobs[0] : s == 2 ? lv.njobs[0] + lv.njobs[1] : lv.njobs[0] + lv.njobs[1] + lv.njobs[2];
+        // The record as eleven scalars, never as an array indexed by the (runtime) size class: such an array lives in scratch memory, and a
+        // scratch load is a vector-memory operation - it returns IN ORDER behind the sample loads and the HBM prefetches issued just before,
+        // so "which slot do I have at level l + 2" waited a whole HBM round trip on every level's critical path (s_waitcnt vmcnt behind
+        // scratch_load_dword in the round-4 listing; the 3100 .. 4700 clocks of the "issue" phase in profiles/r4t_chain_clocks_mul24.jsonl).
+        const int *rec = slev + l * 12;
+        const int fw1 = __builtin_amdgcn_readfirstlane(rec[1]), fw2 = __builtin_amdgcn_readfirstlane(rec[2]), fw3 = __builtin_amdgcn_readfirstlane(rec[3]);
+        const int fw4 = __builtin_amdgcn_readfirstlane(rec[4]);
+        const int n0 = __builtin_amdgcn_readfirstlane(rec[5]), n1 = __builtin_amdgcn_readfirstlane(rec[6]), n2 = __builtin_amdgcn_readfirstlane(rec[7]);
+        const int n3 = __builtin_amdgcn_readfirstlane(rec[8]);
+        const unsigned jobs_off16 = (unsigned)__builtin_amdgcn_readfirstlane(rec[9]), res_off16 = (unsigned)__builtin_amdgcn_readfirstlane(rec[10]);
+        sl.nwaves = fw4;
+        if (w >= fw4) return sl;
+        const int s = w >= fw3 ? 3 : w >= fw2 ? 2 : w >= fw1 ? 1 : 0;
+        const int first_wave = s == 0 ? 0 : s == 1 ? fw1 : s == 2 ? fw2 : fw3;          // (first_wave[0] is 0 by construction)
+        const int first_job = s == 0 ? 0 : s == 1 ? n0 : s == 2 ? n0 + n1 : n0 + n1 + n2;
         sl.s = s;
-        sl.job0 = (w - lv.first_wave[s]) * (16 >> s);
-        sl.n = lv.njobs[s];
-        sl.j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)lv.jobs_off16 * 16) + first_job;
-        sl.r = lv.res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)lv.res_off16 * 16) + first_job : nullptr;
+        sl.job0 = (w - first_wave) * (16 >> s);
+        sl.n = s == 0 ? n0 : s == 1 ? n1 : s == 2 ? n2 : n3;
+        sl.j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)jobs_off16 * 16) + first_job;
+        sl.r = res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)res_off16 * 16) + first_job : nullptr;
         return sl;
     };
+    // The two loaders that run AHEAD of a level (records of level l + 2, residual rows of level l + 1) are written without a branch: one
+    // instruction stream for all four block sizes, every load unconditional, addresses picked by selects on wave-uniform values.  With a
+    // copy of the loader per size class behind `if (sl.s == ...)` the loaded registers met in phi nodes, the compiler merged them with
+    // copies, and a copy needs the value: s_waitcnt vmcnt(0) right behind the issue of the prefetch - the level waited for the loads it was
+    // supposed to hide (the listing of round 4; "issue" = 4700 of a level's 10 500 clocks in profiles/r4t_chain_clocks_mul24.jsonl).
+    // A slot without blocks (s < 0) loads from `base` (the upload buffer: always mapped) and its values are never looked at.
     auto load_recs = [&](const Slot &sl) -> PackRecs {
-        if (sl.s == 0) return pack_load_recs<2>(lane, sl.job0, sl.n, sl.j, sl.r);
-        if (sl.s == 1) return pack_load_recs<3>(lane, sl.job0, sl.n, sl.j, sl.r);
-        if (sl.s == 2) return pack_load_recs<4>(lane, sl.job0, sl.n, sl.j, sl.r);
-        if (sl.s == 3) return pack_load_recs<5>(lane, sl.job0, sl.n, sl.j, sl.r);
-        return PackRecs{ u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
+        const int log2n = sl.s + 2;                                    // (s < 0: 1 - harmless)
+        const int g = lane >> (log2n & 7);
+        PackRecs r;
+        r.valid = sl.s >= 0 && sl.job0 + g < sl.n;
+        const int ji = sl.job0 + g < sl.n ? sl.job0 + g : sl.n - 1;   // lanes behind the last job repeat it and do not store
+        const u32x4 *jp = sl.s >= 0 ? reinterpret_cast<const u32x4 *>(sl.j) + ji : reinterpret_cast<const u32x4 *>(base);
+        const u32x4 *rp = sl.s >= 0 && sl.r != nullptr ? reinterpret_cast<const u32x4 *>(sl.r) + ji : reinterpret_cast<const u32x4 *>(base);
+        r.jw = *jp;
+        r.rw = *rp;
+        r.has_res = sl.s >= 0 && sl.r != nullptr;                      // (applied where the record is READ, pack_kind: a select here would need the value)
+        return r;
     };
     auto load_cq = [&](const Slot &sl, const PackRecs &r, u32x4 (&cq)[4]) {
-        if (sl.s == 0)      pack_load_coeffs<2, true>(r, lane, coeffs, cq);
-        else if (sl.s == 1) pack_load_coeffs<3, true>(r, lane, coeffs, cq);
-        else if (sl.s == 2) pack_load_coeffs<4, true>(r, lane, coeffs, cq);
-        else if (sl.s == 3) pack_load_coeffs<5, true>(r, lane, coeffs, cq);
+        // row i of the block's residual as the pre-pass left it in the arena (READY form of pack_load_coeffs): N / 8 pieces of 16 bytes
+        // (4x4: the piece that holds rows i and i ^ 1); the remaining of the four loads repeat the last piece
+        const int log2n = sl.s + 2, n = 1 << (log2n & 7), i = lane & (n - 1);
+        const int kind = pack_kind(r);
+        const bool is_idct = sl.s >= 0 && coeffs != nullptr && (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4);
+        const int nr = log2n <= 3 ? 1 : n >> 3;
+        const unsigned row_bytes = log2n == 2 ? (unsigned)(i >> 1) * 16u : (unsigned)i * (unsigned)n * 2u;
+        const unsigned char *rowp = is_idct ? reinterpret_cast<const unsigned char *>(coeffs) + ((size_t)r.rw.z * 2u + row_bytes) : base;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cq[q] = *reinterpret_cast<const u32x4 *>(rowp + (is_idct ? 16 * (q < nr ? q : nr - 1) : 0));
     };
     auto load_samples = [&](const Slot &sl, const PackRecs &r) -> PackSamples {
         if (sl.s == 0) return pack_load_samples<2, Pixel>(lane, planes, r);
