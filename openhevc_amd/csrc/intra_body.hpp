@@ -5,11 +5,25 @@
 
 namespace ohevc {
 
-static __device__ const signed char kIntraAngle[33] = {
-    32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
-    -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
-static __device__ const short kIntraInvAngle[15] = {
-    -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+// intraPredAngle and invAngle (H.265 tables 8-4 / 8-5; hevcpred_template.c:425-433) as ARITHMETIC on packed constants, not as tables in
+// memory: a table look-up is a vector-memory load in the middle of the prediction, and vector memory returns in order - the wait for that one
+// byte was a wait for every load issued before it, the HBM prefetches of the chain kernel included (s_waitcnt vmcnt(0) behind
+// global_load_sbyte in the round-4 listing of every intra kernel).
+//   |angle| by distance from the horizontal (10) / vertical (26) mode: 0 2 5 9 13 17 21 26 32, six bits each;
+//   |invAngle| = 8192 / |angle| rounded: 4096 1638 910 630 482 390 315 256, thirteen bits each in two words.
+__device__ __forceinline__ int intra_pred_angle(const int mode)          // mode 2 .. 34
+{
+    const bool vert = mode >= 18;
+    const int d = mode - (vert ? 26 : 10), a = d < 0 ? -d : d;
+    const int mag = (int)((0x2069544d245080ull >> (6 * a)) & 63ull);
+    return (d < 0) == vert ? -mag : mag;
+}
+__device__ __forceinline__ int intra_inv_angle(const int mode)           // mode 11 .. 25 (the negative angles)
+{
+    const int d = mode - (mode >= 18 ? 26 : 10), a = d < 0 ? -d : d;      // 1 .. 8
+    const unsigned long long w = a <= 4 ? 0x13b0e38ccd000ull : 0x8004ec30c1e2ull;
+    return -(int)((w >> (13 * ((a - 1) & 3))) & 0x1fffull);
+}
 
 struct IntraShared {
     int top[68], left[68];        // element k of the reference arrays lives at [k + 1]  (k = -1 .. 2N-1)
@@ -235,13 +249,13 @@ __device__ __forceinline__ void intra_body(IntraShared &sh, const int lane, cons
             *reinterpret_cast<Pixel *>(blk + (size_t)y * stride + (size_t)x * sizeof(Pixel)) = (Pixel)v;
         }
     } else {                                           // pred_angular, :419-510
-        const int angle = kIntraAngle[mode - 2], last = (n * angle) >> 5;
+        const int angle = intra_pred_angle(mode), last = (n * angle) >> 5;
         const bool vertical = mode >= 18;
         const int *mainr = vertical ? t : l, *sider = vertical ? l : t;
         int *ref = sh.ref + 32;
         for (int k = lane; k <= n2; k += 64) ref[k] = mainr[k - 1];
         if (angle < 0 && last < -1) {
-            const int inv = kIntraInvAngle[mode - 11];
+            const int inv = intra_inv_angle(mode);
             const int k = -1 - lane;                   // k = -1 .. last
             if (k >= last) ref[k] = sider[-1 + ((k * inv + 128) >> 8)];
         }

@@ -299,14 +299,14 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
             }
         }
     } else {                                               // pred_angular, :419-510
-        const int angle = kIntraAngle[mode - 2], last = (N * angle) >> 5;
+        const int angle = intra_pred_angle(mode), last = (N * angle) >> 5;
         const bool vertical = mode >= 18;
         const int *mainr = vertical ? t : l, *sider = vertical ? l : t;
         ref[i] = mainr[i - 1];
         ref[N + i] = mainr[N + i - 1];
         if (i == 0) { ref[2 * N] = mainr[2 * N - 1]; ref[2 * N + 1] = 0; }
         if (angle < 0 && last < -1) {
-            const int inv = kIntraInvAngle[mode - 11];
+            const int inv = intra_inv_angle(mode);
             const int k = -1 - i;                           // k = -1 .. last (last >= -N)
             if (k >= last) ref[k] = sider[-1 + ((k * inv + 128) >> 8)];
         }
@@ -603,74 +603,68 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         else if (sl.s == 3) pack_finish<5, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
     };
 
-    // Software pipeline over the levels (slot `wave` of each level; the further slots of a wide level are served plainly, below).
-    Slot s0 = slot_at(0, wave), s1 = slot_at(1, wave);
+    // Software pipeline over STEPS: a step is one pass of the 8-wavefront workgroup over a level - a level of up to 8 wavefront slots is one
+    // step, a wider one several (its blocks do not depend on each other: no release / acquire between its passes, only the barrier that keeps a
+    // wavefront's LDS arrays from being rewritten while some of its lanes still read them).  Every step issues the SAME loads in the same
+    // order - its neighbour samples (L2 hits: the previous level has just written them), then the residual rows of the next step and the
+    // records of the step after that (from HBM: they arrived by DMA) - so the wait in front of the arithmetic is exactly "my five samples",
+    // whatever was issued behind them.  Round 4 served the further passes of a wide level inside the level's loop body with loads of their own
+    // behind `if (pass)`: two paths with different numbers of younger loads meet in front of the arithmetic, the compiler's s_waitcnt takes the
+    // smaller count, and on the common path that count covered the next level's residual prefetch - every level waited for the loads it was
+    // meant to hide (vmcnt(4) .. vmcnt(0) in front of the first use of a sample in the round-4 listing).
+    struct Step { int l, p; };
+    auto next_step = [&](const Step st) -> Step {
+        const int nw = st.l < nlevels ? __builtin_amdgcn_readfirstlane(slev[st.l * 12 + 4]) : 0;
+        return (st.p + 1) * kChainWaves < nw ? Step{ st.l, st.p + 1 } : Step{ st.l + 1, 0 };
+    };
+    auto slot_of = [&](const Step st) -> Slot { return slot_at(st.l, st.p * kChainWaves + wave); };
+    Step st0 = { 0, 0 }, st1 = next_step(st0);
+    Slot s0 = slot_of(st0), s1 = slot_of(st1);
     PackRecs r0 = load_recs(s0), r1 = load_recs(s1);
-    u32x4 cq0[4] = {}, cq1[4] = {};
+    u32x4 cq0[4], cq1[4];
     load_cq(s0, r0, cq0);
-    // phase_clocks != NULL (diagnosis, ohevc_debug_intra_chain_clocks): wavefront 0 adds up, over the levels, the shader clocks it spends
-    // [0] waiting for its stores + in the barrier, [1] issuing the level's loads and prefetches, [2] in the level's arithmetic (incl. the
-    // wait for the samples), [3] in further passes of wide levels; [4] = levels
-    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pcx[3] = { 0, 0, 0 };
-    for (int l = 0; l < nlevels; l++) {
+    // phase_clocks != NULL (diagnosis, ohevc_debug_intra_chain_clocks): wavefront 0 adds up, over the steps, the shader clocks it spends
+    // [0] waiting for its stores + in the barrier, [1] issuing the step's loads and prefetches, [2] in the step's arithmetic (incl. the
+    // wait for the samples), [3] unused; [4] = levels; [5..7] = the issue phase after the sample loads / the residual prefetch / the records
+    unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pcx[3] = { 0, 0, 0 };
+    while (st0.l < nlevels) {
         const unsigned long long tk0 = phase_clocks ? clock64() : 0;
-        if (l) {
-            // The hand-over between two levels is a release / acquire at WORKGROUP scope: every wavefront of the workgroup runs on one CU
-            // and shares its vector L1 (no thread-group split), stores go through that L1, so "my stores have completed" + the barrier is
-            // all it takes (the gfx942 memory model: workgroup-scope acquire needs no cache invalidate).  Rounds 2 - 3 issued the AGENT-scope
-            // acquire here (buffer_inv sc1, what a hand-over between workgroups on different CUs needs): it costs every level microseconds -
-            // a level of twelve 4x4 blocks took as long as one of 32x32 blocks, ~4.5 us (agent_acquire != 0 keeps that form for A/B runs).
-            xcd_release();
+        if (st0.p == 0) {
+            if (st0.l) {
+                // The hand-over between two levels is a release / acquire at WORKGROUP scope: every wavefront of the workgroup runs on one CU
+                // and shares its vector L1 (no thread-group split), stores go through that L1, so "my stores have completed" + the barrier is
+                // all it takes (the gfx942 memory model: workgroup-scope acquire needs no cache invalidate).  Rounds 2 - 3 issued the AGENT-scope
+                // acquire here (buffer_inv sc1, what a hand-over between workgroups on different CUs needs): it costs every level microseconds
+                // (agent_acquire != 0 keeps that form for A/B runs).
+                xcd_release();
+                __syncthreads();
+                if (agent_acquire) xcd_acquire();
+            }
+        } else {
             __syncthreads();
-            if (agent_acquire) xcd_acquire();
         }
         const unsigned long long tk1 = phase_clocks ? clock64() : 0;
-        // ONE copy of the level's code serves the pipelined slot (pass 0) and the further passes of a level wider than the workgroup: the
-        // kernel is 4 block sizes x (sample addressing + smoothing + 35 predictors + residual kinds) of straight-line code, and two inlined
-        // copies of it (65 KB) did not fit the 64 KB instruction cache two CUs share - a level spent more time fetching instructions than
-        // waiting for memory.  The blocks of a level do not depend on each other, so there is no release / acquire between passes; the
-        // workgroup barrier only keeps a wavefront's LDS arrays from being rewritten while some of its lanes still read them (lanes take
-        // different numbers of wave-level scheduling points inside a pass).  Every wavefront takes every pass's barrier, with or without a
-        // slot of its own (s0.nwaves is the level's: the same for all of them).
-        Slot sc = s0;
-        PackRecs rc = r0;
-        u32x4 cqc[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) cqc[q] = cq0[q];
-        Slot s2 = { -1, 0, 0, 0, nullptr, nullptr };
-        PackRecs r2 = { u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
-        unsigned long long tk2 = 0, tk3 = 0;
-        const int level_waves = s0.nwaves > 0 ? s0.nwaves : 1;
-        for (int w0 = 0; w0 < level_waves; w0 += kChainWaves) {
-            if (w0) __syncthreads();
-            const PackSamples sm = load_samples(sc, rc);     // first: they hit the L2 the previous level wrote
-            if (w0) load_cq(sc, rc, cqc);                    // (pass 0 has had its residual rows prefetched a level ago)
-            issue_order_fence();
-            if (w0 == 0 && phase_clocks) pcx[0] += clock64() - tk1;
-            if (w0 == 0) {                                   // behind them: what later levels need, from HBM
-                load_cq(s1, r1, cq1);
-                issue_order_fence();
-                if (phase_clocks) pcx[1] += clock64() - tk1;
-                s2 = slot_at(l + 2, wave);
-                issue_order_fence();
-                if (phase_clocks) pcx[2] += clock64() - tk1;
-                r2 = load_recs(s2);
-            }
-            Slot sxn = { -1, 0, 0, 0, nullptr, nullptr };             // ... and the records of this wavefront's slot in the next pass, if there is one
-            PackRecs rxn = { u32x4{ 0u, 0u, 0u, 0u }, u32x4{ 0u, 0u, 0u, 0u }, false };
-            if (w0 + kChainWaves < level_waves) { sxn = slot_at(l, w0 + kChainWaves + wave); rxn = load_recs(sxn); }
-            issue_order_fence();
-            if (w0 == 0 && phase_clocks) tk2 = clock64();
-            finish(sc, rc, sm, cqc);
-            if (w0 == 0 && phase_clocks) tk3 = clock64();
-            sc = sxn; rc = rxn;
-        }
-        if (phase_clocks) { const unsigned long long tk4 = clock64(); pc0 += tk1 - tk0; pc1 += tk2 - tk1; pc2 += tk3 - tk2; pc3 += tk4 - tk3; }
+        const PackSamples sm = load_samples(s0, r0);         // first: they hit the L2 the previous level wrote
+        issue_order_fence();
+        if (phase_clocks) pcx[0] += clock64() - tk1;
+        load_cq(s1, r1, cq1);                                // behind them: what later steps need, from HBM
+        issue_order_fence();
+        if (phase_clocks) pcx[1] += clock64() - tk1;
+        const Step st2 = next_step(st1);
+        const Slot s2 = slot_of(st2);
+        const PackRecs r2 = load_recs(s2);
+        issue_order_fence();
+        const unsigned long long tk2 = phase_clocks ? clock64() : 0;
+        if (phase_clocks) pcx[2] += tk2 - tk1;
+        finish(s0, r0, sm, cq0);
+        if (phase_clocks) { const unsigned long long tk3 = clock64(); pc0 += tk1 - tk0; pc1 += tk2 - tk1; pc2 += tk3 - tk2; }
+        st0 = st1; st1 = st2;
         s0 = s1; r0 = r1;
 #pragma unroll
         for (int q = 0; q < 4; q++) cq0[q] = cq1[q];
         s1 = s2; r1 = r2;
     }
+    const unsigned long long pc3 = 0;
     if (phase_clocks && threadIdx.x == 0) {
         atomicAdd(&phase_clocks[0], pc0); atomicAdd(&phase_clocks[1], pc1); atomicAdd(&phase_clocks[2], pc2); atomicAdd(&phase_clocks[3], pc3);
         atomicAdd(&phase_clocks[4], (unsigned long long)nlevels);
