@@ -174,12 +174,9 @@ __device__ __forceinline__ void pack_load_coeffs(const PackRecs &r, const int la
 // kernel can issue the loads of a level FIRST behind the level's barrier and its prefetches for later levels behind them (vector memory
 // returns in order: a prefetch from HBM in front of them would delay every level by an HBM round trip).
 struct PackSamples { int v[5]; int none; };
-// ... in two halves, so that the chain kernel can do the address arithmetic of a level BEFORE the barrier in front of it (while the previous
-// level's stores are still on their way to the L2) and only the five loads behind it: byte offsets from the block's plane base
-struct PackSampleAddrs { const unsigned char *p[5]; int none; };
 
 template <int LOG2N, typename Pixel>
-__device__ __forceinline__ PackSampleAddrs pack_sample_addrs(const int lane, const PlaneSet planes, const PackRecs &recs)
+__device__ __forceinline__ PackSamples pack_load_samples(const int lane, const PlaneSet planes, const PackRecs &recs)
 {
     constexpr int N = 1 << LOG2N;
     const int i = lane % N;
@@ -202,31 +199,15 @@ __device__ __forceinline__ PackSampleAddrs pack_sample_addrs(const int lane, con
     const int p_ul = b != NONE ? b : a;
     const int p_u = c_ul ? o_c : b != NONE ? b : (c_ur ? o_tn : NONE);
     const int p_ur = c_u ? o_tm : c_ul ? o_c : b;            // nothing lies after above-right
+    auto REC = [&](const int off) -> int { return (int)*reinterpret_cast<const Pixel *>(blk + (off == NONE ? 0 : off)); };
     const int kt = i < tr_size ? i : tr_size - 1, kb = i < bl_size ? i : bl_size - 1;        // beyond the picture: the last valid sample (:111-114, 164-183)
     const int q_t0 = c_u ? i * P - stride : p_u, q_t1 = c_ur ? (N + kt) * P - stride : p_ur;
     const int q_l0 = c_l ? i * stride - P : p_l, q_l1 = c_bl ? (N + kb) * stride - P : p_bl;
     const int q_c = c_ul ? o_c : p_ul;
-    PackSampleAddrs sa;
-    sa.p[0] = blk + (q_t0 == NONE ? 0 : q_t0); sa.p[1] = blk + (q_t1 == NONE ? 0 : q_t1); sa.p[2] = blk + (q_l0 == NONE ? 0 : q_l0);
-    sa.p[3] = blk + (q_l1 == NONE ? 0 : q_l1); sa.p[4] = blk + (q_c == NONE ? 0 : q_c);
-    sa.none = (q_t0 == NONE ? 1 : 0) | (q_t1 == NONE ? 2 : 0) | (q_l0 == NONE ? 4 : 0) | (q_l1 == NONE ? 8 : 0) | (q_c == NONE ? 16 : 0);
-    return sa;
-}
-
-template <typename Pixel>
-__device__ __forceinline__ PackSamples pack_issue_samples(const PackSampleAddrs &sa)
-{
     PackSamples sm;
-#pragma unroll
-    for (int k = 0; k < 5; k++) sm.v[k] = (int)*reinterpret_cast<const Pixel *>(sa.p[k]);
-    sm.none = sa.none;
+    sm.v[0] = REC(q_t0); sm.v[1] = REC(q_t1); sm.v[2] = REC(q_l0); sm.v[3] = REC(q_l1); sm.v[4] = REC(q_c);
+    sm.none = (q_t0 == NONE ? 1 : 0) | (q_t1 == NONE ? 2 : 0) | (q_l0 == NONE ? 4 : 0) | (q_l1 == NONE ? 8 : 0) | (q_c == NONE ? 16 : 0);
     return sm;
-}
-
-template <int LOG2N, typename Pixel>
-__device__ __forceinline__ PackSamples pack_load_samples(const int lane, const PlaneSet planes, const PackRecs &recs)
-{
-    return pack_issue_samples<Pixel>(pack_sample_addrs<LOG2N, Pixel>(lane, planes, recs));
 }
 
 template <int LOG2N, typename Pixel, bool READY = false>
@@ -596,8 +577,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         r.has_res = sl.s >= 0 && sl.r != nullptr;                      // (applied where the record is READ, pack_kind: a select here would need the value)
         return r;
     };
-    struct CqAddr { const unsigned char *rowp; int step16[4]; };
-    auto cq_addr = [&](const Slot &sl, const PackRecs &r) -> CqAddr {
+    auto load_cq = [&](const Slot &sl, const PackRecs &r, u32x4 (&cq)[4]) {
         // row i of the block's residual as the pre-pass left it in the arena (READY form of pack_load_coeffs): N / 8 pieces of 16 bytes
         // (4x4: the piece that holds rows i and i ^ 1); the remaining of the four loads repeat the last piece
         const int log2n = sl.s + 2, n = 1 << (log2n & 7), i = lane & (n - 1);
@@ -605,23 +585,16 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         const bool is_idct = sl.s >= 0 && coeffs != nullptr && (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4);
         const int nr = log2n <= 3 ? 1 : n >> 3;
         const unsigned row_bytes = log2n == 2 ? (unsigned)(i >> 1) * 16u : (unsigned)i * (unsigned)n * 2u;
-        CqAddr a;
-        a.rowp = is_idct ? reinterpret_cast<const unsigned char *>(coeffs) + ((size_t)r.rw.z * 2u + row_bytes) : base;
+        const unsigned char *rowp = is_idct ? reinterpret_cast<const unsigned char *>(coeffs) + ((size_t)r.rw.z * 2u + row_bytes) : base;
 #pragma unroll
-        for (int q = 0; q < 4; q++) a.step16[q] = is_idct ? 16 * (q < nr ? q : nr - 1) : 0;
-        return a;
+        for (int q = 0; q < 4; q++) cq[q] = *reinterpret_cast<const u32x4 *>(rowp + (is_idct ? 16 * (q < nr ? q : nr - 1) : 0));
     };
-    auto issue_cq = [&](const CqAddr &a, u32x4 (&cq)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) cq[q] = *reinterpret_cast<const u32x4 *>(a.rowp + a.step16[q]);
-    };
-    auto load_cq = [&](const Slot &sl, const PackRecs &r, u32x4 (&cq)[4]) { issue_cq(cq_addr(sl, r), cq); };
-    auto sample_addrs = [&](const Slot &sl, const PackRecs &r) -> PackSampleAddrs {
-        if (sl.s == 0) return pack_sample_addrs<2, Pixel>(lane, planes, r);
-        if (sl.s == 1) return pack_sample_addrs<3, Pixel>(lane, planes, r);
-        if (sl.s == 2) return pack_sample_addrs<4, Pixel>(lane, planes, r);
-        if (sl.s == 3) return pack_sample_addrs<5, Pixel>(lane, planes, r);
-        return PackSampleAddrs{ { base, base, base, base, base }, 31 };
+    auto load_samples = [&](const Slot &sl, const PackRecs &r) -> PackSamples {
+        if (sl.s == 0) return pack_load_samples<2, Pixel>(lane, planes, r);
+        if (sl.s == 1) return pack_load_samples<3, Pixel>(lane, planes, r);
+        if (sl.s == 2) return pack_load_samples<4, Pixel>(lane, planes, r);
+        if (sl.s == 3) return pack_load_samples<5, Pixel>(lane, planes, r);
+        return PackSamples{ { 0, 0, 0, 0, 0 }, 0 };
     };
     auto finish = [&](const Slot &sl, const PackRecs &r, const PackSamples &sm, const u32x4 (&cq)[4]) {
         if (sl.s == 0)      pack_finish<2, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
@@ -656,13 +629,6 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pcx[3] = { 0, 0, 0 };
     while (st0.l < nlevels) {
         const unsigned long long tk0 = phase_clocks ? clock64() : 0;
-        // Address arithmetic first - where this step's five neighbour samples lie, where the next step's residual rows lie - and the barrier
-        // behind it: the previous level's stores need ~1000 clocks to be acknowledged by the L2, the arithmetic takes about as long and
-        // depends on nothing they write.  (The anchors keep the compiler from sinking it behind the barrier again.)
-        const PackSampleAddrs sa = sample_addrs(s0, r0);
-        const CqAddr ca = cq_addr(s1, r1);
-        asm volatile("" :: "v"(sa.p[0]), "v"(sa.p[1]), "v"(sa.p[2]), "v"(sa.p[3]), "v"(sa.p[4]), "v"(sa.none), "v"(ca.rowp), "v"(ca.step16[3]));
-        const unsigned long long tka = phase_clocks ? clock64() : 0;
         if (st0.p == 0) {
             if (st0.l) {
                 // The hand-over between two levels is a release / acquire at WORKGROUP scope: every wavefront of the workgroup runs on one CU
@@ -678,10 +644,10 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
             __syncthreads();
         }
         const unsigned long long tk1 = phase_clocks ? clock64() : 0;
-        const PackSamples sm = pack_issue_samples<Pixel>(sa);    // first: they hit the L2 the previous level wrote
+        const PackSamples sm = load_samples(s0, r0);         // first: they hit the L2 the previous level wrote
         issue_order_fence();
         if (phase_clocks) pcx[0] += clock64() - tk1;
-        issue_cq(ca, cq1);                                   // behind them: what later steps need, from HBM
+        load_cq(s1, r1, cq1);                                // behind them: what later steps need, from HBM
         issue_order_fence();
         if (phase_clocks) pcx[1] += clock64() - tk1;
         const Step st2 = next_step(st1);
@@ -691,7 +657,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         const unsigned long long tk2 = phase_clocks ? clock64() : 0;
         if (phase_clocks) pcx[2] += tk2 - tk1;
         finish(s0, r0, sm, cq0);
-        if (phase_clocks) { const unsigned long long tk3 = clock64(); pc0 += tk1 - tka; pc1 += (tk2 - tk1) + (tka - tk0); pc2 += tk3 - tk2; }
+        if (phase_clocks) { const unsigned long long tk3 = clock64(); pc0 += tk1 - tk0; pc1 += tk2 - tk1; pc2 += tk3 - tk2; }
         st0 = st1; st1 = st2;
         s0 = s1; r0 = r1;
 #pragma unroll
