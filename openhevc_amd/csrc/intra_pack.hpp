@@ -437,7 +437,7 @@ struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
     int reserved;
 };
 
-constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup; a wider level takes ceil(width / 8) passes of it
+constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup; a wider level takes ceil(width / 8) steps of it (4 wavefronts - one per SIMD - measured in round 5: 8 030 clocks per level against 6 390, profiles/r5m_*)
 constexpr int kChainMaxLevels = 1024;   // levels per launch: their records (48 bytes each) are copied to LDS at the kernel's start
 
 // Round 4.  (a) A level may be WIDER than the workgroup: its wavefront slots 8, 9, ... are served by wavefronts 0, 1, ... in further passes
