@@ -96,9 +96,6 @@ int ohevc_debug_level_tu(struct ohevc_ctx *ctx, int level, int log2_size, int ki
 /* the intra work of the CTB executor (level launch mode 2): tasks in raster order, their operation words (ohevc_dev_ctbs) and the job arrays they index */
 int ohevc_debug_ctbs(struct ohevc_ctx *ctx, const struct ohevc_ctb_task **tasks, int *ntasks, const uint32_t **ops, const struct ohevc_intra_job **intra_jobs,
                      const struct ohevc_tu_job **tu_jobs, int *log2_ctb_size);
-/* ohevc_dev_intra_recon_sorted: launches of at least this many groups of blocks (a group = the 16 / 8 / 4 / 2 blocks a wavefront holds) give a
- * wavefront four groups, software-pipelined; below it, one (default 2048; tests force 1).  Returns the previous value. */
-int ohevc_debug_set_intra_multi_min_groups(int n);
 /* 1: the jobs of every dependency level are staged back to front (the kernel emulator runs the workgroups of a launch one after the other in
  * launch order: an order that hides a dependency the level computation missed; the jobs of a level are independent, so any order must do) */
 int ohevc_debug_set_reverse_levels(int on);

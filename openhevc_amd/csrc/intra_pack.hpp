@@ -394,38 +394,6 @@ __device__ __forceinline__ void intra_pack_body(int *ish, unsigned char *tu_lds,
     pack_compute<LOG2N, Pixel>(ish, tu_lds, lane, planes, r, cq, coeffs, bit_depth);
 }
 
-// Several groups of blocks per wavefront, software-pipelined (large launches: thousands of independent blocks).  One group per wavefront
-// is a chain of two dependent round trips - records, then samples and coefficients - and a wavefront has nothing to do while it waits
-// (the kernel's counters: SQ_WAIT_ANY 59 % of its wave cycles, VALU active 15 %, profiles/r5a_sq_counters_intra_pack_before.txt).  Here the
-// records of group k + 2 and the samples / coefficients of group k + 1 are on their way while group k is predicted; every iteration issues
-// the same loads (a group behind the segment's end: the last job's again, never stored), so the wait in front of the arithmetic counts
-// exactly the loads issued behind the ones it needs.
-template <int LOG2N, typename Pixel>
-__device__ __forceinline__ void intra_pack_body_multi(int *ish, unsigned char *tu_lds, const int lane, const int job0, const int njobs, const int groups,
-                                                      const PlaneSet planes, const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
-                                                      const int16_t *__restrict__ coeffs, const int bit_depth)
-{
-    constexpr int G = 64 >> LOG2N;
-    PackRecs r1 = pack_load_recs<LOG2N>(lane, job0, njobs, jobs, residuals);
-    PackRecs r2 = pack_load_recs<LOG2N>(lane, job0 + G, njobs, jobs, residuals);
-    u32x4 cq1[4];
-    pack_load_coeffs<LOG2N>(r1, lane, coeffs, cq1);
-    PackSamples sm1 = pack_load_samples<LOG2N, Pixel>(lane, planes, r1);
-#pragma unroll 1
-    for (int k = 0; k < groups; k++) {
-        u32x4 cq2[4];
-        pack_load_coeffs<LOG2N>(r2, lane, coeffs, cq2);
-        const PackSamples sm2 = pack_load_samples<LOG2N, Pixel>(lane, planes, r2);
-        const PackRecs r3 = pack_load_recs<LOG2N>(lane, job0 + (k + 2) * G, njobs, jobs, residuals);
-        issue_order_fence();
-        pack_finish<LOG2N, Pixel>(ish, tu_lds, lane, planes, r1, sm1, cq1, coeffs, bit_depth);
-        PACK_SYNC();                                       // the next group rewrites this wavefront's LDS arrays
-        r1 = r2; r2 = r3; sm1 = sm2;
-#pragma unroll
-        for (int q = 0; q < 4; q++) cq1[q] = cq2[q];
-    }
-}
-
 #undef PACK_SYNC
 
 // jobs sorted by size: wavefront w serves 64 / N consecutive blocks of the segment it falls into
@@ -436,8 +404,7 @@ struct IntraPackSegs {
 
 // WITH_TU = false: prediction only (no residual records): no transform tile in LDS - 3.4 KB instead of 8.5 KB per wavefront, a third more
 // wavefronts per CU
-// GROUPS > 1: a wavefront takes GROUPS consecutive groups of its segment (first_wave counts such wavefronts), pipelined (intra_pack_body_multi)
-template <typename Pixel, bool WITH_TU, int GROUPS = 1>
+template <typename Pixel, bool WITH_TU>
 __global__ __launch_bounds__(64) void intra_pack_kernel(PlaneSet planes, const ohevc_intra_job *__restrict__ jobs, const ohevc_tu_job *__restrict__ residuals,
                                                         IntraPackSegs segs, int bit_depth, const int16_t *__restrict__ coeffs)
 {
@@ -450,15 +417,6 @@ __global__ __launch_bounds__(64) void intra_pack_kernel(PlaneSet planes, const o
     const ohevc_intra_job *j = jobs + segs.first_job[s];
     const ohevc_tu_job *r = WITH_TU && residuals ? residuals + segs.first_job[s] : nullptr;
     const int n = segs.njobs[s];
-    if constexpr (GROUPS > 1) {
-        // (the groups this wavefront really has: the segment's last wavefront may have fewer)
-        const int per = 16 >> s, left = (n - local * GROUPS * per + per - 1) / per, g = left < GROUPS ? left : GROUPS;
-        if (s == 0)      intra_pack_body_multi<2, Pixel>(ish, tu_lds, lane, local * GROUPS * 16, n, g, planes, j, r, coeffs, bit_depth);
-        else if (s == 1) intra_pack_body_multi<3, Pixel>(ish, tu_lds, lane, local * GROUPS * 8, n, g, planes, j, r, coeffs, bit_depth);
-        else if (s == 2) intra_pack_body_multi<4, Pixel>(ish, tu_lds, lane, local * GROUPS * 4, n, g, planes, j, r, coeffs, bit_depth);
-        else             intra_pack_body_multi<5, Pixel>(ish, tu_lds, lane, local * GROUPS * 2, n, g, planes, j, r, coeffs, bit_depth);
-        return;
-    }
     if (s == 0)      intra_pack_body<2, Pixel>(ish, tu_lds, lane, local * 16, n, planes, j, r, coeffs, bit_depth);
     else if (s == 1) intra_pack_body<3, Pixel>(ish, tu_lds, lane, local * 8, n, planes, j, r, coeffs, bit_depth);
     else if (s == 2) intra_pack_body<4, Pixel>(ish, tu_lds, lane, local * 4, n, planes, j, r, coeffs, bit_depth);

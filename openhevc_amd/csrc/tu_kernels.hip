@@ -1740,9 +1740,6 @@ extern "C" int ohevc_dev_intra_recon_batch(const ohevc_plane planes[3], int bit_
 
 #include "intra_pack.hpp"       // N lanes per N x N block: prediction + residual in registers, one store (uses the residual bodies above)
 
-static int g_intra_multi_min_groups = 2048;      // ohevc_debug_set_intra_multi_min_groups: from this many groups of blocks on, four groups per wavefront
-extern "C" int ohevc_debug_set_intra_multi_min_groups(int n) { const int prev = g_intra_multi_min_groups; g_intra_multi_min_groups = n < 1 ? 1 : n; return prev; }
-
 extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit_depth, const ohevc_intra_job *jobs, const ohevc_tu_job *residuals,
                                             const int32_t count_by_size[4], const int16_t *coeffs, void *stream)
 {
@@ -1750,26 +1747,17 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
     OHEVC_REQUIRE(planes != nullptr && count_by_size != nullptr, "null argument");
     OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
     IntraPackSegs sg = {};
-    long long total = 0, groups_total = 0;
+    long long total = 0;
     for (int s = 0; s < 4; s++) {
         OHEVC_REQUIRE(count_by_size[s] >= 0, "negative job count");
-        total += count_by_size[s];
-        groups_total += (count_by_size[s] + (16 >> s) - 1) / (16 >> s);
-    }
-    OHEVC_REQUIRE(total < (1ll << 30), "too many jobs");
-    if (total == 0) return OHEVC_OK;
-    // Thousands of groups (a batch of independent blocks): four per wavefront, pipelined - there are still far more wavefronts than the device
-    // holds at a time.  A level of a picture (tens of groups): one per wavefront, every CU it can get.
-    constexpr int kMulti = 4;
-    const int per = groups_total >= g_intra_multi_min_groups ? kMulti : 1;
-    total = 0;
-    for (int s = 0; s < 4; s++) {
-        const int per_wave = (16 >> s) * per;
+        const int per_wave = 16 >> s;
         sg.first_job[s] = (int)total;
         sg.njobs[s] = count_by_size[s];
         sg.first_wave[s + 1] = sg.first_wave[s] + (count_by_size[s] + per_wave - 1) / per_wave;
         total += count_by_size[s];
     }
+    OHEVC_REQUIRE(total < (1ll << 30), "too many jobs");
+    if (total == 0) return OHEVC_OK;
     OHEVC_REQUIRE(jobs != nullptr && (reinterpret_cast<uintptr_t>(jobs) & 15) == 0 && (reinterpret_cast<uintptr_t>(residuals) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0, "arrays must be 16-byte aligned");
     OHEVC_REQUIRE(residuals == nullptr || coeffs != nullptr, "residual records without a coefficient arena");
@@ -1778,15 +1766,9 @@ extern "C" int ohevc_dev_intra_recon_sorted(const ohevc_plane planes[3], int bit
     if (rc != OHEVC_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int waves = sg.first_wave[4];
-    if (residuals != nullptr && per > 1) {
-        if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t, true, kMulti>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
-        else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t, true, kMulti>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
-    } else if (residuals != nullptr) {
+    if (residuals != nullptr) {
         if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t, true>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
         else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t, true>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
-    } else if (per > 1) {
-        if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t, false, kMulti>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
-        else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t, false, kMulti>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
     } else {
         if (bit_depth == 8) hipLaunchKernelGGL((intra_pack_kernel<uint8_t, false>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);
         else                hipLaunchKernelGGL((intra_pack_kernel<uint16_t, false>), dim3(waves), dim3(64), 0, st, ps, jobs, residuals, sg, bit_depth, coeffs);

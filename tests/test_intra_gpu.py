@@ -203,21 +203,12 @@ def test_intra_pack_random_calls(oracle, bd):
             assert np.array_equal(got, want[pl]), (it, log2, c_idx, mode, cands, x0, y0, cfi, strong, dis, ctb, pl)
 
 
-@pytest.fixture(params=[False, True], ids=["one_group_per_wavefront", "four_groups_pipelined"])
-def multi_groups(request):
-    """ohevc_dev_intra_recon_sorted gives a wavefront four groups of blocks, software-pipelined, from 2048 groups on: forced for small batches"""
-    lib = L.load_library()
-    prev = lib.ohevc_debug_set_intra_multi_min_groups(1 if request.param else 1 << 30)
-    yield request.param
-    lib.ohevc_debug_set_intra_multi_min_groups(prev)
-
-
 @pytest.mark.parametrize("bd", [8, 10, 14])
-def test_intra_pack_batch_with_residuals(oracle, bd, multi_groups):
+def test_intra_pack_batch_with_residuals(oracle, bd):
     """many independent blocks of all four sizes in ONE launch, most with a residual of a random kind riding along"""
     import ctypes as C
     rng = np.random.default_rng(2900 + bd)
-    W, H = 2048, 1536                                       # 192 blocks: with four groups per wavefront every size class still has wavefronts with a full and a partial set of groups
+    W, H = 1024, 512
     luma = rng.integers(0, 1 << bd, size=(H, W)).astype(G.pixdt(bd))
     planes = [luma, rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd)), rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd))]
     want = [p.copy() for p in planes]
@@ -235,11 +226,6 @@ def test_intra_pack_batch_with_residuals(oracle, bd, multi_groups):
             x0, y0 = cx + 64, cy + 64                      # luma position; chroma blocks sit at half of it
             mode = int(rng.integers(0, 35))
             cands = [int(rng.random() < 0.8) for _ in range(5)]
-            nl = n << sh                                    # (what lies outside the picture is never a candidate: the decoder derives the flags from
-            if y0 + nl >= H:                                #  z-scan availability, hevc.c:1107-1130, and nothing outside the picture is available)
-                cands[0] = 0
-            if x0 + nl >= W:
-                cands[4] = 0
             oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1, strong=1, smoothing_disabled=0,
                               log2_ctb_size=6, log2_min_tb_size=2)
             job = L.intra_make_job(geom, x0, y0, log2, c_idx, mode, cands)[0]
