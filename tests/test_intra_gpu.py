@@ -208,7 +208,7 @@ def test_intra_pack_batch_with_residuals(oracle, bd):
     """many independent blocks of all four sizes in ONE launch, most with a residual of a random kind riding along"""
     import ctypes as C
     rng = np.random.default_rng(2900 + bd)
-    W, H = 1024, 512
+    W, H = 2048, 1536
     luma = rng.integers(0, 1 << bd, size=(H, W)).astype(G.pixdt(bd))
     planes = [luma, rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd)), rng.integers(0, 1 << bd, size=(H // 2, W // 2)).astype(G.pixdt(bd))]
     want = [p.copy() for p in planes]
@@ -226,6 +226,11 @@ def test_intra_pack_batch_with_residuals(oracle, bd):
             x0, y0 = cx + 64, cy + 64                      # luma position; chroma blocks sit at half of it
             mode = int(rng.integers(0, 35))
             cands = [int(rng.random() < 0.8) for _ in range(5)]
+            nl = n << sh                                    # (what lies outside the picture is never a candidate: the decoder derives the flags from
+            if y0 + nl >= H:                                #  z-scan availability, hevc.c:1107-1130, and nothing outside the picture is available)
+                cands[0] = 0
+            if x0 + nl >= W:
+                cands[4] = 0
             oracle.intra_pred(bd, want, W, H, x0, y0, log2, c_idx, mode, cands, chroma_format_idc=1, strong=1, smoothing_disabled=0,
                               log2_ctb_size=6, log2_min_tb_size=2)
             job = L.intra_make_job(geom, x0, y0, log2, c_idx, mode, cands)[0]
