@@ -266,7 +266,7 @@ def drive_tables(reflib, bd, W, H, cur, refs, enc, hevcdsp_hook=None, videodsp_h
     return rc
 
 
-def check_switches(kind, product, names, threads=1):
+def check_switches(kind, product, names, threads=1, combos=((1, 1), (96, 0), (1, 0))):
     """Round-5 switches of the product library that no small stream trips on its own, forced: (a) every frame with intra levels goes to the
     context's long-chain stream (a picture of the golden streams has a few dozen levels, the default threshold is 96) - the hand-over between a
     context's two streams at every picture; (b) coefficients uploaded whole, as in rounds 1-4, against the compact default.  Same pictures."""
@@ -282,7 +282,7 @@ def check_switches(kind, product, names, threads=1):
     elif threads > 1:
         names = [n for n in names if n != "cross_444_10b_tqb"]
     try:
-        for levels, compact in ((1, 1), (96, 0), (1, 0)):
+        for levels, compact in combos:
             product.ohevc_debug_set_long_chain_levels(levels)
             product.ohevc_debug_set_compact_coeffs(compact)
             for name in names:

@@ -429,7 +429,7 @@ def test_idr_segments_are_decoded_by_one_rank_each_and_nothing_is_exchanged(worl
     from test_stream_cpu import load_golden
     if not ps.have("hipemu"):
         pytest.skip("emulator-backed decoder not built (needs the reference tree once)")
-    names, repeat = ["ra_8b_ctb64", "ldb_10b", "ra_8b_nonref_leaves"], 4
+    names, repeat = ["ra_8b_ctb64", "ldb_10b"], 3
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -201,7 +201,7 @@ def test_emu_long_chain_stream_and_whole_coefficient_upload(threads):
     from stream_exec import check_switches
     with ps.Decoder("hipemu") as d:
         product = d.product_lib()
-    check_switches("hipemu", product, ["intra_8b", "ra_8b_ctb64", "ra_10b_odd", "small_blocks", "fmt444_14b_cip_cross", "pcm"], threads)
+    check_switches("hipemu", product, ["intra_8b", "ra_8b_ctb64", "small_blocks", "fmt444_14b_cip_cross"], threads, combos=((1, 1), (1, 0)))
 
 
 # ---------------------------------------------------------------- decoder instances (integration/hip_backend.h), over the emulated device code
