@@ -334,6 +334,21 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
         }
     }
 
+    unsigned char *row = blk + __umul24((unsigned)i, (unsigned)stride);
+    if constexpr (READY) {
+        // the chain's common case: the residual row is in `cq` as packed clip_int16 pairs (the pre-pass transformed in place) - added pairwise
+        if (kind >= 0 && is_idct) {
+            unsigned res2[N / 2];
+            if constexpr (LOG2N == 2) {
+                res2[0] = (i & 1) ? cq[0].z : cq[0].x; res2[1] = (i & 1) ? cq[0].w : cq[0].y;
+            } else {
+#pragma unroll
+                for (int q = 0; q < N / 8; q++) { res2[4 * q] = cq[q].x; res2[4 * q + 1] = cq[q].y; res2[4 * q + 2] = cq[q].z; res2[4 * q + 3] = cq[q].w; }
+            }
+            finish_row_pairs<N, Pixel>(row, pred, res2, bit_depth, valid);
+            return;
+        }
+    }
     // ---- the row as it will lie in memory
     constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
     unsigned px[ROWDW];
@@ -342,7 +357,6 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
         if constexpr (sizeof(Pixel) == 1) px[d] = (unsigned)pred[4 * d] | ((unsigned)pred[4 * d + 1] << 8) | ((unsigned)pred[4 * d + 2] << 16) | ((unsigned)pred[4 * d + 3] << 24);
         else px[d] = (unsigned)pred[2 * d] | ((unsigned)pred[2 * d + 1] << 16);
     }
-    unsigned char *row = blk + __umul24((unsigned)i, (unsigned)stride);
 
     // ---- the block's residual, row i (hevc_cabac.c:1868-1949), added in registers (transform_add, hevcdsp_template.c:45-111)
     if (kind >= 0) {

@@ -183,6 +183,43 @@ __device__ __forceinline__ void finish_row(unsigned char *row, unsigned *px, con
     }
 }
 
+// The same with the prediction still as N ints (what the intra predictors leave) and the residual ALREADY as N / 2 packed pairs of
+// clip_int16'ed values (what intra_chain_residual_kernel left in the arena): the pairs go straight into the packed add - no unpacking of the
+// residual into ints, no packing of the prediction into pixels and back.  A lane of a 32x32 block does this for 32 samples, and a level of the
+// intra chain lasts as long as its largest block.
+template <int N, typename Pixel>
+__device__ __forceinline__ void finish_row_pairs(unsigned char *row, const int *pred, const unsigned *res2, int bit_depth, bool valid)
+{
+    constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
+    constexpr int VEC   = ROWDW >= 4 ? 4 : ROWDW;
+    const unsigned maxv = (1u << bit_depth) - 1u, max2 = maxv | (maxv << 16);
+    unsigned px[ROWDW];
+#pragma unroll
+    for (int d = 0; d < ROWDW; d++) {
+        if constexpr (sizeof(Pixel) == 1) {
+            const unsigned u01 = (unsigned)pred[4 * d] | ((unsigned)pred[4 * d + 1] << 16), u23 = (unsigned)pred[4 * d + 2] | ((unsigned)pred[4 * d + 3] << 16);
+            const unsigned s01 = add_clamp_px2(res2[2 * d], u01, max2), s23 = add_clamp_px2(res2[2 * d + 1], u23, max2);
+            px[d] = __builtin_amdgcn_perm(s23, s01, 0x06040200u);
+        } else {
+            px[d] = add_clamp_upx2(res2[d], (unsigned)pred[2 * d] | ((unsigned)pred[2 * d + 1] << 16), max2);
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int v = 0; v < ROWDW / VEC; v++) {
+            if constexpr (VEC == 4) {
+                u32x4 t = { px[4 * v], px[4 * v + 1], px[4 * v + 2], px[4 * v + 3] };
+                *reinterpret_cast<u32x4 *>(row + 16 * v) = t;
+            } else if constexpr (VEC == 2) {
+                u32x2 t = { px[2 * v], px[2 * v + 1] };
+                *reinterpret_cast<u32x2 *>(row + 8 * v) = t;
+            } else {
+                *reinterpret_cast<unsigned *>(row + 4 * v) = px[v];
+            }
+        }
+    }
+}
+
 // res[0..N-1] (already >> shift, any int32) + prediction row -> clipped pixels, in place in HBM.
 // clip_pixel(pred + clip_int16(r)) is what transform_add computes; sat_pack_i16 is the clip_int16.
 template <int N, typename Pixel>

@@ -12,6 +12,7 @@
 #   bench [bench.py args]        one bench.py line                                                   -> bench<suffix>.json
 #   bench_prof [bench.py args]   rocprofv3 --kernel-trace --stats of the bench command               -> kernel_stats.txt
 #   pmc                          FETCH_SIZE / WRITE_SIZE passes of the bench command                 -> pmc_traffic.json
+#   pmc_row <log2> <bd> <kernel> the same for bench.py --log2 <log2> --bit-depth <bd>                -> pmc_traffic_log2_<log2>_<bd>bit.json
 #   counters <kernel> <cmd ...>  SQ / TCP / TCC counter passes of <cmd>, rows of kernels matching    -> counters_<kernel>.txt
 #   kernels <only> [args]        tools/bench_kernels.py --resident --planes 8 --only <only>          -> bench_kernels_<only>.jsonl
 #   kernels_prof <only> [args]   the same command under rocprofv3 (stats + the two PMC passes)       -> kernel_stats_<only>_<n>.txt, pmc_<only>_<n>.jsonl
@@ -81,6 +82,12 @@ PY
       ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_fetch -o p -- $CMD > /tmp/pmc_fetch.log 2>&1
         timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc_write -o p -- $CMD > /tmp/pmc_write.log 2>&1 )
       python tools/pmc_traffic.py /tmp/pmc_fetch/p_results.db /tmp/pmc_write/p_results.db "tu_idct32_tile1_kernel<unsigned char" | tee $OUT/pmc_traffic.json ;;
+    pmc_row)      # <log2> <bit depth> <kernel name prefix>: the same two passes for another row of the residual kernels (bench.py --log2 / --bit-depth)
+      local l2=$1 bdp=$2 kn=$3
+      local CMD="python $ROOT/bench.py --log2 $l2 --bit-depth $bdp --steps 4 --warmup 2 --no-cpu-baseline --no-decode --no-kernels --no-frames --no-zscan --check-blocks 0"
+      ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmcr_fetch_${l2}_$bdp -o p -- $CMD > /dev/null 2>&1
+        timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmcr_write_${l2}_$bdp -o p -- $CMD > /dev/null 2>&1 )
+      python tools/pmc_traffic.py /tmp/pmcr_fetch_${l2}_$bdp/p_results.db /tmp/pmcr_write_${l2}_$bdp/p_results.db "$kn" | tee $OUT/pmc_traffic_log2_${l2}_${bdp}bit.json ;;
     counters)
       local k=$1 i=0; shift
       # (at most four counters per pass: larger sets were refused by the counter scheduler and left the files empty)
