@@ -210,18 +210,13 @@ __device__ __forceinline__ PackSamples pack_load_samples(const int lane, const P
     return sm;
 }
 
-// SPLIT (32x32 blocks in the chain kernel): the block takes the WHOLE wavefront, two lanes per row - lane (h, i) = samples 16 h .. 16 h + 15 of
-// row i.  A lane of a 32x32 block otherwise predicts, adds and stores 32 samples, a level of the chain lasts as long as its slowest wavefront,
-// and more than half of an encoder-like intra picture's levels hold a 32x32 block.  Both halves stage the same reference arrays (the same
-// values into the same LDS words); `cq` holds the lane's half of the residual row.
-template <int LOG2N, typename Pixel, bool READY = false, bool SPLIT = false>
+template <int LOG2N, typename Pixel, bool READY = false>
 __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, const int lane, const PlaneSet planes, const PackRecs &recs, const PackSamples &sm,
                                             const u32x4 (&cq)[4], const int16_t *__restrict__ coeffs, const int bit_depth)
 {
     using IL = IntraPackLayout<LOG2N>;
-    constexpr int N = IL::N, NX = SPLIT ? N / 2 : N;           // NX: samples of a row this lane produces, from column x0 on
-    static_assert(!SPLIT || (LOG2N == 5 && READY), "the split form serves the 32x32 blocks of the chain kernel");
-    const int g = SPLIT ? 0 : lane / N, i = lane % N, half = SPLIT ? lane / N : 0, x0 = half * NX;
+    constexpr int N = IL::N;
+    const int g = lane / N, i = lane % N;
     const bool valid = recs.valid;
     const u32x4 jw = recs.jw, rw = recs.rw;
     const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
@@ -255,7 +250,6 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
                 const int t0 = top[-1], t63 = top[2 * N - 1], l0 = left[-1], l63 = left[2 * N - 1];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    if (SPLIT && h != half) continue;          // (two lanes per row: each filters one of the row's two entries)
                     const int k = h * N + i;
                     ftop[k]  = k < 2 * N - 1 ? (__mul24(2 * N - 1 - k, t0) + __mul24(k + 1, t63) + N) >> (LOG2N + 1) : t63;
                     fleft[k] = k < 2 * N - 1 ? (__mul24(2 * N - 1 - k, l0) + __mul24(k + 1, l63) + N) >> (LOG2N + 1) : l63;
@@ -264,7 +258,6 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    if (SPLIT && h != half) continue;
                     const int k = h * N + i;
                     ftop[k]  = k < 2 * N - 1 ? (top[k + 1] + 2 * top[k] + top[k - 1] + 2) >> 2 : top[k];
                     fleft[k] = k < 2 * N - 1 ? (left[k + 1] + 2 * left[k] + left[k - 1] + 2) >> 2 : left[k];
@@ -277,7 +270,7 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
     }
 
     // ---- prediction of row i
-    int pred[NX];
+    int pred[N];
     const int maxv = (1 << bit_depth) - 1;
     const bool luma_edge = (flags & OHEVC_INTRA_LUMA_EDGE) && N < 32;
     if (mode == 0) {                                       // pred_planar, :359-372
@@ -286,20 +279,20 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
         // slowest wavefront's instruction stream)
         const int ly = l[i], tn = t[N], ln = l[N];
         const int step = tn - ly, wy = N - 1 - i;
-        int acc = __mul24(N - 1, ly) + tn + __mul24(i + 1, ln) + N + __mul24(x0, step);
+        int acc = __mul24(N - 1, ly) + tn + __mul24(i + 1, ln) + N;
 #pragma unroll
-        for (int x = 0; x < NX; x++) { pred[x] = (acc + __mul24(wy, t[x0 + x])) >> (LOG2N + 1); acc += step; }
+        for (int x = 0; x < N; x++) { pred[x] = (acc + __mul24(wy, t[x])) >> (LOG2N + 1); acc += step; }
     } else if (mode == 1) {                                // pred_dc, :388-417
         int part = l[i] + t[i];
 #pragma unroll
         for (int o = N / 2; o >= 1; o >>= 1) part += __shfl_xor(part, o);
         const int dc = (part + N) >> (LOG2N + 1);
 #pragma unroll
-        for (int x = 0; x < NX; x++) pred[x] = dc;
-        if (luma_edge) {                                   // (never with SPLIT: N < 32 only)
+        for (int x = 0; x < N; x++) pred[x] = dc;
+        if (luma_edge) {
             if (i == 0) {
 #pragma unroll
-                for (int x = 1; x < NX; x++) pred[x] = (t[x] + 3 * dc + 2) >> 2;
+                for (int x = 1; x < N; x++) pred[x] = (t[x] + 3 * dc + 2) >> 2;
                 pred[0] = (l[0] + 2 * dc + t[0] + 2) >> 2;
             } else {
                 pred[0] = (l[i] + 3 * dc + 2) >> 2;
@@ -320,44 +313,44 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
         PACK_SYNC();
         if (vertical) {
             const int pos = (i + 1) * angle, i2 = pos >> 5, fact = pos & 31;
-            int r0 = ref[x0 + i2 + 1];
+            int r0 = ref[i2 + 1];
 #pragma unroll
-            for (int x = 0; x < NX; x++) {
-                const int r1 = ref[x0 + x + i2 + 2];
+            for (int x = 0; x < N; x++) {
+                const int r1 = ref[x + i2 + 2];
                 pred[x] = (__mul24(32 - fact, r0) + __mul24(fact, r1) + 16) >> 5;
                 r0 = r1;
             }
             if (luma_edge && mode == 26) { const int v = t[0] + ((l[i] - l[-1]) >> 1); pred[0] = v < 0 ? 0 : v > maxv ? maxv : v; }
         } else {
 #pragma unroll
-            for (int x = 0; x < NX; x++) {
-                const int pos = (x0 + x + 1) * angle, i2 = pos >> 5, fact = pos & 31;
+            for (int x = 0; x < N; x++) {
+                const int pos = (x + 1) * angle, i2 = pos >> 5, fact = pos & 31;
                 pred[x] = (__mul24(32 - fact, ref[i + i2 + 1]) + __mul24(fact, ref[i + i2 + 2]) + 16) >> 5;
             }
             if (luma_edge && mode == 10 && i == 0) {
 #pragma unroll
-                for (int x = 0; x < NX; x++) { const int v = l[0] + ((t[x] - t[-1]) >> 1); pred[x] = v < 0 ? 0 : v > maxv ? maxv : v; }
+                for (int x = 0; x < N; x++) { const int v = l[0] + ((t[x] - t[-1]) >> 1); pred[x] = v < 0 ? 0 : v > maxv ? maxv : v; }
             }
         }
     }
 
-    unsigned char *row = blk + (__umul24((unsigned)i, (unsigned)stride) + (unsigned)x0 * (unsigned)sizeof(Pixel));
+    unsigned char *row = blk + __umul24((unsigned)i, (unsigned)stride);
     if constexpr (READY) {
         // the chain's common case: the residual row is in `cq` as packed clip_int16 pairs (the pre-pass transformed in place) - added pairwise
         if (kind >= 0 && is_idct) {
-            unsigned res2[NX / 2];
+            unsigned res2[N / 2];
             if constexpr (LOG2N == 2) {
                 res2[0] = (i & 1) ? cq[0].z : cq[0].x; res2[1] = (i & 1) ? cq[0].w : cq[0].y;
             } else {
 #pragma unroll
-                for (int q = 0; q < NX / 8; q++) { res2[4 * q] = cq[q].x; res2[4 * q + 1] = cq[q].y; res2[4 * q + 2] = cq[q].z; res2[4 * q + 3] = cq[q].w; }
+                for (int q = 0; q < N / 8; q++) { res2[4 * q] = cq[q].x; res2[4 * q + 1] = cq[q].y; res2[4 * q + 2] = cq[q].z; res2[4 * q + 3] = cq[q].w; }
             }
-            finish_row_pairs<NX, Pixel>(row, pred, res2, bit_depth, valid);
+            finish_row_pairs<N, Pixel>(row, pred, res2, bit_depth, valid);
             return;
         }
     }
     // ---- the row as it will lie in memory
-    constexpr int ROWDW = NX * (int)sizeof(Pixel) / 4;
+    constexpr int ROWDW = N * (int)sizeof(Pixel) / 4;
     unsigned px[ROWDW];
 #pragma unroll
     for (int d = 0; d < ROWDW; d++) {
@@ -368,19 +361,31 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
     // ---- the block's residual, row i (hevc_cabac.c:1868-1949), added in registers (transform_add, hevcdsp_template.c:45-111)
     if (kind >= 0) {
         int res[N];
-        if (is_idct && !READY) {
+        if (is_idct && READY) {                            // row i of the residual as the pre-pass left it in the arena
+            if constexpr (LOG2N == 2) {
+                const unsigned lo = (i & 1) ? cq[0].z : cq[0].x, hi = (i & 1) ? cq[0].w : cq[0].y;
+                res[0] = (int)(short)(lo & 0xffffu); res[1] = (int)lo >> 16; res[2] = (int)(short)(hi & 0xffffu); res[3] = (int)hi >> 16;
+            } else {
+#pragma unroll
+                for (int q = 0; q < N / 8; q++) {
+                    const unsigned w4[4] = { cq[q].x, cq[q].y, cq[q].z, cq[q].w };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { res[8 * q + 2 * k] = (int)(short)(w4[k] & 0xffffu); res[8 * q + 2 * k + 1] = (int)w4[k] >> 16; }
+                }
+            }
+        } else if (is_idct) {
             if constexpr (LOG2N == 2) {
                 if (kind == OHEVC_TU_DST4) tu4_row<true>(cq[0], cq[1], i, bit_depth, res);
                 else                       tu4_row<false>(cq[0], cq[1], i, bit_depth, res);
             } else {
                 idct_row<LOG2N, LOG2N >= 4>(tu_lds + g * TuLayout<LOG2N>::BLK, i, cq, bit_depth, res);
             }
-        } else {                                           // (READY && is_idct went through finish_row_pairs above)
+        } else {
             tu_rows_residual<LOG2N>(rw, i, coeffs, bit_depth, kind, res);
         }
-        finish_row<NX, Pixel>(row, px, res + x0, bit_depth, valid);
+        finish_row<N, Pixel>(row, px, res, bit_depth, valid);
     } else if (valid) {
-        store_row<NX, Pixel>(row, px);
+        store_row<N, Pixel>(row, px);
     }
 }
 
@@ -539,14 +544,6 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
     for (int i = threadIdx.x; i < nlevels * 12; i += 64 * kChainWaves) slev[i] = reinterpret_cast<const int *>(levels)[i];
     __syncthreads();
-    // This kernel's own division of a level into wavefront slots: 16 / 8 / 4 blocks of 4x4 / 8x8 / 16x16 per wavefront as in the caller's
-    // first_wave[], but ONE 32x32 block per wavefront (two lanes per row, pack_finish SPLIT) - the running counts are rewritten here, once.
-    for (int l = threadIdx.x; l < nlevels; l += 64 * kChainWaves) {
-        int *rec = slev + l * 12;
-        const int f1 = (rec[5] + 15) >> 4, f2 = f1 + ((rec[6] + 7) >> 3), f3 = f2 + ((rec[7] + 3) >> 2);
-        rec[0] = 0; rec[1] = f1; rec[2] = f2; rec[3] = f3; rec[4] = f3 + rec[8];
-    }
-    __syncthreads();
 
     // what wavefront slot w does at a level: the size class of its blocks (-1: nothing), its first block, the level's arrays.  All wave-uniform.
     struct Slot { int s, job0, n, nwaves; const ohevc_intra_job *j; const ohevc_tu_job *r; };
@@ -569,7 +566,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         const int first_wave = s == 0 ? 0 : s == 1 ? fw1 : s == 2 ? fw2 : fw3;          // (first_wave[0] is 0 by construction)
         const int first_job = s == 0 ? 0 : s == 1 ? n0 : s == 2 ? n0 + n1 : n0 + n1 + n2;
         sl.s = s;
-        sl.job0 = (w - first_wave) * (s == 3 ? 1 : 16 >> s);
+        sl.job0 = (w - first_wave) * (16 >> s);
         sl.n = s == 0 ? n0 : s == 1 ? n1 : s == 2 ? n2 : n3;
         sl.j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)jobs_off16 * 16) + first_job;
         sl.r = res_off16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)res_off16 * 16) + first_job : nullptr;
@@ -583,7 +580,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     // A slot without blocks (s < 0) loads from `base` (the upload buffer: always mapped) and its values are never looked at.
     auto load_recs = [&](const Slot &sl) -> PackRecs {
         const int log2n = sl.s + 2;                                    // (s < 0: 1 - harmless)
-        const int g = sl.s == 3 ? 0 : lane >> (log2n & 7);             // (a 32x32 block has the whole wavefront)
+        const int g = lane >> (log2n & 7);
         PackRecs r;
         r.valid = sl.s >= 0 && sl.job0 + g < sl.n;
         const int ji = sl.job0 + g < sl.n ? sl.job0 + g : sl.n - 1;   // lanes behind the last job repeat it and do not store
@@ -600,9 +597,8 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         const int log2n = sl.s + 2, n = 1 << (log2n & 7), i = lane & (n - 1);
         const int kind = pack_kind(r);
         const bool is_idct = sl.s >= 0 && coeffs != nullptr && (kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4);
-        // (32x32: the lane's half of the row - two of its four pieces)
-        const int nr = log2n <= 3 ? 1 : log2n == 5 ? 2 : n >> 3;
-        const unsigned row_bytes = log2n == 2 ? (unsigned)(i >> 1) * 16u : (unsigned)i * (unsigned)n * 2u + (log2n == 5 ? (unsigned)(lane >> 5) * 32u : 0u);
+        const int nr = log2n <= 3 ? 1 : n >> 3;
+        const unsigned row_bytes = log2n == 2 ? (unsigned)(i >> 1) * 16u : (unsigned)i * (unsigned)n * 2u;
         const unsigned char *rowp = is_idct ? reinterpret_cast<const unsigned char *>(coeffs) + ((size_t)r.rw.z * 2u + row_bytes) : base;
 #pragma unroll
         for (int q = 0; q < 4; q++) cq[q] = *reinterpret_cast<const u32x4 *>(rowp + (is_idct ? 16 * (q < nr ? q : nr - 1) : 0));
@@ -618,7 +614,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         if (sl.s == 0)      pack_finish<2, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
         else if (sl.s == 1) pack_finish<3, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
         else if (sl.s == 2) pack_finish<4, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
-        else if (sl.s == 3) pack_finish<5, Pixel, true, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
+        else if (sl.s == 3) pack_finish<5, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
     };
 
     // Software pipeline over STEPS: a step is one pass of the 8-wavefront workgroup over a level - a level of up to 8 wavefront slots is one
