@@ -46,7 +46,9 @@ typedef struct ohhip_frames_mode {
     int (*release)(void *user, int index);
     /* like await_planes, but only rows 0 .. last_luma_row of the picture have to be in the store when it returns (last_luma_row < 0 or beyond the
      * picture: all of it) - the wait of hevc_await_progress (hevc.c:1951-1958) for the rows a picture's motion vectors reach, at the granularity
-     * of the transport's bands.  Calls for one picture may come with growing row numbers.  May be NULL: the hooks then use await_planes. */
+     * of the transport's bands.  Calls for one picture may come with growing row numbers.  Returns < 0 on failure, 0 when the rows asked for
+     * are in, 1 when that happened to complete the picture (the transport may forget it then: do not ask again).  May be NULL: the hooks then
+     * use await_planes. */
     int (*await_rows)(void *user, int index, ohevc_ctx *ctx, int slot, int last_luma_row);
     /* 0: a picture's owner is its decoding-order index % world and exchanged pictures cross the wire (any stream).  1: ownership per IDR SEGMENT -
      * segment number % world, a segment = an IDR picture and everything up to the next one: nothing after an IDR picture predicts from

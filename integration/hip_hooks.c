@@ -1111,9 +1111,14 @@ static int frames_await_planes(ohhip_backend *be, HEVCContext *s)
                 continue;
             if (need >= height - 1)
                 need = -1;                                   /* all of it */
-            if ((be->fm.await_rows ? be->fm.await_rows(be->fm.user, index, t_ctx, slot, need) : be->fm.await_planes(be->fm.user, index, t_ctx, slot)) != 0) {
-                fprintf(stderr, "ohhip: the planes of remote picture %d did not arrive: %s\n", index, ohevc_last_error());
-                return -1;
+            {
+                const int rc = be->fm.await_rows ? be->fm.await_rows(be->fm.user, index, t_ctx, slot, need) : be->fm.await_planes(be->fm.user, index, t_ctx, slot);
+                if (rc < 0) {
+                    fprintf(stderr, "ohhip: the planes of remote picture %d did not arrive: %s\n", index, ohevc_last_error());
+                    return -1;
+                }
+                if (rc > 0)
+                    need = -1;                                   /* the bands asked for happened to be the last ones: the picture is complete */
             }
             pthread_mutex_lock(&be->lock);
             if (be->bufs[bi].index == index) {

@@ -516,7 +516,7 @@ static int cb_await_rows(void *user, int index, ohevc_ctx *ctx, int slot, int la
     ohevc_frames_transport *t = static_cast<ohevc_frames_transport *>(user);
     Msg *m = arrived(t, index);
     if (!m) return -1;
-    if (m->planes_done) return 0;
+    if (m->planes_done) return 1;
     (void)hipSetDevice(t->device);
     const int upto = last_luma_row < 0 || last_luma_row >= m->luma_rows ? m->nb - 1 : m->band_of_luma_row(last_luma_row);
     if (upto >= m->bands_imported) t->stats.awaited_planes++;
@@ -528,11 +528,12 @@ static int cb_await_rows(void *user, int index, ohevc_ctx *ctx, int slot, int la
         }
         m->planes_done = true;
         drop_if_consumed(t, m);
+        return 1;                                              // the whole picture is in: the caller need not (and must not) ask again
     }
     return 0;
 }
 
-static int cb_await_planes(void *user, int index, ohevc_ctx *ctx, int slot) { return cb_await_rows(user, index, ctx, slot, -1); }
+static int cb_await_planes(void *user, int index, ohevc_ctx *ctx, int slot) { return cb_await_rows(user, index, ctx, slot, -1) < 0 ? -1 : 0; }
 
 static int cb_release(void *user, int index)
 {
