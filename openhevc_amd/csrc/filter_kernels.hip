@@ -634,9 +634,120 @@ __device__ __forceinline__ SaoMasks sao_rule_masks(u32x4 j0, u32x4 j1, ohevc_sao
     return SaoMasks{ u32x4{ keep[0], keep[1], keep[2], keep[3] }, u32x4{ bord[0], bord[1], bord[2], bord[3] } };
 }
 
-constexpr int kSaoWideThreads = 256, kSaoWideRows = 2;       // lanes per block of the list (band filter: half of them); rows a lane of the band filter has in flight at a time
+// An edge-class block that no position rule can touch - not at a picture border (so every neighbour of every sample exists), no restored
+// slice / tile edge, no bypass map.  Interior CTBs are most of a picture.  What the short form changes against sao_wide_kernel's general loop
+// (profiles/r5u_*; fractions of the HBM peak in tools/bench_kernels.py's measure, 8 / 10 bit):
+// * ONE wavefront (two at 16 bit) takes the block, kSaoPlainRows row pieces per lane with every load in flight before the first use, no
+//   rule flags, no clamped addresses: ~150 vector and ~330 scalar instructions per wavefront instead of 4 x (330 + 300).  By itself: nothing
+//   (0.288 -> 0.288) - the kernel is not bound by instruction issue.
+// * every load ALIGNED: the classes with a horizontal component (0, 2, 3) read their neighbours one sample to the left / right, and a
+//   16-byte load at an address that is not a multiple of 16 costs the memory pipeline more than twice an aligned one - the vertical class
+//   ran at 0.344 / 0.508, the other three at 0.272 / 0.389.  Here a lane loads the aligned 16-byte piece of the neighbour row, takes the
+//   dword before / after it from the neighbour lane (from memory at the block's own edges) and shifts (v_alignbyte_b32); class 0 needs
+//   no second row at all.
+constexpr int kSaoPlainRows = 4;
+// the value the previous / next lane holds (within a row of 16 lanes; v_mov_b32_dpp row_shr:1 / row_shl:1)
+__device__ __forceinline__ unsigned from_lane_before(unsigned v)
+{
+#ifdef OHEVC_HIPEMU
+    return __shfl_up(v, 1);
+#else
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+#endif
+}
+__device__ __forceinline__ unsigned from_lane_after(unsigned v)
+{
+#ifdef OHEVC_HIPEMU
+    return __shfl_down(v, 1);
+#else
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, false);
+#endif
+}
 template <typename Pixel>
-__global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp, int xcd_spread)
+__device__ __forceinline__ void sao_edge_plain(const ohevc_sao_job &jb, const unsigned char *sbase, unsigned char *dbase, int sstride, int dstride, int maxv)
+{
+    constexpr int PPL = 16 / (int)sizeof(Pixel), U = kSaoPlainRows, LANES = 64 * (int)sizeof(Pixel), P = (int)sizeof(Pixel);
+    const int w = jb.w, h = jb.h, eo = jb.klass;
+    const int pieces = w / PPL, lp = pieces == 1 ? 0 : pieces == 2 ? 1 : pieces == 4 ? 2 : 3, rows_per_pass = LANES >> lp;
+    const int piece = threadIdx.x & (pieces - 1), row0 = threadIdx.x >> lp;
+    const int trips = h > rows_per_pass ? h / rows_per_pass : 1;     // (h is a power of two: the caller's predicate)
+    // The two neighbours of a sample are mirror images and enter the class symmetrically: call L the one at x - 1 (x for the vertical
+    // class) and R the one at x + 1.  Row of L relative to the sample's: class 0 the same, 1 and 2 the row above, 3 the row below.
+    const int off_l = eo == 0 ? 0 : eo == 3 ? sstride : -sstride;
+    // class -> 128 + offset through v_perm_b32; class = 2 + sign(c - a) + sign(c - b), which indexes offset_val as {1, 2, 0, 3, 4}
+    // (edge_idx, hevcdsp_template.c:372-378)
+    const unsigned tab_lo = ((unsigned)(jb.offset_val[1] + 128) & 0xff) | (((unsigned)(jb.offset_val[2] + 128) & 0xff) << 8) |
+                            (((unsigned)(jb.offset_val[0] + 128) & 0xff) << 16) | (((unsigned)(jb.offset_val[3] + 128) & 0xff) << 24);
+    const unsigned tab_hi = (unsigned)(jb.offset_val[4] + 128) & 0xff;
+    const u16x2 maxv2 = { (unsigned short)maxv, (unsigned short)maxv };
+    auto edge2 = [&](unsigned c, unsigned a, unsigned b) {          // two samples in 16-bit lanes
+        const u16x2 c1 = __builtin_bit_cast(u16x2, c) + u16x2{ 1, 1 };
+        // min(max(c + 1 - n, 0), 2) = 0 / 1 / 2 for c < n / c == n / c > n: a saturating subtraction and a minimum
+        const unsigned ka = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_sub_sat(c1, __builtin_bit_cast(u16x2, a)), u16x2{ 2, 2 }));
+        const unsigned kb = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_sub_sat(c1, __builtin_bit_cast(u16x2, b)), u16x2{ 2, 2 }));
+        const unsigned offb = __builtin_amdgcn_perm(tab_hi, tab_lo, ka + kb + 0x0c000c00u);      // (no carry between the lanes: one 32-bit add3)
+        u16x2 t = __builtin_bit_cast(u16x2, c) + __builtin_bit_cast(u16x2, offb);
+        t = __builtin_elementwise_sub_sat(t, u16x2{ 128, 128 });
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_min(t, maxv2));
+    };
+    auto lo2 = [](unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c010c00u); };
+    auto hi2 = [](unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c030c02u); };
+    auto pack4 = [](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); };
+    if (row0 >= h) return;
+    auto pass = [&](auto horizontal_tag, auto second_row_tag, auto one_piece_tag) {
+        // a horizontal component; neighbours in other rows; the block is one piece wide
+        constexpr bool HOR = decltype(horizontal_tag)::value, ROWS = decltype(second_row_tag)::value, ONE = decltype(one_piece_tag)::value;
+        for (int t0 = 0; t0 < trips; t0 += U) {
+            unsigned cv[U][4], lv[U][4], rv[U][4], le[U], re[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {                            // every load of the pass before the first use; no branch among them - with
+                {                                                    // one the compiler's wait counts are the minimum over the paths, i.e. "all"
+                    const int t = t0 + u < trips ? t0 + u : trips - 1;                     // (a pass a small block does not have: reloaded, never stored)
+                    const unsigned char *pc = sbase + ((unsigned)(row0 + t * rows_per_pass) * (unsigned)sstride + (unsigned)piece * 16u);
+                    __builtin_memcpy(cv[u], pc, 16);
+                    if (ROWS) { __builtin_memcpy(lv[u], pc + off_l, 16); __builtin_memcpy(rv[u], pc - off_l, 16); }
+                    // the dword before / after the piece: the neighbour lane holds it, except at the block's own edges
+                    // (ONE load for both: the first piece's lane asks for the dword before, the last piece's for the one after; a block of a
+                    //  single piece needs both)
+                    //  single piece needs both.  Every lane loads - inside a branch the compiler waits for the load before it issues the next row's)
+                    if (HOR) __builtin_memcpy(&le[u], piece == 0 ? pc + off_l - 4 : pc - off_l + 16, 4);
+                    if (HOR && ONE) __builtin_memcpy(&re[u], pc - off_l + 16, 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (t0 + u < trips) {
+                    unsigned o[4];
+                    const unsigned *lr = ROWS ? lv[u] : cv[u], *rr = ROWS ? rv[u] : cv[u];
+                    unsigned before = 0, after = 0;
+                    if (HOR) {
+                        before = from_lane_before(lr[3]); after = from_lane_after(rr[0]);
+                        before = piece == 0 ? le[u] : before; after = piece == pieces - 1 ? (ONE ? re[u] : le[u]) : after;
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const unsigned a = HOR ? align_bytes(lr[d], d ? lr[d - 1] : before, 4 - P) : lr[d];       // the sample at x - 1 of every sample of dword d
+                        const unsigned b = HOR ? align_bytes(d < 3 ? rr[d + 1] : after, rr[d], P) : rr[d];       // ... at x + 1
+                        o[d] = sizeof(Pixel) == 2 ? edge2(cv[u][d], a, b) : pack4(edge2(lo2(cv[u][d]), lo2(a), lo2(b)), edge2(hi2(cv[u][d]), hi2(a), hi2(b)));
+                    }
+                    __builtin_memcpy(dbase + ((unsigned)(row0 + (t0 + u) * rows_per_pass) * (unsigned)dstride + (unsigned)piece * 16u), o, 16);
+                }
+        }
+    };
+    if (eo == 1)          pass(std::false_type{}, std::true_type{}, std::false_type{});
+    else if (pieces == 1) { if (eo == 0) pass(std::true_type{}, std::false_type{}, std::true_type{}); else pass(std::true_type{}, std::true_type{}, std::true_type{}); }
+    else if (eo == 0)     pass(std::true_type{}, std::false_type{}, std::false_type{});
+    else                  pass(std::true_type{}, std::true_type{}, std::false_type{});
+}
+
+constexpr int kSaoWideThreads = 256, kSaoWideRows = 2;       // lanes per block of the list (band filter: half of them); rows a lane of the band filter has in flight at a time
+#ifdef OHEVC_HIPEMU
+#define SAO_WIDE_OCCUPANCY
+#else
+#define SAO_WIDE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7)))      // <= 72 vector registers: sao_edge_plain's four rows in flight must not cost the general loop a wavefront
+#endif
+template <typename Pixel>
+__global__ __launch_bounds__(kSaoWideThreads) SAO_WIDE_OCCUPANCY void sao_wide_kernel(PlaneSet dst, PlaneSet src, const ohevc_sao_job *__restrict__ jobs, int njobs, int bit_depth, ohevc_sao_bypass bp, int xcd_spread)
 {
     constexpr int PPL = 16 / (int)sizeof(Pixel), SB = 8 * (int)sizeof(Pixel), SPD = 4 / (int)sizeof(Pixel);     // samples per lane / dword
     constexpr unsigned M = sizeof(Pixel) == 1 ? 0xffu : 0xffffu;
@@ -647,7 +758,7 @@ __global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst,
     // Renumbered, an XCD takes runs of 16 consecutive list entries (1.02x; 5-10 % faster on the edge classes, profiles/r03m_*); one contiguous
     // eighth of the list per XCD reads as little but runs slower on the band filter.  (gridDim.x is a multiple of 128 / 8.)
     const int vb = blockIdx.x >> 3;
-    const int ji = xcd_spread == 1 ? (int)blockIdx.x : xcd_spread == 2 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3)) + vb
+    const int ji = (xcd_spread & 15) == 1 ? (int)blockIdx.x : (xcd_spread & 15) == 2 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3)) + vb
                                                       : (vb >> 4) * 128 + (int)(blockIdx.x & 7) * 16 + (vb & 15);       // runs of 16 list entries per XCD
     if (ji >= njobs) return;
     const u32x4 j0 = ((cptr)(jobs + ji))[0], j1 = ((cptr)(jobs + ji))[1];
@@ -658,13 +769,21 @@ __global__ __launch_bounds__(kSaoWideThreads) void sao_wide_kernel(PlaneSet dst,
         __builtin_memcpy(&jb, words, sizeof(jb));
     }
     const int w = jb.w, h = jb.h, eo = jb.klass, maxv = (1 << bit_depth) - 1;
+    const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
+    const bool is_band = jb.type == OHEVC_SAO_BAND;
+    // sao_edge_plain's blocks (ohevc_debug_set_sao_variant(16): without that form); all but its wavefronts leave before any other work
+    const bool plain = !is_band && jb.borders == 0 && jb.restore == 0 && bp.map == nullptr && !(xcd_spread & 16) && (h & (h - 1)) == 0 &&
+                       jb.x > 0 && jb.y > 0 && jb.x + w < pw && jb.y + h < ph;
+    if (plain && (int)threadIdx.x >= 64 * (int)sizeof(Pixel)) return;
     const int sstride = PLANE_STRIDE3(src, jb.plane), dstride = PLANE_STRIDE3(dst, jb.plane);
     const unsigned char *splane = PLANE_PTR3(src, jb.plane);
     const unsigned char *sbase = splane + (size_t)jb.y * sstride + (size_t)jb.x * sizeof(Pixel);
     unsigned char *dbase = PLANE_PTR3(dst, jb.plane) + (size_t)jb.y * dstride + (size_t)jb.x * sizeof(Pixel);
-    const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
     if (!sao_wide_ok<Pixel>(jb, sbase, dbase, sstride, dstride, pw, bit_depth)) return;
-    const bool is_band = jb.type == OHEVC_SAO_BAND;
+    if (plain) {
+        sao_edge_plain<Pixel>(jb, sbase, dbase, sstride, dstride, maxv);
+        return;
+    }
     // The edge classes take all 256 lanes of the workgroup - a 64x64 block of 8-bit samples is then ONE row per lane, every load of the block
     // in flight at once (r4z2: +7-8 % at both depths over 128 lanes; the kernel waits for memory more than it computes since the arithmetic
     // went to packed 16-bit, profiles/r4y_sq_counters_sao_wide.txt).  The band filter keeps 128 lanes with two rows each in flight (-12 % at
@@ -1070,8 +1189,9 @@ static int sao_launch(const ohevc_plane dst[3], const ohevc_plane src[3], const 
     if (!(g_sao_variant & 2) && nw > 0) {
         // ohevc_debug_set_sao_variant(4): list order; (8): one contiguous eighth of the list per XCD; default: runs of 16 list entries per XCD
         const int spread = (g_sao_variant & 4) ? 1 : (g_sao_variant & 8) ? 2 : 0, gw = spread == 1 ? nw : spread == 2 ? (nw + 7) & ~7 : (nw + 127) & ~127;
-        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(gw), dim3(kSaoWideThreads), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
-        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(gw), dim3(kSaoWideThreads), 0, st, pd, psrc, jobs, nw, bit_depth, bp, spread);
+        const int sp = spread | (g_sao_variant & 16);       // (16): interior edge-class blocks through the general loop too (the A/B of sao_edge_plain)
+        if (bit_depth == 8) hipLaunchKernelGGL((sao_wide_kernel<uint8_t>), dim3(gw), dim3(kSaoWideThreads), 0, st, pd, psrc, jobs, nw, bit_depth, bp, sp);
+        else                hipLaunchKernelGGL((sao_wide_kernel<uint16_t>), dim3(gw), dim3(kSaoWideThreads), 0, st, pd, psrc, jobs, nw, bit_depth, bp, sp);
     }
     if (n_wide >= 0 && !(g_sao_variant & 2)) { jobs += n_wide; njobs -= n_wide; }
     if (njobs <= 0) { OHEVC_HIP_TRY(hipGetLastError()); return OHEVC_OK; }

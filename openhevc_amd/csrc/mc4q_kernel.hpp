@@ -27,8 +27,11 @@ __device__ __forceinline__ Mc4qRef mc4q_ref(const ohevc_plane *refs, int ref, in
     return Mc4qRef{ pr[0], pr[1], pr[2] };
 }
 // 8 samples of window row r of the lane's block, columns 8 * half ..
-template <typename Pixel>
-__device__ __forceinline__ void mc4q_issue(const Mc4qRef &rec, int wx0, int wy0, int wh, int r, int half, unsigned (&out)[sizeof(Pixel) == 2 ? 4 : 2])
+// ALIGNED (8-bit samples): the window starts wherever the motion vector says, and a vector load at an address that is not a multiple of 4
+// goes through the memory pipeline more than once (measured on the SAO kernel's neighbour loads).  The lane then loads the three
+// aligned dwords that hold its 8 samples and returns the byte offset; mc4q_finish shifts (v_alignbyte_b32).
+template <typename Pixel, bool ALIGNED>
+__device__ __forceinline__ unsigned mc4q_issue(const Mc4qRef &rec, int wx0, int wy0, int wh, int r, int half, unsigned (&out)[sizeof(Pixel) == 2 ? 4 : 3])
 {
     mc4_gptr base = (mc4_gptr)rec.w0;
     const unsigned stride = (unsigned)rec.w1;
@@ -38,19 +41,26 @@ __device__ __forceinline__ void mc4q_issue(const Mc4qRef &rec, int wx0, int wy0,
     int y = wy0 + wr;
     y = y < 0 ? 0 : y > ymax ? ymax : y;
     const unsigned rowoff = __umul24((unsigned)y, stride);
+    if (ALIGNED && sizeof(Pixel) == 1 && col0 >= 4 && col0 + 11 <= xmax) {
+        const unsigned long a = (unsigned long)(base + (rowoff + (unsigned)col0));
+        __builtin_memcpy(out, (const void *)(mc4_gptr)(a & ~3ul), 12);
+        return (unsigned)a & 3u;
+    }
     if (col0 >= 0 && col0 + 7 <= xmax) {
-        __builtin_memcpy(out, (const void *)(base + (rowoff + (unsigned)col0 * (unsigned)sizeof(Pixel))), sizeof(out));
+        __builtin_memcpy(out, (const void *)(base + (rowoff + (unsigned)col0 * (unsigned)sizeof(Pixel))), sizeof(Pixel) == 2 ? 16 : 8);
     } else {
         const u32x4 e = mc4_gather_edge<Pixel>(base + rowoff, col0, xmax);
         out[0] = e.x; out[1] = e.y;
-        if (sizeof(Pixel) == 2) { out[sizeof(Pixel) == 2 ? 2 : 0] = e.z; out[sizeof(Pixel) == 2 ? 3 : 1] = e.w; }
+        if (sizeof(Pixel) == 2) { out[2] = e.z; out[3] = e.w; }
     }
+    if (sizeof(Pixel) == 1) out[2] = 0;
+    return 0;
 }
 
 // one reference of a quad: raw[pair] = the lane's 8 samples (memory-side lane map) -> v[k] = the 14-bit intermediate of the lane's block at
 // (x = 4 (g & 1) + k, y = lane & 7), g = lane >> 4.  b1[pair] / b2[pair]: the lane's constant operands (see the kernel).
 template <typename Pixel>
-__device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixel) == 2 ? 4 : 2], const u32x2 (&b1)[2], const unsigned (&b2)[2], int bit_depth, int lane,
+__device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixel) == 2 ? 4 : 3], const unsigned (&shift)[2], const u32x2 (&b1)[2], const unsigned (&b2)[2], int bit_depth, int lane,
                                             unsigned (&seen)[2], int *v)
 {
     constexpr bool WIDE = sizeof(Pixel) == 2;
@@ -62,7 +72,8 @@ __device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixe
     for (int pair = 0; pair < 2; pair++) {
         unsigned w[WIDE ? 4 : 2];
 #pragma unroll
-        for (int k = 0; k < (WIDE ? 4 : 2); k++) w[k] = (unsigned)__shfl((int)raw[pair][k], src);
+        for (int k = 0; k < (WIDE ? 4 : 2); k++)
+            w[k] = (unsigned)__shfl((int)(WIDE ? raw[pair][k] : __builtin_amdgcn_alignbyte(raw[pair][k + 1], raw[pair][k], shift[pair])), src);
         const long bop1 = mc4_op(b1[pair].x, b1[pair].y);
         mc4_v4i d;
         int hv[4];
@@ -99,7 +110,7 @@ __device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixe
 #else
 #define MC4Q_OCCUPANCY(units) __attribute__((amdgpu_waves_per_eu((units) == 1 ? 8 : 4, 8)))     // one quad per wavefront: 8 wavefronts per SIMD (<= 64 VGPRs)
 #endif
-template <typename Pixel, int UNITS>
+template <typename Pixel, int UNITS, bool ALIGNED>
 __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, int n_ref_slots, const ohevc_mc_job *__restrict__ jobs,
                                                    int njobs, int bit_depth, unsigned *__restrict__ wild_mask)
 {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
     auto field = [&](int block_bytes, int k) -> unsigned { return (unsigned)__builtin_amdgcn_ds_bpermute(block_bytes + 4 * k, (int)jw); };      // dword k of block
     // ---- memory side: lane (r = lane >> 2, g = lane & 3) loads 8 samples of window row r, columns 8 (g & 1) .., of block g >> 1 of each pair
     // (two dependent rounds - job records, samples - each issued for every pair and reference before the first use)
-    unsigned raw[2][2][WIDE ? 4 : 2] = {};
+    unsigned raw[2][2][WIDE ? 4 : 3] = {}, shift[2][2] = {};
     // any job of the quad bi-predicted (wave-uniform): dword 1 of the four records
     const bool any_bi = __ballot(lane < 32 && (lane & 7) == 1 && ((jw >> 24) & OHEVC_MC_BI) != 0) != 0;
     {
@@ -175,8 +186,8 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
 #pragma unroll
         for (int pair = 0; pair < 2; pair++) {
             const int before = plane_m[pair] == 0 ? 3 : 1, taps = plane_m[pair] == 0 ? 8 : 4;
-            mc4q_issue<Pixel>(rec[0][pair], sx0[pair] - before, sy0[pair] - before, h_m[pair] + taps - 1, r, half, raw[0][pair]);
-            if (any_bi) mc4q_issue<Pixel>(rec[1][pair], sx1[pair] - before, sy1[pair] - before, h_m[pair] + taps - 1, r, half, raw[1][pair]);
+            shift[0][pair] = mc4q_issue<Pixel, ALIGNED>(rec[0][pair], sx0[pair] - before, sy0[pair] - before, h_m[pair] + taps - 1, r, half, raw[0][pair]);
+            if (any_bi) shift[1][pair] = mc4q_issue<Pixel, ALIGNED>(rec[1][pair], sx1[pair] - before, sy1[pair] - before, h_m[pair] + taps - 1, r, half, raw[1][pair]);
         }
     }
     // ---- operand side: lane (n = lane & 15, g = lane >> 4)
@@ -204,8 +215,8 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
         }
         unsigned seen0[2] = { 0, 0 }, seen1[2] = { 0, 0 };
         int v0[4], v1[4] = { 0, 0, 0, 0 };
-        mc4q_finish<Pixel>(raw[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
-        if (any_bi) mc4q_finish<Pixel>(raw[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
+        mc4q_finish<Pixel>(raw[0], shift[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
+        if (any_bi) mc4q_finish<Pixel>(raw[1], shift[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
         // ---- result side: lane (y = lane & 15, g): four samples x = 4 (g & 1) .. + 3 of row y & 7 of block  a: y < 8, g < 2   d: y < 8, g >= 2   c: y >= 8, g < 2   b: y >= 8, g >= 2
         const int blk = lowcol ? (lowgrp ? 0 : 3) : (lowgrp ? 2 : 1);
         const unsigned m0 = field(32 * blk, 0), m1 = field(32 * blk, 1), m5 = field(32 * blk, 5), m6 = field(32 * blk, 6), m7 = field(32 * blk, 7);

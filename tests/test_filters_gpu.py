@@ -120,6 +120,52 @@ def test_sao_band_and_edge(oracle, sao_variant, bd):
         assert bad.size == 0, f"bd={bd} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
 
 
+@pytest.mark.parametrize("variant", [0, 16], ids=["shipped", "general_loop"])
+@pytest.mark.parametrize("ctb", [64, 32, 16])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_sao_edge_interior_blocks(oracle, bd, ctb, variant):
+    """Interior CTBs of a picture - edge classes, no picture border, no restored edge - take the wide kernel's short form (sao_edge_plain:
+    aligned loads only, neighbours shifted in registers); every CTB has its own class and offsets, the picture's outer ring has the borders
+    the decoder gives it.  Both forms must match sao_edge_filter (hevcdsp_template.c:372-567)."""
+    lib = L.load_library()
+    prev = lib.ohevc_debug_set_sao_variant(variant)
+    try:
+        rng = np.random.default_rng(4200 + bd + ctb)
+        H, W = ctb * 5 + 8, ctb * 7 + 32                    # ragged last row / column
+        shapes = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+        src = [np.ascontiguousarray(rng.integers(0, 1 << bd, size=sh).astype(G.pixdt(bd))) for sh in shapes]
+        src[1] = (src[1] >> (bd - 3) << (bd - 3)).astype(src[1].dtype)      # coarse plane: many equal neighbours
+        dst = [np.zeros_like(p) for p in src]
+        jobs = []
+        for pl in range(3):
+            h, w = shapes[pl]
+            c = ctb if pl == 0 else ctb // 2
+            for y in range(0, h, c):
+                for x in range(0, w, c):
+                    j = np.zeros(1, L.SAO_JOB)[0]
+                    j["x"], j["y"], j["w"], j["h"], j["plane"] = x, y, min(c, w - x), min(c, h - y), pl
+                    j["type"], j["klass"] = L.SAO_EDGE, int(rng.integers(0, 4))
+                    j["borders"] = (x == 0) * 1 + (y == 0) * 2 + (x + c >= w) * 4 + (y + c >= h) * 8
+                    j["offset_val"] = [0] + [int(v) for v in rng.integers(-7, 8, size=4) << (bd - 8)]
+                    jobs.append(j)
+        batch = np.array(jobs, dtype=L.SAO_JOB)
+        want = [p.copy() for p in dst]
+        for j in batch:
+            pl, b = int(j["plane"]), int(j["borders"])
+            oracle.sao_edge(bd, 0, want[pl], src[pl], int(j["x"]), int(j["y"]), int(j["w"]), int(j["h"]), [int(v) for v in j["offset_val"]], int(j["klass"]),
+                            [b & 1, (b >> 1) & 1, (b >> 2) & 1, (b >> 3) & 1])
+        d_src = [G.to_dev(p) for p in src]; d_dst = [G.to_dev(p) for p in dst]
+        d_jobs = G.to_dev(batch)
+        L.dev_sao_batch(G.planes3(d_dst), G.planes3(d_src), bd, d_jobs.data_ptr(), len(batch), G.stream())
+        G.sync()
+        for pl in range(3):
+            got = G.to_host(d_dst[pl], dst[pl].dtype)
+            bad = np.argwhere(got != want[pl])
+            assert bad.size == 0, f"bd={bd} ctb={ctb} plane={pl}: {len(bad)} mismatches, first {bad[:3].tolist()}"
+    finally:
+        lib.ohevc_debug_set_sao_variant(prev)
+
+
 @pytest.mark.parametrize("exact", [1, 0])
 @pytest.mark.parametrize("bd,cfi,log2_pu", [(8, 1, 2), (10, 2, 3), (8, 3, 2), (10, 1, 2)])
 def test_sao_bypass_map(oracle, sao_variant, bd, cfi, log2_pu, exact):

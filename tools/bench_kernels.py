@@ -28,6 +28,7 @@ PLANES = 1
 ONLY = None
 SAO_VARIANT = None
 MC_CONFIG = None
+SAO_CLASS = 2              # --sao-class K: 0 horizontal, 1 vertical, 2 / 3 the diagonals (edge); the band position (band)
 MC_VARIANT = None           # --mc-variant V: 3 = LDS tiles (mc3), 4 = matrix cores (mc4); tags the rows
 RESIDENT = "--resident" in sys.argv
 RING_BYTES = 2 << 30
@@ -36,6 +37,8 @@ for i, a in enumerate(sys.argv):
         PLANES = int(sys.argv[i + 1])
     if a == "--only":
         ONLY = sys.argv[i + 1]
+    if a == "--sao-class":
+        SAO_CLASS = int(sys.argv[i + 1])
     if a == "--sao-variant":
         SAO_VARIANT = int(sys.argv[i + 1])
     if a == "--mc-variant":
@@ -216,7 +219,7 @@ def main():
             j = np.zeros(n, L.SAO_JOB)
             j["x"], j["y"] = xs.ravel(), ys.ravel()
             j["w"], j["h"] = np.minimum(64, W - j["x"]), np.minimum(64, H - j["y"])
-            j["type"], j["klass"] = typ, 2
+            j["type"], j["klass"] = typ, SAO_CLASS
             j["borders"] = (j["x"] == 0) * 1 + (j["y"] == 0) * 2 + (j["x"] + j["w"] == W) * 4 + (j["y"] + j["h"] == H) * 8
             j["offset_val"] = [0, 3, 1, -1, -3]
             d_jobs = dev(j)
@@ -225,7 +228,7 @@ def main():
                       (lambda pic, ex: L.dev_sao_batch(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, st()))
             ms = timeit(run_sao, lambda: rand_pic(bd, g),
                         name="sao", ring_of=RingExtra(lambda k: rand_pic(bd, g), pic_bytes(src)))
-            report(f"sao {name} luma, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
+            report(f"sao {name} class {SAO_CLASS} luma, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         # ---- intra: independent blocks on a sparse grid (every other block position), all 35 modes
         for log2 in (2, 3, 4, 5):
             nn = 1 << log2
