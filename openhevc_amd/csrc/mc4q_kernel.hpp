@@ -27,10 +27,10 @@ __device__ __forceinline__ Mc4qRef mc4q_ref(const ohevc_plane *refs, int ref, in
     return Mc4qRef{ pr[0], pr[1], pr[2] };
 }
 // 8 samples of window row r of the lane's block, columns 8 * half ..
-// ALIGNED (8-bit samples): the window starts wherever the motion vector says, and a vector load at an address that is not a multiple of 4
-// goes through the memory pipeline more than once (measured on the SAO kernel's neighbour loads).  The lane then loads the three
-// aligned dwords that hold its 8 samples and returns the byte offset; mc4q_finish shifts (v_alignbyte_b32).
-template <typename Pixel, bool ALIGNED>
+// 8-bit samples: the window starts wherever the motion vector says; the lane loads the three ALIGNED dwords that hold its 8 samples and
+// returns the byte offset, mc4q_finish shifts (v_alignbyte_b32): 1.5-2 % on the 8x8 rows (profiles/r5v_*).  The same for 16-bit samples
+// (dwordx4 + dword at a multiple of 4 instead of one dwordx4 at a multiple of 2) ran 3 % slower and needs a 65th register: not done.
+template <typename Pixel>
 __device__ __forceinline__ unsigned mc4q_issue(const Mc4qRef &rec, int wx0, int wy0, int wh, int r, int half, unsigned (&out)[sizeof(Pixel) == 2 ? 4 : 3])
 {
     mc4_gptr base = (mc4_gptr)rec.w0;
@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned mc4q_issue(const Mc4qRef &rec, int wx0, int 
     int y = wy0 + wr;
     y = y < 0 ? 0 : y > ymax ? ymax : y;
     const unsigned rowoff = __umul24((unsigned)y, stride);
-    if (ALIGNED && sizeof(Pixel) == 1 && col0 >= 4 && col0 + 11 <= xmax) {
+    if (sizeof(Pixel) == 1 && col0 >= 4 && col0 + 11 <= xmax) {
         const unsigned long a = (unsigned long)(base + (rowoff + (unsigned)col0));
         __builtin_memcpy(out, (const void *)(mc4_gptr)(a & ~3ul), 12);
         return (unsigned)a & 3u;
@@ -110,7 +110,10 @@ __device__ __forceinline__ void mc4q_finish(const unsigned (&raw)[2][sizeof(Pixe
 #else
 #define MC4Q_OCCUPANCY(units) __attribute__((amdgpu_waves_per_eu((units) == 1 ? 8 : 4, 8)))     // one quad per wavefront: 8 wavefronts per SIMD (<= 64 VGPRs)
 #endif
-template <typename Pixel, int UNITS, bool ALIGNED>
+// TWIN (lab build, ohevc_debug_set_mc_variant(102 / 103)): 1 = the kernel's memory traffic without its arithmetic - records, samples and the
+// store of SOMETHING derived from the lane's own samples; 2 = its arithmetic without the sample loads (made-up samples; records and store
+// as usual).  The two bracket the kernel: what it would cost if either part were free.
+template <typename Pixel, int UNITS, int TWIN>
 __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSet dst, const ohevc_plane *__restrict__ refs, int n_ref_slots, const ohevc_mc_job *__restrict__ jobs,
                                                    int njobs, int bit_depth, unsigned *__restrict__ wild_mask)
 {
@@ -186,8 +189,12 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
 #pragma unroll
         for (int pair = 0; pair < 2; pair++) {
             const int before = plane_m[pair] == 0 ? 3 : 1, taps = plane_m[pair] == 0 ? 8 : 4;
-            shift[0][pair] = mc4q_issue<Pixel, ALIGNED>(rec[0][pair], sx0[pair] - before, sy0[pair] - before, h_m[pair] + taps - 1, r, half, raw[0][pair]);
-            if (any_bi) shift[1][pair] = mc4q_issue<Pixel, ALIGNED>(rec[1][pair], sx1[pair] - before, sy1[pair] - before, h_m[pair] + taps - 1, r, half, raw[1][pair]);
+            if (TWIN == 2) {                                                                     // no sample loads: something the compiler cannot fold
+                for (int k = 0; k < (WIDE ? 4 : 3); k++) { raw[0][pair][k] = (jw * 0x9e3779b1u + (unsigned)(lane * 16 + k)) & (WIDE ? 0x03ff03ffu : ~0u); raw[1][pair][k] = raw[0][pair][k] ^ 0x00550055u; }
+                continue;
+            }
+            shift[0][pair] = mc4q_issue<Pixel>(rec[0][pair], sx0[pair] - before, sy0[pair] - before, h_m[pair] + taps - 1, r, half, raw[0][pair]);
+            if (any_bi) shift[1][pair] = mc4q_issue<Pixel>(rec[1][pair], sx1[pair] - before, sy1[pair] - before, h_m[pair] + taps - 1, r, half, raw[1][pair]);
         }
     }
     // ---- operand side: lane (n = lane & 15, g = lane >> 4)
@@ -215,8 +222,12 @@ __global__ __launch_bounds__(256) MC4Q_OCCUPANCY(UNITS) void mc4q_kernel(PlaneSe
         }
         unsigned seen0[2] = { 0, 0 }, seen1[2] = { 0, 0 };
         int v0[4], v1[4] = { 0, 0, 0, 0 };
-        mc4q_finish<Pixel>(raw[0], shift[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
-        if (any_bi) mc4q_finish<Pixel>(raw[1], shift[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
+        if (TWIN == 1) {                                                                         // no arithmetic: the lane's own samples go out
+            for (int k = 0; k < 4; k++) { v0[k] = (int)((raw[0][0][k & 1] ^ raw[0][1][k & 1] ^ shift[0][0]) & 0xff) << 6; v1[k] = any_bi ? (int)((raw[1][0][k & 1] ^ raw[1][1][k & 1]) & 0xff) << 6 : 0; }
+        } else {
+            mc4q_finish<Pixel>(raw[0], shift[0], b1[0], b2[0], bit_depth, lane, seen0, v0);
+            if (any_bi) mc4q_finish<Pixel>(raw[1], shift[1], b1[1], b2[1], bit_depth, lane, seen1, v1);
+        }
         // ---- result side: lane (y = lane & 15, g): four samples x = 4 (g & 1) .. + 3 of row y & 7 of block  a: y < 8, g < 2   d: y < 8, g >= 2   c: y >= 8, g < 2   b: y >= 8, g >= 2
         const int blk = lowcol ? (lowgrp ? 0 : 3) : (lowgrp ? 2 : 1);
         const unsigned m0 = field(32 * blk, 0), m1 = field(32 * blk, 1), m5 = field(32 * blk, 5), m6 = field(32 * blk, 6), m7 = field(32 * blk, 7);

@@ -596,7 +596,9 @@ __global__ __launch_bounds__(64) void mc3_redo_kernel(PlaneSet dst, const ohevc_
 // 1 = first (scalar) kernel, 2 = packed-pair kernel, 3 = LDS tiles (mc3), 4 (shipped) = matrix cores (mc4) for tiles and mc3's four-jobs-per-
 // wavefront form for the small-block batch (it wins there: profiles/r02zi), 5 = mc4 for both.  (env: A/B of whole-decoder runs)
 int g_mc_variant = 6;
-int g_mc_aligned = 1;       // OHEVC_MC_ALIGNED=0 (lab sessions): the window loads of mc4q_kernel at the window's own address
+#ifdef OHEVC_LAB
+int g_mc_twin = 0;          // ohevc_debug_set_mc_variant(102 / 103 / 104): mc4q_kernel's traffic-only / arithmetic-only twin / the kernel itself
+#endif
 
 #include "mc4_kernel.hpp"
 #include "mc4q_kernel.hpp"
@@ -671,9 +673,15 @@ static int mc_launch(const ohevc_plane dst[3], const ohevc_plane *refs, int n_re
         const int grid = (((njobs + 3) / 4 + 3) / 4 + 7) & ~7;          // quads of jobs, 4 wavefronts per workgroup, XCD-contiguous ranges
         unsigned *wild32 = reinterpret_cast<unsigned *>(wild);
         if (bit_depth > 8) OHEVC_HIP_TRY(hipMemsetAsync(wild32, 0, (size_t)njobs * sizeof(unsigned), st));
-        if (bit_depth == 8 && g_mc_aligned) hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1, true>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
-        else if (bit_depth == 8)            hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1, false>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
-        else                                hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1, false>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+#ifdef OHEVC_LAB
+        if (g_mc_twin == 1 && bit_depth == 8)      hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1, 1>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+        else if (g_mc_twin == 1)                   hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1, 1>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+        else if (g_mc_twin == 2 && bit_depth == 8) hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1, 2>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+        else if (g_mc_twin == 2)                   hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1, 2>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+        else
+#endif
+        if (bit_depth == 8) hipLaunchKernelGGL((mc4q_kernel<uint8_t, 1, 0>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
+        else                hipLaunchKernelGGL((mc4q_kernel<uint16_t, 1, 0>), dim3(grid), dim3(256), 0, st, ps, refs, n_ref_slots, jobs, njobs, bit_depth, wild32);
         if (bit_depth > 8) hipLaunchKernelGGL((mc3_redo_kernel<unsigned>), dim3(redo_grid), dim3(64), 0, st, ps, refs, jobs, njobs, bit_depth, wild32, 16);
     } else if (v4) {                          // the matrix-core form: work unit = one 16x16 tile, 4 units per wavefront, 4 wavefronts per workgroup
         const bool multi = max_w > 16 || max_h > 16;
@@ -740,6 +748,8 @@ extern "C" int ohevc_debug_set_mc_variant(int variant)
 {
     int old = ohevc::g_mc_variant;
     if (variant >= 1 && variant <= 6) ohevc::g_mc_variant = variant;
-    if (variant == 100 || variant == 101) ohevc::g_mc_aligned = variant - 100;       // the A/B of mc4q_kernel's aligned window loads
+#ifdef OHEVC_LAB
+    if (variant >= 102 && variant <= 104) ohevc::g_mc_twin = variant == 104 ? 0 : variant - 101;
+#endif
     return old;
 }

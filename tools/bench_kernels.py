@@ -28,6 +28,7 @@ PLANES = 1
 ONLY = None
 SAO_VARIANT = None
 MC_CONFIG = None
+SAO_WIDTH = 64             # --sao-width W: blocks of W x 64 samples (what a workgroup spanning two CTBs would see: 128)
 SAO_CLASS = 2              # --sao-class K: 0 horizontal, 1 vertical, 2 / 3 the diagonals (edge); the band position (band)
 MC_VARIANT = None           # --mc-variant V: 3 = LDS tiles (mc3), 4 = matrix cores (mc4); tags the rows
 RESIDENT = "--resident" in sys.argv
@@ -39,6 +40,8 @@ for i, a in enumerate(sys.argv):
         ONLY = sys.argv[i + 1]
     if a == "--sao-class":
         SAO_CLASS = int(sys.argv[i + 1])
+    if a == "--sao-width":
+        SAO_WIDTH = int(sys.argv[i + 1])
     if a == "--sao-variant":
         SAO_VARIANT = int(sys.argv[i + 1])
     if a == "--mc-variant":
@@ -214,11 +217,11 @@ def main():
         # ---- SAO: one job per 64x64 luma CTB, edge class 2 / band
         src = rand_pic(bd, g)
         for (typ, name) in [(L.SAO_EDGE, "edge (135 deg)"), (L.SAO_BAND, "band")]:
-            xs, ys = np.meshgrid(np.arange(0, W, 64), np.arange(0, H, 64))
+            xs, ys = np.meshgrid(np.arange(0, W, SAO_WIDTH), np.arange(0, H, 64))
             n = xs.size
             j = np.zeros(n, L.SAO_JOB)
             j["x"], j["y"] = xs.ravel(), ys.ravel()
-            j["w"], j["h"] = np.minimum(64, W - j["x"]), np.minimum(64, H - j["y"])
+            j["w"], j["h"] = np.minimum(SAO_WIDTH, W - j["x"]), np.minimum(64, H - j["y"])
             j["type"], j["klass"] = typ, SAO_CLASS
             j["borders"] = (j["x"] == 0) * 1 + (j["y"] == 0) * 2 + (j["x"] + j["w"] == W) * 4 + (j["y"] + j["h"] == H) * 8
             j["offset_val"] = [0, 3, 1, -1, -3]
@@ -228,7 +231,7 @@ def main():
                       (lambda pic, ex: L.dev_sao_batch(L.planes_of(pic), L.planes_of(ex if ex else src), bd, d_jobs.data_ptr(), n, st()))
             ms = timeit(run_sao, lambda: rand_pic(bd, g),
                         name="sao", ring_of=RingExtra(lambda k: rand_pic(bd, g), pic_bytes(src)))
-            report(f"sao {name} class {SAO_CLASS} luma, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
+            report(f"sao {name} class {SAO_CLASS} width {SAO_WIDTH} luma, full 4K picture, {bd}-bit", ms, W * H, 2 * P * W * H, out)
         # ---- intra: independent blocks on a sparse grid (every other block position), all 35 modes
         for log2 in (2, 3, 4, 5):
             nn = 1 << log2
