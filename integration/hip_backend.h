@@ -37,7 +37,8 @@ typedef struct ohhip_backend ohhip_backend;
 typedef struct ohhip_options {
     int device;              /* HIP device ordinal of this decoder                                     (default: OHHIP_DEVICE or 0) */
     int bulk_filters;        /* 1: the in-loop filter drivers in bulk at the frame end, 0: per-edge calls (default 1; OHHIP_BULK_FILTERS) */
-    int defer_download;      /* 1: a picture is copied back when the application fetches it            (default 0; OHHIP_DEFER_DOWNLOAD) */
+    int defer_download;      /* 1: a picture is copied back when the application fetches it (ohhip_backend_fetch_output), 0: in the frame-end hook
+                              *                                                                          (default 1; OHHIP_DEFER_DOWNLOAD) */
     int pin_frames;          /* 1: page-lock the decoder's frame buffers                               (default 1; OHHIP_PIN_FRAMES) */
     int async_issue;         /* 1: frame ends issued by the library's issuer threads                   (default 0; OHHIP_ASYNC_ISSUE) */
     int record_only;         /* 1: no device, no pixels: host-side profiling / software-executor tests (default 0; OHHIP_RECORD_ONLY) */

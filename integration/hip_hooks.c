@@ -813,7 +813,11 @@ void ohhip_options_default(ohhip_options *o)
     memset(o, 0, sizeof(*o));
     o->device = env_int("OHHIP_DEVICE", 0);
     o->bulk_filters = env_int("OHHIP_BULK_FILTERS", 1) != 0;
-    o->defer_download = env_str("OHHIP_DEFER_DOWNLOAD") != NULL;
+    /* 1 since round 5: ending a frame only ISSUES its device work, the copy-back waits until the application takes the picture
+     * (ohhip_backend_fetch_output, part of the recipe in INTEGRATION.md 2) - the decoding thread goes on parsing instead of waiting for the
+     * device: +18-24 % on an all-intra stream at 16 frame threads, +3-12 % on an encoder-like one (profiles/r5z_intra16_switches.txt).
+     * An application that cannot make that call sets 0. */
+    o->defer_download = env_int("OHHIP_DEFER_DOWNLOAD", 1) != 0;
     o->pin_frames = env_int("OHHIP_PIN_FRAMES", 1) != 0;
     o->async_issue = env_int("OHHIP_ASYNC_ISSUE", 0);
     o->record_only = env_str("OHHIP_RECORD_ONLY") != NULL;

@@ -120,6 +120,19 @@ def test_emu_golden_stream_levels_in_reverse_order(name, monkeypatch):
         product.ohevc_debug_set_reverse_levels(0)
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name", ["ldb_10b", "intra_8b"])
+def test_emu_golden_stream_copy_back_in_the_frame_end_hook(name, threads, monkeypatch):
+    """OHHIP_DEFER_DOWNLOAD=0 (the default until round 5): the frame-end hook copies the picture back itself."""
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_DEFER_DOWNLOAD", "0")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hipemu", aus, threads, 1)) == md5
+
+
 @pytest.mark.parametrize("name", ["ra_10b_odd", "ldb_10b", "pcm", "intra_8b"])
 def test_emu_golden_stream_pipelined_output(name, monkeypatch):
     """One decoding thread, the frame-end hook only issues the device work (OHHIP_DEFER_DOWNLOAD) and the application takes every picture

@@ -46,6 +46,16 @@ def test_golden_stream_filters_derived_on_the_host(name, monkeypatch):
     assert frames_md5(ps.decode_stream("hip", aus)) == md5
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name", ["ra_8b_ctb64", "ldb_10b", "intra_8b", "fmt444_8b"])
+def test_golden_stream_copy_back_in_the_frame_end_hook(name, threads, monkeypatch):
+    """OHHIP_DEFER_DOWNLOAD=0 (ohhip_options.defer_download = 0; the default until round 5): the frame-end hook waits for the device and copies
+    the picture back itself - for applications that cannot call ohhip_backend_fetch_output."""
+    monkeypatch.setenv("OHHIP_DEFER_DOWNLOAD", "0")
+    aus, md5 = load_golden(name)
+    assert frames_md5(ps.decode_stream("hip", aus, threads, 1)) == md5
+
+
 @pytest.mark.parametrize("name", ["ra_8b_ctb64", "ra_10b_odd", "ldb_10b", "pcm", "intra_8b", "weighted"])
 def test_golden_stream_pipelined_output(name, monkeypatch):
     """One decoding thread, deferred copy-back, the application takes every picture one call late: the device works on picture k while the

@@ -38,7 +38,7 @@ print("mismatches", bad, "; seconds", round(time.time() - t0, 1))
 PY
 )
 # the switches that move work to other threads: asynchronous frame ends (the library's issuer threads), deferred copy-back, both
-for env in "OHHIP_ASYNC_ISSUE=1" "OHHIP_DEFER_DOWNLOAD=1" "OHHIP_ASYNC_ISSUE=1 OHHIP_DEFER_DOWNLOAD=1"; do
+for env in "OHHIP_ASYNC_ISSUE=1" "OHHIP_DEFER_DOWNLOAD=0" "OHHIP_ASYNC_ISSUE=1 OHHIP_DEFER_DOWNLOAD=0"; do
 (cd tests && env $env LD_PRELOAD=$RT python - "$env" <<'PY' 2>&1 | grep -v "^\[hevc\|makecontext\|IRAP"
 import sys
 sys.path.insert(0, "..")
