@@ -772,8 +772,10 @@ __global__ __launch_bounds__(kSaoWideThreads) SAO_WIDE_OCCUPANCY void sao_wide_k
     const int pw = PLANE_WIDTH3(src, jb.plane), ph = PLANE_HEIGHT3(src, jb.plane);
     const bool is_band = jb.type == OHEVC_SAO_BAND;
     // sao_edge_plain's blocks (ohevc_debug_set_sao_variant(16): without that form); all but its wavefronts leave before any other work
+    // (the diagonal classes of 8-bit samples stay with the general loop: the short form is no faster there - the halo of a 64-byte row piece -
+    //  and on some boxes 10 % slower)
     const bool plain = !is_band && jb.borders == 0 && jb.restore == 0 && bp.map == nullptr && !(xcd_spread & 16) && (h & (h - 1)) == 0 &&
-                       jb.x > 0 && jb.y > 0 && jb.x + w < pw && jb.y + h < ph;
+                       jb.x > 0 && jb.y > 0 && jb.x + w < pw && jb.y + h < ph && (sizeof(Pixel) == 2 || eo < 2);
     if (plain && (int)threadIdx.x >= 64 * (int)sizeof(Pixel)) return;
     const int sstride = PLANE_STRIDE3(src, jb.plane), dstride = PLANE_STRIDE3(dst, jb.plane);
     const unsigned char *splane = PLANE_PTR3(src, jb.plane);
