@@ -25,13 +25,14 @@ def decode(threads, natural):
         kw.update(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
                                           split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
     aus, _ = ps.generate(ps.StreamParams(**kw))
-    ps.decode_stream("hip", aus[:9], threads, 1)                     # warm-up: library load, allocations
+    kind = os.environ.get("DIAG_KIND", "hip")                        # "hipemu" with OHHIP_RECORD_ONLY=1: the hooks' recording alone, without a device (CPU box)
+    ps.decode_stream(kind, aus[:9], threads, 1)                      # warm-up: library load, allocations
     passes = int(os.environ.get("DIAG_PASSES", "4"))                 # the stream several times through ONE decoder: steady state
     best = None
     for _ in range(2):
         # (no picture is copied out into Python: ps.decode_stream's per-picture numpy copies cap the main thread at ~1500 pictures a second
         # and were what the first overlap profiles of round 3 measured)
-        with ps.Decoder("hip", threads, 1) as d:
+        with ps.Decoder(kind, threads, 1) as d:
             t = time.perf_counter()
             n = 0
             for i, au in enumerate(aus * passes):
