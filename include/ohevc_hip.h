@@ -226,6 +226,7 @@ int ohevc_dev_motion_grid2(const ohevc_mc_job *jobs, int njobs, const ohevc_mc_j
 
 /* device-to-device copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) as a kernel launch: the deblocked copy SAO reads */
 int ohevc_dev_copy(void *dst, const void *src, size_t bytes, void *stream);
+int ohevc_dev_zero(void *dst, size_t bytes, void *stream);                       /* the same for zeros (16-byte aligned buffer and size) */
 
 /* ---- 2.4 SAO: replaces sao_band_filter / sao_edge_filter[0|1] (hevcdsp.h:60-62; hevcdsp_template.c:340-567)
  * as called from sao_filter_CTB (hevc_filter.c:197-322): dst = the picture, src = its deblocked copy

@@ -1698,7 +1698,8 @@ static int motion_grid_ready(ohevc_ctx *c, const Picture *p, int &gw, int &gh)
         int rc = c->d_grid.reserve(grid_bytes + bs_bytes);
         if (rc != OHEVC_OK) return rc;
     }
-    OHEVC_HIP_TRY(hipMemsetAsync(c->d_grid.p, 0, grid_bytes + bs_bytes, c->stream));
+    int rc = ohevc_dev_zero(c->d_grid.p, grid_bytes + bs_bytes, c->stream);     // (a launch, not hipMemsetAsync: see ohevc_dev_zero)
+    if (rc != OHEVC_OK) return rc;
     c->grid_zeroed = true;
     c->grid_bs_off = grid_bytes; c->grid_bs_cap = bs_bytes;
     return OHEVC_OK;
@@ -2385,7 +2386,7 @@ static int frame_end_impl(ohevc_ctx *c)
                     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
                     if ((rc = c->d_bs.reserve(n_v + n_h)) != OHEVC_OK) return rc;
                 }
-                OHEVC_HIP_TRY(hipMemsetAsync(c->d_bs.p, 0, n_v + n_h, c->stream));
+                if ((rc = ohevc_dev_zero(c->d_bs.p, n_v + n_h, c->stream)) != OHEVC_OK) return rc;
                 vbs = static_cast<uint8_t *>(c->d_bs.p);
             }
             ohevc_bs_maps bm = c->bs_maps;

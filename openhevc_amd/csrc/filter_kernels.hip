@@ -1045,6 +1045,28 @@ extern "C" int ohevc_dev_copy(void *dst, const void *src, size_t bytes, void *st
     return OHEVC_OK;
 }
 
+// Zeros as a plain kernel, for the same reason - and one more: on this runtime hipMemsetAsync (like hipMemcpyAsync) does not RETURN while the
+// stream still waits for an event of another stream (ctx.hip, up_stream): the frame end's first clearing sat behind the picture's upload
+// and, in inter pictures, behind the reference pictures' frame ends - 0.3 ms of a decoding thread per picture at 16 frame threads where a
+// launch takes 4 us (OHEVC_TRACE=timing, profiles/r5z_timing_intra_only_16.txt).
+namespace ohevc {
+__global__ __launch_bounds__(256) void zero16_kernel(u32x4 *__restrict__ dst, unsigned n16)
+{
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = u32x4{ 0u, 0u, 0u, 0u };
+}
+}  // namespace ohevc
+extern "C" int ohevc_dev_zero(void *dst, size_t bytes, void *stream)
+{
+    using namespace ohevc;
+    if (bytes == 0) return OHEVC_OK;
+    OHEVC_REQUIRE(dst != nullptr && ((reinterpret_cast<uintptr_t>(dst) | bytes) & 15) == 0 && (bytes >> 4) < 0xffffffffull, "16-byte aligned buffer and size");
+    const unsigned n16 = (unsigned)(bytes >> 4);
+    const unsigned grid = std::min<unsigned>((n16 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(zero16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<u32x4 *>(dst), n16);
+    OHEVC_HIP_TRY(hipGetLastError());
+    return OHEVC_OK;
+}
+
 extern "C" int ohevc_dev_motion_grid2(const ohevc_mc_job *jobs, int njobs, const ohevc_mc_job *more, int nmore, uint8_t *grid, int grid_width, int grid_height,
                                       int log2_unit, void *stream)
 {
