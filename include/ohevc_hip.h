@@ -473,6 +473,11 @@ int ohevc_upsample_make_maps(const ohevc_upsample_params *p, int plane, ohevc_up
 /* one plane; cols / col_of / rows are DEVICE arrays as made above */
 int ohevc_dev_upsample_plane(const ohevc_plane *dst, const ohevc_plane *src, int bit_depth, int chroma, const ohevc_upsample_tap *cols,
                              const int16_t *col_of, const ohevc_upsample_tap *rows, int src_cols, int src_rows, void *stream);
+/* the three planes of an inter-layer picture in one launch (same maps and extents as three ohevc_dev_upsample_plane calls: luma with the
+ * 8-tap filters, the two chroma planes with the 4-tap ones) */
+int ohevc_dev_upsample_picture(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth, const ohevc_upsample_tap *const cols[3],
+                               const int16_t *const col_of[3], const ohevc_upsample_tap *const rows[3], const int src_cols[3], const int src_rows[3],
+                               void *stream);
 
 #ifdef __cplusplus
 }

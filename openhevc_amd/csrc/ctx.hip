@@ -1026,10 +1026,15 @@ extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, cons
         c->up_valid = true;
     }
     unsigned char *base = static_cast<unsigned char *>(c->d_upsample.p);
-    for (int pl = 0; pl < 3; pl++) {
-        int rc = ohevc_dev_upsample_plane(&d->planes[pl], &sp->planes[pl], d->bd, pl != 0, reinterpret_cast<const ohevc_upsample_tap *>(base + c->up_off_cols[pl]),
-                                          reinterpret_cast<const int16_t *>(base + c->up_off_colof[pl]),
-                                          reinterpret_cast<const ohevc_upsample_tap *>(base + c->up_off_rows[pl]), c->up_src_cols[pl], c->up_src_rows[pl], c->stream);
+    {
+        const ohevc_upsample_tap *cols[3], *rows[3];
+        const int16_t *col_of[3];
+        for (int pl = 0; pl < 3; pl++) {
+            cols[pl] = reinterpret_cast<const ohevc_upsample_tap *>(base + c->up_off_cols[pl]);
+            col_of[pl] = reinterpret_cast<const int16_t *>(base + c->up_off_colof[pl]);
+            rows[pl] = reinterpret_cast<const ohevc_upsample_tap *>(base + c->up_off_rows[pl]);
+        }
+        int rc = ohevc_dev_upsample_picture(d->planes, sp->planes, d->bd, cols, col_of, rows, c->up_src_cols, c->up_src_rows, c->stream);      // one launch
         if (rc != OHEVC_OK) return rc;
     }
     hipEvent_t ev = c->ring[c->ring_next];

@@ -122,21 +122,29 @@ __global__ __launch_bounds__(256) void upsample_kernel(ohevc_plane dst, ohevc_pl
 //      four v_dot2_i32_i16 against the row's packed taps.
 // A tile whose maps jump (window larger than the LDS arrays) is left to the gather form above.
 constexpr int UPT_ROWS = 64, UPT_WR = 72, UPT_WC = 72 + 8, UPT_HS = 2 * UPT_WR + 4;     // H column stride in bytes: 37 dwords, odd (x1 needs 64 + 7 rows)
+// The workgroup's LDS: the window, the horizontal pass's columns, the tile's row-map entries and the 16 phases' taps (as int16 pairs, and for
+// 8-bit samples as int8 quads): a row of the vertical pass otherwise costs two dependent scalar loads from memory (rows[y], then the constant
+// table) - the kernel was bound by that latency.  Declared by the kernel, not by the body: the three-plane kernel runs the body with 8 and
+// with 4 taps and must not pay for two copies.
+template <typename Pixel> struct UpTileLds {
+    __attribute__((aligned(16))) unsigned char win[UPT_WR * UPT_WC * (int)sizeof(Pixel)];
+    __attribute__((aligned(16))) unsigned char hcol[64 * UPT_HS];
+    ohevc_upsample_tap srow[UPT_ROWS];
+    __attribute__((aligned(16))) unsigned stap16[16][4];
+    unsigned stap8[16][2];
+};
 template <typename Pixel, int TAPS>
-__global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohevc_plane src, const ohevc_upsample_tap *__restrict__ cols,
-                                                            const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
-                                                            int src_cols, int src_rows, int bit_depth)
+__device__ __forceinline__ void upsample_tile_body(UpTileLds<Pixel> &lds, const ohevc_plane &dst, const ohevc_plane &src, const ohevc_upsample_tap *__restrict__ cols,
+                                                   const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
+                                                   int src_cols, int src_rows, int bit_depth, int tile_x, int tile_y)
 {
     constexpr int HALF = TAPS / 2 - 1, P = (int)sizeof(Pixel);
-    __shared__ __attribute__((aligned(16))) unsigned char win[UPT_WR * UPT_WC * P];
-    __shared__ __attribute__((aligned(16))) unsigned char hcol[64 * UPT_HS];
-    // the tile's row-map entries and the 16 phases' taps (as int16 pairs, and for 8-bit samples as int8 quads): a row of the vertical pass
-    // otherwise costs two dependent scalar loads from memory (rows[y], then the constant table) - the kernel was bound by that latency
-    __shared__ ohevc_upsample_tap srow[UPT_ROWS];
-    __shared__ __attribute__((aligned(16))) unsigned stap16[16][4];
-    __shared__ unsigned stap8[16][2];
+    unsigned char *const win = lds.win, *const hcol = lds.hcol;
+    ohevc_upsample_tap *const srow = lds.srow;
+    unsigned (*const stap16)[4] = lds.stap16;
+    unsigned (*const stap8)[2] = lds.stap8;
     const int tid = threadIdx.x, lx = tid & 63, part = tid >> 6;
-    const int tx0 = blockIdx.x * 64, tx1 = min(tx0 + 63, dst.width - 1), ty0 = blockIdx.y * UPT_ROWS, ty1 = min(ty0 + UPT_ROWS - 1, dst.height - 1);
+    const int tx0 = tile_x * 64, tx1 = min(tx0 + 63, dst.width - 1), ty0 = tile_y * UPT_ROWS, ty1 = min(ty0 + UPT_ROWS - 1, dst.height - 1);
     // the tile's base-layer window; its first column rounded down to a multiple of four samples
     const int cmin = (cols[col_of[tx0]].pos - HALF) & ~3, cmax = cols[col_of[tx1]].pos - HALF + TAPS - 1;
     const int rmin = rows[ty0].pos - HALF, rmax = rows[ty1].pos - HALF + TAPS - 1;
@@ -291,6 +299,46 @@ __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohe
     }
 }
 
+template <typename Pixel, int TAPS>
+__global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohevc_plane src, const ohevc_upsample_tap *__restrict__ cols,
+                                                            const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
+                                                            int src_cols, int src_rows, int bit_depth)
+{
+    __shared__ UpTileLds<Pixel> lds;
+    upsample_tile_body<Pixel, TAPS>(lds, dst, src, cols, col_of, rows, src_cols, src_rows, bit_depth, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// The three planes of an inter-layer picture in ONE launch (a two-layer decode made three per picture, 5.5-8.5 us each): the luma tiles,
+// then the tiles of the two chroma planes; a workgroup finds its plane from its number.
+struct UpPlaneArgs {
+    ohevc_plane dst, src;
+    const ohevc_upsample_tap *cols, *rows;
+    const int16_t *col_of;
+    int src_cols, src_rows, tiles_x, tiles;
+};
+struct UpPictureArgs { UpPlaneArgs pl[3]; };
+template <typename Pixel>
+__global__ __launch_bounds__(256) void upsample_tile3_kernel(UpPictureArgs a, int bit_depth)
+{
+    __shared__ UpTileLds<Pixel> lds;
+    int t = (int)blockIdx.x;
+    if (t < a.pl[0].tiles) {
+        const UpPlaneArgs &q = a.pl[0];
+        upsample_tile_body<Pixel, 8>(lds, q.dst, q.src, q.cols, q.col_of, q.rows, q.src_cols, q.src_rows, bit_depth, t % q.tiles_x, t / q.tiles_x);
+        return;
+    }
+    t -= a.pl[0].tiles;
+    const int c = t < a.pl[1].tiles ? 1 : 2;
+    if (c == 2) t -= a.pl[1].tiles;
+    // (chosen with selects, not through an index: an indexed by-value argument goes to scratch memory)
+    const ohevc_plane dst = c == 1 ? a.pl[1].dst : a.pl[2].dst, src = c == 1 ? a.pl[1].src : a.pl[2].src;
+    const ohevc_upsample_tap *cols = c == 1 ? a.pl[1].cols : a.pl[2].cols, *rows = c == 1 ? a.pl[1].rows : a.pl[2].rows;
+    const int16_t *col_of = c == 1 ? a.pl[1].col_of : a.pl[2].col_of;
+    const int src_cols = c == 1 ? a.pl[1].src_cols : a.pl[2].src_cols, src_rows = c == 1 ? a.pl[1].src_rows : a.pl[2].src_rows;
+    const int tiles_x = c == 1 ? a.pl[1].tiles_x : a.pl[2].tiles_x;
+    upsample_tile_body<Pixel, 4>(lds, dst, src, cols, col_of, rows, src_cols, src_rows, bit_depth, t % tiles_x, t / tiles_x);
+}
+
 // Where an enhancement-layer column / row reads the base layer: centre tap position and phase.
 //   variant 0: the general formula of upsample_base_layer_frame (hevcdsp_template.c:2217-2226, 2255-2262, 2317-2325, 2364-2372)
 //              and of the *_all block slots (:1835-1953);
@@ -349,6 +397,39 @@ extern "C" int ohevc_upsample_make_maps(const ohevc_upsample_params *p, int plan
     // base-layer extent the passes clamp to: luma min(BL height, EL height) rows (:2214); chroma max(BL height, EL height / 2) / 2 (:2306-2312)
     *src_cols = chroma ? p->bl_width >> 1 : p->bl_width;
     *src_rows = chroma ? (std::max(p->bl_height, p->el_height >> 1) >> 1) : std::min(p->bl_height, p->el_height);
+    return OHEVC_OK;
+}
+
+extern "C" int ohevc_dev_upsample_picture(const ohevc_plane dst[3], const ohevc_plane src[3], int bit_depth, const ohevc_upsample_tap *const cols[3],
+                                          const int16_t *const col_of[3], const ohevc_upsample_tap *const rows[3], const int src_cols[3], const int src_rows[3],
+                                          void *stream)
+{
+    using namespace ohevc;
+    OHEVC_REQUIRE(dst != nullptr && src != nullptr && cols != nullptr && col_of != nullptr && rows != nullptr && src_cols != nullptr && src_rows != nullptr, "null argument");
+    OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
+    if (g_upsample_variant != 0) {                       // the strip form has no three-plane kernel
+        for (int pl = 0; pl < 3; pl++) {
+            int rc = ohevc_dev_upsample_plane(&dst[pl], &src[pl], bit_depth, pl != 0, cols[pl], col_of[pl], rows[pl], src_cols[pl], src_rows[pl], stream);
+            if (rc != OHEVC_OK) return rc;
+        }
+        return OHEVC_OK;
+    }
+    UpPictureArgs a;
+    int total = 0;
+    for (int pl = 0; pl < 3; pl++) {
+        OHEVC_REQUIRE(dst[pl].data != nullptr && src[pl].data != nullptr && cols[pl] != nullptr && col_of[pl] != nullptr && rows[pl] != nullptr, "planes / maps");
+        OHEVC_REQUIRE(dst[pl].width > 0 && dst[pl].height > 0 && src_cols[pl] > 0 && src_rows[pl] > 0, "sizes");
+        UpPlaneArgs &q = a.pl[pl];
+        q.dst = dst[pl]; q.src = src[pl]; q.cols = cols[pl]; q.col_of = col_of[pl]; q.rows = rows[pl];
+        q.src_cols = std::min(src_cols[pl], src[pl].width); q.src_rows = std::min(src_rows[pl], src[pl].height);      // (ohevc_dev_upsample_plane)
+        q.tiles_x = (dst[pl].width + 63) / 64;
+        q.tiles = q.tiles_x * ((dst[pl].height + UPT_ROWS - 1) / UPT_ROWS);
+        total += q.tiles;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bit_depth == 8) hipLaunchKernelGGL((upsample_tile3_kernel<uint8_t>), dim3(total), dim3(256), 0, st, a, bit_depth);
+    else                hipLaunchKernelGGL((upsample_tile3_kernel<uint16_t>), dim3(total), dim3(256), 0, st, a, bit_depth);
+    OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }
 

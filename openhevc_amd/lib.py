@@ -253,7 +253,7 @@ def dev_motion_grid2(jobs_ptr, njobs, more_ptr, nmore, grid_ptr, grid_width, gri
                                                 C.c_int(grid_width), C.c_int(grid_height), C.c_int(log2_unit), C.c_void_p(stream)))
 
 
-EXPORTED_SYMBOLS += ["ohevc_dev_boundary_strengths", "ohevc_dev_motion_grid", "ohevc_dev_motion_grid2", "ohevc_dev_copy", "ohevc_dev_zero", "ohevc_frame_keep_motion", "ohevc_tables_keep_motion", "ohevc_rec_bs_call",
+EXPORTED_SYMBOLS += ["ohevc_dev_boundary_strengths", "ohevc_dev_motion_grid", "ohevc_dev_motion_grid2", "ohevc_dev_copy", "ohevc_dev_zero", "ohevc_dev_upsample_picture", "ohevc_frame_keep_motion", "ohevc_tables_keep_motion", "ohevc_rec_bs_call",
                      "ohevc_rec_deblock_maps_bs", "ohevc_tables_bs_wanted", "ohevc_tables_bs_call", "ohevc_tables_bs_calls", "ohevc_rec_bs_calls"]
 
 

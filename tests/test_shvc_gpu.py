@@ -48,6 +48,37 @@ def test_upsample_matches_oracle(bd, block_slots):
     ctx.close()
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_one_launch_per_picture_equals_three_plane_launches(bd):
+    """ohevc_pic_upsample resamples an inter-layer picture's three planes in ONE launch (ohevc_dev_upsample_picture, round 5); the per-plane
+    entry point (ohevc_dev_upsample_plane: what benches and other callers use) must give the same samples."""
+    import gpu_util as G
+    rng = np.random.default_rng(90 + bd)
+    dt = G.pixdt(bd)
+    bw, bh, ew, eh = 208, 120, 416, 240
+    win = (0, 0, 0, 0)
+    up = po.shvc_params(bw, bh, ew, eh, win, phase_align=1)
+    prm = L.upsample_params(ew, eh, bw, bh, win, up, 0)
+    bl = [rng.integers(0, 1 << bd, size=(bh, bw)).astype(dt), rng.integers(0, 1 << bd, size=(bh // 2, bw // 2)).astype(dt),
+          rng.integers(0, 1 << bd, size=(bh // 2, bw // 2)).astype(dt)]
+    shapes = [(eh, ew), (eh // 2, ew // 2), (eh // 2, ew // 2)]
+    ctx = L.Ctx(0)
+    try:
+        s_bl, s_el = ctx.pic_alloc(bw, bh, 1, bd), ctx.pic_alloc(ew, eh, 1, bd)
+        ctx.pic_upload(s_bl, bl)
+        ctx.pic_upsample(s_el, s_bl, prm)
+        one = ctx.pic_download(s_el, shapes, dt)
+    finally:
+        ctx.close()
+    for pl in range(3):
+        cols, col_of, rows, sc, sr = L.upsample_maps(prm, pl)
+        keep = [G.to_dev(a) for a in (cols, col_of, rows)]
+        d_src, d_dst = G.to_dev(bl[pl]), G.to_dev(np.zeros(shapes[pl], dt))
+        L.dev_upsample_plane(d_dst, d_src, bd, int(pl != 0), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), sc, sr, G.stream())
+        G.sync()
+        assert np.array_equal(G.to_host(d_dst, dt), one[pl]), f"plane {pl}"
+
+
 @pytest.mark.parametrize("mode", ["blocks", "frame"])
 def test_reference_call_sequences_on_hooked_tables(ref, mode):
     """The drop-in: oracle/shvc_driver.c makes the reference's own call sequences (CTB by CTB through the twelve block slots and
