@@ -24,6 +24,8 @@ def decode(threads, natural):
     if natural:
         kw.update(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
                                           split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
+    if os.environ.get("DIAG_DENSE") == "1":                             # bench.py's qp22-like density instead
+        kw.update(ps.DENSE_QP22)
     aus, _ = ps.generate(ps.StreamParams(**kw))
     kind = os.environ.get("DIAG_KIND", "hip")                        # "hipemu" with OHHIP_RECORD_ONLY=1: the hooks' recording alone, without a device (CPU box)
     ps.decode_stream(kind, aus[:9], threads, 1)                      # warm-up: library load, allocations
