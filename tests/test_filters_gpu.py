@@ -263,3 +263,18 @@ def test_device_copy_kernel():
         G.sync()
         out = G.to_host(d_dst, np.uint8)
         assert np.array_equal(out[:nbytes], src) and not out[nbytes:].any()
+
+
+def test_device_zero_kernel():
+    """ohevc_dev_zero: the launch that clears the motion grid and the boundary-strength arrays at a frame end (a launch instead of hipMemsetAsync,
+    which does not return while the stream waits for another stream's event)."""
+    import ctypes as C
+    rng = np.random.default_rng(78)
+    lib = L.load_library()
+    for nbytes in (16, 4096, 2 * 1920 * 1088 // 16 * 16, (256 * 16 * 256 + 5) * 16):
+        d_dst = G.to_dev(rng.integers(1, 256, size=nbytes + 16, dtype=np.uint8))
+        L.check(lib.ohevc_dev_zero(C.c_void_p(d_dst.data_ptr()), C.c_size_t(nbytes), C.c_void_p(G.stream())))
+        G.sync()
+        out = G.to_host(d_dst, np.uint8)
+        assert not out[:nbytes].any() and out[nbytes:].all()
+    assert lib.ohevc_dev_zero(C.c_void_p(d_dst.data_ptr() + 1), C.c_size_t(16), C.c_void_p(G.stream())) != 0, "an unaligned buffer must be refused"
