@@ -1,4 +1,7 @@
-// LD_PRELOAD sampling profiler: SIGPROF at 1 kHz of process CPU time, leaf + 3 callers per sample, resolved with dladdr at exit
+// LD_PRELOAD sampling profiler: SIGPROF at 1 kHz of process CPU time, leaf + 3 callers per sample, resolved with dladdr at exit.
+// For the CPU box only (the hooks recording without a device, DIAG_KIND=hipemu OHHIP_RECORD_ONLY=1): with the real HIP runtime loaded and 16
+// decoding threads the process hung on the device box (backtrace() in a signal handler against the runtime's own threads) and took the
+// visit's whole time limit with it - do not preload it there.
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <execinfo.h>

@@ -1,6 +1,6 @@
 import sys, subprocess, collections, re, glob, os
 paths = {}
-for root in ["/root/repo/oracle/_ref", "/root/repo/tests/hipemu", "/root/repo/openhevc_amd", "/root/repo/tests/hipemu/build"]:
+for root in [os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), d) for d in ("oracle/_ref", "tests/hipemu", "openhevc_amd")] + ["/opt/rocm/lib"]:
     for f in glob.glob(root + "/**/*.so", recursive=True): paths.setdefault(os.path.basename(f), f)
 cnt = collections.Counter(); per_lib = collections.defaultdict(set)
 rows = [l.rstrip("\n").split("\t") for l in open(sys.argv[1])]
