@@ -36,13 +36,15 @@ int ohevc_debug_set_tu_pipe_workgroups(int n);
  * four-jobs-per-wavefront form for the small-block entry point, 5 = mc4 for both, 6 (shipped since round 3) = mc4 for tile batches and mc4q
  * - four blocks of at most 8x8 per matrix-core tile - for the small-block entry point.  3, 4 and 5 hand tiles with reference samples above
  * the bit depth's range to the exact redo kernel; 1 and 2 are exact for samples that fit the bit depth.  Env OHEVC_MC_VARIANT sets
- * the initial value (A/B of whole-decoder runs). */
+ * the initial value (A/B of whole-decoder runs).  Lab build only (results are NOT pictures): 102 / 103 = mc4q_kernel's traffic-only /
+ * arithmetic-only twin, 104 = the kernel itself again. */
 int ohevc_debug_set_mc_variant(int variant);
 /* SAO kernel: 0 = shipped (wide form: 16 bytes of one row per lane, no LDS, position rules as byte masks; blocks it cannot take fall
  * back to the LDS-window form); bit 1 = never take the wide form (A/B); bit 0 = the edge classes split a block into its interior (short form: no border / restore predicate can
  * apply there) and its outer ring (full form), enumerated so that whole wavefronts take one form.  Same results (CPU emulation and
  * tests).  Which XCD takes which block of the list: default = runs of 16 consecutive list entries per XCD; bit 2 (4) = list order (workgroup
- * number = list index, i.e. round-robin over the XCDs); bit 3 (8) = one contiguous eighth of the list per XCD (profiles/r03l_*, r03m_*). */
+ * number = list index, i.e. round-robin over the XCDs); bit 3 (8) = one contiguous eighth of the list per XCD (profiles/r03l_*, r03m_*);
+ * bit 4 (16) = interior edge-class blocks through the general loop too instead of the short form sao_edge_plain (round 5). */
 int ohevc_debug_set_sao_variant(int variant);
 /* Band SAO events on samples ABOVE the bit depth's range since the last reset (all streams of the current device; waits for them).  The
  * reference's sao_band_filter reads past its 32-entry offset table for such a sample (hevcdsp_template.c:340-365; constrained intra

@@ -23,7 +23,10 @@ W, H = 3840, 2160
 PEAK = 8000.0
 # --planes N stacks N 4K pictures vertically into one plane per launch: a single 4K plane is 10-60 us of work for this GPU, i.e.
 # mostly launch latency; N = 8 shows what the kernels sustain.  --only SUBSTR keeps the kernels whose name contains SUBSTR.
-# --sao-variant V selects the SAO kernel's form (include/ohevc_debug.h: 0 shipped, 1 interior / ring split) and tags the rows.
+# --sao-variant V selects the SAO kernel's form (include/ohevc_debug.h: 0 shipped, 1 interior / ring split, 16 interior edge-class blocks
+# through the general loop too) and tags the rows; --sao-class K / --sao-width W: the edge class (0 horizontal, 1 vertical, 2 / 3 diagonal)
+# and the block width (128: what a workgroup spanning two CTBs would see) of the SAO rows.
+# --mc-variant V: ohevc_debug_set_mc_variant (1-6 the kernels; lab build: 102 / 103 mc4q_kernel's traffic-only / arithmetic-only twin, 104 back).
 PLANES = 1
 ONLY = None
 SAO_VARIANT = None
