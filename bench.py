@@ -302,6 +302,121 @@ def decode_leg(pictures=33, threads=16, size=(1920, 1080), passes=4, hip_only=Fa
     return out
 
 
+LINE_LIMIT = 8192               # the driver stopped parsing the line somewhere between 15.8 and 22.2 KB (BENCH_r05.parsed = null): stay far below
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(out):
+    """The ONE short line the driver parses (the reference CLI's analogue: one `frame= N fps= F` report, main_hm/main.c:304-306): the headline
+    keys exactly as bench.py always printed them + `summary`: one number per kernel row (`frac` of 8 TB/s) and one short row per decoded
+    stream.  Everything else (workload texts, per-row times and checks, per-picture splits) is in DETAIL_FILE, written next to bench.py."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: (_short(v, 260) if isinstance(v, str) else v) for k, v in cfg.items()}
+    rf = dict(out.get("roofline", {}))
+    if rf.get("traffic_source"):
+        rf["traffic_source"] = "stored (profiles/pmc_traffic.json)"
+    line["roofline"] = rf
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cb.items() if k != "simd_note"}
+    line["checked"] = out.get("checked")
+    ck = out.get("check")
+    if ck is not None:
+        line["check"] = {k: v for k, v in ck.items() if k != "how"}
+    sm = {}
+    if "zscan" in out:
+        sm["zscan_frac"] = out["zscan"].get("frac")
+    kr = out.get("kernels")
+    if isinstance(kr, dict):
+        if "error" in kr:
+            sm["kernels"] = {"error": _short(kr["error"], 160)}
+        else:
+            sm["kernels_frac"] = {k: round(v["frac"], 3) for k, v in kr.items() if isinstance(v, dict) and "frac" in v}
+            bad = [k for k, v in kr.items() if isinstance(v, dict) and not v.get("checked", True)]
+            sm["kernels_checked"] = not bad
+            if bad:
+                sm["kernels_unchecked"] = bad[:8]
+
+    def modes_of(row):
+        return [k[len("hip_"):] for k in row if k.startswith("hip_") and isinstance(row[k], dict) and "fps" in row[k]]
+
+    def fps_pair(row, base, steady=False):
+        return [row.get(f"{base}_{m}", {}).get("fps_after_first_pass" if steady else "fps") for m in modes_of(row)]
+
+    dec = out.get("decode")
+    if isinstance(dec, dict):
+        if "error" in dec:
+            sm["decode"] = {"error": _short(dec["error"], 160)}
+        else:
+            d = {"cols": "fps per thread mode in the order of `modes`; hip = HIP back end, sse = reference as shipped on x86, c = reference C, fe = front end with empty tables; "
+                         "*_steady = after the first pass", "bit_exact": dec.get("bit_exact")}
+            for name, row in dec.get("streams", {}).items():
+                r = {"modes": modes_of(row),
+                     "hip": fps_pair(row, "hip"), "hip_steady": fps_pair(row, "hip", True), "sse": fps_pair(row, "reference_sse"),
+                     "sse_steady": fps_pair(row, "reference_sse", True), "c": fps_pair(row, "reference_c"), "fe": fps_pair(row, "front_end_only"),
+                     "ok": bool(row.get("bit_exact") and all(v for k, v in row.items() if k.startswith("bit_exact_")))}
+                pp = [row[k].get("per_picture") for k in row if k.startswith("hip_") and isinstance(row[k], dict) and row[k].get("per_picture")]
+                if pp:
+                    r["hook_ms"] = [p.get("frame_end_hook_ms") for p in pp]
+                    r["launches"], r["upload_kib"], r["floor_frac"] = pp[0].get("launches"), pp[0].get("upload_kib"), [p.get("floor_frac") for p in pp]
+                d[name] = r
+            for name, row in dec.get("sizes", {}).items():
+                if "error" in row:
+                    d[name] = {"error": _short(row["error"], 120)}
+                    continue
+                d[name] = {"modes": modes_of(row),
+                           "hip": fps_pair(row, "hip"), "hip_steady": fps_pair(row, "hip", True), "sse": fps_pair(row, "reference_sse"),
+                           "sse_steady": fps_pair(row, "reference_sse", True), "fe_steady": fps_pair(row, "front_end_only", True), "ok": bool(row.get("bit_exact"))}
+            sh = dec.get("shvc")
+            if isinstance(sh, dict):
+                d["shvc_x2"] = ({"error": _short(sh["error"], 120)} if "error" in sh else
+                                {k: v.get("aus_per_s") for k, v in sh.items() if isinstance(v, dict)} | {"ok": all(v.get("exact") for v in sh.values() if isinstance(v, dict))})
+            sm["decode"] = d
+    fr = out.get("frames")
+    if isinstance(fr, dict):
+        if "error" in fr:
+            sm["frames"] = {"error": _short(fr["error"], 200)}
+        else:
+            f = {k: fr.get(k) for k in ("value", "unit", "fps", "n_gpus", "steps", "ms_per_step", "speedup_vs_one_rank", "bit_exact", "wire_ranks") if fr.get(k) is not None}
+            f["transport"] = fr.get("config", {}).get("transport")
+            f["one_gpu"] = fr.get("config", {}).get("one_gpu")
+            if "one_rank" in fr:
+                f["one_rank_fps"] = fr["one_rank"].get("fps")
+            if "idr_segments" in fr:
+                f["idr_segments"] = {k: fr["idr_segments"].get(k) for k in ("fps", "speedup_vs_one_rank", "bit_exact") if fr["idr_segments"].get(k) is not None}
+            sm["frames"] = f
+    if "debug_set" in out:
+        sm["debug_set"] = out["debug_set"]
+    line["summary"] = sm
+    line["detail"] = DETAIL_FILE
+    # never let the line outgrow the driver: drop summary parts, largest first, until it fits
+    while len(json.dumps(line, separators=(",", ":"))) > LINE_LIMIT and line["summary"]:
+        big = max(line["summary"], key=lambda k: len(json.dumps(line["summary"][k])))
+        line["summary"].pop(big)
+        line.setdefault("summary_dropped", []).append(big)
+    return line
+
+
+def emit(out):
+    """write the full object next to bench.py (and under gpurun_out/ when that exists: the only directory that comes back from the GPU box),
+    then print the compact line as the LAST stdout line"""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+    print(json.dumps(compact_line(out), separators=(",", ":")), flush=True)
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -844,7 +959,7 @@ def main():
                 out["decode"] = decode_leg(hip_only=args.decode_hip_only, sizes=not args.no_sizes)
             except Exception as e:
                 out["decode"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -35,7 +35,9 @@ n=0
 prof_stats() {      # <dir> <name>: rocprofv3 --kernel-trace --stats summary of "$@" (after the two fixed arguments)
   local dir=$1 name=$2; shift 2
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $dir -o t -- "$@" > /tmp/prof_$name.log 2>&1 )
-  python tools/rocpd_summary.py stats $dir/t_results.db 2>/dev/null | cut -c1-170 | head -${STATS_ROWS:-14}
+  # the header, every row of the product's kernels (ohevc::), and the first few rows of everything else (torch's fill kernels used to crowd
+  # the product's rows out of a 14-line head: VERDICT r5 weak 8)
+  python tools/rocpd_summary.py stats $dir/t_results.db 2>/dev/null | cut -c1-170 | awk -v other=${STATS_ROWS:-6} 'NR == 1 || /ohevc::/ { print; next } other-- > 0 { print }'
 }
 
 # a step may be preceded by VAR=value words: they are exported for that step only (and become part of its file names)
@@ -62,9 +64,11 @@ run_step() {
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "$NOISE" | tail -3 | tee $OUT/smoke.log ;;
     bench)
       local sfx=$(echo "$ENVTAG $*" | tr -c 'a-zA-Z0-9\n' '_' | sed 's/__*/_/g; s/^_//; s/_$//')
+      # the last stdout line = the compact line the driver parses (bench.compact_line); the full object = bench_detail.json
       timeout 900 python bench.py "$@" 2> $OUT/bench_${sfx:-default}.err | tail -1 > $OUT/bench${sfx:+_$sfx}.json
-      cut -c1-1200 $OUT/bench${sfx:+_$sfx}.json; tail -3 $OUT/bench_${sfx:-default}.err | grep -v "$NOISE"
-      python - $OUT/bench${sfx:+_$sfx}.json <<'PY'
+      [ -f bench_detail.json ] && cp bench_detail.json $OUT/bench${sfx:+_$sfx}_detail.json
+      echo "  line: $(wc -c < $OUT/bench${sfx:+_$sfx}.json) bytes"; cut -c1-1200 $OUT/bench${sfx:+_$sfx}.json; tail -3 $OUT/bench_${sfx:-default}.err | grep -v "$NOISE"
+      python - $OUT/bench${sfx:+_$sfx}_detail.json <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
