@@ -27,6 +27,8 @@ extern "C" {
 #endif
 
 typedef struct ohhip_frames_mode {
+    size_t struct_size;      /* sizeof(ohhip_frames_mode) as the caller was compiled: FIRST, checked by ohhip_backend_frames_mode (0 or larger than the
+                              * library's: refused); fields beyond it are taken as NULL / 0; new fields are only ever appended */
     int rank, world;
     void *user;
     /* owner: picture `index` is complete (device work drained): planes in picture-store slot `slot` of ctx, motion field at mvf.

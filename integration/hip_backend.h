@@ -34,7 +34,12 @@ extern "C" {
 struct AVCodecContext;
 typedef struct ohhip_backend ohhip_backend;
 
+/* ABI rule of this struct (and of ohhip_frames_mode, ohevc_frames.h): struct_size comes FIRST and is sizeof(the struct) as the HOST was compiled
+ * (ohhip_options_default fills it in); new fields are only ever APPENDED.  ohhip_backend_new refuses struct_size 0 ("not initialised") and
+ * sizes larger than its own; fields beyond the caller's size keep their library defaults (-1 / NULL), so a host built against an older header
+ * keeps working and can never be over-read. */
 typedef struct ohhip_options {
+    size_t struct_size;      /* sizeof(ohhip_options) of the caller; set by ohhip_options_default */
     int device;              /* HIP device ordinal of this decoder                                     (default: OHHIP_DEVICE or 0) */
     int bulk_filters;        /* 1: the in-loop filter drivers in bulk at the frame end, 0: per-edge calls (default 1; OHHIP_BULK_FILTERS) */
     int defer_download;      /* 1: a picture is copied back when the application fetches it (ohhip_backend_fetch_output), 0: in the frame-end hook
@@ -56,8 +61,11 @@ typedef struct ohhip_options {
 } ohhip_options;
 
 void ohhip_options_default(ohhip_options *o);
-size_t ohhip_options_size(void);                            /* sizeof(ohhip_options) as the back end was compiled: a host built against another version must not go on */
-ohhip_backend *ohhip_backend_new(const ohhip_options *o);                 /* NULL: ohevc_last_error() says why */
+size_t ohhip_options_size(void);                            /* sizeof(ohhip_options) as the back end was compiled (a host's struct_size may be smaller, never larger) */
+ohhip_backend *ohhip_backend_new(const ohhip_options *o);                 /* NULL: refused (struct_size) or the context could not be made; the reason goes to stderr */
+/* the options this back end RUNS with (defaults filled in; a caller's shorter struct completed): out->struct_size says how much of *out may be
+ * written (ohhip_options_default(out) first, or set it by hand); returns 0, -1 for a bad handle or size */
+int  ohhip_backend_options(const ohhip_backend *be, ohhip_options *out);
 int  ohhip_backend_attach(ohhip_backend *be, struct AVCodecContext *avctx);   /* before avcodec_open2 */
 /* "frame complete, before output" for one decoding thread (with frame threads the decoder's own end-of-frame report has done it already) */
 int  ohhip_backend_frame_done(ohhip_backend *be);

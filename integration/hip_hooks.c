@@ -811,6 +811,7 @@ size_t ohhip_options_size(void) { return sizeof(ohhip_options); }     /* for hos
 void ohhip_options_default(ohhip_options *o)
 {
     memset(o, 0, sizeof(*o));
+    o->struct_size = sizeof(*o);
     o->device = env_int("OHHIP_DEVICE", 0);
     o->bulk_filters = env_int("OHHIP_BULK_FILTERS", 1) != 0;
     /* 1 since round 5: ending a frame only ISSUES its device work, the copy-back waits until the application takes the picture
@@ -839,13 +840,24 @@ static void apply_ctx_options(const ohhip_backend *be, ohevc_ctx *ctx)
 ohhip_backend *ohhip_backend_new(const ohhip_options *o)
 {
     ohhip_options def;
-    ohhip_backend *be = calloc(1, sizeof(*be));
+    ohhip_backend *be;
+    /* the caller's struct may be OLDER (smaller) than this library's: its fields are laid over the defaults, the ones it does not have keep
+     * them.  struct_size 0 = a zero-initialised / never-defaulted struct (every field would read as 0: host-side deblock derivation, no
+     * deferred copy-back, "-1 = library default" lost), larger than ours = a host newer than the library: both refused, nothing is read. */
+    ohhip_options_default(&def);
+    if (o) {
+        if (o->struct_size < offsetof(ohhip_options, device) + sizeof(int) || o->struct_size > sizeof(ohhip_options)) {
+            fprintf(stderr, "ohhip: ohhip_backend_new: ohhip_options.struct_size is %zu (this library: %zu): call ohhip_options_default() first\n",
+                    o->struct_size, sizeof(ohhip_options));
+            return NULL;
+        }
+        memcpy(&def, o, o->struct_size);
+        def.struct_size = sizeof(def);
+    }
+    o = &def;
+    be = calloc(1, sizeof(*be));
     if (!be)
         return NULL;
-    if (!o) {
-        ohhip_options_default(&def);
-        o = &def;
-    }
     if (o->crash_backtrace) {
         signal(SIGSEGV, crash_handler);
         signal(SIGABRT, crash_handler);
@@ -887,6 +899,19 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
     g_epoch++;
     pthread_mutex_unlock(&g_reg_lock);
     return be;
+}
+
+int ohhip_backend_options(const ohhip_backend *be, ohhip_options *out)
+{
+    size_t n;
+    if (!be || be->magic != OHHIP_MAGIC || !out)
+        return -1;
+    n = out->struct_size;
+    if (n < offsetof(ohhip_options, device) + sizeof(int) || n > sizeof(ohhip_options))
+        return -1;
+    memcpy(out, &be->opt, n);
+    out->struct_size = n;
+    return 0;
 }
 
 int ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx)
@@ -1029,9 +1054,18 @@ int ohhip_backend_frames_mode(ohhip_backend *be, const ohhip_frames_mode *m)
     be->fm_segment = -1;
     if (!m)
         return 0;
+    /* struct_size first (ohevc_frames.h): a caller compiled against an older header has fewer trailing fields - they read as NULL / 0 here and
+     * the caller's memory is never read beyond what it says it has */
+    if (m->struct_size < offsetof(ohhip_frames_mode, await_planes) + sizeof(m->await_planes) || m->struct_size > sizeof(ohhip_frames_mode)) {
+        fprintf(stderr, "ohhip: ohhip_backend_frames_mode: ohhip_frames_mode.struct_size is %zu (this library: %zu)\n", m->struct_size, sizeof(ohhip_frames_mode));
+        return -1;
+    }
+    memset(&be->fm, 0, sizeof(be->fm));
+    memcpy(&be->fm, m, m->struct_size);
+    be->fm.struct_size = sizeof(be->fm);
+    m = &be->fm;
     if (m->world < 1 || m->rank < 0 || m->rank >= m->world || !m->publish || !m->subscribe || !m->await_motion || !m->await_planes)
         return -1;
-    be->fm = *m;
     be->fm_on = m->world > 1;
     return 0;
 }

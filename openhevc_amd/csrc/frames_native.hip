@@ -693,7 +693,7 @@ extern "C" int ohevc_frames_transport_create(ohevc_frames_transport **out, int r
     ohevc_frames_transport *t = new ohevc_frames_transport();
     t->rank = rank; t->world = world; t->device = device; t->wire = wire; t->timeout_s = timeout_s > 0 ? timeout_s : 60;
     t->rendezvous = rendezvous ? rendezvous : "";
-    t->mode = ohhip_frames_mode{ rank, world, t, cb_publish, cb_subscribe, cb_await_motion, cb_await_planes, cb_release, cb_await_rows, 0 };
+    t->mode = ohhip_frames_mode{ sizeof(ohhip_frames_mode), rank, world, t, cb_publish, cb_subscribe, cb_await_motion, cb_await_planes, cb_release, cb_await_rows, 0 };
     auto fail = [&](int rc) { ohevc_frames_transport_destroy(t); return rc; };
     if (hipSetDevice(device) != hipSuccess) { set_error("frames transport: no device %d", device); return fail(OHEVC_ERR_NODEV); }
     if (wire == OHEVC_FRAMES_WIRE_SOCKETS) {

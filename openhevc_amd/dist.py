@@ -160,7 +160,8 @@ class _FramesMode(_C.Structure):
     AWAIT_PLANES = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int)
     RELEASE = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int)
     AWAIT_ROWS = _C.CFUNCTYPE(_C.c_int, _C.c_void_p, _C.c_int, _C.c_void_p, _C.c_int, _C.c_int)
-    _fields_ = [("rank", _C.c_int), ("world", _C.c_int), ("user", _C.c_void_p), ("publish", PUBLISH), ("subscribe", SUBSCRIBE),
+    _fields_ = [("struct_size", _C.c_size_t),    # first: sizeof(this struct) as THIS caller knows it (ohhip_backend_frames_mode checks it)
+                ("rank", _C.c_int), ("world", _C.c_int), ("user", _C.c_void_p), ("publish", PUBLISH), ("subscribe", SUBSCRIBE),
                 ("await_motion", AWAIT_MOTION), ("await_planes", AWAIT_PLANES), ("release", RELEASE),
                 ("await_rows", AWAIT_ROWS),      # NULL here: this Python transport moves whole pictures (the native one has bands)
                 ("segment_ownership", _C.c_int)]
@@ -209,7 +210,7 @@ class FrameExchange:
         self._cb = (_FramesMode.PUBLISH(self._guard(self._publish)), _FramesMode.SUBSCRIBE(self._guard(self._subscribe)),
                     _FramesMode.AWAIT_MOTION(self._guard(self._await_motion)), _FramesMode.AWAIT_PLANES(self._guard(self._await_planes)),
                     _FramesMode.RELEASE(self._guard(self._release)))
-        self.mode = _FramesMode(self.rank, self.world, None, *self._cb)
+        self.mode = _FramesMode(_C.sizeof(_FramesMode), self.rank, self.world, None, *self._cb)
 
     def _guard(self, fn):
         def call(user, *a):

@@ -116,3 +116,108 @@ def open_close_many(kind, n=50, name="ldp_8b"):
             base = rss_kb()                          # allocator pools and the runtime's caches have settled by now
     grown = rss_kb() - base
     assert grown < 64 * 1024, f"resident set grew by {grown} KiB over {n - 10} open/close cycles"
+
+
+# ---------------------------------------------------------------- the options structs' ABI rule (struct_size first)
+class _Options(C.Structure):
+    """ohhip_options as integration/hip_backend.h has it TODAY"""
+    _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("bulk_filters", C.c_int), ("defer_download", C.c_int), ("pin_frames", C.c_int),
+                ("async_issue", C.c_int), ("record_only", C.c_int), ("test_fail_index", C.c_int), ("flush_intra_kib", C.c_int),
+                ("level_launch", C.c_int), ("device_filters", C.c_int), ("crash_backtrace", C.c_int), ("trace_path", C.c_char_p), ("base_layer", C.c_void_p)]
+
+
+class _OldOptions(C.Structure):
+    """a host compiled against an OLDER header: the struct ended after flush_intra_kib"""
+    _fields_ = _Options._fields_[:9]
+
+
+def options_struct_size_rule(kind):
+    """ohhip_backend_new reads no more of the caller's struct than struct_size says, fills what is missing with the library's defaults
+    (-1 = "library default", not 0 = "host-side derivation"), and refuses a struct nobody initialised or one from a newer host."""
+    L = ps._load(kind)
+    L.ohhip_backend_new.restype = C.c_void_p
+    L.ohhip_backend_new.argtypes = [C.c_void_p]
+    L.ohhip_backend_free.argtypes = [C.c_void_p]
+    L.ohhip_backend_options.argtypes = [C.c_void_p, C.c_void_p]
+    L.ohhip_options_default.argtypes = [C.c_void_p]
+    L.ohhip_options_size.restype = C.c_size_t
+    assert L.ohhip_options_size() == C.sizeof(_Options)
+    dflt = _Options()
+    L.ohhip_options_default(C.byref(dflt))
+    assert dflt.struct_size == C.sizeof(_Options) and dflt.level_launch == -1 and dflt.device_filters == -1 and dflt.defer_download == 1
+
+    def effective(be):
+        got = _Options()
+        got.struct_size = C.sizeof(_Options)
+        assert L.ohhip_backend_options(be, C.byref(got)) == 0
+        return got
+
+    # (a) zero-initialised struct (struct_size 0): refused - every field would have read as 0
+    assert not L.ohhip_backend_new(C.byref(_Options()))
+    # (b) a struct from a newer host (larger than the library's): refused
+    big = _Options()
+    L.ohhip_options_default(C.byref(big))
+    big.struct_size = C.sizeof(_Options) + 8
+    assert not L.ohhip_backend_new(C.byref(big))
+    # (c) an older host: 9 fields, followed in memory by garbage the library must not read
+    class Padded(C.Structure):
+        _fields_ = [("o", _OldOptions), ("junk", C.c_ubyte * 64)]
+    old = Padded()
+    C.memset(C.byref(old), 0xA5, C.sizeof(old))
+    old.o.struct_size = C.sizeof(_OldOptions)
+    old.o.device, old.o.bulk_filters, old.o.defer_download, old.o.pin_frames = dflt.device, 1, 0, 1
+    old.o.async_issue, old.o.record_only, old.o.test_fail_index, old.o.flush_intra_kib = 0, dflt.record_only, -1, 777
+    be = L.ohhip_backend_new(C.byref(old))
+    assert be
+    got = effective(be)
+    assert (got.defer_download, got.flush_intra_kib) == (0, 777)                       # what the old host said
+    assert (got.level_launch, got.device_filters, got.crash_backtrace) == (dflt.level_launch, dflt.device_filters, dflt.crash_backtrace)   # defaults, not 0xA5A5A5A5
+    assert got.trace_path == dflt.trace_path and got.base_layer == dflt.base_layer
+    # the getter honours the asker's size too
+    small = Padded()
+    C.memset(C.byref(small), 0x5A, C.sizeof(small))
+    small.o.struct_size = C.sizeof(_OldOptions)
+    assert L.ohhip_backend_options(be, C.byref(small)) == 0
+    assert small.o.flush_intra_kib == 777 and bytes(small.junk) == b"\x5a" * 64
+    L.ohhip_backend_free(be)
+    # (d) today's struct, one field changed
+    cur = _Options()
+    L.ohhip_options_default(C.byref(cur))
+    cur.level_launch = 3
+    be = L.ohhip_backend_new(C.byref(cur))
+    assert be and effective(be).level_launch == 3
+    L.ohhip_backend_free(be)
+
+
+def frames_mode_struct_size_rule(kind):
+    """ohhip_backend_frames_mode: struct_size first; a caller without the trailing fields (await_rows, segment_ownership) gets NULL / 0 for them,
+    never the bytes behind its struct; 0 and too-large sizes are refused."""
+    from openhevc_amd import dist as D
+    FM = D._FramesMode
+    L = ps._load(kind)
+    L.ohhip_backend_new.restype = C.c_void_p
+    L.ohhip_backend_new.argtypes = [C.c_void_p]
+    L.ohhip_backend_free.argtypes = [C.c_void_p]
+    L.ohhip_backend_frames_mode.argtypes = [C.c_void_p, C.c_void_p]
+    be = L.ohhip_backend_new(None)
+    assert be
+    cbs = (FM.PUBLISH(lambda *a: 0), FM.SUBSCRIBE(lambda *a: 0), FM.AWAIT_MOTION(lambda *a: 0), FM.AWAIT_PLANES(lambda *a: 0), FM.RELEASE(lambda *a: 0))
+
+    class Padded(C.Structure):
+        _fields_ = [("m", FM), ("junk", C.c_ubyte * 32)]
+    p = Padded()
+    p.m = FM(C.sizeof(FM), 0, 2, None, *cbs)
+    assert L.ohhip_backend_frames_mode(be, C.byref(p)) == 0
+    p.m.struct_size = 0
+    assert L.ohhip_backend_frames_mode(be, C.byref(p)) != 0
+    p.m.struct_size = C.sizeof(FM) + 16
+    assert L.ohhip_backend_frames_mode(be, C.byref(p)) != 0
+    # an older caller: the struct ends after `release`; what follows in ITS memory is not ours to read (here: a poisoned pointer and flag)
+    C.memset(C.addressof(p) + FM.await_rows.offset, 0xEE, C.sizeof(p) - FM.await_rows.offset)
+    p.m.struct_size = FM.await_rows.offset
+    assert L.ohhip_backend_frames_mode(be, C.byref(p)) == 0
+    # missing a REQUIRED callback: refused
+    p.m.struct_size = FM.await_planes.offset
+    assert L.ohhip_backend_frames_mode(be, C.byref(p)) != 0
+    assert L.ohhip_backend_frames_mode(be, None) == 0
+    L.ohhip_backend_free(be)

@@ -25,11 +25,17 @@ def test_bench_gpus_2_from_a_bare_shell():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"exactly one JSON line on stdout, got {len(lines)}: {r.stdout[-2000:]}"
+    assert len(lines[0]) < 8192                            # the line the driver parses stays short (bench.compact_line); the rest is in the detail file
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["checked"] is True
     assert d["config"]["one_gpu"] is True                  # two ranks, one device: said in the line
     assert d["roofline"]["frac"] > 0
-    f = d["frames"]
+    sf = d["summary"]["frames"]                            # the compact row of the line ...
+    assert "error" not in sf, sf
+    assert sf["n_gpus"] == 2 and sf["bit_exact"] is True and sf["wire_ranks"] == 2 and sf["fps"] > 0 and sf["idr_segments"]["bit_exact"] is True
+    full = json.load(open(os.path.join(ROOT, d["detail"])))   # ... and the full object, next to bench.py
+    assert full["value"] == d["value"] and full["roofline"] == {**d["roofline"], "traffic_source": full["roofline"]["traffic_source"]}
+    f = full["frames"]
     assert "error" not in f, f
     assert f["n_gpus"] == 2 and f["scaling"] == "strong"
     assert f["bit_exact"] is True and f["one_rank"]["pictures_checked"] == 9 and f["one_rank"]["pictures_differing"] == 0

@@ -234,6 +234,11 @@ def test_emu_two_decoders_with_different_options_in_one_process():
     _instances().two_decoders_with_different_options("hipemu")
 
 
+def test_emu_options_structs_carry_their_size_first():
+    _instances().options_struct_size_rule("hipemu")
+    _instances().frames_mode_struct_size_rule("hipemu")
+
+
 def test_emu_two_decoders_interleaved_on_one_application_thread():
     _instances().interleaved_on_one_thread("hipemu", ("intra_8b", "ra_10b_odd"))
 

@@ -285,6 +285,12 @@ def test_two_decoders_with_different_options_in_one_process():
     instance_cases.two_decoders_with_different_options("hip")
 
 
+def test_options_structs_carry_their_size_first():
+    import instance_cases
+    instance_cases.options_struct_size_rule("hip")
+    instance_cases.frames_mode_struct_size_rule("hip")
+
+
 def test_two_decoders_interleaved_on_one_application_thread():
     import instance_cases
     instance_cases.interleaved_on_one_thread("hip")
