@@ -45,7 +45,9 @@ void ohevc_ctx_destroy(ohevc_ctx *ctx);
  * the recording path.  The caller guarantees what the reference's WPP / tile decoding guarantees: a block is recorded after the
  * blocks it predicts from.  Off (default): a context is not internally synchronised. */
 int  ohevc_ctx_set_concurrent(ohevc_ctx *ctx, int on);
-/* the HIP stream all of this context's copies and launches are issued on (hipStream_t as void*) */
+/* the context's HIP stream (hipStream_t as void*): the same handle for the context's whole life.  Everything the context has issued when
+ * ohevc_frame_end / ohevc_pic_* return is ordered before what the caller enqueues on this handle afterwards (a picture with a long dependency
+ * chain is issued on a second, internal stream and joins this one at its frame end). */
 void *ohevc_ctx_stream(ohevc_ctx *ctx);
 int  ohevc_ctx_sync(ohevc_ctx *ctx);
 
@@ -89,6 +91,9 @@ int  ohevc_pic_import(ohevc_ctx *ctx, int slot, int plane, const void *device_sr
  * first != 0 on the first import of a picture: it orders the slot's memory against its earlier readers / writers. */
 int  ohevc_pic_export_rows(ohevc_ctx *ctx, int slot, int plane, int row0, int rows, void *device_plane_base);
 int  ohevc_pic_import_rows(ohevc_ctx *ctx, int slot, int plane, int row0, int rows, const void *device_plane_base, int first);
+/* a whole band - the row ranges of all three planes (device_plane_base[i] NULL: no such plane) - with ONE wait at the end instead of one per plane */
+int  ohevc_pic_export_band(ohevc_ctx *ctx, int slot, const int row0[3], const int rows[3], void *const device_plane_base[3]);
+int  ohevc_pic_import_band(ohevc_ctx *ctx, int slot, const int row0[3], const int rows[3], const void *const device_plane_base[3], int first);
 /* The deepest LUMA row of reference picture `slot` that the motion compensation recorded for the open frame reads, filter taps included
  * (-1: the frame does not predict from it): how much of a remote picture must have arrived before the frame launches. */
 int  ohevc_frame_ref_reach(ohevc_ctx *ctx, int slot);

@@ -53,9 +53,10 @@ typedef struct ohhip_frames_mode {
      * use await_planes. */
     int (*await_rows)(void *user, int index, ohevc_ctx *ctx, int slot, int last_luma_row);
     /* 0: a picture's owner is its decoding-order index % world and exchanged pictures cross the wire (any stream).  1: ownership per IDR SEGMENT -
-     * segment number % world, a segment = an IDR picture and everything up to the next one: nothing after an IDR picture predicts from
+     * segment number % world, a segment = an IDR or BLA picture and everything up to the next one: nothing after such a picture predicts from
      * anything before it, so a segment needs nothing from the other ranks and NOTHING is exchanged; the ranks decode different segments at the
-     * same time.  For streams with regular IDR pictures (closed GOPs); a stream without them stays on one rank. */
+     * same time.  For streams with regular IDR / BLA pictures (closed GOPs, splices); CRA pictures do not open a segment (their RASL pictures
+     * predict across them), so an open-GOP stream without IDR / BLA pictures stays on one rank: use per-picture ownership there. */
     int segment_ownership;
 } ohhip_frames_mode;
 

@@ -433,7 +433,11 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
          * anything before it (H.265 8.3.1, 8.3.2), so a segment - an IDR picture and everything up to the next one - is decoded by ONE
          * rank, start to end, and nothing of it is needed anywhere else: no exchange at all, the ranks work on different segments of the
          * stream at the same time (the random-access points every broadcast / streaming encoder puts in once a second or two). */
-        if (IS_IDR(s) || be->fm_segment < 0)
+        /* BLA pictures open a segment too: like an IDR picture they empty the decoded picture buffer (hevc.c:561 clears the references for both), what
+         * their leading pictures name from before is generated, not read.  A CRA picture in mid-stream does NOT: its RASL pictures predict from
+         * pictures before it (H.265 8.3.3), which another rank would own - an open-GOP stream without IDR / BLA pictures stays on one rank under
+         * this rule (use per-picture ownership for it); the first picture of a stream opens segment 0 whatever it is. */
+        if (IS_IDR(s) || IS_BLA(s) || be->fm_segment < 0)
             be->fm_segment++;
         owner = be->fm.segment_ownership ? be->fm_segment % be->fm.world : be->bufs[i].index % be->fm.world;
         if (be->fm.segment_ownership)

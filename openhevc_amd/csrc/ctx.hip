@@ -615,7 +615,10 @@ static ohevc_debug_sink g_sink = nullptr;
 static void *g_sink_user = nullptr;
 extern "C" void ohevc_debug_set_frame_sink(ohevc_debug_sink fn, void *user) { g_sink = fn; g_sink_user = user; }
 
-extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream : nullptr; }
+// The handle never changes over a context's life: stream_norm.  A picture with a long dependency chain is ISSUED on stream_long (select_stream),
+// and its frame end joins stream_norm again (frame_end_impl), so that whatever a caller enqueues on - or waits for through - this handle after
+// ohevc_frame_end / ohevc_frame_end_async's issue is ordered behind the picture whichever stream carried it.
+extern "C" void *ohevc_ctx_stream(ohevc_ctx *c) { return c ? (void *)c->stream_norm : nullptr; }
 
 extern "C" int ohevc_ctx_sync(ohevc_ctx *c)
 {
@@ -899,7 +902,7 @@ extern "C" int ohevc_pic_import(ohevc_ctx *c, int slot, int plane, const void *d
 // Row ranges of the two calls above (band-chunked exchange, include/ohevc_frames.h): rows [row0, row0 + rows) of the plane, the buffer
 // laid out like the whole plane (the band sits at row0 * stride).  The first export of a picture is the one that waits for its device
 // work; the first import of a picture (first != 0) is the one that orders the slot's memory against its earlier users.
-extern "C" int ohevc_pic_export_rows(ohevc_ctx *c, int slot, int plane, int row0, int rows, void *device_plane_base)
+static int export_rows_impl(ohevc_ctx *c, int slot, int plane, int row0, int rows, void *device_plane_base, bool wait)
 {
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && device_plane_base != nullptr, "bad argument");
@@ -918,11 +921,29 @@ extern "C" int ohevc_pic_export_rows(ohevc_ctx *c, int slot, int plane, int row0
     const size_t off = (size_t)row0 * pl.stride;
     OHEVC_HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(device_plane_base) + off, static_cast<const unsigned char *>(pl.data) + off, (size_t)rows * pl.stride,
                                  hipMemcpyDeviceToDevice, c->stream));
-    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (wait) OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+extern "C" int ohevc_pic_export_rows(ohevc_ctx *c, int slot, int plane, int row0, int rows, void *device_plane_base)
+{
+    return export_rows_impl(c, slot, plane, row0, rows, device_plane_base, true);
+}
+// one band = the three planes' row ranges, ONE wait for the host (the per-plane calls cost a decoding thread up to 24 stalls per exchanged picture)
+extern "C" int ohevc_pic_export_band(ohevc_ctx *c, int slot, const int row0[3], const int rows[3], void *const device_plane_base[3])
+{
+    OHEVC_REQUIRE(c != nullptr && row0 && rows && device_plane_base, "bad argument");
+    bool any = false;
+    for (int pl = 0; pl < 3; pl++) {
+        if (!device_plane_base[pl] || rows[pl] <= 0) continue;
+        const int rc = export_rows_impl(c, slot, pl, row0[pl], rows[pl], device_plane_base[pl], false);
+        if (rc != OHEVC_OK) return rc;
+        any = true;
+    }
+    if (any && !c->dry) OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     return OHEVC_OK;
 }
 
-extern "C" int ohevc_pic_import_rows(ohevc_ctx *c, int slot, int plane, int row0, int rows, const void *device_plane_base, int first)
+static int import_rows_impl(ohevc_ctx *c, int slot, int plane, int row0, int rows, const void *device_plane_base, int first, bool wait)
 {
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr && plane >= 0 && plane < 3 && device_plane_base != nullptr, "bad argument");
@@ -941,7 +962,24 @@ extern "C" int ohevc_pic_import_rows(ohevc_ctx *c, int slot, int plane, int row0
     const size_t off = (size_t)row0 * pl.stride;
     OHEVC_HIP_TRY(hipMemcpyAsync(static_cast<unsigned char *>(pl.data) + off, static_cast<const unsigned char *>(device_plane_base) + off, (size_t)rows * pl.stride,
                                  hipMemcpyDeviceToDevice, c->stream));
-    OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (wait) OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    return OHEVC_OK;
+}
+extern "C" int ohevc_pic_import_rows(ohevc_ctx *c, int slot, int plane, int row0, int rows, const void *device_plane_base, int first)
+{
+    return import_rows_impl(c, slot, plane, row0, rows, device_plane_base, first, true);
+}
+extern "C" int ohevc_pic_import_band(ohevc_ctx *c, int slot, const int row0[3], const int rows[3], const void *const device_plane_base[3], int first)
+{
+    OHEVC_REQUIRE(c != nullptr && row0 && rows && device_plane_base, "bad argument");
+    bool any = false;
+    for (int pl = 0; pl < 3; pl++) {
+        if (!device_plane_base[pl]) continue;
+        const int rc = import_rows_impl(c, slot, pl, row0[pl], rows[pl] < 0 ? 0 : rows[pl], device_plane_base[pl], first, false);
+        if (rc != OHEVC_OK) return rc;
+        any = any || rows[pl] > 0;
+    }
+    if (any && !c->dry) OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     return OHEVC_OK;
 }
 
@@ -2490,12 +2528,17 @@ static int frame_end_impl(ohevc_ctx *c)
             OHEVC_HIP_TRY(hipEventRecord(c->lane_done[k], c->stream));
             c->lane_done_pending[k] = true;
         }
-        std::lock_guard<std::mutex> g(c->store->m);
-        p->written = ev;
-        for (int r : c->ref_slots) {
-            auto &rd = c->store->pics[r].readers;
-            if (std::find(rd.begin(), rd.end(), ev) == rd.end()) rd.push_back(ev);
+        {
+            std::lock_guard<std::mutex> g(c->store->m);
+            p->written = ev;
+            for (int r : c->ref_slots) {
+                auto &rd = c->store->pics[r].readers;
+                if (std::find(rd.begin(), rd.end(), ev) == rd.end()) rd.push_back(ev);
+            }
         }
+        // a long-chain picture joins the context's public stream again HERE (not at the next frame_begin): a handle cached from
+        // ohevc_ctx_stream stays ordered behind every picture, and the copy-back that follows goes out on the public stream
+        if (c->stream != c->stream_norm && c->stream_norm && (rc = select_stream(c, false)) != OHEVC_OK) return rc;
     }
     {
         std::lock_guard<std::mutex> g(c->store->m);

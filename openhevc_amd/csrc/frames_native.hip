@@ -409,12 +409,14 @@ struct ohevc_frames_transport {
     {
         for (int b = m->bands_imported; b <= upto; b++) {
             if (!part_complete(m, b)) { set_error("frames transport: band %d of picture %d did not arrive from rank %d within %d s", b, m->index, m->root, timeout_s); broken = true; return false; }
+            int r0[3], nr[3];
+            const void *base[3];
             for (int c = 0; c < 3; c++) {
-                const int r0 = m->row0[c][b], nr = m->row0[c][b + 1] - r0;
-                if (wire == OHEVC_FRAMES_WIRE_SOCKETS && nr &&
+                r0[c] = m->row0[c][b]; nr[c] = m->row0[c][b + 1] - r0[c]; base[c] = m->d_plane[c];
+                if (wire == OHEVC_FRAMES_WIRE_SOCKETS && nr[c] &&
                     hipMemcpy(static_cast<unsigned char *>(m->d_plane[c]) + m->band_off(c, b), m->h_plane[c] + m->band_off(c, b), m->band_bytes(c, b), hipMemcpyHostToDevice) != hipSuccess) return false;
-                if (ohevc_pic_import_rows(ctx, slot, c, r0, nr, m->d_plane[c], b == 0) != OHEVC_OK) return false;
             }
+            if (ohevc_pic_import_band(ctx, slot, r0, nr, base, b == 0) != OHEVC_OK) return false;      // three planes, one wait
             m->bands_imported = b + 1;
             stats.bands_imported++;
         }
@@ -436,12 +438,13 @@ static int cb_publish(void *user, int index, ohevc_ctx *ctx, int slot, const voi
     // band b leaves the picture store (and, sockets, the device) while band b - 1 is on the wire.  The export of band 0 is the one that waits
     // for the picture's device work and learns whether it failed: it runs BEFORE the motion-field message, which carries the error mark.
     auto export_band = [&](int b) {
-        for (int c = 0; c < 3; c++) {
-            const int r0 = m->row0[c][b], nr = m->row0[c][b + 1] - r0;
-            if (ohevc_pic_export_rows(ctx, slot, c, r0, nr, m->d_plane[c]) != OHEVC_OK) return false;
-            if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && nr &&
+        int r0[3], nr[3];
+        void *base[3];
+        for (int c = 0; c < 3; c++) { r0[c] = m->row0[c][b]; nr[c] = m->row0[c][b + 1] - r0[c]; base[c] = m->d_plane[c]; }
+        if (ohevc_pic_export_band(ctx, slot, r0, nr, base) != OHEVC_OK) return false;                    // three planes, one wait
+        for (int c = 0; c < 3; c++)
+            if (t->wire == OHEVC_FRAMES_WIRE_SOCKETS && nr[c] &&
                 hipMemcpy(m->h_plane[c] + m->band_off(c, b), static_cast<unsigned char *>(m->d_plane[c]) + m->band_off(c, b), m->band_bytes(c, b), hipMemcpyDeviceToHost) != hipSuccess) return false;
-        }
         return true;
     };
     bool bad = failed || !mvf;

@@ -27,10 +27,17 @@ const Config &config()
         if (const char *v = env("OHEVC_PICTURE_BATCH")) c.picture_batch = atoi(v);
         c.frames_token = env("OHEVC_FRAMES_TOKEN");
         if (const char *v = env("OHEVC_TRACE")) {
-            auto has = [v](const char *w) { const char *p = strstr(v, w); return p && (p == v || p[-1] == ',') && (p[strlen(w)] == 0 || p[strlen(w)] == ','); };
+            // whole comma-separated words only, every occurrence tried ("ctbdebug,ctb" has both; the first strstr hit alone would miss "ctb")
+            auto find = [v](const char *w, bool prefix) -> const char * {
+                const size_t n = strlen(w);
+                for (const char *p = strstr(v, w); p; p = strstr(p + 1, w))
+                    if ((p == v || p[-1] == ',') && (prefix || p[n] == 0 || p[n] == ',')) return p;
+                return nullptr;
+            };
+            auto has = [&](const char *w) { return find(w, false) != nullptr; };
             c.trace_order = has("order"); c.trace_timing = has("timing"); c.trace_ctb = has("ctb"); c.trace_levels = has("levels");
             c.trace_launches = has("launches"); c.trace_sao = has("sao"); c.trace_reg = has("reg"); c.profile_slots = has("slots"); c.ctb_debug = has("ctbdebug");
-            if (const char *at = strstr(v, "at=")) if (sscanf(at + 3, "%d:%d:%d", &c.trace_at[0], &c.trace_at[1], &c.trace_at[2]) != 3) c.trace_at[0] = -1;
+            if (const char *at = find("at=", true)) if (sscanf(at + 3, "%d:%d:%d", &c.trace_at[0], &c.trace_at[1], &c.trace_at[2]) != 3) c.trace_at[0] = -1;
         }
         return c;
     }();

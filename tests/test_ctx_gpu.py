@@ -180,3 +180,47 @@ def test_released_pieces_are_handed_out_again_zeroed():
     got = ctx.pic_download(live[0], shapes, np.uint8)
     assert all(np.array_equal(a, b) for a, b in zip(got, keep_planes)), "a neighbour's piece was touched by the recycling"
     ctx.close()
+
+
+def test_cached_stream_handle_is_ordered_behind_a_long_chain_picture(oracle):
+    """ohevc_ctx_stream is one handle for the context's life (include/ohevc_ctx.h).  A picture whose dependency levels reach
+    ohevc_debug_set_long_chain_levels is issued on the context's second, internal stream; its frame end joins the public stream again, so a
+    caller that cached the handle and synchronises on IT (not on ohevc_ctx_sync) reads finished pixels."""
+    import ctypes
+    import torch
+    if G.emulating():
+        pytest.skip("streams are synchronous in the emulator")
+    lib = L.load_library()
+    lib.ohevc_debug_set_long_chain_levels.argtypes = [ctypes.c_int]
+    bd, W, H = 8, 256, 256
+    rng = np.random.default_rng(77)
+    dims = X.chroma_dims(W, H)
+    cur0 = [rng.integers(0, 256, size=d).astype(np.uint8) for d in dims]
+    refs = [[rng.integers(0, 256, size=d).astype(np.uint8) for d in dims] for _ in range(2)]
+    ops, fops = S.gen_frame_ops(rng, W, H, bd, n_refs=2, intra_frac=0.9)
+    want = X.run_oracle(oracle, po, bd, W, H, [p.copy() for p in cur0], refs, ops, fops)
+    lib.ohevc_debug_set_long_chain_levels(1)                   # every picture with a level at all is a long chain
+    try:
+        ctx = L.Ctx(0)
+        handle = lib.ohevc_ctx_stream(ctx.h)
+        ext = torch.cuda.ExternalStream(handle)
+        ref_slots = []
+        for r in refs:
+            sl = ctx.pic_alloc(W, H, 1, bd); ctx.pic_upload(sl, r); ref_slots.append(sl)
+        for rep in range(6):                                   # the handle survives pictures on either stream
+            planes = [torch.from_numpy(p.copy()).cuda() for p in cur0]
+            torch.cuda.synchronize()
+            cur = ctx.pic_adopt(planes, W, H, 1, bd)
+            ctx.frame_begin(cur)
+            X.record_gpu(ctx, W, H, ref_slots, ops, fops)
+            ctx.frame_end()
+            assert lib.ohevc_ctx_stream(ctx.h) == handle
+            ext.synchronize()                                  # the CACHED handle, nothing else
+            got = [t.cpu().numpy() for t in planes]
+            for c in range(3):
+                assert np.array_equal(got[c], want[c]), f"pass {rep}, plane {c}: read unfinished pixels through the cached stream handle"
+            ctx.pic_release(cur)
+        assert ctx.stats()["launches"] > 0
+        ctx.close()
+    finally:
+        lib.ohevc_debug_set_long_chain_levels(96)

@@ -54,8 +54,24 @@ def worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+def free_port(span=96):
+    """a port p such that p .. p + span - 1 can all be bound right now (the sockets wire listens on port + rank; callers add small offsets per
+    case: a lone free port with a busy neighbour made a rank die at start-up once in a while)"""
+    for _ in range(200):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+        if p + span >= 65535:
+            continue
+        held = []
+        try:
+            for q in range(p, p + span):
+                t = socket.socket(); held.append(t); t.bind(("127.0.0.1", q))
+            return p
+        except OSError:
+            continue
+        finally:
+            for t in held:
+                t.close()
+    raise RuntimeError("no free port range")
 
 
 def test_plan_and_gop_structure():
@@ -273,7 +289,8 @@ def run_frames_hosts(exe, decoder_so, product_so, stream_file, world, wire, rend
     errs = [p.communicate(timeout=240)[1].decode(errors="replace") for p in procs]
     codes = [p.returncode for p in procs]
     merged, stats = {}, []
-    for out in outs:
+    for r, out in enumerate(outs):
+        assert os.path.exists(out), f"rank {r} left no output (exit code {codes[r]}): {errs[r][-1500:]}"
         for line in open(out):
             w = line.split()
             if w[0] == "stats":
