@@ -825,7 +825,7 @@ void ohhip_options_default(ohhip_options *o)
     o->defer_download = env_int("OHHIP_DEFER_DOWNLOAD", 1) != 0;
     o->pin_frames = env_int("OHHIP_PIN_FRAMES", 1) != 0;
     o->async_issue = env_int("OHHIP_ASYNC_ISSUE", 0);
-    o->record_only = env_str("OHHIP_RECORD_ONLY") != NULL;
+    o->record_only = env_str("OHHIP_RECORD_ONLY") ? (atoi(env_str("OHHIP_RECORD_ONLY")) == 2 ? 2 : 1) : 0;
     o->test_fail_index = env_int("OHHIP_TEST_FAIL_INDEX", -1);
     o->trace_path = env_str("OHHIP_TRACE_FRAMES");
     o->flush_intra_kib = env_int("OHHIP_FLUSH_INTRA_KIB", -1);
@@ -876,7 +876,7 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
     /* host-side profiling / host-logic tests without a device (include/ohevc_debug.h): record, produce no pixels.  A test may
      * have switched record-only mode on itself (and installed a frame sink) before opening the decoder: leave that alone. */
     if (o->record_only)
-        ohevc_debug_set_record_only(1);
+        ohevc_debug_set_record_only(o->record_only);
     if (o->base_layer && (o->base_layer->magic != OHHIP_MAGIC || !o->base_layer->root)) {
         fprintf(stderr, "ohhip: base_layer does not name a live back end\n");
         pthread_mutex_destroy(&be->lock);

@@ -157,7 +157,7 @@ static std::atomic<uint64_t> g_ctx_gen{1};
 //      its longest chain of dependent CTBs is short (sparse intra blocks: encoder-like inter pictures), the level form otherwise.
 // Pictures whose intra jobs name no CTB size always take the level form.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
-static bool g_record_only = false;   // ohevc_debug_set_record_only
+static int g_record_only = 0;        // ohevc_debug_set_record_only (2: record the DEVICE forms - maps instead of per-edge jobs - and drop them: profiling of the recording path on a box without a GPU)
 static int g_compact_coeffs = 1;     // ohevc_debug_set_compact_coeffs: 0 = every block crosses the bus whole (rounds 1-4; A/B and tests)
 extern "C" int ohevc_debug_set_compact_coeffs(int on) { g_compact_coeffs = on != 0; return OHEVC_OK; }
 static int g_fuse_intra = 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
@@ -229,6 +229,7 @@ struct Rec {
 
 struct ohevc_ctx : Rec {
     bool dry = false;                 // record-only profiling mode: no device, no pixels (ohevc_debug.h)
+    bool dry_as_device = false;       // ... that records what a context WITH a device records (ohevc_debug_set_record_only(2))
     std::vector<int16_t> dense_host;  // ohevc_debug_arena: the dense arena for host-side consumers of the recorded jobs
     int device = 0;
     hipStream_t stream = nullptr;     // where this context's frames are issued: stream_norm, or - pictures with long dependency chains - stream_long (select_stream)
@@ -483,6 +484,7 @@ extern "C" int ohevc_ctx_create_shared(ohevc_ctx **out, int device, ohevc_ctx *s
         ohevc_ctx *c = new ohevc_ctx();
         c->gen = g_ctx_gen.fetch_add(1);
         c->dry = true;
+        c->dry_as_device = share_with ? share_with->dry_as_device : g_record_only == 2;
         c->store = share_with ? share_with->store : std::make_shared<PicStore>();
         *out = c;
         return OHEVC_OK;
@@ -608,7 +610,7 @@ extern "C" int ohevc_ctx_get_option(const ohevc_ctx *c, int option)
 extern "C" int ohevc_debug_set_intra_chain(int on) { const int prev = g_intra_chain; g_intra_chain = on != 0; return prev; }
 extern "C" int ohevc_debug_set_intra_pack(int on) { const int prev = g_intra_pack; g_intra_pack = on != 0; return prev; }
 extern "C" int ohevc_debug_set_fuse_intra(int on) { const int prev = g_fuse_intra; g_fuse_intra = on != 0; return prev; }
-extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on != 0; return prev; }
+extern "C" int ohevc_debug_set_record_only(int on) { const int prev = g_record_only; g_record_only = on < 0 ? 0 : on > 2 ? 1 : on; return prev; }
 
 // ---- inspection of record-only contexts (ohevc_debug.h): host-logic tests without a GPU
 static ohevc_debug_sink g_sink = nullptr;
@@ -1747,7 +1749,7 @@ static int motion_grid_ready(ohevc_ctx *c, const Picture *p, int &gw, int &gh)
     c->grid_bs_off = grid_bytes; c->grid_bs_cap = bs_bytes;
     return OHEVC_OK;
 }
-extern "C" int ohevc_ctx_has_device(const ohevc_ctx *c) { return c && !c->dry; }
+extern "C" int ohevc_ctx_has_device(const ohevc_ctx *c) { return c && (!c->dry || c->dry_as_device); }
 extern "C" int ohevc_rec_sao_bulk(ohevc_ctx *c, const ohevc_sao_job *jobs, int n)
 {
     for (int i = 0; i < n; i++) { int rc = ohevc_rec_sao(c, jobs + i); if (rc != OHEVC_OK) return rc; }
@@ -2706,7 +2708,7 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
             st.issuer = new Issuer();
             st.issuer->device = c->device;
             st.issuer->store = &st;
-            static const int n_threads = 4;
+            const int n_threads = ohevc::config().issuer_threads;
             for (int k = 0; k < n_threads; k++) st.issuer->th.emplace_back(issuer_run, st.issuer);
         }
         is = st.issuer;

@@ -95,7 +95,8 @@ def _configure_hip_backend():
         prod.ohevc_debug_set_frame_sink(C.cast(sw.ohsw_sink, C.c_void_p), None)
         return sw
     prod.ohevc_debug_set_frame_sink(None, None)
-    prod.ohevc_debug_set_record_only(1 if os.environ.get("OHHIP_RECORD_ONLY") else 0)
+    ro = os.environ.get("OHHIP_RECORD_ONLY")
+    prod.ohevc_debug_set_record_only((2 if ro == "2" else 1) if ro else 0)
     return None
 
 

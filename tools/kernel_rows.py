@@ -346,6 +346,11 @@ def run(orc, po, only=None):
             except Exception as e:                       # a row that cannot run must not take the bench line with it
                 out[f"{name}_error"] = f"{type(e).__name__}: {e}"
             torch.cuda.empty_cache()
+    # the rest of the table (chroma / weighted MC, SAO band, chroma deblocking, small transforms, up-sampling, coefficient expansion, boundary
+    # strengths): tools/kernel_rows_more.py, same rules
+    if only is None or only == "more" or only.startswith("more:"):
+        import kernel_rows_more
+        kernel_rows_more.run(orc, po, out, None if only in (None, "more") else only[5:])
     return out
 
 
