@@ -75,7 +75,7 @@ int  ohevc_host_unpin(ohevc_ctx *ctx, void *ptr, size_t bytes);
  * move for tests).  OHEVC_OPT_LEVEL_LAUNCH: executor of the intra-coded blocks - 0 dependency levels (chain kernel; default), 1 all levels in one
  * launch, 2 chosen per picture, 3 CTB tasks; OHEVC_OPT_FILTERS_ON_DEVICE: 1 deblocking parameters derived on the device from the decoder's maps
  * (default), 0 one job per edge derived on the host. */
-enum { OHEVC_OPT_LEVEL_LAUNCH = 0, OHEVC_OPT_FILTERS_ON_DEVICE = 1 };
+enum { OHEVC_OPT_LEVEL_LAUNCH = 0, OHEVC_OPT_FILTERS_ON_DEVICE = 1, OHEVC_OPT_PARK_FRAMES = 2 };   /* PARK_FRAMES: 1 ohevc_frame_end_deferred may park, 0 (default: parking lost its A/B runs) it is ohevc_frame_end */
 int  ohevc_ctx_set_option(ohevc_ctx *ctx, int option, int value);
 int  ohevc_ctx_get_option(const ohevc_ctx *ctx, int option);
 /* Frame-parallel decoding across GPUs (one process per GPU; the reference's counterpart is the shared DPB of its frame threads,
@@ -188,6 +188,15 @@ int  ohevc_ctx_async_profile(ohevc_ctx *ctx, double *busy_seconds, long long *fr
  * complete-with-error, so that other contexts of the store that reference it -- they block until its frame end has been issued --
  * fail at once with OHEVC_ERR_STATE instead of timing out.  ohevc_frame_end does this itself when it returns an error. */
 int  ohevc_frame_abort(ohevc_ctx *ctx);
+
+/* ohevc_frame_end without the wait for other threads: if the frame end of every reference picture of the open frame has been issued (always so with
+ * one decoding thread) this IS ohevc_frame_end.  If not - frame threads: a picture predicts from one another thread is still parsing - the recorded
+ * frame is parked on the picture store and the call returns; the thread that issues the last missing reference issues the parked frame right
+ * behind it.  The picture's samples are complete where ohevc_pic_download* / ohevc_pic_export* deliver them (they wait, and help).  For callers that
+ * copy the picture back later (the sample hooks' deferred copy-back); a caller that needs the picture on the device when the call returns uses
+ * ohevc_frame_end.  Parking is an option of the context, OFF by default (ohevc_ctx_set_option(OHEVC_OPT_PARK_FRAMES, 1) / ohhip_options.park_frames switch
+ * it on): without it this call is ohevc_frame_end. */
+int  ohevc_frame_end_deferred(ohevc_ctx *ctx);
 
 /* statistics of the last ohevc_frame_end, for benches: launches issued, intra dependency levels, bytes uploaded */
 typedef struct ohevc_frame_stats {

@@ -64,6 +64,8 @@ int ohevc_debug_set_level_launch(int mode);
 /* 1 (default): in the levels form a block's residual rides with its intra job (ohevc_dev_intra_recon_batch: one launch per level); 0: two
  * launches per level.  Env OHEVC_FUSE_INTRA sets the initial value.  Returns the previous setting. */
 int ohevc_debug_set_fuse_intra(int on);
+long ohevc_debug_parked_total(void);          /* frame ends parked so far by ohevc_frame_end_deferred, process-wide */
+int ohevc_debug_set_park_frames(int on);     /* process default of OHEVC_OPT_PARK_FRAMES (0); returns the previous value */
 int ohevc_debug_set_record_only(int on);      /* 2: record the forms a context WITH a device records (filter maps instead of per-edge jobs) and drop them */
 /* 1 (default): the intra blocks of a dependency level go through the packed kernel (ohevc_dev_intra_recon_sorted: N lanes per block,
  * residual added in registers); 0: one wavefront per block (ohevc_dev_intra_recon_batch).  Pictures with constrained intra prediction

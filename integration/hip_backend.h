@@ -58,6 +58,9 @@ typedef struct ohhip_options {
                                            device picture store: the inter-layer reference picture is resampled on the device from the base-layer
                                            picture where it lies (hevc.c:2077-2099, hevc_filter.c:1377-1430).  Free the enhancement layer's back end
                                            before the base layer's.  (default NULL) */
+    int park_frames;         /* frame threads: 1: a frame end whose reference pictures have not been issued yet is parked instead of making the decoding
+                              * thread wait (ohevc_frame_end_deferred, ohevc_ctx.h; needs defer_download), 0: it waits; -1 (default): the library's
+                              * default (OHHIP_PARK_FRAMES) */
 } ohhip_options;
 
 void ohhip_options_default(ohhip_options *o);

@@ -832,6 +832,7 @@ void ohhip_options_default(ohhip_options *o)
     o->level_launch = env_int("OHHIP_LEVEL_LAUNCH", -1);
     o->device_filters = env_int("OHHIP_DEVICE_FILTERS", -1);
     o->crash_backtrace = env_str("OHHIP_BACKTRACE") != NULL;
+    o->park_frames = env_int("OHHIP_PARK_FRAMES", -1);
 }
 
 /* this instance's choices on a context it has made (the library's process-wide debug setters stay what they are: defaults for tests) */
@@ -839,6 +840,7 @@ static void apply_ctx_options(const ohhip_backend *be, ohevc_ctx *ctx)
 {
     ohevc_ctx_set_option(ctx, OHEVC_OPT_LEVEL_LAUNCH, be->opt.level_launch);
     ohevc_ctx_set_option(ctx, OHEVC_OPT_FILTERS_ON_DEVICE, be->opt.device_filters);
+    ohevc_ctx_set_option(ctx, OHEVC_OPT_PARK_FRAMES, be->opt.park_frames);
 }
 
 ohhip_backend *ohhip_backend_new(const ohhip_options *o)
@@ -1222,6 +1224,7 @@ static int frame_done(ohhip_backend *be)
     async = be->opt.async_issue > 0;
     if (async && ((t_s && t_s->decode_checksum_sei) || be->fm_on || !ohevc_ctx_has_device(t_ctx)))
         async = 0;
+    ohevc_ctx_set_option(t_ctx, OHEVC_OPT_PARK_FRAMES, be->fm_on ? 0 : be->opt.park_frames);      /* frames mode over processes exports the picture right below: no parking */
     st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame2(t_ctx, !be->opt.defer_download, &t_issued);
     if (async)
         __atomic_store_n(&be->async_used, 1, __ATOMIC_RELAXED);

@@ -108,6 +108,7 @@ struct Config {
     int ref_wait_seconds = 20;        // OHEVC_REF_WAIT_SECONDS: how long a frame thread waits for another thread's frame end before it gives up
     int prewarm_kib = 3072;           // OHEVC_PREWARM_KIB: first size of a context's upload buffers, touched when the context is made (0: off)
     int issuer_threads = 4;           // OHEVC_ISSUER_THREADS: threads that issue asynchronous frame ends (ohevc_frame_end_async), per picture store
+    int park_threads = 0;             // OHEVC_PARK_THREADS: issuer threads for PARKED frame ends (ohevc_frame_end_deferred); 0: the threads that unblock them issue them
     int picture_batch = 1;            // OHEVC_PICTURE_BATCH=0: every device picture its own allocation (AddressSanitizer / guard-page runs)
     const char *frames_token = nullptr;    // OHEVC_FRAMES_TOKEN: what the ranks of the sockets wire present to each other (set by the launcher)
     // OHEVC_TRACE=word[,word...]: diagnosis output on stderr

@@ -147,6 +147,9 @@ struct LevelBins {
 
 static void async_drain(PicStore &st);
 static void issuer_shutdown(PicStore &st);
+static void issuer_help(PicStore &st);
+static void settle_slot(ohevc_ctx *c, int slot);
+static inline Issuer *get_issuer(PicStore &st) { return __atomic_load_n(&st.issuer, __ATOMIC_ACQUIRE); }
 static std::atomic<uint64_t> g_ctx_gen{1};
 // executor of the intra-coded blocks (ohevc_debug_set_level_launch):
 //   0  one prediction launch and one residual launch per dependency level;   1  all levels inside one ohevc_dev_levels launch;
@@ -288,7 +291,7 @@ struct ohevc_ctx : Rec {
     int flushed_intra = 0;            // ohevc_frame_flush_intra: intra jobs of this frame already handed to the device by an early flush
     bool flush_closed = false;        // ... and no further early flush for this frame (it has inter prediction: its references may not be issued yet)
     int frame_mode = 0;               // the executor of the intra-coded blocks as chosen at frame_begin (one executor per picture)
-    int opt[2] = { -1, -1 };          // ohevc_ctx_set_option: OHEVC_OPT_LEVEL_LAUNCH, OHEVC_OPT_FILTERS_ON_DEVICE (-1: the process default)
+    int opt[3] = { -1, -1, -1 };          // ohevc_ctx_set_option: OHEVC_OPT_LEVEL_LAUNCH, OHEVC_OPT_FILTERS_ON_DEVICE, OHEVC_OPT_PARK_FRAMES (-1: the process default)
     int log2_ctb = 0;                 // CTB size named by the picture's intra jobs (0: none seen yet, -1: they disagree)
     std::vector<ohevc_ctb_task> ctb_tasks;                // scratch of frame_reconstruct
     std::vector<uint32_t> ctb_opwords, ctb_sync_zero;
@@ -296,6 +299,9 @@ struct ohevc_ctx : Rec {
 
     // asynchronous frame ends: an EXECUTOR context (owned by the store's issuer) takes over the recorded frame of a decoding thread's context
     bool is_exec = false, exec_busy = false;
+    bool parked = false;                                   // executor: the frame it holds was parked by ohevc_frame_end_deferred (statistics are added, not assigned)
+    ohevc_frame_stats parked_stats = {};                   // recording context: statistics of its parked frames issued since the last ohevc_frame_get_stats (stats_m)
+    long n_parked = 0;
     ohevc_ctx *async_from = nullptr;                       // the context the frame was recorded into (receives the statistics)
     std::vector<std::pair<int, uint32_t>> async_refs;      // (slot, version) of the reference pictures of the queued frame: it is issued once their frame ends are
     uint32_t my_gen = 0;                                   // version of the target picture this context is recording / executing
@@ -525,6 +531,8 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
 {
     if (!c) return;
     ohevc_tables_forget(c);
+    if (g_trace_timing && c->n_parked)
+        fprintf(stderr, "timing: ctx %p parked %ld of its frame ends (issued by the thread that issued their last missing reference)\n", (void *)c, c->n_parked);
     if (g_trace_timing && c->n_frames)
         fprintf(stderr, "timing: ctx %p %d frames: frame_end %.3f ms/frame of which waiting for reference frames %.3f ms; deblocking derived on the device in %d; "
                         "staging copies %.3f, reconstruction calls %.3f, filter calls %.3f (bs %.3f, vertical edges %.3f, horizontal edges %.3f, copy %.3f, SAO %.3f), "
@@ -598,14 +606,14 @@ extern "C" int ohevc_debug_set_level_launch(int mode) { return g_level_launch.ex
 // per-context choices (a decoder instance sets them on the contexts it makes; the process-wide debug setters only supply the defaults)
 extern "C" int ohevc_ctx_set_option(ohevc_ctx *c, int option, int value)
 {
-    OHEVC_REQUIRE(c != nullptr && (option == OHEVC_OPT_LEVEL_LAUNCH || option == OHEVC_OPT_FILTERS_ON_DEVICE), "unknown option");
+    OHEVC_REQUIRE(c != nullptr && (option == OHEVC_OPT_LEVEL_LAUNCH || option == OHEVC_OPT_FILTERS_ON_DEVICE || option == OHEVC_OPT_PARK_FRAMES), "unknown option");
     OHEVC_REQUIRE(option != OHEVC_OPT_LEVEL_LAUNCH || value <= 3, "level-launch mode 0..3");
     c->opt[option] = value < 0 ? -1 : value;
     return OHEVC_OK;
 }
 extern "C" int ohevc_ctx_get_option(const ohevc_ctx *c, int option)
 {
-    return c && (option == OHEVC_OPT_LEVEL_LAUNCH || option == OHEVC_OPT_FILTERS_ON_DEVICE) ? c->opt[option] : -1;
+    return c && (option == OHEVC_OPT_LEVEL_LAUNCH || option == OHEVC_OPT_FILTERS_ON_DEVICE || option == OHEVC_OPT_PARK_FRAMES) ? c->opt[option] : -1;
 }
 extern "C" int ohevc_debug_set_intra_chain(int on) { const int prev = g_intra_chain; g_intra_chain = on != 0; return prev; }
 extern "C" int ohevc_debug_set_intra_pack(int on) { const int prev = g_intra_pack; g_intra_pack = on != 0; return prev; }
@@ -806,6 +814,28 @@ extern "C" int ohevc_host_unpin(ohevc_ctx *c, void *ptr, size_t bytes)
 }
 
 // the three planes of a picture with ONE wait at the end (ohevc_pic_download waits per plane)
+// Wait (lk = the store's mutex, held) until the frame end of picture p has been ISSUED.  With parked frames in the store (ohevc_frame_end_deferred)
+// the waiting thread helps: it issues whatever parked frame has become ready - the picture it waits for may be one of them, or hang behind one.
+static bool wait_end_issued(ohevc_ctx *c, Picture &p, std::unique_lock<std::mutex> &lk)
+{
+    if (p.end_issued) return true;
+    PicStore &st = *c->store;
+    const double deadline = now_s() + g_ref_wait_s;
+    while (!p.end_issued) {
+        if (get_issuer(st) && !c->is_exec) {
+            lk.unlock();
+            issuer_help(st);
+            lk.lock();
+            if (p.end_issued) break;
+            st.cv.wait_for(lk, std::chrono::milliseconds(1));
+        } else {
+            st.cv.wait_for(lk, std::chrono::milliseconds(50));
+        }
+        if (!p.end_issued && now_s() > deadline) return false;
+    }
+    return true;
+}
+
 extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const host[3], const ptrdiff_t host_stride[3])
 {
     Picture *p = get_pic(c, slot);
@@ -813,7 +843,7 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
     if (c->dry) return OHEVC_OK;
     {
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+        if (!wait_end_issued(c, *p, lk)) {
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
@@ -840,7 +870,7 @@ extern "C" int ohevc_pic_download(ohevc_ctx *c, int slot, int plane, void *host,
     if (c->dry) return OHEVC_OK;
     {   // the picture may be reconstructed by another context of the store (another decoding thread), possibly not even issued yet
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+        if (!wait_end_issued(c, *p, lk)) {
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
@@ -869,7 +899,7 @@ extern "C" int ohevc_pic_export(ohevc_ctx *c, int slot, int plane, void *device_
     if (c->dry) return OHEVC_OK;
     {
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+        if (!wait_end_issued(c, *p, lk)) {
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
@@ -913,7 +943,7 @@ static int export_rows_impl(ohevc_ctx *c, int slot, int plane, int row0, int row
     if (c->dry || rows == 0) return OHEVC_OK;
     {
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+        if (!wait_end_issued(c, *p, lk)) {
             set_error("picture %d was never completed by its decoding thread", slot);
             return OHEVC_ERR_STATE;
         }
@@ -1028,7 +1058,7 @@ extern "C" int ohevc_pic_upsample(ohevc_ctx *c, int dst_slot, int src_slot, cons
     if (c->dry) return OHEVC_OK;
     {
         std::unique_lock<std::mutex> lk(c->store->m);
-        if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return sp->end_issued; })) {
+        if (!wait_end_issued(c, *sp, lk)) {
             set_error("base-layer picture %d was never completed by its decoding thread", src_slot);
             return OHEVC_ERR_STATE;
         }
@@ -1215,6 +1245,7 @@ extern "C" int ohevc_frame_begin(ohevc_ctx *c, int slot)
 {
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
+    if (!c->dry) settle_slot(c, slot);                  // parked frames that still read / write this slot's memory go first
     c->cur = slot;
     if (g_trace_order) fprintf(stderr, "order: ctx %p begins target %d\n", (void *)c, slot);
     {
@@ -1823,7 +1854,7 @@ static int guard_pictures(ohevc_ctx *c, int target)
         if (g_trace_order) fprintf(stderr, "order: ctx %p target %d needs ref %d (issued %d, event %p)\n", (void *)c, target, r, (int)rp.end_issued, (void *)rp.written);
         // (an executor context was taken from the issuer's queue because the versions of its references had been issued; `end_issued` may
         // already speak of a NEWER picture begun in the slot, whose work the issuer holds back until this reader has been issued)
-        if (!c->is_exec && !c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return rp.end_issued; })) {
+        if (!c->is_exec && !wait_end_issued(c, rp, lk)) {
             set_error("reference picture %d was never completed by its decoding thread", r);
             return OHEVC_ERR_STATE;
         }
@@ -2579,36 +2610,92 @@ static void swap_frame_state(ohevc_ctx &a, ohevc_ctx &b)
     std::swap(a.keep_motion_l2, b.keep_motion_l2); std::swap(a.grid_zeroed, b.grid_zeroed);      // (d_grid stays: it is only touched on its owner's stream)
 }
 
+// the first queued frame whose reference pictures have all had their frame ends issued (or failed) - taken off the queue - or nullptr (is->m held)
+static ohevc_ctx *issuer_take_ready_locked(Issuer *is)
+{
+    PicStore &st = *is->store;
+    ohevc_ctx *e = nullptr;
+    std::lock_guard<std::mutex> g(st.m);
+    for (size_t i = 0; i < is->queue.size() && !e; i++) {
+        const ohevc_ctx *q = is->queue[i];
+        bool ready = true;
+        for (const auto &r : q->async_refs) ready = ready && (int32_t)(st.pics[r.first].issued_gen - r.second) >= 0;
+        // ... and no frame submitted earlier still has to read (or write) the memory this one overwrites
+        // (a frame submitted earlier may also read THIS frame's picture - its thread finished parsing first: that one waits for us)
+        auto blocks = [&](const ohevc_ctx *k) {
+            if (k->cur == q->cur) return true;
+            for (const auto &r : k->async_refs) if (r.first == q->cur && (int32_t)(r.second - q->my_gen) < 0) return true;
+            return false;
+        };
+        for (size_t k = 0; k < i && ready; k++) ready = !blocks(is->queue[k]);
+        for (size_t k = 0; k < is->executing.size() && ready; k++) ready = !blocks(is->executing[k]);      // (other issuing threads)
+        if (ready) { e = is->queue[i]; is->queue.erase(is->queue.begin() + (long)i); }
+    }
+    return e;
+}
+
+// issue the frame end of executor context e (taken off the queue; the caller has put it into is->executing and counted it in in_flight)
+static void issuer_issue(Issuer *is, ohevc_ctx *e)
+{
+    PicStore &st = *is->store;
+    const double t0 = now_s();
+    e->ref_slots.clear();
+    e->target_guarded = false;
+    int rc = ohevc_frame_end(e);                   // (aborts and publishes the picture as failed on error)
+    Picture *p = get_pic(e, e->cur);
+    if (p && e->async_host[0]) {
+        hipEvent_t ev = nullptr;
+        if (rc == OHEVC_OK) {
+            ev = e->dl_ring[e->dl_next];
+            e->dl_next = (e->dl_next + 1) % 8;
+            for (int i = 0; i < 3 && rc == OHEVC_OK; i++) {
+                if (!e->async_host[i]) continue;
+                const ohevc_plane &pl = p->planes[i];
+                if (hipMemcpy2DAsync(e->async_host[i], e->async_stride[i], pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
+                                     hipMemcpyDeviceToHost, e->stream) != hipSuccess) { set_error("asynchronous copy-back failed: %s", hipGetErrorString(hipGetLastError())); rc = OHEVC_ERR_HIP; }
+            }
+            if (rc == OHEVC_OK && hipEventRecord(ev, e->stream) != hipSuccess) rc = OHEVC_ERR_HIP;
+        }
+        std::lock_guard<std::mutex> g(st.m);
+        p->host_copy = rc == OHEVC_OK ? ev : nullptr;
+        if (rc != OHEVC_OK) p->failed = true;
+        p->host_copy_issued = true;
+    }
+    st.cv.notify_all();
+    {
+        std::lock_guard<std::mutex> lk(is->m);
+        if (rc != OHEVC_OK && is->error == OHEVC_OK) { is->error = rc; snprintf(is->error_text, sizeof(is->error_text), "%s", ohevc_last_error()); }
+        if (e->async_from) {
+            ohevc_frame_stats done;
+            { std::lock_guard<std::mutex> g(e->stats_m); done = e->last_stats; }
+            std::lock_guard<std::mutex> g(e->async_from->stats_m);
+            if (e->parked) {                       // a parked frame: its numbers are ADDED to what the recording context reports next (ohevc_frame_get_stats)
+                ohevc_frame_stats &a = e->async_from->parked_stats;
+                a.launches += done.launches; a.upload_bytes += done.upload_bytes; a.n_tu += done.n_tu; a.n_mc += done.n_mc; a.n_intra += done.n_intra;
+                a.n_dbk += done.n_dbk; a.n_sao += done.n_sao; a.alg_bytes += done.alg_bytes; a.intra_levels = std::max(a.intra_levels, done.intra_levels);
+            } else {
+                e->async_from->last_stats = done;
+            }
+        }
+        e->exec_busy = false;
+        is->executing.erase(std::find(is->executing.begin(), is->executing.end(), e));
+        is->in_flight--;
+        is->busy_s += now_s() - t0;
+        is->frames++;
+    }
+    is->cv.notify_all();
+}
+
 static void issuer_run(Issuer *is)
 {
     (void)hipSetDevice(is->device);
-    PicStore &st = *is->store;
     for (;;) {
         ohevc_ctx *e = nullptr;
         {
             std::unique_lock<std::mutex> lk(is->m);
             for (;;) {
                 if (is->stop && is->queue.empty()) return;
-                // the first queued frame whose reference pictures have all had their frame ends issued (or failed)
-                {
-                    std::lock_guard<std::mutex> g(st.m);
-                    for (size_t i = 0; i < is->queue.size() && !e; i++) {
-                        const ohevc_ctx *q = is->queue[i];
-                        bool ready = true;
-                        for (const auto &r : q->async_refs) ready = ready && (int32_t)(st.pics[r.first].issued_gen - r.second) >= 0;
-                        // ... and no frame submitted earlier still has to read (or write) the memory this one overwrites
-                        // (a frame submitted earlier may also read THIS frame's picture - its thread finished parsing first: that one waits for us)
-                        auto blocks = [&](const ohevc_ctx *k) {
-                            if (k->cur == q->cur) return true;
-                            for (const auto &r : k->async_refs) if (r.first == q->cur && (int32_t)(r.second - q->my_gen) < 0) return true;
-                            return false;
-                        };
-                        for (size_t k = 0; k < i && ready; k++) ready = !blocks(is->queue[k]);
-                        for (size_t k = 0; k < is->executing.size() && ready; k++) ready = !blocks(is->executing[k]);      // (other issuer threads)
-                        if (ready) { e = is->queue[i]; is->queue.erase(is->queue.begin() + (long)i); }
-                    }
-                }
-                if (e) break;
+                if ((e = issuer_take_ready_locked(is)) != nullptr) break;
                 if (is->queue.empty()) { is->cv.wait(lk); continue; }
                 // frames are queued but none is ready: a reference is still being parsed by its thread.  Its submission wakes us; a thread
                 // that died would leave us here for ever, so the oldest frame gives up after the reference wait limit
@@ -2621,56 +2708,42 @@ static void issuer_run(Issuer *is)
             is->in_flight++;
             is->executing.push_back(e);
         }
-        const double t0 = now_s();
-        e->ref_slots.clear();
-        e->target_guarded = false;
-        int rc = ohevc_frame_end(e);                   // (aborts and publishes the picture as failed on error)
-        Picture *p = get_pic(e, e->cur);
-        if (p && e->async_host[0]) {
-            hipEvent_t ev = nullptr;
-            if (rc == OHEVC_OK) {
-                ev = e->dl_ring[e->dl_next];
-                e->dl_next = (e->dl_next + 1) % 8;
-                for (int i = 0; i < 3 && rc == OHEVC_OK; i++) {
-                    if (!e->async_host[i]) continue;
-                    const ohevc_plane &pl = p->planes[i];
-                    if (hipMemcpy2DAsync(e->async_host[i], e->async_stride[i], pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
-                                         hipMemcpyDeviceToHost, e->stream) != hipSuccess) { set_error("asynchronous copy-back failed: %s", hipGetErrorString(hipGetLastError())); rc = OHEVC_ERR_HIP; }
-                }
-                if (rc == OHEVC_OK && hipEventRecord(ev, e->stream) != hipSuccess) rc = OHEVC_ERR_HIP;
-            }
-            std::lock_guard<std::mutex> g(st.m);
-            p->host_copy = rc == OHEVC_OK ? ev : nullptr;
-            if (rc != OHEVC_OK) p->failed = true;
-            p->host_copy_issued = true;
-        }
-        st.cv.notify_all();
+        issuer_issue(is, e);
+    }
+}
+
+// A thread that has just issued a frame end (or parked one, or waits for one) issues every parked frame that has become ready: the store needs no
+// issuer threads of its own for frames parked by ohevc_frame_end_deferred - whoever unblocks a frame runs it.
+static void issuer_help(PicStore &st)
+{
+    Issuer *is = get_issuer(st);
+    if (!is) return;
+    if (!is->th.empty()) { is->cv.notify_all(); return; }      // the store has issuer threads of its own: they take what has become ready
+    for (;;) {
+        ohevc_ctx *e;
         {
             std::lock_guard<std::mutex> lk(is->m);
-            if (rc != OHEVC_OK && is->error == OHEVC_OK) { is->error = rc; snprintf(is->error_text, sizeof(is->error_text), "%s", ohevc_last_error()); }
-            if (e->async_from) {
-                ohevc_frame_stats done;
-                { std::lock_guard<std::mutex> g(e->stats_m); done = e->last_stats; }
-                std::lock_guard<std::mutex> g(e->async_from->stats_m);
-                e->async_from->last_stats = done;
-            }
-            e->exec_busy = false;
-            is->executing.erase(std::find(is->executing.begin(), is->executing.end(), e));
-            is->in_flight--;
-            is->busy_s += now_s() - t0;
-            is->frames++;
+            if (is->queue.empty() || is->stop) return;
+            if (!(e = issuer_take_ready_locked(is))) return;
+            is->in_flight++;
+            is->executing.push_back(e);
         }
-        is->cv.notify_all();
+        (void)hipSetDevice(is->device);
+        issuer_issue(is, e);
     }
 }
 
 // wait until every submitted frame end has been issued (not: executed)
 static void async_drain(PicStore &st)
 {
-    Issuer *is = st.issuer;
+    Issuer *is = get_issuer(st);
     if (!is) return;
-    std::unique_lock<std::mutex> lk(is->m);
-    is->cv.wait(lk, [&] { return is->queue.empty() && is->in_flight == 0; });
+    for (;;) {
+        issuer_help(st);                                   // (parked frames have no issuer thread of their own)
+        std::unique_lock<std::mutex> lk(is->m);
+        if (is->queue.empty() && is->in_flight == 0) return;
+        is->cv.wait_for(lk, std::chrono::milliseconds(is->th.empty() ? 1 : 20));
+    }
 }
 
 static void issuer_shutdown(PicStore &st)
@@ -2689,27 +2762,37 @@ static void issuer_shutdown(PicStore &st)
     for (ohevc_ctx *e : execs) ohevc_ctx_destroy(e);
 }
 
-extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const ptrdiff_t host_stride[3])
+// the reference pictures (slot, version) of the frame recorded in c (the decoder still holds them: the slots name the right versions)
+static void frame_refs(const ohevc_ctx *c, const PicStore &st, std::vector<std::pair<int, uint32_t>> &out)
 {
-    Picture *p = get_pic(c, c ? c->cur : -1);
-    OHEVC_REQUIRE(p != nullptr, "no frame begun");
-    OHEVC_REQUIRE(!c->is_exec, "executor contexts do not record");
-    if (c->dry) {                                       // record-only contexts have nothing to overlap
-        int rc = ohevc_frame_end(c);
-        return rc;
-    }
-    OHEVC_REQUIRE(!c->grid_zeroed, "a frame that keeps its motion (ohevc_frame_keep_motion) and was partly reconstructed ends with ohevc_frame_end");
+    out.clear();
+    for (const auto *v : {&c->mc, &c->mc_small})
+        for (const ohevc_mc_job &j : *v) {
+            const int refs[2] = {j.ref0, (j.flags & OHEVC_MC_BI) ? j.ref1 : -1};
+            for (int r : refs) {
+                if (r < 0 || r == c->cur) continue;
+                bool seen = false;
+                for (const auto &a : out) seen = seen || a.first == r;
+                if (!seen) out.emplace_back(r, st.pics[r].gen);
+            }
+        }
+}
+
+// hand the frame recorded in c to an executor context on the store's queue.  threads: dedicated issuer threads to start with the store's first
+// submission (0: none - parked frames are issued by the threads that unblock them, issuer_help)
+static int submit_frame(ohevc_ctx *c, void *const host[3], const ptrdiff_t host_stride[3], bool parked, int threads)
+{
+    Picture *p = get_pic(c, c->cur);
     PicStore &st = *c->store;
-    merge_side(c);                                      // the slice threads of this picture have been joined: fold their recorders in
     Issuer *is;
     {
         std::lock_guard<std::mutex> g(st.m);
         if (!st.issuer) {
-            st.issuer = new Issuer();
-            st.issuer->device = c->device;
-            st.issuer->store = &st;
-            const int n_threads = ohevc::config().issuer_threads;
-            for (int k = 0; k < n_threads; k++) st.issuer->th.emplace_back(issuer_run, st.issuer);
+            Issuer *n = new Issuer();
+            n->device = c->device;
+            n->store = &st;
+            for (int k = 0; k < threads; k++) n->th.emplace_back(issuer_run, n);
+            __atomic_store_n(&st.issuer, n, __ATOMIC_RELEASE);
         }
         is = st.issuer;
     }
@@ -2730,19 +2813,10 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
     }
     swap_frame_state(*c, *e);
     e->async_from = c;
-    e->async_refs.clear();
+    e->parked = parked;
     {
         std::lock_guard<std::mutex> g(st.m);                // the decoder still holds this frame's references: their slots name the right versions
-        for (const auto *v : {&e->mc, &e->mc_small})
-            for (const ohevc_mc_job &j : *v) {
-                const int refs[2] = {j.ref0, (j.flags & OHEVC_MC_BI) ? j.ref1 : -1};
-                for (int r : refs) {
-                    if (r < 0 || r == e->cur) continue;
-                    bool seen = false;
-                    for (const auto &a : e->async_refs) seen = seen || a.first == r;
-                    if (!seen) e->async_refs.emplace_back(r, st.pics[r].gen);
-                }
-            }
+        frame_refs(e, st, e->async_refs);
     }
     for (int i = 0; i < 3; i++) { e->async_host[i] = host ? host[i] : nullptr; e->async_stride[i] = host && host_stride ? host_stride[i] : 0; }
     {
@@ -2751,12 +2825,100 @@ extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const pt
         p->host_copy = nullptr;
     }
     c->stats = ohevc_frame_stats{};
+    if (parked) { std::lock_guard<std::mutex> g(c->stats_m); c->last_stats = ohevc_frame_stats{}; }
     {
         std::lock_guard<std::mutex> lk(is->m);
         is->queue.push_back(e);
     }
     is->cv.notify_all();
     return OHEVC_OK;
+}
+
+extern "C" int ohevc_frame_end_async(ohevc_ctx *c, void *const host[3], const ptrdiff_t host_stride[3])
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    OHEVC_REQUIRE(!c->is_exec, "executor contexts do not record");
+    if (c->dry) {                                       // record-only contexts have nothing to overlap
+        int rc = ohevc_frame_end(c);
+        return rc;
+    }
+    OHEVC_REQUIRE(!c->grid_zeroed, "a frame that keeps its motion (ohevc_frame_keep_motion) and was partly reconstructed ends with ohevc_frame_end");
+    merge_side(c);                                      // the slice threads of this picture have been joined: fold their recorders in
+    return submit_frame(c, host, host_stride, false, std::max(1, ohevc::config().issuer_threads));
+}
+
+// ohevc_frame_end that never makes the calling thread WAIT for other threads' frame ends.  The reference's frame threads block only on row progress
+// (pthread_frame.c:479-513); this back end needs no reference rows while it parses, but a picture's device work can only be ORDERED behind its
+// reference pictures' once their frame ends have been issued (their completion events must exist) - and in a random-access GOP the references are
+// the big pictures, still being parsed when the small ones that predict from them are done: at 16 frame threads a decoding thread spent 1-3 ms per
+// picture in that wait (OHEVC_TRACE=timing, profiles/r6f_*).  Here: if every reference has been issued, the frame is issued at once, on this
+// thread (the common case, and the only one with one decoding thread); if not, the recorded frame is PARKED - swapped into an executor context on
+// the store's queue - and the call returns.  Whoever issues the last missing reference issues the parked frame right behind it (issuer_help):
+// the work of the issue moves to the thread that made it possible, nobody waits, no extra threads.  A thread that needs the picture - the
+// application taking it out, a picture begun in a slot a parked frame still reads - helps and waits (wait_end_issued, settle_slot).
+// OFF by default: measured on the device at 16 frame threads (profiles/r6i_*, r6j_*, r6k_*) parking LOSES - encoder-like stream 3440 -> 2940 fps
+// steady, 2360-2690 -> 1670-1810 from a cold decoder, with helpers and with 1 / 2 / 4 issuer threads alike: the wait it removes was idle time of a
+// thread that had nothing else to do (the decoder hands it its next packet only in decoding order), while a parked frame costs an executor context
+// (streams, staging lanes, device buffers: a pool that has to warm up) and moves the issue onto the thread that parses the GOP's big pictures.
+static bool g_park_frames = false;         // ohevc_debug_set_park_frames
+static std::atomic<long> g_parked_total{0};
+extern "C" long ohevc_debug_parked_total(void) { return g_parked_total.load(std::memory_order_relaxed); }      // frames parked so far, process-wide (tests)
+extern "C" int ohevc_debug_set_park_frames(int on) { const int prev = g_park_frames; g_park_frames = on != 0; return prev; }
+extern "C" int ohevc_frame_end_deferred(ohevc_ctx *c)
+{
+    Picture *p = get_pic(c, c ? c->cur : -1);
+    OHEVC_REQUIRE(p != nullptr, "no frame begun");
+    const int park = c->opt[OHEVC_OPT_PARK_FRAMES] >= 0 ? c->opt[OHEVC_OPT_PARK_FRAMES] : (int)g_park_frames;
+    if (c->dry || c->is_exec || c->grid_zeroed || !park) return ohevc_frame_end(c);
+    PicStore &st = *c->store;
+    merge_side(c);
+    bool ready = true;
+    {
+        std::lock_guard<std::mutex> g(st.m);
+        frame_refs(c, st, c->async_refs);
+        for (const auto &r : c->async_refs) ready = ready && st.pics[r.first].end_issued;
+    }
+    c->async_refs.clear();
+    if (ready) {
+        const int rc = ohevc_frame_end(c);
+        issuer_help(st);                                // this picture may be what parked frames were waiting for
+        return rc;
+    }
+    const int rc = submit_frame(c, nullptr, nullptr, true, ohevc::config().park_threads);
+    if (rc != OHEVC_OK) return rc;
+    c->n_parked++;
+    g_parked_total.fetch_add(1, std::memory_order_relaxed);
+    issuer_help(st);                                    // (the missing reference may have been issued between the look above and the push)
+    return OHEVC_OK;
+}
+
+// A picture is about to be begun in (uploaded into, released from) `slot`: frames still on the store's queue that read or write that slot's memory
+// must be issued first - their completion events are what orders the new work behind them (a parked frame has returned from its frame end, so the
+// decoder may recycle the pictures it read).
+static void settle_slot(ohevc_ctx *c, int slot)
+{
+    PicStore &st = *c->store;
+    Issuer *is = get_issuer(st);
+    if (!is || c->is_exec) return;
+    const double deadline = now_s() + g_ref_wait_s;
+    for (;;) {
+        bool busy = false;
+        {
+            std::lock_guard<std::mutex> lk(is->m);
+            auto touches = [&](const ohevc_ctx *q) {
+                if (q->cur == slot) return true;
+                for (const auto &r : q->async_refs) if (r.first == slot) return true;
+                return false;
+            };
+            for (const ohevc_ctx *q : is->queue) busy = busy || touches(q);
+            for (const ohevc_ctx *q : is->executing) busy = busy || touches(q);
+        }
+        if (!busy || now_s() > deadline) return;
+        issuer_help(st);
+        std::unique_lock<std::mutex> lk(is->m);
+        is->cv.wait_for(lk, std::chrono::microseconds(200));
+    }
 }
 
 // the application takes the picture out: its samples are in the planes given to ohevc_frame_end_async when this returns OHEVC_OK
@@ -2878,7 +3040,7 @@ extern "C" int ohevc_debug_wait_picture(ohevc_ctx *c, int slot)
     Picture *p = get_pic(c, slot);
     OHEVC_REQUIRE(p != nullptr, "bad picture slot");
     std::unique_lock<std::mutex> lk(c->store->m);
-    if (!c->store->cv.wait_for(lk, std::chrono::seconds(g_ref_wait_s), [&] { return p->end_issued; })) {
+    if (!wait_end_issued(c, *p, lk)) {
         set_error("picture %d was never completed by its decoding thread", slot);
         return OHEVC_ERR_STATE;
     }
@@ -2890,5 +3052,10 @@ extern "C" int ohevc_frame_get_stats(ohevc_ctx *c, ohevc_frame_stats *out)
     OHEVC_REQUIRE(c != nullptr && out != nullptr, "bad argument");
     std::lock_guard<std::mutex> g(c->stats_m);
     *out = c->last_stats;
+    // frames this context parked that have been issued since the last call: their numbers are reported with this one (sums over a run stay exact)
+    const ohevc_frame_stats &a = c->parked_stats;
+    out->launches += a.launches; out->upload_bytes += a.upload_bytes; out->n_tu += a.n_tu; out->n_mc += a.n_mc; out->n_intra += a.n_intra;
+    out->n_dbk += a.n_dbk; out->n_sao += a.n_sao; out->alg_bytes += a.alg_bytes; out->intra_levels = std::max(out->intra_levels, a.intra_levels);
+    c->parked_stats = ohevc_frame_stats{};
     return OHEVC_OK;
 }

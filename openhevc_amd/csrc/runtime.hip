@@ -25,6 +25,7 @@ const Config &config()
         if (const char *v = env("OHEVC_REF_WAIT_SECONDS")) if (atoi(v) > 0) c.ref_wait_seconds = atoi(v);
         if (const char *v = env("OHEVC_PREWARM_KIB")) c.prewarm_kib = atoi(v);
         if (const char *v = env("OHEVC_PICTURE_BATCH")) c.picture_batch = atoi(v);
+        if (const char *v = env("OHEVC_PARK_THREADS")) if (atoi(v) >= 0 && atoi(v) <= 16) c.park_threads = atoi(v);
         if (const char *v = env("OHEVC_ISSUER_THREADS")) if (atoi(v) >= 1 && atoi(v) <= 16) c.issuer_threads = atoi(v);
         c.frames_token = env("OHEVC_FRAMES_TOKEN");
         if (const char *v = env("OHEVC_TRACE")) {

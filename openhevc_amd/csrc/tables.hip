@@ -819,7 +819,8 @@ static int end_frame_common(ohevc_ctx *ctx, int download, bool async, double *is
         const ptrdiff_t strides[3] = { hp.linesize[0], hp.linesize[1], hp.linesize[2] };
         return ohevc_frame_end_async(ctx, download ? host : nullptr, strides);
     }
-    rc = ohevc_frame_end(ctx);
+    // no copy-back inside this call: the frame may be parked instead of making this thread wait for other threads' frame ends (ohevc_ctx.h)
+    rc = download ? ohevc_frame_end(ctx) : ohevc_frame_end_deferred(ctx);
     if (issued_at) {
         struct timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);

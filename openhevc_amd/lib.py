@@ -339,7 +339,7 @@ def dev_upsample_plane(dst_tensor, src_tensor, bit_depth, chroma, cols_ptr, col_
                                                   C.c_void_p(rows_ptr), C.c_int(src_cols), C.c_int(src_rows), C.c_void_p(stream)))
 
 
-EXPORTED_SYMBOLS += ["ohevc_pic_export_band", "ohevc_pic_import_band", "ohevc_upsample_make_maps", "ohevc_dev_upsample_plane", "ohevc_pic_upsample", "ohevc_tables_upsample_frame", "ohevc_ctx_set_concurrent", "ohevc_tables_host_planes", "ohevc_tables_derive_filters"]
+EXPORTED_SYMBOLS += ["ohevc_frame_end_deferred", "ohevc_debug_set_park_frames", "ohevc_debug_parked_total", "ohevc_pic_export_band", "ohevc_pic_import_band", "ohevc_upsample_make_maps", "ohevc_dev_upsample_plane", "ohevc_pic_upsample", "ohevc_tables_upsample_frame", "ohevc_ctx_set_concurrent", "ohevc_tables_host_planes", "ohevc_tables_derive_filters"]
 
 
 class Ctx:

@@ -234,6 +234,30 @@ def test_emu_two_decoders_with_different_options_in_one_process():
     _instances().two_decoders_with_different_options("hipemu")
 
 
+@pytest.mark.parametrize("park_threads", [0, 2], ids=["helpers", "issuer_threads"])
+def test_emu_parked_frame_ends_with_frame_threads(park_threads, monkeypatch):
+    """ohhip_options.park_frames = 1 (ohevc_frame_end_deferred, include/ohevc_ctx.h; off by default - it lost its A/B runs on the device): a frame end
+    whose reference pictures have not been issued yet is parked and issued by the thread that issues the last of them (or by the store's issuer
+    threads).  Every picture must still be the untouched decoder's, and frames must really have been parked."""
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    from test_stream_cpu import frames_md5, load_golden
+    monkeypatch.setenv("OHHIP_PARK_FRAMES", "1")
+    if park_threads:
+        monkeypatch.setenv("OHEVC_PARK_THREADS", str(park_threads))      # (read once per process: effective when this test is the first to make a store park)
+    with ps.Decoder("hipemu") as d:
+        product = d.product_lib()
+    import ctypes
+    product.ohevc_debug_parked_total.restype = ctypes.c_long
+    before = product.ohevc_debug_parked_total()
+    for name in ("ra_8b_ctb64", "ra_10b_odd", "ldb_10b", "ra_8b_foll_leaf", "weighted"):
+        aus, md5 = load_golden(name)
+        for threads in (4, 6):
+            assert frames_md5(ps.decode_stream("hipemu", aus, threads, 1)) == md5, f"{name} with {threads} frame threads and parked frame ends"
+    assert product.ohevc_debug_parked_total() > before, "no frame end was parked: the test did not exercise ohevc_frame_end_deferred"
+
+
 def test_emu_options_structs_carry_their_size_first():
     _instances().options_struct_size_rule("hipemu")
     _instances().frames_mode_struct_size_rule("hipemu")
