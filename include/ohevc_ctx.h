@@ -51,6 +51,11 @@ int  ohevc_ctx_set_concurrent(ohevc_ctx *ctx, int on);
 void *ohevc_ctx_stream(ohevc_ctx *ctx);
 int  ohevc_ctx_sync(ohevc_ctx *ctx);
 
+/* A picture store holds at most OHEVC_MAX_PICTURES pictures (ohevc_pic_alloc / ohevc_pic_adopt fail with OHEVC_ERR_ARG beyond: a reference slot is one
+ * byte of a motion-compensation job, and the tables of the layers above are sized by it); picture sides are at most 65535 samples (16-bit job
+ * coordinates).  HEVC needs 17 per layer (a DPB of 16 + the current picture). */
+enum { OHEVC_MAX_PICTURES = 127 };
+
 /* ---- picture store: pixel planes of DPB entries, resident in HBM for the life of the HEVCFrame (hevc_refs.c:75-147) */
 int  ohevc_pic_alloc(ohevc_ctx *ctx, int width, int height, int chroma_format_idc, int bit_depth);   /* slot >= 0 or error */
 /* register planes allocated by someone else (e.g. tensors an RCCL broadcast writes into) as a picture; never freed by ctx */

@@ -124,8 +124,14 @@ typedef struct ohevc_mc_job {           /* 32 bytes */
  * hevcdsp_template.c:271-277,288-291).  One record per piece of the compact stream, offsets and sizes in int16 elements:
  *   kind 0     : dims elements copied as they are (whole blocks; dims a multiple of 16, at most 1024);
  *   kind 3,4,5 : an (1 << kind)-sample block; its compact form is rows rows of cols coefficients (dims = cols | rows << 8, multiples of 4),
- *                everything else of the block is written as zero.
- * src: offset in the compact stream (a multiple of 4), dst: offset of the block in the dense arena (a multiple of 16). */
+ *                everything else of the block is written as zero;
+ *   kind 0x100 | log2 | part << 9 (log2 3..5): the SUB-BLOCK form - only the 4x4 coefficient groups that hold a non-zero coefficient travel (the
+ *                coded sub-blocks of residual coding, hevc_cabac.c:1832-1841: at qp22-like density 42 % of a picture's coefficient volume where
+ *                the rectangles keep 61 %), 16 elements each (4 rows of 4), in raster order of the groups; dims = one bit per group of the
+ *                record's region, bit gy * (N / 4) + gx.  part 0: the whole block (log2 3, 4) / rows 0..15 of a 32x32 block, 1: rows 16..31 of a
+ *                32x32 block (dst = the block's offset + 512), 2: a whole 32x32 block whose rows 16..31 are zero (the mask covers rows 0..15).
+ *                Groups without a bit are written as zero.
+ * src: offset in the compact stream (a multiple of 4), dst: offset in the dense arena (a multiple of 16). */
 typedef struct ohevc_expand_rec { uint32_t src, dst, dims, kind; } ohevc_expand_rec;
 int ohevc_dev_expand_coeffs(const int16_t *compact, const ohevc_expand_rec *recs, int nrecs, int16_t *dense, void *stream);
 

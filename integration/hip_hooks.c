@@ -38,7 +38,7 @@
  * instance; the hooks reach it through the decoder context they are handed (s->avctx->opaque: pthread_frame.c:276 copies it into every
  * frame-thread context) after checking it against the registry of live back ends.  File scope keeps only: that registry, the process
  * default for decoders nobody attached a back end to, and process-wide profiling counters. */
-#define MAX_BUFS 120
+#define MAX_BUFS OHEVC_MAX_PICTURES      /* frame buffers of one decoder = pictures of its store (ohevc_ctx.h): the store's limit, not a second one */
 #define MAX_TRACE 8192
 typedef struct ohhip_buf {
     const uint8_t *data0;
@@ -60,7 +60,8 @@ struct ohhip_backend {
     unsigned           id;             /* never reused: thread-local caches name (pointer, id) */
     ohhip_options      opt;
     ohevc_ctx         *root;           /* owns the picture store; one context per decoding thread shares it (ohevc_ctx_create_shared) */
-    ohevc_ctx         *all[128];
+    ohevc_ctx        **all;                      /* every per-thread context this instance made (grows) */
+    int                cap_all;
     int                nall;
     ohevc_ctx         *spare[64];      /* contexts made at attach time, one per decoding thread the decoder will start: a context is a stream,
                                           events and page-locked buffers - milliseconds of driver calls that would otherwise sit in front of
@@ -182,16 +183,21 @@ static ohevc_ctx *new_thread_ctx(ohhip_backend *be)
     }
     apply_ctx_options(be, ctx);
     pthread_mutex_lock(&be->lock);
-    if (be->nall < 128) {
-        be->all[be->nall++] = ctx;
-        pthread_mutex_unlock(&be->lock);
-        return ctx;
+    if (be->nall == be->cap_all) {
+        const int cap = be->cap_all ? 2 * be->cap_all : 32;
+        ohevc_ctx **grown = realloc(be->all, (size_t)cap * sizeof(*grown));
+        if (!grown) {                           /* a context the instance cannot list would never be destroyed: fail instead */
+            pthread_mutex_unlock(&be->lock);
+            ohevc_ctx_destroy(ctx);
+            fprintf(stderr, "ohhip: out of memory listing a per-thread context\n");
+            return NULL;
+        }
+        be->all = grown;
+        be->cap_all = cap;
     }
+    be->all[be->nall++] = ctx;
     pthread_mutex_unlock(&be->lock);
-    /* a context the instance cannot list would never be destroyed: fail instead (128 contexts = 128 threads recording into one decoder) */
-    ohevc_ctx_destroy(ctx);
-    fprintf(stderr, "ohhip: more than 128 per-thread contexts for one decoder instance\n");
-    return NULL;
+    return ctx;
 }
 
 static ohevc_ctx *thread_ctx(ohhip_backend *be)
@@ -317,8 +323,12 @@ static int slot_of_frame_locked(ohhip_backend *be, ohevc_ctx *ctx, const HEVCCon
     if (i == be->nbufs) {
         slot = be->nbufs < MAX_BUFS ? ohevc_pic_alloc(ctx, s->sps->width, s->sps->height, cfmt, s->sps->bit_depth) : -1;
         if (slot < 0) {
+            const int full = be->nbufs >= MAX_BUFS;
             pthread_mutex_unlock(&be->lock);
-            fprintf(stderr, "ohhip: pic_alloc failed: %s\n", ohevc_last_error());
+            if (full)
+                fprintf(stderr, "ohhip: the decoder holds %d frame buffers: more than a picture store takes (OHEVC_MAX_PICTURES)\n", MAX_BUFS);
+            else
+                fprintf(stderr, "ohhip: pic_alloc failed: %s\n", ohevc_last_error());
             note_error(be);
             return -1;
         }
@@ -1035,6 +1045,7 @@ void ohhip_backend_free(ohhip_backend *be)
         }
     for (i = 0; i < be->nall; i++)
         ohevc_ctx_destroy(be->all[i]);
+    free(be->all);
     if (be->root)
         ohevc_ctx_destroy(be->root);
     for (k = 0; k < 4; k++)

@@ -61,7 +61,7 @@ struct Issuer {
 };
 
 // The device picture store = the decoded picture buffer.  One per ohevc_ctx_create, shared by ohevc_ctx_create_shared.
-constexpr int kMaxPics = 127;
+constexpr int kMaxPics = OHEVC_MAX_PICTURES;      // (ohevc_ctx.h; every per-slot table below and in tables.hip / hip_hooks.c is sized by it)
 struct PicStore {
     std::mutex m;
     std::condition_variable cv;           // signalled when a picture's end_issued turns true
@@ -161,8 +161,8 @@ static std::atomic<uint64_t> g_ctx_gen{1};
 // Pictures whose intra jobs name no CTB size always take the level form.
 void ohevc_mc_forget_stream(void *stream);      // mc_kernels.hip: per-stream scratch of the MC redo pass
 static int g_record_only = 0;        // ohevc_debug_set_record_only (2: record the DEVICE forms - maps instead of per-edge jobs - and drop them: profiling of the recording path on a box without a GPU)
-static int g_compact_coeffs = 1;     // ohevc_debug_set_compact_coeffs: 0 = every block crosses the bus whole (rounds 1-4; A/B and tests)
-extern "C" int ohevc_debug_set_compact_coeffs(int on) { g_compact_coeffs = on != 0; return OHEVC_OK; }
+static int g_compact_coeffs = 2;     // ohevc_debug_set_compact_coeffs: 2 = the non-zero 4x4 groups of an inverse-DCT block travel (round 6), 1 = its col_limit rectangle (round 5), 0 = every block whole (rounds 1-4; A/B and tests)
+extern "C" int ohevc_debug_set_compact_coeffs(int on) { g_compact_coeffs = on < 0 ? 0 : on > 2 ? 2 : on; return OHEVC_OK; }
 static int g_fuse_intra = 1;   // ohevc_debug_set_fuse_intra: a block's residual runs in its prediction's wavefront
 static std::atomic<int> g_level_launch{0};      // ohevc_debug_set_level_launch (the sample hooks set it, to the same value, from every decoder that is opened: atomic)
 // The widest level a chain takes.  Inside the chain kernel a level costs ~2 us plus ~1.5 us per further pass of its 8-wavefront workgroup; as a
@@ -226,7 +226,7 @@ struct Rec {
     int nstat[5] = {};                // tu, mc, intra, dbk, sao calls
     int64_t alg = 0;                  // algorithmic bytes of the recorded jobs (ohevc_frame_stats.alg_bytes)
     struct { int level = -1, index = 0, plane = 0, x = 0, y = 0, log2 = 0; } last_intra;   // the most recent intra job of this recorder (levels form)
-    int16_t reach[128];               // [reference slot]: the deepest LUMA row of that picture the recorded motion compensation reads, -1: none (ohevc_frame_ref_reach)
+    int16_t reach[OHEVC_MAX_PICTURES + 1];               // [reference slot]: the deepest LUMA row of that picture the recorded motion compensation reads, -1: none (ohevc_frame_ref_reach)
     Rec() { for (int16_t &v : reach) v = -1; }
 };
 
@@ -447,17 +447,29 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
 // pool: long chains get up to four queues of their own and leave the regular ones to the short frames.
 // ohevc_debug_set_long_chain_levels: a frame whose recorded dependency levels reach this many goes to the long-chain stream (0: never).
 static int g_long_chain_levels = 96;
-static int g_long_chain_pools = 2;       // ohevc_debug_set_long_chain_pools (1: the highest priority only)
-extern "C" int ohevc_debug_set_long_chain_pools(int n) { g_long_chain_pools = n < 1 ? 1 : n > 2 ? 2 : n; return OHEVC_OK; }
+static int g_long_chain_pools = 2;       // ohevc_debug_set_long_chain_pools (1: the highest priority only; 3: a hardware queue of its own per context, below)
+extern "C" int ohevc_debug_set_long_chain_pools(int n) { g_long_chain_pools = n < 1 ? 1 : n > 3 ? 3 : n; return OHEVC_OK; }
 extern "C" int ohevc_debug_set_long_chain_levels(int levels) { g_long_chain_levels = levels < 0 ? 0 : levels; return OHEVC_OK; }
 static int select_stream(ohevc_ctx *c, bool long_chain)
 {
     if (long_chain && !c->stream_long) {
-        int least = 0, greatest = 0;
-        OHEVC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // (contexts alternate between the highest and the lowest priority: two more pools, eight hardware queues for long chains)
-        static std::atomic<unsigned> n_long{0};
-        OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, (n_long.fetch_add(1) & 1u) && g_long_chain_pools > 1 ? least : greatest));
+        if (g_long_chain_pools == 3) {
+            // A stream created with a compute-unit mask is given a hardware queue of ITS OWN by the runtime (not one of the four the streams of a
+            // priority share): with every unit enabled the mask restricts nothing, but sixteen decoding threads' long chains - one workgroup
+            // each, milliseconds long - then run sixteen at a time instead of eight (two priority pools of four queues, the round-5 form).
+            hipDeviceProp_t prop;
+            OHEVC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+            const unsigned words = ((unsigned)prop.multiProcessorCount + 31u) / 32u;
+            std::vector<uint32_t> mask(words ? words : 1u, 0xffffffffu);
+            if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+            OHEVC_HIP_TRY(hipExtStreamCreateWithCUMask(&c->stream_long, (uint32_t)mask.size(), mask.data()));
+        } else {
+            int least = 0, greatest = 0;
+            OHEVC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            // (contexts alternate between the highest and the lowest priority: two more pools, eight hardware queues for long chains)
+            static std::atomic<unsigned> n_long{0};
+            OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, (n_long.fetch_add(1) & 1u) && g_long_chain_pools > 1 ? least : greatest));
+        }
         store_add_stream(*c->store, c->stream_long);
     }
     hipStream_t want = long_chain ? c->stream_long : c->stream_norm;
@@ -1018,7 +1030,7 @@ extern "C" int ohevc_pic_import_band(ohevc_ctx *c, int slot, const int row0[3], 
 // The deepest luma row of reference picture `slot` that the motion compensation recorded for the open frame reads (-1: none of it).
 extern "C" int ohevc_frame_ref_reach(ohevc_ctx *c, int slot)
 {
-    if (!c || slot < 0 || slot >= 128) return -1;
+    if (!c || slot < 0 || slot > OHEVC_MAX_PICTURES) return -1;
     int reach = c->reach[slot];
     if (!c->side.empty()) {
         std::lock_guard<std::mutex> g(c->side_m);
@@ -1298,11 +1310,36 @@ static inline bool rec_levels(const ohevc_ctx *c) { return c->frame_mode != 3 ||
 
 // one N x N block into the recorder's arena; returns its offset in the DENSE arena.  cols / rows: the rectangle that can hold non-zero
 // coefficients (multiples of 4; N x N = everything)
-static inline uint32_t arena_put(Rec &r, const int16_t *coeffs, int log2, int cols, int rows)
+static inline uint32_t arena_put(Rec &r, const int16_t *coeffs, int log2, int cols, int rows, bool groups = false)
 {
     const int n = 1 << log2;
     const uint32_t dst = r.dense, src = (uint32_t)r.coeffs.size();
     r.dense += (uint32_t)(n * n);
+    if (log2 >= 3 && groups) {
+        // the sub-block form (ohevc_hip.h): the 4x4 groups of the rectangle that hold a non-zero coefficient, 16 elements each, and one bit per group
+        const int gpr = n >> 2, gcols = cols >> 2, parts = (log2 == 5 && rows > 16) ? 2 : 1, grows_all = rows >> 2;
+        for (int part = 0; part < parts; part++) {
+            const int gy0 = part * 4, gy1 = std::min(grows_all, log2 == 5 ? gy0 + 4 : gpr);
+            const uint32_t at = (uint32_t)r.coeffs.size();
+            r.coeffs.resize((size_t)at + (size_t)(gy1 - gy0) * gcols * 16);
+            int16_t *d = r.coeffs.data() + at;
+            uint32_t mask = 0;
+            for (int gy = gy0; gy < gy1; gy++)
+                for (int gx = 0; gx < gcols; gx++) {
+                    const int16_t *g4 = coeffs + (size_t)(gy * 4) * n + gx * 4;
+                    uint64_t q[4];
+                    for (int k = 0; k < 4; k++) memcpy(&q[k], g4 + (size_t)k * n, 8);
+                    if (!(q[0] | q[1] | q[2] | q[3])) continue;
+                    memcpy(d, q, 32);
+                    d += 16;
+                    mask |= 1u << ((gy - gy0) * gpr + gx);
+                }
+            r.coeffs.resize((size_t)(d - r.coeffs.data()));
+            const uint32_t code = log2 != 5 ? 0u : parts == 2 ? (uint32_t)part : 2u;
+            r.expand.push_back(ohevc_expand_rec{ at, dst + (uint32_t)part * 512u, mask, 0x100u | (uint32_t)log2 | (code << 9) });
+        }
+        return dst;
+    }
     if (log2 >= 3 && (cols < n || rows < n)) {
         r.coeffs.resize((size_t)src + (size_t)cols * rows);
         int16_t *d = r.coeffs.data() + src;
@@ -1351,7 +1388,7 @@ static int rec_tu_impl(ohevc_ctx *c, int plane, int x, int y, int log2, int kind
     } else {
         // (the caller's buffer is reused by the next TU: copied now).  Only the plain inverse DCT has a known-zero remainder.
         const bool limited = kind == OHEVC_TU_IDCT && g_compact_coeffs;
-        j.coeff_off = arena_put(r, coeffs, log2, limited ? std::min(n, (cols + 3) & ~3) : n, limited ? std::min(n, (rows + 3) & ~3) : n);
+        j.coeff_off = arena_put(r, coeffs, log2, limited ? std::min(n, (cols + 3) & ~3) : n, limited ? std::min(n, (rows + 3) & ~3) : n, limited && g_compact_coeffs == 2);
     }
     // `intra`: the block MAY have been predicted by an intra job of this picture (the table slots cannot tell and always say so): the
     // level map knows -- 0 = no intra job covered it: the residual of an inter block (or PCM samples), level 0
@@ -1447,7 +1484,7 @@ extern "C" int ohevc_rec_mc(ohevc_ctx *c, const ohevc_mc_job *job)
         auto note = [&](int slot, int sy) {
             int row = ((sy + job->h + below) << vs) + vs;
             row = row < 0 ? 0 : row > 32767 ? 32767 : row;
-            if ((unsigned)slot < 128u && row > r.reach[slot]) r.reach[slot] = (int16_t)row;
+            if ((unsigned)slot <= (unsigned)OHEVC_MAX_PICTURES && row > r.reach[slot]) r.reach[slot] = (int16_t)row;
         };
         note(job->ref0, job->sy0);
         if (job->flags & OHEVC_MC_BI) note(job->ref1, job->sy1);
@@ -1666,26 +1703,30 @@ extern "C" int ohevc_rec_deblock_bulk(ohevc_ctx *c, const ohevc_dbk_job *jobs, i
 }
 // The deblocking of the current picture, handed over as the decoder's own maps (ohevc_hip.h, ohevc_dbk_maps): copied here (the
 // decoder reuses its arrays for the next picture), uploaded with the frame end's job arrays, derived and filtered on the device.
-extern "C" int ohevc_rec_deblock_maps(ohevc_ctx *c, const ohevc_dbk_maps *m)
+static int rec_deblock_maps_impl(ohevc_ctx *c, const ohevc_dbk_maps *m, bool with_bs);
+extern "C" int ohevc_rec_deblock_maps(ohevc_ctx *c, const ohevc_dbk_maps *m) { return rec_deblock_maps_impl(c, m, true); }
+// with_bs false: the two boundary-strength arrays are derived on the device (ohevc_rec_deblock_maps_bs) - they do not travel (they used to, as
+// 2 x 133 KB of zeros per 1080p picture: a quarter of an encoder-like picture's upload)
+static int rec_deblock_maps_impl(ohevc_ctx *c, const ohevc_dbk_maps *m, bool with_bs)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && m != nullptr, "no frame begun");
-    OHEVC_REQUIRE(!c->dry, "record-only contexts take deblocking as jobs (no device to derive them)");
+    OHEVC_REQUIRE(!c->dry || c->dry_as_device, "record-only contexts take deblocking as jobs (no device to derive them)");
     OHEVC_REQUIRE(m->width > 0 && m->height > 0 && m->log2_ctb_size >= 4 && m->log2_ctb_size <= 6 && m->log2_min_cb_size >= 3 &&
                   m->chroma_format_idc >= 0 && m->chroma_format_idc <= 3, "picture geometry");
-    OHEVC_REQUIRE(m->horizontal_bs && m->vertical_bs && m->bs_width > 0 && m->qp_y_tab && m->min_cb_width > 0 && m->deblock && m->deblock_stride >= 2,
+    OHEVC_REQUIRE((!with_bs || (m->horizontal_bs && m->vertical_bs)) && m->bs_width > 0 && m->qp_y_tab && m->min_cb_width > 0 && m->deblock && m->deblock_stride >= 2,
                   "deblocking maps");
     OHEVC_REQUIRE(!m->is_pcm || (m->min_pu_width > 0 && m->min_pu_height > 0 && m->log2_min_pu_size >= 2), "pcm map");
     const int hs = m->chroma_format_idc == 1 || m->chroma_format_idc == 2, vs = m->chroma_format_idc == 1;
     const int ctb = 1 << m->log2_ctb_size, ctb_w = (m->width + ctb - 1) >> m->log2_ctb_size, ctb_h = (m->height + ctb - 1) >> m->log2_ctb_size;
     const size_t bs_h = (size_t)(m->height >> 2);
-    const size_t n_v = (size_t)m->bs_width * (bs_h + (4u << vs)), n_h = ((size_t)m->bs_width + (4u << hs)) * bs_h;          // hevc.c:170-171
+    const size_t n_v = with_bs ? (size_t)m->bs_width * (bs_h + (4u << vs)) : 0, n_h = with_bs ? ((size_t)m->bs_width + (4u << hs)) * bs_h : 0;          // hevc.c:170-171
     const size_t n_qp = (size_t)m->min_cb_width * (size_t)(m->height >> m->log2_min_cb_size);
     const size_t n_db = (size_t)ctb_w * ctb_h * m->deblock_stride, n_pcm = m->is_pcm ? (size_t)m->min_pu_width * m->min_pu_height : 0;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_v = 0, o_h = o_v + up(n_v), o_qp = o_h + up(n_h), o_db = o_qp + up(n_qp), o_pcm = o_db + up(n_db), total = o_pcm + up(n_pcm);
     c->dbk_blob.resize(total);
-    memcpy(c->dbk_blob.data() + o_v, m->vertical_bs, n_v);
-    memcpy(c->dbk_blob.data() + o_h, m->horizontal_bs, n_h);
+    if (n_v) memcpy(c->dbk_blob.data() + o_v, m->vertical_bs, n_v);
+    if (n_h) memcpy(c->dbk_blob.data() + o_h, m->horizontal_bs, n_h);
     memcpy(c->dbk_blob.data() + o_qp, m->qp_y_tab, n_qp);
     memcpy(c->dbk_blob.data() + o_db, m->deblock, n_db);
     if (n_pcm) memcpy(c->dbk_blob.data() + o_pcm, m->is_pcm, n_pcm);
@@ -1725,17 +1766,12 @@ extern "C" int ohevc_rec_bs_calls(ohevc_ctx *c, const ohevc_bs_call *calls, int 
 extern "C" int ohevc_rec_deblock_maps_bs(ohevc_ctx *c, const ohevc_dbk_maps *m, const ohevc_bs_maps *bs)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr && m != nullptr && bs != nullptr, "no frame begun");
-    OHEVC_REQUIRE(!c->dry, "record-only contexts take deblocking as jobs (no device to derive them)");
+    OHEVC_REQUIRE(!c->dry || c->dry_as_device, "record-only contexts take deblocking as jobs (no device to derive them)");
     // bs->mvf NULL: the frame keeps the motion of its MC jobs on the device (ohevc_frame_keep_motion) - nothing to copy
     OHEVC_REQUIRE((bs->mvf != nullptr ? bs->mvf_stride >= 20 : c->keep_motion_l2 == bs->log2_min_pu_size) && bs->cbf_luma != nullptr && bs->min_pu_width > 0 &&
                   bs->min_pu_height > 0 && bs->min_tb_width > 0 && bs->min_tb_height > 0, "motion field / cbf map");
-    static thread_local std::vector<uint8_t> zero_bs;
-    ohevc_dbk_maps mm = *m;
-    // the two arrays are written by the device: a zero-length stand-in keeps ohevc_rec_deblock_maps' checks and layout (offsets unused)
-    const size_t bs_h = (size_t)(m->height >> 2), n_v = (size_t)m->bs_width * (bs_h + 8), n_h = ((size_t)m->bs_width + 8) * bs_h;
-    if (zero_bs.size() < std::max(n_v, n_h)) zero_bs.assign(std::max(n_v, n_h), 0);
-    mm.vertical_bs = zero_bs.data(); mm.horizontal_bs = zero_bs.data();
-    int rc = ohevc_rec_deblock_maps(c, &mm);
+    // the two boundary-strength arrays are written by the device: nothing of them in the blob (their offsets are never used: frame_end_impl)
+    int rc = rec_deblock_maps_impl(c, m, false);
     if (rc != OHEVC_OK) return rc;
     const size_t n_mvf = bs->mvf ? (size_t)bs->min_pu_width * bs->min_pu_height * (size_t)bs->mvf_stride : 0, n_cbf = (size_t)bs->min_tb_width * bs->min_tb_height;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1754,7 +1790,7 @@ extern "C" int ohevc_rec_deblock_maps_bs(ohevc_ctx *c, const ohevc_dbk_maps *m, 
 extern "C" int ohevc_frame_keep_motion(ohevc_ctx *c, int log2_unit)
 {
     OHEVC_REQUIRE(get_pic(c, c ? c->cur : -1) != nullptr, "no frame begun");
-    OHEVC_REQUIRE(!c->dry, "record-only contexts have no device to keep it on");
+    OHEVC_REQUIRE(!c->dry || c->dry_as_device, "record-only contexts have no device to keep it on");
     OHEVC_REQUIRE(log2_unit >= 2 && log2_unit <= 5, "log2_unit");
     OHEVC_REQUIRE(c->keep_motion_l2 == 0 || c->keep_motion_l2 == log2_unit, "the frame already keeps its motion at another granularity");
     c->keep_motion_l2 = log2_unit;
@@ -2028,6 +2064,17 @@ extern "C" int ohevc_frame_reconstruct(ohevc_ctx *c)
             fprintf(stderr, " %d", (cnt[0] + 15) / 16 + (cnt[1] + 7) / 8 + (cnt[2] + 3) / 4 + (cnt[3] + 1) / 2);
         }
         fprintf(stderr, "\n");
+    }
+    if (ohevc::config().trace_upload) {       // what this hand-over puts on the bus, by kind (bytes; every array is padded to 256 in the staging buffer)
+        size_t intra = 0, intra_res = 0, tu = 0;
+        for (int l = 0; l <= c->max_level; l++) {
+            intra += c->levels[l].intra.size() * sizeof(ohevc_intra_job); intra_res += c->levels[l].intra_res.size() * sizeof(ohevc_tu_job);
+            for (uint64_t m = c->levels[l].touched; m; m &= m - 1) { const int b = __builtin_ctzll(m); tu += c->levels[l].tu[b >> 4][b & 15].size() * sizeof(ohevc_tu_job); }
+        }
+        fprintf(stderr, "upload: target %d mc %zu mc_small %zu intra %zu intra_res %zu tu %zu coeffs %zu (dense %zu) expand %zu cips %zu ctb %zu levels %d\n", c->cur,
+                c->mc.size() * sizeof(ohevc_mc_job), c->mc_small.size() * sizeof(ohevc_mc_job), intra, intra_res, tu, c->coeffs.size() * 2, (size_t)c->dense * 2,
+                c->expand.size() * sizeof(ohevc_expand_rec), c->cips.size() * sizeof(ohevc_intra_cip),
+                c->ctb_tasks.size() * sizeof(ohevc_ctb_task) + c->ctb_opwords.size() * 4 + c->ctb_intra.size() * sizeof(ohevc_intra_job) + c->ctb_tu.size() * sizeof(ohevc_tu_job), c->max_level);
     }
     if (c->dry) {
         if (g_sink) g_sink(g_sink_user, c, 0);
@@ -2419,6 +2466,9 @@ static int frame_end_impl(ohevc_ctx *c)
         off_b = c->bypass.empty() ? 0 : stage_put(parts, total, c->bypass.data(), c->bypass.size());
         c->tail_parts = parts; c->tail_total = total;
     }
+    if (ohevc::config().trace_upload)
+        fprintf(stderr, "upload: target %d filter maps %zu bs_calls %zu dbk jobs %zu sao %zu bypass %zu\n", c->cur, c->dbk_blob.size(), c->bs_calls.size() * sizeof(ohevc_bs_call),
+                (c->dbk_v.size() + c->dbk_h.size()) * sizeof(ohevc_dbk_job), c->sao.size() * sizeof(ohevc_sao_job), c->bypass.size());
     c->tail_base = SIZE_MAX;
     int rc = ohevc_frame_reconstruct(c);
     c->tail_parts.clear();
@@ -2426,6 +2476,7 @@ static int frame_end_impl(ohevc_ctx *c)
     if (c->dry) {
         if (g_sink) g_sink(g_sink_user, c, 1);
         c->dbk_v.clear(); c->dbk_h.clear(); c->sao.clear(); c->sao_lagged = false;
+        c->dbk_blob.clear(); c->bs_calls.clear(); c->have_bs = false; c->bypass.clear();      // (ohevc_debug_set_record_only(2): the device forms, dropped)
     }
     if (filters) {
         int lane = c->last_recon_lane;                  // (the maps rode with the job arrays of the reconstruction above)
@@ -3010,6 +3061,17 @@ extern "C" int ohevc_debug_arena(ohevc_ctx *c, const int16_t **coeffs, const ohe
         c->dense_host.assign((size_t)c->dense, (int16_t)0);
         for (const ohevc_expand_rec &e : c->expand) {
             if (e.kind == 0) { memcpy(c->dense_host.data() + e.dst, c->coeffs.data() + e.src, (size_t)e.dims * sizeof(int16_t)); continue; }
+            if (e.kind & 0x100u) {                     // sub-block form: the set groups of the record's region, 16 elements each
+                const int n = 1 << (e.kind & 0xff), gpr = n >> 2;
+                const int16_t *in = c->coeffs.data() + e.src;
+                for (int gi = 0; gi < 32; gi++) {
+                    if (!(e.dims >> gi & 1u)) continue;
+                    const int gy = gi / gpr, gx = gi % gpr;
+                    for (int k = 0; k < 4; k++) memcpy(c->dense_host.data() + e.dst + (size_t)(gy * 4 + k) * n + gx * 4, in + 4 * k, 8);
+                    in += 16;
+                }
+                continue;
+            }
             const int n = 1 << e.kind, cols = (int)(e.dims & 0xff), rows = (int)(e.dims >> 8);
             for (int y = 0; y < rows; y++) memcpy(c->dense_host.data() + e.dst + (size_t)y * n, c->coeffs.data() + e.src + (size_t)y * cols, (size_t)cols * sizeof(int16_t));
         }

@@ -38,7 +38,7 @@ const Config &config()
             };
             auto has = [&](const char *w) { return find(w, false) != nullptr; };
             c.trace_order = has("order"); c.trace_timing = has("timing"); c.trace_ctb = has("ctb"); c.trace_levels = has("levels");
-            c.trace_launches = has("launches"); c.trace_sao = has("sao"); c.trace_reg = has("reg"); c.profile_slots = has("slots"); c.ctb_debug = has("ctbdebug");
+            c.trace_launches = has("launches"); c.trace_sao = has("sao"); c.trace_reg = has("reg"); c.trace_upload = has("upload"); c.profile_slots = has("slots"); c.ctb_debug = has("ctbdebug");
             if (const char *at = find("at=", true)) if (sscanf(at + 3, "%d:%d:%d", &c.trace_at[0], &c.trace_at[1], &c.trace_at[2]) != 3) c.trace_at[0] = -1;
         }
         return c;
@@ -86,6 +86,24 @@ static __global__ __launch_bounds__(256) void expand_coeffs_kernel(const int16_t
         const ohevc::u32x2 *in = reinterpret_cast<const ohevc::u32x2 *>(compact + e.src);  // (compact offsets are multiples of 4 elements: 8-byte aligned)
         for (unsigned k = lane; k < e.dims / 8u; k += 64u) {
             const ohevc::u32x2 a = in[2 * k], b = in[2 * k + 1];
+            out[k] = ohevc::u32x4{ a.x, a.y, b.x, b.y };
+        }
+        return;
+    }
+    if (e.kind & 0x100u) {                                 // sub-block form: dims = one bit per 4x4 group of the region, the set ones travel (16 elements each)
+        const unsigned log2n = e.kind & 0xffu, n = 1u << log2n, part = e.kind >> 9, mask = e.dims;
+        const unsigned total = (log2n == 5u && part != 2u) ? 512u : n * n, gshift = log2n - 2u;      // elements this record writes; log2 of the groups per row
+        const int16_t *in = compact + e.src;
+        for (unsigned k = lane; k < total / 8u; k += 64u) {
+            const unsigned row = (8u * k) >> log2n, col = (8u * k) & (n - 1u);
+            const unsigned gi = ((row >> 2) << gshift) + (col >> 2);           // the piece = row (row & 3) of groups gi and gi + 1
+            ohevc::u32x2 a = ohevc::u32x2{ 0u, 0u }, b = ohevc::u32x2{ 0u, 0u };
+            if (gi < 32u) {
+                const unsigned below = mask & ((1u << gi) - 1u), two = mask >> gi;
+                const unsigned at = __builtin_popcount(below) * 16u + (row & 3u) * 4u;
+                if (two & 1u) a = *reinterpret_cast<const ohevc::u32x2 *>(in + at);
+                if (two & 2u) b = *reinterpret_cast<const ohevc::u32x2 *>(in + at + ((two & 1u) ? 16u : 0u));
+            }
             out[k] = ohevc::u32x4{ a.x, a.y, b.x, b.y };
         }
         return;

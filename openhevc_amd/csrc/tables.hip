@@ -100,7 +100,7 @@ struct Entry {
 inline uint64_t next_registry_id() { static std::atomic<uint64_t> n{0}; return ++n; }
 struct Registry {
     std::mutex m;
-    Entry pics[128];
+    Entry pics[OHEVC_MAX_PICTURES + 1];        // one per picture of the store (ohevc_ctx.h) - the store's own limit is met first
     std::atomic<int> n{0};
     const uint64_t id = next_registry_id();    // never reused (an address may be: kept_snapshot)
 };
@@ -204,7 +204,7 @@ thread_local int tl_hint[2] = { -1, -1 };      // the registry entries the last 
 // per entry, stamped with the registry (two decoders of one process have two) and the `gen` it saw - and a look-up is one load of
 // `gen` plus the arithmetic.
 struct KeptSnapshot { uint64_t of = 0; uint32_t gen = 1; HostPic hp; };
-thread_local KeptSnapshot tl_kept[128];
+thread_local KeptSnapshot tl_kept[OHEVC_MAX_PICTURES + 1];
 const HostPic *kept_snapshot(const Entry &e, int i)
 {
     KeptSnapshot &k = tl_kept[i];
@@ -738,7 +738,7 @@ extern "C" int ohevc_tables_register_picture(ohevc_ctx *ctx, int slot, uint8_t *
     if (trace) fprintf(stderr, "reg: slot %d = %p %p %p\n", slot, (void *)hp.data[0], (void *)hp.data[1], (void *)hp.data[2]);
     for (int i = 0; i < n; i++) if (s->pics[i].v.slot == slot) { s->pics[i].publish(hp); return OHEVC_OK; }
     for (int i = 0; i < n; i++) if (s->pics[i].v.slot < 0) { s->pics[i].publish(hp); return OHEVC_OK; }
-    OHEVC_REQUIRE(n < 128, "too many registered pictures");
+    OHEVC_REQUIRE(n <= OHEVC_MAX_PICTURES, "too many registered pictures");
     s->pics[n].publish(hp);
     s->reg->n.store(n + 1, std::memory_order_release);
     return OHEVC_OK;

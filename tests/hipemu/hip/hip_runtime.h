@@ -88,6 +88,7 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s);
 hipError_t hipMemset(void *dst, int v, size_t n);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int priority);
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t cuMaskSize, const uint32_t *cuMask);
 hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamDestroy(hipStream_t s);

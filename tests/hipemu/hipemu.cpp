@@ -316,6 +316,7 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t) { memset(dst,
 hipError_t hipMemset(void *dst, int v, size_t n) { memset(dst, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemuStream(); return hipSuccess; }
 hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = new hipemuStream(); return hipSuccess; }
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { *s = new hipemuStream(); return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { if (least) *least = 0; if (greatest) *greatest = -1; return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t *s) { *s = new hipemuStream(); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }

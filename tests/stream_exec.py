@@ -266,10 +266,10 @@ def drive_tables(reflib, bd, W, H, cur, refs, enc, hevcdsp_hook=None, videodsp_h
     return rc
 
 
-def check_switches(kind, product, names, threads=1, combos=((1, 1), (96, 0), (1, 0))):
+def check_switches(kind, product, names, threads=1, combos=((1, 2), (96, 1), (1, 0))):
     """Round-5 switches of the product library that no small stream trips on its own, forced: (a) every frame with intra levels goes to the
     context's long-chain stream (a picture of the golden streams has a few dozen levels, the default threshold is 96) - the hand-over between a
-    context's two streams at every picture; (b) coefficients uploaded whole, as in rounds 1-4, against the compact default.  Same pictures."""
+    context's two streams at every picture; (b) the three forms coefficients cross the bus in - the non-zero 4x4 groups (2, the default), the col_limit rectangle (1, round 5), whole (0, rounds 1-4).  Same pictures."""
     import ctypes as C
     from oracle import pystream as ps
     from test_stream_cpu import frames_md5, load_golden
@@ -290,4 +290,4 @@ def check_switches(kind, product, names, threads=1, combos=((1, 1), (96, 0), (1,
                 assert frames_md5(ps.decode_stream(kind, aus, threads, 1)) == md5, f"{name}: long_chain_levels {levels}, compact {compact}, {threads} thread(s)"
     finally:
         product.ohevc_debug_set_long_chain_levels(96)
-        product.ohevc_debug_set_compact_coeffs(1)
+        product.ohevc_debug_set_compact_coeffs(2)

@@ -124,3 +124,28 @@ def test_gpu_backed_decoder_links_no_oracle():
     assert all(n.startswith(("libohevc_hip", "libc.", "libm.", "libpthread", "ld-linux")) for n in needed), needed
     hooks = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "integration", "hip_hooks.c")).read(), flags=re.S)
     assert "oracle_api.h" not in hooks and "ohsw_" not in hooks and "ohor_" not in hooks
+
+
+def test_picture_store_limits_fail_loudly():
+    """The fixed sizes of the picture store (include/ohevc_ctx.h: OHEVC_MAX_PICTURES pictures, sides of at most 65535 samples) are met with an error
+    and a message, never with a write past a table: a record-only context (no device) takes exactly OHEVC_MAX_PICTURES pictures."""
+    lib = L.load_library()
+    lib.ohevc_debug_set_record_only.argtypes = [C.c_int]
+    prev = lib.ohevc_debug_set_record_only(1)
+    try:
+        ctx = L.Ctx(0)
+        MAXP = 127
+        slots = [ctx.pic_alloc(64, 64, 1, 8) for _ in range(MAXP)]
+        assert sorted(slots) == list(range(MAXP))
+        assert lib.ohevc_pic_alloc(ctx.h, 64, 64, 1, 8) == L.ERR_ARG and b"too many pictures" in lib.ohevc_last_error()
+        ctx.pic_release(slots[5])                            # a freed slot is handed out again
+        assert ctx.pic_alloc(64, 64, 1, 8) == slots[5]
+        assert lib.ohevc_pic_alloc(ctx.h, 64, 64, 1, 8) == L.ERR_ARG
+        lib.ohevc_frame_ref_reach.argtypes = [C.c_void_p, C.c_int]
+        assert lib.ohevc_frame_ref_reach(ctx.h, MAXP + 1) == -1 and lib.ohevc_frame_ref_reach(ctx.h, -1) == -1
+        ctx.pic_release(slots[6])
+        assert lib.ohevc_pic_alloc(ctx.h, 65536, 64, 1, 8) == L.ERR_ARG and b"picture size" in lib.ohevc_last_error()
+        assert lib.ohevc_pic_alloc(ctx.h, 64, 70000, 1, 8) == L.ERR_ARG
+        ctx.close()
+    finally:
+        lib.ohevc_debug_set_record_only(prev)

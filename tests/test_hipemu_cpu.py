@@ -50,7 +50,7 @@ def _adopt(modname):
             globals()[name] = obj
 
 
-for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_dbk_maps_gpu test_boundary_strength_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu test_frames_bands_gpu").split():
+for _m in os.environ.get("HIPEMU_MODULES", "test_tu_gpu test_mc_gpu test_filters_gpu test_dbk_maps_gpu test_boundary_strength_gpu test_intra_gpu test_shvc_gpu test_ctx_gpu test_tables_gpu test_frames_bands_gpu test_expand_gpu").split():
     _adopt(_m)
 
 
@@ -214,7 +214,7 @@ def test_emu_long_chain_stream_and_whole_coefficient_upload(threads):
     from stream_exec import check_switches
     with ps.Decoder("hipemu") as d:
         product = d.product_lib()
-    check_switches("hipemu", product, ["intra_8b", "ra_8b_ctb64", "small_blocks", "fmt444_14b_cip_cross"], threads, combos=((1, 1), (1, 0)))
+    check_switches("hipemu", product, ["intra_8b", "ra_8b_ctb64", "small_blocks", "fmt444_14b_cip_cross"], threads, combos=((1, 2), (1, 1), (1, 0)))
 
 
 # ---------------------------------------------------------------- decoder instances (integration/hip_backend.h), over the emulated device code

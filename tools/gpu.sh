@@ -97,7 +97,8 @@ PY
       # (at most four counters per pass: larger sets were refused by the counter scheduler and left the files empty)
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" \
                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM" \
-                 "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
+                 "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_READ_sum" \
+                 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr"; do
         i=$((i + 1))
         ( cd $ROOT && timeout 300 rocprofv3 --pmc $set --kernel-trace -d /tmp/ctr_$i -o p -- "$@" > /tmp/ctr_$i.log 2>&1 ) || tail -3 /tmp/ctr_$i.log
         python tools/rocpd_summary.py pmc /tmp/ctr_$i/p_results.db $k 2>&1 | cut -c1-220 | tee -a $OUT/counters_$k.txt
