@@ -2561,8 +2561,8 @@ static int frame_end_impl(ohevc_ctx *c)
                 if ((rc = ohevc_dev_copy(c->lag.planes[1].data, p->planes[1].data, chroma, c->stream)) != OHEVC_OK) return rc;
             } else {
                 for (int i = 1; i < 3; i++)
-                    OHEVC_HIP_TRY(hipMemcpyAsync(c->lag.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
-                                                 hipMemcpyDeviceToDevice, c->stream));
+                    OHEVC_HIP_TRY(hipMemcpy2DAsync(c->lag.planes[i].data, (size_t)c->lag.planes[i].stride, p->planes[i].data, (size_t)p->planes[i].stride,
+                                                   (size_t)p->planes[i].width * (p->bd > 8 ? 2 : 1), (size_t)p->planes[i].height, hipMemcpyDeviceToDevice, c->stream));
             }
         }
         if (!c->dbk_blob.empty()) {
@@ -2582,9 +2582,10 @@ static int frame_end_impl(ohevc_ctx *c)
                 for (int i = 0; i < 3; i++) all += (size_t)p->planes[i].stride * p->planes[i].height;
                 if ((rc = ohevc_dev_copy(c->twin.planes[0].data, p->planes[0].data, all, c->stream)) != OHEVC_OK) return rc;
             } else {
+                // (an adopted picture - ohevc_pic_adopt - keeps its owner's pitch, the copy has the store's: row by row then)
                 for (int i = 0; i < 3; i++)
-                    OHEVC_HIP_TRY(hipMemcpyAsync(c->twin.planes[i].data, p->planes[i].data, (size_t)p->planes[i].stride * p->planes[i].height,
-                                                 hipMemcpyDeviceToDevice, c->stream));
+                    OHEVC_HIP_TRY(hipMemcpy2DAsync(c->twin.planes[i].data, (size_t)c->twin.planes[i].stride, p->planes[i].data, (size_t)p->planes[i].stride,
+                                                   (size_t)p->planes[i].width * (p->bd > 8 ? 2 : 1), (size_t)p->planes[i].height, hipMemcpyDeviceToDevice, c->stream));
             }
             lap(3);
             ohevc_plane lagp[3] = {c->twin.planes[0], lagged ? c->lag.planes[1] : c->twin.planes[1], lagged ? c->lag.planes[2] : c->twin.planes[2]};

@@ -185,13 +185,14 @@ def test_released_pieces_are_handed_out_again_zeroed():
 def test_cached_stream_handle_is_ordered_behind_a_long_chain_picture(oracle):
     """ohevc_ctx_stream is one handle for the context's life (include/ohevc_ctx.h).  A picture whose dependency levels reach
     ohevc_debug_set_long_chain_levels is issued on the context's second, internal stream; its frame end joins the public stream again, so a
-    caller that cached the handle and synchronises on IT (not on ohevc_ctx_sync) reads finished pixels."""
+    caller that cached the handle and synchronises on IT (not on ohevc_ctx_sync) reads finished pixels.  The pictures are ADOPTED
+    planes (ohevc_pic_adopt) with the owner's pitch - half the store's for the chroma planes here: the deblocked copy SAO reads has the store's
+    pitch (a plane-sized linear copy between the two was wrong until round 6).  On the emulator (streams are synchronous) this is the adopted-pitch check alone."""
     import ctypes
-    import torch
-    if G.emulating():
-        pytest.skip("streams are synchronous in the emulator")
+    emu = G.emulating()
     lib = L.load_library()
     lib.ohevc_debug_set_long_chain_levels.argtypes = [ctypes.c_int]
+    lib.ohevc_ctx_stream.restype = ctypes.c_void_p
     bd, W, H = 8, 256, 256
     rng = np.random.default_rng(77)
     dims = X.chroma_dims(W, H)
@@ -203,22 +204,25 @@ def test_cached_stream_handle_is_ordered_behind_a_long_chain_picture(oracle):
     try:
         ctx = L.Ctx(0)
         handle = lib.ohevc_ctx_stream(ctx.h)
-        ext = torch.cuda.ExternalStream(handle)
+        if not emu:
+            import torch
+            ext = torch.cuda.ExternalStream(handle)
         ref_slots = []
         for r in refs:
             sl = ctx.pic_alloc(W, H, 1, bd); ctx.pic_upload(sl, r); ref_slots.append(sl)
-        for rep in range(6):                                   # the handle survives pictures on either stream
-            planes = [torch.from_numpy(p.copy()).cuda() for p in cur0]
-            torch.cuda.synchronize()
+        for rep in range(2 if emu else 6):                     # the handle survives pictures on either stream
+            planes = [G.to_dev(p.copy()) for p in cur0]
+            G.sync()
             cur = ctx.pic_adopt(planes, W, H, 1, bd)
             ctx.frame_begin(cur)
             X.record_gpu(ctx, W, H, ref_slots, ops, fops)
             ctx.frame_end()
             assert lib.ohevc_ctx_stream(ctx.h) == handle
-            ext.synchronize()                                  # the CACHED handle, nothing else
-            got = [t.cpu().numpy() for t in planes]
+            if not emu:
+                ext.synchronize()                              # the CACHED handle, nothing else
+            got = [G.to_host(t, np.uint8) for t in planes]
             for c in range(3):
-                assert np.array_equal(got[c], want[c]), f"pass {rep}, plane {c}: read unfinished pixels through the cached stream handle"
+                assert np.array_equal(got[c], want[c]), f"pass {rep}, plane {c}: read unfinished (or wrongly copied) pixels through the cached stream handle"
             ctx.pic_release(cur)
         assert ctx.stats()["launches"] > 0
         ctx.close()

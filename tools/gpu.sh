@@ -11,6 +11,7 @@
 #   smoke                        __graft_entry__.smoke()                                             -> smoke.log
 #   bench [bench.py args]        one bench.py line                                                   -> bench<suffix>.json
 #   bench_prof [bench.py args]   rocprofv3 --kernel-trace --stats of the bench command               -> kernel_stats.txt
+#   rows_prof [only]             tools/kernel_rows.py under rocprofv3 --stats, then plain (HIP events)   -> kernel_rows_rocprof_stats.txt, kernel_rows_events.txt
 #   pmc                          FETCH_SIZE / WRITE_SIZE passes of the bench command                 -> pmc_traffic.json
 #   pmc_row <log2> <bd> <kernel> the same for bench.py --log2 <log2> --bit-depth <bd>                -> pmc_traffic_log2_<log2>_<bd>bit.json
 #   counters <kernel> <cmd ...>  SQ / TCP / TCC counter passes of <cmd>, rows of kernels matching    -> counters_<kernel>.txt
@@ -81,6 +82,16 @@ PY
       ;;
     bench_prof)
       prof_stats /tmp/prof_bench bench python $ROOT/bench.py --no-cpu-baseline --no-decode --no-zscan "$@" | tee $OUT/kernel_stats.txt ;;
+    rows_prof)      # every row of the per-kernel table under rocprofv3: the per-kernel average durations the bench's HIP-event times are to agree with
+      STATS_ROWS=0 prof_stats /tmp/prof_rows rows python $ROOT/tools/kernel_rows.py "$@" | tee $OUT/kernel_rows_rocprof_stats.txt
+      timeout 600 python tools/kernel_rows.py "$@" > $OUT/kernel_rows.json 2>/dev/null
+      python - $OUT/kernel_rows.json <<'PY' | tee $OUT/kernel_rows_events.txt
+import json, sys
+for k, v in json.load(open(sys.argv[1])).items():
+    if isinstance(v, dict): print(f"{k:52s} {1e3 * v['kernel_ms']:9.2f} us  frac {v['frac']:.3f} checked {v['checked']}")
+    else: print(k, v)
+PY
+      ;;
     pmc)
       local CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-decode --no-zscan --check-blocks 0"
       ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_fetch -o p -- $CMD > /tmp/pmc_fetch.log 2>&1
