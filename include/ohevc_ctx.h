@@ -76,6 +76,15 @@ int  ohevc_host_unpin_all(ohevc_ctx *ctx);
 /* ... or of one allocation only (every registered range overlapping it): the application returned THAT memory to its allocator, e.g. the decoder's
  * buffer pool changed geometry and a buffer address came back with another size.  Copies into other ranges that are in flight are not disturbed. */
 int  ohevc_host_unpin(ohevc_ctx *ctx, void *ptr, size_t bytes);
+/* Page-locked host memory of the library's own (hipHostMalloc; 64-byte aligned, not cleared): what an application - or the sample hooks'
+ * get_buffer2 (integration/hip_hooks.c) - builds the decoder's frame buffers from when it lets the back end allocate them.
+ * Memory BORN page-locked needs no ohevc_host_pin, and, unlike a registration of somebody else's allocation, cannot go stale behind the
+ * library's back: the reference's frame pool frees and re-creates its buffers in mid-stream (update_frame_pool, utils.c:509-575, reached from
+ * every frame thread through one shared FramePool), a large buffer comes back from mmap at the SAME address with the SAME size, and a
+ * registration that still names the dead mapping makes the next copy-back a device fault (round 6: 8K frame threads; profiles/r6u_*).
+ * ohevc_host_free takes no context: a block may outlive the context (frames the application still holds when the decoder is closed). */
+int  ohevc_host_alloc(ohevc_ctx *ctx, size_t bytes, void **out);
+int  ohevc_host_free(void *ptr);
 /* Choices a decoder instance makes for the contexts it creates (value < 0: back to the process default, which include/ohevc_debug.h's setters
  * move for tests).  OHEVC_OPT_LEVEL_LAUNCH: executor of the intra-coded blocks - 0 dependency levels (chain kernel; default), 1 all levels in one
  * launch, 2 chosen per picture, 3 CTB tasks; OHEVC_OPT_FILTERS_ON_DEVICE: 1 deblocking parameters derived on the device from the decoder's maps

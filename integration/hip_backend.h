@@ -61,6 +61,11 @@ typedef struct ohhip_options {
     int park_frames;         /* frame threads: 1: a frame end whose reference pictures have not been issued yet is parked instead of making the decoding
                               * thread wait (ohevc_frame_end_deferred, ohevc_ctx.h; needs defer_download), 0: it waits; -1 (default): the library's
                               * default (OHHIP_PARK_FRAMES) */
+    int own_frames;          /* 1 (default; OHHIP_OWN_FRAMES): ohhip_backend_attach installs a get_buffer2 that builds the decoder's frame buffers from
+                              * page-locked memory of the back end's own (ohevc_host_alloc), recycled by the back end until ohhip_backend_free - unless the
+                              * application has installed a get_buffer2 of its own; 0: the decoder's allocator stays, pin_frames page-locks what it hands out.
+                              * Why it is the default: the reference's frame pool frees and re-creates its buffers in mid-stream (utils.c:509-575), a
+                              * page lock on memory that was freed and mapped again at the same address is dead, and nothing tells the back end */
 } ohhip_options;
 
 void ohhip_options_default(ohhip_options *o);
@@ -82,6 +87,7 @@ int  ohhip_backend_frames_mode(ohhip_backend *be, const ohhip_frames_mode *m);
 void ohhip_backend_frames_install(ohhip_backend *be, struct AVCodecContext *avctx);
 int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 int  ohhip_backend_device(const ohhip_backend *be);
+void ohhip_frame_pool_counts(long long *made, long long *live);   /* own_frames: page-locked frame-buffer blocks ever made / existing now, process-wide */
 int  ohhip_backend_live_count(void);                        /* back ends alive in this process (tests: open / close must not leak) */
 
 #ifdef __cplusplus

@@ -28,6 +28,7 @@
 #include "libavcodec/hevc.h"
 #include "libavcodec/thread.h"
 #include "libavutil/pixdesc.h"
+#include "libavutil/buffer.h"
 
 #include "ohevc_tables.h"
 #include "ohevc_debug.h"
@@ -82,9 +83,145 @@ struct ohhip_backend {
     /* OHHIP_TRACE_FRAMES: host timeline of every picture */
     ohhip_trace_rec   *trace;
     int                ntrace;
+    struct ohhip_frame_pool *pool;     /* own_frames: the page-locked blocks this decoder's frame buffers are made of (outlives the back end while blocks are out) */
+    struct { int w, h, fmt, planes, linesize[4], size[4]; ptrdiff_t off[4]; } layouts[4];      /* frame layouts seen (ohhip_get_buffer2) */
+    int                nlayouts;
     struct ohhip_backend *next;
 };
 #define OHHIP_MAGIC 0x6f686862u
+
+/* ---- own_frames: the decoder's frame buffers out of page-locked memory of the back end's own ----
+ * Blocks are recycled by exact size (a decoder has one size per plane) and given back to the runtime when the back end is freed; a block the
+ * application still holds then (a frame it has not released) frees itself when it is released.  The pool object outlives the back end for that. */
+typedef struct ohhip_block { void *ptr; int size; struct ohhip_frame_pool *pool; struct ohhip_block *next; } ohhip_block;
+typedef struct ohhip_frame_pool {
+    pthread_mutex_t m;
+    int alive, refs;                   /* refs: the back end + every block that is out */
+    ohhip_block *free_list;
+    ohhip_block **blocks;              /* every block that exists (free or out): whose buffer is it? (pool_owns: pointer comparison only) */
+    int nblocks, cap_blocks;
+    long long bytes;
+} ohhip_frame_pool;
+
+static long long g_pool_made, g_pool_live;          /* blocks ever made / existing now, process-wide (ohhip_frame_pool_counts: tests, leak checks) */
+void ohhip_frame_pool_counts(long long *made, long long *live)
+{
+    if (made) *made = __atomic_load_n(&g_pool_made, __ATOMIC_RELAXED);
+    if (live) *live = __atomic_load_n(&g_pool_live, __ATOMIC_RELAXED);
+}
+
+static void pool_forget_locked(ohhip_frame_pool *p, ohhip_block *b)
+{
+    __atomic_fetch_sub(&g_pool_live, 1, __ATOMIC_RELAXED);
+    int i;
+    for (i = 0; i < p->nblocks; i++)
+        if (p->blocks[i] == b) { p->blocks[i] = p->blocks[--p->nblocks]; break; }
+    p->bytes -= b->size;
+}
+static void pool_destroy(ohhip_frame_pool *p) { pthread_mutex_destroy(&p->m); free(p->blocks); free(p); }
+
+/* the AVBuffer free callback of a block: back onto the free list, or - the back end is gone - back to the runtime */
+static void pool_release(void *opaque, uint8_t *data)
+{
+    ohhip_block *b = opaque;
+    ohhip_frame_pool *p = b->pool;
+    int dead, last;
+    (void)data;
+    pthread_mutex_lock(&p->m);
+    dead = !p->alive;
+    if (dead)
+        pool_forget_locked(p, b);
+    else {
+        b->next = p->free_list;
+        p->free_list = b;
+    }
+    last = --p->refs == 0;
+    pthread_mutex_unlock(&p->m);
+    if (dead) {
+        ohevc_host_free(b->ptr);
+        free(b);
+    }
+    if (last)
+        pool_destroy(p);
+}
+
+static AVBufferRef *pool_get(ohhip_backend *be, int size)
+{
+    ohhip_frame_pool *p = be->pool;
+    ohhip_block *b = NULL, **pp;
+    AVBufferRef *ref;
+    pthread_mutex_lock(&p->m);
+    for (pp = &p->free_list; *pp; pp = &(*pp)->next)
+        if ((*pp)->size == size) { b = *pp; *pp = b->next; break; }
+    if (b)
+        p->refs++;
+    pthread_mutex_unlock(&p->m);
+    if (!b) {
+        void *mem = NULL;
+        if (ohevc_host_alloc(be->root, (size_t)size, &mem) != OHEVC_OK)
+            return NULL;
+        memset(mem, 0, (size_t)size);          /* (the decoder's own pool hands out cleared buffers: av_buffer_allocz, utils.c:558-560) */
+        if (!(b = calloc(1, sizeof(*b)))) { ohevc_host_free(mem); return NULL; }
+        b->ptr = mem; b->size = size; b->pool = p;
+        pthread_mutex_lock(&p->m);
+        if (p->nblocks == p->cap_blocks) {
+            const int cap = p->cap_blocks ? 2 * p->cap_blocks : 64;
+            ohhip_block **grown = realloc(p->blocks, (size_t)cap * sizeof(*grown));
+            if (!grown) { pthread_mutex_unlock(&p->m); ohevc_host_free(mem); free(b); return NULL; }
+            p->blocks = grown; p->cap_blocks = cap;
+        }
+        p->blocks[p->nblocks++] = b;
+        p->bytes += size;
+        __atomic_fetch_add(&g_pool_made, 1, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&g_pool_live, 1, __ATOMIC_RELAXED);
+        p->refs++;
+        pthread_mutex_unlock(&p->m);
+    }
+    if (!(ref = av_buffer_create(b->ptr, size, pool_release, b, 0)))
+        pool_release(b, b->ptr);
+    return ref;
+}
+
+/* is this AVBufferRef one of the pool's blocks?  (its opaque pointer is compared, never followed) */
+static int pool_owns(ohhip_backend *be, const AVBufferRef *ref)
+{
+    ohhip_frame_pool *p = be->pool;
+    const void *o;
+    int i, found = 0;
+    if (!p || !ref)
+        return 0;
+    o = av_buffer_get_opaque(ref);
+    pthread_mutex_lock(&p->m);
+    for (i = 0; i < p->nblocks && !found; i++)
+        found = p->blocks[i] == o && p->blocks[i]->ptr == (void *)ref->data;
+    pthread_mutex_unlock(&p->m);
+    return found;
+}
+
+static void pool_close(ohhip_backend *be)       /* ohhip_backend_free: after the contexts (their streams have drained) */
+{
+    ohhip_frame_pool *p = be->pool;
+    ohhip_block *list, *b;
+    int last;
+    if (!p)
+        return;
+    be->pool = NULL;
+    pthread_mutex_lock(&p->m);
+    p->alive = 0;
+    list = p->free_list;
+    p->free_list = NULL;
+    for (b = list; b; b = b->next)
+        pool_forget_locked(p, b);
+    last = --p->refs == 0;
+    pthread_mutex_unlock(&p->m);
+    while ((b = list)) {
+        list = b->next;
+        ohevc_host_free(b->ptr);
+        free(b);
+    }
+    if (last)
+        pool_destroy(p);
+}
 
 static pthread_mutex_t     g_reg_lock = PTHREAD_MUTEX_INITIALIZER;
 static ohhip_backend      *g_backends;             /* live back ends */
@@ -391,7 +528,20 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     /* INTEGRATION.md section 3, row alloc_frame: page-lock the buffers the decoder's pool recycles (hevc_refs.c:75-114, get_buffer.c), so
      * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once.  (After the
      * slot look-up: a buffer that came back with another geometry had its old page locks dropped there.) */
-    if (be->opt.pin_frames && ohevc_ctx_has_device(ctx))
+    if (be->opt.pin_frames && ohevc_ctx_has_device(ctx) && !pool_owns(be, f->buf[0])) {     /* (own_frames: born page-locked) */
+        /* A buffer set seen before but not in this combination: the decoder's pool was re-created in between (utils.c:555-560 - it is, in
+         * mid-stream, under frame threads) and these are NEW allocations, one of which the allocator put where an old one was (a large
+         * buffer comes back from mmap at the same address): the page lock behind that address names a mapping that is gone.  Lock again.
+         * (Only a hint - three new buffers at three old addresses look like a recycled frame.  own_frames, the default, has no such gap.) */
+        if (!fresh && be->bufs[i].pin_ptr[0]) {
+            int mixed = 0;
+            for (k = 1; k < 3 && k < AV_NUM_DATA_POINTERS && f->buf[k]; k++)
+                mixed |= be->bufs[i].pin_ptr[k] && be->bufs[i].pin_ptr[k] != f->buf[k]->data;
+            if (mixed) {
+                ohevc_host_unpin(ctx, be->bufs[i].pin_ptr[0], be->bufs[i].pin_bytes[0]);
+                be->bufs[i].pin_ptr[0] = NULL;
+            }
+        }
         for (k = 0; k < 3 && k < AV_NUM_DATA_POINTERS && f->buf[k]; k++) {
             if (be->bufs[i].pin_ptr[k] == f->buf[k]->data && be->bufs[i].pin_bytes[k] == (size_t)f->buf[k]->size)
                 continue;
@@ -404,6 +554,7 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
             be->bufs[i].pin_ptr[k] = f->buf[k]->data;
             be->bufs[i].pin_bytes[k] = (size_t)f->buf[k]->size;
         }
+    }
     /* (Taking these locks later - at the picture's frame end, out of this serial prologue - was tried at the end of round 4 and gave a fresh
      * decoder's first pass 4.5 ms back (profiles/r14_*), but a page lock wants the store's table exclusively, i.e. waits for every copy-back in
      * flight, and at a frame end other threads are already waiting for THIS picture: when the decoder re-created its buffer pool under four frame
@@ -843,6 +994,7 @@ void ohhip_options_default(ohhip_options *o)
     o->device_filters = env_int("OHHIP_DEVICE_FILTERS", -1);
     o->crash_backtrace = env_str("OHHIP_BACKTRACE") != NULL;
     o->park_frames = env_int("OHHIP_PARK_FRAMES", -1);
+    o->own_frames = env_int("OHHIP_OWN_FRAMES", 1) != 0;
 }
 
 /* this instance's choices on a context it has made (the library's process-wide debug setters stay what they are: defaults for tests) */
@@ -906,6 +1058,10 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
         return NULL;
     }
     apply_ctx_options(be, be->root);
+    if (be->opt.own_frames && (be->pool = calloc(1, sizeof(*be->pool)))) {
+        pthread_mutex_init(&be->pool->m, NULL);
+        be->pool->alive = be->pool->refs = 1;
+    }
     if (o->trace_path)
         be->trace = calloc(MAX_TRACE, sizeof(*be->trace));
     pthread_mutex_lock(&g_reg_lock);
@@ -930,11 +1086,81 @@ int ohhip_backend_options(const ohhip_backend *be, ohhip_options *out)
     return 0;
 }
 
+/* own_frames: AVCodecContext.get_buffer2 of a decoder with this back end (installed by ohhip_backend_attach; thread-safe: frame threads call
+ * it directly, pthread_frame.c:903-908).  The LAYOUT of a frame - plane sizes, line sizes, where the picture starts behind its edge - is the
+ * decoder's own: the first frame of every geometry is made by avcodec_default_get_buffer2 (utils.c:735) and measured; its buffers, and those
+ * of every later frame, are then blocks of the back end's page-locked pool.  Nothing here restates how the reference lays a frame out. */
+static int ohhip_get_buffer2(AVCodecContext *avctx, AVFrame *frame, int flags)
+{
+    ohhip_backend *be = NULL, *b;
+    AVBufferRef *refs[4] = { NULL, NULL, NULL, NULL };
+    int i, k, li = -1, ret;
+    pthread_mutex_lock(&g_reg_lock);
+    for (b = g_backends; b; b = b->next)
+        if ((void *)b == avctx->opaque)
+            be = b;
+    pthread_mutex_unlock(&g_reg_lock);
+    if (!be || !be->pool || !be->root || avctx->codec_type != AVMEDIA_TYPE_VIDEO)
+        return avcodec_default_get_buffer2(avctx, frame, flags);
+    pthread_mutex_lock(&be->lock);
+    for (i = 0; i < be->nlayouts; i++)
+        if (be->layouts[i].w == frame->width && be->layouts[i].h == frame->height && be->layouts[i].fmt == frame->format)
+            li = i;
+    pthread_mutex_unlock(&be->lock);
+    if (li < 0) {
+        int planes = 0, ok = 1;
+        if ((ret = avcodec_default_get_buffer2(avctx, frame, flags)) < 0)
+            return ret;
+        while (planes < 4 && frame->buf[planes])
+            planes++;
+        /* one buffer per plane, the plane inside its buffer, nothing beyond buf[]: anything else keeps the decoder's frame as it is */
+        ok = planes > 0 && planes <= 3 && !frame->buf[planes < 4 ? planes : 3] && frame->extended_data == frame->data && !frame->nb_extended_buf;
+        for (k = 0; k < planes && ok; k++)
+            ok = frame->data[k] >= frame->buf[k]->data && frame->data[k] < frame->buf[k]->data + frame->buf[k]->size && frame->linesize[k] > 0;
+        for (k = planes; k < 4 && ok; k++)
+            ok = !frame->data[k];
+        pthread_mutex_lock(&be->lock);
+        if (ok && be->nlayouts < 4) {
+            li = be->nlayouts;
+            be->layouts[li].w = frame->width; be->layouts[li].h = frame->height; be->layouts[li].fmt = frame->format; be->layouts[li].planes = planes;
+            for (k = 0; k < 4; k++) {
+                be->layouts[li].linesize[k] = frame->linesize[k];
+                be->layouts[li].size[k] = k < planes ? frame->buf[k]->size : 0;
+                be->layouts[li].off[k] = k < planes ? frame->data[k] - frame->buf[k]->data : 0;
+            }
+            be->nlayouts++;
+        }
+        pthread_mutex_unlock(&be->lock);
+        if (li < 0)
+            return 0;                           /* a layout this allocator does not take over (or a fifth geometry): the decoder's own frame */
+    }
+    for (k = 0; k < be->layouts[li].planes; k++)
+        if (!(refs[k] = pool_get(be, be->layouts[li].size[k]))) {
+            while (k-- > 0)
+                av_buffer_unref(&refs[k]);
+            /* no page-locked memory: the decoder's own frame (kept if it was just made to measure the layout) */
+            return frame->buf[0] ? 0 : avcodec_default_get_buffer2(avctx, frame, flags);
+        }
+    for (k = 0; k < 4; k++) {
+        av_buffer_unref(&frame->buf[k]);        /* (the measured frame's buffers go back to the decoder's pool) */
+        frame->buf[k] = refs[k];
+        frame->data[k] = refs[k] ? refs[k]->data + be->layouts[li].off[k] : NULL;
+        frame->linesize[k] = be->layouts[li].linesize[k];
+    }
+    frame->extended_data = frame->data;
+    return 0;
+}
+
 int ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx)
 {
     if (!be || be->magic != OHHIP_MAGIC || !avctx)
         return -1;
     avctx->opaque = be;          /* inherited by every frame-thread copy (pthread_frame.c:276 and the `*copy = *src` of its init) */
+    /* own_frames: unless the application brought an allocator of its own (the field is the default's after avcodec_alloc_context3) */
+    if (be->pool && avctx->get_buffer2 == avcodec_default_get_buffer2) {
+        avctx->get_buffer2 = ohhip_get_buffer2;
+        avctx->thread_safe_callbacks = 1;
+    }
     /* one context per decoding thread the decoder is about to start (the "threads" option is set before avcodec_open2, like this call):
        made here, at open time, instead of in front of every thread's first picture */
     if (be->root && !be->opt.record_only) {
@@ -1048,6 +1274,7 @@ void ohhip_backend_free(ohhip_backend *be)
     free(be->all);
     if (be->root)
         ohevc_ctx_destroy(be->root);
+    pool_close(be);                 /* (after the contexts: no copy into a block is in flight) */
     for (k = 0; k < 4; k++)
         if (t_ctxs[k].be == be)
             t_ctxs[k].be = NULL;

@@ -112,7 +112,7 @@ struct Config {
     int picture_batch = 1;            // OHEVC_PICTURE_BATCH=0: every device picture its own allocation (AddressSanitizer / guard-page runs)
     const char *frames_token = nullptr;    // OHEVC_FRAMES_TOKEN: what the ranks of the sockets wire present to each other (set by the launcher)
     // OHEVC_TRACE=word[,word...]: diagnosis output on stderr
-    bool trace_order = false, trace_timing = false, trace_ctb = false, trace_levels = false, trace_launches = false, trace_sao = false, trace_reg = false, trace_upload = false;
+    bool trace_order = false, trace_timing = false, trace_ctb = false, trace_levels = false, trace_launches = false, trace_sao = false, trace_reg = false, trace_upload = false, trace_pin = false;
     bool profile_slots = false;       // "slots": cycle counters per table-slot family, printed when a context forgets its tables
     bool ctb_debug = false;           // "ctbdebug": the CTB executor's sync words after every launch
     int trace_at[3] = {-1, -1, -1};   // "at=plane:x:y": every recorded job whose block covers that sample

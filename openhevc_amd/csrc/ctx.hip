@@ -419,6 +419,7 @@ static int alloc_picture(Picture &p, int width, int height, int cfi, int bd, boo
         d = static_cast<unsigned char *>(m);
     }
     for (int i = 0; i < 3; i++) p.planes[i].data = dry ? reinterpret_cast<void *>((uintptr_t)0x1000000 * (i + 1)) : static_cast<void *>(d + off[i]);
+    if (ohevc::config().trace_pin && !dry) fprintf(stderr, "pin: device picture %p + %zu (%s)\n", (void *)d, off[3], piece ? "piece" : "own allocation");
     p.used = true; p.single = !dry;
     p.owned = piece == nullptr;           // a piece belongs to its batch (freed with the store)
     return OHEVC_OK;
@@ -751,7 +752,9 @@ extern "C" int ohevc_pic_upload(ohevc_ctx *c, int slot, int plane, const void *h
 // allocated again, and replaces it.  Failure to register is not an error of the decoder: the copies stay pageable.
 static void unpin_locked(PicStore &st, size_t i)
 {
-    (void)hipHostUnregister(reinterpret_cast<void *>(st.pinned[i].first));
+    const hipError_t e = hipHostUnregister(reinterpret_cast<void *>(st.pinned[i].first));
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: unpin %p + %zu: %s\n", (void *)st.pinned[i].first, st.pinned[i].second, hipGetErrorString(e));
+    if (e != hipSuccess) (void)hipGetLastError();
     st.pinned[i] = st.pinned.back();
     st.pinned.pop_back();
 }
@@ -759,7 +762,7 @@ static void unpin_locked(PicStore &st, size_t i)
 extern "C" int ohevc_host_pin(ohevc_ctx *c, void *ptr, size_t bytes)
 {
     OHEVC_REQUIRE(c != nullptr && ptr != nullptr && bytes > 0, "bad argument");
-    if (c->dry) return OHEVC_OK;
+    if (c->dry) { if (ohevc::config().trace_pin) fprintf(stderr, "pin: (record-only) pin %p + %zu\n", ptr, bytes); return OHEVC_OK; }
     const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
     {   // the common case - a buffer of the decoder's pool seen again - takes the shared lock only
         std::shared_lock<std::shared_mutex> g(c->store->pin_m);
@@ -784,6 +787,7 @@ extern "C" int ohevc_host_pin(ohevc_ctx *c, void *ptr, size_t bytes)
         set_error("hipHostRegister(%p, %zu) failed: %s (copies into it stay pageable)", ptr, bytes, hipGetErrorString(e));
         return OHEVC_ERR_HIP;
     }
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: pin %p + %zu (%zu ranges)\n", ptr, bytes, v.size() + 1);
     v.emplace_back(a, bytes);
     return OHEVC_OK;
 }
@@ -822,6 +826,42 @@ extern "C" int ohevc_host_unpin(ohevc_ctx *c, void *ptr, size_t bytes)
         if (v[i].first < a + bytes && a < v[i].first + v[i].second) unpin_locked(*c->store, i);
         else i++;
     }
+    return OHEVC_OK;
+}
+
+// Page-locked memory of the library's own (ohevc_ctx.h).  A 64-byte header in front of the block says how it was made: a record-only context
+// (no device) hands out plain memory, and ohevc_host_free has no context to ask.
+namespace { struct HostBlockHeader { uint64_t magic; uint32_t pinned; uint32_t pad; void *base; char fill[40]; }; static_assert(sizeof(HostBlockHeader) == 64, "header"); }
+static constexpr uint64_t kHostBlockMagic = 0x6f6865766368626bull;
+extern "C" int ohevc_host_alloc(ohevc_ctx *c, size_t bytes, void **out)
+{
+    OHEVC_REQUIRE(c != nullptr && out != nullptr && bytes > 0, "bad argument");
+    *out = nullptr;
+    void *base = nullptr;
+    const bool pinned = !c->dry;
+    if (pinned) {
+        OHEVC_HIP_TRY(hipSetDevice(c->device));
+        const hipError_t e = hipHostMalloc(&base, bytes + sizeof(HostBlockHeader), hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return OHEVC_ERR_HIP; }
+    } else if (posix_memalign(&base, 64, bytes + sizeof(HostBlockHeader)) != 0) {
+        set_error("out of memory (%zu bytes of host memory)", bytes);
+        return OHEVC_ERR_ARG;
+    }
+    HostBlockHeader *h = static_cast<HostBlockHeader *>(base);
+    h->magic = kHostBlockMagic; h->pinned = pinned; h->pad = 0; h->base = base;
+    *out = h + 1;
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: host block %p + %zu (%s)\n", *out, bytes, pinned ? "page-locked" : "plain");
+    return OHEVC_OK;
+}
+extern "C" int ohevc_host_free(void *ptr)
+{
+    if (!ptr) return OHEVC_OK;
+    HostBlockHeader *h = static_cast<HostBlockHeader *>(ptr) - 1;
+    OHEVC_REQUIRE(h->magic == kHostBlockMagic && h->base == h, "not a block of ohevc_host_alloc");
+    h->magic = 0;
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: host block %p freed\n", ptr);
+    if (h->pinned) { const hipError_t e = hipHostFree(h); if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostFree failed: %s", hipGetErrorString(e)); return OHEVC_ERR_HIP; } }
+    else free(h);
     return OHEVC_OK;
 }
 
@@ -864,6 +904,7 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
     }
     const double t0 = g_trace_timing ? now_s() : 0;
     std::shared_lock<std::shared_mutex> pins(c->store->pin_m);     // no page lock is dropped between the issue of these copies and their completion
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: copy-back of slot %d (ctx %p) -> %p %p %p strides %td %td %td\n", slot, (void *)c, host[0], host[1], host[2], host_stride[0], host_stride[1], host_stride[2]);
     for (int i = 0; i < 3; i++) {
         if (!host[i]) continue;
         const ohevc_plane &pl = p->planes[i];
@@ -871,6 +912,7 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
                                        hipMemcpyDeviceToHost, c->stream));
     }
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: copy-back of slot %d landed\n", slot);
     if (g_trace_timing) c->t_part[4] += now_s() - t0;          // (the wait covers the picture's device work as well: nothing waited for it before)
     return OHEVC_OK;
 }

@@ -38,7 +38,7 @@ const Config &config()
             };
             auto has = [&](const char *w) { return find(w, false) != nullptr; };
             c.trace_order = has("order"); c.trace_timing = has("timing"); c.trace_ctb = has("ctb"); c.trace_levels = has("levels");
-            c.trace_launches = has("launches"); c.trace_sao = has("sao"); c.trace_reg = has("reg"); c.trace_upload = has("upload"); c.profile_slots = has("slots"); c.ctb_debug = has("ctbdebug");
+            c.trace_launches = has("launches"); c.trace_sao = has("sao"); c.trace_reg = has("reg"); c.trace_upload = has("upload"); c.trace_pin = has("pin"); c.profile_slots = has("slots"); c.ctb_debug = has("ctbdebug");
             if (const char *at = find("at=", true)) if (sscanf(at + 3, "%d:%d:%d", &c.trace_at[0], &c.trace_at[1], &c.trace_at[2]) != 3) c.trace_at[0] = -1;
         }
         return c;

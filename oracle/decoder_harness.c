@@ -25,7 +25,7 @@
 #ifdef OHDEC_HIP
 /* integration/hip_backend.h: one back end per decoder instance, attached before avcodec_open2 (the structs are passed through opaquely) */
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
+typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames, own_frames; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
 void ohhip_options_default(ohdec_options *o);
 size_t ohhip_options_size(void);
 ohhip_backend *ohhip_backend_new(const ohdec_options *o);
@@ -40,7 +40,7 @@ void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx);
 int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 #else
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
+typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames, own_frames; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
 static void ohhip_options_default(ohdec_options *o) { memset(o, 0, sizeof(*o)); o->struct_size = sizeof(*o); }
 static size_t ohhip_options_size(void) { return sizeof(ohdec_options); }
 static ohhip_backend *ohhip_backend_new(const ohdec_options *o) { (void)o; return NULL; }

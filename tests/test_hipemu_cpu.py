@@ -258,6 +258,60 @@ def test_emu_parked_frame_ends_with_frame_threads(park_threads, monkeypatch):
     assert product.ohevc_debug_parked_total() > before, "no frame end was parked: the test did not exercise ohevc_frame_end_deferred"
 
 
+@pytest.mark.parametrize("own_frames", ["1", "0"], ids=["blocks_of_the_back_end", "the_decoders_allocations"])
+def test_emu_frame_buffers_from_the_back_end_or_from_the_decoder(own_frames, monkeypatch):
+    """ohhip_options.own_frames (integration/hip_backend.h): 1 (default) - ohhip_backend_attach installs a get_buffer2 that builds every frame out
+    of page-locked blocks of the back end (recycled until the back end is freed); 0 - the decoder's own frame pool, page-locked by ohevc_host_pin.
+    Same pictures either way, in every thread mode; with 1 blocks must really have been made, and none may outlive its decoder."""
+    import ctypes
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_OWN_FRAMES", own_frames)
+    L = ps._load("hipemu")
+    made0, live0, made1, live1 = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    L.ohhip_frame_pool_counts(ctypes.byref(made0), ctypes.byref(live0))
+    for name, threads, tt in (("ra_10b_odd", 1, 1), ("ra_10b_odd", 4, 1), ("wpp", 4, 2), ("fmt444_8b", 3, 1), ("ldb_10b", 4, 3)):
+        aus, md5 = load_golden(name)
+        # (the stream twice through one decoder instance - it starts with an IDR picture: buffers are recycled across the passes)
+        assert frames_md5(ps.decode_stream("hipemu", aus * 2, threads, tt)) == list(md5) * 2, f"{name} threads {threads} type {tt} own_frames {own_frames}"
+    L.ohhip_frame_pool_counts(ctypes.byref(made1), ctypes.byref(live1))
+    assert live1.value == live0.value, "frame-buffer blocks outlived their decoders"
+    assert (made1.value > made0.value) == (own_frames == "1")
+
+
+def test_emu_host_blocks_of_the_library():
+    """ohevc_host_alloc / ohevc_host_free (include/ohevc_ctx.h): 64-byte aligned memory the library made (page-locked on a device), freed without a
+    context - also after the context is gone; a pointer the library did not make is refused, not freed."""
+    import ctypes
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    with ps.Decoder("hipemu") as d:
+        lib = d.product_lib()
+    lib.ohevc_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    lib.ohevc_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ohevc_host_free.argtypes = [ctypes.c_void_p]
+    lib.ohevc_ctx_destroy.argtypes = [ctypes.c_void_p]
+    ctx = ctypes.c_void_p()
+    assert lib.ohevc_ctx_create(ctypes.byref(ctx), 0) == 0
+    blocks = []
+    for n in (1, 4096, 3 << 20):
+        p = ctypes.c_void_p()
+        assert lib.ohevc_host_alloc(ctx, n, ctypes.byref(p)) == 0 and p.value and p.value % 64 == 0
+        ctypes.memset(p, 0x5a, n)
+        blocks.append(p)
+    assert lib.ohevc_host_alloc(ctx, 0, ctypes.byref(ctypes.c_void_p())) != 0
+    assert lib.ohevc_host_free(blocks.pop()) == 0
+    lib.ohevc_ctx_destroy(ctx)
+    foreign = ctypes.create_string_buffer(256)
+    assert lib.ohevc_host_free(ctypes.addressof(foreign) + 128) != 0, "a pointer ohevc_host_alloc did not return was accepted"
+    for p in blocks:                                   # (after their context)
+        assert lib.ohevc_host_free(p) == 0
+    assert lib.ohevc_host_free(None) == 0
+
+
 def test_emu_options_structs_carry_their_size_first():
     _instances().options_struct_size_rule("hipemu")
     _instances().frames_mode_struct_size_rule("hipemu")

@@ -196,6 +196,26 @@ def test_config5_8k_main10_on_one_gpu(threads, thread_type):
     _baseline_case(dict(gop="lowdelay_b", nframes=3, seed=3003, width=7680, height=4320, log2_ctb=6, bit_depth=10), threads, thread_type)
 
 
+ENCODER_LIKE = dict(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag=0.7, split_cu=0.3, rqt_root_cbf=0.45, cbf_luma=0.5, cbf_chroma=0.25,
+                                           split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
+
+
+@pytest.mark.parametrize("own_frames", ["1", "0"], ids=["frame_buffers_of_the_back_end", "frame_buffers_of_the_decoder_page_locked"])
+def test_config5_8k_frame_threads_survive_the_decoders_frame_pool_being_re_created(own_frames, monkeypatch):
+    """Round 6's device fault ("Memory access fault ... Write access to a read-only page", bench.py's config 5 row with 17 pictures): under frame
+    threads the reference re-creates its frame pool in mid-stream (update_frame_pool, utils.c:509-575), an 8K luma buffer - 68 MB, always an
+    mmap of its own - is unmapped and mapped again at the SAME address with the SAME size, and a page lock kept under (address, size) names
+    the dead mapping: the next copy-back into it faulted.  own_frames = 1 (default): the decoder's frame buffers are page-locked blocks of the
+    back end's own (ohevc_host_alloc), recycled, never freed in mid-stream; own_frames = 0: the decoder's allocations are page-locked, and a
+    buffer set that comes back in another combination has its luma lock renewed (hip_hooks.c, ohhip_set_new_ref).  Two GOPs, 8 frame threads."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    monkeypatch.setenv("OHHIP_OWN_FRAMES", own_frames)
+    aus, _ = ps.generate(ps.StreamParams(gop="random_access", nframes=17, seed=7, width=7680, height=4320, log2_ctb=6, bit_depth=10, **ENCODER_LIKE))
+    ref = ps.decode_stream("c", aus)
+    _compare(ref, ps.decode_stream("hip", aus, 8, 1))
+
+
 @pytest.mark.parametrize("threads,thread_type", [(1, 1), (8, 1)])
 def test_config4_4k_main10_dense_residual(threads, thread_type):
     """Config 4's geometry in the regime a real 4K Main10 stream lives in: qp22-like syntax statistics (oracle.pystream.DENSE_QP22), ~1 MB of
