@@ -66,6 +66,11 @@ int  ohevc_pic_download(ohevc_ctx *ctx, int slot, int plane, void *host, ptrdiff
 int  ohevc_pic_planes(ohevc_ctx *ctx, int slot, ohevc_plane out[3]);     /* device views (e.g. for an RCCL broadcast) */
 /* the three planes of a picture (host[i] NULL: skip) with one wait at the end */
 int  ohevc_pic_download_planes(ohevc_ctx *ctx, int slot, void *const host[3], const ptrdiff_t host_stride[3]);
+/* ... or QUEUED behind the picture's device work on this context's stream and not waited for: the decoding thread goes on, ohevc_pic_wait_host
+ * (below) returns when the samples are in host[].  The planes must be page-locked memory that stays so until then - blocks of ohevc_host_alloc
+ * (with pageable memory the runtime turns the call into a synchronous copy; a page lock dropped by ohevc_host_unpin in between is NOT waited
+ * for here).  The application's thread then only waits for an event where it used to wait for the device AND issue three copies. */
+int  ohevc_pic_download_queue(ohevc_ctx *ctx, int slot, void *const host[3], const ptrdiff_t host_stride[3]);
 /* Page-lock application memory that ohevc_pic_download / ohevc_pic_upload will be given again and again - the decoder's frame buffers
  * (alloc_frame, hevc_refs.c:75-114: pass the allocations its buffer pool recycles, AVFrame.buf[i]->data / ->size): the copy-back then is
  * one DMA at the bus rate instead of a staged copy through pageable memory.  A range that overlaps an earlier, different registration
@@ -85,6 +90,8 @@ int  ohevc_host_unpin(ohevc_ctx *ctx, void *ptr, size_t bytes);
  * ohevc_host_free takes no context: a block may outlive the context (frames the application still holds when the decoder is closed). */
 int  ohevc_host_alloc(ohevc_ctx *ctx, size_t bytes, void **out);
 int  ohevc_host_free(void *ptr);
+int  ohevc_host_alloc_pins(const ohevc_ctx *ctx);  /* 1: this context's ohevc_host_alloc page-locks (it has a device), 0: a record-only context */
+int  ohevc_host_block_pinned(const void *ptr);     /* 1: page-locked, 0: plain memory (made by a record-only context), -1: not a block of ohevc_host_alloc */
 /* Choices a decoder instance makes for the contexts it creates (value < 0: back to the process default, which include/ohevc_debug.h's setters
  * move for tests).  OHEVC_OPT_LEVEL_LAUNCH: executor of the intra-coded blocks - 0 dependency levels (chain kernel; default), 1 all levels in one
  * launch, 2 chosen per picture, 3 CTB tasks; OHEVC_OPT_FILTERS_ON_DEVICE: 1 deblocking parameters derived on the device from the decoder's maps

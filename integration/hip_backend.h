@@ -66,6 +66,9 @@ typedef struct ohhip_options {
                               * application has installed a get_buffer2 of its own; 0: the decoder's allocator stays, pin_frames page-locks what it hands out.
                               * Why it is the default: the reference's frame pool frees and re-creates its buffers in mid-stream (utils.c:509-575), a
                               * page lock on memory that was freed and mapped again at the same address is dead, and nothing tells the back end */
+    int queue_download;      /* 1 (default; OHHIP_QUEUE_DOWNLOAD): with defer_download and own_frames the copy-back of a picture is QUEUED behind its device
+                              * work by the decoding thread at the frame end (ohevc_pic_download_queue) and ohhip_backend_fetch_output only waits for
+                              * it; 0: fetch_output issues the copies itself (round 5) */
 } ohhip_options;
 
 void ohhip_options_default(ohhip_options *o);
@@ -87,6 +90,7 @@ int  ohhip_backend_frames_mode(ohhip_backend *be, const ohhip_frames_mode *m);
 void ohhip_backend_frames_install(ohhip_backend *be, struct AVCodecContext *avctx);
 int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 int  ohhip_backend_device(const ohhip_backend *be);
+void ohhip_frame_pool_trim(void);                           /* own_frames: blocks of closed decoders are kept for the next one (OHHIP_BLOCK_CACHE_MB, default 1024): give them back */
 void ohhip_frame_pool_counts(long long *made, long long *live);   /* own_frames: page-locked frame-buffer blocks ever made / existing now, process-wide */
 int  ohhip_backend_live_count(void);                        /* back ends alive in this process (tests: open / close must not leak) */
 

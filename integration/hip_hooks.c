@@ -52,6 +52,7 @@ typedef struct ohhip_buf {
     /* the page-locked allocations behind this frame (AVFrame.buf[i]): unpinned when the address comes back with another geometry */
     void *pin_ptr[3];
     size_t pin_bytes[3];
+    int copy_queued;           /* the picture's copy-back was queued at its frame end (queue_download): fetch_output only waits for it */
 } ohhip_buf;
 
 typedef struct ohhip_trace_rec { int tid, poc; double t_start, t_hook, t_issued, t_end; } ohhip_trace_rec;
@@ -83,6 +84,10 @@ struct ohhip_backend {
     /* OHHIP_TRACE_FRAMES: host timeline of every picture */
     ohhip_trace_rec   *trace;
     int                ntrace;
+    int                pinned_blocks;  /* this back end's contexts make page-locked blocks (a record-only back end: plain memory) */
+    int                nthreads;       /* decoding threads of the decoder this back end is attached to */
+    pthread_t          prefetch_thread;            /* own_frames: makes the first blocks ahead of the decoder's requests (pool_prefetch_run) */
+    int                prefetch_started, prefetch_size, prefetch_want, prefetch_cap;
     struct ohhip_frame_pool *pool;     /* own_frames: the page-locked blocks this decoder's frame buffers are made of (outlives the back end while blocks are out) */
     struct { int w, h, fmt, planes, linesize[4], size[4]; ptrdiff_t off[4]; } layouts[4];      /* frame layouts seen (ohhip_get_buffer2) */
     int                nlayouts;
@@ -93,15 +98,71 @@ struct ohhip_backend {
 /* ---- own_frames: the decoder's frame buffers out of page-locked memory of the back end's own ----
  * Blocks are recycled by exact size (a decoder has one size per plane) and given back to the runtime when the back end is freed; a block the
  * application still holds then (a frame it has not released) frees itself when it is released.  The pool object outlives the back end for that. */
-typedef struct ohhip_block { void *ptr; int size; struct ohhip_frame_pool *pool; struct ohhip_block *next; } ohhip_block;
+typedef struct ohhip_block { void *ptr; int size; int out; struct ohhip_frame_pool *pool; struct ohhip_block *next; } ohhip_block;      /* out: plane buffers of it the decoder / the application still holds */
 typedef struct ohhip_frame_pool {
     pthread_mutex_t m;
     int alive, refs;                   /* refs: the back end + every block that is out */
+    int stop_prefetch;
     ohhip_block *free_list;
     ohhip_block **blocks;              /* every block that exists (free or out): whose buffer is it? (pool_owns: pointer comparison only) */
     int nblocks, cap_blocks;
     long long bytes;
 } ohhip_frame_pool;
+
+/* Blocks outlive their decoder in a process-wide cache (by size and kind; OHHIP_BLOCK_CACHE_MB, default 1024, 0: none): an application that
+ * opens a decoder after closing one - a seek, the next file of a play-list, every repetition of a benchmark - gets its frame buffers without
+ * forty page-locking calls in front of its first pictures (0.33 ms per 1080p frame, 7 ms per 8K frame: profiles/r6zc_host_block_probe.txt).
+ * ohhip_frame_pool_trim() gives the cache back to the runtime. */
+static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct { void *ptr; int size; } *g_cache;
+static int g_ncache, g_cap_cache;
+static long long g_cache_bytes, g_cache_limit = -1;
+static void *cache_take(int size, int pinned)
+{
+    void *ptr = NULL;
+    int i;
+    pthread_mutex_lock(&g_cache_lock);
+    for (i = g_ncache - 1; i >= 0 && !ptr; i--)
+        if (g_cache[i].size == size && ohevc_host_block_pinned(g_cache[i].ptr) == pinned) {
+            ptr = g_cache[i].ptr;
+            g_cache[i] = g_cache[--g_ncache];
+            g_cache_bytes -= size;
+        }
+    pthread_mutex_unlock(&g_cache_lock);
+    return ptr;
+}
+static void cache_put(void *ptr, int size)         /* or back to the runtime, when the cache is full */
+{
+    int kept = 0;
+    pthread_mutex_lock(&g_cache_lock);
+    if (g_cache_limit < 0) {
+        const char *v = getenv("OHHIP_BLOCK_CACHE_MB");
+        g_cache_limit = (v && v[0] ? atoll(v) : 1024) << 20;
+    }
+    if (g_cache_bytes + size <= g_cache_limit) {
+        if (g_ncache == g_cap_cache) {
+            const int cap = g_cap_cache ? 2 * g_cap_cache : 64;
+            void *grown = realloc(g_cache, (size_t)cap * sizeof(*g_cache));
+            if (grown) { g_cache = grown; g_cap_cache = cap; }
+        }
+        if (g_ncache < g_cap_cache) {
+            g_cache[g_ncache].ptr = ptr; g_cache[g_ncache].size = size; g_ncache++;
+            g_cache_bytes += size;
+            kept = 1;
+        }
+    }
+    pthread_mutex_unlock(&g_cache_lock);
+    if (!kept)
+        ohevc_host_free(ptr);
+}
+void ohhip_frame_pool_trim(void)
+{
+    pthread_mutex_lock(&g_cache_lock);
+    while (g_ncache > 0)
+        ohevc_host_free(g_cache[--g_ncache].ptr);
+    g_cache_bytes = 0;
+    pthread_mutex_unlock(&g_cache_lock);
+}
 
 static long long g_pool_made, g_pool_live;          /* blocks ever made / existing now, process-wide (ohhip_frame_pool_counts: tests, leak checks) */
 void ohhip_frame_pool_counts(long long *made, long long *live)
@@ -120,13 +181,16 @@ static void pool_forget_locked(ohhip_frame_pool *p, ohhip_block *b)
 }
 static void pool_destroy(ohhip_frame_pool *p) { pthread_mutex_destroy(&p->m); free(p->blocks); free(p); }
 
-/* the AVBuffer free callback of a block: back onto the free list, or - the back end is gone - back to the runtime */
+/* the AVBuffer free callback of a plane of a block; the last one puts the block back onto the free list, or - the back end is gone - gives it
+ * back to the runtime */
 static void pool_release(void *opaque, uint8_t *data)
 {
     ohhip_block *b = opaque;
     ohhip_frame_pool *p = b->pool;
     int dead, last;
     (void)data;
+    if (__atomic_sub_fetch(&b->out, 1, __ATOMIC_ACQ_REL) > 0)
+        return;
     pthread_mutex_lock(&p->m);
     dead = !p->alive;
     if (dead)
@@ -138,48 +202,111 @@ static void pool_release(void *opaque, uint8_t *data)
     last = --p->refs == 0;
     pthread_mutex_unlock(&p->m);
     if (dead) {
-        ohevc_host_free(b->ptr);
+        cache_put(b->ptr, b->size);
         free(b);
     }
     if (last)
         pool_destroy(p);
 }
 
-static AVBufferRef *pool_get(ohhip_backend *be, int size)
+/* a new block of the pool (listed in blocks[]); `out`: handed to the caller (counted in refs) instead of put onto the free list */
+static ohhip_block *pool_make_block(ohhip_frame_pool *p, ohevc_ctx *ctx, int size, int out, int pinned)
+{
+    ohhip_block *b;
+    void *mem = NULL;
+    /* (not cleared, unlike the decoder's own pool - av_buffer_allocz, utils.c:558-560: every sample of the picture area arrives by the
+     * copy-back, the edge around it is read by nobody - motion compensation runs on the device picture) */
+    if (!(mem = cache_take(size, pinned)) && ohevc_host_alloc(ctx, (size_t)size, &mem) != OHEVC_OK)
+        return NULL;
+    if (!(b = calloc(1, sizeof(*b)))) { cache_put(mem, size); return NULL; }
+    b->ptr = mem; b->size = size; b->pool = p;
+    pthread_mutex_lock(&p->m);
+    if (p->nblocks == p->cap_blocks) {
+        const int cap = p->cap_blocks ? 2 * p->cap_blocks : 64;
+        ohhip_block **grown = realloc(p->blocks, (size_t)cap * sizeof(*grown));
+        if (!grown) { pthread_mutex_unlock(&p->m); cache_put(mem, size); free(b); return NULL; }
+        p->blocks = grown; p->cap_blocks = cap;
+    }
+    p->blocks[p->nblocks++] = b;
+    p->bytes += size;
+    __atomic_fetch_add(&g_pool_made, 1, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_pool_live, 1, __ATOMIC_RELAXED);
+    if (out)
+        p->refs++;
+    else {
+        b->next = p->free_list;
+        p->free_list = b;
+    }
+    pthread_mutex_unlock(&p->m);
+    return b;
+}
+
+/* one block = one frame (its planes back to back, each at a multiple of 64 bytes): ONE allocation per frame buffer the decoder ever needs */
+static ohhip_block *pool_get(ohhip_backend *be, int size)
 {
     ohhip_frame_pool *p = be->pool;
     ohhip_block *b = NULL, **pp;
-    AVBufferRef *ref;
     pthread_mutex_lock(&p->m);
     for (pp = &p->free_list; *pp; pp = &(*pp)->next)
         if ((*pp)->size == size) { b = *pp; *pp = b->next; break; }
     if (b)
         p->refs++;
     pthread_mutex_unlock(&p->m);
-    if (!b) {
-        void *mem = NULL;
-        if (ohevc_host_alloc(be->root, (size_t)size, &mem) != OHEVC_OK)
-            return NULL;
-        memset(mem, 0, (size_t)size);          /* (the decoder's own pool hands out cleared buffers: av_buffer_allocz, utils.c:558-560) */
-        if (!(b = calloc(1, sizeof(*b)))) { ohevc_host_free(mem); return NULL; }
-        b->ptr = mem; b->size = size; b->pool = p;
+    if (!b && !(b = pool_make_block(p, be->root, size, 1, be->pinned_blocks)))
+        return NULL;
+    b->out = 1;                         /* the caller's own hold: dropped (pool_release) once the plane buffers are made */
+    return b;
+}
+
+/* Page-locking a frame's worth of memory costs the runtime a fraction of a millisecond (at 8K: several), and a frame thread asks for its frame
+ * in the picture's serial prologue (hevc_frame_start, in front of ff_thread_finish_setup; get_buffer under the decoder's buffer_mutex,
+ * pthread_frame.c:902): during a decoder's first pictures every frame start waited for one such allocation - a fresh decoder's first pass
+ * at 16 frame threads ran at 2200-2400 pictures a second where the round-5 form (page locks taken on the decoder's own buffers) reached
+ * 2600-2800 (profiles/r6za_*).  So the first frame of a geometry starts a helper that makes the blocks the decoder is about to ask for -
+ * one per decoding thread and a picture buffer's worth - while the threads parse; it ends when it has made them or the back end is freed. */
+static void *pool_prefetch_run(void *arg)
+{
+    ohhip_backend *be = arg;
+    ohhip_frame_pool *p = be->pool;
+    int made = 0;
+    while (made < be->prefetch_want) {
+        int go;
         pthread_mutex_lock(&p->m);
-        if (p->nblocks == p->cap_blocks) {
-            const int cap = p->cap_blocks ? 2 * p->cap_blocks : 64;
-            ohhip_block **grown = realloc(p->blocks, (size_t)cap * sizeof(*grown));
-            if (!grown) { pthread_mutex_unlock(&p->m); ohevc_host_free(mem); free(b); return NULL; }
-            p->blocks = grown; p->cap_blocks = cap;
-        }
-        p->blocks[p->nblocks++] = b;
-        p->bytes += size;
-        __atomic_fetch_add(&g_pool_made, 1, __ATOMIC_RELAXED);
-        __atomic_fetch_add(&g_pool_live, 1, __ATOMIC_RELAXED);
-        p->refs++;
+        go = p->alive && !p->stop_prefetch && p->nblocks < be->prefetch_cap;
         pthread_mutex_unlock(&p->m);
+        if (!go || !pool_make_block(p, be->root, be->prefetch_size, 0, be->pinned_blocks))
+            break;
+        made++;
     }
-    if (!(ref = av_buffer_create(b->ptr, size, pool_release, b, 0)))
-        pool_release(b, b->ptr);
-    return ref;
+    return NULL;
+}
+
+static void pool_prefetch_start(ohhip_backend *be, int size)        /* be->lock held (once per back end: the first geometry) */
+{
+    long long budget = 2048ll << 20;            /* at most 2 GiB ahead of demand */
+    int want = be->nthreads + 8;
+    if (be->prefetch_started || !be->pool || be->opt.record_only)
+        return;
+    if ((long long)want * size > budget)
+        want = (int)(budget / size);
+    if (want < 2)
+        return;
+    be->prefetch_size = size;
+    be->prefetch_want = want;
+    be->prefetch_cap = want + 4;
+    if (pthread_create(&be->prefetch_thread, NULL, pool_prefetch_run, be) == 0)
+        be->prefetch_started = 1;
+}
+
+static void pool_prefetch_stop(ohhip_backend *be)                    /* before the contexts go (ohhip_backend_free) */
+{
+    if (!be->prefetch_started)
+        return;
+    pthread_mutex_lock(&be->pool->m);
+    be->pool->stop_prefetch = 1;
+    pthread_mutex_unlock(&be->pool->m);
+    pthread_join(be->prefetch_thread, NULL);
+    be->prefetch_started = 0;
 }
 
 /* is this AVBufferRef one of the pool's blocks?  (its opaque pointer is compared, never followed) */
@@ -193,7 +320,7 @@ static int pool_owns(ohhip_backend *be, const AVBufferRef *ref)
     o = av_buffer_get_opaque(ref);
     pthread_mutex_lock(&p->m);
     for (i = 0; i < p->nblocks && !found; i++)
-        found = p->blocks[i] == o && p->blocks[i]->ptr == (void *)ref->data;
+        found = p->blocks[i] == o && (uint8_t *)p->blocks[i]->ptr <= ref->data && ref->data < (uint8_t *)p->blocks[i]->ptr + p->blocks[i]->size;
     pthread_mutex_unlock(&p->m);
     return found;
 }
@@ -216,7 +343,7 @@ static void pool_close(ohhip_backend *be)       /* ohhip_backend_free: after the
     pthread_mutex_unlock(&p->m);
     while ((b = list)) {
         list = b->next;
-        ohevc_host_free(b->ptr);
+        cache_put(b->ptr, b->size);
         free(b);
     }
     if (last)
@@ -525,6 +652,7 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
     f = s->ref->frame;
     if ((i = slot_of_frame_locked(be, ctx, s, f, &fresh)) < 0)
         return AVERROR(ENOMEM);
+    be->bufs[i].copy_queued = 0;        /* (a picture nobody took out: its queued copy is ordered in front of the new picture's work by the store) */
     /* INTEGRATION.md section 3, row alloc_frame: page-lock the buffers the decoder's pool recycles (hevc_refs.c:75-114, get_buffer.c), so
      * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once.  (After the
      * slot look-up: a buffer that came back with another geometry had its old page locks dropped there.) */
@@ -995,6 +1123,7 @@ void ohhip_options_default(ohhip_options *o)
     o->crash_backtrace = env_str("OHHIP_BACKTRACE") != NULL;
     o->park_frames = env_int("OHHIP_PARK_FRAMES", -1);
     o->own_frames = env_int("OHHIP_OWN_FRAMES", 1) != 0;
+    o->queue_download = env_int("OHHIP_QUEUE_DOWNLOAD", 1) != 0;
 }
 
 /* this instance's choices on a context it has made (the library's process-wide debug setters stay what they are: defaults for tests) */
@@ -1058,6 +1187,7 @@ ohhip_backend *ohhip_backend_new(const ohhip_options *o)
         return NULL;
     }
     apply_ctx_options(be, be->root);
+    be->pinned_blocks = ohevc_host_alloc_pins(be->root);
     if (be->opt.own_frames && (be->pool = calloc(1, sizeof(*be->pool)))) {
         pthread_mutex_init(&be->pool->m, NULL);
         be->pool->alive = be->pool->refs = 1;
@@ -1090,7 +1220,27 @@ int ohhip_backend_options(const ohhip_backend *be, ohhip_options *out)
  * it directly, pthread_frame.c:903-908).  The LAYOUT of a frame - plane sizes, line sizes, where the picture starts behind its edge - is the
  * decoder's own: the first frame of every geometry is made by avcodec_default_get_buffer2 (utils.c:735) and measured; its buffers, and those
  * of every later frame, are then blocks of the back end's page-locked pool.  Nothing here restates how the reference lays a frame out. */
+static int get_buffer2_impl(AVCodecContext *avctx, AVFrame *frame, int flags);
+static double g_getbuf_s; static long g_getbuf_n;       /* OHHIP_TRACE_POOL: time inside get_buffer2, process-wide */
 static int ohhip_get_buffer2(AVCodecContext *avctx, AVFrame *frame, int flags)
+{
+    static int trace = -1;
+    double t0;
+    int ret;
+    if (trace < 0)
+        trace = getenv("OHHIP_TRACE_POOL") != NULL;
+    if (!trace)
+        return get_buffer2_impl(avctx, frame, flags);
+    t0 = now_s();
+    ret = get_buffer2_impl(avctx, frame, flags);
+    pthread_mutex_lock(&g_prof_lock);
+    g_getbuf_s += now_s() - t0; g_getbuf_n++;
+    if (g_getbuf_n % 33 == 0)
+        fprintf(stderr, "pool: %ld frames from get_buffer2, %.3f ms each\n", g_getbuf_n, 1e3 * g_getbuf_s / g_getbuf_n);
+    pthread_mutex_unlock(&g_prof_lock);
+    return ret;
+}
+static int get_buffer2_impl(AVCodecContext *avctx, AVFrame *frame, int flags)
 {
     ohhip_backend *be = NULL, *b;
     AVBufferRef *refs[4] = { NULL, NULL, NULL, NULL };
@@ -1129,18 +1279,40 @@ static int ohhip_get_buffer2(AVCodecContext *avctx, AVFrame *frame, int flags)
                 be->layouts[li].off[k] = k < planes ? frame->data[k] - frame->buf[k]->data : 0;
             }
             be->nlayouts++;
+            if (li == 0) {
+                int total = 0;
+                for (k = 0; k < planes; k++)
+                    total += (be->layouts[0].size[k] + 63) & ~63;
+                pool_prefetch_start(be, total);
+            }
         }
         pthread_mutex_unlock(&be->lock);
         if (li < 0)
             return 0;                           /* a layout this allocator does not take over (or a fifth geometry): the decoder's own frame */
     }
-    for (k = 0; k < be->layouts[li].planes; k++)
-        if (!(refs[k] = pool_get(be, be->layouts[li].size[k]))) {
-            while (k-- > 0)
+    {
+        ohhip_block *blk;
+        int total = 0, at = 0, failed = 0;
+        for (k = 0; k < be->layouts[li].planes; k++)
+            total += (be->layouts[li].size[k] + 63) & ~63;
+        if (!(blk = pool_get(be, total)))       /* no page-locked memory: the decoder's own frame (kept if it was just made to measure the layout) */
+            return frame->buf[0] ? 0 : avcodec_default_get_buffer2(avctx, frame, flags);
+        for (k = 0; k < be->layouts[li].planes && !failed; k++) {
+            __atomic_add_fetch(&blk->out, 1, __ATOMIC_ACQ_REL);
+            if (!(refs[k] = av_buffer_create((uint8_t *)blk->ptr + at, be->layouts[li].size[k], pool_release, blk, 0))) {
+                __atomic_sub_fetch(&blk->out, 1, __ATOMIC_ACQ_REL);
+                failed = 1;
+            }
+            at += (be->layouts[li].size[k] + 63) & ~63;
+        }
+        if (failed) {
+            for (k = 0; k < 4; k++)
                 av_buffer_unref(&refs[k]);
-            /* no page-locked memory: the decoder's own frame (kept if it was just made to measure the layout) */
+            pool_release(blk, NULL);
             return frame->buf[0] ? 0 : avcodec_default_get_buffer2(avctx, frame, flags);
         }
+        pool_release(blk, NULL);                /* (this function's own hold) */
+    }
     for (k = 0; k < 4; k++) {
         av_buffer_unref(&frame->buf[k]);        /* (the measured frame's buffers go back to the decoder's pool) */
         frame->buf[k] = refs[k];
@@ -1157,6 +1329,7 @@ int ohhip_backend_attach(ohhip_backend *be, AVCodecContext *avctx)
         return -1;
     avctx->opaque = be;          /* inherited by every frame-thread copy (pthread_frame.c:276 and the `*copy = *src` of its init) */
     /* own_frames: unless the application brought an allocator of its own (the field is the default's after avcodec_alloc_context3) */
+    be->nthreads = avctx->thread_count > 1 ? avctx->thread_count : 1;
     if (be->pool && avctx->get_buffer2 == avcodec_default_get_buffer2) {
         avctx->get_buffer2 = ohhip_get_buffer2;
         avctx->thread_safe_callbacks = 1;
@@ -1264,6 +1437,7 @@ void ohhip_backend_free(ohhip_backend *be)
         }
     }
     free(be->trace);
+    pool_prefetch_stop(be);
     if (be->opt.base_layer && be->root)         /* the store outlives this back end: give its pictures back */
         for (i = 0; i < be->nbufs; i++) {
             ohevc_tables_unregister_picture(be->root, be->bufs[i].slot);
@@ -1463,7 +1637,25 @@ static int frame_done(ohhip_backend *be)
     if (async && ((t_s && t_s->decode_checksum_sei) || be->fm_on || !ohevc_ctx_has_device(t_ctx)))
         async = 0;
     ohevc_ctx_set_option(t_ctx, OHEVC_OPT_PARK_FRAMES, be->fm_on ? 0 : be->opt.park_frames);      /* frames mode over processes exports the picture right below: no parking */
-    st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame2(t_ctx, !be->opt.defer_download, &t_issued);
+    /* The copy-back: 1 = issued and waited for here (defer_download 0); 0 = left to ohhip_backend_fetch_output; 2 (round 6) = QUEUED here behind
+     * the picture's device work, on this thread's stream, and only WAITED for at fetch - the application's thread, which every picture of
+     * every decoding thread passes through in output order, no longer issues three copies and a wait per picture (0.12 ms of its 0.39 ms per
+     * picture on the encoder-like stream at 16 frame threads, 0.66 of 1.2 ms on the all-intra one: profiles/r6y_app_thread_split.txt).  Only
+     * into frame buffers of the back end's own (page-locked for good), without parked frame ends, not in frames mode. */
+    {
+        int mode = !be->opt.defer_download;
+        if (!async && !mode && be->opt.queue_download && be->opt.park_frames <= 0 && !be->fm_on && t_s && t_s->ref && t_s->ref->frame &&
+            ohevc_ctx_has_device(t_ctx) && pool_owns(be, t_s->ref->frame->buf[0]))
+            mode = 2;
+        st = async ? ohevc_tables_end_frame_async(t_ctx, 1) : ohevc_tables_end_frame2(t_ctx, mode, &t_issued);
+        if (mode == 2 && st == OHEVC_OK) {
+            int i;
+            pthread_mutex_lock(&be->lock);
+            if ((i = find_buf_locked(be, t_s->ref->frame->data[0])) >= 0)
+                be->bufs[i].copy_queued = 1;
+            pthread_mutex_unlock(&be->lock);
+        }
+    }
     if (async)
         __atomic_store_n(&be->async_used, 1, __ATOMIC_RELAXED);
     t1 = now_s();
@@ -1569,19 +1761,29 @@ void ohhip_report_progress(ThreadFrame *f, int progress, int field)
 int ohhip_backend_fetch_output(ohhip_backend *be, uint8_t *const data[3], const int linesize[3])
 {
     ohevc_ctx *ctx;
-    int i, slot = -1;
+    int i, slot = -1, queued = 0;
     if (!be)
         be = t_be;
     if (!be || (!be->opt.defer_download && !__atomic_load_n(&be->async_used, __ATOMIC_RELAXED)) || !be->root || !data[0])
         return 0;
     ctx = t_be == be && t_ctx ? t_ctx : be->root;
     pthread_mutex_lock(&be->lock);
-    if ((i = find_buf_locked(be, data[0])) >= 0)
+    if ((i = find_buf_locked(be, data[0])) >= 0) {
         slot = be->bufs[i].slot;
+        queued = be->bufs[i].copy_queued;
+        be->bufs[i].copy_queued = 0;
+    }
     pthread_mutex_unlock(&be->lock);
     if (slot < 0) {
         fprintf(stderr, "ohhip: output picture is not in the picture store\n");
         return -1;
+    }
+    if (queued) {                               /* the copy-back was queued at the picture's frame end: wait until it has landed */
+        if (ohevc_tables_fetch_picture(ctx, slot) != OHEVC_OK) {
+            fprintf(stderr, "ohhip: queued copy-back failed: %s\n", ohevc_last_error());
+            return -1;
+        }
+        return 0;
     }
     if (__atomic_load_n(&be->async_used, __ATOMIC_RELAXED) && !be->opt.defer_download) {     /* the copy-back was queued by the issuer: wait until it has landed */
         if (ohevc_tables_fetch_picture(ctx, slot) != OHEVC_OK || ohevc_ctx_async_status(ctx) != OHEVC_OK) {

@@ -448,8 +448,8 @@ extern "C" int ohevc_ctx_create(ohevc_ctx **out, int device)
 // pool: long chains get up to four queues of their own and leave the regular ones to the short frames.
 // ohevc_debug_set_long_chain_levels: a frame whose recorded dependency levels reach this many goes to the long-chain stream (0: never).
 static int g_long_chain_levels = 96;
-static int g_long_chain_pools = 2;       // ohevc_debug_set_long_chain_pools (1: the highest priority only; 3: a hardware queue of its own per context, below)
-extern "C" int ohevc_debug_set_long_chain_pools(int n) { g_long_chain_pools = n < 1 ? 1 : n > 3 ? 3 : n; return OHEVC_OK; }
+static int g_long_chain_pools = 2;       // ohevc_debug_set_long_chain_pools (1: the highest priority only; 3: a hardware queue of its own per context, below; 4: the three priorities in turn)
+extern "C" int ohevc_debug_set_long_chain_pools(int n) { g_long_chain_pools = n < 1 ? 1 : n > 4 ? 4 : n; return OHEVC_OK; }
 extern "C" int ohevc_debug_set_long_chain_levels(int levels) { g_long_chain_levels = levels < 0 ? 0 : levels; return OHEVC_OK; }
 static int select_stream(ohevc_ctx *c, bool long_chain)
 {
@@ -469,7 +469,12 @@ static int select_stream(ohevc_ctx *c, bool long_chain)
             OHEVC_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
             // (contexts alternate between the highest and the lowest priority: two more pools, eight hardware queues for long chains)
             static std::atomic<unsigned> n_long{0};
-            OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, (n_long.fetch_add(1) & 1u) && g_long_chain_pools > 1 ? least : greatest));
+            const unsigned k = n_long.fetch_add(1);
+            // (pools 4: every third context's long chains share the NORMAL priority's queues with the short frames - twelve chains at a time on an
+            // all-intra stream, where the regular streams carry next to nothing)
+            const int prio = g_long_chain_pools == 4 ? (k % 3u == 0 ? greatest : k % 3u == 1 ? least : (least + greatest) / 2)
+                                                     : ((k & 1u) && g_long_chain_pools > 1 ? least : greatest);
+            OHEVC_HIP_TRY(hipStreamCreateWithPriority(&c->stream_long, hipStreamNonBlocking, prio));
         }
         store_add_stream(*c->store, c->stream_long);
     }
@@ -582,6 +587,7 @@ extern "C" void ohevc_ctx_destroy(ohevc_ctx *c)
             for (hipEvent_t e : c->ring) {
                 if (!e) continue;
                 if (p.written == e) p.written = nullptr;
+                if (p.host_copy == e) p.host_copy = nullptr;
                 p.readers.erase(std::remove(p.readers.begin(), p.readers.end(), e), p.readers.end());
             }
         }
@@ -853,6 +859,13 @@ extern "C" int ohevc_host_alloc(ohevc_ctx *c, size_t bytes, void **out)
     if (ohevc::config().trace_pin) fprintf(stderr, "pin: host block %p + %zu (%s)\n", *out, bytes, pinned ? "page-locked" : "plain");
     return OHEVC_OK;
 }
+extern "C" int ohevc_host_alloc_pins(const ohevc_ctx *c) { return c && !c->dry; }
+extern "C" int ohevc_host_block_pinned(const void *ptr)      // 1 page-locked, 0 plain memory (a record-only context made it), -1 not a block
+{
+    if (!ptr) return -1;
+    const HostBlockHeader *h = static_cast<const HostBlockHeader *>(ptr) - 1;
+    return h->magic == kHostBlockMagic && h->base == h ? (int)h->pinned : -1;
+}
 extern "C" int ohevc_host_free(void *ptr)
 {
     if (!ptr) return OHEVC_OK;
@@ -914,6 +927,41 @@ extern "C" int ohevc_pic_download_planes(ohevc_ctx *c, int slot, void *const hos
     OHEVC_HIP_TRY(hipStreamSynchronize(c->stream));
     if (ohevc::config().trace_pin) fprintf(stderr, "pin: copy-back of slot %d landed\n", slot);
     if (g_trace_timing) c->t_part[4] += now_s() - t0;          // (the wait covers the picture's device work as well: nothing waited for it before)
+    return OHEVC_OK;
+}
+
+// The copy-back QUEUED behind the picture's device work on this context's stream, not waited for (ohevc_ctx.h): ohevc_pic_wait_host returns when
+// it has landed.  The event of the copy also counts as a reader of the picture: the next picture begun in the slot is ordered behind it.
+extern "C" int ohevc_pic_download_queue(ohevc_ctx *c, int slot, void *const host[3], const ptrdiff_t host_stride[3])
+{
+    Picture *p = get_pic(c, slot);
+    OHEVC_REQUIRE(p != nullptr && host != nullptr && host_stride != nullptr, "bad argument");
+    if (c->dry) return OHEVC_OK;
+    {
+        std::unique_lock<std::mutex> lk(c->store->m);
+        if (!wait_end_issued(c, *p, lk)) {
+            set_error("picture %d was never completed by its decoding thread", slot);
+            return OHEVC_ERR_STATE;
+        }
+        if (p->failed) { set_error("picture %d: its frame failed", slot); return OHEVC_ERR_STATE; }
+        if (p->written) OHEVC_HIP_TRY(hipStreamWaitEvent(c->stream, p->written, 0));
+    }
+    if (ohevc::config().trace_pin) fprintf(stderr, "pin: copy-back of slot %d queued (ctx %p) -> %p %p %p\n", slot, (void *)c, host[0], host[1], host[2]);
+    for (int i = 0; i < 3; i++) {
+        if (!host[i]) continue;
+        const ohevc_plane &pl = p->planes[i];
+        OHEVC_HIP_TRY(hipMemcpy2DAsync(host[i], host_stride[i], pl.data, pl.stride, (size_t)pl.width * (p->bd > 8 ? 2 : 1), pl.height,
+                                       hipMemcpyDeviceToHost, c->stream));
+    }
+    hipEvent_t ev = c->ring[c->ring_next];
+    c->ring_next = (c->ring_next + 1) % 16;
+    OHEVC_HIP_TRY(hipEventRecord(ev, c->stream));
+    {
+        std::lock_guard<std::mutex> g(c->store->m);
+        p->host_copy = ev;
+        p->host_copy_issued = true;
+        if (std::find(p->readers.begin(), p->readers.end(), ev) == p->readers.end()) p->readers.push_back(ev);
+    }
     return OHEVC_OK;
 }
 

@@ -650,9 +650,14 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
                 // all it takes (the gfx942 memory model: workgroup-scope acquire needs no cache invalidate).  Rounds 2 - 3 issued the AGENT-scope
                 // acquire here (buffer_inv sc1, what a hand-over between workgroups on different CUs needs): it costs every level microseconds
                 // (agent_acquire != 0 keeps that form for A/B runs).
-                xcd_release();
+                // Round 6: not even the wait for the level's stores.  On gfx950 outside thread-group-split mode a workgroup-scope release is NO
+                // instruction at all (what the compiler emits for fence(release, "workgroup") - s_barrier - fence(acquire, "workgroup") is the
+                // barrier alone: stores and loads of one CU reach its L1 / the L2 in issue order) - the s_waitcnt vmcnt(0) of rounds 4-5 made
+                // every level wait for the write acknowledgements of its rows (~1000 of a level's 6350 clocks, profiles/r5r_chain_clocks_*)
+                // before the next level could even ISSUE its loads (agent_acquire bit 1 keeps that form for A/B runs).
+                if (agent_acquire & 2) xcd_release();
                 __syncthreads();
-                if (agent_acquire) xcd_acquire();
+                if (agent_acquire & 1) xcd_acquire();
             }
         } else {
             __syncthreads();

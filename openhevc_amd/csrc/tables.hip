@@ -820,6 +820,7 @@ static int end_frame_common(ohevc_ctx *ctx, int download, bool async, double *is
         return ohevc_frame_end_async(ctx, download ? host : nullptr, strides);
     }
     // no copy-back inside this call: the frame may be parked instead of making this thread wait for other threads' frame ends (ohevc_ctx.h)
+    // (download 2: the copy-back is queued behind the frame end just issued - ohevc_pic_download_queue - and waited for by ohevc_tables_fetch_picture)
     rc = download ? ohevc_frame_end(ctx) : ohevc_frame_end_deferred(ctx);
     if (issued_at) {
         struct timespec ts;
@@ -831,7 +832,7 @@ static int end_frame_common(ohevc_ctx *ctx, int download, bool async, double *is
         const HostPic &hp = s->pics[s->cur].v;
         void *const host[3] = { hp.data[0], hp.data[1], hp.data[2] };
         const ptrdiff_t strides[3] = { hp.linesize[0], hp.linesize[1], hp.linesize[2] };
-        if ((rc = ohevc_pic_download_planes(ctx, hp.slot, host, strides)) != OHEVC_OK) return rc;
+        if ((rc = download == 2 ? ohevc_pic_download_queue(ctx, hp.slot, host, strides) : ohevc_pic_download_planes(ctx, hp.slot, host, strides)) != OHEVC_OK) return rc;
     }
     return OHEVC_OK;
 }

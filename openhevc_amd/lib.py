@@ -222,7 +222,7 @@ def dev_intra_recon_sorted(planes, bit_depth, jobs_ptr, residuals_ptr, count_by_
 
 EXPORTED_SYMBOLS += ["ohevc_dev_intra_recon_sorted", "ohevc_dev_intra_recon_batch", "ohevc_dev_intra_chain", "ohevc_intra_chain_max_waves", "ohevc_host_pin",
                      "ohevc_host_unpin_all", "ohevc_pic_download_planes", "ohevc_frames_transport_create", "ohevc_frames_transport_mode", "ohevc_frames_transport_finish",
-                     "ohevc_frames_transport_destroy", "ohevc_frames_transport_stats", "ohevc_frames_transport_selftest", "ohevc_host_unpin", "ohevc_host_alloc", "ohevc_host_free", "ohevc_intra_chain_workgroup_waves", "ohevc_intra_chain_max_levels"]
+                     "ohevc_frames_transport_destroy", "ohevc_frames_transport_stats", "ohevc_frames_transport_selftest", "ohevc_host_unpin", "ohevc_host_alloc", "ohevc_host_free", "ohevc_host_block_pinned", "ohevc_host_alloc_pins", "ohevc_pic_download_queue", "ohevc_debug_set_chain_handover", "ohevc_intra_chain_workgroup_waves", "ohevc_intra_chain_max_levels"]
 
 
 class BsMaps(C.Structure):

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <time.h>
 
 #include "libavcodec/avcodec.h"
 #include "libavutil/opt.h"
@@ -25,7 +26,7 @@
 #ifdef OHDEC_HIP
 /* integration/hip_backend.h: one back end per decoder instance, attached before avcodec_open2 (the structs are passed through opaquely) */
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames, own_frames; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
+typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames, own_frames, queue_download; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
 void ohhip_options_default(ohdec_options *o);
 size_t ohhip_options_size(void);
 ohhip_backend *ohhip_backend_new(const ohdec_options *o);
@@ -40,7 +41,7 @@ void ohhip_backend_frames_install(ohhip_backend *be, AVCodecContext *avctx);
 int  ohhip_backend_frame_is_local(ohhip_backend *be, const unsigned char *data0);
 #else
 typedef struct ohhip_backend ohhip_backend;
-typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames, own_frames; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
+typedef struct ohdec_options { size_t struct_size; int device, bulk_filters, defer_download, pin_frames, async_issue, record_only, test_fail_index, flush_intra_kib, level_launch, device_filters, crash_backtrace; const char *trace_path; ohhip_backend *base_layer; int park_frames, own_frames, queue_download; } ohdec_options;   /* = ohhip_options, integration/hip_backend.h */
 static void ohhip_options_default(ohdec_options *o) { memset(o, 0, sizeof(*o)); o->struct_size = sizeof(*o); }
 static size_t ohhip_options_size(void) { return sizeof(ohdec_options); }
 static ohhip_backend *ohhip_backend_new(const ohdec_options *o) { (void)o; return NULL; }
@@ -79,7 +80,14 @@ typedef struct ohdec {
     int             pkt_cap;
     int             have_frame;
     int             threads;
+    double          t_decode, t_fetch;     /* seconds of the calling thread inside avcodec_decode_video2 / inside the back end's fetch_output (ohdec_times) */
+    long            n_calls;
 } ohdec;
+
+static double harness_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+/* where the application thread's time goes: [0] inside the decoder's call, [1] inside ohhip_backend_fetch_output (the wait for the picture's
+ * device work + its copy-back), [2] calls - since the decoder was opened */
+void ohdec_times(const ohdec *d, double out[3]) { out[0] = d->t_decode; out[1] = d->t_fetch; out[2] = (double)d->n_calls; }
 
 /* thread_type: 1 frame threads, 2 slice/WPP threads, 3 both (the -f option of the reference's CLI, main_hm/getopt.c) */
 /* checksum: the reference's `decode-checksum` option, set BEFORE avcodec_open2 the way main_hm/main.c does (libOpenHevcSetCheckMD5
@@ -264,7 +272,12 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
         return out;
     }
     av_frame_unref(d->frame);
-    ret = avcodec_decode_video2(d->avctx, d->frame, &got, &pkt);
+    {
+        const double t0 = harness_now();
+        ret = avcodec_decode_video2(d->avctx, d->frame, &got, &pkt);
+        d->t_decode += harness_now() - t0;
+        d->n_calls++;
+    }
     if (ret < 0) {
         ohhip_backend_frame_failed(d->backend);         /* the open frame is aborted and, in frames mode, published as failed */
         return -2;
@@ -273,8 +286,12 @@ int ohdec_decode(ohdec *d, const uint8_t *au, int len, int64_t pts)
     if (ohhip_backend_frame_done(d->backend) < 0)
         return -3;
     /* the application takes the picture: with a deferred copy-back this is where its samples reach the host */
-    if (got && ohhip_backend_fetch_output(d->backend, d->frame->data, d->frame->linesize) < 0)
-        return -3;
+    {
+        const double t0 = harness_now();
+        if (got && ohhip_backend_fetch_output(d->backend, d->frame->data, d->frame->linesize) < 0)
+            return -3;
+        d->t_fetch += harness_now() - t0;
+    }
     d->have_frame = got;
     return got ? 1 : 0;
 }

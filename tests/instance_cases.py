@@ -123,7 +123,7 @@ class _Options(C.Structure):
     """ohhip_options as integration/hip_backend.h has it TODAY"""
     _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("bulk_filters", C.c_int), ("defer_download", C.c_int), ("pin_frames", C.c_int),
                 ("async_issue", C.c_int), ("record_only", C.c_int), ("test_fail_index", C.c_int), ("flush_intra_kib", C.c_int),
-                ("level_launch", C.c_int), ("device_filters", C.c_int), ("crash_backtrace", C.c_int), ("trace_path", C.c_char_p), ("base_layer", C.c_void_p), ("park_frames", C.c_int), ("own_frames", C.c_int)]
+                ("level_launch", C.c_int), ("device_filters", C.c_int), ("crash_backtrace", C.c_int), ("trace_path", C.c_char_p), ("base_layer", C.c_void_p), ("park_frames", C.c_int), ("own_frames", C.c_int), ("queue_download", C.c_int)]
 
 
 class _OldOptions(C.Structure):

@@ -47,6 +47,11 @@ def decode(threads, natural):
                     break
                 n += r
             dt = time.perf_counter() - t
+            import ctypes
+            tm = (ctypes.c_double * 3)()
+            if hasattr(d.L, "ohdec_times"):
+                d.L.ohdec_times(ctypes.c_void_p(d.h) if isinstance(d.h, int) else d.h, tm)
+                print(json.dumps(dict(application_thread=dict(wall_s=round(dt, 4), in_decoder_call_s=round(tm[0], 4), in_fetch_output_s=round(tm[1], 4), calls=int(tm[2])))))
         out = [None] * n
         best = dt if best is None else min(best, dt)
     print(json.dumps(dict(threads=threads, natural=bool(natural), passes=passes, pictures=len(out), fps=round(len(out) / best, 1))))
