@@ -452,6 +452,7 @@ struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
 };
 
 constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup; a wider level takes ceil(width / 8) steps of it (4 wavefronts - one per SIMD - measured in round 5: 8 030 clocks per level against 6 390, profiles/r5m_*)
+constexpr bool kChainIdleSkips = false; // true: empty wavefront slots skip their loads behind a scalar branch.  Measured in round 6 (profiles/r6zd_chain_clocks_idle_slots_skip_slower.jsonl): a level 6350 -> 6920 clocks - the skipped path meets the loading one in front of the arithmetic and the wait counts get conservative again (the round-4 lesson); the dummy loads of an idle wavefront were not what an active one waits for
 constexpr int kChainMaxLevels = 1024;   // levels per launch: their records (48 bytes each) are copied to LDS at the kernel's start
 
 // Round 4.  (a) A level may be WIDER than the workgroup: its wavefront slots 8, 9, ... are served by wavefronts 0, 1, ... in further passes
@@ -578,7 +579,9 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     // copies, and a copy needs the value: s_waitcnt vmcnt(0) right behind the issue of the prefetch - the level waited for the loads it was
     // supposed to hide (the listing of round 4; "issue" = 4700 of a level's 10 500 clocks in profiles/r4t_chain_clocks_mul24.jsonl).
     // A slot without blocks (s < 0) loads from `base` (the upload buffer: always mapped) and its values are never looked at.
+    // (kChainIdleSkips: a wavefront whose slot is EMPTY at a step skips that step's loads - tried in round 6, slower, off)
     auto load_recs = [&](const Slot &sl) -> PackRecs {
+        if (kChainIdleSkips && sl.s < 0) { PackRecs r; r.jw = u32x4{ 0u, 0u, 0u, 0u }; r.rw = u32x4{ 0u, 0u, 0u, 0u }; r.valid = false; r.has_res = false; return r; }
         const int log2n = sl.s + 2;                                    // (s < 0: 1 - harmless)
         const int g = lane >> (log2n & 7);
         PackRecs r;
@@ -592,6 +595,11 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         return r;
     };
     auto load_cq = [&](const Slot &sl, const PackRecs &r, u32x4 (&cq)[4]) {
+        if (kChainIdleSkips && sl.s < 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) cq[q] = u32x4{ 0u, 0u, 0u, 0u };
+            return;
+        }
         // row i of the block's residual as the pre-pass left it in the arena (READY form of pack_load_coeffs): N / 8 pieces of 16 bytes
         // (4x4: the piece that holds rows i and i ^ 1); the remaining of the four loads repeat the last piece
         const int log2n = sl.s + 2, n = 1 << (log2n & 7), i = lane & (n - 1);

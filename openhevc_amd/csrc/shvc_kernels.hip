@@ -128,12 +128,15 @@ constexpr int UPT_ROWS = 64, UPT_WR = 72, UPT_WC = 72 + 8, UPT_HS = 2 * UPT_WR +
 // with 4 taps and must not pay for two copies.
 template <typename Pixel> struct UpTileLds {
     __attribute__((aligned(16))) unsigned char win[UPT_WR * UPT_WC * (int)sizeof(Pixel)];
-    __attribute__((aligned(16))) unsigned char hcol[64 * UPT_HS];
+    __attribute__((aligned(16))) unsigned char hcol[64 * UPT_HS + 64];      // (+ 64: the matrix-core vertical pass reads whole 32-row pieces, the last column's beyond its 72 rows - against zero taps)
     ohevc_upsample_tap srow[UPT_ROWS];
     __attribute__((aligned(16))) unsigned stap16[16][4];
     unsigned stap8[16][2];
+    unsigned vtap[16][11];              // matrix-core vertical pass: a phase's taps as bytes 16 .. 23 of 44, zeros around them
 };
-template <typename Pixel, int TAPS>
+typedef int up_v4i __attribute__((ext_vector_type(4)));
+typedef int up_v16i __attribute__((ext_vector_type(16)));
+template <typename Pixel, int TAPS, bool MFMA>
 __device__ __forceinline__ void upsample_tile_body(UpTileLds<Pixel> &lds, const ohevc_plane &dst, const ohevc_plane &src, const ohevc_upsample_tap *__restrict__ cols,
                                                    const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
                                                    int src_cols, int src_rows, int bit_depth, int tile_x, int tile_y)
@@ -190,6 +193,13 @@ __device__ __forceinline__ void upsample_tile_body(UpTileLds<Pixel> &lds, const 
         const int ph = (tid - 128) >> 1, q = (tid - 128) & 1;
         const signed char *t8 = TAPS == 8 ? kUpLuma[ph] : kUpChroma[ph];
         stap8[ph][q] = 4 * q < TAPS ? pack_i8x4(t8[4 * q], t8[4 * q + 1], t8[4 * q + 2], t8[4 * q + 3]) : 0u;
+    } else if (MFMA && tid >= 160 && tid < 176) {
+        const int ph = tid - 160;
+        const signed char *t8 = TAPS == 8 ? kUpLuma[ph] : kUpChroma[ph];
+#pragma unroll
+        for (int q = 0; q < 11; q++) lds.vtap[ph][q] = 0u;
+        lds.vtap[ph][4] = pack_i8x4(t8[0], t8[1], t8[2], t8[3]);
+        if (TAPS == 8) lds.vtap[ph][5] = pack_i8x4(t8[4], t8[5], t8[6], t8[7]);
     }
     // ---- 1. the window, four samples per thread and step.  8-bit samples are stored as sample - 128 (the horizontal pass multiplies signed
     // bytes: one xor per four samples here instead of two per filtered sample there).  (A 16 x 16 thread layout without the division
@@ -250,6 +260,106 @@ __device__ __forceinline__ void upsample_tile_body(UpTileLds<Pixel> &lds, const 
         }
     }
     __syncthreads();
+    if constexpr (MFMA) {
+        // ---- 3 (round 6). The vertical pass on the matrix cores.  For 32 output rows the pass is a product with a BAND matrix: out[col][row] =
+        // sum_k H[col][k] * V[k][row], V[k][row] = tap (k - first(row)) of the row's phase (hevcdsp_template.c:1835-1953: the same eight / four
+        // multiply-adds per sample, the other 24 / 28 products of a row are zeros the matrix cores do not charge for).  A wavefront takes a
+        // 32-column x 32-row quarter of the tile: A = its columns of the horizontal pass (int16, column-major in LDS: 16 consecutive rows of
+        // a column are 8 dwords) split into high and low bytes the way the 32x32 inverse transform splits its coefficients (tu_kernels.hip:
+        // the low byte biased by -128, made good by 128 x the taps' sum = 128 x 64), B = the rows' taps at their places, built per lane from
+        // a 40-byte padded copy of the phase's taps.  D[col][row] puts four NEIGHBOURING columns of a row into one lane: one store per four
+        // samples.  32 output rows reach over at most 39 base rows (x1; 23 at x2, 29 at x1.5): one or two K steps of 32.  22 vector
+        // instructions per output sample become ~9.
+        // (everything that steers the matrix instructions is wave-uniform AND in scalar registers - readfirstlane: the matrix cores do not look
+        // at the execution mask, a K step "skipped" behind a vector condition runs all the same, on registers nobody loaded)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave & 1, rb = wave >> 1, n = lane & 31, h = lane >> 5;
+        auto first_row = [&](int half) { return __builtin_amdgcn_readfirstlane(((int)srow[32 * half].pos - HALF - rmin) & ~1); };      // (even: 16 rows of a column start on a dword)
+        auto rows_spanned = [&](int half) { return __builtin_amdgcn_readfirstlane((int)srow[32 * half + 31].pos - HALF - rmin + TAPS) - first_row(half); };
+        const int kbase = first_row(rb), span = rows_spanned(rb);
+        // (the whole workgroup takes this form or the dot-product form below: both row halves of the tile must fit two K steps)
+        const bool mfma_done = rows_spanned(0) <= 64 && rows_spanned(1) <= 64;
+        constexpr int TS = 64 * P + 4;                          // row stride of the output tile in LDS: 17 / 33 dwords, odd
+        unsigned char *const tile = win;
+        static_assert(64 * TS <= UPT_WR * UPT_WC * P, "the output tile fits the window's LDS");
+        if (mfma_done) {
+            const int nk = span > 32 ? 2 : 1;
+            const ohevc_upsample_tap tr = srow[32 * rb + n];
+            const int f = (int)tr.pos - HALF - rmin;
+            up_v4i ahi[2], alo[2], bv[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                if (ks < nk) {
+                    const unsigned *hc = reinterpret_cast<const unsigned *>(hcol + (32 * cb + n) * UPT_HS + 2 * (kbase + 32 * ks + 16 * h));
+                    unsigned w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) w[q] = hc[q];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        ahi[ks][q] = (int)perm_b32(w[2 * q + 1], w[2 * q], 0x07050301u);
+                        alo[ks][q] = (int)(perm_b32(w[2 * q + 1], w[2 * q], 0x06040200u) ^ 0x80808080u);
+                    }
+                    // bytes s .. s + 15 of the padded taps (the taps are bytes 16 .. 23): s = 16 + (first row of this lane's piece - first tap row)
+                    int sft = kbase + 32 * ks + 16 * h - f;
+                    sft = 16 + (sft < -16 ? -16 : sft > 8 ? 8 : sft);
+                    const unsigned *vt = &lds.vtap[tr.phase][sft >> 2];
+                    const unsigned t0 = vt[0], t1 = vt[1], t2 = vt[2], t3 = vt[3], t4 = vt[4], sh = (unsigned)sft & 3u;
+                    bv[ks][0] = (int)align_bytes(t1, t0, sh); bv[ks][1] = (int)align_bytes(t2, t1, sh);
+                    bv[ks][2] = (int)align_bytes(t3, t2, sh); bv[ks][3] = (int)align_bytes(t4, t3, sh);
+                }
+            }
+            const up_v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            up_v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[0], bv[0], zero, 0, 0, 0);
+            if (nk > 1) d = __builtin_amdgcn_mfma_i32_32x32x32_i8(ahi[1], bv[1], d, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[r] = (d[r] << 8) + (128 * 64 + (1 << 11));      // + the low bytes' bias, + I_OFFSET (hevcdsp.h:40-41)
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[0], bv[0], d, 0, 0, 0);
+            if (nk > 1) d = __builtin_amdgcn_mfma_i32_32x32x32_i8(alo[1], bv[1], d, 0, 0, 0);
+            // D[col][row] leaves a lane four neighbouring samples of ONE row and a wavefront 32 rows: stored from here a store instruction would
+            // touch 8 bytes of each of 32 lines (measured: the pass ran slower than the dot products it replaced, profiles/r6zf_*).  The quarter
+            // tiles meet in LDS instead (the window of stage 1 is free since the second barrier) and leave as whole rows, 16 / 32 bytes a thread.
+            {
+                const int maxv = (1 << bit_depth) - 1;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    int v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int t = d[4 * g + j] >> 12; v[j] = t < 0 ? 0 : t > maxv ? maxv : t; }      // N_SHIFT
+                    unsigned char *tp = tile + (32 * rb + n) * TS + (32 * cb + 8 * g + 4 * h) * P;
+                    if constexpr (P == 1) *reinterpret_cast<unsigned *>(tp) = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+                    else { reinterpret_cast<unsigned *>(tp)[0] = (unsigned)v[0] | ((unsigned)v[1] << 16); reinterpret_cast<unsigned *>(tp)[1] = (unsigned)v[2] | ((unsigned)v[3] << 16); }
+                }
+            }
+        }
+        if (mfma_done) {
+            __syncthreads();
+            // thread -> (row, 16-byte piece of it); 16-bit samples: two pieces
+            const int row = tid >> 2, piece = tid & 3, y = ty0 + row;
+            const bool aligned = ((reinterpret_cast<uintptr_t>(dst.data) | (unsigned)dst.stride) & 15) == 0;
+            if (y < dst.height) {
+                unsigned char *orow = static_cast<unsigned char *>(dst.data) + __umul24((unsigned)y, (unsigned)dst.stride) + (unsigned)tx0 * (unsigned)P;
+#pragma unroll
+                for (int part2 = 0; part2 < P; part2++) {
+                    const int b0 = 16 * (piece + 4 * part2);    // byte offset inside the tile row
+                    const unsigned *tp = reinterpret_cast<const unsigned *>(tile + row * TS + b0);
+                    const u32x4 o = u32x4{ tp[0], tp[1], tp[2], tp[3] };
+                    const int x0 = tx0 + b0 / P;                // first sample of the piece
+                    if (aligned && x0 + 16 / P <= dst.width) {
+                        *reinterpret_cast<u32x4 *>(orow + b0) = o;
+                    } else {
+                        const unsigned ow[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+                        for (int e = 0; e < 16 / P; e++)
+                            if (x0 + e < dst.width) {
+                                if constexpr (P == 1) orow[b0 + e] = (unsigned char)(ow[e >> 2] >> (8 * (e & 3)));
+                                else reinterpret_cast<unsigned short *>(orow + b0)[e] = (unsigned short)(ow[e >> 1] >> (16 * (e & 1)));
+                            }
+                    }
+                }
+            }
+            return;
+        }
+        // (a row map that reaches over more than 64 base rows in 32 output rows: never the reference's x1 .. x2 patterns - the dot-product form below)
+    }
     // ---- 3. vertical pass: thread = (four neighbouring output columns, four consecutive output rows).  One store per four samples (a lane
     // per column stored single bytes: 64 bytes per store instruction of a wavefront), and what depends on the row only - the row's map
     // entry, its taps, the address - once per four samples.
@@ -299,13 +409,13 @@ __device__ __forceinline__ void upsample_tile_body(UpTileLds<Pixel> &lds, const 
     }
 }
 
-template <typename Pixel, int TAPS>
+template <typename Pixel, int TAPS, bool MFMA>
 __global__ __launch_bounds__(256) void upsample_tile_kernel(ohevc_plane dst, ohevc_plane src, const ohevc_upsample_tap *__restrict__ cols,
                                                             const int16_t *__restrict__ col_of, const ohevc_upsample_tap *__restrict__ rows,
                                                             int src_cols, int src_rows, int bit_depth)
 {
     __shared__ UpTileLds<Pixel> lds;
-    upsample_tile_body<Pixel, TAPS>(lds, dst, src, cols, col_of, rows, src_cols, src_rows, bit_depth, (int)blockIdx.x, (int)blockIdx.y);
+    upsample_tile_body<Pixel, TAPS, MFMA>(lds, dst, src, cols, col_of, rows, src_cols, src_rows, bit_depth, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // The three planes of an inter-layer picture in ONE launch (a two-layer decode made three per picture, 5.5-8.5 us each): the luma tiles,
@@ -317,14 +427,14 @@ struct UpPlaneArgs {
     int src_cols, src_rows, tiles_x, tiles;
 };
 struct UpPictureArgs { UpPlaneArgs pl[3]; };
-template <typename Pixel>
+template <typename Pixel, bool MFMA>
 __global__ __launch_bounds__(256) void upsample_tile3_kernel(UpPictureArgs a, int bit_depth)
 {
     __shared__ UpTileLds<Pixel> lds;
     int t = (int)blockIdx.x;
     if (t < a.pl[0].tiles) {
         const UpPlaneArgs &q = a.pl[0];
-        upsample_tile_body<Pixel, 8>(lds, q.dst, q.src, q.cols, q.col_of, q.rows, q.src_cols, q.src_rows, bit_depth, t % q.tiles_x, t / q.tiles_x);
+        upsample_tile_body<Pixel, 8, MFMA>(lds, q.dst, q.src, q.cols, q.col_of, q.rows, q.src_cols, q.src_rows, bit_depth, t % q.tiles_x, t / q.tiles_x);
         return;
     }
     t -= a.pl[0].tiles;
@@ -336,7 +446,7 @@ __global__ __launch_bounds__(256) void upsample_tile3_kernel(UpPictureArgs a, in
     const int16_t *col_of = c == 1 ? a.pl[1].col_of : a.pl[2].col_of;
     const int src_cols = c == 1 ? a.pl[1].src_cols : a.pl[2].src_cols, src_rows = c == 1 ? a.pl[1].src_rows : a.pl[2].src_rows;
     const int tiles_x = c == 1 ? a.pl[1].tiles_x : a.pl[2].tiles_x;
-    upsample_tile_body<Pixel, 4>(lds, dst, src, cols, col_of, rows, src_cols, src_rows, bit_depth, t % tiles_x, t / tiles_x);
+    upsample_tile_body<Pixel, 4, MFMA>(lds, dst, src, cols, col_of, rows, src_cols, src_rows, bit_depth, t % tiles_x, t / tiles_x);
 }
 
 // Where an enhancement-layer column / row reads the base layer: centre tap position and phase.
@@ -366,7 +476,7 @@ static void axis_map(int variant, bool chroma, bool vertical, int v, int start, 
 
 }  // namespace ohevc
 
-static int g_upsample_variant = 0;      // 0: tile form (shipped), 1: round-2 strip form
+static int g_upsample_variant = 0;      // 0: tile form, vertical pass on the matrix cores (shipped since round 6), 2: tile form with the dot-product vertical pass (round 4), 1: round-2 strip form
 extern "C" int ohevc_debug_set_upsample_variant(int v) { const int prev = g_upsample_variant; g_upsample_variant = v; return prev; }
 
 extern "C" int ohevc_upsample_make_maps(const ohevc_upsample_params *p, int plane, ohevc_upsample_tap *cols, int16_t *col_of,
@@ -407,7 +517,7 @@ extern "C" int ohevc_dev_upsample_picture(const ohevc_plane dst[3], const ohevc_
     using namespace ohevc;
     OHEVC_REQUIRE(dst != nullptr && src != nullptr && cols != nullptr && col_of != nullptr && rows != nullptr && src_cols != nullptr && src_rows != nullptr, "null argument");
     OHEVC_REQUIRE(OHEVC_BIT_DEPTH_OK(bit_depth), "bit_depth must be 8..12 or 14");
-    if (g_upsample_variant != 0) {                       // the strip form has no three-plane kernel
+    if (g_upsample_variant == 1) {                       // the strip form has no three-plane kernel
         for (int pl = 0; pl < 3; pl++) {
             int rc = ohevc_dev_upsample_plane(&dst[pl], &src[pl], bit_depth, pl != 0, cols[pl], col_of[pl], rows[pl], src_cols[pl], src_rows[pl], stream);
             if (rc != OHEVC_OK) return rc;
@@ -427,8 +537,13 @@ extern "C" int ohevc_dev_upsample_picture(const ohevc_plane dst[3], const ohevc_
         total += q.tiles;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bit_depth == 8) hipLaunchKernelGGL((upsample_tile3_kernel<uint8_t>), dim3(total), dim3(256), 0, st, a, bit_depth);
-    else                hipLaunchKernelGGL((upsample_tile3_kernel<uint16_t>), dim3(total), dim3(256), 0, st, a, bit_depth);
+    if (g_upsample_variant == 0) {
+        if (bit_depth == 8) hipLaunchKernelGGL((upsample_tile3_kernel<uint8_t, true>), dim3(total), dim3(256), 0, st, a, bit_depth);
+        else                hipLaunchKernelGGL((upsample_tile3_kernel<uint16_t, true>), dim3(total), dim3(256), 0, st, a, bit_depth);
+    } else {
+        if (bit_depth == 8) hipLaunchKernelGGL((upsample_tile3_kernel<uint8_t, false>), dim3(total), dim3(256), 0, st, a, bit_depth);
+        else                hipLaunchKernelGGL((upsample_tile3_kernel<uint16_t, false>), dim3(total), dim3(256), 0, st, a, bit_depth);
+    }
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }
@@ -444,15 +559,17 @@ extern "C" int ohevc_dev_upsample_plane(const ohevc_plane *dst, const ohevc_plan
     // never read below the plane that was handed over (the reference would read its frame padding there, see make_maps)
     src_cols = std::min(src_cols, src->width); src_rows = std::min(src_rows, src->height);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g_upsample_variant == 0) {
+    if (g_upsample_variant != 1) {
         const dim3 tgrid((dst->width + 63) / 64, (dst->height + UPT_ROWS - 1) / UPT_ROWS);
-        if (bit_depth == 8) {
-            if (chroma) hipLaunchKernelGGL((upsample_tile_kernel<uint8_t, 4>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
-            else        hipLaunchKernelGGL((upsample_tile_kernel<uint8_t, 8>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+#define UP_LAUNCH(PIX, TP, MF) hipLaunchKernelGGL((upsample_tile_kernel<PIX, TP, MF>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth)
+        if (g_upsample_variant == 0) {
+            if (bit_depth == 8) { if (chroma) UP_LAUNCH(uint8_t, 4, true); else UP_LAUNCH(uint8_t, 8, true); }
+            else                { if (chroma) UP_LAUNCH(uint16_t, 4, true); else UP_LAUNCH(uint16_t, 8, true); }
         } else {
-            if (chroma) hipLaunchKernelGGL((upsample_tile_kernel<uint16_t, 4>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
-            else        hipLaunchKernelGGL((upsample_tile_kernel<uint16_t, 8>), tgrid, dim3(256), 0, st, *dst, *src, cols, col_of, rows, src_cols, src_rows, bit_depth);
+            if (bit_depth == 8) { if (chroma) UP_LAUNCH(uint8_t, 4, false); else UP_LAUNCH(uint8_t, 8, false); }
+            else                { if (chroma) UP_LAUNCH(uint16_t, 4, false); else UP_LAUNCH(uint16_t, 8, false); }
         }
+#undef UP_LAUNCH
         OHEVC_HIP_TRY(hipGetLastError());
         return OHEVC_OK;
     }
