@@ -20,10 +20,11 @@ except Exception as e:
 PY
 }
 if [ -n "$AB_ONLY" ]; then for v in $AB_ONLY; do case $v in
-    baseline*) one $v -- ;;
+    baseline*) one $v -- $AB_ARGS ;;
     fetch_issues_copies) one $v OHHIP_QUEUE_DOWNLOAD=0 -- ;;
     three_priority_pools) one $v -- --debug-set long_chain_pools=4 ;;
     decoder_frames_pinned) one $v OHHIP_OWN_FRAMES=0 -- ;;
+    flush_*) one $v OHHIP_FLUSH_INTRA_KIB=${v#flush_} -- $AB_ARGS ;;
     *) one $v -- --debug-set $v ;;
   esac; done; exit 0; fi
 one baseline              --
