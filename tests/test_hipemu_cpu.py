@@ -281,6 +281,23 @@ def test_emu_frame_buffers_from_the_back_end_or_from_the_decoder(own_frames, mon
     assert (made1.value > made0.value) == (own_frames == "1")
 
 
+@pytest.mark.parametrize("queue", ["1", "0"], ids=["queued_by_the_decoding_thread", "issued_by_fetch_output"])
+def test_emu_copy_back_queued_at_the_frame_end_or_issued_at_fetch(queue, monkeypatch):
+    """ohhip_options.queue_download (round 6): with the deferred copy-back and frame buffers of the back end's own, the decoding thread queues a
+    picture's copy-back behind its device work at the frame end (ohevc_pic_download_queue) and ohhip_backend_fetch_output only waits for it;
+    0: fetch_output issues the copies (round 5).  Same pictures in every thread mode, also when the application takes pictures one call late."""
+    from test_stream_cpu import frames_md5, load_golden
+    ps = _stream_lib()
+    if ps is None:
+        pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
+    monkeypatch.setenv("OHHIP_QUEUE_DOWNLOAD", queue)
+    for name, threads, tt in (("ra_10b_odd", 1, 1), ("ra_8b_ctb64", 4, 1), ("wpp", 4, 2), ("intra_8b", 3, 1)):
+        aus, md5 = load_golden(name)
+        assert frames_md5(ps.decode_stream("hipemu", aus * 2, threads, tt)) == list(md5) * 2, f"{name} threads {threads} type {tt} queue_download {queue}"
+    aus, md5 = load_golden("ldb_10b")
+    assert frames_md5(ps.decode_stream("hipemu", aus, pipelined=True)) == md5
+
+
 def test_emu_host_blocks_of_the_library():
     """ohevc_host_alloc / ohevc_host_free (include/ohevc_ctx.h): 64-byte aligned memory the library made (page-locked on a device), freed without a
     context - also after the context is gone; a pointer the library did not make is refused, not freed."""

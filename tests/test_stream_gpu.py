@@ -216,6 +216,23 @@ def test_config5_8k_frame_threads_survive_the_decoders_frame_pool_being_re_creat
     _compare(ref, ps.decode_stream("hip", aus, 8, 1))
 
 
+@pytest.mark.parametrize("switches", [dict(OHHIP_QUEUE_DOWNLOAD="0"), dict(OHHIP_OWN_FRAMES="0"), dict(OHHIP_OWN_FRAMES="0", OHHIP_PIN_FRAMES="0"),
+                                      dict(OHHIP_BLOCK_CACHE_MB="0")],
+                         ids=["fetch_issues_the_copies", "decoder_buffers_page_locked", "pageable_buffers", "no_block_cache"])
+def test_frame_buffer_and_copy_back_switches_give_the_same_pictures(switches, monkeypatch):
+    """The host side of a picture (round 6; integration/hip_backend.h): own_frames / pin_frames / queue_download / the block cache change where the
+    decoder's frame buffers come from and who issues the copy-back - never a sample.  1080p encoder-like GOP, 1 and 16 frame threads, the stream
+    twice through each decoder (buffers recycled), two decoders in a row (blocks of the first reused by the second)."""
+    if not (ps.have("gen") and ps.have("c")):
+        pytest.skip("generator / reference decoder libraries not present")
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    aus, _ = ps.generate(ps.StreamParams(gop="random_access", nframes=17, seed=11, width=1920, height=1080, log2_ctb=6, **ENCODER_LIKE))
+    ref = ps.decode_stream("c", aus)
+    for threads in (1, 16, 16):
+        _compare(ref + ref, ps.decode_stream("hip", aus * 2, threads, 1))
+
+
 @pytest.mark.parametrize("threads,thread_type", [(1, 1), (8, 1)])
 def test_config4_4k_main10_dense_residual(threads, thread_type):
     """Config 4's geometry in the regime a real 4K Main10 stream lives in: qp22-like syntax statistics (oracle.pystream.DENSE_QP22), ~1 MB of
