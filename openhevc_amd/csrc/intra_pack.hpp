@@ -649,6 +649,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     // [0] waiting for its stores + in the barrier, [1] issuing the step's loads and prefetches, [2] in the step's arithmetic (incl. the
     // wait for the samples), [3] unused; [4] = levels; [5..7] = the issue phase after the sample loads / the residual prefetch / the records
     unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pcx[3] = { 0, 0, 0 };
+    unsigned long long cls_fin[4] = { 0, 0, 0, 0 }, cls_wait[4] = { 0, 0, 0, 0 }, cls_n[4] = { 0, 0, 0, 0 };
     while (st0.l < nlevels) {
         const unsigned long long tk0 = phase_clocks ? clock64() : 0;
         if (st0.p == 0) {
@@ -683,8 +684,15 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         issue_order_fence();
         const unsigned long long tk2 = phase_clocks ? clock64() : 0;
         if (phase_clocks) pcx[2] += tk2 - tk1;
+        unsigned long long tkw = tk2;
+        if (phase_clocks) { wait_all_but_6_loads(); tkw = clock64(); }      // (the five samples: six younger loads are in flight behind them)
         finish(s0, r0, sm, cq0);
-        if (phase_clocks) { const unsigned long long tk3 = clock64(); pc0 += tk1 - tk0; pc1 += tk2 - tk1; pc2 += tk3 - tk2; }
+        if (phase_clocks) {
+            const unsigned long long tk3 = clock64();
+            pc0 += tk1 - tk0; pc1 += tk2 - tk1; pc2 += tk3 - tk2;
+            if (s0.s >= 0) { cls_fin[s0.s] += tk3 - tk2; cls_wait[s0.s] += tkw - tk2; cls_n[s0.s]++; }
+            if (threadIdx.x == 0 && st0.p == 0) atomicAdd(&phase_clocks[20 + (s0.nwaves < 16 ? s0.nwaves : 16)], 1ull);
+        }
         st0 = st1; st1 = st2;
         s0 = s1; r0 = r1;
 #pragma unroll
@@ -697,6 +705,8 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         atomicAdd(&phase_clocks[4], (unsigned long long)nlevels);
         atomicAdd(&phase_clocks[5], pcx[0]); atomicAdd(&phase_clocks[6], pcx[1]); atomicAdd(&phase_clocks[7], pcx[2]);
     }
+    if (phase_clocks && lane == 0)
+        for (int s = 0; s < 4; s++) { atomicAdd(&phase_clocks[8 + s], cls_fin[s]); atomicAdd(&phase_clocks[12 + s], cls_wait[s]); atomicAdd(&phase_clocks[16 + s], cls_n[s]); }
 }
 
 }  // namespace ohevc

@@ -37,6 +37,7 @@ __device__ __forceinline__ void xcd_acquire() { asm volatile("buffer_inv sc1" ::
 __device__ __forceinline__ void xcd_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // memory operations are neither moved across this point by the compiler nor re-ordered around it by the scheduler: the ISSUE order of two
 // groups of loads is what the code says (vector memory returns in order, so the order decides who waits for whom)
+__device__ __forceinline__ void wait_all_but_6_loads() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }      // (diagnosis: ohevc_debug_intra_chain_clocks)
 __device__ __forceinline__ void issue_order_fence() { asm volatile("" ::: "memory"); }
 
 }  // namespace ohevc

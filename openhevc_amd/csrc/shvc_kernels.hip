@@ -26,6 +26,8 @@ __constant__ signed char kUpChroma[16][4] = {
     {  0, 64,  0,  0 }, { -2, 62,  4,  0 }, { -2, 58, 10, -2 }, { -4, 56, 14, -2 }, { -4, 54, 16, -2 }, { -6, 52, 20, -2 }, { -6, 46, 28, -4 }, { -4, 42, 30, -4 },
     { -4, 36, 36, -4 }, { -4, 30, 42, -4 }, { -4, 28, 46, -6 }, { -2, 20, 52, -6 }, { -2, 16, 54, -4 }, { -2, 14, 56, -4 }, { -2, 10, 58, -2 }, {  0,  4, 62, -2 } };
 
+__constant__ unsigned kUpInv[32] = { 0x0u, 0xffffffffu, 0x80000000u, 0x55555556u, 0x40000000u, 0x33333334u, 0x2aaaaaabu, 0x24924925u, 0x20000000u, 0x1c71c71du, 0x1999999au, 0x1745d175u, 0x15555556u, 0x13b13b14u, 0x12492493u, 0x11111112u, 0x10000000u, 0xf0f0f10u, 0xe38e38fu, 0xd79435fu, 0xccccccdu, 0xc30c30du, 0xba2e8bbu, 0xb21642du, 0xaaaaaabu, 0xa3d70a4u, 0x9d89d8au, 0x97b425fu, 0x924924au, 0x8d3dcb1u, 0x8888889u, 0x8421085u };      // ceil(2^32 / d), d = 2 .. 31 (staging loop of the tile kernel)
+
 // One thread produces ROWS consecutive output rows of one column.  Consecutive output rows read base-layer rows that advance by
 // at most one per row (the enhancement layer is never smaller than the base layer), so the horizontally filtered values live
 // in a sliding window of TAPS registers: TAPS + ROWS - 1 horizontal filters per thread instead of TAPS * ROWS.  The window is
@@ -207,8 +209,10 @@ __device__ __forceinline__ void upsample_tile_body(UpTileLds<Pixel> &lds, const 
     {
         const int wc4 = (wc + 3) >> 2;
         const bool inside = cmin >= 0 && cmin + 4 * wc4 <= src_cols;
+        // (i / wc4 as a multiplication: exact for i < 8192, wc4 < 64 - the window is at most 20 x 72 - where the division is ~25 instructions)
+        const unsigned inv = kUpInv[wc4 & 31];                     // (wc4 <= 20: the window is at most 80 columns)
         for (int i = tid; i < wc4 * wr; i += 256) {
-            const int r = i / wc4, c4 = i - r * wc4;
+            const int r = wc4 == 1 ? i : (int)(((unsigned long long)(unsigned)i * inv) >> 32), c4 = i - r * wc4;
             int ry = rmin + r;
             ry = ry < 0 ? 0 : ry > src_rows - 1 ? src_rows - 1 : ry;
             const unsigned char *srow_p = sbase + __umul24((unsigned)ry, (unsigned)src.stride);

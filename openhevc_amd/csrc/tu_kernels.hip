@@ -1824,12 +1824,12 @@ static unsigned long long *g_chain_clocks = nullptr;
 extern "C" int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8])
 {
     if (on && !g_chain_clocks) {
-        OHEVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_chain_clocks), 8 * sizeof(unsigned long long)));
-        OHEVC_HIP_TRY(hipMemset(g_chain_clocks, 0, 8 * sizeof(unsigned long long)));
+        OHEVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_chain_clocks), 64 * sizeof(unsigned long long)));
+        OHEVC_HIP_TRY(hipMemset(g_chain_clocks, 0, 64 * sizeof(unsigned long long)));
     }
     if (out && g_chain_clocks) {
         OHEVC_HIP_TRY(hipDeviceSynchronize());
-        OHEVC_HIP_TRY(hipMemcpy(out, g_chain_clocks, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        OHEVC_HIP_TRY(hipMemcpy(out, g_chain_clocks, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     if (!on && g_chain_clocks) { (void)hipFree(g_chain_clocks); g_chain_clocks = nullptr; }
     return OHEVC_OK;

@@ -48,5 +48,6 @@ static inline unsigned pack_i8x4(int a, int b, int c, int d)
 static inline void xcd_acquire() {}
 static inline void xcd_release() {}
 static inline void issue_order_fence() {}
+static inline void wait_all_but_6_loads() {}
 
 }  // namespace ohevc
