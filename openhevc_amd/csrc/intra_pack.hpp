@@ -452,8 +452,10 @@ struct IntraChainLevel {             // 48 bytes; mirrors what ctx.hip stages
 };
 
 constexpr int kChainWaves = 8;       // wavefronts of the chain kernel's one workgroup; a wider level takes ceil(width / 8) steps of it (4 wavefronts - one per SIMD - measured in round 5: 8 030 clocks per level against 6 390, profiles/r5m_*)
+constexpr int kChainMaxLevels_v = 1024;
 constexpr bool kChainIdleSkips = false; // true: empty wavefront slots skip their loads behind a scalar branch.  Measured in round 6 (profiles/r6zd_chain_clocks_idle_slots_skip_slower.jsonl): a level 6350 -> 6920 clocks - the skipped path meets the loading one in front of the arithmetic and the wait counts get conservative again (the round-4 lesson); the dummy loads of an idle wavefront were not what an active one waits for
-constexpr int kChainMaxLevels = 1024;   // levels per launch: their records (48 bytes each) are copied to LDS at the kernel's start
+constexpr int kChainMaxSlots = kChainMaxLevels_v * 3;   // descriptors of 16 bytes in the LDS of the level records (48 bytes each)
+constexpr int kChainMaxLevels = kChainMaxLevels_v;   // levels per launch: their records (48 bytes each) are copied to LDS at the kernel's start
 
 // Round 4.  (a) A level may be WIDER than the workgroup: its wavefront slots 8, 9, ... are served by wavefronts 0, 1, ... in further passes
 // behind the first (no barrier in between: the blocks of a level do not depend on each other), so a run no longer ends at every level of
@@ -527,30 +529,91 @@ __global__ __launch_bounds__(64) void intra_chain_residual_kernel(const unsigned
     }
 }
 
-template <typename Pixel>
+// CLOCKS: the diagnosis build of the kernel (ohevc_debug_intra_chain_clocks).  The counters used to be part of THE kernel behind `if
+// (phase_clocks)`: eighteen 64-bit accumulators and a dozen scalar branches a step in a kernel that already spills scalar registers - and a
+// wavefront's instruction stream is what a level costs (one instruction per ~4 clocks, whatever its kind: round 6, the listing between two
+// time stamps).  The shipped instance carries none of it.
+template <typename Pixel, bool CLOCKS>
 __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet planes, const unsigned char *__restrict__ base, const IntraChainLevel *__restrict__ levels,
                                                                        int nlevels, int bit_depth, const int16_t *__restrict__ coeffs, int agent_acquire,
-                                                                       unsigned long long *__restrict__ phase_clocks)
+                                                                       unsigned long long *__restrict__ phase_clocks_arg)
 {
+    unsigned long long *const phase_clocks = CLOCKS ? phase_clocks_arg : nullptr;
     __shared__ int ish[kChainWaves * kIntraPackInts];
     __shared__ __attribute__((aligned(16))) unsigned char tu_lds[kChainWaves * TuLayout<5>::WAVE_BYTES];
     // The level records, all of them, in LDS before the first level starts.  Read from memory as a level needs them (a scalar load whose
     // result the record loads of level l + 2 wait for) they cost every level an HBM round trip on its critical path - the records arrive
     // by DMA, nothing has them in a cache: 4500 of a level's 11 800 shader clocks (ohevc_debug_intra_chain_clocks, profiles/r4g_*).
-    __shared__ int slev[kChainMaxLevels * 12];
+    __shared__ __attribute__((aligned(16))) int slev[kChainMaxLevels * 12];
     static_assert(sizeof(IntraChainLevel) == 48, "12 dwords per level record");
+    // Round 6: "what does wavefront slot w do at level l" took ~100 instructions a step (eleven fields of the level record out of LDS into
+    // scalars, selects by size class, two 64-bit addresses) - a third of a step's 2500 issue clocks, for a value the records fix before the
+    // first level runs.  The prologue now turns the level records into one 16-byte DESCRIPTOR per (level, wavefront slot) - first job record,
+    // first residual record, blocks left, size class - in the LDS the records used to occupy, next to the levels' first-slot indices; a step
+    // reads its descriptor and is done.  A run with more slots than fit (kChainMaxSlots) keeps the record form (slot_at below).
+    __shared__ unsigned short lvl_off[kChainMaxLevels + 2];
+    __shared__ int scan_tot[kChainWaves + 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int *my_ish = ish + wave * kIntraPackInts;
     unsigned char *my_tu = tu_lds + wave * TuLayout<5>::WAVE_BYTES;
-    for (int i = threadIdx.x; i < nlevels * 12; i += 64 * kChainWaves) slev[i] = reinterpret_cast<const int *>(levels)[i];
-    __syncthreads();
+    static_assert(kChainMaxLevels == 2 * 64 * kChainWaves, "two levels per thread in the prologue's scan");
+    bool use_desc;
+    {
+        const int l0 = 2 * (int)threadIdx.x, l1 = l0 + 1;
+        const int nw0 = l0 < nlevels ? levels[l0].first_wave[4] : 0, nw1 = l1 < nlevels ? levels[l1].first_wave[4] : 0;
+        int incl = nw0 + nw1;                                          // inclusive scan over the workgroup's threads (two levels each)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        if (lane == 63) scan_tot[wave] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < kChainWaves; k++) { const int t = scan_tot[k]; if (k < wave) before += t; total += t; }
+        use_desc = __builtin_amdgcn_readfirstlane((int)(total <= kChainMaxSlots)) != 0;
+        if (use_desc) {
+            const int off0 = before + incl - nw0 - nw1, off1 = off0 + nw0;
+            if (l0 <= nlevels) lvl_off[l0] = (unsigned short)off0;     // (entry nlevels = the total: next_step looks one level ahead)
+            if (l1 <= nlevels) lvl_off[l1] = (unsigned short)off1;
+            u32x4 *desc = reinterpret_cast<u32x4 *>(slev);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int l = h ? l1 : l0, off = h ? off1 : off0;
+                if (l >= nlevels) continue;
+                const IntraChainLevel lv = levels[l];
+                const int n0 = lv.njobs[0], n1 = lv.njobs[1], n2 = lv.njobs[2], n3 = lv.njobs[3];
+                for (int w = 0; w < lv.first_wave[4]; w++) {
+                    const int sc = w >= lv.first_wave[3] ? 3 : w >= lv.first_wave[2] ? 2 : w >= lv.first_wave[1] ? 1 : 0;
+                    const int fws = sc == 0 ? 0 : sc == 1 ? lv.first_wave[1] : sc == 2 ? lv.first_wave[2] : lv.first_wave[3];
+                    const int first_job = sc == 0 ? 0 : sc == 1 ? n0 : sc == 2 ? n0 + n1 : n0 + n1 + n2;
+                    const int job0 = (w - fws) * (16 >> sc), n = sc == 0 ? n0 : sc == 1 ? n1 : sc == 2 ? n2 : n3;
+                    desc[off + w] = u32x4{ lv.jobs_off16 + (unsigned)(first_job + job0), lv.res_off16 != 0xffffffffu ? lv.res_off16 + (unsigned)(first_job + job0) : 0xffffffffu,
+                                           (unsigned)(n - job0), (unsigned)sc };
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < nlevels * 12; i += 64 * kChainWaves) slev[i] = reinterpret_cast<const int *>(levels)[i];
+        }
+        __syncthreads();
+    }
 
     // what wavefront slot w does at a level: the size class of its blocks (-1: nothing), its first block, the level's arrays.  All wave-uniform.
     struct Slot { int s, job0, n, nwaves; const ohevc_intra_job *j; const ohevc_tu_job *r; };
     auto slot_at = [&](const int l, const int w) -> Slot {
         Slot sl = { -1, 0, 0, 0, nullptr, nullptr };
         if (l >= nlevels) return sl;
+        if (use_desc) {
+            const int first = __builtin_amdgcn_readfirstlane((int)lvl_off[l]), nw = __builtin_amdgcn_readfirstlane((int)lvl_off[l + 1]) - first;
+            sl.nwaves = nw;
+            if (w >= nw) return sl;
+            const u32x4 dsc = reinterpret_cast<const u32x4 *>(slev)[first + w];
+            const unsigned j16 = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc.x), r16 = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc.y);
+            sl.n = __builtin_amdgcn_readfirstlane((int)dsc.z);            // blocks from this slot's first one to the end of the size class
+            sl.s = __builtin_amdgcn_readfirstlane((int)dsc.w);
+            sl.j = reinterpret_cast<const ohevc_intra_job *>(base + (size_t)j16 * 16);
+            sl.r = r16 != 0xffffffffu ? reinterpret_cast<const ohevc_tu_job *>(base + (size_t)r16 * 16) : nullptr;
+            return sl;
+        }
         // The record as eleven scalars, never as an array indexed by the (runtime) size class: such an array lives in scratch memory, and a
         // scratch load is a vector-memory operation - it returns IN ORDER behind the sample loads and the HBM prefetches issued just before,
         // so "which slot do I have at level l + 2" waited a whole HBM round trip on every level's critical path (s_waitcnt vmcnt behind
@@ -636,7 +699,8 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
     // meant to hide (vmcnt(4) .. vmcnt(0) in front of the first use of a sample in the round-4 listing).
     struct Step { int l, p; };
     auto next_step = [&](const Step st) -> Step {
-        const int nw = st.l < nlevels ? __builtin_amdgcn_readfirstlane(slev[st.l * 12 + 4]) : 0;
+        const int nw = st.l >= nlevels ? 0 : use_desc ? __builtin_amdgcn_readfirstlane((int)lvl_off[st.l + 1]) - __builtin_amdgcn_readfirstlane((int)lvl_off[st.l])
+                                                       : __builtin_amdgcn_readfirstlane(slev[st.l * 12 + 4]);
         return (st.p + 1) * kChainWaves < nw ? Step{ st.l, st.p + 1 } : Step{ st.l + 1, 0 };
     };
     auto slot_of = [&](const Step st) -> Slot { return slot_at(st.l, st.p * kChainWaves + wave); };

@@ -1859,8 +1859,10 @@ extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth,
     if (coeffs != nullptr)
         hipLaunchKernelGGL(intra_chain_residual_kernel, dim3(32, nlevels), dim3(64), 0, st, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth,
                            const_cast<int16_t *>(coeffs));
-    if (bit_depth == 8) hipLaunchKernelGGL((intra_chain_kernel<uint8_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs, g_chain_agent_acquire, g_chain_clocks);
-    else                hipLaunchKernelGGL((intra_chain_kernel<uint16_t>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs, g_chain_agent_acquire, g_chain_clocks);
+#define CHAIN_LAUNCH(PIX, CLK) hipLaunchKernelGGL((intra_chain_kernel<PIX, CLK>), dim3(1), dim3(64 * kChainWaves), 0, st, ps, static_cast<const unsigned char *>(base), lv, nlevels, bit_depth, coeffs, g_chain_agent_acquire, g_chain_clocks)
+    if (g_chain_clocks) { if (bit_depth == 8) CHAIN_LAUNCH(uint8_t, true); else CHAIN_LAUNCH(uint16_t, true); }
+    else                { if (bit_depth == 8) CHAIN_LAUNCH(uint8_t, false); else CHAIN_LAUNCH(uint16_t, false); }
+#undef CHAIN_LAUNCH
     OHEVC_HIP_TRY(hipGetLastError());
     return OHEVC_OK;
 }
