@@ -173,7 +173,7 @@ __device__ __forceinline__ void pack_load_coeffs(const PackRecs &r, const int la
 // has no source (no neighbour group is available) and takes 1 << (bit_depth - 1).  Loading them is a stage of its own so that the chain
 // kernel can issue the loads of a level FIRST behind the level's barrier and its prefetches for later levels behind them (vector memory
 // returns in order: a prefetch from HBM in front of them would delay every level by an HBM round trip).
-struct PackSamples { int v[5]; int none; };
+struct PackSamples { int v[5]; int none; unsigned char *blk; int stride; };      // blk / stride: the block's first sample and its plane's pitch, worked out once
 
 template <int LOG2N, typename Pixel>
 __device__ __forceinline__ PackSamples pack_load_samples(const int lane, const PlaneSet planes, const PackRecs &recs)
@@ -205,6 +205,7 @@ __device__ __forceinline__ PackSamples pack_load_samples(const int lane, const P
     const int q_l0 = c_l ? i * stride - P : p_l, q_l1 = c_bl ? (N + kb) * stride - P : p_bl;
     const int q_c = c_ul ? o_c : p_ul;
     PackSamples sm;
+    sm.blk = const_cast<unsigned char *>(blk); sm.stride = stride;
     sm.v[0] = REC(q_t0); sm.v[1] = REC(q_t1); sm.v[2] = REC(q_l0); sm.v[3] = REC(q_l1); sm.v[4] = REC(q_c);
     sm.none = (q_t0 == NONE ? 1 : 0) | (q_t1 == NONE ? 2 : 0) | (q_l0 == NONE ? 4 : 0) | (q_l1 == NONE ? 8 : 0) | (q_c == NONE ? 16 : 0);
     return sm;
@@ -221,8 +222,9 @@ __device__ __forceinline__ void pack_finish(int *ish, unsigned char *tu_lds, con
     const u32x4 jw = recs.jw, rw = recs.rw;
     const int jx = jw.x & 0xffff, jy = jw.x >> 16, jplane = jw.y & 0xff, mode = (jw.y >> 16) & 0xff, flags = jw.y >> 24;
     const int kind = pack_kind(recs);
-    const int stride = PLANE_STRIDE3(planes, jplane);
-    unsigned char *blk = PLANE_PTR3(planes, jplane) + (__umul24((unsigned)jy, (unsigned)stride) + (unsigned)jx * (unsigned)sizeof(Pixel));
+    const int stride = sm.stride;
+    unsigned char *blk = sm.blk;                             // (pack_load_samples worked them out: a level is one wavefront's instruction stream)
+    (void)jx; (void)jy; (void)jplane;
     const bool is_idct = kind == OHEVC_TU_IDCT || kind == OHEVC_TU_DST4;
     const int dflt = 1 << (bit_depth - 1);
     const int v_t0 = (sm.none & 1) ? dflt : sm.v[0], v_t1 = (sm.none & 2) ? dflt : sm.v[1], v_l0 = (sm.none & 4) ? dflt : sm.v[2];
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         if (sl.s == 1) return pack_load_samples<3, Pixel>(lane, planes, r);
         if (sl.s == 2) return pack_load_samples<4, Pixel>(lane, planes, r);
         if (sl.s == 3) return pack_load_samples<5, Pixel>(lane, planes, r);
-        return PackSamples{ { 0, 0, 0, 0, 0 }, 0 };
+        return PackSamples{ { 0, 0, 0, 0, 0 }, 0, nullptr, 0 };
     };
     auto finish = [&](const Slot &sl, const PackRecs &r, const PackSamples &sm, const u32x4 (&cq)[4]) {
         if (sl.s == 0)      pack_finish<2, Pixel, true>(my_ish, my_tu, lane, planes, r, sm, cq, coeffs, bit_depth);
