@@ -575,8 +575,9 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         use_desc = __builtin_amdgcn_readfirstlane((int)(total <= kChainMaxSlots)) != 0;
         if (use_desc) {
             const int off0 = before + incl - nw0 - nw1, off1 = off0 + nw0;
-            if (l0 <= nlevels) lvl_off[l0] = (unsigned short)off0;     // (entry nlevels = the total: next_step looks one level ahead)
-            if (l1 <= nlevels) lvl_off[l1] = (unsigned short)off1;
+            if (l0 < nlevels) lvl_off[l0] = (unsigned short)off0;
+            if (l1 < nlevels) lvl_off[l1] = (unsigned short)off1;
+            if (threadIdx.x == 0) lvl_off[nlevels] = (unsigned short)total;      // (the last level's slots end here - also when nlevels is the 1024 a launch takes: no thread owns "level 1024")
             u32x4 *desc = reinterpret_cast<u32x4 *>(slev);
 #pragma unroll
             for (int h = 0; h < 2; h++) {

@@ -352,3 +352,57 @@ def test_intra_chain_hands_levels_over_including_levels_wider_than_its_workgroup
         got = G.to_host(d[pl], planes[pl].dtype)
         bad = np.argwhere(got != want[pl])
         assert bad.size == 0, (pl, bad[:4].tolist())
+
+
+@pytest.mark.parametrize("per_level", [1, 64], ids=["1024_levels_of_one_block", "1024_levels_of_four_wavefronts"])
+def test_intra_chain_takes_a_whole_launch_of_levels(oracle, per_level):
+    """ohevc_intra_chain_max_levels() levels in ONE launch - the size the ctx layer cuts a long chain into (an 8K picture has more levels than
+    that).  Round 6 builds a 16-byte descriptor per (level, wavefront slot) in the kernel's prologue, two levels per thread of its 512: with
+    exactly 1024 levels nobody owned the END of the last level's slots and the last level ran on garbage - a device fault in the 8K dense
+    stream test, nowhere else.  1024 levels of one 4x4 block (the descriptors fit), and of four wavefronts each (4096 slots: more than fit -
+    the kernel keeps the record form); every level predicts vertically from the level above."""
+    import ctypes as C
+    if G.emulating() and per_level > 1:
+        pytest.skip("65 536 blocks through the emulator take minutes; the device runs it")
+    bd = 8
+    lib = L.load_library()
+    nlev = int(lib.ohevc_intra_chain_max_levels())
+    assert nlev == 1024
+    rng = np.random.default_rng(4200 + per_level)
+    W, H = 4 * per_level, 64 + 4 * nlev
+    planes = [rng.integers(0, 256, size=(H, W)).astype(np.uint8), rng.integers(0, 256, size=(H // 2, max(W // 2, 2))).astype(np.uint8),
+              rng.integers(0, 256, size=(H // 2, max(W // 2, 2))).astype(np.uint8)]
+    want = [p.copy() for p in planes]
+    geom = L.IntraGeom(W, H, 1, 6, 2, 1, 0, 0)
+    blobs, pos16 = [], 0
+
+    def put(a):
+        nonlocal pos16
+        o = pos16
+        b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        pad = (-b.size) % 256
+        blobs.append(np.concatenate([b, np.zeros(pad, np.uint8)]))
+        pos16 += (b.size + pad) // 16
+        return o
+
+    lev = np.zeros(nlev, np.dtype([("first_wave", np.int32, 5), ("njobs", np.int32, 4), ("jobs_off16", np.uint32), ("res_off16", np.uint32), ("reserved", np.int32)]))
+    for lv in range(nlev):
+        y0 = 64 + 4 * lv
+        jobs = []
+        for k in range(per_level):
+            x0 = 4 * k
+            mode = 26 if per_level > 1 else int(rng.choice([26, 0, 1, 30]))      # (vertical only where the oracle loop is long)
+            cands = [0, 0, 0, 1, 0]
+            oracle.intra_pred(bd, want, W, H, x0, y0, 2, 0, mode, cands, chroma_format_idc=1, strong=1, smoothing_disabled=0, log2_ctb_size=6, log2_min_tb_size=2)
+            jobs.append(L.intra_make_job(geom, x0, y0, 2, 0, mode, cands)[0])
+        jobs = np.array(jobs, dtype=L.INTRA_JOB)
+        nw = (per_level + 15) // 16
+        lev[lv]["first_wave"], lev[lv]["njobs"], lev[lv]["jobs_off16"], lev[lv]["res_off16"] = [0, nw, nw, nw, nw], [per_level, 0, 0, 0], put(jobs), 0xffffffff
+    d = [G.to_dev(p) for p in planes]
+    d_base, d_lev = G.to_dev(np.concatenate(blobs)), G.to_dev(lev)
+    L.check(lib.ohevc_dev_intra_chain(G.planes3(d), C.c_int(bd), C.c_void_p(d_base.data_ptr()), C.c_void_p(d_lev.data_ptr()), C.c_int(nlev),
+                                      None, C.c_void_p(G.stream())))
+    G.sync()
+    got = G.to_host(d[0], np.uint8)
+    bad = np.argwhere(got != want[0])
+    assert bad.size == 0, f"{len(bad)} samples differ, first at {bad[:3].tolist()} (row 64 + 4 x level)"
