@@ -29,6 +29,7 @@
 #include "libavcodec/thread.h"
 #include "libavutil/pixdesc.h"
 #include "libavutil/buffer.h"
+#include "libavutil/buffer_internal.h"      /* struct AVBuffer, BufferPoolEntry: the page locks of decoder-owned frame buffers are dropped where the pool FREES them (guard_pool_entry) */
 
 #include "ohevc_tables.h"
 #include "ohevc_debug.h"
@@ -622,6 +623,49 @@ static int find_buf_locked(ohhip_backend *be, const uint8_t *data0)
     return -1;
 }
 
+/* pin_frames on buffers of the decoder's OWN frame pool (own_frames 0, the default allocator): the pool frees them in mid-stream when it is
+ * re-created (utils.c:555-560), and a page lock that outlives its memory is worse than none - the runtime keeps believing the range is
+ * page-locked, and whatever the allocator puts there next (another frame buffer at the same address: the round-6 device fault; or, after the
+ * decoder is long gone, any array a later copy-back lands in) is written through a mapping that no longer exists.  The pool keeps, per
+ * buffer, the callback that really frees it (BufferPoolEntry.free, buffer_internal.h:60-75; called by buffer_pool_free, buffer.c:227-238):
+ * the hooks put their own in front of it - drop the page lock, forget the address, then let the original free the memory. */
+static int ohhip_get_buffer2(AVCodecContext *avctx, AVFrame *frame, int flags);
+typedef struct pin_guard { void (*free)(void *opaque, uint8_t *data); void *opaque; ohhip_backend *be; unsigned be_id; size_t size; } pin_guard;
+static void guarded_free(void *opaque, uint8_t *data)
+{
+    pin_guard *g = opaque;
+    ohhip_backend *b, *alive = NULL;
+    int i, k;
+    pthread_mutex_lock(&g_reg_lock);
+    for (b = g_backends; b; b = b->next)
+        if (b == g->be && b->id == g->be_id)
+            alive = b;
+    if (alive && alive->root) {                 /* (a back end that is gone dropped all of its page locks in ohhip_backend_pre_close) */
+        ohevc_host_unpin(alive->root, data, g->size);
+        pthread_mutex_lock(&alive->lock);
+        for (i = 0; i < alive->nbufs; i++)
+            for (k = 0; k < 3; k++)
+                if (alive->bufs[i].pin_ptr[k] == (void *)data)
+                    alive->bufs[i].pin_ptr[k] = NULL;
+        pthread_mutex_unlock(&alive->lock);
+    }
+    pthread_mutex_unlock(&g_reg_lock);
+    g->free(g->opaque, data);
+    free(g);
+}
+static void guard_pool_entry(ohhip_backend *be, const AVBufferRef *ref)
+{
+    BufferPoolEntry *e = ref && ref->buffer ? ref->buffer->opaque : NULL;
+    pin_guard *g;
+    if (!e || e->data != ref->data || !e->pool || !e->free || e->free == guarded_free)      /* (not a pool buffer, or guarded already) */
+        return;
+    if (!(g = malloc(sizeof(*g))))
+        return;
+    g->free = e->free; g->opaque = e->opaque; g->be = be; g->be_id = be->id; g->size = (size_t)ref->size;
+    e->opaque = g;
+    e->free = guarded_free;
+}
+
 /* INTEGRATION.md section 3, rows alloc_frame + hevc_frame_start */
 static int device_bs_frame(const HEVCContext *s);
 /* boundary-strength calls the picture's own thread records (ohhip_deblocking_boundary_strengths below) */
@@ -657,19 +701,6 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
      * that the copy-back of every picture is a DMA.  One hipHostRegister per pool buffer, ever: known ranges return at once.  (After the
      * slot look-up: a buffer that came back with another geometry had its old page locks dropped there.) */
     if (be->opt.pin_frames && ohevc_ctx_has_device(ctx) && !pool_owns(be, f->buf[0])) {     /* (own_frames: born page-locked) */
-        /* A buffer set seen before but not in this combination: the decoder's pool was re-created in between (utils.c:555-560 - it is, in
-         * mid-stream, under frame threads) and these are NEW allocations, one of which the allocator put where an old one was (a large
-         * buffer comes back from mmap at the same address): the page lock behind that address names a mapping that is gone.  Lock again.
-         * (Only a hint - three new buffers at three old addresses look like a recycled frame.  own_frames, the default, has no such gap.) */
-        if (!fresh && be->bufs[i].pin_ptr[0]) {
-            int mixed = 0;
-            for (k = 1; k < 3 && k < AV_NUM_DATA_POINTERS && f->buf[k]; k++)
-                mixed |= be->bufs[i].pin_ptr[k] && be->bufs[i].pin_ptr[k] != f->buf[k]->data;
-            if (mixed) {
-                ohevc_host_unpin(ctx, be->bufs[i].pin_ptr[0], be->bufs[i].pin_bytes[0]);
-                be->bufs[i].pin_ptr[0] = NULL;
-            }
-        }
         for (k = 0; k < 3 && k < AV_NUM_DATA_POINTERS && f->buf[k]; k++) {
             if (be->bufs[i].pin_ptr[k] == f->buf[k]->data && be->bufs[i].pin_bytes[k] == (size_t)f->buf[k]->size)
                 continue;
@@ -681,6 +712,10 @@ int ohhip_set_new_ref(HEVCContext *s, AVFrame **frame, int poc)
             }
             be->bufs[i].pin_ptr[k] = f->buf[k]->data;
             be->bufs[i].pin_bytes[k] = (size_t)f->buf[k]->size;
+            /* (buffers of the decoder's own pool: the default allocator - a decoder nobody attached a back end to, own_frames 0 - or
+             * this back end's allocator falling back to it: a fifth geometry, no page-locked memory left) */
+            if (s->avctx->get_buffer2 == avcodec_default_get_buffer2 || s->avctx->get_buffer2 == ohhip_get_buffer2)
+                guard_pool_entry(be, f->buf[k]);        /* the page lock goes where the decoder's pool frees the buffer */
         }
     }
     /* (Taking these locks later - at the picture's frame end, out of this serial prologue - was tried at the end of round 4 and gave a fresh
