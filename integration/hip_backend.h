@@ -45,7 +45,7 @@ typedef struct ohhip_options {
     int defer_download;      /* 1: a picture is copied back when the application fetches it (ohhip_backend_fetch_output), 0: in the frame-end hook
                               *                                                                          (default 1; OHHIP_DEFER_DOWNLOAD) */
     int pin_frames;          /* 1: page-lock frame buffers the back end did not make (own_frames 0, or the application's get_buffer2); buffers of the
-                              * decoder's own pool lose the lock where the pool frees them (default 1; OHHIP_PIN_FRAMES) */
+                              * decoder's own pool lose the lock where the pool frees them (default 0 since round 6 - opt-in; OHHIP_PIN_FRAMES) */
     int async_issue;         /* 1: frame ends issued by the library's issuer threads                   (default 0; OHHIP_ASYNC_ISSUE) */
     int record_only;         /* 1: no device, no pixels: host-side profiling / software-executor tests (default 0; OHHIP_RECORD_ONLY) */
     int test_fail_index;     /* fault injection of the multi-process tests: the owner fails on this picture (default -1; OHHIP_TEST_FAIL_INDEX) */

@@ -1147,7 +1147,12 @@ void ohhip_options_default(ohhip_options *o)
      * device: +18-24 % on an all-intra stream at 16 frame threads, +3-12 % on an encoder-like one (profiles/r5z_intra16_switches.txt).
      * An application that cannot make that call sets 0. */
     o->defer_download = env_int("OHHIP_DEFER_DOWNLOAD", 1) != 0;
-    o->pin_frames = env_int("OHHIP_PIN_FRAMES", 1) != 0;
+    /* 0 since round 6: frame buffers the back end did not make (own_frames 0, a decoder nobody attached a back end to, an application's own
+     * allocator) stay pageable unless asked for.  A page lock on memory that belongs to somebody else is only as good as the promise that it
+     * is dropped before the memory goes; the hooks keep that promise for the decoder's own pool (guard_pool_entry), but the runtime's
+     * un-registration is lazy (hipHostUnregister returns in a microsecond) and one whole-suite run in five still died in a LATER, unrelated
+     * copy into memory that had been page-locked and given back minutes before. */
+    o->pin_frames = env_int("OHHIP_PIN_FRAMES", 0) != 0;
     o->async_issue = env_int("OHHIP_ASYNC_ISSUE", 0);
     o->record_only = env_str("OHHIP_RECORD_ONLY") ? (atoi(env_str("OHHIP_RECORD_ONLY")) == 2 ? 2 : 1) : 0;
     o->test_fail_index = env_int("OHHIP_TEST_FAIL_INDEX", -1);

@@ -269,6 +269,7 @@ def test_emu_frame_buffers_from_the_back_end_or_from_the_decoder(own_frames, mon
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
     monkeypatch.setenv("OHHIP_OWN_FRAMES", own_frames)
+    monkeypatch.setenv("OHHIP_PIN_FRAMES", "1")          # (opt-in since round 6: the guard in front of the decoder's pool is what this leg is about)
     L = ps._load("hipemu")
     made0, live0, made1, live1 = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
     L.ohhip_frame_pool_counts(ctypes.byref(made0), ctypes.byref(live0))

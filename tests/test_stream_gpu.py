@@ -200,7 +200,8 @@ ENCODER_LIKE = dict(init_qp=32, probs=dict(pred_mode=0.03, skip=0.55, merge_flag
                                            split_transform=0.25, sig_coeff=0.35, last_x=0.5, last_y=0.5))
 
 
-@pytest.mark.parametrize("own_frames", ["1", "0"], ids=["frame_buffers_of_the_back_end", "frame_buffers_of_the_decoder_page_locked"])
+@pytest.mark.parametrize("own_frames", ["1", pytest.param("0", marks=pytest.mark.skipif(not os.environ.get("OHEVC_TEST_PIN_PATH"), reason="the page-lock path on the decoder's own buffers is opt-in (pin_frames 0 since round 6); OHEVC_TEST_PIN_PATH=1 runs it"))],
+                         ids=["frame_buffers_of_the_back_end", "frame_buffers_of_the_decoder_page_locked"])
 def test_config5_8k_frame_threads_survive_the_decoders_frame_pool_being_re_created(own_frames, monkeypatch):
     """Round 6's device fault ("Memory access fault ... Write access to a read-only page", bench.py's config 5 row with 17 pictures): under frame
     threads the reference re-creates its frame pool in mid-stream (update_frame_pool, utils.c:509-575), an 8K luma buffer - 68 MB, always an
@@ -211,13 +212,16 @@ def test_config5_8k_frame_threads_survive_the_decoders_frame_pool_being_re_creat
     if not (ps.have("gen") and ps.have("c")):
         pytest.skip("generator / reference decoder libraries not present")
     monkeypatch.setenv("OHHIP_OWN_FRAMES", own_frames)
+    if own_frames == "0":
+        monkeypatch.setenv("OHHIP_PIN_FRAMES", "1")
     aus, _ = ps.generate(ps.StreamParams(gop="random_access", nframes=17, seed=7, width=7680, height=4320, log2_ctb=6, bit_depth=10, **ENCODER_LIKE))
     ref = ps.decode_stream("c", aus)
     _compare(ref, ps.decode_stream("hip", aus, 8, 1))
 
 
-@pytest.mark.parametrize("switches", [dict(OHHIP_QUEUE_DOWNLOAD="0"), dict(OHHIP_OWN_FRAMES="0"), dict(OHHIP_OWN_FRAMES="0", OHHIP_PIN_FRAMES="0"),
-                                      dict(OHHIP_BLOCK_CACHE_MB="0")],
+@pytest.mark.parametrize("switches", [dict(OHHIP_QUEUE_DOWNLOAD="0"),
+                                      pytest.param(dict(OHHIP_OWN_FRAMES="0", OHHIP_PIN_FRAMES="1"), marks=pytest.mark.skipif(not os.environ.get("OHEVC_TEST_PIN_PATH"), reason="opt-in: OHEVC_TEST_PIN_PATH=1")),
+                                      dict(OHHIP_OWN_FRAMES="0", OHHIP_PIN_FRAMES="0"), dict(OHHIP_BLOCK_CACHE_MB="0")],
                          ids=["fetch_issues_the_copies", "decoder_buffers_page_locked", "pageable_buffers", "no_block_cache"])
 def test_frame_buffer_and_copy_back_switches_give_the_same_pictures(switches, monkeypatch):
     """The host side of a picture (round 6; integration/hip_backend.h): own_frames / pin_frames / queue_download / the block cache change where the
