@@ -273,7 +273,7 @@ def test_emu_frame_buffers_from_the_back_end_or_from_the_decoder(own_frames, mon
     L = ps._load("hipemu")
     made0, live0, made1, live1 = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
     L.ohhip_frame_pool_counts(ctypes.byref(made0), ctypes.byref(live0))
-    for name, threads, tt in (("ra_10b_odd", 1, 1), ("ra_10b_odd", 4, 1), ("wpp", 4, 2), ("fmt444_8b", 3, 1), ("ldb_10b", 4, 3)):
+    for name, threads, tt in (("ra_10b_odd", 4, 1), ("wpp", 4, 2), ("ldb_10b", 4, 3)):
         aus, md5 = load_golden(name)
         # (the stream twice through one decoder instance - it starts with an IDR picture: buffers are recycled across the passes)
         assert frames_md5(ps.decode_stream("hipemu", aus * 2, threads, tt)) == list(md5) * 2, f"{name} threads {threads} type {tt} own_frames {own_frames}"
@@ -292,7 +292,7 @@ def test_emu_copy_back_queued_at_the_frame_end_or_issued_at_fetch(queue, monkeyp
     if ps is None:
         pytest.skip("oracle/_ref/libopenhevc_hipemu.so not built (needs the reference tree once)")
     monkeypatch.setenv("OHHIP_QUEUE_DOWNLOAD", queue)
-    for name, threads, tt in (("ra_10b_odd", 1, 1), ("ra_8b_ctb64", 4, 1), ("wpp", 4, 2), ("intra_8b", 3, 1)):
+    for name, threads, tt in (("ra_8b_ctb64", 4, 1), ("wpp", 4, 2)):
         aus, md5 = load_golden(name)
         assert frames_md5(ps.decode_stream("hipemu", aus * 2, threads, tt)) == list(md5) * 2, f"{name} threads {threads} type {tt} queue_download {queue}"
     aus, md5 = load_golden("ldb_10b")
