@@ -251,9 +251,10 @@ def test_emu_parked_frame_ends_with_frame_threads(park_threads, monkeypatch):
     import ctypes
     product.ohevc_debug_parked_total.restype = ctypes.c_long
     before = product.ohevc_debug_parked_total()
-    for name in ("ra_8b_ctb64", "ra_10b_odd", "ldb_10b", "ra_8b_foll_leaf", "weighted"):
+    # (off by default and measured as a loss on the device: three streams keep the option alive - five streams x two thread counts took two minutes)
+    for name, counts in (("ra_8b_ctb64", (4, 6)), ("ra_10b_odd", (4,)), ("weighted", (6,))):
         aus, md5 = load_golden(name)
-        for threads in (4, 6):
+        for threads in counts:
             assert frames_md5(ps.decode_stream("hipemu", aus, threads, 1)) == md5, f"{name} with {threads} frame threads and parked frame ends"
     assert product.ohevc_debug_parked_total() > before, "no frame end was parked: the test did not exercise ohevc_frame_end_deferred"
 
