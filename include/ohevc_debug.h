@@ -121,7 +121,7 @@ int ohevc_debug_wait_picture(struct ohevc_ctx *ctx, int slot);
  * the level's arithmetic incl. the wait for its samples, clocks in further passes of wide levels, levels} of wavefront 0; on == 0 frees them.
  * Shader clock (s_memtime).  Diagnosis only. */
 int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[64]);      /* [5..7]: inside the issue phase - after the sample loads, after the residual prefetch, after the level record; round 6, every wavefront: [8 + s] clocks in the arithmetic of steps whose blocks are of size class s (4x4 .. 32x32), [12 + s] of which waiting for the five samples, [16 + s] such steps; [20 + n] levels of n wavefronts (n = 16: more); [40 + s] clocks of the SLOWEST wavefront's arithmetic being of class s is not recorded - see tools/diag_chain_clocks.py */
-int ohevc_debug_set_chain_handover(int mode);   /* hand-over between two levels of the intra chain kernel: 0 the workgroup barrier alone (default since round 6), 2 wait for the level's stores first (rounds 4-5), 1 / 3 agent-scope acquire behind it (rounds 2-3); returns the previous mode */
+int ohevc_debug_set_chain_handover(int mode);   /* hand-over between two levels of the intra chain kernel: 0 the workgroup barrier alone (default since round 6), 2 wait for the level's stores first (rounds 4-5), 1 / 3 agent-scope acquire behind it (rounds 2-3); + 4: a slot's job from the level records instead of the prologue's descriptors (A/B); returns the previous mode */
 /* SHVC up-sampling kernel: 0 = the tile form (shipped: a workgroup per 64 x 32 output tile, both passes through LDS, dot instructions),
  * 1 = the round-2 strip form (a thread per column strip).  Returns the previous value.  Environment: OHEVC_UPSAMPLE_VARIANT. */
 int ohevc_debug_set_upsample_variant(int variant);

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void intra_chain_kernel(PlaneSet 
         int before = 0, total = 0;
 #pragma unroll
         for (int k = 0; k < kChainWaves; k++) { const int t = scan_tot[k]; if (k < wave) before += t; total += t; }
-        use_desc = __builtin_amdgcn_readfirstlane((int)(total <= kChainMaxSlots)) != 0;
+        use_desc = __builtin_amdgcn_readfirstlane((int)(total <= kChainMaxSlots && !(agent_acquire & 4))) != 0;      // (bit 2 of the hand-over switch: the record form, for A/B runs on one box)
         if (use_desc) {
             const int off0 = before + incl - nw0 - nw1, off1 = off0 + nw0;
             if (l0 < nlevels) lvl_off[l0] = (unsigned short)off0;

@@ -1837,7 +1837,7 @@ extern "C" int ohevc_debug_intra_chain_clocks(int on, unsigned long long out[8])
 // The hand-over between two levels of the chain (ohevc_debug_set_chain_handover): bit 0 = the agent-scope acquire of rounds 2-3 (buffer_inv sc1
 // per level), bit 1 = wait for the level's stores in front of the barrier (s_waitcnt vmcnt(0): rounds 4-5).  0 = the barrier alone.
 static int g_chain_agent_acquire = 0;
-extern "C" int ohevc_debug_set_chain_handover(int mode) { const int prev = g_chain_agent_acquire; g_chain_agent_acquire = mode & 3; return prev; }
+extern "C" int ohevc_debug_set_chain_handover(int mode) { const int prev = g_chain_agent_acquire; g_chain_agent_acquire = mode & 7; return prev; }      // bit 2: slots from the level records (round 5), not from descriptors
 
 extern "C" int ohevc_dev_intra_chain(const ohevc_plane planes[3], int bit_depth, const void *base, const ohevc_intra_chain_level *levels, int nlevels,
                                     const int16_t *coeffs, void *stream)

@@ -28,6 +28,9 @@ def decode(threads, natural):
         kw.update(ps.DENSE_QP22)
     aus, _ = ps.generate(ps.StreamParams(**kw))
     kind = os.environ.get("DIAG_KIND", "hip")                        # "hipemu" with OHHIP_RECORD_ONLY=1: the hooks' recording alone, without a device (CPU box)
+    for a in sys.argv[3:]:                                           # name=value: ohevc_debug_set_<name>(value) of the product library (A/B runs)
+        if "=" in a:
+            getattr(ps._product_lib(), "ohevc_debug_set_" + a.split("=")[0])(int(a.split("=")[1]))
     ps.decode_stream(kind, aus[:9], threads, 1)                      # warm-up: library load, allocations
     passes = int(os.environ.get("DIAG_PASSES", "4"))                 # the stream several times through ONE decoder: steady state
     best = None
@@ -156,6 +159,6 @@ if __name__ == "__main__":
     elif sys.argv[1] == "chain":
         chain(sys.argv[2])
     elif sys.argv[1] == "decode":
-        decode(int(sys.argv[2]), len(sys.argv) > 3 and sys.argv[3] == "natural")
+        decode(int(sys.argv[2]), "natural" in sys.argv[3:])
     else:
         analyze(sys.argv[2])
